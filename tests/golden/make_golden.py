@@ -1,0 +1,494 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference). Nothing here travels to
+the GPU box except the small ``.npz`` / ``.json`` fixtures it writes. Recipe =
+SURVEY.md Appendix A:
+
+* ``plugins/track/oc_sort`` imports with a 3-name ``filterpy`` shim
+  (``oc_sort/kalmanfilter.py:105-106``); ``lap`` is absent so the reference's own
+  scipy fallback runs (``oc_sort/association.py:187-195``).
+* ``plugins/track/bpbreid_strong_sort`` imports with a stub ``cv2`` (``ecc.py:4``)
+  and with ``compute_distance_matrix_using_bp_features`` injected into
+  ``sort/nn_matching.py`` (its try/except at ``:4-8`` leaves the name undefined).
+  That function is third-party (torchreid fork, unpinned): restated below from its
+  published algorithm -> parity is UNPINNED at that single call.
+
+Usage:  python tests/golden/make_golden.py   (solver recorded: scipy <version>)
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import scipy
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REF, "plugins", "track"))
+sys.path.insert(0, REF)
+
+from tracklab_amd.synth import SyntheticStream, ltrb_to_ltwh_rows  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- shims
+def _install_filterpy_shim():
+    fp = types.ModuleType("filterpy")
+    st = types.ModuleType("filterpy.stats")
+    cm = types.ModuleType("filterpy.common")
+    st.logpdf = lambda *a, **k: 0.0
+    cm.pretty_str = lambda label, arr: f"{label} = {arr}"
+
+    def reshape_z(z, dim_z, ndim):
+        z = np.atleast_2d(z)
+        if z.shape[1] == dim_z:
+            z = z.T
+        if z.shape != (dim_z, 1):
+            raise ValueError("z must be convertible to shape ({}, 1)".format(dim_z))
+        if ndim == 1:
+            z = z[:, 0]
+        if ndim == 0:
+            z = z[0, 0]
+        return z
+
+    cm.reshape_z = reshape_z
+    fp.stats, fp.common = st, cm
+    sys.modules.update({"filterpy": fp, "filterpy.stats": st, "filterpy.common": cm})
+
+
+def _install_cv2_stub():
+    cv2 = types.ModuleType("cv2")
+    cv2.MOTION_EUCLIDEAN = 1
+    cv2.MOTION_HOMOGRAPHY = 3
+    sys.modules["cv2"] = cv2
+
+
+def bp_distance_restated(qf, gf, qvis, gvis, use_gpu=False):
+    """Restatement of torchreid(fork).metrics.distance.compute_distance_matrix_using_bp_features
+    (boolean-visibility branch, 'mean' combine, euclidean metric): per part
+    sqrt(relu(|q|^2 - 2 q.g + |g|^2)), mean over parts visible in both, -1 if none."""
+    q = qf.transpose(1, 0)
+    g = gf.transpose(1, 0)
+    dot = torch.matmul(q, g.transpose(2, 1))
+    qs = q.pow(2).sum(dim=-1)
+    gs = g.pow(2).sum(dim=-1)
+    d = qs.unsqueeze(2) - 2 * dot + gs.unsqueeze(1)
+    d = torch.sqrt(torch.nn.functional.relu(d))
+    valid = qvis.t().unsqueeze(2) * gvis.t().unsqueeze(1)
+    validf = valid.to(d.dtype)
+    cnt = validf.sum(dim=0)
+    pair = (d * validf).sum(dim=0) / cnt.clamp(min=1)
+    pair = torch.where(cnt == 0, torch.full_like(pair, -1.0), pair)
+    return pair, d
+
+
+def sha(*arrays) -> str:
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+# ----------------------------------------------------------------------------- OC-SORT
+OCSORT_CONFIGS = {
+    # tracklab/configs/modules/track/oc_sort.yaml:3-14
+    "yaml": dict(min_confidence=0.4, hyper=dict(asso_func="giou", delta_t=1, det_thresh=0,
+                 inertia=0.3941737016672115, iou_threshold=0.22136877277096445,
+                 max_age=50, min_hits=1, use_byte=False)),
+    # OCSort.__init__ defaults (ocsort.py:186-187)
+    "defaults": dict(min_confidence=0.4, hyper=dict(asso_func="iou", delta_t=3, det_thresh=0.6,
+                     inertia=0.2, iou_threshold=0.3, max_age=30, min_hits=3, use_byte=False)),
+    # BASELINE.json configs[0]: "IoU-only SORT" = inertia 0, asso_func iou
+    "iou_only": dict(min_confidence=0.4, hyper=dict(asso_func="iou", delta_t=3, det_thresh=0,
+                     inertia=0.0, iou_threshold=0.3, max_age=30, min_hits=3, use_byte=False)),
+    "byte_diou": dict(min_confidence=0.0, hyper=dict(asso_func="diou", delta_t=2, det_thresh=0.5,
+                      inertia=0.2, iou_threshold=0.3, max_age=20, min_hits=2, use_byte=True)),
+    "ciou": dict(min_confidence=0.4, hyper=dict(asso_func="ciou", delta_t=3, det_thresh=0.1,
+                 inertia=0.3, iou_threshold=0.25, max_age=10, min_hits=1, use_byte=False)),
+    "ct": dict(min_confidence=0.4, hyper=dict(asso_func="ct_dist", delta_t=3, det_thresh=0.1,
+               inertia=0.1, iou_threshold=0.3, max_age=15, min_hits=1, use_byte=False)),
+}
+
+OCSORT_RUNS = [  # (name, config, seed, n_objects, n_frames, stream kwargs)
+    ("yaml_s0_n100", "yaml", 0, 100, 200, {}),
+    ("yaml_s1_n50", "yaml", 1, 50, 200, {}),
+    ("yaml_s2_n10", "yaml", 2, 10, 200, {"miss_prob": 0.15, "churn_period": 20}),
+    ("yaml_s3_n30_gaps", "yaml", 3, 30, 200, {"miss_prob": 0.3, "churn_period": 10}),
+    ("defaults_s0_n50", "defaults", 0, 50, 200, {"miss_prob": 0.1}),
+    ("iou_only_s1_n30", "iou_only", 1, 30, 150, {"miss_prob": 0.1}),
+    ("byte_s2_n40", "byte_diou", 2, 40, 150, {"miss_prob": 0.1, "low_conf_frac": 0.25}),
+    ("ciou_s4_n20", "ciou", 4, 20, 120, {"miss_prob": 0.2, "churn_period": 10}),
+    ("ct_s5_n20", "ct", 5, 20, 120, {"miss_prob": 0.1, "churn_period": 10}),
+    ("yaml_s6_n100_cls2", "yaml", 6, 100, 100, {"cls": 2.0, "miss_prob": 0.05}),
+]
+
+
+def gen_ocsort(out_dir):
+    _install_filterpy_shim()
+    import oc_sort.ocsort as ref  # noqa
+
+    for name, cfgname, seed, nobj, nframes, skw in OCSORT_RUNS:
+        cfg = OCSORT_CONFIGS[cfgname]
+        tracker = ref.OCSort(**cfg["hyper"])
+        stream = SyntheticStream(seed, nobj, nframes, **skw)
+        captured = {}
+
+        real_associate = ref.associate
+
+        def spy(dets, trks, thr, vel, kobs, w, _real=real_associate, _cap=captured):
+            r = _real(dets, trks, thr, vel, kobs, w)
+            _cap["matched"] = np.asarray(r[0], dtype=np.int64).reshape(-1, 2)
+            _cap["um_dets"] = np.asarray(r[1], dtype=np.int64)
+            _cap["um_trks"] = np.asarray(r[2], dtype=np.int64).reshape(-1)
+            if len(trks):
+                _cap["iou"] = ref.iou_batch(dets, trks)
+            return r
+
+        ref.associate = spy
+        blobs = {}
+        in_off, out_off = [0], [0]
+        ins, outs = [], []
+        for fr in stream:
+            dets = fr["dets"]
+            if fr["frame"] % 37 == 5:        # a few empty frames: wrapper skips the tracker (oc_sort_api.py:51-52)
+                dets = dets[:0]
+            ins.append(dets)
+            in_off.append(in_off[-1] + len(dets))
+            if len(dets) == 0:
+                res = np.empty((0, 8))
+            else:
+                inp = torch.from_numpy(dets)
+                inp = inp[inp[:, 4] > cfg["min_confidence"]]
+                captured.clear()
+                res = np.asarray(tracker.update(inp, None), dtype=np.float64).reshape(-1, 8) \
+                    if True else None
+                f = fr["frame"]
+                if f in (1, 7, 50, 99, 120) and "matched" in captured:
+                    blobs[f"f{f}_matched"] = captured["matched"]
+                    blobs[f"f{f}_um_dets"] = captured["um_dets"]
+                    blobs[f"f{f}_um_trks"] = captured["um_trks"]
+                    if "iou" in captured:
+                        blobs[f"f{f}_iou"] = captured["iou"]
+                if f in (7, 50, 99, 119, 149, 199):
+                    blobs[f"f{f}_kf_x"] = np.stack([t.kf.x[:, 0] for t in tracker.trackers]) \
+                        if tracker.trackers else np.empty((0, 7))
+                    blobs[f"f{f}_kf_P"] = np.stack([t.kf.P for t in tracker.trackers]) \
+                        if tracker.trackers else np.empty((0, 7, 7))
+                    blobs[f"f{f}_ids"] = np.array([t.id for t in tracker.trackers], dtype=np.int64)
+            outs.append(res)
+            out_off.append(out_off[-1] + len(res))
+        ref.associate = real_associate
+        np.savez_compressed(
+            os.path.join(out_dir, f"ocsort_{name}.npz"),
+            dets=np.concatenate(ins) if ins else np.empty((0, 7)),
+            det_offsets=np.array(in_off, dtype=np.int64),
+            out=np.concatenate(outs), out_offsets=np.array(out_off, dtype=np.int64),
+            config=json.dumps(cfg), seed=seed, n_objects=nobj, n_frames=nframes,
+            stream_kwargs=json.dumps(skw), **blobs)
+        print(f"ocsort_{name}: frames={nframes} rows_out={out_off[-1]} ids={int(ref.KalmanBoxTracker.count)}")
+
+
+def gen_iou_family(out_dir):
+    _install_filterpy_shim()
+    import oc_sort.association as A
+    rng = np.random.default_rng(11)
+    blobs = {}
+    for tag, (n, m) in {"a": (17, 23), "b": (64, 64), "c": (1, 5), "d": (100, 130)}.items():
+        def boxes(k):
+            x = rng.uniform(0, 1800, k)
+            y = rng.uniform(0, 1000, k)
+            w = rng.uniform(5, 200, k)
+            h = rng.uniform(5, 300, k)
+            return np.stack([x, y, x + w, y + h], 1)
+        b1, b2 = boxes(n), boxes(m)
+        if n > 3:
+            b2[:3] = b1[:3] + rng.normal(0, 2, (3, 4))        # some heavy overlaps
+        blobs[f"{tag}_b1"], blobs[f"{tag}_b2"] = b1, b2
+        for fn in ("iou_batch", "giou_batch", "diou_batch", "ciou_batch", "ct_dist"):
+            blobs[f"{tag}_{fn}"] = getattr(A, fn)(b1, b2)
+    np.savez_compressed(os.path.join(out_dir, "iou_family.npz"), **blobs)
+    print("iou_family ok")
+
+
+def gen_kf7(out_dir):
+    """KalmanBoxTracker / KalmanFilterNew unit vectors incl. freeze/unfreeze replays
+    (ocsort.py:57-169, kalmanfilter.py:339-526)."""
+    _install_filterpy_shim()
+    import oc_sort.ocsort as ref
+    rng = np.random.default_rng(5)
+    blobs = {}
+    case = 0
+    for gap_pattern in ([1] * 12, [1, 1, 0, 1, 1], [1, 0, 0, 1, 0, 1, 1], [1, 1, 0, 0, 0, 0, 0, 1, 1, 0, 1],
+                        [0, 0, 1, 1, 0, 1], [1, 0, 1, 0, 1, 0, 0, 0, 1]):
+        for rep in range(3):
+            ref.KalmanBoxTracker.count = 0
+            x0, y0 = rng.uniform(200, 1500), rng.uniform(200, 800)
+            w, h = rng.uniform(40, 120), rng.uniform(80, 300)
+            vx, vy = rng.normal(0, 4), rng.normal(0, 3)
+            box = lambda t: np.array([x0 + vx * t - w / 2, y0 + vy * t - h / 2,
+                                      x0 + vx * t + w / 2, y0 + vy * t + h / 2, 0.9]) \
+                + np.r_[rng.normal(0, 1, 4), 0]
+            b0 = box(0)
+            trk = ref.KalmanBoxTracker(b0, 1.0, delta_t=3, tracklab_id=0.0)
+            obs, xs, Ps, preds, vels = [b0], [], [], [], []
+            for t, seen in enumerate(gap_pattern, start=1):
+                preds.append(trk.predict()[0])
+                if seen:
+                    b = box(t)
+                    trk.update(b, 1.0, float(t))
+                    obs.append(b)
+                else:
+                    trk.update(None, None)
+                    obs.append(np.full(5, np.nan))
+                xs.append(trk.kf.x[:, 0].copy())
+                Ps.append(trk.kf.P.copy())
+                vels.append(np.zeros(2) if trk.velocity is None else np.asarray(trk.velocity, dtype=float))
+            blobs[f"c{case}_pattern"] = np.array(gap_pattern, dtype=np.int64)
+            blobs[f"c{case}_obs"] = np.stack(obs)
+            blobs[f"c{case}_x"] = np.stack(xs)
+            blobs[f"c{case}_P"] = np.stack(Ps)
+            blobs[f"c{case}_pred"] = np.stack(preds)
+            blobs[f"c{case}_vel"] = np.stack(vels)
+            case += 1
+    blobs["n_cases"] = np.int64(case)
+    np.savez_compressed(os.path.join(out_dir, "kf7_cases.npz"), **blobs)
+    print("kf7 cases", case)
+
+
+# ----------------------------------------------------------------------------- LSA
+def gen_lsa(out_dir):
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(3)
+    cases = []
+
+    def add(c):
+        c = np.asarray(c, dtype=np.float64)
+        r, cc = linear_sum_assignment(c)
+        cases.append((c, r.astype(np.int64), cc.astype(np.int64)))
+
+    # known-answer matrices held by the reference's vendored py-motmetrics tests
+    # (plugins/eval/PoseTrack21/posetrack21_mot/posetrack21_mot/motmetrics/tests/test_lap.py:31-176),
+    # finite ones only; expected values are asserted in tests/test_lsa.py
+    kat = [
+        ([[6, 9, 1], [10, 3, 2], [8, 7, 4]], [0, 1, 2], [2, 1, 0]),
+        ([[5, 5, 6], [1, 2, 5], [2, 4, 5]], [0, 1, 2], [2, 1, 0]),
+        ([[-2, -2, -1], [-6, -5, -2], [-5, -3, -2]], [0, 1, 2], [2, 1, 0]),
+        ([[6, 4, 1], [10, 8, 2]], [0, 1], [1, 2]),
+        ([[6, 10], [4, 8], [1, 2]], [1, 2], [0, 1]),
+    ]
+    with open(os.path.join(out_dir, "lsa_kat.json"), "w") as f:
+        json.dump({"source": "motmetrics/tests/test_lap.py:31-176 (finite cases)",
+                   "cases": [{"cost": c, "rows": r, "cols": cc} for c, r, cc in kat]}, f, indent=1)
+    for (n, m) in [(1, 1), (1, 7), (7, 1), (5, 5), (8, 13), (13, 8), (40, 40), (64, 65), (65, 64),
+                   (100, 100), (100, 117), (117, 100), (128, 128), (3, 200), (200, 3)]:
+        add(rng.uniform(0, 1, (n, m)))
+        add(-rng.uniform(0, 1, (n, m)))
+        # tie-heavy: clamped like linear_assignment.py:55 and integer like GT boxes
+        c = rng.uniform(0, 1, (n, m))
+        c[c > 0.5] = 0.5 + 1e-5
+        add(c)
+        add(rng.integers(0, 4, (n, m)).astype(float))
+        add(np.zeros((n, m)))
+        c = rng.uniform(0, 1, (n, m))
+        c[rng.uniform(0, 1, (n, m)) < 0.7] = 1e5
+        add(c)
+    blobs = {"n_cases": np.int64(len(cases)), "scipy_version": scipy.__version__}
+    for i, (c, r, cc) in enumerate(cases):
+        blobs[f"c{i}_cost"], blobs[f"c{i}_rows"], blobs[f"c{i}_cols"] = c, r, cc
+    np.savez_compressed(os.path.join(out_dir, "lsa_cases.npz"), **blobs)
+    print("lsa cases", len(cases))
+
+
+# ----------------------------------------------------------------------------- coordinates
+def gen_coords(out_dir):
+    import tracklab.utils.coordinates as C
+    rng = np.random.default_rng(9)
+    boxes = np.concatenate([
+        rng.uniform(-50, 2000, (40, 4)),
+        np.array([[0, 0, 10, 10], [1915, 1075, 30, 30], [-5, -5, 3, 3], [100.5, 200.5, 50.49, 60.51],
+                  [1919, 1079, 1, 1], [10, 10, 0, 0]], dtype=float)])
+    blobs = {"boxes": boxes}
+    shape = (1920, 1080)
+    for fn in ("ltwh_to_ltrb", "ltrb_to_ltwh", "ltwh_to_xywh", "ltrb_to_xywh", "xywh_to_ltrb", "xywh_to_ltwh"):
+        f = getattr(C, fn)
+        blobs[fn] = np.stack([f(b.copy()) for b in boxes])
+        if fn.startswith("xywh_to"):   # the reference recurses forever here (coordinates.py:345<->374)
+            continue
+        blobs[fn + "_clip"] = np.stack([f(b.copy(), shape) for b in boxes])
+        blobs[fn + "_clip_round"] = np.stack([f(b.copy(), shape, True) for b in boxes]).astype(np.int64)
+    np.savez_compressed(os.path.join(out_dir, "coords.npz"), **blobs)
+    print("coords ok")
+
+
+# ----------------------------------------------------------------------------- BPBReID-StrongSORT
+BPB_YAML = dict(  # tracklab/configs/modules/track/bpbreid_strong_sort.yaml:3-21
+    ema_alpha=0.9, mc_lambda=0.995, max_dist=0.5, motion_criterium="iou", max_iou_distance=0.8,
+    max_oks_distance=0.7, max_age=300, n_init=0, nn_budget=100, min_bbox_confidence=0.0,
+    only_position_for_kf_gating=False, max_kalman_prediction_without_update=7,
+    matching_strategy="strong_sort_matching", gating_thres_factor=1, w_kfgd=1, w_reid=1, w_st=1)
+
+BPB_RUNS = [  # (name, cfg overrides, seed, n_objects, n_frames, K, D, store_inputs, stream kwargs)
+    ("yaml_s0_n100_d256", {}, 0, 100, 40, 6, 256, False, {}),
+    ("yaml_s1_n50_d256", {}, 1, 50, 80, 6, 256, False, {"miss_prob": 0.05}),
+    ("yaml_s2_n12_d16", {}, 2, 12, 200, 6, 16, True, {"miss_prob": 0.2, "churn_period": 15}),
+    ("ninit3_s3_n20_d32", {"n_init": 3, "max_age": 20, "min_bbox_confidence": 0.55, "max_dist": 0.35},
+     3, 20, 150, 6, 32, True, {"miss_prob": 0.2, "churn_period": 10}),
+    ("posonly_s4_n20_d32", {"only_position_for_kf_gating": True, "max_kalman_prediction_without_update": 2,
+                            "max_age": 30, "ema_alpha": 0.5},
+     4, 20, 120, 4, 32, True, {"miss_prob": 0.25, "churn_period": 10}),
+    ("botsort_s5_n20_d32", {"matching_strategy": "bot_sort_matching", "max_age": 30, "n_init": 1,
+                            "gating_thres_factor": 1.5},
+     5, 20, 120, 6, 32, True, {"miss_prob": 0.15, "churn_period": 10}),
+    ("yaml_s6_n100_d512", {}, 6, 100, 20, 6, 512, False, {}),
+]
+
+STATE_CODE = {"t": 0, "c": 1, "d": 2}
+
+
+def gen_bpbss(out_dir):
+    _install_cv2_stub()
+    import bpbreid_strong_sort.sort.nn_matching as nnm
+    nnm.compute_distance_matrix_using_bp_features = bp_distance_restated
+    import bpbreid_strong_sort.strong_sort as ss
+    import bpbreid_strong_sort.sort.tracker as trk_mod  # noqa
+
+    for name, over, seed, nobj, nframes, K, D, store, skw in BPB_RUNS:
+        cfg = dict(BPB_YAML)
+        cfg.update(over)
+        model = ss.StrongSORT(**cfg)
+        stream = SyntheticStream(seed, nobj, nframes, parts=K, dim=D, with_embeddings=True, **skw)
+        in_off, out_off = [0], [0]
+        ltwhs, confs, ids_in, embs, viss = [], [], [], [], []
+        o_idx, o_tid, o_kf, o_pred, o_pred_valid, o_mname, o_mdist = [], [], [], [], [], [], []
+        o_hits, o_age, o_tsu, o_state = [], [], [], []
+        h = hashlib.sha256()
+        blobs = {}
+        for fr in stream:
+            dets = fr["dets"]
+            if fr["frame"] % 41 == 7:
+                dets, emb, vis = dets[:0], fr["embeddings"][:0], fr["visibility"][:0]
+            else:
+                emb, vis = fr["embeddings"], fr["visibility"]
+            ltwh = ltrb_to_ltwh_rows(dets[:, :4])
+            conf = dets[:, 4].copy()
+            did = dets[:, 6].astype(np.int64)
+            h.update(np.ascontiguousarray(ltwh).tobytes())
+            h.update(np.ascontiguousarray(conf).tobytes())
+            h.update(np.ascontiguousarray(emb).tobytes())
+            h.update(np.ascontiguousarray(vis).tobytes())
+            ltwhs.append(ltwh), confs.append(conf), ids_in.append(did)
+            if store:
+                embs.append(emb), viss.append(vis)
+            in_off.append(in_off[-1] + len(dets))
+            n_out = 0
+            if len(dets) > 0:       # wrapper: process() returns [] on an empty frame (bpbreid_strong_sort_api.py:103-104)
+                df = model.update(torch.from_numpy(did), torch.from_numpy(ltwh), torch.from_numpy(emb),
+                                  torch.from_numpy(vis), torch.from_numpy(conf),
+                                  torch.zeros(len(dets), dtype=torch.float64),
+                                  torch.ones(len(dets), dtype=torch.float64) * fr["frame"], None)
+                for det_id, row in df.iterrows():
+                    o_idx.append(int(det_id))
+                    o_tid.append(int(row.track_id))
+                    o_kf.append(np.asarray(row.track_bbox_kf_ltwh, dtype=np.float64))
+                    if row.track_bbox_pred_kf_ltwh is None:
+                        o_pred.append(np.full(4, np.nan)), o_pred_valid.append(0)
+                    else:
+                        o_pred.append(np.asarray(row.track_bbox_pred_kf_ltwh, dtype=np.float64))
+                        o_pred_valid.append(1)
+                    if row.matched_with is None:
+                        o_mname.append(0), o_mdist.append(np.nan)
+                    else:
+                        o_mname.append({"R": 1, "S": 2}[row.matched_with[0]])
+                        o_mdist.append(float(row.matched_with[1]))
+                    o_hits.append(int(row.hits)), o_age.append(int(row.age))
+                    o_tsu.append(int(row.time_since_update)), o_state.append(STATE_CODE[row.state])
+                    n_out += 1
+                f = fr["frame"]
+                if f in (3, 10, 25, 39, 60, 119) and len(model.tracker.tracks):
+                    tr = model.tracker.tracks
+                    blobs[f"f{f}_track_ids"] = np.array([t.track_id for t in tr], dtype=np.int64)
+                    blobs[f"f{f}_mean"] = np.stack([t.mean for t in tr])
+                    blobs[f"f{f}_cov"] = np.stack([t.covariance for t in tr])
+                    blobs[f"f{f}_feat"] = np.stack([t.features[-1]["reid_features"] for t in tr]).astype(np.float32)
+                    blobs[f"f{f}_fvis"] = np.stack([np.asarray(t.features[-1]["visibility_scores"]) for t in tr])
+            out_off.append(out_off[-1] + n_out)
+        extra = {}
+        if store:
+            extra["embeddings"] = np.concatenate(embs).astype(np.float32)
+            extra["visibility"] = np.concatenate(viss)
+        np.savez_compressed(
+            os.path.join(out_dir, f"bpbss_{name}.npz"),
+            ltwh=np.concatenate(ltwhs), conf=np.concatenate(confs), det_ids=np.concatenate(ids_in),
+            det_offsets=np.array(in_off, dtype=np.int64), out_offsets=np.array(out_off, dtype=np.int64),
+            o_idx=np.array(o_idx, dtype=np.int64), o_track_id=np.array(o_tid, dtype=np.int64),
+            o_kf_ltwh=np.array(o_kf).reshape(-1, 4), o_pred_ltwh=np.array(o_pred).reshape(-1, 4),
+            o_pred_valid=np.array(o_pred_valid, dtype=np.int64),
+            o_matched_name=np.array(o_mname, dtype=np.int64), o_matched_dist=np.array(o_mdist),
+            o_hits=np.array(o_hits, dtype=np.int64), o_age=np.array(o_age, dtype=np.int64),
+            o_tsu=np.array(o_tsu, dtype=np.int64), o_state=np.array(o_state, dtype=np.int64),
+            config=json.dumps(cfg), seed=seed, n_objects=nobj, n_frames=nframes, parts=K, dim=D,
+            stream_kwargs=json.dumps(skw), input_sha256=h.hexdigest(), **extra, **blobs)
+        print(f"bpbss_{name}: rows_out={out_off[-1]} next_id={model.tracker._next_id}")
+
+
+def gen_kf8(out_dir):
+    """8-state xyah NSA Kalman unit vectors (bpbreid_strong_sort/sort/kalman_filter.py:53-227)."""
+    _install_cv2_stub()
+    import bpbreid_strong_sort.sort.kalman_filter as KF
+    rng = np.random.default_rng(21)
+    kf = KF.KalmanFilter()
+    meas = np.stack([rng.uniform(100, 1800, 32), rng.uniform(100, 1000, 32),
+                     rng.uniform(0.3, 0.6, 32), rng.uniform(80, 300, 32)], 1)
+    blobs = {"meas": meas}
+    m0, c0, m1, c1, pm, pc, m2, c2, g4, g2 = ([] for _ in range(10))
+    confs = rng.uniform(0.3, 1.0, 32)
+    cand = np.stack([rng.uniform(100, 1800, 50), rng.uniform(100, 1000, 50),
+                     rng.uniform(0.3, 0.6, 50), rng.uniform(80, 300, 50)], 1)
+    for i in range(32):
+        mean, cov = kf.initiate(meas[i])
+        m0.append(mean), c0.append(cov)
+        for _ in range(i % 4 + 1):
+            mean, cov = kf.predict(mean, cov)
+        m1.append(mean), c1.append(cov)
+        a, b = kf.project(mean, cov, confs[i])
+        pm.append(a), pc.append(b)
+        z = meas[i] + np.r_[rng.normal(0, 3, 2), rng.normal(0, 0.01), rng.normal(0, 3)]
+        cand[i % 50] = z
+        g4.append(kf.gating_distance(mean, cov, cand.copy(), False))
+        g2.append(kf.gating_distance(mean, cov, cand.copy(), True))
+        mean, cov = kf.update(mean, cov, z, confs[i])
+        m2.append(mean), c2.append(cov)
+        blobs[f"z{i}"] = z
+    blobs.update(conf=confs, cand_last=cand, init_mean=np.stack(m0), init_cov=np.stack(c0),
+                 pred_mean=np.stack(m1), pred_cov=np.stack(c1), proj_mean=np.stack(pm), proj_cov=np.stack(pc),
+                 upd_mean=np.stack(m2), upd_cov=np.stack(c2), gate4=np.stack(g4), gate2=np.stack(g2))
+    # candidates evolve per case (cand[i%50]=z): store per-case snapshots for exact replay
+    np.savez_compressed(os.path.join(out_dir, "kf8_cases.npz"), **blobs)
+    print("kf8 ok")
+
+
+def main():
+    out_dir = HERE
+    only = set(sys.argv[1:])
+    gens = {"ocsort": gen_ocsort, "iou": gen_iou_family, "kf7": gen_kf7, "lsa": gen_lsa,
+            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8}
+    for k, fn in gens.items():
+        if not only or k in only:
+            fn(out_dir)
+    with open(os.path.join(out_dir, "MANIFEST.json"), "w") as f:
+        json.dump({"numpy": np.__version__, "scipy": scipy.__version__, "torch": torch.__version__,
+                   "lsa_solver": "scipy.optimize.linear_sum_assignment (lap absent -> reference fallback)",
+                   "reference": "TrackingLaboratory/tracklab v1.3.24 @ /root/reference",
+                   "unpinned": ["torchreid.metrics.distance.compute_distance_matrix_using_bp_features "
+                                "(restated in make_golden.py:bp_distance_restated)"]}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

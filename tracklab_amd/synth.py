@@ -1,0 +1,159 @@
+"""Seeded synthetic 1080p multi-object streams.
+
+One generator feeds the golden-vector script, the parity tests and ``bench.py`` so
+that every consumer sees bit-identical inputs for a given ``(seed, n_objects)``.
+
+Boxes follow the TrackLab conventions of the tracker wrappers
+(``tracklab/wrappers/track/oc_sort_api.py:33-47``): a frame's detections are an
+``(n, 7)`` float64 array ``[l, t, r, b, conf, cls, tracklab_id]``; the
+BPBReID-StrongSORT wrapper (``bpbreid_strong_sort_api.py:73-99``) consumes
+``bbox_ltwh (n,4) f64``, ``embeddings (n,K,D) f32``, ``visibility (n,K) bool``.
+
+numpy only; no torch, no HIP (safe inside DataLoader worker processes).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+WIDTH, HEIGHT = 1920, 1080
+
+
+class SyntheticStream:
+    """Deterministic stream of jittered boxes with births, deaths and misses.
+
+    Parameters mirror SURVEY.md §8(d): centres U([100,1820]x[100,980]),
+    w~U(40,120), h=w*U(1.8,2.6), velocity N(0,3)xN(0,2) px/frame reflected at the
+    borders, per-frame box jitter N(0,1) px on all four coordinates (keeps
+    association costs tie-free), conf~U(0.5,1), 2 % per-frame miss probability,
+    a birth+death roughly every ``churn_period`` frames.
+    """
+
+    def __init__(self, seed: int, n_objects: int = 100, n_frames: int = 600,
+                 parts: int = 6, dim: int = 256, with_embeddings: bool = False,
+                 miss_prob: float = 0.02, churn_period: int = 100,
+                 cls: float = 1.0, low_conf_frac: float = 0.0):
+        self.seed = int(seed)
+        self.n_objects = int(n_objects)
+        self.n_frames = int(n_frames)
+        self.parts = int(parts)
+        self.dim = int(dim)
+        self.with_embeddings = bool(with_embeddings)
+        self.miss_prob = float(miss_prob)
+        self.churn_period = int(churn_period)
+        self.cls = float(cls)
+        self.low_conf_frac = float(low_conf_frac)
+        self._rng = np.random.default_rng(self.seed)
+        self._next_gt = 0
+        self._next_det = 0
+        self._frame = 0
+        n = self.n_objects
+        self._cx = self._rng.uniform(100, WIDTH - 100, n)
+        self._cy = self._rng.uniform(100, HEIGHT - 100, n)
+        self._w = self._rng.uniform(40, 120, n)
+        self._h = self._w * self._rng.uniform(1.8, 2.6, n)
+        self._vx = self._rng.normal(0, 3, n)
+        self._vy = self._rng.normal(0, 2, n)
+        self._gt = np.arange(n, dtype=np.int64)
+        self._next_gt = n
+        if self.with_embeddings:
+            self._proto = self._rng.normal(0, 1, (n, self.parts, self.dim)).astype(np.float32)
+        else:
+            self._proto = None
+
+    # ------------------------------------------------------------------
+    def _respawn(self, idx: int) -> None:
+        r = self._rng
+        self._cx[idx] = r.uniform(100, WIDTH - 100)
+        self._cy[idx] = r.uniform(100, HEIGHT - 100)
+        self._w[idx] = r.uniform(40, 120)
+        self._h[idx] = self._w[idx] * r.uniform(1.8, 2.6)
+        self._vx[idx] = r.normal(0, 3)
+        self._vy[idx] = r.normal(0, 2)
+        self._gt[idx] = self._next_gt
+        self._next_gt += 1
+        if self._proto is not None:
+            self._proto[idx] = r.normal(0, 1, (self.parts, self.dim)).astype(np.float32)
+
+    def step(self) -> dict:
+        """Advance one frame and return its detections.
+
+        Returns a dict with ``dets`` (n,7) f64, ``gt_ids`` (n,) i64, ``gt_boxes``
+        (n_objects,4) ltrb of every live object (for HOTA), ``gt_all_ids`` and,
+        if enabled, ``embeddings`` (n,K,D) f32 / ``visibility`` (n,K) bool.
+        """
+        r = self._rng
+        n = self.n_objects
+        if self._frame > 0:
+            self._cx += self._vx
+            self._cy += self._vy
+            for c, v, lo, hi in ((self._cx, self._vx, 100.0, WIDTH - 100.0),
+                                 (self._cy, self._vy, 100.0, HEIGHT - 100.0)):
+                below = c < lo
+                above = c > hi
+                c[below] = 2 * lo - c[below]
+                c[above] = 2 * hi - c[above]
+                v[below | above] *= -1
+            if self.churn_period > 0 and self._frame % max(1, self.churn_period // max(1, n // 50 + 1)) == 0:
+                self._respawn(int(r.integers(0, n)))
+        jitter = r.normal(0, 1, (n, 4))
+        l = self._cx - self._w / 2 + jitter[:, 0]
+        t = self._cy - self._h / 2 + jitter[:, 1]
+        rr = self._cx + self._w / 2 + jitter[:, 2]
+        b = self._cy + self._h / 2 + jitter[:, 3]
+        conf = r.uniform(0.5, 1.0, n)
+        if self.low_conf_frac > 0:
+            low = r.uniform(0, 1, n) < self.low_conf_frac
+            conf = np.where(low, r.uniform(0.05, 0.45, n), conf)
+        keep = r.uniform(0, 1, n) >= self.miss_prob
+        order = r.permutation(n)            # detectors do not emit boxes in identity order
+        order = order[keep[order]]
+        k = len(order)
+        det_ids = np.arange(self._next_det, self._next_det + k, dtype=np.float64)
+        self._next_det += k
+        dets = np.empty((k, 7), dtype=np.float64)
+        dets[:, 0] = l[order]
+        dets[:, 1] = t[order]
+        dets[:, 2] = rr[order]
+        dets[:, 3] = b[order]
+        dets[:, 4] = conf[order]
+        dets[:, 5] = self.cls
+        dets[:, 6] = det_ids
+        gt_boxes = np.stack([self._cx - self._w / 2, self._cy - self._h / 2,
+                             self._cx + self._w / 2, self._cy + self._h / 2], axis=1)
+        out = {"frame": self._frame, "dets": dets, "gt_ids": self._gt[order].copy(),
+               "gt_boxes": gt_boxes, "gt_all_ids": self._gt.copy()}
+        if self._proto is not None:
+            noise = r.normal(0, 0.1, (n, self.parts, self.dim)).astype(np.float32)
+            emb_all = self._proto + noise
+            vis_all = r.uniform(0, 1, (n, self.parts)) < 0.9
+            vis_all[:, 0] = True
+            out["embeddings"] = np.ascontiguousarray(emb_all[order])
+            out["visibility"] = np.ascontiguousarray(vis_all[order])
+        self._frame += 1
+        return out
+
+    def __iter__(self):
+        for _ in range(self.n_frames):
+            yield self.step()
+
+
+def ltrb_to_ltwh_rows(ltrb: np.ndarray) -> np.ndarray:
+    """(n,4) ltrb -> (n,4) ltwh; same arithmetic as ``coordinates.py:318-328`` per row."""
+    out = np.empty_like(ltrb)
+    out[:, 0] = ltrb[:, 0]
+    out[:, 1] = ltrb[:, 1]
+    out[:, 2] = ltrb[:, 2] - ltrb[:, 0]
+    out[:, 3] = ltrb[:, 3] - ltrb[:, 1]
+    return out
+
+
+def render_frame(rng: np.random.Generator, gt_boxes: np.ndarray,
+                 height: int = HEIGHT, width: int = WIDTH) -> np.ndarray:
+    """uint8 HxWx3 frame: background noise + one flat-colour rectangle per object."""
+    img = rng.integers(0, 64, (height, width, 3), dtype=np.uint8)
+    for i, (l, t, r, b) in enumerate(gt_boxes):
+        l, t = max(0, int(l)), max(0, int(t))
+        r, b = min(width, int(r)), min(height, int(b))
+        if r > l and b > t:
+            img[t:b, l:r] = ((37 * i) % 200 + 55, (91 * i) % 200 + 55, (53 * i) % 200 + 55)
+    return img
