@@ -1,0 +1,102 @@
+/*
+ * tlk.h -- C ABI of libtlk.so: hand-written HIP (gfx950 / MI355X) kernels for TrackLab's
+ * per-frame detector -> ReID -> association hot path.
+ *
+ * Plain pointers and sizes only; no torch types. Every entry point names the reference
+ * interface it replaces (paths relative to the TrackLab tree, v1.3.24). The reference is 100 %
+ * Python, so "the FFI a maintainer would bind" is ctypes: see INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *  - every function returns TLK_OK (0) or a negative TLK_E* code; tlk_last_error() gives the
+ *    message for the calling thread. Nothing aborts the process.
+ *  - "_dev" pointers are device (HBM) addresses on the handle's device; everything else is host.
+ *  - `hip_stream` is a hipStream_t passed as void* (NULL = the default stream); calls that take
+ *    one are asynchronous with respect to the host.
+ *  - a handle is used by one host thread at a time; different handles are independent.
+ *  - arrays are contiguous row-major, float64 unless the name says otherwise.
+ */
+#ifndef TLK_H
+#define TLK_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TLK_OK 0
+#define TLK_EINVAL (-1)     /* bad argument */
+#define TLK_EHIP (-2)       /* HIP runtime error (message has hipGetErrorString) */
+#define TLK_ECAPACITY (-3)  /* more tracks / detections than the handle was created for */
+#define TLK_ENODEVICE (-4)  /* no usable gfx950 device */
+
+const char *tlk_last_error(void);
+int tlk_version(void);               /* 10000*major + 100*minor + patch */
+int tlk_device_count(int *count);    /* number of HIP devices visible to this process */
+
+/* ------------------------------------------------------------------------------------------
+ * Similarity matrices.  Replaces plugins/track/oc_sort/association.py:5-171
+ * (iou_batch / giou_batch / diou_batch / ciou_batch / ct_dist).
+ * b1 (n, 4) xyxy, b2 (m, 4) xyxy -> out (n, m). All device pointers.
+ * ------------------------------------------------------------------------------------------ */
+enum { TLK_IOU = 0, TLK_GIOU = 1, TLK_DIOU = 2, TLK_CIOU = 3, TLK_CT = 4 };
+int tlk_iou_matrix_f64(int variant, const double *b1_dev, int n, const double *b2_dev, int m,
+                       double *out_dev, void *hip_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Linear sum assignment, scipy-identical (rectangular Jonker-Volgenant; same scan order and
+ * tie-breaks as scipy.optimize.linear_sum_assignment).  Replaces the call sites
+ * plugins/track/oc_sort/association.py:193-195 and
+ * plugins/track/bpbreid_strong_sort/sort/linear_assignment.py:56.
+ * Batched: `batch` independent problems, cost_dev (batch, nr, nc). rows/cols_dev
+ * (batch, min(nr,nc)) int32, pairs sorted by row; n_pairs_dev (batch) int32 (= min(nr,nc), or
+ * -1 infeasible / -2 NaN or -inf in the input). One wavefront solves one problem.
+ * ------------------------------------------------------------------------------------------ */
+int tlk_lsa_f64(const double *cost_dev, int batch, int nr, int nc, int32_t *rows_dev, int32_t *cols_dev,
+                int32_t *n_pairs_dev, void *hip_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * OC-SORT tracker bank: `n_streams` independent trackers whose whole state lives in HBM.
+ * Replaces plugins/track/oc_sort/ocsort.py:185-334 (OCSort.__init__/update, KalmanBoxTracker)
+ * + oc_sort/kalmanfilter.py:339-526 (KalmanFilterNew predict/update/freeze/unfreeze)
+ * + oc_sort/association.py:242-298 (associate) and the wrapper's per-frame filtering,
+ * tracklab/wrappers/track/oc_sort_api.py:50-56.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tlk_ocsort tlk_ocsort;
+typedef struct {
+    double det_thresh;       /* ocsort.py:186  */
+    double iou_threshold;
+    double inertia;
+    double min_confidence;   /* oc_sort_api.py:54; only used when wrapper_mode != 0 */
+    int32_t max_age, min_hits, delta_t;
+    int32_t asso_func;       /* TLK_IOU..TLK_CT (ASSO_FUNCS, ocsort.py:178-182) */
+    int32_t use_byte;
+    int32_t wrapper_mode;    /* 1: OCSORT.process semantics (skip the tracker on an empty frame,
+                                filter conf > min_confidence); 0: bare OCSort.update */
+    int32_t max_tracks;      /* capacity per stream (live + coasting tracks), <= 512 */
+    int32_t max_dets;        /* capacity per frame, <= 256 */
+} tlk_ocsort_params;
+
+int tlk_ocsort_create(const tlk_ocsort_params *p, int n_streams, int device, tlk_ocsort **out);
+int tlk_ocsort_destroy(tlk_ocsort *h);
+/* Module.reset(): stream < 0 resets every stream of the bank */
+int tlk_ocsort_reset(tlk_ocsort *h, int stream);
+/* One frame of one stream, host buffers (the drop-in path used by the TrackLab Module):
+ * dets (n,7) [l,t,r,b,conf,cls,tracklab_id] -> out rows (<=out_cap, 8)
+ * [l,t,r,b,track_id,cls,conf,tracklab_id]; synchronous. */
+int tlk_ocsort_update(tlk_ocsort *h, int stream, const double *dets, int n, double *out, int out_cap,
+                      int *n_out);
+/* All streams x n_frames frames in ONE launch, device buffers, asynchronous:
+ * dets_dev (n_streams, n_frames, max_dets, 7); counts_dev (n_streams, n_frames) int32;
+ * out_dev (n_streams, n_frames, out_cap, 8); out_counts_dev (n_streams, n_frames) int32.
+ * out_counts < 0 reports TLK_ECAPACITY for that stream/frame. */
+int tlk_ocsort_update_dev(tlk_ocsort *h, const double *dets_dev, const int32_t *counts_dev, int n_frames,
+                          double *out_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream);
+/* Debug / parity: copy the KF state of stream's live tracks in list order. x (cap,7), P (cap,7,7),
+ * ids (cap) int64; returns count via n_tracks. Synchronous. */
+int tlk_ocsort_get_tracks(tlk_ocsort *h, int stream, double *x, double *P, int64_t *ids, int cap, int *n_tracks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TLK_H */

@@ -1,0 +1,91 @@
+"""-m gpu: stateless kernels through the C ABI vs the oracle / scipy / golden vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _iou_gpu(b1, b2, variant):
+    import torch
+    from tracklab_amd._lib import ASSO, check, lib
+    d1 = torch.from_numpy(np.ascontiguousarray(b1[:, :4])).cuda()
+    d2 = torch.from_numpy(np.ascontiguousarray(b2[:, :4])).cuda()
+    out = torch.empty((len(b1), len(b2)), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    check(lib().tlk_iou_matrix_f64(ASSO[variant], d1.data_ptr(), len(b1), d2.data_ptr(), len(b2), out.data_ptr(), None))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def test_iou_family_golden_bit_exact():
+    g = np.load(os.path.join(GOLDEN, "iou_family.npz"))
+    for tag in "abcd":
+        b1, b2 = g[f"{tag}_b1"], g[f"{tag}_b2"]
+        for fn, var in (("iou_batch", "iou"), ("giou_batch", "giou"), ("diou_batch", "diou"),
+                        ("ciou_batch", "ciou"), ("ct_dist", "ct_dist")):
+            got = _iou_gpu(b1, b2, var)
+            exp = g[f"{tag}_{fn}"]
+            if var in ("iou", "giou", "diou"):
+                np.testing.assert_array_equal(got, exp, err_msg=f"{tag} {fn}")
+            else:       # atan / global-max rescale: not the same libm
+                np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-14, err_msg=f"{tag} {fn}")
+
+
+def _lsa_gpu(costs):
+    import torch
+    from tracklab_amd._lib import check, lib
+    costs = np.ascontiguousarray(costs, dtype=np.float64)
+    B, nr, nc = costs.shape
+    k = min(nr, nc)
+    d = torch.from_numpy(costs).cuda()
+    rows = torch.full((B, max(k, 1)), -7, dtype=torch.int32, device="cuda")
+    cols = torch.full((B, max(k, 1)), -7, dtype=torch.int32, device="cuda")
+    npairs = torch.full((B,), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    check(lib().tlk_lsa_f64(d.data_ptr(), B, nr, nc, rows.data_ptr(), cols.data_ptr(), npairs.data_ptr(), None))
+    torch.cuda.synchronize()
+    return rows.cpu().numpy(), cols.cpu().numpy(), npairs.cpu().numpy()
+
+
+def test_lsa_golden_and_known_answers():
+    g = np.load(os.path.join(GOLDEN, "lsa_cases.npz"))
+    for i in range(int(g["n_cases"])):
+        c = g[f"c{i}_cost"]
+        r, cc, n = _lsa_gpu(c[None])
+        assert n[0] == len(g[f"c{i}_rows"]), f"case {i}"
+        np.testing.assert_array_equal(r[0, :n[0]], g[f"c{i}_rows"], err_msg=f"case {i}")
+        np.testing.assert_array_equal(cc[0, :n[0]], g[f"c{i}_cols"], err_msg=f"case {i}")
+    kat = json.load(open(os.path.join(GOLDEN, "lsa_kat.json")))
+    for case in kat["cases"]:
+        r, cc, n = _lsa_gpu(np.array(case["cost"], dtype=float)[None])
+        assert list(r[0, :n[0]]) == case["rows"] and list(cc[0, :n[0]]) == case["cols"]
+
+
+@pytest.mark.parametrize("shape", [(100, 100), (100, 130), (130, 100), (7, 200), (256, 256)])
+def test_lsa_batched_vs_scipy(shape):
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    B = 24
+    costs = rng.uniform(0, 1, (B,) + shape)
+    costs[1::4] = np.round(costs[1::4] * 4)                       # integer ties
+    costs[2::4][costs[2::4] > 0.3] = 0.3 + 1e-5                    # clamped like linear_assignment.py:55
+    costs[3::4] *= -1
+    r, c, n = _lsa_gpu(costs)
+    for b in range(B):
+        er, ec = linear_sum_assignment(costs[b])
+        assert n[b] == len(er)
+        np.testing.assert_array_equal(r[b, :n[b]], er, err_msg=f"batch {b}")
+        np.testing.assert_array_equal(c[b, :n[b]], ec, err_msg=f"batch {b}")
+
+
+def test_lsa_invalid_inputs_report_like_scipy():
+    c = np.zeros((2, 3, 3))
+    c[0, 1, 1] = np.nan
+    c[1] = np.inf
+    r, cc, n = _lsa_gpu(c)
+    assert n[0] == -2 and n[1] == -1

@@ -1,0 +1,141 @@
+"""ctypes binding of libtlk.so (``include/tlk.h``).
+
+There is NO CPU fallback: if the shared library is missing, or no gfx950 device is visible when a
+handle is created, this raises. (The oracle under ``oracle/`` is test infrastructure and is never
+imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtlk.so")
+
+ASSO = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3, "ct_dist": 4}
+
+_dp = C.POINTER(C.c_double)
+_ip32 = C.POINTER(C.c_int32)
+_ip64 = C.POINTER(C.c_int64)
+
+
+class TlkError(RuntimeError):
+    pass
+
+
+class OcsortParams(C.Structure):
+    _fields_ = [("det_thresh", C.c_double), ("iou_threshold", C.c_double), ("inertia", C.c_double),
+                ("min_confidence", C.c_double),
+                ("max_age", C.c_int32), ("min_hits", C.c_int32), ("delta_t", C.c_int32),
+                ("asso_func", C.c_int32), ("use_byte", C.c_int32), ("wrapper_mode", C.c_int32),
+                ("max_tracks", C.c_int32), ("max_dets", C.c_int32)]
+
+
+_lib = None
+
+
+def build() -> str:
+    """Compile every HIP source for gfx950 into tracklab_amd/lib/libtlk.so (hipcc cross-compiles
+    without a GPU)."""
+    import subprocess
+    subprocess.run(["bash", os.path.join(_HERE, "csrc", "build.sh")], check=True)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TlkError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(tracklab_amd has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    L.tlk_last_error.restype = C.c_char_p
+    L.tlk_version.restype = C.c_int
+    L.tlk_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.tlk_iou_matrix_f64.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.tlk_lsa_f64.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tlk_ocsort_create.argtypes = [C.POINTER(OcsortParams), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.tlk_ocsort_destroy.argtypes = [C.c_void_p]
+    L.tlk_ocsort_reset.argtypes = [C.c_void_p, C.c_int]
+    L.tlk_ocsort_update.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int, _dp, C.c_int, C.POINTER(C.c_int)]
+    L.tlk_ocsort_update_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p]
+    L.tlk_ocsort_get_tracks.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip64, C.c_int, C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+def check(code: int) -> None:
+    if code != 0:
+        raise TlkError(f"libtlk error {code}: {lib().tlk_last_error().decode()}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    lib().tlk_device_count(C.byref(n))
+    return n.value
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def current_stream_ptr():
+    """hipStream_t of torch's current stream (0 if torch is not imported / no GPU)."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class OCSortBank:
+    """``n_streams`` device-resident OC-SORT trackers (``tlk_ocsort_*``).
+
+    Mirrors ``oc_sort.ocsort.OCSort`` hyper-parameters (ocsort.py:186-201); ``wrapper_mode`` adds the
+    per-frame behaviour of ``OCSORT.process`` (oc_sort_api.py:50-56).
+    """
+
+    def __init__(self, det_thresh, max_age=30, min_hits=3, iou_threshold=0.3, delta_t=3,
+                 asso_func="iou", inertia=0.2, use_byte=False, *, min_confidence=0.0,
+                 wrapper_mode=False, n_streams=1, device=0, max_tracks=256, max_dets=128):
+        if asso_func not in ASSO:
+            raise KeyError(asso_func)
+        self.params = OcsortParams(det_thresh, iou_threshold, inertia, min_confidence, max_age, min_hits,
+                                   delta_t, ASSO[asso_func], int(use_byte), int(wrapper_mode),
+                                   max_tracks, max_dets)
+        self.n_streams, self.device = n_streams, device
+        self.max_tracks, self.max_dets = max_tracks, max_dets
+        h = C.c_void_p()
+        check(lib().tlk_ocsort_create(C.byref(self.params), n_streams, device, C.byref(h)))
+        self._h = h
+        self._out = np.empty((max_tracks + max_dets, 8))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tlk_ocsort_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reset(self, stream: int = -1):
+        check(lib().tlk_ocsort_reset(self._h, stream))
+
+    def update(self, dets, stream: int = 0) -> np.ndarray:
+        dets = _f64(dets).reshape(-1, 7)
+        n = C.c_int(0)
+        check(lib().tlk_ocsort_update(self._h, stream, dets.ctypes.data_as(_dp), len(dets),
+                                      self._out.ctypes.data_as(_dp), len(self._out), C.byref(n)))
+        return self._out[:n.value].copy()
+
+    def update_dev(self, dets_ptr, counts_ptr, n_frames, out_ptr, out_cap, out_counts_ptr, stream_ptr=None):
+        check(lib().tlk_ocsort_update_dev(self._h, dets_ptr, counts_ptr, n_frames, out_ptr, out_cap,
+                                          out_counts_ptr, stream_ptr))
+
+    def tracks(self, stream: int = 0):
+        cap = self.max_tracks
+        x, P, ids = np.empty((cap, 7)), np.empty((cap, 7, 7)), np.empty(cap, dtype=np.int64)
+        n = C.c_int(0)
+        check(lib().tlk_ocsort_get_tracks(self._h, stream, x.ctypes.data_as(_dp), P.ctypes.data_as(_dp),
+                                          ids.ctypes.data_as(_ip64), cap, C.byref(n)))
+        return x[:n.value], P[:n.value], ids[:n.value]

@@ -1,0 +1,230 @@
+// tlk_common.hpp -- shared host/device helpers of libtlk.so (gfx950 only, wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "tlk.h"
+
+namespace tlk {
+
+// ------------------------------------------------------------------------------------ host errors
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+#define TLK_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return ::tlk::fail(TLK_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
+    } while (0)
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;          // 4 wavefronts, one per SIMD of a CU
+constexpr int NWAVES = BLOCK / WAVE;
+
+// ------------------------------------------------------------------------------------ device helpers
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ double dmax_(double a, double b) { return a > b ? a : b; }   // np.maximum (non-NaN)
+__device__ __forceinline__ double dmin_(double a, double b) { return a < b ? a : b; }
+
+// Similarity of two xyxy boxes; same operation order as oc_sort/association.py:5-147 so that the
+// fp64 result is bit-identical to numpy's (compiled with -ffp-contract=off). TLK_CT returns the raw
+// centre distance; the matrix-wide rescale of association.py:169-171 is applied by the caller.
+__device__ __forceinline__ double box_similarity(int variant, const double *a, const double *b)
+{
+    if (variant == TLK_CT) {
+        double cx1 = (a[0] + a[2]) / 2.0, cy1 = (a[1] + a[3]) / 2.0;
+        double cx2 = (b[0] + b[2]) / 2.0, cy2 = (b[1] + b[3]) / 2.0;
+        double dx = cx1 - cx2, dy = cy1 - cy2;
+        return sqrt(dx * dx + dy * dy);
+    }
+    double xx1 = dmax_(a[0], b[0]), yy1 = dmax_(a[1], b[1]);
+    double xx2 = dmin_(a[2], b[2]), yy2 = dmin_(a[3], b[3]);
+    double w = dmax_(0., xx2 - xx1), h = dmax_(0., yy2 - yy1);
+    double wh = w * h;
+    double iou = wh / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - wh);
+    if (variant == TLK_IOU) return iou;
+    double xxc1 = dmin_(a[0], b[0]), yyc1 = dmin_(a[1], b[1]);
+    double xxc2 = dmax_(a[2], b[2]), yyc2 = dmax_(a[3], b[3]);
+    if (variant == TLK_GIOU) {
+        double wc = xxc2 - xxc1, hc = yyc2 - yyc1;
+        double area_enclose = wc * hc;
+        double giou = iou - (area_enclose - wh) / area_enclose;
+        return (giou + 1.) / 2.0;
+    }
+    double cx1 = (a[0] + a[2]) / 2.0, cy1 = (a[1] + a[3]) / 2.0;
+    double cx2 = (b[0] + b[2]) / 2.0, cy2 = (b[1] + b[3]) / 2.0;
+    double inner = (cx1 - cx2) * (cx1 - cx2) + (cy1 - cy2) * (cy1 - cy2);
+    double outer = (xxc2 - xxc1) * (xxc2 - xxc1) + (yyc2 - yyc1) * (yyc2 - yyc1);
+    if (variant == TLK_DIOU) return ((iou - inner / outer) + 1) / 2.0;
+    double w1 = a[2] - a[0], h1 = a[3] - a[1], w2 = b[2] - b[0], h2 = b[3] - b[1];
+    h2 = h2 + 1.; h1 = h1 + 1.;
+    double arct = atan(w2 / h2) - atan(w1 / h1);
+    const double PI = 3.141592653589793;
+    double v = (4 / (PI * PI)) * (arct * arct);
+    double S = 1 - iou;
+    double alpha = v / (S + v);
+    return ((iou - inner / outer - alpha * v) + 1) / 2.0;
+}
+
+// Stable stream compaction over i in [0,n): every thread of the 256-thread block must call.
+// emit(i, position) runs for each i with pred(i) true; returns the number of kept items.
+// s_scan: >= NWAVES ints of LDS scratch.
+template <class Pred, class Emit>
+__device__ __forceinline__ int block_compact(int n, Pred pred, Emit emit, int *s_scan)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int base = 0;
+    for (int start = 0; start < n; start += BLOCK) {
+        const int i = start + (int)threadIdx.x;
+        const bool f = (i < n) && pred(i);
+        const unsigned long long m = __ballot(f);
+        const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_scan[w] = __popcll(m);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < NWAVES; ++k) { const int c = s_scan[k]; if (k < w) woff += c; tot += c; }
+        if (f) emit(i, base + woff + prefix);
+        base += tot;
+        __syncthreads();
+    }
+    return base;
+}
+
+// Block-wide max with numpy semantics (NaN propagates). s_red: >= NWAVES doubles of LDS.
+__device__ __forceinline__ double block_max_nan(double v, bool valid, double *s_red)
+{
+    // identity: -inf for invalid lanes
+    double x = valid ? v : -INFINITY;
+    bool isn = valid && (v != v);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double o = __shfl_xor(x, off);
+        x = (o > x) ? o : x;
+    }
+    const unsigned long long nanm = __ballot(isn);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_red[w] = nanm ? NAN : x;
+    __syncthreads();
+    double r = s_red[0];
+#pragma unroll
+    for (int k = 1; k < NWAVES; ++k) { double o = s_red[k]; r = (o != o || r != r) ? NAN : (o > r ? o : r); }
+    __syncthreads();
+    return r;
+}
+
+// LDS work arrays of one LSA problem (sized for max(nr,nc) entries each).
+struct LsaWork {
+    double *u, *v, *spc;
+    int *path, *row4col, *remaining, *col4row;
+    unsigned char *SR, *SC;
+};
+
+// scipy-identical rectangular LSAP solved by ONE wavefront (all 64 lanes must call, converged).
+// cost(i, j) element = cost[i*rs + j*cs] for the ORIGINAL (nr0 x nc0) orientation; tall inputs are
+// solved transposed, exactly like scipy's rectangular_lsap.cpp. Writes pairs sorted by original
+// row to rows_out/cols_out and returns their number (min(nr0,nc0)), or -1 if infeasible.
+// Scan semantics restated: remaining[] is filled in reverse; among minimum shortest-path costs an
+// unassigned column wins (the one scanned last), otherwise the first scanned column.
+__device__ __forceinline__ int wave_lsa(const double *cost, int nr0, int nc0, size_t rs0, size_t cs0,
+                                        const LsaWork &W, int *rows_out, int *cols_out)
+{
+    const int lane = threadIdx.x & 63;
+    if (nr0 == 0 || nc0 == 0) return 0;
+    const bool transpose = nc0 < nr0;
+    const int nr = transpose ? nc0 : nr0, nc = transpose ? nr0 : nc0;
+    const size_t rs = transpose ? cs0 : rs0, cs = transpose ? rs0 : cs0;
+    for (int k = lane; k < nr; k += WAVE) { W.u[k] = 0.0; W.col4row[k] = -1; }
+    for (int k = lane; k < nc; k += WAVE) { W.v[k] = 0.0; W.row4col[k] = -1; W.path[k] = -1; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    int ret = nr;
+    for (int cur = 0; cur < nr; ++cur) {
+        for (int k = lane; k < nc; k += WAVE) { W.remaining[k] = nc - k - 1; W.SC[k] = 0; W.spc[k] = INFINITY; }
+        for (int k = lane; k < nr; k += WAVE) W.SR[k] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        double minval = 0.0;
+        int num_remaining = nc, i = cur, sink = -1;
+        while (sink == -1) {
+            if (lane == 0) W.SR[i] = 1;
+            const double ui = W.u[i];
+            double best = INFINITY;
+            int best_s = -1, best_it = -1;
+            for (int it = lane; it < num_remaining; it += WAVE) {
+                const int j = W.remaining[it];
+                const double r = minval + cost[(size_t)i * rs + (size_t)j * cs] - ui - W.v[j];
+                double sp = W.spc[j];
+                if (r < sp) { W.path[j] = i; W.spc[j] = r; sp = r; }
+                const int s = (W.row4col[j] == -1) ? (nc + it) : (nc - 1 - it);
+                if (sp < best || (sp == best && s > best_s)) { best = sp; best_s = s; best_it = it; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best, off);
+                const int os = __shfl_xor(best_s, off);
+                const int oi = __shfl_xor(best_it, off);
+                if (ob < best || (ob == best && os > best_s)) { best = ob; best_s = os; best_it = oi; }
+            }
+            minval = best;
+            if (!(minval < INFINITY)) { ret = -1; break; }     // infeasible (or NaN cost)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const int j = W.remaining[best_it];
+            const int r4c = W.row4col[j];
+            if (r4c == -1) sink = j; else i = r4c;
+            --num_remaining;
+            const int last = W.remaining[num_remaining];
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) { W.SC[j] = 1; W.remaining[best_it] = last; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (ret < 0) break;
+        // dual update (rectangular_lsap.cpp: "update dual variables")
+        for (int k = lane; k < nr; k += WAVE)
+            if (W.SR[k] && k != cur) W.u[k] += minval - W.spc[W.col4row[k]];
+        if (lane == 0) W.u[cur] += minval;
+        for (int k = lane; k < nc; k += WAVE)
+            if (W.SC[k]) W.v[k] -= minval - W.spc[k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // augment (uniform across lanes; lane 0 writes)
+        int j = sink;
+        for (;;) {
+            const int pi = W.path[j];
+            const int old = W.col4row[pi];
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) { W.row4col[j] = pi; W.col4row[pi] = j; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            j = old;
+            if (pi == cur) break;
+        }
+    }
+    if (ret < 0) return ret;
+    if (!transpose) {
+        for (int k = lane; k < nr; k += WAVE) { rows_out[k] = k; cols_out[k] = W.col4row[k]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        return nr;
+    }
+    // transposed: original row r == transposed column r; emit (r, row4col[r]) for assigned r, ascending
+    int base = 0;
+    for (int start = 0; start < nc; start += WAVE) {
+        const int r = start + lane;
+        const bool f = (r < nc) && (W.row4col[r] != -1);
+        const unsigned long long m = __ballot(f);
+        if (f) { const int p = base + __popcll(m & ((1ull << lane) - 1ull)); rows_out[p] = r; cols_out[p] = W.row4col[r]; }
+        base += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    return base;
+}
+
+#endif  // __HIPCC__
+}  // namespace tlk

@@ -1,0 +1,124 @@
+// tlk_core.hip -- error plumbing + stateless kernels (similarity matrices, batched LSA).
+#include "tlk_common.hpp"
+
+namespace tlk {
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+}  // namespace tlk
+
+using namespace tlk;
+
+extern "C" const char *tlk_last_error(void) { return tlk::g_err.c_str(); }
+extern "C" int tlk_version(void) { return 100; }
+extern "C" int tlk_device_count(int *count)
+{
+    if (!count) return fail(TLK_EINVAL, "tlk_device_count: null pointer");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(TLK_ENODEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *count = n;
+    return TLK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Similarity matrix: one thread per (i, j); a wavefront covers 64 consecutive j of one row so the
+// b2 reads and the out writes are coalesced; b1[i] is a wave-uniform (scalar) load.
+// Algorithmic bytes: (n + m) * 32 read + n*m*8 written -> HBM/launch bound at tracker sizes.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) iou_matrix_kernel(int variant, const double *__restrict__ b1, int n,
+                                                           const double *__restrict__ b2, int m,
+                                                           double *__restrict__ out)
+{
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= m || i >= n) return;
+    double a[4] = {b1[4 * i], b1[4 * i + 1], b1[4 * i + 2], b1[4 * i + 3]};
+    double b[4] = {b2[4 * j], b2[4 * j + 1], b2[4 * j + 2], b2[4 * j + 3]};
+    out[(size_t)i * m + j] = box_similarity(variant, a, b);
+}
+
+// ct_dist rescale (association.py:169-171): d/max, then max' - d. Single block; matrices are tiny.
+__global__ void __launch_bounds__(BLOCK) ct_rescale_kernel(double *out, int total)
+{
+    __shared__ double s_red[NWAVES];
+    double mx = -INFINITY;
+    bool nan = false;
+    for (int k = threadIdx.x; k < total; k += BLOCK) { double v = out[k]; nan |= (v != v); mx = v > mx ? v : mx; }
+    double m1 = block_max_nan(nan ? NAN : mx, true, s_red);
+    double mx2 = -INFINITY;
+    nan = false;
+    for (int k = threadIdx.x; k < total; k += BLOCK) { double v = out[k] / m1; out[k] = v; nan |= (v != v); mx2 = v > mx2 ? v : mx2; }
+    double m2 = block_max_nan(nan ? NAN : mx2, true, s_red);
+    for (int k = threadIdx.x; k < total; k += BLOCK) out[k] = m2 - out[k];
+}
+
+extern "C" int tlk_iou_matrix_f64(int variant, const double *b1, int n, const double *b2, int m, double *out,
+                                  void *hip_stream)
+{
+    if (variant < TLK_IOU || variant > TLK_CT) return fail(TLK_EINVAL, "tlk_iou_matrix_f64: bad variant");
+    if (n < 0 || m < 0) return fail(TLK_EINVAL, "tlk_iou_matrix_f64: negative size");
+    if (n == 0 || m == 0) return TLK_OK;
+    if (!b1 || !b2 || !out) return fail(TLK_EINVAL, "tlk_iou_matrix_f64: null pointer");
+    hipStream_t st = (hipStream_t)hip_stream;
+    dim3 grid((m + BLOCK - 1) / BLOCK, n);
+    hipLaunchKernelGGL(iou_matrix_kernel, grid, dim3(BLOCK), 0, st, variant, b1, n, b2, m, out);
+    if (variant == TLK_CT) hipLaunchKernelGGL(ct_rescale_kernel, dim3(1), dim3(BLOCK), 0, st, out, n * m);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batched LSA: one wavefront per problem, 4 problems per 256-thread workgroup, work arrays in LDS,
+// cost rows read from HBM/L2 (each row scan is one coalesced 64-lane read).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) lsa_kernel(const double *__restrict__ cost, int batch, int nr, int nc,
+                                                    int *__restrict__ rows, int *__restrict__ cols,
+                                                    int *__restrict__ n_pairs, int maxdim)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int prob = blockIdx.x * NWAVES + w;
+    if (prob >= batch) return;                    // whole wave exits together; no block barriers below
+    const size_t per_wave = (size_t)maxdim * (3 * sizeof(double) + 4 * sizeof(int) + 2);
+    unsigned char *base = smem + (size_t)w * ((per_wave + 15) & ~(size_t)15);
+    LsaWork W;
+    W.u = (double *)base;
+    W.v = W.u + maxdim;
+    W.spc = W.v + maxdim;
+    W.path = (int *)(W.spc + maxdim);
+    W.row4col = W.path + maxdim;
+    W.remaining = W.row4col + maxdim;
+    W.col4row = W.remaining + maxdim;
+    W.SR = (unsigned char *)(W.col4row + maxdim);
+    W.SC = W.SR + maxdim;
+    const double *c = cost + (size_t)prob * nr * nc;
+    // scipy: "matrix contains invalid numeric entries" on NaN / -inf
+    bool bad = false;
+    for (int k = lane; k < nr * nc; k += WAVE) { double v = c[k]; bad |= (v != v) || (v == -INFINITY); }
+    const int k = nr < nc ? nr : nc;
+    int *ro = rows + (size_t)prob * k, *co = cols + (size_t)prob * k;
+    if (__ballot(bad)) { if (lane == 0) n_pairs[prob] = -2; return; }
+    const int np = wave_lsa(c, nr, nc, (size_t)nc, (size_t)1, W, ro, co);
+    if (lane == 0) n_pairs[prob] = np;
+}
+
+extern "C" int tlk_lsa_f64(const double *cost, int batch, int nr, int nc, int32_t *rows, int32_t *cols,
+                           int32_t *n_pairs, void *hip_stream)
+{
+    if (batch < 0 || nr < 0 || nc < 0) return fail(TLK_EINVAL, "tlk_lsa_f64: negative size");
+    if (batch == 0) return TLK_OK;
+    if (!n_pairs) return fail(TLK_EINVAL, "tlk_lsa_f64: null n_pairs");
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (nr == 0 || nc == 0) { TLK_HIP(hipMemsetAsync(n_pairs, 0, sizeof(int32_t) * batch, st)); return TLK_OK; }
+    if (!cost || !rows || !cols) return fail(TLK_EINVAL, "tlk_lsa_f64: null pointer");
+    const int maxdim = nr > nc ? nr : nc;
+    const size_t per_wave = ((size_t)maxdim * (3 * sizeof(double) + 4 * sizeof(int) + 2) + 15) & ~(size_t)15;
+    const size_t smem = per_wave * NWAVES;
+    if (smem > 160 * 1024) return fail(TLK_ECAPACITY, "tlk_lsa_f64: problem too large for LDS work arrays");
+    TLK_HIP(hipFuncSetAttribute((const void *)lsa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(lsa_kernel, dim3((batch + NWAVES - 1) / NWAVES), dim3(BLOCK), smem, st, cost, batch, nr, nc,
+                       rows, cols, n_pairs, maxdim);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
