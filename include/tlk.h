@@ -96,6 +96,40 @@ int tlk_ocsort_update_dev(tlk_ocsort *h, const double *dets_dev, const int32_t *
  * ids (cap) int64; returns count via n_tracks. Synchronous. */
 int tlk_ocsort_get_tracks(tlk_ocsort *h, int stream, double *x, double *P, int64_t *ids, int cap, int *n_tracks);
 
+/* ------------------------------------------------------------------------------------------
+ * Detector / ReID pre- and post-processing. In the reference this arithmetic sits in third-party
+ * packages behind the adapters tracklab/wrappers/bbox_detector/rtmlib_api.py:27-46 (rtmlib
+ * YOLOX.preprocess / postprocess, cv2.resize) and tracklab/wrappers/reid/kpreid_api.py:115-144
+ * (crop image[t:b,l:r] of the rounded ltrb + albumentations Resize/Normalize).
+ * ------------------------------------------------------------------------------------------ */
+enum { TLK_NCHW = 0, TLK_NHWC = 1, TLK_FOCUS_NHWC = 2 };   /* FOCUS: YOLOX space-to-depth fused, (B,S/2,S/2,12) */
+enum { TLK_F32 = 0, TLK_F16 = 1, TLK_BF16 = 2 };
+
+/* frames_dev (batch, h, w, 3) uint8 -> out_dev (batch, 3, size, size) in `layout`/`dtype`, values 0..255,
+ * pad 114, ratio = min(size/h, size/w) returned through ratio_out (host). size % 16 == 0. */
+int tlk_letterbox_u8(const uint8_t *frames_dev, int batch, int h, int w, int size, int layout, int dtype,
+                     void *out_dev, double *ratio_out, void *hip_stream);
+
+/* boxes_ltwh_dev (batch, max_n, 4) float32 + counts_dev (batch) -> out_dev (batch*max_n, 3, out_h, out_w);
+ * slot b*max_n+i holds crop i of frame b, slots >= counts[b] are zero. mean3/std3 are HOST float[3]
+ * (ImageNet statistics in kpreid); value = (u8 - 255*mean) * (1/(255*std)). out_w % 8 == 0.
+ * layout TLK_NCHW or TLK_NHWC. */
+int tlk_roi_crop_resize_norm(const uint8_t *frames_dev, int batch, int h, int w, const float *boxes_ltwh_dev,
+                             const int32_t *counts_dev, int max_n, int out_h, int out_w, const float *mean3,
+                             const float *std3, int layout, int dtype, void *out_dev, void *hip_stream);
+
+/* pred_dev (batch, A, 5+num_classes) float32 raw YOLOX head (A = (s/8)^2+(s/16)^2+(s/32)^2) ->
+ * per frame up to max_out detections in rtmlib order (class-major, score-descending):
+ * ltwh_dev (batch,max_out,4) clipped to the image like RTMLibDetector (rtmlib_api.py:36-41),
+ * xyxy_dev unclipped, scores_dev, cls_dev, counts_dev (batch; <0 = TLK_ECAPACITY).
+ * trk_in_dev (optional, may be NULL): (batch, max_out, 7) float64 rows [l,t,r,b,1.0,category_id,det_id]
+ * exactly as OCSORT.preprocess builds them from the detector's float32 ltwh (oc_sort_api.py:37-45), with
+ * det_id = det_id_base + frame*max_out + i, ready for tlk_ocsort_update_dev. */
+int tlk_yolox_decode_nms(const float *pred_dev, int batch, int size, int num_classes, float ratio, float nms_thr,
+                         float score_thr, int img_w, int img_h, int max_out, float *ltwh_dev, float *xyxy_dev,
+                         float *scores_dev, int32_t *cls_dev, int32_t *counts_dev, double *trk_in_dev,
+                         int64_t det_id_base, double category_id, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

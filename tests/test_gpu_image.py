@@ -1,0 +1,146 @@
+"""-m gpu: letterbox / ROI crop-resize-normalize / YOLOX decode+NMS kernels vs the C oracle
+(integer pixel values bit-exact; fp32 normalisation bit-exact; fp16/bf16 = rounded fp32)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(rng, B, H, W):
+    f = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    f[:, ::7, ::5] = 255
+    return f
+
+
+@pytest.mark.parametrize("H,W", [(1080, 1920), (720, 1280), (480, 854), (1000, 600), (333, 517)])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc", "focus_nhwc"])
+def test_letterbox_matches_oracle(orc, H, W, layout):
+    import torch
+    from tracklab_amd import _lib
+    rng = np.random.default_rng(H + W)
+    frames = _frames(rng, 2, H, W)
+    d = torch.from_numpy(frames).cuda()
+    for dtype in (torch.float32, torch.float16, torch.bfloat16):
+        out, ratio = _lib.letterbox(d, 640, layout, dtype)
+        torch.cuda.synchronize()
+        got = out.float().cpu().numpy()
+        if layout == "focus_nhwc":       # undo YOLOX Focus: (tl, bl, tr, br) channel groups
+            g = np.empty((2, 3, 640, 640), dtype=np.float32)
+            g[:, :, 0::2, 0::2] = got[:, 0:3]
+            g[:, :, 1::2, 0::2] = got[:, 3:6]
+            g[:, :, 0::2, 1::2] = got[:, 6:9]
+            g[:, :, 1::2, 1::2] = got[:, 9:12]
+            got = g
+        for b in range(2):
+            exp, eratio = orc.letterbox(frames[b], 640)
+            assert ratio == eratio
+            np.testing.assert_array_equal(got[b], exp)       # integers 0..255 are exact in f16/bf16
+
+
+@pytest.mark.parametrize("oh,ow", [(384, 128), (256, 128), (256, 192)])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_crop_resize_norm_matches_oracle(orc, oh, ow, layout):
+    import torch
+    from tracklab_amd import _lib
+    rng = np.random.default_rng(oh * ow)
+    B, H, W, MAXN = 2, 1080, 1920, 24
+    frames = _frames(rng, B, H, W)
+    boxes = np.zeros((B, MAXN, 4), dtype=np.float32)
+    counts = np.array([MAXN, 17], dtype=np.int32)
+    for b in range(B):
+        x = rng.uniform(-30, W - 20, MAXN)
+        y = rng.uniform(-30, H - 20, MAXN)
+        w = rng.uniform(2, 300, MAXN)
+        h = rng.uniform(2, 500, MAXN)
+        boxes[b] = np.stack([x, y, w, h], 1)
+    boxes[0, 0] = [0, 0, 5000, 5000]          # clipped to the full frame (downscale path)
+    boxes[0, 1] = [100.5, 200.5, 1.2, 1.4]    # tiny box, half-to-even rounding
+    boxes[0, 2] = [1918.7, 1078.2, 50, 50]    # at the border
+    d = torch.from_numpy(frames).cuda()
+    db = torch.from_numpy(boxes).cuda()
+    dc = torch.from_numpy(counts).cuda()
+    out32 = _lib.roi_crop_resize_norm(d, db, dc, oh, ow, layout, torch.float32)
+    out16 = _lib.roi_crop_resize_norm(d, db, dc, oh, ow, layout, torch.float16)
+    outbf = _lib.roi_crop_resize_norm(d, db, dc, oh, ow, layout, torch.bfloat16)
+    torch.cuda.synchronize()
+    got = out32.cpu().numpy()
+    for b in range(B):
+        ltrb = orc.ltwh_to_crop_ltrb(boxes[b].astype(np.float64), W, H)
+        exp = orc.crop_resize_norm(frames[b], ltrb, oh, ow)
+        n = counts[b]
+        np.testing.assert_array_equal(got[b * MAXN:b * MAXN + n], exp[:n])
+        assert not got[b * MAXN + n:(b + 1) * MAXN].any()
+        e16 = torch.from_numpy(exp[:n]).half().numpy()
+        np.testing.assert_array_equal(out16[b * MAXN:b * MAXN + n].cpu().numpy(), e16)
+        ebf = torch.from_numpy(exp[:n]).bfloat16().float().numpy()
+        np.testing.assert_array_equal(outbf[b * MAXN:b * MAXN + n].float().cpu().numpy(), ebf)
+
+
+def synth_head(rng, boxes_xyxy, size=640, ratio=1.0 / 3, num_classes=1, dup=3):
+    """Raw YOLOX head tensor (A, 5+C) whose decode gives `boxes_xyxy` (+ jittered duplicates on neighbouring
+    anchors so that NMS has work to do) on top of low-score clutter."""
+    strides = [8, 16, 32]
+    n = [(size // s) ** 2 for s in strides]
+    A = sum(n)
+    pred = np.zeros((A, 5 + num_classes), dtype=np.float32)
+    pred[:, :4] = rng.normal(0, 0.5, (A, 4))
+    pred[:, 4] = rng.uniform(0, 0.6, A)
+    pred[:, 5:] = rng.uniform(0, 0.9, (A, num_classes))
+    used = set()
+    for k, (x1, y1, x2, y2) in enumerate(boxes_xyxy):
+        cx, cy = (x1 + x2) / 2 * ratio, (y1 + y2) / 2 * ratio
+        w, h = (x2 - x1) * ratio, (y2 - y1) * ratio
+        lvl = 0 if max(w, h) < 64 else (1 if max(w, h) < 128 else 2)
+        s = strides[lvl]
+        ws = size // s
+        for d in range(dup):
+            gx = int(np.clip(cx // s + (d % 2) * (1 if d else 0), 0, ws - 1))
+            gy = int(np.clip(cy // s + (d // 2), 0, ws - 1))
+            a = sum(n[:lvl]) + gy * ws + gx
+            if a in used:
+                continue
+            used.add(a)
+            jit = rng.normal(0, 0.6, 4) if d else np.zeros(4)
+            pred[a, 0] = (cx + jit[0]) / s - gx
+            pred[a, 1] = (cy + jit[1]) / s - gy
+            pred[a, 2] = np.log(max(w + jit[2], 1.0) / s)
+            pred[a, 3] = np.log(max(h + jit[3], 1.0) / s)
+            pred[a, 4] = rng.uniform(0.9, 1.0) if d == 0 else rng.uniform(0.85, 0.95)
+            pred[a, 5 + (k % num_classes)] = rng.uniform(0.9, 1.0)
+    return pred
+
+
+@pytest.mark.parametrize("num_classes,nobj", [(1, 100), (1, 5), (3, 60), (1, 0)])
+def test_yolox_decode_nms_matches_oracle(orc, num_classes, nobj):
+    import torch
+    from tracklab_amd import _lib
+    from tracklab_amd.synth import SyntheticStream
+    rng = np.random.default_rng(77 + nobj)
+    B = 3
+    preds = []
+    for b in range(B):
+        fr = SyntheticStream(100 + b, max(nobj, 1), 1).step()
+        boxes = fr["dets"][:nobj, :4]
+        preds.append(synth_head(rng, boxes, num_classes=num_classes))
+    preds = np.stack(preds)
+    ratio = np.float32(640 / 1920)
+    d = torch.from_numpy(preds).cuda()
+    out = _lib.yolox_decode_nms(d, 640, float(ratio), 1920, 1080, max_out=256)
+    torch.cuda.synchronize()
+    counts = out["counts"].cpu().numpy()
+    for b in range(B):
+        eb, es, ec = orc.yolox_postprocess(preds[b], 640, float(ratio))
+        assert counts[b] == len(eb), (b, counts[b], len(eb))
+        n = counts[b]
+        if nobj >= 5:
+            assert n >= nobj * 0.8
+        np.testing.assert_array_equal(out["cls"][b, :n].cpu().numpy(), ec)
+        np.testing.assert_allclose(out["scores"][b, :n].cpu().numpy(), es, rtol=0, atol=0)
+        np.testing.assert_allclose(out["xyxy"][b, :n].cpu().numpy(), eb, rtol=2e-6, atol=1e-4)   # expf: 1-2 ulp
+        # ltwh = sanitize_bbox_ltrb + ltrb_to_ltwh in float32 (coordinates.py:270-295,318-328)
+        l = np.maximum(0, np.minimum(eb[:, 0], 1918)).astype(np.float32)
+        t = np.maximum(0, np.minimum(eb[:, 1], 1078)).astype(np.float32)
+        r = np.maximum(1, np.minimum(eb[:, 2], 1919)).astype(np.float32)
+        bt = np.maximum(1, np.minimum(eb[:, 3], 1079)).astype(np.float32)
+        exp_ltwh = np.stack([l, t, r - l, bt - t], 1)
+        np.testing.assert_allclose(out["ltwh"][b, :n].cpu().numpy(), exp_ltwh, rtol=2e-6, atol=2e-4)

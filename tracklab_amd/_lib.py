@@ -139,3 +139,101 @@ class OCSortBank:
         check(lib().tlk_ocsort_get_tracks(self._h, stream, x.ctypes.data_as(_dp), P.ctypes.data_as(_dp),
                                           ids.ctypes.data_as(_ip64), cap, C.byref(n)))
         return x[:n.value], P[:n.value], ids[:n.value]
+
+
+# ------------------------------------------------------------------------------------------------
+# image ops on torch device tensors (torch is plumbing here: device memory + the current stream)
+# ------------------------------------------------------------------------------------------------
+LAYOUT = {"nchw": 0, "nhwc": 1, "focus_nhwc": 2}
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def _dtype_code(dtype):
+    import torch
+    return {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[dtype]
+
+
+def _bind_image(L):
+    if getattr(L, "_image_bound", False):
+        return
+    L.tlk_letterbox_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.POINTER(C.c_double), C.c_void_p]
+    L.tlk_roi_crop_resize_norm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
+                                           C.c_int, C.c_void_p, C.c_void_p]
+    L.tlk_yolox_decode_nms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p]
+    L._image_bound = True
+
+
+def letterbox(frames, size=640, layout="nchw", dtype=None, out=None):
+    """frames: (B,H,W,3) uint8 cuda tensor -> letterboxed tensor (logical NCHW shape; memory per `layout`)
+    and the resize ratio (rtmlib YOLOX.preprocess)."""
+    import torch
+    L = lib()
+    _bind_image(L)
+    assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.dim() == 4
+    dtype = dtype or torch.float16
+    B, H, W, _ = frames.shape
+    if out is None:
+        if layout == "nchw":
+            out = torch.empty((B, 3, size, size), dtype=dtype, device=frames.device)
+        elif layout == "nhwc":
+            out = torch.empty((B, size, size, 3), dtype=dtype, device=frames.device)
+        else:
+            out = torch.empty((B, size // 2, size // 2, 12), dtype=dtype, device=frames.device)
+    ratio = C.c_double(0)
+    check(L.tlk_letterbox_u8(frames.data_ptr(), B, H, W, size, LAYOUT[layout], _dtype_code(dtype), out.data_ptr(),
+                             C.byref(ratio), current_stream_ptr()))
+    if layout != "nchw":
+        out = out.permute(0, 3, 1, 2)        # logical NCHW view of channels-last memory
+    return out, ratio.value
+
+
+def roi_crop_resize_norm(frames, boxes_ltwh, counts, out_h, out_w, layout="nchw", dtype=None,
+                         mean=IMAGENET_MEAN, std=IMAGENET_STD, out=None):
+    """frames (B,H,W,3) u8, boxes_ltwh (B,max_n,4) f32, counts (B,) i32 -> (B*max_n, 3, out_h, out_w)."""
+    import torch
+    L = lib()
+    _bind_image(L)
+    assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous()
+    assert boxes_ltwh.dtype == torch.float32 and boxes_ltwh.is_contiguous() and counts.dtype == torch.int32
+    dtype = dtype or torch.float16
+    B, H, W, _ = frames.shape
+    max_n = boxes_ltwh.shape[1]
+    if out is None:
+        shape = (B * max_n, 3, out_h, out_w) if layout == "nchw" else (B * max_n, out_h, out_w, 3)
+        out = torch.empty(shape, dtype=dtype, device=frames.device)
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    check(L.tlk_roi_crop_resize_norm(frames.data_ptr(), B, H, W, boxes_ltwh.data_ptr(), counts.data_ptr(), max_n,
+                                     out_h, out_w, m, s, LAYOUT[layout], _dtype_code(dtype), out.data_ptr(),
+                                     current_stream_ptr()))
+    if layout != "nchw":
+        out = out.permute(0, 3, 1, 2)
+    return out
+
+
+def yolox_decode_nms(pred, size, ratio, img_w, img_h, max_out=128, nms_thr=0.45, score_thr=0.7,
+                     out=None, trk_in=None, det_id_base=0, category_id=1.0):
+    """pred (B, A, 5+C) f32 cuda -> dict of ltwh (B,max_out,4), xyxy, scores, cls, counts (rtmlib order)."""
+    import torch
+    L = lib()
+    _bind_image(L)
+    assert pred.is_cuda and pred.dtype == torch.float32 and pred.is_contiguous() and pred.dim() == 3
+    B, A, F = pred.shape
+    dev = pred.device
+    if out is None:
+        out = {"ltwh": torch.zeros((B, max_out, 4), dtype=torch.float32, device=dev),
+               "xyxy": torch.zeros((B, max_out, 4), dtype=torch.float32, device=dev),
+               "scores": torch.zeros((B, max_out), dtype=torch.float32, device=dev),
+               "cls": torch.zeros((B, max_out), dtype=torch.int32, device=dev),
+               "counts": torch.zeros((B,), dtype=torch.int32, device=dev)}
+    check(L.tlk_yolox_decode_nms(pred.data_ptr(), B, size, F - 5, ratio, nms_thr, score_thr, img_w, img_h, max_out,
+                                 out["ltwh"].data_ptr(), out["xyxy"].data_ptr(), out["scores"].data_ptr(),
+                                 out["cls"].data_ptr(), out["counts"].data_ptr(),
+                                 trk_in.data_ptr() if trk_in is not None else None, det_id_base, category_id,
+                                 current_stream_ptr()))
+    return out

@@ -1,0 +1,177 @@
+"""YOLOX (CSPDarknet + PAFPN + decoupled head), inference form with BN folded into the convs.
+
+The reference runs this network through third-party ``rtmlib.YOLOX`` on ONNXRuntime
+(tracklab/wrappers/bbox_detector/rtmlib_api.py:21,30; model zoo in
+tracklab/configs/modules/bbox_detector/yolox_rtmlib*.yaml). Architecture constants follow the public
+YOLOX definition: s = (depth .33, width .50), m = (.67, .75), l = (1, 1), x = (1.33, 1.25).
+``forward`` takes the letterboxed 0..255 image (NCHW logical shape, any memory format) or, with
+``focused=True``, the space-to-depth tensor (B, 12, S/2, S/2) produced directly by
+``tlk_letterbox_u8(TLK_FOCUS_NHWC)``; it returns the raw head tensor (B, A, 5+C) float32 that
+``tlk_yolox_decode_nms`` consumes (xy/wh undecoded, obj/cls after sigmoid).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+SIZES = {"tiny": (0.33, 0.375), "s": (0.33, 0.50), "m": (0.67, 0.75), "l": (1.0, 1.0), "x": (1.33, 1.25)}
+
+
+class Conv(nn.Module):
+    def __init__(self, cin, cout, k=1, s=1):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, s, (k - 1) // 2, bias=True)   # BN folded
+        self.act = nn.SiLU(inplace=True)
+
+    def forward(self, x):
+        return self.act(self.conv(x))
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, cin, cout, shortcut=True, expansion=0.5):
+        super().__init__()
+        hidden = int(cout * expansion)
+        self.conv1 = Conv(cin, hidden, 1)
+        self.conv2 = Conv(hidden, cout, 3)
+        self.add = shortcut and cin == cout
+
+    def forward(self, x):
+        y = self.conv2(self.conv1(x))
+        return y + x if self.add else y
+
+
+class CSPLayer(nn.Module):
+    def __init__(self, cin, cout, n=1, shortcut=True, expansion=0.5):
+        super().__init__()
+        hidden = int(cout * expansion)
+        self.conv1 = Conv(cin, hidden, 1)
+        self.conv2 = Conv(cin, hidden, 1)
+        self.conv3 = Conv(2 * hidden, cout, 1)
+        self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0) for _ in range(n)])
+
+    def forward(self, x):
+        return self.conv3(torch.cat((self.m(self.conv1(x)), self.conv2(x)), dim=1))
+
+
+class SPPBottleneck(nn.Module):
+    def __init__(self, cin, cout, ks=(5, 9, 13)):
+        super().__init__()
+        hidden = cin // 2
+        self.conv1 = Conv(cin, hidden, 1)
+        self.m = nn.ModuleList([nn.MaxPool2d(k, 1, k // 2) for k in ks])
+        self.conv2 = Conv(hidden * (len(ks) + 1), cout, 1)
+
+    def forward(self, x):
+        x = self.conv1(x)
+        return self.conv2(torch.cat([x] + [m(x) for m in self.m], dim=1))
+
+
+class Focus(nn.Module):
+    def __init__(self, cin, cout, k=3):
+        super().__init__()
+        self.conv = Conv(cin * 4, cout, k)
+
+    def forward(self, x, focused=False):
+        if not focused:
+            tl, tr = x[..., ::2, ::2], x[..., ::2, 1::2]
+            bl, br = x[..., 1::2, ::2], x[..., 1::2, 1::2]
+            x = torch.cat((tl, bl, tr, br), dim=1)
+        return self.conv(x)
+
+
+class CSPDarknet(nn.Module):
+    def __init__(self, dep, wid):
+        super().__init__()
+        b, d = int(wid * 64), max(round(dep * 3), 1)
+        self.stem = Focus(3, b)
+        self.dark2 = nn.Sequential(Conv(b, b * 2, 3, 2), CSPLayer(b * 2, b * 2, d))
+        self.dark3 = nn.Sequential(Conv(b * 2, b * 4, 3, 2), CSPLayer(b * 4, b * 4, d * 3))
+        self.dark4 = nn.Sequential(Conv(b * 4, b * 8, 3, 2), CSPLayer(b * 8, b * 8, d * 3))
+        self.dark5 = nn.Sequential(Conv(b * 8, b * 16, 3, 2), SPPBottleneck(b * 16, b * 16),
+                                   CSPLayer(b * 16, b * 16, d, shortcut=False))
+
+    def forward(self, x, focused=False):
+        x = self.dark2(self.stem(x, focused))
+        c3 = self.dark3(x)
+        c4 = self.dark4(c3)
+        return c3, c4, self.dark5(c4)
+
+
+class PAFPN(nn.Module):
+    def __init__(self, dep, wid):
+        super().__init__()
+        c3, c4, c5 = int(256 * wid), int(512 * wid), int(1024 * wid)
+        n = round(3 * dep)
+        self.up = nn.Upsample(scale_factor=2, mode="nearest")
+        self.lateral_conv0 = Conv(c5, c4, 1)
+        self.C3_p4 = CSPLayer(2 * c4, c4, n, False)
+        self.reduce_conv1 = Conv(c4, c3, 1)
+        self.C3_p3 = CSPLayer(2 * c3, c3, n, False)
+        self.bu_conv2 = Conv(c3, c3, 3, 2)
+        self.C3_n3 = CSPLayer(2 * c3, c4, n, False)
+        self.bu_conv1 = Conv(c4, c4, 3, 2)
+        self.C3_n4 = CSPLayer(2 * c4, c5, n, False)
+
+    def forward(self, feats):
+        x2, x1, x0 = feats
+        fpn0 = self.lateral_conv0(x0)
+        f1 = self.C3_p4(torch.cat([self.up(fpn0), x1], 1))
+        fpn1 = self.reduce_conv1(f1)
+        p3 = self.C3_p3(torch.cat([self.up(fpn1), x2], 1))
+        p4 = self.C3_n3(torch.cat([self.bu_conv2(p3), fpn1], 1))
+        p5 = self.C3_n4(torch.cat([self.bu_conv1(p4), fpn0], 1))
+        return p3, p4, p5
+
+
+class Head(nn.Module):
+    def __init__(self, num_classes, wid):
+        super().__init__()
+        c = int(256 * wid)
+        ins = [int(256 * wid), int(512 * wid), int(1024 * wid)]
+        self.stems = nn.ModuleList([Conv(i, c, 1) for i in ins])
+        self.cls_convs = nn.ModuleList([nn.Sequential(Conv(c, c, 3), Conv(c, c, 3)) for _ in ins])
+        self.reg_convs = nn.ModuleList([nn.Sequential(Conv(c, c, 3), Conv(c, c, 3)) for _ in ins])
+        self.cls_preds = nn.ModuleList([nn.Conv2d(c, num_classes, 1) for _ in ins])
+        self.reg_preds = nn.ModuleList([nn.Conv2d(c, 4, 1) for _ in ins])
+        self.obj_preds = nn.ModuleList([nn.Conv2d(c, 1, 1) for _ in ins])
+
+    def forward(self, feats):
+        outs = []
+        for k, x in enumerate(feats):
+            x = self.stems[k](x)
+            cf, rf = self.cls_convs[k](x), self.reg_convs[k](x)
+            o = torch.cat([self.reg_preds[k](rf), self.obj_preds[k](rf).sigmoid(), self.cls_preds[k](cf).sigmoid()], 1)
+            outs.append(o.flatten(2))
+        return torch.cat(outs, 2).permute(0, 2, 1).float().contiguous()      # (B, A, 5+C)
+
+
+class YOLOX(nn.Module):
+    def __init__(self, size="s", num_classes=1):
+        super().__init__()
+        dep, wid = SIZES[size]
+        self.backbone = CSPDarknet(dep, wid)
+        self.neck = PAFPN(dep, wid)
+        self.head = Head(num_classes, wid)
+        self.size, self.num_classes = size, num_classes
+
+    def forward(self, x, focused=False):
+        return self.head(self.neck(self.backbone(x, focused)))
+
+
+def yolox(size="s", num_classes=1, device="cuda", dtype=torch.float16, channels_last=True, seed=0):
+    """Random-init (no checkpoints offline) YOLOX-`size`, eval mode, on `device` in `dtype`."""
+    g = torch.Generator().manual_seed(seed)
+    m = YOLOX(size, num_classes)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() > 1:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) * (1.0 / fan_in) ** 0.5)
+            else:
+                p.zero_()
+    m = m.eval().to(device=device, dtype=dtype)
+    if channels_last:
+        m = m.to(memory_format=torch.channels_last)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    return m

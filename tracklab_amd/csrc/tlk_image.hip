@@ -1,0 +1,420 @@
+// tlk_image.hip -- detector / ReID pre- and post-processing on gfx950:
+//   * batched letterbox (rtmlib YOLOX.preprocess semantics, cv2 INTER_LINEAR fixed-point bilinear)
+//   * ROI crop -> resize -> normalize for ReID patches (KPReId.preprocess semantics)
+//   * YOLOX grid decode + per-class greedy NMS with wavefront ballot bitmasks
+// HBM-bound byte movers: each thread produces 8 consecutive output pixels so every store is a
+// 16-byte-per-lane coalesced global_store_dwordx4; source rows are re-used through L1/L2.
+#include <hip/hip_fp16.h>
+
+#include "tlk_common.hpp"
+
+using namespace tlk;
+
+namespace {
+
+// ---- cv2.resize(INTER_LINEAR, uint8) coefficients, OpenCV imgproc/resize.cpp (INTER_RESIZE_COEF_BITS = 11)
+struct Coef { int s; int w0, w1; };
+__device__ __forceinline__ Coef cv_coef(int d, int ssize, int dsize, bool is_col)
+{
+    const double scale = (double)ssize / (double)dsize;
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (is_col) {
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    }
+    Coef c;
+    c.s = s;
+    c.w0 = (int)(short)__float2int_rn((1.f - f) * 2048.f);
+    c.w1 = (int)(short)__float2int_rn(f * 2048.f);
+    return c;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// one bilinear sample of 3 interleaved channels; region = (rh x rw) pixels at `base`, row stride in bytes
+__device__ __forceinline__ void sample3(const unsigned char *__restrict__ base, int stride, int rh, int rw, Coef cy, Coef cx,
+                                        int (&v)[3])
+{
+    const unsigned char *r0 = base + (size_t)clampi(cy.s, 0, rh - 1) * stride;
+    const unsigned char *r1 = base + (size_t)clampi(cy.s + 1, 0, rh - 1) * stride;
+    const int x0 = cx.s * 3, x1 = (cx.s + 1 < rw ? cx.s + 1 : rw - 1) * 3;
+    const bool need_x1 = cx.w1 != 0, need_r1 = cy.w1 != 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int S0 = (int)r0[x0 + c] * cx.w0;
+        if (need_x1) S0 += (int)r0[x1 + c] * cx.w1;
+        int S1 = 0;
+        if (need_r1) { S1 = (int)r1[x0 + c] * cx.w0; if (need_x1) S1 += (int)r1[x1 + c] * cx.w1; }
+        const int r = (((cy.w0 * (S0 >> 4)) >> 16) + ((cy.w1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        v[c] = clampi(r, 0, 255);
+    }
+}
+
+template <typename T> __device__ __forceinline__ T cvt(float v);
+template <> __device__ __forceinline__ float cvt<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half cvt<__half>(float v) { return __float2half_rn(v); }
+struct bf16_t { unsigned short x; };
+template <> __device__ __forceinline__ bf16_t cvt<bf16_t>(float v)
+{
+    unsigned int u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);          // round to nearest even (inputs here are finite)
+    bf16_t r; r.x = (unsigned short)(u >> 16); return r;
+}
+
+template <typename T, int N> struct alignas(sizeof(T) * N) Pack { T v[N]; };
+
+enum { LAYOUT_NCHW = 0, LAYOUT_NHWC = 1, LAYOUT_FOCUS_NHWC = 2 };
+
+// ---------------------------------------------------------------------------------------------
+// Letterbox: frames (B, H, W, 3) u8 -> (B, 3, S, S) [NCHW] | (B, S, S, 3) [NHWC] | (B, S/2, S/2, 12) [FOCUS]
+// rtmlib YOLOX.preprocess: ratio = min(S/H, S/W); resized (int(H*ratio), int(W*ratio)) pasted top-left on 114.
+// Thread = 8 consecutive x of one output row (FOCUS: of two rows).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int LAYOUT>
+__global__ void __launch_bounds__(BLOCK) letterbox_kernel(const unsigned char *__restrict__ frames, int B, int H, int W, int S,
+                                                          int rh, int rw, T *__restrict__ out)
+{
+    constexpr int ROWS = (LAYOUT == LAYOUT_FOCUS_NHWC) ? 2 : 1;
+    const int groups_per_row = S / 8;
+    const int rows_units = S / ROWS;
+    const long long gid = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const long long per_frame = (long long)groups_per_row * rows_units;
+    if (gid >= per_frame * B) return;
+    const int b = (int)(gid / per_frame);
+    const int rem = (int)(gid - (long long)b * per_frame);
+    const int yu = rem / groups_per_row, xg = rem - yu * groups_per_row;
+    const int x_base = xg * 8;
+    const unsigned char *img = frames + (size_t)b * H * W * 3;
+    T px[ROWS][8][3];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int y = yu * ROWS + r;
+        const bool yin = y < rh;
+        Coef cy = yin ? cv_coef(y, H, rh, false) : Coef{0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int x = x_base + i;
+            int v[3] = {114, 114, 114};
+            if (yin && x < rw) sample3(img, W * 3, H, W, cy, cv_coef(x, W, rw, true), v);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) px[r][i][c] = cvt<T>((float)v[c]);
+        }
+    }
+    if (LAYOUT == LAYOUT_NCHW) {
+        const int y = yu;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            Pack<T, 8> p;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p.v[i] = px[0][i][c];
+            *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)b * 3 + c) * S + y) * S + x_base) = p;
+        }
+    } else if (LAYOUT == LAYOUT_NHWC) {
+        const int y = yu;
+        T *o = out + (((size_t)b * S + y) * S + x_base) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            Pack<T, 8> p;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[0][idx / 3][idx % 3]; }
+            *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+        }
+    } else {   // FOCUS: channel = c + 3*((x&1)*2 + (y&1)); YOLOX Focus order (tl, bl, tr, br)
+        const int S2 = S / 2;
+        T *o = out + (((size_t)b * S2 + yu) * S2 + x_base / 2) * 12;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            Pack<T, 8> p;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int idx = k * 8 + e;            // 0..47 = 4 focus pixels x 12 channels
+                const int fp = idx / 12, ch = idx % 12;
+                const int grp = ch / 3, c = ch % 3;
+                const int xo = grp >> 1, yo = grp & 1;
+                p.v[e] = px[yo][fp * 2 + xo][c];
+            }
+            *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ROI crop -> resize(OHxOW, cv2 INTER_LINEAR) -> (x - 255*mean) * (1/(255*std)).
+// boxes: (B, max_n, 4) float32 ltwh as emitted by the detector; clip+round per coordinates.py:216-267.
+// out: (B*max_n, 3, OH, OW) NCHW or (B*max_n, OH, OW, 3) NHWC; slots >= counts[b] are zero-filled.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void crop_ltrb(const float *ltwh, int W, int H, int &l, int &t, int &r, int &b)
+{
+    double b0 = ltwh[0], b1 = ltwh[1], b2 = ltwh[2], b3 = ltwh[3];
+    b0 = fmax(0.0, fmin(b0, (double)(W - 2)));
+    b1 = fmax(0.0, fmin(b1, (double)(H - 2)));
+    b2 = fmax(1.0, fmin(b2, (double)(W - 1) - b0));
+    b3 = fmax(1.0, fmin(b3, (double)(H - 1) - b1));
+    l = (int)rint(b0); t = (int)rint(b1); r = (int)rint(b0 + b2); b = (int)rint(b1 + b3);
+}
+
+template <typename T, int LAYOUT>
+__global__ void __launch_bounds__(BLOCK) crop_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
+                                                     const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
+                                                     int OH, int OW, float m0, float m1, float m2, float d0, float d1, float d2,
+                                                     T *__restrict__ out)
+{
+    const int groups_per_row = OW / 8;
+    const int per_crop = groups_per_row * OH;
+    const long long gid = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (gid >= (long long)per_crop * B * max_n) return;
+    const int slot = (int)(gid / per_crop);
+    const int rem = (int)(gid - (long long)slot * per_crop);
+    const int y = rem / groups_per_row, x_base = (rem - y * groups_per_row) * 8;
+    const int b = slot / max_n, i = slot - b * max_n;
+    const float mean[3] = {m0, m1, m2}, den[3] = {d0, d1, d2};
+    T px[8][3];
+    bool valid = i < counts[b];
+    int l = 0, t = 0, r = 0, bt = 0;
+    if (valid) { crop_ltrb(boxes + ((size_t)b * max_n + i) * 4, W, H, l, t, r, bt); valid = (r > l) && (bt > t); }
+    if (valid) {
+        const int cw = r - l, ch = bt - t;
+        const unsigned char *base = frames + ((size_t)b * H * W + (size_t)t * W + l) * 3;
+        const Coef cy = cv_coef(y, ch, OH, false);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int v[3];
+            sample3(base, W * 3, ch, cw, cy, cv_coef(x_base + k, cw, OW, true), v);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { float f = (float)v[c]; f -= mean[c]; f *= den[c]; px[k][c] = cvt<T>(f); }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) px[k][c] = cvt<T>(0.f);
+    }
+    if (LAYOUT == LAYOUT_NCHW) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            Pack<T, 8> p;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p.v[k] = px[k][c];
+            *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)slot * 3 + c) * OH + y) * OW + x_base) = p;
+        }
+    } else {
+        T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            Pack<T, 8> p;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
+            *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// YOLOX decode + per-class greedy NMS (rtmlib YOLOX.postprocess / multiclass_nms / nms), one workgroup
+// per frame. Candidates (score = obj*cls > score_thr) are compacted, sorted by (score desc, anchor desc)
+// with a bitonic network in LDS, then ONE wavefront runs the greedy scan: for every surviving box it
+// tests 64 later candidates per step and clears their bits in an LDS alive-mask with the __ballot result.
+// fp32 arithmetic in the reference's operation order ("+1" pixel convention, ovr <= thr keeps).
+// ---------------------------------------------------------------------------------------------
+constexpr int NMS_CAP = 4096;      // max candidates per (frame, class)
+
+__global__ void __launch_bounds__(BLOCK) yolox_decode_nms_kernel(const float *__restrict__ pred_all, int S, int C, float ratio,
+                                                                 float nms_thr, float score_thr, int img_w, int img_h,
+                                                                 int max_out, float *__restrict__ ltwh_out,
+                                                                 float *__restrict__ xyxy_out, float *__restrict__ score_out,
+                                                                 int *__restrict__ cls_out, int *__restrict__ count_out,
+                                                                 double *__restrict__ trk_in, long long id_base, double category_id)
+{
+    __shared__ unsigned long long key[NMS_CAP];
+    __shared__ float bx[NMS_CAP][4];
+    __shared__ float barea[NMS_CAP];
+    __shared__ unsigned long long alive[NMS_CAP / 64];
+    __shared__ int s_scan[NWAVES];
+    __shared__ int s_n, s_out, s_err;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int n8 = (S / 8) * (S / 8), n16 = (S / 16) * (S / 16), n32 = (S / 32) * (S / 32);
+    const int A = n8 + n16 + n32, F = 5 + C;
+    const float *pred = pred_all + (size_t)b * A * F;
+    if (tid == 0) { s_out = 0; s_err = 0; }
+    __syncthreads();
+    for (int c = 0; c < C; ++c) {
+        // 1. candidates, ascending anchor order
+        const int n = block_compact(A, [&](int a) { return pred[(size_t)a * F + 4] * pred[(size_t)a * F + 5 + c] > score_thr; },
+                                    [&](int a, int pos) {
+                                        if (pos < NMS_CAP) {
+                                            const float s = pred[(size_t)a * F + 4] * pred[(size_t)a * F + 5 + c];
+                                            key[pos] = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned int)a;
+                                        }
+                                    }, s_scan);
+        if (n > NMS_CAP) { if (tid == 0) s_err = 1; }
+        const int m = n < NMS_CAP ? n : NMS_CAP;
+        int p2 = 1;
+        while (p2 < m) p2 <<= 1;
+        for (int k = m + tid; k < p2; k += BLOCK) key[k] = 0ull;      // pad: sorts last (scores > 0)
+        __syncthreads();
+        // 2. bitonic sort, descending by (score bits, anchor)
+        for (int k = 2; k <= p2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < p2; i += BLOCK) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const unsigned long long a = key[i], bb = key[ixj];
+                        const bool desc = (i & k) == 0;
+                        if (desc ? (a < bb) : (a > bb)) { key[i] = bb; key[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        // 3. decode the candidates (rtmlib: (xy+grid)*stride, exp(wh)*stride, /ratio)
+        for (int k = tid; k < m; k += BLOCK) {
+            const int a = (int)(key[k] & 0xffffffffull);
+            int st, loc, ws;
+            if (a < n8) { st = 8; loc = a; ws = S / 8; }
+            else if (a < n8 + n16) { st = 16; loc = a - n8; ws = S / 16; }
+            else { st = 32; loc = a - n8 - n16; ws = S / 32; }
+            const int gy = loc / ws, gx = loc - gy * ws;
+            const float *p = pred + (size_t)a * F;
+            const float fs = (float)st;
+            const float cx = (p[0] + (float)gx) * fs, cy = (p[1] + (float)gy) * fs;
+            const float w = expf(p[2]) * fs, h = expf(p[3]) * fs;
+            float x1 = cx - w / 2.f, y1 = cy - h / 2.f, x2 = cx + w / 2.f, y2 = cy + h / 2.f;
+            x1 /= ratio; y1 /= ratio; x2 /= ratio; y2 /= ratio;
+            bx[k][0] = x1; bx[k][1] = y1; bx[k][2] = x2; bx[k][3] = y2;
+            barea[k] = (x2 - x1 + 1) * (y2 - y1 + 1);
+        }
+        for (int k = tid; k < NMS_CAP / 64; k += BLOCK) {
+            const int lo = k * 64;
+            alive[k] = (lo + 64 <= m) ? ~0ull : (lo >= m ? 0ull : ((1ull << (m - lo)) - 1ull));
+        }
+        __syncthreads();
+        // 4. greedy scan by wavefront 0
+        if (tid < WAVE) {
+            int n_out = s_out;
+            for (int i = 0; i < m; ++i) {
+                const unsigned long long aw = alive[i >> 6];
+                if (!((aw >> (i & 63)) & 1ull)) continue;                 // uniform
+                const float sc = __uint_as_float((unsigned int)(key[i] >> 32));
+                if (sc > 0.3f) {                                            // rtmlib final_scores > 0.3
+                    if (n_out < max_out && lane == 0) {
+                        const size_t o = (size_t)b * max_out + n_out;
+                        float l = bx[i][0], t = bx[i][1], r = bx[i][2], bt = bx[i][3];
+                        xyxy_out[o * 4] = l; xyxy_out[o * 4 + 1] = t; xyxy_out[o * 4 + 2] = r; xyxy_out[o * 4 + 3] = bt;
+                        // RTMLibDetector: ltrb_to_ltwh(bbox, (W,H)) -> sanitize_bbox_ltrb (coordinates.py:270-295,318-328), float32
+                        l = fmaxf(0.f, fminf(l, (float)(img_w - 2))); t = fmaxf(0.f, fminf(t, (float)(img_h - 2)));
+                        r = fmaxf(1.f, fminf(r, (float)(img_w - 1))); bt = fmaxf(1.f, fminf(bt, (float)(img_h - 1)));
+                        ltwh_out[o * 4] = l; ltwh_out[o * 4 + 1] = t; ltwh_out[o * 4 + 2] = r - l; ltwh_out[o * 4 + 3] = bt - t;
+                        score_out[o] = sc; cls_out[o] = c;
+                        if (trk_in) {   // row the tracker wrapper would build (oc_sort_api.py:37-45): float32 ltwh -> ltrb,
+                                        // bbox_conf = 1.0 and category_id as set by RTMLibDetector (rtmlib_api.py:36-41)
+                            double *q = trk_in + o * 7;
+                            const float w = r - l, h = bt - t;
+                            q[0] = (double)l; q[1] = (double)t; q[2] = (double)(l + w); q[3] = (double)(t + h);
+                            q[4] = 1.0; q[5] = category_id; q[6] = (double)(id_base + (long long)b * max_out + n_out);
+                        }
+                    }
+                    ++n_out;
+                }
+                const float ix1 = bx[i][0], iy1 = bx[i][1], ix2 = bx[i][2], iy2 = bx[i][3], ia = barea[i];
+                for (int w0 = (i + 1) & ~63; w0 < m; w0 += 64) {
+                    const int j = w0 + lane;
+                    bool kill = false;
+                    if (j > i && j < m) {
+                        const float xx1 = fmaxf(ix1, bx[j][0]), yy1 = fmaxf(iy1, bx[j][1]);
+                        const float xx2 = fminf(ix2, bx[j][2]), yy2 = fminf(iy2, bx[j][3]);
+                        const float w = fmaxf(0.0f, xx2 - xx1 + 1), h = fmaxf(0.0f, yy2 - yy1 + 1);
+                        const float inter = w * h;
+                        const float ovr = inter / (ia + barea[j] - inter);
+                        kill = !(ovr <= nms_thr);
+                    }
+                    const unsigned long long km = __ballot(kill);
+                    if (lane == 0 && km) alive[w0 >> 6] &= ~km;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (lane == 0) s_out = n_out;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) count_out[b] = s_err ? TLK_ECAPACITY : (s_out > max_out ? TLK_ECAPACITY : s_out);
+}
+
+template <typename T>
+int launch_letterbox(const unsigned char *frames, int B, int H, int W, int S, int rh, int rw, int layout, void *out, hipStream_t st)
+{
+    const long long units = (long long)B * (S / 8) * (layout == LAYOUT_FOCUS_NHWC ? S / 2 : S);
+    const dim3 grid((unsigned)((units + BLOCK - 1) / BLOCK));
+    if (layout == LAYOUT_NCHW) hipLaunchKernelGGL((letterbox_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), 0, st, frames, B, H, W, S, rh, rw, (T *)out);
+    else if (layout == LAYOUT_NHWC) hipLaunchKernelGGL((letterbox_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, S, rh, rw, (T *)out);
+    else hipLaunchKernelGGL((letterbox_kernel<T, LAYOUT_FOCUS_NHWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, S, rh, rw, (T *)out);
+    return TLK_OK;
+}
+
+template <typename T>
+int launch_crop(const unsigned char *frames, int B, int H, int W, const float *boxes, const int *counts, int max_n, int OH, int OW,
+                const float *mean, const float *stdv, int layout, void *out, hipStream_t st)
+{
+    const long long units = (long long)B * max_n * OH * (OW / 8);
+    const dim3 grid((unsigned)((units + BLOCK - 1) / BLOCK));
+    const float m0 = mean[0] * 255.f, m1 = mean[1] * 255.f, m2 = mean[2] * 255.f;
+    const float d0 = 1.0f / (stdv[0] * 255.f), d1 = 1.0f / (stdv[1] * 255.f), d2 = 1.0f / (stdv[2] * 255.f);
+    if (layout == LAYOUT_NCHW)
+        hipLaunchKernelGGL((crop_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out);
+    else
+        hipLaunchKernelGGL((crop_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out);
+    return TLK_OK;
+}
+
+}  // namespace
+
+extern "C" int tlk_letterbox_u8(const uint8_t *frames_dev, int batch, int h, int w, int size, int layout, int dtype,
+                                void *out_dev, double *ratio_out, void *hip_stream)
+{
+    if (batch < 0 || h <= 0 || w <= 0 || size <= 0) return fail(TLK_EINVAL, "tlk_letterbox_u8: bad size");
+    if (size % 16 != 0) return fail(TLK_EINVAL, "tlk_letterbox_u8: size must be a multiple of 16");
+    if (layout < 0 || layout > 2 || dtype < 0 || dtype > 2) return fail(TLK_EINVAL, "tlk_letterbox_u8: bad layout/dtype");
+    const double ratio = std::min((double)size / h, (double)size / w);      // rtmlib YOLOX.preprocess
+    if (ratio_out) *ratio_out = ratio;
+    if (batch == 0) return TLK_OK;
+    if (!frames_dev || !out_dev) return fail(TLK_EINVAL, "tlk_letterbox_u8: null pointer");
+    const int rw = (int)(w * ratio), rh = (int)(h * ratio);
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (dtype == 0) launch_letterbox<float>(frames_dev, batch, h, w, size, rh, rw, layout, out_dev, st);
+    else if (dtype == 1) launch_letterbox<__half>(frames_dev, batch, h, w, size, rh, rw, layout, out_dev, st);
+    else launch_letterbox<bf16_t>(frames_dev, batch, h, w, size, rh, rw, layout, out_dev, st);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
+
+extern "C" int tlk_roi_crop_resize_norm(const uint8_t *frames_dev, int batch, int h, int w, const float *boxes_ltwh_dev,
+                                        const int32_t *counts_dev, int max_n, int out_h, int out_w, const float *mean3,
+                                        const float *std3, int layout, int dtype, void *out_dev, void *hip_stream)
+{
+    if (batch < 0 || h <= 0 || w <= 0 || max_n < 0 || out_h <= 0 || out_w <= 0) return fail(TLK_EINVAL, "tlk_roi_crop_resize_norm: bad size");
+    if (out_w % 8 != 0) return fail(TLK_EINVAL, "tlk_roi_crop_resize_norm: out_w must be a multiple of 8");
+    if (layout < 0 || layout > 1 || dtype < 0 || dtype > 2) return fail(TLK_EINVAL, "tlk_roi_crop_resize_norm: bad layout/dtype");
+    if (batch == 0 || max_n == 0) return TLK_OK;
+    if (!frames_dev || !boxes_ltwh_dev || !counts_dev || !mean3 || !std3 || !out_dev) return fail(TLK_EINVAL, "tlk_roi_crop_resize_norm: null pointer");
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (dtype == 0) launch_crop<float>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st);
+    else if (dtype == 1) launch_crop<__half>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st);
+    else launch_crop<bf16_t>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
+
+extern "C" int tlk_yolox_decode_nms(const float *pred_dev, int batch, int size, int num_classes, float ratio, float nms_thr,
+                                    float score_thr, int img_w, int img_h, int max_out, float *ltwh_dev, float *xyxy_dev,
+                                    float *scores_dev, int32_t *cls_dev, int32_t *counts_dev, double *trk_in_dev,
+                                    int64_t det_id_base, double category_id, void *hip_stream)
+{
+    if (batch < 0 || size <= 0 || size % 32 != 0 || num_classes < 1 || max_out < 0) return fail(TLK_EINVAL, "tlk_yolox_decode_nms: bad size");
+    if (batch == 0) return TLK_OK;
+    if (!pred_dev || !ltwh_dev || !xyxy_dev || !scores_dev || !cls_dev || !counts_dev) return fail(TLK_EINVAL, "tlk_yolox_decode_nms: null pointer");
+    hipLaunchKernelGGL(yolox_decode_nms_kernel, dim3(batch), dim3(BLOCK), 0, (hipStream_t)hip_stream, pred_dev, size, num_classes,
+                       ratio, nms_thr, score_thr, img_w, img_h, max_out, ltwh_dev, xyxy_dev, scores_dev, (int *)cls_dev, (int *)counts_dev,
+                       trk_in_dev, (long long)det_id_base, category_id);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
