@@ -76,38 +76,7 @@ def test_crop_resize_norm_matches_oracle(orc, oh, ow, layout):
         np.testing.assert_array_equal(outbf[b * MAXN:b * MAXN + n].float().cpu().numpy(), ebf)
 
 
-def synth_head(rng, boxes_xyxy, size=640, ratio=1.0 / 3, num_classes=1, dup=3):
-    """Raw YOLOX head tensor (A, 5+C) whose decode gives `boxes_xyxy` (+ jittered duplicates on neighbouring
-    anchors so that NMS has work to do) on top of low-score clutter."""
-    strides = [8, 16, 32]
-    n = [(size // s) ** 2 for s in strides]
-    A = sum(n)
-    pred = np.zeros((A, 5 + num_classes), dtype=np.float32)
-    pred[:, :4] = rng.normal(0, 0.5, (A, 4))
-    pred[:, 4] = rng.uniform(0, 0.6, A)
-    pred[:, 5:] = rng.uniform(0, 0.9, (A, num_classes))
-    used = set()
-    for k, (x1, y1, x2, y2) in enumerate(boxes_xyxy):
-        cx, cy = (x1 + x2) / 2 * ratio, (y1 + y2) / 2 * ratio
-        w, h = (x2 - x1) * ratio, (y2 - y1) * ratio
-        lvl = 0 if max(w, h) < 64 else (1 if max(w, h) < 128 else 2)
-        s = strides[lvl]
-        ws = size // s
-        for d in range(dup):
-            gx = int(np.clip(cx // s + (d % 2) * (1 if d else 0), 0, ws - 1))
-            gy = int(np.clip(cy // s + (d // 2), 0, ws - 1))
-            a = sum(n[:lvl]) + gy * ws + gx
-            if a in used:
-                continue
-            used.add(a)
-            jit = rng.normal(0, 0.6, 4) if d else np.zeros(4)
-            pred[a, 0] = (cx + jit[0]) / s - gx
-            pred[a, 1] = (cy + jit[1]) / s - gy
-            pred[a, 2] = np.log(max(w + jit[2], 1.0) / s)
-            pred[a, 3] = np.log(max(h + jit[3], 1.0) / s)
-            pred[a, 4] = rng.uniform(0.9, 1.0) if d == 0 else rng.uniform(0.85, 0.95)
-            pred[a, 5 + (k % num_classes)] = rng.uniform(0.9, 1.0)
-    return pred
+from tracklab_amd.synth import synth_yolox_head as synth_head  # noqa: E402
 
 
 @pytest.mark.parametrize("num_classes,nobj", [(1, 100), (1, 5), (3, 60), (1, 0)])

@@ -448,7 +448,7 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
         const int n_in = counts[(size_t)s * n_frames + f];
         __syncthreads();
         if (hdr[H_ERR] != 0) { if (tid == 0) *out_count = hdr[H_ERR]; continue; }
-        if (n_in > MAXD) { if (tid == 0) { hdr[H_ERR] = TLK_ECAPACITY; *out_count = TLK_ECAPACITY; } continue; }
+        if (n_in > MAXD || n_in < 0) { if (tid == 0) { hdr[H_ERR] = TLK_ECAPACITY; *out_count = TLK_ECAPACITY; } continue; }
         if (P.wrapper_mode && n_in == 0) { if (tid == 0) *out_count = 0; continue; }   // oc_sort_api.py:51-52
 
         // ---- split detections (ocsort.py:226-231), after the wrapper's conf filter (oc_sort_api.py:54)

@@ -1,0 +1,102 @@
+"""GPU-resident per-frame loops: detector -> (ReID ->) association with no host round trip.
+
+This is the data plane the north star describes: frames sit in HBM, every stage runs on ONE HIP
+stream (torch's current stream), libtlk kernels do everything except the backbone forwards, and the
+only device->host traffic is the small per-step result block (async, pinned).
+
+``DetTrackPipeline``  = BASELINE.json configs[1]: YOLOX -> OC-SORT (no ReID).
+A *step* processes ``frames_per_step`` consecutive frames of each of ``n_streams`` streams:
+  letterbox (1 launch) -> YOLOX forward (torch/MIOpen) -> decode+NMS (1 launch, emits tracker rows)
+  -> OC-SORT (1 launch: one workgroup per stream walks its frames in order).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .backbones.yolox import yolox
+
+
+class DetTrackPipeline:
+    def __init__(self, detector: str = "s", n_streams: int = 1, frames_per_step: int = 16, max_dets: int = 128,
+                 height: int = 1080, width: int = 1920, size: int = 640, dtype=torch.float16,
+                 layout: str = "focus_nhwc", device: int = 0, tracker_cfg: dict | None = None,
+                 num_classes: int = 1, nms_thr: float = 0.45, score_thr: float = 0.7, max_tracks: int = 256):
+        self.S, self.F, self.maxd = n_streams, frames_per_step, max_dets
+        self.H, self.W, self.size, self.dtype, self.layout = height, width, size, dtype, layout
+        self.nms_thr, self.score_thr = nms_thr, score_thr
+        self.dev = torch.device("cuda", device)
+        torch.cuda.set_device(self.dev)
+        cfg = tracker_cfg or dict(
+            # tracklab/configs/modules/track/oc_sort.yaml:3-14
+            min_confidence=0.4, hyper=dict(asso_func="giou", delta_t=1, det_thresh=0, inertia=0.3941737016672115,
+                                           iou_threshold=0.22136877277096445, max_age=50, min_hits=1, use_byte=False))
+        self.tracker_cfg = cfg
+        self.model = yolox(detector, num_classes, device=self.dev, dtype=dtype, channels_last=(layout != "nchw"))
+        self.bank = _lib.OCSortBank(**cfg["hyper"], min_confidence=cfg["min_confidence"], wrapper_mode=True,
+                                    n_streams=n_streams, device=device, max_tracks=max_tracks, max_dets=max_dets)
+        B = n_streams * frames_per_step
+        self.B = B
+        A = sum((size // s) ** 2 for s in (8, 16, 32))
+        self.A = A
+        dev = self.dev
+        if layout == "nchw":
+            self.lb = torch.empty((B, 3, size, size), dtype=dtype, device=dev)
+        elif layout == "nhwc":
+            self.lb = torch.empty((B, size, size, 3), dtype=dtype, device=dev)
+        else:
+            self.lb = torch.empty((B, size // 2, size // 2, 12), dtype=dtype, device=dev)
+        self.det = {"ltwh": torch.zeros((B, max_dets, 4), dtype=torch.float32, device=dev),
+                    "xyxy": torch.zeros((B, max_dets, 4), dtype=torch.float32, device=dev),
+                    "scores": torch.zeros((B, max_dets), dtype=torch.float32, device=dev),
+                    "cls": torch.zeros((B, max_dets), dtype=torch.int32, device=dev),
+                    "counts": torch.zeros((B,), dtype=torch.int32, device=dev)}
+        self.trk_in = torch.zeros((n_streams, frames_per_step, max_dets, 7), dtype=torch.float64, device=dev)
+        self.out_cap = max_dets
+        self.trk_out = torch.zeros((n_streams, frames_per_step, self.out_cap, 8), dtype=torch.float64, device=dev)
+        self.trk_cnt = torch.zeros((n_streams, frames_per_step), dtype=torch.int32, device=dev)
+        self.h_out = torch.zeros((n_streams, frames_per_step, self.out_cap, 8), dtype=torch.float64).pin_memory()
+        self.h_cnt = torch.zeros((n_streams, frames_per_step), dtype=torch.int32).pin_memory()
+        self.ratio = min(size / height, size / width)
+        self.frames_done = 0
+        self.kernel_events = []         # (start, end) torch events around the letterbox launch
+        self.record_kernel_events = False
+
+    def reset(self):
+        self.bank.reset(-1)
+        self.frames_done = 0
+
+    @torch.no_grad()
+    def step(self, frames: torch.Tensor, synth_head: torch.Tensor | None = None, fetch: bool = True):
+        """frames: (S*F, H, W, 3) uint8 on device, ordered stream-major (s*F + f).
+        synth_head: optional (S*F, A, 5+C) float32 replacing the (random-init) detector's head activations
+        while keeping the full forward in the dependency chain. Returns (rows, counts) pinned host tensors
+        (valid after the caller synchronises the stream) or device tensors if fetch=False."""
+        S, F = self.S, self.F
+        if self.record_kernel_events:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        x, ratio = _lib.letterbox(frames, self.size, self.layout, self.dtype, out=self.lb)
+        if self.record_kernel_events:
+            e1.record()
+            self.kernel_events.append((e0, e1))
+        pred = self.model(x, focused=(self.layout == "focus_nhwc"))
+        if synth_head is not None:
+            pred = torch.add(synth_head, torch.nan_to_num(pred), alpha=0.0)
+        _lib.yolox_decode_nms(pred, self.size, float(np.float32(ratio)), self.W, self.H, self.maxd, self.nms_thr,
+                              self.score_thr, out=self.det, trk_in=self.trk_in,
+                              det_id_base=self.frames_done * self.maxd, category_id=1.0)
+        self.bank.update_dev(self.trk_in.data_ptr(), self.det["counts"].data_ptr(), F, self.trk_out.data_ptr(),
+                             self.out_cap, self.trk_cnt.data_ptr(), _lib.current_stream_ptr())
+        self.frames_done += S * F
+        if not fetch:
+            return self.trk_out, self.trk_cnt
+        self.h_out.copy_(self.trk_out, non_blocking=True)
+        self.h_cnt.copy_(self.trk_cnt, non_blocking=True)
+        return self.h_out, self.h_cnt
+
+    def close(self):
+        self.bank.close()

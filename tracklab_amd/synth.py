@@ -157,3 +157,40 @@ def render_frame(rng: np.random.Generator, gt_boxes: np.ndarray,
         if r > l and b > t:
             img[t:b, l:r] = ((37 * i) % 200 + 55, (91 * i) % 200 + 55, (53 * i) % 200 + 55)
     return img
+
+
+def synth_yolox_head(rng: np.random.Generator, boxes_xyxy: np.ndarray, size: int = 640, ratio: float = 1.0 / 3,
+                     num_classes: int = 1, dup: int = 3) -> np.ndarray:
+    """Raw YOLOX head tensor (A, 5+C) float32 whose rtmlib-style decode yields `boxes_xyxy` (image scale),
+    plus lower-scored jittered duplicates on neighbouring anchors (NMS work) over sub-threshold clutter.
+    Stands in for the activations of a trained detector: offline there are no checkpoints, and a
+    random-init network detects nothing."""
+    strides = [8, 16, 32]
+    n = [(size // s) ** 2 for s in strides]
+    A = sum(n)
+    pred = np.zeros((A, 5 + num_classes), dtype=np.float32)
+    pred[:, :4] = rng.normal(0, 0.5, (A, 4))
+    pred[:, 4] = rng.uniform(0, 0.6, A)
+    pred[:, 5:] = rng.uniform(0, 0.9, (A, num_classes))
+    used = set()
+    for k, (x1, y1, x2, y2) in enumerate(boxes_xyxy):
+        cx, cy = (x1 + x2) / 2 * ratio, (y1 + y2) / 2 * ratio
+        w, h = (x2 - x1) * ratio, (y2 - y1) * ratio
+        lvl = 0 if max(w, h) < 64 else (1 if max(w, h) < 128 else 2)
+        s = strides[lvl]
+        ws = size // s
+        for d in range(dup):
+            gx = int(np.clip(cx // s + (d % 2) * (1 if d else 0), 0, ws - 1))
+            gy = int(np.clip(cy // s + (d // 2), 0, ws - 1))
+            a = sum(n[:lvl]) + gy * ws + gx
+            if a in used:
+                continue
+            used.add(a)
+            jit = rng.normal(0, 0.6, 4) if d else np.zeros(4)
+            pred[a, 0] = (cx + jit[0]) / s - gx
+            pred[a, 1] = (cy + jit[1]) / s - gy
+            pred[a, 2] = np.log(max(w + jit[2], 1.0) / s)
+            pred[a, 3] = np.log(max(h + jit[3], 1.0) / s)
+            pred[a, 4] = rng.uniform(0.9, 1.0) if d == 0 else rng.uniform(0.85, 0.95)
+            pred[a, 5 + (k % num_classes)] = rng.uniform(0.9, 1.0)
+    return pred
