@@ -134,7 +134,7 @@ def main():
         got = []
         for k in range(ksteps):
             rows, cnt = run_step(k)
-            torch.cuda.synchronize()
+            pipe.synchronize()
             for f in range(F):
                 got.append(rows[0, f, :int(cnt[0, f])].numpy().copy())
         exp = oracle_chain(oracle, heads_np[0][:ksteps * F], ratio, pipe.tracker_cfg, pipe.maxd)
@@ -147,6 +147,7 @@ def main():
     # ---- warmup ----
     for k in range(args.warmup):
         run_step(k)
+    pipe.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -156,6 +157,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.warmup, total_steps):
         run_step(k)
+    pipe.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

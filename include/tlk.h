@@ -95,6 +95,9 @@ int tlk_ocsort_update_dev(tlk_ocsort *h, const double *dets_dev, const int32_t *
 /* Debug / parity: copy the KF state of stream's live tracks in list order. x (cap,7), P (cap,7,7),
  * ids (cap) int64; returns count via n_tracks. Synchronous. */
 int tlk_ocsort_get_tracks(tlk_ocsort *h, int stream, double *x, double *P, int64_t *ids, int cap, int *n_tracks);
+/* Diagnostics: per-phase 100 MHz wall-clock ticks accumulated since create (only when the bank was created
+ * with TLK_OCSORT_PROF set in the environment). cycles16: 16 int64. */
+int tlk_ocsort_get_profile(tlk_ocsort *h, int stream, long long *cycles16);
 
 /* ------------------------------------------------------------------------------------------
  * Detector / ReID pre- and post-processing. In the reference this arithmetic sits in third-party

@@ -116,7 +116,11 @@ class OCSortBank:
             lib().tlk_ocsort_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def reset(self, stream: int = -1):
         check(lib().tlk_ocsort_reset(self._h, stream))

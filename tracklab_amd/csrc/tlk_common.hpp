@@ -131,7 +131,7 @@ struct LsaWork {
 // row to rows_out/cols_out and returns their number (min(nr0,nc0)), or -1 if infeasible.
 // Scan semantics restated: remaining[] is filled in reverse; among minimum shortest-path costs an
 // unassigned column wins (the one scanned last), otherwise the first scanned column.
-__device__ __forceinline__ int wave_lsa(const double *cost, int nr0, int nc0, size_t rs0, size_t cs0,
+__device__ __noinline__ int wave_lsa_lds(const double *cost, int nr0, int nc0, size_t rs0, size_t cs0,
                                         const LsaWork &W, int *rows_out, int *cols_out)
 {
     const int lane = threadIdx.x & 63;
@@ -224,6 +224,171 @@ __device__ __forceinline__ int wave_lsa(const double *cost, int nr0, int nc0, si
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     return base;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Register-resident variant (max(nr,nc) <= 512): lane l owns columns j = c*64 + l and keeps their dual v,
+// shortest-path cost, path, row4col and position-in-`remaining` in VGPRs, so one scan step is ONE coalesced
+// LDS read of a cost row segment + a DPP min-reduction + a few ballots/readlanes -- no per-step LDS
+// bookkeeping. `remaining[]` of scipy is represented by its inverse permutation pos[j] (scan order only
+// matters for tie-breaks): initially pos[j] = nc-1-j; removing column j* at position p moves the column at
+// the last position to p. Row duals u[] and col4row[] live in LDS (W.u, W.col4row).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int dpp_ror_i32(int v, int n)
+{
+    switch (n) {
+        case 1: return __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false);
+        case 2: return __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false);
+        case 4: return __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false);
+        default: return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);
+    }
+}
+__device__ __forceinline__ double dpp_ror_f64(double v, int n)
+{
+    return __hiloint2double(dpp_ror_i32(__double2hiint(v), n), dpp_ror_i32(__double2loint(v), n));
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_min_f64(double v)      // all lanes get the minimum (no NaNs expected)
+{
+#pragma unroll
+    for (int n = 1; n <= 8; n <<= 1) { const double o = dpp_ror_f64(v, n); v = o < v ? o : v; }
+    const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
+    const double ab = b < a ? b : a, cd = d < c ? d : c;
+    return cd < ab ? cd : ab;
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int n = 1; n <= 8; n <<= 1) { const int o = dpp_ror_i32(v, n); v = o > v ? o : v; }
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const int ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+
+template <int CPL>
+__device__ __noinline__ int wave_lsa_reg(const double *cost, int nr0, int nc0, size_t rs0, size_t cs0,
+                                         const LsaWork &W, int *rows_out, int *cols_out)
+{
+    const int lane = threadIdx.x & 63;
+    const bool transpose = nc0 < nr0;
+    const int nr = transpose ? nc0 : nr0, nc = transpose ? nr0 : nc0;
+    const size_t rs = transpose ? cs0 : rs0, cs = transpose ? rs0 : cs0;
+    double v_[CPL], spc_[CPL];
+    int r4c_[CPL], path_[CPL], pos_[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { v_[c] = 0.0; r4c_[c] = -1; path_[c] = -1; }
+    for (int k = lane; k < nr; k += WAVE) { W.u[k] = 0.0; W.col4row[k] = -1; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int cur = 0; cur < nr; ++cur) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) { const int j = c * WAVE + lane; pos_[c] = j < nc ? nc - 1 - j : -2; spc_[c] = INFINITY; }
+        double minval = 0.0;
+        int num_remaining = nc, i = cur, sink = -1;
+        while (sink == -1) {
+            const double ui = W.u[i];
+            double best = INFINITY;
+            int best_s = -1, best_c = 0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                if (pos_[c] >= 0) {
+                    const int j = c * WAVE + lane;
+                    const double r = minval + cost[(size_t)i * rs + (size_t)j * cs] - ui - v_[c];
+                    if (r < spc_[c]) { path_[c] = i; spc_[c] = r; }
+                    const double sp = spc_[c];
+                    const int s = (r4c_[c] == -1) ? (nc + pos_[c]) : (nc - 1 - pos_[c]);
+                    if (sp < best || (sp == best && s > best_s)) { best = sp; best_s = s; best_c = c; }
+                }
+            }
+            minval = wave_min_f64(best);
+            if (!(minval < INFINITY)) return -1;                    // infeasible
+            unsigned long long m_eq = __ballot(best == minval && best_s >= 0);
+            if (__popcll(m_eq) != 1) {                              // ties: unassigned column scanned last wins, else first scanned
+                const int ms = wave_max_i32((best == minval) ? best_s : -1);
+                m_eq = __ballot(best == minval && best_s == ms);
+            }
+            const int wl = __ffsll((long long)m_eq) - 1;
+            const int wc = __builtin_amdgcn_readlane(best_c, wl);
+            int pos_sel = 0, r4c_sel = 0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) if (c == wc) { pos_sel = pos_[c]; r4c_sel = r4c_[c]; }
+            const int wpos = __builtin_amdgcn_readlane(pos_sel, wl);
+            const int wr4c = __builtin_amdgcn_readlane(r4c_sel, wl);
+            const int jstar = wc * WAVE + wl;
+            const int last = num_remaining - 1;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const bool is_star = (lane == wl) && (c == wc);
+                if (is_star) pos_[c] = -1;                          // SC[j*] = true
+                else if (pos_[c] == last) pos_[c] = wpos;           // remaining[index] = remaining[--num_remaining]
+            }
+            num_remaining = last;
+            if (wr4c == -1) sink = jstar; else i = wr4c;
+        }
+        // dual update: SR \ {cur} == { row4col[j] : j in SC, assigned }
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            if (pos_[c] == -1) {
+                const double d = minval - spc_[c];
+                if (r4c_[c] != -1) W.u[r4c_[c]] += d;
+                v_[c] -= d;
+            }
+        }
+        if (lane == 0) W.u[cur] += minval;
+        // augment along path[] (uniform walk; owner lanes update their registers)
+        int j = sink;
+        for (;;) {
+            const int c = j >> 6, l = j & 63;
+            int path_sel = 0;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) if (q == c) path_sel = path_[q];
+            const int pi = __builtin_amdgcn_readlane(path_sel, l);
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) if (q == c && lane == l) r4c_[q] = pi;
+            const int old = W.col4row[pi];
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) W.col4row[pi] = j;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            j = old;
+            if (pi == cur) break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!transpose) {
+        for (int k = lane; k < nr; k += WAVE) { rows_out[k] = k; cols_out[k] = W.col4row[k]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        return nr;
+    }
+    int base = 0;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {            // original row r == transposed column r, ascending
+        const int r = c * WAVE + lane;
+        const bool f = (r < nc) && (r4c_[c] != -1);
+        const unsigned long long m = __ballot(f);
+        if (f) { const int p = base + __popcll(m & ((1ull << lane) - 1ull)); rows_out[p] = r; cols_out[p] = r4c_[c]; }
+        base += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    return base;
+}
+
+__device__ __forceinline__ int wave_lsa(const double *cost, int nr0, int nc0, size_t rs0, size_t cs0,
+                                        const LsaWork &W, int *rows_out, int *cols_out)
+{
+    if (nr0 == 0 || nc0 == 0) return 0;
+    const int mx = nr0 > nc0 ? nr0 : nc0;
+    if (mx <= 64) return wave_lsa_reg<1>(cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);
+    if (mx <= 128) return wave_lsa_reg<2>(cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);
+    if (mx <= 256) return wave_lsa_reg<4>(cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);
+    if (mx <= 512) return wave_lsa_reg<8>(cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);
+    return wave_lsa_lds(cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);
 }
 
 #endif  // __HIPCC__

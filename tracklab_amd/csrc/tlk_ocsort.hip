@@ -45,6 +45,7 @@ struct OcsDev {
     int *freestk;    // S x MAXT   free slots (stack)
     double *lastb;   // S x MAXT x 5   last_boxes snapshot by position (ocsort.py:248)
     double *cost_g;  // S x MAXD x MAXT   cost-matrix spill when it does not fit LDS
+    long long *prof; // optional S x 16 cycle accumulators (diagnostics)
     int S, MAXT, MAXD, cost_lds_entries;
 };
 
@@ -441,7 +442,10 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
         T.stride_d = stride_d; T.stride_i = stride_i; return T;
     };
 
+    long long t_prev = 0;
+#define PROF(i) do { if (D.prof && tid == 0) { const long long t_ = wall_clock64(); D.prof[(size_t)s * 16 + (i)] += t_ - t_prev; t_prev = t_; } } while (0)
     for (int f = 0; f < n_frames; ++f) {
+        if (D.prof && tid == 0) t_prev = wall_clock64();
         const double *dets = dets_all + (size_t)s * det_stream_stride + (size_t)f * det_frame_stride;
         double *out = out_all + ((size_t)s * n_frames + f) * (size_t)out_cap * 8;
         int *out_count = out_counts + (size_t)s * n_frames + f;
@@ -464,6 +468,7 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
         __syncthreads();
         if (tid == 0) hdr[H_FRAME] = hdr[H_FRAME] + 1;
 
+        PROF(0);
         // ---- predict (ocsort.py:234-244 -> :150-163)
         for (int p = tid; p < T; p += BLOCK) {
             const Trk K = trk_at(order[p]);
@@ -484,6 +489,7 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
             for (int k = 0; k < 4; ++k) L.kobs[(size_t)p * 5 + k] = b[k];       // staging (compacted below)
         }
         __syncthreads();
+        PROF(1);
         {   // drop NaN trackers (stable), free their slots
             for (int p = tid; p < T; p += BLOCK) L.tmp_b[p] = order[p];
             __syncthreads();
@@ -504,6 +510,7 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
         }
         __syncthreads();
 
+        PROF(2);
         // ---- velocities / last_boxes / k_observations (ocsort.py:246-250, :10-18)
         for (int p = tid; p < T; p += BLOCK) {
             const Trk K = trk_at(order[p]);
@@ -533,27 +540,32 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
         for (int k = tid; k < T; k += BLOCK) L.colcnt[k] = 0;
         __syncthreads();
 
+        PROF(3);
         // ---- first association (association.py:242-298)
         double *cost = ((size_t)N * T <= (size_t)D.cost_lds_entries) ? L.cost : (D.cost_g + (size_t)s * MAXD * MAXT);
         int n_mi = 0;
         if (T > 0 && N > 0) {
             const double PI = 3.141592653589793;
+#pragma unroll 4
             for (int e = tid; e < N * T; e += BLOCK) {
                 const int d = e / T, t = e - d * T;
                 const double *de = dets + (size_t)L.hi_idx[d] * 7;
                 const double *ko = L.kobs + (size_t)t * 5;
                 const double iou = box_similarity(TLK_IOU, de, L.trk_box + (size_t)t * 4);
-                const double cx1 = (de[0] + de[2]) / 2.0, cy1 = (de[1] + de[3]) / 2.0;
-                const double cx2 = (ko[0] + ko[2]) / 2.0, cy2 = (ko[1] + ko[3]) / 2.0;
-                double dx = cx1 - cx2, dy = cy1 - cy2;
-                const double norm = sqrt(dx * dx + dy * dy) + 1e-6;
-                dx = dx / norm; dy = dy / norm;
-                double c = L.velp[t * 2 + 1] * dx + L.velp[t * 2] * dy;
-                c = c < -1 ? -1 : (c > 1 ? 1 : c);
-                double ang = acos(c);
-                ang = (PI / 2.0 - fabs(ang)) / PI;
                 const double valid = ko[4] < 0 ? 0.0 : 1.0;
-                const double adc = ((valid * ang) * P.inertia) * de[5];     // "scores" = class column (dets[:, :-1][:, -1])
+                double adc = 0.0;       // ((valid*ang)*w)*cls is an exact (signed) zero when any factor is zero
+                if (valid != 0.0 && P.inertia != 0.0 && de[5] != 0.0) {
+                    const double cx1 = (de[0] + de[2]) / 2.0, cy1 = (de[1] + de[3]) / 2.0;
+                    const double cx2 = (ko[0] + ko[2]) / 2.0, cy2 = (ko[1] + ko[3]) / 2.0;
+                    double dx = cx1 - cx2, dy = cy1 - cy2;
+                    const double norm = sqrt(dx * dx + dy * dy) + 1e-6;
+                    dx = dx / norm; dy = dy / norm;
+                    double c = L.velp[t * 2 + 1] * dx + L.velp[t * 2] * dy;
+                    c = c < -1 ? -1 : (c > 1 ? 1 : c);
+                    double ang = acos(c);
+                    ang = (PI / 2.0 - fabs(ang)) / PI;
+                    adc = ((valid * ang) * P.inertia) * de[5];              // "scores" = class column (dets[:, :-1][:, -1])
+                }
                 cost[e] = -(iou + adc);
                 if (iou > P.iou_threshold) { atomicAdd(&L.rowcnt[d], 1); atomicAdd(&L.colcnt[t], 1); L.rowhit[d] = t; }
             }
@@ -569,6 +581,7 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
             atomicMax(&L.sc[SC_NL], mxc);
             __syncthreads();
             const bool one2one = (L.sc[SC_FLAG] == 1) && (L.sc[SC_NL] == 1);
+            PROF(4);
             __syncthreads();
             if (one2one) {
                 n_mi = block_compact(N, [&](int d) { return L.rowcnt[d] == 1; },
@@ -583,6 +596,7 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
             }
         }
         __syncthreads();
+        PROF(5);
         // unmatched lists + low-IoU rejection (association.py:276-296)
         int nud = 0, nut = 0, nm = 0;
         if (T == 0) {
@@ -607,10 +621,12 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
             nud += nrej; nut += nrej;
         }
         __syncthreads();
+        PROF(6);
         for (int k = tid; k < nm; k += BLOCK)                                  // ocsort.py:257-258
             kbt_update(trk_at(order[L.m_t[k]]), dets + (size_t)L.hi_idx[L.m_d[k]] * 7, P.delta_t);
         __syncthreads();
 
+        PROF(7);
         // ---- second-round rounds share one routine: rows = candidate dets, cols = unmatched tracks
         auto second_round = [&](bool byte_round) {
             const int nrow = byte_round ? N2 : nud;
@@ -664,6 +680,7 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
         if (nud > 0 && nut > 0) second_round(false);                               // ocsort.py:284-306
         __syncthreads();
 
+        PROF(8);
         for (int k = tid; k < nut; k += BLOCK) kf_update_none(trk_at(order[L.um_t[k]]));   // ocsort.py:308-309
         // ---- births (ocsort.py:312-314)
         int nfree = hdr[H_NFREE], nextid = hdr[H_NEXTID];
@@ -679,6 +696,7 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
         }
         __syncthreads();
         nfree -= nud; nextid += nud; T += nud;
+        PROF(9);
         // ---- emit rows in reversed list order + drop dead tracklets (ocsort.py:315-331)
         const int frame_count = hdr[H_FRAME];
         for (int q = tid; q < T; q += BLOCK) {
@@ -712,6 +730,7 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
             nfree += T - kept;
         }
         __syncthreads();
+        PROF(10);
         if (tid == 0) {
             hdr[H_NTRK] = kept; hdr[H_NFREE] = nfree; hdr[H_NEXTID] = nextid;
             *out_count = rows > out_cap ? TLK_ECAPACITY : rows;
@@ -763,7 +782,7 @@ static int ocs_free(tlk_ocsort *h)
     if (!h) return TLK_OK;
     hipSetDevice(h->device);
     hipFree(h->D.fd); hipFree(h->D.fi); hipFree(h->D.hdr); hipFree(h->D.order); hipFree(h->D.freestk);
-    hipFree(h->D.lastb); hipFree(h->D.cost_g); hipFree(h->d_dets); hipFree(h->d_out); hipFree(h->d_cnt); hipFree(h->d_ocnt);
+    hipFree(h->D.lastb); hipFree(h->D.cost_g); if (h->D.prof) hipFree(h->D.prof); hipFree(h->d_dets); hipFree(h->d_out); hipFree(h->d_cnt); hipFree(h->d_ocnt);
     if (h->h_pin) hipHostFree(h->h_pin);
     if (h->h_cnt) hipHostFree(h->h_cnt);
     delete h;
@@ -805,6 +824,8 @@ extern "C" int tlk_ocsort_create(const tlk_ocsort_params *p, int n_streams, int 
     OCS_ALLOC(D.freestk, sizeof(int) * slots);
     OCS_ALLOC(D.lastb, sizeof(double) * 5 * slots);
     OCS_ALLOC(D.cost_g, sizeof(double) * (size_t)n_streams * MAXD * MAXT);
+    D.prof = nullptr;
+    if (getenv("TLK_OCSORT_PROF")) { OCS_ALLOC(D.prof, sizeof(long long) * 16 * n_streams); hipMemset(D.prof, 0, sizeof(long long) * 16 * n_streams); }
     h->out_cap = MAXT + MAXD;
     OCS_ALLOC(h->d_dets, sizeof(double) * 7 * MAXD);
     OCS_ALLOC(h->d_out, sizeof(double) * 8 * h->out_cap);
@@ -872,6 +893,7 @@ extern "C" int tlk_ocsort_update(tlk_ocsort *h, int stream, const double *dets, 
     V.fd += (size_t)stream * V.MAXT; V.fi += (size_t)stream * V.MAXT;
     V.hdr += (size_t)stream * H_COUNT; V.order += (size_t)stream * V.MAXT; V.freestk += (size_t)stream * V.MAXT;
     V.lastb += (size_t)stream * V.MAXT * 5; V.cost_g += (size_t)stream * V.MAXD * V.MAXT;
+    if (V.prof) V.prof += (size_t)stream * 16;
     hipLaunchKernelGGL(ocsort_frames_kernel, dim3(1), dim3(BLOCK), h->smem, st, V, h->P, (const double *)h->d_dets,
                        (const int *)h->d_cnt, 1, (size_t)0, (size_t)0, h->d_out, h->out_cap, h->d_ocnt);
     TLK_HIP(hipGetLastError());
@@ -912,5 +934,15 @@ extern "C" int tlk_ocsort_get_tracks(tlk_ocsort *h, int stream, double *x, doubl
     hipFree(dx); hipFree(dP); hipFree(di); hipFree(dn);
     if (e != hipSuccess) return fail(TLK_EHIP, std::string("tlk_ocsort_get_tracks: ") + hipGetErrorString(e));
     *n_tracks = n;
+    return TLK_OK;
+}
+
+extern "C" int tlk_ocsort_get_profile(tlk_ocsort *h, int stream, long long *cycles16)
+{
+    if (!h || !cycles16) return fail(TLK_EINVAL, "tlk_ocsort_get_profile: null pointer");
+    if (!h->D.prof) return fail(TLK_EINVAL, "tlk_ocsort_get_profile: create the bank with TLK_OCSORT_PROF=1 in the environment");
+    if (stream < 0 || stream >= h->D.S) return fail(TLK_EINVAL, "tlk_ocsort_get_profile: stream out of range");
+    TLK_HIP(hipSetDevice(h->device));
+    TLK_HIP(hipMemcpy(cycles16, h->D.prof + (size_t)stream * 16, sizeof(long long) * 16, hipMemcpyDeviceToHost));
     return TLK_OK;
 }

@@ -49,33 +49,51 @@ class DetTrackPipeline:
             self.lb = torch.empty((B, size, size, 3), dtype=dtype, device=dev)
         else:
             self.lb = torch.empty((B, size // 2, size // 2, 12), dtype=dtype, device=dev)
-        self.det = {"ltwh": torch.zeros((B, max_dets, 4), dtype=torch.float32, device=dev),
-                    "xyxy": torch.zeros((B, max_dets, 4), dtype=torch.float32, device=dev),
-                    "scores": torch.zeros((B, max_dets), dtype=torch.float32, device=dev),
-                    "cls": torch.zeros((B, max_dets), dtype=torch.int32, device=dev),
-                    "counts": torch.zeros((B,), dtype=torch.int32, device=dev)}
-        self.trk_in = torch.zeros((n_streams, frames_per_step, max_dets, 7), dtype=torch.float64, device=dev)
         self.out_cap = max_dets
-        self.trk_out = torch.zeros((n_streams, frames_per_step, self.out_cap, 8), dtype=torch.float64, device=dev)
-        self.trk_cnt = torch.zeros((n_streams, frames_per_step), dtype=torch.int32, device=dev)
-        self.h_out = torch.zeros((n_streams, frames_per_step, self.out_cap, 8), dtype=torch.float64).pin_memory()
-        self.h_cnt = torch.zeros((n_streams, frames_per_step), dtype=torch.int32).pin_memory()
+        self.nbuf = 2       # double-buffered hand-off between the detector stream and the tracker stream
+        self.bufs = []
+        for _ in range(self.nbuf):
+            self.bufs.append({
+                "det": {"ltwh": torch.zeros((B, max_dets, 4), dtype=torch.float32, device=dev),
+                        "xyxy": torch.zeros((B, max_dets, 4), dtype=torch.float32, device=dev),
+                        "scores": torch.zeros((B, max_dets), dtype=torch.float32, device=dev),
+                        "cls": torch.zeros((B, max_dets), dtype=torch.int32, device=dev),
+                        "counts": torch.zeros((B,), dtype=torch.int32, device=dev)},
+                "trk_in": torch.zeros((n_streams, frames_per_step, max_dets, 7), dtype=torch.float64, device=dev),
+                "trk_out": torch.zeros((n_streams, frames_per_step, self.out_cap, 8), dtype=torch.float64, device=dev),
+                "trk_cnt": torch.zeros((n_streams, frames_per_step), dtype=torch.int32, device=dev),
+                "h_out": torch.zeros((n_streams, frames_per_step, self.out_cap, 8), dtype=torch.float64).pin_memory(),
+                "h_cnt": torch.zeros((n_streams, frames_per_step), dtype=torch.int32).pin_memory(),
+                "det_ready": torch.cuda.Event(), "trk_done": torch.cuda.Event()})
+        self.trk_stream = torch.cuda.Stream(device=dev)   # association overlaps the next step's detector forward
+        self.step_idx = 0
         self.ratio = min(size / height, size / width)
         self.frames_done = 0
         self.kernel_events = []         # (start, end) torch events around the letterbox launch
         self.record_kernel_events = False
 
     def reset(self):
+        torch.cuda.synchronize(self.dev)
         self.bank.reset(-1)
         self.frames_done = 0
+
+    def synchronize(self):
+        self.trk_stream.synchronize()
+        torch.cuda.current_stream(self.dev).synchronize()
 
     @torch.no_grad()
     def step(self, frames: torch.Tensor, synth_head: torch.Tensor | None = None, fetch: bool = True):
         """frames: (S*F, H, W, 3) uint8 on device, ordered stream-major (s*F + f).
         synth_head: optional (S*F, A, 5+C) float32 replacing the (random-init) detector's head activations
         while keeping the full forward in the dependency chain. Returns (rows, counts) pinned host tensors
-        (valid after the caller synchronises the stream) or device tensors if fetch=False."""
+        (valid after ``synchronize()``) or device tensors if fetch=False.
+        Detector stages run on torch's current stream; the association kernel + result copies run on a side
+        stream, so the tracker of step k overlaps the detector forward of step k+1."""
         S, F = self.S, self.F
+        buf = self.bufs[self.step_idx % self.nbuf]
+        self.step_idx += 1
+        main = torch.cuda.current_stream(self.dev)
+        main.wait_event(buf["trk_done"])      # buffer reuse: tracker of step k-nbuf has consumed it
         if self.record_kernel_events:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -87,16 +105,22 @@ class DetTrackPipeline:
         if synth_head is not None:
             pred = torch.add(synth_head, torch.nan_to_num(pred), alpha=0.0)
         _lib.yolox_decode_nms(pred, self.size, float(np.float32(ratio)), self.W, self.H, self.maxd, self.nms_thr,
-                              self.score_thr, out=self.det, trk_in=self.trk_in,
+                              self.score_thr, out=buf["det"], trk_in=buf["trk_in"],
                               det_id_base=self.frames_done * self.maxd, category_id=1.0)
-        self.bank.update_dev(self.trk_in.data_ptr(), self.det["counts"].data_ptr(), F, self.trk_out.data_ptr(),
-                             self.out_cap, self.trk_cnt.data_ptr(), _lib.current_stream_ptr())
+        buf["det_ready"].record(main)
         self.frames_done += S * F
+        with torch.cuda.stream(self.trk_stream):
+            self.trk_stream.wait_event(buf["det_ready"])
+            self.bank.update_dev(buf["trk_in"].data_ptr(), buf["det"]["counts"].data_ptr(), F, buf["trk_out"].data_ptr(),
+                                 self.out_cap, buf["trk_cnt"].data_ptr(), C.c_void_p(self.trk_stream.cuda_stream))
+            if fetch:
+                buf["h_out"].copy_(buf["trk_out"], non_blocking=True)
+                buf["h_cnt"].copy_(buf["trk_cnt"], non_blocking=True)
+            buf["trk_done"].record(self.trk_stream)
+        self.last = buf
         if not fetch:
-            return self.trk_out, self.trk_cnt
-        self.h_out.copy_(self.trk_out, non_blocking=True)
-        self.h_cnt.copy_(self.trk_cnt, non_blocking=True)
-        return self.h_out, self.h_cnt
+            return buf["trk_out"], buf["trk_cnt"]
+        return buf["h_out"], buf["h_cnt"]
 
     def close(self):
         self.bank.close()
