@@ -24,7 +24,8 @@ class DetTrackPipeline:
     def __init__(self, detector: str = "s", n_streams: int = 1, frames_per_step: int = 16, max_dets: int = 128,
                  height: int = 1080, width: int = 1920, size: int = 640, dtype=torch.float16,
                  layout: str = "focus_nhwc", device: int = 0, tracker_cfg: dict | None = None,
-                 num_classes: int = 1, nms_thr: float = 0.45, score_thr: float = 0.7, max_tracks: int = 256):
+                 num_classes: int = 1, nms_thr: float = 0.45, score_thr: float = 0.7, max_tracks: int = 256,
+                 use_graph: bool = True):
         self.S, self.F, self.maxd = n_streams, frames_per_step, max_dets
         self.H, self.W, self.size, self.dtype, self.layout = height, width, size, dtype, layout
         self.nms_thr, self.score_thr = nms_thr, score_thr
@@ -66,6 +67,8 @@ class DetTrackPipeline:
                 "h_cnt": torch.zeros((n_streams, frames_per_step), dtype=torch.int32).pin_memory(),
                 "det_ready": torch.cuda.Event(), "trk_done": torch.cuda.Event()})
         self.trk_stream = torch.cuda.Stream(device=dev)   # association overlaps the next step's detector forward
+        self.use_graph = use_graph
+        self.graphs = {}        # frames.data_ptr() -> (hipGraph of letterbox + forward, static head output)
         self.step_idx = 0
         self.ratio = min(size / height, size / width)
         self.frames_done = 0
@@ -97,11 +100,15 @@ class DetTrackPipeline:
         if self.record_kernel_events:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        x, ratio = _lib.letterbox(frames, self.size, self.layout, self.dtype, out=self.lb)
-        if self.record_kernel_events:
-            e1.record()
-            self.kernel_events.append((e0, e1))
-        pred = self.model(x, focused=(self.layout == "focus_nhwc"))
+        ratio = self.ratio
+        if self.use_graph and not self.record_kernel_events:
+            pred = self._forward_graphed(frames)
+        else:
+            x, ratio = _lib.letterbox(frames, self.size, self.layout, self.dtype, out=self.lb)
+            if self.record_kernel_events:
+                e1.record()
+                self.kernel_events.append((e0, e1))
+            pred = self.model(x, focused=(self.layout == "focus_nhwc"))
         if synth_head is not None:
             pred = torch.add(synth_head, torch.nan_to_num(pred), alpha=0.0)
         _lib.yolox_decode_nms(pred, self.size, float(np.float32(ratio)), self.W, self.H, self.maxd, self.nms_thr,
@@ -122,5 +129,30 @@ class DetTrackPipeline:
             return buf["trk_out"], buf["trk_cnt"]
         return buf["h_out"], buf["h_cnt"]
 
+    def _forward_graphed(self, frames):
+        """letterbox + YOLOX forward replayed from a hipGraph (the forward is ~300 short launches and is
+        host-launch-bound in eager mode). One graph per input buffer address."""
+        key = frames.data_ptr()
+        ent = self.graphs.get(key)
+        if ent is None:
+            focused = self.layout == "focus_nhwc"
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):          # eager warm-up on a side stream (MIOpen picks its kernels here)
+                for _ in range(2):
+                    x, _ = _lib.letterbox(frames, self.size, self.layout, self.dtype, out=self.lb)
+                    self.model(x, focused=focused)
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                x, _ = _lib.letterbox(frames, self.size, self.layout, self.dtype, out=self.lb)
+                out = self.model(x, focused=focused)
+            ent = (g, out)
+            self.graphs[key] = ent
+        ent[0].replay()
+        return ent[1]
+
     def close(self):
+        self.graphs.clear()
         self.bank.close()
