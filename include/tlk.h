@@ -100,6 +100,70 @@ int tlk_ocsort_get_tracks(tlk_ocsort *h, int stream, double *x, double *P, int64
 int tlk_ocsort_get_profile(tlk_ocsort *h, int stream, long long *cycles16);
 
 /* ------------------------------------------------------------------------------------------
+ * Part-based ReID distance (the one embedding x embedding contraction of the path; f32 MFMA).
+ * Replaces NearestNeighborDistanceMetric.distance -> _nn_part_based
+ * (plugins/track/bpbreid_strong_sort/sort/nn_matching.py:191-200, :99-135) including the third-party
+ * torchreid compute_distance_matrix_using_bp_features it calls (:127-134):
+ * L2-normalise every part embedding, per part d = sqrt(relu(|q|^2 - 2 q.g + |g|^2)), mean over the parts
+ * visible in both (-1 if none), / 2.  q_dev (T,K,D) f32, qvis_dev (T,K) u8, g_dev (N,K,D) f32,
+ * gvis_dev (N,K) u8 -> out_dev (T,N) f64. K <= 8, D % 16 == 0.
+ * ------------------------------------------------------------------------------------------ */
+int tlk_partdist_f32(const float *q_dev, const uint8_t *qvis_dev, int T, const float *g_dev, const uint8_t *gvis_dev,
+                     int N, int K, int D, double *out_dev, void *hip_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BPBReID-StrongSORT tracker bank (n_streams independent trackers, state in HBM).
+ * Replaces plugins/track/bpbreid_strong_sort/strong_sort.py:11-147 (StrongSORT.update),
+ * sort/tracker.py:92-441 (predict, update, strong_sort_matching / bot_sort_matching, _initiate_track),
+ * sort/track.py:68-187, sort/kalman_filter.py:53-227, sort/linear_assignment.py:11-175,
+ * sort/iou_matching.py:7-78, sort/nn_matching.py:173-200 and the wrapper's empty-frame rule
+ * (tracklab/wrappers/track/bpbreid_strong_sort_api.py:103-104).
+ * Not covered: motion_criterium "oks", ECC camera compensation (ecc: False in the yaml), the per-detection
+ * debug `costs` dictionaries (tracker.py:365-407).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tlk_bpbss tlk_bpbss;
+typedef struct {
+    double ema_alpha, mc_lambda, max_dist, max_iou_distance, min_bbox_confidence, gating_thres_factor;
+    double w_kfgd, w_reid, w_st;
+    int32_t max_age, n_init, only_position_for_kf_gating, max_kalman_prediction_without_update;
+    int32_t matching_strategy;   /* 0 strong_sort_matching, 1 bot_sort_matching */
+    int32_t wrapper_mode;        /* 1: skip the tracker entirely on a frame with 0 detections */
+    int32_t parts, dim;          /* K, D of the embeddings */
+    int32_t max_tracks;          /* <= 512 */
+    int32_t max_dets;            /* <= 256 */
+} tlk_bpbss_params;
+
+typedef struct {                 /* one output row = one confirmed track updated in this frame (strong_sort.py:93-141) */
+    int64_t det_id, track_id;
+    double kf_ltwh[4];           /* track_bbox_kf_ltwh      */
+    double pred_ltwh[4];         /* track_bbox_pred_kf_ltwh (NaN when None) */
+    int32_t pred_valid;
+    int32_t matched_name;        /* matched_with: 0 None, 1 "R" (ReID stage), 2 "S" (spatio-temporal stage) */
+    double matched_dist;
+    int32_t hits, age, time_since_update;
+    int32_t state;               /* 0 't', 1 'c', 2 'd' (TrackState, track.py:16-18) */
+} tlk_bpbss_row;
+
+int tlk_bpbss_create(const tlk_bpbss_params *p, int n_streams, int device, tlk_bpbss **out);
+int tlk_bpbss_destroy(tlk_bpbss *h);
+int tlk_bpbss_reset(tlk_bpbss *h, int stream);
+/* one frame of one stream, host buffers, synchronous: ids (n) int64, ltwh (n,4) f64, emb (n,K,D) f32,
+ * vis (n,K) u8, conf (n) f64 -> rows (<= cap) */
+int tlk_bpbss_update(tlk_bpbss *h, int stream, const int64_t *ids, const double *ltwh, const float *emb,
+                     const uint8_t *vis, const double *conf, int n, tlk_bpbss_row *rows, int cap, int *n_out);
+/* n_frames consecutive frames of every stream, device buffers, asynchronous (3 launches per frame):
+ * ids_dev (S,F,max_dets) int64; ltwh_dev (S,F,max_dets,4) f64; emb_dev (S,F,max_dets,K,D) f32;
+ * vis_dev (S,F,max_dets,K) u8; conf_dev (S,F,max_dets) f64; counts_dev (S,F) int32;
+ * rows_dev (S,F,out_cap) tlk_bpbss_row; out_counts_dev (S,F) int32 (<0 = error code). */
+int tlk_bpbss_update_dev(tlk_bpbss *h, const int64_t *ids_dev, const double *ltwh_dev, const float *emb_dev,
+                         const uint8_t *vis_dev, const double *conf_dev, const int32_t *counts_dev, int n_frames,
+                         tlk_bpbss_row *rows_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream);
+/* Debug / parity: live tracks of a stream in list order. ids (cap) int64, mean (cap,8), cov (cap,8,8),
+ * feat (cap,K,D) f32, fvis (cap,K) u8 (any may be NULL). Synchronous. */
+int tlk_bpbss_get_tracks(tlk_bpbss *h, int stream, int64_t *ids, double *mean, double *cov, float *feat,
+                         uint8_t *fvis, int cap, int *n_tracks);
+
+/* ------------------------------------------------------------------------------------------
  * Detector / ReID pre- and post-processing. In the reference this arithmetic sits in third-party
  * packages behind the adapters tracklab/wrappers/bbox_detector/rtmlib_api.py:27-46 (rtmlib
  * YOLOX.preprocess / postprocess, cv2.resize) and tracklab/wrappers/reid/kpreid_api.py:115-144

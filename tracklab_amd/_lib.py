@@ -241,3 +241,116 @@ def yolox_decode_nms(pred, size, ratio, img_w, img_h, max_out=128, nms_thr=0.45,
                                  trk_in.data_ptr() if trk_in is not None else None, det_id_base, category_id,
                                  current_stream_ptr()))
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# BPBReID-StrongSORT bank + part-based distance
+# ------------------------------------------------------------------------------------------------
+class BpbssParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("ema_alpha", "mc_lambda", "max_dist", "max_iou_distance", "min_bbox_confidence",
+                                          "gating_thres_factor", "w_kfgd", "w_reid", "w_st")] + \
+               [(n, C.c_int32) for n in ("max_age", "n_init", "only_position_for_kf_gating",
+                                         "max_kalman_prediction_without_update", "matching_strategy", "wrapper_mode",
+                                         "parts", "dim", "max_tracks", "max_dets")]
+
+
+BPBSS_ROW = np.dtype([("det_id", "<i8"), ("track_id", "<i8"), ("kf_ltwh", "<f8", (4,)), ("pred_ltwh", "<f8", (4,)),
+                      ("pred_valid", "<i4"), ("matched_name", "<i4"), ("matched_dist", "<f8"), ("hits", "<i4"),
+                      ("age", "<i4"), ("tsu", "<i4"), ("state", "<i4")], align=True)
+MATCHING = {"strong_sort_matching": 0, "bot_sort_matching": 1}
+
+
+def _bind_bpbss(L):
+    if getattr(L, "_bpbss_bound", False):
+        return
+    L.tlk_bpbss_create.argtypes = [C.POINTER(BpbssParams), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.tlk_bpbss_destroy.argtypes = [C.c_void_p]
+    L.tlk_bpbss_reset.argtypes = [C.c_void_p, C.c_int]
+    L.tlk_bpbss_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.tlk_bpbss_update_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.tlk_bpbss_get_tracks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.POINTER(C.c_int)]
+    L.tlk_partdist_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p]
+    L._bpbss_bound = True
+
+
+class BpbssBank:
+    """``n_streams`` device-resident BPBReID-StrongSORT trackers (``tlk_bpbss_*``); hyper-parameter names follow
+    ``StrongSORT.__init__`` (bpbreid_strong_sort/strong_sort.py:12-31)."""
+
+    def __init__(self, parts, dim, ema_alpha=0.9, mc_lambda=0.995, max_dist=0.2, motion_criterium="iou",
+                 max_iou_distance=0.7, max_oks_distance=0.7, max_age=30, n_init=3, nn_budget=100,
+                 min_bbox_confidence=0.2, only_position_for_kf_gating=False, max_kalman_prediction_without_update=7,
+                 matching_strategy="strong_sort_matching", gating_thres_factor=1.5, w_kfgd=1, w_reid=1, w_st=1, *,
+                 wrapper_mode=False, n_streams=1, device=0, max_tracks=256, max_dets=128):
+        if motion_criterium != "iou":
+            raise NotImplementedError("libtlk implements motion_criterium='iou' (oks is listed as next in DESIGN.md)")
+        L = lib()
+        _bind_bpbss(L)
+        self.params = BpbssParams(ema_alpha, mc_lambda, max_dist, max_iou_distance, min_bbox_confidence,
+                                  gating_thres_factor, w_kfgd, w_reid, w_st, max_age, n_init,
+                                  int(only_position_for_kf_gating), max_kalman_prediction_without_update,
+                                  MATCHING[matching_strategy], int(wrapper_mode), parts, dim, max_tracks, max_dets)
+        self.K, self.D, self.n_streams, self.max_tracks, self.max_dets = parts, dim, n_streams, max_tracks, max_dets
+        h = C.c_void_p()
+        check(L.tlk_bpbss_create(C.byref(self.params), n_streams, device, C.byref(h)))
+        self._h = h
+        self._rows = np.zeros(max_dets, dtype=BPBSS_ROW)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tlk_bpbss_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, stream=-1):
+        check(lib().tlk_bpbss_reset(self._h, stream))
+
+    def update(self, ids, ltwh, emb, vis, conf, stream=0):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        ltwh = _f64(ltwh).reshape(-1, 4)
+        emb = np.ascontiguousarray(emb, dtype=np.float32)
+        vis = np.ascontiguousarray(vis, dtype=np.uint8)
+        conf = _f64(conf)
+        n = C.c_int(0)
+        check(lib().tlk_bpbss_update(self._h, stream, ids.ctypes.data, ltwh.ctypes.data, emb.ctypes.data, vis.ctypes.data,
+                                     conf.ctypes.data, len(ids), self._rows.ctypes.data, len(self._rows), C.byref(n)))
+        return self._rows[:n.value].copy()
+
+    def update_dev(self, ids, ltwh, emb, vis, conf, counts, n_frames, rows, out_cap, out_counts, stream_ptr=None):
+        check(lib().tlk_bpbss_update_dev(self._h, ids, ltwh, emb, vis, conf, counts, n_frames, rows, out_cap, out_counts,
+                                         stream_ptr))
+
+    def tracks(self, stream=0):
+        cap = self.max_tracks
+        ids = np.empty(cap, dtype=np.int64)
+        mean, cov = np.empty((cap, 8)), np.empty((cap, 8, 8))
+        feat = np.empty((cap, self.K, self.D), dtype=np.float32)
+        fvis = np.empty((cap, self.K), dtype=np.uint8)
+        n = C.c_int(0)
+        check(lib().tlk_bpbss_get_tracks(self._h, stream, ids.ctypes.data, mean.ctypes.data, cov.ctypes.data,
+                                         feat.ctypes.data, fvis.ctypes.data, cap, C.byref(n)))
+        k = n.value
+        return ids[:k], mean[:k], cov[:k], feat[:k], fvis[:k]
+
+
+def partdist(q, qvis, g, gvis):
+    """q (T,K,D) f32, qvis (T,K) u8, g (N,K,D) f32, gvis (N,K) u8 cuda tensors -> (T,N) f64 cuda tensor."""
+    import torch
+    L = lib()
+    _bind_bpbss(L)
+    T, K, D = q.shape
+    N = g.shape[0]
+    assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and g.is_contiguous()
+    assert qvis.dtype == torch.uint8 and gvis.dtype == torch.uint8
+    out = torch.empty((T, N), dtype=torch.float64, device=q.device)
+    check(L.tlk_partdist_f32(q.data_ptr(), qvis.data_ptr(), T, g.data_ptr(), gvis.data_ptr(), N, K, D, out.data_ptr(),
+                             current_stream_ptr()))
+    return out

@@ -1,0 +1,956 @@
+// tlk_bpbss.hip -- BPBReID-StrongSORT on gfx950: three launches per frame for ALL streams of a bank.
+//
+//   1. partnorm_kernel   one wavefront per (row, part) embedding: L2 norm + squared norm of the normalised vector
+//   2. partdist_kernel   f32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32 FMA chains): one workgroup per 16x16 tile of
+//                        the track x detection matrix, one wavefront per body part; masked mean over common parts
+//   3. bpbss_assoc_kernel one 256-thread workgroup per stream: KF predict, KF gating, two-stage (or BoT-SORT style)
+//                        assignment with the scipy-identical wavefront LSA, KF update, visibility-aware EMA of the
+//                        part embeddings, track lifecycle, output rows.
+// fp64 association math in the reference's operation order (-ffp-contract=off); fp32 embeddings like torch.
+// State: field-major SoA per slot; list order kept as an indirection (order[]), so deaths compact 4-byte indices.
+#include "tlk_common.hpp"
+
+using namespace tlk;
+
+namespace {
+
+constexpr double INFTY_COST = 1e+5;                    // sort/linear_assignment.py:8
+__device__ __constant__ double CHI2INV95[10] = {0, 3.8415, 5.9915, 7.8147, 9.4877, 11.070, 12.592, 14.067, 15.507, 16.919};
+constexpr double W_POS = 1. / 20, W_VEL = 1. / 160;   // sort/kalman_filter.py:50-51
+
+enum : int { BD_MEAN = 0, BD_COV = 8, BD_PRED = 72, BD_MDIST = 76, BD_COUNT = 77 };
+enum : int { BI_TID = 0, BI_HITS, BI_AGE, BI_TSU, BI_STATE, BI_MNAME, BI_PVALID, BI_COUNT };
+enum : int { H_NTRK = 0, H_NEXTID, H_NFREE, H_ERR, H_COUNT = 8 };
+enum : int { ST_TENTATIVE = 0, ST_CONFIRMED = 1, ST_DELETED = 2 };
+
+struct BpbDev {
+    double *fd;              // BD_COUNT x S x MAXT
+    int *fi;                 // BI_COUNT x S x MAXT
+    long long *detid;        // S x MAXT   last_detection.id per slot
+    int *hdr, *order, *freestk;
+    float *feat;             // S x MAXT x K x D   by slot
+    unsigned char *fvis;     // S x MAXT x K       by slot
+    float *tnorm;            // S x MAXT x K x 2   by list position: (norm, sum of squares of the normalised vector)
+    float *dnorm;            // S x MAXD x K x 2   by input detection index
+    double *reid;            // S x MAXT x MAXD    part-based distance, row = list position, col = input detection index
+    double *gl;              // S x MAXT x 20      per track: projected mean (4) + Cholesky factor (16) for gating
+    double *cost_g;          // S x MAXT x MAXD    cost-matrix spill
+    int S, MAXT, MAXD, K, D, cost_lds_entries;
+};
+
+struct BpbP {
+    double ema_alpha, mc_lambda, max_dist, max_iou_distance, min_conf, gating_thres_factor, w_kfgd, w_reid, w_st;
+    int max_age, n_init, only_position, max_pred, strategy, wrapper_mode;
+};
+
+struct FrameIn {            // per-(stream, frame) strides in elements
+    const long long *ids; const double *ltwh; const float *emb; const unsigned char *vis; const double *conf;
+    const int *counts; size_t stream_stride_dets; size_t count_stride;   // dets index = s*stream_stride_dets + i
+};
+
+// ------------------------------------------------------------------------------------------------ norms
+__global__ void __launch_bounds__(BLOCK) partnorm_kernel(BpbDev Dv, FrameIn in, int wrapper_mode)
+{
+    const int s = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int K = Dv.K, D = Dv.D;
+    const int T = Dv.hdr[(size_t)s * H_COUNT + H_NTRK];
+    const int N = in.counts[(size_t)s * in.count_stride];
+    if (N <= 0 || N > Dv.MAXD) return;
+    const int vec = blockIdx.x * NWAVES + w;             // [0, (T+N)*K)
+    if (vec >= (T + N) * K) return;
+    const bool is_trk = vec < T * K;
+    const int row = is_trk ? vec / K : (vec - T * K) / K, k = is_trk ? vec % K : (vec - T * K) % K;
+    const float *x = is_trk ? Dv.feat + (((size_t)s * Dv.MAXT + Dv.order[(size_t)s * Dv.MAXT + row]) * K + k) * D
+                            : in.emb + (((size_t)s * in.stream_stride_dets + row) * K + k) * D;
+    float ss = 0.f;
+    for (int d = lane; d < D; d += WAVE) { const float v = x[d]; ss += v * v; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    float nrm = sqrtf(ss);
+    if (nrm < 1e-12f) nrm = 1e-12f;                       // F.normalize(eps=1e-12)
+    float s2 = 0.f;
+    for (int d = lane; d < D; d += WAVE) { const float v = x[d] / nrm; s2 += v * v; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off);
+    if (lane == 0) {
+        float *o = is_trk ? Dv.tnorm + (((size_t)s * Dv.MAXT + row) * K + k) * 2 : Dv.dnorm + (((size_t)s * Dv.MAXD + row) * K + k) * 2;
+        o[0] = nrm; o[1] = s2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ MFMA distance
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// blockDim = 64*K. Tile (blockIdx.y = track tile, blockIdx.x = det tile) of stream blockIdx.z.
+__global__ void __launch_bounds__(512) partdist_kernel(BpbDev Dv, FrameIn in)
+{
+    __shared__ float s_dist[8][256];
+    __shared__ unsigned char s_valid[8][256];
+    const int s = blockIdx.z, k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int K = Dv.K, D = Dv.D;
+    const int T = Dv.hdr[(size_t)s * H_COUNT + H_NTRK];
+    const int N = in.counts[(size_t)s * in.count_stride];
+    if (N <= 0 || N > Dv.MAXD) return;
+    const int t0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    if (t0 >= T || n0 >= N) return;
+    const int i = lane & 15, g = lane >> 4;
+    const int tp = min(t0 + i, T - 1), dn = min(n0 + i, N - 1);
+    const int slot = Dv.order[(size_t)s * Dv.MAXT + tp];
+    const float *qrow = Dv.feat + (((size_t)s * Dv.MAXT + slot) * K + k) * D;
+    const float *grow = in.emb + (((size_t)s * in.stream_stride_dets + dn) * K + k) * D;
+    const float nq = Dv.tnorm[(((size_t)s * Dv.MAXT + tp) * K + k) * 2];
+    const float ng = Dv.dnorm[(((size_t)s * Dv.MAXD + dn) * K + k) * 2];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < D; c += 16) {
+        const float4 a = *reinterpret_cast<const float4 *>(qrow + c + 4 * g);
+        const float4 b = *reinterpret_cast<const float4 *>(grow + c + 4 * g);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x / nq, b.x / ng, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y / nq, b.y / ng, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z / nq, b.z / ng, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w / nq, b.w / ng, acc, 0, 0, 0);
+    }
+    // C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+    const int cn = min(n0 + i, N - 1);
+    const float gs = Dv.dnorm[(((size_t)s * Dv.MAXD + cn) * K + k) * 2 + 1];
+    const bool gv = in.vis[((size_t)s * in.stream_stride_dets + cn) * K + k] != 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = g * 4 + r;
+        const int rt = min(t0 + row, T - 1);
+        const float qs = Dv.tnorm[(((size_t)s * Dv.MAXT + rt) * K + k) * 2 + 1];
+        const bool qv = Dv.fvis[((size_t)s * Dv.MAXT + Dv.order[(size_t)s * Dv.MAXT + rt]) * K + k] != 0;
+        float d2 = qs - 2 * acc[r] + gs;
+        d2 = d2 < 0.f ? 0.f : d2;
+        const bool valid = qv && gv;
+        s_dist[k][row * 16 + i] = valid ? sqrtf(d2) : 0.f;
+        s_valid[k][row * 16 + i] = valid ? 1 : 0;
+    }
+    __syncthreads();
+    if (k == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = e * 64 + lane;
+            const int row = idx >> 4, col = idx & 15;
+            float sum = 0.f; int cnt = 0;
+            for (int p = 0; p < K; ++p) { sum += s_dist[p][idx]; cnt += s_valid[p][idx]; }
+            const float pair = cnt ? sum / (float)cnt : -1.0f;
+            if (t0 + row < T && n0 + col < N)
+                Dv.reid[((size_t)s * Dv.MAXT + t0 + row) * Dv.MAXD + n0 + col] = (double)(pair / 2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ KF8 in registers
+__device__ __forceinline__ void kf8_predict(double (&mean)[8], double (&cov)[64])     // kalman_filter.py:85-119
+{
+    const double sp = W_POS * mean[3], sv = W_VEL * mean[3];
+    // F (cov F^T): numpy's multi_dot picks A(BC) on the equal-cost tie
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cov[i * 8 + j] = cov[i * 8 + j] + cov[i * 8 + j + 4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cov[i * 8 + j] = cov[i * 8 + j] + cov[(i + 4) * 8 + j];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { cov[i * 9] += sp * sp; cov[(4 + i) * 9] += sv * sv; mean[i] = mean[i] + mean[i + 4]; }
+}
+
+__device__ __forceinline__ void chol4(const double (&a)[16], int n, double (&L)[16])   // lower Cholesky of the leading n x n (stride n)
+{
+#pragma unroll
+    for (int q = 0; q < 16; ++q) L[q] = 0.0;
+    for (int j = 0; j < n; ++j) {
+        double sacc = a[j * n + j];
+        for (int k = 0; k < j; ++k) sacc -= L[j * n + k] * L[j * n + k];
+        const double d = sqrt(sacc);
+        L[j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double v = a[i * n + j];
+            for (int k = 0; k < j; ++k) v -= L[i * n + k] * L[j * n + k];
+            L[i * n + j] = v / d;
+        }
+    }
+}
+
+__device__ __forceinline__ void chol4_full(const double (&a)[16], double (&L)[16])
+{
+#pragma unroll
+    for (int q = 0; q < 16; ++q) L[q] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double sacc = a[j * 4 + j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < j) sacc -= L[j * 4 + k] * L[j * 4 + k];
+        const double d = sqrt(sacc);
+        L[j * 4 + j] = d;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i > j) {
+            double v = a[i * 4 + j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k < j) v -= L[i * 4 + k] * L[j * 4 + k];
+            L[i * 4 + j] = v / d;
+        }
+    }
+}
+
+__device__ __forceinline__ void kf8_update(double (&mean)[8], double (&cov)[64], const double *z, double conf)   // :154-187
+{
+    double pm[4], S[16], L[16], X[32], Kg[32], B[32];
+    const double sstd = (1 - conf) * (W_POS * mean[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        pm[i] = mean[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) S[i * 4 + j] = cov[i * 8 + j] + (i == j ? sstd * sstd : 0.0);
+    }
+    chol4_full(S, L);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        double y[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double v = cov[c * 8 + i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k < i) v -= L[i * 4 + k] * y[k];
+            y[i] = v / L[i * 4 + i];
+        }
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            double v = y[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k > i) v -= L[k * 4 + i] * X[k * 8 + c];
+            X[i * 8 + c] = v / L[i * 4 + i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Kg[i * 4 + j] = X[j * 8 + i];
+    double inn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) inn[j] = z[j] - pm[j];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        double sacc = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sacc += inn[j] * Kg[i * 4 + j];
+        mean[i] = mean[i] + sacc;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            double sacc = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sacc += S[j * 4 + k] * Kg[c * 4 + k];
+            B[j * 8 + c] = sacc;
+        }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            double sacc = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sacc += Kg[i * 4 + j] * B[j * 8 + c];
+            cov[i * 8 + c] = cov[i * 8 + c] - sacc;
+        }
+}
+
+// squared Mahalanobis distance of measurement m (xyah) to the track whose (pm, L) were prepared (:189-227)
+__device__ __forceinline__ double gating_from(const double *glrow, const double *m, int d)
+{
+    double zz[4], acc = 0;
+    for (int i = 0; i < d; ++i) {
+        double v = m[i] - glrow[i];
+        for (int k = 0; k < i; ++k) v -= glrow[4 + i * d + k] * zz[k];
+        zz[i] = v / glrow[4 + i * d + i];
+    }
+    for (int i = 0; i < d; ++i) acc += zz[i] * zz[i];
+    return acc;
+}
+
+__device__ __forceinline__ double iou_ltwh(const double *b, const double *c)     // sort/iou_matching.py:7-39
+{
+    const double bbr0 = b[0] + b[2], bbr1 = b[1] + b[3], cbr0 = c[0] + c[2], cbr1 = c[1] + c[3];
+    const double tl0 = b[0] > c[0] ? b[0] : c[0], tl1 = b[1] > c[1] ? b[1] : c[1];
+    const double br0 = bbr0 < cbr0 ? bbr0 : cbr0, br1 = bbr1 < cbr1 ? bbr1 : cbr1;
+    double w = br0 - tl0, h = br1 - tl1;
+    w = w > 0. ? w : 0.; h = h > 0. ? h : 0.;
+    const double ai = w * h;
+    return ai / (b[2] * b[3] + c[2] * c[3] - ai);
+}
+
+struct BTrk {
+    double *fd; int *fi; size_t stride;
+    __device__ double &d(int f) const { return fd[(size_t)f * stride]; }
+    __device__ int &i(int f) const { return fi[(size_t)f * stride]; }
+};
+__device__ __forceinline__ void trk_ltwh(const BTrk &T, double *o)     // track.py:97-100
+{
+    const double x = T.d(BD_MEAN), y = T.d(BD_MEAN + 1), a = T.d(BD_MEAN + 2), h = T.d(BD_MEAN + 3);
+    const double w = a * h;
+    o[0] = x - w / 2; o[1] = y - h / 2; o[2] = w; o[3] = h;
+}
+
+// ------------------------------------------------------------------------------------------------ LDS carve
+struct BLds {
+    double *dxyah, *dltwh;        // MAXD*4 each (filtered detection order)
+    double *d_mdist;              // MAXD
+    LsaWork W;
+    int *sel;                     // MAXD filtered -> input index
+    int *cand, *bc;               // MAXT
+    int *um_ta, *um_tb, *um_t;    // MAXT, MAXT, 2*MAXT
+    int *um_da, *um_db;           // MAXD each
+    int *mi_r, *mi_c;             // MAXX
+    int *m_t, *m_d;               // 2*MAXX each (stage a then b)
+    int *rowf, *colf, *rej;       // MAXT, MAXD, MAXX
+    int *d_mname;                 // MAXD
+    int *tmp;                     // MAXT
+    int *scan, *sc;
+    double *cost;
+};
+
+__host__ __device__ inline size_t blds_fixed(int MAXT, int MAXD)
+{
+    const size_t MAXX = MAXT > MAXD ? MAXT : MAXD;
+    size_t b = sizeof(double) * ((size_t)MAXD * 9 + MAXX * 3);
+    b += sizeof(int) * (MAXX * 4) + MAXX * 2;
+    b = (b + 15) & ~(size_t)15;
+    b += sizeof(int) * ((size_t)MAXD * 5 + (size_t)MAXT * 8 + MAXX * 7 + NWAVES + 32);
+    return (b + 31) & ~(size_t)15;
+}
+
+__device__ inline void bcarve(unsigned char *smem, int MAXT, int MAXD, BLds &L)
+{
+    const int MAXX = MAXT > MAXD ? MAXT : MAXD;
+    double *d = (double *)smem;
+    L.dxyah = d; d += (size_t)MAXD * 4; L.dltwh = d; d += (size_t)MAXD * 4; L.d_mdist = d; d += MAXD;
+    L.W.u = d; d += MAXX; L.W.v = d; d += MAXX; L.W.spc = d; d += MAXX;
+    int *ip = (int *)d;
+    L.W.path = ip; ip += MAXX; L.W.row4col = ip; ip += MAXX; L.W.remaining = ip; ip += MAXX; L.W.col4row = ip; ip += MAXX;
+    unsigned char *bp = (unsigned char *)ip;
+    L.W.SR = bp; bp += MAXX; L.W.SC = bp; bp += MAXX;
+    bp = (unsigned char *)(((uintptr_t)bp + 15) & ~(uintptr_t)15);
+    ip = (int *)bp;
+    L.sel = ip; ip += MAXD; L.um_da = ip; ip += MAXD; L.um_db = ip; ip += MAXD; L.colf = ip; ip += MAXD; L.d_mname = ip; ip += MAXD;
+    L.cand = ip; ip += MAXT; L.bc = ip; ip += MAXT; L.um_ta = ip; ip += MAXT; L.um_tb = ip; ip += MAXT; L.um_t = ip; ip += 2 * MAXT;
+    L.rowf = ip; ip += MAXT; L.tmp = ip; ip += MAXT;
+    L.mi_r = ip; ip += MAXX; L.mi_c = ip; ip += MAXX; L.m_t = ip; ip += 2 * MAXX; L.m_d = ip; ip += 2 * MAXX; L.rej = ip; ip += MAXX;
+    L.scan = ip; ip += NWAVES; L.sc = ip; ip += 32;
+    bp = (unsigned char *)(((uintptr_t)ip + 15) & ~(uintptr_t)15);
+    L.cost = (double *)bp;
+}
+
+// sort/linear_assignment.py:11-73 on a (nt x nd) cost already thresholded in `th` (row-major, ld = nd).
+// trk_idx / det_idx map rows / columns to track positions / filtered detection indices.
+// Appends matches at m_t/m_d[nm0..], writes unmatched lists. All 256 threads call; returns via LDS scalars.
+struct McmOut { int nm, n_um_t, n_um_d; };
+__device__ McmOut min_cost_matching(const double *th, int nt, int nd, double max_distance, const int *trk_idx, const int *det_idx,
+                                    int *m_t, int *m_d, int *um_t, int *um_d, BLds &L)
+{
+    McmOut o{0, 0, 0};
+    const int tid = threadIdx.x;
+    if (nd == 0 || nt == 0) {
+        for (int i = tid; i < nt; i += BLOCK) um_t[i] = trk_idx[i];
+        for (int j = tid; j < nd; j += BLOCK) um_d[j] = det_idx[j];
+        o.n_um_t = nt; o.n_um_d = nd;
+        __syncthreads();
+        return o;
+    }
+    __syncthreads();
+    if (tid < WAVE) {
+        const int r = wave_lsa(th, nt, nd, (size_t)nd, (size_t)1, L.W, L.mi_r, L.mi_c);
+        if (tid == 0) L.sc[0] = r < 0 ? 0 : r;
+    }
+    __syncthreads();
+    const int np = L.sc[0];
+    for (int k = tid; k < nt; k += BLOCK) L.rowf[k] = 0;
+    for (int k = tid; k < nd; k += BLOCK) L.colf[k] = 0;
+    __syncthreads();
+    for (int k = tid; k < np; k += BLOCK) {
+        L.rowf[L.mi_r[k]] = 1; L.colf[L.mi_c[k]] = 1;
+        L.rej[k] = th[(size_t)L.mi_r[k] * nd + L.mi_c[k]] > max_distance ? 1 : 0;
+    }
+    __syncthreads();
+    o.n_um_d = block_compact(nd, [&](int c) { return L.colf[c] == 0; }, [&](int c, int pos) { um_d[pos] = det_idx[c]; }, L.scan);
+    o.n_um_t = block_compact(nt, [&](int r) { return L.rowf[r] == 0; }, [&](int r, int pos) { um_t[pos] = trk_idx[r]; }, L.scan);
+    const int nrej = block_compact(np, [&](int k) { return L.rej[k] == 1; },
+                                   [&](int k, int pos) { um_t[o.n_um_t + pos] = trk_idx[L.mi_r[k]]; um_d[o.n_um_d + pos] = det_idx[L.mi_c[k]]; }, L.scan);
+    o.nm = block_compact(np, [&](int k) { return L.rej[k] == 0; },
+                         [&](int k, int pos) { m_t[pos] = trk_idx[L.mi_r[k]]; m_d[pos] = det_idx[L.mi_c[k]]; }, L.scan);
+    o.n_um_t += nrej; o.n_um_d += nrej;
+    __syncthreads();
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------------ association kernel
+__global__ void __launch_bounds__(BLOCK, 1)
+bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ rows_all, size_t rows_stream_stride, int out_cap,
+                   int *__restrict__ out_counts, size_t oc_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int MAXT = Dv.MAXT, MAXD = Dv.MAXD, K = Dv.K, D = Dv.D;
+    const size_t FD = (size_t)K * D;
+    BLds L;
+    bcarve(smem, MAXT, MAXD, L);
+    int *hdr = Dv.hdr + (size_t)s * H_COUNT;
+    int *order = Dv.order + (size_t)s * MAXT;
+    int *freestk = Dv.freestk + (size_t)s * MAXT;
+    const size_t stride = (size_t)Dv.S * MAXT;
+    auto trk_at = [&](int slot) { BTrk T; T.fd = Dv.fd + (size_t)s * MAXT + slot; T.fi = Dv.fi + (size_t)s * MAXT + slot; T.stride = stride; return T; };
+    float *featS = Dv.feat + (size_t)s * MAXT * FD;
+    unsigned char *fvisS = Dv.fvis + (size_t)s * MAXT * K;
+    long long *detidS = Dv.detid + (size_t)s * MAXT;
+    const double *reid = Dv.reid + (size_t)s * MAXT * MAXD;
+    double *gl = Dv.gl + (size_t)s * MAXT * 20;
+    tlk_bpbss_row *rows = rows_all + (size_t)s * rows_stream_stride;
+    int *out_count = out_counts + (size_t)s * oc_stride;
+    const size_t dbase = (size_t)s * in.stream_stride_dets;
+    const int n_in = in.counts[(size_t)s * in.count_stride];
+
+    if (hdr[H_ERR] != 0) { if (tid == 0) *out_count = hdr[H_ERR]; return; }
+    if (n_in > MAXD || n_in < 0) { if (tid == 0) { hdr[H_ERR] = TLK_ECAPACITY; *out_count = TLK_ECAPACITY; } return; }
+    if (P.wrapper_mode && n_in == 0) { if (tid == 0) *out_count = 0; return; }      // bpbreid_strong_sort_api.py:103-104
+
+    // filter_detections (strong_sort.py:143-147)
+    const int N = block_compact(n_in, [&](int i) { return in.conf[dbase + i] > P.min_conf; }, [&](int i, int pos) { L.sel[pos] = i; }, L.scan);
+    int T = hdr[H_NTRK];
+    __syncthreads();
+    // Tracker.predict (tracker.py:92-99, track.py:128-135)
+    for (int p = tid; p < T; p += BLOCK) {
+        const BTrk Kt = trk_at(order[p]);
+        const int tsu = Kt.i(BI_TSU);
+        if (tsu < P.max_pred) {
+            double mean[8], cov[64];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mean[k] = Kt.d(BD_MEAN + k);
+#pragma unroll
+            for (int k = 0; k < 64; ++k) cov[k] = Kt.d(BD_COV + k);
+            kf8_predict(mean, cov);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) Kt.d(BD_MEAN + k) = mean[k];
+#pragma unroll
+            for (int k = 0; k < 64; ++k) Kt.d(BD_COV + k) = cov[k];
+        }
+        Kt.i(BI_AGE) = Kt.i(BI_AGE) + 1;
+        Kt.i(BI_TSU) = tsu + 1;
+    }
+    __syncthreads();
+    if (N > 0) {
+        const int gdim = P.only_position ? 2 : 4;
+        for (int j = tid; j < N; j += BLOCK) {              // detection.py:31-58
+            const double *b = in.ltwh + (dbase + L.sel[j]) * 4;
+            L.dltwh[j * 4] = b[0]; L.dltwh[j * 4 + 1] = b[1]; L.dltwh[j * 4 + 2] = b[2]; L.dltwh[j * 4 + 3] = b[3];
+            L.dxyah[j * 4] = b[0] + b[2] / 2; L.dxyah[j * 4 + 1] = b[1] + b[3] / 2; L.dxyah[j * 4 + 2] = b[2] / b[3]; L.dxyah[j * 4 + 3] = b[3];
+            L.d_mname[j] = 0; L.d_mdist[j] = 0.0;
+        }
+        // per-track gating factors: projected mean + Cholesky of the projected covariance (conf = 0)
+        for (int p = tid; p < T; p += BLOCK) {
+            const BTrk Kt = trk_at(order[p]);
+            const double h = Kt.d(BD_MEAN + 3);
+            const double sstd = (1 - 0.0) * (W_POS * h);
+            double Sd[16], Lc[16];
+            for (int i = 0; i < gdim; ++i)
+                for (int j = 0; j < gdim; ++j) Sd[i * gdim + j] = Kt.d(BD_COV + i * 8 + j) + (i == j ? sstd * sstd : 0.0);
+            chol4(Sd, gdim, Lc);
+            double *g = gl + (size_t)p * 20;
+            for (int i = 0; i < 4; ++i) g[i] = Kt.d(BD_MEAN + i);
+            for (int q = 0; q < 16; ++q) g[4 + q] = Lc[q];
+        }
+        __syncthreads();
+        int nm = 0, n_umt = 0, n_umd = 0;
+        int *um_d_final = L.um_db;
+        if (P.strategy == 0) {
+            // ---------------- strong_sort_matching (tracker.py:242-333) ----------------
+            const int nc = block_compact(T, [&](int p) { return trk_at(order[p]).i(BI_STATE) == ST_CONFIRMED; },
+                                         [&](int p, int pos) { L.cand[pos] = p; }, L.scan);
+            const int nu = block_compact(T, [&](int p) { return trk_at(order[p]).i(BI_STATE) != ST_CONFIRMED; },
+                                         [&](int p, int pos) { L.bc[pos] = p; }, L.scan);
+            double *cm = ((size_t)nc * N <= (size_t)Dv.cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
+            // gate_cost_matrix (linear_assignment.py:132-175) + thresholding (:54-55)
+            for (int e = tid; e < nc * N; e += BLOCK) {
+                const int r = e / N, j = e - r * N;
+                const int p = L.cand[r];
+                double c = reid[(size_t)p * MAXD + L.sel[j]];
+                const double gd = gating_from(gl + (size_t)p * 20, L.dxyah + j * 4, gdim);
+                if (gd > CHI2INV95[gdim]) c = INFTY_COST;
+                c = P.mc_lambda * c + (1 - P.mc_lambda) * gd;
+                cm[e] = c > P.max_dist ? P.max_dist + 1e-5 : c;
+            }
+            // all detections as columns: det_idx = identity -> reuse um_db as identity scratch
+            for (int j = tid; j < N; j += BLOCK) L.um_db[j] = j;
+            __syncthreads();
+            const McmOut A = min_cost_matching(cm, nc, N, P.max_dist, L.cand, L.um_db, L.m_t, L.m_d, L.um_ta, L.um_da, L);
+            if (nc > 0)
+                for (int k = tid; k < A.nm; k += BLOCK) {       // add_matching_information "R": un-thresholded gated cost (tracker.py:409-425)
+                    const int p = L.m_t[k], j = L.m_d[k];
+                    double c = reid[(size_t)p * MAXD + L.sel[j]];
+                    const double gd = gating_from(gl + (size_t)p * 20, L.dxyah + j * 4, gdim);
+                    if (gd > CHI2INV95[gdim]) c = INFTY_COST;
+                    L.d_mname[j] = 1; L.d_mdist[j] = P.mc_lambda * c + (1 - P.mc_lambda) * gd;
+                }
+            __syncthreads();
+            // matching_cascade: unmatched_tracks = set(track_indices) - matched (ascending), linear_assignment.py:128
+            for (int p = tid; p < T; p += BLOCK) L.rowf[p] = 0;
+            __syncthreads();
+            for (int k = tid; k < A.nm; k += BLOCK) L.rowf[L.m_t[k]] = 1;     // by track position
+            __syncthreads();
+            // split by time_since_update == 1 (tracker.py:308-313)
+            const int nb_extra = block_compact(nc, [&](int r) { return L.rowf[L.cand[r]] == 0 && trk_at(order[L.cand[r]]).i(BI_TSU) == 1; },
+                                               [&](int r, int pos) { L.bc[nu + pos] = L.cand[r]; }, L.scan);
+            const int n_uta = block_compact(nc, [&](int r) { return L.rowf[L.cand[r]] == 0 && trk_at(order[L.cand[r]]).i(BI_TSU) != 1; },
+                                            [&](int r, int pos) { L.um_t[pos] = L.cand[r]; }, L.scan);
+            const int nb = nu + nb_extra, n_uda = A.n_um_d;
+            __syncthreads();
+            double *cb = ((size_t)nb * n_uda <= (size_t)Dv.cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
+            for (int e = tid; e < nb * n_uda; e += BLOCK) {          // iou_cost (iou_matching.py:42-78) + thresholding
+                const int r = e / n_uda, c = e - r * n_uda;
+                double tl[4];
+                trk_ltwh(trk_at(order[L.bc[r]]), tl);
+                const double v = 1. - iou_ltwh(tl, L.dltwh + L.um_da[c] * 4);
+                cb[e] = v > P.max_iou_distance ? P.max_iou_distance + 1e-5 : v;
+            }
+            __syncthreads();
+            const McmOut Bm = min_cost_matching(cb, nb, n_uda, P.max_iou_distance, L.bc, L.um_da, L.m_t + A.nm, L.m_d + A.nm,
+                                                L.um_tb, L.um_db, L);
+            if (nb > 0 && n_uda > 0)
+                for (int k = tid; k < Bm.nm; k += BLOCK) {        // "S"
+                    const int p = L.m_t[A.nm + k], j = L.m_d[A.nm + k];
+                    double tl[4];
+                    trk_ltwh(trk_at(order[p]), tl);
+                    L.d_mname[j] = 2; L.d_mdist[j] = 1. - iou_ltwh(tl, L.dltwh + j * 4);
+                }
+            nm = A.nm + Bm.nm;
+            for (int k = tid; k < Bm.n_um_t; k += BLOCK) L.um_t[n_uta + k] = L.um_tb[k];
+            n_umt = n_uta + Bm.n_um_t; n_umd = Bm.n_um_d;
+            um_d_final = L.um_db;
+            __syncthreads();
+        } else {
+            // ---------------- bot_sort_matching (tracker.py:335-363, _full_cost_metric :169-240) ----------------
+            for (int p = tid; p < T; p += BLOCK) L.cand[p] = p;
+            for (int j = tid; j < N; j += BLOCK) L.um_db[j] = j;
+            double *cm = ((size_t)T * N <= (size_t)Dv.cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
+            const double GT = sqrt(CHI2INV95[gdim]);
+            const double wsum = P.w_kfgd + P.w_reid + P.w_st;
+            auto full_cost = [&](int p, int j) {
+                const double gd = gating_from(gl + (size_t)p * 20, L.dxyah + j * 4, gdim);
+                const double pos = sqrt(gd) / (GT * P.gating_thres_factor);
+                const double app = reid[(size_t)p * MAXD + L.sel[j]];
+                double tl[4];
+                trk_ltwh(trk_at(order[p]), tl);
+                const double st = 1. - iou_ltwh(tl, L.dltwh + j * 4);
+                const bool pos_gate = P.w_kfgd > 0 ? pos > 1.0 : false;
+                const bool app_gate = P.w_reid > 0 ? app > P.max_dist : false;
+                const bool st_gate = P.w_st > 0 ? st > P.max_iou_distance : false;
+                const double c = (P.w_kfgd * pos + P.w_reid * app + st * P.w_st) / wsum;
+                // np.logical_or(pos_gate, app_gate, st_gate): the third argument is out= -> st_gate is not part of the mask
+                const bool m = P.w_kfgd > 0 ? (pos_gate || app_gate) : (P.w_st > 0 ? (app_gate || st_gate) : app_gate);
+                return m ? INFTY_COST : c;
+            };
+            __syncthreads();
+            for (int e = tid; e < T * N; e += BLOCK) {
+                const int p = e / N, j = e - p * N;
+                const double c = full_cost(p, j);
+                cm[e] = c > P.max_dist ? P.max_dist + 1e-5 : c;
+            }
+            __syncthreads();
+            const McmOut A = min_cost_matching(cm, T, N, P.max_dist, L.cand, L.um_db, L.m_t, L.m_d, L.um_ta, L.um_da, L);
+            if (T > 0)
+                for (int k = tid; k < A.nm; k += BLOCK) { const int p = L.m_t[k], j = L.m_d[k]; L.d_mname[j] = 1; L.d_mdist[j] = full_cost(p, j); }
+            for (int r = tid; r < T; r += BLOCK) L.rowf[r] = 0;
+            __syncthreads();
+            for (int k = tid; k < A.nm; k += BLOCK) L.rowf[L.m_t[k]] = 1;
+            __syncthreads();
+            n_umt = block_compact(T, [&](int r) { return L.rowf[r] == 0; }, [&](int r, int pos) { L.um_t[pos] = r; }, L.scan);
+            nm = A.nm; n_umd = A.n_um_d; um_d_final = L.um_da;
+            __syncthreads();
+        }
+
+        // ---------------- Tracker.update (tracker.py:134-167) ----------------
+        for (int k = tid; k < nm; k += BLOCK) {               // Track.update: KF part (track.py:137-148)
+            const int j = L.m_d[k];
+            const BTrk Kt = trk_at(order[L.m_t[k]]);
+            double mean[8], cov[64], tl[4];
+            trk_ltwh(Kt, tl);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Kt.d(BD_PRED + q) = tl[q];
+            Kt.i(BI_PVALID) = 1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mean[q] = Kt.d(BD_MEAN + q);
+#pragma unroll
+            for (int q = 0; q < 64; ++q) cov[q] = Kt.d(BD_COV + q);
+            kf8_update(mean, cov, L.dxyah + j * 4, in.conf[dbase + L.sel[j]]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) Kt.d(BD_MEAN + q) = mean[q];
+#pragma unroll
+            for (int q = 0; q < 64; ++q) Kt.d(BD_COV + q) = cov[q];
+            detidS[order[L.m_t[k]]] = in.ids[dbase + L.sel[j]];
+            Kt.i(BI_MNAME) = L.d_mname[j];
+            Kt.d(BD_MDIST) = L.d_mdist[j];
+            const int hits = Kt.i(BI_HITS) + 1;
+            Kt.i(BI_HITS) = hits; Kt.i(BI_TSU) = 0;
+            if (Kt.i(BI_STATE) == ST_TENTATIVE && hits >= P.n_init) Kt.i(BI_STATE) = ST_CONFIRMED;
+        }
+        // visibility-aware EMA of the part embeddings (track.py:150-170): one wavefront per (match, part)
+        {
+            const float a_t = (float)P.ema_alpha, a_d = (float)(1 - P.ema_alpha);
+            const int w = tid >> 6, lane = tid & 63;
+            for (int job = w; job < nm * K; job += NWAVES) {
+                const int k = job / K, p = job - k * K;
+                const int slot = order[L.m_t[k]], di = L.sel[L.m_d[k]];
+                const bool tv = fvisS[(size_t)slot * K + p] != 0, dv = in.vis[(dbase + di) * K + p] != 0;
+                const bool both = tv && dv, x = tv != dv;
+                const float et = (float)both * a_t + (float)(x && tv);
+                const float ed = (float)both * a_d + (float)(x && dv);
+                float *f = featS + (size_t)slot * FD + (size_t)p * D;
+                const float *df = in.emb + (dbase + di) * FD + (size_t)p * D;
+                if (et == 0.f && ed == 0.f) { for (int d = lane; d < D; d += WAVE) f[d] = 1.f; }
+                else for (int d = lane; d < D; d += WAVE) { const float a = et * f[d]; const float b = ed * df[d]; f[d] = a + b; }
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) fvisS[(size_t)slot * K + p] = (tv || dv) ? 1 : 0;
+            }
+        }
+        for (int k = tid; k < n_umt; k += BLOCK) {            // mark_missed (track.py:181-187)
+            const BTrk Kt = trk_at(order[L.um_t[k]]);
+            if (Kt.i(BI_STATE) == ST_TENTATIVE) Kt.i(BI_STATE) = ST_DELETED;
+            else if (Kt.i(BI_TSU) > P.max_age) Kt.i(BI_STATE) = ST_DELETED;
+        }
+        __syncthreads();
+        // _initiate_track (tracker.py:427-441) in the order of unmatched_detections
+        int nfree = hdr[H_NFREE], nextid = hdr[H_NEXTID];
+        if (T + n_umd > MAXT) { if (tid == 0) { hdr[H_ERR] = TLK_ECAPACITY; *out_count = TLK_ECAPACITY; } return; }
+        for (int k = tid; k < n_umd; k += BLOCK) {
+            const int j = um_d_final[k];
+            const int slot = freestk[nfree - 1 - k];
+            order[T + k] = slot;
+            const BTrk Kt = trk_at(slot);
+            const double *m = L.dxyah + j * 4;                // kalman_filter.py:53-83
+            const double sp = 2 * W_POS * m[3], sv = 10 * W_VEL * m[3];
+#pragma unroll
+            for (int q = 0; q < 64; ++q) Kt.d(BD_COV + q) = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { Kt.d(BD_MEAN + q) = m[q]; Kt.d(BD_MEAN + 4 + q) = 0.0; Kt.d(BD_COV + q * 9) = sp * sp; Kt.d(BD_COV + (4 + q) * 9) = sv * sv; }
+            Kt.i(BI_TID) = nextid + k; Kt.i(BI_HITS) = 1; Kt.i(BI_AGE) = 1; Kt.i(BI_TSU) = 0;
+            Kt.i(BI_STATE) = (1 >= P.n_init) ? ST_CONFIRMED : ST_TENTATIVE;
+            Kt.i(BI_MNAME) = L.d_mname[j]; Kt.d(BD_MDIST) = L.d_mdist[j]; Kt.i(BI_PVALID) = 0;
+            detidS[slot] = in.ids[dbase + L.sel[j]];
+        }
+        {   // copy the new tracks' part embeddings + visibility
+            const int w = tid >> 6, lane = tid & 63;
+            for (int job = w; job < n_umd * K; job += NWAVES) {
+                const int k = job / K, p = job - k * K;
+                const int slot = freestk[nfree - 1 - k], di = L.sel[um_d_final[k]];
+                float *f = featS + (size_t)slot * FD + (size_t)p * D;
+                const float *df = in.emb + (dbase + di) * FD + (size_t)p * D;
+                for (int d = lane; d < D; d += WAVE) f[d] = df[d];
+                if (lane == 0) fvisS[(size_t)slot * K + p] = in.vis[(dbase + di) * K + p] != 0 ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        nfree -= n_umd; nextid += n_umd; T += n_umd;
+        // drop deleted tracks (stable), tracker.py:154
+        for (int p = tid; p < T; p += BLOCK) { L.tmp[p] = order[p]; L.rowf[p] = trk_at(order[p]).i(BI_STATE) == ST_DELETED ? 1 : 0; }
+        __syncthreads();
+        const int kept = block_compact(T, [&](int p) { return L.rowf[p] == 0; }, [&](int p, int pos) { order[pos] = L.tmp[p]; }, L.scan);
+        if (kept != T) {
+            block_compact(T, [&](int p) { return L.rowf[p] != 0; }, [&](int p, int pos) { freestk[nfree + pos] = L.tmp[p]; }, L.scan);
+            nfree += T - kept;
+        }
+        T = kept;
+        __syncthreads();
+        if (tid == 0) { hdr[H_NTRK] = T; hdr[H_NFREE] = nfree; hdr[H_NEXTID] = nextid; }
+    }
+    __syncthreads();
+    // outputs (strong_sort.py:93-141): confirmed tracks updated in this frame, list order
+    const int nrows = block_compact(T, [&](int p) { const BTrk Kt = trk_at(order[p]); return Kt.i(BI_STATE) == ST_CONFIRMED && Kt.i(BI_TSU) == 0; },
+                                    [&](int p, int pos) {
+                                        if (pos >= out_cap) return;
+                                        const int slot = order[p];
+                                        const BTrk Kt = trk_at(slot);
+                                        tlk_bpbss_row r;
+                                        r.det_id = detidS[slot]; r.track_id = Kt.i(BI_TID);
+                                        trk_ltwh(Kt, r.kf_ltwh);
+                                        r.pred_valid = Kt.i(BI_PVALID);
+                                        for (int q = 0; q < 4; ++q) r.pred_ltwh[q] = r.pred_valid ? Kt.d(BD_PRED + q) : NAN;
+                                        r.matched_name = Kt.i(BI_MNAME);
+                                        r.matched_dist = r.matched_name ? Kt.d(BD_MDIST) : NAN;
+                                        r.hits = Kt.i(BI_HITS); r.age = Kt.i(BI_AGE); r.time_since_update = Kt.i(BI_TSU); r.state = Kt.i(BI_STATE);
+                                        rows[pos] = r;
+                                    }, L.scan);
+    if (tid == 0) *out_count = nrows > out_cap ? TLK_ECAPACITY : nrows;
+}
+
+__global__ void bpbss_reset_kernel(BpbDev D, int stream)
+{
+    const int s0 = stream < 0 ? 0 : stream, s1 = stream < 0 ? D.S : stream + 1;
+    for (int s = s0 + blockIdx.x; s < s1; s += gridDim.x) {
+        int *hdr = D.hdr + (size_t)s * H_COUNT;
+        for (int k = threadIdx.x; k < D.MAXT; k += blockDim.x) D.freestk[(size_t)s * D.MAXT + k] = D.MAXT - 1 - k;
+        if (threadIdx.x == 0) { hdr[H_NTRK] = 0; hdr[H_NEXTID] = 1; hdr[H_NFREE] = D.MAXT; hdr[H_ERR] = 0; }   // _next_id = 1 (tracker.py:87)
+    }
+}
+
+__global__ void bpbss_gather_kernel(BpbDev D, int stream, long long *ids, double *mean, double *cov, float *feat, unsigned char *fvis,
+                                    int cap, int *n_out)
+{
+    const int T = D.hdr[(size_t)stream * H_COUNT + H_NTRK];
+    if (threadIdx.x == 0 && blockIdx.x == 0) *n_out = T;
+    const size_t stride = (size_t)D.S * D.MAXT, FD = (size_t)D.K * D.D;
+    for (int p = blockIdx.x; p < T && p < cap; p += gridDim.x) {
+        const int slot = D.order[(size_t)stream * D.MAXT + p];
+        const double *fd = D.fd + (size_t)stream * D.MAXT + slot;
+        if (ids && threadIdx.x == 0) ids[p] = D.fi[(size_t)BI_TID * stride + (size_t)stream * D.MAXT + slot];
+        if (mean) for (int k = threadIdx.x; k < 8; k += blockDim.x) mean[(size_t)p * 8 + k] = fd[(size_t)(BD_MEAN + k) * stride];
+        if (cov) for (int k = threadIdx.x; k < 64; k += blockDim.x) cov[(size_t)p * 64 + k] = fd[(size_t)(BD_COV + k) * stride];
+        if (feat) for (size_t k = threadIdx.x; k < FD; k += blockDim.x) feat[(size_t)p * FD + k] = D.feat[((size_t)stream * D.MAXT + slot) * FD + k];
+        if (fvis) for (int k = threadIdx.x; k < D.K; k += blockDim.x) fvis[(size_t)p * D.K + k] = D.fvis[((size_t)stream * D.MAXT + slot) * D.K + k];
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ host side
+struct tlk_bpbss {
+    BpbDev D; BpbP P; int device; size_t smem;
+    // staging for the host-buffer entry point
+    long long *d_ids; double *d_ltwh; float *d_emb; unsigned char *d_vis; double *d_conf; int *d_cnt, *d_ocnt; tlk_bpbss_row *d_rows;
+    int out_cap;
+};
+
+static void bpb_free(tlk_bpbss *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    BpbDev &D = h->D;
+    void *ptrs[] = {D.fd, D.fi, D.detid, D.hdr, D.order, D.freestk, D.feat, D.fvis, D.tnorm, D.dnorm, D.reid, D.gl, D.cost_g,
+                    h->d_ids, h->d_ltwh, h->d_emb, h->d_vis, h->d_conf, h->d_cnt, h->d_ocnt, h->d_rows};
+    for (void *p : ptrs) if (p) hipFree(p);
+    delete h;
+}
+
+static int launch_frame(tlk_bpbss *h, const BpbDev &Dv, int n_streams, const FrameIn &in, tlk_bpbss_row *rows, size_t rows_stream_stride,
+                        int out_cap, int *out_counts, size_t oc_stride, hipStream_t st)
+{
+    const int K = Dv.K;
+    const int nvec = (Dv.MAXT + Dv.MAXD) * K;
+    hipLaunchKernelGGL(partnorm_kernel, dim3((nvec + NWAVES - 1) / NWAVES, n_streams), dim3(BLOCK), 0, st, Dv, in, h->P.wrapper_mode);
+    hipLaunchKernelGGL(partdist_kernel, dim3((Dv.MAXD + 15) / 16, (Dv.MAXT + 15) / 16, n_streams), dim3(64 * K), 0, st, Dv, in);
+    hipLaunchKernelGGL(bpbss_assoc_kernel, dim3(n_streams), dim3(BLOCK), h->smem, st, Dv, h->P, in, rows, rows_stream_stride, out_cap,
+                       out_counts, oc_stride);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
+
+extern "C" int tlk_bpbss_create(const tlk_bpbss_params *p, int n_streams, int device, tlk_bpbss **out)
+{
+    if (!p || !out) return fail(TLK_EINVAL, "tlk_bpbss_create: null pointer");
+    if (n_streams < 1) return fail(TLK_EINVAL, "tlk_bpbss_create: n_streams must be >= 1");
+    if (p->parts < 1 || p->parts > 8) return fail(TLK_EINVAL, "tlk_bpbss_create: parts must be in [1, 8]");
+    if (p->dim < 16 || p->dim % 16 != 0) return fail(TLK_EINVAL, "tlk_bpbss_create: dim must be a positive multiple of 16");
+    if (p->matching_strategy < 0 || p->matching_strategy > 1) return fail(TLK_EINVAL, "tlk_bpbss_create: unknown matching_strategy");
+    const int MAXT = p->max_tracks > 0 ? p->max_tracks : 256, MAXD = p->max_dets > 0 ? p->max_dets : 128;
+    if (MAXT > 512 || MAXD > 256) return fail(TLK_ECAPACITY, "tlk_bpbss_create: max_tracks <= 512 and max_dets <= 256");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(TLK_ENODEVICE, "tlk_bpbss_create: no HIP device (libtlk has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(TLK_EINVAL, "tlk_bpbss_create: bad device index");
+    TLK_HIP(hipSetDevice(device));
+    tlk_bpbss *h = new tlk_bpbss();
+    memset(h, 0, sizeof(*h));
+    h->device = device;
+    h->P = BpbP{p->ema_alpha, p->mc_lambda, p->max_dist, p->max_iou_distance, p->min_bbox_confidence, p->gating_thres_factor,
+                p->w_kfgd, p->w_reid, p->w_st, p->max_age, p->n_init, p->only_position_for_kf_gating,
+                p->max_kalman_prediction_without_update, p->matching_strategy, p->wrapper_mode};
+    BpbDev &D = h->D;
+    D.S = n_streams; D.MAXT = MAXT; D.MAXD = MAXD; D.K = p->parts; D.D = p->dim;
+    const size_t fixed = blds_fixed(MAXT, MAXD), budget = 160 * 1024 - 256;
+    if (fixed + 4096 > budget) { delete h; return fail(TLK_ECAPACITY, "tlk_bpbss_create: LDS budget exceeded"); }
+    D.cost_lds_entries = (int)((budget - fixed) / sizeof(double));
+    h->smem = fixed + (size_t)D.cost_lds_entries * sizeof(double);
+    const size_t slots = (size_t)n_streams * MAXT, FD = (size_t)D.K * D.D;
+    h->out_cap = MAXD;
+#define BPB_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void **)&(ptr), (bytes)); \
+        if (e_ != hipSuccess) { bpb_free(h); return fail(TLK_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e_)); } } while (0)
+    BPB_ALLOC(D.fd, sizeof(double) * BD_COUNT * slots);
+    BPB_ALLOC(D.fi, sizeof(int) * BI_COUNT * slots);
+    BPB_ALLOC(D.detid, sizeof(long long) * slots);
+    BPB_ALLOC(D.hdr, sizeof(int) * H_COUNT * n_streams);
+    BPB_ALLOC(D.order, sizeof(int) * slots);
+    BPB_ALLOC(D.freestk, sizeof(int) * slots);
+    BPB_ALLOC(D.feat, sizeof(float) * FD * slots);
+    BPB_ALLOC(D.fvis, (size_t)D.K * slots);
+    BPB_ALLOC(D.tnorm, sizeof(float) * 2 * D.K * slots);
+    BPB_ALLOC(D.dnorm, sizeof(float) * 2 * D.K * (size_t)n_streams * MAXD);
+    BPB_ALLOC(D.reid, sizeof(double) * slots * MAXD);
+    BPB_ALLOC(D.gl, sizeof(double) * 20 * slots);
+    BPB_ALLOC(D.cost_g, sizeof(double) * slots * MAXD);
+    BPB_ALLOC(h->d_ids, sizeof(long long) * MAXD);
+    BPB_ALLOC(h->d_ltwh, sizeof(double) * 4 * MAXD);
+    BPB_ALLOC(h->d_emb, sizeof(float) * FD * MAXD);
+    BPB_ALLOC(h->d_vis, (size_t)D.K * MAXD);
+    BPB_ALLOC(h->d_conf, sizeof(double) * MAXD);
+    BPB_ALLOC(h->d_cnt, sizeof(int));
+    BPB_ALLOC(h->d_ocnt, sizeof(int));
+    BPB_ALLOC(h->d_rows, sizeof(tlk_bpbss_row) * h->out_cap);
+#undef BPB_ALLOC
+    hipError_t e = hipMemset(D.fd, 0, sizeof(double) * BD_COUNT * slots);
+    if (e == hipSuccess) e = hipMemset(D.fi, 0, sizeof(int) * BI_COUNT * slots);
+    if (e == hipSuccess) e = hipMemset(D.feat, 0, sizeof(float) * FD * slots);
+    if (e == hipSuccess) e = hipMemset(D.fvis, 0, (size_t)D.K * slots);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)bpbss_assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem);
+    if (e != hipSuccess) { bpb_free(h); return fail(TLK_EHIP, std::string("tlk_bpbss_create: ") + hipGetErrorString(e)); }
+    hipLaunchKernelGGL(bpbss_reset_kernel, dim3(n_streams < 256 ? n_streams : 256), dim3(BLOCK), 0, 0, D, -1);
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) { bpb_free(h); return fail(TLK_EHIP, std::string("tlk_bpbss_create: ") + hipGetErrorString(e)); }
+    *out = h;
+    return TLK_OK;
+}
+
+extern "C" int tlk_bpbss_destroy(tlk_bpbss *h) { bpb_free(h); return TLK_OK; }
+
+extern "C" int tlk_bpbss_reset(tlk_bpbss *h, int stream)
+{
+    if (!h) return fail(TLK_EINVAL, "tlk_bpbss_reset: null handle");
+    if (stream >= h->D.S) return fail(TLK_EINVAL, "tlk_bpbss_reset: stream out of range");
+    TLK_HIP(hipSetDevice(h->device));
+    hipLaunchKernelGGL(bpbss_reset_kernel, dim3(stream < 0 ? (h->D.S < 256 ? h->D.S : 256) : 1), dim3(BLOCK), 0, 0, h->D, stream);
+    TLK_HIP(hipGetLastError());
+    TLK_HIP(hipStreamSynchronize(0));
+    return TLK_OK;
+}
+
+extern "C" int tlk_bpbss_update_dev(tlk_bpbss *h, const int64_t *ids_dev, const double *ltwh_dev, const float *emb_dev,
+                                    const uint8_t *vis_dev, const double *conf_dev, const int32_t *counts_dev, int n_frames,
+                                    tlk_bpbss_row *rows_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream)
+{
+    if (!h) return fail(TLK_EINVAL, "tlk_bpbss_update_dev: null handle");
+    if (n_frames < 0 || out_cap < 0) return fail(TLK_EINVAL, "tlk_bpbss_update_dev: negative size");
+    if (n_frames == 0) return TLK_OK;
+    if (!ids_dev || !ltwh_dev || !emb_dev || !vis_dev || !conf_dev || !counts_dev || !rows_dev || !out_counts_dev)
+        return fail(TLK_EINVAL, "tlk_bpbss_update_dev: null pointer");
+    TLK_HIP(hipSetDevice(h->device));
+    const BpbDev &D = h->D;
+    const size_t FD = (size_t)D.K * D.D;
+    for (int f = 0; f < n_frames; ++f) {
+        const size_t off = (size_t)f * D.MAXD;          // dets index within a stream block of n_frames*MAXD
+        FrameIn in;
+        in.ids = (const long long *)ids_dev + off; in.ltwh = ltwh_dev + off * 4; in.emb = emb_dev + off * FD;
+        in.vis = vis_dev + off * D.K; in.conf = conf_dev + off; in.counts = (const int *)counts_dev + f;
+        in.stream_stride_dets = (size_t)n_frames * D.MAXD; in.count_stride = (size_t)n_frames;
+        const int rc = launch_frame(h, D, D.S, in, rows_dev + (size_t)f * out_cap, (size_t)n_frames * out_cap, out_cap,
+                                    (int *)out_counts_dev + f, (size_t)n_frames, (hipStream_t)hip_stream);
+        if (rc != TLK_OK) return rc;
+    }
+    return TLK_OK;
+}
+
+extern "C" int tlk_bpbss_update(tlk_bpbss *h, int stream, const int64_t *ids, const double *ltwh, const float *emb,
+                                const uint8_t *vis, const double *conf, int n, tlk_bpbss_row *rows, int cap, int *n_out)
+{
+    if (!h || !n_out) return fail(TLK_EINVAL, "tlk_bpbss_update: null pointer");
+    if (stream < 0 || stream >= h->D.S) return fail(TLK_EINVAL, "tlk_bpbss_update: stream out of range");
+    if (n < 0 || (n > 0 && (!ids || !ltwh || !emb || !vis || !conf))) return fail(TLK_EINVAL, "tlk_bpbss_update: bad detections");
+    if (n > h->D.MAXD) return fail(TLK_ECAPACITY, "tlk_bpbss_update: more detections than max_dets");
+    TLK_HIP(hipSetDevice(h->device));
+    hipStream_t st = 0;
+    const size_t FD = (size_t)h->D.K * h->D.D;
+    if (n) {
+        TLK_HIP(hipMemcpyAsync(h->d_ids, ids, sizeof(long long) * n, hipMemcpyHostToDevice, st));
+        TLK_HIP(hipMemcpyAsync(h->d_ltwh, ltwh, sizeof(double) * 4 * n, hipMemcpyHostToDevice, st));
+        TLK_HIP(hipMemcpyAsync(h->d_emb, emb, sizeof(float) * FD * n, hipMemcpyHostToDevice, st));
+        TLK_HIP(hipMemcpyAsync(h->d_vis, vis, (size_t)h->D.K * n, hipMemcpyHostToDevice, st));
+        TLK_HIP(hipMemcpyAsync(h->d_conf, conf, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    }
+    TLK_HIP(hipMemcpyAsync(h->d_cnt, &n, sizeof(int), hipMemcpyHostToDevice, st));
+    BpbDev V = h->D;       // single-stream view: shift per-stream bases, keep strides
+    const size_t sl = (size_t)stream * V.MAXT;
+    V.fd += sl; V.fi += sl; V.detid += sl; V.hdr += (size_t)stream * H_COUNT; V.order += sl; V.freestk += sl;
+    V.feat += sl * FD; V.fvis += sl * V.K; V.tnorm += sl * V.K * 2; V.dnorm += (size_t)stream * V.MAXD * V.K * 2;
+    V.reid += sl * V.MAXD; V.gl += sl * 20; V.cost_g += sl * V.MAXD;
+    FrameIn in;
+    in.ids = h->d_ids; in.ltwh = h->d_ltwh; in.emb = h->d_emb; in.vis = h->d_vis; in.conf = h->d_conf; in.counts = h->d_cnt;
+    in.stream_stride_dets = 0; in.count_stride = 0;
+    const int rc = launch_frame(h, V, 1, in, h->d_rows, 0, h->out_cap, h->d_ocnt, 0, st);
+    if (rc != TLK_OK) return rc;
+    int rows_n = 0;
+    TLK_HIP(hipMemcpyAsync(&rows_n, h->d_ocnt, sizeof(int), hipMemcpyDeviceToHost, st));
+    TLK_HIP(hipStreamSynchronize(st));
+    if (rows_n < 0) return fail(rows_n, "tlk_bpbss_update: tracker capacity exceeded (max_tracks/max_dets)");
+    if (rows_n > cap) return fail(TLK_ECAPACITY, "tlk_bpbss_update: output buffer too small");
+    if (rows_n) TLK_HIP(hipMemcpy(rows, h->d_rows, sizeof(tlk_bpbss_row) * rows_n, hipMemcpyDeviceToHost));
+    *n_out = rows_n;
+    return TLK_OK;
+}
+
+extern "C" int tlk_bpbss_get_tracks(tlk_bpbss *h, int stream, int64_t *ids, double *mean, double *cov, float *feat, uint8_t *fvis,
+                                    int cap, int *n_tracks)
+{
+    if (!h || !n_tracks) return fail(TLK_EINVAL, "tlk_bpbss_get_tracks: null pointer");
+    if (stream < 0 || stream >= h->D.S) return fail(TLK_EINVAL, "tlk_bpbss_get_tracks: stream out of range");
+    TLK_HIP(hipSetDevice(h->device));
+    const size_t c = cap > 0 ? cap : 1, FD = (size_t)h->D.K * h->D.D;
+    long long *di = nullptr; double *dm = nullptr, *dc = nullptr; float *df = nullptr; unsigned char *dv = nullptr; int *dn = nullptr;
+    TLK_HIP(hipMalloc((void **)&di, sizeof(long long) * c));
+    TLK_HIP(hipMalloc((void **)&dm, sizeof(double) * 8 * c));
+    TLK_HIP(hipMalloc((void **)&dc, sizeof(double) * 64 * c));
+    TLK_HIP(hipMalloc((void **)&df, sizeof(float) * FD * c));
+    TLK_HIP(hipMalloc((void **)&dv, (size_t)h->D.K * c));
+    TLK_HIP(hipMalloc((void **)&dn, sizeof(int)));
+    hipLaunchKernelGGL(bpbss_gather_kernel, dim3(64), dim3(BLOCK), 0, 0, h->D, stream, di, dm, dc, df, dv, cap, dn);
+    int n = 0;
+    hipError_t e = hipMemcpy(&n, dn, sizeof(int), hipMemcpyDeviceToHost);
+    const int k = n < cap ? n : cap;
+    if (e == hipSuccess && k > 0) {
+        if (ids) e = hipMemcpy(ids, di, sizeof(long long) * k, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && mean) e = hipMemcpy(mean, dm, sizeof(double) * 8 * k, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && cov) e = hipMemcpy(cov, dc, sizeof(double) * 64 * k, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && feat) e = hipMemcpy(feat, df, sizeof(float) * FD * k, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && fvis) e = hipMemcpy(fvis, dv, (size_t)h->D.K * k, hipMemcpyDeviceToHost);
+    }
+    hipFree(di); hipFree(dm); hipFree(dc); hipFree(df); hipFree(dv); hipFree(dn);
+    if (e != hipSuccess) return fail(TLK_EHIP, std::string("tlk_bpbss_get_tracks: ") + hipGetErrorString(e));
+    *n_tracks = n;
+    return TLK_OK;
+}
+
+// stateless part distance: builds a throw-away identity-ordered view
+extern "C" int tlk_partdist_f32(const float *q_dev, const uint8_t *qvis_dev, int T, const float *g_dev, const uint8_t *gvis_dev,
+                                int N, int K, int D, double *out_dev, void *hip_stream)
+{
+    if (T < 0 || N < 0 || K < 1 || K > 8 || D < 16 || D % 16 != 0) return fail(TLK_EINVAL, "tlk_partdist_f32: bad shape (K in [1,8], D % 16 == 0)");
+    if (T == 0 || N == 0) return TLK_OK;
+    if (!q_dev || !qvis_dev || !g_dev || !gvis_dev || !out_dev) return fail(TLK_EINVAL, "tlk_partdist_f32: null pointer");
+    hipStream_t st = (hipStream_t)hip_stream;
+    BpbDev V;
+    memset(&V, 0, sizeof(V));
+    V.S = 1; V.MAXT = T; V.MAXD = N; V.K = K; V.D = D;
+    int *hdr = nullptr, *order = nullptr, *cnt = nullptr; float *tn = nullptr, *dn = nullptr;
+    TLK_HIP(hipMallocAsync((void **)&hdr, sizeof(int) * H_COUNT, st));
+    TLK_HIP(hipMallocAsync((void **)&order, sizeof(int) * T, st));
+    TLK_HIP(hipMallocAsync((void **)&cnt, sizeof(int), st));
+    TLK_HIP(hipMallocAsync((void **)&tn, sizeof(float) * 2 * K * T, st));
+    TLK_HIP(hipMallocAsync((void **)&dn, sizeof(float) * 2 * K * N, st));
+    std::string tmp((size_t)sizeof(int) * (H_COUNT + T + 1), '\0');
+    int *hp = (int *)tmp.data();
+    hp[H_NTRK] = T;
+    for (int i = 0; i < T; ++i) hp[H_COUNT + i] = i;
+    hp[H_COUNT + T] = N;
+    TLK_HIP(hipMemcpyAsync(hdr, hp, sizeof(int) * H_COUNT, hipMemcpyHostToDevice, st));
+    TLK_HIP(hipMemcpyAsync(order, hp + H_COUNT, sizeof(int) * T, hipMemcpyHostToDevice, st));
+    TLK_HIP(hipMemcpyAsync(cnt, hp + H_COUNT + T, sizeof(int), hipMemcpyHostToDevice, st));
+    TLK_HIP(hipStreamSynchronize(st));           // staging buffer `tmp` goes out of scope below
+    V.hdr = hdr; V.order = order; V.feat = const_cast<float *>(q_dev); V.fvis = const_cast<unsigned char *>(qvis_dev);
+    V.tnorm = tn; V.dnorm = dn; V.reid = out_dev;
+    FrameIn in;
+    memset(&in, 0, sizeof(in));
+    in.emb = g_dev; in.vis = gvis_dev; in.counts = cnt;
+    const int nvec = (T + N) * K;
+    hipLaunchKernelGGL(partnorm_kernel, dim3((nvec + NWAVES - 1) / NWAVES, 1), dim3(BLOCK), 0, st, V, in, 0);
+    hipLaunchKernelGGL(partdist_kernel, dim3((N + 15) / 16, (T + 15) / 16, 1), dim3(64 * K), 0, st, V, in);
+    TLK_HIP(hipGetLastError());
+    TLK_HIP(hipFreeAsync(hdr, st)); TLK_HIP(hipFreeAsync(order, st)); TLK_HIP(hipFreeAsync(cnt, st));
+    TLK_HIP(hipFreeAsync(tn, st)); TLK_HIP(hipFreeAsync(dn, st));
+    return TLK_OK;
+}
