@@ -474,11 +474,59 @@ def gen_kf8(out_dir):
     print("kf8 ok")
 
 
+def gen_hota(out_dir):
+    """HOTA of a tracker output vs synthetic GT through the TrackEval copy vendored by the reference, loaded file by
+    file (trackeval/__init__ pulls shapely): plugins/eval/PoseTrack21/posetrack21/posetrack21/trackeval/."""
+    import importlib.util
+    base = os.path.join(REF, "plugins", "eval", "PoseTrack21", "posetrack21", "posetrack21", "trackeval")
+    pkg = types.ModuleType("trackeval"); pkg.__path__ = [base]; sys.modules["trackeval"] = pkg
+    mpkg = types.ModuleType("trackeval.metrics"); mpkg.__path__ = [os.path.join(base, "metrics")]; sys.modules["trackeval.metrics"] = mpkg
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec); sys.modules[name] = m; spec.loader.exec_module(m); return m
+    load("trackeval._timing", os.path.join(base, "_timing.py"))
+    load("trackeval.utils", os.path.join(base, "utils.py"))
+    load("trackeval.metrics._base_metric", os.path.join(base, "metrics", "_base_metric.py"))
+    H = load("trackeval.metrics.hota", os.path.join(base, "metrics", "hota.py")).HOTA()
+    _install_filterpy_shim()
+    import oc_sort.ocsort as ref
+    from tracklab_amd.hota import box_iou_matrix
+    blobs = {}
+    per_seq = []
+    for si, (seed, nobj, nfr, skw) in enumerate([(0, 30, 120, {"miss_prob": 0.1}), (1, 12, 80, {"miss_prob": 0.3, "churn_period": 8})]):
+        trk = ref.OCSort(**OCSORT_CONFIGS["yaml"]["hyper"])
+        gmap, tmap = {}, {}
+        gt_ids, tr_ids, sims = [], [], []
+        for fr in SyntheticStream(seed, nobj, nfr, **skw):
+            inp = torch.from_numpy(fr["dets"]); inp = inp[inp[:, 4] > 0.4]
+            out = np.asarray(trk.update(inp, None), dtype=np.float64).reshape(-1, 8)
+            g = np.array([gmap.setdefault(int(x), len(gmap)) for x in fr["gt_all_ids"]], dtype=int)
+            t = np.array([tmap.setdefault(int(x), len(tmap)) for x in out[:, 4]], dtype=int)
+            sim = box_iou_matrix(fr["gt_boxes"], out[:, :4])
+            gt_ids.append(g); tr_ids.append(t); sims.append(sim)
+            blobs[f"s{si}_f{fr['frame']}_gt_ids"] = fr["gt_all_ids"]; blobs[f"s{si}_f{fr['frame']}_gt_boxes"] = fr["gt_boxes"]
+            blobs[f"s{si}_f{fr['frame']}_tr_ids"] = out[:, 4].astype(np.int64); blobs[f"s{si}_f{fr['frame']}_tr_boxes"] = out[:, :4]
+        data = {"num_tracker_dets": sum(len(t) for t in tr_ids), "num_gt_dets": sum(len(g) for g in gt_ids),
+                "num_gt_ids": len(gmap), "num_tracker_ids": len(tmap), "num_timesteps": nfr,
+                "gt_ids": gt_ids, "tracker_ids": tr_ids, "similarity_scores": sims}
+        res = H.eval_sequence(data)
+        per_seq.append(res)
+        blobs[f"s{si}_n_frames"] = np.int64(nfr)
+        for k in ("HOTA", "DetA", "AssA", "DetRe", "DetPr", "AssRe", "AssPr", "LocA", "HOTA_TP", "HOTA_FN", "HOTA_FP"):
+            blobs[f"s{si}_{k}"] = np.asarray(res[k], dtype=np.float64)
+    comb = H.combine_sequences({"a": per_seq[0], "b": per_seq[1]})
+    for k in ("HOTA", "DetA", "AssA", "DetRe", "DetPr", "AssRe", "AssPr", "LocA", "HOTA_TP", "HOTA_FN", "HOTA_FP"):
+        blobs[f"comb_{k}"] = np.asarray(comb[k], dtype=np.float64)
+    np.savez_compressed(os.path.join(out_dir, "hota_cases.npz"), **blobs)
+    print("hota ok", float(np.mean(comb["HOTA"])))
+
+
 def main():
     out_dir = HERE
     only = set(sys.argv[1:])
     gens = {"ocsort": gen_ocsort, "iou": gen_iou_family, "kf7": gen_kf7, "lsa": gen_lsa,
-            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8}
+            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota}
     for k, fn in gens.items():
         if not only or k in only:
             fn(out_dir)

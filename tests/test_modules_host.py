@@ -1,0 +1,113 @@
+"""Host logic of the TrackLab modules (DataFrame <-> arrays, index handling, plugin contract), on CPU with the
+oracle injected as the backend (tests may use the oracle; the product backend is libtlk and needs a GPU)."""
+import numpy as np
+import pandas as pd
+import pytest
+from torch.utils.data.dataloader import default_collate
+
+from tracklab_amd.pipeline_api import ImageLevelModule
+from tracklab_amd.synth import SyntheticStream, ltrb_to_ltwh_rows
+from tracklab_amd.wrappers import HipBPBReIDStrongSORT, HipOCSORT
+
+
+class NS(dict):
+    __getattr__ = dict.__getitem__
+
+
+HYPER = dict(asso_func="giou", delta_t=1, det_thresh=0, inertia=0.3941737016672115,
+             iou_threshold=0.22136877277096445, max_age=50, min_hits=1, use_byte=False)
+
+
+def _frame_df(fr, dtype=np.float64, id0=0):
+    d = fr["dets"]
+    ltwh = ltrb_to_ltwh_rows(d[:, :4]).astype(dtype)
+    return pd.DataFrame({"bbox_ltwh": list(ltwh), "bbox_conf": d[:, 4], "category_id": np.ones(len(d), dtype=int),
+                         "image_id": fr["frame"], "video_id": 0}, index=(d[:, 6].astype(int) + id0))
+
+
+def test_plugin_contract():
+    m = HipOCSORT(NS(min_confidence=0.4, hyperparams=HYPER), "cuda:0", tracking_dataset=None)
+    assert isinstance(m, ImageLevelModule) and m.level == "image" and m.name == "HipOCSORT" and m.batch_size == 1
+    assert m.input_columns == ["bbox_ltwh", "bbox_conf", "category_id"]
+    assert m.output_columns == ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
+    b = HipBPBReIDStrongSORT(NS(ecc=False), "cuda:0", batch_size=8)
+    assert b.level == "image" and b.batch_size == 1 and len(b.output_columns) == 9
+    assert m.preprocess(None, pd.DataFrame(), pd.Series(dtype=float)) == {"input": []}
+    assert m.process({"input": []}, pd.DataFrame(), pd.DataFrame()) == []
+
+
+def test_ocsort_module_matches_oracle_wrapper(orc):
+    class Backend:                                   # same surface as tracklab_amd._lib.OCSortBank
+        def __init__(self):
+            self.t = orc.OCSort(**HYPER)
+
+        def update(self, dets, stream):
+            return orc.ocsort_wrapper_step(self.t, dets, 0.4)
+
+        def reset(self, stream):
+            self.t = orc.OCSort(**HYPER)
+
+    m = HipOCSORT(NS(min_confidence=0.4, hyperparams=HYPER), "cuda:0")
+    m._make_backend = lambda: Backend()
+    ref = orc.OCSort(**HYPER)
+    m.reset()
+    for dtype in (np.float64, np.float32):
+        m.reset()
+        ref = orc.OCSort(**HYPER)
+        for fr in SyntheticStream(3, 25, 40, miss_prob=0.1):
+            df = _frame_df(fr, dtype, id0=1000)
+            sample = m.preprocess(None, df, pd.Series({"frame": fr["frame"]}))
+            # reference semantics of OCSORT.preprocess: ltwh -> ltrb in the column's dtype, then a float64 row
+            ltwh = np.stack(df.bbox_ltwh.to_list())
+            exp_in = np.column_stack([ltwh[:, 0], ltwh[:, 1], ltwh[:, 0] + ltwh[:, 2], ltwh[:, 1] + ltwh[:, 3],
+                                      df.bbox_conf, df.category_id, df.index]).astype(np.float64)
+            np.testing.assert_array_equal(sample["input"], exp_in)
+            batch = default_collate([sample])               # what the engine's DataLoader does (batch_size 1)
+            out = m.process(batch, df, None)
+            exp = orc.ocsort_wrapper_step(ref, exp_in, 0.4)
+            if len(exp) == 0:
+                assert isinstance(out, list) and not out
+                continue
+            assert list(out.index) == list(exp[:, 7].astype(int)) and set(out.index) <= set(df.index)
+            np.testing.assert_array_equal(out.track_id.to_numpy(), exp[:, 4])
+            np.testing.assert_array_equal(np.stack(out.track_bbox_ltwh.to_list()),
+                                          np.column_stack([exp[:, 0], exp[:, 1], exp[:, 2] - exp[:, 0], exp[:, 3] - exp[:, 1]]))
+            np.testing.assert_array_equal(out.track_bbox_conf.to_numpy(), exp[:, 6])
+
+
+def test_bpbss_module_matches_oracle(orc):
+    K, D = 6, 16
+    cfg = NS(ecc=False, ema_alpha=0.9, mc_lambda=0.995, max_dist=0.5, motion_criterium="iou", max_iou_distance=0.8,
+             max_oks_distance=0.7, max_age=300, n_init=0, nn_budget=100, min_bbox_confidence=0.0,
+             only_position_for_kf_gating=False, max_kalman_prediction_without_update=7,
+             matching_strategy="strong_sort_matching", gating_thres_factor=1, w_kfgd=1, w_reid=1, w_st=1)
+    kw = {k: v for k, v in cfg.items() if k != "ecc"}
+
+    class Backend:
+        def __init__(self, parts, dim):
+            self.t = orc.StrongSORT(parts, dim, **kw)
+
+        def update(self, ids, ltwh, emb, vis, conf, stream):
+            return self.t.update(ids, ltwh, emb, vis, conf)
+
+    m = HipBPBReIDStrongSORT(cfg, "cuda:0")
+    m._make_backend = lambda parts, dim: Backend(parts, dim)
+    ref = orc.StrongSORT(K, D, **kw)
+    for fr in SyntheticStream(4, 15, 30, parts=K, dim=D, with_embeddings=True, miss_prob=0.1):
+        d = fr["dets"]
+        df = _frame_df(fr)
+        df["embeddings"] = list(fr["embeddings"])
+        df["visibility_scores"] = list(fr["visibility"])
+        sample = m.preprocess(None, df, pd.Series({"frame": fr["frame"]}))
+        out = m.process(default_collate([sample]), df, None)
+        exp = ref.update(d[:, 6].astype(np.int64), ltrb_to_ltwh_rows(d[:, :4]), fr["embeddings"], fr["visibility"], d[:, 4])
+        assert list(out.columns) == m.output_columns
+        assert list(out.index) == list(exp["det_id"])
+        np.testing.assert_array_equal(out.track_id.to_numpy(), exp["track_id"])
+        assert list(out.state) == [{0: "t", 1: "c", 2: "d"}[s] for s in exp["state"]]
+        for (mw, name, dist) in zip(out.matched_with, exp["matched_name"], exp["matched_dist"]):
+            assert (mw is None) == (name == 0)
+            if mw is not None:
+                assert mw[0] == {1: "R", 2: "S"}[name] and mw[1] == dist
+        np.testing.assert_array_equal(np.stack(out.track_bbox_kf_ltwh.to_list()), exp["kf_ltwh"])
+        assert all((p is None) == (v == 0) for p, v in zip(out.track_bbox_pred_kf_ltwh, exp["pred_valid"]))

@@ -51,6 +51,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise TlkError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(tracklab_amd has no CPU fallback)")
+    try:
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7). Loading it
+        # first lets libtlk's DT_NEEDED resolve to the same copy; the other order loads /opt/rocm's copy next to torch's
+        # and torch then reports "No HIP GPUs are available".
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.tlk_last_error.restype = C.c_char_p
     L.tlk_version.restype = C.c_int

@@ -1,0 +1,3 @@
+from .track import HipBPBReIDStrongSORT, HipOCSORT  # noqa: F401
+from .detect import HipYOLOX  # noqa: F401
+from .reid import HipPartReID  # noqa: F401

@@ -1,0 +1,150 @@
+"""Tracker modules: same plugin surface as ``tracklab.wrappers.OCSORT`` / ``BPBReIDStrongSORT``
+(tracklab/wrappers/track/oc_sort_api.py:14-76, bpbreid_strong_sort_api.py:14-118), association on the GPU.
+
+``preprocess`` is numpy/pandas only (it may run in a DataLoader worker process, datapipe.py:37-46);
+all HIP state is created lazily in the main process on the first ``process`` / ``reset``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+
+from ..pipeline_api import ImageLevelModule, cfg_get, to_numpy
+
+STATE_CHARS = {0: "t", 1: "c", 2: "d"}       # TrackState, bpbreid_strong_sort/sort/track.py:16-18
+MATCH_NAMES = {1: "R", 2: "S"}
+
+
+class HipOCSORT(ImageLevelModule):
+    input_columns = ["bbox_ltwh", "bbox_conf", "category_id"]
+    output_columns = ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
+
+    def __init__(self, cfg, device, **kwargs):          # kwargs swallows tracking_dataset (main.py:36-39)
+        super().__init__(batch_size=1)                  # trackers are strictly sequential (oc_sort_api.py:23)
+        self.cfg = cfg
+        self.device = device
+        self._bank = None
+
+    # -- backend -----------------------------------------------------------------------------------------
+    def _make_backend(self):
+        from .._lib import OCSortBank
+        hyper = dict(cfg_get(self.cfg, "hyperparams"))
+        dev = _device_index(self.device)
+        return OCSortBank(**hyper, min_confidence=float(cfg_get(self.cfg, "min_confidence", 0.0)), wrapper_mode=True,
+                          device=dev, max_tracks=int(cfg_get(self.cfg, "max_tracks", 256)),
+                          max_dets=int(cfg_get(self.cfg, "max_dets", 128)))
+
+    def reset(self):
+        """New video: tracker state dropped, ids restart at 1 (oc_sort_api.py:28-30 re-creates the tracker)."""
+        if self._bank is None:
+            self._bank = self._make_backend()
+        else:
+            self._bank.reset(-1)
+
+    # -- plugin API --------------------------------------------------------------------------------------
+    def preprocess(self, image, detections: pd.DataFrame, metadata: pd.Series):
+        if len(detections) == 0:
+            return {"input": []}
+        ltwh = np.stack(detections.bbox_ltwh.to_list())                 # keeps the detector's dtype (float32 for rtmlib)
+        ltrb = np.stack([ltwh[:, 0], ltwh[:, 1], ltwh[:, 0] + ltwh[:, 2], ltwh[:, 1] + ltwh[:, 3]], axis=1)   # ltwh_to_ltrb
+        conf = detections.bbox_conf.to_numpy(dtype=np.float64) if "bbox_conf" in detections else np.ones(len(detections))
+        out = np.empty((len(detections), 7), dtype=np.float64)
+        out[:, :4] = ltrb
+        out[:, 4] = conf
+        out[:, 5] = detections.category_id.to_numpy(dtype=np.float64)
+        out[:, 6] = detections.index.to_numpy().astype(np.int64)
+        return {"input": out}
+
+    def process(self, batch, detections: pd.DataFrame, metadatas: pd.DataFrame):
+        if len(detections) == 0:
+            return []
+        if self._bank is None:
+            self.reset()
+        inputs = to_numpy(batch["input"])
+        inputs = inputs[0] if inputs.ndim == 3 else inputs              # (1, N, 7) after default_collate
+        results = self._bank.update(np.ascontiguousarray(inputs, dtype=np.float64).reshape(-1, 7), 0)
+        if not results.size:
+            return []
+        idxs = results[:, 7].astype(int)
+        assert set(idxs).issubset(detections.index), \
+            "Mismatch of indexes during the tracking. The results should match the detections."
+        ltwh = np.stack([results[:, 0], results[:, 1], results[:, 2] - results[:, 0], results[:, 3] - results[:, 1]], axis=1)
+        return pd.DataFrame({"track_bbox_ltwh": list(ltwh), "track_bbox_conf": list(results[:, 6]),
+                             "track_id": list(results[:, 4])}, index=pd.Index(idxs, name="idxs"))
+
+
+class HipBPBReIDStrongSORT(ImageLevelModule):
+    input_columns = ["bbox_ltwh", "embeddings", "visibility_scores"]
+    output_columns = ["track_id", "track_bbox_kf_ltwh", "track_bbox_pred_kf_ltwh", "matched_with", "costs",
+                      "hits", "age", "time_since_update", "state"]
+
+    def __init__(self, cfg, device, batch_size=None, **kwargs):
+        super().__init__(batch_size=1)
+        self.cfg = cfg
+        self.device = device
+        self._bank = None
+        self._shape = None
+        if cfg_get(cfg, "ecc", False):
+            raise NotImplementedError("ecc camera compensation is not part of the HIP path (reference default: ecc False)")
+
+    def _make_backend(self, parts, dim):
+        from .._lib import BpbssBank
+        c = self.cfg
+        names = ("ema_alpha", "mc_lambda", "max_dist", "motion_criterium", "max_iou_distance", "max_oks_distance", "max_age",
+                 "n_init", "nn_budget", "min_bbox_confidence", "only_position_for_kf_gating",
+                 "max_kalman_prediction_without_update", "matching_strategy", "gating_thres_factor", "w_kfgd", "w_reid", "w_st")
+        kw = {n: cfg_get(c, n) for n in names if cfg_get(c, n) is not None}
+        return BpbssBank(parts, dim, **kw, wrapper_mode=True, device=_device_index(self.device),
+                         max_tracks=int(cfg_get(c, "max_tracks", 512)), max_dets=int(cfg_get(c, "max_dets", 128)))
+
+    def reset(self):
+        if self._bank is not None:
+            self._bank.reset(-1)
+
+    def preprocess(self, image, detections: pd.DataFrame, metadata: pd.Series):
+        if len(detections) == 0:
+            return {"id": [], "bbox_ltwh": [], "reid_features": [], "visibility_scores": [], "scores": [], "classes": [], "frame": []}
+        score = detections.bbox_conf if "bbox_conf" in detections else detections.keypoints_conf
+        return {"id": detections.index.to_numpy(),
+                "bbox_ltwh": np.stack(detections.bbox_ltwh.to_list()),
+                "reid_features": np.stack(detections.embeddings.to_list()),
+                "visibility_scores": np.stack(detections.visibility_scores.to_list()),
+                "scores": np.asarray(score, dtype=np.float64),
+                "classes": np.zeros(len(detections.index)),
+                "frame": np.ones(len(detections.index)) * metadata.frame}
+
+    def process(self, batch, detections: pd.DataFrame, metadatas: pd.DataFrame):
+        if len(detections) == 0:
+            return []
+        ids = _strip(to_numpy(batch["id"]), 1)                      # default_collate adds a leading batch dim of 1
+        ltwh = _strip(to_numpy(batch["bbox_ltwh"]), 2)
+        emb = _strip(to_numpy(batch["reid_features"]), 3)
+        vis = _strip(to_numpy(batch["visibility_scores"]), 2)
+        conf = _strip(to_numpy(batch["scores"]), 1)
+        if self._bank is None:
+            self._bank = self._make_backend(emb.shape[1], emb.shape[2])
+        rows = self._bank.update(ids.astype(np.int64), ltwh.astype(np.float64), emb.astype(np.float32),
+                                 vis.astype(bool).astype(np.uint8), conf.astype(np.float64), 0)
+        assert set(rows["det_id"]).issubset(detections.index), \
+            "Mismatch of indexes during the tracking. The results should match the detections."
+        out = pd.DataFrame({
+            "track_id": rows["track_id"].astype(int),
+            "track_bbox_kf_ltwh": list(rows["kf_ltwh"]),
+            "track_bbox_pred_kf_ltwh": [p if v else None for p, v in zip(rows["pred_ltwh"], rows["pred_valid"])],
+            "matched_with": [(MATCH_NAMES[m], d) if m else None for m, d in zip(rows["matched_name"], rows["matched_dist"])],
+            "costs": [{} for _ in range(len(rows))],      # debug-only dictionaries of the reference are not produced
+            "hits": rows["hits"].astype(int), "age": rows["age"].astype(int),
+            "time_since_update": rows["tsu"].astype(int), "state": [STATE_CHARS[s] for s in rows["state"]],
+        }, index=np.asarray(rows["det_id"]), columns=self.output_columns)
+        return out
+
+
+def _strip(a, ndim):
+    return a[0] if a.ndim == ndim + 1 else a
+
+
+def _device_index(device) -> int:
+    s = str(device)
+    if ":" in s:
+        return int(s.split(":")[1])
+    return 0
