@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py -- tracked frames/s of the GPU-resident detector -> association loop on synthetic 1080p streams.
+"""bench.py -- tracked frames/s of the GPU-resident detect -> (ReID ->) associate loop on synthetic 1080p streams.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2] ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config3|config2] ...
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One rank per GPU; every rank tracks its own stream(s) (seed = global stream id), so throughput scales
-weakly with no data-path collective; RCCL is used only for the barrier / max-time / metric reduction.
-A *step* = `frames_per_step` consecutive frames of each local stream through
-letterbox -> YOLOX forward -> decode+NMS -> OC-SORT, inputs resident in HBM, results copied back
-to pinned host memory. Prints ONE JSON line (rank 0).
+Workloads (BASELINE.json `configs`):
+  config3 (default; the metric's "1080p, 100 dets/frame" configuration): YOLOX-m + part-based ReID (BPBReID shape,
+          384x128 crops, K=6 x D=256) + BPBReID-StrongSORT, 100-object stream.
+  config2 (= configs[1]): YOLOX-s + OC-SORT, 50-object stream.
+One rank per GPU; every rank tracks its own stream(s) (seed = global stream id): weak scaling, no data-path collective;
+RCCL only for the barrier, the max-time reduction and the per-epoch metric all-reduce.
+A *step* = `frames_per_step` consecutive frames of each local stream through the whole chain, inputs resident in HBM,
+results copied back to pinned host memory. Prints ONE JSON line (rank 0).
 """
 from __future__ import annotations
 
@@ -24,31 +27,37 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+from tracklab_amd import dist as tdist  # noqa: E402
 from tracklab_amd.synth import HEIGHT, WIDTH, SyntheticStream, render_frame, synth_yolox_head  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+WORKLOADS = {
+    "config3": dict(detector="m", objects=100, frames_per_step=8, max_dets=104,
+                    name="BASELINE configs[2]/[4] shape: YOLOX-m + part-based ReID (384x128, 6x256) + BPBReID-StrongSORT, "
+                         "synthetic 1080p 100-obj stream"),
+    "config2": dict(detector="s", objects=50, frames_per_step=32, max_dets=128,
+                    name="BASELINE configs[1]: YOLOX-s + OC-SORT (IoU+Kalman, no ReID), synthetic 1080p 50-obj stream"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="config2", choices=["config2"])
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="config3", choices=list(WORKLOADS))
     ap.add_argument("--streams", type=int, default=1, help="streams per GPU")
-    ap.add_argument("--frames-per-step", type=int, default=16)
+    ap.add_argument("--frames-per-step", type=int, default=None)
     ap.add_argument("--objects", type=int, default=None)
     ap.add_argument("--detector", default=None)
-    ap.add_argument("--layout", default="focus_nhwc", choices=["nchw", "nhwc", "focus_nhwc"])
     ap.add_argument("--no-graph", action="store_true", help="eager backbone launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=64)
-    ap.add_argument("--check-frames", type=int, default=32, help="frames verified against the oracle (untimed)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--check-frames", type=int, default=16, help="frames verified against the oracle (untimed)")
     return ap.parse_args()
 
 
 def build_stream_inputs(seed, n_objects, n_frames, ratio):
-    """Per-frame synthetic detector heads (A,6) + the boxes they encode, for one stream."""
     rng = np.random.default_rng(10_000 + seed)
     heads, gts = [], []
     for fr in SyntheticStream(seed, n_objects, n_frames):
@@ -57,52 +66,39 @@ def build_stream_inputs(seed, n_objects, n_frames, ratio):
     return np.stack(heads), gts
 
 
-def oracle_chain(oracle, heads, ratio, tracker_cfg, max_dets, frames_done0=0):
-    """Reference-order CPU chain on the same heads: rtmlib postprocess -> RTMLibDetector rows ->
-    OCSORT.preprocess/process (oracle C port). Returns list of (rows, 8) arrays."""
-    trk = oracle.OCSort(**tracker_cfg["hyper"])
-    outs = []
-    for f, head in enumerate(heads):
-        boxes, scores, cls = oracle.yolox_postprocess(head, 640, float(np.float32(ratio)))
-        l = np.maximum(0, np.minimum(boxes[:, 0], WIDTH - 2)).astype(np.float32)
-        t = np.maximum(0, np.minimum(boxes[:, 1], HEIGHT - 2)).astype(np.float32)
-        r = np.maximum(1, np.minimum(boxes[:, 2], WIDTH - 1)).astype(np.float32)
-        b = np.maximum(1, np.minimum(boxes[:, 3], HEIGHT - 1)).astype(np.float32)
-        w, h = r - l, b - t
-        n = len(boxes)
-        dets = np.zeros((n, 7))
-        dets[:, 0], dets[:, 1], dets[:, 2], dets[:, 3] = l, t, (l + w).astype(np.float32), (t + h).astype(np.float32)
-        dets[:, 4], dets[:, 5] = 1.0, 1.0
-        dets[:, 6] = (frames_done0 + f) * max_dets + np.arange(n)
-        outs.append(oracle.ocsort_wrapper_step(trk, dets, tracker_cfg["min_confidence"]))
-    return outs
+def detector_rows(oracle, head, ratio):
+    """rtmlib postprocess + RTMLibDetector.process in float32 (rtmlib_api.py:27-46): ltwh rows."""
+    boxes, scores, cls = oracle.yolox_postprocess(head, 640, float(np.float32(ratio)))
+    l = np.maximum(0, np.minimum(boxes[:, 0], WIDTH - 2)).astype(np.float32)
+    t = np.maximum(0, np.minimum(boxes[:, 1], HEIGHT - 2)).astype(np.float32)
+    r = np.maximum(1, np.minimum(boxes[:, 2], WIDTH - 1)).astype(np.float32)
+    b = np.maximum(1, np.minimum(boxes[:, 3], HEIGHT - 1)).astype(np.float32)
+    return np.stack([l, t, r - l, b - t], axis=1)
 
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        dist = None
+    world, rank, local_rank = tdist.env_world()
+    dist = tdist.init("nccl") if world > 1 else None
+    if dist is None:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
-
-    n_objects = args.objects or 50
-    detector = args.detector or "s"
-    S, F = args.streams, args.frames_per_step
+    wl = WORKLOADS[args.workload]
+    n_objects = args.objects or wl["objects"]
+    detector = args.detector or wl["detector"]
+    S, F = args.streams, args.frames_per_step or wl["frames_per_step"]
     B = S * F
     total_steps = args.warmup + args.steps
     n_frames = total_steps * F
+    is3 = args.workload == "config3"
 
-    from tracklab_amd.gpu_pipeline import DetTrackPipeline
-    pipe = DetTrackPipeline(detector, n_streams=S, frames_per_step=F, layout=args.layout, device=dev.index,
-                            use_graph=not args.no_graph)
+    from tracklab_amd import gpu_pipeline as gp
+    if is3:
+        pipe = gp.DetReidTrackPipeline(detector, n_streams=S, frames_per_step=F, max_dets=wl["max_dets"], device=dev.index,
+                                       use_graph=not args.no_graph)
+    else:
+        pipe = gp.DetTrackPipeline(detector, n_streams=S, frames_per_step=F, max_dets=wl["max_dets"], device=dev.index,
+                                   use_graph=not args.no_graph)
     ratio = pipe.ratio
 
     # ---- synthetic inputs, resident in HBM before the timed region ----
@@ -112,12 +108,11 @@ def main():
         heads_np.append(h)
         gts.append(g)
     heads_np = np.stack(heads_np)                              # (S, n_frames, A, 6)
-    # step k uses frames [k*F, (k+1)*F) of every stream, ordered stream-major
     heads_steps = np.ascontiguousarray(
         heads_np.reshape(S, total_steps, F, -1, heads_np.shape[-1]).transpose(1, 0, 2, 3, 4)).reshape(
-        total_steps, B, -1, heads_np.shape[-1])
+        total_steps, B, -1, heads_np.shape[-1])                # step k = frames [kF, (k+1)F) of every stream, stream-major
     d_heads = torch.from_numpy(heads_steps).to(dev)
-    pool_steps = 3
+    pool_steps = max(2, min(4, 64 // B))
     prng = np.random.default_rng(123 + rank)
     pool = np.stack([render_frame(prng, gts[(i // F) % S][i % n_frames]["gt_boxes"]) for i in range(pool_steps * B)])
     d_pool = torch.from_numpy(pool).to(dev).reshape(pool_steps, B, HEIGHT, WIDTH, 3)
@@ -127,26 +122,56 @@ def main():
     def run_step(k, fetch=True):
         return pipe.step(d_pool[k % pool_steps], d_heads[k], fetch=fetch)
 
-    # ---- untimed parity check against the oracle chain (first frames of stream 0) ----
+    # ---- untimed parity check against the oracle chain (first frames of local stream 0) ----
     parity = None
     if rank == 0 and args.check_frames > 0:
         import oracle
         oracle.build()
         ksteps = min(total_steps, max(1, (args.check_frames + F - 1) // F))
-        got = []
-        for k in range(ksteps):
-            rows, cnt = run_step(k)
-            pipe.synchronize()
-            for f in range(F):
-                got.append(rows[0, f, :int(cnt[0, f])].numpy().copy())
-        exp = oracle_chain(oracle, heads_np[0][:ksteps * F], ratio, pipe.tracker_cfg, pipe.maxd)
-        ids_ok = all(g.shape == e.shape and np.array_equal(g[:, [4, 7]], e[:, [4, 7]]) for g, e in zip(got, exp))
-        box_ok = ids_ok and all(np.allclose(g, e, rtol=1e-6, atol=1e-3) for g, e in zip(got, exp))
-        parity = {"frames": ksteps * F, "track_ids_equal_oracle": bool(ids_ok), "boxes_close": bool(box_ok),
-                  "tracks": int(max((g[:, 4].max() if len(g) else 0) for g in got))}
+        if is3:
+            ref = oracle.StrongSORT(pipe.K, pipe.D, **pipe.tracker_cfg)
+            ids_ok, tracks, frames_checked = True, 0, 0
+            for k in range(ksteps):
+                h_rows, h_cnt = run_step(k)
+                pipe.synchronize()
+                rows, cnt = pipe.rows_numpy(h_rows, h_cnt)
+                emb = pipe.last["emb"].cpu().numpy().reshape(S, F, pipe.maxd, pipe.K, pipe.D)
+                vis = pipe.last["vis"].cpu().numpy().reshape(S, F, pipe.maxd, pipe.K)
+                for f in range(F):
+                    ltwh32 = detector_rows(oracle, heads_np[0][k * F + f], ratio)
+                    n = len(ltwh32)
+                    ids = (k * B + f) * pipe.maxd + np.arange(n)
+                    exp = ref.update(ids, ltwh32.astype(np.float64), emb[0, f, :n], vis[0, f, :n], np.ones(n)) if n else []
+                    got = rows[0][f]
+                    ok = len(got) == len(exp) and (len(exp) == 0 or (np.array_equal(got["det_id"], exp["det_id"]) and
+                                                                      np.array_equal(got["track_id"], exp["track_id"])))
+                    ids_ok &= bool(ok)
+                    tracks = max(tracks, int(got["track_id"].max()) if len(got) else 0)
+                    frames_checked += 1
+            parity = {"frames": frames_checked, "track_ids_equal_oracle": bool(ids_ok), "tracks": tracks,
+                      "note": "oracle chain = C decode/NMS + C BPBReID-StrongSORT fed with the embeddings the GPU ReID net produced"}
+        else:
+            trk = oracle.OCSort(**pipe.tracker_cfg["hyper"])
+            got, exp = [], []
+            for k in range(ksteps):
+                rows, cnt = run_step(k)
+                pipe.synchronize()
+                for f in range(F):
+                    got.append(rows[0, f, :int(cnt[0, f])].numpy().copy())
+                    ltwh = detector_rows(oracle, heads_np[0][k * F + f], ratio)
+                    n = len(ltwh)
+                    dets = np.zeros((n, 7))
+                    dets[:, 0], dets[:, 1] = ltwh[:, 0], ltwh[:, 1]
+                    dets[:, 2], dets[:, 3] = (ltwh[:, 0] + ltwh[:, 2]).astype(np.float32), (ltwh[:, 1] + ltwh[:, 3]).astype(np.float32)
+                    dets[:, 4], dets[:, 5] = 1.0, 1.0
+                    dets[:, 6] = (k * B + f) * pipe.maxd + np.arange(n)
+                    exp.append(oracle.ocsort_wrapper_step(trk, dets, pipe.tracker_cfg["min_confidence"]))
+            ids_ok = all(g.shape == e.shape and np.array_equal(g[:, [4, 7]], e[:, [4, 7]]) for g, e in zip(got, exp))
+            parity = {"frames": len(got), "track_ids_equal_oracle": bool(ids_ok),
+                      "tracks": int(max((g[:, 4].max() if len(g) else 0) for g in got))}
         pipe.reset()
 
-    # ---- warmup ----
+    # ---- warmup, then the timed region ----
     for k in range(args.warmup):
         run_step(k)
     pipe.synchronize()
@@ -162,84 +187,98 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tracks = torch.tensor([float(pipe.frames_done)], dtype=torch.float64, device=dev)
-        dist.all_reduce(tracks, op=dist.ReduceOp.SUM)      # per-epoch metric reduction (tiny, latency-bound)
+    elapsed = tdist.allreduce_max(time.perf_counter() - t0, dist, dev)
     frames_total = args.steps * B * world
     fps = frames_total / elapsed
+    # per-epoch metric reduction across ranks (tiny, latency-bound): frames + seconds here; HOTA statistics use the same call
+    stats = tdist.allreduce_sum(np.array([args.steps * B, elapsed]), dist, dev)
 
-    # ---- roofline of the dominant byte-moving libtlk kernel (letterbox): HIP events on the launch stream around
-    # every letterbox launch of K further steps of the same workload (eager launches so that events can bracket
-    # the kernel; inside the timed region above it is a node of the replayed hipGraph) ----
+    # ---- roofline of the dominant byte-moving libtlk kernel: HIP events on the launch stream around every launch of
+    # K further steps of the same workload ----
     pipe.record_kernel_events = True
     pipe.kernel_events.clear()
     for k in range(args.warmup, total_steps):
         run_step(k)
     pipe.synchronize()
     pipe.record_kernel_events = False
-    lb_ms = [e0.elapsed_time(e1) for e0, e1 in pipe.kernel_events]
-    lb_ms_avg = float(np.mean(lb_ms)) if lb_ms else float("nan")
-    rh, rw = int(HEIGHT * ratio), int(WIDTH * ratio)
-    from tracklab_amd.roofline import letterbox_bytes
-    alg_bytes = letterbox_bytes(HEIGHT, WIDTH, 640, rh, rw, elem_bytes=2) * B
-    achieved = alg_bytes / (lb_ms_avg * 1e-3) / 1e9 if lb_ms else None
+    k_ms = [e0.elapsed_time(e1) for e0, e1 in pipe.kernel_events]
+    k_ms_avg = float(np.mean(k_ms)) if k_ms else float("nan")
+    from tracklab_amd import roofline as rl
+    if is3:
+        kname, tfile = "crop_kernel", "crop_traffic.json"
+        # mean crop of the synthetic stream: w~U(40,120), h=w*U(1.8,2.6) -> E[w*h] = E[w^2]*2.2
+        cnt_mean = float(np.mean([len(g["dets"]) for g in gts[0][:64]]))
+        ew2 = (120 ** 3 - 40 ** 3) / (3 * 80)
+        alg_bytes = B * (cnt_mean * ew2 * 2.2 * 3 + pipe.maxd * 3 * pipe.reid_hw[0] * pipe.reid_hw[1] * 2)
+    else:
+        kname, tfile = "letterbox_kernel", "letterbox_traffic.json"
+        rh, rw = int(HEIGHT * ratio), int(WIDTH * ratio)
+        alg_bytes = rl.letterbox_bytes(HEIGHT, WIDTH, 640, rh, rw, elem_bytes=2) * B
+    achieved = alg_bytes / (k_ms_avg * 1e-3) / 1e9 if k_ms else None
     traffic = None
-    tpath = os.path.join(REPO, "profiles", "letterbox_traffic.json")
+    tpath = os.path.join(REPO, "profiles", tfile)
     if os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"kernel": "letterbox_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                "avg_launch_ms": lb_ms_avg, "algorithmic_bytes_per_launch": alg_bytes}
+                "avg_launch_ms": k_ms_avg, "algorithmic_bytes_per_launch": alg_bytes}
 
-    # ---- CPU baseline: the same chain on host cores (oracle port + torch CPU forward), bounded sample ----
+    # ---- CPU baseline: the same chain on host cores (oracle C port + torch CPU forwards), bounded sample ----
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         import oracle
         oracle.build()
+        from tracklab_amd.backbones.reid import part_based_reid
         from tracklab_amd.backbones.yolox import yolox
-        nfr = min(args.cpu_frames, n_frames)
-        cpu_model = yolox(detector, device="cpu", dtype=torch.float32, channels_last=False)
+        cpu_det = yolox(detector, device="cpu", dtype=torch.float32, channels_last=False)
+        cpu_reid = part_based_reid(6, 256, device="cpu", dtype=torch.float32, channels_last=False) if is3 else None
         frame = render_frame(np.random.default_rng(5), gts[0][0]["gt_boxes"])
-        trk = oracle.OCSort(**pipe.tracker_cfg["hyper"])
+        trk = oracle.StrongSORT(6, 256, **pipe.tracker_cfg) if is3 else oracle.OCSort(**pipe.tracker_cfg["hyper"])
         tc0 = time.perf_counter()
         done = 0
         with torch.no_grad():
-            for f in range(nfr):
-                img, r = oracle.letterbox(frame, 640)
-                _ = cpu_model(torch.from_numpy(img)[None])
-                boxes, scores, cls = oracle.yolox_postprocess(heads_np[0][f], 640, float(np.float32(ratio)))
-                n = len(boxes)
-                dets = np.zeros((n, 7))
-                dets[:, :4] = boxes
-                dets[:, 4], dets[:, 5], dets[:, 6] = 1.0, 1.0, np.arange(n)
-                oracle.ocsort_wrapper_step(trk, dets, pipe.tracker_cfg["min_confidence"])
+            for f in range(n_frames):
+                img, _ = oracle.letterbox(frame, 640)
+                cpu_det(torch.from_numpy(img)[None])
+                ltwh = detector_rows(oracle, heads_np[0][f], ratio)
+                n = len(ltwh)
+                if is3:
+                    ltrb = oracle.ltwh_to_crop_ltrb(ltwh.astype(np.float64), WIDTH, HEIGHT)
+                    crops = oracle.crop_resize_norm(frame, ltrb, 384, 128)
+                    emb, vis = cpu_reid(torch.from_numpy(crops))
+                    trk.update(np.arange(n) + f * 1000, ltwh.astype(np.float64), emb.numpy(), vis.numpy(), np.ones(n))
+                else:
+                    dets = np.zeros((n, 7))
+                    dets[:, :2] = ltwh[:, :2]
+                    dets[:, 2:4] = ltwh[:, :2] + ltwh[:, 2:]
+                    dets[:, 4], dets[:, 5], dets[:, 6] = 1.0, 1.0, np.arange(n)
+                    oracle.ocsort_wrapper_step(trk, dets, pipe.tracker_cfg["min_confidence"])
                 done += 1
-                if time.perf_counter() - tc0 > 25:
+                if time.perf_counter() - tc0 > args.cpu_seconds:
                     break
         cpu_t = time.perf_counter() - tc0
+        chain = ("oracle C letterbox + YOLOX-%s fp32 (torch CPU, batch 1) + oracle C decode/NMS" % detector) + \
+                (" + oracle C crop-resize-normalize + part-based ReID R50 fp32 (torch CPU, 100 crops/batch) + oracle C BPBReID-StrongSORT"
+                 if is3 else " + oracle C OC-SORT")
         cpu = {"value": done / cpu_t, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": f"{done} frames of the same stream: oracle C letterbox + YOLOX-{detector} fp32 forward on torch CPU "
-                         f"(batch 1, {torch.get_num_threads()} threads) + oracle C decode/NMS + oracle C OC-SORT"}
+               "sample": f"{done} frames of the same stream in {cpu_t:.1f} s: {chain}"}
 
     if rank == 0:
         line = {
-            "metric": "tracked frames/sec/GPU (1080p) + HOTA vs reference",
+            "metric": "tracked frames/sec/GPU (1080p, 100 dets/frame) + HOTA vs reference",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16",
-            "data": "synthetic 1080p streams resident in HBM; random-init YOLOX (no checkpoints offline): the full forward "
-                    "runs, its head activations are replaced by a synthetic head encoding the stream's boxes + NMS duplicates",
-            "config": {"workload": f"BASELINE configs[1]: YOLOX-{detector} + OC-SORT (IoU+Kalman, no ReID), synthetic 1080p "
-                                   f"{n_objects}-obj stream", "streams_per_gpu": S, "frames_per_step": F,
-                       "frames_per_gpu_per_step": B, "parallelism": f"stream-parallel x{world}", "layout": args.layout},
-            "per_gpu_fps": fps / world,
+            "data": "synthetic 1080p streams resident in HBM; random-init backbones (no checkpoints offline): every forward runs in "
+                    "full, the detector's head activations are replaced by a synthetic head that encodes the stream's boxes + NMS "
+                    "duplicates; ReID embeddings are whatever the random-init network produces for the crops",
+            "config": {"workload": wl["name"].replace("100-obj", f"{n_objects}-obj").replace("50-obj", f"{n_objects}-obj"),
+                       "detector": f"yolox-{detector}", "streams_per_gpu": S, "frames_per_step": F,
+                       "frames_per_gpu_per_step": B, "parallelism": f"stream-parallel x{world}", "hip_graphs": not args.no_graph},
+            "per_gpu_fps": fps / world, "frames_total": float(stats[0]),
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(line), flush=True)

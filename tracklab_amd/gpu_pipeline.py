@@ -156,3 +156,155 @@ class DetTrackPipeline:
     def close(self):
         self.graphs.clear()
         self.bank.close()
+
+
+class DetReidTrackPipeline:
+    """BASELINE.json configs[2]/[4]: YOLOX -> part-based ReID -> BPBReID-StrongSORT, GPU-resident.
+
+    A step = ``frames_per_step`` consecutive frames of each of ``n_streams`` streams:
+      letterbox + YOLOX forward (hipGraph) -> decode+NMS -> ROI crop-resize-normalize of every detection straight
+      from the frames in HBM (1 launch) -> ReID forward (hipGraph) -> per frame: part-norms, MFMA part distance,
+      association (3 launches) on a side stream that overlaps the next step's detector/ReID forwards.
+    """
+
+    def __init__(self, detector: str = "m", n_streams: int = 1, frames_per_step: int = 8, max_dets: int = 104,
+                 height: int = 1080, width: int = 1920, size: int = 640, dtype=torch.float16, device: int = 0,
+                 parts: int = 6, dim: int = 256, reid_hw=(384, 128), tracker_cfg: dict | None = None,
+                 nms_thr: float = 0.45, score_thr: float = 0.7, max_tracks: int = 512, use_graph: bool = True):
+        from .backbones.reid import part_based_reid
+        self.S, self.F, self.maxd = n_streams, frames_per_step, max_dets
+        self.H, self.W, self.size, self.dtype = height, width, size, dtype
+        self.K, self.D, self.reid_hw = parts, dim, reid_hw
+        self.nms_thr, self.score_thr = nms_thr, score_thr
+        self.dev = torch.device("cuda", device)
+        torch.cuda.set_device(self.dev)
+        self.tracker_cfg = tracker_cfg or dict(      # tracklab/configs/modules/track/bpbreid_strong_sort.yaml:3-21
+            ema_alpha=0.9, mc_lambda=0.995, max_dist=0.5, motion_criterium="iou", max_iou_distance=0.8, max_oks_distance=0.7,
+            max_age=300, n_init=0, nn_budget=100, min_bbox_confidence=0.0, only_position_for_kf_gating=False,
+            max_kalman_prediction_without_update=7, matching_strategy="strong_sort_matching", gating_thres_factor=1,
+            w_kfgd=1, w_reid=1, w_st=1)
+        self.model = yolox(detector, 1, device=self.dev, dtype=dtype, channels_last=True)
+        self.reid = part_based_reid(parts, dim, device=self.dev, dtype=dtype, channels_last=True)
+        self.bank = _lib.BpbssBank(parts, dim, **self.tracker_cfg, wrapper_mode=True, n_streams=n_streams, device=device,
+                                   max_tracks=max_tracks, max_dets=max_dets)
+        B = n_streams * frames_per_step
+        self.B = B
+        dev = self.dev
+        self.lb = torch.empty((B, size // 2, size // 2, 12), dtype=dtype, device=dev)
+        self.crops = torch.empty((B * max_dets, reid_hw[0], reid_hw[1], 3), dtype=dtype, device=dev)
+        self.det = {"ltwh": torch.zeros((B, max_dets, 4), dtype=torch.float32, device=dev),
+                    "xyxy": torch.zeros((B, max_dets, 4), dtype=torch.float32, device=dev),
+                    "scores": torch.zeros((B, max_dets), dtype=torch.float32, device=dev),
+                    "cls": torch.zeros((B, max_dets), dtype=torch.int32, device=dev),
+                    "counts": torch.zeros((B,), dtype=torch.int32, device=dev)}
+        self.conf = torch.ones((B, max_dets), dtype=torch.float64, device=dev)        # RTMLibDetector: bbox_conf = 1.0
+        self.id_off = torch.arange(B * max_dets, dtype=torch.int64, device=dev).reshape(B, max_dets)
+        self.nbuf = 2
+        self.bufs = []
+        row_bytes = _lib.BPBSS_ROW.itemsize
+        for _ in range(self.nbuf):
+            self.bufs.append({
+                "ids": torch.zeros((B, max_dets), dtype=torch.int64, device=dev),
+                "ltwh": torch.zeros((B, max_dets, 4), dtype=torch.float64, device=dev),
+                "emb": torch.zeros((B, max_dets, parts, dim), dtype=torch.float32, device=dev),
+                "vis": torch.zeros((B, max_dets, parts), dtype=torch.uint8, device=dev),
+                "counts": torch.zeros((B,), dtype=torch.int32, device=dev),
+                "rows": torch.zeros((B, max_dets, row_bytes), dtype=torch.uint8, device=dev),
+                "ocnt": torch.zeros((B,), dtype=torch.int32, device=dev),
+                "h_rows": torch.zeros((B, max_dets, row_bytes), dtype=torch.uint8).pin_memory(),
+                "h_ocnt": torch.zeros((B,), dtype=torch.int32).pin_memory(),
+                "ready": torch.cuda.Event(), "done": torch.cuda.Event()})
+        self.trk_stream = torch.cuda.Stream(device=dev)
+        self.use_graph = use_graph
+        self.det_graphs, self.reid_graph = {}, None
+        self.step_idx = 0
+        self.frames_done = 0
+        self.ratio = min(size / height, size / width)
+        self.kernel_events = []
+        self.record_kernel_events = False
+
+    def reset(self):
+        torch.cuda.synchronize(self.dev)
+        self.bank.reset(-1)
+        self.frames_done = 0
+
+    def synchronize(self):
+        self.trk_stream.synchronize()
+        torch.cuda.current_stream(self.dev).synchronize()
+
+    def _graphed(self, cache, key, fn):
+        ent = cache.get(key)
+        if ent is None:
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    fn()
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = fn()
+            ent = (g, out)
+            cache[key] = ent
+        ent[0].replay()
+        return ent[1]
+
+    @torch.no_grad()
+    def step(self, frames: torch.Tensor, synth_head: torch.Tensor | None = None, fetch: bool = True):
+        S, F, maxd = self.S, self.F, self.maxd
+        buf = self.bufs[self.step_idx % self.nbuf]
+        self.step_idx += 1
+        main = torch.cuda.current_stream(self.dev)
+        main.wait_event(buf["done"])
+
+        def det_fwd():
+            x, _ = _lib.letterbox(frames, self.size, "focus_nhwc", self.dtype, out=self.lb)
+            return self.model(x, focused=True)
+        pred = self._graphed(self.det_graphs, frames.data_ptr(), det_fwd) if self.use_graph else det_fwd()
+        if synth_head is not None:
+            pred = torch.add(synth_head, torch.nan_to_num(pred), alpha=0.0)
+        _lib.yolox_decode_nms(pred, self.size, float(np.float32(self.ratio)), self.W, self.H, maxd, self.nms_thr,
+                              self.score_thr, out=self.det)
+        if self.record_kernel_events:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        crops = _lib.roi_crop_resize_norm(frames, self.det["ltwh"], self.det["counts"], self.reid_hw[0], self.reid_hw[1],
+                                          "nhwc", self.dtype, out=self.crops)
+        if self.record_kernel_events:
+            e1.record()
+            self.kernel_events.append((e0, e1))
+        if self.use_graph:
+            emb, vis = self._graphed(self.__dict__.setdefault("_rg", {}), 0, lambda: self.reid(crops))
+        else:
+            emb, vis = self.reid(crops)
+        # hand-off buffers for the association stream (detector ltwh is float32: widen like numpy would)
+        buf["emb"].copy_(emb.view(self.B, maxd, self.K, self.D))
+        buf["vis"].copy_(vis.view(self.B, maxd, self.K))
+        buf["ltwh"].copy_(self.det["ltwh"])
+        buf["counts"].copy_(self.det["counts"])
+        torch.add(self.id_off, self.frames_done * maxd, out=buf["ids"])
+        buf["ready"].record(main)
+        self.frames_done += S * F
+        with torch.cuda.stream(self.trk_stream):
+            self.trk_stream.wait_event(buf["ready"])
+            self.bank.update_dev(buf["ids"].data_ptr(), buf["ltwh"].data_ptr(), buf["emb"].data_ptr(), buf["vis"].data_ptr(),
+                                 self.conf.data_ptr(), buf["counts"].data_ptr(), F, buf["rows"].data_ptr(), maxd,
+                                 buf["ocnt"].data_ptr(), C.c_void_p(self.trk_stream.cuda_stream))
+            if fetch:
+                buf["h_rows"].copy_(buf["rows"], non_blocking=True)
+                buf["h_ocnt"].copy_(buf["ocnt"], non_blocking=True)
+            buf["done"].record(self.trk_stream)
+        self.last = buf
+        return (buf["h_rows"], buf["h_ocnt"]) if fetch else (buf["rows"], buf["ocnt"])
+
+    def rows_numpy(self, h_rows, h_ocnt):
+        """(S, F) nested lists of structured row arrays from the pinned result block."""
+        r = h_rows.numpy().view(_lib.BPBSS_ROW).reshape(self.S, self.F, self.maxd)
+        c = h_ocnt.numpy().reshape(self.S, self.F)
+        return [[r[s, f, :max(int(c[s, f]), 0)].copy() for f in range(self.F)] for s in range(self.S)], c
+
+    def close(self):
+        self.det_graphs.clear()
+        self.__dict__.pop("_rg", None)
+        self.bank.close()
