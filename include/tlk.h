@@ -197,6 +197,15 @@ int tlk_yolox_decode_nms(const float *pred_dev, int batch, int size, int num_cla
                          float *scores_dev, int32_t *cls_dev, int32_t *counts_dev, double *trk_in_dev,
                          int64_t det_id_base, double category_id, void *hip_stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused convolution epilogue for the PyTorch-ROCm backbones (not a reference function: the reference's
+ * backbones run inside third-party ONNXRuntime / torchreid): x = act(x + bias[c] (+ residual)) in place on a
+ * channels-last activation viewed as (rows, channels), channels % 8 == 0. act: 0 none, 1 ReLU, 2 SiLU.
+ * dtype TLK_F16 or TLK_BF16; bias has `channels` elements of the same dtype; residual may be NULL.
+ * ------------------------------------------------------------------------------------------ */
+int tlk_bias_act_nhwc(void *x_dev, const void *bias_dev, const void *residual_dev, long long rows, int channels,
+                      int act_kind, int dtype, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,3 +113,22 @@ def test_yolox_decode_nms_matches_oracle(orc, num_classes, nobj):
         bt = np.maximum(1, np.minimum(eb[:, 3], 1079)).astype(np.float32)
         exp_ltwh = np.stack([l, t, r - l, bt - t], 1)
         np.testing.assert_allclose(out["ltwh"][b, :n].cpu().numpy(), exp_ltwh, rtol=2e-6, atol=2e-4)
+
+
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("act", ["relu", "silu", None])
+def test_fused_bias_act_epilogue_matches_torch(dtype_name, act):
+    import torch
+    from tracklab_amd import _lib
+    dtype = getattr(torch, dtype_name)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((5, 72, 13, 11), generator=g, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    res = torch.randn((5, 72, 13, 11), generator=g, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn((72,), generator=g, device="cuda").to(dtype)
+    for r in (None, res):
+        ref = x.float() + bias.float().view(1, -1, 1, 1) + (r.float() if r is not None else 0)
+        ref = torch.relu(ref) if act == "relu" else (torch.nn.functional.silu(ref) if act == "silu" else ref)
+        got = _lib.bias_act_(x.clone(memory_format=torch.channels_last), bias, act, r)
+        torch.cuda.synchronize()
+        tol = 2e-3 if dtype == torch.float16 else 1.6e-2          # one rounding to the storage dtype (+ fast exp in SiLU)
+        torch.testing.assert_close(got.float(), ref.to(dtype).float(), rtol=tol, atol=tol)

@@ -361,3 +361,25 @@ def partdist(q, qvis, g, gvis):
     check(L.tlk_partdist_f32(q.data_ptr(), qvis.data_ptr(), T, g.data_ptr(), gvis.data_ptr(), N, K, D, out.data_ptr(),
                              current_stream_ptr()))
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# fused conv epilogue (bias + activation (+ residual)) for channels-last backbones
+# ------------------------------------------------------------------------------------------------
+ACT = {None: 0, "none": 0, "relu": 1, "silu": 2}
+
+
+def bias_act_(x, bias, act="relu", residual=None):
+    """In place: x = act(x + bias[c] (+ residual)) for a channels-last (N,C,H,W) fp16/bf16 cuda tensor."""
+    import torch
+    L = lib()
+    if not getattr(L, "_epi_bound", False):
+        L.tlk_bias_act_nhwc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L._epi_bound = True
+    N, Cc, H, W = x.shape
+    assert x.is_contiguous(memory_format=torch.channels_last) and bias.dtype == x.dtype and bias.is_contiguous()
+    if residual is not None:
+        assert residual.shape == x.shape and residual.dtype == x.dtype and residual.is_contiguous(memory_format=torch.channels_last)
+    check(L.tlk_bias_act_nhwc(x.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
+                              N * H * W, Cc, ACT[act], _dtype_code(x.dtype), current_stream_ptr()))
+    return x

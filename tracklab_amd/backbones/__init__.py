@@ -2,5 +2,11 @@
 PyTorch (MIOpen / hipBLASLt); everything around them is libtlk. Random-init weights of the named
 architectures (no network access for checkpoints); BatchNorm is folded into the convolutions, as any
 inference deployment does."""
-from .yolox import YOLOX, yolox  # noqa: F401
-from .reid import PartBasedReID  # noqa: F401
+import os as _os
+
+# MIOpen's Find step times every applicable solver once per new convolution shape; its reference "naive" solver takes
+# ~140 ms per shape at ReID batch sizes (60+ s of start-up for ResNet-50). It is never the winner: leave it out.
+_os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
+
+from .yolox import YOLOX, yolox  # noqa: F401,E402
+from .reid import PartBasedReID  # noqa: F401,E402

@@ -1,0 +1,61 @@
+"""Shared pieces of the backbones: convolution (no bias) + ONE fused libtlk epilogue pass."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def epilogue_(x: torch.Tensor, bias: torch.Tensor, act: str | None, residual: torch.Tensor | None = None) -> torch.Tensor:
+    """x = act(x + bias[c] (+ residual)). On the GPU (fp16/bf16, channels-last) this is one in-place
+    ``tlk_bias_act_nhwc`` launch instead of MIOpen's bias op-tensor + activation + add passes; elsewhere
+    (the CPU forward of bench.py's cpu_baseline) plain torch ops."""
+    if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.shape[1] % 8 == 0 \
+            and x.is_contiguous(memory_format=torch.channels_last):
+        from .. import _lib
+        if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
+            residual = residual.contiguous(memory_format=torch.channels_last)
+        return _lib.bias_act_(x, bias, act, residual)
+    y = x + bias.view(1, -1, 1, 1)
+    if residual is not None:
+        y = y + residual
+    if act == "relu":
+        return F.relu(y, inplace=True)
+    if act == "silu":
+        return F.silu(y, inplace=True)
+    return y
+
+
+class ConvBiasAct(nn.Module):
+    """Conv2d (BatchNorm folded into weight + bias) followed by the fused epilogue."""
+
+    def __init__(self, cin, cout, k=1, s=1, act="silu"):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, s, (k - 1) // 2, bias=False)
+        self.bias = nn.Parameter(torch.zeros(cout))
+        self.act = act
+
+    def forward(self, x, residual=None):
+        return epilogue_(self.conv(x), self.bias, self.act, residual)
+
+
+def random_init_(module: nn.Module, seed: int = 0) -> nn.Module:
+    """Variance-preserving random weights (no checkpoints offline); biases zero."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in module.parameters():
+            if p.dim() > 1:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) * (1.0 / fan_in) ** 0.5)
+            else:
+                p.zero_()
+    return module
+
+
+def finalize(module: nn.Module, device, dtype, channels_last: bool) -> nn.Module:
+    module = module.eval().to(device=device, dtype=dtype)
+    if channels_last:
+        module = module.to(memory_format=torch.channels_last)
+    for p in module.parameters():
+        p.requires_grad_(False)
+    return module

@@ -4,28 +4,28 @@ pixel-wise part classifier, attention-weighted pooling per part).
 The reference runs this through the third-party torchreid fork
 (tracklab/wrappers/reid/kpreid_api.py:147-182, configs/modules/reid/bpbreid.yaml: 384x128 input,
 ``dim_reduce_output: 256``, five body parts + foreground = K 6) and emits ``embeddings (N,K,D) f32``
-and ``visibility_scores (N,K) bool``. Random-init here (no checkpoints offline); BN folded.
+and ``visibility_scores (N,K) bool``. Random-init here (no checkpoints offline); BN folded into conv weight + bias;
+every conv is followed by ONE fused libtlk epilogue launch (bias + ReLU (+ residual)).
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
+
+from .common import ConvBiasAct, finalize, random_init_
 
 
 class _Bottleneck(nn.Module):
     def __init__(self, cin, planes, stride=1, down=False):
         super().__init__()
-        self.c1 = nn.Conv2d(cin, planes, 1, bias=True)
-        self.c2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=True)
-        self.c3 = nn.Conv2d(planes, planes * 4, 1, bias=True)
-        self.down = nn.Conv2d(cin, planes * 4, 1, stride, bias=True) if down else None
+        self.c1 = ConvBiasAct(cin, planes, 1, 1, "relu")
+        self.c2 = ConvBiasAct(planes, planes, 3, stride, "relu")
+        self.c3 = ConvBiasAct(planes, planes * 4, 1, 1, "relu")             # ReLU applied after the residual add
+        self.down = ConvBiasAct(cin, planes * 4, 1, stride, None) if down else None
 
     def forward(self, x):
         idt = x if self.down is None else self.down(x)
-        y = F.relu(self.c1(x), inplace=True)
-        y = F.relu(self.c2(y), inplace=True)
-        return F.relu(self.c3(y) + idt, inplace=True)
+        return self.c3(self.c2(self.c1(x)), residual=idt)
 
 
 def _layer(cin, planes, n, stride):
@@ -36,18 +36,18 @@ def _layer(cin, planes, n, stride):
 class PartBasedReID(nn.Module):
     def __init__(self, parts=6, dim=256, vis_threshold=0.5):
         super().__init__()
-        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=True)
+        self.conv1 = ConvBiasAct(3, 64, 7, 2, "relu")
         self.pool = nn.MaxPool2d(3, 2, 1)
         self.layer1 = _layer(64, 64, 3, 1)
         self.layer2 = _layer(256, 128, 4, 2)
         self.layer3 = _layer(512, 256, 6, 2)
         self.layer4 = _layer(1024, 512, 3, 1)          # last_stride = 1 (BPBReID)
-        self.reduce = nn.Conv2d(2048, dim, 1, bias=True)
+        self.reduce = ConvBiasAct(2048, dim, 1, 1, None)
         self.part_cls = nn.Conv2d(dim, parts, 1, bias=True)   # foreground + (parts-1) body parts
         self.parts, self.dim, self.vis_threshold = parts, dim, vis_threshold
 
     def forward(self, x):
-        x = self.pool(F.relu(self.conv1(x), inplace=True))
+        x = self.pool(self.conv1(x))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         f = self.reduce(x)                                   # (N, D, h, w)
         att = torch.softmax(self.part_cls(f).float(), dim=1)  # (N, K, h, w) pixel-wise part attention
@@ -60,18 +60,4 @@ class PartBasedReID(nn.Module):
 
 
 def part_based_reid(parts=6, dim=256, device="cuda", dtype=torch.float16, channels_last=True, seed=0):
-    g = torch.Generator().manual_seed(seed)
-    m = PartBasedReID(parts, dim)
-    with torch.no_grad():
-        for p in m.parameters():
-            if p.dim() > 1:
-                fan_in = p[0].numel()
-                p.copy_(torch.randn(p.shape, generator=g) * (1.0 / fan_in) ** 0.5)
-            else:
-                p.zero_()
-    m = m.eval().to(device=device, dtype=dtype)
-    if channels_last:
-        m = m.to(memory_format=torch.channels_last)
-    for p in m.parameters():
-        p.requires_grad_(False)
-    return m
+    return finalize(random_init_(PartBasedReID(parts, dim), seed), device, dtype, channels_last)

@@ -14,17 +14,10 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from .common import ConvBiasAct as Conv
+from .common import finalize, random_init_
+
 SIZES = {"tiny": (0.33, 0.375), "s": (0.33, 0.50), "m": (0.67, 0.75), "l": (1.0, 1.0), "x": (1.33, 1.25)}
-
-
-class Conv(nn.Module):
-    def __init__(self, cin, cout, k=1, s=1):
-        super().__init__()
-        self.conv = nn.Conv2d(cin, cout, k, s, (k - 1) // 2, bias=True)   # BN folded
-        self.act = nn.SiLU(inplace=True)
-
-    def forward(self, x):
-        return self.act(self.conv(x))
 
 
 class Bottleneck(nn.Module):
@@ -160,18 +153,4 @@ class YOLOX(nn.Module):
 
 def yolox(size="s", num_classes=1, device="cuda", dtype=torch.float16, channels_last=True, seed=0):
     """Random-init (no checkpoints offline) YOLOX-`size`, eval mode, on `device` in `dtype`."""
-    g = torch.Generator().manual_seed(seed)
-    m = YOLOX(size, num_classes)
-    with torch.no_grad():
-        for p in m.parameters():
-            if p.dim() > 1:
-                fan_in = p[0].numel()
-                p.copy_(torch.randn(p.shape, generator=g) * (1.0 / fan_in) ** 0.5)
-            else:
-                p.zero_()
-    m = m.eval().to(device=device, dtype=dtype)
-    if channels_last:
-        m = m.to(memory_format=torch.channels_last)
-    for p in m.parameters():
-        p.requires_grad_(False)
-    return m
+    return finalize(random_init_(YOLOX(size, num_classes), seed), device, dtype, channels_last)
