@@ -6,6 +6,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+import os as _os
+
+USE_GEMM_1X1 = _os.environ.get("TLK_CONV1X1_GEMM", "1") != "0"
+
+
 def epilogue_(x: torch.Tensor, bias: torch.Tensor, act: str | None, residual: torch.Tensor | None = None) -> torch.Tensor:
     """x = act(x + bias[c] (+ residual)). On the GPU (fp16/bf16, channels-last) this is one in-place
     ``tlk_bias_act_nhwc`` launch instead of MIOpen's bias op-tensor + activation + add passes; elsewhere
@@ -36,7 +41,15 @@ class ConvBiasAct(nn.Module):
         self.act = act
 
     def forward(self, x, residual=None):
-        return epilogue_(self.conv(x), self.bias, self.act, residual)
+        if USE_GEMM_1X1 and self.conv.kernel_size == (1, 1) and self.conv.stride == (1, 1) and x.is_cuda \
+                and x.is_contiguous(memory_format=torch.channels_last):
+            # a channels-last 1x1 convolution IS a plain GEMM (rows = N*H*W): hand it to hipBLASLt
+            n, c, h, w = x.shape
+            y = F.linear(x.permute(0, 2, 3, 1).reshape(-1, c), self.conv.weight.reshape(self.conv.out_channels, c))
+            y = y.view(n, h, w, -1).permute(0, 3, 1, 2)
+        else:
+            y = self.conv(x)
+        return epilogue_(y, self.bias, self.act, residual)
 
 
 def random_init_(module: nn.Module, seed: int = 0) -> nn.Module:
