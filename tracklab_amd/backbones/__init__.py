@@ -10,3 +10,7 @@ _os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
 
 from .yolox import YOLOX, yolox  # noqa: F401,E402
 from .reid import PartBasedReID  # noqa: F401,E402
+
+if _os.environ.get("TLK_MIOPEN_BENCHMARK", "0") == "1":      # exhaustive MIOpen find (slow start-up), opt-in
+    import torch as _torch
+    _torch.backends.cudnn.benchmark = True
