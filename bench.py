@@ -32,7 +32,7 @@ from tracklab_amd.synth import HEIGHT, WIDTH, SyntheticStream, render_frame, syn
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 WORKLOADS = {
-    "config3": dict(detector="m", objects=100, frames_per_step=8, max_dets=104,
+    "config3": dict(detector="m", objects=100, frames_per_step=24, max_dets=104,
                     name="BASELINE configs[2]/[4] shape: YOLOX-m + part-based ReID (384x128, 6x256) + BPBReID-StrongSORT, "
                          "synthetic 1080p 100-obj stream"),
     "config2": dict(detector="s", objects=50, frames_per_step=32, max_dets=128,
@@ -205,13 +205,13 @@ def main():
     k_ms_avg = float(np.mean(k_ms)) if k_ms else float("nan")
     from tracklab_amd import roofline as rl
     if is3:
-        kname, tfile = "crop_kernel", "crop_traffic.json"
+        kname, tfile = "crop_lds_kernel", "crop_traffic.json"
         # mean crop of the synthetic stream: w~U(40,120), h=w*U(1.8,2.6) -> E[w*h] = E[w^2]*2.2
         cnt_mean = float(np.mean([len(g["dets"]) for g in gts[0][:64]]))
         ew2 = (120 ** 3 - 40 ** 3) / (3 * 80)
         alg_bytes = B * (cnt_mean * ew2 * 2.2 * 3 + pipe.maxd * 3 * pipe.reid_hw[0] * pipe.reid_hw[1] * 2)
     else:
-        kname, tfile = "letterbox_kernel", "letterbox_traffic.json"
+        kname, tfile = "letterbox_lds_kernel", "letterbox_traffic.json"
         rh, rw = int(HEIGHT * ratio), int(WIDTH * ratio)
         alg_bytes = rl.letterbox_bytes(HEIGHT, WIDTH, 640, rh, rw, elem_bytes=2) * B
     achieved = alg_bytes / (k_ms_avg * 1e-3) / 1e9 if k_ms else None

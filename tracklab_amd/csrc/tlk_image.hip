@@ -211,6 +211,266 @@ __global__ void __launch_bounds__(BLOCK) crop_kernel(const unsigned char *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// LDS-staged variants (the fast paths). A workgroup owns a band of output rows: it (1) stages the source-row
+// segments the band samples into LDS with coalesced 16-byte global loads (each source byte leaves HBM/L2 once per band
+// instead of once per tap through the texture-address path), (2) builds the cv2 coefficient tables of the band once,
+// (3) lets every thread produce 8 output pixels from LDS and emit 16-byte stores.
+// ---------------------------------------------------------------------------------------------
+constexpr int STAGE_PAD = 32;           // bytes of slack per staged row (alignment shift + clamped x+1 tap)
+
+// Copy bytes [g0, g0+len) of global memory to LDS so that byte g lands at lds[(g - (g0 & ~15))]; 16-byte loads on the
+// aligned body, byte loads on a tail that would cross `gend` (end of the allocation).
+__device__ __forceinline__ void stage_row(const unsigned char *__restrict__ g0, int len, unsigned char *lds, const unsigned char *gend,
+                                          int tid, int nthreads)
+{
+    const uintptr_t a0 = (uintptr_t)g0 & ~(uintptr_t)15;
+    const int shift = (int)((uintptr_t)g0 - a0);
+    const int chunks = (shift + len + 15) >> 4;
+    const unsigned char *src = (const unsigned char *)a0;
+    for (int c = tid; c < chunks; c += nthreads) {
+        const unsigned char *p = src + (size_t)c * 16;
+        if (p + 16 <= gend) *reinterpret_cast<uint4 *>(lds + c * 16) = *reinterpret_cast<const uint4 *>(p);
+        else for (int k = 0; k < 16 && p + k < gend; ++k) lds[c * 16 + k] = p[k];
+    }
+}
+
+struct XCoef { short off; short w0, w1, pad; };       // byte offset of tap 0 inside the staged row, weights; tap 1 = off + step
+static_assert(sizeof(XCoef) == 8, "XCoef");
+
+// ---- crop: workgroup = (slot, band of CROP_BAND output rows); OW <= 256
+constexpr int CROP_BAND = 16;
+constexpr int CROP_LDS_ROW_BYTES = 1024;               // staged segment per source row (crops up to ~330 px wide)
+constexpr int CROP_LDS_ROWS = 40;
+
+template <typename T, int LAYOUT>
+__global__ void __launch_bounds__(BLOCK) crop_lds_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
+                                                         const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
+                                                         int OH, int OW, float m0, float m1, float m2, float d0, float d1, float d2,
+                                                         T *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_rows[CROP_LDS_ROWS * CROP_LDS_ROW_BYTES];
+    __shared__ int s_xoff[256], s_xw0[256], s_xw1[256], s_xstep[256];
+    __shared__ int s_y0[CROP_BAND], s_y1[CROP_BAND], s_yw0[CROP_BAND], s_yw1[CROP_BAND];
+    __shared__ int s_hdr[8];
+    const int tid = threadIdx.x;
+    const int bands = (OH + CROP_BAND - 1) / CROP_BAND;
+    const int slot = blockIdx.x / bands, band = blockIdx.x - slot * bands;
+    const int b = slot / max_n, i = slot - b * max_n;
+    const int y_base = band * CROP_BAND;
+    const int groups_per_row = OW / 8;
+    const float mean[3] = {m0, m1, m2}, den[3] = {d0, d1, d2};
+    bool valid = i < counts[b];
+    int l = 0, t = 0, r = 0, bt = 0;
+    if (valid) { crop_ltrb(boxes + ((size_t)b * max_n + i) * 4, W, H, l, t, r, bt); valid = (r > l) && (bt > t); }
+    const int cw = r - l, ch = bt - t;
+    bool staged = false;
+    if (valid) {
+        // band row range (uniform): first/last source rows touched by output rows [y_base, y_base+CROP_BAND)
+        const int ylast = min(y_base + CROP_BAND, OH) - 1;
+        const Coef c_first = cv_coef(y_base, ch, OH, false), c_last = cv_coef(ylast, ch, OH, false);
+        const int r_lo = clampi(c_first.s, 0, ch - 1), r_hi = clampi(c_last.s + 1, 0, ch - 1);
+        const int nrows = r_hi - r_lo + 1;
+        staged = nrows <= CROP_LDS_ROWS && cw * 3 + STAGE_PAD <= CROP_LDS_ROW_BYTES;
+        if (staged) {
+            const unsigned char *gend = frames + (size_t)B * H * W * 3;
+            for (int rr = 0; rr < nrows; ++rr)
+                stage_row(frames + ((size_t)b * H * W + (size_t)(t + r_lo + rr) * W + l) * 3, cw * 3,
+                          s_rows + rr * CROP_LDS_ROW_BYTES, gend, tid, BLOCK);
+            if (tid < OW) {
+                const Coef cx = cv_coef(tid, cw, OW, true);
+                s_xoff[tid] = cx.s * 3; s_xw0[tid] = cx.w0; s_xw1[tid] = cx.w1;
+                s_xstep[tid] = (cx.s + 1 < cw ? 3 : 0);
+            }
+            if (tid < CROP_BAND && y_base + tid < OH) {
+                const Coef cy = cv_coef(y_base + tid, ch, OH, false);
+                s_y0[tid] = clampi(cy.s, 0, ch - 1) - r_lo; s_y1[tid] = clampi(cy.s + 1, 0, ch - 1) - r_lo;
+                s_yw0[tid] = cy.w0; s_yw1[tid] = cy.w1;
+            }
+            if (tid == 0) s_hdr[0] = r_lo;
+        }
+    }
+    __syncthreads();
+    const int row_in_band = tid / groups_per_row, xg = tid - row_in_band * groups_per_row;
+    // thread -> (row, 8-px group); bands of CROP_BAND rows x groups_per_row groups may exceed BLOCK: loop
+    for (int unit = tid; unit < CROP_BAND * groups_per_row; unit += BLOCK) {
+        const int ry = unit / groups_per_row, x_base = (unit - ry * groups_per_row) * 8;
+        const int y = y_base + ry;
+        if (y >= OH) continue;
+        T px[8][3];
+        if (valid && staged) {
+            // alignment shift of each staged row: rows are W*3 apart in memory -> shift differs per row
+            const uintptr_t g0 = (uintptr_t)(frames + ((size_t)b * H * W + (size_t)(t + s_hdr[0] + s_y0[ry]) * W + l) * 3);
+            const uintptr_t g1 = (uintptr_t)(frames + ((size_t)b * H * W + (size_t)(t + s_hdr[0] + s_y1[ry]) * W + l) * 3);
+            const unsigned char *p0 = s_rows + s_y0[ry] * CROP_LDS_ROW_BYTES + (int)(g0 & 15);
+            const unsigned char *p1 = s_rows + s_y1[ry] * CROP_LDS_ROW_BYTES + (int)(g1 & 15);
+            const int b0 = s_yw0[ry], b1 = s_yw1[ry];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int x = x_base + k;
+                const int o0 = s_xoff[x], o1 = o0 + s_xstep[x], a0 = s_xw0[x], a1 = s_xw1[x];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int S0 = (int)p0[o0 + c] * a0 + (int)p0[o1 + c] * a1;
+                    const int S1 = (int)p1[o0 + c] * a0 + (int)p1[o1 + c] * a1;
+                    const int v = clampi((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2, 0, 255);
+                    float f = (float)v; f -= mean[c]; f *= den[c];
+                    px[k][c] = cvt<T>(f);
+                }
+            }
+        } else if (valid) {
+            const unsigned char *base = frames + ((size_t)b * H * W + (size_t)t * W + l) * 3;
+            const Coef cy = cv_coef(y, ch, OH, false);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int v[3];
+                sample3(base, W * 3, ch, cw, cy, cv_coef(x_base + k, cw, OW, true), v);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { float f = (float)v[c]; f -= mean[c]; f *= den[c]; px[k][c] = cvt<T>(f); }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) px[k][c] = cvt<T>(0.f);
+        }
+        if (LAYOUT == LAYOUT_NCHW) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                Pack<T, 8> p;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) p.v[k] = px[k][c];
+                *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)slot * 3 + c) * OH + y) * OW + x_base) = p;
+            }
+        } else {
+            T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Pack<T, 8> p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
+                *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+            }
+        }
+    }
+    (void)row_in_band; (void)xg;
+}
+
+// ---- letterbox: workgroup = (frame, LB_BAND output rows); stages the source rows with non-zero weight
+constexpr int LB_BAND = 4;
+
+template <typename T, int LAYOUT>
+__global__ void __launch_bounds__(BLOCK) letterbox_lds_kernel(const unsigned char *__restrict__ frames, int B, int H, int W, int S,
+                                                              int rh, int rw, T *__restrict__ out, int row_bytes_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    __shared__ int s_y0[LB_BAND], s_y1[LB_BAND], s_yw0[LB_BAND], s_yw1[LB_BAND], s_sh0[LB_BAND], s_sh1[LB_BAND];
+    const int tid = threadIdx.x;
+    const int bands = S / LB_BAND;
+    const int b = blockIdx.x / bands, band = blockIdx.x - b * bands;
+    const int y_base = band * LB_BAND;
+    const unsigned char *img = frames + (size_t)b * H * W * 3;
+    const unsigned char *gend = frames + (size_t)B * H * W * 3;
+    // x coefficient table lives behind the staged rows
+    int *s_xoff = reinterpret_cast<int *>(s_dyn + (size_t)2 * LB_BAND * row_bytes_lds);
+    int *s_xw0 = s_xoff + S, *s_xw1 = s_xw0 + S, *s_xstep = s_xw1 + S;
+    const bool any_real = y_base < rh;
+    if (any_real) {
+        for (int ry = 0; ry < LB_BAND; ++ry) {
+            const int y = y_base + ry;
+            if (y >= rh) break;
+            const Coef cy = cv_coef(y, H, rh, false);
+            const int r0 = clampi(cy.s, 0, H - 1), r1 = clampi(cy.s + 1, 0, H - 1);
+            const unsigned char *g0 = img + (size_t)r0 * W * 3, *g1 = img + (size_t)r1 * W * 3;
+            stage_row(g0, W * 3, s_dyn + (size_t)(2 * ry) * row_bytes_lds, gend, tid, BLOCK);
+            if (cy.w1 != 0) stage_row(g1, W * 3, s_dyn + (size_t)(2 * ry + 1) * row_bytes_lds, gend, tid, BLOCK);
+            if (tid == 0) {
+                s_y0[ry] = 2 * ry; s_y1[ry] = cy.w1 != 0 ? 2 * ry + 1 : 2 * ry;
+                s_yw0[ry] = cy.w0; s_yw1[ry] = cy.w1;
+                s_sh0[ry] = (int)((uintptr_t)g0 & 15); s_sh1[ry] = cy.w1 != 0 ? (int)((uintptr_t)g1 & 15) : (int)((uintptr_t)g0 & 15);
+            }
+        }
+        for (int x = tid; x < rw; x += BLOCK) {
+            const Coef cx = cv_coef(x, W, rw, true);
+            s_xoff[x] = cx.s * 3; s_xw0[x] = cx.w0; s_xw1[x] = cx.w1; s_xstep[x] = (cx.s + 1 < W ? 3 : 0);
+        }
+    }
+    __syncthreads();
+    constexpr int ROWS = (LAYOUT == LAYOUT_FOCUS_NHWC) ? 2 : 1;
+    const int groups_per_row = S / 8;
+    for (int unit = tid; unit < (LB_BAND / ROWS) * groups_per_row; unit += BLOCK) {
+        const int ru = unit / groups_per_row, x_base = (unit - ru * groups_per_row) * 8;
+        T px[ROWS][8][3];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int ry = ru * ROWS + r, y = y_base + ry;
+            const bool yin = y < rh;
+            const unsigned char *p0 = s_dyn, *p1 = s_dyn;
+            int b0 = 0, b1 = 0;
+            if (yin) {
+                p0 = s_dyn + (size_t)s_y0[ry] * row_bytes_lds + s_sh0[ry];
+                p1 = s_dyn + (size_t)s_y1[ry] * row_bytes_lds + s_sh1[ry];
+                b0 = s_yw0[ry]; b1 = s_yw1[ry];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int x = x_base + k;
+                if (yin && x < rw) {
+                    const int o0 = s_xoff[x], o1 = o0 + s_xstep[x], a0 = s_xw0[x], a1 = s_xw1[x];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        int S0 = (int)p0[o0 + c] * a0;
+                        if (a1) S0 += (int)p0[o1 + c] * a1;
+                        int S1 = 0;
+                        if (b1) { S1 = (int)p1[o0 + c] * a0; if (a1) S1 += (int)p1[o1 + c] * a1; }
+                        const int v = clampi((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2, 0, 255);
+                        px[r][k][c] = cvt<T>((float)v);
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) px[r][k][c] = cvt<T>(114.f);
+                }
+            }
+        }
+        if (LAYOUT == LAYOUT_NCHW) {
+            const int y = y_base + ru;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                Pack<T, 8> p;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) p.v[k] = px[0][k][c];
+                *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)b * 3 + c) * S + y) * S + x_base) = p;
+            }
+        } else if (LAYOUT == LAYOUT_NHWC) {
+            const int y = y_base + ru;
+            T *o = out + (((size_t)b * S + y) * S + x_base) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Pack<T, 8> p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[0][idx / 3][idx % 3]; }
+                *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+            }
+        } else {
+            const int S2 = S / 2, yu = y_base / 2 + ru;
+            T *o = out + (((size_t)b * S2 + yu) * S2 + x_base / 2) * 12;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                Pack<T, 8> p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int idx = k * 8 + e;
+                    const int fp = idx / 12, chn = idx % 12;
+                    const int grp = chn / 3, c = chn % 3;
+                    const int xo = grp >> 1, yo = grp & 1;
+                    p.v[e] = px[ROWS > 1 ? yo : 0][fp * 2 + xo][c];
+                }
+                *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // YOLOX decode + per-class greedy NMS (rtmlib YOLOX.postprocess / multiclass_nms / nms), one workgroup
 // per frame. Candidates (score = obj*cls > score_thr) are compacted, sorted by (score desc, anchor desc)
 // with a bitonic network in LDS, then ONE wavefront runs the greedy scan: for every surviving box it
@@ -343,6 +603,15 @@ __global__ void __launch_bounds__(BLOCK) yolox_decode_nms_kernel(const float *__
 template <typename T>
 int launch_letterbox(const unsigned char *frames, int B, int H, int W, int S, int rh, int rw, int layout, void *out, hipStream_t st)
 {
+    const int row_bytes = ((W * 3 + STAGE_PAD) + 15) & ~15;
+    const size_t smem = (size_t)2 * LB_BAND * row_bytes + (size_t)4 * S * sizeof(int);
+    if (smem <= 64 * 1024 && S % LB_BAND == 0) {          // LDS-staged fast path
+        const dim3 grid((unsigned)(B * (S / LB_BAND)));
+        if (layout == LAYOUT_NCHW) hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes);
+        else if (layout == LAYOUT_NHWC) hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes);
+        else hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_FOCUS_NHWC>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes);
+        return TLK_OK;
+    }
     const long long units = (long long)B * (S / 8) * (layout == LAYOUT_FOCUS_NHWC ? S / 2 : S);
     const dim3 grid((unsigned)((units + BLOCK - 1) / BLOCK));
     if (layout == LAYOUT_NCHW) hipLaunchKernelGGL((letterbox_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), 0, st, frames, B, H, W, S, rh, rw, (T *)out);
@@ -359,6 +628,14 @@ int launch_crop(const unsigned char *frames, int B, int H, int W, const float *b
     const dim3 grid((unsigned)((units + BLOCK - 1) / BLOCK));
     const float m0 = mean[0] * 255.f, m1 = mean[1] * 255.f, m2 = mean[2] * 255.f;
     const float d0 = 1.0f / (stdv[0] * 255.f), d1 = 1.0f / (stdv[1] * 255.f), d2 = 1.0f / (stdv[2] * 255.f);
+    if (OW <= 256) {                                       // LDS-staged fast path: workgroup = (slot, band of rows)
+        const dim3 g2((unsigned)((long long)B * max_n * ((OH + CROP_BAND - 1) / CROP_BAND)));
+        if (layout == LAYOUT_NCHW)
+            hipLaunchKernelGGL((crop_lds_kernel<T, LAYOUT_NCHW>), g2, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out);
+        else
+            hipLaunchKernelGGL((crop_lds_kernel<T, LAYOUT_NHWC>), g2, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out);
+        return TLK_OK;
+    }
     if (layout == LAYOUT_NCHW)
         hipLaunchKernelGGL((crop_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out);
     else
