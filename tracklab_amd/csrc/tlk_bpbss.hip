@@ -594,23 +594,41 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             Kt.i(BI_HITS) = hits; Kt.i(BI_TSU) = 0;
             if (Kt.i(BI_STATE) == ST_TENTATIVE && hits >= P.n_init) Kt.i(BI_STATE) = ST_CONFIRMED;
         }
-        // visibility-aware EMA of the part embeddings (track.py:150-170): one wavefront per (match, part)
+        // visibility-aware EMA of the part embeddings (track.py:150-170). Flat float4 sweep over (match, part, d): every
+        // thread keeps 4 independent 16-byte loads in flight (the per-(match,part) wavefront loop it replaces was a chain of
+        // dependent global round trips). Visibility is read here and rewritten after the barrier below.
         {
             const float a_t = (float)P.ema_alpha, a_d = (float)(1 - P.ema_alpha);
-            const int w = tid >> 6, lane = tid & 63;
-            for (int job = w; job < nm * K; job += NWAVES) {
+            const int D4 = D >> 2;
+            const int total = nm * K * D4;
+#pragma unroll 4
+            for (int e = tid; e < total; e += BLOCK) {
+                const int job = e / D4, d4 = e - job * D4;
                 const int k = job / K, p = job - k * K;
                 const int slot = order[L.m_t[k]], di = L.sel[L.m_d[k]];
                 const bool tv = fvisS[(size_t)slot * K + p] != 0, dv = in.vis[(dbase + di) * K + p] != 0;
                 const bool both = tv && dv, x = tv != dv;
                 const float et = (float)both * a_t + (float)(x && tv);
                 const float ed = (float)both * a_d + (float)(x && dv);
-                float *f = featS + (size_t)slot * FD + (size_t)p * D;
-                const float *df = in.emb + (dbase + di) * FD + (size_t)p * D;
-                if (et == 0.f && ed == 0.f) { for (int d = lane; d < D; d += WAVE) f[d] = 1.f; }
-                else for (int d = lane; d < D; d += WAVE) { const float a = et * f[d]; const float b = ed * df[d]; f[d] = a + b; }
-                __builtin_amdgcn_wave_barrier();
-                if (lane == 0) fvisS[(size_t)slot * K + p] = (tv || dv) ? 1 : 0;
+                float4 *f = reinterpret_cast<float4 *>(featS + (size_t)slot * FD + (size_t)p * D) + d4;
+                const float4 df = *(reinterpret_cast<const float4 *>(in.emb + (dbase + di) * FD + (size_t)p * D) + d4);
+                float4 o;
+                if (et == 0.f && ed == 0.f) { o.x = 1.f; o.y = 1.f; o.z = 1.f; o.w = 1.f; }
+                else {
+                    const float4 tf = *f;
+                    float a, b;
+                    a = et * tf.x; b = ed * df.x; o.x = a + b;
+                    a = et * tf.y; b = ed * df.y; o.y = a + b;
+                    a = et * tf.z; b = ed * df.z; o.z = a + b;
+                    a = et * tf.w; b = ed * df.w; o.w = a + b;
+                }
+                *f = o;
+            }
+            __syncthreads();
+            for (int job = tid; job < nm * K; job += BLOCK) {
+                const int k = job / K, p = job - k * K;
+                const int slot = order[L.m_t[k]], di = L.sel[L.m_d[k]];
+                if (in.vis[(dbase + di) * K + p] != 0) fvisS[(size_t)slot * K + p] = 1;       // max(tv, dv)
             }
         }
         for (int k = tid; k < n_umt; k += BLOCK) {            // mark_missed (track.py:181-187)
