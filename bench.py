@@ -131,6 +131,7 @@ def main():
         if is3:
             ref = oracle.StrongSORT(pipe.K, pipe.D, **pipe.tracker_cfg)
             ids_ok, tracks, frames_checked = True, 0, 0
+            gt_fr, gpu_fr, orc_fr = [], [], []
             for k in range(ksteps):
                 h_rows, h_cnt = run_step(k)
                 pipe.synchronize()
@@ -147,8 +148,18 @@ def main():
                                                                       np.array_equal(got["track_id"], exp["track_id"])))
                     ids_ok &= bool(ok)
                     tracks = max(tracks, int(got["track_id"].max()) if len(got) else 0)
+                    g = gts[0][k * F + f]
+                    ltrb = lambda r: np.column_stack([r["kf_ltwh"][:, 0], r["kf_ltwh"][:, 1], r["kf_ltwh"][:, 0] + r["kf_ltwh"][:, 2],
+                                                      r["kf_ltwh"][:, 1] + r["kf_ltwh"][:, 3]]) if len(r) else np.zeros((0, 4))
+                    gt_fr.append((g["gt_all_ids"], g["gt_boxes"]))
+                    gpu_fr.append((got["track_id"], ltrb(got)))
+                    orc_fr.append((exp["track_id"], ltrb(exp)) if len(exp) else (np.zeros(0, dtype=int), np.zeros((0, 4))))
                     frames_checked += 1
+            from tracklab_amd import hota
+            h_gpu = hota.finalize(hota.pack(hota.hota_sequence(*hota.sequence_from_rows(gt_fr, gpu_fr))))["summary"]
+            h_orc = hota.finalize(hota.pack(hota.hota_sequence(*hota.sequence_from_rows(gt_fr, orc_fr))))["summary"]
             parity = {"frames": frames_checked, "track_ids_equal_oracle": bool(ids_ok), "tracks": tracks,
+                      "HOTA_gpu": h_gpu["HOTA"], "HOTA_oracle": h_orc["HOTA"], "AssA_gpu": h_gpu["AssA"], "DetA_gpu": h_gpu["DetA"],
                       "note": "oracle chain = C decode/NMS + C BPBReID-StrongSORT fed with the embeddings the GPU ReID net produced"}
         else:
             trk = oracle.OCSort(**pipe.tracker_cfg["hyper"])

@@ -18,7 +18,7 @@ def env_world():
 def init(backend: str | None = None):
     """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
     world, rank, local_rank = env_world()
-    if world == 1:
+    if world == 1 and os.environ.get("TLK_FORCE_DIST") != "1":
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
