@@ -112,6 +112,16 @@ int tlk_partdist_f32(const float *q_dev, const uint8_t *qvis_dev, int T, const f
                      int N, int K, int D, double *out_dev, void *hip_stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Cosine gallery distance (f32 MFMA): cost[t][n] = min over track t's gallery of 1 - cos(gallery row, det n).
+ * Replaces NearestNeighborDistanceMetric("cosine").distance of plain StrongSORT
+ * (plugins/track/strong_sort/sort/nn_matching.py:30-50 _cosine_distance, :73-91 _nn_cosine_distance, :144-161).
+ * gallery_dev (gallery_rows, D) f32, rows of track t = [offsets[t], offsets[t+1]); offsets_dev (T+1) int32;
+ * dets_dev (N, D) f32 -> out_dev (T, N) f64. D % 16 == 0.
+ * ------------------------------------------------------------------------------------------ */
+int tlk_cosine_gallery_min_f32(const float *gallery_dev, const int32_t *offsets_dev, int T, int gallery_rows,
+                               const float *dets_dev, int N, int D, double *out_dev, void *hip_stream);
+
+/* ------------------------------------------------------------------------------------------
  * BPBReID-StrongSORT tracker bank (n_streams independent trackers, state in HBM).
  * Replaces plugins/track/bpbreid_strong_sort/strong_sort.py:11-147 (StrongSORT.update),
  * sort/tracker.py:92-441 (predict, update, strong_sort_matching / bot_sort_matching, _initiate_track),

@@ -522,11 +522,39 @@ def gen_hota(out_dir):
     print("hota ok", float(np.mean(comb["HOTA"])))
 
 
+def gen_cosine(out_dir):
+    """Cosine gallery metric of plain StrongSORT (strong_sort/sort/nn_matching.py), imported file-by-file (the package
+    __init__ chain needs ultralytics/torchvision; this module only needs numpy + torch)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ss_nn_matching", os.path.join(REF, "plugins", "track", "strong_sort", "sort", "nn_matching.py"))
+    nnm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(nnm)
+    rng = np.random.default_rng(17)
+    blobs = {}
+    for ci, (T, N, D, gmax) in enumerate([(60, 100, 512, 40), (7, 33, 64, 5), (1, 1, 16, 1), (40, 130, 128, 100)]):
+        metric = nnm.NearestNeighborDistanceMetric("cosine", 0.2, 100)
+        proto = rng.normal(0, 1, (max(T, N), D)).astype(np.float32)
+        sizes = rng.integers(1, gmax + 1, T)
+        gal, offs = [], [0]
+        for t in range(T):
+            feats = [(proto[t] + 0.3 * rng.normal(0, 1, D)).astype(np.float32) for _ in range(sizes[t])]
+            metric.samples[t] = feats
+            gal += feats
+            offs.append(offs[-1] + len(feats))
+        dets = (proto[:N] + 0.3 * rng.normal(0, 1, (N, D))).astype(np.float32)
+        cost = metric.distance(dets, list(range(T)))
+        blobs[f"c{ci}_gallery"], blobs[f"c{ci}_offsets"] = np.stack(gal), np.array(offs, dtype=np.int32)
+        blobs[f"c{ci}_dets"], blobs[f"c{ci}_cost"] = dets, np.asarray(cost, dtype=np.float64)
+    blobs["n_cases"] = np.int64(4)
+    np.savez_compressed(os.path.join(out_dir, "cosine_gallery.npz"), **blobs)
+    print("cosine ok")
+
+
 def main():
     out_dir = HERE
     only = set(sys.argv[1:])
     gens = {"ocsort": gen_ocsort, "iou": gen_iou_family, "kf7": gen_kf7, "lsa": gen_lsa,
-            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota}
+            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine}
     for k, fn in gens.items():
         if not only or k in only:
             fn(out_dir)

@@ -89,3 +89,16 @@ def test_lsa_invalid_inputs_report_like_scipy():
     c[1] = np.inf
     r, cc, n = _lsa_gpu(c)
     assert n[0] == -2 and n[1] == -1
+
+
+def test_cosine_gallery_mfma_matches_reference_golden_and_oracle(orc):
+    """tlk_cosine_gallery_min_f32 vs strong_sort NearestNeighborDistanceMetric('cosine').distance (golden by import)."""
+    import torch
+    from tracklab_amd import _lib
+    g = np.load(os.path.join(GOLDEN, "cosine_gallery.npz"))
+    for c in range(int(g["n_cases"])):
+        gal, offs, dets = g[f"c{c}_gallery"], g[f"c{c}_offsets"], g[f"c{c}_dets"]
+        out = _lib.cosine_gallery_min(torch.from_numpy(gal).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(dets).cuda())
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out.cpu().numpy(), g[f"c{c}_cost"], rtol=0, atol=3e-6, err_msg=f"case {c} vs reference")
+        np.testing.assert_allclose(out.cpu().numpy(), orc.cosine_gallery_min(gal, offs, dets), rtol=0, atol=3e-6)

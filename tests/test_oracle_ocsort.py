@@ -72,3 +72,10 @@ def test_kalman_box_tracker_replays(orc):
             np.testing.assert_allclose(x, g[f"c{c}_x"][t - 1], rtol=1e-9, atol=1e-9, err_msg=f"case {c} t {t}")
             np.testing.assert_allclose(P, g[f"c{c}_P"][t - 1], rtol=1e-9, atol=1e-8, err_msg=f"case {c} t {t}")
             np.testing.assert_allclose(v, g[f"c{c}_vel"][t - 1], rtol=1e-12, atol=1e-12)
+
+
+def test_cosine_gallery_oracle_matches_reference(orc):
+    g = np.load(os.path.join(GOLDEN, "cosine_gallery.npz"))
+    for c in range(int(g["n_cases"])):
+        out = orc.cosine_gallery_min(g[f"c{c}_gallery"], g[f"c{c}_offsets"], g[f"c{c}_dets"])
+        np.testing.assert_allclose(out, g[f"c{c}_cost"], rtol=0, atol=3e-6)      # fp32 dot products, different summation order

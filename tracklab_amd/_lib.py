@@ -383,3 +383,20 @@ def bias_act_(x, bias, act="relu", residual=None):
     check(L.tlk_bias_act_nhwc(x.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
                               N * H * W, Cc, ACT[act], _dtype_code(x.dtype), current_stream_ptr()))
     return x
+
+
+def cosine_gallery_min(gallery, offsets, dets):
+    """gallery (G, D) f32, offsets (T+1,) int32 (CSR per track), dets (N, D) f32 cuda tensors -> (T, N) f64."""
+    import torch
+    L = lib()
+    if not getattr(L, "_cos_bound", False):
+        L.tlk_cosine_gallery_min_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                 C.c_void_p, C.c_void_p]
+        L._cos_bound = True
+    T, (N, D) = offsets.numel() - 1, dets.shape
+    assert gallery.dtype == torch.float32 and dets.dtype == torch.float32 and offsets.dtype == torch.int32
+    assert gallery.is_contiguous() and dets.is_contiguous()
+    out = torch.empty((T, N), dtype=torch.float64, device=dets.device)
+    check(L.tlk_cosine_gallery_min_f32(gallery.data_ptr(), offsets.data_ptr(), T, gallery.shape[0], dets.data_ptr(), N, D,
+                                       out.data_ptr(), current_stream_ptr()))
+    return out
