@@ -71,6 +71,73 @@ __global__ void __launch_bounds__(BLOCK) cosine_gallery_kernel(const float *__re
     if (g == 0 && n0 + i < N) out[(size_t)t * N + n0 + i] = (double)m;
 }
 
+// Pipelined variant for D = 16*DS in {64,128,256,512}: the wave's detection operand (16 dets x D, normalised) stays in
+// VGPRs for the whole gallery walk; gallery rows stream through two register buffers of GS k-steps each, the next group's
+// 16-byte loads in flight while the current group's 4*GS MFMAs issue (the straightforward kernel above exposes one L2
+// round trip per 4 MFMAs: 8.8 % MFMA busy; this one keeps the matrix pipe fed).
+template <int DS>
+__global__ void __launch_bounds__(BLOCK) cosine_gallery_kernel_t(const float *__restrict__ gallery, const int *__restrict__ offsets, int T,
+                                                                 const float *__restrict__ dets, int N,
+                                                                 const float *__restrict__ gnorm, const float *__restrict__ dnorm,
+                                                                 double *__restrict__ out)
+{
+    constexpr int D = DS * 16;
+    constexpr int GS = DS >= 16 ? 8 : DS / 2;
+    constexpr int GROUPS = DS / GS;               // even by construction
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.y * NWAVES + w;
+    if (t >= T) return;
+    const int n0 = blockIdx.x * 16;
+    const int i = lane & 15, g = lane >> 4;
+    const int dn = min(n0 + i, N - 1);
+    float4 breg[DS];
+    {
+        const float4 *drow = reinterpret_cast<const float4 *>(dets + (size_t)dn * D) + g;
+        const float nd = dnorm[dn];
+#pragma unroll
+        for (int s = 0; s < DS; ++s) { float4 b = drow[s * 4]; b.x /= nd; b.y /= nd; b.z /= nd; b.w /= nd; breg[s] = b; }
+    }
+    const int g_lo = offsets[t], g_hi = offsets[t + 1];
+    float best[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    float4 A0[GS], A1[GS];
+    auto load = [&](float4 (&buf)[GS], int c0, int grp) {
+        const int gr = min(c0 + i, g_hi - 1);
+        const float4 *grow = reinterpret_cast<const float4 *>(gallery + (size_t)gr * D) + g + grp * GS * 4;
+#pragma unroll
+        for (int s = 0; s < GS; ++s) buf[s] = grow[s * 4];
+    };
+    if (g_lo < g_hi) load(A0, g_lo, 0);
+    for (int c0 = g_lo; c0 < g_hi; c0 += 16) {
+        const float ng = gnorm[min(c0 + i, g_hi - 1)];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int grp = 0; grp < GROUPS; ++grp) {
+            // prefetch the next group (or the first group of the next chunk) into the other buffer
+            if (grp + 1 < GROUPS) { if (grp & 1) load(A0, c0, grp + 1); else load(A1, c0, grp + 1); }
+            else if (c0 + 16 < g_hi) { load(A0, c0 + 16, 0); }       // GROUPS even -> group 0 always lives in A0
+#pragma unroll
+            for (int s = 0; s < GS; ++s) {
+                const float4 a = (grp & 1) ? A1[s] : A0[s];
+                const float4 b = breg[grp * GS + s];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x / ng, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y / ng, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z / ng, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w / ng, b.w, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool valid = c0 + g * 4 + r < g_hi;
+            const float v = 1.f - acc[r];
+            if (valid && v < best[r]) best[r] = v;
+        }
+    }
+    float m = fminf(fminf(best[0], best[1]), fminf(best[2], best[3]));
+    m = fminf(m, __shfl_xor(m, 16));
+    m = fminf(m, __shfl_xor(m, 32));
+    if (g == 0 && n0 + i < N) out[(size_t)t * N + n0 + i] = (double)m;
+}
+
 }  // namespace
 
 extern "C" int tlk_cosine_gallery_min_f32(const float *gallery_dev, const int32_t *offsets_dev, int T, int gallery_rows,
@@ -86,8 +153,16 @@ extern "C" int tlk_cosine_gallery_min_f32(const float *gallery_dev, const int32_
     if (gallery_rows > 0)
         hipLaunchKernelGGL(rownorm_kernel, dim3((gallery_rows + NWAVES - 1) / NWAVES), dim3(BLOCK), 0, st, gallery_dev, gallery_rows, D, gn);
     hipLaunchKernelGGL(rownorm_kernel, dim3((N + NWAVES - 1) / NWAVES), dim3(BLOCK), 0, st, dets_dev, N, D, dn);
-    hipLaunchKernelGGL(cosine_gallery_kernel, dim3((N + 15) / 16, (T + NWAVES - 1) / NWAVES), dim3(BLOCK), 0, st, gallery_dev,
-                       (const int *)offsets_dev, T, dets_dev, N, D, gn, dn, out_dev);
+    const dim3 grid((N + 15) / 16, (T + NWAVES - 1) / NWAVES);
+#define COS_LAUNCH(DS) hipLaunchKernelGGL((cosine_gallery_kernel_t<DS>), grid, dim3(BLOCK), 0, st, gallery_dev, (const int *)offsets_dev, \
+                                          T, dets_dev, N, (const float *)gn, (const float *)dn, out_dev)
+    if (D == 512) COS_LAUNCH(32);
+    else if (D == 256) COS_LAUNCH(16);
+    else if (D == 128) COS_LAUNCH(8);
+    else if (D == 64) COS_LAUNCH(4);
+    else hipLaunchKernelGGL(cosine_gallery_kernel, grid, dim3(BLOCK), 0, st, gallery_dev, (const int *)offsets_dev, T, dets_dev, N, D,
+                            (const float *)gn, (const float *)dn, out_dev);
+#undef COS_LAUNCH
     TLK_HIP(hipGetLastError());
     TLK_HIP(hipFreeAsync(gn, st));
     TLK_HIP(hipFreeAsync(dn, st));
