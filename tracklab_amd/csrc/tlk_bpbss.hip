@@ -101,13 +101,15 @@ __global__ void __launch_bounds__(512) partdist_kernel(BpbDev Dv, FrameIn in)
     const float nq = Dv.tnorm[(((size_t)s * Dv.MAXT + tp) * K + k) * 2];
     const float ng = Dv.dnorm[(((size_t)s * Dv.MAXD + dn) * K + k) * 2];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float rq = 1.f / nq, rg = 1.f / ng;      // reciprocal multiply: the loop was VALU-bound on fp32 divisions
+#pragma unroll 4
     for (int c = 0; c < D; c += 16) {
         const float4 a = *reinterpret_cast<const float4 *>(qrow + c + 4 * g);
         const float4 b = *reinterpret_cast<const float4 *>(grow + c + 4 * g);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x / nq, b.x / ng, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y / nq, b.y / ng, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z / nq, b.z / ng, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w / nq, b.w / ng, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x * rq, b.x * rg, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y * rq, b.y * rg, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z * rq, b.z * rg, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w * rq, b.w * rg, acc, 0, 0, 0);
     }
     // C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
     const int cn = min(n0 + i, N - 1);

@@ -95,7 +95,9 @@ __global__ void __launch_bounds__(BLOCK) cosine_gallery_kernel_t(const float *__
         const float4 *drow = reinterpret_cast<const float4 *>(dets + (size_t)dn * D) + g;
         const float nd = dnorm[dn];
 #pragma unroll
-        for (int s = 0; s < DS; ++s) { float4 b = drow[s * 4]; b.x /= nd; b.y /= nd; b.z /= nd; b.w /= nd; breg[s] = b; }
+        const float rnd = 1.f / nd;
+#pragma unroll
+        for (int s = 0; s < DS; ++s) { float4 b = drow[s * 4]; b.x *= rnd; b.y *= rnd; b.z *= rnd; b.w *= rnd; breg[s] = b; }
     }
     const int g_lo = offsets[t], g_hi = offsets[t + 1];
     float best[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
@@ -108,7 +110,6 @@ __global__ void __launch_bounds__(BLOCK) cosine_gallery_kernel_t(const float *__
     };
     if (g_lo < g_hi) load(A0, g_lo, 0);
     for (int c0 = g_lo; c0 < g_hi; c0 += 16) {
-        const float ng = gnorm[min(c0 + i, g_hi - 1)];
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int grp = 0; grp < GROUPS; ++grp) {
@@ -119,16 +120,19 @@ __global__ void __launch_bounds__(BLOCK) cosine_gallery_kernel_t(const float *__
             for (int s = 0; s < GS; ++s) {
                 const float4 a = (grp & 1) ? A1[s] : A0[s];
                 const float4 b = breg[grp * GS + s];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x / ng, b.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y / ng, b.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z / ng, b.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w / ng, b.w, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
             }
         }
+        // the gallery row's 1/|g| is applied to the finished dot product (one multiply per output instead of a division per
+        // element in front of every MFMA, which made the loop VALU-bound); fp32 rounding differs by ~1e-7 relative.
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool valid = c0 + g * 4 + r < g_hi;
-            const float v = 1.f - acc[r];
+            const int row = c0 + g * 4 + r;
+            const bool valid = row < g_hi;
+            const float v = 1.f - acc[r] * (1.f / gnorm[min(row, g_hi - 1)]);
             if (valid && v < best[r]) best[r] = v;
         }
     }
