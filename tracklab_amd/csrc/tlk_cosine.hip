@@ -94,7 +94,6 @@ __global__ void __launch_bounds__(BLOCK) cosine_gallery_kernel_t(const float *__
     {
         const float4 *drow = reinterpret_cast<const float4 *>(dets + (size_t)dn * D) + g;
         const float nd = dnorm[dn];
-#pragma unroll
         const float rnd = 1.f / nd;
 #pragma unroll
         for (int s = 0; s < DS; ++s) { float4 b = drow[s * 4]; b.x *= rnd; b.y *= rnd; b.z *= rnd; b.w *= rnd; breg[s] = b; }
