@@ -84,9 +84,9 @@ __global__ void __launch_bounds__(BLOCK) cosine_gallery_kernel_t(const float *__
     constexpr int D = DS * 16;
     constexpr int GS = DS >= 16 ? 8 : DS / 2;
     constexpr int GROUPS = DS / GS;               // even by construction
+    __shared__ float s_min[NWAVES][16];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = blockIdx.y * NWAVES + w;
-    if (t >= T) return;
+    const int t = blockIdx.y;                     // workgroup = (track, 16 detections); its 4 waves interleave the gallery chunks
     const int n0 = blockIdx.x * 16;
     const int i = lane & 15, g = lane >> 4;
     const int dn = min(n0 + i, N - 1);
@@ -107,14 +107,15 @@ __global__ void __launch_bounds__(BLOCK) cosine_gallery_kernel_t(const float *__
 #pragma unroll
         for (int s = 0; s < GS; ++s) buf[s] = grow[s * 4];
     };
-    if (g_lo < g_hi) load(A0, g_lo, 0);
-    for (int c0 = g_lo; c0 < g_hi; c0 += 16) {
+    const int c_first = g_lo + 16 * w;
+    if (c_first < g_hi) load(A0, c_first, 0);
+    for (int c0 = c_first; c0 < g_hi; c0 += 16 * NWAVES) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int grp = 0; grp < GROUPS; ++grp) {
             // prefetch the next group (or the first group of the next chunk) into the other buffer
             if (grp + 1 < GROUPS) { if (grp & 1) load(A0, c0, grp + 1); else load(A1, c0, grp + 1); }
-            else if (c0 + 16 < g_hi) { load(A0, c0 + 16, 0); }       // GROUPS even -> group 0 always lives in A0
+            else if (c0 + 16 * NWAVES < g_hi) { load(A0, c0 + 16 * NWAVES, 0); }       // GROUPS even -> group 0 always lives in A0
 #pragma unroll
             for (int s = 0; s < GS; ++s) {
                 const float4 a = (grp & 1) ? A1[s] : A0[s];
@@ -138,7 +139,10 @@ __global__ void __launch_bounds__(BLOCK) cosine_gallery_kernel_t(const float *__
     float m = fminf(fminf(best[0], best[1]), fminf(best[2], best[3]));
     m = fminf(m, __shfl_xor(m, 16));
     m = fminf(m, __shfl_xor(m, 32));
-    if (g == 0 && n0 + i < N) out[(size_t)t * N + n0 + i] = (double)m;
+    if (g == 0) s_min[w][i] = m;
+    __syncthreads();
+    if (w == 0 && g == 0 && n0 + i < N)
+        out[(size_t)t * N + n0 + i] = (double)fminf(fminf(s_min[0][i], s_min[1][i]), fminf(s_min[2][i], s_min[3][i]));
 }
 
 }  // namespace
@@ -156,8 +160,8 @@ extern "C" int tlk_cosine_gallery_min_f32(const float *gallery_dev, const int32_
     if (gallery_rows > 0)
         hipLaunchKernelGGL(rownorm_kernel, dim3((gallery_rows + NWAVES - 1) / NWAVES), dim3(BLOCK), 0, st, gallery_dev, gallery_rows, D, gn);
     hipLaunchKernelGGL(rownorm_kernel, dim3((N + NWAVES - 1) / NWAVES), dim3(BLOCK), 0, st, dets_dev, N, D, dn);
-    const dim3 grid((N + 15) / 16, (T + NWAVES - 1) / NWAVES);
-#define COS_LAUNCH(DS) hipLaunchKernelGGL((cosine_gallery_kernel_t<DS>), grid, dim3(BLOCK), 0, st, gallery_dev, (const int *)offsets_dev, \
+    const dim3 grid((N + 15) / 16, (T + NWAVES - 1) / NWAVES), grid_t((N + 15) / 16, T);
+#define COS_LAUNCH(DS) hipLaunchKernelGGL((cosine_gallery_kernel_t<DS>), grid_t, dim3(BLOCK), 0, st, gallery_dev, (const int *)offsets_dev, \
                                           T, dets_dev, N, (const float *)gn, (const float *)dn, out_dev)
     if (D == 512) COS_LAUNCH(32);
     else if (D == 256) COS_LAUNCH(16);
