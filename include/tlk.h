@@ -128,8 +128,9 @@ int tlk_cosine_gallery_min_f32(const float *gallery_dev, const int32_t *offsets_
  * sort/track.py:68-187, sort/kalman_filter.py:53-227, sort/linear_assignment.py:11-175,
  * sort/iou_matching.py:7-78, sort/nn_matching.py:173-200 and the wrapper's empty-frame rule
  * (tracklab/wrappers/track/bpbreid_strong_sort_api.py:103-104).
- * Not covered: motion_criterium "oks", ECC camera compensation (ecc: False in the yaml), the per-detection
- * debug `costs` dictionaries (tracker.py:365-407).
+ * Also sort/oks_matching.py:7-128 (motion_criterium "oks" on COCO-17 keypoints).
+ * Not covered: ECC camera compensation (ecc: False in the yaml), the per-detection debug `costs` dictionaries
+ * (tracker.py:365-407).
  * ------------------------------------------------------------------------------------------ */
 typedef struct tlk_bpbss tlk_bpbss;
 typedef struct {
@@ -141,6 +142,9 @@ typedef struct {
     int32_t parts, dim;          /* K, D of the embeddings */
     int32_t max_tracks;          /* <= 512 */
     int32_t max_dets;            /* <= 256 */
+    int32_t motion_criterium;    /* 0 "iou" (sort/iou_matching.py), 1 "oks" (sort/oks_matching.py; needs keypoints) */
+    int32_t reserved_;
+    double max_oks_distance;
 } tlk_bpbss_params;
 
 typedef struct {                 /* one output row = one confirmed track updated in this frame (strong_sort.py:93-141) */
@@ -158,16 +162,18 @@ int tlk_bpbss_create(const tlk_bpbss_params *p, int n_streams, int device, tlk_b
 int tlk_bpbss_destroy(tlk_bpbss *h);
 int tlk_bpbss_reset(tlk_bpbss *h, int stream);
 /* one frame of one stream, host buffers, synchronous: ids (n) int64, ltwh (n,4) f64, emb (n,K,D) f32,
- * vis (n,K) u8, conf (n) f64 -> rows (<= cap) */
+ * vis (n,K) u8, conf (n) f64, kps (n,17,3) f64 [x,y,conf] or NULL -> rows (<= cap) */
 int tlk_bpbss_update(tlk_bpbss *h, int stream, const int64_t *ids, const double *ltwh, const float *emb,
-                     const uint8_t *vis, const double *conf, int n, tlk_bpbss_row *rows, int cap, int *n_out);
+                     const uint8_t *vis, const double *conf, const double *kps, int n, tlk_bpbss_row *rows, int cap,
+                     int *n_out);
 /* n_frames consecutive frames of every stream, device buffers, asynchronous (3 launches per frame):
  * ids_dev (S,F,max_dets) int64; ltwh_dev (S,F,max_dets,4) f64; emb_dev (S,F,max_dets,K,D) f32;
- * vis_dev (S,F,max_dets,K) u8; conf_dev (S,F,max_dets) f64; counts_dev (S,F) int32;
+ * vis_dev (S,F,max_dets,K) u8; conf_dev (S,F,max_dets) f64; kps_dev (S,F,max_dets,17,3) f64 or NULL;
+ * counts_dev (S,F) int32;
  * rows_dev (S,F,out_cap) tlk_bpbss_row; out_counts_dev (S,F) int32 (<0 = error code). */
 int tlk_bpbss_update_dev(tlk_bpbss *h, const int64_t *ids_dev, const double *ltwh_dev, const float *emb_dev,
-                         const uint8_t *vis_dev, const double *conf_dev, const int32_t *counts_dev, int n_frames,
-                         tlk_bpbss_row *rows_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream);
+                         const uint8_t *vis_dev, const double *conf_dev, const double *kps_dev, const int32_t *counts_dev,
+                         int n_frames, tlk_bpbss_row *rows_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream);
 /* Debug / parity: live tracks of a stream in list order. ids (cap) int64, mean (cap,8), cov (cap,8,8),
  * feat (cap,K,D) f32, fvis (cap,K) u8 (any may be NULL). Synchronous. */
 int tlk_bpbss_get_tracks(tlk_bpbss *h, int stream, int64_t *ids, double *mean, double *cov, float *feat,

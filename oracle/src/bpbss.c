@@ -138,6 +138,7 @@ typedef struct {
     /* last_detection */
     int64_t det_id; int matched_name; double matched_dist;
     int pred_valid; double pred_ltwh[4];
+    double kp[51];             /* last_detection.keypoints */
 } trk_t;
 
 struct orc_bpbss {
@@ -178,6 +179,49 @@ static double iou_ltwh(const double *b, const double *c)
     return ai / (b[2] * b[3] + c[2] * c[3] - ai);
 }
 
+/* sort/oks_matching.py:7-92: similarity of track keypoints `kp` (17,3) to candidate `c` (17,3) */
+static const double KAPPA[17] = {0.026, 0.025, 0.025, 0.035, 0.035, 0.079, 0.079, 0.072, 0.072, 0.062, 0.062, 0.107, 0.107, 0.087, 0.087, 0.089, 0.089};
+static double oks_scale(const double *kp, int *nvis_out)
+{
+    const double c45 = 0.7071067811865476, s45 = 0.7071067811865475;     /* np.cos/np.sin(np.deg2rad(45)) */
+    double tl[2] = {INFINITY, INFINITY}, br[2] = {-INFINITY, -INFINITY}, ttl[2] = {INFINITY, INFINITY}, tbr[2] = {-INFINITY, -INFINITY};
+    double tl4[2] = {INFINITY, INFINITY}, br4[2] = {-INFINITY, -INFINITY}, ttl4[2] = {INFINITY, INFINITY}, tbr4[2] = {-INFINITY, -INFINITY};
+    int nvis = 0;
+    for (int k = 0; k < 17; ++k) {
+        double x = kp[3 * k], y = kp[3 * k + 1];
+        double r[2] = {c45 * x + (-s45) * y, s45 * x + c45 * y};
+        double p[2] = {x, y};
+        int v = kp[3 * k + 2] > 0.0;
+        nvis += v;
+        for (int a = 0; a < 2; ++a) {
+            if (p[a] < ttl[a]) ttl[a] = p[a]; if (p[a] > tbr[a]) tbr[a] = p[a];
+            if (r[a] < ttl4[a]) ttl4[a] = r[a]; if (r[a] > tbr4[a]) tbr4[a] = r[a];
+            if (v) { if (p[a] < tl[a]) tl[a] = p[a]; if (p[a] > br[a]) br[a] = p[a];
+                     if (r[a] < tl4[a]) tl4[a] = r[a]; if (r[a] > br4[a]) br4[a] = r[a]; }
+        }
+    }
+    *nvis_out = nvis;
+    double area = (br[0] - tl[0]) * (br[1] - tl[1]), total_area = (tbr[0] - ttl[0]) * (tbr[1] - ttl[1]);
+    double area45 = (br4[0] - tl4[0]) * (br4[1] - tl4[1]), total45 = (tbr4[0] - ttl4[0]) * (tbr4[1] - ttl4[1]);
+    double f1 = area > 0.1 ? total_area / area : INFINITY, f2 = area45 > 0.1 ? total45 / area45 : INFINITY;
+    double factor = sqrt(f1 < f2 ? f1 : f2);
+    double fc = factor < 5.0 ? factor : 5.0;
+    double scale = sqrt(area) * fc;
+    if (scale < 0.1) scale = NAN;
+    return scale;
+}
+static double oks_one(const double *kp, double scale, int nvis, const double *c)
+{
+    double sum = 0;
+    for (int k = 0; k < 17; ++k) {
+        double dx = kp[3 * k] - c[3 * k], dy = kp[3 * k + 1] - c[3 * k + 1];
+        double d = sqrt(dx * dx + dy * dy);
+        double e = exp(-(d * d) / (2 * (scale * scale) * (KAPPA[k] * KAPPA[k])));
+        sum += e * (kp[3 * k + 2] > 0.0 ? 1.0 : 0.0);
+    }
+    return sum / (double)nvis;
+}
+
 /* sort/linear_assignment.py:11-73. cost (nt, nd) un-thresholded. outputs index lists into trk_idx/det_idx */
 static void min_cost_matching(const double *cost, int nt, int nd, double max_distance, const int *trk_idx, const int *det_idx,
                               int *m_t, int *m_d, int *m_row, int *m_col, int *nm, int *um_t, int *n_um_t, int *um_d, int *n_um_d)
@@ -207,6 +251,10 @@ static int cmp_int(const void *a, const void *b) { int x = *(const int *)a, y = 
 
 int orc_bpbss_update(orc_bpbss *T, const int64_t *ids_in, const double *ltwh_in, const float *emb_in, const uint8_t *vis_in,
                      const double *conf_in, const double *classes, int n_in, orc_bpbss_row *out)
+{ return orc_bpbss_update_kp(T, ids_in, ltwh_in, emb_in, vis_in, conf_in, classes, NULL, n_in, out); }
+
+int orc_bpbss_update_kp(orc_bpbss *T, const int64_t *ids_in, const double *ltwh_in, const float *emb_in, const uint8_t *vis_in,
+                        const double *conf_in, const double *classes, const double *kps_in, int n_in, orc_bpbss_row *out)
 {
     const int K = T->K, D = T->D;
     const size_t FD = (size_t)K * D;
@@ -248,6 +296,12 @@ int orc_bpbss_update(orc_bpbss *T, const int64_t *ids_in, const double *ltwh_in,
         orc_partdist_f32(tf, tv, NT, demb, dvis, N, K, D, reid);
         const int gdim = T->c.only_position ? 2 : 4;
         for (int t = 0; t < NT; ++t) orc_kf8_gating(T->trk[t].mean, T->trk[t].cov, xyah, N, T->c.only_position, gate + (size_t)t * N);
+        if (T->c.motion_criterium == 1 && kps_in) {      /* oks_cost, oks_matching.py:95-128 */
+            for (int t = 0; t < NT; ++t) {
+                int nvis; double sc = oks_scale(T->trk[t].kp, &nvis);
+                for (int j = 0; j < N; ++j) stc[(size_t)t * N + j] = 1.0 - oks_one(T->trk[t].kp, sc, nvis, kps_in + 51 * (size_t)sel[j]);
+            }
+        } else
         for (int t = 0; t < NT; ++t) { double tl[4]; trk_to_ltwh(&T->trk[t], tl); for (int j = 0; j < N; ++j) stc[(size_t)t * N + j] = 1. - iou_ltwh(tl, dltwh + 4 * j); }
 
         if (T->c.matching_strategy == 0) {
@@ -276,7 +330,7 @@ int orc_bpbss_update(orc_bpbss *T, const int64_t *ids_in, const double *ltwh_in,
             double *cb = malloc(sizeof(double) * (size_t)(nb + 1) * (n_uda + 1));
             for (int r = 0; r < nb; ++r) for (int j = 0; j < n_uda; ++j) cb[(size_t)r * n_uda + j] = stc[(size_t)bc[r] * N + um_da[j]];
             int nmb = 0, n_utb = 0, n_udb = 0;
-            min_cost_matching(cb, nb, n_uda, T->c.max_iou_distance, bc, um_da, m_t + nma, m_d + nma, m_row, m_col, &nmb, um_tb, &n_utb, um_db, &n_udb);
+            min_cost_matching(cb, nb, n_uda, (T->c.motion_criterium == 1 ? T->c.max_oks_distance : T->c.max_iou_distance), bc, um_da, m_t + nma, m_d + nma, m_row, m_col, &nmb, um_tb, &n_utb, um_db, &n_udb);
             if (nb > 0 && n_uda > 0) for (int k = 0; k < nmb; ++k) { d_mname[m_d[nma + k]] = 2; d_mdist[m_d[nma + k]] = cb[(size_t)m_row[k] * n_uda + m_col[k]]; }
             nm = nma + nmb;
             for (int k = 0; k < n_uta; ++k) um_t[n_umt++] = um_ta[k];
@@ -294,7 +348,7 @@ int orc_bpbss_update(orc_bpbss *T, const int64_t *ids_in, const double *ltwh_in,
                 double pos = sqrt(gate[e]) / (GT * T->c.gating_thres_factor);
                 int pos_gate = T->c.w_kfgd > 0 ? pos > 1.0 : 0;
                 int app_gate = T->c.w_reid > 0 ? reid[e] > T->c.max_dist : 0;
-                int st_gate = T->c.w_st > 0 ? stc[e] > T->c.max_iou_distance : 0;
+                int st_gate = T->c.w_st > 0 ? stc[e] > (T->c.motion_criterium == 1 ? T->c.max_oks_distance : T->c.max_iou_distance) : 0;
                 double c = (T->c.w_kfgd * pos + T->c.w_reid * reid[e] + stc[e] * T->c.w_st) / wsum;
                 int m = T->c.w_kfgd > 0 ? (pos_gate || app_gate)          /* np.logical_or(a, b, out=st_gate): st_gate is the out= array */
                                         : (T->c.w_st > 0 ? (app_gate || st_gate) : app_gate);
@@ -316,6 +370,7 @@ int orc_bpbss_update(orc_bpbss *T, const int64_t *ids_in, const double *ltwh_in,
             trk_t *tr = &T->trk[m_t[k]]; int j = m_d[k];
             tr->det_id = ids_in[sel[j]]; tr->matched_name = d_mname[j]; tr->matched_dist = d_mdist[j];
             trk_to_ltwh(tr, tr->pred_ltwh); tr->pred_valid = 1;
+            if (kps_in) memcpy(tr->kp, kps_in + 51 * (size_t)sel[j], sizeof(tr->kp));
             orc_kf8_update(tr->mean, tr->cov, xyah + 4 * j, conf_in[sel[j]]);
             const float a_t = (float)T->c.ema_alpha, a_d = (float)(1 - T->c.ema_alpha);
             for (int p = 0; p < K; ++p) {
@@ -346,6 +401,7 @@ int orc_bpbss_update(orc_bpbss *T, const int64_t *ids_in, const double *ltwh_in,
             memcpy(tr->feat, demb + FD * j, sizeof(float) * FD); memcpy(tr->fvis, dvis + (size_t)K * j, (size_t)K);
             orc_kf8_initiate(xyah + 4 * j, tr->mean, tr->cov);
             tr->det_id = ids_in[sel[j]]; tr->matched_name = d_mname[j]; tr->matched_dist = d_mdist[j]; tr->pred_valid = 0;
+            if (kps_in) memcpy(tr->kp, kps_in + 51 * (size_t)sel[j], sizeof(tr->kp));
             if (tr->hits >= T->c.n_init) tr->state = ST_CONFIRMED;
         }
         { int k2 = 0;                            /* drop deleted (stable) */

@@ -35,7 +35,7 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REF, "plugins", "track"))
 sys.path.insert(0, REF)
 
-from tracklab_amd.synth import SyntheticStream, ltrb_to_ltwh_rows  # noqa: E402
+from tracklab_amd.synth import SyntheticStream, ltrb_to_ltwh_rows, synth_keypoints  # noqa: E402
 
 
 # ----------------------------------------------------------------------------- shims
@@ -347,6 +347,11 @@ BPB_RUNS = [  # (name, cfg overrides, seed, n_objects, n_frames, K, D, store_inp
                             "gating_thres_factor": 1.5},
      5, 20, 120, 6, 32, True, {"miss_prob": 0.15, "churn_period": 10}),
     ("yaml_s6_n100_d512", {}, 6, 100, 20, 6, 512, False, {}),
+    # motion_criterium "oks": stage B (and BoT-SORT's spatio-temporal term) on COCO keypoints (sort/oks_matching.py)
+    ("oks_s7_n20_d32", {"motion_criterium": "oks", "max_oks_distance": 0.7, "n_init": 2, "max_age": 30, "max_dist": 0.3},
+     7, 20, 120, 6, 32, True, {"miss_prob": 0.2, "churn_period": 10}),
+    ("oks_botsort_s8_n15_d32", {"motion_criterium": "oks", "matching_strategy": "bot_sort_matching", "max_age": 30, "n_init": 1},
+     8, 15, 100, 6, 32, True, {"miss_prob": 0.15, "churn_period": 10}),
 ]
 
 STATE_CODE = {"t": 0, "c": 1, "d": 2}
@@ -370,12 +375,18 @@ def gen_bpbss(out_dir):
         o_hits, o_age, o_tsu, o_state = [], [], [], []
         h = hashlib.sha256()
         blobs = {}
+        use_kp = cfg.get("motion_criterium") == "oks"
+        kp_rng = np.random.default_rng(900 + seed)
+        kps = []
         for fr in stream:
             dets = fr["dets"]
             if fr["frame"] % 41 == 7:
                 dets, emb, vis = dets[:0], fr["embeddings"][:0], fr["visibility"][:0]
             else:
                 emb, vis = fr["embeddings"], fr["visibility"]
+            kp = synth_keypoints(kp_rng, dets[:, :4]) if use_kp else None
+            if use_kp:
+                kps.append(kp)
             ltwh = ltrb_to_ltwh_rows(dets[:, :4])
             conf = dets[:, 4].copy()
             did = dets[:, 6].astype(np.int64)
@@ -392,7 +403,8 @@ def gen_bpbss(out_dir):
                 df = model.update(torch.from_numpy(did), torch.from_numpy(ltwh), torch.from_numpy(emb),
                                   torch.from_numpy(vis), torch.from_numpy(conf),
                                   torch.zeros(len(dets), dtype=torch.float64),
-                                  torch.ones(len(dets), dtype=torch.float64) * fr["frame"], None)
+                                  torch.ones(len(dets), dtype=torch.float64) * fr["frame"],
+                                  torch.from_numpy(kp) if use_kp else None)
                 for det_id, row in df.iterrows():
                     o_idx.append(int(det_id))
                     o_tid.append(int(row.track_id))
@@ -423,6 +435,8 @@ def gen_bpbss(out_dir):
         if store:
             extra["embeddings"] = np.concatenate(embs).astype(np.float32)
             extra["visibility"] = np.concatenate(viss)
+        if use_kp:
+            extra["keypoints"] = np.concatenate(kps)
         np.savez_compressed(
             os.path.join(out_dir, f"bpbss_{name}.npz"),
             ltwh=np.concatenate(ltwhs), conf=np.concatenate(confs), det_ids=np.concatenate(ids_in),

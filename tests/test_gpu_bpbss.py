@@ -26,8 +26,8 @@ def test_hip_bpbss_matches_reference_golden(path):
     cfg = json.loads(str(g["config"]))
     K, D = int(g["parts"]), int(g["dim"])
     bank = _bank(cfg, K, D, wrapper_mode=True)
-    for f, (ids, ltwh, emb, vis, conf) in enumerate(bpbss_inputs(g)):
-        rows = bank.update(ids, ltwh, emb, vis, conf)
+    for f, (ids, ltwh, emb, vis, conf, kp) in enumerate(bpbss_inputs(g)):
+        rows = bank.update(ids, ltwh, emb, vis, conf, keypoints=kp)
         check_bpbss_rows(g, f, rows)
         if f"f{f}_track_ids" in g:
             tid, mean, cov, feat, fvis = bank.tracks()

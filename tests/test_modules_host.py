@@ -87,8 +87,8 @@ def test_bpbss_module_matches_oracle(orc):
         def __init__(self, parts, dim):
             self.t = orc.StrongSORT(parts, dim, **kw)
 
-        def update(self, ids, ltwh, emb, vis, conf, stream):
-            return self.t.update(ids, ltwh, emb, vis, conf)
+        def update(self, ids, ltwh, emb, vis, conf, stream, keypoints=None):
+            return self.t.update(ids, ltwh, emb, vis, conf, keypoints=keypoints)
 
     m = HipBPBReIDStrongSORT(cfg, "cuda:0")
     m._make_backend = lambda parts, dim: Backend(parts, dim)

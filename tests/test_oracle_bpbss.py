@@ -37,7 +37,8 @@ def bpbss_inputs(g):
             assert np.array_equal(ltrb_to_ltwh_rows(dets[:, :4]), ltwh), "synthetic generator drifted from the golden run"
         for arr in (ltwh, conf, emb, vis):
             h.update(np.ascontiguousarray(arr).tobytes())
-        frames.append((ids, ltwh, emb, vis, conf))
+        kp = g["keypoints"][a:b] if "keypoints" in g else None
+        frames.append((ids, ltwh, emb, vis, conf, kp))
     assert h.hexdigest() == str(g["input_sha256"]), "inputs differ from the ones the reference consumed"
     return frames
 
@@ -65,10 +66,10 @@ def test_bpbss_oracle_matches_reference(orc, path):
     cfg = json.loads(str(g["config"]))
     K, D = int(g["parts"]), int(g["dim"])
     trk = orc.StrongSORT(K, D, **cfg)
-    for f, (ids, ltwh, emb, vis, conf) in enumerate(bpbss_inputs(g)):
+    for f, (ids, ltwh, emb, vis, conf, kp) in enumerate(bpbss_inputs(g)):
         if len(ids) == 0:      # wrapper: process() returns [] without stepping (bpbreid_strong_sort_api.py:103-104)
             continue
-        rows = trk.update(ids, ltwh, emb, vis, conf)
+        rows = trk.update(ids, ltwh, emb, vis, conf, keypoints=kp)
         check_bpbss_rows(g, f, rows)
         if f"f{f}_track_ids" in g:
             tid, mean, cov, feat, fvis = trk.tracks()

@@ -258,7 +258,8 @@ class BpbssParams(C.Structure):
                                           "gating_thres_factor", "w_kfgd", "w_reid", "w_st")] + \
                [(n, C.c_int32) for n in ("max_age", "n_init", "only_position_for_kf_gating",
                                          "max_kalman_prediction_without_update", "matching_strategy", "wrapper_mode",
-                                         "parts", "dim", "max_tracks", "max_dets")]
+                                         "parts", "dim", "max_tracks", "max_dets", "motion_criterium", "reserved_")] + \
+               [("max_oks_distance", C.c_double)]
 
 
 BPBSS_ROW = np.dtype([("det_id", "<i8"), ("track_id", "<i8"), ("kf_ltwh", "<f8", (4,)), ("pred_ltwh", "<f8", (4,)),
@@ -274,8 +275,8 @@ def _bind_bpbss(L):
     L.tlk_bpbss_destroy.argtypes = [C.c_void_p]
     L.tlk_bpbss_reset.argtypes = [C.c_void_p, C.c_int]
     L.tlk_bpbss_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
-    L.tlk_bpbss_update_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+                                   C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.tlk_bpbss_update_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.tlk_bpbss_get_tracks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.POINTER(C.c_int)]
     L.tlk_partdist_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -292,14 +293,15 @@ class BpbssBank:
                  min_bbox_confidence=0.2, only_position_for_kf_gating=False, max_kalman_prediction_without_update=7,
                  matching_strategy="strong_sort_matching", gating_thres_factor=1.5, w_kfgd=1, w_reid=1, w_st=1, *,
                  wrapper_mode=False, n_streams=1, device=0, max_tracks=256, max_dets=128):
-        if motion_criterium != "iou":
-            raise NotImplementedError("libtlk implements motion_criterium='iou' (oks is listed as next in DESIGN.md)")
+        if motion_criterium not in ("iou", "oks"):
+            raise ValueError("motion_criterium should be either 'iou' or 'oks'")
         L = lib()
         _bind_bpbss(L)
         self.params = BpbssParams(ema_alpha, mc_lambda, max_dist, max_iou_distance, min_bbox_confidence,
                                   gating_thres_factor, w_kfgd, w_reid, w_st, max_age, n_init,
                                   int(only_position_for_kf_gating), max_kalman_prediction_without_update,
-                                  MATCHING[matching_strategy], int(wrapper_mode), parts, dim, max_tracks, max_dets)
+                                  MATCHING[matching_strategy], int(wrapper_mode), parts, dim, max_tracks, max_dets,
+                                  {"iou": 0, "oks": 1}[motion_criterium], 0, max_oks_distance)
         self.K, self.D, self.n_streams, self.max_tracks, self.max_dets = parts, dim, n_streams, max_tracks, max_dets
         h = C.c_void_p()
         check(L.tlk_bpbss_create(C.byref(self.params), n_streams, device, C.byref(h)))
@@ -320,19 +322,21 @@ class BpbssBank:
     def reset(self, stream=-1):
         check(lib().tlk_bpbss_reset(self._h, stream))
 
-    def update(self, ids, ltwh, emb, vis, conf, stream=0):
+    def update(self, ids, ltwh, emb, vis, conf, stream=0, keypoints=None):
         ids = np.ascontiguousarray(ids, dtype=np.int64)
+        kps = None if keypoints is None else _f64(keypoints).reshape(-1, 51)
         ltwh = _f64(ltwh).reshape(-1, 4)
         emb = np.ascontiguousarray(emb, dtype=np.float32)
         vis = np.ascontiguousarray(vis, dtype=np.uint8)
         conf = _f64(conf)
         n = C.c_int(0)
         check(lib().tlk_bpbss_update(self._h, stream, ids.ctypes.data, ltwh.ctypes.data, emb.ctypes.data, vis.ctypes.data,
-                                     conf.ctypes.data, len(ids), self._rows.ctypes.data, len(self._rows), C.byref(n)))
+                                     conf.ctypes.data, None if kps is None else kps.ctypes.data, len(ids),
+                                     self._rows.ctypes.data, len(self._rows), C.byref(n)))
         return self._rows[:n.value].copy()
 
-    def update_dev(self, ids, ltwh, emb, vis, conf, counts, n_frames, rows, out_cap, out_counts, stream_ptr=None):
-        check(lib().tlk_bpbss_update_dev(self._h, ids, ltwh, emb, vis, conf, counts, n_frames, rows, out_cap, out_counts,
+    def update_dev(self, ids, ltwh, emb, vis, conf, counts, n_frames, rows, out_cap, out_counts, stream_ptr=None, kps=None):
+        check(lib().tlk_bpbss_update_dev(self._h, ids, ltwh, emb, vis, conf, kps, counts, n_frames, rows, out_cap, out_counts,
                                          stream_ptr))
 
     def tracks(self, stream=0):

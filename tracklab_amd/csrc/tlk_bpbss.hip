@@ -18,7 +18,8 @@ constexpr double INFTY_COST = 1e+5;                    // sort/linear_assignment
 __device__ __constant__ double CHI2INV95[10] = {0, 3.8415, 5.9915, 7.8147, 9.4877, 11.070, 12.592, 14.067, 15.507, 16.919};
 constexpr double W_POS = 1. / 20, W_VEL = 1. / 160;   // sort/kalman_filter.py:50-51
 
-enum : int { BD_MEAN = 0, BD_COV = 8, BD_PRED = 72, BD_MDIST = 76, BD_COUNT = 77 };
+enum : int { BD_MEAN = 0, BD_COV = 8, BD_PRED = 72, BD_MDIST = 76, BD_KP = 77, BD_COUNT = 77 + 51 };   // KP: last_detection.keypoints (17,3)
+constexpr int GLN = 24;   // per-track scratch: projected mean (4), Cholesky factor (16), OKS scale, OKS visible count
 enum : int { BI_TID = 0, BI_HITS, BI_AGE, BI_TSU, BI_STATE, BI_MNAME, BI_PVALID, BI_COUNT };
 enum : int { H_NTRK = 0, H_NEXTID, H_NFREE, H_ERR, H_COUNT = 8 };
 enum : int { ST_TENTATIVE = 0, ST_CONFIRMED = 1, ST_DELETED = 2 };
@@ -33,18 +34,20 @@ struct BpbDev {
     float *tnorm;            // S x MAXT x K x 2   by list position: (norm, sum of squares of the normalised vector)
     float *dnorm;            // S x MAXD x K x 2   by input detection index
     double *reid;            // S x MAXT x MAXD    part-based distance, row = list position, col = input detection index
-    double *gl;              // S x MAXT x 20      per track: projected mean (4) + Cholesky factor (16) for gating
+    double *gl;              // S x MAXT x GLN     per track: projected mean (4) + Cholesky factor (16) for gating, OKS scale + count
     double *cost_g;          // S x MAXT x MAXD    cost-matrix spill
     int S, MAXT, MAXD, K, D, cost_lds_entries;
 };
 
 struct BpbP {
     double ema_alpha, mc_lambda, max_dist, max_iou_distance, min_conf, gating_thres_factor, w_kfgd, w_reid, w_st;
-    int max_age, n_init, only_position, max_pred, strategy, wrapper_mode;
+    int max_age, n_init, only_position, max_pred, strategy, wrapper_mode, motion;
+    double max_oks_distance;
 };
 
 struct FrameIn {            // per-(stream, frame) strides in elements
     const long long *ids; const double *ltwh; const float *emb; const unsigned char *vis; const double *conf;
+    const double *kps;       // (.., 17, 3) COCO keypoints per detection or nullptr
     const int *counts; size_t stream_stride_dets; size_t count_stride;   // dets index = s*stream_stride_dets + i
 };
 
@@ -284,6 +287,58 @@ __device__ __forceinline__ double iou_ltwh(const double *b, const double *c)    
     return ai / (b[2] * b[3] + c[2] * c[3] - ai);
 }
 
+// sort/oks_matching.py:7-92. Scale of the track's keypoints (visible / all, axis-aligned and 45-degree rotated extents).
+__device__ __constant__ double KAPPA[17] = {0.026, 0.025, 0.025, 0.035, 0.035, 0.079, 0.079, 0.072, 0.072, 0.062, 0.062, 0.107, 0.107, 0.087, 0.087, 0.089, 0.089};
+template <class KP>
+__device__ double oks_scale(KP kp, int *nvis_out)
+{
+    const double c45 = 0.7071067811865476, s45 = 0.7071067811865475;       // np.cos / np.sin(np.deg2rad(45))
+    double tl[2] = {INFINITY, INFINITY}, br[2] = {-INFINITY, -INFINITY}, ttl[2] = {INFINITY, INFINITY}, tbr[2] = {-INFINITY, -INFINITY};
+    double tl4[2] = {INFINITY, INFINITY}, br4[2] = {-INFINITY, -INFINITY}, ttl4[2] = {INFINITY, INFINITY}, tbr4[2] = {-INFINITY, -INFINITY};
+    int nvis = 0;
+    for (int k = 0; k < 17; ++k) {
+        const double x = kp(3 * k), y = kp(3 * k + 1);
+        const double r[2] = {c45 * x + (-s45) * y, s45 * x + c45 * y};
+        const double p[2] = {x, y};
+        const bool v = kp(3 * k + 2) > 0.0;
+        nvis += v ? 1 : 0;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            if (p[a] < ttl[a]) ttl[a] = p[a];
+            if (p[a] > tbr[a]) tbr[a] = p[a];
+            if (r[a] < ttl4[a]) ttl4[a] = r[a];
+            if (r[a] > tbr4[a]) tbr4[a] = r[a];
+            if (v) {
+                if (p[a] < tl[a]) tl[a] = p[a];
+                if (p[a] > br[a]) br[a] = p[a];
+                if (r[a] < tl4[a]) tl4[a] = r[a];
+                if (r[a] > br4[a]) br4[a] = r[a];
+            }
+        }
+    }
+    *nvis_out = nvis;
+    const double area = (br[0] - tl[0]) * (br[1] - tl[1]), total_area = (tbr[0] - ttl[0]) * (tbr[1] - ttl[1]);
+    const double area45 = (br4[0] - tl4[0]) * (br4[1] - tl4[1]), total45 = (tbr4[0] - ttl4[0]) * (tbr4[1] - ttl4[1]);
+    const double f1 = area > 0.1 ? total_area / area : INFINITY, f2 = area45 > 0.1 ? total45 / area45 : INFINITY;
+    const double factor = sqrt(f1 < f2 ? f1 : f2);
+    const double fc = factor < 5.0 ? factor : 5.0;
+    double scale = sqrt(area) * fc;
+    if (scale < 0.1) scale = NAN;
+    return scale;
+}
+template <class KP>
+__device__ double oks_one(KP kp, double scale, int nvis, const double *c)
+{
+    double sum = 0;
+    for (int k = 0; k < 17; ++k) {
+        const double dx = kp(3 * k) - c[3 * k], dy = kp(3 * k + 1) - c[3 * k + 1];
+        const double d = sqrt(dx * dx + dy * dy);
+        const double e = exp(-(d * d) / (2 * (scale * scale) * (KAPPA[k] * KAPPA[k])));
+        sum += e * (kp(3 * k + 2) > 0.0 ? 1.0 : 0.0);
+    }
+    return sum / (double)nvis;
+}
+
 struct BTrk {
     double *fd; int *fi; size_t stride;
     __device__ double &d(int f) const { return fd[(size_t)f * stride]; }
@@ -407,7 +462,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
     unsigned char *fvisS = Dv.fvis + (size_t)s * MAXT * K;
     long long *detidS = Dv.detid + (size_t)s * MAXT;
     const double *reid = Dv.reid + (size_t)s * MAXT * MAXD;
-    double *gl = Dv.gl + (size_t)s * MAXT * 20;
+    double *gl = Dv.gl + (size_t)s * MAXT * GLN;
     tlk_bpbss_row *rows = rows_all + (size_t)s * rows_stream_stride;
     int *out_count = out_counts + (size_t)s * oc_stride;
     const size_t dbase = (size_t)s * in.stream_stride_dets;
@@ -443,6 +498,19 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
     __syncthreads();
     if (N > 0) {
         const int gdim = P.only_position ? 2 : 4;
+        const bool use_oks = P.motion == 1 && in.kps != nullptr;
+        const double motion_max = P.motion == 1 ? P.max_oks_distance : P.max_iou_distance;
+        // spatio-temporal cost of track position p vs filtered detection j: 1 - IoU (iou_matching.py:42-78) or 1 - OKS (oks_matching.py:95-128)
+        auto motion_cost = [&](int p, int j) {
+            const BTrk Kt = trk_at(order[p]);
+            if (use_oks) {
+                const double *g = gl + (size_t)p * GLN;
+                return 1.0 - oks_one([&](int q) { return Kt.d(BD_KP + q); }, g[20], (int)g[21], in.kps + (dbase + L.sel[j]) * 51);
+            }
+            double tl[4];
+            trk_ltwh(Kt, tl);
+            return 1. - iou_ltwh(tl, L.dltwh + j * 4);
+        };
         for (int j = tid; j < N; j += BLOCK) {              // detection.py:31-58
             const double *b = in.ltwh + (dbase + L.sel[j]) * 4;
             L.dltwh[j * 4] = b[0]; L.dltwh[j * 4 + 1] = b[1]; L.dltwh[j * 4 + 2] = b[2]; L.dltwh[j * 4 + 3] = b[3];
@@ -458,9 +526,10 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             for (int i = 0; i < gdim; ++i)
                 for (int j = 0; j < gdim; ++j) Sd[i * gdim + j] = Kt.d(BD_COV + i * 8 + j) + (i == j ? sstd * sstd : 0.0);
             chol4(Sd, gdim, Lc);
-            double *g = gl + (size_t)p * 20;
+            double *g = gl + (size_t)p * GLN;
             for (int i = 0; i < 4; ++i) g[i] = Kt.d(BD_MEAN + i);
             for (int q = 0; q < 16; ++q) g[4 + q] = Lc[q];
+            if (use_oks) { int nv; g[20] = oks_scale([&](int q) { return Kt.d(BD_KP + q); }, &nv); g[21] = (double)nv; }
         }
         __syncthreads();
         int nm = 0, n_umt = 0, n_umd = 0;
@@ -477,7 +546,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
                 const int r = e / N, j = e - r * N;
                 const int p = L.cand[r];
                 double c = reid[(size_t)p * MAXD + L.sel[j]];
-                const double gd = gating_from(gl + (size_t)p * 20, L.dxyah + j * 4, gdim);
+                const double gd = gating_from(gl + (size_t)p * GLN, L.dxyah + j * 4, gdim);
                 if (gd > CHI2INV95[gdim]) c = INFTY_COST;
                 c = P.mc_lambda * c + (1 - P.mc_lambda) * gd;
                 cm[e] = c > P.max_dist ? P.max_dist + 1e-5 : c;
@@ -490,7 +559,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
                 for (int k = tid; k < A.nm; k += BLOCK) {       // add_matching_information "R": un-thresholded gated cost (tracker.py:409-425)
                     const int p = L.m_t[k], j = L.m_d[k];
                     double c = reid[(size_t)p * MAXD + L.sel[j]];
-                    const double gd = gating_from(gl + (size_t)p * 20, L.dxyah + j * 4, gdim);
+                    const double gd = gating_from(gl + (size_t)p * GLN, L.dxyah + j * 4, gdim);
                     if (gd > CHI2INV95[gdim]) c = INFTY_COST;
                     L.d_mname[j] = 1; L.d_mdist[j] = P.mc_lambda * c + (1 - P.mc_lambda) * gd;
                 }
@@ -510,20 +579,16 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             double *cb = ((size_t)nb * n_uda <= (size_t)Dv.cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
             for (int e = tid; e < nb * n_uda; e += BLOCK) {          // iou_cost (iou_matching.py:42-78) + thresholding
                 const int r = e / n_uda, c = e - r * n_uda;
-                double tl[4];
-                trk_ltwh(trk_at(order[L.bc[r]]), tl);
-                const double v = 1. - iou_ltwh(tl, L.dltwh + L.um_da[c] * 4);
-                cb[e] = v > P.max_iou_distance ? P.max_iou_distance + 1e-5 : v;
+                const double v = motion_cost(L.bc[r], L.um_da[c]);
+                cb[e] = v > motion_max ? motion_max + 1e-5 : v;
             }
             __syncthreads();
-            const McmOut Bm = min_cost_matching(cb, nb, n_uda, P.max_iou_distance, L.bc, L.um_da, L.m_t + A.nm, L.m_d + A.nm,
+            const McmOut Bm = min_cost_matching(cb, nb, n_uda, motion_max, L.bc, L.um_da, L.m_t + A.nm, L.m_d + A.nm,
                                                 L.um_tb, L.um_db, L);
             if (nb > 0 && n_uda > 0)
                 for (int k = tid; k < Bm.nm; k += BLOCK) {        // "S"
                     const int p = L.m_t[A.nm + k], j = L.m_d[A.nm + k];
-                    double tl[4];
-                    trk_ltwh(trk_at(order[p]), tl);
-                    L.d_mname[j] = 2; L.d_mdist[j] = 1. - iou_ltwh(tl, L.dltwh + j * 4);
+                    L.d_mname[j] = 2; L.d_mdist[j] = motion_cost(p, j);
                 }
             nm = A.nm + Bm.nm;
             for (int k = tid; k < Bm.n_um_t; k += BLOCK) L.um_t[n_uta + k] = L.um_tb[k];
@@ -538,15 +603,13 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             const double GT = sqrt(CHI2INV95[gdim]);
             const double wsum = P.w_kfgd + P.w_reid + P.w_st;
             auto full_cost = [&](int p, int j) {
-                const double gd = gating_from(gl + (size_t)p * 20, L.dxyah + j * 4, gdim);
+                const double gd = gating_from(gl + (size_t)p * GLN, L.dxyah + j * 4, gdim);
                 const double pos = sqrt(gd) / (GT * P.gating_thres_factor);
                 const double app = reid[(size_t)p * MAXD + L.sel[j]];
-                double tl[4];
-                trk_ltwh(trk_at(order[p]), tl);
-                const double st = 1. - iou_ltwh(tl, L.dltwh + j * 4);
+                const double st = motion_cost(p, j);
                 const bool pos_gate = P.w_kfgd > 0 ? pos > 1.0 : false;
                 const bool app_gate = P.w_reid > 0 ? app > P.max_dist : false;
-                const bool st_gate = P.w_st > 0 ? st > P.max_iou_distance : false;
+                const bool st_gate = P.w_st > 0 ? st > motion_max : false;
                 const double c = (P.w_kfgd * pos + P.w_reid * app + st * P.w_st) / wsum;
                 // np.logical_or(pos_gate, app_gate, st_gate): the third argument is out= -> st_gate is not part of the mask
                 const bool m = P.w_kfgd > 0 ? (pos_gate || app_gate) : (P.w_st > 0 ? (app_gate || st_gate) : app_gate);
@@ -590,6 +653,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
 #pragma unroll
             for (int q = 0; q < 64; ++q) Kt.d(BD_COV + q) = cov[q];
             detidS[order[L.m_t[k]]] = in.ids[dbase + L.sel[j]];
+            if (in.kps) for (int q = 0; q < 51; ++q) Kt.d(BD_KP + q) = in.kps[(dbase + L.sel[j]) * 51 + q];
             Kt.i(BI_MNAME) = L.d_mname[j];
             Kt.d(BD_MDIST) = L.d_mdist[j];
             const int hits = Kt.i(BI_HITS) + 1;
@@ -657,6 +721,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             Kt.i(BI_STATE) = (1 >= P.n_init) ? ST_CONFIRMED : ST_TENTATIVE;
             Kt.i(BI_MNAME) = L.d_mname[j]; Kt.d(BD_MDIST) = L.d_mdist[j]; Kt.i(BI_PVALID) = 0;
             detidS[slot] = in.ids[dbase + L.sel[j]];
+            if (in.kps) for (int q = 0; q < 51; ++q) Kt.d(BD_KP + q) = in.kps[(dbase + L.sel[j]) * 51 + q];
         }
         {   // copy the new tracks' part embeddings + visibility
             const int w = tid >> 6, lane = tid & 63;
@@ -736,7 +801,7 @@ __global__ void bpbss_gather_kernel(BpbDev D, int stream, long long *ids, double
 struct tlk_bpbss {
     BpbDev D; BpbP P; int device; size_t smem;
     // staging for the host-buffer entry point
-    long long *d_ids; double *d_ltwh; float *d_emb; unsigned char *d_vis; double *d_conf; int *d_cnt, *d_ocnt; tlk_bpbss_row *d_rows;
+    long long *d_ids; double *d_ltwh; float *d_emb; unsigned char *d_vis; double *d_conf, *d_kps; int *d_cnt, *d_ocnt; tlk_bpbss_row *d_rows;
     int out_cap;
 };
 
@@ -746,7 +811,7 @@ static void bpb_free(tlk_bpbss *h)
     hipSetDevice(h->device);
     BpbDev &D = h->D;
     void *ptrs[] = {D.fd, D.fi, D.detid, D.hdr, D.order, D.freestk, D.feat, D.fvis, D.tnorm, D.dnorm, D.reid, D.gl, D.cost_g,
-                    h->d_ids, h->d_ltwh, h->d_emb, h->d_vis, h->d_conf, h->d_cnt, h->d_ocnt, h->d_rows};
+                    h->d_ids, h->d_ltwh, h->d_emb, h->d_vis, h->d_conf, h->d_kps, h->d_cnt, h->d_ocnt, h->d_rows};
     for (void *p : ptrs) if (p) hipFree(p);
     delete h;
 }
@@ -782,7 +847,8 @@ extern "C" int tlk_bpbss_create(const tlk_bpbss_params *p, int n_streams, int de
     h->device = device;
     h->P = BpbP{p->ema_alpha, p->mc_lambda, p->max_dist, p->max_iou_distance, p->min_bbox_confidence, p->gating_thres_factor,
                 p->w_kfgd, p->w_reid, p->w_st, p->max_age, p->n_init, p->only_position_for_kf_gating,
-                p->max_kalman_prediction_without_update, p->matching_strategy, p->wrapper_mode};
+                p->max_kalman_prediction_without_update, p->matching_strategy, p->wrapper_mode, p->motion_criterium, p->max_oks_distance};
+    if (p->motion_criterium < 0 || p->motion_criterium > 1) { delete h; return fail(TLK_EINVAL, "tlk_bpbss_create: motion_criterium must be 0 (iou) or 1 (oks)"); }
     BpbDev &D = h->D;
     D.S = n_streams; D.MAXT = MAXT; D.MAXD = MAXD; D.K = p->parts; D.D = p->dim;
     const size_t fixed = blds_fixed(MAXT, MAXD), budget = 160 * 1024 - 256;
@@ -804,13 +870,14 @@ extern "C" int tlk_bpbss_create(const tlk_bpbss_params *p, int n_streams, int de
     BPB_ALLOC(D.tnorm, sizeof(float) * 2 * D.K * slots);
     BPB_ALLOC(D.dnorm, sizeof(float) * 2 * D.K * (size_t)n_streams * MAXD);
     BPB_ALLOC(D.reid, sizeof(double) * slots * MAXD);
-    BPB_ALLOC(D.gl, sizeof(double) * 20 * slots);
+    BPB_ALLOC(D.gl, sizeof(double) * GLN * slots);
     BPB_ALLOC(D.cost_g, sizeof(double) * slots * MAXD);
     BPB_ALLOC(h->d_ids, sizeof(long long) * MAXD);
     BPB_ALLOC(h->d_ltwh, sizeof(double) * 4 * MAXD);
     BPB_ALLOC(h->d_emb, sizeof(float) * FD * MAXD);
     BPB_ALLOC(h->d_vis, (size_t)D.K * MAXD);
     BPB_ALLOC(h->d_conf, sizeof(double) * MAXD);
+    BPB_ALLOC(h->d_kps, sizeof(double) * 51 * MAXD);
     BPB_ALLOC(h->d_cnt, sizeof(int));
     BPB_ALLOC(h->d_ocnt, sizeof(int));
     BPB_ALLOC(h->d_rows, sizeof(tlk_bpbss_row) * h->out_cap);
@@ -842,8 +909,8 @@ extern "C" int tlk_bpbss_reset(tlk_bpbss *h, int stream)
 }
 
 extern "C" int tlk_bpbss_update_dev(tlk_bpbss *h, const int64_t *ids_dev, const double *ltwh_dev, const float *emb_dev,
-                                    const uint8_t *vis_dev, const double *conf_dev, const int32_t *counts_dev, int n_frames,
-                                    tlk_bpbss_row *rows_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream)
+                                    const uint8_t *vis_dev, const double *conf_dev, const double *kps_dev, const int32_t *counts_dev,
+                                    int n_frames, tlk_bpbss_row *rows_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream)
 {
     if (!h) return fail(TLK_EINVAL, "tlk_bpbss_update_dev: null handle");
     if (n_frames < 0 || out_cap < 0) return fail(TLK_EINVAL, "tlk_bpbss_update_dev: negative size");
@@ -858,6 +925,7 @@ extern "C" int tlk_bpbss_update_dev(tlk_bpbss *h, const int64_t *ids_dev, const 
         FrameIn in;
         in.ids = (const long long *)ids_dev + off; in.ltwh = ltwh_dev + off * 4; in.emb = emb_dev + off * FD;
         in.vis = vis_dev + off * D.K; in.conf = conf_dev + off; in.counts = (const int *)counts_dev + f;
+        in.kps = kps_dev ? kps_dev + off * 51 : nullptr;
         in.stream_stride_dets = (size_t)n_frames * D.MAXD; in.count_stride = (size_t)n_frames;
         const int rc = launch_frame(h, D, D.S, in, rows_dev + (size_t)f * out_cap, (size_t)n_frames * out_cap, out_cap,
                                     (int *)out_counts_dev + f, (size_t)n_frames, (hipStream_t)hip_stream);
@@ -867,7 +935,8 @@ extern "C" int tlk_bpbss_update_dev(tlk_bpbss *h, const int64_t *ids_dev, const 
 }
 
 extern "C" int tlk_bpbss_update(tlk_bpbss *h, int stream, const int64_t *ids, const double *ltwh, const float *emb,
-                                const uint8_t *vis, const double *conf, int n, tlk_bpbss_row *rows, int cap, int *n_out)
+                                const uint8_t *vis, const double *conf, const double *kps, int n, tlk_bpbss_row *rows, int cap,
+                                int *n_out)
 {
     if (!h || !n_out) return fail(TLK_EINVAL, "tlk_bpbss_update: null pointer");
     if (stream < 0 || stream >= h->D.S) return fail(TLK_EINVAL, "tlk_bpbss_update: stream out of range");
@@ -882,15 +951,18 @@ extern "C" int tlk_bpbss_update(tlk_bpbss *h, int stream, const int64_t *ids, co
         TLK_HIP(hipMemcpyAsync(h->d_emb, emb, sizeof(float) * FD * n, hipMemcpyHostToDevice, st));
         TLK_HIP(hipMemcpyAsync(h->d_vis, vis, (size_t)h->D.K * n, hipMemcpyHostToDevice, st));
         TLK_HIP(hipMemcpyAsync(h->d_conf, conf, sizeof(double) * n, hipMemcpyHostToDevice, st));
+        if (kps) TLK_HIP(hipMemcpyAsync(h->d_kps, kps, sizeof(double) * 51 * n, hipMemcpyHostToDevice, st));
     }
     TLK_HIP(hipMemcpyAsync(h->d_cnt, &n, sizeof(int), hipMemcpyHostToDevice, st));
     BpbDev V = h->D;       // single-stream view: shift per-stream bases, keep strides
     const size_t sl = (size_t)stream * V.MAXT;
     V.fd += sl; V.fi += sl; V.detid += sl; V.hdr += (size_t)stream * H_COUNT; V.order += sl; V.freestk += sl;
     V.feat += sl * FD; V.fvis += sl * V.K; V.tnorm += sl * V.K * 2; V.dnorm += (size_t)stream * V.MAXD * V.K * 2;
-    V.reid += sl * V.MAXD; V.gl += sl * 20; V.cost_g += sl * V.MAXD;
+    V.reid += sl * V.MAXD; V.gl += sl * GLN; V.cost_g += sl * V.MAXD;
     FrameIn in;
     in.ids = h->d_ids; in.ltwh = h->d_ltwh; in.emb = h->d_emb; in.vis = h->d_vis; in.conf = h->d_conf; in.counts = h->d_cnt;
+    in.kps = kps ? h->d_kps : nullptr;
+    if (h->P.motion == 1 && n > 0 && !kps) return fail(TLK_EINVAL, "tlk_bpbss_update: motion_criterium 'oks' needs keypoints");
     in.stream_stride_dets = 0; in.count_stride = 0;
     const int rc = launch_frame(h, V, 1, in, h->d_rows, 0, h->out_cap, h->d_ocnt, 0, st);
     if (rc != TLK_OK) return rc;

@@ -194,3 +194,23 @@ def synth_yolox_head(rng: np.random.Generator, boxes_xyxy: np.ndarray, size: int
             pred[a, 4] = rng.uniform(0.9, 1.0) if d == 0 else rng.uniform(0.85, 0.95)
             pred[a, 5 + (k % num_classes)] = rng.uniform(0.9, 1.0)
     return pred
+
+
+_KP_REL = np.array([[0.50, 0.07], [0.56, 0.05], [0.44, 0.05], [0.63, 0.08], [0.37, 0.08], [0.75, 0.22], [0.25, 0.22],
+                    [0.85, 0.38], [0.15, 0.38], [0.88, 0.52], [0.12, 0.52], [0.65, 0.55], [0.35, 0.55],
+                    [0.66, 0.75], [0.34, 0.75], [0.67, 0.95], [0.33, 0.95]])
+
+
+def synth_keypoints(rng: np.random.Generator, ltrb: np.ndarray, invisible_prob: float = 0.15) -> np.ndarray:
+    """COCO-17 keypoints (n,17,3) [x, y, conf] placed at fixed relative positions inside each box + 2 px jitter;
+    a random subset gets conf 0 (invisible; at least the shoulders and hips stay visible)."""
+    n = len(ltrb)
+    w, h = ltrb[:, 2] - ltrb[:, 0], ltrb[:, 3] - ltrb[:, 1]
+    kp = np.empty((n, 17, 3))
+    kp[:, :, 0] = ltrb[:, None, 0] + _KP_REL[None, :, 0] * w[:, None] + rng.normal(0, 2, (n, 17))
+    kp[:, :, 1] = ltrb[:, None, 1] + _KP_REL[None, :, 1] * h[:, None] + rng.normal(0, 2, (n, 17))
+    conf = rng.uniform(0.3, 1.0, (n, 17))
+    conf[rng.uniform(0, 1, (n, 17)) < invisible_prob] = 0.0
+    conf[:, [5, 6, 11, 12]] = np.maximum(conf[:, [5, 6, 11, 12]], 0.3)
+    kp[:, :, 2] = conf
+    return kp

@@ -111,7 +111,8 @@ class HipBPBReIDStrongSORT(ImageLevelModule):
                 "visibility_scores": np.stack(detections.visibility_scores.to_list()),
                 "scores": np.asarray(score, dtype=np.float64),
                 "classes": np.zeros(len(detections.index)),
-                "frame": np.ones(len(detections.index)) * metadata.frame}
+                "frame": np.ones(len(detections.index)) * metadata.frame,
+                **({"keypoints": np.stack(detections.keypoints_xyc.to_list())} if "keypoints_xyc" in detections else {})}
 
     def process(self, batch, detections: pd.DataFrame, metadatas: pd.DataFrame):
         if len(detections) == 0:
@@ -123,8 +124,9 @@ class HipBPBReIDStrongSORT(ImageLevelModule):
         conf = _strip(to_numpy(batch["scores"]), 1)
         if self._bank is None:
             self._bank = self._make_backend(emb.shape[1], emb.shape[2])
+        kps = _strip(to_numpy(batch["keypoints"]), 3).astype(np.float64) if "keypoints" in batch else None
         rows = self._bank.update(ids.astype(np.int64), ltwh.astype(np.float64), emb.astype(np.float32),
-                                 vis.astype(bool).astype(np.uint8), conf.astype(np.float64), 0)
+                                 vis.astype(bool).astype(np.uint8), conf.astype(np.float64), 0, keypoints=kps)
         assert set(rows["det_id"]).issubset(detections.index), \
             "Mismatch of indexes during the tracking. The results should match the detections."
         out = pd.DataFrame({
