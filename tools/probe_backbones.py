@@ -1,5 +1,7 @@
 """Probe (not product): backbone forward times on the GPU box for the design notes."""
 import sys, time, torch
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tracklab_amd.backbones.yolox import yolox
 from tracklab_amd.backbones.reid import part_based_reid
 

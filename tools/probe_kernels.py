@@ -5,6 +5,8 @@ read exactly once by the same byte loads) and a 1 GiB torch copy (wide coalesced
 import numpy as np
 import torch
 
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tracklab_amd import _lib
 from tracklab_amd.synth import SyntheticStream
 

@@ -1,6 +1,8 @@
 """Probe (not product): the two MFMA kernels at canonical sizes, for rocprofv3 timing / MFMA counters."""
 import numpy as np
 import torch
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tracklab_amd import _lib
 rng = np.random.default_rng(0)
 T, G, N, D = 100, 100, 100, 512

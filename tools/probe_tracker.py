@@ -8,6 +8,8 @@ import numpy as np
 import torch
 
 os.environ.setdefault("TLK_OCSORT_PROF", "1")
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tracklab_amd import _lib
 from tracklab_amd.synth import SyntheticStream
 
