@@ -239,8 +239,9 @@ static_assert(sizeof(XCoef) == 8, "XCoef");
 
 // ---- crop: workgroup = (slot, band of CROP_BAND output rows); OW <= 256
 constexpr int CROP_BAND = 16;
-constexpr int CROP_LDS_ROW_BYTES = 1024;               // staged segment per source row (crops up to ~330 px wide)
-constexpr int CROP_LDS_ROWS = 40;
+constexpr int CROP_LDS_ROW_BYTES = 544;                // staged segment per source row: crops up to 170 px wide; 136 words -> rows
+                                                       // start 8 banks apart (a 128-byte-multiple stride made every row hit the same banks)
+constexpr int CROP_LDS_ROWS = 18;                      // 16 output rows of an upscaled band touch <= 18 source rows (9.8 KB -> 8 workgroups/CU)
 
 template <typename T, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK) crop_lds_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
@@ -249,7 +250,7 @@ __global__ void __launch_bounds__(BLOCK) crop_lds_kernel(const unsigned char *__
                                                          T *__restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_rows[CROP_LDS_ROWS * CROP_LDS_ROW_BYTES];
-    __shared__ int s_xoff[256], s_xw0[256], s_xw1[256], s_xstep[256];
+    __shared__ int4 s_xc[256];          // (byte offset of tap 0, w0, w1, tap-1 step) stored k-major: [k * groups + xg] -> lanes read consecutive 16 B
     __shared__ int s_y0[CROP_BAND], s_y1[CROP_BAND], s_yw0[CROP_BAND], s_yw1[CROP_BAND];
     __shared__ int s_hdr[8];
     const int tid = threadIdx.x;
@@ -278,8 +279,7 @@ __global__ void __launch_bounds__(BLOCK) crop_lds_kernel(const unsigned char *__
                           s_rows + rr * CROP_LDS_ROW_BYTES, gend, tid, BLOCK);
             if (tid < OW) {
                 const Coef cx = cv_coef(tid, cw, OW, true);
-                s_xoff[tid] = cx.s * 3; s_xw0[tid] = cx.w0; s_xw1[tid] = cx.w1;
-                s_xstep[tid] = (cx.s + 1 < cw ? 3 : 0);
+                s_xc[(tid & 7) * groups_per_row + (tid >> 3)] = make_int4(cx.s * 3, cx.w0, cx.w1, (cx.s + 1 < cw ? 3 : 0));
             }
             if (tid < CROP_BAND && y_base + tid < OH) {
                 const Coef cy = cv_coef(y_base + tid, ch, OH, false);
@@ -306,8 +306,8 @@ __global__ void __launch_bounds__(BLOCK) crop_lds_kernel(const unsigned char *__
             const int b0 = s_yw0[ry], b1 = s_yw1[ry];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int x = x_base + k;
-                const int o0 = s_xoff[x], o1 = o0 + s_xstep[x], a0 = s_xw0[x], a1 = s_xw1[x];
+                const int4 cx = s_xc[k * groups_per_row + (x_base >> 3)];
+                const int o0 = cx.x, o1 = o0 + cx.w, a0 = cx.y, a1 = cx.z;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const int S0 = (int)p0[o0 + c] * a0 + (int)p0[o1 + c] * a1;
