@@ -14,7 +14,7 @@ namespace {
 
 // ---- cv2.resize(INTER_LINEAR, uint8) coefficients, OpenCV imgproc/resize.cpp (INTER_RESIZE_COEF_BITS = 11)
 struct Coef { int s; int w0, w1; };
-__device__ __forceinline__ Coef cv_coef(int d, int ssize, int dsize, bool is_col)
+__host__ __device__ __forceinline__ Coef cv_coef(int d, int ssize, int dsize, bool is_col)
 {
     const double scale = (double)ssize / (double)dsize;
     float f = (float)(((double)d + 0.5) * scale - 0.5);
@@ -26,8 +26,8 @@ __device__ __forceinline__ Coef cv_coef(int d, int ssize, int dsize, bool is_col
     }
     Coef c;
     c.s = s;
-    c.w0 = (int)(short)__float2int_rn((1.f - f) * 2048.f);
-    c.w1 = (int)(short)__float2int_rn(f * 2048.f);
+    c.w0 = (int)(short)(int)rintf((1.f - f) * 2048.f);      // round-half-even, as cvRound
+    c.w1 = (int)(short)(int)rintf(f * 2048.f);
     return c;
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -274,9 +274,21 @@ __global__ void __launch_bounds__(BLOCK) crop_lds_kernel(const unsigned char *__
         staged = nrows <= CROP_LDS_ROWS && cw * 3 + STAGE_PAD <= CROP_LDS_ROW_BYTES;
         if (staged) {
             const unsigned char *gend = frames + (size_t)B * H * W * 3;
-            for (int rr = 0; rr < nrows; ++rr)
-                stage_row(frames + ((size_t)b * H * W + (size_t)(t + r_lo + rr) * W + l) * 3, cw * 3,
-                          s_rows + rr * CROP_LDS_ROW_BYTES, gend, tid, BLOCK);
+            // all (row, 16-byte chunk) pairs of the band are fetched in ONE sweep (a row is only ~10 chunks: staging row after
+            // row serialised nrows global round trips per workgroup and left 60 % of the wave cycles waiting)
+            const int cmax = (cw * 3 + 30) >> 4;
+            for (int idx = tid; idx < nrows * cmax; idx += BLOCK) {
+                const int rr = idx / cmax, c = idx - rr * cmax;
+                const unsigned char *g0 = frames + ((size_t)b * H * W + (size_t)(t + r_lo + rr) * W + l) * 3;
+                const uintptr_t a0 = (uintptr_t)g0 & ~(uintptr_t)15;
+                const int chunks = ((int)((uintptr_t)g0 - a0) + cw * 3 + 15) >> 4;
+                if (c < chunks) {
+                    const unsigned char *p = (const unsigned char *)a0 + (size_t)c * 16;
+                    unsigned char *lds = s_rows + rr * CROP_LDS_ROW_BYTES + c * 16;
+                    if (p + 16 <= gend) *reinterpret_cast<uint4 *>(lds) = *reinterpret_cast<const uint4 *>(p);
+                    else for (int k = 0; k < 16 && p + k < gend; ++k) lds[k] = p[k];
+                }
+            }
             if (tid < OW) {
                 const Coef cx = cv_coef(tid, cw, OW, true);
                 s_xc[(tid & 7) * groups_per_row + (tid >> 3)] = make_int4(cx.s * 3, cx.w0, cx.w1, (cx.s + 1 < cw ? 3 : 0));
@@ -360,43 +372,75 @@ constexpr int LB_BAND = 4;
 
 template <typename T, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK) letterbox_lds_kernel(const unsigned char *__restrict__ frames, int B, int H, int W, int S,
-                                                              int rh, int rw, T *__restrict__ out, int row_bytes_lds)
+                                                              int rh, int rw, T *__restrict__ out, int row_bytes_lds, int max_rows)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     __shared__ int s_y0[LB_BAND], s_y1[LB_BAND], s_yw0[LB_BAND], s_yw1[LB_BAND], s_sh0[LB_BAND], s_sh1[LB_BAND];
+    __shared__ int s_src[2 * LB_BAND], s_dst[2 * LB_BAND], s_nsrc;
     const int tid = threadIdx.x;
     const int bands = S / LB_BAND;
     const int b = blockIdx.x / bands, band = blockIdx.x - b * bands;
     const int y_base = band * LB_BAND;
     const unsigned char *img = frames + (size_t)b * H * W * 3;
     const unsigned char *gend = frames + (size_t)B * H * W * 3;
-    // x coefficient table lives behind the staged rows
-    int *s_xoff = reinterpret_cast<int *>(s_dyn + (size_t)2 * LB_BAND * row_bytes_lds);
-    int *s_xw0 = s_xoff + S, *s_xw1 = s_xw0 + S, *s_xstep = s_xw1 + S;
+    // x coefficient table lives behind the staged rows: (byte offset of tap 0, w0, w1, tap-1 step), k-major
+    // [k * groups + xg] so that the 64 lanes of a wave read consecutive 16-byte entries
+    int4 *s_xc = reinterpret_cast<int4 *>(s_dyn + (size_t)max_rows * row_bytes_lds);
+    const int groups_per_row = S / 8;
     const bool any_real = y_base < rh;
     if (any_real) {
-        for (int ry = 0; ry < LB_BAND; ++ry) {
-            const int y = y_base + ry;
-            if (y >= rh) break;
-            const Coef cy = cv_coef(y, H, rh, false);
-            const int r0 = clampi(cy.s, 0, H - 1), r1 = clampi(cy.s + 1, 0, H - 1);
-            const unsigned char *g0 = img + (size_t)r0 * W * 3, *g1 = img + (size_t)r1 * W * 3;
-            stage_row(g0, W * 3, s_dyn + (size_t)(2 * ry) * row_bytes_lds, gend, tid, BLOCK);
-            if (cy.w1 != 0) stage_row(g1, W * 3, s_dyn + (size_t)(2 * ry + 1) * row_bytes_lds, gend, tid, BLOCK);
-            if (tid == 0) {
-                s_y0[ry] = 2 * ry; s_y1[ry] = cy.w1 != 0 ? 2 * ry + 1 : 2 * ry;
+        if (tid == 0) {
+            int n = 0;
+            for (int ry = 0; ry < LB_BAND; ++ry) {
+                const int y = y_base + ry;
+                if (y >= rh) break;
+                const Coef cy = cv_coef(y, H, rh, false);
+                const int r0 = clampi(cy.s, 0, H - 1), r1 = clampi(cy.s + 1, 0, H - 1);
+                const unsigned char *g0 = img + (size_t)r0 * W * 3, *g1 = img + (size_t)r1 * W * 3;
+                s_y0[ry] = n; s_y1[ry] = cy.w1 != 0 ? n + 1 : n;      // staged slots are handed out compactly (host sized the LDS for it)
                 s_yw0[ry] = cy.w0; s_yw1[ry] = cy.w1;
                 s_sh0[ry] = (int)((uintptr_t)g0 & 15); s_sh1[ry] = cy.w1 != 0 ? (int)((uintptr_t)g1 & 15) : (int)((uintptr_t)g0 & 15);
+                s_src[n] = r0; s_dst[n] = n; ++n;
+                if (cy.w1 != 0) { s_src[n] = r1; s_dst[n] = n; ++n; }
             }
+            s_nsrc = n;
         }
         for (int x = tid; x < rw; x += BLOCK) {
             const Coef cx = cv_coef(x, W, rw, true);
-            s_xoff[x] = cx.s * 3; s_xw0[x] = cx.w0; s_xw1[x] = cx.w1; s_xstep[x] = (cx.s + 1 < W ? 3 : 0);
+            s_xc[(x & 7) * groups_per_row + (x >> 3)] = make_int4(cx.s * 3, cx.w0, cx.w1, (cx.s + 1 < W ? 3 : 0));
+        }
+        __syncthreads();
+        // every (source row, 16-byte chunk) pair of the band in one flat sweep, 4 loads in flight per thread before the
+        // LDS stores (row-after-row staging serialised up to 2*LB_BAND global round trips per workgroup)
+        const int cmax = (W * 3 + 30) >> 4;
+        const int total = s_nsrc * cmax;
+        for (int base = 0; base < total; base += 4 * BLOCK) {
+            uint4 v[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * BLOCK + tid;
+                dst[u] = -1;
+                if (idx < total) {
+                    const int j = idx / cmax, c = idx - j * cmax;
+                    const unsigned char *g0 = img + (size_t)s_src[j] * W * 3;
+                    const uintptr_t a0 = (uintptr_t)g0 & ~(uintptr_t)15;
+                    const int chunks = ((int)((uintptr_t)g0 - a0) + W * 3 + 15) >> 4;
+                    if (c < chunks) {
+                        const unsigned char *p = (const unsigned char *)a0 + (size_t)c * 16;
+                        const int d = s_dst[j] * row_bytes_lds + c * 16;
+                        if (p + 16 <= gend) { v[u] = *reinterpret_cast<const uint4 *>(p); dst[u] = d; }
+                        else for (int k = 0; k < 16 && p + k < gend; ++k) s_dyn[d + k] = p[k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst[u] >= 0) *reinterpret_cast<uint4 *>(s_dyn + dst[u]) = v[u];
         }
     }
     __syncthreads();
     constexpr int ROWS = (LAYOUT == LAYOUT_FOCUS_NHWC) ? 2 : 1;
-    const int groups_per_row = S / 8;
     for (int unit = tid; unit < (LB_BAND / ROWS) * groups_per_row; unit += BLOCK) {
         const int ru = unit / groups_per_row, x_base = (unit - ru * groups_per_row) * 8;
         T px[ROWS][8][3];
@@ -415,7 +459,8 @@ __global__ void __launch_bounds__(BLOCK) letterbox_lds_kernel(const unsigned cha
             for (int k = 0; k < 8; ++k) {
                 const int x = x_base + k;
                 if (yin && x < rw) {
-                    const int o0 = s_xoff[x], o1 = o0 + s_xstep[x], a0 = s_xw0[x], a1 = s_xw1[x];
+                    const int4 cx = s_xc[k * groups_per_row + (x_base >> 3)];
+                    const int o0 = cx.x, o1 = o0 + cx.w, a0 = cx.y, a1 = cx.z;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         int S0 = (int)p0[o0 + c] * a0;
@@ -604,12 +649,21 @@ template <typename T>
 int launch_letterbox(const unsigned char *frames, int B, int H, int W, int S, int rh, int rw, int layout, void *out, hipStream_t st)
 {
     const int row_bytes = ((W * 3 + STAGE_PAD) + 15) & ~15;
-    const size_t smem = (size_t)2 * LB_BAND * row_bytes + (size_t)4 * S * sizeof(int);
+    // staged source rows per band: one per output row plus one more where the vertical tap-1 weight is non-zero (same
+    // cv_coef as the kernel, evaluated here so the LDS allocation -- and with it the workgroups per CU -- is what the ratio needs)
+    int max_rows = 1;
+    if (S % LB_BAND == 0)
+        for (int y0 = 0; y0 < rh; y0 += LB_BAND) {
+            int n = 0;
+            for (int y = y0; y < y0 + LB_BAND && y < rh; ++y) n += cv_coef(y, H, rh, false).w1 != 0 ? 2 : 1;
+            if (n > max_rows) max_rows = n;
+        }
+    const size_t smem = (size_t)max_rows * row_bytes + (size_t)4 * S * sizeof(int);
     if (smem <= 64 * 1024 && S % LB_BAND == 0) {          // LDS-staged fast path
         const dim3 grid((unsigned)(B * (S / LB_BAND)));
-        if (layout == LAYOUT_NCHW) hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes);
-        else if (layout == LAYOUT_NHWC) hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes);
-        else hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_FOCUS_NHWC>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes);
+        if (layout == LAYOUT_NCHW) hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes, max_rows);
+        else if (layout == LAYOUT_NHWC) hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes, max_rows);
+        else hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_FOCUS_NHWC>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes, max_rows);
         return TLK_OK;
     }
     const long long units = (long long)B * (S / 8) * (layout == LAYOUT_FOCUS_NHWC ? S / 2 : S);
