@@ -14,9 +14,8 @@ namespace {
 
 // ---- cv2.resize(INTER_LINEAR, uint8) coefficients, OpenCV imgproc/resize.cpp (INTER_RESIZE_COEF_BITS = 11)
 struct Coef { int s; int w0, w1; };
-__host__ __device__ __forceinline__ Coef cv_coef(int d, int ssize, int dsize, bool is_col)
+__host__ __device__ __forceinline__ Coef cv_coef_s(int d, int ssize, double scale, bool is_col)
 {
-    const double scale = (double)ssize / (double)dsize;
     float f = (float)(((double)d + 0.5) * scale - 0.5);
     int s = (int)floorf(f);
     f -= (float)s;
@@ -29,6 +28,10 @@ __host__ __device__ __forceinline__ Coef cv_coef(int d, int ssize, int dsize, bo
     c.w0 = (int)(short)(int)rintf((1.f - f) * 2048.f);      // round-half-even, as cvRound
     c.w1 = (int)(short)(int)rintf(f * 2048.f);
     return c;
+}
+__host__ __device__ __forceinline__ Coef cv_coef(int d, int ssize, int dsize, bool is_col)
+{
+    return cv_coef_s(d, ssize, (double)ssize / (double)dsize, is_col);
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -238,10 +241,10 @@ struct XCoef { short off; short w0, w1, pad; };       // byte offset of tap 0 in
 static_assert(sizeof(XCoef) == 8, "XCoef");
 
 // ---- crop: workgroup = (slot, band of CROP_BAND output rows); OW <= 256
-constexpr int CROP_BAND = 16;
+constexpr int CROP_BAND = 32;
 constexpr int CROP_LDS_ROW_BYTES = 544;                // staged segment per source row: crops up to 170 px wide; 136 words -> rows
                                                        // start 8 banks apart (a 128-byte-multiple stride made every row hit the same banks)
-constexpr int CROP_LDS_ROWS = 18;                      // 16 output rows of an upscaled band touch <= 18 source rows (9.8 KB -> 8 workgroups/CU)
+constexpr int CROP_LDS_ROWS = 34;                      // 32 output rows of an upscaled band touch <= 34 source rows (18 KB -> 8 workgroups/CU)
 
 template <typename T, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK) crop_lds_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
@@ -268,7 +271,8 @@ __global__ void __launch_bounds__(BLOCK) crop_lds_kernel(const unsigned char *__
     if (valid) {
         // band row range (uniform): first/last source rows touched by output rows [y_base, y_base+CROP_BAND)
         const int ylast = min(y_base + CROP_BAND, OH) - 1;
-        const Coef c_first = cv_coef(y_base, ch, OH, false), c_last = cv_coef(ylast, ch, OH, false);
+        const double scale_y = (double)ch / (double)OH, scale_x = (double)cw / (double)OW;     // one fp64 division per axis
+        const Coef c_first = cv_coef_s(y_base, ch, scale_y, false), c_last = cv_coef_s(ylast, ch, scale_y, false);
         const int r_lo = clampi(c_first.s, 0, ch - 1), r_hi = clampi(c_last.s + 1, 0, ch - 1);
         const int nrows = r_hi - r_lo + 1;
         staged = nrows <= CROP_LDS_ROWS && cw * 3 + STAGE_PAD <= CROP_LDS_ROW_BYTES;
@@ -290,11 +294,11 @@ __global__ void __launch_bounds__(BLOCK) crop_lds_kernel(const unsigned char *__
                 }
             }
             if (tid < OW) {
-                const Coef cx = cv_coef(tid, cw, OW, true);
+                const Coef cx = cv_coef_s(tid, cw, scale_x, true);
                 s_xc[(tid & 7) * groups_per_row + (tid >> 3)] = make_int4(cx.s * 3, cx.w0, cx.w1, (cx.s + 1 < cw ? 3 : 0));
             }
             if (tid < CROP_BAND && y_base + tid < OH) {
-                const Coef cy = cv_coef(y_base + tid, ch, OH, false);
+                const Coef cy = cv_coef_s(y_base + tid, ch, scale_y, false);
                 s_y0[tid] = clampi(cy.s, 0, ch - 1) - r_lo; s_y1[tid] = clampi(cy.s + 1, 0, ch - 1) - r_lo;
                 s_yw0[tid] = cy.w0; s_yw1[tid] = cy.w1;
             }
