@@ -100,6 +100,47 @@ int tlk_ocsort_get_tracks(tlk_ocsort *h, int stream, double *x, double *P, int64
 int tlk_ocsort_get_profile(tlk_ocsort *h, int stream, long long *cycles16);
 
 /* ------------------------------------------------------------------------------------------
+ * Stateless Kalman-filter steps, batched: entry i of every array is one independent filter
+ * (one GPU thread per filter, state in registers). They are the same device functions the fused
+ * tracker kernels call; exported so each reference method has its own parity test.
+ *
+ * KF7 = OC-SORT's KalmanFilterNew(dim_x=7, dim_z=4) as configured by KalmanBoxTracker
+ * (plugins/track/oc_sort/ocsort.py:63-107: F, H, R[2:,2:]*=10, P, Q):
+ *   tlk_kf7_predict_f64  <- KalmanFilterNew.predict   (oc_sort/kalmanfilter.py:368-379), x (n,7), P (n,7,7) in place
+ *   tlk_kf7_update_f64   <- KalmanFilterNew.update(z) (oc_sort/kalmanfilter.py:480-526, z is not None branch), z (n,4)
+ * KF8 = StrongSORT's xyah filter with NSA noise scaling (plugins/track/bpbreid_strong_sort/sort/kalman_filter.py):
+ *   tlk_kf8_initiate_f64 <- initiate :53-83     meas (n,4) xyah -> mean (n,8), cov (n,8,8)
+ *   tlk_kf8_predict_f64  <- predict  :85-119    in place
+ *   tlk_kf8_project_f64  <- project  :121-152   conf_dev (n) or NULL (= 0) -> pmean (n,4), pcov (n,4,4)
+ *   tlk_kf8_update_f64   <- update   :154-187   in place; conf_dev (n) or NULL
+ *   tlk_kf8_gate_f64     <- gating_distance :189-227  (T filters) x (N measurements) -> out (T,N) squared Mahalanobis
+ * ------------------------------------------------------------------------------------------ */
+int tlk_kf7_predict_f64(double *x_dev, double *P_dev, int n, void *hip_stream);
+int tlk_kf7_update_f64(double *x_dev, double *P_dev, const double *z_dev, int n, void *hip_stream);
+int tlk_kf8_initiate_f64(const double *meas_xyah_dev, double *mean_dev, double *cov_dev, int n, void *hip_stream);
+int tlk_kf8_predict_f64(double *mean_dev, double *cov_dev, int n, void *hip_stream);
+int tlk_kf8_project_f64(const double *mean_dev, const double *cov_dev, const double *conf_dev, double *pmean_dev,
+                        double *pcov_dev, int n, void *hip_stream);
+int tlk_kf8_update_f64(double *mean_dev, double *cov_dev, const double *meas_xyah_dev, const double *conf_dev, int n,
+                       void *hip_stream);
+int tlk_kf8_gate_f64(const double *mean_dev, const double *cov_dev, int n_tracks, const double *meas_xyah_dev, int n_meas,
+                     int only_position, double *out_dev, void *hip_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Motion costs of the StrongSORT family, (T tracks) x (N detections) -> out (T,N) f64:
+ *   tlk_iou_ltwh_cost_f64 <- iou / iou_cost (plugins/track/bpbreid_strong_sort/sort/iou_matching.py:7-39, :42-78):
+ *                            1 - IoU of ltwh boxes (the time_since_update > 1 -> INFTY_COST row rule of :68-70 is the
+ *                            caller's: it depends on track state, not on geometry)
+ *   tlk_oks_cost_f64      <- oks / oks_cost (sort/oks_matching.py:30-92, :95-128; kappa :7-27): keypoints (.,17,3) f64
+ *                            [x, y, visibility]; scale from the track's visible-keypoint extent, 45-degree fallback,
+ *                            factor clip 5, scale < 0.1 -> NaN
+ * ------------------------------------------------------------------------------------------ */
+int tlk_iou_ltwh_cost_f64(const double *tracks_ltwh_dev, int n_tracks, const double *dets_ltwh_dev, int n_dets,
+                          double *out_dev, void *hip_stream);
+int tlk_oks_cost_f64(const double *track_kps_dev, int n_tracks, const double *det_kps_dev, int n_dets, double *out_dev,
+                     void *hip_stream);
+
+/* ------------------------------------------------------------------------------------------
  * Part-based ReID distance (the one embedding x embedding contraction of the path; f32 MFMA).
  * Replaces NearestNeighborDistanceMetric.distance -> _nn_part_based
  * (plugins/track/bpbreid_strong_sort/sort/nn_matching.py:191-200, :99-135) including the third-party

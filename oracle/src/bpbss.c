@@ -222,6 +222,19 @@ static double oks_one(const double *kp, double scale, int nvis, const double *c)
     return sum / (double)nvis;
 }
 
+/* iou_cost / oks_cost as (T x N) matrices (iou_matching.py:42-78 without the time_since_update row rule, oks_matching.py:95-128) */
+void orc_iou_ltwh_cost(const double *trk, int T, const double *det, int N, double *out)
+{
+    for (int t = 0; t < T; ++t) for (int j = 0; j < N; ++j) out[(size_t)t * N + j] = 1. - iou_ltwh(trk + 4 * t, det + 4 * j);
+}
+void orc_oks_cost(const double *tkp, int T, const double *dkp, int N, double *out)
+{
+    for (int t = 0; t < T; ++t) {
+        int nvis; double sc = oks_scale(tkp + 51 * (size_t)t, &nvis);
+        for (int j = 0; j < N; ++j) out[(size_t)t * N + j] = 1.0 - oks_one(tkp + 51 * (size_t)t, sc, nvis, dkp + 51 * (size_t)j);
+    }
+}
+
 /* sort/linear_assignment.py:11-73. cost (nt, nd) un-thresholded. outputs index lists into trk_idx/det_idx */
 static void min_cost_matching(const double *cost, int nt, int nd, double max_distance, const int *trk_idx, const int *det_idx,
                               int *m_t, int *m_d, int *m_row, int *m_col, int *nm, int *um_t, int *n_um_t, int *um_d, int *n_um_d)

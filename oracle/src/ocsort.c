@@ -105,6 +105,20 @@ static void kf7_update_core(kf7 *k, const double *z)    /* kalmanfilter.py:480-5
     for (int i = 0; i < 49; ++i) k->P[i] = t2[i] + t3[i];
 }
 
+/* stateless forms (for per-method parity tests): x (7), P (7,7) in place */
+void orc_kf7_predict(double *x, double *P)
+{
+    kf7 k; memset(&k, 0, sizeof(k)); memcpy(k.x, x, sizeof(k.x)); memcpy(k.P, P, sizeof(k.P));
+    kf7_predict(&k);
+    memcpy(x, k.x, sizeof(k.x)); memcpy(P, k.P, sizeof(k.P));
+}
+void orc_kf7_update(double *x, double *P, const double *z)
+{
+    kf7 k; memset(&k, 0, sizeof(k)); memcpy(k.x, x, sizeof(k.x)); memcpy(k.P, P, sizeof(k.P));
+    kf7_update_core(&k, z);
+    memcpy(x, k.x, sizeof(k.x)); memcpy(P, k.P, sizeof(k.P));
+}
+
 static void kf7_update(kf7 *k, const double *z /* or NULL */)
 {
     if (!z) {                                   /* kalmanfilter.py:465-477 */

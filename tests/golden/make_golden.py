@@ -564,11 +564,50 @@ def gen_cosine(out_dir):
     print("cosine ok")
 
 
+def gen_motion_costs(out_dir):
+    """iou / oks of the StrongSORT family (bpbreid_strong_sort/sort/iou_matching.py:7-39, oks_matching.py:30-92), row by row
+    as iou_cost / oks_cost call them (:73-76, :124-127)."""
+    _install_cv2_stub()
+    import bpbreid_strong_sort.sort.iou_matching as ium
+    import bpbreid_strong_sort.sort.oks_matching as okm
+    rng = np.random.default_rng(23)
+    blobs = {}
+    for ci, (T, N) in enumerate([(40, 55), (1, 1), (100, 130), (3, 17)]):
+        c = rng.uniform(100, 1800, (max(T, N), 2))
+        wh = np.stack([rng.uniform(40, 120, max(T, N)), rng.uniform(90, 300, max(T, N))], 1)
+        trk = np.concatenate([c[:T] - wh[:T] / 2 + rng.normal(0, 6, (T, 2)), wh[:T] * rng.uniform(0.9, 1.1, (T, 2))], 1)
+        det = np.concatenate([c[:N] - wh[:N] / 2, wh[:N]], 1)
+        iou_cost = np.stack([1.0 - ium.iou(trk[t], det) for t in range(T)])
+
+        def skeleton(box, jitter):
+            l, t, w, h = box
+            kp = np.empty((17, 3))
+            kp[:, 0] = l + w * rng.uniform(0.1, 0.9, 17) + rng.normal(0, jitter, 17)
+            kp[:, 1] = t + h * np.linspace(0.05, 0.95, 17) + rng.normal(0, jitter, 17)
+            kp[:, 2] = np.where(rng.uniform(0, 1, 17) < 0.8, rng.uniform(0.3, 1.0, 17), 0.0)
+            kp[0, 2] = max(kp[0, 2], 0.5)
+            return kp
+        tk = np.stack([skeleton(b, 0.0) for b in trk])
+        dk = np.stack([skeleton(b, 3.0) for b in det])
+        if ci == 0:
+            # degenerate skeletons: collinear visible keypoints (axis-aligned area 0 -> 45-degree fallback), a single visible
+            # keypoint (scale < 0.1 -> NaN row), all keypoints visible
+            tk[0, :, 0] = tk[0, 0, 0]
+            tk[1, :, 2] = 0.0; tk[1, 3, 2] = 0.9
+            tk[2, :, 2] = 1.0
+        oks_cost = np.stack([1.0 - okm.oks(tk[t], dk) for t in range(T)])
+        blobs[f"c{ci}_trk_ltwh"], blobs[f"c{ci}_det_ltwh"], blobs[f"c{ci}_iou_cost"] = trk, det, iou_cost
+        blobs[f"c{ci}_trk_kps"], blobs[f"c{ci}_det_kps"], blobs[f"c{ci}_oks_cost"] = tk, dk, oks_cost
+    blobs["n_cases"] = np.int64(4)
+    np.savez_compressed(os.path.join(out_dir, "motion_costs.npz"), **blobs)
+    print("motion costs ok")
+
+
 def main():
     out_dir = HERE
     only = set(sys.argv[1:])
     gens = {"ocsort": gen_ocsort, "iou": gen_iou_family, "kf7": gen_kf7, "lsa": gen_lsa,
-            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine}
+            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs}
     for k, fn in gens.items():
         if not only or k in only:
             fn(out_dir)

@@ -102,3 +102,87 @@ def test_cosine_gallery_mfma_matches_reference_golden_and_oracle(orc):
         torch.cuda.synchronize()
         np.testing.assert_allclose(out.cpu().numpy(), g[f"c{c}_cost"], rtol=0, atol=3e-6, err_msg=f"case {c} vs reference")
         np.testing.assert_allclose(out.cpu().numpy(), orc.cosine_gallery_min(gal, offs, dets), rtol=0, atol=3e-6)
+
+
+# ------------------------------------------------------------------------------------------------ stateless KF / motion costs
+def _cuda(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+def test_kf7_stateless_golden_and_oracle(orc):
+    from test_oracle_motion import kf7_chain_steps
+    from tracklab_amd import _lib
+    g = np.load(os.path.join(GOLDEN, "kf7_cases.npz"))
+    steps = list(kf7_chain_steps(g))
+    x = _cuda(np.stack([s[0] for s in steps])); P = _cuda(np.stack([s[1] for s in steps])); z = _cuda(np.stack([s[2] for s in steps]))
+    _lib.kf7_predict_(x, P)
+    xp, Pp = x.cpu().numpy().copy(), P.cpu().numpy().copy()
+    _lib.kf7_update_(x, P, z)
+    xu, Pu = x.cpu().numpy(), P.cpu().numpy()
+    for i, (x0, P0, zi, x1, P1) in enumerate(steps):
+        ox, oP = orc.kf7_predict(x0, P0)
+        np.testing.assert_array_equal(xp[i], ox); np.testing.assert_array_equal(Pp[i], oP)          # bit-exact vs the oracle
+        ox, oP = orc.kf7_update(ox, oP, zi)
+        np.testing.assert_array_equal(xu[i], ox); np.testing.assert_array_equal(Pu[i], oP)
+        np.testing.assert_allclose(xu[i], x1, rtol=1e-10, atol=1e-10)                                # and the reference's states
+        np.testing.assert_allclose(Pu[i], P1, rtol=1e-9, atol=1e-9)
+
+
+def test_kf8_stateless_golden_and_oracle(orc):
+    from tracklab_amd import _lib
+    g = np.load(os.path.join(GOLDEN, "kf8_cases.npz"))
+    n = 32
+    mean, cov = _lib.kf8_initiate(_cuda(g["meas"]))
+    np.testing.assert_array_equal(mean.cpu().numpy(), g["init_mean"])
+    np.testing.assert_allclose(cov.cpu().numpy(), g["init_cov"], rtol=1e-15)
+    # case i is predicted i % 4 + 1 times: run 4 rounds, freezing the cases that are done
+    m_np, c_np = mean.cpu().numpy().copy(), cov.cpu().numpy().copy()
+    for rnd in range(4):
+        sel = np.array([i for i in range(n) if i % 4 + 1 > rnd])
+        ms, cs = _cuda(m_np[sel]), _cuda(c_np[sel])
+        _lib.kf8_predict_(ms, cs)
+        m_np[sel], c_np[sel] = ms.cpu().numpy(), cs.cpu().numpy()
+    np.testing.assert_array_equal(m_np, g["pred_mean"])
+    np.testing.assert_allclose(c_np, g["pred_cov"], rtol=1e-14, atol=1e-14)
+    mean, cov, conf = _cuda(m_np), _cuda(c_np), _cuda(g["conf"])
+    pm, pc = _lib.kf8_project(mean, cov, conf)
+    np.testing.assert_array_equal(pm.cpu().numpy(), g["proj_mean"])
+    np.testing.assert_allclose(pc.cpu().numpy(), g["proj_cov"], rtol=1e-14, atol=1e-14)
+    z = np.stack([g[f"z{i}"] for i in range(n)])
+    for only_pos, key in ((False, "gate4"), (True, "gate2")):
+        gate = _lib.kf8_gate(mean, cov, _cuda(z), only_pos).cpu().numpy()          # (32 filters) x (32 measurements)
+        for i in range(n):
+            np.testing.assert_allclose(gate[i, i], g[key][i][i % 50], rtol=1e-9)
+            np.testing.assert_array_equal(gate[i], orc.kf8_gating(m_np[i], c_np[i], z, only_pos))
+    _lib.kf8_update_(mean, cov, _cuda(z), conf)
+    mu, cu = mean.cpu().numpy(), cov.cpu().numpy()
+    np.testing.assert_allclose(mu, g["upd_mean"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(cu, g["upd_cov"], rtol=1e-9, atol=1e-10)
+    for i in range(n):
+        om, oc = orc.kf8_update(m_np[i], c_np[i], z[i], g["conf"][i])
+        np.testing.assert_array_equal(mu[i], om); np.testing.assert_array_equal(cu[i], oc)
+
+
+def test_motion_costs_golden_and_oracle(orc):
+    from tracklab_amd import _lib
+    g = np.load(os.path.join(GOLDEN, "motion_costs.npz"))
+    for c in range(int(g["n_cases"])):
+        iou_c = _lib.iou_ltwh_cost(_cuda(g[f"c{c}_trk_ltwh"]), _cuda(g[f"c{c}_det_ltwh"])).cpu().numpy()
+        np.testing.assert_array_equal(iou_c, g[f"c{c}_iou_cost"])
+        oks_c = _lib.oks_cost(_cuda(g[f"c{c}_trk_kps"]), _cuda(g[f"c{c}_det_kps"])).cpu().numpy()
+        np.testing.assert_allclose(oks_c, g[f"c{c}_oks_cost"], rtol=1e-12, atol=1e-15, equal_nan=True)
+        np.testing.assert_allclose(oks_c, orc.oks_cost(g[f"c{c}_trk_kps"], g[f"c{c}_det_kps"]), rtol=1e-13, atol=1e-16, equal_nan=True)
+
+
+def test_stateless_entry_points_reject_bad_arguments():
+    import torch
+    from tracklab_amd._lib import TlkError, check, lib, _bind_kf
+    L = lib(); _bind_kf(L)
+    with pytest.raises(TlkError):
+        check(L.tlk_kf7_predict_f64(None, None, 4, None))
+    with pytest.raises(TlkError):
+        check(L.tlk_kf8_gate_f64(None, None, 3, None, 3, 0, None, None))
+    with pytest.raises(TlkError):
+        check(L.tlk_oks_cost_f64(None, -1, None, 2, None, None))
+    check(L.tlk_iou_ltwh_cost_f64(None, 0, None, 5, None, None))        # empty problem is a no-op

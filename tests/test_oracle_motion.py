@@ -1,0 +1,45 @@
+"""CPU: the oracle's stateless KF7 step and the StrongSORT motion costs against vectors produced by the reference itself
+(tests/golden/make_golden.py gen_kf7 / gen_motion_costs)."""
+import os
+
+import numpy as np
+
+from conftest import GOLDEN
+
+
+def bbox_to_z(b):
+    """oc_sort/ocsort.py:21-34 convert_bbox_to_z."""
+    w, h = b[2] - b[0], b[3] - b[1]
+    return np.array([b[0] + w / 2.0, b[1] + h / 2.0, w * h, w / float(h + 1e-6)])
+
+
+def kf7_chain_steps(g):
+    """(x_prev, P_prev, z, x_next, P_next) for every step of the KalmanBoxTracker replays in which plain predict + update(z)
+    links two stored states: the step and the two before it observed (no freeze/unfreeze in between)."""
+    for c in range(int(g["n_cases"])):
+        obs, pat = g[f"c{c}_obs"], g[f"c{c}_pattern"]
+        for t in range(2, len(pat) + 1):          # state index t-1 is after step t (1-based)
+            if pat[t - 1] and pat[t - 2] and (t < 3 or pat[t - 3]):
+                yield g[f"c{c}_x"][t - 2], g[f"c{c}_P"][t - 2], bbox_to_z(obs[t][:4]), g[f"c{c}_x"][t - 1], g[f"c{c}_P"][t - 1]
+
+
+def test_kf7_stateless_matches_reference_states(orc):
+    g = np.load(os.path.join(GOLDEN, "kf7_cases.npz"))
+    n = 0
+    for x0, P0, z, x1, P1 in kf7_chain_steps(g):
+        x, P = orc.kf7_predict(x0, P0)
+        x, P = orc.kf7_update(x, P, z)
+        np.testing.assert_allclose(x, x1, rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(P, P1, rtol=1e-9, atol=1e-9)
+        n += 1
+    assert n >= 20
+
+
+def test_motion_costs_match_reference(orc):
+    g = np.load(os.path.join(GOLDEN, "motion_costs.npz"))
+    for c in range(int(g["n_cases"])):
+        iou_c = orc.iou_ltwh_cost(g[f"c{c}_trk_ltwh"], g[f"c{c}_det_ltwh"])
+        np.testing.assert_array_equal(iou_c, g[f"c{c}_iou_cost"])                       # same op order -> bit-exact
+        oks_c = orc.oks_cost(g[f"c{c}_trk_kps"], g[f"c{c}_det_kps"])
+        np.testing.assert_allclose(oks_c, g[f"c{c}_oks_cost"], rtol=1e-12, atol=1e-15, equal_nan=True)   # exp() of libm vs numpy
+    assert np.isnan(g["c0_oks_cost"][1]).all()         # the single-visible-keypoint track: scale < 0.1 -> NaN (oks_matching.py:80-81)

@@ -368,6 +368,118 @@ def partdist(q, qvis, g, gvis):
 
 
 # ------------------------------------------------------------------------------------------------
+# stateless Kalman steps and motion costs (include/tlk.h: tlk_kf7_*, tlk_kf8_*, tlk_iou_ltwh_cost_f64, tlk_oks_cost_f64)
+# All take/return float64 cuda tensors; the in-place ones return their (modified) arguments.
+# ------------------------------------------------------------------------------------------------
+def _bind_kf(L):
+    if getattr(L, "_kf_bound", False):
+        return
+    vp, ci = C.c_void_p, C.c_int
+    L.tlk_kf7_predict_f64.argtypes = [vp, vp, ci, vp]
+    L.tlk_kf7_update_f64.argtypes = [vp, vp, vp, ci, vp]
+    L.tlk_kf8_initiate_f64.argtypes = [vp, vp, vp, ci, vp]
+    L.tlk_kf8_predict_f64.argtypes = [vp, vp, ci, vp]
+    L.tlk_kf8_project_f64.argtypes = [vp, vp, vp, vp, vp, ci, vp]
+    L.tlk_kf8_update_f64.argtypes = [vp, vp, vp, vp, ci, vp]
+    L.tlk_kf8_gate_f64.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp]
+    L.tlk_iou_ltwh_cost_f64.argtypes = [vp, ci, vp, ci, vp, vp]
+    L.tlk_oks_cost_f64.argtypes = [vp, ci, vp, ci, vp, vp]
+    L._kf_bound = True
+
+
+def _f64c(t, *shape_tail):
+    import torch
+    assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous(), "float64 contiguous cuda tensor expected"
+    assert tuple(t.shape[1:]) == tuple(shape_tail), f"shape (n,{shape_tail}) expected, got {tuple(t.shape)}"
+    return t
+
+
+def kf7_predict_(x, P):
+    L = lib(); _bind_kf(L)
+    n = _f64c(x, 7).shape[0]; _f64c(P, 7, 7)
+    check(L.tlk_kf7_predict_f64(x.data_ptr(), P.data_ptr(), n, current_stream_ptr()))
+    return x, P
+
+
+def kf7_update_(x, P, z):
+    L = lib(); _bind_kf(L)
+    n = _f64c(x, 7).shape[0]; _f64c(P, 7, 7); _f64c(z, 4)
+    check(L.tlk_kf7_update_f64(x.data_ptr(), P.data_ptr(), z.data_ptr(), n, current_stream_ptr()))
+    return x, P
+
+
+def kf8_initiate(meas):
+    import torch
+    L = lib(); _bind_kf(L)
+    n = _f64c(meas, 4).shape[0]
+    mean = torch.empty((n, 8), dtype=torch.float64, device=meas.device)
+    cov = torch.empty((n, 8, 8), dtype=torch.float64, device=meas.device)
+    check(L.tlk_kf8_initiate_f64(meas.data_ptr(), mean.data_ptr(), cov.data_ptr(), n, current_stream_ptr()))
+    return mean, cov
+
+
+def kf8_predict_(mean, cov):
+    L = lib(); _bind_kf(L)
+    n = _f64c(mean, 8).shape[0]; _f64c(cov, 8, 8)
+    check(L.tlk_kf8_predict_f64(mean.data_ptr(), cov.data_ptr(), n, current_stream_ptr()))
+    return mean, cov
+
+
+def kf8_project(mean, cov, conf=None):
+    import torch
+    L = lib(); _bind_kf(L)
+    n = _f64c(mean, 8).shape[0]; _f64c(cov, 8, 8)
+    if conf is not None:
+        _f64c(conf)
+    pm = torch.empty((n, 4), dtype=torch.float64, device=mean.device)
+    pc = torch.empty((n, 4, 4), dtype=torch.float64, device=mean.device)
+    check(L.tlk_kf8_project_f64(mean.data_ptr(), cov.data_ptr(), conf.data_ptr() if conf is not None else None, pm.data_ptr(),
+                                pc.data_ptr(), n, current_stream_ptr()))
+    return pm, pc
+
+
+def kf8_update_(mean, cov, meas, conf=None):
+    L = lib(); _bind_kf(L)
+    n = _f64c(mean, 8).shape[0]; _f64c(cov, 8, 8); _f64c(meas, 4)
+    if conf is not None:
+        _f64c(conf)
+    check(L.tlk_kf8_update_f64(mean.data_ptr(), cov.data_ptr(), meas.data_ptr(), conf.data_ptr() if conf is not None else None, n,
+                               current_stream_ptr()))
+    return mean, cov
+
+
+def kf8_gate(mean, cov, meas, only_position=False):
+    import torch
+    L = lib(); _bind_kf(L)
+    T = _f64c(mean, 8).shape[0]; _f64c(cov, 8, 8)
+    N = _f64c(meas, 4).shape[0]
+    out = torch.empty((T, N), dtype=torch.float64, device=mean.device)
+    check(L.tlk_kf8_gate_f64(mean.data_ptr(), cov.data_ptr(), T, meas.data_ptr(), N, int(bool(only_position)), out.data_ptr(),
+                             current_stream_ptr()))
+    return out
+
+
+def iou_ltwh_cost(tracks_ltwh, dets_ltwh):
+    import torch
+    L = lib(); _bind_kf(L)
+    T = _f64c(tracks_ltwh, 4).shape[0]
+    N = _f64c(dets_ltwh, 4).shape[0]
+    out = torch.empty((T, N), dtype=torch.float64, device=tracks_ltwh.device)
+    check(L.tlk_iou_ltwh_cost_f64(tracks_ltwh.data_ptr(), T, dets_ltwh.data_ptr(), N, out.data_ptr(), current_stream_ptr()))
+    return out
+
+
+def oks_cost(track_kps, det_kps):
+    import torch
+    L = lib(); _bind_kf(L)
+    T = _f64c(track_kps, 17, 3).shape[0]
+    N = _f64c(det_kps, 17, 3).shape[0]
+    out = torch.empty((T, N), dtype=torch.float64, device=track_kps.device)
+    check(L.tlk_oks_cost_f64(track_kps.data_ptr(), T, det_kps.data_ptr(), N, out.data_ptr(), current_stream_ptr()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # fused conv epilogue (bias + activation (+ residual)) for channels-last backbones
 # ------------------------------------------------------------------------------------------------
 ACT = {None: 0, "none": 0, "relu": 1, "silu": 2}

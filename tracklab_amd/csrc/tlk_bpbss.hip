@@ -795,6 +795,105 @@ __global__ void bpbss_gather_kernel(BpbDev D, int stream, long long *ids, double
     }
 }
 
+// ------------------------------------------------------------------ stateless KF8 / motion-cost entry points
+__device__ __forceinline__ void ld8(const double *m, const double *c, size_t i, double (&mean)[8], double (&cov)[64])
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mean[k] = m[i * 8 + k];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) cov[k] = c[i * 64 + k];
+}
+__device__ __forceinline__ void st8(double *m, double *c, size_t i, const double (&mean)[8], const double (&cov)[64])
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[i * 8 + k] = mean[k];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) c[i * 64 + k] = cov[k];
+}
+__global__ void __launch_bounds__(BLOCK) kf8_initiate_kernel(const double *__restrict__ meas, double *__restrict__ means, double *__restrict__ covs, int n)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;      // kalman_filter.py:53-83
+    if (i >= n) return;
+    double mean[8], cov[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) cov[k] = 0.0;
+    const double h = meas[(size_t)i * 4 + 3];
+    const double sp = 2 * W_POS * h, sv = 10 * W_VEL * h;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mean[k] = meas[(size_t)i * 4 + k]; mean[4 + k] = 0.0; cov[k * 9] = sp * sp; cov[(4 + k) * 9] = sv * sv; }
+    st8(means, covs, (size_t)i, mean, cov);
+}
+__global__ void __launch_bounds__(BLOCK) kf8_predict_kernel(double *__restrict__ means, double *__restrict__ covs, int n)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double mean[8], cov[64];
+    ld8(means, covs, (size_t)i, mean, cov);
+    kf8_predict(mean, cov);
+    st8(means, covs, (size_t)i, mean, cov);
+}
+__global__ void __launch_bounds__(BLOCK) kf8_project_kernel(const double *__restrict__ means, const double *__restrict__ covs, const double *__restrict__ conf,
+                                                            double *__restrict__ pm, double *__restrict__ pc, int n)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;      // kalman_filter.py:121-152
+    if (i >= n) return;
+    const double *m = means + (size_t)i * 8, *c = covs + (size_t)i * 64;
+    const double sstd = (1 - (conf ? conf[i] : 0.0)) * (W_POS * m[3]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        pm[(size_t)i * 4 + a] = m[a];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) pc[(size_t)i * 16 + a * 4 + b] = c[a * 8 + b] + (a == b ? sstd * sstd : 0.0);
+    }
+}
+__global__ void __launch_bounds__(BLOCK) kf8_update_kernel(double *__restrict__ means, double *__restrict__ covs, const double *__restrict__ z,
+                                                           const double *__restrict__ conf, int n)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double mean[8], cov[64];
+    ld8(means, covs, (size_t)i, mean, cov);
+    kf8_update(mean, cov, z + (size_t)i * 4, conf ? conf[i] : 0.0);
+    st8(means, covs, (size_t)i, mean, cov);
+}
+// grid.x = track, threads stride over the measurements; every thread factors the track's projected covariance itself (4x4)
+__global__ void __launch_bounds__(BLOCK) kf8_gate_kernel(const double *__restrict__ means, const double *__restrict__ covs, int T,
+                                                         const double *__restrict__ meas, int N, int d, double *__restrict__ out)
+{
+    const int t = blockIdx.x;                            // kalman_filter.py:189-227
+    const double *m = means + (size_t)t * 8, *c = covs + (size_t)t * 64;
+    double gl[GLN], Sd[16], Lc[16];
+    const double sstd = W_POS * m[3];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Sd[q] = 0.0;
+    for (int a = 0; a < d; ++a)
+        for (int b = 0; b < d; ++b) Sd[a * d + b] = c[a * 8 + b] + (a == b ? sstd * sstd : 0.0);
+    chol4(Sd, d, Lc);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) gl[a] = m[a];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gl[4 + q] = Lc[q];
+    for (int j = threadIdx.x; j < N; j += BLOCK) out[(size_t)t * N + j] = gating_from(gl, meas + (size_t)j * 4, d);
+}
+__global__ void __launch_bounds__(BLOCK) iou_ltwh_cost_kernel(const double *__restrict__ trk, int T, const double *__restrict__ det, int N,
+                                                              double *__restrict__ out)
+{
+    const long long gid = (long long)blockIdx.x * BLOCK + threadIdx.x;     // sort/iou_matching.py:42-78 without the age gate
+    if (gid >= (long long)T * N) return;
+    const int t = (int)(gid / N), j = (int)(gid - (long long)t * N);
+    out[gid] = 1.0 - iou_ltwh(trk + (size_t)t * 4, det + (size_t)j * 4);
+}
+struct KpPtr { const double *p; __device__ double operator()(int i) const { return p[i]; } };
+__global__ void __launch_bounds__(BLOCK) oks_cost_kernel(const double *__restrict__ trk_kp, int T, const double *__restrict__ det_kp, int N,
+                                                         double *__restrict__ out)
+{
+    const int t = blockIdx.x;                            // sort/oks_matching.py:95-128
+    const KpPtr kp{trk_kp + (size_t)t * 51};
+    int nvis = 0;
+    const double sc = oks_scale(kp, &nvis);
+    for (int j = threadIdx.x; j < N; j += BLOCK) out[(size_t)t * N + j] = 1.0 - oks_one(kp, sc, nvis, det_kp + (size_t)j * 51);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1044,5 +1143,69 @@ extern "C" int tlk_partdist_f32(const float *q_dev, const uint8_t *qvis_dev, int
     TLK_HIP(hipGetLastError());
     TLK_HIP(hipFreeAsync(hdr, st)); TLK_HIP(hipFreeAsync(order, st)); TLK_HIP(hipFreeAsync(cnt, st));
     TLK_HIP(hipFreeAsync(tn, st)); TLK_HIP(hipFreeAsync(dn, st));
+    return TLK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ stateless KF8 / motion costs
+#define KF8_LAUNCH(name, kern, n, ...)                                                                                   \
+    do {                                                                                                                 \
+        if ((n) < 0) return fail(TLK_EINVAL, name ": n < 0");                                                            \
+        if ((n) == 0) return TLK_OK;                                                                                     \
+        hipLaunchKernelGGL(kern, dim3(((n) + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)hip_stream, __VA_ARGS__); \
+        TLK_HIP(hipGetLastError());                                                                                      \
+        return TLK_OK;                                                                                                   \
+    } while (0)
+
+extern "C" int tlk_kf8_initiate_f64(const double *meas_xyah_dev, double *mean_dev, double *cov_dev, int n, void *hip_stream)
+{
+    if (n > 0 && (!meas_xyah_dev || !mean_dev || !cov_dev)) return fail(TLK_EINVAL, "tlk_kf8_initiate_f64: null pointer");
+    KF8_LAUNCH("tlk_kf8_initiate_f64", kf8_initiate_kernel, n, meas_xyah_dev, mean_dev, cov_dev, n);
+}
+extern "C" int tlk_kf8_predict_f64(double *mean_dev, double *cov_dev, int n, void *hip_stream)
+{
+    if (n > 0 && (!mean_dev || !cov_dev)) return fail(TLK_EINVAL, "tlk_kf8_predict_f64: null pointer");
+    KF8_LAUNCH("tlk_kf8_predict_f64", kf8_predict_kernel, n, mean_dev, cov_dev, n);
+}
+extern "C" int tlk_kf8_project_f64(const double *mean_dev, const double *cov_dev, const double *conf_dev, double *pmean_dev, double *pcov_dev,
+                                   int n, void *hip_stream)
+{
+    if (n > 0 && (!mean_dev || !cov_dev || !pmean_dev || !pcov_dev)) return fail(TLK_EINVAL, "tlk_kf8_project_f64: null pointer");
+    KF8_LAUNCH("tlk_kf8_project_f64", kf8_project_kernel, n, mean_dev, cov_dev, conf_dev, pmean_dev, pcov_dev, n);
+}
+extern "C" int tlk_kf8_update_f64(double *mean_dev, double *cov_dev, const double *meas_xyah_dev, const double *conf_dev, int n, void *hip_stream)
+{
+    if (n > 0 && (!mean_dev || !cov_dev || !meas_xyah_dev)) return fail(TLK_EINVAL, "tlk_kf8_update_f64: null pointer");
+    KF8_LAUNCH("tlk_kf8_update_f64", kf8_update_kernel, n, mean_dev, cov_dev, meas_xyah_dev, conf_dev, n);
+}
+extern "C" int tlk_kf8_gate_f64(const double *mean_dev, const double *cov_dev, int n_tracks, const double *meas_xyah_dev, int n_meas,
+                                int only_position, double *out_dev, void *hip_stream)
+{
+    if (n_tracks < 0 || n_meas < 0) return fail(TLK_EINVAL, "tlk_kf8_gate_f64: negative size");
+    if (n_tracks == 0 || n_meas == 0) return TLK_OK;
+    if (!mean_dev || !cov_dev || !meas_xyah_dev || !out_dev) return fail(TLK_EINVAL, "tlk_kf8_gate_f64: null pointer");
+    hipLaunchKernelGGL(kf8_gate_kernel, dim3(n_tracks), dim3(BLOCK), 0, (hipStream_t)hip_stream, mean_dev, cov_dev, n_tracks, meas_xyah_dev, n_meas,
+                       only_position ? 2 : 4, out_dev);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
+extern "C" int tlk_iou_ltwh_cost_f64(const double *tracks_ltwh_dev, int n_tracks, const double *dets_ltwh_dev, int n_dets, double *out_dev,
+                                     void *hip_stream)
+{
+    if (n_tracks < 0 || n_dets < 0) return fail(TLK_EINVAL, "tlk_iou_ltwh_cost_f64: negative size");
+    if (n_tracks == 0 || n_dets == 0) return TLK_OK;
+    if (!tracks_ltwh_dev || !dets_ltwh_dev || !out_dev) return fail(TLK_EINVAL, "tlk_iou_ltwh_cost_f64: null pointer");
+    const long long tot = (long long)n_tracks * n_dets;
+    hipLaunchKernelGGL(iou_ltwh_cost_kernel, dim3((unsigned)((tot + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)hip_stream, tracks_ltwh_dev,
+                       n_tracks, dets_ltwh_dev, n_dets, out_dev);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
+extern "C" int tlk_oks_cost_f64(const double *track_kps_dev, int n_tracks, const double *det_kps_dev, int n_dets, double *out_dev, void *hip_stream)
+{
+    if (n_tracks < 0 || n_dets < 0) return fail(TLK_EINVAL, "tlk_oks_cost_f64: negative size");
+    if (n_tracks == 0 || n_dets == 0) return TLK_OK;
+    if (!track_kps_dev || !det_kps_dev || !out_dev) return fail(TLK_EINVAL, "tlk_oks_cost_f64: null pointer");
+    hipLaunchKernelGGL(oks_cost_kernel, dim3(n_tracks), dim3(BLOCK), 0, (hipStream_t)hip_stream, track_kps_dev, n_tracks, det_kps_dev, n_dets, out_dev);
+    TLK_HIP(hipGetLastError());
     return TLK_OK;
 }

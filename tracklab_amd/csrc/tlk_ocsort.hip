@@ -763,6 +763,40 @@ __global__ void ocsort_gather_kernel(OcsDev D, int stream, double *x, double *Pm
     }
 }
 
+// ------------------------------------------------------------------ stateless KF7 entry points: one thread = one filter
+__global__ void __launch_bounds__(BLOCK) kf7_predict_kernel(double *__restrict__ xs, double *__restrict__ Ps, int n)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double x[7], P[49];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x[k] = xs[(size_t)i * 7 + k];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) P[k] = Ps[(size_t)i * 49 + k];
+    kf7_predict(x, P);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) xs[(size_t)i * 7 + k] = x[k];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) Ps[(size_t)i * 49 + k] = P[k];
+}
+__global__ void __launch_bounds__(BLOCK) kf7_update_kernel(double *__restrict__ xs, double *__restrict__ Ps, const double *__restrict__ zs, int n)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double x[7], P[49], z[4];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x[k] = xs[(size_t)i * 7 + k];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) P[k] = Ps[(size_t)i * 49 + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] = zs[(size_t)i * 4 + k];
+    kf7_update_core(x, P, z);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) xs[(size_t)i * 7 + k] = x[k];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) Ps[(size_t)i * 49 + k] = P[k];
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------ host side
@@ -944,5 +978,25 @@ extern "C" int tlk_ocsort_get_profile(tlk_ocsort *h, int stream, long long *cycl
     if (stream < 0 || stream >= h->D.S) return fail(TLK_EINVAL, "tlk_ocsort_get_profile: stream out of range");
     TLK_HIP(hipSetDevice(h->device));
     TLK_HIP(hipMemcpy(cycles16, h->D.prof + (size_t)stream * 16, sizeof(long long) * 16, hipMemcpyDeviceToHost));
+    return TLK_OK;
+}
+
+extern "C" int tlk_kf7_predict_f64(double *x_dev, double *P_dev, int n, void *hip_stream)
+{
+    if (n < 0) return fail(TLK_EINVAL, "tlk_kf7_predict_f64: n < 0");
+    if (n == 0) return TLK_OK;
+    if (!x_dev || !P_dev) return fail(TLK_EINVAL, "tlk_kf7_predict_f64: null pointer");
+    hipLaunchKernelGGL(kf7_predict_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)hip_stream, x_dev, P_dev, n);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
+
+extern "C" int tlk_kf7_update_f64(double *x_dev, double *P_dev, const double *z_dev, int n, void *hip_stream)
+{
+    if (n < 0) return fail(TLK_EINVAL, "tlk_kf7_update_f64: n < 0");
+    if (n == 0) return TLK_OK;
+    if (!x_dev || !P_dev || !z_dev) return fail(TLK_EINVAL, "tlk_kf7_update_f64: null pointer");
+    hipLaunchKernelGGL(kf7_update_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, (hipStream_t)hip_stream, x_dev, P_dev, z_dev, n);
+    TLK_HIP(hipGetLastError());
     return TLK_OK;
 }
