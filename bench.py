@@ -295,6 +295,7 @@ def main():
         print(json.dumps(line), flush=True)
     pipe.close()
     if dist is not None:
+        dist.barrier()          # rank 0 spends ~20 s in the CPU baseline: keep the others from tearing the group down under it
         dist.destroy_process_group()
 
 

@@ -376,7 +376,7 @@ constexpr int LB_BAND = 4;
 
 template <typename T, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK) letterbox_lds_kernel(const unsigned char *__restrict__ frames, int B, int H, int W, int S,
-                                                              int rh, int rw, T *__restrict__ out, int row_bytes_lds, int max_rows)
+                                                              int rh, int rw, T *__restrict__ out, int row_bytes_lds, int max_rows, int out_off)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     __shared__ int s_y0[LB_BAND], s_y1[LB_BAND], s_yw0[LB_BAND], s_yw1[LB_BAND], s_sh0[LB_BAND], s_sh1[LB_BAND];
@@ -418,36 +418,47 @@ __global__ void __launch_bounds__(BLOCK) letterbox_lds_kernel(const unsigned cha
         // LDS stores (row-after-row staging serialised up to 2*LB_BAND global round trips per workgroup)
         const int cmax = (W * 3 + 30) >> 4;
         const int total = s_nsrc * cmax;
-        for (int base = 0; base < total; base += 4 * BLOCK) {
-            uint4 v[4];
-            int dst[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base + u * BLOCK + tid;
-                dst[u] = -1;
-                if (idx < total) {
-                    const int j = idx / cmax, c = idx - j * cmax;
-                    const unsigned char *g0 = img + (size_t)s_src[j] * W * 3;
-                    const uintptr_t a0 = (uintptr_t)g0 & ~(uintptr_t)15;
-                    const int chunks = ((int)((uintptr_t)g0 - a0) + W * 3 + 15) >> 4;
-                    if (c < chunks) {
-                        const unsigned char *p = (const unsigned char *)a0 + (size_t)c * 16;
-                        const int d = s_dst[j] * row_bytes_lds + c * 16;
-                        if (p + 16 <= gend) { v[u] = *reinterpret_cast<const uint4 *>(p); dst[u] = d; }
-                        else for (int k = 0; k < 16 && p + k < gend; ++k) s_dyn[d + k] = p[k];
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (dst[u] >= 0) *reinterpret_cast<uint4 *>(s_dyn + dst[u]) = v[u];
+        auto fetch = [&](int idx, uint4 &v, int &dst) {
+            dst = -1;
+            if (idx >= total) return;
+            const int j = idx / cmax, c = idx - j * cmax;
+            const unsigned char *g0 = img + (size_t)s_src[j] * W * 3;
+            const uintptr_t a0 = (uintptr_t)g0 & ~(uintptr_t)15;
+            const int chunks = ((int)((uintptr_t)g0 - a0) + W * 3 + 15) >> 4;
+            if (c >= chunks) return;
+            const unsigned char *p = (const unsigned char *)a0 + (size_t)c * 16;
+            const int d = s_dst[j] * row_bytes_lds + c * 16;
+            if (p + 16 <= gend) { v = *reinterpret_cast<const uint4 *>(p); dst = d; }
+            else for (int k = 0; k < 16 && p + k < gend; ++k) s_dyn[d + k] = p[k];
+        };
+        for (int base = tid; base < total; base += 4 * BLOCK) {
+            uint4 v0, v1, v2, v3;           // named registers (an indexed array of these went to scratch memory)
+            int d0, d1, d2, d3;
+            fetch(base, v0, d0); fetch(base + BLOCK, v1, d1); fetch(base + 2 * BLOCK, v2, d2); fetch(base + 3 * BLOCK, v3, d3);
+            if (d0 >= 0) *reinterpret_cast<uint4 *>(s_dyn + d0) = v0;
+            if (d1 >= 0) *reinterpret_cast<uint4 *>(s_dyn + d1) = v1;
+            if (d2 >= 0) *reinterpret_cast<uint4 *>(s_dyn + d2) = v2;
+            if (d3 >= 0) *reinterpret_cast<uint4 *>(s_dyn + d3) = v3;
         }
     }
     __syncthreads();
     constexpr int ROWS = (LAYOUT == LAYOUT_FOCUS_NHWC) ? 2 : 1;
-    for (int unit = tid; unit < (LB_BAND / ROWS) * groups_per_row; unit += BLOCK) {
+    // Focus layout with 2-byte elements (the detector's input): the 96 contiguous bytes a thread produces are 96 bytes apart from
+    // its neighbour's, so direct 16-byte stores touch 64 different 128-byte lines per instruction and the L2 wrote partial
+    // lines back (WRITE_SIZE 1.6x the tensor). The units go through LDS instead and leave as fully coalesced 16-byte stores:
+    // the band's output is one contiguous block. out_off < 0: direct stores; the staging area may alias the source rows
+    // (out_off == 0, all units computed in one sweep) -> barrier between the last tap read and the first staged write.
+    constexpr bool LDS_STORE = (LAYOUT == LAYOUT_FOCUS_NHWC) && sizeof(T) == 2;
+    constexpr int OUT_STRIDE_W = 28;            // words per unit in LDS: 96 B payload, 16-byte aligned, 2-way write conflicts at most
+    const int units_total = (LB_BAND / ROWS) * groups_per_row;
+    const bool lds_store = LDS_STORE && out_off >= 0;
+    unsigned int *s_out = reinterpret_cast<unsigned int *>(s_dyn + (out_off > 0 ? out_off : 0));
+    for (int unit0 = 0; unit0 < units_total; unit0 += BLOCK) {
+        const int unit = unit0 + tid;
+        const bool act = unit < units_total;
         const int ru = unit / groups_per_row, x_base = (unit - ru * groups_per_row) * 8;
         T px[ROWS][8][3];
+        if (act) {
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int ry = ru * ROWS + r, y = y_base + ry;
@@ -480,6 +491,9 @@ __global__ void __launch_bounds__(BLOCK) letterbox_lds_kernel(const unsigned cha
                 }
             }
         }
+        }
+        if (lds_store && out_off == 0) __syncthreads();
+        if (!act) continue;
         if (LAYOUT == LAYOUT_NCHW) {
             const int y = y_base + ru;
 #pragma unroll
@@ -513,8 +527,18 @@ __global__ void __launch_bounds__(BLOCK) letterbox_lds_kernel(const unsigned cha
                     const int xo = grp >> 1, yo = grp & 1;
                     p.v[e] = px[ROWS > 1 ? yo : 0][fp * 2 + xo][c];
                 }
-                *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+                if (LDS_STORE && lds_store) *reinterpret_cast<Pack<T, 8> *>(s_out + unit * OUT_STRIDE_W + k * 4) = p;
+                else *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
             }
+        }
+    }
+    if (LDS_STORE && lds_store) {
+        __syncthreads();
+        const int S2 = S / 2;
+        uint4 *gout = reinterpret_cast<uint4 *>(out + ((size_t)b * S2 + y_base / 2) * S2 * 12);
+        for (int c = tid; c < units_total * 6; c += BLOCK) {
+            const int u = c / 6, piece = c - u * 6;
+            gout[c] = *reinterpret_cast<const uint4 *>(s_out + u * OUT_STRIDE_W + piece * 4);
         }
     }
 }
@@ -662,12 +686,21 @@ int launch_letterbox(const unsigned char *frames, int B, int H, int W, int S, in
             for (int y = y0; y < y0 + LB_BAND && y < rh; ++y) n += cv_coef(y, H, rh, false).w1 != 0 ? 2 : 1;
             if (n > max_rows) max_rows = n;
         }
-    const size_t smem = (size_t)max_rows * row_bytes + (size_t)4 * S * sizeof(int);
+    size_t smem = (size_t)max_rows * row_bytes + (size_t)4 * S * sizeof(int);
+    // focus layout, 2-byte elements: output units leave through an LDS staging area (28 words per 96-byte unit); it aliases the
+    // source rows when one sweep computes every unit of the band, else it is appended
+    int out_off = -1;
+    if (layout == LAYOUT_FOCUS_NHWC && sizeof(T) == 2) {
+        const int units = (LB_BAND / 2) * (S / 8);
+        const size_t need = (size_t)units * 28 * 4;
+        if (units <= BLOCK && (size_t)max_rows * row_bytes >= need) out_off = 0;
+        else { out_off = (int)smem; smem += need; }
+    }
     if (smem <= 64 * 1024 && S % LB_BAND == 0) {          // LDS-staged fast path
         const dim3 grid((unsigned)(B * (S / LB_BAND)));
-        if (layout == LAYOUT_NCHW) hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes, max_rows);
-        else if (layout == LAYOUT_NHWC) hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes, max_rows);
-        else hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_FOCUS_NHWC>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes, max_rows);
+        if (layout == LAYOUT_NCHW) hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes, max_rows, out_off);
+        else if (layout == LAYOUT_NHWC) hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes, max_rows, out_off);
+        else hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_FOCUS_NHWC>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes, max_rows, out_off);
         return TLK_OK;
     }
     const long long units = (long long)B * (S / 8) * (layout == LAYOUT_FOCUS_NHWC ? S / 2 : S);
