@@ -603,11 +603,113 @@ def gen_motion_costs(out_dir):
     print("motion costs ok")
 
 
+SS_DEFAULTS = dict(max_dist=0.2, max_iou_dist=0.7, max_age=70, max_unmatched_preds=7, n_init=3, nn_budget=100, mc_lambda=0.995, ema_alpha=0.9)
+SS_YAML = dict(ema_alpha=0.8962157769329083, max_age=40, max_dist=0.1594374041012136, max_iou_dist=0.5431835667667874,
+               max_unmatched_preds=0, mc_lambda=0.995, n_init=3, nn_budget=100)     # configs/modules/track/strong_sort.yaml
+SS_RUNS = [  # name, hyperparams, seed, objects, frames, D, store embeddings, stream kwargs
+    ("defaults_s0_n100_d512", SS_DEFAULTS, 0, 100, 60, 512, False, {}),
+    ("yaml_s1_n50_d128", SS_YAML, 1, 50, 120, 128, False, {}),
+    ("budget5_s2_n20_d32", dict(SS_DEFAULTS, nn_budget=5, max_age=12), 2, 20, 160, 32, True, dict(miss_prob=0.12, churn_period=30)),
+    ("ninit1_s3_n20_d32", dict(SS_DEFAULTS, n_init=1, max_unmatched_preds=0, max_age=8, max_dist=0.3), 3, 20, 160, 32, True,
+     dict(miss_prob=0.1, churn_period=25)),
+    ("lowconf_s4_n30_d64", dict(SS_DEFAULTS, max_iou_dist=0.5), 4, 30, 120, 64, False, dict(miss_prob=0.05, churn_period=40, low_conf_frac=0.3)),
+]
+
+
+def _import_plain_strong_sort():
+    """plugins/track/strong_sort/strong_sort.py with its heavy imports stubbed: gdown / torchvision / ultralytics are only used by
+    the ReID model loader (never constructed here); ultralytics.utils.ops.xyxy2xywh is the one function update() calls and is
+    restated from its published definition (centre = mean of corners, size = difference)."""
+    import types
+    _install_cv2_stub()
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    def xyxy2xywh(x):
+        y = np.empty_like(x)
+        y[..., 0] = (x[..., 0] + x[..., 2]) / 2
+        y[..., 1] = (x[..., 1] + x[..., 3]) / 2
+        y[..., 2] = x[..., 2] - x[..., 0]
+        y[..., 3] = x[..., 3] - x[..., 1]
+        return y
+    if "gdown" not in sys.modules:
+        stub("gdown")
+    if "torchvision" not in sys.modules:
+        tv = stub("torchvision")
+        tv.transforms = stub("torchvision.transforms")
+    if "ultralytics" not in sys.modules:
+        stub("ultralytics")
+        stub("ultralytics.utils", LOGGER=None)
+        stub("ultralytics.utils.ops", xyxy2xywh=xyxy2xywh)
+        stub("ultralytics.utils.checks", check_requirements=None, check_version=None)
+    import strong_sort.strong_sort as ss
+    from strong_sort.sort.nn_matching import NearestNeighborDistanceMetric
+    from strong_sort.sort.tracker import Tracker
+    return ss, NearestNeighborDistanceMetric, Tracker
+
+
+def gen_ssort(out_dir):
+    """Plain StrongSORT (plugins/track/strong_sort): StrongSORT.update (strong_sort.py:41-84) run as is, with _get_features
+    (the OSNet forward on image crops) replaced by the synthetic stream's embeddings."""
+    ss, Metric, Tracker = _import_plain_strong_sort()
+    for name, hp, seed, nobj, nframes, D, store, skw in SS_RUNS:
+        model = object.__new__(ss.StrongSORT)            # __init__ would load ReID weights (strong_sort.py:33)
+        model.max_dist = hp["max_dist"]
+        model.tracker = Tracker(Metric("cosine", hp["max_dist"], hp["nn_budget"]), max_iou_dist=hp["max_iou_dist"], max_age=hp["max_age"],
+                                n_init=hp["n_init"], max_unmatched_preds=hp["max_unmatched_preds"], mc_lambda=hp["mc_lambda"],
+                                ema_alpha=hp["ema_alpha"])     # strong_sort.py:36-39
+        stream = SyntheticStream(seed, nobj, nframes, parts=1, dim=D, with_embeddings=True, **skw)
+        frame_img = np.zeros((1080, 1920, 3), dtype=np.uint8)
+        in_off, out_off = [0], [0]
+        dets_all, embs, rows = [], [], []
+        h = hashlib.sha256()
+        blobs = {}
+        for fr in stream:
+            dets = fr["dets"]
+            emb = fr["embeddings"][:, 0, :].astype(np.float32)
+            if fr["frame"] % 37 == 11:
+                dets, emb = dets[:0], emb[:0]
+            h.update(np.ascontiguousarray(dets).tobytes()); h.update(np.ascontiguousarray(emb).tobytes())
+            dets_all.append(dets)
+            if store:
+                embs.append(emb)
+            in_off.append(in_off[-1] + len(dets))
+            n_out = 0
+            if len(dets) > 0:                             # wrapper: process() returns [] on an empty frame (strong_sort_api.py:68-69)
+                feats = torch.from_numpy(emb.copy())
+                model._get_features = lambda xywhs, img, feats=feats: feats
+                out = model.update(torch.from_numpy(dets.copy()), frame_img)
+                for r in out:
+                    rows.append([float(r[0]), float(r[1]), float(r[2]), float(r[3]), float(r[4]), float(r[5]), float(r[6]), float(r[8])])
+                    n_out += 1
+                f = fr["frame"]
+                if f in (2, 9, 30, 59, 100, 150) and len(model.tracker.tracks):
+                    tr = model.tracker.tracks
+                    blobs[f"f{f}_track_ids"] = np.array([t.track_id for t in tr], dtype=np.int64)
+                    blobs[f"f{f}_mean"] = np.stack([t.mean for t in tr])
+                    blobs[f"f{f}_cov"] = np.stack([t.covariance for t in tr])
+                    blobs[f"f{f}_feat"] = np.stack([t.features[-1] for t in tr]).astype(np.float32)
+                    blobs[f"f{f}_state"] = np.array([[t.hits, t.age, t.time_since_update, t.state, t.updates_wo_assignment] for t in tr], dtype=np.int64)
+                    blobs[f"f{f}_gallery"] = np.array([len(model.tracker.metric.samples.get(t.track_id, [])) for t in tr], dtype=np.int64)
+            out_off.append(out_off[-1] + n_out)
+        extra = {"embeddings": np.concatenate(embs).astype(np.float32)} if store else {}
+        np.savez_compressed(
+            os.path.join(out_dir, f"ssort_{name}.npz"), dets=np.concatenate(dets_all), det_offsets=np.array(in_off, dtype=np.int64),
+            out_offsets=np.array(out_off, dtype=np.int64), rows=np.array(rows, dtype=np.float64).reshape(-1, 8),
+            config=json.dumps(hp), seed=seed, n_objects=nobj, n_frames=nframes, dim=D, stream_kwargs=json.dumps(skw),
+            input_sha256=h.hexdigest(), **extra, **blobs)
+        print(f"ssort_{name}: rows_out={out_off[-1]} next_id={model.tracker._next_id}")
+
+
 def main():
     out_dir = HERE
     only = set(sys.argv[1:])
     gens = {"ocsort": gen_ocsort, "iou": gen_iou_family, "kf7": gen_kf7, "lsa": gen_lsa,
-            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs}
+            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort}
     for k, fn in gens.items():
         if not only or k in only:
             fn(out_dir)

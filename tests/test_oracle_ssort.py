@@ -1,0 +1,56 @@
+"""CPU: the plain-StrongSORT oracle (oracle/src/ssort.c) against runs of the reference's own StrongSORT.update
+(tests/golden/make_golden.py gen_ssort: plugins/track/strong_sort imported, ReID forward replaced by synthetic embeddings)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+RUNS = sorted(os.path.basename(p)[6:-4] for p in glob.glob(os.path.join(GOLDEN, "ssort_*.npz")))
+
+
+def replay(name, make_tracker, check_state=None):
+    """Feed a golden run frame by frame to `make_tracker(D, hyper)`.update(dets, emb); yields nothing, asserts rows."""
+    from tracklab_amd.synth import SyntheticStream
+    g = np.load(os.path.join(GOLDEN, f"ssort_{name}.npz"))
+    hp, D = json.loads(str(g["config"])), int(g["dim"])
+    trk = make_tracker(D, hp)
+    stream = SyntheticStream(int(g["seed"]), int(g["n_objects"]), int(g["n_frames"]), parts=1, dim=D, with_embeddings=True,
+                             **json.loads(str(g["stream_kwargs"])))
+    do, oo = g["det_offsets"], g["out_offsets"]
+    stored = g["embeddings"] if "embeddings" in g.files else None
+    for f, fr in enumerate(stream):
+        dets = g["dets"][do[f]:do[f + 1]]
+        emb = fr["embeddings"][:, 0, :].astype(np.float32)
+        if f % 37 == 11:
+            emb = emb[:0]
+        assert len(emb) == len(dets)
+        if stored is not None:
+            np.testing.assert_array_equal(emb, stored[do[f]:do[f + 1]])         # the stream generator still produces the golden inputs
+        if len(dets) == 0:
+            continue                                                            # wrapper: process() returns [] (strong_sort_api.py:68-69)
+        out = trk.update(dets, emb)
+        exp = g["rows"][oo[f]:oo[f + 1]]
+        assert out.shape == exp.shape, f"{name} frame {f}"
+        np.testing.assert_array_equal(out[:, [0, 1, 2, 3, 4, 5, 7]], exp[:, [0, 1, 2, 3, 4, 5, 7]], err_msg=f"{name} frame {f}")
+        np.testing.assert_array_equal(out[:, 6], exp[:, 6])
+        if check_state is not None and f"f{f}_track_ids" in g.files:
+            check_state(trk, g, f)
+
+
+def check_state_oracle(trk, g, f):
+    ids, mean, cov, feat, st, gl = trk.tracks()
+    np.testing.assert_array_equal(ids, g[f"f{f}_track_ids"])
+    np.testing.assert_array_equal(st, g[f"f{f}_state"])          # hits, age, time_since_update, state, updates_wo_assignment
+    np.testing.assert_array_equal(gl, g[f"f{f}_gallery"])        # len(metric.samples[track_id])
+    np.testing.assert_allclose(mean, g[f"f{f}_mean"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(cov, g[f"f{f}_cov"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(feat, g[f"f{f}_feat"], rtol=0, atol=5e-7)      # float32 EMA + renorm, summation order of the norm
+
+
+@pytest.mark.parametrize("name", RUNS)
+def test_plain_strongsort_oracle_matches_reference(orc, name):
+    replay(name, lambda D, hp: orc.PlainStrongSORT(D, **hp), check_state_oracle)

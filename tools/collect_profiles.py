@@ -1,0 +1,95 @@
+"""HERE, after `gpurun -- tools/make_profiles.sh`: turn gpurun_out/round into the tracked profiles/ artifacts.
+usage: python tools/collect_profiles.py gpurun_out/round r01"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(REPO, "profiles")
+
+
+def stats_rows(d):
+    paths = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+    rows = []
+    for p in paths:
+        rows += list(csv.DictReader(open(p)))
+    return rows, paths
+
+
+def write_summary(wl, title, cmd):
+    rows, paths = stats_rows(os.path.join(src, f"prof_{wl}"))
+    if not rows:
+        print("no stats for", wl); return
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    line = open(os.path.join(src, f"prof_{wl}.json")).read().strip().splitlines()
+    bench = json.loads(line[-1]) if line else {}
+    out = [f"# {tag} -- {title}", "", f"command: `{cmd}`", "",
+           f"bench line of this profiled run: value = {bench.get('value', float('nan')):.1f} {bench.get('unit', '')}, ms_per_step = {bench.get('ms_per_step', float('nan')):.2f}",
+           "", "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
+    for r in rows[:45]:
+        name = r["Name"]
+        name = name if len(name) < 100 else name[:97] + "..."
+        out.append(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.2f} | "
+                   f"{float(r['MinNs']) / 1e3:.2f} | {float(r['MaxNs']) / 1e3:.2f} | {100 * float(r['TotalDurationNs']) / tot:.2f} |")
+    out.append(f"\ntotal kernel time: {tot / 1e6:.2f} ms over {len(rows)} distinct kernels\n")
+    open(os.path.join(dst, f"{tag}_{wl}_rocprof.md"), "w").write("\n".join(out))
+    shutil.copy(paths[0], os.path.join(dst, f"{tag}_{wl}_rocprof_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, f"bench_{wl}.json"), os.path.join(dst, f"{tag}_bench_{wl}.json"))
+
+
+def counter_means(d, counter):
+    acc = collections.defaultdict(list)
+    for p in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(p)):
+            if r.get("Counter_Name") == counter:
+                acc[r["Kernel_Name"]].append((int(r.get("Dispatch_Id", 0)), float(r["Counter_Value"])))
+    return acc
+
+
+def pick(acc, frag, which=None):
+    for k, v in acc.items():
+        if frag in k:
+            v = sorted(v)
+            vals = [x[1] for x in v]
+            if which is not None:           # letterbox is launched twice per iteration (640 calibration, then 1080p): split by parity
+                vals = vals[which::2]
+            vals = [x for x in vals if x >= 0.5 * max(vals)]      # drop unrelated small launches that share the kernel name
+            return sum(vals) / len(vals)
+    return None
+
+
+def write_traffic():
+    fetch, write = counter_means(os.path.join(src, "pmc_fetch"), "FETCH_SIZE"), counter_means(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+    if not fetch or not write:
+        print("no PMC data"); return
+    cal = {"copy_1GiB_FETCH_SIZE_KB": pick(fetch, "elementwise") or pick(fetch, "copy"),
+           "copy_1GiB_WRITE_SIZE_KB": pick(write, "elementwise") or pick(write, "copy"),
+           "letterbox_640to640_FETCH_SIZE_KB": pick(fetch, "letterbox_lds_kernel", 0),
+           "letterbox_640to640_expected_read_KB": 32 * 640 * 640 * 3 / 1024,
+           "note": "gfx950: FETCH_SIZE reports 1/2 of the bytes fetched (a wide copy AND our 16-byte staging loads calibrate to x2); "
+                   "WRITE_SIZE calibrates to x1 (KB)"}
+    for kern, frag, which, launch, fname in (
+            ("letterbox_lds_kernel", "letterbox_lds_kernel", 1, "32 frames 1080p -> 640 focus_nhwc f16 (= one config2 bench launch)", "letterbox_traffic.json"),
+            ("crop_lds_kernel", "crop_lds_kernel", None, "24 frames x 104 slots -> 384x128 nhwc f16 (= one config3 bench launch)", "crop_traffic.json")):
+        f, w = pick(fetch, frag, which), pick(write, frag, which)
+        if f is None or w is None:
+            continue
+        json.dump({"kernel": kern, "launch": launch, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "calibration": cal,
+                   "hbm_bytes_per_launch": (2 * f + w) * 1024}, open(os.path.join(dst, fname), "w"), indent=1)
+        print(fname, "read MB", 2 * f / 1024, "write MB", w / 1024)
+
+
+write_summary("config3", "config3 (YOLOX-m + ReID + BPBReID-StrongSORT), 24 frames/step",
+              "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload config3 --steps 10 --warmup 2 --no-cpu-baseline --check-frames 0")
+write_summary("config2", "config2 (YOLOX-s + OC-SORT), 32 frames/step",
+              "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload config2 --steps 10 --warmup 2 --no-cpu-baseline --check-frames 0")
+rows, paths = stats_rows(os.path.join(src, "kt_probe"))
+if paths:
+    shutil.copy(paths[0], os.path.join(dst, f"{tag}_probe_kernels_kernel_stats.csv"))
+write_traffic()
