@@ -221,6 +221,54 @@ int tlk_bpbss_get_tracks(tlk_bpbss *h, int stream, int64_t *ids, double *mean, d
                          uint8_t *fvis, int cap, int *n_tracks);
 
 /* ------------------------------------------------------------------------------------------
+ * Plain StrongSORT tracker bank (n_streams independent trackers, state + feature galleries in HBM).
+ * Replaces strong_sort.StrongSORT.update (plugins/track/strong_sort/strong_sort.py:41-84) from the point where the
+ * ReID features exist, i.e. Tracker.predict / Tracker.update (sort/tracker.py:53-114, _match :152-188),
+ * linear_assignment.{min_cost_matching,matching_cascade,gate_cost_matrix} (sort/linear_assignment.py:11-174),
+ * iou_matching.{iou,iou_cost} (sort/iou_matching.py:7-82), Track (sort/track.py:69-301), KalmanFilter
+ * (sort/kalman_filter.py:50-214), NearestNeighborDistanceMetric("cosine") with budget (sort/nn_matching.py:94-161),
+ * and the output loop with _tlwh_to_xyxy (strong_sort.py:62-79, :111-122).
+ * Hyper-parameter names = configs/modules/track/strong_sort.yaml `hyperparams` (+ the wrapper's min_confidence).
+ * nn_budget must be in [1, 1024] (preallocated ring); the reference's budget=None is not supported. ECC
+ * (cfg.ecc, sort/track.py:130-239) is out of scope.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tlk_ssort_params {
+    double max_dist, max_iou_dist;      /* strong_sort.py:24-25 */
+    int32_t max_age, max_unmatched_preds, n_init, nn_budget;
+    double mc_lambda, ema_alpha;
+    double min_confidence;              /* wrapper filter `inputs[:, 4] > min_confidence` (strong_sort_api.py:71); -inf disables */
+    int32_t wrapper_mode;               /* 1: a frame without detections leaves the tracker untouched (strong_sort_api.py:68-69) */
+    int32_t img_w, img_h;               /* ori_img.shape: output boxes are int-truncated and clipped to it */
+    int32_t dim;                        /* feature length: 32, 64, 128, 256 or 512 */
+    int32_t max_tracks, max_dets;       /* capacities per stream (0 = 256 / 128) */
+} tlk_ssort_params;
+
+typedef struct tlk_ssort_row {          /* one row of StrongSORT.update's output (strong_sort.py:70-77) */
+    int64_t det_id;                     /* tracklab_id of the detection last matched to the track */
+    int64_t track_id;
+    double ltrb[4];                     /* integer-valued, clipped to the image */
+    double conf;
+    int32_t class_id, time_since_update;
+} tlk_ssort_row;
+
+typedef struct tlk_ssort tlk_ssort;
+int tlk_ssort_create(const tlk_ssort_params *p, int n_streams, int device, tlk_ssort **out);
+int tlk_ssort_destroy(tlk_ssort *h);
+int tlk_ssort_reset(tlk_ssort *h, int stream);       /* stream < 0: all */
+/* host buffers: dets (n,7) f64 [x1,y1,x2,y2,conf,cls,tracklab_id], feat (n,dim) f32 -> rows (cap) */
+int tlk_ssort_update(tlk_ssort *h, int stream, const double *dets, const float *feat, int n, tlk_ssort_row *rows, int cap,
+                     int *n_out);
+/* device buffers, all streams, n_frames consecutive frames per stream, asynchronous on hip_stream:
+ * dets_dev (S, n_frames, max_dets, 7), feat_dev (S, n_frames, max_dets, dim), counts_dev (S, n_frames) ->
+ * rows_dev (S, n_frames, out_cap), out_counts_dev (S, n_frames) (negative = TLK_E* for that stream) */
+int tlk_ssort_update_dev(tlk_ssort *h, const double *dets_dev, const float *feat_dev, const int32_t *counts_dev, int n_frames,
+                         tlk_ssort_row *rows_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream);
+/* debug/test: track list in list order: ids, mean (.,8), cov (.,8,8), feat (.,dim), state5 (.,5) [hits, age,
+ * time_since_update, state (1 tentative, 2 confirmed), updates_wo_assignment], gallery_rows (.); any may be NULL */
+int tlk_ssort_get_tracks(tlk_ssort *h, int stream, int64_t *ids, double *mean, double *cov, float *feat, int64_t *state5,
+                         int64_t *gallery_rows, int cap, int *n_tracks);
+
+/* ------------------------------------------------------------------------------------------
  * Detector / ReID pre- and post-processing. In the reference this arithmetic sits in third-party
  * packages behind the adapters tracklab/wrappers/bbox_detector/rtmlib_api.py:27-46 (rtmlib
  * YOLOX.preprocess / postprocess, cv2.resize) and tracklab/wrappers/reid/kpreid_api.py:115-144

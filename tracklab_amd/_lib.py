@@ -352,6 +352,89 @@ class BpbssBank:
         return ids[:k], mean[:k], cov[:k], feat[:k], fvis[:k]
 
 
+# ------------------------------------------------------------------------------------------------
+# plain StrongSORT bank
+# ------------------------------------------------------------------------------------------------
+class SsortParams(C.Structure):
+    _fields_ = [("max_dist", C.c_double), ("max_iou_dist", C.c_double), ("max_age", C.c_int32), ("max_unmatched_preds", C.c_int32),
+                ("n_init", C.c_int32), ("nn_budget", C.c_int32), ("mc_lambda", C.c_double), ("ema_alpha", C.c_double),
+                ("min_confidence", C.c_double), ("wrapper_mode", C.c_int32), ("img_w", C.c_int32), ("img_h", C.c_int32),
+                ("dim", C.c_int32), ("max_tracks", C.c_int32), ("max_dets", C.c_int32)]
+
+
+SSORT_ROW = np.dtype([("det_id", "<i8"), ("track_id", "<i8"), ("ltrb", "<f8", (4,)), ("conf", "<f8"), ("class_id", "<i4"),
+                      ("tsu", "<i4")], align=True)
+
+
+def _bind_ssort(L):
+    if getattr(L, "_ssort_bound", False):
+        return
+    vp, ci = C.c_void_p, C.c_int
+    L.tlk_ssort_create.argtypes = [C.POINTER(SsortParams), ci, ci, C.POINTER(vp)]
+    L.tlk_ssort_destroy.argtypes = [vp]
+    L.tlk_ssort_reset.argtypes = [vp, ci]
+    L.tlk_ssort_update.argtypes = [vp, ci, vp, vp, ci, vp, ci, C.POINTER(ci)]
+    L.tlk_ssort_update_dev.argtypes = [vp, vp, vp, vp, ci, vp, ci, vp, vp]
+    L.tlk_ssort_get_tracks.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ci, C.POINTER(ci)]
+    L._ssort_bound = True
+
+
+class SsortBank:
+    """``n_streams`` device-resident plain-StrongSORT trackers (``tlk_ssort_*``); hyper-parameter names follow
+    ``StrongSORT.__init__`` (plugins/track/strong_sort/strong_sort.py:19-32)."""
+
+    def __init__(self, dim, max_dist=0.2, max_iou_dist=0.7, max_age=70, max_unmatched_preds=7, n_init=3, nn_budget=100,
+                 mc_lambda=0.995, ema_alpha=0.9, *, min_confidence=-np.inf, wrapper_mode=False, img_w=1920, img_h=1080,
+                 n_streams=1, device=0, max_tracks=256, max_dets=128):
+        if nn_budget is None:
+            raise ValueError("nn_budget=None (unbounded gallery) is not supported by the preallocated HBM ring; give a budget")
+        L = lib()
+        _bind_ssort(L)
+        self.params = SsortParams(max_dist, max_iou_dist, max_age, max_unmatched_preds, n_init, int(nn_budget), mc_lambda, ema_alpha,
+                                  float(min_confidence), int(wrapper_mode), img_w, img_h, dim, max_tracks, max_dets)
+        self.D, self.n_streams, self.max_tracks, self.max_dets = dim, n_streams, max_tracks, max_dets
+        h = C.c_void_p()
+        check(L.tlk_ssort_create(C.byref(self.params), n_streams, device, C.byref(h)))
+        self._h = h
+        self._rows = np.zeros(max_tracks, dtype=SSORT_ROW)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tlk_ssort_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, stream=-1):
+        check(lib().tlk_ssort_reset(self._h, stream))
+
+    def update(self, dets, feat, stream=0):
+        """dets (n,7) [x1,y1,x2,y2,conf,cls,tracklab_id], feat (n,dim) -> structured rows (SSORT_ROW)."""
+        dets = _f64(dets).reshape(-1, 7)
+        feat = np.ascontiguousarray(feat, dtype=np.float32).reshape(len(dets), self.D)
+        n = C.c_int(0)
+        check(lib().tlk_ssort_update(self._h, stream, dets.ctypes.data, feat.ctypes.data, len(dets), self._rows.ctypes.data,
+                                     len(self._rows), C.byref(n)))
+        return self._rows[:n.value].copy()
+
+    def update_dev(self, dets, feat, counts, n_frames, rows, out_cap, out_counts, stream_ptr=None):
+        check(lib().tlk_ssort_update_dev(self._h, dets, feat, counts, n_frames, rows, out_cap, out_counts, stream_ptr))
+
+    def tracks(self, stream=0):
+        cap = self.max_tracks
+        ids, st, gl = np.empty(cap, np.int64), np.empty((cap, 5), np.int64), np.empty(cap, np.int64)
+        mean, cov, feat = np.empty((cap, 8)), np.empty((cap, 8, 8)), np.empty((cap, self.D), np.float32)
+        n = C.c_int(0)
+        check(lib().tlk_ssort_get_tracks(self._h, stream, ids.ctypes.data, mean.ctypes.data, cov.ctypes.data, feat.ctypes.data,
+                                         st.ctypes.data, gl.ctypes.data, cap, C.byref(n)))
+        k = n.value
+        return ids[:k], mean[:k], cov[:k], feat[:k], st[:k], gl[:k]
+
+
 def partdist(q, qvis, g, gvis):
     """q (T,K,D) f32, qvis (T,K) u8, g (N,K,D) f32, gvis (N,K) u8 cuda tensors -> (T,N) f64 cuda tensor."""
     import torch

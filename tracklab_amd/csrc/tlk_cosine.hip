@@ -7,12 +7,11 @@
 // chunks of 16 rows, keeps the running minimum in the accumulator layout and reduces it across rows at the end, so no
 // atomics and no intermediate (Gtot x N) matrix ever reaches HBM.
 #include "tlk_common.hpp"
+#include "tlk_cosine.hpp"
 
 using namespace tlk;
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // one wavefront per row: L2 norm (np.linalg.norm on float32)
 __global__ void __launch_bounds__(BLOCK) rownorm_kernel(const float *__restrict__ x, int rows, int D, float *__restrict__ nrm)
@@ -71,78 +70,16 @@ __global__ void __launch_bounds__(BLOCK) cosine_gallery_kernel(const float *__re
     if (g == 0 && n0 + i < N) out[(size_t)t * N + n0 + i] = (double)m;
 }
 
-// Pipelined variant for D = 16*DS in {64,128,256,512}: the wave's detection operand (16 dets x D, normalised) stays in
-// VGPRs for the whole gallery walk; gallery rows stream through two register buffers of GS k-steps each, the next group's
-// 16-byte loads in flight while the current group's 4*GS MFMAs issue (the straightforward kernel above exposes one L2
-// round trip per 4 MFMAs: 8.8 % MFMA busy; this one keeps the matrix pipe fed).
+// Pipelined variant for D = 16*DS in {64,128,256,512}: workgroup = (track, 16 detections), see tlk_cosine.hpp.
 template <int DS>
 __global__ void __launch_bounds__(BLOCK) cosine_gallery_kernel_t(const float *__restrict__ gallery, const int *__restrict__ offsets, int T,
                                                                  const float *__restrict__ dets, int N,
                                                                  const float *__restrict__ gnorm, const float *__restrict__ dnorm,
                                                                  double *__restrict__ out)
 {
-    constexpr int D = DS * 16;
-    constexpr int GS = DS >= 16 ? 8 : DS / 2;
-    constexpr int GROUPS = DS / GS;               // even by construction
     __shared__ float s_min[NWAVES][16];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = blockIdx.y;                     // workgroup = (track, 16 detections); its 4 waves interleave the gallery chunks
-    const int n0 = blockIdx.x * 16;
-    const int i = lane & 15, g = lane >> 4;
-    const int dn = min(n0 + i, N - 1);
-    float4 breg[DS];
-    {
-        const float4 *drow = reinterpret_cast<const float4 *>(dets + (size_t)dn * D) + g;
-        const float nd = dnorm[dn];
-        const float rnd = 1.f / nd;
-#pragma unroll
-        for (int s = 0; s < DS; ++s) { float4 b = drow[s * 4]; b.x *= rnd; b.y *= rnd; b.z *= rnd; b.w *= rnd; breg[s] = b; }
-    }
-    const int g_lo = offsets[t], g_hi = offsets[t + 1];
-    float best[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
-    float4 A0[GS], A1[GS];
-    auto load = [&](float4 (&buf)[GS], int c0, int grp) {
-        const int gr = min(c0 + i, g_hi - 1);
-        const float4 *grow = reinterpret_cast<const float4 *>(gallery + (size_t)gr * D) + g + grp * GS * 4;
-#pragma unroll
-        for (int s = 0; s < GS; ++s) buf[s] = grow[s * 4];
-    };
-    const int c_first = g_lo + 16 * w;
-    if (c_first < g_hi) load(A0, c_first, 0);
-    for (int c0 = c_first; c0 < g_hi; c0 += 16 * NWAVES) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int grp = 0; grp < GROUPS; ++grp) {
-            // prefetch the next group (or the first group of the next chunk) into the other buffer
-            if (grp + 1 < GROUPS) { if (grp & 1) load(A0, c0, grp + 1); else load(A1, c0, grp + 1); }
-            else if (c0 + 16 * NWAVES < g_hi) { load(A0, c0 + 16 * NWAVES, 0); }       // GROUPS even -> group 0 always lives in A0
-#pragma unroll
-            for (int s = 0; s < GS; ++s) {
-                const float4 a = (grp & 1) ? A1[s] : A0[s];
-                const float4 b = breg[grp * GS + s];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
-            }
-        }
-        // the gallery row's 1/|g| is applied to the finished dot product (one multiply per output instead of a division per
-        // element in front of every MFMA, which made the loop VALU-bound); fp32 rounding differs by ~1e-7 relative.
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = c0 + g * 4 + r;
-            const bool valid = row < g_hi;
-            const float v = 1.f - acc[r] * (1.f / gnorm[min(row, g_hi - 1)]);
-            if (valid && v < best[r]) best[r] = v;
-        }
-    }
-    float m = fminf(fminf(best[0], best[1]), fminf(best[2], best[3]));
-    m = fminf(m, __shfl_xor(m, 16));
-    m = fminf(m, __shfl_xor(m, 32));
-    if (g == 0) s_min[w][i] = m;
-    __syncthreads();
-    if (w == 0 && g == 0 && n0 + i < N)
-        out[(size_t)t * N + n0 + i] = (double)fminf(fminf(s_min[0][i], s_min[1][i]), fminf(s_min[2][i], s_min[3][i]));
+    const int t = blockIdx.y;
+    cosine_gallery_tile<DS>(gallery, offsets[t], offsets[t + 1], gnorm, dets, N, blockIdx.x * 16, dnorm, out + (size_t)t * N, s_min);
 }
 
 }  // namespace
