@@ -181,3 +181,125 @@ void orc_ltwh_to_crop_ltrb(const double *ltwh, int n, int img_w, int img_h, int3
         ltrb[4 * i + 3] = (int32_t)nearbyint(b1 + b3);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Plain StrongSORT's ReID input. strong_sort.py:102-108 + :135-141 crop ori_img[y1:y2, x1:x2];
+ * reid_multibackend.py:44-52, :184-195: ToPILImage -> Resize((256,128)) -> ToTensor -> Normalize(ImageNet).
+ * The resize arithmetic is third-party Pillow (12.2.0 in this image), src/libImaging/Resample.c: bilinear filter with
+ * support 1.0 scaled by the downscale factor (antialias), precompute_coeffs, normalize_coeffs_8bpc (22 fractional bits),
+ * horizontal pass into an 8-bit intermediate, then vertical pass. Pinned on tests/golden/pil_preprocess.npz (made by Pillow).
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define PIL_PRECISION_BITS (32 - 8 - 2)
+
+static int pil_coeffs(int inSize, int outSize, int **bounds_out, int32_t **kk_out)
+{
+    double scale = (double)inSize / outSize, filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 1.0 * filterscale;
+    const int ksize = (int)ceil(support) * 2 + 1;
+    int *bounds = malloc(sizeof(int) * 2 * (size_t)outSize);
+    int32_t *kk = malloc(sizeof(int32_t) * (size_t)outSize * ksize);
+    double *k = malloc(sizeof(double) * ksize);
+    for (int xx = 0; xx < outSize; ++xx) {
+        const double center = 0.0 + (xx + 0.5) * scale, ss = 1.0 / filterscale;
+        double ww = 0.0;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > inSize) xmax = inSize;
+        xmax -= xmin;
+        int x;
+        for (x = 0; x < xmax; ++x) {
+            double a = (x + xmin - center + 0.5) * ss;
+            if (a < 0.0) a = -a;
+            const double w = a < 1.0 ? 1.0 - a : 0.0;
+            k[x] = w; ww += w;
+        }
+        for (x = 0; x < xmax; ++x) if (ww != 0.0) k[x] /= ww;
+        for (; x < ksize; ++x) k[x] = 0;
+        for (x = 0; x < ksize; ++x)
+            kk[(size_t)xx * ksize + x] = k[x] < 0 ? (int)(-0.5 + k[x] * (1 << PIL_PRECISION_BITS)) : (int)(0.5 + k[x] * (1 << PIL_PRECISION_BITS));
+        bounds[xx * 2] = xmin; bounds[xx * 2 + 1] = xmax;
+    }
+    free(k);
+    *bounds_out = bounds; *kk_out = kk;
+    return ksize;
+}
+static inline uint8_t pil_clip8(int v) { v >>= PIL_PRECISION_BITS; return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+/* Image.resize((dw, dh), BILINEAR) of an RGB image src (sh, sw, 3) with row stride sstride bytes -> dst (dh, dw, 3) */
+void orc_pil_resize_bilinear_rgb(const uint8_t *src, int sh, int sw, int sstride, uint8_t *dst, int dh, int dw)
+{
+    if (sh == dh && sw == dw) {                              /* Image.resize returns self.copy() when nothing changes */
+        for (int y = 0; y < sh; ++y) memcpy(dst + (size_t)y * dw * 3, src + (size_t)y * sstride, (size_t)sw * 3);
+        return;
+    }
+    int *bh, *bv; int32_t *kh, *kv;
+    const int ksh = pil_coeffs(sw, dw, &bh, &kh), ksv = pil_coeffs(sh, dh, &bv, &kv);
+    const int need_h = dw != sw, need_v = dh != sh;
+    const int y_first = bv[0], y_last = bv[dh * 2 - 2] + bv[dh * 2 - 1];
+    const uint8_t *in = src; int in_stride = sstride, in_w = sw;
+    uint8_t *tmp = NULL;
+    int voff = 0;                                            /* first source row of the vertical pass inside `in` */
+    if (need_h) {
+        tmp = malloc((size_t)(y_last - y_first) * dw * 3);
+        for (int yy = 0; yy < y_last - y_first; ++yy)
+            for (int xx = 0; xx < dw; ++xx) {
+                const int xmin = bh[xx * 2], xmax = bh[xx * 2 + 1];
+                const int32_t *k = kh + (size_t)xx * ksh;
+                int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0;
+                const uint8_t *row = src + (size_t)(yy + y_first) * sstride;
+                for (int x = 0; x < xmax; ++x) { s0 += row[(x + xmin) * 3] * k[x]; s1 += row[(x + xmin) * 3 + 1] * k[x]; s2 += row[(x + xmin) * 3 + 2] * k[x]; }
+                uint8_t *o = tmp + ((size_t)yy * dw + xx) * 3;
+                o[0] = pil_clip8(s0); o[1] = pil_clip8(s1); o[2] = pil_clip8(s2);
+            }
+        in = tmp; in_stride = dw * 3; in_w = dw; voff = y_first;    /* bounds_vert shifted by ybox_first */
+    }
+    if (need_v) {
+        for (int yy = 0; yy < dh; ++yy) {
+            const int ymin = bv[yy * 2] - voff, ymax = bv[yy * 2 + 1];
+            const int32_t *k = kv + (size_t)yy * ksv;
+            for (int xx = 0; xx < in_w; ++xx) {
+                int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0;
+                for (int y = 0; y < ymax; ++y) {
+                    const uint8_t *p = in + (size_t)(y + ymin) * in_stride + xx * 3;
+                    s0 += p[0] * k[y]; s1 += p[1] * k[y]; s2 += p[2] * k[y];
+                }
+                uint8_t *o = dst + ((size_t)yy * dw + xx) * 3;
+                o[0] = pil_clip8(s0); o[1] = pil_clip8(s1); o[2] = pil_clip8(s2);
+            }
+        }
+    } else {
+        for (int y = 0; y < dh; ++y) memcpy(dst + (size_t)y * dw * 3, in + (size_t)y * in_stride, (size_t)dw * 3);
+    }
+    free(tmp); free(bh); free(bv); free(kh); free(kv);
+}
+
+/* strong_sort.py:43-51 + :102-108: xyxy (float64) -> xywh -> int-truncated, clipped x1,y1,x2,y2 */
+void orc_ssort_crop_box(const double *xyxy, int img_w, int img_h, int32_t *out4)
+{
+    const double x = (xyxy[0] + xyxy[2]) / 2, y = (xyxy[1] + xyxy[3]) / 2, w = xyxy[2] - xyxy[0], h = xyxy[3] - xyxy[1];
+    int x1 = (int)(x - w / 2), x2 = (int)(x + w / 2), y1 = (int)(y - h / 2), y2 = (int)(y + h / 2);
+    out4[0] = x1 > 0 ? x1 : 0; out4[2] = x2 < img_w - 1 ? x2 : img_w - 1;
+    out4[1] = y1 > 0 ? y1 : 0; out4[3] = y2 < img_h - 1 ? y2 : img_h - 1;
+}
+
+/* crop + Resize + ToTensor + Normalize: out (3, oh, ow) float32 = ((u8 / 255) - mean[c]) / std[c] in float32; also the resized u8 (oh, ow, 3) if u8_out */
+void orc_ssort_reid_preprocess(const uint8_t *img, int h, int w, const double *xyxy, int oh, int ow, const float *mean3, const float *std3,
+                               float *out, uint8_t *u8_out)
+{
+    int32_t b[4];
+    orc_ssort_crop_box(xyxy, w, h, b);
+    const int cw = b[2] - b[0], ch = b[3] - b[1];
+    uint8_t *r = malloc((size_t)oh * ow * 3);
+    if (cw <= 0 || ch <= 0) memset(r, 0, (size_t)oh * ow * 3);          /* the reference raises on an empty crop */
+    else orc_pil_resize_bilinear_rgb(img + ((size_t)b[1] * w + b[0]) * 3, ch, cw, w * 3, r, oh, ow);
+    for (int c = 0; c < 3; ++c)
+        for (int i = 0; i < oh * ow; ++i) {
+            float v = (float)r[i * 3 + c] / 255.0f;
+            v = v - mean3[c];
+            out[(size_t)c * oh * ow + i] = v / std3[c];
+        }
+    if (u8_out) memcpy(u8_out, r, (size_t)oh * ow * 3);
+    free(r);
+}

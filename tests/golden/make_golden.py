@@ -705,11 +705,60 @@ def gen_ssort(out_dir):
         print(f"ssort_{name}: rows_out={out_off[-1]} next_id={model.tracker._next_id}")
 
 
+def gen_pil_preprocess(out_dir):
+    """Plain StrongSORT's ReID input: crop ori_img[y1:y2, x1:x2] of the int-truncated, clipped box
+    (strong_sort.py:102-108, :135-141), then ReIDDetectMultiBackend._preprocess (reid_multibackend.py:44-52, :184-195):
+    ToPILImage -> Resize((256, 128)) -> ToTensor -> Normalize(ImageNet). torchvision is not installed; its three transforms
+    are thin wrappers whose arithmetic is Pillow's Image.resize(BILINEAR) [third-party, Pillow 12.2.0 here] followed by
+    uint8 -> float32 .div(255) and .sub_(mean).div_(std) on torch tensors, which is what runs below."""
+    from PIL import Image
+    rng = np.random.default_rng(31)
+    H, W = 540, 960
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.stack([(xx * 255 // W), (yy * 255 // H), ((xx + yy) % 256)], axis=2).astype(np.int64)
+    img = np.clip(img + rng.integers(-40, 40, img.shape), 0, 255).astype(np.uint8)
+    for _ in range(30):                                      # flat rectangles like the synthetic renderer
+        x, y, w, h = rng.integers(0, W - 80), rng.integers(0, H - 160), rng.integers(20, 80), rng.integers(40, 160)
+        img[y:y + h, x:x + w] = rng.integers(0, 255, 3)
+    boxes = np.array([
+        [100.3, 50.7, 161.9, 203.2],      # typical person: upscale in both directions
+        [400.0, 100.0, 528.0, 356.0],     # exactly 128 x 256: Pillow still resamples only if the size differs -> copy
+        [10.2, 20.9, 330.7, 520.1],       # larger than the target: antialiased downscale in both directions
+        [600.5, 30.5, 900.4, 180.9],      # wide and short: downscale x, upscale y
+        [-15.0, -8.0, 40.6, 99.0],        # clipped at the top-left
+        [930.2, 400.0, 975.0, 560.0],     # clipped at the bottom-right
+        [300.0, 300.0, 303.9, 420.0],     # 3 px wide
+        [500.0, 200.0, 590.0, 204.2],     # 4 px tall
+        [700.1, 250.2, 701.9, 252.8],     # 1 x 2 px
+        [50.9, 260.1, 179.2, 389.9],      # 128 px wide, shorter than 256
+    ])
+
+    def xyxy_int(b):                                          # xyxy2xywh then _xywh_to_xyxy (strong_sort.py:102-108)
+        x, y, w, h = (b[0] + b[2]) / 2, (b[1] + b[3]) / 2, b[2] - b[0], b[3] - b[1]
+        return max(int(x - w / 2), 0), max(int(y - h / 2), 0), min(int(x + w / 2), W - 1), min(int(y + h / 2), H - 1)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    resized, ints, tensors = [], [], {}
+    for i, b in enumerate(boxes):
+        x1, y1, x2, y2 = xyxy_int(b)
+        crop = img[y1:y2, x1:x2]
+        pil = Image.fromarray(crop)                           # ToPILImage on an (H, W, 3) uint8 ndarray
+        r = np.asarray(pil.resize((128, 256), Image.BILINEAR))        # Resize((256, 128)) = (h, w); PIL takes (w, h)
+        resized.append(r); ints.append([x1, y1, x2, y2])
+        if i in (0, 2):
+            t = torch.from_numpy(r.copy()).permute(2, 0, 1).contiguous().to(torch.float32).div(255)      # ToTensor
+            tensors[f"norm{i}"] = t.sub_(mean).div_(std).numpy()                                          # Normalize
+    lut = torch.arange(256, dtype=torch.uint8).view(1, 256, 1).repeat(3, 1, 1).to(torch.float32).div(255).sub_(mean).div_(std)
+    np.savez_compressed(os.path.join(out_dir, "pil_preprocess.npz"), image=img, boxes=boxes, boxes_int=np.array(ints, dtype=np.int64),
+                        resized=np.stack(resized), norm_lut=lut.numpy()[:, :, 0], pillow=np.array(Image.__version__), **tensors)
+    print("pil preprocess ok", len(boxes))
+
+
 def main():
     out_dir = HERE
     only = set(sys.argv[1:])
     gens = {"ocsort": gen_ocsort, "iou": gen_iou_family, "kf7": gen_kf7, "lsa": gen_lsa,
-            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort}
+            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess}
     for k, fn in gens.items():
         if not only or k in only:
             fn(out_dir)

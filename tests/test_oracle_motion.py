@@ -43,3 +43,18 @@ def test_motion_costs_match_reference(orc):
         oks_c = orc.oks_cost(g[f"c{c}_trk_kps"], g[f"c{c}_det_kps"])
         np.testing.assert_allclose(oks_c, g[f"c{c}_oks_cost"], rtol=1e-12, atol=1e-15, equal_nan=True)   # exp() of libm vs numpy
     assert np.isnan(g["c0_oks_cost"][1]).all()         # the single-visible-keypoint track: scale < 0.1 -> NaN (oks_matching.py:80-81)
+
+
+def test_pil_reid_preprocess_matches_pillow(orc):
+    """crop box, Pillow bilinear resize (bit-exact) and ToTensor+Normalize (bit-exact float32)."""
+    g = np.load(os.path.join(GOLDEN, "pil_preprocess.npz"))
+    img = g["image"]
+    H, W = img.shape[:2]
+    np.testing.assert_array_equal(orc.ssort_crop_box(g["boxes"], W, H), g["boxes_int"])
+    for i, b in enumerate(g["boxes"]):
+        out, u8 = orc.ssort_reid_preprocess(img, b)
+        np.testing.assert_array_equal(u8, g["resized"][i], err_msg=f"box {i}")
+        if f"norm{i}" in g.files:
+            np.testing.assert_array_equal(out, g[f"norm{i}"])
+        for c in range(3):                         # every crop: normalisation = the (value, channel) table torch produced
+            np.testing.assert_array_equal(out[c], g["norm_lut"][c][u8[:, :, c]])
