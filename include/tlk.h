@@ -290,6 +290,18 @@ int tlk_roi_crop_resize_norm(const uint8_t *frames_dev, int batch, int h, int w,
                              const int32_t *counts_dev, int max_n, int out_h, int out_w, const float *mean3,
                              const float *std3, int layout, int dtype, void *out_dev, void *hip_stream);
 
+/* Plain StrongSORT's ReID input. Replaces StrongSORT._get_features' crop loop
+ * (plugins/track/strong_sort/strong_sort.py:135-141 with _xywh_to_xyxy :102-108: int-truncated box clipped to
+ * [0, w-1] x [0, h-1], crop ori_img[y1:y2, x1:x2]) and ReIDDetectMultiBackend._preprocess
+ * (plugins/track/strong_sort/reid_multibackend.py:44-52, :184-195: ToPILImage -> Resize((256,128)) -> ToTensor ->
+ * Normalize). The resize is Pillow's Image.resize(BILINEAR): separable, antialiased (support = max(1, scale)),
+ * 22-bit fixed-point weights, uint8 intermediate -- bit-exact; value = ((u8 / 255) - mean) / std in float32.
+ * boxes_xyxy_dev: (batch, max_n) rows of `box_stride` doubles whose first four are x1,y1,x2,y2 (box_stride = 7 reads
+ * the tracker's (n,7) detection rows in place). out as tlk_roi_crop_resize_norm. mean3/std3 HOST float[3]. */
+int tlk_roi_crop_pil_resize_norm(const uint8_t *frames_dev, int batch, int h, int w, const double *boxes_xyxy_dev, int box_stride,
+                                 const int32_t *counts_dev, int max_n, int out_h, int out_w, const float *mean3,
+                                 const float *std3, int layout, int dtype, void *out_dev, void *hip_stream);
+
 /* pred_dev (batch, A, 5+num_classes) float32 raw YOLOX head (A = (s/8)^2+(s/16)^2+(s/32)^2) ->
  * per frame up to max_out detections in rtmlib order (class-major, score-descending):
  * ltwh_dev (batch,max_out,4) clipped to the image like RTMLibDetector (rtmlib_api.py:36-41),

@@ -291,9 +291,13 @@ void orc_ssort_reid_preprocess(const uint8_t *img, int h, int w, const double *x
     int32_t b[4];
     orc_ssort_crop_box(xyxy, w, h, b);
     const int cw = b[2] - b[0], ch = b[3] - b[1];
+    if (cw <= 0 || ch <= 0) {                                /* the reference raises on an empty crop; the HIP path emits a zero slot */
+        memset(out, 0, sizeof(float) * 3 * (size_t)oh * ow);
+        if (u8_out) memset(u8_out, 0, (size_t)oh * ow * 3);
+        return;
+    }
     uint8_t *r = malloc((size_t)oh * ow * 3);
-    if (cw <= 0 || ch <= 0) memset(r, 0, (size_t)oh * ow * 3);          /* the reference raises on an empty crop */
-    else orc_pil_resize_bilinear_rgb(img + ((size_t)b[1] * w + b[0]) * 3, ch, cw, w * 3, r, oh, ow);
+    orc_pil_resize_bilinear_rgb(img + ((size_t)b[1] * w + b[0]) * 3, ch, cw, w * 3, r, oh, ow);
     for (int c = 0; c < 3; ++c)
         for (int i = 0; i < oh * ow; ++i) {
             float v = (float)r[i * 3 + c] / 255.0f;

@@ -1,7 +1,11 @@
 """-m gpu: letterbox / ROI crop-resize-normalize / YOLOX decode+NMS kernels vs the C oracle
 (integer pixel values bit-exact; fp32 normalisation bit-exact; fp16/bf16 = rounded fp32)."""
+import os
+
 import numpy as np
 import pytest
+
+from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
@@ -132,3 +136,48 @@ def test_fused_bias_act_epilogue_matches_torch(dtype_name, act):
         torch.cuda.synchronize()
         tol = 2e-3 if dtype == torch.float16 else 1.6e-2          # one rounding to the storage dtype (+ fast exp in SiLU)
         torch.testing.assert_close(got.float(), ref.to(dtype).float(), rtol=tol, atol=tol)
+
+
+# ------------------------------------------------------------------------------------------------ plain StrongSORT ReID input (G1)
+def test_pil_crop_resize_norm_golden_bit_exact():
+    """Pillow-made golden: float32 output of every crop equals torch's (value, channel) normalisation table looked up at the
+    resized uint8 Pillow produced -> the resize is bit-exact and so is the normalisation."""
+    import torch
+    from tracklab_amd import _lib
+    g = np.load(os.path.join(GOLDEN, "pil_preprocess.npz"))
+    img = torch.from_numpy(g["image"]).cuda()[None].contiguous()
+    n = len(g["boxes"])
+    boxes = torch.zeros((1, n + 2, 7), dtype=torch.float64, device="cuda")          # (n,7) detection rows: stride 7
+    boxes[0, :n, :4] = torch.from_numpy(g["boxes"]).cuda()
+    counts = torch.tensor([n], dtype=torch.int32, device="cuda")
+    for layout in ("nchw", "nhwc"):
+        out = _lib.roi_crop_pil_resize_norm(img, boxes, counts, 256, 128, layout, torch.float32).cpu().numpy()
+        for i in range(n):
+            exp = np.stack([g["norm_lut"][c][g["resized"][i][:, :, c]] for c in range(3)])
+            np.testing.assert_array_equal(out[i], exp, err_msg=f"{layout} box {i}")
+            if f"norm{i}" in g.files:
+                np.testing.assert_array_equal(out[i], g[f"norm{i}"])
+        assert not out[n:].any()                                                       # slots >= count are zero
+    half = _lib.roi_crop_pil_resize_norm(img, boxes, counts, 256, 128, "nhwc", torch.float16).cpu().numpy()
+    np.testing.assert_array_equal(half[0], g["norm0"].astype(np.float16))
+
+
+@pytest.mark.parametrize("oh,ow", [(256, 128), (128, 64), (384, 128)])
+def test_pil_crop_resize_norm_vs_oracle_1080p(orc, oh, ow):
+    import torch
+    from tracklab_amd import _lib
+    from tracklab_amd.synth import SyntheticStream, render_frame
+    rng = np.random.default_rng(3)
+    fr = SyntheticStream(4, 60, 1).step()
+    frame = render_frame(rng, fr["gt_boxes"])
+    dets = fr["dets"].copy()
+    dets[0, :4] = [5.2, 3.1, 700.7, 1000.9]            # far larger than the target: direct (unstaged) branch
+    dets[1, :4] = [1900.0, 1000.0, 1950.0, 1100.0]     # clipped at the border
+    dets[2, :4] = [300.0, 300.0, 300.4, 300.9]         # empty crop -> zeros
+    n = len(dets)
+    boxes = torch.from_numpy(dets[None]).cuda().contiguous()
+    counts = torch.tensor([n], dtype=torch.int32, device="cuda")
+    out = _lib.roi_crop_pil_resize_norm(torch.from_numpy(frame).cuda()[None].contiguous(), boxes, counts, oh, ow, "nchw", torch.float32).cpu().numpy()
+    for i in range(n):
+        exp, _ = orc.ssort_reid_preprocess(frame, dets[i, :4], oh, ow)
+        np.testing.assert_array_equal(out[i], exp, err_msg=f"crop {i} box {dets[i, :4]}")

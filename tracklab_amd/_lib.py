@@ -227,6 +227,36 @@ def roi_crop_resize_norm(frames, boxes_ltwh, counts, out_h, out_w, layout="nchw"
     return out
 
 
+def roi_crop_pil_resize_norm(frames, boxes_xyxy, counts, out_h=256, out_w=128, layout="nchw", dtype=None,
+                             mean=IMAGENET_MEAN, std=IMAGENET_STD, out=None):
+    """Plain StrongSORT's ReID input (int-truncated crop + Pillow bilinear resize + ToTensor + Normalize).
+    frames (B,H,W,3) u8, boxes_xyxy (B,max_n,S>=4) f64 whose first four columns are x1,y1,x2,y2 (the tracker's (n,7)
+    detection rows can be passed as they are), counts (B,) i32 -> (B*max_n, 3, out_h, out_w)."""
+    import torch
+    L = lib()
+    _bind_image(L)
+    if not getattr(L, "_pil_bound", False):
+        L.tlk_roi_crop_pil_resize_norm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                   C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int,
+                                                   C.c_void_p, C.c_void_p]
+        L._pil_bound = True
+    assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous()
+    assert boxes_xyxy.dtype == torch.float64 and boxes_xyxy.is_contiguous() and boxes_xyxy.dim() == 3 and counts.dtype == torch.int32
+    dtype = dtype or torch.float16
+    B, H, W, _ = frames.shape
+    max_n, stride = boxes_xyxy.shape[1], boxes_xyxy.shape[2]
+    if out is None:
+        shape = (B * max_n, 3, out_h, out_w) if layout == "nchw" else (B * max_n, out_h, out_w, 3)
+        out = torch.empty(shape, dtype=dtype, device=frames.device)
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    check(L.tlk_roi_crop_pil_resize_norm(frames.data_ptr(), B, H, W, boxes_xyxy.data_ptr(), stride, counts.data_ptr(), max_n,
+                                         out_h, out_w, m, s, LAYOUT[layout], _dtype_code(dtype), out.data_ptr(), current_stream_ptr()))
+    if layout != "nchw":
+        out = out.permute(0, 3, 1, 2)
+    return out
+
+
 def yolox_decode_nms(pred, size, ratio, img_w, img_h, max_out=128, nms_thr=0.45, score_thr=0.7,
                      out=None, trk_in=None, det_id_base=0, category_id=1.0):
     """pred (B, A, 5+C) f32 cuda -> dict of ltwh (B,max_out,4), xyxy, scores, cls, counts (rtmlib order)."""

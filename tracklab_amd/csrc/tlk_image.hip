@@ -371,6 +371,237 @@ __global__ void __launch_bounds__(BLOCK) crop_lds_kernel(const unsigned char *__
     (void)row_in_band; (void)xg;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Plain StrongSORT's ReID input: crop ori_img[y1:y2, x1:x2] of the int-truncated, clipped box
+// (strong_sort.py:102-108, :135-141) -> Pillow Image.resize(BILINEAR) -> ToTensor -> Normalize
+// (reid_multibackend.py:44-52, :184-195). Pillow's resample (src/libImaging/Resample.c) is separable with an 8-bit
+// intermediate: horizontal pass (support = max(1, scale) source pixels either side, weights normalised, 22-bit fixed
+// point, rounded and clipped to uint8), then the same vertically. Workgroup = (slot, band of PIL_BAND output rows):
+// stage the source rows of the band in LDS, run the horizontal pass into a second LDS plane, then the vertical pass +
+// normalisation straight to 16-byte stores. Crops too large for the LDS planes take the direct (recompute) branch.
+// ---------------------------------------------------------------------------------------------
+constexpr int PIL_BITS = 32 - 8 - 2;
+constexpr int PIL_BAND = 32;
+constexpr int PIL_KMAX = 5;                           // taps per axis handled from LDS tables: scale <= 2
+constexpr int PIL_ROWS = 40;                          // staged source rows per band
+constexpr int PIL_ROW_BYTES = 544;                    // as CROP_LDS_ROW_BYTES: crops up to 170 px wide
+constexpr int PIL_OW_MAX = 128;
+
+struct PilAxis { double scale, support, ss; int ksize; };
+__host__ __device__ __forceinline__ PilAxis pil_axis(int inSize, int outSize)
+{
+    PilAxis a;
+    a.scale = (double)inSize / (double)outSize;
+    const double fs = a.scale < 1.0 ? 1.0 : a.scale;
+    a.support = 1.0 * fs;
+    a.ss = 1.0 / fs;
+    a.ksize = (int)ceil(a.support) * 2 + 1;
+    return a;
+}
+__host__ __device__ __forceinline__ void pil_bounds(const PilAxis &a, int inSize, int xx, int &xmin, int &xmax)
+{
+    const double center = 0.0 + (xx + 0.5) * a.scale;
+    xmin = (int)(center - a.support + 0.5);
+    if (xmin < 0) xmin = 0;
+    xmax = (int)(center + a.support + 0.5);
+    if (xmax > inSize) xmax = inSize;
+    xmax -= xmin;
+}
+__host__ __device__ __forceinline__ double pil_tri(const PilAxis &a, int xx, int xmin, int x)
+{
+    const double center = 0.0 + (xx + 0.5) * a.scale;
+    double v = (x + xmin - center + 0.5) * a.ss;
+    if (v < 0.0) v = -v;
+    return v < 1.0 ? 1.0 - v : 0.0;
+}
+__host__ __device__ __forceinline__ double pil_wsum(const PilAxis &a, int xx, int xmin, int xmax)
+{
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) ww += pil_tri(a, xx, xmin, x);
+    return ww;
+}
+__host__ __device__ __forceinline__ int pil_fixed(const PilAxis &a, int xx, int xmin, int x, double ww)
+{
+    double w = pil_tri(a, xx, xmin, x);
+    if (ww != 0.0) w /= ww;
+    return (int)(0.5 + w * (double)(1 << PIL_BITS));
+}
+__device__ __forceinline__ int pil_clip8(int v) { v >>= PIL_BITS; return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+__device__ __forceinline__ void ssort_crop_box(const double *xyxy, int W, int H, int &x1, int &y1, int &x2, int &y2)
+{
+    const double x = (xyxy[0] + xyxy[2]) / 2, y = (xyxy[1] + xyxy[3]) / 2, w = xyxy[2] - xyxy[0], h = xyxy[3] - xyxy[1];
+    x1 = (int)(x - w / 2); x2 = (int)(x + w / 2); y1 = (int)(y - h / 2); y2 = (int)(y + h / 2);
+    x1 = x1 > 0 ? x1 : 0; y1 = y1 > 0 ? y1 : 0;
+    x2 = x2 < W - 1 ? x2 : W - 1; y2 = y2 < H - 1 ? y2 : H - 1;
+}
+
+// one horizontally resampled uint8 sample (3 channels) of source row `row` (global memory) at output column xx
+__device__ __forceinline__ void pil_hsample(const unsigned char *__restrict__ row, const PilAxis &ax, int cw, int xx, int (&o)[3])
+{
+    int xmin, xmax;
+    pil_bounds(ax, cw, xx, xmin, xmax);
+    const double ww = pil_wsum(ax, xx, xmin, xmax);
+    int s0 = 1 << (PIL_BITS - 1), s1 = s0, s2 = s0;
+    for (int x = 0; x < xmax; ++x) {
+        const int k = pil_fixed(ax, xx, xmin, x, ww);
+        const unsigned char *p = row + (size_t)(x + xmin) * 3;
+        s0 += (int)p[0] * k; s1 += (int)p[1] * k; s2 += (int)p[2] * k;
+    }
+    o[0] = pil_clip8(s0); o[1] = pil_clip8(s1); o[2] = pil_clip8(s2);
+}
+
+template <typename T, int LAYOUT>
+__global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
+                                                         const double *__restrict__ boxes, int box_stride, const int *__restrict__ counts,
+                                                         int max_n, int OH, int OW, float m0, float m1, float m2, float d0, float d1, float d2,
+                                                         T *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_rows[PIL_ROWS * PIL_ROW_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char s_h[PIL_ROWS * (PIL_OW_MAX * 3 + 16)];
+    __shared__ int s_hmin[PIL_OW_MAX], s_hmax[PIL_OW_MAX], s_hk[PIL_OW_MAX][PIL_KMAX];
+    __shared__ int s_vmin[PIL_BAND], s_vmax[PIL_BAND], s_vk[PIL_BAND][PIL_KMAX];
+    const int HS = OW * 3 + 16;
+    const int tid = threadIdx.x;
+    const int bands = (OH + PIL_BAND - 1) / PIL_BAND;
+    const int slot = blockIdx.x / bands, band = blockIdx.x - slot * bands;
+    const int b = slot / max_n, i = slot - b * max_n;
+    const int y_base = band * PIL_BAND;
+    const int nb = min(PIL_BAND, OH - y_base);
+    const int groups_per_row = OW / 8;
+    const float mean[3] = {m0, m1, m2}, stdv[3] = {d0, d1, d2};
+    bool valid = i < counts[b];
+    int x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+    if (valid) { ssort_crop_box(boxes + ((size_t)b * max_n + i) * box_stride, W, H, x1, y1, x2, y2); valid = (x2 > x1) && (y2 > y1); }
+    const int cw = x2 - x1, ch = y2 - y1;
+    const PilAxis ax = pil_axis(valid ? cw : 1, OW), ay = pil_axis(valid ? ch : 1, OH);
+    bool staged = false;
+    int r_lo = 0, nrows = 0;
+    if (valid) {
+        int lo0, n0_, lo1, n1_;
+        pil_bounds(ay, ch, y_base, lo0, n0_);
+        pil_bounds(ay, ch, y_base + nb - 1, lo1, n1_);
+        r_lo = lo0; nrows = lo1 + n1_ - lo0;
+        staged = OW <= PIL_OW_MAX && nrows <= PIL_ROWS && cw * 3 + STAGE_PAD <= PIL_ROW_BYTES && ax.ksize <= PIL_KMAX && ay.ksize <= PIL_KMAX;
+    }
+    if (valid && staged) {
+        const unsigned char *gend = frames + (size_t)B * H * W * 3;
+        const int cmax = (cw * 3 + 30) >> 4;
+        for (int idx = tid; idx < nrows * cmax; idx += BLOCK) {                 // source rows of the band, one flat sweep
+            const int rr = idx / cmax, c = idx - rr * cmax;
+            const unsigned char *g0 = frames + ((size_t)b * H * W + (size_t)(y1 + r_lo + rr) * W + x1) * 3;
+            const uintptr_t a0 = (uintptr_t)g0 & ~(uintptr_t)15;
+            const int chunks = ((int)((uintptr_t)g0 - a0) + cw * 3 + 15) >> 4;
+            if (c < chunks) {
+                const unsigned char *p = (const unsigned char *)a0 + (size_t)c * 16;
+                unsigned char *lds = s_rows + rr * PIL_ROW_BYTES + c * 16;
+                if (p + 16 <= gend) *reinterpret_cast<uint4 *>(lds) = *reinterpret_cast<const uint4 *>(p);
+                else for (int k = 0; k < 16 && p + k < gend; ++k) lds[k] = p[k];
+            }
+        }
+        if (tid < OW) {                                                         // horizontal coefficient rows
+            int xmin, xmax;
+            pil_bounds(ax, cw, tid, xmin, xmax);
+            const double ww = pil_wsum(ax, tid, xmin, xmax);
+            s_hmin[tid] = xmin * 3; s_hmax[tid] = xmax;
+            for (int k = 0; k < PIL_KMAX; ++k) s_hk[tid][k] = k < xmax ? pil_fixed(ax, tid, xmin, k, ww) : 0;
+        }
+        if (tid >= BLOCK - PIL_BAND && tid - (BLOCK - PIL_BAND) < nb) {         // vertical coefficient rows (last wavefront's lanes)
+            const int ry = tid - (BLOCK - PIL_BAND);
+            int ymin, ymax;
+            pil_bounds(ay, ch, y_base + ry, ymin, ymax);
+            const double ww = pil_wsum(ay, y_base + ry, ymin, ymax);
+            s_vmin[ry] = ymin - r_lo; s_vmax[ry] = ymax;
+            for (int k = 0; k < PIL_KMAX; ++k) s_vk[ry][k] = k < ymax ? pil_fixed(ay, y_base + ry, ymin, k, ww) : 0;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < nrows * OW; idx += BLOCK) {                   // horizontal pass -> 8-bit plane
+            const int rr = idx / OW, x = idx - rr * OW;
+            const uintptr_t g0 = (uintptr_t)(frames + ((size_t)b * H * W + (size_t)(y1 + r_lo + rr) * W + x1) * 3);
+            const unsigned char *p = s_rows + rr * PIL_ROW_BYTES + (int)(g0 & 15) + s_hmin[x];
+            const int n = s_hmax[x];
+            int s0 = 1 << (PIL_BITS - 1), s1 = s0, s2 = s0;
+#pragma unroll
+            for (int k = 0; k < PIL_KMAX; ++k)
+                if (k < n) { const int kv = s_hk[x][k]; s0 += (int)p[k * 3] * kv; s1 += (int)p[k * 3 + 1] * kv; s2 += (int)p[k * 3 + 2] * kv; }
+            unsigned char *o = s_h + rr * HS + x * 3;
+            o[0] = (unsigned char)pil_clip8(s0); o[1] = (unsigned char)pil_clip8(s1); o[2] = (unsigned char)pil_clip8(s2);
+        }
+    }
+    __syncthreads();
+    for (int unit = tid; unit < PIL_BAND * groups_per_row; unit += BLOCK) {
+        const int ry = unit / groups_per_row, x_base = (unit - ry * groups_per_row) * 8;
+        const int y = y_base + ry;
+        if (y >= OH) continue;
+        T px[8][3];
+        if (valid && staged) {
+            const unsigned char *p = s_h + s_vmin[ry] * HS + x_base * 3;
+            const int n = s_vmax[ry];
+            int acc[24];
+#pragma unroll
+            for (int q = 0; q < 24; ++q) acc[q] = 1 << (PIL_BITS - 1);
+#pragma unroll
+            for (int k = 0; k < PIL_KMAX; ++k)
+                if (k < n) {
+                    const int kv = s_vk[ry][k];
+                    const unsigned char *r = p + k * HS;
+#pragma unroll
+                    for (int q = 0; q < 24; ++q) acc[q] += (int)r[q] * kv;
+                }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float f = (float)pil_clip8(acc[k * 3 + c]) / 255.0f; f = f - mean[c]; f = f / stdv[c];
+                    px[k][c] = cvt<T>(f);
+                }
+        } else if (valid) {
+            // direct branch: every vertical tap recomputes its horizontally resampled (and uint8-rounded) sample from global memory
+            int ymin, ymax;
+            pil_bounds(ay, ch, y, ymin, ymax);
+            const double wwy = pil_wsum(ay, y, ymin, ymax);
+            const unsigned char *base = frames + ((size_t)b * H * W + (size_t)y1 * W + x1) * 3;
+            for (int k = 0; k < 8; ++k) {
+                int s[3] = {1 << (PIL_BITS - 1), 1 << (PIL_BITS - 1), 1 << (PIL_BITS - 1)};
+                for (int t = 0; t < ymax; ++t) {
+                    const int kv = pil_fixed(ay, y, ymin, t, wwy);
+                    int hv[3];
+                    pil_hsample(base + (size_t)(ymin + t) * W * 3, ax, cw, x_base + k, hv);
+                    s[0] += hv[0] * kv; s[1] += hv[1] * kv; s[2] += hv[2] * kv;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float f = (float)pil_clip8(s[c]) / 255.0f; f = f - mean[c]; f = f / stdv[c];
+                    px[k][c] = cvt<T>(f);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) px[k][c] = cvt<T>(0.f);
+        }
+        if (LAYOUT == LAYOUT_NCHW) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                Pack<T, 8> p;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) p.v[k] = px[k][c];
+                *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)slot * 3 + c) * OH + y) * OW + x_base) = p;
+            }
+        } else {
+            T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Pack<T, 8> p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
+                *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+            }
+        }
+    }
+}
+
 // ---- letterbox: workgroup = (frame, LB_BAND output rows); stages the source rows with non-zero weight
 constexpr int LB_BAND = 4;
 
@@ -768,6 +999,37 @@ extern "C" int tlk_roi_crop_resize_norm(const uint8_t *frames_dev, int batch, in
     if (dtype == 0) launch_crop<float>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st);
     else if (dtype == 1) launch_crop<__half>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st);
     else launch_crop<bf16_t>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
+
+template <typename T>
+int launch_pil_crop(const unsigned char *frames, int B, int H, int W, const double *boxes, int box_stride, const int *counts, int max_n,
+                    int OH, int OW, const float *mean, const float *stdv, int layout, void *out, hipStream_t st)
+{
+    const dim3 grid((unsigned)((long long)B * max_n * ((OH + PIL_BAND - 1) / PIL_BAND)));
+    if (layout == LAYOUT_NCHW)
+        hipLaunchKernelGGL((pil_crop_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, box_stride, counts, max_n, OH, OW,
+                           mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], (T *)out);
+    else
+        hipLaunchKernelGGL((pil_crop_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, box_stride, counts, max_n, OH, OW,
+                           mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], (T *)out);
+    return TLK_OK;
+}
+
+extern "C" int tlk_roi_crop_pil_resize_norm(const uint8_t *frames_dev, int batch, int h, int w, const double *boxes_xyxy_dev, int box_stride,
+                                            const int32_t *counts_dev, int max_n, int out_h, int out_w, const float *mean3,
+                                            const float *std3, int layout, int dtype, void *out_dev, void *hip_stream)
+{
+    if (batch < 0 || h <= 0 || w <= 0 || max_n < 0 || out_h <= 0 || out_w <= 0 || box_stride < 4) return fail(TLK_EINVAL, "tlk_roi_crop_pil_resize_norm: bad size");
+    if (out_w % 8 != 0) return fail(TLK_EINVAL, "tlk_roi_crop_pil_resize_norm: out_w must be a multiple of 8");
+    if (layout < 0 || layout > 1 || dtype < 0 || dtype > 2) return fail(TLK_EINVAL, "tlk_roi_crop_pil_resize_norm: bad layout/dtype");
+    if (batch == 0 || max_n == 0) return TLK_OK;
+    if (!frames_dev || !boxes_xyxy_dev || !counts_dev || !mean3 || !std3 || !out_dev) return fail(TLK_EINVAL, "tlk_roi_crop_pil_resize_norm: null pointer");
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (dtype == 0) launch_pil_crop<float>(frames_dev, batch, h, w, boxes_xyxy_dev, box_stride, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st);
+    else if (dtype == 1) launch_pil_crop<__half>(frames_dev, batch, h, w, boxes_xyxy_dev, box_stride, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st);
+    else launch_pil_crop<bf16_t>(frames_dev, batch, h, w, boxes_xyxy_dev, box_stride, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st);
     TLK_HIP(hipGetLastError());
     return TLK_OK;
 }
