@@ -82,3 +82,43 @@ def test_backbone_gemm_and_fused_epilogue_paths_agree_with_plain_torch():
         fast, ref = (fast[0], ref[0]) if isinstance(fast, tuple) else (fast, ref)
         err = (fast.float() - ref).abs().max().item() / (ref.abs().max().item() + 1e-6)
         assert err < 3e-2, err                   # fp16 activations through ~50 layers vs fp32
+
+
+def test_hip_strongsort_module_end_to_end_on_device(orc):
+    """HipStrongSORT: GPU crop (Pillow semantics) + ReID forward + tlk_ssort bank through the plugin API. The oracle tracker fed
+    with the module's own features must give the same rows; the crops the module cut are checked against the oracle too."""
+    import torch
+    from test_modules_host import _frame_df
+    from tracklab_amd import _lib
+    from tracklab_amd.synth import SyntheticStream, render_frame
+    from tracklab_amd.wrappers import HipStrongSORT
+    hyper = dict(ema_alpha=0.9, max_age=10, max_dist=0.3, max_iou_dist=0.7, max_unmatched_preds=7, mc_lambda=0.995, n_init=2, nn_budget=10)
+    m = HipStrongSORT(NS(min_confidence=0.4, ecc=False, feature_dim=64, hyperparams=hyper), "cuda:0", tracking_dataset=None)
+    ref = orc.PlainStrongSORT(64, **hyper, img_w=1920, img_h=1080)
+    rng = np.random.default_rng(2)
+    feats_seen = []
+    orig = m._features
+    m._features = lambda image, dets: feats_seen.append(orig(image, dets)) or feats_seen[-1]
+    n_rows = 0
+    for fr in SyntheticStream(6, 15, 12, miss_prob=0.05):
+        img = render_frame(rng, fr["gt_boxes"])
+        df = _frame_df(fr, np.float64, id0=200)
+        sample = m.preprocess(img, df, pd.Series({"frame": fr["frame"]}))
+        out = m.process(default_collate([sample]), df, pd.DataFrame({"file_path": ["unused"]}))
+        f = feats_seen[-1]
+        assert f.shape == (len(df), 64) and np.isfinite(f).all()
+        keep = sample["input"][:, 4] > 0.4
+        exp = ref.update(sample["input"][keep], f[keep])
+        assert len(out) == len(exp)
+        if len(exp):
+            np.testing.assert_array_equal(out.index.to_numpy(), exp[:, 7].astype(int))
+            np.testing.assert_array_equal(out.track_id.to_numpy(), exp[:, 4])
+            np.testing.assert_array_equal(np.stack(out.track_bbox_ltwh.to_list())[:, :2], exp[:, :2])
+            n_rows += len(exp)
+    assert n_rows > 50
+    # the crops the module feeds its network
+    boxes = torch.from_numpy(sample["input"][None]).cuda()
+    crops = _lib.roi_crop_pil_resize_norm(torch.from_numpy(img).cuda()[None].contiguous(), boxes, torch.tensor([len(df)], dtype=torch.int32, device="cuda"),
+                                          256, 128, "nchw", torch.float32).cpu().numpy()
+    for i in range(len(df)):
+        np.testing.assert_array_equal(crops[i], orc.ssort_reid_preprocess(img, sample["input"][i, :4])[0])

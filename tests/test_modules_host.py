@@ -111,3 +111,56 @@ def test_bpbss_module_matches_oracle(orc):
                 assert mw[0] == {1: "R", 2: "S"}[name] and mw[1] == dist
         np.testing.assert_array_equal(np.stack(out.track_bbox_kf_ltwh.to_list()), exp["kf_ltwh"])
         assert all((p is None) == (v == 0) for p, v in zip(out.track_bbox_pred_kf_ltwh, exp["pred_valid"]))
+
+
+def test_strongsort_module_host_logic_with_oracle_backend(orc):
+    """HipStrongSORT's DataFrame plumbing with the oracle standing in for the bank and synthetic features for the ReID forward:
+    rows, index (= tracklab ids, including the stale id of a coasting track) and ltwh conversion as strong_sort_api.py:73-101."""
+    from tracklab_amd._lib import SSORT_ROW
+    from tracklab_amd.wrappers import HipStrongSORT
+    hyper = dict(ema_alpha=0.9, max_age=10, max_dist=0.2, max_iou_dist=0.7, max_unmatched_preds=7, mc_lambda=0.995, n_init=2, nn_budget=10)
+    D = 32
+
+    class Backend:                                   # same surface as tracklab_amd._lib.SsortBank
+        def __init__(self):
+            self.t = orc.PlainStrongSORT(D, **hyper, img_w=1920, img_h=1080)
+
+        def update(self, dets, feat, stream):
+            keep = dets[:, 4] > 0.4                  # the bank applies min_confidence itself
+            r = self.t.update(dets[keep], feat[keep])
+            out = np.zeros(len(r), dtype=SSORT_ROW)
+            out["ltrb"], out["track_id"], out["class_id"], out["conf"], out["det_id"] = r[:, :4], r[:, 4], r[:, 5], r[:, 6], r[:, 7]
+            return out
+
+        def reset(self, stream):
+            self.t = orc.PlainStrongSORT(D, **hyper, img_w=1920, img_h=1080)
+
+    m = HipStrongSORT(NS(min_confidence=0.4, ecc=False, hyperparams=hyper), "cuda:0", tracking_dataset=None)
+    assert m.level == "image" and m.batch_size == 1 and m.output_columns == ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
+    with pytest.raises(NotImplementedError):
+        HipStrongSORT(NS(ecc=True, hyperparams=hyper), "cuda:0")
+    m._make_backend = lambda dim, h, w: Backend()
+    ref = orc.PlainStrongSORT(D, **hyper, img_w=1920, img_h=1080)
+    frame = np.zeros((1080, 1920, 3), np.uint8)
+    seen = 0
+    for fr in SyntheticStream(5, 20, 40, parts=1, dim=D, with_embeddings=True, miss_prob=0.1, low_conf_frac=0.2):
+        df = _frame_df(fr, np.float64, id0=500)
+        emb = fr["embeddings"][:, 0, :].astype(np.float32)
+        m._features = lambda image, dets, emb=emb: emb
+        sample = m.preprocess(frame, df, pd.Series({"frame": fr["frame"]}))
+        batch = default_collate([sample])
+        out = m.process(batch, df, pd.DataFrame({"file_path": ["unused"]}))
+        d = fr["dets"].copy()
+        d[:, 5] = 1.0; d[:, 6] += 500
+        keep = d[:, 4] > 0.4
+        exp = ref.update(d[keep], emb[keep])
+        if len(exp) == 0:
+            assert len(out) == 0
+            continue
+        seen += len(exp)
+        np.testing.assert_array_equal(out.index.to_numpy(), exp[:, 7].astype(int))
+        np.testing.assert_array_equal(out.track_id.to_numpy(), exp[:, 4])
+        np.testing.assert_array_equal(np.stack(out.track_bbox_ltwh.to_list()),
+                                      np.stack([exp[:, 0], exp[:, 1], exp[:, 2] - exp[:, 0], exp[:, 3] - exp[:, 1]], axis=1))
+        np.testing.assert_array_equal(out.track_bbox_conf.to_numpy(), exp[:, 6])
+    assert seen > 300

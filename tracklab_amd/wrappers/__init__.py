@@ -1,3 +1,3 @@
-from .track import HipBPBReIDStrongSORT, HipOCSORT  # noqa: F401
+from .track import HipBPBReIDStrongSORT, HipOCSORT, HipStrongSORT  # noqa: F401
 from .detect import HipYOLOX  # noqa: F401
 from .reid import HipPartReID  # noqa: F401

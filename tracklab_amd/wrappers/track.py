@@ -141,6 +141,98 @@ class HipBPBReIDStrongSORT(ImageLevelModule):
         return out
 
 
+class HipStrongSORT(ImageLevelModule):
+    """Plain StrongSORT (tracklab/wrappers/track/strong_sort_api.py:17-105): the tracker owns its ReID network. Crops are cut
+    and resized on the GPU with the reference's own arithmetic (int-truncated box, Pillow bilinear, ImageNet normalisation:
+    tlk_roi_crop_pil_resize_norm), one backbone forward gives the 512-d features, tlk_ssort_update does the rest."""
+    input_columns = ["bbox_ltwh", "bbox_conf", "category_id"]
+    output_columns = ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
+
+    def __init__(self, cfg, device, **kwargs):
+        super().__init__(batch_size=1)
+        self.cfg = cfg
+        self.device = device
+        self._bank = None
+        self._model = None
+        self._img_hw = None
+        if cfg_get(cfg, "ecc", False):
+            raise NotImplementedError("ecc camera compensation (sort/track.py:130-239, cv2.findTransformECC) is not part of the HIP path; "
+                                      "set ecc: false")
+
+    def _make_backend(self, dim, img_h, img_w):
+        from .._lib import SsortBank
+        hyper = dict(cfg_get(self.cfg, "hyperparams"))
+        return SsortBank(dim, **hyper, min_confidence=float(cfg_get(self.cfg, "min_confidence", 0.0)), wrapper_mode=True,
+                         img_w=int(img_w), img_h=int(img_h), device=_device_index(self.device),
+                         max_tracks=int(cfg_get(self.cfg, "max_tracks", 256)), max_dets=int(cfg_get(self.cfg, "max_dets", 128)))
+
+    def reset(self):
+        """New video (strong_sort_api.py:31-40 rebuilds model + tracker): state dropped, ids restart at 1."""
+        if self._bank is not None:
+            self._bank.reset(-1)
+
+    def preprocess(self, image, detections: pd.DataFrame, metadata: pd.Series):
+        if len(detections) == 0:
+            return {"input": []}
+        ltwh = np.stack(detections.bbox_ltwh.to_list())
+        out = np.empty((len(detections), 7), dtype=np.float64)             # [*ltrb, conf, cls, tracklab_id] (strong_sort_api.py:47-55)
+        out[:, 0], out[:, 1], out[:, 2], out[:, 3] = ltwh[:, 0], ltwh[:, 1], ltwh[:, 0] + ltwh[:, 2], ltwh[:, 1] + ltwh[:, 3]
+        out[:, 4] = detections.bbox_conf.to_numpy(dtype=np.float64)
+        out[:, 5] = detections.category_id.to_numpy(dtype=np.float64)
+        out[:, 6] = detections.index.to_numpy().astype(np.int64)
+        return {"input": out, "image": np.ascontiguousarray(image)}         # the frame travels with the batch instead of a second disk read
+
+    def _features(self, image, dets):
+        """StrongSORT._get_features (strong_sort.py:135-145) for all rows of `dets` (n, 7) on the GPU -> (n, D) float32 numpy."""
+        import torch
+        from .. import _lib
+        if self._model is None:
+            from ..backbones.reid import part_based_reid
+            self._dim = int(cfg_get(self.cfg, "feature_dim", 512))
+            self._model = part_based_reid(1, self._dim, device=self.device, dtype=torch.float16, channels_last=True)
+            ckpt = cfg_get(self.cfg, "model_weights", None)
+            if ckpt:
+                import os
+                if os.path.exists(str(ckpt)):
+                    self._model.load_state_dict(torch.load(str(ckpt), map_location=self.device))
+        frames = (image if hasattr(image, "detach") else torch.from_numpy(np.asarray(image))).to(self.device)
+        if frames.dim() == 3:
+            frames = frames[None]
+        n = len(dets)
+        boxes = torch.from_numpy(np.ascontiguousarray(dets, dtype=np.float64)[None]).to(self.device)
+        counts = torch.tensor([n], dtype=torch.int32, device=self.device)
+        with torch.no_grad():
+            crops = _lib.roi_crop_pil_resize_norm(frames.contiguous(), boxes, counts, 256, 128, "nhwc", torch.float16)
+            emb, _ = self._model(crops)
+        return to_numpy(emb[:, 0, :].float())
+
+    def process(self, batch, detections: pd.DataFrame, metadatas: pd.DataFrame):
+        if len(detections) == 0:
+            return []
+        inputs = to_numpy(batch["input"])
+        inputs = np.ascontiguousarray(inputs[0] if inputs.ndim == 3 else inputs, dtype=np.float64).reshape(-1, 7)
+        image = batch.get("image") if hasattr(batch, "get") else None
+        if image is None:                                                    # reference: cv2_load_image(metadatas['file_path'])
+            from PIL import Image
+            image = np.asarray(Image.open(metadatas["file_path"].values[0]).convert("RGB"))
+        image = to_numpy(image) if not hasattr(image, "detach") else image
+        if getattr(image, "ndim", 3) == 4:
+            image = image[0]
+        h, w = int(image.shape[0]), int(image.shape[1])
+        feats = self._features(image, inputs)
+        if self._bank is None or self._img_hw != (h, w):
+            self._bank = self._make_backend(feats.shape[1], h, w)
+            self._img_hw = (h, w)
+        rows = self._bank.update(inputs, feats, 0)
+        if not len(rows):
+            return []
+        ltrb = rows["ltrb"]
+        ltwh = np.stack([ltrb[:, 0], ltrb[:, 1], ltrb[:, 2] - ltrb[:, 0], ltrb[:, 3] - ltrb[:, 1]], axis=1)      # ltrb_to_ltwh
+        # no subset assert: like the reference (strong_sort_api.py:85-89) a coasting track reports the id of its previous detection
+        return pd.DataFrame({"track_bbox_ltwh": list(ltwh), "track_bbox_conf": list(rows["conf"]),
+                             "track_id": list(rows["track_id"].astype(float))}, index=pd.Index(rows["det_id"].astype(int), name="idxs"))
+
+
 def _strip(a, ndim):
     return a[0] if a.ndim == ndim + 1 else a
 
