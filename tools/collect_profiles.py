@@ -14,7 +14,7 @@ dst = os.path.join(REPO, "profiles")
 
 
 def stats_rows(d):
-    paths = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+    paths = sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1:]   # newest run only
     rows = []
     for p in paths:
         rows += list(csv.DictReader(open(p)))
@@ -45,7 +45,7 @@ def write_summary(wl, title, cmd):
 
 def counter_means(d, counter):
     acc = collections.defaultdict(list)
-    for p in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for p in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:   # newest run only
         for r in csv.DictReader(open(p)):
             if r.get("Counter_Name") == counter:
                 acc[r["Kernel_Name"]].append((int(r.get("Dispatch_Id", 0)), float(r["Counter_Value"])))
@@ -82,7 +82,15 @@ def write_traffic():
             continue
         json.dump({"kernel": kern, "launch": launch, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "calibration": cal,
                    "hbm_bytes_per_launch": (2 * f + w) * 1024}, open(os.path.join(dst, fname), "w"), indent=1)
-        print(fname, "read MB", 2 * f / 1024, "write MB", w / 1024)
+        print(fname, "read MiB", 2 * f / 1024, "write MiB", w / 1024)
+        # the bench of this same GPU call read the PREVIOUS traffic file: stamp the copy kept in profiles/ with this call's counters
+        wl = "config3" if kern == "crop_lds_kernel" else "config2"
+        bp = os.path.join(dst, f"{tag}_bench_{wl}.json")
+        if os.path.exists(bp):
+            line = json.loads(open(bp).read().strip().splitlines()[-1])
+            if line.get("roofline", {}).get("kernel") == kern:
+                line["roofline"]["traffic"] = (2 * f + w) * 1024
+                open(bp, "w").write(json.dumps(line) + "\n")
 
 
 write_summary("config3", "config3 (YOLOX-m + ReID + BPBReID-StrongSORT), 24 frames/step",
@@ -93,3 +101,30 @@ rows, paths = stats_rows(os.path.join(src, "kt_probe"))
 if paths:
     shutil.copy(paths[0], os.path.join(dst, f"{tag}_probe_kernels_kernel_stats.csv"))
 write_traffic()
+
+
+def write_mfma():
+    """MFMA kernels (cosine gallery, part distance) at canonical sizes: time, TFLOP/s vs the 157.3 TFLOP/s dense f32-MFMA peak, and
+    the matrix-pipe busy counter (SQ_VALU_MFMA_BUSY_CYCLES summed over SIMDs) vs duration x 1024 SIMDs x 2.4 GHz."""
+    rows, paths = stats_rows(os.path.join(src, "kt_mfma"))
+    if not rows:
+        print("no mfma stats"); return
+    busy = counter_means(os.path.join(src, "pmc_mfma"), "SQ_VALU_MFMA_BUSY_CYCLES")
+    flops = {"cosine_gallery_kernel_t": 2 * 100 * 100 * 100 * 512, "partdist_kernel": 2 * 110 * 100 * 6 * 256}
+    out = [f"# {tag} -- MFMA kernels (tools/probe_mfma.py: cosine gallery 100 tracks x 100 gallery rows x 100 dets x D=512; part distance 110x100, K=6, D=256)",
+           "", "command: `rocprofv3 --kernel-trace --stats` and, separately, `rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES`", "",
+           "| kernel | calls | avg us | FLOP/launch | TFLOP/s | frac of 157.3 TF f32 MFMA | MFMA busy cycles/launch | MFMA pipe busy (of 1024 SIMDs x duration @2.4 GHz) |",
+           "|---|---|---|---|---|---|---|---|"]
+    for r in rows:
+        for frag, fl in flops.items():
+            if frag in r["Name"]:
+                avg = float(r["AverageNs"]) * 1e-9
+                b = pick(busy, frag)
+                util = (b / (avg * 2.4e9 * 1024)) if b else float("nan")
+                out.append(f"| `{frag}` | {r['Calls']} | {avg * 1e6:.2f} | {fl:.3e} | {fl / avg / 1e12:.2f} | {fl / avg / 157.3e12:.4f} | "
+                           f"{b if b else float('nan'):.0f} | {util:.3f} |")
+    open(os.path.join(dst, f"{tag}_mfma.md"), "w").write("\n".join(out) + "\n")
+    print("\n".join(out[-3:]))
+
+
+write_mfma()
