@@ -302,6 +302,24 @@ int tlk_roi_crop_pil_resize_norm(const uint8_t *frames_dev, int batch, int h, in
                                  const int32_t *counts_dev, int max_n, int out_h, int out_w, const float *mean3,
                                  const float *std3, int layout, int dtype, void *out_dev, void *hip_stream);
 
+/* Pose-estimator pre/post-processing (config 4). Replaces what rtmlib.RTMPose(image, bboxes) does around its network, behind
+ * tracklab/wrappers/pose_estimator/rtmlib_api.py:27-33 (third-party rtmlib 0.0.13: RTMPose.preprocess / postprocess,
+ * bbox_xyxy2cs(padding 1.25), _fix_aspect_ratio, get_warp_matrix, top_down_affine, get_simcc_maximum; OpenCV
+ * getAffineTransform + warpAffine INTER_LINEAR, constant-0 border).
+ *   tlk_pose_crop_warp_norm: boxes (batch, max_n) rows of `box_stride` doubles starting with x1,y1,x2,y2 + counts ->
+ *     out (batch*max_n, 3, in_h, in_w) [layout/dtype as the other crops], value = (float)((u8 - mean) / std) with HOST double
+ *     mean3/std3 (rtmlib: 123.675,116.28,103.53 / 58.395,57.12,57.375), and meta (batch*max_n, 10) f64 =
+ *     [centre x,y, scale w,h, inverse warp matrix (6)] which tlk_simcc_decode needs. in_w % 8 == 0.
+ *   tlk_simcc_decode: simcc_x (n, K, wx), simcc_y (n, K, wy) f32 -> kps_xyc (n, K, 3) f64 [x, y, score] in image coordinates
+ *     (= keypoints_xyc, directly usable as tlk_bpbss_update*'s keypoints), scores (n, K) f32, conf (n) f32 = mean score
+ *     (= keypoints_conf; may be NULL). split_ratio = 2.0 for RTMPose. */
+int tlk_pose_crop_warp_norm(const uint8_t *frames_dev, int batch, int h, int w, const double *boxes_xyxy_dev, int box_stride,
+                            const int32_t *counts_dev, int max_n, int in_w, int in_h, const double *mean3, const double *std3,
+                            int layout, int dtype, void *out_dev, double *meta_dev, void *hip_stream);
+int tlk_simcc_decode(const float *simcc_x_dev, const float *simcc_y_dev, int n, int n_keypoints, int wx, int wy, double split_ratio,
+                     const double *meta_dev, int in_w, int in_h, double *kps_xyc_dev, float *scores_dev, float *conf_dev,
+                     void *hip_stream);
+
 /* pred_dev (batch, A, 5+num_classes) float32 raw YOLOX head (A = (s/8)^2+(s/16)^2+(s/32)^2) ->
  * per frame up to max_out detections in rtmlib order (class-major, score-descending):
  * ltwh_dev (batch,max_out,4) clipped to the image like RTMLibDetector (rtmlib_api.py:36-41),

@@ -257,6 +257,61 @@ def roi_crop_pil_resize_norm(frames, boxes_xyxy, counts, out_h=256, out_w=128, l
     return out
 
 
+RTMPOSE_MEAN = (123.675, 116.28, 103.53)
+RTMPOSE_STD = (58.395, 57.12, 57.375)
+
+
+def _bind_pose(L):
+    if getattr(L, "_pose_bound", False):
+        return
+    vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+    L.tlk_pose_crop_warp_norm.argtypes = [vp, ci, ci, ci, vp, ci, vp, ci, ci, ci, C.POINTER(cd), C.POINTER(cd), ci, ci, vp, vp, vp]
+    L.tlk_simcc_decode.argtypes = [vp, vp, ci, ci, ci, ci, cd, vp, ci, ci, vp, vp, vp, vp]
+    L._pose_bound = True
+
+
+def pose_crop_warp_norm(frames, boxes_xyxy, counts, in_w=192, in_h=256, layout="nchw", dtype=None, mean=RTMPOSE_MEAN,
+                        std=RTMPOSE_STD, out=None, meta=None):
+    """rtmlib RTMPose.preprocess for every box of a batch of frames. frames (B,H,W,3) u8, boxes_xyxy (B,max_n,S>=4) f64,
+    counts (B,) i32 -> (crops (B*max_n, 3, in_h, in_w), meta (B*max_n, 10) f64 [centre, scale, inverse matrix])."""
+    import torch
+    L = lib()
+    _bind_pose(L)
+    assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous()
+    assert boxes_xyxy.dtype == torch.float64 and boxes_xyxy.is_contiguous() and boxes_xyxy.dim() == 3 and counts.dtype == torch.int32
+    dtype = dtype or torch.float16
+    B, H, W, _ = frames.shape
+    max_n, stride = boxes_xyxy.shape[1], boxes_xyxy.shape[2]
+    if out is None:
+        shape = (B * max_n, 3, in_h, in_w) if layout == "nchw" else (B * max_n, in_h, in_w, 3)
+        out = torch.empty(shape, dtype=dtype, device=frames.device)
+    if meta is None:
+        meta = torch.empty((B * max_n, 10), dtype=torch.float64, device=frames.device)
+    m, s = (C.c_double * 3)(*mean), (C.c_double * 3)(*std)
+    check(L.tlk_pose_crop_warp_norm(frames.data_ptr(), B, H, W, boxes_xyxy.data_ptr(), stride, counts.data_ptr(), max_n, in_w, in_h,
+                                    m, s, LAYOUT[layout], _dtype_code(dtype), out.data_ptr(), meta.data_ptr(), current_stream_ptr()))
+    if layout != "nchw":
+        out = out.permute(0, 3, 1, 2)
+    return out, meta
+
+
+def simcc_decode(simcc_x, simcc_y, meta, in_w=192, in_h=256, split_ratio=2.0, out=None):
+    """simcc_x (n,K,Wx), simcc_y (n,K,Wy) f32 cuda + meta (n,10) -> dict kps_xyc (n,K,3) f64, scores (n,K) f32, conf (n,) f32."""
+    import torch
+    L = lib()
+    _bind_pose(L)
+    assert simcc_x.is_cuda and simcc_x.dtype == torch.float32 and simcc_x.is_contiguous() and simcc_y.is_contiguous()
+    n, K, Wx = simcc_x.shape
+    Wy = simcc_y.shape[2]
+    if out is None:
+        out = {"kps_xyc": torch.empty((n, K, 3), dtype=torch.float64, device=simcc_x.device),
+               "scores": torch.empty((n, K), dtype=torch.float32, device=simcc_x.device),
+               "conf": torch.empty((n,), dtype=torch.float32, device=simcc_x.device)}
+    check(L.tlk_simcc_decode(simcc_x.data_ptr(), simcc_y.data_ptr(), n, K, Wx, Wy, float(split_ratio), meta.data_ptr(), in_w, in_h,
+                             out["kps_xyc"].data_ptr(), out["scores"].data_ptr(), out["conf"].data_ptr(), current_stream_ptr()))
+    return out
+
+
 def yolox_decode_nms(pred, size, ratio, img_w, img_h, max_out=128, nms_thr=0.45, score_thr=0.7,
                      out=None, trk_in=None, det_id_base=0, category_id=1.0):
     """pred (B, A, 5+C) f32 cuda -> dict of ltwh (B,max_out,4), xyxy, scores, cls, counts (rtmlib order)."""
