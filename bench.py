@@ -35,6 +35,9 @@ WORKLOADS = {
     "config3": dict(detector="m", objects=100, frames_per_step=24, max_dets=104,
                     name="BASELINE configs[2]/[4] shape: YOLOX-m + part-based ReID (384x128, 6x256) + BPBReID-StrongSORT, "
                          "synthetic 1080p 100-obj stream"),
+    "config4": dict(detector="m", objects=100, frames_per_step=24, max_dets=104, pose="m",
+                    name="BASELINE configs[3] shape: YOLOX-m + RTMPose-m (256x192 SimCC) + part-based ReID + StrongSORT-family tracker "
+                         "with OKS motion cost (bpbreid_strong_sort, motion_criterium oks), synthetic 1080p 100-obj stream"),
     "config2": dict(detector="s", objects=50, frames_per_step=32, max_dets=128,
                     name="BASELINE configs[1]: YOLOX-s + OC-SORT (IoU+Kalman, no ReID), synthetic 1080p 50-obj stream"),
 }
@@ -90,12 +93,12 @@ def main():
     B = S * F
     total_steps = args.warmup + args.steps
     n_frames = total_steps * F
-    is3 = args.workload == "config3"
+    is3 = args.workload in ("config3", "config4")
 
     from tracklab_amd import gpu_pipeline as gp
     if is3:
         pipe = gp.DetReidTrackPipeline(detector, n_streams=S, frames_per_step=F, max_dets=wl["max_dets"], device=dev.index,
-                                       use_graph=not args.no_graph)
+                                       use_graph=not args.no_graph, pose=wl.get("pose"))
     else:
         pipe = gp.DetTrackPipeline(detector, n_streams=S, frames_per_step=F, max_dets=wl["max_dets"], device=dev.index,
                                    use_graph=not args.no_graph)
@@ -138,11 +141,13 @@ def main():
                 rows, cnt = pipe.rows_numpy(h_rows, h_cnt)
                 emb = pipe.last["emb"].cpu().numpy().reshape(S, F, pipe.maxd, pipe.K, pipe.D)
                 vis = pipe.last["vis"].cpu().numpy().reshape(S, F, pipe.maxd, pipe.K)
+                kps = pipe.last["kps"].cpu().numpy().reshape(S, F, pipe.maxd, 17, 3) if pipe.pose is not None else None
                 for f in range(F):
                     ltwh32 = detector_rows(oracle, heads_np[0][k * F + f], ratio)
                     n = len(ltwh32)
                     ids = (k * B + f) * pipe.maxd + np.arange(n)
-                    exp = ref.update(ids, ltwh32.astype(np.float64), emb[0, f, :n], vis[0, f, :n], np.ones(n)) if n else []
+                    exp = ref.update(ids, ltwh32.astype(np.float64), emb[0, f, :n], vis[0, f, :n], np.ones(n),
+                                     keypoints=None if kps is None else kps[0, f, :n]) if n else []
                     got = rows[0][f]
                     ok = len(got) == len(exp) and (len(exp) == 0 or (np.array_equal(got["det_id"], exp["det_id"]) and
                                                                       np.array_equal(got["track_id"], exp["track_id"])))
@@ -160,7 +165,8 @@ def main():
             h_orc = hota.finalize(hota.pack(hota.hota_sequence(*hota.sequence_from_rows(gt_fr, orc_fr))))["summary"]
             parity = {"frames": frames_checked, "track_ids_equal_oracle": bool(ids_ok), "tracks": tracks,
                       "HOTA_gpu": h_gpu["HOTA"], "HOTA_oracle": h_orc["HOTA"], "AssA_gpu": h_gpu["AssA"], "DetA_gpu": h_gpu["DetA"],
-                      "note": "oracle chain = C decode/NMS + C BPBReID-StrongSORT fed with the embeddings the GPU ReID net produced"}
+                      "note": "oracle chain = C decode/NMS + C BPBReID-StrongSORT fed with the embeddings the GPU ReID net produced"
+                              + (" and the keypoints the GPU pose stage produced (OKS motion cost)" if pipe.pose is not None else "")}
         else:
             trk = oracle.OCSort(**pipe.tracker_cfg["hyper"])
             got, exp = [], []
@@ -246,6 +252,10 @@ def main():
         from tracklab_amd.backbones.yolox import yolox
         cpu_det = yolox(detector, device="cpu", dtype=torch.float32, channels_last=False)
         cpu_reid = part_based_reid(6, 256, device="cpu", dtype=torch.float32, channels_last=False) if is3 else None
+        cpu_pose = None
+        if is3 and wl.get("pose"):
+            from tracklab_amd.backbones.rtmpose import rtmpose
+            cpu_pose = rtmpose(wl["pose"], device="cpu", dtype=torch.float32, channels_last=False)
         frame = render_frame(np.random.default_rng(5), gts[0][0]["gt_boxes"])
         trk = oracle.StrongSORT(6, 256, **pipe.tracker_cfg) if is3 else oracle.OCSort(**pipe.tracker_cfg["hyper"])
         tc0 = time.perf_counter()
@@ -260,7 +270,16 @@ def main():
                     ltrb = oracle.ltwh_to_crop_ltrb(ltwh.astype(np.float64), WIDTH, HEIGHT)
                     crops = oracle.crop_resize_norm(frame, ltrb, 384, 128)
                     emb, vis = cpu_reid(torch.from_numpy(crops))
-                    trk.update(np.arange(n) + f * 1000, ltwh.astype(np.float64), emb.numpy(), vis.numpy(), np.ones(n))
+                    kps = None
+                    if cpu_pose is not None:
+                        xyxy = np.column_stack([ltwh[:, 0], ltwh[:, 1], ltwh[:, 0] + ltwh[:, 2], ltwh[:, 1] + ltwh[:, 3]]).astype(np.float64)
+                        pre = [oracle.rtmpose_preprocess(frame, b) for b in xyxy]
+                        sx, sy = cpu_pose(torch.from_numpy(np.stack([p[0] for p in pre])))
+                        kps = np.zeros((n, 17, 3))
+                        for i, (_, c, sc) in enumerate(pre):
+                            kp, score = oracle.simcc_decode(sx[i].numpy(), sy[i].numpy(), c, sc)
+                            kps[i, :, :2], kps[i, :, 2] = kp, score
+                    trk.update(np.arange(n) + f * 1000, ltwh.astype(np.float64), emb.numpy(), vis.numpy(), np.ones(n), keypoints=kps)
                 else:
                     dets = np.zeros((n, 7))
                     dets[:, :2] = ltwh[:, :2]
@@ -272,6 +291,7 @@ def main():
                     break
         cpu_t = time.perf_counter() - tc0
         chain = ("oracle C letterbox + YOLOX-%s fp32 (torch CPU, batch 1) + oracle C decode/NMS" % detector) + \
+                ((" + oracle C affine pose crops + RTMPose-%s fp32 (torch CPU) + oracle C SimCC decode" % wl["pose"]) if is3 and wl.get("pose") else "") + \
                 (" + oracle C crop-resize-normalize + part-based ReID R50 fp32 (torch CPU, 100 crops/batch) + oracle C BPBReID-StrongSORT"
                  if is3 else " + oracle C OC-SORT")
         cpu = {"value": done / cpu_t, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",

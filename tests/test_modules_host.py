@@ -164,3 +164,17 @@ def test_strongsort_module_host_logic_with_oracle_backend(orc):
                                       np.stack([exp[:, 0], exp[:, 1], exp[:, 2] - exp[:, 0], exp[:, 3] - exp[:, 1]], axis=1))
         np.testing.assert_array_equal(out.track_bbox_conf.to_numpy(), exp[:, 6])
     assert seen > 300
+
+
+def test_rtmpose_module_contract_and_preprocess():
+    from tracklab_amd.wrappers import HipRTMPose
+    m = HipRTMPose("cuda:0", cfg=NS(arch="m", model_input_size=[192, 256], max_dets=16), tracking_dataset=None)
+    assert m.level == "image" and m.batch_size == 1 and m.input_columns == [] and m.output_columns == ["keypoints_xyc", "keypoints_conf"]
+    img = np.arange(4 * 6 * 3, dtype=np.uint8).reshape(4, 6, 3)
+    df = pd.DataFrame({"bbox_ltwh": [np.array([1.5, 2.0, 3.0, 4.0], np.float32), np.array([0, 0, 2, 2], np.float32)]}, index=[7, 9])
+    s = m.preprocess(img, df, pd.Series(dtype=float))
+    assert (s["image"][..., 0] == img[..., 2]).all() and s["count"] == 2           # RGB -> BGR like cv2.imread
+    np.testing.assert_array_equal(s["boxes"][:2], [[1.5, 2.0, 4.5, 6.0], [0, 0, 2, 2]])
+    assert not s["boxes"][2:].any() and s["boxes"].shape == (16, 4)
+    empty = pd.DataFrame()
+    assert m.process({}, empty, pd.DataFrame()) is empty

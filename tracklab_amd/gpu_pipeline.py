@@ -170,7 +170,10 @@ class DetReidTrackPipeline:
     def __init__(self, detector: str = "m", n_streams: int = 1, frames_per_step: int = 8, max_dets: int = 104,
                  height: int = 1080, width: int = 1920, size: int = 640, dtype=torch.float16, device: int = 0,
                  parts: int = 6, dim: int = 256, reid_hw=(384, 128), tracker_cfg: dict | None = None,
-                 nms_thr: float = 0.45, score_thr: float = 0.7, max_tracks: int = 512, use_graph: bool = True):
+                 nms_thr: float = 0.45, score_thr: float = 0.7, max_tracks: int = 512, use_graph: bool = True,
+                 pose: str | None = None):
+        """pose = "t"/"s"/"m"/"l": BASELINE.json configs[3] -- a top-down RTMPose stage (tlk_pose_crop_warp_norm -> network ->
+        tlk_simcc_decode) between detector and ReID; its keypoints drive the tracker's OKS motion cost (motion_criterium "oks")."""
         from .backbones.reid import part_based_reid
         self.S, self.F, self.maxd = n_streams, frames_per_step, max_dets
         self.H, self.W, self.size, self.dtype = height, width, size, dtype
@@ -183,6 +186,11 @@ class DetReidTrackPipeline:
             max_age=300, n_init=0, nn_budget=100, min_bbox_confidence=0.0, only_position_for_kf_gating=False,
             max_kalman_prediction_without_update=7, matching_strategy="strong_sort_matching", gating_thres_factor=1,
             w_kfgd=1, w_reid=1, w_st=1)
+        self.pose = None
+        if pose:
+            from .backbones.rtmpose import rtmpose
+            self.tracker_cfg = dict(self.tracker_cfg, motion_criterium="oks")
+            self.pose = rtmpose(pose, device=self.dev, dtype=dtype, channels_last=True)
         self.model = yolox(detector, 1, device=self.dev, dtype=dtype, channels_last=True)
         self.reid = part_based_reid(parts, dim, device=self.dev, dtype=dtype, channels_last=True)
         self.bank = _lib.BpbssBank(parts, dim, **self.tracker_cfg, wrapper_mode=True, n_streams=n_streams, device=device,
@@ -198,6 +206,14 @@ class DetReidTrackPipeline:
                     "cls": torch.zeros((B, max_dets), dtype=torch.int32, device=dev),
                     "counts": torch.zeros((B,), dtype=torch.int32, device=dev)}
         self.conf = torch.ones((B, max_dets), dtype=torch.float64, device=dev)        # RTMLibDetector: bbox_conf = 1.0
+        if self.pose is not None:
+            self.pose_hw = (256, 192)
+            self.pose_crops = torch.empty((B * max_dets, 256, 192, 3), dtype=dtype, device=dev)
+            self.pose_meta = torch.zeros((B * max_dets, 10), dtype=torch.float64, device=dev)
+            self.xyxy64 = torch.zeros((B, max_dets, 4), dtype=torch.float64, device=dev)
+            self.pose_out = {"kps_xyc": torch.zeros((B * max_dets, 17, 3), dtype=torch.float64, device=dev),
+                             "scores": torch.zeros((B * max_dets, 17), dtype=torch.float32, device=dev),
+                             "conf": torch.zeros((B * max_dets,), dtype=torch.float32, device=dev)}
         self.id_off = torch.arange(B * max_dets, dtype=torch.int64, device=dev).reshape(B, max_dets)
         self.nbuf = 2
         self.bufs = []
@@ -209,6 +225,7 @@ class DetReidTrackPipeline:
                 "emb": torch.zeros((B, max_dets, parts, dim), dtype=torch.float32, device=dev),
                 "vis": torch.zeros((B, max_dets, parts), dtype=torch.uint8, device=dev),
                 "counts": torch.zeros((B,), dtype=torch.int32, device=dev),
+                "kps": torch.zeros((B, max_dets, 17, 3), dtype=torch.float64, device=dev) if self.pose is not None else None,
                 "rows": torch.zeros((B, max_dets, row_bytes), dtype=torch.uint8, device=dev),
                 "ocnt": torch.zeros((B,), dtype=torch.int32, device=dev),
                 "h_rows": torch.zeros((B, max_dets, row_bytes), dtype=torch.uint8).pin_memory(),
@@ -274,6 +291,17 @@ class DetReidTrackPipeline:
         if self.record_kernel_events:
             e1.record()
             self.kernel_events.append((e0, e1))
+        if self.pose is not None:
+            # pose stage (rtmlib RTMPose(image, bboxes)): affine crops of every box -> network -> SimCC decode, all in HBM
+            self.xyxy64.copy_(self.det["xyxy"])
+            pcrops, _ = _lib.pose_crop_warp_norm(frames, self.xyxy64, self.det["counts"], 192, 256, "nhwc", self.dtype,
+                                                 out=self.pose_crops, meta=self.pose_meta)
+            if self.use_graph:
+                sx, sy = self._graphed(self.__dict__.setdefault("_pg", {}), 0, lambda: self.pose(pcrops))
+            else:
+                sx, sy = self.pose(pcrops)
+            _lib.simcc_decode(sx, sy, self.pose_meta, 192, 256, 2.0, out=self.pose_out)
+            buf["kps"].copy_(self.pose_out["kps_xyc"].view(self.B, maxd, 17, 3))
         if self.use_graph:
             emb, vis = self._graphed(self.__dict__.setdefault("_rg", {}), 0, lambda: self.reid(crops))
         else:
@@ -290,7 +318,8 @@ class DetReidTrackPipeline:
             self.trk_stream.wait_event(buf["ready"])
             self.bank.update_dev(buf["ids"].data_ptr(), buf["ltwh"].data_ptr(), buf["emb"].data_ptr(), buf["vis"].data_ptr(),
                                  self.conf.data_ptr(), buf["counts"].data_ptr(), F, buf["rows"].data_ptr(), maxd,
-                                 buf["ocnt"].data_ptr(), C.c_void_p(self.trk_stream.cuda_stream))
+                                 buf["ocnt"].data_ptr(), C.c_void_p(self.trk_stream.cuda_stream),
+                                 kps=buf["kps"].data_ptr() if self.pose is not None else None)
             if fetch:
                 buf["h_rows"].copy_(buf["rows"], non_blocking=True)
                 buf["h_ocnt"].copy_(buf["ocnt"], non_blocking=True)
@@ -307,4 +336,5 @@ class DetReidTrackPipeline:
     def close(self):
         self.det_graphs.clear()
         self.__dict__.pop("_rg", None)
+        self.__dict__.pop("_pg", None)
         self.bank.close()
