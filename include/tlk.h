@@ -55,6 +55,14 @@ int tlk_iou_matrix_f64(int variant, const double *b1_dev, int n, const double *b
 int tlk_lsa_f64(const double *cost_dev, int batch, int nr, int nc, int32_t *rows_dev, int32_t *cols_dev,
                 int32_t *n_pairs_dev, void *hip_stream);
 
+/* lap.lapjv(cost, extend_cost=True, cost_limit=L) as ByteTrack's linear_assignment uses it
+ * (plugins/track/byte_track/matching.py:37-48; third-party lap, not installed -> restated from its documented
+ * embedding: (nr+nc)^2 problem, padding entries L/2, lower-right block 0). x_dev (batch, nr): column of row i or -1;
+ * y_dev (batch, nc): row of column j or -1. The set of matched pairs is the unique optimum whenever no two
+ * real costs tie; a pair is only kept when it beats leaving both ends unmatched (cost < L). nr + nc <= 512. */
+int tlk_lsa_lapjv_limit_f64(const double *cost_dev, int batch, int nr, int nc, double cost_limit, int32_t *x_dev,
+                            int32_t *y_dev, void *hip_stream);
+
 /* ------------------------------------------------------------------------------------------
  * OC-SORT tracker bank: `n_streams` independent trackers whose whole state lives in HBM.
  * Replaces plugins/track/oc_sort/ocsort.py:185-334 (OCSort.__init__/update, KalmanBoxTracker)

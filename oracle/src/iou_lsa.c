@@ -142,3 +142,24 @@ int orc_lsa(const double *cost, int nr0, int nc0, int64_t *rows, int64_t *cols)
     free(u); free(v); free(spc); free(path); free(col4row); free(row4col); free(remaining); free(SR); free(SC);
     return ret;
 }
+
+/* lap.lapjv(cost, extend_cost=True, cost_limit=L) (byte_track/matching.py:37-48; third-party `lap`, restated from its documented
+ * embedding): square (nr+nc) problem with L/2 padding and a zero lower-right block. x (nr) / y (nc): partner or -1. */
+int orc_lapjv_limit(const double *cost, int nr, int nc, double cost_limit, int32_t *x, int32_t *y)
+{
+    for (int i = 0; i < nr; ++i) x[i] = -1;
+    for (int j = 0; j < nc; ++j) y[j] = -1;
+    if (nr == 0 || nc == 0) return 0;
+    const int n = nr + nc;
+    double *ext = malloc(sizeof(double) * (size_t)n * n);
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c)
+            ext[(size_t)r * n + c] = (r >= nr && c >= nc) ? 0.0 : ((r < nr && c < nc) ? cost[(size_t)r * nc + c] : cost_limit / 2.);
+    int64_t *rows = malloc(sizeof(int64_t) * n), *cols = malloc(sizeof(int64_t) * n);
+    const int np = orc_lsa(ext, n, n, rows, cols);
+    int matched = 0;
+    for (int k = 0; k < np; ++k)
+        if (rows[k] < nr && cols[k] < nc) { x[rows[k]] = (int32_t)cols[k]; y[cols[k]] = (int32_t)rows[k]; ++matched; }
+    free(ext); free(rows); free(cols);
+    return np < 0 ? np : matched;
+}

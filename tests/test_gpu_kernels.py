@@ -1,6 +1,7 @@
 """-m gpu: stateless kernels through the C ABI vs the oracle / scipy / golden vectors."""
 import json
 import os
+from ctypes import c_double as C_double, c_int as C_int, c_void_p as C_void_p
 
 import numpy as np
 import pytest
@@ -186,3 +187,24 @@ def test_stateless_entry_points_reject_bad_arguments():
     with pytest.raises(TlkError):
         check(L.tlk_oks_cost_f64(None, -1, None, 2, None, None))
     check(L.tlk_iou_ltwh_cost_f64(None, 0, None, 5, None, None))        # empty problem is a no-op
+
+
+def test_lapjv_cost_limit_matches_oracle(orc):
+    import torch
+    from tracklab_amd._lib import check, lib
+    L = lib()
+    L.tlk_lsa_lapjv_limit_f64.argtypes = [C_void_p, C_int, C_int, C_int, C_double, C_void_p, C_void_p, C_void_p]
+    rng = np.random.default_rng(9)
+    for nr, nc, limit, batch in [(30, 45, 0.3, 5), (100, 100, 0.8, 3), (7, 1, 0.5, 2), (1, 9, 2.0, 4), (60, 20, 0.05, 2)]:
+        cost = rng.uniform(0, 1, (batch, nr, nc))
+        d = torch.from_numpy(cost).cuda()
+        x = torch.empty((batch, nr), dtype=torch.int32, device="cuda"); y = torch.empty((batch, nc), dtype=torch.int32, device="cuda")
+        check(L.tlk_lsa_lapjv_limit_f64(d.data_ptr(), batch, nr, nc, limit, x.data_ptr(), y.data_ptr(), None))
+        torch.cuda.synchronize()
+        for b in range(batch):
+            ex, ey = orc.lapjv_limit(cost[b], limit)
+            np.testing.assert_array_equal(x[b].cpu().numpy(), ex); np.testing.assert_array_equal(y[b].cpu().numpy(), ey)
+    y = torch.zeros((2, 4), dtype=torch.int32, device="cuda")
+    check(L.tlk_lsa_lapjv_limit_f64(None, 2, 0, 4, 0.5, None, y.data_ptr(), None))         # no rows: every column unmatched
+    torch.cuda.synchronize()
+    assert (y.cpu().numpy() == -1).all()

@@ -122,3 +122,67 @@ extern "C" int tlk_lsa_f64(const double *cost, int batch, int nr, int nc, int32_
     TLK_HIP(hipGetLastError());
     return TLK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// lap.lapjv(cost, extend_cost=True, cost_limit=L) as ByteTrack calls it (byte_track/matching.py:37-48): the (nr x nc) cost is
+// embedded in an (nr+nc)^2 problem -- every other entry cost_limit/2, the lower-right block 0 -- and solved as a square LSA; a
+// row stays unmatched (x = -1) when it is assigned to a padding column, i.e. when no pair cheaper than cost_limit exists for it.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) lapjv_extend_kernel(const double *__restrict__ cost, int batch, int nr, int nc, double half_limit,
+                                                             double *__restrict__ ext)
+{
+    const int n = nr + nc;
+    const long long tot = (long long)batch * n * n;
+    for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < tot; e += (long long)gridDim.x * BLOCK) {
+        const int b = (int)(e / ((long long)n * n));
+        const int r = (int)((e - (long long)b * n * n) / n), c = (int)(e - (long long)b * n * n - (long long)r * n);
+        double v = half_limit;
+        if (r >= nr && c >= nc) v = 0.0;
+        else if (r < nr && c < nc) v = cost[((size_t)b * nr + r) * nc + c];
+        ext[e] = v;
+    }
+}
+__global__ void __launch_bounds__(BLOCK) lapjv_unpack_kernel(const int *__restrict__ rows, const int *__restrict__ cols, const int *__restrict__ np,
+                                                             int batch, int nr, int nc, int *__restrict__ x, int *__restrict__ y)
+{
+    const int b = blockIdx.x, n = nr + nc;
+    for (int i = threadIdx.x; i < nr; i += BLOCK) x[(size_t)b * nr + i] = -1;
+    for (int j = threadIdx.x; j < nc; j += BLOCK) y[(size_t)b * nc + j] = -1;
+    __syncthreads();
+    if (np[b] < 0) return;
+    for (int k = threadIdx.x; k < n; k += BLOCK) {
+        const int r = rows[(size_t)b * n + k], c = cols[(size_t)b * n + k];
+        if (r < nr && c < nc) { x[(size_t)b * nr + r] = c; y[(size_t)b * nc + c] = r; }
+    }
+}
+
+extern "C" int tlk_lsa_lapjv_limit_f64(const double *cost_dev, int batch, int nr, int nc, double cost_limit, int32_t *x_dev, int32_t *y_dev,
+                                       void *hip_stream)
+{
+    if (batch < 0 || nr < 0 || nc < 0) return fail(TLK_EINVAL, "tlk_lsa_lapjv_limit_f64: negative size");
+    if (!(cost_limit < INFINITY) || cost_limit != cost_limit) return fail(TLK_EINVAL, "tlk_lsa_lapjv_limit_f64: cost_limit must be finite");
+    if (batch == 0 || (nr == 0 && nc == 0)) return TLK_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (nr == 0 || nc == 0) {                      // matching.py:38-39: nothing to match
+        if (nr && x_dev) TLK_HIP(hipMemsetAsync(x_dev, 0xff, sizeof(int32_t) * (size_t)batch * nr, st));
+        if (nc && y_dev) TLK_HIP(hipMemsetAsync(y_dev, 0xff, sizeof(int32_t) * (size_t)batch * nc, st));
+        return TLK_OK;
+    }
+    if (!cost_dev || !x_dev || !y_dev) return fail(TLK_EINVAL, "tlk_lsa_lapjv_limit_f64: null pointer");
+    const int n = nr + nc;
+    double *ext = nullptr; int *rows = nullptr, *cols = nullptr, *np = nullptr;
+    TLK_HIP(hipMallocAsync((void **)&ext, sizeof(double) * (size_t)batch * n * n, st));
+    TLK_HIP(hipMallocAsync((void **)&rows, sizeof(int) * (size_t)batch * n * 2 + sizeof(int) * batch, st));
+    cols = rows + (size_t)batch * n; np = cols + (size_t)batch * n;
+    const long long tot = (long long)batch * n * n;
+    hipLaunchKernelGGL(lapjv_extend_kernel, dim3((unsigned)((tot + BLOCK - 1) / BLOCK < 65535 ? (tot + BLOCK - 1) / BLOCK : 65535)), dim3(BLOCK), 0, st,
+                       cost_dev, batch, nr, nc, cost_limit / 2., ext);
+    int rc = tlk_lsa_f64(ext, batch, n, n, rows, cols, np, hip_stream);
+    if (rc == TLK_OK) {
+        hipLaunchKernelGGL(lapjv_unpack_kernel, dim3(batch), dim3(BLOCK), 0, st, (const int *)rows, (const int *)cols, (const int *)np, batch, nr, nc,
+                           x_dev, y_dev);
+        if (hipGetLastError() != hipSuccess) rc = fail(TLK_EHIP, "tlk_lsa_lapjv_limit_f64: launch failed");
+    }
+    hipFreeAsync(ext, st); hipFreeAsync(rows, st);
+    return rc;
+}
