@@ -754,11 +754,103 @@ def gen_pil_preprocess(out_dir):
     print("pil preprocess ok", len(boxes))
 
 
+BT_RUNS = [  # name, hyperparams, seed, objects, frames, stream kwargs
+    ("yaml_s0_n100", dict(track_thresh=0.6, track_buffer=30, match_thresh=0.8, frame_rate=30), 0, 100, 80, dict(low_conf_frac=0.2)),
+    ("defaults_s1_n50", dict(track_thresh=0.45, match_thresh=0.8, track_buffer=25, frame_rate=30), 1, 50, 150, dict(miss_prob=0.08, churn_period=40, low_conf_frac=0.3)),
+    ("short_buffer_s2_n20", dict(track_thresh=0.5, match_thresh=0.7, track_buffer=5, frame_rate=30), 2, 20, 200, dict(miss_prob=0.15, churn_period=25, low_conf_frac=0.3)),
+    ("fps15_s3_n30", dict(track_thresh=0.6, match_thresh=0.9, track_buffer=30, frame_rate=15), 3, 30, 150, dict(miss_prob=0.1, churn_period=30, low_conf_frac=0.4)),
+]
+
+
+def _import_byte_track():
+    """plugins/track/byte_track with `lap` (not installed) shimmed: lapjv(cost, extend_cost=True, cost_limit=L) = optimum of the
+    documented (nr+nc)^2 embedding (padding L/2, zero lower-right block), solved with scipy -- the matched pairs are the unique
+    optimum whenever no two real costs tie, whatever solver finds it -- and ultralytics' box conversions restated."""
+    import types
+    from scipy.optimize import linear_sum_assignment
+
+    def lapjv(cost, extend_cost=False, cost_limit=np.inf, return_cost=True):
+        cost = np.ascontiguousarray(cost, dtype=np.double)
+        nr, nc = cost.shape
+        n = nr + nc
+        ext = np.full((n, n), cost_limit / 2.0)
+        ext[nr:, nc:] = 0
+        ext[:nr, :nc] = cost
+        r, c = linear_sum_assignment(ext)
+        x = np.full(nr, -1, dtype=int); y = np.full(nc, -1, dtype=int)
+        for i, j in zip(r, c):
+            if i < nr and j < nc:
+                x[i] = j; y[j] = i
+        return float(cost[x >= 0, x[x >= 0]].sum()), x, y
+
+    def xyxy2xywh(x):
+        y = np.empty_like(x)
+        y[..., 0] = (x[..., 0] + x[..., 2]) / 2; y[..., 1] = (x[..., 1] + x[..., 3]) / 2
+        y[..., 2] = x[..., 2] - x[..., 0]; y[..., 3] = x[..., 3] - x[..., 1]
+        return y
+
+    def xywh2xyxy(x):
+        y = np.empty_like(x)
+        xy, wh = x[..., :2], x[..., 2:] / 2
+        y[..., :2] = xy - wh; y[..., 2:] = xy + wh
+        return y
+    m = types.ModuleType("lap"); m.lapjv = lapjv; sys.modules["lap"] = m
+    for name in ("ultralytics", "ultralytics.utils"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    ops = sys.modules.get("ultralytics.utils.ops") or types.ModuleType("ultralytics.utils.ops")
+    ops.xyxy2xywh, ops.xywh2xyxy = xyxy2xywh, xywh2xyxy
+    sys.modules["ultralytics.utils.ops"] = ops
+    import byte_track.byte_tracker as bt
+    from byte_track.basetrack import BaseTrack
+    return bt, BaseTrack
+
+
+def gen_bytetrack(out_dir):
+    """ByteTrack (plugins/track/byte_track): BYTETracker.update run as is behind the wrapper's confidence filter
+    (wrappers/track/byte_track_api.py:57-60)."""
+    bt, BaseTrack = _import_byte_track()
+    for name, hp, seed, nobj, nframes, skw in BT_RUNS:
+        BaseTrack._count = 0                               # class-level id counter: our handles restart at 1 per stream
+        model = bt.BYTETracker(**hp)
+        stream = SyntheticStream(seed, nobj, nframes, **skw)
+        in_off, out_off, dets_all, rows = [0], [0], [], []
+        blobs = {}
+        for fr in stream:
+            dets = fr["dets"]
+            if fr["frame"] % 43 == 17:
+                dets = dets[:0]
+            dets_all.append(dets)
+            in_off.append(in_off[-1] + len(dets))
+            n_out = 0
+            if len(dets) > 0:
+                inputs = torch.from_numpy(dets.copy())
+                inputs = inputs[inputs[:, 4] > 0.4]
+                out = model.update(inputs, None)
+                for r in out:
+                    rows.append([float(v) for v in r])
+                    n_out += 1
+                f = fr["frame"]
+                if f in (0, 1, 2, 10, 40, 79, 120, 199):
+                    for lname, lst in (("trk", model.tracked_stracks), ("lost", model.lost_stracks)):
+                        blobs[f"f{f}_{lname}_ids"] = np.array([t.track_id for t in lst], dtype=np.int64)
+                        blobs[f"f{f}_{lname}_mean"] = np.array([np.asarray(t.mean, dtype=np.float64) for t in lst]).reshape(-1, 8)
+                        blobs[f"f{f}_{lname}_cov"] = np.array([np.asarray(t.covariance, dtype=np.float64) for t in lst]).reshape(-1, 8, 8)
+                        blobs[f"f{f}_{lname}_state"] = np.array([[t.state, int(t.is_activated), t.frame_id, t.start_frame, t.tracklet_len]
+                                                               for t in lst], dtype=np.int64).reshape(-1, 5)
+            out_off.append(out_off[-1] + n_out)
+        np.savez_compressed(
+            os.path.join(out_dir, f"bytetrack_{name}.npz"), dets=np.concatenate(dets_all), det_offsets=np.array(in_off, dtype=np.int64),
+            out_offsets=np.array(out_off, dtype=np.int64), rows=np.array(rows, dtype=np.float64).reshape(-1, 8), config=json.dumps(hp),
+            seed=seed, n_objects=nobj, n_frames=nframes, stream_kwargs=json.dumps(skw), min_confidence=0.4, **blobs)
+        print(f"bytetrack_{name}: rows_out={out_off[-1]} next_id={BaseTrack._count + 1} lost={len(model.lost_stracks)} removed={len(model.removed_stracks)}")
+
+
 def main():
     out_dir = HERE
     only = set(sys.argv[1:])
     gens = {"ocsort": gen_ocsort, "iou": gen_iou_family, "kf7": gen_kf7, "lsa": gen_lsa,
-            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess}
+            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack}
     for k, fn in gens.items():
         if not only or k in only:
             fn(out_dir)
