@@ -229,6 +229,45 @@ int tlk_bpbss_get_tracks(tlk_bpbss *h, int stream, int64_t *ids, double *mean, d
                          uint8_t *fvis, int cap, int *n_tracks);
 
 /* ------------------------------------------------------------------------------------------
+ * ByteTrack tracker bank (n_streams independent trackers, state in HBM). Replaces BYTETracker.update
+ * (plugins/track/byte_track/byte_tracker.py:167-320) with STrack (:13-152), joint/sub/remove_duplicate_stracks
+ * (:323-361), matching.{iou_distance, ious, bbox_ious, fuse_score, linear_assignment} (byte_track/matching.py:37-90,
+ * :171-217) and KalmanFilter (byte_track/kalman_filter.py:55-270). Hyper-parameter names =
+ * configs/modules/track/byte_track.yaml `hyperparams` (+ the wrapper's min_confidence, byte_track_api.py:58).
+ * The id counter (class-level BaseTrack._count in the reference) is per stream and restarts at 1 on reset.
+ * max_tracks (live = tracked + lost) + max_dets <= 512.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tlk_bytetrack_params {
+    double track_thresh, match_thresh, frame_rate;
+    double min_confidence;              /* -inf disables */
+    int32_t track_buffer;
+    int32_t wrapper_mode;               /* 1: a frame without detections leaves the tracker untouched (byte_track_api.py:55-56) */
+    int32_t max_tracks, max_dets;       /* capacities per stream (0 = 256 / 128) */
+} tlk_bytetrack_params;
+
+typedef struct tlk_bytetrack_row {      /* one row of BYTETracker.update's output (byte_tracker.py:296-308) */
+    int64_t det_id;                     /* tracklab_id of the detection last matched to the track */
+    int64_t track_id;
+    double ltrb[4];
+    double score, cls;
+} tlk_bytetrack_row;
+
+typedef struct tlk_bytetrack tlk_bytetrack;
+int tlk_bytetrack_create(const tlk_bytetrack_params *p, int n_streams, int device, tlk_bytetrack **out);
+int tlk_bytetrack_destroy(tlk_bytetrack *h);
+int tlk_bytetrack_reset(tlk_bytetrack *h, int stream);       /* stream < 0: all */
+/* host buffers: dets (n,7) f64 [x1,y1,x2,y2,conf,cls,tracklab_id] -> rows (cap) */
+int tlk_bytetrack_update(tlk_bytetrack *h, int stream, const double *dets, int n, tlk_bytetrack_row *rows, int cap, int *n_out);
+/* device buffers, all streams, n_frames consecutive frames per stream, asynchronous on hip_stream:
+ * dets_dev (S, n_frames, max_dets, 7), counts_dev (S, n_frames) -> rows_dev (S, n_frames, out_cap), out_counts_dev (S, n_frames) */
+int tlk_bytetrack_update_dev(tlk_bytetrack *h, const double *dets_dev, const int32_t *counts_dev, int n_frames,
+                             tlk_bytetrack_row *rows_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream);
+/* debug/test: which = 0 tracked_stracks, 1 lost_stracks, in list order: ids, mean (.,8), cov (.,8,8), state5 (.,5)
+ * [state (1 tracked, 2 lost, 3 removed), is_activated, frame_id, start_frame, tracklet_len]; any may be NULL */
+int tlk_bytetrack_get_tracks(tlk_bytetrack *h, int stream, int which, int64_t *ids, double *mean, double *cov, int64_t *state5,
+                             int cap, int *n_tracks);
+
+/* ------------------------------------------------------------------------------------------
  * Plain StrongSORT tracker bank (n_streams independent trackers, state + feature galleries in HBM).
  * Replaces strong_sort.StrongSORT.update (plugins/track/strong_sort/strong_sort.py:41-84) from the point where the
  * ReID features exist, i.e. Tracker.predict / Tracker.update (sort/tracker.py:53-114, _match :152-188),

@@ -520,6 +520,80 @@ class SsortBank:
         return ids[:k], mean[:k], cov[:k], feat[:k], st[:k], gl[:k]
 
 
+# ------------------------------------------------------------------------------------------------
+# ByteTrack bank
+# ------------------------------------------------------------------------------------------------
+class ByteTrackParams(C.Structure):
+    _fields_ = [("track_thresh", C.c_double), ("match_thresh", C.c_double), ("frame_rate", C.c_double), ("min_confidence", C.c_double),
+                ("track_buffer", C.c_int32), ("wrapper_mode", C.c_int32), ("max_tracks", C.c_int32), ("max_dets", C.c_int32)]
+
+
+BYTETRACK_ROW = np.dtype([("det_id", "<i8"), ("track_id", "<i8"), ("ltrb", "<f8", (4,)), ("score", "<f8"), ("cls", "<f8")], align=True)
+
+
+def _bind_bytetrack(L):
+    if getattr(L, "_bt_bound", False):
+        return
+    vp, ci = C.c_void_p, C.c_int
+    L.tlk_bytetrack_create.argtypes = [C.POINTER(ByteTrackParams), ci, ci, C.POINTER(vp)]
+    L.tlk_bytetrack_destroy.argtypes = [vp]
+    L.tlk_bytetrack_reset.argtypes = [vp, ci]
+    L.tlk_bytetrack_update.argtypes = [vp, ci, vp, ci, vp, ci, C.POINTER(ci)]
+    L.tlk_bytetrack_update_dev.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp]
+    L.tlk_bytetrack_get_tracks.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, C.POINTER(ci)]
+    L._bt_bound = True
+
+
+class ByteTrackBank:
+    """``n_streams`` device-resident ByteTrack trackers (``tlk_bytetrack_*``); hyper-parameter names follow
+    ``BYTETracker.__init__`` (plugins/track/byte_track/byte_tracker.py:155)."""
+
+    def __init__(self, track_thresh=0.45, match_thresh=0.8, track_buffer=25, frame_rate=30, *, min_confidence=-np.inf,
+                 wrapper_mode=False, n_streams=1, device=0, max_tracks=256, max_dets=128):
+        L = lib()
+        _bind_bytetrack(L)
+        self.params = ByteTrackParams(track_thresh, match_thresh, float(frame_rate), float(min_confidence), int(track_buffer),
+                                      int(wrapper_mode), max_tracks, max_dets)
+        self.n_streams, self.max_tracks, self.max_dets = n_streams, max_tracks, max_dets
+        h = C.c_void_p()
+        check(L.tlk_bytetrack_create(C.byref(self.params), n_streams, device, C.byref(h)))
+        self._h = h
+        self._rows = np.zeros(max_tracks, dtype=BYTETRACK_ROW)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tlk_bytetrack_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, stream=-1):
+        check(lib().tlk_bytetrack_reset(self._h, stream))
+
+    def update(self, dets, stream=0):
+        dets = _f64(dets).reshape(-1, 7)
+        n = C.c_int(0)
+        check(lib().tlk_bytetrack_update(self._h, stream, dets.ctypes.data, len(dets), self._rows.ctypes.data, len(self._rows), C.byref(n)))
+        return self._rows[:n.value].copy()
+
+    def update_dev(self, dets, counts, n_frames, rows, out_cap, out_counts, stream_ptr=None):
+        check(lib().tlk_bytetrack_update_dev(self._h, dets, counts, n_frames, rows, out_cap, out_counts, stream_ptr))
+
+    def tracks(self, which=0, stream=0):
+        cap = self.max_tracks
+        ids, st = np.empty(cap, np.int64), np.empty((cap, 5), np.int64)
+        mean, cov = np.empty((cap, 8)), np.empty((cap, 8, 8))
+        n = C.c_int(0)
+        check(lib().tlk_bytetrack_get_tracks(self._h, stream, which, ids.ctypes.data, mean.ctypes.data, cov.ctypes.data, st.ctypes.data, cap,
+                                             C.byref(n)))
+        k = n.value
+        return ids[:k], mean[:k], cov[:k], st[:k]
+
+
 def partdist(q, qvis, g, gvis):
     """q (T,K,D) f32, qvis (T,K) u8, g (N,K,D) f32, gvis (N,K) u8 cuda tensors -> (T,N) f64 cuda tensor."""
     import torch
