@@ -178,3 +178,45 @@ def test_rtmpose_module_contract_and_preprocess():
     assert not s["boxes"][2:].any() and s["boxes"].shape == (16, 4)
     empty = pd.DataFrame()
     assert m.process({}, empty, pd.DataFrame()) is empty
+
+
+def test_bytetrack_module_host_logic_with_oracle_backend(orc):
+    from tracklab_amd._lib import BYTETRACK_ROW
+    from tracklab_amd.wrappers import HipByteTrack
+    hyper = dict(track_thresh=0.6, track_buffer=30, match_thresh=0.8, frame_rate=30)
+
+    class Backend:                                   # same surface as tracklab_amd._lib.ByteTrackBank
+        def __init__(self):
+            self.t = orc.ByteTrack(**hyper)
+
+        def update(self, dets, stream):
+            r = self.t.update(dets[dets[:, 4] > 0.4])
+            out = np.zeros(len(r), dtype=BYTETRACK_ROW)
+            out["ltrb"], out["track_id"], out["cls"], out["score"], out["det_id"] = r[:, :4], r[:, 4], r[:, 5], r[:, 6], r[:, 7]
+            return out
+
+        def reset(self, stream):
+            self.t = orc.ByteTrack(**hyper)
+
+    m = HipByteTrack(NS(min_confidence=0.4, hyperparams=hyper), "cuda:0", tracking_dataset=None)
+    assert m.level == "image" and m.batch_size == 1 and m.input_columns == ["bbox_ltwh", "bbox_conf", "category_id"]
+    m._make_backend = lambda: Backend()
+    m.reset()
+    ref = orc.ByteTrack(**hyper)
+    n_rows = 0
+    for fr in SyntheticStream(7, 20, 40, miss_prob=0.1, low_conf_frac=0.3):
+        df = _frame_df(fr, np.float64, id0=300)
+        out = m.process(default_collate([m.preprocess(None, df, pd.Series({"frame": fr["frame"]}))]), df, None)
+        d = fr["dets"].copy()
+        d[:, 5] = 1.0; d[:, 6] += 300
+        exp = ref.update(d[d[:, 4] > 0.4])
+        if len(exp) == 0:
+            assert len(out) == 0
+            continue
+        n_rows += len(exp)
+        np.testing.assert_array_equal(out.index.to_numpy(), exp[:, 7].astype(int))
+        np.testing.assert_array_equal(out.track_id.to_numpy(), exp[:, 4])
+        np.testing.assert_array_equal(out.track_bbox_conf.to_numpy(), exp[:, 6])
+        np.testing.assert_array_equal(np.stack(out.track_bbox_ltwh.to_list()),
+                                      np.stack([exp[:, 0], exp[:, 1], exp[:, 2] - exp[:, 0], exp[:, 3] - exp[:, 1]], axis=1))
+    assert n_rows > 300

@@ -141,6 +141,53 @@ class HipBPBReIDStrongSORT(ImageLevelModule):
         return out
 
 
+class HipByteTrack(ImageLevelModule):
+    """ByteTrack (tracklab/wrappers/track/byte_track_api.py:14-84) with the tracker step on the GPU (tlk_bytetrack_update)."""
+    input_columns = ["bbox_ltwh", "bbox_conf", "category_id"]
+    output_columns = ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
+
+    def __init__(self, cfg, device, **kwargs):
+        super().__init__(batch_size=1)
+        self.cfg = cfg
+        self.device = device
+        self._bank = None
+
+    def _make_backend(self):
+        from .._lib import ByteTrackBank
+        hyper = dict(cfg_get(self.cfg, "hyperparams"))
+        return ByteTrackBank(**hyper, min_confidence=float(cfg_get(self.cfg, "min_confidence", 0.0)), wrapper_mode=True,
+                             device=_device_index(self.device), max_tracks=int(cfg_get(self.cfg, "max_tracks", 256)),
+                             max_dets=int(cfg_get(self.cfg, "max_dets", 128)))
+
+    def reset(self):
+        """New video (byte_track_api.py:29-31 rebuilds the tracker). The reference's id counter is class-level and keeps
+        counting across videos; here ids restart at 1 per video like every other tracker."""
+        if self._bank is None:
+            self._bank = self._make_backend()
+        else:
+            self._bank.reset(-1)
+
+    preprocess = HipOCSORT.preprocess          # same (N, 7) [*ltrb, conf, cls, tracklab_id] rows (byte_track_api.py:33-50)
+
+    def process(self, batch, detections: pd.DataFrame, metadatas: pd.DataFrame):
+        if len(detections) == 0:
+            return []
+        if self._bank is None:
+            self.reset()
+        inputs = to_numpy(batch["input"])
+        inputs = inputs[0] if inputs.ndim == 3 else inputs
+        rows = self._bank.update(np.ascontiguousarray(inputs, dtype=np.float64).reshape(-1, 7), 0)
+        if not len(rows):
+            return []
+        idxs = rows["det_id"].astype(int)
+        assert set(idxs).issubset(detections.index), \
+            "Mismatch of indexes during the tracking. The results should match the detections."
+        ltrb = rows["ltrb"]
+        ltwh = np.stack([ltrb[:, 0], ltrb[:, 1], ltrb[:, 2] - ltrb[:, 0], ltrb[:, 3] - ltrb[:, 1]], axis=1)
+        return pd.DataFrame({"track_bbox_ltwh": list(ltwh), "track_bbox_conf": list(rows["score"]),
+                             "track_id": list(rows["track_id"].astype(float))}, index=pd.Index(idxs, name="idxs"))
+
+
 class HipStrongSORT(ImageLevelModule):
     """Plain StrongSORT (tracklab/wrappers/track/strong_sort_api.py:17-105): the tracker owns its ReID network. Crops are cut
     and resized on the GPU with the reference's own arithmetic (int-truncated box, Pillow bilinear, ImageNet normalisation:
