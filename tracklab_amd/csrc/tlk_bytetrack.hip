@@ -2,8 +2,8 @@
 //
 // bytetrack_kernel: one 256-thread workgroup per stream walks BYTETracker.update (byte_tracker.py:167-320): split detections by
 // score, predict the pool (tracked + lost), first association (IoU fused with the score) / second association (low scores) /
-// unconfirmed tracks -- each a lap.lapjv(extend_cost=True, cost_limit) problem solved by the scipy-identical wavefront LSA on
-// the (rows + cols)^2 embedding kept in HBM/L2 --, KF updates, new tracks, time-outs, the tracked / lost list bookkeeping
+// unconfirmed tracks -- each a lap.lapjv(extend_cost=True, cost_limit) problem solved by the scipy-identical wavefront LSA in
+// its reduced rows x cols form held in LDS (see lapjv_assign) --, KF updates, new tracks, time-outs, the tracked / lost list bookkeeping
 // (including the frame a timed-out track lingers in the lost list, :296-298) and duplicate removal, output rows.
 // Arithmetic follows the reference's dtype trail: boxes and IoU in float32 (+1 pixel convention, matching.py:181-217), a
 // track's mean is float32 until its first predict/update, everything else float64 (-ffp-contract=off).
@@ -23,8 +23,8 @@ struct ByDev {
     double *fd;              // YD_COUNT x S x MAXT
     int *fi;                 // YI_COUNT x S x MAXT
     int *hdr, *tracked, *lost, *freestk;      // lists hold slots, in list order
-    double *ebuf;            // S x NX x NX   embedded cost matrix of the current lapjv problem
-    int S, MAXT, MAXD, NX;
+    double *ebuf;            // S x NX x NX   spill area of the assignment problem when it does not fit the LDS cost area
+    int S, MAXT, MAXD, NX, cost_lds_entries;
 };
 struct ByP { double track_thresh, match_thresh, det_thresh, min_conf; int max_time_lost, wrapper_mode; };
 struct ByIn { const double *dets; const int *counts; size_t stream_stride_dets, count_stride; };
@@ -39,6 +39,7 @@ struct ByLds {
     LsaWork W;                                                // NX
     int *mi_r, *mi_c;                                         // NX
     int *scan, *sc;
+    double *cost;                                             // rest of the LDS allocation: the current assignment problem
 };
 
 __host__ __device__ inline size_t bylds_bytes(int MAXT, int MAXD, int NX)
@@ -65,7 +66,8 @@ __device__ inline void bycarve(unsigned char *smem, int MAXT, int MAXD, int NX, 
     L.mi_r = ip; ip += NX; L.mi_c = ip; ip += NX;
     L.scan = ip; ip += NWAVES; L.sc = ip; ip += 32;
     unsigned char *bp = (unsigned char *)ip;
-    L.W.SR = bp; bp += NX; L.W.SC = bp;
+    L.W.SR = bp; bp += NX; L.W.SC = bp; bp += NX;
+    L.cost = (double *)(((uintptr_t)bp + 15) & ~(uintptr_t)15);
 }
 
 // multi_predict (kalman_filter.py:155-193): left = F cov first, then left F^T; noise from a float32 mean array stays float32
@@ -128,9 +130,14 @@ __device__ __forceinline__ float bbox_iou32(const float *b, const float *q)     
 
 struct AsgOut { int nm, n_ur, n_uc; };
 // linear_assignment (matching.py:37-48): lap.lapjv(extend_cost=True, cost_limit=thresh) on cost(i, j), i < nr, j < nc.
-// Fills L.m_r/m_c (matches, ascending rows), L.u_r, L.u_c (ascending). All 256 threads call.
+// lap embeds the problem in an (nr+nc)^2 one with thresh/2 padding; its objective is
+//   sum over matched pairs of c_ij  +  (unmatched rows + unmatched columns) * thresh / 2  =  const + sum over matched (c_ij - thresh),
+// i.e. a rectangular assignment on min(c_ij - thresh, 0) where a row sitting on a 0 entry is "unmatched". That problem is nr x nc
+// (4x fewer entries, and it fits the LDS cost area) and has the same optimal pair set whenever no two real costs tie
+// (tlk_lsa_lapjv_limit_f64 keeps the literal embedding; tests compare the two). Fills L.m_r/m_c (matches, ascending rows),
+// L.u_r, L.u_c (ascending). All 256 threads call.
 template <class CostFn>
-__device__ AsgOut lapjv_assign(int nr, int nc, double thresh, CostFn cost, double *ebuf, ByLds &L)
+__device__ AsgOut lapjv_assign(int nr, int nc, double thresh, CostFn cost, double *ebuf, double *lds_cost, int lds_entries, ByLds &L)
 {
     AsgOut o{0, 0, 0};
     const int tid = threadIdx.x;
@@ -141,25 +148,25 @@ __device__ AsgOut lapjv_assign(int nr, int nc, double thresh, CostFn cost, doubl
         __syncthreads();
         return o;
     }
-    const int n = nr + nc;
-    const double half = thresh / 2.;
-    for (int e = tid; e < n * n; e += BLOCK) {
-        const int r = e / n, c = e - r * n;
-        ebuf[e] = (r < nr && c < nc) ? cost(r, c) : ((r >= nr && c >= nc) ? 0.0 : half);
+    double *cm = (nr * nc <= lds_entries) ? lds_cost : ebuf;
+    for (int e = tid; e < nr * nc; e += BLOCK) {
+        const int r = e / nc, c = e - r * nc;
+        const double v = cost(r, c) - thresh;
+        cm[e] = v < 0.0 ? v : 0.0;
     }
     for (int i = tid; i < nr; i += BLOCK) L.x[i] = -1;
     for (int j = tid; j < nc; j += BLOCK) L.y[j] = -1;
     __threadfence_block();
     __syncthreads();
     if (tid < WAVE) {
-        const int r = wave_lsa(ebuf, n, n, (size_t)n, (size_t)1, L.W, L.mi_r, L.mi_c);
+        const int r = wave_lsa(cm, nr, nc, (size_t)nc, (size_t)1, L.W, L.mi_r, L.mi_c);
         if (tid == 0) L.sc[0] = r < 0 ? 0 : r;
     }
     __syncthreads();
     const int np = L.sc[0];
     for (int k = tid; k < np; k += BLOCK) {
         const int r = L.mi_r[k], c = L.mi_c[k];
-        if (r < nr && c < nc) { L.x[r] = c; L.y[c] = r; }
+        if (cm[(size_t)r * nc + c] < 0.0) { L.x[r] = c; L.y[c] = r; }
     }
     __syncthreads();
     o.nm = block_compact(nr, [&](int i) { return L.x[i] >= 0; }, [&](int i, int pos) { L.m_r[pos] = i; L.m_c[pos] = L.x[i]; }, L.scan);
@@ -270,7 +277,7 @@ bytetrack_kernel(ByDev Dv, ByP P, ByIn in, tlk_bytetrack_row *__restrict__ rows_
         const float c32 = 1 - bbox_iou32(L.tbox + r * 4, L.dbox + j * 4);        // iou_distance (float32)
         const float sim = 1 - c32;                                               // fuse_score: (1 - cost) * score in float64
         return 1 - (double)sim * L.dscore[j];
-    }, ebuf, L);
+    }, ebuf, L.cost, Dv.cost_lds_entries, L);
     for (int k = tid; k < A1.nm; k += BLOCK) apply(L.pool[L.m_r[k]], L.hi[L.m_c[k]], L.pre[L.m_r[k]] != BT_TRACKED);
     const int n_ref = block_compact(A1.nm, [&](int k) { return L.pre[L.m_r[k]] != BT_TRACKED; }, [&](int k, int pos) { L.refind[pos] = L.pool[L.m_r[k]]; }, L.scan);
     for (int k = tid; k < A1.n_uc; k += BLOCK) L.udet1[k] = L.hi[L.u_c[k]];     // remaining high-score detections (filtered index)
@@ -282,7 +289,7 @@ bytetrack_kernel(ByDev Dv, ByP P, ByIn in, tlk_bytetrack_row *__restrict__ rows_
     __syncthreads();
     const AsgOut A2 = lapjv_assign(n_rtr, nlo, 0.5, [&](int r, int c) {
         return (double)(float)(1 - bbox_iou32(L.tbox + r * 4, L.dbox + L.lo[c] * 4));
-    }, ebuf, L);
+    }, ebuf, L.cost, Dv.cost_lds_entries, L);
     for (int k = tid; k < A2.nm; k += BLOCK) apply(L.rtr[L.m_r[k]], L.lo[L.m_c[k]], false);
     for (int k = tid; k < A2.n_ur; k += BLOCK) { const int slot = L.rtr[L.u_r[k]]; trk_at(slot).i(YI_STATE) = BT_LOST; L.newlost[k] = slot; }   // mark_lost
     const int n_newlost = A2.n_ur;
@@ -295,7 +302,7 @@ bytetrack_kernel(ByDev Dv, ByP P, ByIn in, tlk_bytetrack_row *__restrict__ rows_
         const float c32 = 1 - bbox_iou32(L.tbox + r * 4, L.dbox + j * 4);
         const float sim = 1 - c32;
         return 1 - (double)sim * L.dscore[j];
-    }, ebuf, L);
+    }, ebuf, L.cost, Dv.cost_lds_entries, L);
     for (int k = tid; k < A3.nm; k += BLOCK) apply(L.unconf[L.m_r[k]], L.udet1[L.m_c[k]], false);
     for (int k = tid; k < A3.n_ur; k += BLOCK) { const int slot = L.unconf[L.u_r[k]]; trk_at(slot).i(YI_STATE) = BT_REMOVED; L.removed[k] = slot; }
     int n_removed = A3.n_ur;
@@ -467,8 +474,10 @@ extern "C" int tlk_bytetrack_create(const tlk_bytetrack_params *p, int n_streams
     h->P = ByP{p->track_thresh, p->match_thresh, p->track_thresh + 0.1, p->min_confidence, (int)(p->frame_rate / 30.0 * p->track_buffer), p->wrapper_mode};
     ByDev &D = h->D;
     D.S = n_streams; D.MAXT = MAXT; D.MAXD = MAXD; D.NX = MAXT + MAXD;
-    h->smem = bylds_bytes(MAXT, MAXD, D.NX);
-    if (h->smem > 160 * 1024 - 256) { delete h; return fail(TLK_ECAPACITY, "tlk_bytetrack_create: LDS budget exceeded"); }
+    const size_t fixed = bylds_bytes(MAXT, MAXD, D.NX) + 16, budget = 160 * 1024 - 256;
+    if (fixed + 4096 > budget) { delete h; return fail(TLK_ECAPACITY, "tlk_bytetrack_create: LDS budget exceeded"); }
+    D.cost_lds_entries = (int)((budget - fixed) / sizeof(double));
+    h->smem = fixed + (size_t)D.cost_lds_entries * sizeof(double);
     const size_t slots = (size_t)n_streams * MAXT;
     h->out_cap = MAXT;
 #define BY_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void **)&(ptr), (bytes)); \
