@@ -1,0 +1,72 @@
+"""-m gpu: the per-video online loop with the columnar detection table (tracklab_amd/engine.py) against the oracle chain run
+frame by frame (C decode/NMS + C tracker), for both pipeline shapes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(seed, n_obj, n_frames, ratio):
+    from tracklab_amd.synth import SyntheticStream, render_frame, synth_yolox_head
+    rng = np.random.default_rng(seed)
+    heads, frames = [], []
+    for fr in SyntheticStream(seed, n_obj, n_frames):
+        heads.append(synth_yolox_head(rng, fr["dets"][:, :4], ratio=ratio))
+        frames.append(render_frame(rng, fr["gt_boxes"]))
+    return np.stack(heads), frames
+
+
+def _detector_rows(orc, head, ratio):
+    boxes, _, _ = orc.yolox_postprocess(head, 640, float(np.float32(ratio)))
+    l = np.maximum(0, np.minimum(boxes[:, 0], 1918)).astype(np.float32); t = np.maximum(0, np.minimum(boxes[:, 1], 1078)).astype(np.float32)
+    r = np.maximum(1, np.minimum(boxes[:, 2], 1919)).astype(np.float32); b = np.maximum(1, np.minimum(boxes[:, 3], 1079)).astype(np.float32)
+    return np.stack([l, t, r - l, b - t], axis=1)
+
+
+def test_video_engine_det_ocsort_table_matches_oracle_chain(orc):
+    from tracklab_amd import gpu_pipeline as gp
+    from tracklab_amd.engine import HipVideoEngine
+    F, T = 4, 10                                            # 10 frames = 2 full steps + a partial one
+    pipe = gp.DetTrackPipeline("s", n_streams=1, frames_per_step=F, max_dets=64, use_graph=False)
+    heads, frames = _inputs(21, 12, T, pipe.ratio)
+    eng = HipVideoEngine(pipe)
+    df = eng.video_loop(iter(frames), video_id=5, synth_heads=lambda t0, n: heads[t0:t0 + n])
+    trk = orc.OCSort(**pipe.tracker_cfg["hyper"])
+    assert list(df.columns) == ["image_id", "video_id", "category_id", "bbox_ltwh", "bbox_conf", "track_id", "track_bbox_ltwh", "track_bbox_conf"]
+    assert (df.video_id == 5).all() and (df.category_id == 1).all() and (df.bbox_conf == 1.0).all()
+    for f in range(T):
+        ltwh = _detector_rows(orc, heads[f], pipe.ratio)
+        sub = df[df.image_id == f]
+        np.testing.assert_allclose(np.stack(sub.bbox_ltwh.to_list()), ltwh, rtol=2e-6, atol=2e-4)     # expf: 1-2 ulp vs libm
+        ltwh = np.stack(sub.bbox_ltwh.to_list())               # the tracker is checked on the boxes the table holds
+        ids = f * 64 + np.arange(len(ltwh))
+        np.testing.assert_array_equal(sub.index.to_numpy(), ids)
+        dets = np.zeros((len(ltwh), 7))
+        dets[:, 0], dets[:, 1] = ltwh[:, 0], ltwh[:, 1]
+        dets[:, 2], dets[:, 3] = (ltwh[:, 0] + ltwh[:, 2]).astype(np.float32), (ltwh[:, 1] + ltwh[:, 3]).astype(np.float32)
+        dets[:, 4], dets[:, 5], dets[:, 6] = 1.0, 1.0, ids
+        exp = orc.ocsort_wrapper_step(trk, dets, pipe.tracker_cfg["min_confidence"])
+        got = sub[sub.track_id.notna()]
+        assert len(got) == len(exp)
+        order = np.argsort(exp[:, 7])
+        np.testing.assert_array_equal(got.index.to_numpy(), exp[order, 7].astype(int))
+        np.testing.assert_array_equal(got.track_id.to_numpy(), exp[order, 4])
+    second = eng.video_loop(np.stack(frames), video_id=6, synth_heads=lambda t0, n: heads[t0:t0 + n])      # reset between videos
+    np.testing.assert_array_equal(second.track_id.to_numpy(), df.track_id.to_numpy())
+    pipe.close()
+
+
+def test_video_engine_det_reid_strongsort_runs_and_keeps_ids_stable(orc):
+    from tracklab_amd import gpu_pipeline as gp
+    from tracklab_amd.engine import HipVideoEngine
+    F, T = 3, 7
+    pipe = gp.DetReidTrackPipeline("s", n_streams=1, frames_per_step=F, max_dets=32, dim=64, use_graph=False)
+    heads, frames = _inputs(22, 10, T, pipe.ratio)
+    df = HipVideoEngine(pipe).video_loop(frames, synth_heads=lambda t0, n: heads[t0:t0 + n])
+    per_frame = df.groupby("image_id").size()
+    assert len(per_frame) == T and (per_frame >= 9).all()
+    tracked = df[df.track_id.notna()]
+    assert len(tracked) >= 0.9 * len(df)                        # n_init = 0: tracks are confirmed on their first frame
+    assert tracked.track_id.nunique() <= 14                     # 10 objects, near-identical boxes frame to frame: ids persist
+    assert np.isfinite(np.stack(tracked.track_bbox_ltwh.to_list())).all()
+    pipe.close()
