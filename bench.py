@@ -38,6 +38,11 @@ WORKLOADS = {
     "config4": dict(detector="m", objects=100, frames_per_step=24, max_dets=104, pose="m",
                     name="BASELINE configs[3] shape: YOLOX-m + RTMPose-m (256x192 SimCC) + part-based ReID + StrongSORT-family tracker "
                          "with OKS motion cost (bpbreid_strong_sort, motion_criterium oks), synthetic 1080p 100-obj stream"),
+    "config3s": dict(detector="m", objects=100, frames_per_step=24, max_dets=104, tracker="strong_sort",
+                     name="BASELINE configs[2] with the plain StrongSORT reading (cosine + IoU cost): YOLOX-m + 512-d ReID on Pillow-semantics "
+                          "256x128 crops + strong_sort.StrongSORT (cosine gallery, budget 100), synthetic 1080p 100-obj stream"),
+    "config2b": dict(detector="s", objects=50, frames_per_step=32, max_dets=128, tracker="byte_track",
+                     name="YOLOX-s + ByteTrack (IoU fused with score, lapjv cost limits), synthetic 1080p 50-obj stream"),
     "config2": dict(detector="s", objects=50, frames_per_step=32, max_dets=128,
                     name="BASELINE configs[1]: YOLOX-s + OC-SORT (IoU+Kalman, no ReID), synthetic 1080p 50-obj stream"),
 }
@@ -93,15 +98,17 @@ def main():
     B = S * F
     total_steps = args.warmup + args.steps
     n_frames = total_steps * F
-    is3 = args.workload in ("config3", "config4")
+    is3 = args.workload in ("config3", "config4", "config3s")
+    ssort = wl.get("tracker") == "strong_sort"
+    byte = wl.get("tracker") == "byte_track"
 
     from tracklab_amd import gpu_pipeline as gp
     if is3:
         pipe = gp.DetReidTrackPipeline(detector, n_streams=S, frames_per_step=F, max_dets=wl["max_dets"], device=dev.index,
-                                       use_graph=not args.no_graph, pose=wl.get("pose"))
+                                       use_graph=not args.no_graph, pose=wl.get("pose"), tracker=wl.get("tracker", "bpbreid"))
     else:
         pipe = gp.DetTrackPipeline(detector, n_streams=S, frames_per_step=F, max_dets=wl["max_dets"], device=dev.index,
-                                   use_graph=not args.no_graph)
+                                   use_graph=not args.no_graph, tracker=wl.get("tracker", "oc_sort"))
     ratio = pipe.ratio
 
     # ---- synthetic inputs, resident in HBM before the timed region ----
@@ -132,7 +139,8 @@ def main():
         oracle.build()
         ksteps = min(total_steps, max(1, (args.check_frames + F - 1) // F))
         if is3:
-            ref = oracle.StrongSORT(pipe.K, pipe.D, **pipe.tracker_cfg)
+            ref = oracle.PlainStrongSORT(pipe.D, **pipe.tracker_cfg, img_w=WIDTH, img_h=HEIGHT) if ssort else \
+                oracle.StrongSORT(pipe.K, pipe.D, **pipe.tracker_cfg)
             ids_ok, tracks, frames_checked = True, 0, 0
             gt_fr, gpu_fr, orc_fr = [], [], []
             for k in range(ksteps):
@@ -146,9 +154,24 @@ def main():
                     ltwh32 = detector_rows(oracle, heads_np[0][k * F + f], ratio)
                     n = len(ltwh32)
                     ids = (k * B + f) * pipe.maxd + np.arange(n)
-                    exp = ref.update(ids, ltwh32.astype(np.float64), emb[0, f, :n], vis[0, f, :n], np.ones(n),
-                                     keypoints=None if kps is None else kps[0, f, :n]) if n else []
-                    got = rows[0][f]
+                    if ssort:
+                        d7 = np.zeros((n, 7))
+                        d7[:, 0], d7[:, 1] = ltwh32[:, 0], ltwh32[:, 1]
+                        d7[:, 2], d7[:, 3] = (ltwh32[:, 0] + ltwh32[:, 2]).astype(np.float32), (ltwh32[:, 1] + ltwh32[:, 3]).astype(np.float32)
+                        d7[:, 4], d7[:, 5], d7[:, 6] = 1.0, 1.0, ids
+                        e8 = ref.update(d7, emb[0, f, :n, 0, :]) if n else np.zeros((0, 8))
+                        exp = np.zeros(len(e8), dtype=[("det_id", "<i8"), ("track_id", "<i8"), ("kf_ltwh", "<f8", (4,))])
+                        exp["det_id"], exp["track_id"] = e8[:, 7], e8[:, 4]
+                        exp["kf_ltwh"] = np.stack([e8[:, 0], e8[:, 1], e8[:, 2] - e8[:, 0], e8[:, 3] - e8[:, 1]], axis=1).reshape(-1, 4)
+                        g_ = rows[0][f]
+                        got = np.zeros(len(g_), dtype=exp.dtype)
+                        got["det_id"], got["track_id"] = g_["det_id"], g_["track_id"]
+                        got["kf_ltwh"] = np.stack([g_["ltrb"][:, 0], g_["ltrb"][:, 1], g_["ltrb"][:, 2] - g_["ltrb"][:, 0],
+                                                   g_["ltrb"][:, 3] - g_["ltrb"][:, 1]], axis=1).reshape(-1, 4)
+                    else:
+                        exp = ref.update(ids, ltwh32.astype(np.float64), emb[0, f, :n], vis[0, f, :n], np.ones(n),
+                                         keypoints=None if kps is None else kps[0, f, :n]) if n else []
+                        got = rows[0][f]
                     ok = len(got) == len(exp) and (len(exp) == 0 or (np.array_equal(got["det_id"], exp["det_id"]) and
                                                                       np.array_equal(got["track_id"], exp["track_id"])))
                     ids_ok &= bool(ok)
@@ -165,16 +188,18 @@ def main():
             h_orc = hota.finalize(hota.pack(hota.hota_sequence(*hota.sequence_from_rows(gt_fr, orc_fr))))["summary"]
             parity = {"frames": frames_checked, "track_ids_equal_oracle": bool(ids_ok), "tracks": tracks,
                       "HOTA_gpu": h_gpu["HOTA"], "HOTA_oracle": h_orc["HOTA"], "AssA_gpu": h_gpu["AssA"], "DetA_gpu": h_gpu["DetA"],
-                      "note": "oracle chain = C decode/NMS + C BPBReID-StrongSORT fed with the embeddings the GPU ReID net produced"
+                      "note": "oracle chain = C decode/NMS + C " + ("plain StrongSORT" if ssort else "BPBReID-StrongSORT") +
+                              " fed with the embeddings the GPU ReID net produced"
                               + (" and the keypoints the GPU pose stage produced (OKS motion cost)" if pipe.pose is not None else "")}
         else:
-            trk = oracle.OCSort(**pipe.tracker_cfg["hyper"])
+            trk = oracle.ByteTrack(**pipe.tracker_cfg["hyper"]) if byte else oracle.OCSort(**pipe.tracker_cfg["hyper"])
             got, exp = [], []
             for k in range(ksteps):
                 rows, cnt = run_step(k)
                 pipe.synchronize()
+                rows_a = pipe.rows_array(rows)
                 for f in range(F):
-                    got.append(rows[0, f, :int(cnt[0, f])].numpy().copy())
+                    got.append(np.array(rows_a[0, f, :int(cnt[0, f])]))
                     ltwh = detector_rows(oracle, heads_np[0][k * F + f], ratio)
                     n = len(ltwh)
                     dets = np.zeros((n, 7))
@@ -182,7 +207,8 @@ def main():
                     dets[:, 2], dets[:, 3] = (ltwh[:, 0] + ltwh[:, 2]).astype(np.float32), (ltwh[:, 1] + ltwh[:, 3]).astype(np.float32)
                     dets[:, 4], dets[:, 5] = 1.0, 1.0
                     dets[:, 6] = (k * B + f) * pipe.maxd + np.arange(n)
-                    exp.append(oracle.ocsort_wrapper_step(trk, dets, pipe.tracker_cfg["min_confidence"]))
+                    exp.append(trk.update(dets[dets[:, 4] > pipe.tracker_cfg["min_confidence"]]) if byte else
+                               oracle.ocsort_wrapper_step(trk, dets, pipe.tracker_cfg["min_confidence"]))
             ids_ok = all(g.shape == e.shape and np.array_equal(g[:, [4, 7]], e[:, [4, 7]]) for g, e in zip(got, exp))
             parity = {"frames": len(got), "track_ids_equal_oracle": bool(ids_ok),
                       "tracks": int(max((g[:, 4].max() if len(g) else 0) for g in got))}
@@ -222,7 +248,7 @@ def main():
     k_ms_avg = float(np.mean(k_ms)) if k_ms else float("nan")
     from tracklab_amd import roofline as rl
     if is3:
-        kname, tfile = "crop_lds_kernel", "crop_traffic.json"
+        kname, tfile = ("pil_crop_kernel", "pil_crop_traffic.json") if ssort else ("crop_lds_kernel", "crop_traffic.json")
         # mean crop of the synthetic stream: w~U(40,120), h=w*U(1.8,2.6) -> E[w*h] = E[w^2]*2.2
         cnt_mean = float(np.mean([len(g["dets"]) for g in gts[0][:64]]))
         ew2 = (120 ** 3 - 40 ** 3) / (3 * 80)
@@ -251,13 +277,18 @@ def main():
         from tracklab_amd.backbones.reid import part_based_reid
         from tracklab_amd.backbones.yolox import yolox
         cpu_det = yolox(detector, device="cpu", dtype=torch.float32, channels_last=False)
-        cpu_reid = part_based_reid(6, 256, device="cpu", dtype=torch.float32, channels_last=False) if is3 else None
+        cpu_reid = part_based_reid(pipe.K, pipe.D, device="cpu", dtype=torch.float32, channels_last=False) if is3 else None
         cpu_pose = None
         if is3 and wl.get("pose"):
             from tracklab_amd.backbones.rtmpose import rtmpose
             cpu_pose = rtmpose(wl["pose"], device="cpu", dtype=torch.float32, channels_last=False)
         frame = render_frame(np.random.default_rng(5), gts[0][0]["gt_boxes"])
-        trk = oracle.StrongSORT(6, 256, **pipe.tracker_cfg) if is3 else oracle.OCSort(**pipe.tracker_cfg["hyper"])
+        if ssort:
+            trk = oracle.PlainStrongSORT(pipe.D, **pipe.tracker_cfg, img_w=WIDTH, img_h=HEIGHT)
+        elif is3:
+            trk = oracle.StrongSORT(pipe.K, pipe.D, **pipe.tracker_cfg)
+        else:
+            trk = oracle.ByteTrack(**pipe.tracker_cfg["hyper"]) if byte else oracle.OCSort(**pipe.tracker_cfg["hyper"])
         tc0 = time.perf_counter()
         done = 0
         with torch.no_grad():
@@ -266,7 +297,13 @@ def main():
                 cpu_det(torch.from_numpy(img)[None])
                 ltwh = detector_rows(oracle, heads_np[0][f], ratio)
                 n = len(ltwh)
-                if is3:
+                if ssort:
+                    d7 = np.zeros((n, 7))
+                    d7[:, :2] = ltwh[:, :2]; d7[:, 2:4] = ltwh[:, :2] + ltwh[:, 2:]; d7[:, 4], d7[:, 5], d7[:, 6] = 1.0, 1.0, np.arange(n) + f * 1000
+                    crops = np.stack([oracle.ssort_reid_preprocess(frame, b)[0] for b in d7[:, :4]]) if n else np.zeros((0, 3, 256, 128), np.float32)
+                    emb, _ = cpu_reid(torch.from_numpy(crops))
+                    trk.update(d7, emb.numpy()[:, 0, :])
+                elif is3:
                     ltrb = oracle.ltwh_to_crop_ltrb(ltwh.astype(np.float64), WIDTH, HEIGHT)
                     crops = oracle.crop_resize_norm(frame, ltrb, 384, 128)
                     emb, vis = cpu_reid(torch.from_numpy(crops))
@@ -285,15 +322,19 @@ def main():
                     dets[:, :2] = ltwh[:, :2]
                     dets[:, 2:4] = ltwh[:, :2] + ltwh[:, 2:]
                     dets[:, 4], dets[:, 5], dets[:, 6] = 1.0, 1.0, np.arange(n)
-                    oracle.ocsort_wrapper_step(trk, dets, pipe.tracker_cfg["min_confidence"])
+                    if byte:
+                        trk.update(dets[dets[:, 4] > pipe.tracker_cfg["min_confidence"]])
+                    else:
+                        oracle.ocsort_wrapper_step(trk, dets, pipe.tracker_cfg["min_confidence"])
                 done += 1
                 if time.perf_counter() - tc0 > args.cpu_seconds:
                     break
         cpu_t = time.perf_counter() - tc0
         chain = ("oracle C letterbox + YOLOX-%s fp32 (torch CPU, batch 1) + oracle C decode/NMS" % detector) + \
                 ((" + oracle C affine pose crops + RTMPose-%s fp32 (torch CPU) + oracle C SimCC decode" % wl["pose"]) if is3 and wl.get("pose") else "") + \
-                (" + oracle C crop-resize-normalize + part-based ReID R50 fp32 (torch CPU, 100 crops/batch) + oracle C BPBReID-StrongSORT"
-                 if is3 else " + oracle C OC-SORT")
+                (" + oracle C Pillow-semantics crops + ReID R50 fp32 512-d (torch CPU, 100 crops/batch) + oracle C plain StrongSORT" if ssort else
+                 " + oracle C crop-resize-normalize + part-based ReID R50 fp32 (torch CPU, 100 crops/batch) + oracle C BPBReID-StrongSORT"
+                 if is3 else (" + oracle C ByteTrack" if byte else " + oracle C OC-SORT"))
         cpu = {"value": done / cpu_t, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                "sample": f"{done} frames of the same stream in {cpu_t:.1f} s: {chain}"}
 

@@ -97,6 +97,9 @@ write_summary("config3", "config3 (YOLOX-m + ReID + BPBReID-StrongSORT), 24 fram
               "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload config3 --steps 10 --warmup 2 --no-cpu-baseline --check-frames 0")
 write_summary("config2", "config2 (YOLOX-s + OC-SORT), 32 frames/step",
               "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload config2 --steps 10 --warmup 2 --no-cpu-baseline --check-frames 0")
+for wl in ("config4", "config3s", "config2b"):
+    if os.path.exists(os.path.join(src, f"bench_{wl}.json")):
+        shutil.copy(os.path.join(src, f"bench_{wl}.json"), os.path.join(dst, f"{tag}_bench_{wl}.json"))
 rows, paths = stats_rows(os.path.join(src, "kt_probe"))
 if paths:
     shutil.copy(paths[0], os.path.join(dst, f"{tag}_probe_kernels_kernel_stats.csv"))

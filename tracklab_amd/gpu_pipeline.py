@@ -25,7 +25,9 @@ class DetTrackPipeline:
                  height: int = 1080, width: int = 1920, size: int = 640, dtype=torch.float16,
                  layout: str = "focus_nhwc", device: int = 0, tracker_cfg: dict | None = None,
                  num_classes: int = 1, nms_thr: float = 0.45, score_thr: float = 0.7, max_tracks: int = 256,
-                 use_graph: bool = True):
+                 use_graph: bool = True, tracker: str = "oc_sort"):
+        """tracker: "oc_sort" (configs[1]) or "byte_track" (same detector, ByteTrack association)."""
+        self.tracker = tracker
         self.S, self.F, self.maxd = n_streams, frames_per_step, max_dets
         self.H, self.W, self.size, self.dtype, self.layout = height, width, size, dtype, layout
         self.nms_thr, self.score_thr = nms_thr, score_thr
@@ -35,10 +37,18 @@ class DetTrackPipeline:
             # tracklab/configs/modules/track/oc_sort.yaml:3-14
             min_confidence=0.4, hyper=dict(asso_func="giou", delta_t=1, det_thresh=0, inertia=0.3941737016672115,
                                            iou_threshold=0.22136877277096445, max_age=50, min_hits=1, use_byte=False))
+        if tracker == "byte_track" and tracker_cfg is None:      # tracklab/configs/modules/track/byte_track.yaml
+            cfg = dict(min_confidence=0.4, hyper=dict(track_thresh=0.6, track_buffer=30, match_thresh=0.8, frame_rate=30))
         self.tracker_cfg = cfg
         self.model = yolox(detector, num_classes, device=self.dev, dtype=dtype, channels_last=(layout != "nchw"))
-        self.bank = _lib.OCSortBank(**cfg["hyper"], min_confidence=cfg["min_confidence"], wrapper_mode=True,
-                                    n_streams=n_streams, device=device, max_tracks=max_tracks, max_dets=max_dets)
+        if tracker == "byte_track":
+            self.bank = _lib.ByteTrackBank(**cfg["hyper"], min_confidence=cfg["min_confidence"], wrapper_mode=True,
+                                           n_streams=n_streams, device=device, max_tracks=max_tracks, max_dets=max_dets)
+            self.row_dtype = _lib.BYTETRACK_ROW
+        else:
+            self.bank = _lib.OCSortBank(**cfg["hyper"], min_confidence=cfg["min_confidence"], wrapper_mode=True,
+                                        n_streams=n_streams, device=device, max_tracks=max_tracks, max_dets=max_dets)
+            self.row_dtype = None
         B = n_streams * frames_per_step
         self.B = B
         A = sum((size // s) ** 2 for s in (8, 16, 32))
@@ -129,6 +139,16 @@ class DetTrackPipeline:
             return buf["trk_out"], buf["trk_cnt"]
         return buf["h_out"], buf["h_cnt"]
 
+    def rows_array(self, h_out):
+        """Host result block -> (S, F, cap, 8) float64 rows [x1,y1,x2,y2,track_id,cls,conf,det_id] for either tracker."""
+        a = h_out.numpy()
+        if self.row_dtype is None:
+            return a
+        r = a.view(self.row_dtype).reshape(a.shape[:3])          # ByteTrack rows are 8 x 8 bytes as well
+        out = np.empty(a.shape[:3] + (8,))
+        out[..., :4] = r["ltrb"]; out[..., 4] = r["track_id"]; out[..., 5] = r["cls"]; out[..., 6] = r["score"]; out[..., 7] = r["det_id"]
+        return out
+
     def _forward_graphed(self, frames):
         """letterbox + YOLOX forward replayed from a hipGraph (the forward is ~300 short launches and is
         host-launch-bound in eager mode). One graph per input buffer address."""
@@ -171,10 +191,15 @@ class DetReidTrackPipeline:
                  height: int = 1080, width: int = 1920, size: int = 640, dtype=torch.float16, device: int = 0,
                  parts: int = 6, dim: int = 256, reid_hw=(384, 128), tracker_cfg: dict | None = None,
                  nms_thr: float = 0.45, score_thr: float = 0.7, max_tracks: int = 512, use_graph: bool = True,
-                 pose: str | None = None):
-        """pose = "t"/"s"/"m"/"l": BASELINE.json configs[3] -- a top-down RTMPose stage (tlk_pose_crop_warp_norm -> network ->
+                 pose: str | None = None, tracker: str = "bpbreid"):
+        """tracker = "strong_sort": plain StrongSORT (strong_sort.StrongSORT: Pillow-semantics 256x128 crops of the int-truncated
+        boxes, one global 512-d feature per crop, cosine gallery on MFMA, tlk_ssort bank) instead of BPBReID-StrongSORT.
+        pose = "t"/"s"/"m"/"l": BASELINE.json configs[3] -- a top-down RTMPose stage (tlk_pose_crop_warp_norm -> network ->
         tlk_simcc_decode) between detector and ReID; its keypoints drive the tracker's OKS motion cost (motion_criterium "oks")."""
         from .backbones.reid import part_based_reid
+        self.tracker = tracker
+        if tracker == "strong_sort":
+            parts, dim, reid_hw = 1, 512, (256, 128)
         self.S, self.F, self.maxd = n_streams, frames_per_step, max_dets
         self.H, self.W, self.size, self.dtype = height, width, size, dtype
         self.K, self.D, self.reid_hw = parts, dim, reid_hw
@@ -186,6 +211,9 @@ class DetReidTrackPipeline:
             max_age=300, n_init=0, nn_budget=100, min_bbox_confidence=0.0, only_position_for_kf_gating=False,
             max_kalman_prediction_without_update=7, matching_strategy="strong_sort_matching", gating_thres_factor=1,
             w_kfgd=1, w_reid=1, w_st=1)
+        if tracker == "strong_sort" and tracker_cfg is None:       # StrongSORT.__init__ defaults (strong_sort.py:19-32) + wrapper filter
+            self.tracker_cfg = dict(max_dist=0.2, max_iou_dist=0.7, max_age=70, max_unmatched_preds=7, n_init=3, nn_budget=100,
+                                    mc_lambda=0.995, ema_alpha=0.9)
         self.pose = None
         if pose:
             from .backbones.rtmpose import rtmpose
@@ -193,8 +221,14 @@ class DetReidTrackPipeline:
             self.pose = rtmpose(pose, device=self.dev, dtype=dtype, channels_last=True)
         self.model = yolox(detector, 1, device=self.dev, dtype=dtype, channels_last=True)
         self.reid = part_based_reid(parts, dim, device=self.dev, dtype=dtype, channels_last=True)
-        self.bank = _lib.BpbssBank(parts, dim, **self.tracker_cfg, wrapper_mode=True, n_streams=n_streams, device=device,
-                                   max_tracks=max_tracks, max_dets=max_dets)
+        if tracker == "strong_sort":
+            self.bank = _lib.SsortBank(dim, **self.tracker_cfg, min_confidence=0.4, wrapper_mode=True, img_w=width, img_h=height,
+                                       n_streams=n_streams, device=device, max_tracks=min(max_tracks, 256), max_dets=max_dets)
+            self.row_dtype = _lib.SSORT_ROW
+        else:
+            self.bank = _lib.BpbssBank(parts, dim, **self.tracker_cfg, wrapper_mode=True, n_streams=n_streams, device=device,
+                                       max_tracks=max_tracks, max_dets=max_dets)
+            self.row_dtype = _lib.BPBSS_ROW
         B = n_streams * frames_per_step
         self.B = B
         dev = self.dev
@@ -217,7 +251,7 @@ class DetReidTrackPipeline:
         self.id_off = torch.arange(B * max_dets, dtype=torch.int64, device=dev).reshape(B, max_dets)
         self.nbuf = 2
         self.bufs = []
-        row_bytes = _lib.BPBSS_ROW.itemsize
+        row_bytes = self.row_dtype.itemsize
         for _ in range(self.nbuf):
             self.bufs.append({
                 "ids": torch.zeros((B, max_dets), dtype=torch.int64, device=dev),
@@ -225,6 +259,7 @@ class DetReidTrackPipeline:
                 "emb": torch.zeros((B, max_dets, parts, dim), dtype=torch.float32, device=dev),
                 "vis": torch.zeros((B, max_dets, parts), dtype=torch.uint8, device=dev),
                 "counts": torch.zeros((B,), dtype=torch.int32, device=dev),
+                "trk_in": torch.zeros((B, max_dets, 7), dtype=torch.float64, device=dev) if tracker == "strong_sort" else None,
                 "kps": torch.zeros((B, max_dets, 17, 3), dtype=torch.float64, device=dev) if self.pose is not None else None,
                 "rows": torch.zeros((B, max_dets, row_bytes), dtype=torch.uint8, device=dev),
                 "ocnt": torch.zeros((B,), dtype=torch.int32, device=dev),
@@ -282,12 +317,16 @@ class DetReidTrackPipeline:
         if synth_head is not None:
             pred = torch.add(synth_head, torch.nan_to_num(pred), alpha=0.0)
         _lib.yolox_decode_nms(pred, self.size, float(np.float32(self.ratio)), self.W, self.H, maxd, self.nms_thr,
-                              self.score_thr, out=self.det)
+                              self.score_thr, out=self.det, trk_in=buf["trk_in"], det_id_base=self.frames_done * maxd, category_id=1.0)
         if self.record_kernel_events:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        crops = _lib.roi_crop_resize_norm(frames, self.det["ltwh"], self.det["counts"], self.reid_hw[0], self.reid_hw[1],
-                                          "nhwc", self.dtype, out=self.crops)
+        if self.tracker == "strong_sort":       # StrongSORT._get_features: int-truncated boxes, Pillow resize, ImageNet normalisation
+            crops = _lib.roi_crop_pil_resize_norm(frames, buf["trk_in"], self.det["counts"], self.reid_hw[0], self.reid_hw[1],
+                                                  "nhwc", self.dtype, out=self.crops)
+        else:
+            crops = _lib.roi_crop_resize_norm(frames, self.det["ltwh"], self.det["counts"], self.reid_hw[0], self.reid_hw[1],
+                                              "nhwc", self.dtype, out=self.crops)
         if self.record_kernel_events:
             e1.record()
             self.kernel_events.append((e0, e1))
@@ -316,10 +355,14 @@ class DetReidTrackPipeline:
         self.frames_done += S * F
         with torch.cuda.stream(self.trk_stream):
             self.trk_stream.wait_event(buf["ready"])
-            self.bank.update_dev(buf["ids"].data_ptr(), buf["ltwh"].data_ptr(), buf["emb"].data_ptr(), buf["vis"].data_ptr(),
-                                 self.conf.data_ptr(), buf["counts"].data_ptr(), F, buf["rows"].data_ptr(), maxd,
-                                 buf["ocnt"].data_ptr(), C.c_void_p(self.trk_stream.cuda_stream),
-                                 kps=buf["kps"].data_ptr() if self.pose is not None else None)
+            if self.tracker == "strong_sort":
+                self.bank.update_dev(buf["trk_in"].data_ptr(), buf["emb"].data_ptr(), buf["counts"].data_ptr(), F, buf["rows"].data_ptr(),
+                                     maxd, buf["ocnt"].data_ptr(), C.c_void_p(self.trk_stream.cuda_stream))
+            else:
+                self.bank.update_dev(buf["ids"].data_ptr(), buf["ltwh"].data_ptr(), buf["emb"].data_ptr(), buf["vis"].data_ptr(),
+                                     self.conf.data_ptr(), buf["counts"].data_ptr(), F, buf["rows"].data_ptr(), maxd,
+                                     buf["ocnt"].data_ptr(), C.c_void_p(self.trk_stream.cuda_stream),
+                                     kps=buf["kps"].data_ptr() if self.pose is not None else None)
             if fetch:
                 buf["h_rows"].copy_(buf["rows"], non_blocking=True)
                 buf["h_ocnt"].copy_(buf["ocnt"], non_blocking=True)
@@ -329,7 +372,7 @@ class DetReidTrackPipeline:
 
     def rows_numpy(self, h_rows, h_ocnt):
         """(S, F) nested lists of structured row arrays from the pinned result block."""
-        r = h_rows.numpy().view(_lib.BPBSS_ROW).reshape(self.S, self.F, self.maxd)
+        r = h_rows.numpy().view(self.row_dtype).reshape(self.S, self.F, self.maxd)
         c = h_ocnt.numpy().reshape(self.S, self.F)
         return [[r[s, f, :max(int(c[s, f]), 0)].copy() for f in range(self.F)] for s in range(self.S)], c
 
