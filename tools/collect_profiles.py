@@ -40,7 +40,8 @@ def write_summary(wl, title, cmd):
     out.append(f"\ntotal kernel time: {tot / 1e6:.2f} ms over {len(rows)} distinct kernels\n")
     open(os.path.join(dst, f"{tag}_{wl}_rocprof.md"), "w").write("\n".join(out))
     shutil.copy(paths[0], os.path.join(dst, f"{tag}_{wl}_rocprof_kernel_stats.csv"))
-    shutil.copy(os.path.join(src, f"bench_{wl}.json"), os.path.join(dst, f"{tag}_bench_{wl}.json"))
+    if os.path.exists(os.path.join(src, f"bench_{wl}.json")):
+        shutil.copy(os.path.join(src, f"bench_{wl}.json"), os.path.join(dst, f"{tag}_bench_{wl}.json"))
 
 
 def counter_means(d, counter):
@@ -100,6 +101,8 @@ write_summary("config2", "config2 (YOLOX-s + OC-SORT), 32 frames/step",
 for wl in ("config4", "config3s", "config2b"):
     if os.path.exists(os.path.join(src, f"bench_{wl}.json")):
         shutil.copy(os.path.join(src, f"bench_{wl}.json"), os.path.join(dst, f"{tag}_bench_{wl}.json"))
+write_summary("config3s", "config3s (YOLOX-m + 512-d ReID + plain StrongSORT: cosine gallery on MFMA), 24 frames/step",
+              "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload config3s --steps 10 --warmup 2 --no-cpu-baseline --check-frames 0")
 rows, paths = stats_rows(os.path.join(src, "kt_probe"))
 if paths:
     shutil.copy(paths[0], os.path.join(dst, f"{tag}_probe_kernels_kernel_stats.csv"))

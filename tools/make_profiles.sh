@@ -14,7 +14,7 @@ for wl in config4 config3s config2b; do
   python bench.py --workload $wl --steps 6 --warmup 2 > "$OUT/bench_$wl.json" 2> "$OUT/bench_$wl.err"
 done
 cd /tmp && export TMPDIR=/tmp
-for wl in config3 config2; do
+for wl in config3 config2 config3s; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$wl" -- \
     python "$R/bench.py" --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --check-frames 0 > "$OUT/prof_$wl.json" 2> "$OUT/prof_$wl.err"
   find "$OUT/prof_$wl" -name '*kernel_trace.csv' -delete       # keep the stats, drop the raw trace (size)
