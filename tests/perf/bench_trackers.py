@@ -1,6 +1,7 @@
-"""Probe (not product): association-only throughput of every tracker bank, device entry points (`*_update_dev`), synthetic
+"""Measurement script kept under tests/ because it times the C oracle next to the GPU banks (only tests/, smoke() and bench.py's
+cpu_baseline leg may touch oracle/): association-only throughput of every tracker bank, device entry points (`*_update_dev`), synthetic
 1080p streams with 100 objects, next to the C oracle on one host core. Writes gpurun_out/trackers.json; tools/collect_profiles.py
-turns it into profiles/<tag>_trackers.md.  usage: python tools/bench_trackers.py [frames] [streams]"""
+turns it into profiles/<tag>_trackers.md.  usage: python tests/perf/bench_trackers.py [frames] [streams]"""
 import json
 import os
 import sys
@@ -9,9 +10,9 @@ import time
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
-import oracle  # noqa: E402  (probe: the oracle is the timed CPU port here)
+import oracle  # noqa: E402  (the oracle is the timed CPU port here)
 from tracklab_amd import _lib  # noqa: E402
 from tracklab_amd.synth import SyntheticStream, ltrb_to_ltwh_rows  # noqa: E402
 

@@ -143,7 +143,7 @@ def write_trackers():
     if not os.path.exists(path):
         print("no trackers.json"); return
     res = json.load(open(path))
-    out = [f"# {tag} -- association-only throughput of the tracker banks (tools/bench_trackers.py)", "",
+    out = [f"# {tag} -- association-only throughput of the tracker banks (tests/perf/bench_trackers.py)", "",
            "Synthetic 1080p streams, 100 objects, 120 frames per stream; device entry points (`tlk_*_update_dev`, all frames of all streams "
            "enqueued on one HIP stream, inputs resident in HBM); CPU column = the C oracle on one host core for the same stream.", "",
            "| tracker | streams | GPU frames/s | us per frame-launch | CPU oracle frames/s (1 core) | row counts = oracle |", "|---|---|---|---|---|---|"]

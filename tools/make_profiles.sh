@@ -25,6 +25,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python "$R/tools/probe_kernels.py" > "$OUT/pmc_write.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_mfma" -- python "$R/tools/probe_mfma.py" > "$OUT/kt_mfma.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d "$OUT/pmc_mfma" -- python "$R/tools/probe_mfma.py" > "$OUT/pmc_mfma.log" 2>&1
-python "$R/tools/bench_trackers.py" 120 64 > "$OUT/trackers.log" 2>&1; cp "$R/gpurun_out/trackers.json" "$OUT/trackers.json"
+python "$R/tests/perf/bench_trackers.py" 120 64 > "$OUT/trackers.log" 2>&1; cp "$R/gpurun_out/trackers.json" "$OUT/trackers.json"
 find "$OUT" -name '*kernel_trace.csv' -delete
 echo "profiles raw data in $OUT"; ls "$OUT"
