@@ -29,6 +29,7 @@ extern "C" {
 #define TLK_EHIP (-2)       /* HIP runtime error (message has hipGetErrorString) */
 #define TLK_ECAPACITY (-3)  /* more tracks / detections than the handle was created for */
 #define TLK_ENODEVICE (-4)  /* no usable gfx950 device */
+#define TLK_EUNSUPPORTED (-5) /* an optional library route is not available (callers keep their other GPU route) */
 
 const char *tlk_last_error(void);
 int tlk_version(void);               /* 10000*major + 100*minor + patch */
@@ -387,6 +388,15 @@ int tlk_yolox_decode_nms(const float *pred_dev, int batch, int size, int num_cla
  * ------------------------------------------------------------------------------------------ */
 int tlk_bias_act_nhwc(void *x_dev, const void *bias_dev, const void *residual_dev, long long rows, int channels,
                       int act_kind, int dtype, void *hip_stream);
+
+/* 1x1 convolution of a channels-last tensor as ONE GEMM with the convolution epilogue inside:
+ *   out[M,N] = act(x[M,K] . w[N,K]^T + bias[N] (+ residual[M,N])),  act 0 none / 1 ReLU / 2 SiLU, dtype TLK_F16 or TLK_BF16.
+ * hipBLASLt (library GEMM, taken from the process with dlopen) with its BIAS / RELU_BIAS / SWISH_BIAS epilogue and beta*C for
+ * the residual; the algorithm is tuned per (M,N,K,epilogue) over the heuristic's candidates on first use and cached.
+ * Replaces conv + tlk_bias_act_nhwc for the bottleneck 1x1 convolutions of the backbones. Returns TLK_EUNSUPPORTED when
+ * hipBLASLt or a matching algorithm is missing (callers fall back to GEMM + tlk_bias_act_nhwc, still on the GPU). */
+int tlk_gemm_bias_act(const void *x_dev, const void *w_dev, const void *bias_dev, const void *residual_dev, void *out_dev,
+                      long long M, int N, int K, int act, int dtype, void *hip_stream);
 
 #ifdef __cplusplus
 }

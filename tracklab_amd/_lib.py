@@ -609,6 +609,35 @@ def partdist(q, qvis, g, gvis):
     return out
 
 
+_GEMM_OK = None          # None: untried, True / False afterwards
+
+
+def gemm_bias_act(x2d, weight2d, bias, act="relu", residual2d=None):
+    """out (M, N) = act(x2d (M, K) @ weight2d (N, K)^T + bias (+ residual2d (M, N))) in ONE hipBLASLt call (tlk_gemm_bias_act).
+    Returns None when that route is unavailable (callers then use GEMM + tlk_bias_act_nhwc)."""
+    global _GEMM_OK
+    import torch
+    if _GEMM_OK is False:
+        return None
+    L = lib()
+    if not getattr(L, "_gemm_bound", False):
+        L.tlk_gemm_bias_act.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_void_p]
+        L._gemm_bound = True
+    M, K = x2d.shape
+    N = weight2d.shape[0]
+    out = torch.empty((M, N), dtype=x2d.dtype, device=x2d.device)
+    rc = L.tlk_gemm_bias_act(x2d.data_ptr(), weight2d.data_ptr(), bias.data_ptr(), residual2d.data_ptr() if residual2d is not None else None,
+                             out.data_ptr(), M, N, K, ACT[act], _dtype_code(x2d.dtype), current_stream_ptr())
+    if rc == -5:            # TLK_EUNSUPPORTED
+        if _GEMM_OK is None:
+            _GEMM_OK = False
+        return None
+    check(rc)
+    _GEMM_OK = True
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # stateless Kalman steps and motion costs (include/tlk.h: tlk_kf7_*, tlk_kf8_*, tlk_iou_ltwh_cost_f64, tlk_oks_cost_f64)
 # All take/return float64 cuda tensors; the in-place ones return their (modified) arguments.

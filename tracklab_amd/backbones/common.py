@@ -9,6 +9,7 @@ import torch.nn.functional as F
 import os as _os
 
 USE_GEMM_1X1 = _os.environ.get("TLK_CONV1X1_GEMM", "1") != "0"
+USE_FUSED_GEMM = _os.environ.get("TLK_FUSED_GEMM", "1") != "0"
 
 
 def epilogue_(x: torch.Tensor, bias: torch.Tensor, act: str | None, residual: torch.Tensor | None = None) -> torch.Tensor:
@@ -45,10 +46,23 @@ class ConvBiasAct(nn.Module):
                 and x.is_contiguous(memory_format=torch.channels_last):
             # a channels-last 1x1 convolution IS a plain GEMM (rows = N*H*W): hand it to hipBLASLt
             n, c, h, w = x.shape
-            # (measured: riding the residual in as the GEMM's beta*C, or hipBLASLt's bias+ReLU epilogue via
-            #  torch._addmm_activation, select slower GEMM kernels here: 206 -> 192 frames/s on config3. Plain GEMM + one
-            #  fused libtlk epilogue pass is the faster split.)
-            y = F.linear(x.permute(0, 2, 3, 1).reshape(-1, c), self.conv.weight.reshape(self.conv.out_channels, c))
+            x2 = x.permute(0, 2, 3, 1).reshape(-1, c)
+            w2 = self.conv.weight.reshape(self.conv.out_channels, c)
+            if USE_FUSED_GEMM and x.dtype in (torch.float16, torch.bfloat16):
+                # one hipBLASLt call with bias + activation (+ residual as beta*C) inside, algorithm tuned per shape by libtlk
+                # (tlk_gemm_bias_act): 1.4-2.3x faster than GEMM + epilogue pass on the ReID bottleneck shapes
+                from .. import _lib
+                r2 = None
+                if residual is not None:
+                    if not residual.is_contiguous(memory_format=torch.channels_last):
+                        residual = residual.contiguous(memory_format=torch.channels_last)
+                    r2 = residual.permute(0, 2, 3, 1).reshape(-1, self.conv.out_channels)
+                y2 = _lib.gemm_bias_act(x2, w2, self.bias, self.act, r2)
+                if y2 is not None:
+                    return y2.view(n, h, w, -1).permute(0, 3, 1, 2)
+            # (measured: torch's own routes to the fused epilogue -- riding the residual in as the GEMM's beta*C, or
+            #  torch._addmm_activation -- take the heuristic's first algorithm, which is slower here: 206 -> 192 frames/s on config3.)
+            y = F.linear(x2, w2)
             y = y.view(n, h, w, -1).permute(0, 3, 1, 2)
         else:
             y = self.conv(x)
