@@ -208,3 +208,31 @@ def test_lapjv_cost_limit_matches_oracle(orc):
     check(L.tlk_lsa_lapjv_limit_f64(None, 2, 0, 4, 0.5, None, y.data_ptr(), None))         # no rows: every column unmatched
     torch.cuda.synchronize()
     assert (y.cpu().numpy() == -1).all()
+
+
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("act,residual", [("relu", True), ("relu", False), ("silu", False), (None, False), (None, True)])
+def test_fused_gemm_bias_act_matches_fp32_reference(dtype_name, act, residual):
+    """tlk_gemm_bias_act (one tuned hipBLASLt call: GEMM + bias + activation + residual) vs the same op in fp32 torch.
+    Tolerance = one rounding of the output to the 16-bit type plus fp32 accumulation-order noise."""
+    import torch
+    import torch.nn.functional as F
+    from tracklab_amd import _lib
+    dt = getattr(torch, dtype_name)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for M, K, N in [(4096, 64, 256), (1000, 256, 64), (77, 128, 512)]:
+        x = torch.randn(M, K, device="cuda", generator=g).to(dt)
+        w = (torch.randn(N, K, device="cuda", generator=g) * 0.1).to(dt)
+        b = torch.randn(N, device="cuda", generator=g).to(dt)
+        r = torch.randn(M, N, device="cuda", generator=g).to(dt) if residual else None
+        out = _lib.gemm_bias_act(x, w, b, act, r)
+        if out is None:
+            pytest.skip("hipBLASLt route unavailable in this process (callers keep GEMM + tlk_bias_act_nhwc)")
+        ref = x.float() @ w.float().t() + b.float()
+        if residual:
+            ref = ref + r.float()
+        ref = F.relu(ref) if act == "relu" else (F.silu(ref) if act == "silu" else ref)
+        tol = 2e-3 if dt == torch.float16 else 1.6e-2
+        torch.testing.assert_close(out.float(), ref, rtol=tol, atol=tol * 4)
+        again = _lib.gemm_bias_act(x, w, b, act, r)                  # cached plan: identical result
+        assert torch.equal(out, again)
