@@ -57,7 +57,7 @@ class DetectionTable:
 
     def set_tracks(self, base, det_ids_frame, row_det_ids, track_ids, track_ltwh, track_conf):
         """Tracker rows of one frame keyed by detection id -> table rows [base, base + len(det_ids_frame)) (ids ascending)."""
-        if len(row_det_ids) == 0:
+        if len(row_det_ids) == 0 or len(det_ids_frame) == 0:
             return
         pos = np.searchsorted(det_ids_frame, row_det_ids)
         ok = (pos < len(det_ids_frame)) & (det_ids_frame[np.minimum(pos, len(det_ids_frame) - 1)] == row_det_ids)
