@@ -38,6 +38,9 @@ WORKLOADS = {
     "config4": dict(detector="m", objects=100, frames_per_step=24, max_dets=104, pose="m",
                     name="BASELINE configs[3] shape: YOLOX-m + RTMPose-m (256x192 SimCC) + part-based ReID + StrongSORT-family tracker "
                          "with OKS motion cost (bpbreid_strong_sort, motion_criterium oks), synthetic 1080p 100-obj stream"),
+    "config5": dict(detector="l", objects=100, frames_per_step=24, max_dets=104,
+                    name="BASELINE configs[4] per-GPU unit: YOLOX-l + part-based ReID + BPBReID-StrongSORT, one synthetic 1080p 100-obj stream "
+                         "per GPU (launch with --gpus 8 for the 8-stream configuration)"),
     "config3s": dict(detector="m", objects=100, frames_per_step=24, max_dets=104, tracker="strong_sort",
                      name="BASELINE configs[2] with the plain StrongSORT reading (cosine + IoU cost): YOLOX-m + 512-d ReID on Pillow-semantics "
                           "256x128 crops + strong_sort.StrongSORT (cosine gallery, budget 100), synthetic 1080p 100-obj stream"),
@@ -98,7 +101,7 @@ def main():
     B = S * F
     total_steps = args.warmup + args.steps
     n_frames = total_steps * F
-    is3 = args.workload in ("config3", "config4", "config3s")
+    is3 = args.workload in ("config3", "config4", "config3s", "config5")
     ssort = wl.get("tracker") == "strong_sort"
     byte = wl.get("tracker") == "byte_track"
 
