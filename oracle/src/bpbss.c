@@ -1,5 +1,5 @@
 /* CPU ORACLE (test infrastructure) -- see orc.h.
- * BPBReID-StrongSORT restated from plugins/track/bpbreid_strong_sort/{strong_sort.py, sort/*.py}. */
+ * BPBReID-StrongSORT restated from plugins/track/bpbreid_strong_sort/(strong_sort.py and the sort package). */
 #include "orc.h"
 #include <math.h>
 #include <stdlib.h>

@@ -1,6 +1,6 @@
 /*
  * oracle/src/ssort.c -- CPU ORACLE (test infrastructure, NOT product code).
- * Plain StrongSORT: plugins/track/strong_sort/{strong_sort.py, sort/*.py} restated in C.
+ * Plain StrongSORT: plugins/track/strong_sort/(strong_sort.py and the sort package) restated in C.
  *
  *   update()                      strong_sort.py:41-84      (xyxy -> xywh -> tlwh(float32) Detections, predict, update, outputs)
  *   Tracker.predict/update/_match sort/tracker.py:53-58, :81-114, :152-188
