@@ -641,11 +641,13 @@ def _import_plain_strong_sort():
     if "torchvision" not in sys.modules:
         tv = stub("torchvision")
         tv.transforms = stub("torchvision.transforms")
-    if "ultralytics" not in sys.modules:
-        stub("ultralytics")
-        stub("ultralytics.utils", LOGGER=None)
-        stub("ultralytics.utils.ops", xyxy2xywh=xyxy2xywh)
-        stub("ultralytics.utils.checks", check_requirements=None, check_version=None)
+    for name, attrs in (("ultralytics", {}), ("ultralytics.utils", dict(LOGGER=None)), ("ultralytics.utils.ops", {}),
+                        ("ultralytics.utils.checks", dict(check_requirements=None, check_version=None))):
+        m = sys.modules.get(name) or stub(name)
+        m.__dict__.update(attrs)
+        m.__path__ = getattr(m, "__path__", [])             # a package, so that submodule imports resolve through sys.modules
+    if not hasattr(sys.modules["ultralytics.utils.ops"], "xyxy2xywh"):
+        sys.modules["ultralytics.utils.ops"].xyxy2xywh = xyxy2xywh
     import strong_sort.strong_sort as ss
     from strong_sort.sort.nn_matching import NearestNeighborDistanceMetric
     from strong_sort.sort.tracker import Tracker
@@ -798,6 +800,7 @@ def _import_byte_track():
     for name in ("ultralytics", "ultralytics.utils"):
         if name not in sys.modules:
             sys.modules[name] = types.ModuleType(name)
+        sys.modules[name].__path__ = getattr(sys.modules[name], "__path__", [])
     ops = sys.modules.get("ultralytics.utils.ops") or types.ModuleType("ultralytics.utils.ops")
     ops.xyxy2xywh, ops.xywh2xyxy = xyxy2xywh, xywh2xyxy
     sys.modules["ultralytics.utils.ops"] = ops
@@ -846,11 +849,86 @@ def gen_bytetrack(out_dir):
         print(f"bytetrack_{name}: rows_out={out_off[-1]} next_id={BaseTrack._count + 1} lost={len(model.lost_stracks)} removed={len(model.removed_stracks)}")
 
 
+BOT_DEFAULTS = dict(track_high_thresh=0.45, new_track_thresh=0.6, track_buffer=30, match_thresh=0.8, proximity_thresh=0.5,
+                    appearance_thresh=0.25, frame_rate=30, lambda_=0.985)
+BOT_YAML = dict(appearance_thresh=0.4818211117541298, frame_rate=30, lambda_=0.9896143462366406, match_thresh=0.22734550911325851,
+                new_track_thresh=0.21144301345190655, proximity_thresh=0.5945380911899254, track_buffer=60,
+                track_high_thresh=0.33824964456239337)          # configs/modules/track/bot_sort.yaml (cmc_method replaced by none)
+BOT_RUNS = [  # name, hyperparams, seed, objects, frames, D, stream kwargs
+    ("defaults_s0_n60_d128", BOT_DEFAULTS, 0, 60, 100, 128, dict(low_conf_frac=0.2, miss_prob=0.05)),
+    ("yaml_s1_n40_d64", BOT_YAML, 1, 40, 150, 64, dict(low_conf_frac=0.3, miss_prob=0.1, churn_period=40)),
+    ("short_s2_n20_d32", dict(BOT_DEFAULTS, track_buffer=6, match_thresh=0.6, appearance_thresh=0.4), 2, 20, 200, 32,
+     dict(low_conf_frac=0.3, miss_prob=0.15, churn_period=25)),
+    ("classes_s3_n25_d32", dict(BOT_DEFAULTS, new_track_thresh=0.5), 3, 25, 120, 32, dict(low_conf_frac=0.25, miss_prob=0.1, churn_period=30)),
+]
+
+
+def gen_botsort(out_dir):
+    """BoT-SORT (plugins/track/bot_sort): BoTSORT.update run as is with cmc_method 'none' (the camera-motion estimators are cv2),
+    `lap` shimmed like for ByteTrack, the ReID forward (_get_features) replaced by synthetic embeddings."""
+    _import_byte_track()                                  # installs the lap / ultralytics shims
+    _import_plain_strong_sort()                           # installs the gdown / torchvision stubs the ReID loader imports
+    import bot_sort.bot_sort as bs
+    from bot_sort.basetrack import BaseTrack
+    from bot_sort.gmc import GMC
+    from bot_sort.kalman_filter import KalmanFilter
+    for name, hp, seed, nobj, nframes, D, skw in BOT_RUNS:
+        model = object.__new__(bs.BoTSORT)                # __init__ loads ReID weights (bot_sort.py:237-270)
+        model.tracked_stracks, model.lost_stracks, model.removed_stracks = [], [], []
+        BaseTrack.clear_count()
+        model.frame_id = 0
+        model.lambda_ = hp["lambda_"]; model.track_high_thresh = hp["track_high_thresh"]; model.new_track_thresh = hp["new_track_thresh"]
+        model.buffer_size = int(hp["frame_rate"] / 30.0 * hp["track_buffer"]); model.max_time_lost = model.buffer_size
+        model.kalman_filter = KalmanFilter()
+        model.proximity_thresh = hp["proximity_thresh"]; model.appearance_thresh = hp["appearance_thresh"]; model.match_thresh = hp["match_thresh"]
+        model.gmc = GMC(method="none", verbose=[None, False])
+        stream = SyntheticStream(seed, nobj, nframes, parts=1, dim=D, with_embeddings=True, **skw)
+        frame_img = np.zeros((1080, 1920, 3), dtype=np.uint8)
+        rng_cls = np.random.default_rng(500 + seed)
+        in_off, out_off, dets_all, rows = [0], [0], [], []
+        blobs = {}
+        for fr in stream:
+            dets = fr["dets"].copy()
+            emb = fr["embeddings"][:, 0, :].astype(np.float32)
+            if name.startswith("classes"):
+                dets[:, 5] = rng_cls.integers(0, 3, len(dets))            # noisy class labels: exercises the cls_hist vote
+            if fr["frame"] % 41 == 13:
+                dets, emb = dets[:0], emb[:0]
+            dets_all.append(dets)
+            in_off.append(in_off[-1] + len(dets))
+            n_out = 0
+            if len(dets) > 0:
+                keep = dets[:, 4] > 0.4                                   # wrapper filter (bot_sort_api.py:67)
+                d_in, e_in = dets[keep], emb[keep]
+                hi = d_in[:, 4] > hp["track_high_thresh"]
+                feats = torch.from_numpy(e_in[hi].copy())
+                model._get_features = lambda xywh, img, feats=feats: feats
+                out = model.update(torch.from_numpy(d_in.copy()), frame_img)
+                for r in out:
+                    rows.append([float(v) for v in r]); n_out += 1
+                f = fr["frame"]
+                if f in (0, 1, 2, 10, 40, 99, 149, 199):
+                    for lname, lst in (("trk", model.tracked_stracks), ("lost", model.lost_stracks)):
+                        blobs[f"f{f}_{lname}_ids"] = np.array([t.track_id for t in lst], dtype=np.int64)
+                        blobs[f"f{f}_{lname}_mean"] = np.array([np.asarray(t.mean, dtype=np.float64) for t in lst]).reshape(-1, 8)
+                        blobs[f"f{f}_{lname}_cov"] = np.array([np.asarray(t.covariance, dtype=np.float64) for t in lst]).reshape(-1, 8, 8)
+                        blobs[f"f{f}_{lname}_state"] = np.array([[t.state, int(t.is_activated), t.frame_id, t.start_frame, t.tracklet_len]
+                                                               for t in lst], dtype=np.int64).reshape(-1, 5)
+                        blobs[f"f{f}_{lname}_feat"] = np.array([np.asarray(t.smooth_feat, dtype=np.float32) for t in lst]).reshape(-1, D)
+            out_off.append(out_off[-1] + n_out)
+        np.savez_compressed(
+            os.path.join(out_dir, f"botsort_{name}.npz"), dets=np.concatenate(dets_all), det_offsets=np.array(in_off, dtype=np.int64),
+            out_offsets=np.array(out_off, dtype=np.int64), rows=np.array(rows, dtype=np.float64).reshape(-1, 8), config=json.dumps(hp),
+            seed=seed, n_objects=nobj, n_frames=nframes, dim=D, stream_kwargs=json.dumps(skw), min_confidence=0.4,
+            noisy_classes=int(name.startswith("classes")), **blobs)
+        print(f"botsort_{name}: rows_out={out_off[-1]} next_id={BaseTrack._count + 1} lost={len(model.lost_stracks)}")
+
+
 def main():
     out_dir = HERE
     only = set(sys.argv[1:])
     gens = {"ocsort": gen_ocsort, "iou": gen_iou_family, "kf7": gen_kf7, "lsa": gen_lsa,
-            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack}
+            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack, "botsort": gen_botsort}
     for k, fn in gens.items():
         if not only or k in only:
             fn(out_dir)
