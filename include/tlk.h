@@ -269,6 +269,46 @@ int tlk_bytetrack_get_tracks(tlk_bytetrack *h, int stream, int which, int64_t *i
                              int cap, int *n_tracks);
 
 /* ------------------------------------------------------------------------------------------
+ * BoT-SORT tracker bank (n_streams independent trackers, state + smoothed features in HBM).
+ * Replaces bot_sort.BoTSORT.update (plugins/track/bot_sort/bot_sort.py:275-485) from the point where the ReID features of
+ * the high-score detections exist: STrack (bot_sort.py:15-232: update_features, update_cls, multi_predict, multi_gmc with
+ * the identity warp, activate / re_activate / update), matching.{embedding_distance, fuse_motion, iou_distance, fuse_score,
+ * linear_assignment} (matching.py:37-48, :85-103, :127-142, :159-171, :188-196), the (x, y, w, h) KalmanFilter
+ * (kalman_filter.py:55-269), joint / sub / remove_duplicate_stracks (bot_sort.py:507-545) and the output rows (:468-485).
+ * Hyper-parameter names = configs/modules/track/bot_sort.yaml `hyperparams` (+ the wrapper's min_confidence,
+ * bot_sort_api.py:62). cmc_method must be 0 ("none", gmc.py:75-78): the other estimators are cv2 (out of scope) and
+ * tlk_botsort_create answers TLK_EUNSUPPORTED for them. A track may collect at most 16 distinct classes (cls_hist).
+ * max_tracks (live = tracked + lost) + max_dets <= 512; dim % 4 == 0.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tlk_botsort_params {
+    double track_high_thresh, new_track_thresh, match_thresh, proximity_thresh, appearance_thresh, frame_rate, lambda_;
+    double min_confidence;              /* -inf disables */
+    int32_t track_buffer;
+    int32_t cmc_method;                 /* 0 = "none" */
+    int32_t wrapper_mode;               /* 1: a frame without detections leaves the tracker untouched (bot_sort_api.py:59-60) */
+    int32_t dim;                        /* ReID embedding length */
+    int32_t max_tracks, max_dets;       /* capacities per stream (0 = 256 / 128) */
+} tlk_botsort_params;
+
+typedef tlk_bytetrack_row tlk_botsort_row;      /* same columns: bot_sort.py:471-483 */
+
+typedef struct tlk_botsort tlk_botsort;
+int tlk_botsort_create(const tlk_botsort_params *p, int n_streams, int device, tlk_botsort **out);
+int tlk_botsort_destroy(tlk_botsort *h);
+int tlk_botsort_reset(tlk_botsort *h, int stream);           /* stream < 0: all */
+/* host buffers: dets (n,7) f64 [x1,y1,x2,y2,conf,cls,tracklab_id], feats (n,dim) f32 (rows of detections with
+ * conf <= track_high_thresh are not read) -> rows (cap) */
+int tlk_botsort_update(tlk_botsort *h, int stream, const double *dets, const float *feats, int n, tlk_botsort_row *rows, int cap, int *n_out);
+/* device buffers, all streams, n_frames consecutive frames per stream, asynchronous on hip_stream:
+ * dets_dev (S, n_frames, max_dets, 7), feats_dev (S, n_frames, max_dets, dim), counts_dev (S, n_frames)
+ * -> rows_dev (S, n_frames, out_cap), out_counts_dev (S, n_frames) */
+int tlk_botsort_update_dev(tlk_botsort *h, const double *dets_dev, const float *feats_dev, const int32_t *counts_dev, int n_frames,
+                           tlk_botsort_row *rows_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream);
+/* debug/test: as tlk_bytetrack_get_tracks plus smooth_feat (., dim) f32; state: 1 tracked, 2 lost, 4 removed */
+int tlk_botsort_get_tracks(tlk_botsort *h, int stream, int which, int64_t *ids, double *mean, double *cov, int64_t *state5,
+                           float *smooth_feat, int cap, int *n_tracks);
+
+/* ------------------------------------------------------------------------------------------
  * Plain StrongSORT tracker bank (n_streams independent trackers, state + feature galleries in HBM).
  * Replaces strong_sort.StrongSORT.update (plugins/track/strong_sort/strong_sort.py:41-84) from the point where the
  * ReID features exist, i.e. Tracker.predict / Tracker.update (sort/tracker.py:53-114, _match :152-188),

@@ -117,6 +117,15 @@ run("strong_sort", lambda S: _lib.SsortBank(D, **SS, min_confidence=0.4, wrapper
     lambda ref, fr: ref.update(fr["dets"][fr["dets"][:, 4] > 0.4], fr["embeddings"][:, 0, :][fr["dets"][:, 4] > 0.4]), _lib.SSORT_ROW,
     parts=1, dim=D, with_embeddings=True)
 
+# ---- BoT-SORT (D = 512, cmc none) ----
+BO = dict(track_high_thresh=0.6, new_track_thresh=0.7, track_buffer=30, match_thresh=0.8, proximity_thresh=0.5, appearance_thresh=0.25,
+          frame_rate=30, lambda_=0.985)
+run("bot_sort", lambda S: _lib.BoTSORTBank(D, **BO, min_confidence=0.4, wrapper_mode=True, n_streams=S, max_dets=MAXD, max_tracks=256),
+    lambda: oracle.BoTSORT(D, **BO), pack_ss,
+    lambda b, B, rows, oc: b.update_dev(B["dets"].data_ptr(), B["feat"].data_ptr(), B["counts"].data_ptr(), F, rows.data_ptr(), MAXD * 2, oc.data_ptr()),
+    lambda ref, fr: ref.update(fr["dets"][fr["dets"][:, 4] > 0.4], fr["embeddings"][:, 0, :][fr["dets"][:, 4] > 0.4]), _lib.BOTSORT_ROW,
+    parts=1, dim=D, with_embeddings=True, low_conf_frac=0.2)
+
 # ---- BPBReID-StrongSORT (K = 6, D = 256) ----
 K, DP = 6, 256
 BP = dict(ema_alpha=0.9, mc_lambda=0.995, max_dist=0.5, motion_criterium="iou", max_iou_distance=0.8, max_age=300, n_init=0, nn_budget=100,

@@ -122,3 +122,36 @@ def test_hip_strongsort_module_end_to_end_on_device(orc):
                                           256, 128, "nchw", torch.float32).cpu().numpy()
     for i in range(len(df)):
         np.testing.assert_array_equal(crops[i], orc.ssort_reid_preprocess(img, sample["input"][i, :4])[0])
+
+
+def test_hip_botsort_module_end_to_end_on_device(orc):
+    """HipBoTSORT: GPU crop + ReID forward for the high-score detections + tlk_botsort bank through the plugin API; the oracle
+    tracker fed with the module's own features must give the same rows."""
+    from test_modules_host import _frame_df
+    from tracklab_amd.synth import SyntheticStream, render_frame
+    from tracklab_amd.wrappers import HipBoTSORT
+    hyper = dict(track_high_thresh=0.5, new_track_thresh=0.6, track_buffer=10, match_thresh=0.8, proximity_thresh=0.5, appearance_thresh=0.25,
+                 cmc_method="none", frame_rate=30, lambda_=0.985)
+    m = HipBoTSORT(NS(min_confidence=0.4, feature_dim=64, hyperparams=hyper), "cuda:0", tracking_dataset=None)
+    ref = orc.BoTSORT(64, **{k: v for k, v in hyper.items() if k != "cmc_method"})
+    rng = np.random.default_rng(2)
+    feats_seen = []
+    orig = m._frame_features
+    m._frame_features = lambda image, dets: feats_seen.append(orig(image, dets)) or feats_seen[-1]
+    n_rows = 0
+    for fr in SyntheticStream(6, 15, 12, miss_prob=0.05, low_conf_frac=0.3):
+        img = render_frame(rng, fr["gt_boxes"])
+        df = _frame_df(fr, np.float64, id0=200)
+        sample = m.preprocess(img, df, pd.Series({"frame": fr["frame"]}))
+        out = m.process(default_collate([sample]), df, pd.DataFrame({"file_path": ["unused"]}))
+        f = feats_seen[-1]
+        assert f.shape == (len(df), 64) and np.isfinite(f).all()
+        keep = sample["input"][:, 4] > 0.4
+        exp = ref.update(sample["input"][keep], f[keep])
+        assert len(out) == len(exp)
+        if len(exp):
+            np.testing.assert_array_equal(out.index.to_numpy(), exp[:, 7].astype(int))
+            np.testing.assert_array_equal(out.track_id.to_numpy(), exp[:, 4])
+            np.testing.assert_array_equal(np.stack(out.track_bbox_ltwh.to_list())[:, :2], exp[:, :2])
+            n_rows += len(exp)
+    assert n_rows > 50

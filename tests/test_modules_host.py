@@ -166,6 +166,65 @@ def test_strongsort_module_host_logic_with_oracle_backend(orc):
     assert seen > 300
 
 
+def test_botsort_module_host_logic_with_oracle_backend(orc):
+    """HipBoTSORT's DataFrame plumbing with the oracle standing in for the bank: the ReID forward only sees the detections above
+    track_high_thresh (bot_sort.py:293-314), rows / index / ltwh conversion as bot_sort_api.py:63-86."""
+    from tracklab_amd._lib import BOTSORT_ROW
+    from tracklab_amd.wrappers import HipBoTSORT
+    hyper = dict(track_high_thresh=0.5, new_track_thresh=0.6, track_buffer=10, match_thresh=0.8, proximity_thresh=0.5, appearance_thresh=0.25,
+                 cmc_method="none", frame_rate=30, lambda_=0.985)
+    core = {k: v for k, v in hyper.items() if k != "cmc_method"}
+    D = 32
+
+    class Backend:                                   # same surface as tracklab_amd._lib.BoTSORTBank
+        def __init__(self):
+            self.t = orc.BoTSORT(D, **core)
+
+        def update(self, dets, feat, stream):
+            keep = dets[:, 4] > 0.4                  # the bank applies min_confidence itself
+            r = self.t.update(dets[keep], feat[keep])
+            out = np.zeros(len(r), dtype=BOTSORT_ROW)
+            out["ltrb"], out["track_id"], out["cls"], out["score"], out["det_id"] = r[:, :4], r[:, 4], r[:, 5], r[:, 6], r[:, 7]
+            return out
+
+        def reset(self, stream):
+            self.t = orc.BoTSORT(D, **core)
+
+    m = HipBoTSORT(NS(min_confidence=0.4, feature_dim=D, hyperparams=hyper), "cuda:0", tracking_dataset=None)
+    assert m.level == "image" and m.batch_size == 1 and m.output_columns == ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
+    with pytest.raises(NotImplementedError):
+        HipBoTSORT(NS(hyperparams=dict(hyper, cmc_method="sparseOptFlow")), "cuda:0")
+    m._make_backend = lambda dim, h, w: Backend()
+    ref = orc.BoTSORT(D, **core)
+    frame = np.zeros((1080, 1920, 3), np.uint8)
+    seen = 0
+    for fr in SyntheticStream(5, 20, 40, parts=1, dim=D, with_embeddings=True, miss_prob=0.1, low_conf_frac=0.3):
+        df = _frame_df(fr, np.float64, id0=500)
+        emb = fr["embeddings"][:, 0, :].astype(np.float32)
+        d = fr["dets"].copy()
+        d[:, 5] = 1.0; d[:, 6] += 500
+        hi = (d[:, 4] > 0.4) & (d[:, 4] > 0.5)
+
+        def features(image, dets, emb=emb, d=d, hi=hi):
+            np.testing.assert_allclose(dets, d[hi], rtol=1e-14)        # only the high-score rows reach the network
+            return emb[hi]
+        m._features = features
+        sample = m.preprocess(frame, df, pd.Series({"frame": fr["frame"]}))
+        out = m.process(default_collate([sample]), df, pd.DataFrame({"file_path": ["unused"]}))
+        keep = d[:, 4] > 0.4
+        exp = ref.update(sample["input"][keep], emb[keep])
+        if len(exp) == 0:
+            assert len(out) == 0
+            continue
+        seen += len(exp)
+        np.testing.assert_array_equal(out.index.to_numpy(), exp[:, 7].astype(int))
+        np.testing.assert_array_equal(out.track_id.to_numpy(), exp[:, 4])
+        np.testing.assert_array_equal(np.stack(out.track_bbox_ltwh.to_list()),
+                                      np.stack([exp[:, 0], exp[:, 1], exp[:, 2] - exp[:, 0], exp[:, 3] - exp[:, 1]], axis=1))
+        np.testing.assert_array_equal(out.track_bbox_conf.to_numpy(), exp[:, 6])
+    assert seen > 300
+
+
 def test_rtmpose_module_contract_and_preprocess():
     from tracklab_amd.wrappers import HipRTMPose
     m = HipRTMPose("cuda:0", cfg=NS(arch="m", model_input_size=[192, 256], max_dets=16), tracking_dataset=None)

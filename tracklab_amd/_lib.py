@@ -594,6 +594,89 @@ class ByteTrackBank:
         return ids[:k], mean[:k], cov[:k], st[:k]
 
 
+# ------------------------------------------------------------------------------------------------
+# BoT-SORT bank
+# ------------------------------------------------------------------------------------------------
+class BoTSORTParams(C.Structure):
+    _fields_ = [("track_high_thresh", C.c_double), ("new_track_thresh", C.c_double), ("match_thresh", C.c_double),
+                ("proximity_thresh", C.c_double), ("appearance_thresh", C.c_double), ("frame_rate", C.c_double), ("lambda_", C.c_double),
+                ("min_confidence", C.c_double), ("track_buffer", C.c_int32), ("cmc_method", C.c_int32), ("wrapper_mode", C.c_int32),
+                ("dim", C.c_int32), ("max_tracks", C.c_int32), ("max_dets", C.c_int32)]
+
+
+BOTSORT_ROW = BYTETRACK_ROW
+CMC_METHODS = {"none": 0, None: 0, "orb": 1, "sift": 2, "ecc": 3, "sparseOptFlow": 4, "file": 5, "files": 5}      # gmc.py:18-78
+
+
+def _bind_botsort(L):
+    if getattr(L, "_bo_bound", False):
+        return
+    vp, ci = C.c_void_p, C.c_int
+    L.tlk_botsort_create.argtypes = [C.POINTER(BoTSORTParams), ci, ci, C.POINTER(vp)]
+    L.tlk_botsort_destroy.argtypes = [vp]
+    L.tlk_botsort_reset.argtypes = [vp, ci]
+    L.tlk_botsort_update.argtypes = [vp, ci, vp, vp, ci, vp, ci, C.POINTER(ci)]
+    L.tlk_botsort_update_dev.argtypes = [vp, vp, vp, vp, ci, vp, ci, vp, vp]
+    L.tlk_botsort_get_tracks.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, C.POINTER(ci)]
+    L._bo_bound = True
+
+
+class BoTSORTBank:
+    """``n_streams`` device-resident BoT-SORT trackers (``tlk_botsort_*``); hyper-parameter names follow ``BoTSORT.__init__``
+    (plugins/track/bot_sort/bot_sort.py:236-249). Only ``cmc_method="none"`` runs; the cv2 estimators raise TlkError(UNSUPPORTED)."""
+
+    def __init__(self, dim, track_high_thresh=0.45, new_track_thresh=0.6, track_buffer=30, match_thresh=0.8, proximity_thresh=0.5,
+                 appearance_thresh=0.25, cmc_method="none", frame_rate=30, lambda_=0.985, *, min_confidence=-np.inf, wrapper_mode=False,
+                 n_streams=1, device=0, max_tracks=256, max_dets=128):
+        L = lib()
+        _bind_botsort(L)
+        if cmc_method not in CMC_METHODS:
+            raise ValueError(f"Unknown CMC method: {cmc_method}")                  # gmc.py:80
+        self.params = BoTSORTParams(track_high_thresh, new_track_thresh, match_thresh, proximity_thresh, appearance_thresh, float(frame_rate),
+                                    lambda_, float(min_confidence), int(track_buffer), CMC_METHODS[cmc_method], int(wrapper_mode), int(dim),
+                                    max_tracks, max_dets)
+        self.n_streams, self.max_tracks, self.max_dets, self.dim = n_streams, max_tracks, max_dets, int(dim)
+        h = C.c_void_p()
+        check(L.tlk_botsort_create(C.byref(self.params), n_streams, device, C.byref(h)))
+        self._h = h
+        self._rows = np.zeros(max_tracks, dtype=BOTSORT_ROW)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tlk_botsort_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, stream=-1):
+        check(lib().tlk_botsort_reset(self._h, stream))
+
+    def update(self, dets, feats, stream=0):
+        dets = _f64(dets).reshape(-1, 7)
+        feats = np.ascontiguousarray(feats, dtype=np.float32).reshape(len(dets), self.dim)
+        n = C.c_int(0)
+        check(lib().tlk_botsort_update(self._h, stream, dets.ctypes.data, feats.ctypes.data, len(dets), self._rows.ctypes.data, len(self._rows),
+                                       C.byref(n)))
+        return self._rows[:n.value].copy()
+
+    def update_dev(self, dets, feats, counts, n_frames, rows, out_cap, out_counts, stream_ptr=None):
+        check(lib().tlk_botsort_update_dev(self._h, dets, feats, counts, n_frames, rows, out_cap, out_counts, stream_ptr))
+
+    def tracks(self, which=0, stream=0):
+        cap = self.max_tracks
+        ids, st = np.empty(cap, np.int64), np.empty((cap, 5), np.int64)
+        mean, cov, feat = np.empty((cap, 8)), np.empty((cap, 8, 8)), np.empty((cap, self.dim), np.float32)
+        n = C.c_int(0)
+        check(lib().tlk_botsort_get_tracks(self._h, stream, which, ids.ctypes.data, mean.ctypes.data, cov.ctypes.data, st.ctypes.data,
+                                           feat.ctypes.data, cap, C.byref(n)))
+        k = n.value
+        return ids[:k], mean[:k], cov[:k], st[:k], feat[:k]
+
+
 def partdist(q, qvis, g, gvis):
     """q (T,K,D) f32, qvis (T,K) u8, g (N,K,D) f32, gvis (N,K) u8 cuda tensors -> (T,N) f64 cuda tensor."""
     import torch

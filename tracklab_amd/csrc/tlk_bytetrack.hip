@@ -9,6 +9,7 @@
 // track's mean is float32 until its first predict/update, everything else float64 (-ffp-contract=off).
 #include "tlk_common.hpp"
 #include "tlk_strongsort_common.hpp"
+#include "tlk_bytetrack_common.hpp"
 
 using namespace tlk;
 
@@ -28,47 +29,6 @@ struct ByDev {
 };
 struct ByP { double track_thresh, match_thresh, det_thresh, min_conf; int max_time_lost, wrapper_mode; };
 struct ByIn { const double *dets; const int *counts; size_t stream_stride_dets, count_stride; };
-
-struct ByLds {
-    float *dbox, *dxyah;           // MAXD*4 each, by filtered detection index
-    double *dscore;                // MAXD
-    float *tbox;                   // MAXT*4 scratch (rows of the current cost matrix)
-    int *sel, *hi, *lo, *rem, *udet1;                         // MAXD
-    int *pool, *unconf, *rtr, *refind, *newlost, *removed, *newtrk, *pre, *alive, *ntr, *nlost, *dupa, *dupb;   // MAXT
-    int *x, *y, *m_r, *m_c, *u_r, *u_c;                       // NX
-    LsaWork W;                                                // NX
-    int *mi_r, *mi_c;                                         // NX
-    int *scan, *sc;
-    double *cost;                                             // rest of the LDS allocation: the current assignment problem
-};
-
-__host__ __device__ inline size_t bylds_bytes(int MAXT, int MAXD, int NX)
-{
-    size_t b = sizeof(double) * ((size_t)MAXD + 3 * (size_t)NX);
-    b += sizeof(float) * ((size_t)MAXD * 8 + (size_t)MAXT * 4);
-    b += sizeof(int) * ((size_t)MAXD * 5 + (size_t)MAXT * 13 + (size_t)NX * (6 + 4 + 2) + NWAVES + 32);
-    b += (size_t)NX * 2 + 64;
-    return (b + 15) & ~(size_t)15;
-}
-__device__ inline void bycarve(unsigned char *smem, int MAXT, int MAXD, int NX, ByLds &L)
-{
-    double *d = (double *)smem;
-    L.dscore = d; d += MAXD; L.W.u = d; d += NX; L.W.v = d; d += NX; L.W.spc = d; d += NX;
-    float *f = (float *)d;
-    L.dbox = f; f += (size_t)MAXD * 4; L.dxyah = f; f += (size_t)MAXD * 4; L.tbox = f; f += (size_t)MAXT * 4;
-    int *ip = (int *)f;
-    L.sel = ip; ip += MAXD; L.hi = ip; ip += MAXD; L.lo = ip; ip += MAXD; L.rem = ip; ip += MAXD; L.udet1 = ip; ip += MAXD;
-    L.pool = ip; ip += MAXT; L.unconf = ip; ip += MAXT; L.rtr = ip; ip += MAXT; L.refind = ip; ip += MAXT; L.newlost = ip; ip += MAXT;
-    L.removed = ip; ip += MAXT; L.newtrk = ip; ip += MAXT; L.pre = ip; ip += MAXT; L.alive = ip; ip += MAXT; L.ntr = ip; ip += MAXT;
-    L.nlost = ip; ip += MAXT; L.dupa = ip; ip += MAXT; L.dupb = ip; ip += MAXT;
-    L.x = ip; ip += NX; L.y = ip; ip += NX; L.m_r = ip; ip += NX; L.m_c = ip; ip += NX; L.u_r = ip; ip += NX; L.u_c = ip; ip += NX;
-    L.W.path = ip; ip += NX; L.W.row4col = ip; ip += NX; L.W.remaining = ip; ip += NX; L.W.col4row = ip; ip += NX;
-    L.mi_r = ip; ip += NX; L.mi_c = ip; ip += NX;
-    L.scan = ip; ip += NWAVES; L.sc = ip; ip += 32;
-    unsigned char *bp = (unsigned char *)ip;
-    L.W.SR = bp; bp += NX; L.W.SC = bp; bp += NX;
-    L.cost = (double *)(((uintptr_t)bp + 15) & ~(uintptr_t)15);
-}
 
 // multi_predict (kalman_filter.py:155-193): left = F cov first, then left F^T; noise from a float32 mean array stays float32
 __device__ __forceinline__ void kfb_predict(double (&mean)[8], double (&cov)[64], bool all_f32)
@@ -112,68 +72,6 @@ __device__ __forceinline__ void trk_tlbr32(const BTrk &T, float *o)
         r2 *= r3; r0 -= r2 / 2; r1 -= r3 / 2;
         o[0] = (float)r0; o[1] = (float)r1; o[2] = (float)(r2 + r0); o[3] = (float)(r3 + r1);
     }
-}
-
-__device__ __forceinline__ float bbox_iou32(const float *b, const float *q)       // matching.py:181-217
-{
-    const float box_area = (q[2] - q[0] + 1) * (q[3] - q[1] + 1);
-    const float iw = (b[2] < q[2] ? b[2] : q[2]) - (b[0] > q[0] ? b[0] : q[0]) + 1;
-    if (iw > 0) {
-        const float ih = (b[3] < q[3] ? b[3] : q[3]) - (b[1] > q[1] ? b[1] : q[1]) + 1;
-        if (ih > 0) {
-            const float uaf = (b[2] - b[0] + 1) * (b[3] - b[1] + 1) + box_area - iw * ih;
-            return (float)((double)(iw * ih) / (double)uaf);
-        }
-    }
-    return 0.f;
-}
-
-struct AsgOut { int nm, n_ur, n_uc; };
-// linear_assignment (matching.py:37-48): lap.lapjv(extend_cost=True, cost_limit=thresh) on cost(i, j), i < nr, j < nc.
-// lap embeds the problem in an (nr+nc)^2 one with thresh/2 padding; its objective is
-//   sum over matched pairs of c_ij  +  (unmatched rows + unmatched columns) * thresh / 2  =  const + sum over matched (c_ij - thresh),
-// i.e. a rectangular assignment on min(c_ij - thresh, 0) where a row sitting on a 0 entry is "unmatched". That problem is nr x nc
-// (4x fewer entries, and it fits the LDS cost area) and has the same optimal pair set whenever no two real costs tie
-// (tlk_lsa_lapjv_limit_f64 keeps the literal embedding; tests compare the two). Fills L.m_r/m_c (matches, ascending rows),
-// L.u_r, L.u_c (ascending). All 256 threads call.
-template <class CostFn>
-__device__ AsgOut lapjv_assign(int nr, int nc, double thresh, CostFn cost, double *ebuf, double *lds_cost, int lds_entries, ByLds &L)
-{
-    AsgOut o{0, 0, 0};
-    const int tid = threadIdx.x;
-    if (nr == 0 || nc == 0) {
-        for (int i = tid; i < nr; i += BLOCK) L.u_r[i] = i;
-        for (int j = tid; j < nc; j += BLOCK) L.u_c[j] = j;
-        o.n_ur = nr; o.n_uc = nc;
-        __syncthreads();
-        return o;
-    }
-    double *cm = (nr * nc <= lds_entries) ? lds_cost : ebuf;
-    for (int e = tid; e < nr * nc; e += BLOCK) {
-        const int r = e / nc, c = e - r * nc;
-        const double v = cost(r, c) - thresh;
-        cm[e] = v < 0.0 ? v : 0.0;
-    }
-    for (int i = tid; i < nr; i += BLOCK) L.x[i] = -1;
-    for (int j = tid; j < nc; j += BLOCK) L.y[j] = -1;
-    __threadfence_block();
-    __syncthreads();
-    if (tid < WAVE) {
-        const int r = wave_lsa(cm, nr, nc, (size_t)nc, (size_t)1, L.W, L.mi_r, L.mi_c);
-        if (tid == 0) L.sc[0] = r < 0 ? 0 : r;
-    }
-    __syncthreads();
-    const int np = L.sc[0];
-    for (int k = tid; k < np; k += BLOCK) {
-        const int r = L.mi_r[k], c = L.mi_c[k];
-        if (cm[(size_t)r * nc + c] < 0.0) { L.x[r] = c; L.y[c] = r; }
-    }
-    __syncthreads();
-    o.nm = block_compact(nr, [&](int i) { return L.x[i] >= 0; }, [&](int i, int pos) { L.m_r[pos] = i; L.m_c[pos] = L.x[i]; }, L.scan);
-    o.n_ur = block_compact(nr, [&](int i) { return L.x[i] < 0; }, [&](int i, int pos) { L.u_r[pos] = i; }, L.scan);
-    o.n_uc = block_compact(nc, [&](int j) { return L.y[j] < 0; }, [&](int j, int pos) { L.u_c[pos] = j; }, L.scan);
-    __syncthreads();
-    return o;
 }
 
 __global__ void __launch_bounds__(BLOCK, 1)

@@ -188,30 +188,11 @@ class HipByteTrack(ImageLevelModule):
                              "track_id": list(rows["track_id"].astype(float))}, index=pd.Index(idxs, name="idxs"))
 
 
-class HipStrongSORT(ImageLevelModule):
-    """Plain StrongSORT (tracklab/wrappers/track/strong_sort_api.py:17-105): the tracker owns its ReID network. Crops are cut
-    and resized on the GPU with the reference's own arithmetic (int-truncated box, Pillow bilinear, ImageNet normalisation:
-    tlk_roi_crop_pil_resize_norm), one backbone forward gives the 512-d features, tlk_ssort_update does the rest."""
-    input_columns = ["bbox_ltwh", "bbox_conf", "category_id"]
-    output_columns = ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
-
-    def __init__(self, cfg, device, **kwargs):
-        super().__init__(batch_size=1)
-        self.cfg = cfg
-        self.device = device
-        self._bank = None
-        self._model = None
-        self._img_hw = None
-        if cfg_get(cfg, "ecc", False):
-            raise NotImplementedError("ecc camera compensation (sort/track.py:130-239, cv2.findTransformECC) is not part of the HIP path; "
-                                      "set ecc: false")
-
-    def _make_backend(self, dim, img_h, img_w):
-        from .._lib import SsortBank
-        hyper = dict(cfg_get(self.cfg, "hyperparams"))
-        return SsortBank(dim, **hyper, min_confidence=float(cfg_get(self.cfg, "min_confidence", 0.0)), wrapper_mode=True,
-                         img_w=int(img_w), img_h=int(img_h), device=_device_index(self.device),
-                         max_tracks=int(cfg_get(self.cfg, "max_tracks", 256)), max_dets=int(cfg_get(self.cfg, "max_dets", 128)))
+class _ReidTrackerBase:
+    """What the two trackers that own a ReID network share (strong_sort_api.py / bot_sort_api.py are the same wrapper around a
+    different tracker): DataFrame -> (n, 7) rows, GPU crop-out + backbone forward, bank update, rows -> DataFrame. A mixin, not a
+    base module: TrackLab derives a module's level from its FIRST base class (pipeline/module.py:33-37)."""
+    _conf_field = "conf"
 
     def reset(self):
         """New video (strong_sort_api.py:31-40 rebuilds model + tracker): state dropped, ids restart at 1."""
@@ -253,6 +234,9 @@ class HipStrongSORT(ImageLevelModule):
             emb, _ = self._model(crops)
         return to_numpy(emb[:, 0, :].float())
 
+    def _frame_features(self, image, inputs):
+        return self._features(image, inputs)
+
     def process(self, batch, detections: pd.DataFrame, metadatas: pd.DataFrame):
         if len(detections) == 0:
             return []
@@ -266,7 +250,7 @@ class HipStrongSORT(ImageLevelModule):
         if getattr(image, "ndim", 3) == 4:
             image = image[0]
         h, w = int(image.shape[0]), int(image.shape[1])
-        feats = self._features(image, inputs)
+        feats = self._frame_features(image, inputs)
         if self._bank is None or self._img_hw != (h, w):
             self._bank = self._make_backend(feats.shape[1], h, w)
             self._img_hw = (h, w)
@@ -276,8 +260,74 @@ class HipStrongSORT(ImageLevelModule):
         ltrb = rows["ltrb"]
         ltwh = np.stack([ltrb[:, 0], ltrb[:, 1], ltrb[:, 2] - ltrb[:, 0], ltrb[:, 3] - ltrb[:, 1]], axis=1)      # ltrb_to_ltwh
         # no subset assert: like the reference (strong_sort_api.py:85-89) a coasting track reports the id of its previous detection
-        return pd.DataFrame({"track_bbox_ltwh": list(ltwh), "track_bbox_conf": list(rows["conf"]),
+        return pd.DataFrame({"track_bbox_ltwh": list(ltwh), "track_bbox_conf": list(rows[self._conf_field]),
                              "track_id": list(rows["track_id"].astype(float))}, index=pd.Index(rows["det_id"].astype(int), name="idxs"))
+
+
+class HipStrongSORT(ImageLevelModule, _ReidTrackerBase):
+    """Plain StrongSORT (tracklab/wrappers/track/strong_sort_api.py:17-105): the tracker owns its ReID network. Crops are cut
+    and resized on the GPU with the reference's own arithmetic (int-truncated box, Pillow bilinear, ImageNet normalisation:
+    tlk_roi_crop_pil_resize_norm), one backbone forward gives the 512-d features, tlk_ssort_update does the rest."""
+    input_columns = ["bbox_ltwh", "bbox_conf", "category_id"]
+    output_columns = ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
+    preprocess, process, reset = _ReidTrackerBase.preprocess, _ReidTrackerBase.process, _ReidTrackerBase.reset    # ahead of the abstract ones in the MRO
+
+    def __init__(self, cfg, device, **kwargs):
+        super().__init__(batch_size=1)
+        self.cfg = cfg
+        self.device = device
+        self._bank = None
+        self._model = None
+        self._img_hw = None
+        if cfg_get(cfg, "ecc", False):
+            raise NotImplementedError("ecc camera compensation (sort/track.py:130-239, cv2.findTransformECC) is not part of the HIP path; "
+                                      "set ecc: false")
+
+    def _make_backend(self, dim, img_h, img_w):
+        from .._lib import SsortBank
+        hyper = dict(cfg_get(self.cfg, "hyperparams"))
+        return SsortBank(dim, **hyper, min_confidence=float(cfg_get(self.cfg, "min_confidence", 0.0)), wrapper_mode=True,
+                         img_w=int(img_w), img_h=int(img_h), device=_device_index(self.device),
+                         max_tracks=int(cfg_get(self.cfg, "max_tracks", 256)), max_dets=int(cfg_get(self.cfg, "max_dets", 128)))
+
+
+class HipBoTSORT(ImageLevelModule, _ReidTrackerBase):
+    """BoT-SORT (tracklab/wrappers/track/bot_sort_api.py:16-88). Same crop-out as plain StrongSORT (both use
+    ReIDDetectMultiBackend's ToPILImage / Resize / Normalize on the int-truncated box: bot_sort.py:487-505,
+    deep_oc_sort/reid_multibackend.py:44-53), features only for the detections above track_high_thresh (bot_sort.py:293-314),
+    tlk_botsort_update for the rest. cmc_method must be "none": the camera-motion estimators are cv2 (gmc.py)."""
+    input_columns = ["bbox_ltwh", "bbox_conf", "category_id"]
+    output_columns = ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
+    _conf_field = "score"
+    preprocess, process, reset = _ReidTrackerBase.preprocess, _ReidTrackerBase.process, _ReidTrackerBase.reset    # ahead of the abstract ones in the MRO
+
+    def __init__(self, cfg, device, **kwargs):
+        super().__init__(batch_size=1)
+        self.cfg = cfg
+        self.device = device
+        self._bank = None
+        self._model = None
+        self._img_hw = None
+        cmc = dict(cfg_get(cfg, "hyperparams")).get("cmc_method", "sparseOptFlow")
+        if cmc not in ("none", None):
+            raise NotImplementedError(f"cmc_method {cmc!r} (gmc.py: cv2 feature / optical-flow / ECC estimators) is not part of the HIP path; "
+                                      "set cmc_method: none")
+
+    def _make_backend(self, dim, img_h, img_w):
+        from .._lib import BoTSORTBank
+        hyper = dict(cfg_get(self.cfg, "hyperparams"))
+        return BoTSORTBank(dim, **hyper, min_confidence=float(cfg_get(self.cfg, "min_confidence", 0.0)), wrapper_mode=True,
+                           device=_device_index(self.device), max_tracks=int(cfg_get(self.cfg, "max_tracks", 256)),
+                           max_dets=int(cfg_get(self.cfg, "max_dets", 128)))
+
+    def _frame_features(self, image, inputs):
+        hyper = dict(cfg_get(self.cfg, "hyperparams"))
+        hi = (inputs[:, 4] > float(cfg_get(self.cfg, "min_confidence", 0.0))) & (inputs[:, 4] > float(hyper.get("track_high_thresh", 0.45)))
+        dim = int(cfg_get(self.cfg, "feature_dim", 512))
+        feats = np.zeros((len(inputs), dim), dtype=np.float32)
+        if hi.any():
+            feats[hi] = self._features(image, inputs[hi])
+        return feats
 
 
 def _strip(a, ndim):
