@@ -924,11 +924,99 @@ def gen_botsort(out_dir):
         print(f"botsort_{name}: rows_out={out_off[-1]} next_id={BaseTrack._count + 1} lost={len(model.lost_stracks)}")
 
 
+DOC_YAML = dict(det_thresh=0, max_age=50, min_hits=1, iou_threshold=0.22136877277096445, delta_t=1, asso_func="giou",
+                inertia=0.3941737016672115, w_association_emb=0.75, alpha_fixed_emb=0.95, aw_param=0.5, embedding_off=False,
+                cmc_off=True, aw_off=False, new_kf_off=False)     # configs/modules/track/deep_oc_sort.yaml (cmc_off: cv2 optical flow)
+DOC_DEFAULTS = dict(det_thresh=0.3, max_age=30, min_hits=3, iou_threshold=0.3, delta_t=3, asso_func="iou", inertia=0.2,
+                    w_association_emb=0.75, alpha_fixed_emb=0.95, aw_param=0.5, embedding_off=False, cmc_off=True, aw_off=False,
+                    new_kf_off=False)
+DOC_RUNS = [  # name, hyperparams, seed, objects, frames, D, normalise the detector embeddings, stream kwargs
+    ("yaml_s0_n60_d128", DOC_YAML, 0, 60, 100, 128, True, dict(miss_prob=0.05)),
+    ("defaults_s1_n40_d64", DOC_DEFAULTS, 1, 40, 150, 64, True, dict(low_conf_frac=0.2, miss_prob=0.15, churn_period=40)),
+    ("rawemb_awoff_s2_n20_d32", dict(DOC_YAML, aw_off=True, max_age=8, asso_func="diou", delta_t=2), 2, 20, 200, 32, False,
+     dict(miss_prob=0.2, churn_period=25)),
+    ("classes_s3_n25_d32", dict(DOC_YAML, asso_func="ciou", w_association_emb=0.4, aw_param=0.7, alpha_fixed_emb=0.8), 3, 25, 120, 32, True,
+     dict(miss_prob=0.1, churn_period=30)),
+]
+
+
+def gen_deepocsort(out_dir):
+    """Deep-OC-SORT (plugins/track/deep_oc_sort): OCSort.update run as is with cmc_off (CMCComputer is cv2 optical flow), the ReID
+    forward (_get_features) replaced by synthetic float32 torch embeddings (the reference mixes torch tensors and numpy scalars:
+    the dtype trail of the track embeddings comes from running it), scipy's linear_sum_assignment (`lap` is not installed in
+    the reference's fallback path: association.py:202-212)."""
+    _install_filterpy_shim()
+    _import_plain_strong_sort()                           # cv2 / gdown / torchvision / ultralytics stubs for the module imports
+    saved_lap = sys.modules.get("lap", "absent")
+    sys.modules["lap"] = None                             # `import lap` raises ImportError -> scipy fallback
+    import deep_oc_sort.ocsort as doc
+    try:
+        for name, hp, seed, nobj, nframes, D, normed, skw in DOC_RUNS:
+            model = object.__new__(doc.OCSort)            # __init__ loads ReID weights and builds the cv2 CMC (ocsort.py:386-391)
+            model.max_age, model.min_hits, model.iou_threshold = hp["max_age"], hp["min_hits"], hp["iou_threshold"]
+            model.trackers, model.frame_count, model.det_thresh, model.delta_t = [], 0, hp["det_thresh"], hp["delta_t"]
+            model.asso_func, model.inertia = doc.ASSO_FUNCS[hp["asso_func"]], hp["inertia"]
+            model.w_association_emb, model.alpha_fixed_emb, model.aw_param = hp["w_association_emb"], hp["alpha_fixed_emb"], hp["aw_param"]
+            doc.KalmanBoxTracker.count = 0
+            model.embedding_off, model.cmc_off, model.aw_off, model.new_kf_off = hp["embedding_off"], hp["cmc_off"], hp["aw_off"], hp["new_kf_off"]
+            stream = SyntheticStream(seed, nobj, nframes, parts=1, dim=D, with_embeddings=True, **skw)
+            frame_img = np.zeros((1080, 1920, 3), dtype=np.uint8)
+            rng_cls = np.random.default_rng(700 + seed)
+            in_off, out_off, dets_all, embs_all, rows = [0], [0], [], [], []
+            blobs = {}
+            for fr in stream:
+                dets = fr["dets"].copy()
+                emb = fr["embeddings"][:, 0, :].astype(np.float32)
+                if normed:
+                    emb = emb / np.linalg.norm(emb, axis=1, keepdims=True)
+                if name.startswith("classes"):
+                    dets[:, 5] = rng_cls.integers(0, 3, len(dets))        # class 0 zeroes the angle cost ("scores" is the class column)
+                if fr["frame"] % 43 == 17:
+                    dets, emb = dets[:0], emb[:0]
+                dets_all.append(dets); embs_all.append(emb)
+                in_off.append(in_off[-1] + len(dets))
+                n_out = 0
+                if len(dets) > 0:
+                    keep = dets[:, 4] > 0.4                               # wrapper filter (deep_oc_sort_api.py:62)
+                    d_in, e_in = dets[keep], emb[keep]
+                    thr = d_in[:, 4] > hp["det_thresh"]
+                    feats = torch.from_numpy(e_in[thr].copy())
+                    model._get_features = lambda xyxy, img, feats=feats: feats
+                    out = model.update(torch.from_numpy(d_in.copy()), frame_img)
+                    for r in np.asarray(out, dtype=np.float64).reshape(-1, 8):
+                        rows.append(list(r)); n_out += 1
+                    f = fr["frame"]
+                    if f in (0, 1, 2, 3, 10, 40, 99, 149, 199):
+                        T = model.trackers
+                        blobs[f"f{f}_ids"] = np.array([t.id for t in T], dtype=np.int64)
+                        blobs[f"f{f}_x"] = np.array([t.kf.x[:, 0] for t in T], dtype=np.float64).reshape(-1, 8)
+                        blobs[f"f{f}_P"] = np.array([t.kf.P for t in T], dtype=np.float64).reshape(-1, 8, 8)
+                        blobs[f"f{f}_emb"] = np.array([np.asarray(t.emb, dtype=np.float64) for t in T]).reshape(-1, D)
+                        blobs[f"f{f}_emb_f64"] = np.array([int(np.asarray(t.emb).dtype == np.float64) for t in T], dtype=np.int64)
+                        blobs[f"f{f}_state"] = np.array([[t.time_since_update, t.hits, t.hit_streak, t.age, int(t.frozen), int(t.kf.observed)]
+                                                         for t in T], dtype=np.int64).reshape(-1, 6)
+                        blobs[f"f{f}_vel"] = np.array([t.velocity if t.velocity is not None else (0, 0) for t in T], dtype=np.float64).reshape(-1, 2)
+                        blobs[f"f{f}_last"] = np.array([t.last_observation for t in T], dtype=np.float64).reshape(-1, 5)
+                out_off.append(out_off[-1] + n_out)
+            np.savez_compressed(
+                os.path.join(out_dir, f"deepocsort_{name}.npz"), dets=np.concatenate(dets_all), embeddings=np.concatenate(embs_all),
+                det_offsets=np.array(in_off, dtype=np.int64), out_offsets=np.array(out_off, dtype=np.int64),
+                rows=np.array(rows, dtype=np.float64).reshape(-1, 8), config=json.dumps(hp), seed=seed, n_objects=nobj, n_frames=nframes, dim=D,
+                stream_kwargs=json.dumps(skw), min_confidence=0.4, **blobs)
+            print(f"deepocsort_{name}: rows_out={out_off[-1]} next_id={doc.KalmanBoxTracker.count} live={len(model.trackers)} "
+                  f"f64_embs={sum(int(np.asarray(t.emb).dtype == np.float64) for t in model.trackers)}")
+    finally:
+        if saved_lap == "absent":
+            sys.modules.pop("lap", None)
+        else:
+            sys.modules["lap"] = saved_lap
+
+
 def main():
     out_dir = HERE
     only = set(sys.argv[1:])
     gens = {"ocsort": gen_ocsort, "iou": gen_iou_family, "kf7": gen_kf7, "lsa": gen_lsa,
-            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack, "botsort": gen_botsort}
+            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack, "botsort": gen_botsort, "deepocsort": gen_deepocsort}
     for k, fn in gens.items():
         if not only or k in only:
             fn(out_dir)
