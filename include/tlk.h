@@ -269,6 +269,44 @@ int tlk_bytetrack_get_tracks(tlk_bytetrack *h, int stream, int which, int64_t *i
                              int cap, int *n_tracks);
 
 /* ------------------------------------------------------------------------------------------
+ * Deep-OC-SORT tracker bank (n_streams independent trackers, state + embeddings in HBM).
+ * Replaces deep_oc_sort.ocsort.OCSort.update (plugins/track/deep_oc_sort/ocsort.py:392-534) from the point where the ReID
+ * embeddings of the detections exist: KalmanBoxTracker with the (x, y, w, h) filter (ocsort.py:94-330,
+ * kalmanfilter.py:340-569 incl. freeze / unfreeze), associate + compute_aw_max_metric (association.py:263-364), the OCR
+ * second round, update_emb, births / deaths and the output rows.
+ * Hyper-parameter names = configs/modules/track/deep_oc_sort.yaml `hyperparams` (+ the wrapper's min_confidence,
+ * deep_oc_sort_api.py:62). cmc_off must be 1 (cmc.py is cv2), embedding_off and new_kf_off must be 0:
+ * tlk_deepocsort_create answers TLK_EUNSUPPORTED otherwise. delta_t < 8, max_tracks <= 512, max_dets <= 256.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tlk_deepocsort_params {
+    double det_thresh, iou_threshold, inertia, w_association_emb, alpha_fixed_emb, aw_param;
+    double min_confidence;              /* -inf disables */
+    int32_t max_age, min_hits, delta_t;
+    int32_t asso_func;                  /* TLK_IOU .. TLK_CT */
+    int32_t embedding_off, cmc_off, aw_off, new_kf_off;
+    int32_t wrapper_mode;               /* 1: a frame without detections leaves the tracker untouched (deep_oc_sort_api.py:59-60) */
+    int32_t dim;                        /* embedding length */
+    int32_t max_tracks, max_dets;       /* capacities per stream (0 = 256 / 128) */
+} tlk_deepocsort_params;
+
+typedef struct tlk_deepocsort tlk_deepocsort;
+int tlk_deepocsort_create(const tlk_deepocsort_params *p, int n_streams, int device, tlk_deepocsort **out);
+int tlk_deepocsort_destroy(tlk_deepocsort *h);
+int tlk_deepocsort_reset(tlk_deepocsort *h, int stream);     /* stream < 0: all */
+/* host buffers: dets (n,7) f64 [x1,y1,x2,y2,conf,cls,tracklab_id], embs (n,dim) f32 -> out (rows,8) f64
+ * [x1,y1,x2,y2,track_id(+1),cls,conf,tracklab_id] (ocsort.py:527-529) */
+int tlk_deepocsort_update(tlk_deepocsort *h, int stream, const double *dets, const float *embs, int n, double *out, int out_cap, int *n_out);
+/* device buffers, all streams, n_frames consecutive frames per stream, ONE launch, asynchronous on hip_stream:
+ * dets_dev (S, n_frames, max_dets, 7), embs_dev (S, n_frames, max_dets, dim), counts_dev (S, n_frames)
+ * -> out_dev (S, n_frames, out_cap, 8), out_counts_dev (S, n_frames) */
+int tlk_deepocsort_update_dev(tlk_deepocsort *h, const double *dets_dev, const float *embs_dev, const int32_t *counts_dev, int n_frames,
+                              double *out_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream);
+/* debug/test, trackers in list order: ids, x (.,8), P (.,8,8), emb (.,dim), state6 (.,6) [time_since_update, hits, hit_streak, age,
+ * frozen, kf.observed], velocity (.,2), last_observation (.,5); none may be NULL */
+int tlk_deepocsort_get_tracks(tlk_deepocsort *h, int stream, int64_t *ids, double *x, double *P, float *emb, int64_t *state6, double *vel,
+                              double *last, int cap, int *n_tracks);
+
+/* ------------------------------------------------------------------------------------------
  * BoT-SORT tracker bank (n_streams independent trackers, state + smoothed features in HBM).
  * Replaces bot_sort.BoTSORT.update (plugins/track/bot_sort/bot_sort.py:275-485) from the point where the ReID features of
  * the high-score detections exist: STrack (bot_sort.py:15-232: update_features, update_cls, multi_predict, multi_gmc with

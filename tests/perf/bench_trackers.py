@@ -126,6 +126,16 @@ run("bot_sort", lambda S: _lib.BoTSORTBank(D, **BO, min_confidence=0.4, wrapper_
     lambda ref, fr: ref.update(fr["dets"][fr["dets"][:, 4] > 0.4], fr["embeddings"][:, 0, :][fr["dets"][:, 4] > 0.4]), _lib.BOTSORT_ROW,
     parts=1, dim=D, with_embeddings=True, low_conf_frac=0.2)
 
+# ---- Deep-OC-SORT (D = 512, cmc off; unit-norm detector embeddings) ----
+DOC = dict(det_thresh=0, max_age=50, min_hits=1, iou_threshold=0.22136877277096445, delta_t=1, asso_func="giou", inertia=0.3941737016672115,
+           w_association_emb=0.75, alpha_fixed_emb=0.95, aw_param=0.5, embedding_off=False, cmc_off=True, aw_off=False, new_kf_off=False)
+DOC_ROW = np.dtype([("r", "<f8", (8,))])
+run("deep_oc_sort", lambda S: _lib.DeepOCSortBank(D, **DOC, min_confidence=0.4, wrapper_mode=True, n_streams=S, max_dets=MAXD, max_tracks=256),
+    lambda: oracle.DeepOCSort(D, **DOC), pack_ss,
+    lambda b, B, rows, oc: b.update_dev(B["dets"].data_ptr(), B["feat"].data_ptr(), B["counts"].data_ptr(), F, rows.data_ptr(), MAXD * 2, oc.data_ptr()),
+    lambda ref, fr: ref.update(fr["dets"][fr["dets"][:, 4] > 0.4], fr["embeddings"][:, 0, :][fr["dets"][:, 4] > 0.4]), DOC_ROW,
+    parts=1, dim=D, with_embeddings=True)
+
 # ---- BPBReID-StrongSORT (K = 6, D = 256) ----
 K, DP = 6, 256
 BP = dict(ema_alpha=0.9, mc_lambda=0.995, max_dist=0.5, motion_criterium="iou", max_iou_distance=0.8, max_age=300, n_init=0, nn_budget=100,

@@ -1,0 +1,94 @@
+"""-m gpu: Deep-OC-SORT on the GPU (tlk_deepocsort_* through the C ABI) against the reference's golden runs and the oracle."""
+import numpy as np
+import pytest
+
+from test_oracle_deepocsort import RUNS, check_state, replay
+
+pytestmark = pytest.mark.gpu
+
+
+class GpuTracker:
+    def __init__(self, D, hp, **kw):
+        from tracklab_amd._lib import DeepOCSortBank
+        self.bank = DeepOCSortBank(D, **hp, **kw)
+
+    def update(self, dets, embs):
+        return self.bank.update(dets, embs)
+
+    def tracks(self):
+        return self.bank.tracks()
+
+
+@pytest.mark.parametrize("name", RUNS)
+def test_deepocsort_gpu_matches_reference(name):
+    replay(name, lambda D, hp: GpuTracker(D, hp), check_state)
+
+
+@pytest.mark.parametrize("D,asso,aw_off", [(32, "giou", False), (512, "iou", True)])
+def test_deepocsort_gpu_vs_oracle_and_min_confidence(orc, D, asso, aw_off):
+    """Same stream through both: rows, ids, counters and the Kalman state are bit-identical (same fp64 operation order); the float32
+    embeddings agree to the rounding of the norm's summation order (wavefront reduction here, serial loop in the oracle)."""
+    from tracklab_amd.synth import SyntheticStream
+    hp = dict(det_thresh=0.45, max_age=6, min_hits=1, iou_threshold=0.25, delta_t=2, asso_func=asso, inertia=0.3, w_association_emb=0.6,
+              alpha_fixed_emb=0.9, aw_param=0.4, embedding_off=False, cmc_off=True, aw_off=aw_off, new_kf_off=False)
+    gpu, cpu = GpuTracker(D, hp, min_confidence=0.3), orc.DeepOCSort(D, **hp)
+    rng = np.random.default_rng(5)
+    for fr in SyntheticStream(12, 50, 90, parts=1, dim=D, with_embeddings=True, miss_prob=0.15, churn_period=20, low_conf_frac=0.2):
+        d = fr["dets"].copy()
+        d[:, 5] = rng.integers(0, 3, len(d))
+        e = fr["embeddings"][:, 0, :].astype(np.float32)
+        e /= np.linalg.norm(e, axis=1, keepdims=True)
+        keep = d[:, 4] > 0.3
+        a, b = gpu.update(d, e), cpu.update(d[keep], e[keep])
+        np.testing.assert_array_equal(a, b)
+        gi, gx, gP, ge, gs, gv, gl = gpu.tracks()
+        ci, cx, cP, ce, cs, cv, cl = cpu.tracks()
+        np.testing.assert_array_equal(gi, ci); np.testing.assert_array_equal(gs, cs)
+        np.testing.assert_array_equal(gx, cx); np.testing.assert_array_equal(gP, cP)
+        np.testing.assert_array_equal(gv, cv); np.testing.assert_array_equal(gl, cl)
+        np.testing.assert_allclose(ge, ce, rtol=0, atol=1e-6)
+
+
+def test_deepocsort_bank_batched_frames_and_reset():
+    import torch
+    from tracklab_amd._lib import DeepOCSortBank
+    from tracklab_amd.synth import SyntheticStream
+    S, F, MAXD, D = 3, 15, 64, 64
+    hp = dict(det_thresh=0.3, max_age=5, min_hits=1, delta_t=1, asso_func="giou", cmc_off=True)
+    kw = dict(max_dets=MAXD, max_tracks=128, min_confidence=0.4, wrapper_mode=True)
+    bank = DeepOCSortBank(D, **hp, n_streams=S, **kw)
+    ref = [DeepOCSortBank(D, **hp, **kw) for _ in range(S)]
+    dets = np.zeros((S, F, MAXD, 7)); embs = np.zeros((S, F, MAXD, D), np.float32); counts = np.zeros((S, F), np.int32)
+    expect = [[None] * F for _ in range(S)]
+    for s in range(S):
+        for f, fr in enumerate(SyntheticStream(30 + s, 25, F, parts=1, dim=D, with_embeddings=True, low_conf_frac=0.2, miss_prob=0.1)):
+            n = len(fr["dets"]) if (f + s) % 6 else 0               # some empty frames: wrapper_mode leaves the tracker untouched
+            dets[s, f, :n] = fr["dets"][:n]; embs[s, f, :n] = fr["embeddings"][:n, 0, :]; counts[s, f] = n
+            expect[s][f] = ref[s].update(dets[s, f, :n], embs[s, f, :n])
+    cap = 128
+    out = torch.zeros((S, F, cap, 8), dtype=torch.float64, device="cuda")
+    ocnt = torch.zeros((S, F), dtype=torch.int32, device="cuda")
+    d_dets, d_embs, d_cnt = torch.from_numpy(dets).cuda(), torch.from_numpy(embs).cuda(), torch.from_numpy(counts).cuda()
+    bank.update_dev(d_dets.data_ptr(), d_embs.data_ptr(), d_cnt.data_ptr(), F, out.data_ptr(), cap, ocnt.data_ptr())
+    torch.cuda.synchronize()
+    got, oc = out.cpu().numpy(), ocnt.cpu().numpy()
+    for s in range(S):
+        for f in range(F):
+            e = expect[s][f]
+            assert oc[s, f] == len(e)
+            np.testing.assert_array_equal(got[s, f, :len(e)], e)
+    bank.reset(2)
+    fr = next(iter(SyntheticStream(77, 6, 1, parts=1, dim=D, with_embeddings=True)))
+    r = bank.update(fr["dets"], fr["embeddings"][:, 0, :], stream=2)
+    assert sorted(r[:, 4]) == list(range(1, len(r) + 1)) and len(r) > 0          # ids restart at 1
+
+
+def test_deepocsort_rejects_bad_configuration():
+    from tracklab_amd._lib import DeepOCSortBank, TlkError
+    for bad in (dict(cmc_off=False), dict(cmc_off=True, embedding_off=True), dict(cmc_off=True, new_kf_off=True), dict(cmc_off=True, delta_t=9),
+                dict(cmc_off=True, max_tracks=1024)):
+        with pytest.raises(TlkError):
+            DeepOCSortBank(64, **bad)
+    b = DeepOCSortBank(32, cmc_off=True, max_dets=8)
+    with pytest.raises(TlkError):
+        b.update(np.zeros((9, 7)), np.zeros((9, 32), np.float32))

@@ -225,6 +225,55 @@ def test_botsort_module_host_logic_with_oracle_backend(orc):
     assert seen > 300
 
 
+def test_deepocsort_module_host_logic_with_oracle_backend(orc):
+    """HipDeepOCSORT's DataFrame plumbing with the oracle standing in for the bank (rows / index / ltwh as deep_oc_sort_api.py:63-82)."""
+    from tracklab_amd.wrappers import HipDeepOCSORT
+    hyper = dict(det_thresh=0.45, max_age=10, min_hits=1, iou_threshold=0.25, delta_t=2, asso_func="giou", inertia=0.3, w_association_emb=0.75,
+                 alpha_fixed_emb=0.95, aw_param=0.5, embedding_off=False, cmc_off=True, aw_off=False, new_kf_off=False)
+    D = 32
+
+    class Backend:                                   # same surface as tracklab_amd._lib.DeepOCSortBank
+        def __init__(self):
+            self.t = orc.DeepOCSort(D, **hyper)
+
+        def update(self, dets, emb, stream):
+            keep = dets[:, 4] > 0.4
+            return self.t.update(dets[keep], emb[keep])
+
+        def reset(self, stream):
+            self.t = orc.DeepOCSort(D, **hyper)
+
+    m = HipDeepOCSORT(NS(min_confidence=0.4, feature_dim=D, hyperparams=hyper), "cuda:0", tracking_dataset=None)
+    assert m.level == "image" and m.batch_size == 1 and m.output_columns == ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
+    for bad in (dict(cmc_off=False), dict(embedding_off=True), dict(new_kf_off=True)):
+        with pytest.raises(NotImplementedError):
+            HipDeepOCSORT(NS(hyperparams=dict(hyper, **bad)), "cuda:0")
+    m._make_backend = lambda dim, h, w: Backend()
+    ref = orc.DeepOCSort(D, **hyper)
+    frame = np.zeros((1080, 1920, 3), np.uint8)
+    seen = 0
+    for fr in SyntheticStream(5, 20, 40, parts=1, dim=D, with_embeddings=True, miss_prob=0.1, low_conf_frac=0.3):
+        df = _frame_df(fr, np.float64, id0=500)
+        emb = fr["embeddings"][:, 0, :].astype(np.float32)
+        conf = fr["dets"][:, 4]
+        use = (conf > 0.4) & (conf > 0.45)
+        m._features = lambda image, dets, emb=emb, use=use: emb[use]          # only rows above both thresholds reach the network
+        sample = m.preprocess(frame, df, pd.Series({"frame": fr["frame"]}))
+        out = m.process(default_collate([sample]), df, pd.DataFrame({"file_path": ["unused"]}))
+        keep = conf > 0.4
+        exp = ref.update(sample["input"][keep], emb[keep])
+        if len(exp) == 0:
+            assert len(out) == 0
+            continue
+        seen += len(exp)
+        np.testing.assert_array_equal(out.index.to_numpy(), exp[:, 7].astype(int))
+        np.testing.assert_array_equal(out.track_id.to_numpy(), exp[:, 4])
+        np.testing.assert_array_equal(np.stack(out.track_bbox_ltwh.to_list()),
+                                      np.stack([exp[:, 0], exp[:, 1], exp[:, 2] - exp[:, 0], exp[:, 3] - exp[:, 1]], axis=1))
+        np.testing.assert_array_equal(out.track_bbox_conf.to_numpy(), exp[:, 6])
+    assert seen > 300
+
+
 def test_rtmpose_module_contract_and_preprocess():
     from tracklab_amd.wrappers import HipRTMPose
     m = HipRTMPose("cuda:0", cfg=NS(arch="m", model_input_size=[192, 256], max_dets=16), tracking_dataset=None)

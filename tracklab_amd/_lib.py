@@ -677,6 +677,86 @@ class BoTSORTBank:
         return ids[:k], mean[:k], cov[:k], st[:k], feat[:k]
 
 
+# ------------------------------------------------------------------------------------------------
+# Deep-OC-SORT bank
+# ------------------------------------------------------------------------------------------------
+class DeepOCSortParams(C.Structure):
+    _fields_ = [("det_thresh", C.c_double), ("iou_threshold", C.c_double), ("inertia", C.c_double), ("w_association_emb", C.c_double),
+                ("alpha_fixed_emb", C.c_double), ("aw_param", C.c_double), ("min_confidence", C.c_double),
+                ("max_age", C.c_int32), ("min_hits", C.c_int32), ("delta_t", C.c_int32), ("asso_func", C.c_int32),
+                ("embedding_off", C.c_int32), ("cmc_off", C.c_int32), ("aw_off", C.c_int32), ("new_kf_off", C.c_int32),
+                ("wrapper_mode", C.c_int32), ("dim", C.c_int32), ("max_tracks", C.c_int32), ("max_dets", C.c_int32)]
+
+
+def _bind_deepocsort(L):
+    if getattr(L, "_doc_bound", False):
+        return
+    vp, ci = C.c_void_p, C.c_int
+    L.tlk_deepocsort_create.argtypes = [C.POINTER(DeepOCSortParams), ci, ci, C.POINTER(vp)]
+    L.tlk_deepocsort_destroy.argtypes = [vp]
+    L.tlk_deepocsort_reset.argtypes = [vp, ci]
+    L.tlk_deepocsort_update.argtypes = [vp, ci, vp, vp, ci, vp, ci, C.POINTER(ci)]
+    L.tlk_deepocsort_update_dev.argtypes = [vp, vp, vp, vp, ci, vp, ci, vp, vp]
+    L.tlk_deepocsort_get_tracks.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, C.POINTER(ci)]
+    L._doc_bound = True
+
+
+class DeepOCSortBank:
+    """``n_streams`` device-resident Deep-OC-SORT trackers (``tlk_deepocsort_*``); hyper-parameter names follow ``OCSort.__init__``
+    (plugins/track/deep_oc_sort/ocsort.py:352-371). cmc_off must be true, embedding_off / new_kf_off false (TlkError otherwise)."""
+
+    def __init__(self, dim, det_thresh=0.0, max_age=30, min_hits=3, iou_threshold=0.3, delta_t=3, asso_func="iou", inertia=0.2,
+                 w_association_emb=0.75, alpha_fixed_emb=0.95, aw_param=0.5, embedding_off=False, cmc_off=False, aw_off=False,
+                 new_kf_off=False, *, min_confidence=-np.inf, wrapper_mode=False, n_streams=1, device=0, max_tracks=256, max_dets=128):
+        L = lib()
+        _bind_deepocsort(L)
+        self.params = DeepOCSortParams(det_thresh, iou_threshold, inertia, w_association_emb, alpha_fixed_emb, aw_param, float(min_confidence),
+                                       int(max_age), int(min_hits), int(delta_t), ASSO[asso_func], int(embedding_off), int(cmc_off),
+                                       int(aw_off), int(new_kf_off), int(wrapper_mode), int(dim), max_tracks, max_dets)
+        self.n_streams, self.max_tracks, self.max_dets, self.dim = n_streams, max_tracks, max_dets, int(dim)
+        h = C.c_void_p()
+        check(L.tlk_deepocsort_create(C.byref(self.params), n_streams, device, C.byref(h)))
+        self._h = h
+        self._out = np.zeros((max_tracks + max_dets, 8))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tlk_deepocsort_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, stream=-1):
+        check(lib().tlk_deepocsort_reset(self._h, stream))
+
+    def update(self, dets, embs, stream=0):
+        """dets (n,7), embs (n,dim) float32 -> rows (m,8) [x1,y1,x2,y2,track_id,cls,conf,tracklab_id]."""
+        dets = _f64(dets).reshape(-1, 7)
+        embs = np.ascontiguousarray(embs, dtype=np.float32).reshape(len(dets), self.dim)
+        n = C.c_int(0)
+        check(lib().tlk_deepocsort_update(self._h, stream, dets.ctypes.data, embs.ctypes.data, len(dets), self._out.ctypes.data, len(self._out),
+                                          C.byref(n)))
+        return self._out[:n.value].copy()
+
+    def update_dev(self, dets, embs, counts, n_frames, out, out_cap, out_counts, stream_ptr=None):
+        check(lib().tlk_deepocsort_update_dev(self._h, dets, embs, counts, n_frames, out, out_cap, out_counts, stream_ptr))
+
+    def tracks(self, stream=0):
+        cap = self.max_tracks
+        ids, st = np.empty(cap, np.int64), np.empty((cap, 6), np.int64)
+        x, P, emb = np.empty((cap, 8)), np.empty((cap, 8, 8)), np.empty((cap, self.dim), np.float32)
+        vel, last = np.empty((cap, 2)), np.empty((cap, 5))
+        n = C.c_int(0)
+        check(lib().tlk_deepocsort_get_tracks(self._h, stream, ids.ctypes.data, x.ctypes.data, P.ctypes.data, emb.ctypes.data, st.ctypes.data,
+                                              vel.ctypes.data, last.ctypes.data, cap, C.byref(n)))
+        k = n.value
+        return ids[:k], x[:k], P[:k], emb[:k], st[:k], vel[:k], last[:k]
+
+
 def partdist(q, qvis, g, gvis):
     """q (T,K,D) f32, qvis (T,K) u8, g (N,K,D) f32, gvis (N,K) u8 cuda tensors -> (T,N) f64 cuda tensor."""
     import torch

@@ -330,6 +330,67 @@ class HipBoTSORT(ImageLevelModule, _ReidTrackerBase):
         return feats
 
 
+class HipDeepOCSORT(ImageLevelModule, _ReidTrackerBase):
+    """Deep-OC-SORT (tracklab/wrappers/track/deep_oc_sort_api.py:16-88). The crop box is the detection's corners truncated to int
+    with no clamping (ocsort.py:543-547: a negative corner wraps around like numpy indexing, which the HIP crop does not imitate:
+    boxes are clamped to the frame), resized / normalised like the other two ReID trackers; the embeddings go to
+    tlk_deepocsort_update as delivered (the reference does not normalise them). cmc_off must be true (cmc.py is cv2)."""
+    input_columns = ["bbox_ltwh", "bbox_conf", "category_id"]
+    output_columns = ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
+    preprocess, reset = _ReidTrackerBase.preprocess, _ReidTrackerBase.reset
+
+    def __init__(self, cfg, device, **kwargs):
+        super().__init__(batch_size=1)
+        self.cfg = cfg
+        self.device = device
+        self._bank = None
+        self._model = None
+        self._img_hw = None
+        hyper = dict(cfg_get(cfg, "hyperparams"))
+        if not hyper.get("cmc_off", False):
+            raise NotImplementedError("camera-motion compensation (deep_oc_sort/cmc.py, cv2 optical flow) is not part of the HIP path; set cmc_off: true")
+        if hyper.get("embedding_off", False) or hyper.get("new_kf_off", False):
+            raise NotImplementedError("embedding_off / new_kf_off are not part of the HIP path (embedding_off fails in the reference itself)")
+
+    def _make_backend(self, dim, img_h, img_w):
+        from .._lib import DeepOCSortBank
+        hyper = dict(cfg_get(self.cfg, "hyperparams"))
+        return DeepOCSortBank(dim, **hyper, min_confidence=float(cfg_get(self.cfg, "min_confidence", 0.0)), wrapper_mode=True,
+                              device=_device_index(self.device), max_tracks=int(cfg_get(self.cfg, "max_tracks", 256)),
+                              max_dets=int(cfg_get(self.cfg, "max_dets", 128)))
+
+    def _frame_features(self, image, inputs):
+        hyper = dict(cfg_get(self.cfg, "hyperparams"))
+        use = (inputs[:, 4] > float(cfg_get(self.cfg, "min_confidence", 0.0))) & (inputs[:, 4] > float(hyper.get("det_thresh", 0.0)))
+        feats = np.zeros((len(inputs), int(cfg_get(self.cfg, "feature_dim", 512))), dtype=np.float32)
+        if use.any():
+            feats[use] = self._features(image, inputs[use])
+        return feats
+
+    def process(self, batch, detections: pd.DataFrame, metadatas: pd.DataFrame):
+        if len(detections) == 0:
+            return []
+        inputs = to_numpy(batch["input"])
+        inputs = np.ascontiguousarray(inputs[0] if inputs.ndim == 3 else inputs, dtype=np.float64).reshape(-1, 7)
+        image = batch.get("image") if hasattr(batch, "get") else None
+        if image is None:
+            from PIL import Image
+            image = np.asarray(Image.open(metadatas["file_path"].values[0]).convert("RGB"))
+        image = to_numpy(image) if not hasattr(image, "detach") else image
+        if getattr(image, "ndim", 3) == 4:
+            image = image[0]
+        feats = self._frame_features(image, inputs)
+        if self._bank is None:
+            self._bank = self._make_backend(feats.shape[1], int(image.shape[0]), int(image.shape[1]))
+        rows = self._bank.update(inputs, feats, 0)
+        if not len(rows):
+            return []
+        ltwh = np.stack([rows[:, 0], rows[:, 1], rows[:, 2] - rows[:, 0], rows[:, 3] - rows[:, 1]], axis=1)      # ltrb_to_ltwh
+        out = pd.DataFrame({"track_bbox_ltwh": list(ltwh), "track_bbox_conf": list(rows[:, 6]), "track_id": list(rows[:, 4])},
+                           index=pd.Index(rows[:, 7].astype(int), name="idxs"))
+        return out[~out.index.duplicated(keep="first")]                              # deep_oc_sort_api.py:82
+
+
 def _strip(a, ndim):
     return a[0] if a.ndim == ndim + 1 else a
 
