@@ -305,6 +305,8 @@ int tlk_deepocsort_update_dev(tlk_deepocsort *h, const double *dets_dev, const f
  * frozen, kf.observed], velocity (.,2), last_observation (.,5); none may be NULL */
 int tlk_deepocsort_get_tracks(tlk_deepocsort *h, int stream, int64_t *ids, double *x, double *P, float *emb, int64_t *state6, double *vel,
                               double *last, int cap, int *n_tracks);
+/* diagnostics: 16 accumulated wall-clock counters (100 MHz) per kernel phase; the bank must be created with TLK_DEEPOCSORT_PROF=1 */
+int tlk_deepocsort_get_profile(tlk_deepocsort *h, int stream, long long *cycles16);
 
 /* ------------------------------------------------------------------------------------------
  * BoT-SORT tracker bank (n_streams independent trackers, state + smoothed features in HBM).

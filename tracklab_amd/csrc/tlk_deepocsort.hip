@@ -7,7 +7,7 @@
 //     (kalmanfilter.py:433-478) run with the filter's default R = I, Q = I on boxes that read (x, y, w, h) as (x, y, s, r);
 //     `frozen` tracks predict with zero w / h velocity (:293-297)
 //   * the embedding cost dets_embs @ trk_embs.T in float32, needed only where IoU > 0 (association.py:343): pairs with IoU > 0 are
-//     compacted into a list and each wavefront reduces one dot product at a time (D <= 4096)
+//     found by a wavefront ballot over 64 entries and reduced one dot product per wavefront at a time (D <= 4096)
 //   * compute_aw_max_metric (association.py:263-288): float32 row / column weights from the two largest entries
 //   * update_emb (ocsort.py:254-256): float32 EMA with the detection's confidence-dependent alpha, float32 renormalisation
 // Reference quirks kept: OCSort.update never increments frame_count (min_hits is inert), a track's conf is the one of its first
@@ -48,8 +48,8 @@ struct DocDev {
     float *emb;      // S x MAXT x D      track embedding by slot
     double *lastb;   // S x MAXT x 5
     double *cost_g;  // S x MAXD x MAXT   cost-matrix spill
-    float *ec;       // S x MAXD x MAXT   embedding cost (row = detection, col = list position)
-    int *pairs;      // S x MAXD x MAXT   entries of ec with IoU > 0
+    long long *prof; // optional S x 16 cycle accumulators (diagnostics)
+    int *pairs;      // S x MAXD x MAXT   spill of the (detection, track) pairs with IoU > 0 that do not fit the LDS list
     int S, MAXT, MAXD, D, cost_lds_entries;
 };
 struct DocP {
@@ -298,6 +298,104 @@ __device__ __forceinline__ float aw_weight(float top1, float top2, double bottom
     return 1.f - m / (float)(1 - bottom);
 }
 
+// The two float32 embedding phases live in their own (non-inlined) functions: inside the 256-VGPR tracker kernel the register
+// allocator serialised every load behind a scratch spill; on their own they keep sixteen float4 loads in flight per lane.
+//
+// dets_embs @ trk_embs.T for the listed (detection, track) pairs (association.py:343: only where IoU > 0): eight dot products per
+// wavefront at a time, 8 lanes each. All threads of the block call; the result does not depend on the list order.
+__device__ __noinline__ void emb_pair_dots(const float *__restrict__ demb, const float *__restrict__ temb, const int *hi_idx, const int *order,
+                                           const int *plist, int plist_cap, const int *pairs_g, int npairs, int T, int DIM, double *cost)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 3, j = lane & 7;
+    const int nblk = (DIM & 3) == 0 ? DIM / 256 : 0;           // full 8 x float4 x 8-lane blocks
+    for (int k0 = wv * 8; k0 < npairs; k0 += NWAVES * 8) {
+        const int k = k0 + g;
+        const bool act = k < npairs;
+        int e = 0;
+        float sacc = 0.f;
+        if (act) {
+            e = k < plist_cap ? plist[k] : pairs_g[k - plist_cap];
+            const int d = e / T, t = e - d * T;
+            const float *a = demb + (size_t)hi_idx[d] * DIM, *b = temb + (size_t)order[t] * DIM;
+            for (int blk = 0; blk < nblk; ++blk) {
+                const float4 *a4 = (const float4 *)(a + blk * 256) + j, *b4 = (const float4 *)(b + blk * 256) + j;
+                float4 x[8], y[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { x[i] = a4[8 * i]; y[i] = b4[8 * i]; }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { sacc += x[i].x * y[i].x; sacc += x[i].y * y[i].y; sacc += x[i].z * y[i].z; sacc += x[i].w * y[i].w; }
+            }
+            for (int q = nblk * 256 + j; q < DIM; q += 8) sacc += a[q] * b[q];
+        }
+        sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4);
+        if (act && j == 0) cost[e] = (double)sacc;
+    }
+}
+
+// update_emb (ocsort.py:254-256) for `cnt` (track position, input detection index) pairs: float32 EMA with the detection's
+// confidence-dependent alpha (:433-436), float32 renormalisation. D <= 512 and D % 4 == 0: four pairs per wavefront, the new
+// embedding stays in registers between the EMA and the division; otherwise one wavefront per pair through memory.
+__device__ __noinline__ void emb_update_pairs(const double *__restrict__ dets, const float *__restrict__ demb, float *temb, const int *order,
+                                              const int *trk_pos, const int *det_in, int cnt, int DIM, double det_thresh, double alpha_fixed)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    auto alpha_of = [&](int di) {
+        const double conf = dets[(size_t)di * 7 + 4];
+        const double trust = (conf - det_thresh) / (1 - det_thresh);
+        return alpha_fixed + (1 - alpha_fixed) * (1 - trust);
+    };
+    if (DIM <= 512 && (DIM & 3) == 0) {
+        const int g = lane >> 4, j = lane & 15;
+        const int nq = DIM >> 2;                               // float4 per row
+        for (int k0 = wv * 4; k0 < cnt; k0 += NWAVES * 4) {
+            const int k = k0 + g;
+            const bool act = k < cnt;
+            float4 r[8];
+            float ss = 0.f;
+            float4 *te4 = (float4 *)temb;
+            if (act) {
+                const int di = det_in[k];
+                const double alpha = alpha_of(di);
+                const float a = (float)alpha, b = (float)(1 - alpha);
+                te4 = (float4 *)(temb + (size_t)order[trk_pos[k]] * DIM);
+                const float4 *de4 = (const float4 *)(demb + (size_t)di * DIM);
+                float4 x[8], y[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const int q = j + 16 * i; const int qq = q < nq ? q : 0; x[i] = te4[qq]; y[i] = de4[qq]; }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float4 o;
+                    { const float u = a * x[i].x, v = b * y[i].x; o.x = u + v; }
+                    { const float u = a * x[i].y, v = b * y[i].y; o.y = u + v; }
+                    { const float u = a * x[i].z, v = b * y[i].z; o.z = u + v; }
+                    { const float u = a * x[i].w, v = b * y[i].w; o.w = u + v; }
+                    r[i] = o;
+                    if (j + 16 * i < nq) { ss += o.x * o.x; ss += o.y * o.y; ss += o.z * o.z; ss += o.w * o.w; }
+                }
+            }
+            ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
+            const float n = sqrtf(ss);
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (j + 16 * i < nq) te4[j + 16 * i] = make_float4(r[i].x / n, r[i].y / n, r[i].z / n, r[i].w / n);
+            }
+        }
+        return;
+    }
+    for (int k = wv; k < cnt; k += NWAVES) {
+        const int di = det_in[k];
+        const double alpha = alpha_of(di);
+        const float a = (float)alpha, b = (float)(1 - alpha);
+        float *te = temb + (size_t)order[trk_pos[k]] * DIM;
+        const float *de = demb + (size_t)di * DIM;
+        float ss = 0.f;
+        for (int q = lane; q < DIM; q += WAVE) { const float u = a * te[q], v = b * de[q]; const float r = u + v; te[q] = r; ss += r * r; }
+        const float n = sqrtf(wave_sum_f(ss));
+        for (int q = lane; q < DIM; q += WAVE) te[q] = te[q] / n;
+    }
+}
+
 __global__ void __launch_bounds__(BLOCK, 1)
 deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, const float *__restrict__ embs_all, const int *__restrict__ counts,
                          int n_frames, size_t det_stream_stride, size_t det_frame_stride, double *__restrict__ out_all, int out_cap,
@@ -312,16 +410,18 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
     int *order = D.order + (size_t)s * MAXT;
     int *freestk = D.freestk + (size_t)s * MAXT;
     double *lastb = D.lastb + (size_t)s * MAXT * 5;
+    int *pairs_g = D.pairs + (size_t)s * MAXD * MAXT;
     float *temb = D.emb + (size_t)s * MAXT * DIM;
-    float *ec = D.ec + (size_t)s * MAXD * MAXT;
-    int *pairs = D.pairs + (size_t)s * MAXD * MAXT;
     const size_t stride_d = (size_t)S * MAXT, stride_i = (size_t)S * MAXT;
     auto trk_at = [&](int slot) {
         Trk T; T.fd = D.fd + (size_t)s * MAXT + slot; T.fi = D.fi + (size_t)s * MAXT + slot;
         T.stride_d = stride_d; T.stride_i = stride_i; return T;
     };
 
+    long long t_prev = 0;
+#define PROF(i) do { if (D.prof && tid == 0) { const long long t_ = wall_clock64(); D.prof[(size_t)s * 16 + (i)] += t_ - t_prev; t_prev = t_; } } while (0)
     for (int f = 0; f < n_frames; ++f) {
+        if (D.prof && tid == 0) t_prev = wall_clock64();
         const double *dets = dets_all + (size_t)s * det_stream_stride * 7 + (size_t)f * det_frame_stride * 7;
         const float *demb = embs_all + ((size_t)s * det_stream_stride + (size_t)f * det_frame_stride) * DIM;
         double *out = out_all + ((size_t)s * n_frames + f) * (size_t)out_cap * 8;
@@ -338,6 +438,7 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
         int T = hdr[H_NTRK];
         __syncthreads();
 
+        PROF(0);
         // ---- predict (ocsort.py:439-456 -> :283-309)
         for (int p = tid; p < T; p += BLOCK) {
             const Trk K = trk_at(order[p]);
@@ -361,6 +462,7 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
             for (int k = 0; k < 4; ++k) L.kobs[(size_t)p * 5 + k] = b[k];
         }
         __syncthreads();
+        PROF(1);
         {   // drop NaN trackers (stable), free their slots
             for (int p = tid; p < T; p += BLOCK) L.tmp_b[p] = order[p];
             __syncthreads();
@@ -380,6 +482,7 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
         }
         __syncthreads();
 
+        PROF(2);
         // ---- velocities / last_boxes / k_observations (ocsort.py:458-460)
         for (int p = tid; p < T; p += BLOCK) {
             const Trk K = trk_at(order[p]);
@@ -407,18 +510,26 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
         }
         for (int k = tid; k < N; k += BLOCK) { L.rowcnt[k] = 0; L.rowhit[k] = -1; }
         for (int k = tid; k < T; k += BLOCK) L.colcnt[k] = 0;
+        if (tid == 0) L.sc[SC_NREM] = 0;
+        // list of the pairs with IoU > 0: the assignment scratch lists (mi_r .. um_t, contiguous, unused until the LSA) first, HBM beyond
+        int *plist = L.mi_r;
+        const int plist_cap = 6 * (MAXT > MAXD ? MAXT : MAXD) + MAXD + MAXT;
         __syncthreads();
 
+        PROF(3);
         // ---- first association (association.py:291-364)
         double *cost = ((size_t)N * T <= (size_t)D.cost_lds_entries) ? L.cost : (D.cost_g + (size_t)s * MAXD * MAXT);
+        // until the cost fill, cost[e] holds the float32 embedding cost of the pair (exact in a double): no second N x T array
         int n_mi = 0;
         if (T > 0 && N > 0) {
             for (int e = tid; e < N * T; e += BLOCK) {
                 const int d = e / T, t = e - d * T;
                 const double iou = box_similarity(TLK_IOU, dets + (size_t)L.hi_idx[d] * 7, L.trk_box + (size_t)t * 4);
-                ec[e] = 0.f;
+                cost[e] = 0.0;                              // emb_cost[iou_matrix <= 0] = 0 (association.py:343)
+                if (iou > 0) { const int pos = atomicAdd(&L.sc[SC_NREM], 1); if (pos < plist_cap) plist[pos] = e; else pairs_g[pos - plist_cap] = e; }
                 if (iou > P.iou_threshold) { atomicAdd(&L.rowcnt[d], 1); atomicAdd(&L.colcnt[t], 1); L.rowhit[d] = t; }
             }
+            __threadfence_block();
             __syncthreads();
             int mx = 0;
             for (int k = tid; k < N; k += BLOCK) mx = max(mx, L.rowcnt[k]);
@@ -435,22 +546,11 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
                 n_mi = block_compact(N, [&](int d) { return L.rowcnt[d] == 1; },
                                      [&](int d, int pos) { L.mi_r[pos] = d; L.mi_c[pos] = L.rowhit[d]; }, L.scan);
             } else {
-                // embedding cost where IoU > 0: compact the pairs, one wavefront per dot product (float32)
-                const int npairs = block_compact(N * T, [&](int e) { const int d = e / T, t = e - d * T;
-                                                                     return box_similarity(TLK_IOU, dets + (size_t)L.hi_idx[d] * 7, L.trk_box + (size_t)t * 4) > 0; },
-                                                 [&](int e, int pos) { pairs[pos] = e; }, L.scan);
+                PROF(4);
+                emb_pair_dots(demb, temb, L.hi_idx, order, plist, plist_cap, pairs_g, L.sc[SC_NREM], T, DIM, cost);
                 __threadfence_block();
                 __syncthreads();
-                for (int k = wv; k < npairs; k += NWAVES) {
-                    const int e = pairs[k], d = e / T, t = e - d * T;
-                    const float *a = demb + (size_t)L.hi_idx[d] * DIM, *b = temb + (size_t)order[t] * DIM;
-                    float sacc = 0.f;
-                    for (int q = lane; q < DIM; q += WAVE) sacc += a[q] * b[q];
-                    sacc = wave_sum_f(sacc);
-                    if (lane == 0) ec[e] = sacc;
-                }
-                __threadfence_block();
-                __syncthreads();
+                PROF(5);
                 // compute_aw_max_metric: row weights (per detection) and column weights (per track) from the top two entries
                 float *roww = (float *)L.tmp_a, *colw = (float *)L.tmp_b;
                 if (!P.aw_off) {
@@ -458,7 +558,7 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
                         float w = 1.f;
                         if (T >= 2) {
                             float a = -INFINITY, b = -INFINITY;
-                            for (int t = 0; t < T; ++t) { const float v = ec[(size_t)d * T + t]; if (v > a) { b = a; a = v; } else if (v > b) b = v; }
+                            for (int t = 0; t < T; ++t) { const float v = (float)cost[(size_t)d * T + t]; if (v > a) { b = a; a = v; } else if (v > b) b = v; }
                             w = aw_weight(a, b, P.aw_param);
                         }
                         roww[d] = w;
@@ -467,7 +567,7 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
                         float w = 1.f;
                         if (N >= 2) {
                             float a = -INFINITY, b = -INFINITY;
-                            for (int d = 0; d < N; ++d) { const float v = ec[(size_t)d * T + t]; if (v > a) { b = a; a = v; } else if (v > b) b = v; }
+                            for (int d = 0; d < N; ++d) { const float v = (float)cost[(size_t)d * T + t]; if (v > a) { b = a; a = v; } else if (v > b) b = v; }
                             w = aw_weight(a, b, P.aw_param);
                         }
                         colw[t] = w;
@@ -497,11 +597,13 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
                     float w;
                     if (P.aw_off) w = (float)P.w_emb;
                     else { w = (float)P.w_emb; if (T >= 2) w *= roww[d]; if (N >= 2) w *= colw[t]; }
-                    const float ecw = P.aw_off ? ec[e] * w : w * ec[e];
+                    const float ecv = (float)cost[e];
+                    const float ecw = P.aw_off ? ecv * w : w * ecv;
                     cost[e] = -((iou + adc) + (double)ecw);
                 }
                 __threadfence_block();
                 __syncthreads();
+                PROF(6);
                 if (tid < WAVE) {
                     const int r = wave_lsa(cost, N, T, (size_t)T, (size_t)1, L.W, L.mi_r, L.mi_c);
                     if (tid == 0) L.sc[SC_NMI] = r < 0 ? 0 : r;
@@ -511,6 +613,7 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
             }
         }
         __syncthreads();
+        PROF(7);
         // unmatched lists + low-IoU rejection (association.py:344-362)
         int nud = 0, nut = 0, nm = 0;
         if (T == 0) {
@@ -534,21 +637,10 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
             nud += nrej; nut += nrej;
         }
         __syncthreads();
+        PROF(8);
         // update_emb (ocsort.py:254-256) for `cnt` (track position, input detection index) pairs: one wavefront per pair
         auto update_embs = [&](int cnt, const int *trk_pos, const int *det_in) {
-            for (int k = wv; k < cnt; k += NWAVES) {
-                const int di = det_in[k];
-                const double conf = dets[(size_t)di * 7 + 4];
-                const double trust = (conf - P.det_thresh) / (1 - P.det_thresh);
-                const double alpha = P.alpha_fixed + (1 - P.alpha_fixed) * (1 - trust);          // ocsort.py:433-436
-                const float a = (float)alpha, b = (float)(1 - alpha);
-                float *te = temb + (size_t)order[trk_pos[k]] * DIM;
-                const float *de = demb + (size_t)di * DIM;
-                float ss = 0.f;
-                for (int q = lane; q < DIM; q += WAVE) { const float u = a * te[q], v = b * de[q]; const float r = u + v; te[q] = r; ss += r * r; }
-                const float n = sqrtf(wave_sum_f(ss));
-                for (int q = lane; q < DIM; q += WAVE) te[q] = te[q] / n;
-            }
+            emb_update_pairs(dets, demb, temb, order, trk_pos, det_in, cnt, DIM, P.det_thresh, P.alpha_fixed);
         };
         for (int k = tid; k < nm; k += BLOCK) {                                 // ocsort.py:475-477
             kbt_update(trk_at(order[L.m_t[k]]), dets + (size_t)L.hi_idx[L.m_d[k]] * 7, P.delta_t);
@@ -558,6 +650,7 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
         update_embs(nm, L.m_t, L.tmp_a);
         __syncthreads();
 
+        PROF(9);
         // ---- second round by OCR on the last observations (ocsort.py:480-513)
         if (nud > 0 && nut > 0) {
             const int nrow = nud, ncol = nut;
@@ -605,6 +698,7 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
         }
         __syncthreads();
 
+        PROF(10);
         for (int k = tid; k < nut; k += BLOCK) kf_update_none(trk_at(order[L.um_t[k]]));   // ocsort.py:515-516
         // ---- births (ocsort.py:519-524)
         int nfree = hdr[H_NFREE], nextid = hdr[H_NEXTID];
@@ -627,6 +721,7 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
         }
         __syncthreads();
         nfree -= nud; nextid += nud; T += nud;
+        PROF(11);
         // ---- emit rows in reversed list order + drop dead tracklets (ocsort.py:525-531; frame_count stays 0 in the reference)
         for (int q = tid; q < T; q += BLOCK) {
             const Trk K = trk_at(order[T - 1 - q]);
@@ -657,6 +752,7 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
             nfree += T - kept;
         }
         __syncthreads();
+        PROF(12);
         if (tid == 0) {
             hdr[H_NTRK] = kept; hdr[H_NFREE] = nfree; hdr[H_NEXTID] = nextid;
             *out_count = rows > out_cap ? TLK_ECAPACITY : rows;
@@ -713,7 +809,7 @@ static int doc_free(tlk_deepocsort *h)
 {
     if (!h) return TLK_OK;
     hipSetDevice(h->device);
-    void *ptrs[] = {h->D.fd, h->D.fi, h->D.hdr, h->D.order, h->D.freestk, h->D.emb, h->D.lastb, h->D.cost_g, h->D.ec, h->D.pairs,
+    void *ptrs[] = {h->D.fd, h->D.fi, h->D.hdr, h->D.order, h->D.freestk, h->D.emb, h->D.lastb, h->D.cost_g, h->D.prof, h->D.pairs,
                     h->d_dets, h->d_out, h->d_embs, h->d_cnt, h->d_ocnt};
     for (void *p : ptrs) if (p) hipFree(p);
     delete h;
@@ -759,8 +855,8 @@ extern "C" int tlk_deepocsort_create(const tlk_deepocsort_params *p, int n_strea
     DOC_ALLOC(D.emb, sizeof(float) * slots * D.D);
     DOC_ALLOC(D.lastb, sizeof(double) * 5 * slots);
     DOC_ALLOC(D.cost_g, sizeof(double) * (size_t)n_streams * MAXD * MAXT);
-    DOC_ALLOC(D.ec, sizeof(float) * (size_t)n_streams * MAXD * MAXT);
     DOC_ALLOC(D.pairs, sizeof(int) * (size_t)n_streams * MAXD * MAXT);
+    if (getenv("TLK_DEEPOCSORT_PROF")) { DOC_ALLOC(D.prof, sizeof(long long) * 16 * n_streams); hipMemset(D.prof, 0, sizeof(long long) * 16 * n_streams); }
     DOC_ALLOC(h->d_dets, sizeof(double) * 7 * MAXD);
     DOC_ALLOC(h->d_embs, sizeof(float) * (size_t)MAXD * D.D);
     DOC_ALLOC(h->d_out, sizeof(double) * 8 * h->out_cap);
@@ -822,7 +918,7 @@ extern "C" int tlk_deepocsort_update(tlk_deepocsort *h, int stream, const double
     DocDev V = h->D;
     const size_t sl = (size_t)stream * V.MAXT;
     V.fd += sl; V.fi += sl; V.hdr += (size_t)stream * H_COUNT; V.order += sl; V.freestk += sl; V.emb += sl * V.D; V.lastb += sl * 5;
-    V.cost_g += (size_t)stream * V.MAXD * V.MAXT; V.ec += (size_t)stream * V.MAXD * V.MAXT; V.pairs += (size_t)stream * V.MAXD * V.MAXT;
+    V.cost_g += (size_t)stream * V.MAXD * V.MAXT; V.pairs += (size_t)stream * V.MAXD * V.MAXT; if (V.prof) V.prof += (size_t)stream * 16;
     hipLaunchKernelGGL(deepocsort_frames_kernel, dim3(1), dim3(BLOCK), h->smem, st, V, h->P, (const double *)h->d_dets, (const float *)h->d_embs,
                        (const int *)h->d_cnt, 1, (size_t)0, (size_t)0, h->d_out, h->out_cap, h->d_ocnt);
     TLK_HIP(hipGetLastError());
@@ -864,5 +960,15 @@ extern "C" int tlk_deepocsort_get_tracks(tlk_deepocsort *h, int stream, int64_t 
     hipFree(d_ids); hipFree(d_st); hipFree(d_x); hipFree(d_P); hipFree(d_vel); hipFree(d_last); hipFree(d_emb); hipFree(d_n);
     if (e != hipSuccess) return fail(TLK_EHIP, std::string("tlk_deepocsort_get_tracks: ") + hipGetErrorString(e));
     *n_tracks = n;
+    return TLK_OK;
+}
+
+extern "C" int tlk_deepocsort_get_profile(tlk_deepocsort *h, int stream, long long *cycles16)
+{
+    if (!h || !cycles16) return fail(TLK_EINVAL, "tlk_deepocsort_get_profile: null pointer");
+    if (!h->D.prof) return fail(TLK_EINVAL, "tlk_deepocsort_get_profile: create the bank with TLK_DEEPOCSORT_PROF=1 in the environment");
+    if (stream < 0 || stream >= h->D.S) return fail(TLK_EINVAL, "tlk_deepocsort_get_profile: stream out of range");
+    TLK_HIP(hipSetDevice(h->device));
+    TLK_HIP(hipMemcpy(cycles16, h->D.prof + (size_t)stream * 16, sizeof(long long) * 16, hipMemcpyDeviceToHost));
     return TLK_OK;
 }
