@@ -47,6 +47,12 @@ WORKLOADS = {
     "config3s": dict(detector="m", objects=100, frames_per_step=24, max_dets=104, tracker="strong_sort",
                      name="BASELINE configs[2] with the plain StrongSORT reading (cosine + IoU cost): YOLOX-m + 512-d ReID on Pillow-semantics "
                           "256x128 crops + strong_sort.StrongSORT (cosine gallery, budget 100), synthetic 1080p 100-obj stream"),
+    "config3b": dict(detector="m", objects=100, frames_per_step=24, max_dets=104, tracker="bot_sort",
+                     name="YOLOX-m + 512-d ReID on Pillow-semantics 256x128 crops + BoT-SORT (cmc none: embedding + Mahalanobis first stage), "
+                          "synthetic 1080p 100-obj stream"),
+    "config3d": dict(detector="m", objects=100, frames_per_step=24, max_dets=104, tracker="deep_oc_sort",
+                     name="YOLOX-m + 512-d ReID on Pillow-semantics 256x128 crops + Deep-OC-SORT (cmc off: IoU + angle + adaptive-weighted "
+                          "embedding cost), synthetic 1080p 100-obj stream"),
     "config2b": dict(detector="s", objects=50, frames_per_step=32, max_dets=128, tracker="byte_track",
                      name="YOLOX-s + ByteTrack (IoU fused with score, lapjv cost limits), synthetic 1080p 50-obj stream"),
     "config2": dict(detector="s", objects=50, frames_per_step=32, max_dets=128,
@@ -182,8 +188,16 @@ def main():
     B = S * F
     total_steps = args.warmup + args.steps
     n_frames = total_steps * F
-    is3 = args.workload in ("config3", "config4", "config3s", "config5")
-    ssort = wl.get("tracker") == "strong_sort"
+    is3 = args.workload in ("config3", "config4", "config3s", "config3b", "config3d", "config5")
+    ssort = wl.get("tracker") in ("strong_sort", "bot_sort", "deep_oc_sort")      # global-feature trackers: (n,7) rows + (n,D) features
+
+    def gfeat_oracle(oracle, pipe):
+        if wl["tracker"] == "bot_sort":
+            return oracle.BoTSORT(pipe.D, **pipe.tracker_cfg)
+        if wl["tracker"] == "deep_oc_sort":
+            return oracle.DeepOCSort(pipe.D, **pipe.tracker_cfg)
+        return oracle.PlainStrongSORT(pipe.D, **pipe.tracker_cfg, img_w=WIDTH, img_h=HEIGHT)
+    gfeat_name = {"strong_sort": "plain StrongSORT", "bot_sort": "BoT-SORT", "deep_oc_sort": "Deep-OC-SORT"}.get(wl.get("tracker"), "")
     byte = wl.get("tracker") == "byte_track"
 
     from tracklab_amd import gpu_pipeline as gp
@@ -223,8 +237,7 @@ def main():
         oracle.build()
         ksteps = min(total_steps, max(1, (args.check_frames + F - 1) // F))
         if is3:
-            ref = oracle.PlainStrongSORT(pipe.D, **pipe.tracker_cfg, img_w=WIDTH, img_h=HEIGHT) if ssort else \
-                oracle.StrongSORT(pipe.K, pipe.D, **pipe.tracker_cfg)
+            ref = gfeat_oracle(oracle, pipe) if ssort else oracle.StrongSORT(pipe.K, pipe.D, **pipe.tracker_cfg)
             ids_ok, tracks, frames_checked = True, 0, 0
             gt_fr, gpu_fr, orc_fr = [], [], []
             for k in range(ksteps):
@@ -249,7 +262,7 @@ def main():
                         exp["kf_ltwh"] = np.stack([e8[:, 0], e8[:, 1], e8[:, 2] - e8[:, 0], e8[:, 3] - e8[:, 1]], axis=1).reshape(-1, 4)
                         g_ = rows[0][f]
                         got = np.zeros(len(g_), dtype=exp.dtype)
-                        got["det_id"], got["track_id"] = g_["det_id"], g_["track_id"]
+                        got["det_id"], got["track_id"] = g_["det_id"].astype(np.int64), g_["track_id"].astype(np.int64)
                         got["kf_ltwh"] = np.stack([g_["ltrb"][:, 0], g_["ltrb"][:, 1], g_["ltrb"][:, 2] - g_["ltrb"][:, 0],
                                                    g_["ltrb"][:, 3] - g_["ltrb"][:, 1]], axis=1).reshape(-1, 4)
                     else:
@@ -272,7 +285,7 @@ def main():
             h_orc = hota.finalize(hota.pack(hota.hota_sequence(*hota.sequence_from_rows(gt_fr, orc_fr))))["summary"]
             parity = {"frames": frames_checked, "track_ids_equal_oracle": bool(ids_ok), "tracks": tracks,
                       "HOTA_gpu": h_gpu["HOTA"], "HOTA_oracle": h_orc["HOTA"], "AssA_gpu": h_gpu["AssA"], "DetA_gpu": h_gpu["DetA"],
-                      "note": "oracle chain = C decode/NMS + C " + ("plain StrongSORT" if ssort else "BPBReID-StrongSORT") +
+                      "note": "oracle chain = C decode/NMS + C " + (gfeat_name if ssort else "BPBReID-StrongSORT") +
                               " fed with the embeddings the GPU ReID net produced"
                               + (" and the keypoints the GPU pose stage produced (OKS motion cost)" if pipe.pose is not None else "")}
         else:
@@ -368,7 +381,7 @@ def main():
             cpu_pose = rtmpose(wl["pose"], device="cpu", dtype=torch.float32, channels_last=False)
         frame = render_frame(np.random.default_rng(5), gts[0][0]["gt_boxes"])
         if ssort:
-            trk = oracle.PlainStrongSORT(pipe.D, **pipe.tracker_cfg, img_w=WIDTH, img_h=HEIGHT)
+            trk = gfeat_oracle(oracle, pipe)
         elif is3:
             trk = oracle.StrongSORT(pipe.K, pipe.D, **pipe.tracker_cfg)
         else:
@@ -416,7 +429,7 @@ def main():
         cpu_t = time.perf_counter() - tc0
         chain = ("oracle C letterbox + YOLOX-%s fp32 (torch CPU, batch 1) + oracle C decode/NMS" % detector) + \
                 ((" + oracle C affine pose crops + RTMPose-%s fp32 (torch CPU) + oracle C SimCC decode" % wl["pose"]) if is3 and wl.get("pose") else "") + \
-                (" + oracle C Pillow-semantics crops + ReID R50 fp32 512-d (torch CPU, 100 crops/batch) + oracle C plain StrongSORT" if ssort else
+                (" + oracle C Pillow-semantics crops + ReID R50 fp32 512-d (torch CPU, 100 crops/batch) + oracle C " + gfeat_name if ssort else
                  " + oracle C crop-resize-normalize + part-based ReID R50 fp32 (torch CPU, 100 crops/batch) + oracle C BPBReID-StrongSORT"
                  if is3 else (" + oracle C ByteTrack" if byte else " + oracle C OC-SORT"))
         cpu = {"value": done / cpu_t, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",

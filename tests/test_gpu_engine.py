@@ -70,3 +70,37 @@ def test_video_engine_det_reid_strongsort_runs_and_keeps_ids_stable(orc):
     assert tracked.track_id.nunique() <= 14                     # 10 objects, near-identical boxes frame to frame: ids persist
     assert np.isfinite(np.stack(tracked.track_bbox_ltwh.to_list())).all()
     pipe.close()
+
+
+@pytest.mark.parametrize("tracker", ["strong_sort", "bot_sort", "deep_oc_sort"])
+def test_pipeline_global_feature_trackers_match_oracle_fed_with_gpu_embeddings(orc, tracker):
+    """DetReidTrackPipeline.step with each tracker that owns a global-feature ReID net: the rows the bank produced on the device
+    equal the C oracle's for the same detector rows and the embeddings the GPU network produced."""
+    import torch
+    from tracklab_amd import gpu_pipeline as gp
+    F, T = 4, 12
+    pipe = gp.DetReidTrackPipeline("s", n_streams=1, frames_per_step=F, max_dets=32, use_graph=False, tracker=tracker)
+    heads, frames = _inputs(33, 10, T, pipe.ratio)
+    cfg = pipe.tracker_cfg
+    ref = {"strong_sort": lambda: orc.PlainStrongSORT(pipe.D, **cfg, img_w=1920, img_h=1080), "bot_sort": lambda: orc.BoTSORT(pipe.D, **cfg),
+           "deep_oc_sort": lambda: orc.DeepOCSort(pipe.D, **cfg)}[tracker]()
+    n_rows = 0
+    for k in range(T // F):
+        fr = torch.from_numpy(np.stack(frames[k * F:(k + 1) * F])).cuda()
+        h_rows, h_cnt = pipe.step(fr, torch.from_numpy(heads[k * F:(k + 1) * F]).cuda())
+        pipe.synchronize()
+        rows, cnt = pipe.rows_numpy(h_rows, h_cnt)
+        emb = pipe.last["emb"].cpu().numpy().reshape(1, F, pipe.maxd, pipe.D)
+        trk_in = pipe.last["trk_in"].cpu().numpy().reshape(1, F, pipe.maxd, 7)
+        dcnt = pipe.last["counts"].cpu().numpy()
+        for f in range(F):
+            n = int(dcnt[f])
+            exp = ref.update(trk_in[0, f, :n], emb[0, f, :n]) if n else np.zeros((0, 8))
+            got = rows[0][f]
+            assert len(got) == len(exp), (tracker, k, f)
+            np.testing.assert_array_equal(got["det_id"].astype(np.int64), exp[:, 7].astype(np.int64))
+            np.testing.assert_array_equal(got["track_id"].astype(np.int64), exp[:, 4].astype(np.int64))
+            np.testing.assert_allclose(got["ltrb"], exp[:, :4], rtol=1e-9, atol=1e-7)
+            n_rows += len(exp)
+    assert n_rows > 40
+    pipe.close()

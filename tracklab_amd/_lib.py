@@ -688,6 +688,10 @@ class DeepOCSortParams(C.Structure):
                 ("wrapper_mode", C.c_int32), ("dim", C.c_int32), ("max_tracks", C.c_int32), ("max_dets", C.c_int32)]
 
 
+# rows of tlk_deepocsort_update(_dev) viewed with the field names of the other banks (ocsort.py:527-529)
+DEEPOCSORT_ROW = np.dtype([("ltrb", "<f8", (4,)), ("track_id", "<f8"), ("cls", "<f8"), ("conf", "<f8"), ("det_id", "<f8")])
+
+
 def _bind_deepocsort(L):
     if getattr(L, "_doc_bound", False):
         return

@@ -198,7 +198,9 @@ class DetReidTrackPipeline:
         tlk_simcc_decode) between detector and ReID; its keypoints drive the tracker's OKS motion cost (motion_criterium "oks")."""
         from .backbones.reid import part_based_reid
         self.tracker = tracker
-        if tracker == "strong_sort":
+        # trackers that own a global-feature ReID net on Pillow-semantics 256x128 crops (ReIDDetectMultiBackend): same stages, other bank
+        self.global_feat = tracker in ("strong_sort", "bot_sort", "deep_oc_sort")
+        if self.global_feat:
             parts, dim, reid_hw = 1, 512, (256, 128)
         self.S, self.F, self.maxd = n_streams, frames_per_step, max_dets
         self.H, self.W, self.size, self.dtype = height, width, size, dtype
@@ -214,6 +216,13 @@ class DetReidTrackPipeline:
         if tracker == "strong_sort" and tracker_cfg is None:       # StrongSORT.__init__ defaults (strong_sort.py:19-32) + wrapper filter
             self.tracker_cfg = dict(max_dist=0.2, max_iou_dist=0.7, max_age=70, max_unmatched_preds=7, n_init=3, nn_budget=100,
                                     mc_lambda=0.995, ema_alpha=0.9)
+        if tracker == "bot_sort" and tracker_cfg is None:          # BoTSORT.__init__ defaults (bot_sort.py:236-249), cmc_method none
+            self.tracker_cfg = dict(track_high_thresh=0.45, new_track_thresh=0.6, track_buffer=30, match_thresh=0.8, proximity_thresh=0.5,
+                                    appearance_thresh=0.25, frame_rate=30, lambda_=0.985)
+        if tracker == "deep_oc_sort" and tracker_cfg is None:      # configs/modules/track/deep_oc_sort.yaml with cmc_off
+            self.tracker_cfg = dict(det_thresh=0, max_age=50, min_hits=1, iou_threshold=0.22136877277096445, delta_t=1, asso_func="giou",
+                                    inertia=0.3941737016672115, w_association_emb=0.75, alpha_fixed_emb=0.95, aw_param=0.5,
+                                    embedding_off=False, cmc_off=True, aw_off=False, new_kf_off=False)
         self.pose = None
         if pose:
             from .backbones.rtmpose import rtmpose
@@ -225,6 +234,14 @@ class DetReidTrackPipeline:
             self.bank = _lib.SsortBank(dim, **self.tracker_cfg, min_confidence=0.4, wrapper_mode=True, img_w=width, img_h=height,
                                        n_streams=n_streams, device=device, max_tracks=min(max_tracks, 256), max_dets=max_dets)
             self.row_dtype = _lib.SSORT_ROW
+        elif tracker == "bot_sort":
+            self.bank = _lib.BoTSORTBank(dim, **self.tracker_cfg, min_confidence=0.4, wrapper_mode=True, n_streams=n_streams, device=device,
+                                         max_tracks=min(max_tracks, 512 - max_dets), max_dets=max_dets)
+            self.row_dtype = _lib.BOTSORT_ROW
+        elif tracker == "deep_oc_sort":
+            self.bank = _lib.DeepOCSortBank(dim, **self.tracker_cfg, min_confidence=0.4, wrapper_mode=True, n_streams=n_streams, device=device,
+                                            max_tracks=min(max_tracks, 512), max_dets=max_dets)
+            self.row_dtype = _lib.DEEPOCSORT_ROW
         else:
             self.bank = _lib.BpbssBank(parts, dim, **self.tracker_cfg, wrapper_mode=True, n_streams=n_streams, device=device,
                                        max_tracks=max_tracks, max_dets=max_dets)
@@ -259,7 +276,7 @@ class DetReidTrackPipeline:
                 "emb": torch.zeros((B, max_dets, parts, dim), dtype=torch.float32, device=dev),
                 "vis": torch.zeros((B, max_dets, parts), dtype=torch.uint8, device=dev),
                 "counts": torch.zeros((B,), dtype=torch.int32, device=dev),
-                "trk_in": torch.zeros((B, max_dets, 7), dtype=torch.float64, device=dev) if tracker == "strong_sort" else None,
+                "trk_in": torch.zeros((B, max_dets, 7), dtype=torch.float64, device=dev) if self.global_feat else None,
                 "kps": torch.zeros((B, max_dets, 17, 3), dtype=torch.float64, device=dev) if self.pose is not None else None,
                 "rows": torch.zeros((B, max_dets, row_bytes), dtype=torch.uint8, device=dev),
                 "ocnt": torch.zeros((B,), dtype=torch.int32, device=dev),
@@ -321,7 +338,7 @@ class DetReidTrackPipeline:
         if self.record_kernel_events:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if self.tracker == "strong_sort":       # StrongSORT._get_features: int-truncated boxes, Pillow resize, ImageNet normalisation
+        if self.global_feat:                    # StrongSORT._get_features: int-truncated boxes, Pillow resize, ImageNet normalisation
             crops = _lib.roi_crop_pil_resize_norm(frames, buf["trk_in"], self.det["counts"], self.reid_hw[0], self.reid_hw[1],
                                                   "nhwc", self.dtype, out=self.crops)
         else:
@@ -355,7 +372,7 @@ class DetReidTrackPipeline:
         self.frames_done += S * F
         with torch.cuda.stream(self.trk_stream):
             self.trk_stream.wait_event(buf["ready"])
-            if self.tracker == "strong_sort":
+            if self.global_feat:
                 self.bank.update_dev(buf["trk_in"].data_ptr(), buf["emb"].data_ptr(), buf["counts"].data_ptr(), F, buf["rows"].data_ptr(),
                                      maxd, buf["ocnt"].data_ptr(), C.c_void_p(self.trk_stream.cuda_stream))
             else:
