@@ -10,8 +10,8 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$R"
 python bench.py --workload config3 --steps 6 --warmup 2 > "$OUT/bench_config3.json" 2> "$OUT/bench_config3.err"
 python bench.py --workload config2 --steps 10 --warmup 2 > "$OUT/bench_config2.json" 2> "$OUT/bench_config2.err"
-for wl in config1 config4 config5 config3s config2b; do
-  python bench.py --workload $wl --steps 6 --warmup 2 > "$OUT/bench_$wl.json" 2> "$OUT/bench_$wl.err"
+for wl in config1 config4 config5 config3s config3b config3d config2b; do
+  python bench.py --workload $wl --steps 6 --warmup 2 --cpu-seconds 10 > "$OUT/bench_$wl.json" 2> "$OUT/bench_$wl.err"
 done
 cd /tmp && export TMPDIR=/tmp
 for wl in config3 config2 config3s; do
