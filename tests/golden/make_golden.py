@@ -25,6 +25,7 @@ import sys
 import types
 
 import numpy as np
+import pandas as pd
 import scipy
 import torch
 
@@ -1012,11 +1013,120 @@ def gen_deepocsort(out_dir):
             sys.modules["lap"] = saved_lap
 
 
+CLEARMOT_METRICS = ["num_frames", "num_matches", "num_switches", "num_transfer", "num_ascend", "num_migrate", "num_false_positives", "num_misses",
+                    "num_objects", "num_predictions", "num_unique_objects", "mostly_tracked", "partially_tracked", "mostly_lost",
+                    "num_fragmentations", "num_detections", "idtp", "idfp", "idfn", "motp", "mota", "precision", "recall", "idp", "idr", "idf1"]
+
+
+def gen_clearmot(out_dir):
+    """CLEAR-MOT / ID measures: the py-motmetrics copy vendored by the reference (plugins/eval/PoseTrack21/posetrack21_mot) run on
+    synthetic sequences (ground truth vs. jittered, dropped, id-swapped and spurious hypotheses), scipy solver (the `lap` solver its
+    evaluate_mot.py selects is not installed), per sequence and overall (compute_many(generate_overall=True))."""
+    import types
+    sys.path.insert(0, os.path.join(REF, "plugins", "eval", "PoseTrack21", "posetrack21_mot", "posetrack21_mot"))
+    if not hasattr(np, "asfarray"):
+        np.asfarray = lambda a, dtype=float: np.asarray(a, dtype=dtype)          # numpy 2 removed it (distances.py:122)
+    sys.modules.setdefault("xmltodict", types.ModuleType("xmltodict"))           # motmetrics/io.py imports it for a loader not used here
+    import motmetrics as mm
+    mm.lap.default_solver = "scipy"
+    rng = np.random.default_rng(77)
+    seqs, accs = [], []
+    for s, (nobj, nframes, jitter, drop, swap, spurious) in enumerate([(8, 60, 2.0, 0.05, 0.02, 0.3), (20, 80, 6.0, 0.2, 0.05, 1.0),
+                                                                       (5, 40, 1.0, 0.0, 0.0, 0.0), (12, 50, 15.0, 0.4, 0.1, 2.0)]):
+        stream = SyntheticStream(300 + s, nobj, nframes, miss_prob=0.0)
+        acc = mm.MOTAccumulator(auto_id=True)
+        perm = {}
+        frames = []
+        for fr in stream:
+            gt_ids = fr["gt_all_ids"].astype(np.int64)
+            gb = fr["gt_boxes"]
+            gt = np.column_stack([gb[:, 0], gb[:, 1], gb[:, 2] - gb[:, 0], gb[:, 3] - gb[:, 1]])
+            keep = rng.random(len(gt)) >= drop
+            hyp = gt[keep] + rng.normal(0, jitter, (int(keep.sum()), 4))
+            hyp[:, 2:] = np.maximum(hyp[:, 2:], 1.0)
+            hid = gt_ids[keep].copy()
+            for k in range(len(hid)):                          # persistent identity swaps
+                if rng.random() < swap:
+                    perm[hid[k]] = 1000 + int(rng.integers(0, 50))
+                hid[k] = perm.get(hid[k], hid[k])
+            _, first = np.unique(hid, return_index=True)       # hypotheses ids are unique within a frame
+            hyp, hid = hyp[np.sort(first)], hid[np.sort(first)]
+            nsp = rng.poisson(spurious)
+            if nsp:
+                sp = np.column_stack([rng.uniform(0, 1800, nsp), rng.uniform(0, 1000, nsp), rng.uniform(30, 120, nsp), rng.uniform(60, 250, nsp)])
+                hyp = np.concatenate([hyp, sp]); hid = np.concatenate([hid, 5000 + rng.integers(0, 20, nsp)])
+                _, first = np.unique(hid, return_index=True)
+                hyp, hid = hyp[np.sort(first)], hid[np.sort(first)]
+            d = mm.distances.iou_matrix(gt, hyp, max_iou=0.5)
+            acc.update(gt_ids, hid, d)
+            frames.append((gt_ids, gt, hid, hyp, d))
+        seqs.append(frames); accs.append(acc)
+    mh = mm.metrics.create()
+    summ = mh.compute_many(accs, metrics=[m for m in CLEARMOT_METRICS], names=[f"s{i}" for i in range(len(accs))], generate_overall=True)
+    blobs = {"metric_names": np.array(CLEARMOT_METRICS), "summary": summ[CLEARMOT_METRICS].to_numpy(dtype=np.float64),
+             "row_names": np.array(list(summ.index))}
+    for s, frames in enumerate(seqs):
+        blobs[f"s{s}_offsets_gt"] = np.cumsum([0] + [len(f[0]) for f in frames]).astype(np.int64)
+        blobs[f"s{s}_offsets_hyp"] = np.cumsum([0] + [len(f[2]) for f in frames]).astype(np.int64)
+        blobs[f"s{s}_gt_ids"] = np.concatenate([f[0] for f in frames]); blobs[f"s{s}_gt_ltwh"] = np.concatenate([f[1] for f in frames])
+        blobs[f"s{s}_hyp_ids"] = np.concatenate([f[2] for f in frames]); blobs[f"s{s}_hyp_ltwh"] = np.concatenate([f[3] for f in frames])
+        blobs[f"s{s}_dist_f10"] = frames[10][4]                # one distance matrix per sequence for iou_distance_matrix
+    np.savez_compressed(os.path.join(out_dir, "clearmot.npz"), **blobs)
+    print(summ[["mota", "motp", "idf1", "num_switches", "num_fragmentations", "mostly_tracked"]])
+
+
+def gen_mot_io(out_dir):
+    """MOTChallenge text export: TrackingDataset.save_for_eval (tracklab/datastruct/tracking_dataset.py:161-236) loaded from its file
+    with tracklab.utils (wandb / omegaconf imports) stubbed; inputs and the files it wrote are the fixture."""
+    import importlib.util
+    import tempfile
+    import types
+    for name in ("tracklab", "tracklab.utils"):
+        if name not in sys.modules:
+            m = types.ModuleType(name); m.__path__ = []; sys.modules[name] = m
+    sys.modules["tracklab.utils"].wandb = types.SimpleNamespace(log=lambda *a, **k: None)
+    spec = importlib.util.spec_from_file_location("ref_tracking_dataset", os.path.join(REF, "tracklab", "datastruct", "tracking_dataset.py"))
+    td = importlib.util.module_from_spec(spec); spec.loader.exec_module(td)
+    ds = object.__new__(td.TrackingDataset)
+    rng = np.random.default_rng(4)
+    nv, per = 3, [25, 1, 12]
+    video = pd.DataFrame({"name": ["seq-A", "seq_B", "c"] + ["empty"]}, index=pd.Index([3, 7, 11, 20], name="id"))
+    img_rows, det_rows = [], []
+    iid, did = 1000, 50000
+    for v, (vid, nfr) in enumerate(zip([3, 7, 11], per)):
+        for f in range(nfr):
+            img_rows.append((iid, f, vid))
+            for k in range(int(rng.integers(0, 5))):
+                box = rng.uniform(0, 900, 4).astype(np.float32) if v != 2 else rng.uniform(0, 900, 4)      # float32 and float64 boxes
+                det_rows.append((did, iid, vid, box, float(np.round(rng.uniform(0.1, 1.0), int(rng.integers(1, 9)))),
+                                 float(rng.integers(1, 9)) if rng.random() > 0.15 else np.nan, int(rng.integers(1, 4))))
+                did += 1
+            iid += 1
+    imgs = pd.DataFrame({"frame": [r[1] for r in img_rows], "video_id": [r[2] for r in img_rows]}, index=pd.Index([r[0] for r in img_rows], name="id"))
+    det = pd.DataFrame({"image_id": [r[1] for r in det_rows], "video_id": [r[2] for r in det_rows], "bbox_ltwh": [r[3] for r in det_rows],
+                        "bbox_conf": [r[4] for r in det_rows], "track_id": [r[5] for r in det_rows], "category_id": [r[6] for r in det_rows]},
+                       index=pd.Index([r[0] for r in det_rows], name="id"))
+    det = det.sample(frac=1.0, random_state=1)                 # detections arrive in any order
+    blobs = {}
+    for tag, kw in (("plain", {}), ("classes", dict(save_classes=True))):
+        with tempfile.TemporaryDirectory() as tmp:
+            ds.save_for_eval(det, imgs.copy(), video, tmp, **kw)
+            for name in video["name"]:
+                blobs[f"{tag}_{name}"] = np.array(open(os.path.join(tmp, f"{name}.txt")).read())
+    np.savez_compressed(os.path.join(out_dir, "mot_io.npz"), det_index=det.index.to_numpy(), det_image_id=det.image_id.to_numpy(),
+                        det_video_id=det.video_id.to_numpy(), det_ltwh=np.stack([np.asarray(b, np.float64) for b in det.bbox_ltwh]),
+                        det_is_f32=np.array([b.dtype == np.float32 for b in det.bbox_ltwh]), det_conf=det.bbox_conf.to_numpy(),
+                        det_track_id=det.track_id.to_numpy(), det_category=det.category_id.to_numpy(), img_index=imgs.index.to_numpy(),
+                        img_frame=imgs.frame.to_numpy(), img_video_id=imgs.video_id.to_numpy(), video_index=video.index.to_numpy(),
+                        video_name=np.array(list(video["name"])), **blobs)
+    print("mot_io:", {k: len(str(v)) for k, v in blobs.items()})
+
+
 def main():
     out_dir = HERE
     only = set(sys.argv[1:])
     gens = {"ocsort": gen_ocsort, "iou": gen_iou_family, "kf7": gen_kf7, "lsa": gen_lsa,
-            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack, "botsort": gen_botsort, "deepocsort": gen_deepocsort}
+            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack, "botsort": gen_botsort, "deepocsort": gen_deepocsort, "clearmot": gen_clearmot, "mot_io": gen_mot_io}
     for k, fn in gens.items():
         if not only or k in only:
             fn(out_dir)
