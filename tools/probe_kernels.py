@@ -1,5 +1,5 @@
 """Probe (not product): launch the byte-moving libtlk kernels in isolation for rocprofv3 --pmc passes.
-Shapes = one bench launch: letterbox of 32 (config2) frames, crop of 24 frames x 104 slots (config3).
+Shapes = one bench launch: letterbox of 32 (config2) frames, crop of 24 frames x 104 slots (config3; Pillow-semantics crop: config3s/3b/3d).
 Calibration launches with a known byte count in the SAME access pattern: letterbox 640x640 -> 640 (every source byte
 read exactly once by the same byte loads) and a 1 GiB torch copy (wide coalesced)."""
 import numpy as np
@@ -26,6 +26,11 @@ big = torch.empty(1 << 28, dtype=torch.float32, device="cuda")     # 1 GiB
 big2 = torch.empty_like(big)
 out_lb = torch.empty((32, 320, 320, 12), dtype=torch.float16, device="cuda")
 out_cr = torch.empty((24 * 104, 384, 128, 3), dtype=torch.float16, device="cuda")
+out_pil = torch.empty((24 * 104, 256, 128, 3), dtype=torch.float16, device="cuda")
+xyxy = np.zeros((24, 104, 7))                                      # tracker input rows [x1, y1, x2, y2, conf, cls, id] (config3s/3b/3d)
+xyxy[..., 0], xyxy[..., 1] = boxes[..., 0], boxes[..., 1]
+xyxy[..., 2], xyxy[..., 3] = boxes[..., 0] + boxes[..., 2], boxes[..., 1] + boxes[..., 3]
+dx = torch.from_numpy(xyxy).cuda()
 src_bytes = float(sum((np.clip(np.rint(boxes[b, :counts[b], 2]), 1, None) * np.clip(np.rint(boxes[b, :counts[b], 3]), 1, None)).sum() for b in range(24)) * 3)
 print("crop source bytes (approx)", src_bytes, "crop out bytes", out_cr.numel() * 2)
 for it in range(5):
@@ -33,5 +38,6 @@ for it in range(5):
     _lib.letterbox(f640, 640, "focus_nhwc", torch.float16, out=out_lb)
     _lib.letterbox(f1080, 640, "focus_nhwc", torch.float16, out=out_lb)
     _lib.roi_crop_resize_norm(f1080[:24], db, dc, 384, 128, "nhwc", torch.float16, out=out_cr)
+    _lib.roi_crop_pil_resize_norm(f1080[:24], dx, dc, 256, 128, "nhwc", torch.float16, out=out_pil)
 torch.cuda.synchronize()
 print("done")
