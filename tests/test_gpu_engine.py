@@ -104,3 +104,22 @@ def test_pipeline_global_feature_trackers_match_oracle_fed_with_gpu_embeddings(o
             n_rows += len(exp)
     assert n_rows > 40
     pipe.close()
+
+
+@pytest.mark.parametrize("tracker", ["strong_sort", "bot_sort", "deep_oc_sort"])
+def test_video_engine_runs_the_global_feature_trackers(tracker):
+    """The per-video loop fills the table for every ReID tracker's row type (ltrb + the tracker's own confidence column)."""
+    from tracklab_amd import gpu_pipeline as gp
+    from tracklab_amd.engine import HipVideoEngine
+    F, T = 3, 8
+    pipe = gp.DetReidTrackPipeline("s", n_streams=1, frames_per_step=F, max_dets=32, use_graph=False, tracker=tracker)
+    heads, frames = _inputs(24, 10, T, pipe.ratio)
+    df = HipVideoEngine(pipe).video_loop(frames, synth_heads=lambda t0, n: heads[t0:t0 + n])
+    assert df.image_id.nunique() == T
+    tracked = df[df.track_id.notna()]
+    first = 0 if tracker != "strong_sort" else 2                # n_init = 3: plain StrongSORT reports from its third hit on
+    late = tracked[tracked.image_id >= first]
+    assert len(late) >= 0.8 * len(df[df.image_id >= first]) and late.track_id.nunique() <= 14
+    ltwh = np.stack(late.track_bbox_ltwh.to_list())
+    assert np.isfinite(ltwh).all() and (ltwh[:, 2:] > 0).all() and np.isfinite(late.track_bbox_conf.to_numpy()).all()
+    pipe.close()

@@ -75,8 +75,8 @@ class DetectionTable:
 
 
 class HipVideoEngine:
-    """One video through a ``gpu_pipeline.DetTrackPipeline`` (detector + OC-SORT) or ``DetReidTrackPipeline`` (detector +
-    [pose +] ReID + BPBReID-StrongSORT) with ``n_streams == 1``. ``video_loop`` mirrors
+    """One video through a ``gpu_pipeline.DetTrackPipeline`` (detector + OC-SORT / ByteTrack) or ``DetReidTrackPipeline`` (detector +
+    [pose +] ReID + BPBReID-StrongSORT / plain StrongSORT / BoT-SORT / Deep-OC-SORT) with ``n_streams == 1``. ``video_loop`` mirrors
     ``VideoOnlineTrackingEngine.video_loop`` (engine/video.py:67-117): modules are reset, frames go through in order, one
     detections frame comes back."""
 
@@ -163,7 +163,14 @@ class HipVideoEngine:
             base = table.append_frame(first + f, det_ids, ltwh[f, :m], 1.0, 1)         # RTMLibDetector: bbox_conf 1.0, category 1
             if self._is_reid:
                 r = rows_sf[0][f]
-                table.set_tracks(base, det_ids, r["det_id"], r["track_id"].astype(np.float64), r["kf_ltwh"], np.ones(len(r)))
+                names = r.dtype.names
+                if "kf_ltwh" in names:               # BPBReID-StrongSORT rows
+                    tl, conf = r["kf_ltwh"], np.ones(len(r))
+                else:                                # plain StrongSORT / BoT-SORT / Deep-OC-SORT rows: ltrb + the tracker's confidence column
+                    b = r["ltrb"]
+                    tl = np.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], axis=1) if len(r) else np.zeros((0, 4))
+                    conf = r["conf"] if "conf" in names else r["score"]
+                table.set_tracks(base, det_ids, r["det_id"].astype(np.int64), r["track_id"].astype(np.float64), tl, conf)
             else:
                 r = rows_arr[0, f, :int(cnt[0, f])]
                 tl = np.stack([r[:, 0], r[:, 1], r[:, 2] - r[:, 0], r[:, 3] - r[:, 1]], axis=1) if len(r) else np.zeros((0, 4))
