@@ -162,7 +162,7 @@ __device__ __forceinline__ void store_xp(const Trk &T, const double (&x)[8], con
 }
 
 // KalmanFilterNew.update(z, R=R) incl. the unfreeze replay (kalmanfilter.py:433-478, :480-569)
-__device__ void kf_update_obs(const Trk &T, const double *z, const double (&R)[4])
+__device__ __noinline__ void kf_update_obs(const Trk &T, const double *z, const double (&R)[4])
 {
     double x[8], P[64];
     const bool observed = T.i(GI_OBSERVED) != 0, has_saved = T.i(GI_HAS_SAVED) != 0;
@@ -224,7 +224,7 @@ __device__ __forceinline__ bool obs_lookup(const Trk &T, int age, double *box)
 }
 
 // KalmanBoxTracker.update(bbox, cls, tracklab_id) (ocsort.py:208-252). det = 7-vector
-__device__ void kbt_update(const Trk &T, const double *det, int delta_t)
+__device__ __noinline__ void kbt_update(const Trk &T, const double *det, int delta_t)
 {
     double lo[5];
 #pragma unroll
@@ -263,7 +263,7 @@ __device__ void kbt_update(const Trk &T, const double *det, int delta_t)
     T.d(GD_TID) = det[6];
 }
 
-__device__ void kbt_init(const Trk &T, const double *det, int id)   // ocsort.py:100-206 (new_kf)
+__device__ __noinline__ void kbt_init(const Trk &T, const double *det, int id)   // ocsort.py:100-206 (new_kf)
 {
     double z[4], q[8];
     bbox_to_z(det, z);

@@ -163,7 +163,7 @@ __device__ __forceinline__ void store_xp(const Trk &T, const double (&x)[7], con
 }
 
 // KalmanFilterNew.update(z) incl. unfreeze replay (kalmanfilter.py:390-434,437-526)
-__device__ void kf_update_obs(const Trk &T, const double *z)
+__device__ __noinline__ void kf_update_obs(const Trk &T, const double *z)
 {
     double x[7], P[49];
     const bool observed = T.i(FI_OBSERVED) != 0, has_saved = T.i(FI_HAS_SAVED) != 0;
@@ -225,7 +225,7 @@ __device__ __forceinline__ bool obs_lookup(const Trk &T, int age, double *box)
 }
 
 // KalmanBoxTracker.update(bbox, cls, tracklab_id), ocsort.py:109-148. det = 7-vector
-__device__ void kbt_update(const Trk &T, const double *det, int delta_t)
+__device__ __noinline__ void kbt_update(const Trk &T, const double *det, int delta_t)
 {
     double lo[5];
 #pragma unroll
@@ -262,7 +262,7 @@ __device__ void kbt_update(const Trk &T, const double *det, int delta_t)
     T.d(FD_TID) = det[6];
 }
 
-__device__ void kbt_init(const Trk &T, const double *det, int id)   // ocsort.py:63-107
+__device__ __noinline__ void kbt_init(const Trk &T, const double *det, int id)   // ocsort.py:63-107
 {
 #pragma unroll
     for (int k = 0; k < 49; ++k) T.d(FD_P + k) = 0.0;
