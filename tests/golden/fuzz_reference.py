@@ -1,7 +1,7 @@
 """Differential fuzzing of the C oracle against the reference itself (THIS container only: imports /root/reference through the
 same shims as make_golden.py). Not part of the test suite -- the committed goldens are; this widens the net over random
 hyper-parameters and streams and prints the first divergence of each tracker, if any.
-usage: python tests/golden/fuzz_reference.py [n_trials] [trackers: bytetrack,botsort,deepocsort,ssort]"""
+usage: python tests/golden/fuzz_reference.py [n_trials] [trackers: ocsort,bpbss,bytetrack,botsort,deepocsort,ssort]"""
 import os
 import sys
 
@@ -12,11 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import make_golden as mg  # noqa: E402  (sets sys.path for the reference plugins and the repo)
 import oracle  # noqa: E402
-from tracklab_amd.synth import SyntheticStream  # noqa: E402
+from tracklab_amd.synth import SyntheticStream, ltrb_to_ltwh_rows, synth_keypoints  # noqa: E402
 
 oracle.build()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-WHICH = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else {"bytetrack", "botsort", "deepocsort", "ssort"}
+WHICH = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else {"ocsort", "bpbss", "bytetrack", "botsort", "deepocsort", "ssort"}
 IMG = np.zeros((1080, 1920, 3), np.uint8)
 
 
@@ -144,7 +144,61 @@ def fuzz_ssort(trial, rng):
     return True
 
 
-FUZZ = {"bytetrack": fuzz_bytetrack, "botsort": fuzz_botsort, "deepocsort": fuzz_deepocsort, "ssort": fuzz_ssort}
+def fuzz_ocsort(trial, rng):
+    mg._install_filterpy_shim()
+    import oc_sort.ocsort as ref
+    hp = dict(det_thresh=float(rng.choice([0.0, 0.3, 0.5])), max_age=int(rng.integers(3, 40)), min_hits=int(rng.integers(1, 4)),
+              iou_threshold=float(rng.uniform(0.15, 0.4)), delta_t=int(rng.integers(1, 4)), asso_func=str(rng.choice(["iou", "giou", "diou", "ciou", "ct_dist"])),
+              inertia=float(rng.uniform(0.0, 0.5)), use_byte=bool(rng.random() < 0.4))
+    trk, orc = ref.OCSort(**hp), oracle.OCSort(**hp)
+    for fr in SyntheticStream(5000 + trial, int(rng.integers(5, 60)), 120, **stream_kw(rng)):
+        d = fr["dets"]
+        if len(d) == 0:
+            continue
+        inp = torch.from_numpy(d.copy())
+        exp = np.asarray(trk.update(inp[inp[:, 4] > 0.4], None), dtype=np.float64).reshape(-1, 8)
+        if not compare("ocsort", trial, fr["frame"], oracle.ocsort_wrapper_step(orc, d, 0.4), exp, tol=1e-9):
+            return False
+    return True
+
+
+def fuzz_bpbss(trial, rng):
+    mg._install_cv2_stub()
+    import bpbreid_strong_sort.sort.nn_matching as nnm
+    nnm.compute_distance_matrix_using_bp_features = mg.bp_distance_restated
+    import bpbreid_strong_sort.strong_sort as ss
+    K, D = int(rng.choice([3, 6])), int(rng.choice([16, 32]))
+    oks = bool(rng.random() < 0.3)
+    cfg = dict(mg.BPB_YAML, ema_alpha=float(rng.uniform(0.5, 0.95)), max_dist=float(rng.uniform(0.25, 0.6)), max_iou_distance=float(rng.uniform(0.6, 0.9)),
+               max_age=int(rng.integers(5, 60)), n_init=int(rng.integers(0, 4)), min_bbox_confidence=float(rng.choice([0.0, 0.5])),
+               only_position_for_kf_gating=bool(rng.random() < 0.3), max_kalman_prediction_without_update=int(rng.integers(0, 8)),
+               matching_strategy=str(rng.choice(["strong_sort_matching", "bot_sort_matching"])), gating_thres_factor=float(rng.choice([1, 1.5])),
+               motion_criterium="oks" if oks else "iou")
+    model, orc = ss.StrongSORT(**cfg), oracle.StrongSORT(K, D, **cfg)
+    kp_rng = np.random.default_rng(77 + trial)
+    for fr in SyntheticStream(6000 + trial, int(rng.integers(5, 40)), 100, parts=K, dim=D, with_embeddings=True, **stream_kw(rng)):
+        d = fr["dets"]
+        if len(d) == 0:
+            continue
+        ltwh, conf, did = ltrb_to_ltwh_rows(d[:, :4]), d[:, 4].copy(), d[:, 6].astype(np.int64)
+        kp = synth_keypoints(kp_rng, d[:, :4]) if oks else None
+        df = model.update(torch.from_numpy(did), torch.from_numpy(ltwh), torch.from_numpy(fr["embeddings"]), torch.from_numpy(fr["visibility"]),
+                          torch.from_numpy(conf), torch.zeros(len(d), dtype=torch.float64), torch.ones(len(d), dtype=torch.float64) * fr["frame"],
+                          torch.from_numpy(kp) if oks else None)
+        got = orc.update(did, ltwh, fr["embeddings"], fr["visibility"], conf, keypoints=kp)
+        exp_idx = np.array([int(i) for i in df.index], dtype=np.int64)
+        exp_tid = np.array([int(t) for t in df.track_id], dtype=np.int64) if len(df) else np.zeros(0, np.int64)
+        ok = len(got) == len(df) and np.array_equal(got["det_id"], exp_idx) and np.array_equal(got["track_id"], exp_tid)
+        if ok and len(df):
+            ok = np.allclose(got["kf_ltwh"], np.stack([np.asarray(b, dtype=np.float64) for b in df.track_bbox_kf_ltwh]), rtol=1e-7, atol=1e-7) and \
+                np.array_equal(got["hits"], df.hits.to_numpy().astype(np.int32)) and np.array_equal(got["tsu"], df.time_since_update.to_numpy().astype(np.int32))
+        if not ok:
+            print(f"DIVERGENCE bpbss trial {trial} frame {fr['frame']} cfg {cfg}")
+            return False
+    return True
+
+
+FUZZ = {"ocsort": fuzz_ocsort, "bpbss": fuzz_bpbss, "bytetrack": fuzz_bytetrack, "botsort": fuzz_botsort, "deepocsort": fuzz_deepocsort, "ssort": fuzz_ssort}
 for name in sorted(WHICH):
     ok = 0
     for t in range(N):
