@@ -32,6 +32,7 @@ def test_plugin_contract():
     assert m.output_columns == ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
     b = HipBPBReIDStrongSORT(NS(ecc=False), "cuda:0", batch_size=8)
     assert b.level == "image" and b.batch_size == 1 and len(b.output_columns) == 9
+    HipBPBReIDStrongSORT(NS(ecc=True), "cuda:0")     # inert in the reference too: prepare_next_frame (its only ECC call site) is never called
     assert m.preprocess(None, pd.DataFrame(), pd.Series(dtype=float)) == {"input": []}
     assert m.process({"input": []}, pd.DataFrame(), pd.DataFrame()) == []
 

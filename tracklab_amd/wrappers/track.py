@@ -85,7 +85,11 @@ class HipBPBReIDStrongSORT(ImageLevelModule):
         self._bank = None
         self._shape = None
         if cfg_get(cfg, "ecc", False):
-            raise NotImplementedError("ecc camera compensation is not part of the HIP path (reference default: ecc False)")
+            # The reference's only ECC call site for this tracker is BPBReIDStrongSORT.prepare_next_frame
+            # (bpbreid_strong_sort_api.py:62-70), which nothing calls: StrongSORT.update predicts itself (strong_sort.py:86).
+            # `ecc: true` therefore changes nothing there, and nothing here.
+            import logging
+            logging.getLogger(__name__).info("ecc: true has no effect for BPBReID-StrongSORT (the reference never calls prepare_next_frame)")
 
     def _make_backend(self, parts, dim):
         from .._lib import BpbssBank
