@@ -379,3 +379,33 @@ int orc_ssort_tracks(const orc_ssort *T, int64_t *ids, double *mean, double *cov
     }
     return n;
 }
+
+/* Tracker.camera_update -> Track.camera_update (sort/tracker.py:66-68, sort/track.py:221-239) with the ECC estimate passed in:
+ * warp (2,3) as cv2.findTransformECC returned it (float32 values) after the translation rescaling of Track.ECC (:204-206); a third row
+ * [0, 0, 1] is appended, get_matrix (:213-219) replaces it by the identity when ||I - M||_F >= 100, every track's (x1, y1, x2, y2)
+ * corners go through it and the mean becomes [cx, cy, w / h, h] in the mean's own dtype. The estimator itself is cv2. */
+void orc_ssort_camera_update(orc_ssort *t, const double *warp6)
+{
+    double M[9] = {warp6[0], warp6[1], warp6[2], warp6[3], warp6[4], warp6[5], 0, 0, 1};
+    double d2 = 0;
+    for (int i = 0; i < 9; ++i) { const double e = (i % 4 == 0 ? 1.0 : 0.0) - M[i]; d2 += e * e; }
+    if (!(sqrt(d2) < 100)) { memset(M, 0, sizeof(M)); M[0] = M[4] = M[8] = 1; }
+    for (int i = 0; i < t->n; ++i) {
+        strk *k = &t->trk[i];
+        double x1, y1, x2, y2;
+        if (k->f32_state) {                                   /* to_tlwh / to_tlbr on a float32 mean (track.py:94-113) */
+            float r0 = (float)k->mean[0], r1 = (float)k->mean[1], r2 = (float)k->mean[2]; const float r3 = (float)k->mean[3];
+            r2 *= r3; r0 -= r2 / 2; r1 -= r3 / 2;
+            x1 = r0; y1 = r1; x2 = (float)(r0 + r2); y2 = (float)(r1 + r3);
+        } else {
+            double r0 = k->mean[0], r1 = k->mean[1], r2 = k->mean[2]; const double r3 = k->mean[3];
+            r2 *= r3; r0 -= r2 / 2; r1 -= r3 / 2;
+            x1 = r0; y1 = r1; x2 = r0 + r2; y2 = r1 + r3;
+        }
+        const double x1_ = M[0] * x1 + M[1] * y1 + M[2] * 1.0, y1_ = M[3] * x1 + M[4] * y1 + M[5] * 1.0;
+        const double x2_ = M[0] * x2 + M[1] * y2 + M[2] * 1.0, y2_ = M[3] * x2 + M[4] * y2 + M[5] * 1.0;
+        const double w = x2_ - x1_, h = y2_ - y1_, cx = x1_ + w / 2, cy = y1_ + h / 2;
+        const double nm[4] = {cx, cy, w / h, h};
+        for (int q = 0; q < 4; ++q) k->mean[q] = k->f32_state ? (double)(float)nm[q] : nm[q];
+    }
+}

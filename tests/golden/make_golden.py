@@ -1122,11 +1122,64 @@ def gen_mot_io(out_dir):
     print("mot_io:", {k: len(str(v)) for k, v in blobs.items()})
 
 
+def gen_ssort_camera(out_dir):
+    """Plain StrongSORT with `ecc: true` minus the estimator: Tracker.camera_update (sort/tracker.py:66-68) -> Track.camera_update
+    (sort/track.py:221-239) run as is before every StrongSORT.update, like strong_sort_api.py:62-65, with Track.ECC (the
+    cv2.findTransformECC call) replaced by a per-frame synthetic float32 (2,3) warp; one frame gets a far-off warp (get_matrix -> identity)."""
+    ss, Metric, Tracker = _import_plain_strong_sort()
+    import strong_sort.sort.track as track_mod
+    hp = dict(max_dist=0.2, max_iou_dist=0.7, max_age=30, max_unmatched_preds=7, n_init=2, nn_budget=20, mc_lambda=0.995, ema_alpha=0.9)
+    D, nframes = 32, 60
+    rng = np.random.default_rng(11)
+    warps = []
+    for f in range(nframes):
+        th = rng.normal(0, 0.004)
+        wm = np.array([[np.cos(th), -np.sin(th), rng.normal(0, 3.0)], [np.sin(th), np.cos(th), rng.normal(0, 2.0)]], dtype=np.float32)
+        if f == 25:
+            wm[0, 2] = 500.0                                   # ||I - M|| >= 100: get_matrix falls back to the identity
+        warps.append(wm)
+    cur = {}
+    orig = track_mod.Track.ECC
+    track_mod.Track.ECC = lambda self, src, dst, *a, **k: (cur["w"].copy(), None)
+    try:
+        model = object.__new__(ss.StrongSORT)
+        model.max_dist = hp["max_dist"]
+        model.tracker = Tracker(Metric("cosine", hp["max_dist"], hp["nn_budget"]), max_iou_dist=hp["max_iou_dist"], max_age=hp["max_age"],
+                                n_init=hp["n_init"], max_unmatched_preds=hp["max_unmatched_preds"], mc_lambda=hp["mc_lambda"], ema_alpha=hp["ema_alpha"])
+        img = np.zeros((1080, 1920, 3), dtype=np.uint8)
+        in_off, out_off, dets_all, embs, rows, blobs = [0], [0], [], [], [], {}
+        prev = None
+        for fr in SyntheticStream(21, 25, nframes, parts=1, dim=D, with_embeddings=True, miss_prob=0.15, churn_period=20):
+            f = fr["frame"]
+            dets, emb = fr["dets"], fr["embeddings"][:, 0, :].astype(np.float32)
+            cur["w"] = warps[f]
+            if prev is not None:                               # strong_sort_api.py:62-65
+                model.tracker.camera_update(prev, img)
+            prev = img
+            dets_all.append(dets); embs.append(emb); in_off.append(in_off[-1] + len(dets))
+            feats = torch.from_numpy(emb.copy())
+            model._get_features = lambda xywhs, im, feats=feats: feats
+            out = model.update(torch.from_numpy(dets.copy()), img)
+            for r in out:
+                rows.append([float(r[k]) for k in (0, 1, 2, 3, 4, 5, 6, 8)])
+            out_off.append(out_off[-1] + len(out))
+            if f in (1, 2, 10, 25, 26, 59):
+                tr = model.tracker.tracks
+                blobs[f"f{f}_track_ids"] = np.array([t.track_id for t in tr], dtype=np.int64)
+                blobs[f"f{f}_mean"] = np.stack([np.asarray(t.mean, dtype=np.float64) for t in tr]).reshape(-1, 8)
+    finally:
+        track_mod.Track.ECC = orig
+    np.savez_compressed(os.path.join(out_dir, "camera_ssort.npz"), dets=np.concatenate(dets_all), embeddings=np.concatenate(embs),
+                        det_offsets=np.array(in_off, dtype=np.int64), out_offsets=np.array(out_off, dtype=np.int64),
+                        rows=np.array(rows, dtype=np.float64).reshape(-1, 8), warps=np.stack(warps), config=json.dumps(hp), dim=D, **blobs)
+    print(f"ssort_camera: rows_out={out_off[-1]} tracks={len(model.tracker.tracks)}")
+
+
 def main():
     out_dir = HERE
     only = set(sys.argv[1:])
     gens = {"ocsort": gen_ocsort, "iou": gen_iou_family, "kf7": gen_kf7, "lsa": gen_lsa,
-            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack, "botsort": gen_botsort, "deepocsort": gen_deepocsort, "clearmot": gen_clearmot, "mot_io": gen_mot_io}
+            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack, "botsort": gen_botsort, "deepocsort": gen_deepocsort, "clearmot": gen_clearmot, "mot_io": gen_mot_io, "ssort_camera": gen_ssort_camera}
     for k, fn in gens.items():
         if not only or k in only:
             fn(out_dir)

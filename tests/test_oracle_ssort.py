@@ -54,3 +54,23 @@ def check_state_oracle(trk, g, f):
 @pytest.mark.parametrize("name", RUNS)
 def test_plain_strongsort_oracle_matches_reference(orc, name):
     replay(name, lambda D, hp: orc.PlainStrongSORT(D, **hp), check_state_oracle)
+
+
+def test_plain_strongsort_camera_update_matches_reference(orc):
+    """`ecc: true` minus the cv2 estimator: Tracker.camera_update / Track.camera_update run by the reference with a synthetic warp
+    per frame (tests/golden/make_golden.py gen_ssort_camera), the oracle applying the same warps before each update."""
+    g = np.load(os.path.join(GOLDEN, "camera_ssort.npz"))
+    hp, D = json.loads(str(g["config"])), int(g["dim"])
+    trk = orc.PlainStrongSORT(D, **hp)
+    do, oo = g["det_offsets"], g["out_offsets"]
+    for f in range(len(do) - 1):
+        if f > 0:
+            trk.camera_update(g["warps"][f])                   # strong_sort_api.py:62-65: from the second frame on, before update()
+        out = trk.update(g["dets"][do[f]:do[f + 1]], g["embeddings"][do[f]:do[f + 1]])
+        exp = g["rows"][oo[f]:oo[f + 1]]
+        assert out.shape == exp.shape, f
+        np.testing.assert_array_equal(out, exp, err_msg=f"frame {f}")              # int boxes, ids, class, conf, tracklab id
+        if f"f{f}_track_ids" in g.files:
+            ids, mean = trk.tracks()[:2]
+            np.testing.assert_array_equal(ids, g[f"f{f}_track_ids"])
+            np.testing.assert_allclose(mean, g[f"f{f}_mean"], rtol=1e-11, atol=1e-10)
