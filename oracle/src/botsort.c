@@ -250,7 +250,29 @@ static void trk_update(orc_botsort *B, strk *k, sdet *d, int frame_id, int react
     k->tracklab_id = d->tracklab_id;
 }
 
+/* STrack.multi_gmc with a general (2,3) warp H (bot_sort.py:93-109): mean = kron(I4, R) mean, mean[:2] += t, cov = kron(I4, R) cov kron(I4, R)^T */
+static void gmc_apply(strk *k, const double *H)
+{
+    const double R[4] = {H[0], H[1], H[3], H[4]}, t[2] = {H[2], H[5]};
+    double m[8], t1[64], c2[64];
+    for (int b = 0; b < 4; ++b) {
+        m[2 * b] = R[0] * k->mean[2 * b] + R[1] * k->mean[2 * b + 1];
+        m[2 * b + 1] = R[2] * k->mean[2 * b] + R[3] * k->mean[2 * b + 1];
+    }
+    m[0] += t[0]; m[1] += t[1];
+    for (int i = 0; i < 8; ++i)                 /* t1 = R8 cov: row i mixes rows 2*(i/2), 2*(i/2)+1 */
+        for (int j = 0; j < 8; ++j) { const int r0 = i & ~1; t1[i * 8 + j] = R[(i & 1) * 2] * k->cov[r0 * 8 + j] + R[(i & 1) * 2 + 1] * k->cov[(r0 + 1) * 8 + j]; }
+    for (int i = 0; i < 8; ++i)                 /* c2 = t1 R8^T: column j mixes columns 2*(j/2), 2*(j/2)+1 */
+        for (int j = 0; j < 8; ++j) { const int c0 = j & ~1; c2[i * 8 + j] = t1[i * 8 + c0] * R[(j & 1) * 2] + t1[i * 8 + c0 + 1] * R[(j & 1) * 2 + 1]; }
+    memcpy(k->mean, m, sizeof(m)); memcpy(k->cov, c2, sizeof(c2));
+}
+
+int orc_botsort_update_gmc(orc_botsort *B, const double *dets, const float *feats, int N, const double *warp6, double *rows_out, int out_cap);
 int orc_botsort_update(orc_botsort *B, const double *dets, const float *feats, int N, double *rows_out, int out_cap)
+{ return orc_botsort_update_gmc(B, dets, feats, N, NULL, rows_out, out_cap); }
+
+/* warp6: what GMC.apply returned for this frame ((2,3) float64, bot_sort.py:341), NULL = cmc_method "none" (the identity) */
+int orc_botsort_update_gmc(orc_botsort *B, const double *dets, const float *feats, int N, const double *warp6, double *rows_out, int out_cap)
 {
     const int D = B->D;
     B->frame_id++;
@@ -288,9 +310,9 @@ int orc_botsort_update(orc_botsort *B, const double *dets, const float *feats, i
         for (int i = 0; i < n_pool; ++i) all_f32 &= B->T[pool[i]].f32;
         for (int i = 0; i < n_pool; ++i) { strk *k = &B->T[pool[i]]; if (k->state != BS_TRACKED) { k->mean[6] = 0; k->mean[7] = 0; } kf_predict(k, all_f32); }
     }
-    /* multi_gmc with the identity warp (:82-99): values unchanged, the arrays become float64 */
-    for (int i = 0; i < n_pool; ++i) B->T[pool[i]].f32 = 0;
-    for (int i = 0; i < n_unconf; ++i) B->T[unconf[i]].f32 = 0;
+    /* multi_gmc (:93-109): the arrays become float64; with the identity warp the values are unchanged */
+    for (int i = 0; i < n_pool; ++i) { B->T[pool[i]].f32 = 0; if (warp6) gmc_apply(&B->T[pool[i]], warp6); }
+    for (int i = 0; i < n_unconf; ++i) { B->T[unconf[i]].f32 = 0; if (warp6) gmc_apply(&B->T[unconf[i]], warp6); }
     int *activated = malloc(sizeof(int) * cap), *refind = malloc(sizeof(int) * cap), *newlost = malloc(sizeof(int) * cap), *removed = malloc(sizeof(int) * cap);
     int n_act = 0, n_ref = 0, n_newlost = 0, n_removed = 0;
     int *m_r = malloc(sizeof(int) * cap), *m_c = malloc(sizeof(int) * cap), *u_r = malloc(sizeof(int) * cap), *u_c = malloc(sizeof(int) * cap);

@@ -1175,11 +1175,61 @@ def gen_ssort_camera(out_dir):
     print(f"ssort_camera: rows_out={out_off[-1]} tracks={len(model.tracker.tracks)}")
 
 
+def gen_botsort_gmc(out_dir):
+    """BoT-SORT with camera-motion compensation minus the estimator: BoTSORT.update run as is with GMC.apply (the cv2 estimators,
+    gmc.py) replaced by a synthetic (2,3) float64 warp per frame (small rotation + scale + translation), so that STrack.multi_gmc
+    (bot_sort.py:93-109) runs on non-identity warps."""
+    _import_byte_track()
+    _import_plain_strong_sort()
+    import bot_sort.bot_sort as bs
+    from bot_sort.basetrack import BaseTrack
+    from bot_sort.kalman_filter import KalmanFilter
+    hp, D, nframes = dict(BOT_DEFAULTS, track_buffer=15), 32, 80
+    model = object.__new__(bs.BoTSORT)
+    model.tracked_stracks, model.lost_stracks, model.removed_stracks = [], [], []
+    BaseTrack.clear_count()
+    model.frame_id, model.lambda_, model.track_high_thresh, model.new_track_thresh = 0, hp["lambda_"], hp["track_high_thresh"], hp["new_track_thresh"]
+    model.buffer_size = model.max_time_lost = int(hp["frame_rate"] / 30.0 * hp["track_buffer"])
+    model.kalman_filter = KalmanFilter()
+    model.proximity_thresh, model.appearance_thresh, model.match_thresh = hp["proximity_thresh"], hp["appearance_thresh"], hp["match_thresh"]
+    rng = np.random.default_rng(31)
+    warps = []
+    for f in range(nframes):
+        th, sc = rng.normal(0, 0.003), 1 + rng.normal(0, 0.002)
+        warps.append(np.array([[sc * np.cos(th), -sc * np.sin(th), rng.normal(0, 2.5)], [sc * np.sin(th), sc * np.cos(th), rng.normal(0, 1.5)]]))
+    cur = {}
+    model.gmc = types.SimpleNamespace(apply=lambda img, dets: cur["w"].copy())
+    img = np.zeros((1080, 1920, 3), dtype=np.uint8)
+    in_off, out_off, dets_all, embs, rows, blobs = [0], [0], [], [], [], {}
+    for fr in SyntheticStream(41, 30, nframes, parts=1, dim=D, with_embeddings=True, miss_prob=0.1, low_conf_frac=0.25, churn_period=25):
+        f = fr["frame"]
+        keep = fr["dets"][:, 4] > 0.4
+        d, e = fr["dets"][keep], fr["embeddings"][keep, 0, :].astype(np.float32)
+        dets_all.append(d); embs.append(e); in_off.append(in_off[-1] + len(d))
+        cur["w"] = warps[f]
+        hi = d[:, 4] > hp["track_high_thresh"]
+        feats = torch.from_numpy(e[hi].copy())
+        model._get_features = lambda xywh, im, feats=feats: feats
+        out = model.update(torch.from_numpy(d.copy()), img)
+        for r in out:
+            rows.append([float(v) for v in r])
+        out_off.append(out_off[-1] + len(out))
+        if f in (1, 2, 20, 79):
+            for lname, lst in (("trk", model.tracked_stracks), ("lost", model.lost_stracks)):
+                blobs[f"f{f}_{lname}_ids"] = np.array([t.track_id for t in lst], dtype=np.int64)
+                blobs[f"f{f}_{lname}_mean"] = np.array([np.asarray(t.mean, dtype=np.float64) for t in lst]).reshape(-1, 8)
+                blobs[f"f{f}_{lname}_cov"] = np.array([np.asarray(t.covariance, dtype=np.float64) for t in lst]).reshape(-1, 8, 8)
+    np.savez_compressed(os.path.join(out_dir, "gmc_botsort.npz"), dets=np.concatenate(dets_all), embeddings=np.concatenate(embs),
+                        det_offsets=np.array(in_off, dtype=np.int64), out_offsets=np.array(out_off, dtype=np.int64),
+                        rows=np.array(rows, dtype=np.float64).reshape(-1, 8), warps=np.stack(warps), config=json.dumps(hp), dim=D, **blobs)
+    print(f"gmc_botsort: rows_out={out_off[-1]} next_id={BaseTrack._count + 1}")
+
+
 def main():
     out_dir = HERE
     only = set(sys.argv[1:])
     gens = {"ocsort": gen_ocsort, "iou": gen_iou_family, "kf7": gen_kf7, "lsa": gen_lsa,
-            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack, "botsort": gen_botsort, "deepocsort": gen_deepocsort, "clearmot": gen_clearmot, "mot_io": gen_mot_io, "ssort_camera": gen_ssort_camera}
+            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack, "botsort": gen_botsort, "deepocsort": gen_deepocsort, "clearmot": gen_clearmot, "mot_io": gen_mot_io, "ssort_camera": gen_ssort_camera, "botsort_gmc": gen_botsort_gmc}
     for k, fn in gens.items():
         if not only or k in only:
             fn(out_dir)

@@ -54,3 +54,23 @@ def check_lists_exact(trk, g, f):
 @pytest.mark.parametrize("name", RUNS)
 def test_botsort_oracle_matches_reference(orc, name):
     replay(name, lambda D, hp: orc.BoTSORT(D, **hp), check_lists_exact)
+
+
+def test_botsort_oracle_with_camera_motion_warps_matches_reference(orc):
+    """multi_gmc on non-identity warps (bot_sort.py:93-109): BoTSORT.update run by the reference with GMC.apply patched to return a
+    synthetic (2,3) warp per frame (tests/golden/make_golden.py gen_botsort_gmc); the oracle gets the same warps."""
+    g = np.load(os.path.join(GOLDEN, "gmc_botsort.npz"))
+    trk = orc.BoTSORT(int(g["dim"]), **json.loads(str(g["config"])))
+    do, oo = g["det_offsets"], g["out_offsets"]
+    for f in range(len(do) - 1):
+        out = trk.update(g["dets"][do[f]:do[f + 1]], g["embeddings"][do[f]:do[f + 1]], warp=g["warps"][f])
+        exp = g["rows"][oo[f]:oo[f + 1]]
+        assert out.shape == exp.shape, f
+        np.testing.assert_array_equal(out[:, 4:], exp[:, 4:], err_msg=f"frame {f}")
+        np.testing.assert_allclose(out[:, :4], exp[:, :4], rtol=1e-11, atol=1e-9, err_msg=f"frame {f}")
+        if f"f{f}_trk_ids" in g.files:
+            for which, ln in ((0, "trk"), (1, "lost")):
+                ids, mean, cov = trk.tracks(which)[:3]
+                np.testing.assert_array_equal(ids, g[f"f{f}_{ln}_ids"])
+                np.testing.assert_allclose(mean, g[f"f{f}_{ln}_mean"], rtol=1e-11, atol=1e-10)
+                np.testing.assert_allclose(cov, g[f"f{f}_{ln}_cov"], rtol=1e-9, atol=1e-9)
