@@ -149,7 +149,7 @@ static void kfn_update(kfn *k, const double *z /* or NULL */, const double *rdia
 typedef struct {
     kfn kf;
     int64_t id;
-    int tsu, hits, hit_streak, age, delta_t, frozen;
+    int tsu, hits, hit_streak, age, delta_t, frozen, last_upd_age;
     double conf, cls, tracklab_id;
     double last_obs[5];
     int has_vel; double vel[2];
@@ -214,6 +214,7 @@ static void kbt_update(dkbt *t, const double *bbox5, double cls, double tid)    
             t->has_vel = 1;
         }
         memcpy(t->last_obs, bbox5, 5 * sizeof(double));
+        t->last_upd_age = t->age;
         const int s = t->age % RING;
         t->obs_age[s] = t->age; memcpy(t->obs_box[s], bbox5, 5 * sizeof(double));
         t->n_obs += 1;
@@ -248,6 +249,52 @@ static void kbt_predict(dkbt *t, double *pos)                                   
     if (t->tsu > 0) t->hit_streak = 0;
     t->tsu += 1;
     x_to_bbox(t->kf.x, pos);
+}
+
+/* KalmanBoxTracker.apply_affine_correction (ocsort.py:261-281) + KalmanFilterNew.apply_affine_correction (kalmanfilter.py:387-405,
+ * new_kf branch). last_observation and observations[age of the last update] are the SAME numpy array in the reference (update()
+ * stores one view of the detection row in both, ocsort.py:232-234), so a box inside the delta_t window is warped twice. */
+static void affine_pts(const double *A, double *b4)
+{
+    const double x1 = A[0] * b4[0] + A[1] * b4[1], y1 = A[3] * b4[0] + A[4] * b4[1];
+    const double x2 = A[0] * b4[2] + A[1] * b4[3], y2 = A[3] * b4[2] + A[4] * b4[3];
+    b4[0] = x1 + A[2]; b4[1] = y1 + A[5]; b4[2] = x2 + A[2]; b4[3] = y2 + A[5];
+}
+static void affine_state(const double *A, double *x, double *P)
+{
+    const double R[4] = {A[0], A[1], A[3], A[4]};
+    double m[8], t1[64], c2[64];
+    for (int b = 0; b < 4; ++b) { m[2 * b] = R[0] * x[2 * b] + R[1] * x[2 * b + 1]; m[2 * b + 1] = R[2] * x[2 * b] + R[3] * x[2 * b + 1]; }
+    m[0] += A[2]; m[1] += A[5];
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) { const int r0 = i & ~1; t1[i * 8 + j] = R[(i & 1) * 2] * P[r0 * 8 + j] + R[(i & 1) * 2 + 1] * P[(r0 + 1) * 8 + j]; }
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) { const int c0 = j & ~1; c2[i * 8 + j] = t1[i * 8 + c0] * R[(j & 1) * 2] + t1[i * 8 + c0 + 1] * R[(j & 1) * 2 + 1]; }
+    memcpy(x, m, sizeof(m)); memcpy(P, c2, sizeof(c2));
+}
+static void kbt_affine(dkbt *t, const double *A)
+{
+    const int alias_slot = (t->n_obs > 0) ? t->last_upd_age % RING : -1;
+    if (sum5(t->last_obs) > 0) {
+        affine_pts(A, t->last_obs);
+        if (alias_slot >= 0 && t->obs_age[alias_slot] == t->last_upd_age) memcpy(t->obs_box[alias_slot], t->last_obs, 4 * sizeof(double));
+    }
+    for (int dt = t->delta_t; dt >= 0; --dt) {
+        const int age = t->age - dt;
+        if (age < 0) continue;
+        const int s = age % RING;
+        if (t->obs_age[s] != age) continue;
+        affine_pts(A, t->obs_box[s]);
+        if (s == alias_slot && age == t->last_upd_age) memcpy(t->last_obs, t->obs_box[s], 4 * sizeof(double));
+    }
+    affine_state(A, t->kf.x, t->kf.P);
+    if (!t->kf.observed && t->kf.has_saved) {
+        affine_state(A, t->kf.sx, t->kf.sP);
+        double *lm = t->kf.last_z;
+        const double p0 = A[0] * lm[0] + A[1] * lm[1] + A[2], p1 = A[3] * lm[0] + A[4] * lm[1] + A[5];
+        const double s0 = A[0] * lm[2] + A[1] * lm[3], s1 = A[3] * lm[2] + A[4] * lm[3];
+        lm[0] = p0; lm[1] = p1; lm[2] = s0; lm[3] = s1;
+    }
 }
 
 orc_deepocsort *orc_deepocsort_create(double det_thresh, int max_age, int min_hits, double iou_threshold, int delta_t, int asso_func,
@@ -398,9 +445,15 @@ static void associate(const orc_deepocsort *o, const double *dets, const float *
     free(mi_r); free(mi_c); free(iou);
 }
 
+int orc_deepocsort_update_cmc(orc_deepocsort *o, const double *dets_in, const float *embs_in, int n_in, const double *warp6, double *out, int out_cap);
 int orc_deepocsort_update(orc_deepocsort *o, const double *dets_in, const float *embs_in, int n_in, double *out, int out_cap)
+{ return orc_deepocsort_update_cmc(o, dets_in, embs_in, n_in, NULL, out, out_cap); }
+
+/* warp6: what CMCComputer.compute_affine returned for this frame ((2,3) float64, ocsort.py:425-428), NULL = cmc_off */
+int orc_deepocsort_update_cmc(orc_deepocsort *o, const double *dets_in, const float *embs_in, int n_in, const double *warp6, double *out, int out_cap)
 {
     const int D = o->D;
+    if (warp6) for (int t = 0; t < o->n; ++t) kbt_affine(o->trk[t], warp6);
     double *dets = malloc(sizeof(double) * 7 * (size_t)(n_in + 1)), *alpha = malloc(sizeof(double) * (size_t)(n_in + 1));
     float *demb = malloc(sizeof(float) * (size_t)(n_in + 1) * D);
     int N = 0;

@@ -1225,11 +1225,75 @@ def gen_botsort_gmc(out_dir):
     print(f"gmc_botsort: rows_out={out_off[-1]} next_id={BaseTrack._count + 1}")
 
 
+def gen_deepocsort_cmc(out_dir):
+    """Deep-OC-SORT with camera-motion compensation minus the estimator: OCSort.update run as is with cmc_off False and
+    CMCComputer.compute_affine (cv2 optical flow, cmc.py) replaced by a synthetic (2,3) float64 warp per frame, so that
+    KalmanBoxTracker.apply_affine_correction / KalmanFilterNew.apply_affine_correction (ocsort.py:261-281, kalmanfilter.py:387-405) run
+    on non-identity warps -- including the double warp of a last observation that is still inside the delta_t window (one numpy array
+    is stored as last_observation AND observations[age]) and the frozen state of unobserved tracks."""
+    _install_filterpy_shim()
+    _import_plain_strong_sort()
+    saved_lap = sys.modules.get("lap", "absent")
+    sys.modules["lap"] = None
+    import deep_oc_sort.ocsort as doc
+    try:
+        hp = dict(DOC_DEFAULTS, det_thresh=0.3, delta_t=3, max_age=12, min_hits=1, cmc_off=False)
+        D, nframes = 32, 90
+        model = object.__new__(doc.OCSort)
+        model.max_age, model.min_hits, model.iou_threshold = hp["max_age"], hp["min_hits"], hp["iou_threshold"]
+        model.trackers, model.frame_count, model.det_thresh, model.delta_t = [], 0, hp["det_thresh"], hp["delta_t"]
+        model.asso_func, model.inertia = doc.ASSO_FUNCS[hp["asso_func"]], hp["inertia"]
+        model.w_association_emb, model.alpha_fixed_emb, model.aw_param = hp["w_association_emb"], hp["alpha_fixed_emb"], hp["aw_param"]
+        doc.KalmanBoxTracker.count = 0
+        model.embedding_off, model.cmc_off, model.aw_off, model.new_kf_off = False, False, False, False
+        rng = np.random.default_rng(51)
+        warps = []
+        for f in range(nframes):
+            th, sc = rng.normal(0, 0.003), 1 + rng.normal(0, 0.002)
+            warps.append(np.array([[sc * np.cos(th), -sc * np.sin(th), rng.normal(0, 2.5)], [sc * np.sin(th), sc * np.cos(th), rng.normal(0, 1.5)]]))
+        cur = {}
+        model.cmc = types.SimpleNamespace(compute_affine=lambda img, dets, tag: cur["w"].copy())
+        img = np.zeros((1080, 1920, 3), dtype=np.uint8)
+        in_off, out_off, dets_all, embs, rows, blobs = [0], [0], [], [], [], {}
+        for fr in SyntheticStream(61, 25, nframes, parts=1, dim=D, with_embeddings=True, miss_prob=0.2, churn_period=25):
+            f = fr["frame"]
+            keep = fr["dets"][:, 4] > 0.4
+            d, e = fr["dets"][keep], fr["embeddings"][keep, 0, :].astype(np.float32)
+            e = e / np.linalg.norm(e, axis=1, keepdims=True)
+            dets_all.append(d); embs.append(e); in_off.append(in_off[-1] + len(d))
+            cur["w"] = warps[f]
+            thr = d[:, 4] > hp["det_thresh"]
+            feats = torch.from_numpy(e[thr].copy())
+            model._get_features = lambda xyxy, im, feats=feats: feats
+            out = np.asarray(model.update(torch.from_numpy(d.copy()), img), dtype=np.float64).reshape(-1, 8)
+            rows.extend(out.tolist())
+            out_off.append(out_off[-1] + len(out))
+            if f in (1, 2, 3, 10, 40, 89):
+                T = model.trackers
+                blobs[f"f{f}_ids"] = np.array([t.id for t in T], dtype=np.int64)
+                blobs[f"f{f}_x"] = np.array([t.kf.x[:, 0] for t in T], dtype=np.float64).reshape(-1, 8)
+                blobs[f"f{f}_P"] = np.array([t.kf.P for t in T], dtype=np.float64).reshape(-1, 8, 8)
+                blobs[f"f{f}_last"] = np.array([t.last_observation for t in T], dtype=np.float64).reshape(-1, 5)
+                blobs[f"f{f}_vel"] = np.array([t.velocity if t.velocity is not None else (0, 0) for t in T], dtype=np.float64).reshape(-1, 2)
+                blobs[f"f{f}_state"] = np.array([[t.time_since_update, t.hits, t.hit_streak, t.age, int(t.frozen), int(t.kf.observed)]
+                                                 for t in T], dtype=np.int64).reshape(-1, 6)
+        np.savez_compressed(os.path.join(out_dir, "cmc_deepocsort.npz"), dets=np.concatenate(dets_all), embeddings=np.concatenate(embs),
+                            det_offsets=np.array(in_off, dtype=np.int64), out_offsets=np.array(out_off, dtype=np.int64),
+                            rows=np.array(rows, dtype=np.float64).reshape(-1, 8), warps=np.stack(warps),
+                            config=json.dumps(dict(hp, cmc_off=True)), dim=D, **blobs)
+        print(f"cmc_deepocsort: rows_out={out_off[-1]} next_id={doc.KalmanBoxTracker.count}")
+    finally:
+        if saved_lap == "absent":
+            sys.modules.pop("lap", None)
+        else:
+            sys.modules["lap"] = saved_lap
+
+
 def main():
     out_dir = HERE
     only = set(sys.argv[1:])
     gens = {"ocsort": gen_ocsort, "iou": gen_iou_family, "kf7": gen_kf7, "lsa": gen_lsa,
-            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack, "botsort": gen_botsort, "deepocsort": gen_deepocsort, "clearmot": gen_clearmot, "mot_io": gen_mot_io, "ssort_camera": gen_ssort_camera, "botsort_gmc": gen_botsort_gmc}
+            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack, "botsort": gen_botsort, "deepocsort": gen_deepocsort, "clearmot": gen_clearmot, "mot_io": gen_mot_io, "ssort_camera": gen_ssort_camera, "botsort_gmc": gen_botsort_gmc, "deepocsort_cmc": gen_deepocsort_cmc}
     for k, fn in gens.items():
         if not only or k in only:
             fn(out_dir)

@@ -47,3 +47,25 @@ def check_state(trk, g, f, x_tol=1e-9, emb_tol=1e-6):
 @pytest.mark.parametrize("name", RUNS)
 def test_deepocsort_oracle_matches_reference(orc, name):
     replay(name, lambda D, hp: orc.DeepOCSort(D, **hp), check_state)
+
+
+def test_deepocsort_oracle_with_camera_motion_warps_matches_reference(orc):
+    """apply_affine_correction on non-identity warps: OCSort.update run by the reference with cmc_off False and
+    CMCComputer.compute_affine patched to return a synthetic (2,3) warp per frame (gen_deepocsort_cmc); the oracle gets the same warps."""
+    g = np.load(os.path.join(GOLDEN, "cmc_deepocsort.npz"))
+    trk = orc.DeepOCSort(int(g["dim"]), **json.loads(str(g["config"])))
+    do, oo = g["det_offsets"], g["out_offsets"]
+    for f in range(len(do) - 1):
+        out = trk.update(g["dets"][do[f]:do[f + 1]], g["embeddings"][do[f]:do[f + 1]], warp=g["warps"][f])
+        exp = g["rows"][oo[f]:oo[f + 1]]
+        assert out.shape == exp.shape, f
+        np.testing.assert_array_equal(out[:, 4:], exp[:, 4:], err_msg=f"frame {f}")
+        np.testing.assert_allclose(out[:, :4], exp[:, :4], rtol=1e-12, atol=1e-10, err_msg=f"frame {f}")
+        if f"f{f}_ids" in g.files:
+            ids, x, P, emb, st, vel, last = trk.tracks()
+            np.testing.assert_array_equal(ids, g[f"f{f}_ids"])
+            np.testing.assert_array_equal(st, g[f"f{f}_state"])
+            np.testing.assert_allclose(last, g[f"f{f}_last"], rtol=1e-12, atol=1e-10)
+            np.testing.assert_allclose(vel, g[f"f{f}_vel"], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(x, g[f"f{f}_x"], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(P, g[f"f{f}_P"], rtol=1e-8, atol=1e-8)
