@@ -293,6 +293,10 @@ typedef struct tlk_deepocsort tlk_deepocsort;
 int tlk_deepocsort_create(const tlk_deepocsort_params *p, int n_streams, int device, tlk_deepocsort **out);
 int tlk_deepocsort_destroy(tlk_deepocsort *h);
 int tlk_deepocsort_reset(tlk_deepocsort *h, int stream);     /* stream < 0: all */
+/* camera-motion compensation with the estimate passed in (host pointer to the (2,3) affine CMCComputer.compute_affine returns):
+ * KalmanBoxTracker.apply_affine_correction for every tracker (ocsort.py:261-281, :425-428), to be called before
+ * tlk_deepocsort_update; the estimator (cmc.py, cv2 optical flow) is not part of libtlk. stream < 0: all. Asynchronous. */
+int tlk_deepocsort_affine_correction(tlk_deepocsort *h, int stream, const double *warp6, void *hip_stream);
 /* host buffers: dets (n,7) f64 [x1,y1,x2,y2,conf,cls,tracklab_id], embs (n,dim) f32 -> out (rows,8) f64
  * [x1,y1,x2,y2,track_id(+1),cls,conf,tracklab_id] (ocsort.py:527-529) */
 int tlk_deepocsort_update(tlk_deepocsort *h, int stream, const double *dets, const float *embs, int n, double *out, int out_cap, int *n_out);
@@ -383,6 +387,10 @@ typedef struct tlk_ssort tlk_ssort;
 int tlk_ssort_create(const tlk_ssort_params *p, int n_streams, int device, tlk_ssort **out);
 int tlk_ssort_destroy(tlk_ssort *h);
 int tlk_ssort_reset(tlk_ssort *h, int stream);       /* stream < 0: all */
+/* camera compensation with the ECC estimate passed in (host pointer to the (2,3) warp Track.ECC returns): Tracker.camera_update ->
+ * Track.camera_update (sort/tracker.py:66-68, sort/track.py:221-239), to be called before tlk_ssort_update like
+ * strong_sort_api.py:62-65 does; the estimator (cv2.findTransformECC) is not part of libtlk. stream < 0: all. Asynchronous. */
+int tlk_ssort_camera_update(tlk_ssort *h, int stream, const double *warp6, void *hip_stream);
 /* host buffers: dets (n,7) f64 [x1,y1,x2,y2,conf,cls,tracklab_id], feat (n,dim) f32 -> rows (cap) */
 int tlk_ssort_update(tlk_ssort *h, int stream, const double *dets, const float *feat, int n, tlk_ssort_row *rows, int cap,
                      int *n_out);

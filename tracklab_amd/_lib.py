@@ -497,6 +497,13 @@ class SsortBank:
     def reset(self, stream=-1):
         check(lib().tlk_ssort_reset(self._h, stream))
 
+    def camera_update(self, warp, stream=0, stream_ptr=None):
+        """Tracker.camera_update with the ECC estimate passed in: warp = the (2,3) matrix Track.ECC returns. Call before update()."""
+        L = lib()
+        L.tlk_ssort_camera_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        w = _f64(warp).reshape(6)
+        check(L.tlk_ssort_camera_update(self._h, stream, w.ctypes.data, stream_ptr))
+
     def update(self, dets, feat, stream=0):
         """dets (n,7) [x1,y1,x2,y2,conf,cls,tracklab_id], feat (n,dim) -> structured rows (SSORT_ROW)."""
         dets = _f64(dets).reshape(-1, 7)
@@ -736,6 +743,14 @@ class DeepOCSortBank:
 
     def reset(self, stream=-1):
         check(lib().tlk_deepocsort_reset(self._h, stream))
+
+    def affine_correction(self, warp, stream=0, stream_ptr=None):
+        """apply_affine_correction of every tracker with the estimate passed in: warp = the (2,3) affine compute_affine returns.
+        Call before update() (the reference applies it ahead of predict, ocsort.py:425-428)."""
+        L = lib()
+        L.tlk_deepocsort_affine_correction.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        w = _f64(warp).reshape(6)
+        check(L.tlk_deepocsort_affine_correction(self._h, stream, w.ctypes.data, stream_ptr))
 
     def update(self, dets, embs, stream=0):
         """dets (n,7), embs (n,dim) float32 -> rows (m,8) [x1,y1,x2,y2,track_id,cls,conf,tracklab_id]."""

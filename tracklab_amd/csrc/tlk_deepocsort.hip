@@ -762,6 +762,87 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
     }
 }
 
+// KalmanBoxTracker.apply_affine_correction + KalmanFilterNew.apply_affine_correction (ocsort.py:261-281, kalmanfilter.py:387-405, new_kf
+// branch) with the camera-motion estimate passed in: one thread per live track, a launch of its own ahead of the frame kernel (the
+// reference applies it before predict, ocsort.py:425-428). last_observation and observations[age of the last update] are one numpy
+// array in the reference (update() stores the same view in both): the ring slot with the newest age mirrors last_observation, and a
+// box still inside the delta_t window is warped twice.
+struct DocWarp { double m[6]; };
+__device__ __forceinline__ void doc_affine_pts(const double (&A)[6], double (&b)[4])
+{
+    const double x1 = A[0] * b[0] + A[1] * b[1], y1 = A[3] * b[0] + A[4] * b[1];
+    const double x2 = A[0] * b[2] + A[1] * b[3], y2 = A[3] * b[2] + A[4] * b[3];
+    b[0] = x1 + A[2]; b[1] = y1 + A[5]; b[2] = x2 + A[2]; b[3] = y2 + A[5];
+}
+// x = kron(I4, R) x, x[:2] += t, P = kron(I4, R) P kron(I4, R)^T on the slot fields starting at fx / fP
+__device__ void doc_affine_state(const Trk &T, int fx, int fP, const double (&A)[6])
+{
+    const double R[4] = {A[0], A[1], A[3], A[4]};
+    double m[8];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const double u = T.d(fx + 2 * b), v = T.d(fx + 2 * b + 1);
+        m[2 * b] = R[0] * u + R[1] * v; m[2 * b + 1] = R[2] * u + R[3] * v;
+    }
+    m[0] += A[2]; m[1] += A[5];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) T.d(fx + k) = m[k];
+    for (int bi = 0; bi < 4; ++bi)             // 2x2 blocks: P'[bi][bj] = R P[bi][bj] R^T, rows first, then columns
+        for (int bj = 0; bj < 4; ++bj) {
+            const int r0 = 2 * bi, c0 = 2 * bj;
+            const double p00 = T.d(fP + r0 * 8 + c0), p01 = T.d(fP + r0 * 8 + c0 + 1), p10 = T.d(fP + (r0 + 1) * 8 + c0), p11 = T.d(fP + (r0 + 1) * 8 + c0 + 1);
+            const double t00 = R[0] * p00 + R[1] * p10, t01 = R[0] * p01 + R[1] * p11;
+            const double t10 = R[2] * p00 + R[3] * p10, t11 = R[2] * p01 + R[3] * p11;
+            T.d(fP + r0 * 8 + c0) = t00 * R[0] + t01 * R[1]; T.d(fP + r0 * 8 + c0 + 1) = t00 * R[2] + t01 * R[3];
+            T.d(fP + (r0 + 1) * 8 + c0) = t10 * R[0] + t11 * R[1]; T.d(fP + (r0 + 1) * 8 + c0 + 1) = t10 * R[2] + t11 * R[3];
+        }
+}
+__global__ void deepocsort_affine_kernel(DocDev D, int stream, int delta_t, DocWarp W)
+{
+    const int s0 = stream < 0 ? 0 : stream, s1 = stream < 0 ? D.S : stream + 1;
+    double A[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) A[i] = W.m[i];
+    const size_t stride = (size_t)D.S * D.MAXT;
+    for (int s = s0 + blockIdx.x; s < s1; s += gridDim.x) {
+        const int T = D.hdr[(size_t)s * H_COUNT + H_NTRK];
+        for (int p = threadIdx.x; p < T; p += blockDim.x) {
+            const int slot = D.order[(size_t)s * D.MAXT + p];
+            Trk K; K.fd = D.fd + (size_t)s * D.MAXT + slot; K.fi = D.fi + (size_t)s * D.MAXT + slot; K.stride_d = stride; K.stride_i = stride;
+            const int age = K.i(GI_AGE);
+            int alias = -1, alias_age = -1;                                     // ring slot of the last update == last_observation's array
+            if (K.i(GI_NOBS) > 0)
+                for (int q = 0; q < RINGN; ++q) { const int a = K.i(GI_OBAGE + q); if (a > alias_age) { alias_age = a; alias = q; } }
+            double lo[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) lo[k] = K.d(GD_LO + k);
+            if (sum5(lo) > 0) {
+                double b[4] = {lo[0], lo[1], lo[2], lo[3]};
+                doc_affine_pts(A, b);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { K.d(GD_LO + k) = b[k]; if (alias >= 0) K.d(GD_OB + alias * 5 + k) = b[k]; }
+            }
+            for (int dt = delta_t; dt >= 0; --dt) {
+                const int a = age - dt;
+                if (a < 0) continue;
+                const int q = a % RINGN;
+                if (K.i(GI_OBAGE + q) != a) continue;
+                double b[4] = {K.d(GD_OB + q * 5), K.d(GD_OB + q * 5 + 1), K.d(GD_OB + q * 5 + 2), K.d(GD_OB + q * 5 + 3)};
+                doc_affine_pts(A, b);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { K.d(GD_OB + q * 5 + k) = b[k]; if (q == alias) K.d(GD_LO + k) = b[k]; }
+            }
+            doc_affine_state(K, GD_X, GD_P, A);
+            if (K.i(GI_OBSERVED) == 0 && K.i(GI_HAS_SAVED) != 0) {
+                doc_affine_state(K, GD_SX, GD_SP, A);
+                const double l0 = K.d(GD_LZ), l1 = K.d(GD_LZ + 1), l2 = K.d(GD_LZ + 2), l3 = K.d(GD_LZ + 3);
+                K.d(GD_LZ) = A[0] * l0 + A[1] * l1 + A[2]; K.d(GD_LZ + 1) = A[3] * l0 + A[4] * l1 + A[5];
+                K.d(GD_LZ + 2) = A[0] * l2 + A[1] * l3; K.d(GD_LZ + 3) = A[3] * l2 + A[4] * l3;
+            }
+        }
+    }
+}
+
 __global__ void deepocsort_reset_kernel(DocDev D, int stream)
 {
     const int s0 = stream < 0 ? 0 : stream, s1 = stream < 0 ? D.S : stream + 1;
@@ -885,6 +966,19 @@ extern "C" int tlk_deepocsort_reset(tlk_deepocsort *h, int stream)
     hipLaunchKernelGGL(deepocsort_reset_kernel, dim3(stream < 0 ? (h->D.S < 256 ? h->D.S : 256) : 1), dim3(BLOCK), 0, 0, h->D, stream);
     TLK_HIP(hipGetLastError());
     TLK_HIP(hipStreamSynchronize(0));
+    return TLK_OK;
+}
+
+extern "C" int tlk_deepocsort_affine_correction(tlk_deepocsort *h, int stream, const double *warp6, void *hip_stream)
+{
+    if (!h || !warp6) return fail(TLK_EINVAL, "tlk_deepocsort_affine_correction: null pointer");
+    if (stream >= h->D.S) return fail(TLK_EINVAL, "tlk_deepocsort_affine_correction: stream out of range");
+    TLK_HIP(hipSetDevice(h->device));
+    DocWarp W;
+    for (int i = 0; i < 6; ++i) W.m[i] = warp6[i];
+    hipLaunchKernelGGL(deepocsort_affine_kernel, dim3(stream < 0 ? (h->D.S < 256 ? h->D.S : 256) : 1), dim3(BLOCK), 0, (hipStream_t)hip_stream, h->D, stream,
+                       h->P.delta_t, W);
+    TLK_HIP(hipGetLastError());
     return TLK_OK;
 }
 

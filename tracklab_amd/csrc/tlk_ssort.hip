@@ -424,6 +424,49 @@ __global__ void ssort_reset_kernel(SsDev D, int stream)
     }
 }
 
+// Tracker.camera_update -> Track.camera_update (sort/tracker.py:66-68, sort/track.py:221-239) with the ECC estimate passed in:
+// one thread per live track; [0, 0, 1] appended, get_matrix's identity fallback (||I - M||_F >= 100), corners through the matrix,
+// mean[:4] = [cx, cy, w / h, h] in the mean's own dtype. A launch of its own: the frame kernels are untouched.
+struct SsWarp { double m[6]; };
+__global__ void ssort_camera_kernel(SsDev D, int stream, SsWarp W)
+{
+    const int s0 = stream < 0 ? 0 : stream, s1 = stream < 0 ? D.S : stream + 1;
+    double M[6];
+    double d2 = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { const double v = i < 6 ? W.m[i] : (i == 8 ? 1.0 : 0.0); const double e = (i % 4 == 0 ? 1.0 : 0.0) - v; d2 += e * e; }
+    const bool ok = sqrt(d2) < 100;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) M[i] = ok ? W.m[i] : ((i == 0 || i == 4) ? 1.0 : 0.0);
+    const size_t stride = (size_t)D.S * D.MAXT;
+    for (int s = s0 + blockIdx.x; s < s1; s += gridDim.x) {
+        const int T = D.hdr[(size_t)s * H_COUNT + H_NTRK];
+        for (int p = threadIdx.x; p < T; p += blockDim.x) {
+            const int slot = D.order[(size_t)s * D.MAXT + p];
+            double *fd = D.fd + (size_t)s * D.MAXT + slot;
+            const bool f32 = D.fi[(size_t)SI_F32 * stride + (size_t)s * D.MAXT + slot] != 0;
+            double x1, y1, x2, y2;
+            if (f32) {
+                float r0 = (float)fd[(size_t)(SD_MEAN + 0) * stride], r1 = (float)fd[(size_t)(SD_MEAN + 1) * stride], r2 = (float)fd[(size_t)(SD_MEAN + 2) * stride];
+                const float r3 = (float)fd[(size_t)(SD_MEAN + 3) * stride];
+                r2 *= r3; r0 -= r2 / 2; r1 -= r3 / 2;
+                x1 = r0; y1 = r1; x2 = (float)(r0 + r2); y2 = (float)(r1 + r3);
+            } else {
+                double r0 = fd[(size_t)(SD_MEAN + 0) * stride], r1 = fd[(size_t)(SD_MEAN + 1) * stride], r2 = fd[(size_t)(SD_MEAN + 2) * stride];
+                const double r3 = fd[(size_t)(SD_MEAN + 3) * stride];
+                r2 *= r3; r0 -= r2 / 2; r1 -= r3 / 2;
+                x1 = r0; y1 = r1; x2 = r0 + r2; y2 = r1 + r3;
+            }
+            const double x1_ = M[0] * x1 + M[1] * y1 + M[2] * 1.0, y1_ = M[3] * x1 + M[4] * y1 + M[5] * 1.0;
+            const double x2_ = M[0] * x2 + M[1] * y2 + M[2] * 1.0, y2_ = M[3] * x2 + M[4] * y2 + M[5] * 1.0;
+            const double w = x2_ - x1_, h = y2_ - y1_, cx = x1_ + w / 2, cy = y1_ + h / 2;
+            const double nm[4] = {cx, cy, w / h, h};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fd[(size_t)(SD_MEAN + q) * stride] = f32 ? (double)(float)nm[q] : nm[q];
+        }
+    }
+}
+
 __global__ void ssort_gather_kernel(SsDev D, int stream, long long *ids, double *mean, double *cov, float *feat, long long *state5,
                                     long long *glen, int cap, int *n_out)
 {
@@ -555,6 +598,18 @@ extern "C" int tlk_ssort_reset(tlk_ssort *h, int stream)
     hipLaunchKernelGGL(ssort_reset_kernel, dim3(stream < 0 ? (h->D.S < 256 ? h->D.S : 256) : 1), dim3(BLOCK), 0, 0, h->D, stream);
     TLK_HIP(hipGetLastError());
     TLK_HIP(hipStreamSynchronize(0));
+    return TLK_OK;
+}
+
+extern "C" int tlk_ssort_camera_update(tlk_ssort *h, int stream, const double *warp6, void *hip_stream)
+{
+    if (!h || !warp6) return fail(TLK_EINVAL, "tlk_ssort_camera_update: null pointer");
+    if (stream >= h->D.S) return fail(TLK_EINVAL, "tlk_ssort_camera_update: stream out of range");
+    TLK_HIP(hipSetDevice(h->device));
+    SsWarp W;
+    for (int i = 0; i < 6; ++i) W.m[i] = warp6[i];
+    hipLaunchKernelGGL(ssort_camera_kernel, dim3(stream < 0 ? (h->D.S < 256 ? h->D.S : 256) : 1), dim3(BLOCK), 0, (hipStream_t)hip_stream, h->D, stream, W);
+    TLK_HIP(hipGetLastError());
     return TLK_OK;
 }
 
