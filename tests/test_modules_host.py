@@ -167,6 +167,86 @@ def test_strongsort_module_host_logic_with_oracle_backend(orc):
     assert seen > 300
 
 
+def test_strongsort_module_ecc_flow_with_a_stand_in_estimator(orc, monkeypatch):
+    """`ecc: true`: the module asks OpenCV for one warp per frame (Track.ECC's parameters) from the second frame on, also on frames
+    without detections, and hands it to the bank's camera_update before the update -- checked with a stand-in cv2 (OpenCV is not
+    installed here) and the oracle as the bank, against the oracle driven directly in the reference's order (strong_sort_api.py:60-72)."""
+    import sys
+    import types
+    from tracklab_amd._lib import SSORT_ROW
+    from tracklab_amd.wrappers import HipStrongSORT
+    hyper = dict(ema_alpha=0.9, max_age=10, max_dist=0.2, max_iou_dist=0.7, max_unmatched_preds=7, mc_lambda=0.995, n_init=2, nn_budget=10)
+    D = 16
+    with pytest.raises(NotImplementedError):                   # no OpenCV: said loudly, not skipped
+        HipStrongSORT(NS(ecc=True, hyperparams=hyper), "cuda:0")
+    rng = np.random.default_rng(3)
+    calls = []
+
+    class CvError(Exception):
+        pass
+
+    def find_transform_ecc(src, dst, warp, mode, criteria, mask, gauss):
+        assert src.shape == (108, 192) and warp.dtype == np.float32 and mode == 1 and criteria == (3, 100, 1e-5) and gauss == 1
+        if len(calls) == 4:
+            calls.append(None)
+            raise CvError("did not converge")
+        w = np.array([[1, -0.002, rng.normal(0, 0.3)], [0.002, 1, rng.normal(0, 0.2)]], dtype=np.float32)
+        calls.append(w.copy())
+        return 0.99, w
+    cv2 = types.ModuleType("cv2")
+    cv2.COLOR_BGR2GRAY, cv2.INTER_LINEAR, cv2.MOTION_EUCLIDEAN, cv2.TERM_CRITERIA_EPS, cv2.TERM_CRITERIA_COUNT = 6, 1, 1, 2, 1
+    cv2.error = CvError
+    cv2.cvtColor = lambda img, code: img[..., 0]
+    cv2.resize = lambda img, size, fx, fy, interpolation: img[::10, ::10]
+    cv2.findTransformECC = find_transform_ecc
+    monkeypatch.setitem(sys.modules, "cv2", cv2)
+
+    class Backend:
+        def __init__(self):
+            self.t = orc.PlainStrongSORT(D, **hyper, img_w=1920, img_h=1080)
+
+        def camera_update(self, warp, stream):
+            self.t.camera_update(warp)
+
+        def update(self, dets, feat, stream):
+            keep = dets[:, 4] > 0.4
+            r = self.t.update(dets[keep], feat[keep])
+            out = np.zeros(len(r), dtype=SSORT_ROW)
+            out["ltrb"], out["track_id"], out["class_id"], out["conf"], out["det_id"] = r[:, :4], r[:, 4], r[:, 5], r[:, 6], r[:, 7]
+            return out
+
+        def reset(self, stream):
+            self.t = orc.PlainStrongSORT(D, **hyper, img_w=1920, img_h=1080)
+
+    m = HipStrongSORT(NS(min_confidence=0.4, ecc=True, hyperparams=hyper), "cuda:0", tracking_dataset=None)
+    m._make_backend = lambda dim, h, w: Backend()
+    ref = orc.PlainStrongSORT(D, **hyper, img_w=1920, img_h=1080)
+    frame = np.zeros((1080, 1920, 3), np.uint8)
+    seen, k = 0, 0
+    for fr in SyntheticStream(8, 12, 12, parts=1, dim=D, with_embeddings=True, miss_prob=0.1):
+        df = _frame_df(fr, np.float64, id0=100)
+        emb = fr["embeddings"][:, 0, :].astype(np.float32)
+        m._features = lambda image, dets, emb=emb: emb
+        sample = m.preprocess(frame, df, pd.Series({"frame": fr["frame"]}))
+        out = m.process(default_collate([sample]), df, pd.DataFrame({"file_path": ["unused"]}))
+        if fr["frame"] >= 1:                                   # strong_sort_api.py:62-65: from the second frame on
+            w = calls[k]; k += 1
+            if w is not None:
+                w = w.copy()
+                w[0, 2] = w[0, 2] / 0.1; w[1, 2] = w[1, 2] / 0.1       # Track.ECC rescales the translation to full resolution (float32)
+                ref.camera_update(w)
+        keep = sample["input"][:, 4] > 0.4
+        exp = ref.update(sample["input"][keep], emb[keep])
+        assert len(out) == len(exp)
+        if len(exp):
+            np.testing.assert_array_equal(out.track_id.to_numpy(), exp[:, 4])
+            np.testing.assert_array_equal(np.stack(out.track_bbox_ltwh.to_list())[:, :2], exp[:, :2])
+            seen += len(exp)
+    assert seen > 60 and k == len(calls) == 11 and calls[4] is None
+    m.reset()
+    assert m._prev_frame is None
+
+
 def test_botsort_module_host_logic_with_oracle_backend(orc):
     """HipBoTSORT's DataFrame plumbing with the oracle standing in for the bank: the ReID forward only sees the detections above
     track_high_thresh (bot_sort.py:293-314), rows / index / ltwh conversion as bot_sort_api.py:63-86."""

@@ -241,8 +241,12 @@ class _ReidTrackerBase:
     def _frame_features(self, image, inputs):
         return self._features(image, inputs)
 
+    def _camera_step(self, image, metadatas):
+        """Camera-motion compensation ahead of the tracker step; nothing unless a subclass estimates a warp."""
+
     def process(self, batch, detections: pd.DataFrame, metadatas: pd.DataFrame):
         if len(detections) == 0:
+            self._camera_step(None, metadatas)               # the reference compensates before its empty-frame return too
             return []
         inputs = to_numpy(batch["input"])
         inputs = np.ascontiguousarray(inputs[0] if inputs.ndim == 3 else inputs, dtype=np.float64).reshape(-1, 7)
@@ -254,6 +258,7 @@ class _ReidTrackerBase:
         if getattr(image, "ndim", 3) == 4:
             image = image[0]
         h, w = int(image.shape[0]), int(image.shape[1])
+        self._camera_step(image, metadatas)
         feats = self._frame_features(image, inputs)
         if self._bank is None or self._img_hw != (h, w):
             self._bank = self._make_backend(feats.shape[1], h, w)
@@ -274,7 +279,7 @@ class HipStrongSORT(ImageLevelModule, _ReidTrackerBase):
     tlk_roi_crop_pil_resize_norm), one backbone forward gives the 512-d features, tlk_ssort_update does the rest."""
     input_columns = ["bbox_ltwh", "bbox_conf", "category_id"]
     output_columns = ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
-    preprocess, process, reset = _ReidTrackerBase.preprocess, _ReidTrackerBase.process, _ReidTrackerBase.reset    # ahead of the abstract ones in the MRO
+    preprocess, process = _ReidTrackerBase.preprocess, _ReidTrackerBase.process    # ahead of the abstract ones in the MRO
 
     def __init__(self, cfg, device, **kwargs):
         super().__init__(batch_size=1)
@@ -283,9 +288,53 @@ class HipStrongSORT(ImageLevelModule, _ReidTrackerBase):
         self._bank = None
         self._model = None
         self._img_hw = None
-        if cfg_get(cfg, "ecc", False):
-            raise NotImplementedError("ecc camera compensation (sort/track.py:130-239, cv2.findTransformECC) is not part of the HIP path; "
-                                      "set ecc: false")
+        self._ecc = bool(cfg_get(cfg, "ecc", False))
+        self._prev_frame = None
+        if self._ecc:
+            try:
+                import cv2  # noqa: F401  (the estimator is OpenCV's, exactly as in the reference; only its result goes to the GPU)
+            except ImportError as e:
+                raise NotImplementedError("ecc: true needs OpenCV for the estimator (cv2.findTransformECC, sort/track.py:130-211); the warp is "
+                                          "applied on the GPU (tlk_ssort_camera_update). Install opencv-python or set ecc: false") from e
+
+    def reset(self):
+        self._prev_frame = None
+        if self._bank is not None:
+            self._bank.reset(-1)
+
+    @staticmethod
+    def _ecc_warp(src, dst, scale=0.1, eps=1e-5, max_iter=100):
+        """Track.ECC (strong_sort/sort/track.py:130-211) with its defaults: grey, 0.1-scaled frames, Euclidean model, translation
+        rescaled. One estimate per frame (the reference recomputes the same one for every track). None when cv2 gives up."""
+        import cv2
+        if src.shape != dst.shape:
+            return None
+        if src.ndim == 3:
+            src, dst = cv2.cvtColor(src, cv2.COLOR_BGR2GRAY), cv2.cvtColor(dst, cv2.COLOR_BGR2GRAY)
+        src_r = cv2.resize(src, (0, 0), fx=scale, fy=scale, interpolation=cv2.INTER_LINEAR)
+        dst_r = cv2.resize(dst, (0, 0), fx=scale, fy=scale, interpolation=cv2.INTER_LINEAR)
+        warp = np.eye(2, 3, dtype=np.float32)
+        criteria = (cv2.TERM_CRITERIA_EPS | cv2.TERM_CRITERIA_COUNT, max_iter, eps)
+        try:
+            _, warp = cv2.findTransformECC(src_r, dst_r, warp, cv2.MOTION_EUCLIDEAN, criteria, None, 1)
+        except cv2.error:
+            return None
+        warp[0, 2] = warp[0, 2] / scale
+        warp[1, 2] = warp[1, 2] / scale
+        return warp
+
+    def _camera_step(self, image, metadatas):
+        if not self._ecc:
+            return
+        if image is None:                                                    # strong_sort_api.py:61: the frame is read before the empty check
+            from PIL import Image
+            image = np.asarray(Image.open(metadatas["file_path"].values[0]).convert("RGB"))
+        img = np.ascontiguousarray(to_numpy(image))
+        if self._prev_frame is not None and self._bank is not None:          # strong_sort_api.py:62-65
+            warp = self._ecc_warp(self._prev_frame, img)
+            if warp is not None:
+                self._bank.camera_update(warp, 0)
+        self._prev_frame = img
 
     def _make_backend(self, dim, img_h, img_w):
         from .._lib import SsortBank
