@@ -326,9 +326,10 @@ def test_deepocsort_module_host_logic_with_oracle_backend(orc):
 
     m = HipDeepOCSORT(NS(min_confidence=0.4, feature_dim=D, hyperparams=hyper), "cuda:0", tracking_dataset=None)
     assert m.level == "image" and m.batch_size == 1 and m.output_columns == ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
-    for bad in (dict(cmc_off=False), dict(embedding_off=True), dict(new_kf_off=True)):
+    for bad in (dict(embedding_off=True), dict(new_kf_off=True)):
         with pytest.raises(NotImplementedError):
             HipDeepOCSORT(NS(hyperparams=dict(hyper, **bad)), "cuda:0")
+    HipDeepOCSORT(NS(hyperparams=dict(hyper, cmc_off=False)), "cuda:0")     # the reference's default: inert there (tag-keyed cache), inert here
     m._make_backend = lambda dim, h, w: Backend()
     ref = orc.DeepOCSort(D, **hyper)
     frame = np.zeros((1080, 1920, 3), np.uint8)

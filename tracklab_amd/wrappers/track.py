@@ -387,7 +387,8 @@ class HipDeepOCSORT(ImageLevelModule, _ReidTrackerBase):
     """Deep-OC-SORT (tracklab/wrappers/track/deep_oc_sort_api.py:16-88). The crop box is the detection's corners truncated to int
     with no clamping (ocsort.py:543-547: a negative corner wraps around like numpy indexing, which the HIP crop does not imitate:
     boxes are clamped to the frame), resized / normalised like the other two ReID trackers; the embeddings go to
-    tlk_deepocsort_update as delivered (the reference does not normalise them). cmc_off must be true (cmc.py is cv2)."""
+    tlk_deepocsort_update as delivered (the reference does not normalise them). cmc_off: false is accepted and inert, as it is in the
+    reference's wiring (see __init__)."""
     input_columns = ["bbox_ltwh", "bbox_conf", "category_id"]
     output_columns = ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
     preprocess, reset = _ReidTrackerBase.preprocess, _ReidTrackerBase.reset
@@ -401,13 +402,19 @@ class HipDeepOCSORT(ImageLevelModule, _ReidTrackerBase):
         self._img_hw = None
         hyper = dict(cfg_get(cfg, "hyperparams"))
         if not hyper.get("cmc_off", False):
-            raise NotImplementedError("camera-motion compensation (deep_oc_sort/cmc.py, cv2 optical flow) is not part of the HIP path; set cmc_off: true")
+            # OCSort.update is always called with its default tag 'blub' (deep_oc_sort_api.py:64, ocsort.py:392) and CMCComputer caches its
+            # result by tag (cmc.py:68-72): the first frame's estimate -- the identity, there is no previous frame yet (cmc.py:144-147) --
+            # is returned for every later frame. apply_affine_correction with the identity changes nothing, so cmc_off: false is inert
+            # in TrackLab's wiring (short of a stale ./cache/affine_ocsort.pkl), and it is inert here.
+            import logging
+            logging.getLogger(__name__).info("cmc_off: false is inert for Deep-OC-SORT as TrackLab wires it (CMCComputer caches the first frame's "
+                                             "identity under the constant tag); running without camera-motion compensation")
         if hyper.get("embedding_off", False) or hyper.get("new_kf_off", False):
             raise NotImplementedError("embedding_off / new_kf_off are not part of the HIP path (embedding_off fails in the reference itself)")
 
     def _make_backend(self, dim, img_h, img_w):
         from .._lib import DeepOCSortBank
-        hyper = dict(cfg_get(self.cfg, "hyperparams"))
+        hyper = dict(cfg_get(self.cfg, "hyperparams"), cmc_off=True)       # see __init__: false is the identity in the reference's wiring
         return DeepOCSortBank(dim, **hyper, min_confidence=float(cfg_get(self.cfg, "min_confidence", 0.0)), wrapper_mode=True,
                               device=_device_index(self.device), max_tracks=int(cfg_get(self.cfg, "max_tracks", 256)),
                               max_dets=int(cfg_get(self.cfg, "max_dets", 128)))
