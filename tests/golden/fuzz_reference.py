@@ -1,7 +1,7 @@
 """Differential fuzzing of the C oracle against the reference itself (THIS container only: imports /root/reference through the
 same shims as make_golden.py). Not part of the test suite -- the committed goldens are; this widens the net over random
 hyper-parameters and streams and prints the first divergence of each tracker, if any.
-usage: python tests/golden/fuzz_reference.py [n_trials] [trackers: ocsort,bpbss,bytetrack,botsort,deepocsort,ssort]"""
+usage: python tests/golden/fuzz_reference.py [n_trials] [trackers: ocsort,bpbss,bytetrack,botsort,deepocsort,ssort,ssort_cam,botsort_gmc,deepocsort_cmc]"""
 import os
 import sys
 
@@ -198,7 +198,123 @@ def fuzz_bpbss(trial, rng):
     return True
 
 
-FUZZ = {"ocsort": fuzz_ocsort, "bpbss": fuzz_bpbss, "bytetrack": fuzz_bytetrack, "botsort": fuzz_botsort, "deepocsort": fuzz_deepocsort, "ssort": fuzz_ssort}
+def _rand_warp(rng, big=False):
+    th, sc = rng.normal(0, 0.004), 1 + rng.normal(0, 0.003)
+    return np.array([[sc * np.cos(th), -sc * np.sin(th), rng.normal(0, 200.0 if big else 3.0)], [sc * np.sin(th), sc * np.cos(th), rng.normal(0, 2.0)]])
+
+
+def fuzz_ssort_cam(trial, rng):
+    """plain StrongSORT with Tracker.camera_update before every update (strong_sort_api.py:62-65), Track.ECC patched to a random warp."""
+    ss, Metric, Tracker = mg._import_plain_strong_sort()
+    import strong_sort.sort.track as track_mod
+    D = 16
+    hp = dict(max_dist=float(rng.uniform(0.1, 0.4)), max_iou_dist=float(rng.uniform(0.5, 0.9)), max_age=int(rng.integers(3, 40)),
+              max_unmatched_preds=int(rng.integers(0, 8)), n_init=int(rng.integers(1, 4)), nn_budget=int(rng.integers(2, 30)),
+              mc_lambda=float(rng.uniform(0.9, 0.999)), ema_alpha=float(rng.uniform(0.8, 0.95)))
+    cur = {}
+    orig = track_mod.Track.ECC
+    track_mod.Track.ECC = lambda self, src, dst, *a, **k: (cur["w"].copy(), None)
+    try:
+        m = object.__new__(ss.StrongSORT)
+        m.max_dist = hp["max_dist"]
+        m.tracker = Tracker(Metric("cosine", hp["max_dist"], hp["nn_budget"]), max_iou_dist=hp["max_iou_dist"], max_age=hp["max_age"],
+                            n_init=hp["n_init"], max_unmatched_preds=hp["max_unmatched_preds"], mc_lambda=hp["mc_lambda"], ema_alpha=hp["ema_alpha"])
+        orc = oracle.PlainStrongSORT(D, **hp, img_w=1920, img_h=1080)
+        prev = None
+        for fr in SyntheticStream(7000 + trial, int(rng.integers(5, 40)), 80, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
+            d, e = fr["dets"], fr["embeddings"][:, 0, :].astype(np.float32)
+            cur["w"] = _rand_warp(rng, big=rng.random() < 0.05).astype(np.float32)
+            if prev is not None:
+                m.tracker.camera_update(prev, IMG); orc.camera_update(cur["w"])
+            prev = IMG
+            if len(d) == 0:
+                continue
+            m._get_features = lambda xywh, img, e=e: torch.from_numpy(e.copy())
+            out = m.update(torch.from_numpy(d.copy()), IMG)
+            exp = np.array([[float(r[k]) for k in (0, 1, 2, 3, 4, 5, 6, 8)] for r in out], dtype=np.float64).reshape(-1, 8)
+            if not compare("ssort_cam", trial, fr["frame"], orc.update(d, e), exp, tol=0):
+                return False
+        return True
+    finally:
+        track_mod.Track.ECC = orig
+
+
+def fuzz_botsort_gmc(trial, rng):
+    import types
+    mg._import_byte_track(); mg._import_plain_strong_sort()
+    import bot_sort.bot_sort as bs
+    from bot_sort.basetrack import BaseTrack
+    from bot_sort.kalman_filter import KalmanFilter
+    D = 16
+    hp = dict(track_high_thresh=float(rng.uniform(0.3, 0.7)), new_track_thresh=float(rng.uniform(0.3, 0.8)), track_buffer=int(rng.integers(3, 40)),
+              match_thresh=float(rng.uniform(0.3, 0.9)), proximity_thresh=float(rng.uniform(0.3, 0.7)), appearance_thresh=float(rng.uniform(0.1, 0.5)),
+              frame_rate=30, lambda_=float(rng.uniform(0.9, 0.995)))
+    m = object.__new__(bs.BoTSORT)
+    m.tracked_stracks, m.lost_stracks, m.removed_stracks = [], [], []
+    BaseTrack.clear_count()
+    m.frame_id, m.lambda_, m.track_high_thresh, m.new_track_thresh = 0, hp["lambda_"], hp["track_high_thresh"], hp["new_track_thresh"]
+    m.buffer_size = m.max_time_lost = int(hp["frame_rate"] / 30.0 * hp["track_buffer"])
+    m.kalman_filter = KalmanFilter()
+    m.proximity_thresh, m.appearance_thresh, m.match_thresh = hp["proximity_thresh"], hp["appearance_thresh"], hp["match_thresh"]
+    cur = {}
+    m.gmc = types.SimpleNamespace(apply=lambda img, dets: cur["w"].copy())
+    orc = oracle.BoTSORT(D, **hp)
+    for fr in SyntheticStream(8000 + trial, int(rng.integers(5, 40)), 80, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
+        keep = fr["dets"][:, 4] > 0.4
+        d, e = fr["dets"][keep], fr["embeddings"][keep, 0, :].astype(np.float32)
+        if len(d) == 0:
+            continue
+        cur["w"] = _rand_warp(rng)
+        hi = d[:, 4] > hp["track_high_thresh"]
+        feats = torch.from_numpy(e[hi].copy())
+        m._get_features = lambda xywh, img, feats=feats: feats
+        if not compare("botsort_gmc", trial, fr["frame"], orc.update(d, e, warp=cur["w"]), m.update(torch.from_numpy(d.copy()), IMG), tol=1e-9):
+            return False
+    return True
+
+
+def fuzz_deepocsort_cmc(trial, rng):
+    import types
+    mg._install_filterpy_shim(); mg._import_plain_strong_sort()
+    saved = sys.modules.get("lap", "absent")
+    sys.modules["lap"] = None
+    try:
+        import deep_oc_sort.ocsort as doc
+        D = 16
+        hp = dict(det_thresh=float(rng.choice([0.0, 0.3, 0.5])), max_age=int(rng.integers(3, 30)), min_hits=1, iou_threshold=float(rng.uniform(0.15, 0.4)),
+                  delta_t=int(rng.integers(1, 6)), asso_func=str(rng.choice(["iou", "giou", "diou", "ciou"])), inertia=float(rng.uniform(0.0, 0.5)),
+                  w_association_emb=float(rng.uniform(0.2, 1.0)), alpha_fixed_emb=float(rng.uniform(0.8, 0.98)), aw_param=float(rng.uniform(0.3, 0.7)),
+                  embedding_off=False, cmc_off=True, aw_off=bool(rng.random() < 0.3), new_kf_off=False)
+        m = object.__new__(doc.OCSort)
+        m.max_age, m.min_hits, m.iou_threshold, m.trackers, m.frame_count = hp["max_age"], hp["min_hits"], hp["iou_threshold"], [], 0
+        m.det_thresh, m.delta_t, m.asso_func, m.inertia = hp["det_thresh"], hp["delta_t"], doc.ASSO_FUNCS[hp["asso_func"]], hp["inertia"]
+        m.w_association_emb, m.alpha_fixed_emb, m.aw_param = hp["w_association_emb"], hp["alpha_fixed_emb"], hp["aw_param"]
+        doc.KalmanBoxTracker.count = 0
+        m.embedding_off, m.cmc_off, m.aw_off, m.new_kf_off = False, False, hp["aw_off"], False
+        cur = {}
+        m.cmc = types.SimpleNamespace(compute_affine=lambda img, dets, tag: cur["w"].copy())
+        orc = oracle.DeepOCSort(D, **hp)
+        for fr in SyntheticStream(9000 + trial, int(rng.integers(5, 40)), 80, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
+            keep = fr["dets"][:, 4] > 0.4
+            d, e = fr["dets"][keep], fr["embeddings"][keep, 0, :].astype(np.float32)
+            if len(d) == 0:
+                continue
+            e = e / np.linalg.norm(e, axis=1, keepdims=True)
+            cur["w"] = _rand_warp(rng)
+            thr = d[:, 4] > hp["det_thresh"]
+            feats = torch.from_numpy(e[thr].copy())
+            m._get_features = lambda xyxy, img, feats=feats: feats
+            if not compare("deepocsort_cmc", trial, fr["frame"], orc.update(d, e, warp=cur["w"]), np.asarray(m.update(torch.from_numpy(d.copy()), IMG)), tol=1e-9):
+                return False
+        return True
+    finally:
+        if saved == "absent":
+            sys.modules.pop("lap", None)
+        else:
+            sys.modules["lap"] = saved
+
+
+FUZZ = {"ssort_cam": fuzz_ssort_cam, "botsort_gmc": fuzz_botsort_gmc, "deepocsort_cmc": fuzz_deepocsort_cmc, "ocsort": fuzz_ocsort, "bpbss": fuzz_bpbss, "bytetrack": fuzz_bytetrack, "botsort": fuzz_botsort, "deepocsort": fuzz_deepocsort, "ssort": fuzz_ssort}
 for name in sorted(WHICH):
     ok = 0
     for t in range(N):
