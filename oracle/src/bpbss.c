@@ -333,7 +333,8 @@ int orc_bpbss_update_kp(orc_bpbss *T, const int64_t *ids_in, const double *ltwh_
             if (nc > 0) for (int k = 0; k < nma; ++k) { d_mname[m_d[k]] = 1; d_mdist[m_d[k]] = cm[(size_t)m_row[k] * N + m_col[k]]; }
             /* matching_cascade: unmatched_tracks = list(set(track_indices) - matched) -> ascending */
             n_uta = 0;
-            for (int r = 0; r < nc; ++r) { int f = 0; for (int k = 0; k < nma; ++k) if (m_t[k] == cand[r]) { f = 1; break; } if (!f) um_ta[n_uta++] = cand[r]; }
+            if (orc_get_python_set_order()) n_uta = orc_pyset_difference_order(cand, nc, m_t, nma, um_ta);
+            else for (int r = 0; r < nc; ++r) { int f = 0; for (int k = 0; k < nma; ++k) if (m_t[k] == cand[r]) { f = 1; break; } if (!f) um_ta[n_uta++] = cand[r]; }
             /* stage B candidates */
             int nb = 0; int *bc = malloc(sizeof(int) * (size_t)cap);
             for (int k = 0; k < nu; ++k) bc[nb++] = unconf[k];

@@ -264,7 +264,8 @@ int orc_ssort_update(orc_ssort *T, const double *dets, const float *feat_in, int
         }
         min_cost_matching(cm, nc, N, T->c.max_dist, conf_idx, alld, m_t, m_d, &nma, um_ta, &n_uta, um_da, &n_uda);
         free(cm);
-        qsort(um_ta, n_uta, sizeof(int), cmp_int);             /* list(set(track_indices) - matched): small ints iterate ascending */
+        if (orc_get_python_set_order()) n_uta = orc_pyset_difference_order(conf_idx, nc, m_t, nma, um_ta);      /* linear_assignment.py:126 */
+        else qsort(um_ta, n_uta, sizeof(int), cmp_int);        /* list(set(track_indices) - matched): ascending while indices < table size */
     }
     /* ---- IoU stage (tracker.py:173-184) ---- */
     int *cand = malloc(sizeof(int) * cap), ncand = 0, *left = malloc(sizeof(int) * cap), nleft = 0;

@@ -15,6 +15,7 @@ import oracle  # noqa: E402
 from tracklab_amd.synth import SyntheticStream, ltrb_to_ltwh_rows, synth_keypoints  # noqa: E402
 
 oracle.build()
+oracle.python_set_order(os.environ.get("ORC_PYTHON_SET_ORDER", "1") == "1")     # compare with the reference as CPython 3.10 runs it
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 WHICH = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else {"ocsort", "bpbss", "bytetrack", "botsort", "deepocsort", "ssort"}
 IMG = np.zeros((1080, 1920, 3), np.uint8)
@@ -146,6 +147,7 @@ def fuzz_ssort(trial, rng):
 
 def fuzz_ocsort(trial, rng):
     mg._install_filterpy_shim()
+    sys.modules["lap"] = None                                   # `import lap` fails -> scipy fallback, as in the reference's environment
     import oc_sort.ocsort as ref
     hp = dict(det_thresh=float(rng.choice([0.0, 0.3, 0.5])), max_age=int(rng.integers(3, 40)), min_hits=int(rng.integers(1, 4)),
               iou_threshold=float(rng.uniform(0.15, 0.4)), delta_t=int(rng.integers(1, 4)), asso_func=str(rng.choice(["iou", "giou", "diou", "ciou", "ct_dist"])),

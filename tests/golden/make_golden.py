@@ -1289,11 +1289,40 @@ def gen_deepocsort_cmc(out_dir):
             sys.modules["lap"] = saved_lap
 
 
+def gen_ssort_setorder(out_dir):
+    """A plain-StrongSORT run (found by tests/golden/fuzz_reference.py, trial 57) in which the iteration order of the CPython set behind
+    `unmatched_tracks = list(set(track_indices) - set(k for k, _ in matches))` (sort/linear_assignment.py:126) is NOT ascending and decides
+    the ids of two tracks born in the same frame: 32 objects, so track indices exceed the 8- / 32-entry tables of small result sets."""
+    ss, Metric, Tracker = _import_plain_strong_sort()
+    hp = dict(max_dist=0.24058051284092766, max_iou_dist=0.8946939275194115, max_age=10, max_unmatched_preds=2, n_init=3, nn_budget=11,
+              mc_lambda=0.9660812618861851, ema_alpha=0.8694303929964391)
+    D = 16
+    model = object.__new__(ss.StrongSORT)
+    model.max_dist = hp["max_dist"]
+    model.tracker = Tracker(Metric("cosine", hp["max_dist"], hp["nn_budget"]), max_iou_dist=hp["max_iou_dist"], max_age=hp["max_age"],
+                            n_init=hp["n_init"], max_unmatched_preds=hp["max_unmatched_preds"], mc_lambda=hp["mc_lambda"], ema_alpha=hp["ema_alpha"])
+    img = np.zeros((1080, 1920, 3), dtype=np.uint8)
+    in_off, out_off, dets_all, embs, rows = [0], [0], [], [], []
+    for fr in SyntheticStream(4057, 32, 30, parts=1, dim=D, with_embeddings=True, miss_prob=0.05, low_conf_frac=0.2, churn_period=1000):
+        d, e = fr["dets"], fr["embeddings"][:, 0, :].astype(np.float32)
+        dets_all.append(d); embs.append(e); in_off.append(in_off[-1] + len(d))
+        feats = torch.from_numpy(e.copy())
+        model._get_features = lambda xywhs, im, feats=feats: feats
+        out = model.update(torch.from_numpy(d.copy()), img)
+        rows.extend([[float(r[k]) for k in (0, 1, 2, 3, 4, 5, 6, 8)] for r in out])
+        out_off.append(out_off[-1] + len(out))
+    np.savez_compressed(os.path.join(out_dir, "setorder_ssort.npz"), dets=np.concatenate(dets_all), embeddings=np.concatenate(embs),
+                        det_offsets=np.array(in_off, dtype=np.int64), out_offsets=np.array(out_off, dtype=np.int64),
+                        rows=np.array(rows, dtype=np.float64).reshape(-1, 8), config=json.dumps(hp), dim=D,
+                        python=np.array(sys.version.split()[0]))
+    print(f"setorder_ssort: rows_out={out_off[-1]} python {sys.version.split()[0]}")
+
+
 def main():
     out_dir = HERE
     only = set(sys.argv[1:])
     gens = {"ocsort": gen_ocsort, "iou": gen_iou_family, "kf7": gen_kf7, "lsa": gen_lsa,
-            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack, "botsort": gen_botsort, "deepocsort": gen_deepocsort, "clearmot": gen_clearmot, "mot_io": gen_mot_io, "ssort_camera": gen_ssort_camera, "botsort_gmc": gen_botsort_gmc, "deepocsort_cmc": gen_deepocsort_cmc}
+            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack, "botsort": gen_botsort, "deepocsort": gen_deepocsort, "clearmot": gen_clearmot, "mot_io": gen_mot_io, "ssort_camera": gen_ssort_camera, "botsort_gmc": gen_botsort_gmc, "deepocsort_cmc": gen_deepocsort_cmc, "ssort_setorder": gen_ssort_setorder}
     for k, fn in gens.items():
         if not only or k in only:
             fn(out_dir)
