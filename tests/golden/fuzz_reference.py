@@ -19,6 +19,11 @@ oracle.python_set_order(os.environ.get("ORC_PYTHON_SET_ORDER", "1") == "1")     
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 WHICH = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else {"ocsort", "bpbss", "bytetrack", "botsort", "deepocsort", "ssort"}
 IMG = np.zeros((1080, 1920, 3), np.uint8)
+BIG = int(os.environ.get("FUZZ_MAX_OBJECTS", "0"))          # > 0: streams with up to this many objects (crowded scenes)
+
+
+def nobj(rng, lo, hi):
+    return int(rng.integers(lo, BIG if BIG > 0 else hi))
 
 
 def stream_kw(rng):
@@ -42,7 +47,7 @@ def fuzz_bytetrack(trial, rng):
               frame_rate=int(rng.choice([15, 30])))
     BaseTrack._count = 0
     ref, orc = BYTETracker(**hp), oracle.ByteTrack(**hp)
-    for fr in SyntheticStream(1000 + trial, int(rng.integers(5, 60)), 120, **stream_kw(rng)):
+    for fr in SyntheticStream(1000 + trial, nobj(rng, 5, 60), 120, **stream_kw(rng)):
         d = fr["dets"][fr["dets"][:, 4] > 0.4]
         if len(d) == 0:
             continue
@@ -70,7 +75,7 @@ def fuzz_botsort(trial, rng):
     m.proximity_thresh, m.appearance_thresh, m.match_thresh = hp["proximity_thresh"], hp["appearance_thresh"], hp["match_thresh"]
     m.gmc = GMC(method="none", verbose=[None, False])
     orc = oracle.BoTSORT(D, **hp)
-    for fr in SyntheticStream(2000 + trial, int(rng.integers(5, 50)), 120, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
+    for fr in SyntheticStream(2000 + trial, nobj(rng, 5, 50), 120, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
         keep = fr["dets"][:, 4] > 0.4
         d, e = fr["dets"][keep], fr["embeddings"][keep, 0, :].astype(np.float32)
         if len(d) == 0:
@@ -102,7 +107,7 @@ def fuzz_deepocsort(trial, rng):
         m.embedding_off, m.cmc_off, m.aw_off, m.new_kf_off = False, True, hp["aw_off"], False
         orc = oracle.DeepOCSort(D, **hp)
         normed = rng.random() < 0.7
-        for fr in SyntheticStream(3000 + trial, int(rng.integers(5, 50)), 120, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
+        for fr in SyntheticStream(3000 + trial, nobj(rng, 5, 50), 120, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
             keep = fr["dets"][:, 4] > 0.4
             d, e = fr["dets"][keep], fr["embeddings"][keep, 0, :].astype(np.float32)
             if normed and len(e):
@@ -133,7 +138,7 @@ def fuzz_ssort(trial, rng):
     m.tracker = Tracker(Metric("cosine", hp["max_dist"], hp["nn_budget"]), max_iou_dist=hp["max_iou_dist"], max_age=hp["max_age"],
                         n_init=hp["n_init"], max_unmatched_preds=hp["max_unmatched_preds"], mc_lambda=hp["mc_lambda"], ema_alpha=hp["ema_alpha"])
     orc = oracle.PlainStrongSORT(D, **hp, img_w=1920, img_h=1080)
-    for fr in SyntheticStream(4000 + trial, int(rng.integers(5, 40)), 100, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
+    for fr in SyntheticStream(4000 + trial, nobj(rng, 5, 40), 100, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
         d, e = fr["dets"], fr["embeddings"][:, 0, :].astype(np.float32)
         if len(d) == 0:
             continue
@@ -153,7 +158,7 @@ def fuzz_ocsort(trial, rng):
               iou_threshold=float(rng.uniform(0.15, 0.4)), delta_t=int(rng.integers(1, 4)), asso_func=str(rng.choice(["iou", "giou", "diou", "ciou", "ct_dist"])),
               inertia=float(rng.uniform(0.0, 0.5)), use_byte=bool(rng.random() < 0.4))
     trk, orc = ref.OCSort(**hp), oracle.OCSort(**hp)
-    for fr in SyntheticStream(5000 + trial, int(rng.integers(5, 60)), 120, **stream_kw(rng)):
+    for fr in SyntheticStream(5000 + trial, nobj(rng, 5, 60), 120, **stream_kw(rng)):
         d = fr["dets"]
         if len(d) == 0:
             continue
@@ -178,7 +183,7 @@ def fuzz_bpbss(trial, rng):
                motion_criterium="oks" if oks else "iou")
     model, orc = ss.StrongSORT(**cfg), oracle.StrongSORT(K, D, **cfg)
     kp_rng = np.random.default_rng(77 + trial)
-    for fr in SyntheticStream(6000 + trial, int(rng.integers(5, 40)), 100, parts=K, dim=D, with_embeddings=True, **stream_kw(rng)):
+    for fr in SyntheticStream(6000 + trial, nobj(rng, 5, 40), 100, parts=K, dim=D, with_embeddings=True, **stream_kw(rng)):
         d = fr["dets"]
         if len(d) == 0:
             continue
@@ -223,7 +228,7 @@ def fuzz_ssort_cam(trial, rng):
                             n_init=hp["n_init"], max_unmatched_preds=hp["max_unmatched_preds"], mc_lambda=hp["mc_lambda"], ema_alpha=hp["ema_alpha"])
         orc = oracle.PlainStrongSORT(D, **hp, img_w=1920, img_h=1080)
         prev = None
-        for fr in SyntheticStream(7000 + trial, int(rng.integers(5, 40)), 80, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
+        for fr in SyntheticStream(7000 + trial, nobj(rng, 5, 40), 80, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
             d, e = fr["dets"], fr["embeddings"][:, 0, :].astype(np.float32)
             cur["w"] = _rand_warp(rng, big=rng.random() < 0.05).astype(np.float32)
             if prev is not None:
@@ -261,7 +266,7 @@ def fuzz_botsort_gmc(trial, rng):
     cur = {}
     m.gmc = types.SimpleNamespace(apply=lambda img, dets: cur["w"].copy())
     orc = oracle.BoTSORT(D, **hp)
-    for fr in SyntheticStream(8000 + trial, int(rng.integers(5, 40)), 80, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
+    for fr in SyntheticStream(8000 + trial, nobj(rng, 5, 40), 80, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
         keep = fr["dets"][:, 4] > 0.4
         d, e = fr["dets"][keep], fr["embeddings"][keep, 0, :].astype(np.float32)
         if len(d) == 0:
@@ -296,7 +301,7 @@ def fuzz_deepocsort_cmc(trial, rng):
         cur = {}
         m.cmc = types.SimpleNamespace(compute_affine=lambda img, dets, tag: cur["w"].copy())
         orc = oracle.DeepOCSort(D, **hp)
-        for fr in SyntheticStream(9000 + trial, int(rng.integers(5, 40)), 80, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
+        for fr in SyntheticStream(9000 + trial, nobj(rng, 5, 40), 80, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
             keep = fr["dets"][:, 4] > 0.4
             d, e = fr["dets"][keep], fr["embeddings"][keep, 0, :].astype(np.float32)
             if len(d) == 0:
