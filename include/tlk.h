@@ -56,6 +56,14 @@ int tlk_iou_matrix_f64(int variant, const double *b1_dev, int n, const double *b
 int tlk_lsa_f64(const double *cost_dev, int batch, int nr, int nc, int32_t *rows_dev, int32_t *cols_dev,
                 int32_t *n_pairs_dev, void *hip_stream);
 
+/* `list(set(a) - set(b))` in the order CPython 3.10 iterates the result set -- how both StrongSORT plugins build the
+ * unmatched-track list of their matching cascade (plugins/track/strong_sort/sort/linear_assignment.py:126-127,
+ * plugins/track/bpbreid_strong_sort/sort/linear_assignment.py:127-128); that list is the row order of the IoU / OKS stage.
+ * HOST buffers: a (na) ascending distinct non-negative keys (the cascade's track_indices), b (nb) distinct keys out of a
+ * (the matched tracks), out (na) / n_out the ordered difference. tlk_ssort_* / tlk_bpbss_* run the same device code inside
+ * their association kernels; force_table != 0 skips the "no key can wrap -> ascending" shortcut (test hook). */
+int tlk_pyset_difference_order(const int32_t *a, int na, const int32_t *b, int nb, int32_t *out, int32_t *n_out, int force_table);
+
 /* lap.lapjv(cost, extend_cost=True, cost_limit=L) as ByteTrack's linear_assignment uses it
  * (plugins/track/byte_track/matching.py:37-48; third-party lap, not installed -> restated from its documented
  * embedding: (nr+nc)^2 problem, padding entries L/2, lower-right block 0). x_dev (batch, nr): column of row i or -1;

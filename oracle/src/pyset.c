@@ -118,9 +118,10 @@ int orc_pyset_difference_order(const int *a, int na, const int *b, int nb, int *
     return n;
 }
 
-/* 0 (default): the matching cascades order their unmatched-track lists ascending -- what the HIP kernels do and what CPython yields
- * while every index is below the set's table size; 1: CPython 3.10's own iteration order (differs once track indices exceed the
- * table size of a small result set; it changes the row order of the IoU stage and with it the ids of tracks born in one frame). */
-static int g_python_set_order = 0;
+/* 1 (default): CPython 3.10's own iteration order -- what the reference does and what the HIP association kernels reproduce
+ * (tracklab_amd/csrc/tlk_pyset.hpp); 0: ascending, kept as a switch for the tests that show where the two differ (once a track
+ * index exceeds the table size of a small result set the order changes the rows of the IoU stage and with them the ids of
+ * tracks born in one frame). */
+static int g_python_set_order = 1;
 void orc_set_python_set_order(int on) { g_python_set_order = on; }
 int orc_get_python_set_order(void) { return g_python_set_order; }

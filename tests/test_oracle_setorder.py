@@ -42,14 +42,14 @@ def _replay(orc, g):
 
 
 def test_plain_strongsort_set_order_case(orc):
-    """With CPython's order the oracle reproduces the reference on the run the fuzzer found; with ascending order (the default, what
-    the HIP kernels implement) the two tracks born in frame 5 swap ids and keep them swapped -- the known non-reproduction."""
+    """With CPython's order (the oracle's default, and what tlk_ssort / tlk_bpbss implement on the device) the oracle reproduces the
+    reference on the run the fuzzer found; with ascending order the two tracks born in frame 5 swap ids and keep them swapped."""
     g = np.load(os.path.join(GOLDEN, "setorder_ssort.npz"))
     try:
-        orc.python_set_order(True)
+        assert orc.lib().orc_get_python_set_order() == 1
         assert _replay(orc, g) == []
         orc.python_set_order(False)
         bad = _replay(orc, g)
         assert bad and bad[0] == 5
     finally:
-        orc.python_set_order(False)
+        orc.python_set_order(True)

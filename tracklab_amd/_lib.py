@@ -969,3 +969,18 @@ def cosine_gallery_min(gallery, offsets, dets):
     check(L.tlk_cosine_gallery_min_f32(gallery.data_ptr(), offsets.data_ptr(), T, gallery.shape[0], dets.data_ptr(), N, D,
                                        out.data_ptr(), current_stream_ptr()))
     return out
+
+
+def pyset_difference_order(a, b, force_table=False):
+    """`list(set(a) - set(b))` in CPython 3.10's set-iteration order, computed on the device by the code the StrongSORT-family
+    association kernels run (tlk_pyset.hpp; sort/linear_assignment.py:126-128). a ascending distinct non-negative ints, b out of a."""
+    L = lib()
+    ip = C.POINTER(C.c_int32)
+    L.tlk_pyset_difference_order.argtypes = [ip, C.c_int, ip, C.c_int, ip, C.POINTER(C.c_int32), C.c_int]
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    b = np.ascontiguousarray(b, dtype=np.int32)
+    out = np.zeros(max(len(a), 1), dtype=np.int32)
+    n = C.c_int32(0)
+    check(L.tlk_pyset_difference_order(a.ctypes.data_as(ip), len(a), b.ctypes.data_as(ip), len(b), out.ctypes.data_as(ip), C.byref(n),
+                                       int(bool(force_table))))
+    return out[:n.value].copy()

@@ -11,7 +11,10 @@ pids=()
 for src in "$HERE"/*.hip; do
   obj="$HERE/.obj/$(basename "${src%.hip}").o"
   objs+=("$obj")
-  if [[ ! -f "$obj" || "$src" -nt "$obj" || "$HERE/tlk_common.hpp" -nt "$obj" || "$HERE/tlk_strongsort_common.hpp" -nt "$obj" || "$HERE/tlk_cosine.hpp" -nt "$obj" || "$HERE/tlk_bytetrack_common.hpp" -nt "$obj" || "$HERE/tlk_ocsort_common.hpp" -nt "$obj" || "$HERE/../../include/tlk.h" -nt "$obj" ]]; then
+  stale=0
+  [[ ! -f "$obj" || "$src" -nt "$obj" ]] && stale=1
+  for h in "$HERE"/*.hpp "$HERE/../../include/tlk.h"; do [[ "$h" -nt "$obj" ]] && stale=1; done
+  if [[ $stale == 1 ]]; then
     "$HIPCC" "${FLAGS[@]}" -c "$src" -o "$obj" &
     pids+=($!)
   fi

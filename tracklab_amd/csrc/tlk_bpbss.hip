@@ -34,7 +34,8 @@ struct BpbDev {
     double *reid;            // S x MAXT x MAXD    part-based distance, row = list position, col = input detection index
     double *gl;              // S x MAXT x GLN     per track: projected mean (4) + Cholesky factor (16) for gating, OKS scale + count
     double *cost_g;          // S x MAXT x MAXD    cost-matrix spill
-    int S, MAXT, MAXD, K, D, cost_lds_entries;
+    int *ps_ws;              // S x 4 x ps_cap      hash tables of the set-order emulation when they do not fit the LDS cost area
+    int S, MAXT, MAXD, K, D, cost_lds_entries, ps_cap;
 };
 
 struct BpbP {
@@ -341,16 +342,19 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
                     L.d_mname[j] = 1; L.d_mdist[j] = P.mc_lambda * c + (1 - P.mc_lambda) * gd;
                 }
             __syncthreads();
-            // matching_cascade: unmatched_tracks = set(track_indices) - matched (ascending), linear_assignment.py:128
+            // matching_cascade: unmatched_tracks = list(set(track_indices) - matched), linear_assignment.py:128 ...
             for (int p = tid; p < T; p += BLOCK) L.rowf[p] = 0;
             __syncthreads();
             for (int k = tid; k < A.nm; k += BLOCK) L.rowf[L.m_t[k]] = 1;     // by track position
             __syncthreads();
-            // split by time_since_update == 1 (tracker.py:308-313)
-            const int nb_extra = block_compact(nc, [&](int r) { return L.rowf[L.cand[r]] == 0 && trk_at(order[L.cand[r]]).i(BI_TSU) == 1; },
-                                               [&](int r, int pos) { L.bc[nu + pos] = L.cand[r]; }, L.scan);
-            const int n_uta = block_compact(nc, [&](int r) { return L.rowf[L.cand[r]] == 0 && trk_at(order[L.cand[r]]).i(BI_TSU) != 1; },
-                                            [&](int r, int pos) { L.um_t[pos] = L.cand[r]; }, L.scan);
+            // ... in CPython's set-iteration order (cm has been consumed: the LDS cost area doubles as the hash-table scratch)
+            int *psw = ((size_t)Dv.cost_lds_entries * sizeof(double) >= (size_t)16 * Dv.ps_cap) ? (int *)L.cost : Dv.ps_ws + (size_t)s * 4 * Dv.ps_cap;
+            const int n_unm = cascade_unmatched_tracks(L.cand, nc, A.nm, L.tmp, psw, (unsigned)Dv.ps_cap, L);
+            // split by time_since_update == 1 (tracker.py:308-313), order kept
+            const int nb_extra = block_compact(n_unm, [&](int r) { return trk_at(order[L.tmp[r]]).i(BI_TSU) == 1; },
+                                               [&](int r, int pos) { L.bc[nu + pos] = L.tmp[r]; }, L.scan);
+            const int n_uta = block_compact(n_unm, [&](int r) { return trk_at(order[L.tmp[r]]).i(BI_TSU) != 1; },
+                                            [&](int r, int pos) { L.um_t[pos] = L.tmp[r]; }, L.scan);
             const int nb = nu + nb_extra, n_uda = A.n_um_d;
             __syncthreads();
             double *cb = ((size_t)nb * n_uda <= (size_t)Dv.cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
@@ -686,7 +690,7 @@ static void bpb_free(tlk_bpbss *h)
     if (!h) return;
     hipSetDevice(h->device);
     BpbDev &D = h->D;
-    void *ptrs[] = {D.fd, D.fi, D.detid, D.hdr, D.order, D.freestk, D.feat, D.fvis, D.tnorm, D.dnorm, D.reid, D.gl, D.cost_g,
+    void *ptrs[] = {D.fd, D.fi, D.detid, D.hdr, D.order, D.freestk, D.feat, D.fvis, D.tnorm, D.dnorm, D.reid, D.gl, D.cost_g, D.ps_ws,
                     h->d_ids, h->d_ltwh, h->d_emb, h->d_vis, h->d_conf, h->d_kps, h->d_cnt, h->d_ocnt, h->d_rows};
     for (void *p : ptrs) if (p) hipFree(p);
     delete h;
@@ -748,6 +752,8 @@ extern "C" int tlk_bpbss_create(const tlk_bpbss_params *p, int n_streams, int de
     BPB_ALLOC(D.reid, sizeof(double) * slots * MAXD);
     BPB_ALLOC(D.gl, sizeof(double) * GLN * slots);
     BPB_ALLOC(D.cost_g, sizeof(double) * slots * MAXD);
+    D.ps_cap = (int)pyset::table_capacity((unsigned)MAXT);
+    BPB_ALLOC(D.ps_ws, sizeof(int) * 4 * (size_t)D.ps_cap * n_streams);
     BPB_ALLOC(h->d_ids, sizeof(long long) * MAXD);
     BPB_ALLOC(h->d_ltwh, sizeof(double) * 4 * MAXD);
     BPB_ALLOC(h->d_emb, sizeof(float) * FD * MAXD);
@@ -834,7 +840,7 @@ extern "C" int tlk_bpbss_update(tlk_bpbss *h, int stream, const int64_t *ids, co
     const size_t sl = (size_t)stream * V.MAXT;
     V.fd += sl; V.fi += sl; V.detid += sl; V.hdr += (size_t)stream * H_COUNT; V.order += sl; V.freestk += sl;
     V.feat += sl * FD; V.fvis += sl * V.K; V.tnorm += sl * V.K * 2; V.dnorm += (size_t)stream * V.MAXD * V.K * 2;
-    V.reid += sl * V.MAXD; V.gl += sl * GLN; V.cost_g += sl * V.MAXD;
+    V.reid += sl * V.MAXD; V.gl += sl * GLN; V.cost_g += sl * V.MAXD; V.ps_ws += (size_t)stream * 4 * V.ps_cap;
     FrameIn in;
     in.ids = h->d_ids; in.ltwh = h->d_ltwh; in.emb = h->d_emb; in.vis = h->d_vis; in.conf = h->d_conf; in.counts = h->d_cnt;
     in.kps = kps ? h->d_kps : nullptr;

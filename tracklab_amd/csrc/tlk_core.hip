@@ -1,5 +1,6 @@
 // tlk_core.hip -- error plumbing + stateless kernels (similarity matrices, batched LSA).
 #include "tlk_common.hpp"
+#include "tlk_pyset.hpp"
 
 namespace tlk {
 static thread_local std::string g_err;
@@ -185,4 +186,64 @@ extern "C" int tlk_lsa_lapjv_limit_f64(const double *cost_dev, int batch, int nr
     }
     hipFreeAsync(ext, st); hipFreeAsync(rows, st);
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// list(set(a) - set(b)) in CPython 3.10's iteration order (tlk_pyset.hpp): the stateless form of what the StrongSORT-family
+// association kernels run after their appearance stage (sort/linear_assignment.py:126-128 of both plugins).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) pyset_difference_kernel(const int *__restrict__ a, int na, const int *__restrict__ b, int nb, int key_cap,
+                                                                 int *__restrict__ in_b, int *__restrict__ ws, unsigned cap, int force_table,
+                                                                 int *__restrict__ out, int *__restrict__ n_out)
+{
+    __shared__ int s_scan[NWAVES];
+    for (int k = threadIdx.x; k < key_cap; k += BLOCK) in_b[k] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < nb; k += BLOCK) in_b[b[k]] = 1;
+    __syncthreads();
+    const int nu = block_compact(na, [&](int r) { return in_b[a[r]] == 0; }, [&](int r, int pos) { out[pos] = a[r]; }, s_scan);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = nu;
+        if (na > 0 && (force_table || !pyset::ascending_is_exact(na, a[na - 1], nb, out, nu)))
+            n = pyset::difference_order_serial(a, na, in_b, nb, out, ws, cap);
+        *n_out = n;
+    }
+}
+
+extern "C" int tlk_pyset_difference_order(const int32_t *a, int na, const int32_t *b, int nb, int32_t *out, int32_t *n_out, int force_table)
+{
+    if (na < 0 || nb < 0 || (na && !a) || (nb && !b) || !out || !n_out) return fail(TLK_EINVAL, "tlk_pyset_difference_order: bad arguments");
+    int key_cap = 1;
+    for (int i = 0; i < na; ++i) {
+        if (a[i] < 0 || (i && a[i] <= a[i - 1])) return fail(TLK_EINVAL, "tlk_pyset_difference_order: a must be ascending, distinct and non-negative");
+        key_cap = a[i] + 1;
+    }
+    for (int i = 0; i < nb; ++i) {
+        bool found = false;
+        for (int k = 0; k < na && !found; ++k) found = a[k] == b[i];
+        if (!found) return fail(TLK_EINVAL, "tlk_pyset_difference_order: b must be a subset of a");
+        for (int k = 0; k < i; ++k) if (b[k] == b[i]) return fail(TLK_EINVAL, "tlk_pyset_difference_order: b must hold distinct keys");
+    }
+    *n_out = 0;
+    if (na == 0) return TLK_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(TLK_ENODEVICE, "tlk_pyset_difference_order: no HIP device (libtlk has no CPU fallback)");
+    const unsigned cap = pyset::table_capacity((unsigned)na);
+    int *d = nullptr;
+    const size_t ints = (size_t)na * 2 + nb + key_cap + 4 * (size_t)cap + 1;
+    TLK_HIP(hipMalloc((void **)&d, sizeof(int) * ints));
+    int *d_a = d, *d_b = d_a + na, *d_out = d_b + nb, *d_inb = d_out + na, *d_ws = d_inb + key_cap, *d_n = d_ws + 4 * (size_t)cap;
+    hipError_t e = hipMemcpy(d_a, a, sizeof(int) * na, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nb) e = hipMemcpy(d_b, b, sizeof(int) * nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pyset_difference_kernel, dim3(1), dim3(BLOCK), 0, 0, (const int *)d_a, na, (const int *)d_b, nb, key_cap, d_inb, d_ws, cap,
+                           force_table, d_out, d_n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(n_out, d_n, sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && *n_out > 0) e = hipMemcpy(out, d_out, sizeof(int) * (size_t)*n_out, hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) return fail(TLK_EHIP, std::string("tlk_pyset_difference_order: ") + hipGetErrorString(e));
+    return TLK_OK;
 }

@@ -36,7 +36,8 @@ struct SsDev {
     double *reid;            // S x MAXT x MAXD     cosine gallery minimum, row = list position, col = input detection index
     double *gl;              // S x MAXT x SGL
     double *cost_g;          // S x MAXT x MAXD     cost-matrix spill
-    int S, MAXT, MAXD, D, B, cost_lds_entries;
+    int *ps_ws;              // S x 4 x ps_cap       hash tables of the set-order emulation when they do not fit the LDS cost area
+    int S, MAXT, MAXD, D, B, cost_lds_entries, ps_cap;
 };
 
 struct SsP {
@@ -246,11 +247,14 @@ ssort_assoc_kernel(SsDev Dv, SsP P, SsIn in, tlk_ssort_row *__restrict__ rows_al
     __syncthreads();
     for (int k = tid; k < A.nm; k += BLOCK) L.rowf[L.m_t[k]] = 1;     // by track position
     __syncthreads();
-    // unmatched confirmed tracks (ascending, list(set(..)) of small ints) split by time_since_update == 1 (tracker.py:174-179)
-    const int nb_extra = block_compact(nc, [&](int r) { return L.rowf[L.cand[r]] == 0 && trk_at(order[L.cand[r]]).i(SI_TSU) == 1; },
-                                       [&](int r, int pos) { L.bc[nu + pos] = L.cand[r]; }, L.scan);
-    const int n_uta = block_compact(nc, [&](int r) { return L.rowf[L.cand[r]] == 0 && trk_at(order[L.cand[r]]).i(SI_TSU) != 1; },
-                                    [&](int r, int pos) { L.um_t[pos] = L.cand[r]; }, L.scan);
+    // unmatched confirmed tracks = list(set(track_indices) - matched) in CPython's set-iteration order (linear_assignment.py:126-127;
+    // cm has been consumed: the LDS cost area doubles as the hash-table scratch), split by time_since_update == 1 (tracker.py:174-179)
+    int *psw = ((size_t)Dv.cost_lds_entries * sizeof(double) >= (size_t)16 * Dv.ps_cap) ? (int *)L.cost : Dv.ps_ws + (size_t)s * 4 * Dv.ps_cap;
+    const int n_unm = cascade_unmatched_tracks(L.cand, nc, A.nm, L.tmp, psw, (unsigned)Dv.ps_cap, L);
+    const int nb_extra = block_compact(n_unm, [&](int r) { return trk_at(order[L.tmp[r]]).i(SI_TSU) == 1; },
+                                       [&](int r, int pos) { L.bc[nu + pos] = L.tmp[r]; }, L.scan);
+    const int n_uta = block_compact(n_unm, [&](int r) { return trk_at(order[L.tmp[r]]).i(SI_TSU) != 1; },
+                                    [&](int r, int pos) { L.um_t[pos] = L.tmp[r]; }, L.scan);
     const int nb = nu + nb_extra, n_uda = A.n_um_d;
     __syncthreads();
     double *cb = ((size_t)nb * n_uda <= (size_t)Dv.cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
@@ -503,7 +507,7 @@ static void ss_free(tlk_ssort *h)
     if (!h) return;
     hipSetDevice(h->device);
     SsDev &D = h->D;
-    void *ptrs[] = {D.fd, D.fi, D.hdr, D.order, D.freestk, D.feat, D.gal, D.gnorm, D.dnorm, D.reid, D.gl, D.cost_g,
+    void *ptrs[] = {D.fd, D.fi, D.hdr, D.order, D.freestk, D.feat, D.gal, D.gnorm, D.dnorm, D.reid, D.gl, D.cost_g, D.ps_ws,
                     h->d_dets, h->d_feat, h->d_cnt, h->d_ocnt, h->d_rows};
     for (void *p : ptrs) if (p) hipFree(p);
     delete h;
@@ -569,6 +573,8 @@ extern "C" int tlk_ssort_create(const tlk_ssort_params *p, int n_streams, int de
     SS_ALLOC(D.reid, sizeof(double) * slots * MAXD);
     SS_ALLOC(D.gl, sizeof(double) * SGL * slots);
     SS_ALLOC(D.cost_g, sizeof(double) * slots * MAXD);
+    D.ps_cap = (int)pyset::table_capacity((unsigned)MAXT);
+    SS_ALLOC(D.ps_ws, sizeof(int) * 4 * (size_t)D.ps_cap * n_streams);
     SS_ALLOC(h->d_dets, sizeof(double) * 7 * MAXD);
     SS_ALLOC(h->d_feat, sizeof(float) * D.D * MAXD);
     SS_ALLOC(h->d_cnt, sizeof(int));
@@ -651,7 +657,7 @@ extern "C" int tlk_ssort_update(tlk_ssort *h, int stream, const double *dets, co
     const size_t sl = (size_t)stream * V.MAXT;
     V.fd += sl; V.fi += sl; V.hdr += (size_t)stream * H_COUNT; V.order += sl; V.freestk += sl;
     V.feat += sl * V.D; V.gal += sl * V.B * V.D; V.gnorm += sl * V.B; V.dnorm += (size_t)stream * V.MAXD;
-    V.reid += sl * V.MAXD; V.gl += sl * SGL; V.cost_g += sl * V.MAXD;
+    V.reid += sl * V.MAXD; V.gl += sl * SGL; V.cost_g += sl * V.MAXD; V.ps_ws += (size_t)stream * 4 * V.ps_cap;
     SsIn in;
     in.dets = h->d_dets; in.feat = h->d_feat; in.counts = h->d_cnt; in.stream_stride_dets = 0; in.count_stride = 0;
     const int rc = ss_launch_frame(h, V, 1, in, h->d_rows, 0, h->out_cap, h->d_ocnt, 0, st);

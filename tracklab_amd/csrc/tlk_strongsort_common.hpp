@@ -2,6 +2,7 @@
 // xyah Kalman update / gating in registers, the LDS work area of the association workgroup and min_cost_matching.
 #pragma once
 #include "tlk_common.hpp"
+#include "tlk_pyset.hpp"
 
 namespace {
 using namespace tlk;
@@ -236,6 +237,20 @@ __device__ McmOut min_cost_matching(const double *th, int nt, int nd, double max
     o.n_um_t += nrej; o.n_um_d += nrej;
     __syncthreads();
     return o;
+}
+
+// matching_cascade (sort/linear_assignment.py:126-128 in both StrongSORT plugins): unmatched_tracks = list(set(track_indices) -
+// set(k for k, _ in matches)) in the order CPython iterates the result set (tlk_pyset.hpp). cand[0..nc) = track_indices (ascending
+// track positions), L.rowf[position] = 1 for matched positions, nmatched = len(matches). Writes the list to out, returns its length.
+// ws = 4 * cap ints of scratch (LDS or HBM), cap >= pyset::table_capacity(MAXT). All BLOCK threads call.
+__device__ int cascade_unmatched_tracks(const int *cand, int nc, int nmatched, int *out, int *ws, unsigned cap, BLds &L)
+{
+    const int nu = block_compact(nc, [&](int r) { return L.rowf[cand[r]] == 0; }, [&](int r, int pos) { out[pos] = cand[r]; }, L.scan);
+    __syncthreads();
+    if (threadIdx.x == 0 && nc > 0 && !pyset::ascending_is_exact(nc, cand[nc - 1], nmatched, out, nu))
+        pyset::difference_order_serial(cand, nc, L.rowf, nmatched, out, ws, cap);
+    __syncthreads();
+    return nu;
 }
 
 }  // namespace
