@@ -419,6 +419,11 @@ int tlk_ssort_get_tracks(tlk_ssort *h, int stream, int64_t *ids, double *mean, d
  * (crop image[t:b,l:r] of the rounded ltrb + albumentations Resize/Normalize).
  * ------------------------------------------------------------------------------------------ */
 enum { TLK_NCHW = 0, TLK_NHWC = 1, TLK_FOCUS_NHWC = 2 };   /* FOCUS: YOLOX space-to-depth fused, (B,S/2,S/2,12) */
+/* OR-ed into a `layout` argument: output channel c is SOURCE channel 2 - c (mean3/std3 stay indexed by OUTPUT channel).
+ * TrackLab keeps one RGB frame (cv2_load_image) for the ReID crops while its detector / pose estimator re-read the file
+ * as BGR (rtmlib on cv2.imread, wrappers/bbox_detector/rtmlib_api.py:30, wrappers/pose_estimator/rtmlib_api.py:30):
+ * with this flag the frames stay RGB in HBM and the letterbox / pose crops read them as BGR without a flip pass. */
+enum { TLK_SWAP_RB = 0x100 };
 enum { TLK_F32 = 0, TLK_F16 = 1, TLK_BF16 = 2 };
 
 /* frames_dev (batch, h, w, 3) uint8 -> out_dev (batch, 3, size, size) in `layout`/`dtype`, values 0..255,

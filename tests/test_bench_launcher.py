@@ -1,0 +1,55 @@
+"""CPU: the bench ENTRY POINT's multi-GPU launch path with world size 2 on gloo -- `python bench.py --gpus 2` re-executes itself
+under torch.distributed.run, and the driver's own torchrun command line reaches the same code. `--dry-run` replaces the GPU step with a
+stand-in (ground truth as tracker output): what is under test is the spawn, the 127.0.0.1 rendezvous, stream s -> rank s mod world, the
+barrier / max-time reduction, the all-gather of per-rank rates and the SUM all-reduce of the HOTA statistics, and the JSON contract."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+from conftest import REPO
+
+ARGS = ["--dry-run", "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "config2", "--frames-per-step", "4", "--objects", "8"]
+
+
+def _check(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out                      # exactly ONE JSON line, from rank 0
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak" and j["higher_is_better"] is True
+    assert sorted(r for r, _ in j["ranks_seen"]) == [0, 1] and len(j["per_rank_fps"]) == 2 and all(f > 0 for f in j["per_rank_fps"])
+    assert j["streams_of_rank0"] == [0]                                        # stream s -> rank s mod world, one stream per rank
+    assert j["hota_allreduce"]["frames"] == 2 * 3 * 4                          # both ranks' frames arrived through the all-reduce
+    assert abs(j["hota_allreduce"]["HOTA"] - 1.0) < 1e-12                      # the stand-in tracker is perfect
+    assert j["config"]["parallelism"] == "stream-parallel x2" and j["dry_run"] is True and j["value"] is None
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = REPO
+    return env
+
+
+def test_bench_gpus_flag_spawns_the_ranks_itself():
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + ARGS, capture_output=True, text=True, timeout=300, env=_env(), cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check(r.stdout)
+
+
+def test_bench_under_the_drivers_torchrun_command_line():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py")] + ARGS
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=_env(), cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check(r.stdout)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """Without --dry-run the launcher must not silently run on fewer devices than asked for."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "64", "--steps", "1"], capture_output=True, text=True,
+                       timeout=300, env=_env(), cwd=REPO)
+    assert r.returncode != 0 and "--gpus 64" in (r.stderr + r.stdout)

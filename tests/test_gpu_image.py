@@ -181,3 +181,37 @@ def test_pil_crop_resize_norm_vs_oracle_1080p(orc, oh, ow):
     for i in range(n):
         exp, _ = orc.ssort_reid_preprocess(frame, dets[i, :4], oh, ow)
         np.testing.assert_array_equal(out[i], exp, err_msg=f"crop {i} box {dets[i, :4]}")
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc", "focus_nhwc"])
+def test_swap_rb_reads_the_frame_as_bgr(layout):
+    """TLK_SWAP_RB (output channel c = source channel 2 - c, statistics indexed by OUTPUT channel) == the same kernel on the flipped frame:
+    letterbox, both crop kernels and the pose warp. That is how the fused pipeline keeps ONE RGB frame in HBM for the ReID crops while the
+    detector / pose estimator see BGR like the reference's cv2.imread (rtmlib_api.py:30)."""
+    import torch
+    from tracklab_amd import _lib
+    rng = np.random.default_rng(77)
+    B, H, W, MAXN = 2, 720, 1280, 12
+    frames = _frames(rng, B, H, W)
+    d, dflip = torch.from_numpy(frames).cuda(), torch.from_numpy(np.ascontiguousarray(frames[..., ::-1])).cuda()
+    for dtype in (torch.float32, torch.float16):
+        a, _ = _lib.letterbox(d, 640, layout, dtype, swap_rb=True)
+        b, _ = _lib.letterbox(dflip, 640, layout, dtype)
+        assert torch.equal(a, b)
+    if layout == "focus_nhwc":
+        return
+    boxes = np.zeros((B, MAXN, 4), dtype=np.float32)
+    boxes[..., 0] = rng.uniform(0, W - 200, (B, MAXN)); boxes[..., 1] = rng.uniform(0, H - 300, (B, MAXN))
+    boxes[..., 2] = rng.uniform(20, 180, (B, MAXN)); boxes[..., 3] = rng.uniform(40, 290, (B, MAXN))
+    boxes[0, 0] = [0, 0, 5000, 5000]                                   # direct (unstaged) branch
+    counts = torch.tensor([MAXN, 7], dtype=torch.int32).cuda()
+    db = torch.from_numpy(boxes).cuda()
+    xyxy = torch.from_numpy(np.concatenate([boxes[..., :2], boxes[..., :2] + boxes[..., 2:]], axis=-1).astype(np.float64)).cuda().contiguous()
+    for dtype in (torch.float32, torch.float16):
+        assert torch.equal(_lib.roi_crop_resize_norm(d, db, counts, 384, 128, layout, dtype, swap_rb=True),
+                           _lib.roi_crop_resize_norm(dflip, db, counts, 384, 128, layout, dtype))
+        assert torch.equal(_lib.roi_crop_pil_resize_norm(d, xyxy, counts, 256, 128, layout, dtype, swap_rb=True),
+                           _lib.roi_crop_pil_resize_norm(dflip, xyxy, counts, 256, 128, layout, dtype))
+        pa, ma = _lib.pose_crop_warp_norm(d, xyxy, counts, 192, 256, layout, dtype, swap_rb=True)
+        pb, mb = _lib.pose_crop_warp_norm(dflip, xyxy, counts, 192, 256, layout, dtype)
+        assert torch.equal(pa, pb) and torch.equal(ma, mb)

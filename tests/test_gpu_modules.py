@@ -44,7 +44,7 @@ def test_detector_and_reid_modules_run_and_feed_the_tracker():
     img = render_frame(rng, fr["gt_boxes"])
     meta = pd.DataFrame({"id": [7], "video_id": [3], "frame": [0]})
     s = det.preprocess(img, pd.DataFrame(), meta.iloc[0])
-    assert s["image"].shape == (1080, 1920, 3) and (s["image"][..., 0] == img[..., 2]).all()      # RGB -> BGR
+    assert s["image"].shape == (1080, 1920, 3) and (s["image"] == img).all()      # stays RGB: the letterbox kernel reads it as BGR (TLK_SWAP_RB)
     out = det.process(default_collate([s]), pd.DataFrame(), meta)
     assert isinstance(out, list)          # random-init detector: usually no boxes; contract = list of Series
     # feed known boxes through ReID + tracker

@@ -1,0 +1,79 @@
+"""-m gpu: the backbones' compute precision. The reference runs its networks in fp32 (ONNXRuntime detector / pose, torchreid ReID;
+`fp16: false` in configs/modules/track/strong_sort.yaml:10); bench.py's default is f16 with `--dtype f32` beside it. This file states the
+tolerance that makes f16 admissible and checks it on the same weights:
+
+  * part embeddings (N, K, D): per-part cosine distance between the f16 and the f32 network's output <= EMB_COS_TOL, and the
+    part-based ReID distance matrix the tracker consumes (tlk_partdist_f32) moves by <= DIST_TOL (its gate `max_dist` is 0.5);
+  * visibility flags identical;
+  * the tracks: detection -> track id assignment of the fused pipeline over a 48-frame stream is IDENTICAL under f16 and f32.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EMB_COS_TOL = 2e-3      # measured 1e-5 .. 4e-4 on random-init R50 (printed below); trained networks sit at the low end
+DIST_TOL = 1e-2         # absolute, on distances in [0, 1]; association thresholds: max_dist 0.5, matched pairs are < 0.1 apart
+
+
+def _crops(dtype, n=64):
+    import torch
+    from tracklab_amd import _lib
+    from tracklab_amd.synth import SyntheticStream, render_frame
+    fr = SyntheticStream(5, n, 1).step()
+    frame = render_frame(np.random.default_rng(1), fr["gt_boxes"])
+    d = fr["dets"]
+    boxes = np.zeros((1, 128, 4), np.float32)
+    boxes[0, :len(d)] = np.column_stack([d[:, 0], d[:, 1], d[:, 2] - d[:, 0], d[:, 3] - d[:, 1]])
+    c = _lib.roi_crop_resize_norm(torch.from_numpy(frame[None]).cuda(), torch.from_numpy(boxes).cuda(),
+                                  torch.tensor([len(d)], dtype=torch.int32).cuda(), 384, 128, "nhwc", dtype)
+    return c[:len(d)]
+
+
+def test_f16_embeddings_within_stated_tolerance_of_fp32():
+    import torch
+    from tracklab_amd import _lib
+    from tracklab_amd.backbones.reid import part_based_reid
+    K, D = 6, 256
+    with torch.no_grad():
+        e16, v16 = part_based_reid(K, D, dtype=torch.float16)(_crops(torch.float16))
+        e32, v32 = part_based_reid(K, D, dtype=torch.float32)(_crops(torch.float32))       # same seed -> same weights
+    assert torch.equal(v16, v32), "visibility flags differ between f16 and f32"
+    a, b = torch.nn.functional.normalize(e16.float(), dim=-1), torch.nn.functional.normalize(e32.float(), dim=-1)
+    cos_dist = (1 - (a * b).sum(-1)).abs().max().item()
+    u16, u32 = v16.to(torch.uint8).contiguous(), v32.to(torch.uint8).contiguous()
+    d16 = _lib.partdist(e16.float().contiguous(), u16, e16.float().contiguous(), u16)
+    d32 = _lib.partdist(e32.float().contiguous(), u32, e32.float().contiguous(), u32)
+    dist_err = (d16 - d32).abs().max().item()
+    print(f"f16 vs f32 part embeddings: max cosine distance {cos_dist:.2e}, max |delta part distance| {dist_err:.2e}")
+    assert cos_dist <= EMB_COS_TOL and dist_err <= DIST_TOL
+
+
+def test_track_ids_identical_under_f16_and_f32_backbones():
+    import torch
+    from tracklab_amd import gpu_pipeline as gp
+    from tracklab_amd.synth import SyntheticStream, render_frame, synth_yolox_head
+    F, steps, nobj = 8, 6, 40
+    rng = np.random.default_rng(4)
+    heads, frames = [], []
+    stream = list(SyntheticStream(17, nobj, F * steps, miss_prob=0.05))
+    ratio = min(640 / 1080, 640 / 1920)
+    for fr in stream:
+        heads.append(synth_yolox_head(rng, fr["dets"][:, :4], ratio=ratio))
+        frames.append(render_frame(rng, fr["gt_boxes"]))
+    d_heads = torch.from_numpy(np.stack(heads)).cuda().reshape(steps, F, -1, 6)
+    d_frames = torch.from_numpy(np.stack(frames)).cuda().reshape(steps, F, 1080, 1920, 3)
+    out = {}
+    for dt in (torch.float16, torch.float32):
+        pipe = gp.DetReidTrackPipeline("s", n_streams=1, frames_per_step=F, max_dets=64, dim=64, dtype=dt, use_graph=False)
+        rows_all = []
+        for k in range(steps):
+            h_rows, h_cnt = pipe.step(d_frames[k], d_heads[k])
+            pipe.synchronize()
+            rows, _ = pipe.rows_numpy(h_rows, h_cnt)
+            rows_all += [np.stack([r["det_id"], r["track_id"]], 1) for r in rows[0]]
+        out[dt] = rows_all
+        pipe.close()
+    assert sum(len(r) for r in out[torch.float16]) > 0.9 * nobj * F * steps * 0.95
+    for f, (a, b) in enumerate(zip(out[torch.float16], out[torch.float32])):
+        np.testing.assert_array_equal(a, b, err_msg=f"frame {f}: f16 and f32 backbones give different tracks")

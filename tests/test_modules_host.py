@@ -363,7 +363,7 @@ def test_rtmpose_module_contract_and_preprocess():
     img = np.arange(4 * 6 * 3, dtype=np.uint8).reshape(4, 6, 3)
     df = pd.DataFrame({"bbox_ltwh": [np.array([1.5, 2.0, 3.0, 4.0], np.float32), np.array([0, 0, 2, 2], np.float32)]}, index=[7, 9])
     s = m.preprocess(img, df, pd.Series(dtype=float))
-    assert (s["image"][..., 0] == img[..., 2]).all() and s["count"] == 2           # RGB -> BGR like cv2.imread
+    assert (s["image"] == img).all() and s["count"] == 2           # stays RGB: the warp kernel reads it as BGR (TLK_SWAP_RB), like cv2.imread would give
     np.testing.assert_array_equal(s["boxes"][:2], [[1.5, 2.0, 4.5, 6.0], [0, 0, 2, 2]])
     assert not s["boxes"][2:].any() and s["boxes"].shape == (16, 4)
     empty = pd.DataFrame()

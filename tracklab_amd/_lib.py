@@ -179,9 +179,12 @@ def _bind_image(L):
     L._image_bound = True
 
 
-def letterbox(frames, size=640, layout="nchw", dtype=None, out=None):
+SWAP_RB = 0x100     # include/tlk.h TLK_SWAP_RB: output channel c = source channel 2 - c
+
+
+def letterbox(frames, size=640, layout="nchw", dtype=None, out=None, swap_rb=False):
     """frames: (B,H,W,3) uint8 cuda tensor -> letterboxed tensor (logical NCHW shape; memory per `layout`)
-    and the resize ratio (rtmlib YOLOX.preprocess)."""
+    and the resize ratio (rtmlib YOLOX.preprocess). swap_rb: read the (RGB) frames as BGR, like the reference's detector does."""
     import torch
     L = lib()
     _bind_image(L)
@@ -196,7 +199,7 @@ def letterbox(frames, size=640, layout="nchw", dtype=None, out=None):
         else:
             out = torch.empty((B, size // 2, size // 2, 12), dtype=dtype, device=frames.device)
     ratio = C.c_double(0)
-    check(L.tlk_letterbox_u8(frames.data_ptr(), B, H, W, size, LAYOUT[layout], _dtype_code(dtype), out.data_ptr(),
+    check(L.tlk_letterbox_u8(frames.data_ptr(), B, H, W, size, LAYOUT[layout] | (SWAP_RB if swap_rb else 0), _dtype_code(dtype), out.data_ptr(),
                              C.byref(ratio), current_stream_ptr()))
     if layout != "nchw":
         out = out.permute(0, 3, 1, 2)        # logical NCHW view of channels-last memory
@@ -204,7 +207,7 @@ def letterbox(frames, size=640, layout="nchw", dtype=None, out=None):
 
 
 def roi_crop_resize_norm(frames, boxes_ltwh, counts, out_h, out_w, layout="nchw", dtype=None,
-                         mean=IMAGENET_MEAN, std=IMAGENET_STD, out=None):
+                         mean=IMAGENET_MEAN, std=IMAGENET_STD, out=None, swap_rb=False):
     """frames (B,H,W,3) u8, boxes_ltwh (B,max_n,4) f32, counts (B,) i32 -> (B*max_n, 3, out_h, out_w)."""
     import torch
     L = lib()
@@ -220,7 +223,7 @@ def roi_crop_resize_norm(frames, boxes_ltwh, counts, out_h, out_w, layout="nchw"
     m = (C.c_float * 3)(*mean)
     s = (C.c_float * 3)(*std)
     check(L.tlk_roi_crop_resize_norm(frames.data_ptr(), B, H, W, boxes_ltwh.data_ptr(), counts.data_ptr(), max_n,
-                                     out_h, out_w, m, s, LAYOUT[layout], _dtype_code(dtype), out.data_ptr(),
+                                     out_h, out_w, m, s, LAYOUT[layout] | (SWAP_RB if swap_rb else 0), _dtype_code(dtype), out.data_ptr(),
                                      current_stream_ptr()))
     if layout != "nchw":
         out = out.permute(0, 3, 1, 2)
@@ -228,7 +231,7 @@ def roi_crop_resize_norm(frames, boxes_ltwh, counts, out_h, out_w, layout="nchw"
 
 
 def roi_crop_pil_resize_norm(frames, boxes_xyxy, counts, out_h=256, out_w=128, layout="nchw", dtype=None,
-                             mean=IMAGENET_MEAN, std=IMAGENET_STD, out=None):
+                             mean=IMAGENET_MEAN, std=IMAGENET_STD, out=None, swap_rb=False):
     """Plain StrongSORT's ReID input (int-truncated crop + Pillow bilinear resize + ToTensor + Normalize).
     frames (B,H,W,3) u8, boxes_xyxy (B,max_n,S>=4) f64 whose first four columns are x1,y1,x2,y2 (the tracker's (n,7)
     detection rows can be passed as they are), counts (B,) i32 -> (B*max_n, 3, out_h, out_w)."""
@@ -251,7 +254,7 @@ def roi_crop_pil_resize_norm(frames, boxes_xyxy, counts, out_h=256, out_w=128, l
     m = (C.c_float * 3)(*mean)
     s = (C.c_float * 3)(*std)
     check(L.tlk_roi_crop_pil_resize_norm(frames.data_ptr(), B, H, W, boxes_xyxy.data_ptr(), stride, counts.data_ptr(), max_n,
-                                         out_h, out_w, m, s, LAYOUT[layout], _dtype_code(dtype), out.data_ptr(), current_stream_ptr()))
+                                         out_h, out_w, m, s, LAYOUT[layout] | (SWAP_RB if swap_rb else 0), _dtype_code(dtype), out.data_ptr(), current_stream_ptr()))
     if layout != "nchw":
         out = out.permute(0, 3, 1, 2)
     return out
@@ -271,7 +274,7 @@ def _bind_pose(L):
 
 
 def pose_crop_warp_norm(frames, boxes_xyxy, counts, in_w=192, in_h=256, layout="nchw", dtype=None, mean=RTMPOSE_MEAN,
-                        std=RTMPOSE_STD, out=None, meta=None):
+                        std=RTMPOSE_STD, out=None, meta=None, swap_rb=False):
     """rtmlib RTMPose.preprocess for every box of a batch of frames. frames (B,H,W,3) u8, boxes_xyxy (B,max_n,S>=4) f64,
     counts (B,) i32 -> (crops (B*max_n, 3, in_h, in_w), meta (B*max_n, 10) f64 [centre, scale, inverse matrix])."""
     import torch
@@ -289,7 +292,7 @@ def pose_crop_warp_norm(frames, boxes_xyxy, counts, in_w=192, in_h=256, layout="
         meta = torch.empty((B * max_n, 10), dtype=torch.float64, device=frames.device)
     m, s = (C.c_double * 3)(*mean), (C.c_double * 3)(*std)
     check(L.tlk_pose_crop_warp_norm(frames.data_ptr(), B, H, W, boxes_xyxy.data_ptr(), stride, counts.data_ptr(), max_n, in_w, in_h,
-                                    m, s, LAYOUT[layout], _dtype_code(dtype), out.data_ptr(), meta.data_ptr(), current_stream_ptr()))
+                                    m, s, LAYOUT[layout] | (SWAP_RB if swap_rb else 0), _dtype_code(dtype), out.data_ptr(), meta.data_ptr(), current_stream_ptr()))
     if layout != "nchw":
         out = out.permute(0, 3, 1, 2)
     return out, meta

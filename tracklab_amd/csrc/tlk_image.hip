@@ -76,7 +76,7 @@ enum { LAYOUT_NCHW = 0, LAYOUT_NHWC = 1, LAYOUT_FOCUS_NHWC = 2 };
 // ---------------------------------------------------------------------------------------------
 template <typename T, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK) letterbox_kernel(const unsigned char *__restrict__ frames, int B, int H, int W, int S,
-                                                          int rh, int rw, T *__restrict__ out)
+                                                          int rh, int rw, T *__restrict__ out, int swap_rb)
 {
     constexpr int ROWS = (LAYOUT == LAYOUT_FOCUS_NHWC) ? 2 : 1;
     const int groups_per_row = S / 8;
@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(BLOCK) letterbox_kernel(const unsigned char *_
             if (yin && x < rw) sample3(img, W * 3, H, W, cy, cv_coef(x, W, rw, true), v);
 #pragma unroll
             for (int c = 0; c < 3; ++c) px[r][i][c] = cvt<T>((float)v[c]);
+            if (swap_rb) { const T t0 = px[r][i][0]; px[r][i][0] = px[r][i][2]; px[r][i][2] = t0; }
         }
     }
     if (LAYOUT == LAYOUT_NCHW) {
@@ -161,7 +162,7 @@ template <typename T, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK) crop_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
                                                      const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
                                                      int OH, int OW, float m0, float m1, float m2, float d0, float d1, float d2,
-                                                     T *__restrict__ out)
+                                                     T *__restrict__ out, int swap_rb)
 {
     const int groups_per_row = OW / 8;
     const int per_crop = groups_per_row * OH;
@@ -192,6 +193,10 @@ __global__ void __launch_bounds__(BLOCK) crop_kernel(const unsigned char *__rest
         for (int k = 0; k < 8; ++k)
 #pragma unroll
             for (int c = 0; c < 3; ++c) px[k][c] = cvt<T>(0.f);
+    }
+    if (swap_rb) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const T t0 = px[k][0]; px[k][0] = px[k][2]; px[k][2] = t0; }
     }
     if (LAYOUT == LAYOUT_NCHW) {
 #pragma unroll
@@ -250,7 +255,7 @@ template <typename T, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK) crop_lds_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
                                                          const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
                                                          int OH, int OW, float m0, float m1, float m2, float d0, float d1, float d2,
-                                                         T *__restrict__ out)
+                                                         T *__restrict__ out, int swap_rb)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_rows[CROP_LDS_ROWS * CROP_LDS_ROW_BYTES];
     __shared__ int4 s_xc[256];          // (byte offset of tap 0, w0, w1, tap-1 step) stored k-major: [k * groups + xg] -> lanes read consecutive 16 B
@@ -348,6 +353,10 @@ __global__ void __launch_bounds__(BLOCK) crop_lds_kernel(const unsigned char *__
             for (int k = 0; k < 8; ++k)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) px[k][c] = cvt<T>(0.f);
+        }
+        if (swap_rb) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const T t0 = px[k][0]; px[k][0] = px[k][2]; px[k][2] = t0; }
         }
         if (LAYOUT == LAYOUT_NCHW) {
 #pragma unroll
@@ -455,7 +464,7 @@ template <typename T, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
                                                          const double *__restrict__ boxes, int box_stride, const int *__restrict__ counts,
                                                          int max_n, int OH, int OW, float m0, float m1, float m2, float d0, float d1, float d2,
-                                                         T *__restrict__ out)
+                                                         T *__restrict__ out, int swap_rb)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_rows[PIL_ROWS * PIL_ROW_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char s_h[PIL_ROWS * (PIL_OW_MAX * 3 + 16)];
@@ -581,6 +590,10 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
 #pragma unroll
                 for (int c = 0; c < 3; ++c) px[k][c] = cvt<T>(0.f);
         }
+        if (swap_rb) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const T t0 = px[k][0]; px[k][0] = px[k][2]; px[k][2] = t0; }
+        }
         if (LAYOUT == LAYOUT_NCHW) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -607,7 +620,7 @@ constexpr int LB_BAND = 4;
 
 template <typename T, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK) letterbox_lds_kernel(const unsigned char *__restrict__ frames, int B, int H, int W, int S,
-                                                              int rh, int rw, T *__restrict__ out, int row_bytes_lds, int max_rows, int out_off)
+                                                              int rh, int rw, T *__restrict__ out, int row_bytes_lds, int max_rows, int out_off, int swap_rb)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     __shared__ int s_y0[LB_BAND], s_y1[LB_BAND], s_yw0[LB_BAND], s_yw1[LB_BAND], s_sh0[LB_BAND], s_sh1[LB_BAND];
@@ -720,6 +733,7 @@ __global__ void __launch_bounds__(BLOCK) letterbox_lds_kernel(const unsigned cha
 #pragma unroll
                     for (int c = 0; c < 3; ++c) px[r][k][c] = cvt<T>(114.f);
                 }
+                if (swap_rb) { const T t0 = px[r][k][0]; px[r][k][0] = px[r][k][2]; px[r][k][2] = t0; }
             }
         }
         }
@@ -905,7 +919,7 @@ __global__ void __launch_bounds__(BLOCK) yolox_decode_nms_kernel(const float *__
 }
 
 template <typename T>
-int launch_letterbox(const unsigned char *frames, int B, int H, int W, int S, int rh, int rw, int layout, void *out, hipStream_t st)
+int launch_letterbox(const unsigned char *frames, int B, int H, int W, int S, int rh, int rw, int layout, void *out, hipStream_t st, int swap_rb)
 {
     const int row_bytes = ((W * 3 + STAGE_PAD) + 15) & ~15;
     // staged source rows per band: one per output row plus one more where the vertical tap-1 weight is non-zero (same
@@ -929,39 +943,41 @@ int launch_letterbox(const unsigned char *frames, int B, int H, int W, int S, in
     }
     if (smem <= 64 * 1024 && S % LB_BAND == 0) {          // LDS-staged fast path
         const dim3 grid((unsigned)(B * (S / LB_BAND)));
-        if (layout == LAYOUT_NCHW) hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes, max_rows, out_off);
-        else if (layout == LAYOUT_NHWC) hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes, max_rows, out_off);
-        else hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_FOCUS_NHWC>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes, max_rows, out_off);
+        if (layout == LAYOUT_NCHW) hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes, max_rows, out_off, swap_rb);
+        else if (layout == LAYOUT_NHWC) hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes, max_rows, out_off, swap_rb);
+        else hipLaunchKernelGGL((letterbox_lds_kernel<T, LAYOUT_FOCUS_NHWC>), grid, dim3(BLOCK), smem, st, frames, B, H, W, S, rh, rw, (T *)out, row_bytes, max_rows, out_off, swap_rb);
         return TLK_OK;
     }
     const long long units = (long long)B * (S / 8) * (layout == LAYOUT_FOCUS_NHWC ? S / 2 : S);
     const dim3 grid((unsigned)((units + BLOCK - 1) / BLOCK));
-    if (layout == LAYOUT_NCHW) hipLaunchKernelGGL((letterbox_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), 0, st, frames, B, H, W, S, rh, rw, (T *)out);
-    else if (layout == LAYOUT_NHWC) hipLaunchKernelGGL((letterbox_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, S, rh, rw, (T *)out);
-    else hipLaunchKernelGGL((letterbox_kernel<T, LAYOUT_FOCUS_NHWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, S, rh, rw, (T *)out);
+    if (layout == LAYOUT_NCHW) hipLaunchKernelGGL((letterbox_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), 0, st, frames, B, H, W, S, rh, rw, (T *)out, swap_rb);
+    else if (layout == LAYOUT_NHWC) hipLaunchKernelGGL((letterbox_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, S, rh, rw, (T *)out, swap_rb);
+    else hipLaunchKernelGGL((letterbox_kernel<T, LAYOUT_FOCUS_NHWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, S, rh, rw, (T *)out, swap_rb);
     return TLK_OK;
 }
 
 template <typename T>
 int launch_crop(const unsigned char *frames, int B, int H, int W, const float *boxes, const int *counts, int max_n, int OH, int OW,
-                const float *mean, const float *stdv, int layout, void *out, hipStream_t st)
+                const float *mean, const float *stdv, int layout, void *out, hipStream_t st, int swap_rb)
 {
     const long long units = (long long)B * max_n * OH * (OW / 8);
     const dim3 grid((unsigned)((units + BLOCK - 1) / BLOCK));
-    const float m0 = mean[0] * 255.f, m1 = mean[1] * 255.f, m2 = mean[2] * 255.f;
-    const float d0 = 1.0f / (stdv[0] * 255.f), d1 = 1.0f / (stdv[1] * 255.f), d2 = 1.0f / (stdv[2] * 255.f);
+    // swap_rb: output channel c is source channel 2 - c; the kernels normalise per SOURCE channel and exchange 0 <-> 2 at the store
+    const int sw0 = swap_rb ? 2 : 0, sw2 = swap_rb ? 0 : 2;
+    const float m0 = mean[sw0] * 255.f, m1 = mean[1] * 255.f, m2 = mean[sw2] * 255.f;
+    const float d0 = 1.0f / (stdv[sw0] * 255.f), d1 = 1.0f / (stdv[1] * 255.f), d2 = 1.0f / (stdv[sw2] * 255.f);
     if (OW <= 256) {                                       // LDS-staged fast path: workgroup = (slot, band of rows)
         const dim3 g2((unsigned)((long long)B * max_n * ((OH + CROP_BAND - 1) / CROP_BAND)));
         if (layout == LAYOUT_NCHW)
-            hipLaunchKernelGGL((crop_lds_kernel<T, LAYOUT_NCHW>), g2, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out);
+            hipLaunchKernelGGL((crop_lds_kernel<T, LAYOUT_NCHW>), g2, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb);
         else
-            hipLaunchKernelGGL((crop_lds_kernel<T, LAYOUT_NHWC>), g2, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out);
+            hipLaunchKernelGGL((crop_lds_kernel<T, LAYOUT_NHWC>), g2, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb);
         return TLK_OK;
     }
     if (layout == LAYOUT_NCHW)
-        hipLaunchKernelGGL((crop_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out);
+        hipLaunchKernelGGL((crop_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb);
     else
-        hipLaunchKernelGGL((crop_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out);
+        hipLaunchKernelGGL((crop_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb);
     return TLK_OK;
 }
 
@@ -972,6 +988,8 @@ extern "C" int tlk_letterbox_u8(const uint8_t *frames_dev, int batch, int h, int
 {
     if (batch < 0 || h <= 0 || w <= 0 || size <= 0) return fail(TLK_EINVAL, "tlk_letterbox_u8: bad size");
     if (size % 16 != 0) return fail(TLK_EINVAL, "tlk_letterbox_u8: size must be a multiple of 16");
+    const int swap_rb = (layout & TLK_SWAP_RB) ? 1 : 0;
+    layout &= ~TLK_SWAP_RB;
     if (layout < 0 || layout > 2 || dtype < 0 || dtype > 2) return fail(TLK_EINVAL, "tlk_letterbox_u8: bad layout/dtype");
     const double ratio = std::min((double)size / h, (double)size / w);      // rtmlib YOLOX.preprocess
     if (ratio_out) *ratio_out = ratio;
@@ -979,9 +997,9 @@ extern "C" int tlk_letterbox_u8(const uint8_t *frames_dev, int batch, int h, int
     if (!frames_dev || !out_dev) return fail(TLK_EINVAL, "tlk_letterbox_u8: null pointer");
     const int rw = (int)(w * ratio), rh = (int)(h * ratio);
     hipStream_t st = (hipStream_t)hip_stream;
-    if (dtype == 0) launch_letterbox<float>(frames_dev, batch, h, w, size, rh, rw, layout, out_dev, st);
-    else if (dtype == 1) launch_letterbox<__half>(frames_dev, batch, h, w, size, rh, rw, layout, out_dev, st);
-    else launch_letterbox<bf16_t>(frames_dev, batch, h, w, size, rh, rw, layout, out_dev, st);
+    if (dtype == 0) launch_letterbox<float>(frames_dev, batch, h, w, size, rh, rw, layout, out_dev, st, swap_rb);
+    else if (dtype == 1) launch_letterbox<__half>(frames_dev, batch, h, w, size, rh, rw, layout, out_dev, st, swap_rb);
+    else launch_letterbox<bf16_t>(frames_dev, batch, h, w, size, rh, rw, layout, out_dev, st, swap_rb);
     TLK_HIP(hipGetLastError());
     return TLK_OK;
 }
@@ -992,28 +1010,31 @@ extern "C" int tlk_roi_crop_resize_norm(const uint8_t *frames_dev, int batch, in
 {
     if (batch < 0 || h <= 0 || w <= 0 || max_n < 0 || out_h <= 0 || out_w <= 0) return fail(TLK_EINVAL, "tlk_roi_crop_resize_norm: bad size");
     if (out_w % 8 != 0) return fail(TLK_EINVAL, "tlk_roi_crop_resize_norm: out_w must be a multiple of 8");
+    const int swap_rb = (layout & TLK_SWAP_RB) ? 1 : 0;
+    layout &= ~TLK_SWAP_RB;
     if (layout < 0 || layout > 1 || dtype < 0 || dtype > 2) return fail(TLK_EINVAL, "tlk_roi_crop_resize_norm: bad layout/dtype");
     if (batch == 0 || max_n == 0) return TLK_OK;
     if (!frames_dev || !boxes_ltwh_dev || !counts_dev || !mean3 || !std3 || !out_dev) return fail(TLK_EINVAL, "tlk_roi_crop_resize_norm: null pointer");
     hipStream_t st = (hipStream_t)hip_stream;
-    if (dtype == 0) launch_crop<float>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st);
-    else if (dtype == 1) launch_crop<__half>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st);
-    else launch_crop<bf16_t>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st);
+    if (dtype == 0) launch_crop<float>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st, swap_rb);
+    else if (dtype == 1) launch_crop<__half>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st, swap_rb);
+    else launch_crop<bf16_t>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st, swap_rb);
     TLK_HIP(hipGetLastError());
     return TLK_OK;
 }
 
 template <typename T>
 int launch_pil_crop(const unsigned char *frames, int B, int H, int W, const double *boxes, int box_stride, const int *counts, int max_n,
-                    int OH, int OW, const float *mean, const float *stdv, int layout, void *out, hipStream_t st)
+                    int OH, int OW, const float *mean, const float *stdv, int layout, void *out, hipStream_t st, int swap_rb)
 {
+    const int sw0 = swap_rb ? 2 : 0, sw2 = swap_rb ? 0 : 2;
     const dim3 grid((unsigned)((long long)B * max_n * ((OH + PIL_BAND - 1) / PIL_BAND)));
     if (layout == LAYOUT_NCHW)
         hipLaunchKernelGGL((pil_crop_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, box_stride, counts, max_n, OH, OW,
-                           mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], (T *)out);
+                           mean[sw0], mean[1], mean[sw2], stdv[sw0], stdv[1], stdv[sw2], (T *)out, swap_rb);
     else
         hipLaunchKernelGGL((pil_crop_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, box_stride, counts, max_n, OH, OW,
-                           mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], (T *)out);
+                           mean[sw0], mean[1], mean[sw2], stdv[sw0], stdv[1], stdv[sw2], (T *)out, swap_rb);
     return TLK_OK;
 }
 
@@ -1023,13 +1044,15 @@ extern "C" int tlk_roi_crop_pil_resize_norm(const uint8_t *frames_dev, int batch
 {
     if (batch < 0 || h <= 0 || w <= 0 || max_n < 0 || out_h <= 0 || out_w <= 0 || box_stride < 4) return fail(TLK_EINVAL, "tlk_roi_crop_pil_resize_norm: bad size");
     if (out_w % 8 != 0) return fail(TLK_EINVAL, "tlk_roi_crop_pil_resize_norm: out_w must be a multiple of 8");
+    const int swap_rb = (layout & TLK_SWAP_RB) ? 1 : 0;
+    layout &= ~TLK_SWAP_RB;
     if (layout < 0 || layout > 1 || dtype < 0 || dtype > 2) return fail(TLK_EINVAL, "tlk_roi_crop_pil_resize_norm: bad layout/dtype");
     if (batch == 0 || max_n == 0) return TLK_OK;
     if (!frames_dev || !boxes_xyxy_dev || !counts_dev || !mean3 || !std3 || !out_dev) return fail(TLK_EINVAL, "tlk_roi_crop_pil_resize_norm: null pointer");
     hipStream_t st = (hipStream_t)hip_stream;
-    if (dtype == 0) launch_pil_crop<float>(frames_dev, batch, h, w, boxes_xyxy_dev, box_stride, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st);
-    else if (dtype == 1) launch_pil_crop<__half>(frames_dev, batch, h, w, boxes_xyxy_dev, box_stride, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st);
-    else launch_pil_crop<bf16_t>(frames_dev, batch, h, w, boxes_xyxy_dev, box_stride, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st);
+    if (dtype == 0) launch_pil_crop<float>(frames_dev, batch, h, w, boxes_xyxy_dev, box_stride, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st, swap_rb);
+    else if (dtype == 1) launch_pil_crop<__half>(frames_dev, batch, h, w, boxes_xyxy_dev, box_stride, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st, swap_rb);
+    else launch_pil_crop<bf16_t>(frames_dev, batch, h, w, boxes_xyxy_dev, box_stride, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st, swap_rb);
     TLK_HIP(hipGetLastError());
     return TLK_OK;
 }

@@ -103,7 +103,7 @@ __device__ __forceinline__ int sat_short(int v) { return v < -32768 ? -32768 : (
 template <typename T, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK) pose_warp_kernel(const unsigned char *__restrict__ frames, int B, int H, int W, const int *__restrict__ counts,
                                                           int max_n, int in_w, int in_h, const double *__restrict__ meta,
-                                                          double m0, double m1, double m2, double s0, double s1, double s2, T *__restrict__ out)
+                                                          double m0, double m1, double m2, double s0, double s1, double s2, T *__restrict__ out, int swap_rb)
 {
     __shared__ float s_lut[3][256];
     const int tid = threadIdx.x;
@@ -160,6 +160,10 @@ __global__ void __launch_bounds__(BLOCK) pose_warp_kernel(const unsigned char *_
         for (int k = 0; k < 8; ++k)
 #pragma unroll
             for (int c = 0; c < 3; ++c) px[k][c] = pcvt<T>(0.f);
+    }
+    if (swap_rb) {      // output channel c = source channel 2 - c (the look-up table is already per SOURCE channel)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const T t0 = px[k][0]; px[k][0] = px[k][2]; px[k][2] = t0; }
     }
     if (LAYOUT == LAYOUT_NCHW) {
 #pragma unroll
@@ -240,16 +244,17 @@ __global__ void __launch_bounds__(BLOCK) simcc_conf_kernel(const float *__restri
 
 template <typename T>
 void launch_pose_warp(const unsigned char *frames, int B, int H, int W, const int *counts, int max_n, int in_w, int in_h, const double *meta,
-                      const double *mean, const double *stdv, int layout, void *out, hipStream_t st)
+                      const double *mean, const double *stdv, int layout, void *out, hipStream_t st, int swap_rb)
 {
+    const int sw0 = swap_rb ? 2 : 0, sw2 = swap_rb ? 0 : 2;
     const long long units = (long long)B * max_n * in_h * (in_w / 8);
     const dim3 grid((unsigned)((units + BLOCK - 1) / BLOCK));
     if (layout == LAYOUT_NCHW)
         hipLaunchKernelGGL((pose_warp_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), 0, st, frames, B, H, W, counts, max_n, in_w, in_h, meta,
-                           mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], (T *)out);
+                           mean[sw0], mean[1], mean[sw2], stdv[sw0], stdv[1], stdv[sw2], (T *)out, swap_rb);
     else
         hipLaunchKernelGGL((pose_warp_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, counts, max_n, in_w, in_h, meta,
-                           mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], (T *)out);
+                           mean[sw0], mean[1], mean[sw2], stdv[sw0], stdv[1], stdv[sw2], (T *)out, swap_rb);
 }
 
 }  // namespace
@@ -260,6 +265,8 @@ extern "C" int tlk_pose_crop_warp_norm(const uint8_t *frames_dev, int batch, int
 {
     if (batch < 0 || h <= 0 || w <= 0 || max_n < 0 || in_w <= 0 || in_h <= 0 || box_stride < 4) return fail(TLK_EINVAL, "tlk_pose_crop_warp_norm: bad size");
     if (in_w % 8 != 0) return fail(TLK_EINVAL, "tlk_pose_crop_warp_norm: in_w must be a multiple of 8");
+    const int swap_rb = (layout & TLK_SWAP_RB) ? 1 : 0;
+    layout &= ~TLK_SWAP_RB;
     if (layout < 0 || layout > 1 || dtype < 0 || dtype > 2) return fail(TLK_EINVAL, "tlk_pose_crop_warp_norm: bad layout/dtype");
     if (batch == 0 || max_n == 0) return TLK_OK;
     if (!frames_dev || !boxes_xyxy_dev || !counts_dev || !mean3 || !std3 || !out_dev || !meta_dev) return fail(TLK_EINVAL, "tlk_pose_crop_warp_norm: null pointer");
@@ -267,9 +274,9 @@ extern "C" int tlk_pose_crop_warp_norm(const uint8_t *frames_dev, int batch, int
     const int slots = batch * max_n;
     hipLaunchKernelGGL(pose_prep_kernel, dim3((slots + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, boxes_xyxy_dev, box_stride, (const int *)counts_dev,
                        batch, max_n, in_w, in_h, 1.25, meta_dev);
-    if (dtype == 0) launch_pose_warp<float>(frames_dev, batch, h, w, (const int *)counts_dev, max_n, in_w, in_h, meta_dev, mean3, std3, layout, out_dev, st);
-    else if (dtype == 1) launch_pose_warp<__half>(frames_dev, batch, h, w, (const int *)counts_dev, max_n, in_w, in_h, meta_dev, mean3, std3, layout, out_dev, st);
-    else launch_pose_warp<bf16p_t>(frames_dev, batch, h, w, (const int *)counts_dev, max_n, in_w, in_h, meta_dev, mean3, std3, layout, out_dev, st);
+    if (dtype == 0) launch_pose_warp<float>(frames_dev, batch, h, w, (const int *)counts_dev, max_n, in_w, in_h, meta_dev, mean3, std3, layout, out_dev, st, swap_rb);
+    else if (dtype == 1) launch_pose_warp<__half>(frames_dev, batch, h, w, (const int *)counts_dev, max_n, in_w, in_h, meta_dev, mean3, std3, layout, out_dev, st, swap_rb);
+    else launch_pose_warp<bf16p_t>(frames_dev, batch, h, w, (const int *)counts_dev, max_n, in_w, in_h, meta_dev, mean3, std3, layout, out_dev, st, swap_rb);
     TLK_HIP(hipGetLastError());
     return TLK_OK;
 }

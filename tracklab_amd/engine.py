@@ -1,15 +1,21 @@
-"""Per-video online loop over the fused GPU pipeline with a columnar detection table.
+"""Per-video online loop over the fused GPU pipeline with a columnar, HBM-resident detection table.
 
 The reference's engines walk ``pipeline=[bbox_detector, reid, track]`` module by module and glue the results with
 ``merge_dataframes`` once per module and batch (tracklab/engine/engine.py:18-41, 148-185; the true per-frame loop is
 tracklab/engine/video.py:67-117): every step re-slices and re-merges a growing pandas frame. Here one video is
 
-    decode once -> H2D of ``frames_per_step`` frames (pinned, double-buffered) -> ``pipeline.step`` (letterbox, detector,
-    decode+NMS, [pose,] [crop, ReID,] association: all on the GPU, no host round trip) -> D2H of the small result block
+    frames (decoded once) -> H2D of ``frames_per_step`` frames (pinned, double-buffered, on a copy stream) -> ``pipeline.step``
+    (letterbox, detector, decode+NMS, [pose,] [crop, ReID,] association: all on the GPU) -> device-to-device append of the step's
+    rows to the per-video table in HBM
 
-and the per-video table is columnar numpy that only becomes a ``pd.DataFrame`` once, at the end, with the columns the
-reference's module chain would have produced (``image_id, video_id, category_id, bbox_ltwh, bbox_conf`` from the detector,
-``track_id`` + the tracker's box columns) indexed by detection id.
+with NO host synchronisation inside the loop (``resident`` mode, the default): the table crosses PCIe once, at the end of the
+video, and only then becomes a ``pd.DataFrame`` with the columns the reference's module chain would have produced
+(``image_id, video_id, category_id, bbox_ltwh, bbox_conf`` from the detector, ``track_id`` + the tracker's box columns) indexed by
+detection id. ``online`` mode copies every step's rows to pinned host memory instead and drains step k while step k+1 runs, so
+per-image consumers (``on_image_loop_end`` callbacks: visualisation, live export) see detections one step late at most.
+
+``HipTrackingEngine`` wraps the loop in TrackLab's engine contract (``TrackingEngine.__init__`` / ``track_dataset`` / callback
+hooks, engine/engine.py:76-126) so that ``engine=hip_fused`` drops in next to ``offline`` / ``video``.
 """
 from __future__ import annotations
 
@@ -17,11 +23,11 @@ import numpy as np
 import pandas as pd
 import torch
 
-from . import _lib
+from . import _lib  # noqa: F401  (fails loudly when libtlk is missing: no CPU fallback)
 
 
 class DetectionTable:
-    """Columnar, append-only per-video detection table (amortised O(1) appends of whole frames; no per-row Python objects)."""
+    """Columnar, append-only per-video detection table on the host (amortised O(1) appends of whole steps; no per-row Python objects)."""
 
     def __init__(self, capacity: int = 4096):
         self.n = 0
@@ -44,34 +50,80 @@ class DetectionTable:
             w[:cap] = v
             self.cols[k] = w
 
-    def append_frame(self, image_id, det_ids, ltwh, conf, category):
-        m = len(det_ids)
+    def append_step(self, first_frame, n_frames, id_base, maxd, ltwh, dcnt, trk):
+        """One pipeline step, vectorised. ltwh (F, maxd, 4), dcnt (F,) detector output; detection ids are
+        id_base + frame * maxd + i (what tlk_yolox_decode_nms wrote into the tracker rows); trk = (frame, det_id, track_id, ltwh,
+        conf) flat arrays of the tracker's rows (``pipeline.track_columns``). Returns the slice of new table rows."""
+        dcnt = np.asarray(dcnt[:n_frames], dtype=np.int64)
+        if (dcnt < 0).any():
+            raise RuntimeError("HipVideoEngine: detection capacity exceeded (more boxes than max_dets / NMS candidates)")
+        f, i = np.nonzero(np.arange(maxd)[None, :] < dcnt[:, None])          # row-major: by frame, then by detection
+        m = len(f)
         self._grow(m)
         s = slice(self.n, self.n + m)
-        self.index[s] = det_ids
         c = self.cols
-        c["image_id"][s] = image_id; c["bbox_ltwh"][s] = ltwh; c["bbox_conf"][s] = conf; c["category_id"][s] = category
+        self.index[s] = id_base + f * maxd + i
+        c["image_id"][s] = first_frame + f
+        c["bbox_ltwh"][s] = ltwh[f, i]
+        c["bbox_conf"][s] = 1.0                   # RTMLibDetector: bbox_conf 1.0, category 1 (rtmlib_api.py:36-45)
+        c["category_id"][s] = 1
         c["track_id"][s] = np.nan; c["track_bbox_ltwh"][s] = np.nan; c["track_bbox_conf"][s] = np.nan
+        tf, tdet, tid, tl, tconf = trk
+        keep = tf < n_frames
+        if keep.any():
+            tf, tdet, tid, tl, tconf = tf[keep], tdet[keep], tid[keep], tl[keep], tconf[keep]
+            off = np.concatenate([[0], np.cumsum(dcnt)[:-1]])
+            rel = tdet - id_base
+            rf, ri = rel // maxd, rel % maxd
+            ok = (rel >= 0) & (rf < n_frames) & (ri < dcnt[np.clip(rf, 0, n_frames - 1)])
+            rows = self.n + off[rf[ok]] + ri[ok]
+            c["track_id"][rows] = tid[ok]
+            c["track_bbox_ltwh"][rows] = tl[ok]
+            c["track_bbox_conf"][rows] = tconf[ok]
         self.n += m
-        return s.start
+        return s
 
-    def set_tracks(self, base, det_ids_frame, row_det_ids, track_ids, track_ltwh, track_conf):
-        """Tracker rows of one frame keyed by detection id -> table rows [base, base + len(det_ids_frame)) (ids ascending)."""
-        if len(row_det_ids) == 0 or len(det_ids_frame) == 0:
-            return
-        pos = np.searchsorted(det_ids_frame, row_det_ids)
-        ok = (pos < len(det_ids_frame)) & (det_ids_frame[np.minimum(pos, len(det_ids_frame) - 1)] == row_det_ids)
-        rows = base + pos[ok]
-        self.cols["track_id"][rows] = track_ids[ok]
-        self.cols["track_bbox_ltwh"][rows] = track_ltwh[ok]
-        self.cols["track_bbox_conf"][rows] = track_conf[ok]
+    def to_dataframe(self, video_id=0, rows: slice | None = None) -> pd.DataFrame:
+        c = self.cols
+        s = rows if rows is not None else slice(0, self.n)
+        return pd.DataFrame({"image_id": c["image_id"][s], "video_id": video_id, "category_id": c["category_id"][s],
+                             "bbox_ltwh": list(c["bbox_ltwh"][s]), "bbox_conf": c["bbox_conf"][s], "track_id": c["track_id"][s],
+                             "track_bbox_ltwh": list(c["track_bbox_ltwh"][s]), "track_bbox_conf": c["track_bbox_conf"][s]},
+                            index=pd.Index(self.index[s], name="id"))
 
-    def to_dataframe(self, video_id=0) -> pd.DataFrame:
-        n, c = self.n, self.cols
-        return pd.DataFrame({"image_id": c["image_id"][:n], "video_id": video_id, "category_id": c["category_id"][:n],
-                             "bbox_ltwh": list(c["bbox_ltwh"][:n]), "bbox_conf": c["bbox_conf"][:n], "track_id": c["track_id"][:n],
-                             "track_bbox_ltwh": list(c["track_bbox_ltwh"][:n]), "track_bbox_conf": c["track_bbox_conf"][:n]},
-                            index=pd.Index(self.index[:n], name="id"))
+
+class DeviceStepLog:
+    """The per-video table while it lives in HBM: every step's result tensors appended by device-to-device copies on the
+    association stream (chunks of ``chunk`` steps, no reallocation), fetched with ONE synchronisation at the end of the video."""
+
+    def __init__(self, chunk: int = 64):
+        self.chunk = chunk
+        self.chunks = []            # dict name -> (chunk, ...) device tensor
+        self.meta = []              # (first frame, frames in the step, id_base) per step
+        self.n = 0
+
+    def sink(self, first_frame, n_frames, id_base):
+        k = self.n
+        self.n += 1
+        self.meta.append((first_frame, n_frames, id_base))
+
+        def write(res):
+            ci, si = divmod(k, self.chunk)
+            if ci == len(self.chunks):
+                self.chunks.append({name: torch.empty((self.chunk,) + tuple(t.shape), dtype=t.dtype, device=t.device) for name, t in res.items()})
+            for name, t in res.items():
+                self.chunks[ci][name][si].copy_(t, non_blocking=True)
+        return write
+
+    def fetch(self):
+        """-> list of (first frame, n frames, id_base, dict of numpy arrays) per step; ONE device synchronisation."""
+        host = [{name: t[:min(self.chunk, self.n - ci * self.chunk)].to("cpu", non_blocking=False) for name, t in ch.items()}
+                for ci, ch in enumerate(self.chunks)]
+        out = []
+        for k, (first, n, idb) in enumerate(self.meta):
+            ci, si = divmod(k, self.chunk)
+            out.append((first, n, idb, {name: t[si].numpy() for name, t in host[ci].items()}))
+        return out
 
 
 class HipVideoEngine:
@@ -87,91 +139,222 @@ class HipVideoEngine:
         H, W = pipeline.H, pipeline.W
         self._pinned = [torch.empty((self.F, H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
         self._dev = [torch.empty((self.F, H, W, 3), dtype=torch.uint8, device=pipeline.dev) for _ in range(2)]
+        self._h2d_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._frames_free = [None, None]
         self._copy_stream = torch.cuda.Stream(device=pipeline.dev)
-        self._is_reid = hasattr(pipeline, "reid")
+        self.h2d_bytes = 0
+
+    # ---- frame batching -------------------------------------------------------------------------------------------------
+    def _batches(self, frames):
+        """-> (cpu uint8 tensor (n, H, W, 3) with n <= F, is_pinned) per step. Pinned (n, H, W, 3) tensors pass through untouched
+        (a decoder writing into pinned memory); single frames / numpy arrays are packed into the engine's own pinned staging buffers."""
+        F = self.F
+        k = 0
+        if isinstance(frames, np.ndarray) and frames.ndim == 4:
+            frames = iter(frames)
+        it = iter(frames)
+        pending = None
+        while True:
+            first = pending if pending is not None else next(it, None)
+            pending = None
+            if first is None:
+                return
+            if torch.is_tensor(first) and first.dim() == 4:
+                assert first.shape[0] <= F and first.dtype == torch.uint8
+                yield first, first.is_pinned()
+                continue
+            slot = k % 2
+            self._h2d_done[slot].synchronize()           # the H2D that last read this staging buffer (two steps ago) has finished
+            buf = self._pinned[slot]
+            n = 0
+            fr = first
+            while fr is not None:
+                buf[n].copy_(torch.from_numpy(np.ascontiguousarray(fr)) if not torch.is_tensor(fr) else fr)
+                n += 1
+                if n == F:
+                    break
+                fr = next(it, None)
+                if fr is not None and torch.is_tensor(fr) and fr.dim() == 4:
+                    pending, fr = fr, None
+            k += 1
+            yield buf[:n], True
 
     @torch.no_grad()
-    def video_loop(self, frames, video_id=0, rgb=True, synth_heads=None) -> pd.DataFrame:
-        """frames: (T, H, W, 3) uint8 array or an iterable of (H, W, 3) frames (RGB like cv2_load_image unless rgb=False).
-        synth_heads: optional callable(first_frame, n) -> (n, A, 6) float32 detector-head activations replacing the network's
-        (random-init detectors produce no boxes; the benchmarks and tests feed a head that encodes known boxes)."""
+    def video_loop(self, frames, video_id=0, synth_heads=None, online=False, on_step=None) -> pd.DataFrame:
+        """frames: (T, H, W, 3) uint8 RGB array, an iterable of (H, W, 3) frames, or an iterable of pinned (n <= F, H, W, 3) uint8
+        tensors (uploaded without a staging copy). RGB like TrackLab's cv2_load_image (channel contract: gpu_pipeline docstring).
+        synth_heads: optional callable(first_frame, n) -> (n, A, 6) float32 detector-head activations (numpy, or a cuda tensor of
+        a full step) replacing the network's (random-init detectors produce no boxes; benchmarks and tests feed a head that encodes
+        known boxes). online: drain every step to the host while the next one runs and call on_step(detections_of_the_step: DataFrame)
+        -- the per-image hook of the reference's online engine; otherwise the table stays in HBM until the video ends."""
         pipe, F, maxd = self.pipe, self.F, self.maxd
         pipe.reset()
         table = DetectionTable()
-        it = iter(frames)
-        t0, done, k = 0, False, 0
-        pending = None                      # (first frame index, frames in the step, result handles)
+        log = None if online else DeviceStepLog()
         main = torch.cuda.current_stream(pipe.dev)
-        while not done or pending is not None:
-            step = None
-            if not done:
-                buf = self._pinned[k % 2]
-                n = 0
-                for fr in it:
-                    buf[n].copy_(torch.from_numpy(np.ascontiguousarray(fr)))
-                    n += 1
-                    if n == F:
-                        break
-                if n < F:
-                    done = True
-                if n > 0:
-                    if n < F:
-                        buf[n:].zero_()
-                    dev = self._dev[k % 2]
-                    with torch.cuda.stream(self._copy_stream):       # H2D of step k overlaps the kernels of step k-1
-                        self._copy_stream.wait_stream(main)
-                        dev.copy_(buf, non_blocking=True)
-                        if rgb:
-                            dev.copy_(dev.flip(-1))                   # the reference's detector re-reads the file as BGR
-                    main.wait_stream(self._copy_stream)
-                    head = None
-                    if synth_heads is not None:
-                        h = np.zeros((F,) + synth_heads(t0, 1).shape[1:], np.float32)
-                        h[..., 4] = -1.0                              # padded frames of the last step: no detections
-                        h[:n] = synth_heads(t0, n)
-                        head = torch.from_numpy(h).to(pipe.dev)
-                    h_rows, h_cnt = pipe.step(dev, head)
-                    det = pipe.det if self._is_reid else pipe.last["det"]
-                    h_ltwh = det["ltwh"].to("cpu", non_blocking=True)
-                    h_dcnt = det["counts"].to("cpu", non_blocking=True)
-                    ev = pipe.last["done" if self._is_reid else "trk_done"]
-                    step = (t0, n, h_rows, h_cnt, h_ltwh, h_dcnt, (pipe.frames_done - F) * maxd, ev)
-                    t0 += n
-                    k += 1
+        t0, k, pending = 0, 0, None
+        for src, pinned in self._batches(frames):
+            n = src.shape[0]
+            slot = k % 2
+            dev = self._dev[slot]
+            with torch.cuda.stream(self._copy_stream):       # H2D of step k overlaps the kernels of step k-1
+                if self._frames_free[slot] is not None:
+                    self._copy_stream.wait_event(self._frames_free[slot])      # step k-2 no longer reads this device buffer
+                dev[:n].copy_(src, non_blocking=pinned)
+                self._h2d_done[slot].record(self._copy_stream)
+            self.h2d_bytes += src.numel()
+            main.wait_event(self._h2d_done[slot])
+            head = None
+            if synth_heads is not None:
+                h = synth_heads(t0, n)
+                if torch.is_tensor(h) and h.is_cuda and h.shape[0] == F:
+                    head = h
+                else:
+                    hn = np.zeros((F,) + tuple(h.shape[1:]), np.float32)
+                    hn[..., 4] = -1.0                         # padded frames of the last step: no detections
+                    hn[:n] = h.cpu().numpy() if torch.is_tensor(h) else h
+                    head = torch.from_numpy(hn).to(pipe.dev)
+            elif n < F:
+                dev[n:].zero_()
+            id_base = pipe.frames_done * maxd
+            if online:
+                pipe.step(dev, head, fetch=True)
+                step = (t0, n, id_base, pipe.last)
+            else:
+                pipe.step(dev, head, fetch=False, sink=log.sink(t0, n, id_base))
+                step = None
+            self._frames_free[slot] = pipe.frames_free
+            t0 += n
+            k += 1
             if pending is not None:
-                self._drain(table, pending)
+                self._drain(table, pending, video_id, on_step)
             pending = step
-            if pending is not None and done:
-                self._drain(table, pending)
-                pending = None
+        if pending is not None:
+            self._drain(table, pending, video_id, on_step)
+        if log is not None:
+            for first, n, idb, res in log.fetch():
+                table.append_step(first, n, idb, maxd, res["ltwh"], res["dcnt"], self._trk_columns(res))
         return table.to_dataframe(video_id)
 
-    def _drain(self, table, step):
-        first, n, h_rows, h_cnt, h_ltwh, h_dcnt, id_base, ev = step
-        pipe, maxd = self.pipe, self.maxd
-        ev.synchronize()                      # this step's association + result copies; the next step keeps running
-        ltwh, dcnt = h_ltwh.numpy(), h_dcnt.numpy()
-        if self._is_reid:
-            rows_sf, cnt = pipe.rows_numpy(h_rows, h_cnt)
-        else:
-            rows_arr, cnt = h_rows.numpy(), h_cnt.numpy()
-        for f in range(n):
-            m = int(dcnt[f])
-            if m < 0 or int(cnt[0][f] if self._is_reid else cnt[0, f]) < 0:
-                raise RuntimeError("HipVideoEngine: detection / tracker capacity exceeded")
-            det_ids = id_base + f * maxd + np.arange(m, dtype=np.int64)
-            base = table.append_frame(first + f, det_ids, ltwh[f, :m], 1.0, 1)         # RTMLibDetector: bbox_conf 1.0, category 1
-            if self._is_reid:
-                r = rows_sf[0][f]
-                names = r.dtype.names
-                if "kf_ltwh" in names:               # BPBReID-StrongSORT rows
-                    tl, conf = r["kf_ltwh"], np.ones(len(r))
-                else:                                # plain StrongSORT / BoT-SORT / Deep-OC-SORT rows: ltrb + the tracker's confidence column
-                    b = r["ltrb"]
-                    tl = np.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], axis=1) if len(r) else np.zeros((0, 4))
-                    conf = r["conf"] if "conf" in names else r["score"]
-                table.set_tracks(base, det_ids, r["det_id"].astype(np.int64), r["track_id"].astype(np.float64), tl, conf)
-            else:
-                r = rows_arr[0, f, :int(cnt[0, f])]
-                tl = np.stack([r[:, 0], r[:, 1], r[:, 2] - r[:, 0], r[:, 3] - r[:, 1]], axis=1) if len(r) else np.zeros((0, 4))
-                table.set_tracks(base, det_ids, r[:, 7].astype(np.int64), r[:, 4], tl, r[:, 6])
+    def _trk_columns(self, res):
+        if (np.asarray(res["ocnt"]) < 0).any():
+            raise RuntimeError("HipVideoEngine: tracker capacity exceeded")
+        return self.pipe.track_columns(res["rows"], np.asarray(res["ocnt"], dtype=np.int64))
+
+    def _drain(self, table, step, video_id, on_step):
+        first, n, id_base, buf = step
+        buf[self.pipe.done_key].synchronize()     # this step's association + pinned result copies; the next step keeps running
+        res = self.pipe.host_results(buf)
+        rows = table.append_step(first, n, id_base, self.maxd, res["ltwh"], res["dcnt"], self._trk_columns(res))
+        if on_step is not None:
+            on_step(table.to_dataframe(video_id, rows))
+
+
+class _CallbackList:
+    """``fabric.call(name, **kwargs)`` of the reference's engines (lightning.Fabric is used only as a callback dispatcher,
+    engine/engine.py:92-93): call ``name`` on every callback that defines it."""
+
+    def __init__(self, callbacks):
+        self.callbacks = list(callbacks)
+
+    def call(self, name, *args, **kwargs):
+        for cb in self.callbacks:
+            fn = getattr(cb, name, None)
+            if callable(fn):
+                fn(*args, **kwargs)
+
+
+try:  # pragma: no cover - only where TrackLab (and lightning) are installed
+    from tracklab.engine import TrackingEngine as _EngineBase  # type: ignore
+    HAVE_TRACKLAB_ENGINE = True
+except Exception:
+    _EngineBase = object
+    HAVE_TRACKLAB_ENGINE = False
+
+
+class HipTrackingEngine(_EngineBase):
+    """TrackLab engine whose ``video_loop`` is the fused GPU pipeline (one ``HipVideoEngine`` per video) instead of the
+    module-by-module dataloader walk. Same constructor and hooks as ``TrackingEngine`` (engine/engine.py:76-126):
+    ``on_dataset_track_start/end``, ``on_video_loop_start/end`` around every video, ``on_module_step_start/end`` around every fused
+    step (task = "hip_fused_pipeline"), and -- when a callback defines ``on_image_loop_end`` -- the per-image hooks of the online
+    engine (engine/video.py:93-117), fed from the ``online`` drain. ``modules`` may be empty: the pipeline replaces them.
+
+    image_loader(file_path) -> (H, W, 3) uint8 RGB array (default: Pillow, like cv2_load_image's RGB output)."""
+
+    def __init__(self, modules=None, tracker_state=None, num_workers: int = 0, callbacks=None, pipeline=None, image_loader=None,
+                 synth_heads=None, **_unused):
+        self.module_names = [m.name for m in (modules or [])]
+        self.callbacks = dict(callbacks or {})
+        cbs = list(self.callbacks.values())
+        before = [c for c in cbs if not getattr(c, "after_saved_state", False)]
+        after = [c for c in cbs if getattr(c, "after_saved_state", False)]
+        self.fabric = _CallbackList(before + ([tracker_state] if tracker_state is not None else []) + after)
+        self.callback = lambda name, **kw: self.fabric.call(name, engine=self, **kw)
+        self.num_workers = num_workers
+        self.tracker_state = tracker_state
+        self.img_metadatas = getattr(tracker_state, "image_metadatas", None)
+        self.video_metadatas = getattr(tracker_state, "video_metadatas", None)
+        self.models = {m.name: m for m in (modules or [])}
+        if pipeline is None:
+            raise ValueError("HipTrackingEngine needs a gpu_pipeline.DetTrackPipeline / DetReidTrackPipeline (engine.pipeline in the yaml)")
+        self.pipeline = pipeline
+        self.video_engine = HipVideoEngine(pipeline)
+        self.image_loader = image_loader or self._load_rgb
+        self.synth_heads = synth_heads
+        self._per_image = any(callable(getattr(c, "on_image_loop_end", None)) for c in cbs)
+
+    @staticmethod
+    def _load_rgb(path):
+        from PIL import Image
+        return np.asarray(Image.open(path).convert("RGB"))
+
+    def track_dataset(self):
+        """engine/engine.py:105-126."""
+        self.callback("on_dataset_track_start")
+        for i, (video_idx, video_metadata) in enumerate(self.video_metadatas.iterrows()):
+            ctx = self.tracker_state(video_idx) if callable(self.tracker_state) else _Null(self.tracker_state)
+            with ctx as tracker_state:
+                self.callback("on_video_loop_start", video_metadata=video_metadata, video_idx=video_idx, index=i)
+                detections, image_pred = self.video_loop(tracker_state, video_metadata, video_idx)
+                self.callback("on_video_loop_end", video_metadata=video_metadata, video_idx=video_idx, detections=detections,
+                              image_pred=image_pred)
+        self.callback("on_dataset_track_end")
+
+    def video_loop(self, tracker_state, video_metadata, video_id):
+        imgs = self.img_metadatas[self.img_metadatas.video_id == video_id]
+        image_ids = imgs.index.to_numpy()
+        paths = imgs.file_path.to_list()
+        F = self.video_engine.F
+
+        def frames():
+            for j, p in enumerate(paths):
+                if j % F == 0:
+                    self.callback("on_module_step_start", task="hip_fused_pipeline", batch=(image_ids[j:j + F], None))
+                yield self.image_loader(p)
+
+        def on_step(df):
+            df = df.assign(image_id=image_ids[df.image_id.to_numpy()])
+            self.callback("on_module_step_end", task="hip_fused_pipeline", batch=None, detections=df)
+            for img_id, sub in df.groupby("image_id"):
+                self.callback("on_image_loop_end", image_metadata=imgs.loc[img_id], image=None, image_idx=img_id, detections=sub)
+
+        heads = None
+        if self.synth_heads is not None:
+            heads = lambda t0, n: self.synth_heads(video_id, t0, n)      # noqa: E731
+        det = self.video_engine.video_loop(frames(), video_id=video_id, synth_heads=heads, online=self._per_image,
+                                           on_step=on_step if self._per_image else None)
+        det["image_id"] = image_ids[det.image_id.to_numpy()] if len(det) else det.image_id
+        if not self._per_image:
+            self.callback("on_module_step_end", task="hip_fused_pipeline", batch=None, detections=det)
+        return det, imgs
+
+
+class _Null:
+    def __init__(self, v):
+        self.v = v
+
+    def __enter__(self):
+        return self.v
+
+    def __exit__(self, *a):
+        return False

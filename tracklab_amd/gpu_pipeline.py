@@ -4,6 +4,12 @@ This is the data plane the north star describes: frames sit in HBM, every stage 
 stream (torch's current stream), libtlk kernels do everything except the backbone forwards, and the
 only device->host traffic is the small per-step result block (async, pinned).
 
+Channel contract of ``step(frames)``: frames are RGB, as TrackLab's ``cv2_load_image`` hands them to every module. The reference's
+detector and pose estimator re-read the file with ``cv2.imread`` (BGR; wrappers/bbox_detector/rtmlib_api.py:30,
+wrappers/pose_estimator/rtmlib_api.py:30) while the ReID crops are cut from the RGB image and normalised with RGB ImageNet statistics
+(wrappers/reid/kpreid_api.py:115-144; strong_sort/reid_multibackend.py:184-195). So the letterbox and the pose warp read the frame with
+``TLK_SWAP_RB`` and the ReID crop kernels read it as is -- one copy of the frame in HBM, no flip pass.
+
 ``DetTrackPipeline``  = BASELINE.json configs[1]: YOLOX -> OC-SORT (no ReID).
 A *step* processes ``frames_per_step`` consecutive frames of each of ``n_streams`` streams:
   letterbox (1 launch) -> YOLOX forward (torch/MIOpen) -> decode+NMS (1 launch, emits tracker rows)
@@ -75,6 +81,8 @@ class DetTrackPipeline:
                 "trk_cnt": torch.zeros((n_streams, frames_per_step), dtype=torch.int32, device=dev),
                 "h_out": torch.zeros((n_streams, frames_per_step, self.out_cap, 8), dtype=torch.float64).pin_memory(),
                 "h_cnt": torch.zeros((n_streams, frames_per_step), dtype=torch.int32).pin_memory(),
+                "h_ltwh": torch.zeros((B, max_dets, 4), dtype=torch.float32).pin_memory(),
+                "h_dcnt": torch.zeros((B,), dtype=torch.int32).pin_memory(),
                 "det_ready": torch.cuda.Event(), "trk_done": torch.cuda.Event()})
         self.trk_stream = torch.cuda.Stream(device=dev, priority=int(__import__("os").environ.get("TLK_TRK_PRIO", "0")))   # association overlaps the next step (high priority measured slower: 227 vs 262 frames/s)
         self.use_graph = use_graph
@@ -95,8 +103,11 @@ class DetTrackPipeline:
         torch.cuda.current_stream(self.dev).synchronize()
 
     @torch.no_grad()
-    def step(self, frames: torch.Tensor, synth_head: torch.Tensor | None = None, fetch: bool = True):
-        """frames: (S*F, H, W, 3) uint8 on device, ordered stream-major (s*F + f).
+    def step(self, frames: torch.Tensor, synth_head: torch.Tensor | None = None, fetch: bool = True, sink=None):
+        """frames: (S*F, H, W, 3) uint8 RGB on device, ordered stream-major (s*F + f).
+        sink: optional callable(result_tensors) run on the association stream right after the tracker launch (device-side
+        consumers such as the engine's HBM-resident detection table: device-to-device copies, no host sync).
+        After the call ``self.frames_free`` is an event on the main stream behind the last kernel that reads ``frames``.
         synth_head: optional (S*F, A, 5+C) float32 replacing the (random-init) detector's head activations
         while keeping the full forward in the dependency chain. Returns (rows, counts) pinned host tensors
         (valid after ``synchronize()``) or device tensors if fetch=False.
@@ -114,11 +125,13 @@ class DetTrackPipeline:
         if self.use_graph and not self.record_kernel_events:
             pred = self._forward_graphed(frames)
         else:
-            x, ratio = _lib.letterbox(frames, self.size, self.layout, self.dtype, out=self.lb)
+            x, ratio = _lib.letterbox(frames, self.size, self.layout, self.dtype, out=self.lb, swap_rb=True)
             if self.record_kernel_events:
                 e1.record()
                 self.kernel_events.append((e0, e1))
             pred = self.model(x, focused=(self.layout == "focus_nhwc"))
+        self.frames_free = torch.cuda.Event()
+        self.frames_free.record(main)
         if synth_head is not None:
             pred = torch.add(synth_head, torch.nan_to_num(pred), alpha=0.0)
         _lib.yolox_decode_nms(pred, self.size, float(np.float32(ratio)), self.W, self.H, self.maxd, self.nms_thr,
@@ -130,14 +143,45 @@ class DetTrackPipeline:
             self.trk_stream.wait_event(buf["det_ready"])
             self.bank.update_dev(buf["trk_in"].data_ptr(), buf["det"]["counts"].data_ptr(), F, buf["trk_out"].data_ptr(),
                                  self.out_cap, buf["trk_cnt"].data_ptr(), C.c_void_p(self.trk_stream.cuda_stream))
-            if fetch:
+            if sink is not None:
+                sink(self.result_tensors(buf))
+            if fetch:       # every host-visible result of the step is in pinned memory before `trk_done`
                 buf["h_out"].copy_(buf["trk_out"], non_blocking=True)
                 buf["h_cnt"].copy_(buf["trk_cnt"], non_blocking=True)
+                buf["h_ltwh"].copy_(buf["det"]["ltwh"], non_blocking=True)
+                buf["h_dcnt"].copy_(buf["det"]["counts"], non_blocking=True)
             buf["trk_done"].record(self.trk_stream)
         self.last = buf
         if not fetch:
             return buf["trk_out"], buf["trk_cnt"]
         return buf["h_out"], buf["h_cnt"]
+
+    def result_tensors(self, buf):
+        """Device tensors one step leaves behind, in the shape the engine's detection table stores them (n_streams == 1: B == F)."""
+        return {"rows": buf["trk_out"].view(self.B, self.out_cap, 8), "ocnt": buf["trk_cnt"].view(self.B),
+                "ltwh": buf["det"]["ltwh"], "dcnt": buf["det"]["counts"]}
+
+    def host_results(self, buf):
+        """The pinned host copies of the same four arrays (valid once ``buf["trk_done"]`` has been synchronised)."""
+        return {"rows": buf["h_out"].numpy().reshape(self.B, self.out_cap, 8), "ocnt": buf["h_cnt"].numpy().reshape(self.B),
+                "ltwh": buf["h_ltwh"].numpy(), "dcnt": buf["h_dcnt"].numpy()}
+
+    done_key = "trk_done"
+
+    def track_columns(self, rows, ocnt):
+        """(frames, cap, 8) float64 row blocks + (frames,) counts -> flat (frame index, det_id, track_id, ltwh, conf) of the valid rows."""
+        a = self.rows_array_np(rows)
+        f, i = np.nonzero(np.arange(a.shape[1])[None, :] < ocnt[:, None])
+        r = a[f, i]
+        return f, r[:, 7].astype(np.int64), r[:, 4], np.stack([r[:, 0], r[:, 1], r[:, 2] - r[:, 0], r[:, 3] - r[:, 1]], axis=1).reshape(-1, 4), r[:, 6]
+
+    def rows_array_np(self, a):
+        if self.row_dtype is None:
+            return a
+        r = np.ascontiguousarray(a).view(self.row_dtype).reshape(a.shape[:-1])
+        out = np.empty(a.shape[:-1] + (8,))
+        out[..., :4] = r["ltrb"]; out[..., 4] = r["track_id"]; out[..., 5] = r["cls"]; out[..., 6] = r["score"]; out[..., 7] = r["det_id"]
+        return out
 
     def rows_array(self, h_out):
         """Host result block -> (S, F, cap, 8) float64 rows [x1,y1,x2,y2,track_id,cls,conf,det_id] for either tracker."""
@@ -160,13 +204,13 @@ class DetTrackPipeline:
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):          # eager warm-up on a side stream (MIOpen picks its kernels here)
                 for _ in range(2):
-                    x, _ = _lib.letterbox(frames, self.size, self.layout, self.dtype, out=self.lb)
+                    x, _ = _lib.letterbox(frames, self.size, self.layout, self.dtype, out=self.lb, swap_rb=True)
                     self.model(x, focused=focused)
             torch.cuda.current_stream(self.dev).wait_stream(side)
             torch.cuda.synchronize(self.dev)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                x, _ = _lib.letterbox(frames, self.size, self.layout, self.dtype, out=self.lb)
+                x, _ = _lib.letterbox(frames, self.size, self.layout, self.dtype, out=self.lb, swap_rb=True)
                 out = self.model(x, focused=focused)
             ent = (g, out)
             self.graphs[key] = ent
@@ -261,6 +305,7 @@ class DetReidTrackPipeline:
             self.pose_hw = (256, 192)
             self.pose_crops = torch.empty((B * max_dets, 256, 192, 3), dtype=dtype, device=dev)
             self.pose_meta = torch.zeros((B * max_dets, 10), dtype=torch.float64, device=dev)
+            self.xyxy32 = torch.zeros((B, max_dets, 4), dtype=torch.float32, device=dev)
             self.xyxy64 = torch.zeros((B, max_dets, 4), dtype=torch.float64, device=dev)
             self.pose_out = {"kps_xyc": torch.zeros((B * max_dets, 17, 3), dtype=torch.float64, device=dev),
                              "scores": torch.zeros((B * max_dets, 17), dtype=torch.float32, device=dev),
@@ -282,6 +327,8 @@ class DetReidTrackPipeline:
                 "ocnt": torch.zeros((B,), dtype=torch.int32, device=dev),
                 "h_rows": torch.zeros((B, max_dets, row_bytes), dtype=torch.uint8).pin_memory(),
                 "h_ocnt": torch.zeros((B,), dtype=torch.int32).pin_memory(),
+                "h_ltwh": torch.zeros((B, max_dets, 4), dtype=torch.float64).pin_memory(),
+                "h_dcnt": torch.zeros((B,), dtype=torch.int32).pin_memory(),
                 "ready": torch.cuda.Event(), "done": torch.cuda.Event()})
         self.trk_stream = torch.cuda.Stream(device=dev, priority=int(__import__("os").environ.get("TLK_TRK_PRIO", "0")))
         self.use_graph = use_graph
@@ -320,7 +367,9 @@ class DetReidTrackPipeline:
         return ent[1]
 
     @torch.no_grad()
-    def step(self, frames: torch.Tensor, synth_head: torch.Tensor | None = None, fetch: bool = True):
+    def step(self, frames: torch.Tensor, synth_head: torch.Tensor | None = None, fetch: bool = True, sink=None):
+        """frames (S*F, H, W, 3) uint8 RGB on device (channel contract: module docstring); sink / ``self.frames_free`` as in
+        ``DetTrackPipeline.step``."""
         S, F, maxd = self.S, self.F, self.maxd
         buf = self.bufs[self.step_idx % self.nbuf]
         self.step_idx += 1
@@ -328,7 +377,7 @@ class DetReidTrackPipeline:
         main.wait_event(buf["done"])
 
         def det_fwd():
-            x, _ = _lib.letterbox(frames, self.size, "focus_nhwc", self.dtype, out=self.lb)
+            x, _ = _lib.letterbox(frames, self.size, "focus_nhwc", self.dtype, out=self.lb, swap_rb=True)
             return self.model(x, focused=True)
         pred = self._graphed(self.det_graphs, frames.data_ptr(), det_fwd) if self.use_graph else det_fwd()
         if synth_head is not None:
@@ -349,9 +398,17 @@ class DetReidTrackPipeline:
             self.kernel_events.append((e0, e1))
         if self.pose is not None:
             # pose stage (rtmlib RTMPose(image, bboxes)): affine crops of every box -> network -> SimCC decode, all in HBM
-            self.xyxy64.copy_(self.det["xyxy"])
+            # boxes as RTMPose.process sees them: detections.bbox.ltrb() of the SANITIZED float32 bbox_ltwh the detector stored
+            # (l, t, l + w, t + h in float32, widened), not the decode kernel's unclipped xyxy
+            ltwh32 = self.det["ltwh"]
+            self.xyxy32[..., :2].copy_(ltwh32[..., :2])
+            torch.add(ltwh32[..., :2], ltwh32[..., 2:], out=self.xyxy32[..., 2:])
+            self.xyxy64.copy_(self.xyxy32)
             pcrops, _ = _lib.pose_crop_warp_norm(frames, self.xyxy64, self.det["counts"], 192, 256, "nhwc", self.dtype,
-                                                 out=self.pose_crops, meta=self.pose_meta)
+                                                 out=self.pose_crops, meta=self.pose_meta, swap_rb=True)
+        self.frames_free = torch.cuda.Event()       # the crop kernels were the last readers of `frames`
+        self.frames_free.record(main)
+        if self.pose is not None:
             if self.use_graph:
                 sx, sy = self._graphed(self.__dict__.setdefault("_pg", {}), 0, lambda: self.pose(pcrops))
             else:
@@ -380,12 +437,38 @@ class DetReidTrackPipeline:
                                      self.conf.data_ptr(), buf["counts"].data_ptr(), F, buf["rows"].data_ptr(), maxd,
                                      buf["ocnt"].data_ptr(), C.c_void_p(self.trk_stream.cuda_stream),
                                      kps=buf["kps"].data_ptr() if self.pose is not None else None)
-            if fetch:
+            if sink is not None:
+                sink(self.result_tensors(buf))
+            if fetch:       # every host-visible result of the step is in pinned memory before `done`
                 buf["h_rows"].copy_(buf["rows"], non_blocking=True)
                 buf["h_ocnt"].copy_(buf["ocnt"], non_blocking=True)
+                buf["h_ltwh"].copy_(buf["ltwh"], non_blocking=True)
+                buf["h_dcnt"].copy_(buf["counts"], non_blocking=True)
             buf["done"].record(self.trk_stream)
         self.last = buf
         return (buf["h_rows"], buf["h_ocnt"]) if fetch else (buf["rows"], buf["ocnt"])
+
+    def result_tensors(self, buf):
+        return {"rows": buf["rows"], "ocnt": buf["ocnt"], "ltwh": buf["ltwh"], "dcnt": buf["counts"]}
+
+    def host_results(self, buf):
+        return {"rows": buf["h_rows"].numpy(), "ocnt": buf["h_ocnt"].numpy(), "ltwh": buf["h_ltwh"].numpy(), "dcnt": buf["h_dcnt"].numpy()}
+
+    done_key = "done"
+
+    def track_columns(self, rows, ocnt):
+        """(frames, maxd, row bytes) uint8 row blocks + (frames,) counts -> flat (frame index, det_id, track_id, ltwh, conf) of the valid rows."""
+        r = np.ascontiguousarray(rows).view(self.row_dtype).reshape(rows.shape[0], rows.shape[1])
+        f, i = np.nonzero(np.arange(r.shape[1])[None, :] < ocnt[:, None])
+        r = r[f, i]
+        names = r.dtype.names
+        if "kf_ltwh" in names:                   # BPBReID-StrongSORT rows
+            tl, conf = r["kf_ltwh"].reshape(-1, 4), np.ones(len(r))
+        else:                                    # plain StrongSORT / BoT-SORT / Deep-OC-SORT rows: ltrb + the tracker's confidence column
+            b = r["ltrb"].reshape(-1, 4)
+            tl = np.stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]], axis=1).reshape(-1, 4)
+            conf = r["conf"] if "conf" in names else r["score"]
+        return f, r["det_id"].astype(np.int64), r["track_id"].astype(np.float64), tl, np.asarray(conf, dtype=np.float64)
 
     def rows_numpy(self, h_rows, h_ocnt):
         """(S, F) nested lists of structured row arrays from the pinned result block."""

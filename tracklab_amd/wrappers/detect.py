@@ -38,8 +38,9 @@ class HipYOLOX(ImageLevelModule):
                 self._model.load_state_dict(torch.load(self.checkpoint, map_location=self.device))
 
     def preprocess(self, image, detections: pd.DataFrame, metadata: pd.Series):
-        # TrackLab hands RGB (cv2_load_image); the reference detector re-reads the file as BGR (rtmlib_api.py:28)
-        return {"image": np.ascontiguousarray(np.asarray(image)[..., ::-1])}
+        # TrackLab hands RGB (cv2_load_image); the reference detector re-reads the file as BGR (rtmlib_api.py:28): the frame stays RGB
+        # here and the letterbox kernel reads it as BGR (TLK_SWAP_RB) -- no flip pass on the host
+        return {"image": np.ascontiguousarray(np.asarray(image))}
 
     def process(self, batch, detections: pd.DataFrame, metadatas: pd.DataFrame):
         from .. import _lib
@@ -50,7 +51,7 @@ class HipYOLOX(ImageLevelModule):
         frames = frames.to(self.device, non_blocking=True).contiguous()
         B, H, W, _ = frames.shape
         with torch.no_grad():
-            x, ratio = _lib.letterbox(frames, self.size, "focus_nhwc", torch.float16)
+            x, ratio = _lib.letterbox(frames, self.size, "focus_nhwc", torch.float16, swap_rb=True)
             pred = self._model(x, focused=True)
             out = _lib.yolox_decode_nms(pred, self.size, float(np.float32(ratio)), W, H, self.max_dets, self.nms_thr, self.score_thr)
         counts = to_numpy(out["counts"])

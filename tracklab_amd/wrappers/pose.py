@@ -43,8 +43,9 @@ class HipRTMPose(ImageLevelModule):
         if n:
             ltwh = np.stack(detections.bbox_ltwh.to_list())                          # detections.bbox.ltrb(): l, t, l + w, t + h
             boxes[:n] = np.stack([ltwh[:, 0], ltwh[:, 1], ltwh[:, 0] + ltwh[:, 2], ltwh[:, 1] + ltwh[:, 3]], axis=1)
-        # TrackLab hands RGB; the reference re-reads the file with cv2.imread: BGR (rtmlib_api.py:28)
-        return {"image": np.ascontiguousarray(np.asarray(image)[..., ::-1]), "boxes": boxes, "count": np.int32(n)}
+        # TrackLab hands RGB; the reference re-reads the file with cv2.imread: BGR (rtmlib_api.py:28) -> the warp kernel reads the RGB
+        # frame as BGR (TLK_SWAP_RB), no flip pass on the host
+        return {"image": np.ascontiguousarray(np.asarray(image)), "boxes": boxes, "count": np.int32(n)}
 
     def process(self, batch, detections: pd.DataFrame, metadatas: pd.DataFrame):
         if len(detections) == 0:
@@ -60,7 +61,7 @@ class HipRTMPose(ImageLevelModule):
             frames, boxes = frames[None], boxes[None]
         n = len(detections)
         with torch.no_grad():
-            crops, meta = _lib.pose_crop_warp_norm(frames, boxes, counts, self.in_w, self.in_h, "nhwc", torch.float16)
+            crops, meta = _lib.pose_crop_warp_norm(frames, boxes, counts, self.in_w, self.in_h, "nhwc", torch.float16, swap_rb=True)
             sx, sy = self._model(crops[:n])
             out = _lib.simcc_decode(sx, sy, meta[:n], self.in_w, self.in_h, 2.0)
         detections = detections.copy()
