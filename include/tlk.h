@@ -336,7 +336,9 @@ typedef struct tlk_botsort_params {
     double track_high_thresh, new_track_thresh, match_thresh, proximity_thresh, appearance_thresh, frame_rate, lambda_;
     double min_confidence;              /* -inf disables */
     int32_t track_buffer;
-    int32_t cmc_method;                 /* 0 = "none" */
+    int32_t cmc_method;                 /* gmc.py:18-78: 0 none, 1 orb, 2 sift, 3 ecc, 4 sparseOptFlow, 5 file. The bank APPLIES a warp
+                                         * (STrack.multi_gmc); it does not estimate one: with a method other than 0 every update must
+                                         * come through the *_gmc entry points with the frame's (2,3) warp (tlk_cmc_* estimate it) */
     int32_t wrapper_mode;               /* 1: a frame without detections leaves the tracker untouched (bot_sort_api.py:59-60) */
     int32_t dim;                        /* ReID embedding length */
     int32_t max_tracks, max_dets;       /* capacities per stream (0 = 256 / 128) */
@@ -356,6 +358,15 @@ int tlk_botsort_update(tlk_botsort *h, int stream, const double *dets, const flo
  * -> rows_dev (S, n_frames, out_cap), out_counts_dev (S, n_frames) */
 int tlk_botsort_update_dev(tlk_botsort *h, const double *dets_dev, const float *feats_dev, const int32_t *counts_dev, int n_frames,
                            tlk_botsort_row *rows_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream);
+/* The same with camera-motion compensation: warp6 / warps_dev = what GMC.apply returned for the frame, a (2,3) float64 matrix
+ * [[a, b, tx], [c, d, ty]] (plugins/track/bot_sort/bot_sort.py:341-343), applied to the predicted pool tracks and to the unconfirmed
+ * tracks between multi_predict and the association (STrack.multi_gmc, bot_sort.py:93-109). NULL = identity (cmc_method "none").
+ * warps_dev: (S, n_frames, 6). */
+int tlk_botsort_update_gmc(tlk_botsort *h, int stream, const double *dets, const float *feats, int n, const double *warp6,
+                           tlk_botsort_row *rows, int cap, int *n_out);
+int tlk_botsort_update_dev_gmc(tlk_botsort *h, const double *dets_dev, const float *feats_dev, const int32_t *counts_dev,
+                               const double *warps_dev, int n_frames, tlk_botsort_row *rows_dev, int out_cap, int32_t *out_counts_dev,
+                               void *hip_stream);
 /* debug/test: as tlk_bytetrack_get_tracks plus smooth_feat (., dim) f32; state: 1 tracked, 2 lost, 4 removed */
 int tlk_botsort_get_tracks(tlk_botsort *h, int stream, int which, int64_t *ids, double *mean, double *cov, int64_t *state5,
                            float *smooth_feat, int cap, int *n_tracks);

@@ -627,13 +627,17 @@ def _bind_botsort(L):
     L.tlk_botsort_reset.argtypes = [vp, ci]
     L.tlk_botsort_update.argtypes = [vp, ci, vp, vp, ci, vp, ci, C.POINTER(ci)]
     L.tlk_botsort_update_dev.argtypes = [vp, vp, vp, vp, ci, vp, ci, vp, vp]
+    L.tlk_botsort_update_gmc.argtypes = [vp, ci, vp, vp, ci, vp, vp, ci, C.POINTER(ci)]
+    L.tlk_botsort_update_dev_gmc.argtypes = [vp, vp, vp, vp, vp, ci, vp, ci, vp, vp]
     L.tlk_botsort_get_tracks.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, C.POINTER(ci)]
     L._bo_bound = True
 
 
 class BoTSORTBank:
     """``n_streams`` device-resident BoT-SORT trackers (``tlk_botsort_*``); hyper-parameter names follow ``BoTSORT.__init__``
-    (plugins/track/bot_sort/bot_sort.py:236-249). Only ``cmc_method="none"`` runs; the cv2 estimators raise TlkError(UNSUPPORTED)."""
+    (plugins/track/bot_sort/bot_sort.py:236-249). With a ``cmc_method`` other than "none" every update takes the frame's (2,3) warp
+    (``update(..., warp=H)`` / ``update_dev(..., warps=ptr)``): the bank applies it on the device (STrack.multi_gmc), the estimate comes
+    from ``tracklab_amd.cmc`` (tlk_cmc_*) or any other source."""
 
     def __init__(self, dim, track_high_thresh=0.45, new_track_thresh=0.6, track_buffer=30, match_thresh=0.8, proximity_thresh=0.5,
                  appearance_thresh=0.25, cmc_method="none", frame_rate=30, lambda_=0.985, *, min_confidence=-np.inf, wrapper_mode=False,
@@ -665,16 +669,19 @@ class BoTSORTBank:
     def reset(self, stream=-1):
         check(lib().tlk_botsort_reset(self._h, stream))
 
-    def update(self, dets, feats, stream=0):
+    def update(self, dets, feats, stream=0, warp=None):
+        """warp: the frame's (2,3) camera-motion matrix (GMC.apply's return value, bot_sort.py:341) or None for the identity."""
         dets = _f64(dets).reshape(-1, 7)
         feats = np.ascontiguousarray(feats, dtype=np.float32).reshape(len(dets), self.dim)
         n = C.c_int(0)
-        check(lib().tlk_botsort_update(self._h, stream, dets.ctypes.data, feats.ctypes.data, len(dets), self._rows.ctypes.data, len(self._rows),
-                                       C.byref(n)))
+        w = None if warp is None else _f64(warp).reshape(6)
+        check(lib().tlk_botsort_update_gmc(self._h, stream, dets.ctypes.data, feats.ctypes.data, len(dets), None if w is None else w.ctypes.data,
+                                           self._rows.ctypes.data, len(self._rows), C.byref(n)))
         return self._rows[:n.value].copy()
 
-    def update_dev(self, dets, feats, counts, n_frames, rows, out_cap, out_counts, stream_ptr=None):
-        check(lib().tlk_botsort_update_dev(self._h, dets, feats, counts, n_frames, rows, out_cap, out_counts, stream_ptr))
+    def update_dev(self, dets, feats, counts, n_frames, rows, out_cap, out_counts, stream_ptr=None, warps=None):
+        """warps: device pointer to (S, n_frames, 6) float64 warps, or None (identity)."""
+        check(lib().tlk_botsort_update_dev_gmc(self._h, dets, feats, counts, warps, n_frames, rows, out_cap, out_counts, stream_ptr))
 
     def tracks(self, which=0, stream=0):
         cap = self.max_tracks

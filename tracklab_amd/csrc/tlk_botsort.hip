@@ -42,7 +42,31 @@ struct BoDev {
     int S, MAXT, MAXD, NX, D, cost_lds_entries;
 };
 struct BoP { double track_high, new_track, match_thresh, proximity, appearance, lambda_, min_conf; int max_time_lost, wrapper_mode; };
-struct BoIn { const double *dets; const float *feats; const int *counts; size_t stream_stride_dets, count_stride; };
+struct BoIn { const double *dets; const float *feats; const int *counts; size_t stream_stride_dets, count_stride;
+              const double *warps; size_t warp_stride; };      // warps: per stream a (2,3) float64 camera-motion warp of this frame, nullptr = identity
+
+// STrack.multi_gmc with a (2,3) warp H (bot_sort.py:93-109): mean = kron(I4, R) mean, mean[:2] += t, cov = kron(I4, R) cov kron(I4, R)^T
+__device__ __forceinline__ void bo_gmc_apply(double (&mean)[8], double (&cov)[64], const double *H)
+{
+    const double R[4] = {H[0], H[1], H[3], H[4]};
+    double m[8], t1[64];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        m[2 * b] = R[0] * mean[2 * b] + R[1] * mean[2 * b + 1];
+        m[2 * b + 1] = R[2] * mean[2 * b] + R[3] * mean[2 * b + 1];
+    }
+    m[0] += H[2]; m[1] += H[5];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)                 // t1 = R8 cov: row i mixes rows 2*(i/2), 2*(i/2)+1
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int r0 = i & ~1; t1[i * 8 + j] = R[(i & 1) * 2] * cov[r0 * 8 + j] + R[(i & 1) * 2 + 1] * cov[(r0 + 1) * 8 + j]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)                 // cov = t1 R8^T: column j mixes columns 2*(j/2), 2*(j/2)+1
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int c0 = j & ~1; cov[i * 8 + j] = t1[i * 8 + c0] * R[(j & 1) * 2] + t1[i * 8 + c0 + 1] * R[(j & 1) * 2 + 1]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mean[k] = m[k];
+}
 
 __device__ __forceinline__ float wave_sum(float v)
 {
@@ -233,8 +257,10 @@ botsort_kernel(BoDev Dv, BoP P, BoIn in, tlk_botsort_row *__restrict__ rows_all,
     const int n_pool = n_act0 + n_lost;
     for (int p = tid; p < MAXT; p += BLOCK) L.alive[p] = 0;
     __syncthreads();
-    // multi_predict (:79-91), then multi_gmc with the identity (:93-109): pool and unconfirmed become float64, and each pool
-    // track's gate (project(): mean, Cholesky of the projected covariance) is prepared for fuse_motion
+    // multi_predict (:79-91), then multi_gmc with this frame's camera-motion warp (:93-109; bot_sort.py:341-343): pool and
+    // unconfirmed become float64, and each pool track's gate (project(): mean, Cholesky of the projected covariance) is prepared
+    // for fuse_motion from the WARPED state
+    const double *warp = in.warps ? in.warps + (size_t)s * in.warp_stride : nullptr;
     {
         int f32all = 1;
         for (int p = tid; p < n_pool; p += BLOCK) f32all &= trk_at(L.pool[p]).i(OI_F32) != 0;
@@ -248,6 +274,7 @@ botsort_kernel(BoDev Dv, BoP P, BoIn in, tlk_botsort_row *__restrict__ rows_all,
             for (int k = 0; k < 64; ++k) cov[k] = Kt.d(OD_COV + k);
             if (Kt.i(OI_STATE) != OT_TRACKED) { mean[6] = 0; mean[7] = 0; }
             kfo_predict(mean, cov, all_f32 != 0);
+            if (warp) bo_gmc_apply(mean, cov, warp);
 #pragma unroll
             for (int k = 0; k < 8; ++k) Kt.d(OD_MEAN + k) = mean[k];
 #pragma unroll
@@ -267,7 +294,22 @@ botsort_kernel(BoDev Dv, BoP P, BoIn in, tlk_botsort_row *__restrict__ rows_all,
 #pragma unroll
             for (int i = 0; i < 16; ++i) g[4 + i] = Lc[i];
         }
-        for (int p = tid; p < n_unconf; p += BLOCK) trk_at(L.unconf[p]).i(OI_F32) = 0;
+        for (int p = tid; p < n_unconf; p += BLOCK) {
+            const BTrk Kt = trk_at(L.unconf[p]);
+            Kt.i(OI_F32) = 0;
+            if (warp) {
+                double mean[8], cov[64];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) mean[k] = Kt.d(OD_MEAN + k);
+#pragma unroll
+                for (int k = 0; k < 64; ++k) cov[k] = Kt.d(OD_COV + k);
+                bo_gmc_apply(mean, cov, warp);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) Kt.d(OD_MEAN + k) = mean[k];
+#pragma unroll
+                for (int k = 0; k < 64; ++k) Kt.d(OD_COV + k) = cov[k];
+            }
+        }
     }
     __threadfence_block();
     __syncthreads();
@@ -506,8 +548,8 @@ __global__ void botsort_gather_kernel(BoDev D, int stream, int which, long long 
 
 struct tlk_botsort {
     BoDev D; BoP P; int device; size_t smem;
-    double *d_dets; float *d_feats; int *d_cnt, *d_ocnt; tlk_botsort_row *d_rows;
-    int out_cap;
+    double *d_dets; float *d_feats; int *d_cnt, *d_ocnt; tlk_botsort_row *d_rows; double *d_warp;
+    int out_cap, cmc_method;
 };
 
 static void bo_free(tlk_botsort *h)
@@ -515,7 +557,7 @@ static void bo_free(tlk_botsort *h)
     if (!h) return;
     hipSetDevice(h->device);
     void *ptrs[] = {h->D.fd, h->D.fi, h->D.hdr, h->D.tracked, h->D.lost, h->D.freestk, h->D.feat, h->D.dfeat, h->D.dist, h->D.gl, h->D.ebuf,
-                    h->d_dets, h->d_feats, h->d_cnt, h->d_ocnt, h->d_rows};
+                    h->d_dets, h->d_feats, h->d_cnt, h->d_ocnt, h->d_rows, h->d_warp};
     for (void *p : ptrs) if (p) hipFree(p);
     delete h;
 }
@@ -535,7 +577,7 @@ extern "C" int tlk_botsort_create(const tlk_botsort_params *p, int n_streams, in
     if (!p || !out) return fail(TLK_EINVAL, "tlk_botsort_create: null pointer");
     if (n_streams < 1) return fail(TLK_EINVAL, "tlk_botsort_create: n_streams must be >= 1");
     if (p->dim < 4 || p->dim > 4096 || p->dim % 4) return fail(TLK_EINVAL, "tlk_botsort_create: dim must be a multiple of 4 in [4, 4096]");
-    if (p->cmc_method != 0) return fail(TLK_EUNSUPPORTED, "tlk_botsort_create: only cmc_method \"none\" (0) is implemented; the camera-motion estimators are cv2");
+    if (p->cmc_method < 0 || p->cmc_method > 5) return fail(TLK_EINVAL, "tlk_botsort_create: cmc_method out of range (gmc.py:18-78: 0 none, 1 orb, 2 sift, 3 ecc, 4 sparseOptFlow, 5 file)");
     const int MAXT = p->max_tracks > 0 ? p->max_tracks : 256, MAXD = p->max_dets > 0 ? p->max_dets : 128;
     if (MAXT + MAXD > 512) return fail(TLK_ECAPACITY, "tlk_botsort_create: max_tracks + max_dets <= 512");
     int ndev = 0;
@@ -545,6 +587,7 @@ extern "C" int tlk_botsort_create(const tlk_botsort_params *p, int n_streams, in
     tlk_botsort *h = new tlk_botsort();
     memset(h, 0, sizeof(*h));
     h->device = device;
+    h->cmc_method = p->cmc_method;
     h->P = BoP{p->track_high_thresh, p->new_track_thresh, p->match_thresh, p->proximity_thresh, p->appearance_thresh, p->lambda_, p->min_confidence,
                (int)(p->frame_rate / 30.0 * p->track_buffer), p->wrapper_mode};
     BoDev &D = h->D;
@@ -572,6 +615,7 @@ extern "C" int tlk_botsort_create(const tlk_botsort_params *p, int n_streams, in
     BO_ALLOC(h->d_feats, sizeof(float) * (size_t)MAXD * D.D);
     BO_ALLOC(h->d_cnt, sizeof(int));
     BO_ALLOC(h->d_ocnt, sizeof(int));
+    BO_ALLOC(h->d_warp, sizeof(double) * 6);
     BO_ALLOC(h->d_rows, sizeof(tlk_botsort_row) * h->out_cap);
 #undef BO_ALLOC
     hipError_t e = hipMemset(D.fd, 0, sizeof(double) * OD_COUNT * slots);
@@ -599,19 +643,22 @@ extern "C" int tlk_botsort_reset(tlk_botsort *h, int stream)
     return TLK_OK;
 }
 
-extern "C" int tlk_botsort_update_dev(tlk_botsort *h, const double *dets_dev, const float *feats_dev, const int32_t *counts_dev, int n_frames,
-                                      tlk_botsort_row *rows_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream)
+extern "C" int tlk_botsort_update_dev_gmc(tlk_botsort *h, const double *dets_dev, const float *feats_dev, const int32_t *counts_dev, const double *warps_dev,
+                                          int n_frames, tlk_botsort_row *rows_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream)
 {
     if (!h) return fail(TLK_EINVAL, "tlk_botsort_update_dev: null handle");
     if (n_frames < 0 || out_cap < 0) return fail(TLK_EINVAL, "tlk_botsort_update_dev: negative size");
     if (n_frames == 0) return TLK_OK;
     if (!dets_dev || !feats_dev || !counts_dev || !rows_dev || !out_counts_dev) return fail(TLK_EINVAL, "tlk_botsort_update_dev: null pointer");
+    if (h->cmc_method != 0 && !warps_dev)
+        return fail(TLK_EINVAL, "tlk_botsort_update_dev: this tracker was created with a camera-motion method: pass the frames' warps (tlk_botsort_update_dev_gmc)");
     TLK_HIP(hipSetDevice(h->device));
     const BoDev &D = h->D;
     for (int f = 0; f < n_frames; ++f) {
         BoIn in;
         in.dets = dets_dev + (size_t)f * D.MAXD * 7; in.feats = feats_dev + (size_t)f * D.MAXD * D.D; in.counts = (const int *)counts_dev + f;
         in.stream_stride_dets = (size_t)n_frames * D.MAXD; in.count_stride = (size_t)n_frames;
+        in.warps = warps_dev ? warps_dev + (size_t)f * 6 : nullptr; in.warp_stride = (size_t)n_frames * 6;
         const int rc = bo_launch_frame(h, D, D.S, in, rows_dev + (size_t)f * out_cap, (size_t)n_frames * out_cap, out_cap, (int *)out_counts_dev + f,
                                        (size_t)n_frames, (hipStream_t)hip_stream);
         if (rc != TLK_OK) return rc;
@@ -619,12 +666,21 @@ extern "C" int tlk_botsort_update_dev(tlk_botsort *h, const double *dets_dev, co
     return TLK_OK;
 }
 
-extern "C" int tlk_botsort_update(tlk_botsort *h, int stream, const double *dets, const float *feats, int n, tlk_botsort_row *rows, int cap, int *n_out)
+extern "C" int tlk_botsort_update_dev(tlk_botsort *h, const double *dets_dev, const float *feats_dev, const int32_t *counts_dev, int n_frames,
+                                      tlk_botsort_row *rows_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream)
+{
+    return tlk_botsort_update_dev_gmc(h, dets_dev, feats_dev, counts_dev, nullptr, n_frames, rows_dev, out_cap, out_counts_dev, hip_stream);
+}
+
+extern "C" int tlk_botsort_update_gmc(tlk_botsort *h, int stream, const double *dets, const float *feats, int n, const double *warp6,
+                                      tlk_botsort_row *rows, int cap, int *n_out)
 {
     if (!h || !n_out) return fail(TLK_EINVAL, "tlk_botsort_update: null pointer");
     if (stream < 0 || stream >= h->D.S) return fail(TLK_EINVAL, "tlk_botsort_update: stream out of range");
     if (n < 0 || (n > 0 && (!dets || !feats))) return fail(TLK_EINVAL, "tlk_botsort_update: bad detections");
     if (n > h->D.MAXD) return fail(TLK_ECAPACITY, "tlk_botsort_update: more detections than max_dets");
+    if (h->cmc_method != 0 && !warp6)
+        return fail(TLK_EINVAL, "tlk_botsort_update: this tracker was created with a camera-motion method: pass the frame's warp (tlk_botsort_update_gmc)");
     TLK_HIP(hipSetDevice(h->device));
     hipStream_t st = 0;
     if (n) {
@@ -632,12 +688,14 @@ extern "C" int tlk_botsort_update(tlk_botsort *h, int stream, const double *dets
         TLK_HIP(hipMemcpyAsync(h->d_feats, feats, sizeof(float) * (size_t)n * h->D.D, hipMemcpyHostToDevice, st));
     }
     TLK_HIP(hipMemcpyAsync(h->d_cnt, &n, sizeof(int), hipMemcpyHostToDevice, st));
+    if (warp6) TLK_HIP(hipMemcpyAsync(h->d_warp, warp6, sizeof(double) * 6, hipMemcpyHostToDevice, st));
     BoDev V = h->D;
     const size_t sl = (size_t)stream * V.MAXT;
     V.fd += sl; V.fi += sl; V.hdr += (size_t)stream * OH_COUNT; V.tracked += sl; V.lost += sl; V.freestk += sl;
     V.feat += sl * V.D; V.dfeat += (size_t)stream * V.MAXD * V.D; V.dist += sl * V.MAXD; V.gl += sl * GLD; V.ebuf += sl * V.MAXD;
     BoIn in;
     in.dets = h->d_dets; in.feats = h->d_feats; in.counts = h->d_cnt; in.stream_stride_dets = 0; in.count_stride = 0;
+    in.warps = warp6 ? h->d_warp : nullptr; in.warp_stride = 0;
     const int rc = bo_launch_frame(h, V, 1, in, h->d_rows, (size_t)0, h->out_cap, h->d_ocnt, (size_t)0, st);
     if (rc != TLK_OK) return rc;
     int rows_n = 0;
@@ -648,6 +706,11 @@ extern "C" int tlk_botsort_update(tlk_botsort *h, int stream, const double *dets
     if (rows_n) TLK_HIP(hipMemcpy(rows, h->d_rows, sizeof(tlk_botsort_row) * rows_n, hipMemcpyDeviceToHost));
     *n_out = rows_n;
     return TLK_OK;
+}
+
+extern "C" int tlk_botsort_update(tlk_botsort *h, int stream, const double *dets, const float *feats, int n, tlk_botsort_row *rows, int cap, int *n_out)
+{
+    return tlk_botsort_update_gmc(h, stream, dets, feats, n, nullptr, rows, cap, n_out);
 }
 
 extern "C" int tlk_botsort_get_tracks(tlk_botsort *h, int stream, int which, int64_t *ids, double *mean, double *cov, int64_t *state5,
