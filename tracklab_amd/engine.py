@@ -232,6 +232,7 @@ class HipVideoEngine:
         if pending is not None:
             self._drain(table, pending, video_id, on_step)
         if log is not None:
+            pipe.synchronize()                  # the appends ran on the association stream: they must be complete before the ONE fetch
             for first, n, idb, res in log.fetch():
                 table.append_step(first, n, idb, maxd, res["ltwh"], res["dcnt"], self._trk_columns(res))
         return table.to_dataframe(video_id)
