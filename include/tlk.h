@@ -443,7 +443,8 @@ int tlk_letterbox_u8(const uint8_t *frames_dev, int batch, int h, int w, int siz
                      void *out_dev, double *ratio_out, void *hip_stream);
 
 /* boxes_ltwh_dev (batch, max_n, 4) float32 + counts_dev (batch) -> out_dev (batch*max_n, 3, out_h, out_w);
- * slot b*max_n+i holds crop i of frame b, slots >= counts[b] are zero. mean3/std3 are HOST float[3]
+ * slot b*max_n+i holds crop i of frame b; slots >= counts[b] are NOT written (zero the buffer once if the consumer
+ * needs zeros there; a box that is empty after clipping gives a zero crop). mean3/std3 are HOST float[3]
  * (ImageNet statistics in kpreid); value = (u8 - 255*mean) * (1/(255*std)). out_w % 8 == 0.
  * layout TLK_NCHW or TLK_NHWC. */
 int tlk_roi_crop_resize_norm(const uint8_t *frames_dev, int batch, int h, int w, const float *boxes_ltwh_dev,

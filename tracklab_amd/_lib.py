@@ -217,9 +217,9 @@ def roi_crop_resize_norm(frames, boxes_ltwh, counts, out_h, out_w, layout="nchw"
     dtype = dtype or torch.float16
     B, H, W, _ = frames.shape
     max_n = boxes_ltwh.shape[1]
-    if out is None:
+    if out is None:      # zeros: the kernel does not touch the padding slots (i >= counts[b])
         shape = (B * max_n, 3, out_h, out_w) if layout == "nchw" else (B * max_n, out_h, out_w, 3)
-        out = torch.empty(shape, dtype=dtype, device=frames.device)
+        out = torch.zeros(shape, dtype=dtype, device=frames.device)
     m = (C.c_float * 3)(*mean)
     s = (C.c_float * 3)(*std)
     check(L.tlk_roi_crop_resize_norm(frames.data_ptr(), B, H, W, boxes_ltwh.data_ptr(), counts.data_ptr(), max_n,
@@ -248,9 +248,9 @@ def roi_crop_pil_resize_norm(frames, boxes_xyxy, counts, out_h=256, out_w=128, l
     dtype = dtype or torch.float16
     B, H, W, _ = frames.shape
     max_n, stride = boxes_xyxy.shape[1], boxes_xyxy.shape[2]
-    if out is None:
+    if out is None:      # zeros: the kernel does not touch the padding slots (i >= counts[b])
         shape = (B * max_n, 3, out_h, out_w) if layout == "nchw" else (B * max_n, out_h, out_w, 3)
-        out = torch.empty(shape, dtype=dtype, device=frames.device)
+        out = torch.zeros(shape, dtype=dtype, device=frames.device)
     m = (C.c_float * 3)(*mean)
     s = (C.c_float * 3)(*std)
     check(L.tlk_roi_crop_pil_resize_norm(frames.data_ptr(), B, H, W, boxes_xyxy.data_ptr(), stride, counts.data_ptr(), max_n,

@@ -381,6 +381,202 @@ __global__ void __launch_bounds__(BLOCK) crop_lds_kernel(const unsigned char *__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Separable form of the same crop -> cv2 INTER_LINEAR resize -> normalise (the fast path since round 2).
+// cv2's fixed-point bilinear is  S_r = p[r][x0]*a0 + p[r][x1]*a1  (11-bit weights) for the two source rows r = y0, y1, then
+// v = (((b0 * (S_y0 >> 4)) >> 16) + ((b1 * (S_y1 >> 4)) >> 16) + 2) >> 2.  H[r][x][c] = S_r >> 4 depends on the SOURCE row only, and
+// an upscaled crop (the normal case: boxes ~80 x 176 px -> 384 x 128) samples every source row from ~4.4 output rows. So a
+// workgroup = (slot, band of CS_BAND output rows)
+//   1. stages the band's source-row segments in LDS (one flat sweep of 16-byte loads, as crop_lds_kernel),
+//   2. runs the horizontal pass ONCE per (source row, x, channel): two byte taps packed in one register, one v_dot2_u32_u16
+//      against the packed (a0, a1), >> 4, stored as 16 bits in an LDS plane,
+//   3. runs the vertical pass per output value from 16-byte LDS reads of that plane: 2 mul24 + shifts + add, and turns the 8-bit
+//      result into the normalised output element through a 3 x 256 look-up table built per workgroup with exactly the
+//      reference's float arithmetic ((float)v - 255*mean) * (1/(255*std)) -> T): no per-value cvt/sub/mul/cvt.
+// ~9 VALU + ~2.5 LDS operations per output value instead of ~16 + 4. Padding slots (i >= counts[b]) are not touched at all.
+// Blocks are remapped so that the bands of one crop run on ONE XCD (blockIdx round-robins over the 8 XCDs; the bands share
+// source rows through that XCD's L2).
+// ---------------------------------------------------------------------------------------------
+constexpr int CS_BAND = 16;                            // output rows per workgroup
+constexpr int CS_ROWS = 18;                            // staged source rows: CS_BAND * scale + 2 <= 18 for scale <= 1 (up-scaling / same size)
+constexpr int CS_ROW_BYTES = 544;                      // as CROP_LDS_ROW_BYTES
+
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+template <typename T> struct LutBits;
+template <> struct LutBits<float> { using type = unsigned int; };
+template <> struct LutBits<__half> { using type = unsigned short; };
+template <> struct LutBits<bf16_t> { using type = unsigned short; };
+
+__host__ __device__ inline size_t crop_sep_lds_bytes(int OW) { return (size_t)CS_ROWS * CS_ROW_BYTES + (size_t)CS_ROWS * OW * 3 * 2 + (size_t)OW * 8 + 3 * 256 * 4; }
+
+template <typename T, int LAYOUT>
+__global__ void __launch_bounds__(BLOCK) crop_sep_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
+                                                         const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
+                                                         int OH, int OW, float m0, float m1, float m2, float d0, float d1, float d2,
+                                                         T *__restrict__ out, int swap_rb, int nwg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    __shared__ int s_y0[CS_BAND], s_y1[CS_BAND], s_yw[CS_BAND], s_rsh[CS_ROWS];
+    static_assert(BLOCK == 256, "the look-up table is built one 8-bit value per thread");
+    const int tid = threadIdx.x;
+    // bijective XCD-aware remap (cdna_hip_programming.md: block b runs on XCD b % 8)
+    int wg;
+    {
+        const int orig = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int bands = (OH + CS_BAND - 1) / CS_BAND;
+    const int slot = wg / bands, band = wg - slot * bands;
+    const int b = slot / max_n, i = slot - b * max_n;
+    if (i >= counts[b]) return;                         // padding slot: left untouched
+    const int y_base = band * CS_BAND;
+    const int nb = min(CS_BAND, OH - y_base);
+    const int groups_per_row = OW / 8;
+    int l, t, r, bt;
+    crop_ltrb(boxes + ((size_t)b * max_n + i) * 4, W, H, l, t, r, bt);
+    const bool valid = (r > l) && (bt > t);
+    const int cw = r - l, ch = bt - t;
+    unsigned char *s_rows = s_dyn;
+    unsigned short *s_h = reinterpret_cast<unsigned short *>(s_dyn + CS_ROWS * CS_ROW_BYTES);
+    int2 *s_xc = reinterpret_cast<int2 *>(s_dyn + CS_ROWS * CS_ROW_BYTES + (size_t)CS_ROWS * OW * 6);
+    using LB = typename LutBits<T>::type;
+    // look-up table: one 4-byte slot per (channel, 8-bit value) -- the byte address of an entry is ((sum + 2) & ~3), no shift pair
+    unsigned char *s_lut = s_dyn + CS_ROWS * CS_ROW_BYTES + (size_t)CS_ROWS * OW * 6 + (size_t)OW * 8;
+    const int HS = OW * 3;                              // 16-bit elements per plane row
+    bool staged = false;
+    int r_lo = 0, nrows = 0;
+    double scale_y = 1.0, scale_x = 1.0;
+    if (valid) {
+        const int ylast = y_base + nb - 1;
+        scale_y = (double)ch / (double)OH; scale_x = (double)cw / (double)OW;
+        const Coef c_first = cv_coef_s(y_base, ch, scale_y, false), c_last = cv_coef_s(ylast, ch, scale_y, false);
+        r_lo = clampi(c_first.s, 0, ch - 1);
+        nrows = clampi(c_last.s + 1, 0, ch - 1) - r_lo + 1;
+        staged = nrows <= CS_ROWS && cw * 3 + STAGE_PAD <= CS_ROW_BYTES;
+    }
+    if (staged) {
+        const unsigned char *gend = frames + (size_t)B * H * W * 3;
+        const int cmax = (cw * 3 + 30) >> 4;
+        for (int idx = tid; idx < nrows * cmax; idx += BLOCK) {         // all (row, 16-byte chunk) pairs of the band in ONE sweep
+            const int rr = idx / cmax, c = idx - rr * cmax;
+            const unsigned char *g0 = frames + ((size_t)b * H * W + (size_t)(t + r_lo + rr) * W + l) * 3;
+            const uintptr_t a0 = (uintptr_t)g0 & ~(uintptr_t)15;
+            const int chunks = ((int)((uintptr_t)g0 - a0) + cw * 3 + 15) >> 4;
+            if (c < chunks) {
+                const unsigned char *p = (const unsigned char *)a0 + (size_t)c * 16;
+                unsigned char *lds = s_rows + rr * CS_ROW_BYTES + c * 16;
+                if (p + 16 <= gend) *reinterpret_cast<uint4 *>(lds) = *reinterpret_cast<const uint4 *>(p);
+                else for (int k = 0; k < 16 && p + k < gend; ++k) lds[k] = p[k];
+            }
+        }
+        if (tid < OW) {
+            const Coef cx = cv_coef_s(tid, cw, scale_x, true);
+            s_xc[tid] = make_int2((cx.s * 3) | ((cx.s + 1 < cw ? 3 : 0) << 16), (cx.w0 & 0xffff) | (cx.w1 << 16));
+        }
+        if (tid >= BLOCK - CS_BAND && tid - (BLOCK - CS_BAND) < nb) {
+            const int ry = tid - (BLOCK - CS_BAND);
+            const Coef cy = cv_coef_s(y_base + ry, ch, scale_y, false);
+            s_y0[ry] = clampi(cy.s, 0, ch - 1) - r_lo; s_y1[ry] = clampi(cy.s + 1, 0, ch - 1) - r_lo;
+            s_yw[ry] = (cy.w0 & 0xffff) | (cy.w1 << 16);
+        }
+        if (tid >= 64 && tid - 64 < nrows) {
+            const int rr = tid - 64;
+            s_rsh[rr] = (int)((uintptr_t)(frames + ((size_t)b * H * W + (size_t)(t + r_lo + rr) * W + l) * 3) & 15);
+        }
+        {   // the normalisation table, per SOURCE channel (swap_rb exchanges channels 0 and 2 at the store): the reference's
+            // float32 arithmetic value for value, then the conversion to T
+            const float mean[3] = {m0, m1, m2}, den[3] = {d0, d1, d2};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float f = (float)tid; f -= mean[c]; f *= den[c];
+                const T v = cvt<T>(f);
+                *reinterpret_cast<LB *>(s_lut + (c * 256 + tid) * 4) = *reinterpret_cast<const LB *>(&v);
+            }
+        }
+        __syncthreads();
+        // ---- horizontal pass: one (source row, x) per thread and iteration, three channels
+        for (int idx = tid; idx < nrows * OW; idx += BLOCK) {
+            const int rr = idx / OW, x = idx - rr * OW;
+            const int2 xc = s_xc[x];
+            const int o0 = xc.x & 0xffff, o1 = o0 + (xc.x >> 16);
+            const unsigned char *p = s_rows + rr * CS_ROW_BYTES + s_rsh[rr];
+            const us2_t A = __builtin_bit_cast(us2_t, xc.y);
+            unsigned short *o = s_h + rr * HS + x * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned int P = (unsigned int)p[o0 + c] | ((unsigned int)p[o1 + c] << 16);
+                o[c] = (unsigned short)(__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, P), A, 0u, false) >> 4);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- vertical pass + normalisation: thread -> (row of the band, 8 consecutive x)
+    for (int unit = tid; unit < nb * groups_per_row; unit += BLOCK) {
+        const int ry = unit / groups_per_row, x_base = (unit - ry * groups_per_row) * 8;
+        const int y = y_base + ry;
+        T px[8][3];
+        if (staged) {
+            const uint4 *h0 = reinterpret_cast<const uint4 *>(s_h + s_y0[ry] * HS + x_base * 3);
+            const uint4 *h1 = reinterpret_cast<const uint4 *>(s_h + s_y1[ry] * HS + x_base * 3);
+            const unsigned int yw = (unsigned int)s_yw[ry], b0 = yw & 0xffffu, b1 = yw >> 16;
+            unsigned int w0[12], w1[12];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint4 u = h0[k], v = h1[k];
+                w0[k * 4] = u.x; w0[k * 4 + 1] = u.y; w0[k * 4 + 2] = u.z; w0[k * 4 + 3] = u.w;
+                w1[k * 4] = v.x; w1[k * 4 + 1] = v.y; w1[k * 4 + 2] = v.z; w1[k * 4 + 3] = v.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 24; ++q) {
+                const unsigned int a = (q & 1) ? (w0[q >> 1] >> 16) : (w0[q >> 1] & 0xffffu);
+                const unsigned int c1 = (q & 1) ? (w1[q >> 1] >> 16) : (w1[q >> 1] & 0xffffu);
+                // 4 * v with v = (.. + 2) >> 2 <= 255 always: H <= (255 * 2049) >> 4 and b0 + b1 <= 2049 bound the sum by 1020
+                const unsigned int v4 = ((__umul24(b0, a) >> 16) + (__umul24(b1, c1) >> 16) + 2u) & ~3u;
+                const LB bits = *reinterpret_cast<const LB *>(s_lut + (q % 3) * 1024 + v4);
+                px[q / 3][q % 3] = *reinterpret_cast<const T *>(&bits);
+            }
+        } else if (valid) {
+            const float mean[3] = {m0, m1, m2}, den[3] = {d0, d1, d2};
+            const unsigned char *base = frames + ((size_t)b * H * W + (size_t)t * W + l) * 3;
+            const Coef cy = cv_coef(y, ch, OH, false);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int v[3];
+                sample3(base, W * 3, ch, cw, cy, cv_coef(x_base + k, cw, OW, true), v);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { float f = (float)v[c]; f -= mean[c]; f *= den[c]; px[k][c] = cvt<T>(f); }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) px[k][c] = cvt<T>(0.f);
+        }
+        if (swap_rb) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const T t0 = px[k][0]; px[k][0] = px[k][2]; px[k][2] = t0; }
+        }
+        if (LAYOUT == LAYOUT_NCHW) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                Pack<T, 8> p;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) p.v[k] = px[k][c];
+                *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)slot * 3 + c) * OH + y) * OW + x_base) = p;
+            }
+        } else {
+            T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Pack<T, 8> p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
+                *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Plain StrongSORT's ReID input: crop ori_img[y1:y2, x1:x2] of the int-truncated, clipped box
 // (strong_sort.py:102-108, :135-141) -> Pillow Image.resize(BILINEAR) -> ToTensor -> Normalize
 // (reid_multibackend.py:44-52, :184-195). Pillow's resample (src/libImaging/Resample.c) is separable with an 8-bit
@@ -470,6 +666,10 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
     __shared__ __attribute__((aligned(16))) unsigned char s_h[PIL_ROWS * (PIL_OW_MAX * 3 + 16)];
     __shared__ int s_hmin[PIL_OW_MAX], s_hmax[PIL_OW_MAX], s_hk[PIL_OW_MAX][PIL_KMAX];
     __shared__ int s_vmin[PIL_BAND], s_vmax[PIL_BAND], s_vk[PIL_BAND][PIL_KMAX];
+    // ToTensor + Normalize of an 8-bit value, per SOURCE channel, with exactly the reference's float32 arithmetic ((v / 255) - mean) / std:
+    // one table entry per (channel, value) instead of two IEEE divisions per output element
+    __shared__ T s_lut[3][256];
+    static_assert(BLOCK == 256, "the look-up table is built one 8-bit value per thread");
     const int HS = OW * 3 + 16;
     const int tid = threadIdx.x;
     const int bands = (OH + PIL_BAND - 1) / PIL_BAND;
@@ -480,6 +680,9 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
     const int groups_per_row = OW / 8;
     const float mean[3] = {m0, m1, m2}, stdv[3] = {d0, d1, d2};
     bool valid = i < counts[b];
+    if (!valid) return;                                  // padding slot: left untouched
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { float f = (float)tid / 255.0f; f = f - mean[c]; f = f / stdv[c]; s_lut[c][tid] = cvt<T>(f); }
     int x1 = 0, y1 = 0, x2 = 0, y2 = 0;
     if (valid) { ssort_crop_box(boxes + ((size_t)b * max_n + i) * box_stride, W, H, x1, y1, x2, y2); valid = (x2 > x1) && (y2 > y1); }
     const int cw = x2 - x1, ch = y2 - y1;
@@ -532,7 +735,7 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
             int s0 = 1 << (PIL_BITS - 1), s1 = s0, s2 = s0;
 #pragma unroll
             for (int k = 0; k < PIL_KMAX; ++k)
-                if (k < n) { const int kv = s_hk[x][k]; s0 += (int)p[k * 3] * kv; s1 += (int)p[k * 3 + 1] * kv; s2 += (int)p[k * 3 + 2] * kv; }
+                if (k < n) { const int kv = s_hk[x][k]; s0 += __mul24((int)p[k * 3], kv); s1 += __mul24((int)p[k * 3 + 1], kv); s2 += __mul24((int)p[k * 3 + 2], kv); }
             unsigned char *o = s_h + rr * HS + x * 3;
             o[0] = (unsigned char)pil_clip8(s0); o[1] = (unsigned char)pil_clip8(s1); o[2] = (unsigned char)pil_clip8(s2);
         }
@@ -555,15 +758,12 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
                     const int kv = s_vk[ry][k];
                     const unsigned char *r = p + k * HS;
 #pragma unroll
-                    for (int q = 0; q < 24; ++q) acc[q] += (int)r[q] * kv;
+                    for (int q = 0; q < 24; ++q) acc[q] += __mul24((int)r[q], kv);
                 }
 #pragma unroll
             for (int k = 0; k < 8; ++k)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float f = (float)pil_clip8(acc[k * 3 + c]) / 255.0f; f = f - mean[c]; f = f / stdv[c];
-                    px[k][c] = cvt<T>(f);
-                }
+                for (int c = 0; c < 3; ++c) px[k][c] = s_lut[c][pil_clip8(acc[k * 3 + c])];
         } else if (valid) {
             // direct branch: every vertical tap recomputes its horizontally resampled (and uint8-rounded) sample from global memory
             int ymin, ymax;
@@ -966,7 +1166,17 @@ int launch_crop(const unsigned char *frames, int B, int H, int W, const float *b
     const int sw0 = swap_rb ? 2 : 0, sw2 = swap_rb ? 0 : 2;
     const float m0 = mean[sw0] * 255.f, m1 = mean[1] * 255.f, m2 = mean[sw2] * 255.f;
     const float d0 = 1.0f / (stdv[sw0] * 255.f), d1 = 1.0f / (stdv[1] * 255.f), d2 = 1.0f / (stdv[sw2] * 255.f);
-    if (OW <= 256) {                                       // LDS-staged fast path: workgroup = (slot, band of rows)
+    static const int variant = [] { const char *e = getenv("TLK_CROP_KERNEL"); return e ? atoi(e) : 2; }();     // 2 separable (default), 1 round-1 LDS kernel, 0 direct
+    if (variant == 2 && OW <= 256) {                       // separable fast path: workgroup = (slot, band of CS_BAND rows)
+        const int nwg = (int)((long long)B * max_n * ((OH + CS_BAND - 1) / CS_BAND));
+        const size_t smem = crop_sep_lds_bytes(OW);
+        if (layout == LAYOUT_NCHW)
+            hipLaunchKernelGGL((crop_sep_kernel<T, LAYOUT_NCHW>), dim3(nwg), dim3(BLOCK), smem, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg);
+        else
+            hipLaunchKernelGGL((crop_sep_kernel<T, LAYOUT_NHWC>), dim3(nwg), dim3(BLOCK), smem, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg);
+        return TLK_OK;
+    }
+    if (variant >= 1 && OW <= 256) {                       // round-1 LDS-staged path: workgroup = (slot, band of rows)
         const dim3 g2((unsigned)((long long)B * max_n * ((OH + CROP_BAND - 1) / CROP_BAND)));
         if (layout == LAYOUT_NCHW)
             hipLaunchKernelGGL((crop_lds_kernel<T, LAYOUT_NCHW>), g2, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb);

@@ -294,7 +294,7 @@ class DetReidTrackPipeline:
         self.B = B
         dev = self.dev
         self.lb = torch.empty((B, size // 2, size // 2, 12), dtype=dtype, device=dev)
-        self.crops = torch.empty((B * max_dets, reid_hw[0], reid_hw[1], 3), dtype=dtype, device=dev)
+        self.crops = torch.zeros((B * max_dets, reid_hw[0], reid_hw[1], 3), dtype=dtype, device=dev)      # padding slots stay as they are
         self.det = {"ltwh": torch.zeros((B, max_dets, 4), dtype=torch.float32, device=dev),
                     "xyxy": torch.zeros((B, max_dets, 4), dtype=torch.float32, device=dev),
                     "scores": torch.zeros((B, max_dets), dtype=torch.float32, device=dev),
