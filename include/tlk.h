@@ -218,6 +218,10 @@ typedef struct {                 /* one output row = one confirmed track updated
 
 int tlk_bpbss_create(const tlk_bpbss_params *p, int n_streams, int device, tlk_bpbss **out);
 int tlk_bpbss_destroy(tlk_bpbss *h);
+/* diagnostics: per-phase time accumulators of the association kernel in 100 MHz ticks (bank created with TLK_BPBSS_PROF set
+ * in the environment; the extra barriers make the kernel slower). ticks16: 16 int64: filter+predict, preparation, appearance cost
+ * fill, LSA A, set order + motion cost fill, LSA B, Kalman updates, embedding EMA, misses + births, deaths + rows. */
+int tlk_bpbss_get_profile(tlk_bpbss *h, int stream, long long *ticks16);
 int tlk_bpbss_reset(tlk_bpbss *h, int stream);
 /* one frame of one stream, host buffers, synchronous: ids (n) int64, ltwh (n,4) f64, emb (n,K,D) f32,
  * vis (n,K) u8, conf (n) f64, kps (n,17,3) f64 [x,y,conf] or NULL -> rows (<= cap) */

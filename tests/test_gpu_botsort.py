@@ -99,8 +99,9 @@ def test_botsort_rejects_bad_configuration():
     from tracklab_amd._lib import BoTSORTBank, TlkError
     with pytest.raises(TlkError):
         BoTSORTBank(64, max_tracks=400, max_dets=200)
+    b = BoTSORTBank(64, cmc_method="sparseOptFlow")            # the reference's default: accepted, but every update must bring the frame's warp
     with pytest.raises(TlkError):
-        BoTSORTBank(64, cmc_method="sparseOptFlow")            # the reference's default: cv2 optical flow, not implemented
+        b.update(np.zeros((1, 7)), np.zeros((1, 64), np.float32))
     with pytest.raises(ValueError):
         BoTSORTBank(64, cmc_method="nope")
     b = BoTSORTBank(32, max_dets=8)

@@ -34,6 +34,7 @@ struct BpbDev {
     double *reid;            // S x MAXT x MAXD    part-based distance, row = list position, col = input detection index
     double *gl;              // S x MAXT x GLN     per track: projected mean (4) + Cholesky factor (16) for gating, OKS scale + count
     double *cost_g;          // S x MAXT x MAXD    cost-matrix spill
+    long long *prof;         // optional S x 16 phase accumulators in 100 MHz ticks (diagnostics: TLK_BPBSS_PROF)
     int *ps_ws;              // S x 4 x ps_cap      hash tables of the set-order emulation when they do not fit the LDS cost area
     int S, MAXT, MAXD, K, D, cost_lds_entries, ps_cap;
 };
@@ -249,6 +250,9 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
     if (hdr[H_ERR] != 0) { if (tid == 0) *out_count = hdr[H_ERR]; return; }
     if (n_in > MAXD || n_in < 0) { if (tid == 0) { hdr[H_ERR] = TLK_ECAPACITY; *out_count = TLK_ECAPACITY; } return; }
     if (P.wrapper_mode && n_in == 0) { if (tid == 0) *out_count = 0; return; }      // bpbreid_strong_sort_api.py:103-104
+    long long t_prev = 0;
+#define BPB_PROF(i) do { if (Dv.prof) { __syncthreads(); if (tid == 0) { const long long t_ = wall_clock64(); Dv.prof[(size_t)s * 16 + (i)] += t_ - t_prev; t_prev = t_; } } } while (0)
+    if (Dv.prof && tid == 0) t_prev = wall_clock64();
 
     // filter_detections (strong_sort.py:143-147)
     const int N = block_compact(n_in, [&](int i) { return in.conf[dbase + i] > P.min_conf; }, [&](int i, int pos) { L.sel[pos] = i; }, L.scan);
@@ -274,6 +278,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
         Kt.i(BI_TSU) = tsu + 1;
     }
     __syncthreads();
+    BPB_PROF(0);                                          // filter + predict
     if (N > 0) {
         const int gdim = P.only_position ? 2 : 4;
         const bool use_oks = P.motion == 1 && in.kps != nullptr;
@@ -310,6 +315,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             if (use_oks) { int nv; g[20] = oks_scale([&](int q) { return Kt.d(BD_KP + q); }, &nv); g[21] = (double)nv; }
         }
         __syncthreads();
+        BPB_PROF(1);                                      // detection + gate preparation
         int nm = 0, n_umt = 0, n_umd = 0;
         int *um_d_final = L.um_db;
         if (P.strategy == 0) {
@@ -332,7 +338,9 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             // all detections as columns: det_idx = identity -> reuse um_db as identity scratch
             for (int j = tid; j < N; j += BLOCK) L.um_db[j] = j;
             __syncthreads();
+            BPB_PROF(2);                                  // appearance cost fill
             const McmOut A = min_cost_matching(cm, nc, N, P.max_dist, L.cand, L.um_db, L.m_t, L.m_d, L.um_ta, L.um_da, L);
+            BPB_PROF(3);                                  // LSA + match lists, stage A
             if (nc > 0)
                 for (int k = tid; k < A.nm; k += BLOCK) {       // add_matching_information "R": un-thresholded gated cost (tracker.py:409-425)
                     const int p = L.m_t[k], j = L.m_d[k];
@@ -364,6 +372,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
                 cb[e] = v > motion_max ? motion_max + 1e-5 : v;
             }
             __syncthreads();
+            BPB_PROF(4);                                  // matched info, set order, motion cost fill
             const McmOut Bm = min_cost_matching(cb, nb, n_uda, motion_max, L.bc, L.um_da, L.m_t + A.nm, L.m_d + A.nm,
                                                 L.um_tb, L.um_db, L);
             if (nb > 0 && n_uda > 0)
@@ -376,6 +385,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             n_umt = n_uta + Bm.n_um_t; n_umd = Bm.n_um_d;
             um_d_final = L.um_db;
             __syncthreads();
+            BPB_PROF(5);                                  // LSA + match lists, stage B
         } else {
             // ---------------- bot_sort_matching (tracker.py:335-363, _full_cost_metric :169-240) ----------------
             for (int p = tid; p < T; p += BLOCK) L.cand[p] = p;
@@ -441,6 +451,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             Kt.i(BI_HITS) = hits; Kt.i(BI_TSU) = 0;
             if (Kt.i(BI_STATE) == ST_TENTATIVE && hits >= P.n_init) Kt.i(BI_STATE) = ST_CONFIRMED;
         }
+        BPB_PROF(6);                                      // Kalman update of the matched tracks
         // visibility-aware EMA of the part embeddings (track.py:150-170). Flat float4 sweep over (match, part, d): every
         // thread keeps 4 independent 16-byte loads in flight (the per-(match,part) wavefront loop it replaces was a chain of
         // dependent global round trips). Visibility is read here and rewritten after the barrier below.
@@ -478,6 +489,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
                 if (in.vis[(dbase + di) * K + p] != 0) fvisS[(size_t)slot * K + p] = 1;       // max(tv, dv)
             }
         }
+        BPB_PROF(7);                                      // embedding EMA
         for (int k = tid; k < n_umt; k += BLOCK) {            // mark_missed (track.py:181-187)
             const BTrk Kt = trk_at(order[L.um_t[k]]);
             if (Kt.i(BI_STATE) == ST_TENTATIVE) Kt.i(BI_STATE) = ST_DELETED;
@@ -517,6 +529,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
         }
         __syncthreads();
         nfree -= n_umd; nextid += n_umd; T += n_umd;
+        BPB_PROF(8);                                      // mark_missed + births
         // drop deleted tracks (stable), tracker.py:154
         for (int p = tid; p < T; p += BLOCK) { L.tmp[p] = order[p]; L.rowf[p] = trk_at(order[p]).i(BI_STATE) == ST_DELETED ? 1 : 0; }
         __syncthreads();
@@ -547,6 +560,8 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
                                         rows[pos] = r;
                                     }, L.scan);
     if (tid == 0) *out_count = nrows > out_cap ? TLK_ECAPACITY : nrows;
+    BPB_PROF(9);                                          // deaths + output rows
+#undef BPB_PROF
 }
 
 __global__ void bpbss_reset_kernel(BpbDev D, int stream)
@@ -690,7 +705,7 @@ static void bpb_free(tlk_bpbss *h)
     if (!h) return;
     hipSetDevice(h->device);
     BpbDev &D = h->D;
-    void *ptrs[] = {D.fd, D.fi, D.detid, D.hdr, D.order, D.freestk, D.feat, D.fvis, D.tnorm, D.dnorm, D.reid, D.gl, D.cost_g, D.ps_ws,
+    void *ptrs[] = {D.fd, D.fi, D.detid, D.hdr, D.order, D.freestk, D.feat, D.fvis, D.tnorm, D.dnorm, D.reid, D.gl, D.cost_g, D.ps_ws, D.prof,
                     h->d_ids, h->d_ltwh, h->d_emb, h->d_vis, h->d_conf, h->d_kps, h->d_cnt, h->d_ocnt, h->d_rows};
     for (void *p : ptrs) if (p) hipFree(p);
     delete h;
@@ -754,6 +769,7 @@ extern "C" int tlk_bpbss_create(const tlk_bpbss_params *p, int n_streams, int de
     BPB_ALLOC(D.cost_g, sizeof(double) * slots * MAXD);
     D.ps_cap = (int)pyset::table_capacity((unsigned)MAXT);
     BPB_ALLOC(D.ps_ws, sizeof(int) * 4 * (size_t)D.ps_cap * n_streams);
+    if (getenv("TLK_BPBSS_PROF")) { BPB_ALLOC(D.prof, sizeof(long long) * 16 * n_streams); hipMemset(D.prof, 0, sizeof(long long) * 16 * n_streams); }
     BPB_ALLOC(h->d_ids, sizeof(long long) * MAXD);
     BPB_ALLOC(h->d_ltwh, sizeof(double) * 4 * MAXD);
     BPB_ALLOC(h->d_emb, sizeof(float) * FD * MAXD);
@@ -778,6 +794,17 @@ extern "C" int tlk_bpbss_create(const tlk_bpbss_params *p, int n_streams, int de
 }
 
 extern "C" int tlk_bpbss_destroy(tlk_bpbss *h) { bpb_free(h); return TLK_OK; }
+
+extern "C" int tlk_bpbss_get_profile(tlk_bpbss *h, int stream, long long *ticks16)
+{
+    if (!h || !ticks16) return fail(TLK_EINVAL, "tlk_bpbss_get_profile: null pointer");
+    if (!h->D.prof) return fail(TLK_EINVAL, "tlk_bpbss_get_profile: create the bank with TLK_BPBSS_PROF=1 in the environment");
+    if (stream < 0 || stream >= h->D.S) return fail(TLK_EINVAL, "tlk_bpbss_get_profile: stream out of range");
+    TLK_HIP(hipSetDevice(h->device));
+    TLK_HIP(hipDeviceSynchronize());
+    TLK_HIP(hipMemcpy(ticks16, h->D.prof + (size_t)stream * 16, sizeof(long long) * 16, hipMemcpyDeviceToHost));
+    return TLK_OK;
+}
 
 extern "C" int tlk_bpbss_reset(tlk_bpbss *h, int stream)
 {
@@ -840,7 +867,7 @@ extern "C" int tlk_bpbss_update(tlk_bpbss *h, int stream, const int64_t *ids, co
     const size_t sl = (size_t)stream * V.MAXT;
     V.fd += sl; V.fi += sl; V.detid += sl; V.hdr += (size_t)stream * H_COUNT; V.order += sl; V.freestk += sl;
     V.feat += sl * FD; V.fvis += sl * V.K; V.tnorm += sl * V.K * 2; V.dnorm += (size_t)stream * V.MAXD * V.K * 2;
-    V.reid += sl * V.MAXD; V.gl += sl * GLN; V.cost_g += sl * V.MAXD; V.ps_ws += (size_t)stream * 4 * V.ps_cap;
+    V.reid += sl * V.MAXD; V.gl += sl * GLN; V.cost_g += sl * V.MAXD; V.ps_ws += (size_t)stream * 4 * V.ps_cap; if (V.prof) V.prof += (size_t)stream * 16;
     FrameIn in;
     in.ids = h->d_ids; in.ltwh = h->d_ltwh; in.emb = h->d_emb; in.vis = h->d_vis; in.conf = h->d_conf; in.counts = h->d_cnt;
     in.kps = kps ? h->d_kps : nullptr;

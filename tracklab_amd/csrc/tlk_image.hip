@@ -406,13 +406,20 @@ template <> struct LutBits<float> { using type = unsigned int; };
 template <> struct LutBits<__half> { using type = unsigned short; };
 template <> struct LutBits<bf16_t> { using type = unsigned short; };
 
-__host__ __device__ inline size_t crop_sep_lds_bytes(int OW) { return (size_t)CS_ROWS * CS_ROW_BYTES + (size_t)CS_ROWS * OW * 3 * 2 + (size_t)OW * 8 + 3 * 256 * 4; }
+// region 0 holds the staged source rows and, once the horizontal pass is done with them, the band's output rows on their way to
+// fully coalesced stores (CS_BAND rows x OW x 3 elements)
+__host__ __device__ inline size_t crop_sep_region0(int OW, size_t elem)
+{
+    const size_t a = (size_t)CS_ROWS * CS_ROW_BYTES, b = (size_t)CS_BAND * OW * 3 * elem;
+    return ((a > b ? a : b) + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t crop_sep_lds_bytes(int OW, size_t elem) { return crop_sep_region0(OW, elem) + (size_t)CS_ROWS * OW * 3 * 2 + (size_t)OW * 8 + 3 * 256 * 4; }
 
 template <typename T, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK) crop_sep_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
                                                          const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
                                                          int OH, int OW, float m0, float m1, float m2, float d0, float d1, float d2,
-                                                         T *__restrict__ out, int swap_rb, int nwg)
+                                                         T *__restrict__ out, int swap_rb, int nwg, int coalesce)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     __shared__ int s_y0[CS_BAND], s_y1[CS_BAND], s_yw[CS_BAND], s_rsh[CS_ROWS];
@@ -435,12 +442,13 @@ __global__ void __launch_bounds__(BLOCK) crop_sep_kernel(const unsigned char *__
     crop_ltrb(boxes + ((size_t)b * max_n + i) * 4, W, H, l, t, r, bt);
     const bool valid = (r > l) && (bt > t);
     const int cw = r - l, ch = bt - t;
+    const size_t R0 = crop_sep_region0(OW, sizeof(T));
     unsigned char *s_rows = s_dyn;
-    unsigned short *s_h = reinterpret_cast<unsigned short *>(s_dyn + CS_ROWS * CS_ROW_BYTES);
-    int2 *s_xc = reinterpret_cast<int2 *>(s_dyn + CS_ROWS * CS_ROW_BYTES + (size_t)CS_ROWS * OW * 6);
+    unsigned short *s_h = reinterpret_cast<unsigned short *>(s_dyn + R0);
+    int2 *s_xc = reinterpret_cast<int2 *>(s_dyn + R0 + (size_t)CS_ROWS * OW * 6);
     using LB = typename LutBits<T>::type;
     // look-up table: one 4-byte slot per (channel, 8-bit value) -- the byte address of an entry is ((sum + 2) & ~3), no shift pair
-    unsigned char *s_lut = s_dyn + CS_ROWS * CS_ROW_BYTES + (size_t)CS_ROWS * OW * 6 + (size_t)OW * 8;
+    unsigned char *s_lut = s_dyn + R0 + (size_t)CS_ROWS * OW * 6 + (size_t)OW * 8;
     const int HS = OW * 3;                              // 16-bit elements per plane row
     bool staged = false;
     int r_lo = 0, nrows = 0;
@@ -509,6 +517,7 @@ __global__ void __launch_bounds__(BLOCK) crop_sep_kernel(const unsigned char *__
         }
         __syncthreads();
     }
+    const bool use_lds_store = coalesce && LAYOUT == LAYOUT_NHWC && ((size_t)OW * 3 * sizeof(T)) % 16 == 0;       // staged or not, uniform
     // ---- vertical pass + normalisation: thread -> (row of the band, 8 consecutive x)
     for (int unit = tid; unit < nb * groups_per_row; unit += BLOCK) {
         const int ry = unit / groups_per_row, x_base = (unit - ry * groups_per_row) * 8;
@@ -563,6 +572,18 @@ __global__ void __launch_bounds__(BLOCK) crop_sep_kernel(const unsigned char *__
                 for (int k = 0; k < 8; ++k) p.v[k] = px[k][c];
                 *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)slot * 3 + c) * OH + y) * OW + x_base) = p;
             }
+        } else if (use_lds_store) {
+            // NHWC: a thread's 24 elements are contiguous but 24 elements apart from its neighbour's, so a direct 16-byte store
+            // instruction touches every 128-byte line of the band partially. The band's output (nb rows = ONE contiguous block of
+            // memory) is put together in region 0 instead and leaves below as fully coalesced 16-byte stores.
+            T *o = reinterpret_cast<T *>(s_dyn) + ((size_t)ry * OW + x_base) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Pack<T, 8> p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
+                *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+            }
         } else {
             T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
 #pragma unroll
@@ -573,6 +594,13 @@ __global__ void __launch_bounds__(BLOCK) crop_sep_kernel(const unsigned char *__
                 *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
             }
         }
+    }
+    if (use_lds_store) {
+        __syncthreads();
+        const int n16 = (int)((size_t)nb * OW * 3 * sizeof(T) / 16);
+        uint4 *g = reinterpret_cast<uint4 *>(out + ((size_t)slot * OH + y_base) * OW * 3);
+        const uint4 *l4 = reinterpret_cast<const uint4 *>(s_dyn);
+        for (int c = tid; c < n16; c += BLOCK) g[c] = l4[c];
     }
 }
 
@@ -586,7 +614,7 @@ __global__ void __launch_bounds__(BLOCK) crop_sep_kernel(const unsigned char *__
 // normalisation straight to 16-byte stores. Crops too large for the LDS planes take the direct (recompute) branch.
 // ---------------------------------------------------------------------------------------------
 constexpr int PIL_BITS = 32 - 8 - 2;
-constexpr int PIL_BAND = 32;
+constexpr int PIL_BAND = 16;
 constexpr int PIL_KMAX = 5;                           // taps per axis handled from LDS tables: scale <= 2
 constexpr int PIL_ROWS = 40;                          // staged source rows per band
 constexpr int PIL_ROW_BYTES = 544;                    // as CROP_LDS_ROW_BYTES: crops up to 170 px wide
@@ -741,6 +769,8 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
         }
     }
     __syncthreads();
+    // (the direct branch reads global memory only, so the source-row area is free for the output in every case)
+    const bool use_lds_store = LAYOUT == LAYOUT_NHWC && ((size_t)OW * 3 * sizeof(T)) % 16 == 0 && (size_t)nb * OW * 3 * sizeof(T) <= sizeof(s_rows);
     for (int unit = tid; unit < PIL_BAND * groups_per_row; unit += BLOCK) {
         const int ry = unit / groups_per_row, x_base = (unit - ry * groups_per_row) * 8;
         const int y = y_base + ry;
@@ -802,6 +832,15 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
                 for (int k = 0; k < 8; ++k) p.v[k] = px[k][c];
                 *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)slot * 3 + c) * OH + y) * OW + x_base) = p;
             }
+        } else if (use_lds_store) {      // as crop_sep_kernel: the band's output is ONE contiguous block; assemble it in the (dead) source-row area
+            T *o = reinterpret_cast<T *>(s_rows) + ((size_t)ry * OW + x_base) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Pack<T, 8> p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
+                *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+            }
         } else {
             T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
 #pragma unroll
@@ -812,6 +851,13 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
                 *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
             }
         }
+    }
+    if (use_lds_store) {
+        __syncthreads();
+        const int n16 = (int)((size_t)nb * OW * 3 * sizeof(T) / 16);
+        uint4 *g = reinterpret_cast<uint4 *>(out + ((size_t)slot * OH + y_base) * OW * 3);
+        const uint4 *l4 = reinterpret_cast<const uint4 *>(s_rows);
+        for (int c = tid; c < n16; c += BLOCK) g[c] = l4[c];
     }
 }
 
@@ -1168,12 +1214,13 @@ int launch_crop(const unsigned char *frames, int B, int H, int W, const float *b
     const float d0 = 1.0f / (stdv[sw0] * 255.f), d1 = 1.0f / (stdv[1] * 255.f), d2 = 1.0f / (stdv[sw2] * 255.f);
     static const int variant = [] { const char *e = getenv("TLK_CROP_KERNEL"); return e ? atoi(e) : 2; }();     // 2 separable (default), 1 round-1 LDS kernel, 0 direct
     if (variant == 2 && OW <= 256) {                       // separable fast path: workgroup = (slot, band of CS_BAND rows)
+        static const int coalesce = [] { const char *e = getenv("TLK_CROP_STORE"); return e ? atoi(e) : 1; }();     // 1: band output through LDS
         const int nwg = (int)((long long)B * max_n * ((OH + CS_BAND - 1) / CS_BAND));
-        const size_t smem = crop_sep_lds_bytes(OW);
+        const size_t smem = crop_sep_lds_bytes(OW, sizeof(T));
         if (layout == LAYOUT_NCHW)
-            hipLaunchKernelGGL((crop_sep_kernel<T, LAYOUT_NCHW>), dim3(nwg), dim3(BLOCK), smem, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg);
+            hipLaunchKernelGGL((crop_sep_kernel<T, LAYOUT_NCHW>), dim3(nwg), dim3(BLOCK), smem, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg, coalesce);
         else
-            hipLaunchKernelGGL((crop_sep_kernel<T, LAYOUT_NHWC>), dim3(nwg), dim3(BLOCK), smem, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg);
+            hipLaunchKernelGGL((crop_sep_kernel<T, LAYOUT_NHWC>), dim3(nwg), dim3(BLOCK), smem, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg, coalesce);
         return TLK_OK;
     }
     if (variant >= 1 && OW <= 256) {                       // round-1 LDS-staged path: workgroup = (slot, band of rows)
