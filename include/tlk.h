@@ -269,6 +269,9 @@ typedef struct tlk_bytetrack tlk_bytetrack;
 int tlk_bytetrack_create(const tlk_bytetrack_params *p, int n_streams, int device, tlk_bytetrack **out);
 int tlk_bytetrack_destroy(tlk_bytetrack *h);
 int tlk_bytetrack_reset(tlk_bytetrack *h, int stream);       /* stream < 0: all */
+/* as tlk_bytetrack_reset but the id counter keeps counting: the reference's BaseTrack._count is class-level and never reset
+ * (plugins/track/byte_track/basetrack.py:13,35-37), so the tracks of a second video continue the numbering of the first */
+int tlk_bytetrack_reset_keep_ids(tlk_bytetrack *h, int stream);
 /* host buffers: dets (n,7) f64 [x1,y1,x2,y2,conf,cls,tracklab_id] -> rows (cap) */
 int tlk_bytetrack_update(tlk_bytetrack *h, int stream, const double *dets, int n, tlk_bytetrack_row *rows, int cap, int *n_out);
 /* device buffers, all streams, n_frames consecutive frames per stream, asynchronous on hip_stream:
@@ -354,6 +357,9 @@ typedef struct tlk_botsort tlk_botsort;
 int tlk_botsort_create(const tlk_botsort_params *p, int n_streams, int device, tlk_botsort **out);
 int tlk_botsort_destroy(tlk_botsort *h);
 int tlk_botsort_reset(tlk_botsort *h, int stream);           /* stream < 0: all */
+/* as tlk_botsort_reset but the id counter keeps counting: the reference's BaseTrack._count is class-level and never reset
+ * (plugins/track/bot_sort/basetrack.py), so the tracks of a second video continue the numbering of the first */
+int tlk_botsort_reset_keep_ids(tlk_botsort *h, int stream);
 /* host buffers: dets (n,7) f64 [x1,y1,x2,y2,conf,cls,tracklab_id], feats (n,dim) f32 (rows of detections with
  * conf <= track_high_thresh are not read) -> rows (cap) */
 int tlk_botsort_update(tlk_botsort *h, int stream, const double *dets, const float *feats, int n, tlk_botsort_row *rows, int cap, int *n_out);

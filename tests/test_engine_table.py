@@ -21,12 +21,14 @@ def test_append_step_matches_per_row_merge():
             for i in rng.permutation(int(dcnt[f]))[:int(rng.integers(0, dcnt[f] + 1))]:       # the tracker reports a subset, in its own order
                 tf.append(f); tdet.append(id_base + f * maxd + int(i)); tid.append(float(rng.integers(1, 99)))
                 tl.append(rng.uniform(0, 500, 4)); tconf.append(rng.uniform())
+        tf.append(0); tdet.append(id_base + maxd - 1 if dcnt[0] < maxd else id_base - 1); tid.append(777.0)        # a row whose detection id is
+        tl.append(np.zeros(4)); tconf.append(0.0)                                                                   # not in the frame: ignored
         trk = (np.array(tf, dtype=np.int64), np.array(tdet, dtype=np.int64), np.array(tid), np.array(tl).reshape(-1, 4), np.array(tconf))
         table.append_step(first, n, id_base, maxd, ltwh, dcnt, trk)
         for f in range(n):
             for i in range(int(dcnt[f])):
                 expect[id_base + f * maxd + i] = [first + f, ltwh[f, i], np.nan, None, np.nan]
-        for k in range(len(tf)):
+        for k in range(len(tf) - 1):
             if tf[k] < n:
                 e = expect[tdet[k]]
                 e[2], e[3], e[4] = tid[k], tl[k], tconf[k]

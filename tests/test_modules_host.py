@@ -410,37 +410,3 @@ def test_bytetrack_module_host_logic_with_oracle_backend(orc):
         np.testing.assert_array_equal(np.stack(out.track_bbox_ltwh.to_list()),
                                       np.stack([exp[:, 0], exp[:, 1], exp[:, 2] - exp[:, 0], exp[:, 3] - exp[:, 1]], axis=1))
     assert n_rows > 300
-
-
-def test_detection_table_columnar_appends_and_track_join():
-    """tracklab_amd.engine.DetectionTable: whole-frame appends, growth, tracker rows joined by detection id, one DataFrame out."""
-    from tracklab_amd.engine import DetectionTable
-    t = DetectionTable(capacity=4)                       # forces several growth steps
-    rng = np.random.default_rng(0)
-    expect = {}
-    for f in range(20):
-        m = int(rng.integers(0, 9))
-        ids = f * 16 + np.arange(m, dtype=np.int64)
-        ltwh = rng.uniform(0, 100, (m, 4)).astype(np.float32)
-        base = t.append_frame(f, ids, ltwh, 1.0, 1)
-        pick = rng.permutation(m)[: m // 2]               # tracker reports a subset, in its own order
-        tid = rng.integers(1, 50, len(pick)).astype(np.float64)
-        tl = rng.uniform(0, 100, (len(pick), 4))
-        stale = np.array([f * 16 + 15], dtype=np.int64)   # an id that is not in this frame (coasting track): ignored
-        t.set_tracks(base, ids, np.concatenate([ids[pick], stale]), np.concatenate([tid, [99.0]]), np.concatenate([tl, [[0, 0, 1, 1]]]),
-                     np.ones(len(pick) + 1))
-        for i in range(m):
-            expect[int(ids[i])] = (f, ltwh[i], None)
-        for k, i in enumerate(pick):
-            expect[int(ids[i])] = (f, ltwh[i], (tid[k], tl[k]))
-    df = t.to_dataframe(video_id=3)
-    assert len(df) == len(expect) and df.index.is_unique and (df.video_id == 3).all()
-    for det_id, (f, ltwh, trk) in expect.items():
-        row = df.loc[det_id]
-        assert row.image_id == f
-        np.testing.assert_array_equal(row.bbox_ltwh, ltwh)
-        if trk is None:
-            assert np.isnan(row.track_id) and np.isnan(row.track_bbox_ltwh).all()
-        else:
-            assert row.track_id == trk[0]
-            np.testing.assert_array_equal(row.track_bbox_ltwh, trk[1])

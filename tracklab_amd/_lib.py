@@ -548,6 +548,7 @@ def _bind_bytetrack(L):
     L.tlk_bytetrack_create.argtypes = [C.POINTER(ByteTrackParams), ci, ci, C.POINTER(vp)]
     L.tlk_bytetrack_destroy.argtypes = [vp]
     L.tlk_bytetrack_reset.argtypes = [vp, ci]
+    L.tlk_bytetrack_reset_keep_ids.argtypes = [vp, ci]
     L.tlk_bytetrack_update.argtypes = [vp, ci, vp, ci, vp, ci, C.POINTER(ci)]
     L.tlk_bytetrack_update_dev.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp]
     L.tlk_bytetrack_get_tracks.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, C.POINTER(ci)]
@@ -581,8 +582,9 @@ class ByteTrackBank:
         except Exception:
             pass
 
-    def reset(self, stream=-1):
-        check(lib().tlk_bytetrack_reset(self._h, stream))
+    def reset(self, stream=-1, keep_ids=False):
+        """keep_ids: state dropped but the id counter keeps counting, like the reference's class-level BaseTrack._count (basetrack.py:13,35-37)."""
+        check((lib().tlk_bytetrack_reset_keep_ids if keep_ids else lib().tlk_bytetrack_reset)(self._h, stream))
 
     def update(self, dets, stream=0):
         dets = _f64(dets).reshape(-1, 7)
@@ -625,6 +627,7 @@ def _bind_botsort(L):
     L.tlk_botsort_create.argtypes = [C.POINTER(BoTSORTParams), ci, ci, C.POINTER(vp)]
     L.tlk_botsort_destroy.argtypes = [vp]
     L.tlk_botsort_reset.argtypes = [vp, ci]
+    L.tlk_botsort_reset_keep_ids.argtypes = [vp, ci]
     L.tlk_botsort_update.argtypes = [vp, ci, vp, vp, ci, vp, ci, C.POINTER(ci)]
     L.tlk_botsort_update_dev.argtypes = [vp, vp, vp, vp, ci, vp, ci, vp, vp]
     L.tlk_botsort_update_gmc.argtypes = [vp, ci, vp, vp, ci, vp, vp, ci, C.POINTER(ci)]
@@ -666,8 +669,9 @@ class BoTSORTBank:
         except Exception:
             pass
 
-    def reset(self, stream=-1):
-        check(lib().tlk_botsort_reset(self._h, stream))
+    def reset(self, stream=-1, keep_ids=False):
+        """keep_ids: state dropped but the id counter keeps counting, like the reference's class-level BaseTrack._count."""
+        check((lib().tlk_botsort_reset_keep_ids if keep_ids else lib().tlk_botsort_reset)(self._h, stream))
 
     def update(self, dets, feats, stream=0, warp=None):
         """warp: the frame's (2,3) camera-motion matrix (GMC.apply's return value, bot_sort.py:341) or None for the identity."""

@@ -511,13 +511,13 @@ botsort_kernel(BoDev Dv, BoP P, BoIn in, tlk_botsort_row *__restrict__ rows_all,
     if (tid == 0) { const int err = hdr[OH_ERR]; *out_count = err != 0 ? err : (nrows > out_cap ? TLK_ECAPACITY : nrows); }
 }
 
-__global__ void botsort_reset_kernel(BoDev D, int stream)
+__global__ void botsort_reset_kernel(BoDev D, int stream, int keep_ids)
 {
     const int s0 = stream < 0 ? 0 : stream, s1 = stream < 0 ? D.S : stream + 1;
     for (int s = s0 + blockIdx.x; s < s1; s += gridDim.x) {
         int *hdr = D.hdr + (size_t)s * OH_COUNT;
         for (int k = threadIdx.x; k < D.MAXT; k += blockDim.x) D.freestk[(size_t)s * D.MAXT + k] = D.MAXT - 1 - k;
-        if (threadIdx.x == 0) { hdr[OH_NTRK] = 0; hdr[OH_NLOST] = 0; hdr[OH_NFREE] = D.MAXT; hdr[OH_COUNT_ID] = 0; hdr[OH_FRAME] = 0; hdr[OH_ERR] = 0; }
+        if (threadIdx.x == 0) { hdr[OH_NTRK] = 0; hdr[OH_NLOST] = 0; hdr[OH_NFREE] = D.MAXT; if (!keep_ids) hdr[OH_COUNT_ID] = 0; hdr[OH_FRAME] = 0; hdr[OH_ERR] = 0; }
     }
 }
 
@@ -623,7 +623,7 @@ extern "C" int tlk_botsort_create(const tlk_botsort_params *p, int n_streams, in
     if (e == hipSuccess) e = hipMemset(D.feat, 0, sizeof(float) * slots * D.D);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)botsort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem);
     if (e != hipSuccess) { bo_free(h); return fail(TLK_EHIP, std::string("tlk_botsort_create: ") + hipGetErrorString(e)); }
-    hipLaunchKernelGGL(botsort_reset_kernel, dim3(n_streams < 256 ? n_streams : 256), dim3(BLOCK), 0, 0, D, -1);
+    hipLaunchKernelGGL(botsort_reset_kernel, dim3(n_streams < 256 ? n_streams : 256), dim3(BLOCK), 0, 0, D, -1, 0);
     e = hipDeviceSynchronize();
     if (e != hipSuccess) { bo_free(h); return fail(TLK_EHIP, std::string("tlk_botsort_create: ") + hipGetErrorString(e)); }
     *out = h;
@@ -632,16 +632,19 @@ extern "C" int tlk_botsort_create(const tlk_botsort_params *p, int n_streams, in
 
 extern "C" int tlk_botsort_destroy(tlk_botsort *h) { bo_free(h); return TLK_OK; }
 
-extern "C" int tlk_botsort_reset(tlk_botsort *h, int stream)
+static int botsort_reset_impl(tlk_botsort *h, int stream, int keep_ids)
 {
     if (!h) return fail(TLK_EINVAL, "tlk_botsort_reset: null handle");
     if (stream >= h->D.S) return fail(TLK_EINVAL, "tlk_botsort_reset: stream out of range");
     TLK_HIP(hipSetDevice(h->device));
-    hipLaunchKernelGGL(botsort_reset_kernel, dim3(stream < 0 ? (h->D.S < 256 ? h->D.S : 256) : 1), dim3(BLOCK), 0, 0, h->D, stream);
+    hipLaunchKernelGGL(botsort_reset_kernel, dim3(stream < 0 ? (h->D.S < 256 ? h->D.S : 256) : 1), dim3(BLOCK), 0, 0, h->D, stream, keep_ids);
     TLK_HIP(hipGetLastError());
     TLK_HIP(hipStreamSynchronize(0));
     return TLK_OK;
 }
+
+extern "C" int tlk_botsort_reset(tlk_botsort *h, int stream) { return botsort_reset_impl(h, stream, 0); }
+extern "C" int tlk_botsort_reset_keep_ids(tlk_botsort *h, int stream) { return botsort_reset_impl(h, stream, 1); }
 
 extern "C" int tlk_botsort_update_dev_gmc(tlk_botsort *h, const double *dets_dev, const float *feats_dev, const int32_t *counts_dev, const double *warps_dev,
                                           int n_frames, tlk_botsort_row *rows_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream)

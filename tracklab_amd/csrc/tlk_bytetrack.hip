@@ -308,13 +308,13 @@ bytetrack_kernel(ByDev Dv, ByP P, ByIn in, tlk_bytetrack_row *__restrict__ rows_
     if (tid == 0) *out_count = nrows > out_cap ? TLK_ECAPACITY : nrows;
 }
 
-__global__ void bytetrack_reset_kernel(ByDev D, int stream)
+__global__ void bytetrack_reset_kernel(ByDev D, int stream, int keep_ids)
 {
     const int s0 = stream < 0 ? 0 : stream, s1 = stream < 0 ? D.S : stream + 1;
     for (int s = s0 + blockIdx.x; s < s1; s += gridDim.x) {
         int *hdr = D.hdr + (size_t)s * YH_COUNT;
         for (int k = threadIdx.x; k < D.MAXT; k += blockDim.x) D.freestk[(size_t)s * D.MAXT + k] = D.MAXT - 1 - k;
-        if (threadIdx.x == 0) { hdr[YH_NTRK] = 0; hdr[YH_NLOST] = 0; hdr[YH_NFREE] = D.MAXT; hdr[YH_COUNT_ID] = 0; hdr[YH_FRAME] = 0; hdr[YH_ERR] = 0; }
+        if (threadIdx.x == 0) { hdr[YH_NTRK] = 0; hdr[YH_NLOST] = 0; hdr[YH_NFREE] = D.MAXT; if (!keep_ids) hdr[YH_COUNT_ID] = 0; hdr[YH_FRAME] = 0; hdr[YH_ERR] = 0; }
     }
 }
 
@@ -396,7 +396,7 @@ extern "C" int tlk_bytetrack_create(const tlk_bytetrack_params *p, int n_streams
     if (e == hipSuccess) e = hipMemset(D.fi, 0, sizeof(int) * YI_COUNT * slots);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)bytetrack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem);
     if (e != hipSuccess) { by_free(h); return fail(TLK_EHIP, std::string("tlk_bytetrack_create: ") + hipGetErrorString(e)); }
-    hipLaunchKernelGGL(bytetrack_reset_kernel, dim3(n_streams < 256 ? n_streams : 256), dim3(BLOCK), 0, 0, D, -1);
+    hipLaunchKernelGGL(bytetrack_reset_kernel, dim3(n_streams < 256 ? n_streams : 256), dim3(BLOCK), 0, 0, D, -1, 0);
     e = hipDeviceSynchronize();
     if (e != hipSuccess) { by_free(h); return fail(TLK_EHIP, std::string("tlk_bytetrack_create: ") + hipGetErrorString(e)); }
     *out = h;
@@ -405,16 +405,19 @@ extern "C" int tlk_bytetrack_create(const tlk_bytetrack_params *p, int n_streams
 
 extern "C" int tlk_bytetrack_destroy(tlk_bytetrack *h) { by_free(h); return TLK_OK; }
 
-extern "C" int tlk_bytetrack_reset(tlk_bytetrack *h, int stream)
+static int bytetrack_reset_impl(tlk_bytetrack *h, int stream, int keep_ids)
 {
     if (!h) return fail(TLK_EINVAL, "tlk_bytetrack_reset: null handle");
     if (stream >= h->D.S) return fail(TLK_EINVAL, "tlk_bytetrack_reset: stream out of range");
     TLK_HIP(hipSetDevice(h->device));
-    hipLaunchKernelGGL(bytetrack_reset_kernel, dim3(stream < 0 ? (h->D.S < 256 ? h->D.S : 256) : 1), dim3(BLOCK), 0, 0, h->D, stream);
+    hipLaunchKernelGGL(bytetrack_reset_kernel, dim3(stream < 0 ? (h->D.S < 256 ? h->D.S : 256) : 1), dim3(BLOCK), 0, 0, h->D, stream, keep_ids);
     TLK_HIP(hipGetLastError());
     TLK_HIP(hipStreamSynchronize(0));
     return TLK_OK;
 }
+
+extern "C" int tlk_bytetrack_reset(tlk_bytetrack *h, int stream) { return bytetrack_reset_impl(h, stream, 0); }
+extern "C" int tlk_bytetrack_reset_keep_ids(tlk_bytetrack *h, int stream) { return bytetrack_reset_impl(h, stream, 1); }
 
 extern "C" int tlk_bytetrack_update_dev(tlk_bytetrack *h, const double *dets_dev, const int32_t *counts_dev, int n_frames,
                                         tlk_bytetrack_row *rows_dev, int out_cap, int32_t *out_counts_dev, void *hip_stream)

@@ -164,12 +164,13 @@ class HipByteTrack(ImageLevelModule):
                              max_dets=int(cfg_get(self.cfg, "max_dets", 128)))
 
     def reset(self):
-        """New video (byte_track_api.py:29-31 rebuilds the tracker). The reference's id counter is class-level and keeps
-        counting across videos; here ids restart at 1 per video like every other tracker."""
+        """New video (byte_track_api.py:29-31 rebuilds the tracker). The reference's id counter is class-level (BaseTrack._count,
+        byte_track/basetrack.py:13,35-37) and keeps counting across videos: so does this one (``reset_ids_per_video: true`` in the yaml
+        restarts at 1 instead)."""
         if self._bank is None:
             self._bank = self._make_backend()
         else:
-            self._bank.reset(-1)
+            self._bank.reset(-1, keep_ids=not bool(cfg_get(self.cfg, "reset_ids_per_video", False)))
 
     preprocess = HipOCSORT.preprocess          # same (N, 7) [*ltrb, conf, cls, tracklab_id] rows (byte_track_api.py:33-50)
 
@@ -225,8 +226,10 @@ class _ReidTrackerBase:
             ckpt = cfg_get(self.cfg, "model_weights", None)
             if ckpt:
                 import os
-                if os.path.exists(str(ckpt)):
-                    self._model.load_state_dict(torch.load(str(ckpt), map_location=self.device))
+                if not os.path.exists(str(ckpt)):       # never fall back to random weights silently (the reference's OSNet / BPBReID
+                    raise FileNotFoundError(             # checkpoints are not loadable either: INTEGRATION.md "checkpoints")
+                        f"model_weights {ckpt!r} does not exist; set model_weights: null to run with random-init weights (throughput only)")
+                self._model.load_state_dict(torch.load(str(ckpt), map_location=self.device))
         frames = (image if hasattr(image, "detach") else torch.from_numpy(np.asarray(image))).to(self.device)
         if frames.dim() == 3:
             frames = frames[None]
@@ -352,7 +355,13 @@ class HipBoTSORT(ImageLevelModule, _ReidTrackerBase):
     input_columns = ["bbox_ltwh", "bbox_conf", "category_id"]
     output_columns = ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
     _conf_field = "score"
-    preprocess, process, reset = _ReidTrackerBase.preprocess, _ReidTrackerBase.process, _ReidTrackerBase.reset    # ahead of the abstract ones in the MRO
+    preprocess, process = _ReidTrackerBase.preprocess, _ReidTrackerBase.process    # ahead of the abstract ones in the MRO
+
+    def reset(self):
+        """New video: state dropped; the id counter keeps counting like the reference's class-level BaseTrack._count
+        (bot_sort/basetrack.py) unless ``reset_ids_per_video: true``."""
+        if self._bank is not None:
+            self._bank.reset(-1, keep_ids=not bool(cfg_get(self.cfg, "reset_ids_per_video", False)))
 
     def __init__(self, cfg, device, **kwargs):
         super().__init__(batch_size=1)
