@@ -34,6 +34,7 @@ struct BpbDev {
     double *reid;            // S x MAXT x MAXD    part-based distance, row = list position, col = input detection index
     double *gl;              // S x MAXT x GLN     per track: projected mean (4) + Cholesky factor (16) for gating, OKS scale + count
     double *cost_g;          // S x MAXT x MAXD    cost-matrix spill
+    int *ema_list, *ema_n;   // S x MAXD x 2 (slot, input detection index) / S: matches of the frame, consumed by bpbss_ema_kernel
     long long *prof;         // optional S x 16 phase accumulators in 100 MHz ticks (diagnostics: TLK_BPBSS_PROF)
     int *ps_ws;              // S x 4 x ps_cap      hash tables of the set-order emulation when they do not fit the LDS cost area
     int S, MAXT, MAXD, K, D, cost_lds_entries, ps_cap;
@@ -247,6 +248,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
     const size_t dbase = (size_t)s * in.stream_stride_dets;
     const int n_in = in.counts[(size_t)s * in.count_stride];
 
+    if (tid == 0) Dv.ema_n[s] = 0;                       // nothing for bpbss_ema_kernel unless matches are published below
     if (hdr[H_ERR] != 0) { if (tid == 0) *out_count = hdr[H_ERR]; return; }
     if (n_in > MAXD || n_in < 0) { if (tid == 0) { hdr[H_ERR] = TLK_ECAPACITY; *out_count = TLK_ECAPACITY; } return; }
     if (P.wrapper_mode && n_in == 0) { if (tid == 0) *out_count = 0; return; }      // bpbreid_strong_sort_api.py:103-104
@@ -325,15 +327,39 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             const int nu = block_compact(T, [&](int p) { return trk_at(order[p]).i(BI_STATE) != ST_CONFIRMED; },
                                          [&](int p, int pos) { L.bc[pos] = p; }, L.scan);
             double *cm = ((size_t)nc * N <= (size_t)Dv.cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
-            // gate_cost_matrix (linear_assignment.py:132-175) + thresholding (:54-55)
-            for (int e = tid; e < nc * N; e += BLOCK) {
-                const int r = e / N, j = e - r * N;
-                const int p = L.cand[r];
-                double c = reid[(size_t)p * MAXD + L.sel[j]];
-                const double gd = gating_from(gl + (size_t)p * GLN, L.dxyah + j * 4, gdim);
-                if (gd > CHI2INV95[gdim]) c = INFTY_COST;
-                c = P.mc_lambda * c + (1 - P.mc_lambda) * gd;
-                cm[e] = c > P.max_dist ? P.max_dist + 1e-5 : c;
+            // gate_cost_matrix (linear_assignment.py:132-175) + thresholding (:54-55). One wavefront per track row: the row's gate
+            // (projected mean + Cholesky factor, 20 doubles in HBM) sits in registers and the NEXT row's is already in flight while
+            // this one is computed -- the entry-per-thread loop re-read it for every entry and ran at the latency of ~25 dependent
+            // global loads per entry (70 us for 110 x 98)
+            {
+                const int wv = tid >> 6, lane = tid & 63;
+                const double chi = CHI2INV95[gdim];
+                double gA[20];
+                int r = wv;
+                if (r < nc) {
+                    const double *g = gl + (size_t)L.cand[r] * GLN;
+#pragma unroll
+                    for (int q = 0; q < 20; ++q) gA[q] = g[q];
+                }
+                for (; r < nc; r += NWAVES) {
+                    const int p = L.cand[r];
+                    double gB[20];
+                    const int rn = r + NWAVES;
+                    if (rn < nc) {
+                        const double *g = gl + (size_t)L.cand[rn] * GLN;
+#pragma unroll
+                        for (int q = 0; q < 20; ++q) gB[q] = g[q];
+                    }
+                    for (int j = lane; j < N; j += WAVE) {
+                        double c = reid[(size_t)p * MAXD + L.sel[j]];
+                        const double gd = gdim == 4 ? gating_reg<4>(gA, L.dxyah + j * 4) : gating_reg<2>(gA, L.dxyah + j * 4);
+                        if (gd > chi) c = INFTY_COST;
+                        c = P.mc_lambda * c + (1 - P.mc_lambda) * gd;
+                        cm[(size_t)r * N + j] = c > P.max_dist ? P.max_dist + 1e-5 : c;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 20; ++q) gA[q] = gB[q];
+                }
             }
             // all detections as columns: det_idx = identity -> reuse um_db as identity scratch
             for (int j = tid; j < N; j += BLOCK) L.um_db[j] = j;
@@ -452,43 +478,12 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             if (Kt.i(BI_STATE) == ST_TENTATIVE && hits >= P.n_init) Kt.i(BI_STATE) = ST_CONFIRMED;
         }
         BPB_PROF(6);                                      // Kalman update of the matched tracks
-        // visibility-aware EMA of the part embeddings (track.py:150-170). Flat float4 sweep over (match, part, d): every
-        // thread keeps 4 independent 16-byte loads in flight (the per-(match,part) wavefront loop it replaces was a chain of
-        // dependent global round trips). Visibility is read here and rewritten after the barrier below.
-        {
-            const float a_t = (float)P.ema_alpha, a_d = (float)(1 - P.ema_alpha);
-            const int D4 = D >> 2;
-            const int total = nm * K * D4;
-#pragma unroll 4
-            for (int e = tid; e < total; e += BLOCK) {
-                const int job = e / D4, d4 = e - job * D4;
-                const int k = job / K, p = job - k * K;
-                const int slot = order[L.m_t[k]], di = L.sel[L.m_d[k]];
-                const bool tv = fvisS[(size_t)slot * K + p] != 0, dv = in.vis[(dbase + di) * K + p] != 0;
-                const bool both = tv && dv, x = tv != dv;
-                const float et = (float)both * a_t + (float)(x && tv);
-                const float ed = (float)both * a_d + (float)(x && dv);
-                float4 *f = reinterpret_cast<float4 *>(featS + (size_t)slot * FD + (size_t)p * D) + d4;
-                const float4 df = *(reinterpret_cast<const float4 *>(in.emb + (dbase + di) * FD + (size_t)p * D) + d4);
-                float4 o;
-                if (et == 0.f && ed == 0.f) { o.x = 1.f; o.y = 1.f; o.z = 1.f; o.w = 1.f; }
-                else {
-                    const float4 tf = *f;
-                    float a, b;
-                    a = et * tf.x; b = ed * df.x; o.x = a + b;
-                    a = et * tf.y; b = ed * df.y; o.y = a + b;
-                    a = et * tf.z; b = ed * df.z; o.z = a + b;
-                    a = et * tf.w; b = ed * df.w; o.w = a + b;
-                }
-                *f = o;
-            }
-            __syncthreads();
-            for (int job = tid; job < nm * K; job += BLOCK) {
-                const int k = job / K, p = job - k * K;
-                const int slot = order[L.m_t[k]], di = L.sel[L.m_d[k]];
-                if (in.vis[(dbase + di) * K + p] != 0) fvisS[(size_t)slot * K + p] = 1;       // max(tv, dv)
-            }
-        }
+        // visibility-aware EMA of the part embeddings (track.py:150-170): 0.6 MB read + written per side per frame -- far too much for
+        // ONE workgroup (it ran at 18 GB/s: 102 us of a 440 us frame). The association kernel only publishes the match list
+        // (slot, input detection index); bpbss_ema_kernel, launched right behind it on the same stream, sweeps it with one
+        // wavefront per (match, part) across the whole chip.
+        for (int k = tid; k < nm; k += BLOCK) { Dv.ema_list[((size_t)s * MAXD + k) * 2] = order[L.m_t[k]]; Dv.ema_list[((size_t)s * MAXD + k) * 2 + 1] = L.sel[L.m_d[k]]; }
+        if (tid == 0) Dv.ema_n[s] = nm;
         BPB_PROF(7);                                      // embedding EMA
         for (int k = tid; k < n_umt; k += BLOCK) {            // mark_missed (track.py:181-187)
             const BTrk Kt = trk_at(order[L.um_t[k]]);
@@ -498,7 +493,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
         __syncthreads();
         // _initiate_track (tracker.py:427-441) in the order of unmatched_detections
         int nfree = hdr[H_NFREE], nextid = hdr[H_NEXTID];
-        if (T + n_umd > MAXT) { if (tid == 0) { hdr[H_ERR] = TLK_ECAPACITY; *out_count = TLK_ECAPACITY; } return; }
+        if (T + n_umd > MAXT) { if (tid == 0) { hdr[H_ERR] = TLK_ECAPACITY; *out_count = TLK_ECAPACITY; Dv.ema_n[s] = 0; } return; }
         for (int k = tid; k < n_umd; k += BLOCK) {
             const int j = um_d_final[k];
             const int slot = freestk[nfree - 1 - k];
@@ -562,6 +557,41 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
     if (tid == 0) *out_count = nrows > out_cap ? TLK_ECAPACITY : nrows;
     BPB_PROF(9);                                          // deaths + output rows
 #undef BPB_PROF
+}
+
+// visibility-aware EMA of the part embeddings of the matched tracks (track.py:150-170): one wavefront per (match, part);
+// rows with both weights zero are set to 1 (:166-169); the track's visibility becomes max(track, detection) (:170)
+__global__ void __launch_bounds__(BLOCK) bpbss_ema_kernel(BpbDev Dv, BpbP P, FrameIn in)
+{
+    const int s = blockIdx.y, K = Dv.K, D = Dv.D;
+    const int nm = Dv.ema_n[s];
+    const int job = blockIdx.x * NWAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (job >= nm * K) return;
+    const int k = job / K, p = job - k * K;
+    const int slot = Dv.ema_list[((size_t)s * Dv.MAXD + k) * 2], di = Dv.ema_list[((size_t)s * Dv.MAXD + k) * 2 + 1];
+    const size_t FD = (size_t)K * D, dbase = (size_t)s * in.stream_stride_dets;
+    unsigned char *tvp = Dv.fvis + ((size_t)s * Dv.MAXT + slot) * K + p;
+    const bool tv = *tvp != 0, dv = in.vis[(dbase + di) * K + p] != 0;
+    const bool both = tv && dv, x = tv != dv;
+    const float a_t = (float)P.ema_alpha, a_d = (float)(1 - P.ema_alpha);
+    const float et = (float)both * a_t + (float)(x && tv);
+    const float ed = (float)both * a_d + (float)(x && dv);
+    float4 *f = reinterpret_cast<float4 *>(Dv.feat + ((size_t)s * Dv.MAXT + slot) * FD + (size_t)p * D);
+    const float4 *df = reinterpret_cast<const float4 *>(in.emb + (dbase + di) * FD + (size_t)p * D);
+    for (int d4 = lane; d4 < (D >> 2); d4 += WAVE) {
+        float4 o;
+        if (et == 0.f && ed == 0.f) { o.x = 1.f; o.y = 1.f; o.z = 1.f; o.w = 1.f; }
+        else {
+            const float4 tf = f[d4], dd = df[d4];
+            float a, b;
+            a = et * tf.x; b = ed * dd.x; o.x = a + b;
+            a = et * tf.y; b = ed * dd.y; o.y = a + b;
+            a = et * tf.z; b = ed * dd.z; o.z = a + b;
+            a = et * tf.w; b = ed * dd.w; o.w = a + b;
+        }
+        f[d4] = o;
+    }
+    if (lane == 0 && dv) *tvp = 1;
 }
 
 __global__ void bpbss_reset_kernel(BpbDev D, int stream)
@@ -705,7 +735,7 @@ static void bpb_free(tlk_bpbss *h)
     if (!h) return;
     hipSetDevice(h->device);
     BpbDev &D = h->D;
-    void *ptrs[] = {D.fd, D.fi, D.detid, D.hdr, D.order, D.freestk, D.feat, D.fvis, D.tnorm, D.dnorm, D.reid, D.gl, D.cost_g, D.ps_ws, D.prof,
+    void *ptrs[] = {D.fd, D.fi, D.detid, D.hdr, D.order, D.freestk, D.feat, D.fvis, D.tnorm, D.dnorm, D.reid, D.gl, D.cost_g, D.ps_ws, D.prof, D.ema_list, D.ema_n,
                     h->d_ids, h->d_ltwh, h->d_emb, h->d_vis, h->d_conf, h->d_kps, h->d_cnt, h->d_ocnt, h->d_rows};
     for (void *p : ptrs) if (p) hipFree(p);
     delete h;
@@ -720,6 +750,7 @@ static int launch_frame(tlk_bpbss *h, const BpbDev &Dv, int n_streams, const Fra
     hipLaunchKernelGGL(partdist_kernel, dim3((Dv.MAXD + 15) / 16, (Dv.MAXT + 15) / 16, n_streams), dim3(64 * K), 0, st, Dv, in);
     hipLaunchKernelGGL(bpbss_assoc_kernel, dim3(n_streams), dim3(BLOCK), h->smem, st, Dv, h->P, in, rows, rows_stream_stride, out_cap,
                        out_counts, oc_stride);
+    hipLaunchKernelGGL(bpbss_ema_kernel, dim3((Dv.MAXD * K + NWAVES - 1) / NWAVES, n_streams), dim3(BLOCK), 0, st, Dv, h->P, in);
     TLK_HIP(hipGetLastError());
     return TLK_OK;
 }
@@ -769,6 +800,8 @@ extern "C" int tlk_bpbss_create(const tlk_bpbss_params *p, int n_streams, int de
     BPB_ALLOC(D.cost_g, sizeof(double) * slots * MAXD);
     D.ps_cap = (int)pyset::table_capacity((unsigned)MAXT);
     BPB_ALLOC(D.ps_ws, sizeof(int) * 4 * (size_t)D.ps_cap * n_streams);
+    BPB_ALLOC(D.ema_list, sizeof(int) * 2 * (size_t)MAXD * n_streams);
+    BPB_ALLOC(D.ema_n, sizeof(int) * n_streams);
     if (getenv("TLK_BPBSS_PROF")) { BPB_ALLOC(D.prof, sizeof(long long) * 16 * n_streams); hipMemset(D.prof, 0, sizeof(long long) * 16 * n_streams); }
     BPB_ALLOC(h->d_ids, sizeof(long long) * MAXD);
     BPB_ALLOC(h->d_ltwh, sizeof(double) * 4 * MAXD);
@@ -868,6 +901,7 @@ extern "C" int tlk_bpbss_update(tlk_bpbss *h, int stream, const int64_t *ids, co
     V.fd += sl; V.fi += sl; V.detid += sl; V.hdr += (size_t)stream * H_COUNT; V.order += sl; V.freestk += sl;
     V.feat += sl * FD; V.fvis += sl * V.K; V.tnorm += sl * V.K * 2; V.dnorm += (size_t)stream * V.MAXD * V.K * 2;
     V.reid += sl * V.MAXD; V.gl += sl * GLN; V.cost_g += sl * V.MAXD; V.ps_ws += (size_t)stream * 4 * V.ps_cap; if (V.prof) V.prof += (size_t)stream * 16;
+    V.ema_list += (size_t)stream * V.MAXD * 2; V.ema_n += stream;
     FrameIn in;
     in.ids = h->d_ids; in.ltwh = h->d_ltwh; in.emb = h->d_emb; in.vis = h->d_vis; in.conf = h->d_conf; in.counts = h->d_cnt;
     in.kps = kps ? h->d_kps : nullptr;

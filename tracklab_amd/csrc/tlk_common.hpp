@@ -270,19 +270,26 @@ __device__ __forceinline__ int wave_max_i32(int v)
     return ab > cd ? ab : cd;
 }
 
-template <int CPL>
-__device__ __noinline__ int wave_lsa_reg(const double *cost, int nr0, int nc0, size_t rs0, size_t cs0,
-                                         const LsaWork &W, int *rows_out, int *cols_out)
+// Address spaces matter here: through generic pointers every access of the solver became a flat_load / flat_store (and the LsaWork
+// members were re-read from the caller's stack inside the loops); with LDS-qualified pointers they are ds_read / ds_write with
+// immediate offsets and the work-area pointers stay in registers.
+#define TLK_LDS __attribute__((address_space(3)))
+#define TLK_GLOBAL __attribute__((address_space(1)))
+
+template <int CPL, typename CostPtr>
+__device__ __noinline__ int wave_lsa_reg(CostPtr cost, int nr0, int nc0, unsigned rs0, unsigned cs0,
+                                         TLK_LDS double *u_lds, TLK_LDS int *col4row, int *rows_out, int *cols_out)
 {
     const int lane = threadIdx.x & 63;
     const bool transpose = nc0 < nr0;
     const int nr = transpose ? nc0 : nr0, nc = transpose ? nr0 : nc0;
-    const size_t rs = transpose ? cs0 : rs0, cs = transpose ? rs0 : cs0;
+    const unsigned rs = transpose ? cs0 : rs0, cs = transpose ? rs0 : cs0;
     double v_[CPL], spc_[CPL];
     int r4c_[CPL], path_[CPL], pos_[CPL];
+    unsigned coff_[CPL];                                   // element offset of the lane's columns inside a cost row
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) { v_[c] = 0.0; r4c_[c] = -1; path_[c] = -1; }
-    for (int k = lane; k < nr; k += WAVE) { W.u[k] = 0.0; W.col4row[k] = -1; }
+    for (int c = 0; c < CPL; ++c) { v_[c] = 0.0; r4c_[c] = -1; path_[c] = -1; coff_[c] = (unsigned)(c * WAVE + lane) * cs; }
+    for (int k = lane; k < nr; k += WAVE) { u_lds[k] = 0.0; col4row[k] = -1; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     for (int cur = 0; cur < nr; ++cur) {
@@ -291,14 +298,17 @@ __device__ __noinline__ int wave_lsa_reg(const double *cost, int nr0, int nc0, s
         double minval = 0.0;
         int num_remaining = nc, i = cur, sink = -1;
         while (sink == -1) {
-            const double ui = W.u[i];
+            const double ui = u_lds[i];
+            const unsigned rbase = (unsigned)i * rs;
+            double cval[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) cval[c] = pos_[c] >= 0 ? cost[rbase + coff_[c]] : 0.0;      // all loads of the row in flight together
             double best = INFINITY;
             int best_s = -1, best_c = 0;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 if (pos_[c] >= 0) {
-                    const int j = c * WAVE + lane;
-                    const double r = minval + cost[(size_t)i * rs + (size_t)j * cs] - ui - v_[c];
+                    const double r = minval + cval[c] - ui - v_[c];
                     if (r < spc_[c]) { path_[c] = i; spc_[c] = r; }
                     const double sp = spc_[c];
                     const int s = (r4c_[c] == -1) ? (nc + pos_[c]) : (nc - 1 - pos_[c]);
@@ -335,11 +345,11 @@ __device__ __noinline__ int wave_lsa_reg(const double *cost, int nr0, int nc0, s
         for (int c = 0; c < CPL; ++c) {
             if (pos_[c] == -1) {
                 const double d = minval - spc_[c];
-                if (r4c_[c] != -1) W.u[r4c_[c]] += d;
+                if (r4c_[c] != -1) u_lds[r4c_[c]] += d;
                 v_[c] -= d;
             }
         }
-        if (lane == 0) W.u[cur] += minval;
+        if (lane == 0) u_lds[cur] += minval;
         // augment along path[] (uniform walk; owner lanes update their registers)
         int j = sink;
         for (;;) {
@@ -350,9 +360,9 @@ __device__ __noinline__ int wave_lsa_reg(const double *cost, int nr0, int nc0, s
             const int pi = __builtin_amdgcn_readlane(path_sel, l);
 #pragma unroll
             for (int q = 0; q < CPL; ++q) if (q == c && lane == l) r4c_[q] = pi;
-            const int old = W.col4row[pi];
+            const int old = col4row[pi];
             __builtin_amdgcn_wave_barrier();
-            if (lane == 0) W.col4row[pi] = j;
+            if (lane == 0) col4row[pi] = j;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             j = old;
@@ -362,7 +372,7 @@ __device__ __noinline__ int wave_lsa_reg(const double *cost, int nr0, int nc0, s
         __builtin_amdgcn_wave_barrier();
     }
     if (!transpose) {
-        for (int k = lane; k < nr; k += WAVE) { rows_out[k] = k; cols_out[k] = W.col4row[k]; }
+        for (int k = lane; k < nr; k += WAVE) { rows_out[k] = k; cols_out[k] = col4row[k]; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         return nr;
     }
@@ -379,16 +389,28 @@ __device__ __noinline__ int wave_lsa_reg(const double *cost, int nr0, int nc0, s
     return base;
 }
 
+template <typename CostPtr>
+__device__ __forceinline__ int wave_lsa_reg_cpl(CostPtr cost, int nr0, int nc0, size_t rs0, size_t cs0, const LsaWork &W, int *rows_out, int *cols_out)
+{
+    // the work area of every caller is carved out of its workgroup's LDS
+    TLK_LDS double *u = (TLK_LDS double *)W.u;
+    TLK_LDS int *c4r = (TLK_LDS int *)W.col4row;
+    const int mx = nr0 > nc0 ? nr0 : nc0;
+    if (mx <= 64) return wave_lsa_reg<1>(cost, nr0, nc0, (unsigned)rs0, (unsigned)cs0, u, c4r, rows_out, cols_out);
+    if (mx <= 128) return wave_lsa_reg<2>(cost, nr0, nc0, (unsigned)rs0, (unsigned)cs0, u, c4r, rows_out, cols_out);
+    if (mx <= 256) return wave_lsa_reg<4>(cost, nr0, nc0, (unsigned)rs0, (unsigned)cs0, u, c4r, rows_out, cols_out);
+    return wave_lsa_reg<8>(cost, nr0, nc0, (unsigned)rs0, (unsigned)cs0, u, c4r, rows_out, cols_out);
+}
+
 __device__ __forceinline__ int wave_lsa(const double *cost, int nr0, int nc0, size_t rs0, size_t cs0,
                                         const LsaWork &W, int *rows_out, int *cols_out)
 {
     if (nr0 == 0 || nc0 == 0) return 0;
     const int mx = nr0 > nc0 ? nr0 : nc0;
-    if (mx <= 64) return wave_lsa_reg<1>(cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);
-    if (mx <= 128) return wave_lsa_reg<2>(cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);
-    if (mx <= 256) return wave_lsa_reg<4>(cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);
-    if (mx <= 512) return wave_lsa_reg<8>(cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);
-    return wave_lsa_lds(cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);
+    if (mx > 512) return wave_lsa_lds(cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);
+    if (__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)cost))       // wave-uniform: the matrix sits in LDS ...
+        return wave_lsa_reg_cpl((const TLK_LDS double *)cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);
+    return wave_lsa_reg_cpl((const TLK_GLOBAL double *)cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);       // ... or spilled to HBM
 }
 
 #endif  // __HIPCC__

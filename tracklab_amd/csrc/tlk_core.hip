@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(BLOCK) pyset_difference_kernel(const int *__re
     if (threadIdx.x == 0) {
         int n = nu;
         if (na > 0 && (force_table || !pyset::ascending_is_exact(na, a[na - 1], nb, out, nu)))
-            n = pyset::difference_order_serial(a, na, in_b, nb, out, ws, cap);
+            n = pyset::difference_order_serial(a, na, in_b, nb, out, ws, cap, force_table > 1 ? -1 : nu);
         *n_out = n;
     }
 }

@@ -8,6 +8,10 @@
 
 #include "tlk_common.hpp"
 
+#include <map>
+#include <mutex>
+#include <type_traits>
+
 using namespace tlk;
 
 namespace {
@@ -384,21 +388,26 @@ __global__ void __launch_bounds__(BLOCK) crop_lds_kernel(const unsigned char *__
 // Separable form of the same crop -> cv2 INTER_LINEAR resize -> normalise (the fast path since round 2).
 // cv2's fixed-point bilinear is  S_r = p[r][x0]*a0 + p[r][x1]*a1  (11-bit weights) for the two source rows r = y0, y1, then
 // v = (((b0 * (S_y0 >> 4)) >> 16) + ((b1 * (S_y1 >> 4)) >> 16) + 2) >> 2.  H[r][x][c] = S_r >> 4 depends on the SOURCE row only, and
-// an upscaled crop (the normal case: boxes ~80 x 176 px -> 384 x 128) samples every source row from ~4.4 output rows. So a
-// workgroup = (slot, band of CS_BAND output rows)
-//   1. stages the band's source-row segments in LDS (one flat sweep of 16-byte loads, as crop_lds_kernel),
-//   2. runs the horizontal pass ONCE per (source row, x, channel): two byte taps packed in one register, one v_dot2_u32_u16
-//      against the packed (a0, a1), >> 4, stored as 16 bits in an LDS plane,
-//   3. runs the vertical pass per output value from 16-byte LDS reads of that plane: 2 mul24 + shifts + add, and turns the 8-bit
-//      result into the normalised output element through a 3 x 256 look-up table built per workgroup with exactly the
-//      reference's float arithmetic ((float)v - 255*mean) * (1/(255*std)) -> T): no per-value cvt/sub/mul/cvt.
-// ~9 VALU + ~2.5 LDS operations per output value instead of ~16 + 4. Padding slots (i >= counts[b]) are not touched at all.
-// Blocks are remapped so that the bands of one crop run on ONE XCD (blockIdx round-robins over the 8 XCDs; the bands share
-// source rows through that XCD's L2).
+// an upscaled crop (the normal case: boxes ~80 x 176 px -> 384 x 128) samples every source row from ~4.4 output rows. PMC counters
+// put round 1's kernel (and a first separable version) at ~620 VALU instructions per thread, 4 cycles each: issue-bound at 0.31 of
+// the HBM roof whatever the memory side did. This version is built around the instruction count. A workgroup = (slot, band of
+// CS_BAND output rows):
+//   0. wavefront 0 alone does the crop geometry (float64 clip + round, band row range) and the x / y coefficient tables and hands
+//      them over through LDS; wavefronts 1-3 meanwhile copy the normalisation table (below) into LDS;
+//   1. all: the band's source-row segments -> LDS (16-byte loads, lane = chunk, 8 rows per sweep: no index divisions);
+//   2. horizontal pass ONCE per (source row, x, channel): thread = one x (its tap offsets and packed weights stay in registers), loop
+//      over the staged rows: two byte taps packed in one register, one v_dot2_u32_u16 against (a0, a1), >> 4 -> 16-bit LDS plane;
+//   3. vertical pass per output value from 16-byte reads of that plane: two 24-bit multiplies and ONE add that picks the high halves
+//      (SDWA), then a table look-up: the table is indexed by t = (b0*H0 >> 16) + (b1*H1 >> 16) directly (t <= 1020) and holds
+//      T((float)((t + 2) >> 2) - 255*mean) * (1 / (255*std))) -- exactly the reference's float arithmetic, built once per
+//      (device, statistics, dtype) by a tiny kernel and cached;
+//   4. the band's output (ONE contiguous block for NHWC) is assembled in LDS and leaves as fully coalesced 16-byte stores.
+// Padding slots (i >= counts[b]) are not touched at all. Blocks are remapped so that the bands of one crop run on ONE XCD.
 // ---------------------------------------------------------------------------------------------
 constexpr int CS_BAND = 16;                            // output rows per workgroup
 constexpr int CS_ROWS = 18;                            // staged source rows: CS_BAND * scale + 2 <= 18 for scale <= 1 (up-scaling / same size)
-constexpr int CS_ROW_BYTES = 544;                      // as CROP_LDS_ROW_BYTES
+constexpr int CS_ROW_BYTES = 512;                      // 32 chunks of 16 bytes: crops up to 160 px wide
+constexpr int CS_LUT_N = 1024;                         // entries per channel (t <= 1020)
 
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 template <typename T> struct LutBits;
@@ -413,17 +422,38 @@ __host__ __device__ inline size_t crop_sep_region0(int OW, size_t elem)
     const size_t a = (size_t)CS_ROWS * CS_ROW_BYTES, b = (size_t)CS_BAND * OW * 3 * elem;
     return ((a > b ? a : b) + 15) & ~(size_t)15;
 }
-__host__ __device__ inline size_t crop_sep_lds_bytes(int OW, size_t elem) { return crop_sep_region0(OW, elem) + (size_t)CS_ROWS * OW * 3 * 2 + (size_t)OW * 8 + 3 * 256 * 4; }
+__host__ __device__ inline size_t crop_sep_lds_bytes(int OW, size_t elem)
+{
+    return crop_sep_region0(OW, elem) + (size_t)CS_ROWS * OW * 3 * 2 + (size_t)OW * 8 + (size_t)3 * CS_LUT_N * elem;
+}
 
-template <typename T, int LAYOUT>
+// lut[c][t] = T(((float)min((t + 2) >> 2, 255) - m[c]) * d[c]): float32 subtract then multiply, then the conversion -- value for
+// value what crop_kernel / the oracle compute per element
+template <typename T>
+__global__ void crop_lut_kernel(T *__restrict__ lut, float m0, float m1, float m2, float d0, float d1, float d2)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= CS_LUT_N) return;
+    const float mean[3] = {m0, m1, m2}, den[3] = {d0, d1, d2};
+    int v = (t + 2) >> 2;
+    v = v > 255 ? 255 : v;
+    for (int c = 0; c < 3; ++c) { float f = (float)v; f -= mean[c]; f *= den[c]; lut[c * CS_LUT_N + t] = cvt<T>(f); }
+}
+
+struct CropPar { int l, t, cw, ch, r_lo, nrows, staged, valid; };
+
+template <typename T, int LAYOUT, int OWC>
 __global__ void __launch_bounds__(BLOCK) crop_sep_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
                                                          const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
-                                                         int OH, int OW, float m0, float m1, float m2, float d0, float d1, float d2,
-                                                         T *__restrict__ out, int swap_rb, int nwg, int coalesce)
+                                                         int OH, int OW_rt, const T *__restrict__ lut_g, float m0, float m1, float m2,
+                                                         float d0, float d1, float d2, T *__restrict__ out, int swap_rb, int nwg)
 {
+    static_assert(BLOCK == 256, "thread <-> (x, row parity) mapping of the horizontal pass");
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    __shared__ int s_y0[CS_BAND], s_y1[CS_BAND], s_yw[CS_BAND], s_rsh[CS_ROWS];
-    static_assert(BLOCK == 256, "the look-up table is built one 8-bit value per thread");
+    __shared__ int s_y[CS_BAND * 2];                   // per band row: (index of staged row y0) | (y1 << 16), (b0 | b1 << 16)
+    __shared__ int s_rsh[CS_ROWS];                     // alignment shift of every staged row
+    __shared__ CropPar s_par;
+    const int OW = OWC ? OWC : OW_rt;
     const int tid = threadIdx.x;
     // bijective XCD-aware remap (cdna_hip_programming.md: block b runs on XCD b % 8)
     int wg;
@@ -437,38 +467,60 @@ __global__ void __launch_bounds__(BLOCK) crop_sep_kernel(const unsigned char *__
     if (i >= counts[b]) return;                         // padding slot: left untouched
     const int y_base = band * CS_BAND;
     const int nb = min(CS_BAND, OH - y_base);
-    const int groups_per_row = OW / 8;
-    int l, t, r, bt;
-    crop_ltrb(boxes + ((size_t)b * max_n + i) * 4, W, H, l, t, r, bt);
-    const bool valid = (r > l) && (bt > t);
-    const int cw = r - l, ch = bt - t;
+    const int groups_per_row = OW >> 3;
     const size_t R0 = crop_sep_region0(OW, sizeof(T));
     unsigned char *s_rows = s_dyn;
     unsigned short *s_h = reinterpret_cast<unsigned short *>(s_dyn + R0);
     int2 *s_xc = reinterpret_cast<int2 *>(s_dyn + R0 + (size_t)CS_ROWS * OW * 6);
-    using LB = typename LutBits<T>::type;
-    // look-up table: one 4-byte slot per (channel, 8-bit value) -- the byte address of an entry is ((sum + 2) & ~3), no shift pair
-    unsigned char *s_lut = s_dyn + R0 + (size_t)CS_ROWS * OW * 6 + (size_t)OW * 8;
+    T *s_lut = reinterpret_cast<T *>(s_dyn + R0 + (size_t)CS_ROWS * OW * 6 + (size_t)OW * 8);
     const int HS = OW * 3;                              // 16-bit elements per plane row
-    bool staged = false;
-    int r_lo = 0, nrows = 0;
-    double scale_y = 1.0, scale_x = 1.0;
-    if (valid) {
-        const int ylast = y_base + nb - 1;
-        scale_y = (double)ch / (double)OH; scale_x = (double)cw / (double)OW;
-        const Coef c_first = cv_coef_s(y_base, ch, scale_y, false), c_last = cv_coef_s(ylast, ch, scale_y, false);
-        r_lo = clampi(c_first.s, 0, ch - 1);
-        nrows = clampi(c_last.s + 1, 0, ch - 1) - r_lo + 1;
-        staged = nrows <= CS_ROWS && cw * 3 + STAGE_PAD <= CS_ROW_BYTES;
+    const size_t frame_off = (size_t)b * H * W * 3;
+    if (tid < WAVE) {
+        // ---- 0. geometry + coefficient tables: ONE wavefront (the float64 clip / round / scale arithmetic is ~150 instructions)
+        int l, t, r, bt;
+        crop_ltrb(boxes + ((size_t)b * max_n + i) * 4, W, H, l, t, r, bt);
+        const bool valid = (r > l) && (bt > t);
+        const int cw = r - l, ch = bt - t;
+        int r_lo = 0, nrows = 0;
+        bool staged = false;
+        if (valid) {
+            const double scale_y = (double)ch / (double)OH, scale_x = (double)cw / (double)OW;     // one fp64 division per axis
+            const Coef c_first = cv_coef_s(y_base, ch, scale_y, false), c_last = cv_coef_s(y_base + nb - 1, ch, scale_y, false);
+            r_lo = clampi(c_first.s, 0, ch - 1);
+            nrows = clampi(c_last.s + 1, 0, ch - 1) - r_lo + 1;
+            staged = nrows <= CS_ROWS && cw * 3 + STAGE_PAD <= CS_ROW_BYTES;
+            if (staged) {
+                for (int x = tid; x < OW; x += WAVE) {
+                    const Coef cx = cv_coef_s(x, cw, scale_x, true);
+                    s_xc[x] = make_int2((cx.s * 3) | ((cx.s + 1 < cw ? 3 : 0) << 16), (cx.w0 & 0xffff) | (cx.w1 << 16));
+                }
+                if (tid < nb) {
+                    const Coef cy = cv_coef_s(y_base + tid, ch, scale_y, false);
+                    s_y[tid * 2] = (clampi(cy.s, 0, ch - 1) - r_lo) | ((clampi(cy.s + 1, 0, ch - 1) - r_lo) << 16);
+                    s_y[tid * 2 + 1] = (cy.w0 & 0xffff) | (cy.w1 << 16);
+                }
+                if (tid < nrows) s_rsh[tid] = (int)((uintptr_t)(frames + frame_off + ((size_t)(t + r_lo + tid) * W + l) * 3) & 15);
+            }
+        }
+        if (tid == 0) { CropPar p; p.l = l; p.t = t; p.cw = cw; p.ch = ch; p.r_lo = r_lo; p.nrows = nrows; p.staged = staged; p.valid = valid; s_par = p; }
+    } else {
+        // wavefronts 1-3: the normalisation table -> LDS (16-byte chunks)
+        const int n16 = (int)(3 * CS_LUT_N * sizeof(T) / 16);
+        const uint4 *g = reinterpret_cast<const uint4 *>(lut_g);
+        uint4 *d = reinterpret_cast<uint4 *>(s_lut);
+        for (int c = tid - WAVE; c < n16; c += BLOCK - WAVE) d[c] = g[c];
     }
+    __syncthreads();
+    const CropPar par = s_par;
+    const bool staged = par.staged != 0, valid = par.valid != 0;
     if (staged) {
+        // ---- 1. source rows -> LDS: lane = 16-byte chunk of a row (32 per row), 8 rows per sweep
         const unsigned char *gend = frames + (size_t)B * H * W * 3;
-        const int cmax = (cw * 3 + 30) >> 4;
-        for (int idx = tid; idx < nrows * cmax; idx += BLOCK) {         // all (row, 16-byte chunk) pairs of the band in ONE sweep
-            const int rr = idx / cmax, c = idx - rr * cmax;
-            const unsigned char *g0 = frames + ((size_t)b * H * W + (size_t)(t + r_lo + rr) * W + l) * 3;
+        const int c = tid & 31;
+        for (int rr = tid >> 5; rr < par.nrows; rr += 8) {
+            const unsigned char *g0 = frames + frame_off + ((size_t)(par.t + par.r_lo + rr) * W + par.l) * 3;
             const uintptr_t a0 = (uintptr_t)g0 & ~(uintptr_t)15;
-            const int chunks = ((int)((uintptr_t)g0 - a0) + cw * 3 + 15) >> 4;
+            const int chunks = ((int)((uintptr_t)g0 - a0) + par.cw * 3 + 15) >> 4;
             if (c < chunks) {
                 const unsigned char *p = (const unsigned char *)a0 + (size_t)c * 16;
                 unsigned char *lds = s_rows + rr * CS_ROW_BYTES + c * 16;
@@ -476,57 +528,51 @@ __global__ void __launch_bounds__(BLOCK) crop_sep_kernel(const unsigned char *__
                 else for (int k = 0; k < 16 && p + k < gend; ++k) lds[k] = p[k];
             }
         }
-        if (tid < OW) {
-            const Coef cx = cv_coef_s(tid, cw, scale_x, true);
-            s_xc[tid] = make_int2((cx.s * 3) | ((cx.s + 1 < cw ? 3 : 0) << 16), (cx.w0 & 0xffff) | (cx.w1 << 16));
-        }
-        if (tid >= BLOCK - CS_BAND && tid - (BLOCK - CS_BAND) < nb) {
-            const int ry = tid - (BLOCK - CS_BAND);
-            const Coef cy = cv_coef_s(y_base + ry, ch, scale_y, false);
-            s_y0[ry] = clampi(cy.s, 0, ch - 1) - r_lo; s_y1[ry] = clampi(cy.s + 1, 0, ch - 1) - r_lo;
-            s_yw[ry] = (cy.w0 & 0xffff) | (cy.w1 << 16);
-        }
-        if (tid >= 64 && tid - 64 < nrows) {
-            const int rr = tid - 64;
-            s_rsh[rr] = (int)((uintptr_t)(frames + ((size_t)b * H * W + (size_t)(t + r_lo + rr) * W + l) * 3) & 15);
-        }
-        {   // the normalisation table, per SOURCE channel (swap_rb exchanges channels 0 and 2 at the store): the reference's
-            // float32 arithmetic value for value, then the conversion to T
-            const float mean[3] = {m0, m1, m2}, den[3] = {d0, d1, d2};
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float f = (float)tid; f -= mean[c]; f *= den[c];
-                const T v = cvt<T>(f);
-                *reinterpret_cast<LB *>(s_lut + (c * 256 + tid) * 4) = *reinterpret_cast<const LB *>(&v);
-            }
-        }
         __syncthreads();
-        // ---- horizontal pass: one (source row, x) per thread and iteration, three channels
-        for (int idx = tid; idx < nrows * OW; idx += BLOCK) {
-            const int rr = idx / OW, x = idx - rr * OW;
+        // ---- 2. horizontal pass: thread = one x, every (BLOCK / OW)-th staged row
+        if (OWC == 128) {
+            const int x = tid & 127;
             const int2 xc = s_xc[x];
             const int o0 = xc.x & 0xffff, o1 = o0 + (xc.x >> 16);
-            const unsigned char *p = s_rows + rr * CS_ROW_BYTES + s_rsh[rr];
             const us2_t A = __builtin_bit_cast(us2_t, xc.y);
-            unsigned short *o = s_h + rr * HS + x * 3;
+            for (int rr = tid >> 7; rr < par.nrows; rr += 2) {
+                const unsigned char *p = s_rows + rr * CS_ROW_BYTES + s_rsh[rr];
+                unsigned short *o = s_h + rr * HS + x * 3;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const unsigned int P = (unsigned int)p[o0 + c] | ((unsigned int)p[o1 + c] << 16);
-                o[c] = (unsigned short)(__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, P), A, 0u, false) >> 4);
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    const unsigned int P = (unsigned int)p[o0 + c3] | ((unsigned int)p[o1 + c3] << 16);
+                    o[c3] = (unsigned short)(__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, P), A, 0u, false) >> 4);
+                }
+            }
+        } else {
+            for (int idx = tid; idx < par.nrows * OW; idx += BLOCK) {
+                const int rr = idx / OW, x = idx - rr * OW;
+                const int2 xc = s_xc[x];
+                const int o0 = xc.x & 0xffff, o1 = o0 + (xc.x >> 16);
+                const unsigned char *p = s_rows + rr * CS_ROW_BYTES + s_rsh[rr];
+                const us2_t A = __builtin_bit_cast(us2_t, xc.y);
+                unsigned short *o = s_h + rr * HS + x * 3;
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    const unsigned int P = (unsigned int)p[o0 + c3] | ((unsigned int)p[o1 + c3] << 16);
+                    o[c3] = (unsigned short)(__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, P), A, 0u, false) >> 4);
+                }
             }
         }
         __syncthreads();
     }
-    const bool use_lds_store = coalesce && LAYOUT == LAYOUT_NHWC && ((size_t)OW * 3 * sizeof(T)) % 16 == 0;       // staged or not, uniform
-    // ---- vertical pass + normalisation: thread -> (row of the band, 8 consecutive x)
+    // ---- 3. vertical pass + normalisation: thread -> (row of the band, 8 consecutive x)
+    const bool use_lds_store = LAYOUT == LAYOUT_NHWC && ((size_t)OW * 3 * sizeof(T)) % 16 == 0;       // staged or not, uniform
     for (int unit = tid; unit < nb * groups_per_row; unit += BLOCK) {
-        const int ry = unit / groups_per_row, x_base = (unit - ry * groups_per_row) * 8;
+        const int ry = OWC == 128 ? (unit >> 4) : unit / groups_per_row;
+        const int x_base = (unit - ry * groups_per_row) * 8;
         const int y = y_base + ry;
         T px[8][3];
         if (staged) {
-            const uint4 *h0 = reinterpret_cast<const uint4 *>(s_h + s_y0[ry] * HS + x_base * 3);
-            const uint4 *h1 = reinterpret_cast<const uint4 *>(s_h + s_y1[ry] * HS + x_base * 3);
-            const unsigned int yw = (unsigned int)s_yw[ry], b0 = yw & 0xffffu, b1 = yw >> 16;
+            const unsigned int yi = (unsigned int)s_y[ry * 2], yw = (unsigned int)s_y[ry * 2 + 1];
+            const uint4 *h0 = reinterpret_cast<const uint4 *>(s_h + (yi & 0xffffu) * HS + x_base * 3);
+            const uint4 *h1 = reinterpret_cast<const uint4 *>(s_h + (yi >> 16) * HS + x_base * 3);
+            const unsigned int b0 = yw & 0xffffu, b1 = yw >> 16;
             unsigned int w0[12], w1[12];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -538,19 +584,22 @@ __global__ void __launch_bounds__(BLOCK) crop_sep_kernel(const unsigned char *__
             for (int q = 0; q < 24; ++q) {
                 const unsigned int a = (q & 1) ? (w0[q >> 1] >> 16) : (w0[q >> 1] & 0xffffu);
                 const unsigned int c1 = (q & 1) ? (w1[q >> 1] >> 16) : (w1[q >> 1] & 0xffffu);
-                // 4 * v with v = (.. + 2) >> 2 <= 255 always: H <= (255 * 2049) >> 4 and b0 + b1 <= 2049 bound the sum by 1020
-                const unsigned int v4 = ((__umul24(b0, a) >> 16) + (__umul24(b1, c1) >> 16) + 2u) & ~3u;
-                const LB bits = *reinterpret_cast<const LB *>(s_lut + (q % 3) * 1024 + v4);
-                px[q / 3][q % 3] = *reinterpret_cast<const T *>(&bits);
+                // t <= 1020 always: H <= (255 * 2049) >> 4 and b0 + b1 <= 2049
+                // (the compiler distributes the table's element size over the two shifted terms: 5 VALU per value; adding the two
+                //  HIGH HALVES in one SDWA add keeps it at 4)
+                const unsigned int xa = __umul24(b0, a), xb = __umul24(b1, c1);
+                unsigned int t;
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t) : "v"(xa), "v"(xb));
+                px[q / 3][q % 3] = s_lut[(q % 3) * CS_LUT_N + t];
             }
         } else if (valid) {
             const float mean[3] = {m0, m1, m2}, den[3] = {d0, d1, d2};
-            const unsigned char *base = frames + ((size_t)b * H * W + (size_t)t * W + l) * 3;
-            const Coef cy = cv_coef(y, ch, OH, false);
+            const unsigned char *base = frames + frame_off + ((size_t)par.t * W + par.l) * 3;
+            const Coef cy = cv_coef(y, par.ch, OH, false);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 int v[3];
-                sample3(base, W * 3, ch, cw, cy, cv_coef(x_base + k, cw, OW, true), v);
+                sample3(base, W * 3, par.ch, par.cw, cy, cv_coef(x_base + k, par.cw, OW, true), v);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { float f = (float)v[c]; f -= mean[c]; f *= den[c]; px[k][c] = cvt<T>(f); }
             }
@@ -572,20 +621,11 @@ __global__ void __launch_bounds__(BLOCK) crop_sep_kernel(const unsigned char *__
                 for (int k = 0; k < 8; ++k) p.v[k] = px[k][c];
                 *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)slot * 3 + c) * OH + y) * OW + x_base) = p;
             }
-        } else if (use_lds_store) {
+        } else {
             // NHWC: a thread's 24 elements are contiguous but 24 elements apart from its neighbour's, so a direct 16-byte store
             // instruction touches every 128-byte line of the band partially. The band's output (nb rows = ONE contiguous block of
             // memory) is put together in region 0 instead and leaves below as fully coalesced 16-byte stores.
-            T *o = reinterpret_cast<T *>(s_dyn) + ((size_t)ry * OW + x_base) * 3;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                Pack<T, 8> p;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
-                *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
-            }
-        } else {
-            T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
+            T *o = use_lds_store ? reinterpret_cast<T *>(s_dyn) + ((size_t)ry * OW + x_base) * 3 : out + (((size_t)slot * OH + y) * OW + x_base) * 3;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 Pack<T, 8> p;
@@ -614,7 +654,7 @@ __global__ void __launch_bounds__(BLOCK) crop_sep_kernel(const unsigned char *__
 // normalisation straight to 16-byte stores. Crops too large for the LDS planes take the direct (recompute) branch.
 // ---------------------------------------------------------------------------------------------
 constexpr int PIL_BITS = 32 - 8 - 2;
-constexpr int PIL_BAND = 16;
+constexpr int PIL_BAND = 32;                          // (16 rows measured slower: 428 vs 356 us -- twice the per-band set-up)
 constexpr int PIL_KMAX = 5;                           // taps per axis handled from LDS tables: scale <= 2
 constexpr int PIL_ROWS = 40;                          // staged source rows per band
 constexpr int PIL_ROW_BYTES = 544;                    // as CROP_LDS_ROW_BYTES: crops up to 170 px wide
@@ -690,7 +730,8 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
                                                          int max_n, int OH, int OW, float m0, float m1, float m2, float d0, float d1, float d2,
                                                          T *__restrict__ out, int swap_rb)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char s_rows[PIL_ROWS * PIL_ROW_BYTES];
+    // the source rows; afterwards the band's output on its way to coalesced stores (PIL_BAND rows x 128 px x 3 two-byte elements)
+    __shared__ __attribute__((aligned(16))) unsigned char s_rows[PIL_ROWS * PIL_ROW_BYTES > PIL_BAND * PIL_OW_MAX * 6 ? PIL_ROWS * PIL_ROW_BYTES : PIL_BAND * PIL_OW_MAX * 6];
     __shared__ __attribute__((aligned(16))) unsigned char s_h[PIL_ROWS * (PIL_OW_MAX * 3 + 16)];
     __shared__ int s_hmin[PIL_OW_MAX], s_hmax[PIL_OW_MAX], s_hk[PIL_OW_MAX][PIL_KMAX];
     __shared__ int s_vmin[PIL_BAND], s_vmax[PIL_BAND], s_vk[PIL_BAND][PIL_KMAX];
@@ -1202,6 +1243,30 @@ int launch_letterbox(const unsigned char *frames, int B, int H, int W, int S, in
     return TLK_OK;
 }
 
+// the normalisation table of crop_sep_kernel: built once per (device, statistics, element type) by crop_lut_kernel and kept for the
+// life of the process (3 x 1024 elements)
+struct CropLutKey { int dev, elem; float v[6]; bool operator<(const CropLutKey &o) const { return memcmp(this, &o, sizeof(*this)) < 0; } };
+template <typename T>
+const void *crop_lut(float m0, float m1, float m2, float d0, float d1, float d2)
+{
+    static std::mutex mu;
+    static std::map<CropLutKey, void *> cache;
+    CropLutKey k;
+    memset(&k, 0, sizeof(k));
+    if (hipGetDevice(&k.dev) != hipSuccess) return nullptr;
+    k.elem = (int)sizeof(T) * 4 + (std::is_same<T, bf16_t>::value ? 1 : 0);
+    k.v[0] = m0; k.v[1] = m1; k.v[2] = m2; k.v[3] = d0; k.v[4] = d1; k.v[5] = d2;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.find(k);
+    if (it != cache.end()) return it->second;
+    void *p = nullptr;
+    if (hipMalloc(&p, 3 * CS_LUT_N * sizeof(T)) != hipSuccess) { set_error("tlk_roi_crop_resize_norm: hipMalloc of the normalisation table failed"); return nullptr; }
+    hipLaunchKernelGGL((crop_lut_kernel<T>), dim3(CS_LUT_N / 256), dim3(256), 0, 0, (T *)p, m0, m1, m2, d0, d1, d2);
+    if (hipDeviceSynchronize() != hipSuccess) { hipFree(p); set_error("tlk_roi_crop_resize_norm: building the normalisation table failed"); return nullptr; }
+    cache[k] = p;
+    return p;
+}
+
 template <typename T>
 int launch_crop(const unsigned char *frames, int B, int H, int W, const float *boxes, const int *counts, int max_n, int OH, int OW,
                 const float *mean, const float *stdv, int layout, void *out, hipStream_t st, int swap_rb)
@@ -1214,13 +1279,15 @@ int launch_crop(const unsigned char *frames, int B, int H, int W, const float *b
     const float d0 = 1.0f / (stdv[sw0] * 255.f), d1 = 1.0f / (stdv[1] * 255.f), d2 = 1.0f / (stdv[sw2] * 255.f);
     static const int variant = [] { const char *e = getenv("TLK_CROP_KERNEL"); return e ? atoi(e) : 2; }();     // 2 separable (default), 1 round-1 LDS kernel, 0 direct
     if (variant == 2 && OW <= 256) {                       // separable fast path: workgroup = (slot, band of CS_BAND rows)
-        static const int coalesce = [] { const char *e = getenv("TLK_CROP_STORE"); return e ? atoi(e) : 1; }();     // 1: band output through LDS
+        const T *lut = (const T *)crop_lut<T>(m0, m1, m2, d0, d1, d2);
+        if (!lut) return TLK_EHIP;
         const int nwg = (int)((long long)B * max_n * ((OH + CS_BAND - 1) / CS_BAND));
         const size_t smem = crop_sep_lds_bytes(OW, sizeof(T));
-        if (layout == LAYOUT_NCHW)
-            hipLaunchKernelGGL((crop_sep_kernel<T, LAYOUT_NCHW>), dim3(nwg), dim3(BLOCK), smem, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg, coalesce);
-        else
-            hipLaunchKernelGGL((crop_sep_kernel<T, LAYOUT_NHWC>), dim3(nwg), dim3(BLOCK), smem, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg, coalesce);
+#define CROP_SEP_LAUNCH(LAY, OWC) hipLaunchKernelGGL((crop_sep_kernel<T, LAY, OWC>), dim3(nwg), dim3(BLOCK), smem, st, frames, B, H, W, boxes, counts, \
+                                                     max_n, OH, OW, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg)
+        if (layout == LAYOUT_NCHW) { if (OW == 128) CROP_SEP_LAUNCH(LAYOUT_NCHW, 128); else CROP_SEP_LAUNCH(LAYOUT_NCHW, 0); }
+        else { if (OW == 128) CROP_SEP_LAUNCH(LAYOUT_NHWC, 128); else CROP_SEP_LAUNCH(LAYOUT_NHWC, 0); }
+#undef CROP_SEP_LAUNCH
         return TLK_OK;
     }
     if (variant >= 1 && OW <= 256) {                       // round-1 LDS-staged path: workgroup = (slot, band of rows)

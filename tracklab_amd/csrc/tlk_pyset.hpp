@@ -117,29 +117,40 @@ __device__ inline void set_discard(Set &s, int key)                        // se
 
 // ONE thread: out[] = list(set(a) - set(b)) in CPython's order, a[0..na) distinct keys in insertion order, in_b[key] != 0 <=> key in b,
 // nb = len(set(b)), b a subset of a. ws = 4 * cap ints (cap >= table_capacity(na)). Returns len(out).
-__device__ inline int difference_order_serial(const int *a, int na, const int *in_b, int nb, int *out, int *ws, unsigned cap)
+// n_asc >= 0: out[0..n_asc) already holds the difference in ascending order (saves the membership sweep over a).
+__device__ inline int difference_order_serial(const int *a, int na, const int *in_b, int nb, int *out, int *ws, unsigned cap, int n_asc = -1)
 {
     Set A, R;
-    set_init(A, ws, ws + cap);
-    for (int i = 0; i < na; ++i) set_add(A, a[i]);
+    // while every key of a is below the size its table ends up with, key k sits in slot k: the table iterates in a's own (ascending)
+    // order and need not be built (the normal case -- what wraps is the small RESULT set); `ord(i)` = i-th key in a's iteration order
+    const bool a_plain = na == 0 || (unsigned)a[na - 1] < size_after_adds((unsigned)na);
+    unsigned a_mask = size_after_adds((unsigned)na) - 1, a_used = (unsigned)na;
+    if (!a_plain) {
+        set_init(A, ws, ws + cap);
+        for (int i = 0; i < na; ++i) set_add(A, a[i]);
+        a_mask = A.mask; a_used = A.used;
+    }
+    const unsigned a_slots = a_plain ? (unsigned)na : a_mask + 1;
+    auto a_at = [&](unsigned i) { return a_plain ? a[i] : A.t[i]; };        // < 0: empty slot
     int n = 0;
-    if ((A.used >> 2) > (unsigned)nb) {                                     // set_copy_and_difference
+    if ((a_used >> 2) > (unsigned)nb) {                                     // set_copy_and_difference
         set_init(R, ws + 2 * cap, ws + 3 * cap);
-        if (A.used != 0) {
-            if ((R.fill + A.used) * 5 >= R.mask * 3) {                      // set_merge's up-front resize of the (empty) target
+        if (a_used != 0) {
+            if ((R.fill + a_used) * 5 >= R.mask * 3) {                      // set_merge's up-front resize of the (empty) target
                 unsigned ns = 8;
-                while (ns <= A.used * 2) ns <<= 1;
+                while (ns <= a_used * 2) ns <<= 1;
                 for (unsigned i = 0; i < ns; ++i) R.t[i] = EMPTY;
                 R.mask = ns - 1;
             }
-            if (R.mask == A.mask) { for (unsigned i = 0; i <= A.mask; ++i) R.t[i] = A.t[i]; }
-            else { for (unsigned i = 0; i <= A.mask; ++i) if (A.t[i] >= 0) insert_clean(R.t, R.mask, A.t[i]); }
-            R.fill = R.used = A.used;
+            if (R.mask == a_mask && !a_plain) { for (unsigned i = 0; i <= a_mask; ++i) R.t[i] = A.t[i]; }
+            else { for (unsigned i = 0; i < a_slots; ++i) { const int k = a_at(i); if (k >= 0) insert_clean(R.t, R.mask, k); } }    // (a plain table copies to the same slots either way)
+            R.fill = R.used = a_used;
         }
         for (unsigned i = 0; i <= R.mask; ++i) if (R.t[i] >= 0 && !in_b[R.t[i]]) out[n++] = R.t[i];     // discards leave dummies in place
     } else {                                                                // set_difference: add every key of a that is not in b
         set_init(R, ws + 2 * cap, ws + 3 * cap);
-        for (unsigned i = 0; i <= A.mask; ++i) if (A.t[i] >= 0 && !in_b[A.t[i]]) set_add(R, A.t[i]);
+        if (a_plain && n_asc >= 0) { for (int i = 0; i < n_asc; ++i) set_add(R, out[i]); }
+        else for (unsigned i = 0; i < a_slots; ++i) { const int k = a_at(i); if (k >= 0 && !in_b[k]) set_add(R, k); }
         for (unsigned i = 0; i <= R.mask; ++i) if (R.t[i] >= 0) out[n++] = R.t[i];
     }
     return n;

@@ -132,6 +132,23 @@ __device__ __forceinline__ double gating_from(const double *glrow, const double 
     return acc;
 }
 
+// the same with the track's gate row in registers (fully unrolled: no dynamic indexing, same operation order)
+template <int DIM>
+__device__ __forceinline__ double gating_reg(const double (&g)[20], const double *m)
+{
+    double zz[DIM], acc = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) {
+        double v = m[i] - g[i];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) if (k < i) v -= g[4 + i * DIM + k] * zz[k];
+        zz[i] = v / g[4 + i * DIM + i];
+    }
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) acc += zz[i] * zz[i];
+    return acc;
+}
+
 __device__ __forceinline__ double iou_ltwh(const double *b, const double *c)     // sort/iou_matching.py:7-39
 {
     const double bbr0 = b[0] + b[2], bbr1 = b[1] + b[3], cbr0 = c[0] + c[2], cbr1 = c[1] + c[3];
@@ -248,7 +265,7 @@ __device__ int cascade_unmatched_tracks(const int *cand, int nc, int nmatched, i
     const int nu = block_compact(nc, [&](int r) { return L.rowf[cand[r]] == 0; }, [&](int r, int pos) { out[pos] = cand[r]; }, L.scan);
     __syncthreads();
     if (threadIdx.x == 0 && nc > 0 && !pyset::ascending_is_exact(nc, cand[nc - 1], nmatched, out, nu))
-        pyset::difference_order_serial(cand, nc, L.rowf, nmatched, out, ws, cap);
+        pyset::difference_order_serial(cand, nc, L.rowf, nmatched, out, ws, cap, nu);
     __syncthreads();
     return nu;
 }
