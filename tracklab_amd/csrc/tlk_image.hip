@@ -645,6 +645,227 @@ __global__ void __launch_bounds__(BLOCK) crop_sep_kernel(const unsigned char *__
 }
 
 // ---------------------------------------------------------------------------------------------
+// crop_fat_kernel: the same arithmetic as crop_sep_kernel for the ReID shape (OW = 128), but a workgroup owns CF_BANDS consecutive
+// bands of ONE crop. With a workgroup per band the kernel was bound by neither VALU issue nor HBM (the time did not move when the
+// VALU instruction count fell by 44 %): every workgroup ran geometry -> barrier -> global loads -> barrier -> horizontal ->
+// barrier -> vertical -> store as a ~6 us dependent chain with 4 workgroups per CU in flight, 55 rounds of that per launch.
+// Here geometry, the x table, the y tables of all CF_BANDS bands and the normalisation table are set up ONCE per workgroup, and
+// the source rows of band k+1 are already in flight (in registers) while band k goes through its vertical pass: two barriers per
+// band, no global-load latency on the critical path after the first band.
+// ---------------------------------------------------------------------------------------------
+constexpr int CF_BANDS = 8;
+
+// rare paths kept out of line so that their registers do not count against the main loop's occupancy
+__device__ __noinline__ uint4 load16_clipped(const unsigned char *p, const unsigned char *gend)     // 16 bytes at p, zero beyond gend
+{
+    unsigned int w[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 16 && p + k < gend; ++k) w[k >> 2] |= (unsigned int)p[k] << ((k & 3) * 8);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+template <typename T, int LAYOUT>
+__device__ __noinline__ void crop_direct_unit(const unsigned char *__restrict__ base, int W, int ch, int cw, int OH, int OW, int y, int x_base,
+                                              float m0, float m1, float m2, float d0, float d1, float d2, int swap_rb, T *__restrict__ out, size_t slot)
+{
+    const float mean[3] = {m0, m1, m2}, den[3] = {d0, d1, d2};
+    const Coef cy = cv_coef(y, ch, OH, false);
+    T px[8][3];
+    for (int k = 0; k < 8; ++k) {
+        int v[3];
+        sample3(base, W * 3, ch, cw, cy, cv_coef(x_base + k, cw, OW, true), v);
+        for (int c = 0; c < 3; ++c) { float f = (float)v[c]; f -= mean[c]; f *= den[c]; px[k][swap_rb ? 2 - c : c] = cvt<T>(f); }
+    }
+    for (int k = 0; k < 8; ++k)
+        for (int c = 0; c < 3; ++c) {
+            if (LAYOUT == LAYOUT_NCHW) out[((slot * 3 + c) * OH + y) * OW + x_base + k] = px[k][c];
+            else out[((slot * OH + y) * OW + x_base + k) * 3 + c] = px[k][c];
+        }
+}
+
+template <typename T, int LAYOUT>
+__global__ void __launch_bounds__(BLOCK) crop_fat_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
+                                                         const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
+                                                         int OH, const T *__restrict__ lut_g, float m0, float m1, float m2,
+                                                         float d0, float d1, float d2, T *__restrict__ out, int swap_rb, int nwg)
+{
+    static_assert(BLOCK == 256, "thread <-> (x, row parity) mapping of the horizontal pass");
+    constexpr int OW = 128, HS = OW * 3, GROUPS = OW / 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    __shared__ int s_y[CF_BANDS * CS_BAND * 2];         // per output row of the chunk: (source row y0 | y1 << 16) relative to the crop, (b0 | b1 << 16)
+    __shared__ int s_rsh[CS_ROWS];
+    __shared__ CropPar s_par;
+    const int tid = threadIdx.x;
+    int wg;
+    {
+        const int orig = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int bands = (OH + CS_BAND - 1) / CS_BAND, chunks = (bands + CF_BANDS - 1) / CF_BANDS;
+    const int slot = wg / chunks, chunk = wg - slot * chunks;
+    const int b = slot / max_n, i = slot - b * max_n;
+    if (i >= counts[b]) return;                         // padding slot: left untouched
+    const int band0 = chunk * CF_BANDS, nbands = min(CF_BANDS, bands - band0);
+    unsigned char *s_rows = s_dyn;
+    unsigned short *s_h = reinterpret_cast<unsigned short *>(s_dyn + CS_ROWS * CS_ROW_BYTES);
+    int2 *s_xc = reinterpret_cast<int2 *>(s_dyn + CS_ROWS * CS_ROW_BYTES + CS_ROWS * HS * 2);
+    T *s_lut = reinterpret_cast<T *>(s_dyn + CS_ROWS * CS_ROW_BYTES + CS_ROWS * HS * 2 + OW * 8);
+    const size_t frame_off = (size_t)b * H * W * 3;
+    // ---- set-up, once per workgroup: wave 0 geometry + x table, waves 1-2 the y tables of the chunk, wave 3 the normalisation table
+    if (tid < WAVE) {
+        int l, t, r, bt;
+        crop_ltrb(boxes + ((size_t)b * max_n + i) * 4, W, H, l, t, r, bt);
+        const bool valid = (r > l) && (bt > t);
+        const int cw = r - l, ch = bt - t;
+        const bool wide_ok = cw * 3 + STAGE_PAD <= CS_ROW_BYTES;
+        if (valid && wide_ok) {
+            const double scale_x = (double)cw / (double)OW;
+            for (int x = tid; x < OW; x += WAVE) {
+                const Coef cx = cv_coef_s(x, cw, scale_x, true);
+                s_xc[x] = make_int2((cx.s * 3) | ((cx.s + 1 < cw ? 3 : 0) << 16), (cx.w0 & 0xffff) | (cx.w1 << 16));
+            }
+        }
+        if (tid == 0) { CropPar p; p.l = l; p.t = t; p.cw = cw; p.ch = ch; p.r_lo = 0; p.nrows = 0; p.staged = wide_ok; p.valid = valid; s_par = p; }
+    } else if (tid < 3 * WAVE) {
+        int l, t, r, bt;
+        crop_ltrb(boxes + ((size_t)b * max_n + i) * 4, W, H, l, t, r, bt);
+        const int ch = bt - t, row = tid - WAVE, y = band0 * CS_BAND + row;
+        if (bt > t && r > l && y < OH && row < nbands * CS_BAND) {
+            const Coef cy = cv_coef_s(y, ch, (double)ch / (double)OH, false);
+            s_y[row * 2] = clampi(cy.s, 0, ch - 1) | (clampi(cy.s + 1, 0, ch - 1) << 16);
+            s_y[row * 2 + 1] = (cy.w0 & 0xffff) | (cy.w1 << 16);
+        }
+    } else {
+        const int n16 = (int)(3 * CS_LUT_N * sizeof(T) / 16);
+        const uint4 *g = reinterpret_cast<const uint4 *>(lut_g);
+        uint4 *d = reinterpret_cast<uint4 *>(s_lut);
+        for (int c = tid - 3 * WAVE; c < n16; c += WAVE) d[c] = g[c];
+    }
+    __syncthreads();
+    const CropPar par = s_par;
+    const bool valid = par.valid != 0;
+    const unsigned char *gend = frames + (size_t)B * H * W * 3;
+    const int c16 = tid & 31, rsub = tid >> 5;
+    uint4 stage[3];
+    int r_lo_next = 0, nrows_next = 0;
+    bool staged_next = false;
+    // source rows of band kb -> registers (lane = 16-byte chunk of a row, rows rsub, rsub + 8, rsub + 16)
+    auto fetch = [&](int kb) {
+        const int row_first = kb * CS_BAND, row_last = min(kb * CS_BAND + CS_BAND, OH - band0 * CS_BAND) - 1;
+        r_lo_next = s_y[row_first * 2] & 0xffff;
+        nrows_next = (int)((unsigned int)s_y[row_last * 2] >> 16) - r_lo_next + 1;
+        staged_next = par.staged && nrows_next <= CS_ROWS;
+        if (!staged_next) return;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int rr = rsub + 8 * j;
+            stage[j] = make_uint4(0, 0, 0, 0);
+            if (rr < nrows_next) {
+                const unsigned char *g0 = frames + frame_off + ((size_t)(par.t + r_lo_next + rr) * W + par.l) * 3;
+                const uintptr_t a0 = (uintptr_t)g0 & ~(uintptr_t)15;
+                const int nchunks = ((int)((uintptr_t)g0 - a0) + par.cw * 3 + 15) >> 4;
+                const unsigned char *p = (const unsigned char *)a0 + (size_t)c16 * 16;
+                if (c16 < nchunks) {
+                    if (p + 16 <= gend) stage[j] = *reinterpret_cast<const uint4 *>(p);
+                    else stage[j] = load16_clipped(p, gend);
+                }
+            }
+        }
+    };
+    if (valid) fetch(0);
+    for (int kb = 0; kb < nbands; ++kb) {
+        const int y_base = (band0 + kb) * CS_BAND, nb = min(CS_BAND, OH - y_base);
+        const int r_lo = r_lo_next, nrows = nrows_next;
+        const bool staged = valid && staged_next;
+        if (staged) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int rr = rsub + 8 * j;
+                if (rr < nrows) *reinterpret_cast<uint4 *>(s_rows + rr * CS_ROW_BYTES + c16 * 16) = stage[j];
+            }
+            if (tid < nrows) s_rsh[tid] = (int)((uintptr_t)(frames + frame_off + ((size_t)(par.t + r_lo + tid) * W + par.l) * 3) & 15);
+        }
+        __syncthreads();
+        if (staged) {                                   // horizontal pass: thread = one x, every second staged row
+            const int x = tid & 127;
+            const int2 xc = s_xc[x];
+            const int o0 = xc.x & 0xffff, o1 = o0 + (xc.x >> 16);
+            const us2_t A = __builtin_bit_cast(us2_t, xc.y);
+            for (int rr = tid >> 7; rr < nrows; rr += 2) {
+                const unsigned char *p = s_rows + rr * CS_ROW_BYTES + s_rsh[rr];
+                unsigned short *o = s_h + rr * HS + x * 3;
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    const unsigned int P = (unsigned int)p[o0 + c3] | ((unsigned int)p[o1 + c3] << 16);
+                    o[c3] = (unsigned short)(__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, P), A, 0u, false) >> 4);
+                }
+            }
+        }
+        __syncthreads();
+        if (valid && kb + 1 < nbands) fetch(kb + 1);    // in flight during the vertical pass
+        const int ry = tid >> 4, x_base = (tid & (GROUPS - 1)) * 8;
+        const int y = y_base + ry;
+        if (ry < nb && !staged) {
+            // crops too tall / wide for the staged path: direct sampling (mean / std per SOURCE channel were swapped on the host for swap_rb)
+            if (valid) crop_direct_unit<T, LAYOUT>(frames + frame_off + ((size_t)par.t * W + par.l) * 3, W, par.ch, par.cw, OH, OW, y, x_base, m0, m1, m2, d0, d1, d2,
+                                                   swap_rb, out, (size_t)slot);
+            else {
+                for (int k = 0; k < 8; ++k)
+                    for (int c = 0; c < 3; ++c) {
+                        if (LAYOUT == LAYOUT_NCHW) out[(((size_t)slot * 3 + c) * OH + y) * OW + x_base + k] = cvt<T>(0.f);
+                        else out[(((size_t)slot * OH + y) * OW + x_base + k) * 3 + c] = cvt<T>(0.f);
+                    }
+            }
+        } else if (ry < nb) {
+            T px[8][3];
+            {
+                const int row = kb * CS_BAND + ry;
+                const unsigned int yi = (unsigned int)s_y[row * 2], yw = (unsigned int)s_y[row * 2 + 1];
+                const uint4 *h0 = reinterpret_cast<const uint4 *>(s_h + ((yi & 0xffffu) - r_lo) * HS + x_base * 3);
+                const uint4 *h1 = reinterpret_cast<const uint4 *>(s_h + ((yi >> 16) - r_lo) * HS + x_base * 3);
+                const unsigned int b0 = yw & 0xffffu, b1 = yw >> 16;
+                unsigned int w0[12], w1[12];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const uint4 u = h0[k], v = h1[k];
+                    w0[k * 4] = u.x; w0[k * 4 + 1] = u.y; w0[k * 4 + 2] = u.z; w0[k * 4 + 3] = u.w;
+                    w1[k * 4] = v.x; w1[k * 4 + 1] = v.y; w1[k * 4 + 2] = v.z; w1[k * 4 + 3] = v.w;
+                }
+#pragma unroll
+                for (int q = 0; q < 24; ++q) {
+                    const unsigned int a = (q & 1) ? (w0[q >> 1] >> 16) : (w0[q >> 1] & 0xffffu);
+                    const unsigned int c1 = (q & 1) ? (w1[q >> 1] >> 16) : (w1[q >> 1] & 0xffffu);
+                    const unsigned int xa = __umul24(b0, a), xb = __umul24(b1, c1);
+                    unsigned int t;                     // t <= 1020 always (see crop_sep_kernel)
+                    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t) : "v"(xa), "v"(xb));
+                    px[q / 3][q % 3] = s_lut[(q % 3) * CS_LUT_N + t];
+                }
+            }
+            if (swap_rb) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const T t0 = px[k][0]; px[k][0] = px[k][2]; px[k][2] = t0; }
+            }
+            if (LAYOUT == LAYOUT_NCHW) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    Pack<T, 8> p;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) p.v[k] = px[k][c];
+                    *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)slot * 3 + c) * OH + y) * OW + x_base) = p;
+                }
+            } else {
+                T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    Pack<T, 8> p;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
+                    *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Plain StrongSORT's ReID input: crop ori_img[y1:y2, x1:x2] of the int-truncated, clipped box
 // (strong_sort.py:102-108, :135-141) -> Pillow Image.resize(BILINEAR) -> ToTensor -> Normalize
 // (reid_multibackend.py:44-52, :184-195). Pillow's resample (src/libImaging/Resample.c) is separable with an 8-bit
@@ -1285,6 +1506,17 @@ int launch_crop(const unsigned char *frames, int B, int H, int W, const float *b
         const size_t smem = crop_sep_lds_bytes(OW, sizeof(T));
 #define CROP_SEP_LAUNCH(LAY, OWC) hipLaunchKernelGGL((crop_sep_kernel<T, LAY, OWC>), dim3(nwg), dim3(BLOCK), smem, st, frames, B, H, W, boxes, counts, \
                                                      max_n, OH, OW, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg)
+        static const int fat = [] { const char *e = getenv("TLK_CROP_FAT"); return e ? atoi(e) : 1; }();       // 0: a workgroup per band (crop_sep_kernel)
+        if (OW == 128 && fat) {                            // the ReID shape: a workgroup per CF_BANDS bands of a crop
+            const int bands = (OH + CS_BAND - 1) / CS_BAND, chunks = (bands + CF_BANDS - 1) / CF_BANDS;
+            const int nwg2 = (int)((long long)B * max_n * chunks);
+            const size_t smem2 = (size_t)CS_ROWS * CS_ROW_BYTES + (size_t)CS_ROWS * 128 * 6 + 128 * 8 + (size_t)3 * CS_LUT_N * sizeof(T);
+            if (layout == LAYOUT_NCHW)
+                hipLaunchKernelGGL((crop_fat_kernel<T, LAYOUT_NCHW>), dim3(nwg2), dim3(BLOCK), smem2, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg2);
+            else
+                hipLaunchKernelGGL((crop_fat_kernel<T, LAYOUT_NHWC>), dim3(nwg2), dim3(BLOCK), smem2, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg2);
+            return TLK_OK;
+        }
         if (layout == LAYOUT_NCHW) { if (OW == 128) CROP_SEP_LAUNCH(LAYOUT_NCHW, 128); else CROP_SEP_LAUNCH(LAYOUT_NCHW, 0); }
         else { if (OW == 128) CROP_SEP_LAUNCH(LAYOUT_NHWC, 128); else CROP_SEP_LAUNCH(LAYOUT_NHWC, 0); }
 #undef CROP_SEP_LAUNCH
