@@ -46,4 +46,22 @@ for name, fn, hw, dt in (("crop 384x128 f16", lambda o: _lib.roi_crop_resize_nor
     ms = float(np.median([e0.elapsed_time(e1) for e0, e1 in ev]))
     alg = src + ncrops * 3 * hw[0] * hw[1] * out.element_size()
     res[name] = {"us": ms * 1e3, "alg_GBps": alg / (ms * 1e-3) / 1e9, "frac_of_8TBps": alg / (ms * 1e-3) / 8e12}
+# write roof on this box: a plain fill of the crop tensor (write-only, perfectly coalesced) and a copy (read + write)
+for name, shape, dt in (("fill 708MB f16", (B * MAXD, 384, 128, 3), torch.float16), ("fill 1.4GB f32", (B * MAXD, 384, 128, 3), torch.float32)):
+    t = torch.empty(shape, dtype=dt, device="cuda"); u = torch.empty_like(t)
+    for _ in range(3):
+        t.fill_(1.0); u.copy_(t)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for e0, e1 in ev:
+        e0.record(); t.fill_(1.0); e1.record()
+    torch.cuda.synchronize()
+    ms = float(np.median([e0.elapsed_time(e1) for e0, e1 in ev]))
+    for e0, e1 in ev:
+        e0.record(); u.copy_(t); e1.record()
+    torch.cuda.synchronize()
+    ms2 = float(np.median([e0.elapsed_time(e1) for e0, e1 in ev]))
+    nbytes = t.numel() * t.element_size()
+    res[name] = {"fill_us": ms * 1e3, "fill_GBps": nbytes / (ms * 1e-3) / 1e9, "copy_us": ms2 * 1e3, "copy_GBps_rw": 2 * nbytes / (ms2 * 1e-3) / 1e9}
+    del t, u
 print(json.dumps(res))

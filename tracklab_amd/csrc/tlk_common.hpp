@@ -270,6 +270,44 @@ __device__ __forceinline__ int wave_max_i32(int v)
     return ab > cd ? ab : cd;
 }
 
+// (mov_dpp, i.e. an UNDEFINED old operand, is what lets the compiler fold the lane rotation into the min / max itself:
+//  v_min_u32_dpp, one instruction per level instead of copy + rotate + min)
+__device__ __forceinline__ unsigned int wave_min_u32(unsigned int v)      // wave-uniform result
+{
+    v = min(v, (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0x121, 0xf, 0xf, true));
+    v = min(v, (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0x122, 0xf, 0xf, true));
+    v = min(v, (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xf, 0xf, true));
+    v = min(v, (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, true));
+    const unsigned int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const unsigned int ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+__device__ __forceinline__ int wave_max_i32_fast(int v)
+{
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x121, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x122, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x124, 0xf, 0xf, true));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, true));
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const int ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+// order-preserving map double -> (hi, lo) unsigned pair: numeric < on non-NaN doubles == lexicographic unsigned < on (hi, lo)
+__device__ __forceinline__ void f64_key(double x, unsigned int &hi, unsigned int &lo)
+{
+    const int h = __double2hiint(x);
+    const unsigned int m = (unsigned int)(h >> 31);
+    hi = (unsigned int)h ^ (m | 0x80000000u);
+    lo = (unsigned int)__double2loint(x) ^ m;
+}
+__device__ __forceinline__ double f64_unkey(unsigned int hi, unsigned int lo)
+{
+    const unsigned int m = (hi & 0x80000000u) ? 0u : 0xffffffffu;
+    return __hiloint2double((int)(hi ^ (m | 0x80000000u)), (int)(lo ^ m));
+}
+
 // Address spaces matter here: through generic pointers every access of the solver became a flat_load / flat_store (and the LsaWork
 // members were re-read from the caller's stack inside the loops); with LDS-qualified pointers they are ds_read / ds_write with
 // immediate offsets and the work-area pointers stay in registers.
@@ -288,7 +326,7 @@ __device__ __noinline__ int wave_lsa_reg(CostPtr cost, int nr0, int nc0, unsigne
     int r4c_[CPL], path_[CPL], pos_[CPL];
     unsigned coff_[CPL];                                   // element offset of the lane's columns inside a cost row
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) { v_[c] = 0.0; r4c_[c] = -1; path_[c] = -1; coff_[c] = (unsigned)(c * WAVE + lane) * cs; }
+    for (int c = 0; c < CPL; ++c) { v_[c] = 0.0; r4c_[c] = -1; path_[c] = -1; const int j = c * WAVE + lane; coff_[c] = (unsigned)(j < nc ? j : 0) * cs; }
     for (int k = lane; k < nr; k += WAVE) { u_lds[k] = 0.0; col4row[k] = -1; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -302,25 +340,39 @@ __device__ __noinline__ int wave_lsa_reg(CostPtr cost, int nr0, int nc0, unsigne
             const unsigned rbase = (unsigned)i * rs;
             double cval[CPL];
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) cval[c] = pos_[c] >= 0 ? cost[rbase + coff_[c]] : 0.0;      // all loads of the row in flight together
+            for (int c = 0; c < CPL; ++c) cval[c] = cost[rbase + coff_[c]];      // unconditional (offsets of absent columns point at column 0): all loads in flight together
+            // branch-free scan of the lane's columns (select instead of exec-mask regions), then the wave minimum through 32-bit
+            // DPP reductions of an order-preserving integer key (the fp64 compare-and-select ladder was ~60 dependent instructions)
             double best = INFINITY;
             int best_s = -1, best_c = 0;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
-                if (pos_[c] >= 0) {
-                    const double r = minval + cval[c] - ui - v_[c];
-                    if (r < spc_[c]) { path_[c] = i; spc_[c] = r; }
-                    const double sp = spc_[c];
-                    const int s = (r4c_[c] == -1) ? (nc + pos_[c]) : (nc - 1 - pos_[c]);
-                    if (sp < best || (sp == best && s > best_s)) { best = sp; best_s = s; best_c = c; }
-                }
+                const int pos = pos_[c];
+                const int act = -(int)(pos >= 0);                   // all-ones mask for a column still in `remaining`
+                const double r = minval + cval[c] - ui - v_[c];
+                const bool upd = (act != 0) & (r < spc_[c]);
+                path_[c] = upd ? i : path_[c];
+                spc_[c] = upd ? r : spc_[c];
+                const double sp = act ? spc_[c] : INFINITY;
+                // tie-break rank: an unassigned column ranks by nc + pos (the one scanned last wins), an assigned one by nc - 1 - pos
+                // (first scanned wins); -1 for a column that is out of the scan. Arithmetic only: no divergent regions.
+                const int un = -(int)(r4c_[c] == -1);
+                const int sr = ((nc + pos) & un) | ((nc - 1 - pos) & ~un);
+                const int s = (sr & act) | ~act;
+                const bool better = (sp < best) | ((sp == best) & (s > best_s));
+                best = better ? sp : best; best_s = better ? s : best_s; best_c = better ? c : best_c;
             }
-            minval = wave_min_f64(best);
+            unsigned int khi, klo;
+            f64_key(best + 0.0, khi, klo);                          // + 0.0: -0.0 and +0.0 compare equal, so must their keys
+            const unsigned int mhi = wave_min_u32(khi);
+            const unsigned int mlo = wave_min_u32(khi == mhi ? klo : 0xffffffffu);
+            minval = f64_unkey(mhi, mlo);
             if (!(minval < INFINITY)) return -1;                    // infeasible
-            unsigned long long m_eq = __ballot(best == minval && best_s >= 0);
+            const bool is_min = khi == mhi && klo == mlo;
+            unsigned long long m_eq = __ballot(is_min && best_s >= 0);
             if (__popcll(m_eq) != 1) {                              // ties: unassigned column scanned last wins, else first scanned
-                const int ms = wave_max_i32((best == minval) ? best_s : -1);
-                m_eq = __ballot(best == minval && best_s == ms);
+                const int ms = wave_max_i32_fast(is_min ? best_s : -1);
+                m_eq = __ballot(is_min && best_s == ms);
             }
             const int wl = __ffsll((long long)m_eq) - 1;
             const int wc = __builtin_amdgcn_readlane(best_c, wl);
