@@ -42,4 +42,5 @@ if PROF:
     names = ["filter+predict", "det+gate prep", "appearance cost fill", "LSA A + lists", "set order + motion fill", "LSA B + lists", "KF update matched",
              "embedding EMA", "misses + births", "deaths + rows"]
     out["phases_us_per_frame"] = {n: buf[i] * 10 / F / 1e3 for i, n in enumerate(names)}
+    out["shader_clock_MHz"] = buf[14] / max(buf[15], 1) * 100.0
 print(json.dumps(out))

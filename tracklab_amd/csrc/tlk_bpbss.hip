@@ -254,7 +254,8 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
     if (P.wrapper_mode && n_in == 0) { if (tid == 0) *out_count = 0; return; }      // bpbreid_strong_sort_api.py:103-104
     long long t_prev = 0;
 #define BPB_PROF(i) do { if (Dv.prof) { __syncthreads(); if (tid == 0) { const long long t_ = wall_clock64(); Dv.prof[(size_t)s * 16 + (i)] += t_ - t_prev; t_prev = t_; } } } while (0)
-    if (Dv.prof && tid == 0) t_prev = wall_clock64();
+    long long c_start = 0, w_start = 0;
+    if (Dv.prof && tid == 0) { t_prev = wall_clock64(); w_start = t_prev; c_start = clock64(); }
 
     // filter_detections (strong_sort.py:143-147)
     const int N = block_compact(n_in, [&](int i) { return in.conf[dbase + i] > P.min_conf; }, [&](int i, int pos) { L.sel[pos] = i; }, L.scan);
@@ -556,6 +557,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
                                     }, L.scan);
     if (tid == 0) *out_count = nrows > out_cap ? TLK_ECAPACITY : nrows;
     BPB_PROF(9);                                          // deaths + output rows
+    if (Dv.prof && tid == 0) { Dv.prof[(size_t)s * 16 + 14] += clock64() - c_start; Dv.prof[(size_t)s * 16 + 15] += wall_clock64() - w_start; }   // shader cycles vs 100 MHz ticks: the clock the kernel ran at
 #undef BPB_PROF
 }
 
