@@ -504,6 +504,28 @@ int tlk_yolox_decode_nms(const float *pred_dev, int batch, int size, int num_cla
                          int64_t det_id_base, double category_id, void *hip_stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Camera-motion estimation on the device. Replaces GMC(method="sparseOptFlow", downscale).apply(frame) of
+ * plugins/track/bot_sort/gmc.py:239-303 (cv2.cvtColor -> resize -> goodFeaturesToTrack(1000, 0.01, 1, 3) ->
+ * calcOpticalFlowPyrLK -> estimateAffinePartial2D(RANSAC)); the same chain is deep_oc_sort/cmc.py:136-166. All of it is
+ * third-party OpenCV in the reference -- PARITY UNPINNED; the kernels follow oracle/src/cmc.c operation for operation.
+ * One handle = one video stream (it keeps the previous frame's pyramid and corners). The first frame returns the identity.
+ *   tlk_cmc_apply_dev: frame_dev (h, w, 3) uint8 on the device, as the tracker receives it (the reference hands its RGB frame
+ *     to COLOR_BGR2GRAY; so does this); warp6_dev: 6 doubles [[a, b, tx], [c, d, ty]] in device memory, ready for
+ *     tlk_botsort_update_dev_gmc. Asynchronous on hip_stream, no host synchronisation.
+ *   tlk_cmc_apply: the same with a host frame and a host result (n_inliers may be NULL).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tlk_cmc tlk_cmc;
+int tlk_cmc_create(int h, int w, int downscale, int max_corners, int device, tlk_cmc **out);
+int tlk_cmc_destroy(tlk_cmc *c);
+int tlk_cmc_reset(tlk_cmc *c);                        /* new video: forget the previous frame */
+int tlk_cmc_apply_dev(tlk_cmc *c, const uint8_t *frame_dev, double *warp6_dev, void *hip_stream);
+int tlk_cmc_apply(tlk_cmc *c, const uint8_t *frame_host, double *warp6_host, int *n_inliers);
+/* debug / test: stage outputs of the last tlk_cmc_apply*: what = 0 downscaled grey image, 1 eigenvalue image (float32), 2 corners
+ * (n, 2) float32, 3 tracked positions of the previous corners, 4 their status bytes, 10 + l pyramid image l, 20 + l its int16
+ * (dx, dy) Scharr derivatives. n_out: element / point count (row width for the pyramid items). */
+int tlk_cmc_debug_get(tlk_cmc *c, int what, void *host_buf, size_t cap_bytes, int *n_out);
+
+/* ------------------------------------------------------------------------------------------
  * Fused convolution epilogue for the PyTorch-ROCm backbones (not a reference function: the reference's
  * backbones run inside third-party ONNXRuntime / torchreid): x = act(x + bias[c] (+ residual)) in place on a
  * channels-last activation viewed as (rows, channels), channels % 8 == 0. act: 0 none, 1 ReLU, 2 SiLU.

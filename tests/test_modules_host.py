@@ -261,9 +261,9 @@ def test_botsort_module_host_logic_with_oracle_backend(orc):
         def __init__(self):
             self.t = orc.BoTSORT(D, **core)
 
-        def update(self, dets, feat, stream):
+        def update(self, dets, feat, stream, warp=None):
             keep = dets[:, 4] > 0.4                  # the bank applies min_confidence itself
-            r = self.t.update(dets[keep], feat[keep])
+            r = self.t.update(dets[keep], feat[keep], warp=warp)
             out = np.zeros(len(r), dtype=BOTSORT_ROW)
             out["ltrb"], out["track_id"], out["cls"], out["score"], out["det_id"] = r[:, :4], r[:, 4], r[:, 5], r[:, 6], r[:, 7]
             return out
@@ -274,7 +274,8 @@ def test_botsort_module_host_logic_with_oracle_backend(orc):
     m = HipBoTSORT(NS(min_confidence=0.4, feature_dim=D, hyperparams=hyper), "cuda:0", tracking_dataset=None)
     assert m.level == "image" and m.batch_size == 1 and m.output_columns == ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
     with pytest.raises(NotImplementedError):
-        HipBoTSORT(NS(hyperparams=dict(hyper, cmc_method="sparseOptFlow")), "cuda:0")
+        HipBoTSORT(NS(hyperparams=dict(hyper, cmc_method="orb")), "cuda:0")         # cv2 feature matching: not part of the HIP path
+    HipBoTSORT(NS(hyperparams=dict(hyper, cmc_method="sparseOptFlow")), "cuda:0")   # the reference's default: accepted (estimator on the device)
     m._make_backend = lambda dim, h, w: Backend()
     ref = orc.BoTSORT(D, **core)
     frame = np.zeros((1080, 1920, 3), np.uint8)

@@ -1,0 +1,125 @@
+"""CPU: the camera-motion estimator's restatement (oracle/src/cmc.c) -- GMC.applySparseOptFlow of plugins/track/bot_sort/gmc.py:239-303.
+Every step is OpenCV in the reference and OpenCV is not installed: PARITY UNPINNED. What can be pinned here: closed-form properties of the
+stages (grey weights, exact 2:1 resize, pyramid of a constant image, Scharr of a ramp, OpenCV's documented RNG sequence head) and, end to
+end, that the chain recovers the KNOWN similarity transform between synthetic frames."""
+import numpy as np
+import pytest
+
+
+def _textured(rng, h, w):
+    """Smooth random texture with plenty of corners: sum of blurred blobs + a few rectangles."""
+    img = rng.integers(0, 255, (h // 8 + 2, w // 8 + 2, 3)).astype(np.float32)
+    img = np.kron(img, np.ones((8, 8, 1), np.float32))[:h + 8, :w + 8]
+    k = np.ones(5) / 5
+    for ax in (0, 1):
+        img = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), ax, img)
+    return img
+
+
+def _warp(img, a, b, tx, ty, h, w):
+    """out(x, y) = img(R^-1 ((x, y) - t)) with bilinear sampling: a frame whose content moved by p -> R p + t."""
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    det = a * a + b * b
+    u, v = xs - tx, ys - ty
+    sx, sy = (a * u + b * v) / det, (-b * u + a * v) / det
+    x0, y0 = np.floor(sx).astype(int), np.floor(sy).astype(int)
+    fx, fy = (sx - x0)[..., None], (sy - y0)[..., None]
+    x0c, x1c = np.clip(x0, 0, img.shape[1] - 1), np.clip(x0 + 1, 0, img.shape[1] - 1)
+    y0c, y1c = np.clip(y0, 0, img.shape[0] - 1), np.clip(y0 + 1, 0, img.shape[0] - 1)
+    out = img[y0c, x0c] * (1 - fx) * (1 - fy) + img[y0c, x1c] * fx * (1 - fy) + img[y1c, x0c] * (1 - fx) * fy + img[y1c, x1c] * fx * fy
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+def test_grey_and_resize_closed_forms(orc):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (40, 64, 3), dtype=np.uint8)
+    g = orc.cmc_gray(img)
+    exp = (img[..., 0].astype(np.int64) * 3735 + img[..., 1].astype(np.int64) * 19235 + img[..., 2].astype(np.int64) * 9798 + (1 << 14)) >> 15
+    np.testing.assert_array_equal(g, exp)                                   # channel 0 takes the "B" weight: the reference feeds RGB to BGR2GRAY
+    assert (orc.cmc_gray(np.full((8, 8, 3), 200, np.uint8)) == 200).all()   # the weights sum to 1 << 15
+    half = orc.cmc_resize_gray(g, 20, 32)                                   # exact 2:1: both taps weigh 1/2 on each axis
+    s = g.astype(np.int64)
+    exp2 = (((1024 * ((s[0::2, 0::2] * 1024 + s[0::2, 1::2] * 1024) >> 4)) >> 16) + ((1024 * ((s[1::2, 0::2] * 1024 + s[1::2, 1::2] * 1024) >> 4)) >> 16) + 2) >> 2
+    np.testing.assert_array_equal(half, exp2)
+
+
+def test_pyramid_and_scharr_closed_forms(orc):
+    pyr = orc.CmcPyramid(np.full((120, 200), 77, np.uint8)).levels()
+    assert [p[0].shape for p in pyr] == [(120, 200), (60, 100), (30, 50)]   # the 4th level (15 x 25) is not larger than the 21 x 21 window
+    assert all((im == 77).all() and not d.any() for im, d in pyr)           # the kernel sums to 256; a flat image has no gradient
+    ramp = np.tile(np.arange(100, dtype=np.uint8) * 2, (60, 1))
+    d = orc.CmcPyramid(ramp).levels()[0][1]
+    assert (d[5:-5, 5:-5, 0] == 4 * 16).all() and not d[5:-5, 5:-5, 1].any()  # Scharr: (3 + 10 + 3) x central difference (2 px apart, slope 2)
+
+
+def test_corner_detector_finds_the_corners_of_rectangles(orc):
+    img = np.zeros((80, 120), np.uint8)
+    img[20:50, 30:90] = 200
+    pts = orc.cmc_good_features(img)
+    assert 4 <= len(pts) <= 16
+    corners = np.array([[30, 20], [89, 20], [30, 49], [89, 49]], np.float32)
+    for c in corners:
+        assert np.abs(pts - c).sum(1).min() <= 2                            # every rectangle corner has a detected corner within 2 px
+    eig = orc.cmc_min_eigen(img)
+    assert eig[35, 60] == 0 and eig[35, 30] < 1e-6 and eig[20, 30] > 1e-3   # flat: 0; along an edge: one vanishing eigenvalue; corner: both large
+
+
+def test_ransac_sampler_and_similarity(orc):
+    import ctypes as C
+    L = orc.lib()
+    ids = np.zeros((2000, 2), np.int32)
+    L.orc_cmc_ransac_subsets.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int32)]
+    assert L.orc_cmc_ransac_subsets(100, 2000, ids.ctypes.data_as(C.POINTER(C.c_int32))) == 2000
+    # cv::RNG(0xffffffffffffffff): state_{k+1} = lo * 4164903690 + hi; the draws are state_{k+1} mod 100
+    s, draws = 0xffffffffffffffff, []
+    for _ in range(4):
+        s = ((s & 0xffffffff) * 4164903690 + (s >> 32)) & 0xffffffffffffffff
+        draws.append((s & 0xffffffff) % 100)
+    assert ids[0, 0] == draws[0] and (ids[:, 0] != ids[:, 1]).all() and ids.min() >= 0 and ids.max() < 100
+    rng = np.random.default_rng(3)
+    src = rng.uniform(0, 900, (300, 2)).astype(np.float32)
+    a, b, tx, ty = 1.01 * np.cos(0.02), 1.01 * np.sin(0.02), 7.5, -3.25
+    dst = np.stack([a * src[:, 0] - b * src[:, 1] + tx, b * src[:, 0] + a * src[:, 1] + ty], 1) + rng.normal(0, 0.3, (300, 2))
+    dst[:60] += rng.uniform(-80, 80, (60, 2))                               # 20 % outliers
+    M, inl = orc.cmc_estimate_affine_partial(src, dst.astype(np.float32))
+    assert inl[60:].mean() > 0.97 and inl[:60].mean() < 0.2
+    np.testing.assert_allclose(M, [[a, -b, tx], [b, a, ty]], atol=0.08, rtol=2e-3)
+
+
+@pytest.mark.parametrize("angle,scale,tx,ty", [(0.0, 1.0, 6.0, -4.0), (0.01, 1.0, -9.0, 5.0), (-0.006, 1.01, 3.0, 8.0)])
+def test_sparse_flow_chain_recovers_a_known_camera_motion(orc, angle, scale, tx, ty):
+    """Two frames of one scene related by a similarity: the estimated warp maps frame-1 coordinates to frame-2 coordinates."""
+    H_, W_ = 360, 640
+    rng = np.random.default_rng(11)
+    base = _textured(rng, H_ + 80, W_ + 80)
+    f0 = np.clip(np.rint(base[40:40 + H_, 40:40 + W_]), 0, 255).astype(np.uint8)
+    a, b = scale * np.cos(angle), scale * np.sin(angle)
+    f1 = _warp(base[40:, 40:], a, b, tx, ty, H_, W_)
+    gmc = orc.SparseOptFlowGMC(H_, W_, downscale=2)
+    first = gmc.apply(f0)
+    np.testing.assert_array_equal(first, np.eye(2, 3))                      # gmc.py:263-271: the first frame only initialises
+    H = gmc.apply(f1)
+    assert gmc.inliers > 50
+    np.testing.assert_allclose(H[:, :2], [[a, -b], [b, a]], atol=2e-3)
+    np.testing.assert_allclose(H[:, 2], [tx, ty], atol=0.35)                # sub-pixel at half resolution, doubled
+
+
+def test_oracle_against_opencv_fixture(orc):
+    """Pins oracle/src/cmc.c on OpenCV itself -- once tests/golden/make_cmc_golden.py has been run on a machine that has cv2."""
+    import os
+    from conftest import GOLDEN
+    path = os.path.join(GOLDEN, "cmc_opencv.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/cmc_opencv.npz absent: OpenCV is not installed in the build container (parity unpinned)")
+    g = np.load(path)
+    for k in (0, 1):
+        np.testing.assert_array_equal(orc.cmc_gray(g[f"f{k}"]), g[f"gray{k}"])
+        np.testing.assert_array_equal(orc.cmc_resize_gray(g[f"gray{k}"], 180, 320), g[f"small{k}"])
+        np.testing.assert_allclose(orc.cmc_min_eigen(g[f"small{k}"]), g[f"eig{k}"], rtol=1e-5, atol=1e-9)
+        np.testing.assert_array_equal(orc.cmc_good_features(g[f"small{k}"]), g[f"corners{k}"])
+    nxt, st = orc.cmc_lk(orc.CmcPyramid(g["small0"]), orc.CmcPyramid(g["small1"]), g["corners0"])
+    np.testing.assert_array_equal(st, g["lk_status"].astype(bool))
+    np.testing.assert_allclose(nxt[st], g["lk_next"][st], atol=1e-3)
+    M, inl = orc.cmc_estimate_affine_partial(g["corners0"][st], g["lk_next"][st])
+    np.testing.assert_array_equal(inl, g["inliers"].astype(bool))
+    np.testing.assert_allclose(M, g["affine"], atol=1e-6)

@@ -998,3 +998,88 @@ def pyset_difference_order(a, b, force_table=False):
     check(L.tlk_pyset_difference_order(a.ctypes.data_as(ip), len(a), b.ctypes.data_as(ip), len(b), out.ctypes.data_as(ip), C.byref(n),
                                        int(bool(force_table))))
     return out[:n.value].copy()
+
+
+# ------------------------------------------------------------------------------------------------
+# camera-motion estimation on the device (tlk_cmc_*): GMC.applySparseOptFlow of BoT-SORT (gmc.py:239-303)
+# ------------------------------------------------------------------------------------------------
+class CmcEstimator:
+    """One video stream's camera-motion estimator: ``apply(frame)`` -> (2, 3) float64 warp for ``BoTSORTBank.update(..., warp=)``;
+    ``apply_dev(frame_cuda_tensor)`` leaves the warp in device memory (``.warp_dev``: 6 doubles) for ``update_dev(..., warps=)`` with
+    no host synchronisation. OpenCV's arithmetic restated: PARITY UNPINNED (tlk_cmc.hip, oracle/src/cmc.c)."""
+
+    def __init__(self, height, width, downscale=2, max_corners=1000, device=0):
+        L = lib()
+        vp, ci = C.c_void_p, C.c_int
+        L.tlk_cmc_create.argtypes = [ci, ci, ci, ci, ci, C.POINTER(vp)]
+        L.tlk_cmc_destroy.argtypes = [vp]
+        L.tlk_cmc_reset.argtypes = [vp]
+        L.tlk_cmc_apply_dev.argtypes = [vp, vp, vp, vp]
+        L.tlk_cmc_apply.argtypes = [vp, vp, vp, C.POINTER(ci)]
+        L.tlk_cmc_debug_get.argtypes = [vp, ci, vp, C.c_size_t, C.POINTER(ci)]
+        self.h, self.w, self.downscale = int(height), int(width), max(1, int(downscale))
+        self.dh, self.dw = (self.h // self.downscale, self.w // self.downscale) if self.downscale > 1 else (self.h, self.w)
+        h = vp()
+        check(L.tlk_cmc_create(self.h, self.w, self.downscale, int(max_corners), device, C.byref(h)))
+        self._h = h
+        self.inliers = 0
+        self.warp_dev = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tlk_cmc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        check(lib().tlk_cmc_reset(self._h))
+
+    def apply(self, frame):
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        assert frame.shape == (self.h, self.w, 3)
+        H = np.zeros(6)
+        n = C.c_int(0)
+        check(lib().tlk_cmc_apply(self._h, frame.ctypes.data, H.ctypes.data, C.byref(n)))
+        self.inliers = n.value
+        return H.reshape(2, 3)
+
+    def apply_dev(self, frame, stream_ptr=None):
+        import torch
+        assert frame.is_cuda and frame.dtype == torch.uint8 and frame.is_contiguous() and tuple(frame.shape) == (self.h, self.w, 3)
+        if self.warp_dev is None:
+            self.warp_dev = torch.zeros(6, dtype=torch.float64, device=frame.device)
+        check(lib().tlk_cmc_apply_dev(self._h, frame.data_ptr(), self.warp_dev.data_ptr(), stream_ptr if stream_ptr is not None else current_stream_ptr()))
+        return self.warp_dev
+
+    def debug(self, what):
+        """Stage outputs of the last apply (tlk.h tlk_cmc_debug_get)."""
+        n = C.c_int(0)
+        if what in (0,) or 10 <= what < 20:
+            buf = np.zeros(self.dh * self.dw, np.uint8)
+        elif what == 1:
+            buf = np.zeros(self.dh * self.dw, np.float32)
+        elif what in (2, 3):
+            buf = np.zeros((1024, 2), np.float32)
+        elif what == 4:
+            buf = np.zeros(1024, np.uint8)
+        else:
+            buf = np.zeros(self.dh * self.dw * 2, np.int16)
+        check(lib().tlk_cmc_debug_get(self._h, what, buf.ctypes.data, buf.nbytes, C.byref(n)))
+        if what == 0:
+            return buf.reshape(self.dh, self.dw)
+        if what == 1:
+            return buf.reshape(self.dh, self.dw)
+        if what in (2, 3):
+            return buf[:n.value].copy()
+        if what == 4:
+            return buf[:n.value].astype(bool)
+        w = n.value
+        if 10 <= what < 20:
+            h = -(-self.dh // (1 << (what - 10)))
+            return buf[:h * w].reshape(h, w) if what == 10 else buf[:(buf.size // w) * w].reshape(-1, w)
+        return buf[:(buf.size // (2 * w)) * 2 * w].reshape(-1, w, 2)

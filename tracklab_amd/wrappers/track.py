@@ -247,6 +247,9 @@ class _ReidTrackerBase:
     def _camera_step(self, image, metadatas):
         """Camera-motion compensation ahead of the tracker step; nothing unless a subclass estimates a warp."""
 
+    def _update(self, inputs, feats, image):
+        return self._bank.update(inputs, feats, 0)
+
     def process(self, batch, detections: pd.DataFrame, metadatas: pd.DataFrame):
         if len(detections) == 0:
             self._camera_step(None, metadatas)               # the reference compensates before its empty-frame return too
@@ -266,7 +269,7 @@ class _ReidTrackerBase:
         if self._bank is None or self._img_hw != (h, w):
             self._bank = self._make_backend(feats.shape[1], h, w)
             self._img_hw = (h, w)
-        rows = self._bank.update(inputs, feats, 0)
+        rows = self._update(inputs, feats, image)
         if not len(rows):
             return []
         ltrb = rows["ltrb"]
@@ -351,7 +354,9 @@ class HipBoTSORT(ImageLevelModule, _ReidTrackerBase):
     """BoT-SORT (tracklab/wrappers/track/bot_sort_api.py:16-88). Same crop-out as plain StrongSORT (both use
     ReIDDetectMultiBackend's ToPILImage / Resize / Normalize on the int-truncated box: bot_sort.py:487-505,
     deep_oc_sort/reid_multibackend.py:44-53), features only for the detections above track_high_thresh (bot_sort.py:293-314),
-    tlk_botsort_update for the rest. cmc_method must be "none": the camera-motion estimators are cv2 (gmc.py)."""
+    tlk_botsort_update for the rest. cmc_method "sparseOptFlow" (the reference's default) runs on the device: tlk_cmc_* estimates the
+    frame's warp (grey + 2:1 resize, Shi-Tomasi corners, pyramidal Lucas-Kanade, RANSAC similarity; OpenCV restated, parity
+    unpinned), tlk_botsort_update_gmc applies it between predict and association. orb / sift / ecc / file stay cv2-only."""
     input_columns = ["bbox_ltwh", "bbox_conf", "category_id"]
     output_columns = ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
     _conf_field = "score"
@@ -359,9 +364,11 @@ class HipBoTSORT(ImageLevelModule, _ReidTrackerBase):
 
     def reset(self):
         """New video: state dropped; the id counter keeps counting like the reference's class-level BaseTrack._count
-        (bot_sort/basetrack.py) unless ``reset_ids_per_video: true``."""
+        (bot_sort/basetrack.py) unless ``reset_ids_per_video: true``. The camera-motion estimator forgets its previous frame."""
         if self._bank is not None:
             self._bank.reset(-1, keep_ids=not bool(cfg_get(self.cfg, "reset_ids_per_video", False)))
+        if self._cmc is not None:
+            self._cmc.reset()
 
     def __init__(self, cfg, device, **kwargs):
         super().__init__(batch_size=1)
@@ -370,10 +377,23 @@ class HipBoTSORT(ImageLevelModule, _ReidTrackerBase):
         self._bank = None
         self._model = None
         self._img_hw = None
-        cmc = dict(cfg_get(cfg, "hyperparams")).get("cmc_method", "sparseOptFlow")
-        if cmc not in ("none", None):
-            raise NotImplementedError(f"cmc_method {cmc!r} (gmc.py: cv2 feature / optical-flow / ECC estimators) is not part of the HIP path; "
-                                      "set cmc_method: none")
+        self._cmc = None
+        self._cmc_method = dict(cfg_get(cfg, "hyperparams")).get("cmc_method", "sparseOptFlow")
+        if self._cmc_method in ("None",):
+            self._cmc_method = "none"
+        if self._cmc_method not in ("none", None, "sparseOptFlow"):
+            raise NotImplementedError(f"cmc_method {self._cmc_method!r} (gmc.py: cv2 ORB / SIFT / ECC estimators, GMC files) is not part of the HIP path; "
+                                      "use sparseOptFlow (the reference's default, on the device) or none")
+
+    def _update(self, inputs, feats, image):
+        warp = None
+        if self._cmc_method == "sparseOptFlow":              # bot_sort.py:341: warp = self.gmc.apply(img, dets)
+            from .._lib import CmcEstimator
+            frame = to_numpy(image) if hasattr(image, "detach") else np.asarray(image)
+            if self._cmc is None or (self._cmc.h, self._cmc.w) != frame.shape[:2]:
+                self._cmc = CmcEstimator(frame.shape[0], frame.shape[1], downscale=2, device=_device_index(self.device))
+            warp = self._cmc.apply(frame)
+        return self._bank.update(inputs, feats, 0, warp=warp)
 
     def _make_backend(self, dim, img_h, img_w):
         from .._lib import BoTSORTBank
