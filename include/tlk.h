@@ -526,6 +526,17 @@ int tlk_cmc_apply(tlk_cmc *c, const uint8_t *frame_host, double *warp6_host, int
 int tlk_cmc_debug_get(tlk_cmc *c, int what, void *host_buf, size_t cap_bytes, int *n_out);
 
 /* ------------------------------------------------------------------------------------------
+ * HOTA of one sequence on the device. Replaces HOTA.eval_sequence of the TrackEval copy the reference vendors
+ * (plugins/eval/PoseTrack21/posetrack21/posetrack21/trackeval/metrics/hota.py:30-155; official path: pip trackeval behind
+ * tracklab/wrappers/eval/trackeval_evaluator.py:28-110). HOST buffers: gt_ids / tr_ids (ids re-labelled 0..n-1 like TrackEval's
+ * preprocessing, frames concatenated), *_ltrb (., 4) float64 x0 y0 x1 y1, *_off (n_frames + 1) frame offsets, alphas19 the 19
+ * thresholds (np.arange(0.05, 0.99, 0.05)). stats (7, 19) float64: HOTA_TP, HOTA_FN, HOTA_FP, LocA sum, AssA, AssRe, AssPr per
+ * threshold -- what tracklab_amd.hota.pack() turns into the vector the ranks SUM all-reduce. At most 512 boxes per frame and side.
+ * ------------------------------------------------------------------------------------------ */
+int tlk_hota_sequence_f64(const int32_t *gt_ids, const double *gt_ltrb, const int64_t *gt_off, const int32_t *tr_ids, const double *tr_ltrb,
+                          const int64_t *tr_off, int n_frames, int n_gt, int n_tr, const double *alphas19, double *stats);
+
+/* ------------------------------------------------------------------------------------------
  * Fused convolution epilogue for the PyTorch-ROCm backbones (not a reference function: the reference's
  * backbones run inside third-party ONNXRuntime / torchreid): x = act(x + bias[c] (+ residual)) in place on a
  * channels-last activation viewed as (rows, channels), channels % 8 == 0. act: 0 none, 1 ReLU, 2 SiLU.

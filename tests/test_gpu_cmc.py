@@ -73,7 +73,7 @@ def test_cmc_device_entry_point_leaves_the_warp_on_the_device(orc):
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         for fr in (f0, f1):
-            w = est.apply_dev(torch.from_numpy(fr).cuda())
+            w = est.apply_dev(torch.from_numpy(np.ascontiguousarray(fr)).cuda())
     side.synchronize()
     ref.apply(f0)
     np.testing.assert_allclose(w.cpu().numpy().reshape(2, 3), ref.apply(f1), rtol=0, atol=1e-9)

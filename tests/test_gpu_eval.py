@@ -1,0 +1,59 @@
+"""-m gpu: HOTA on the device (tlk_hota_sequence_f64) against the reference-made TrackEval fixtures (tests/golden/hota_cases.npz) and, on a
+600-frame 100-object stream tracked by the oracle, against the numpy restatement that those fixtures pin (tracklab_amd/hota.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("HOTA", "DetA", "AssA", "DetRe", "DetPr", "AssRe", "AssPr", "LocA", "HOTA_TP", "HOTA_FN", "HOTA_FP")
+
+
+def test_gpu_hota_matches_vendored_trackeval():
+    from tracklab_amd import hota
+    g = np.load(os.path.join(GOLDEN, "hota_cases.npz"))
+    packs = []
+    for si in range(2):
+        n = int(g[f"s{si}_n_frames"])
+        gt = [(g[f"s{si}_f{f}_gt_ids"], g[f"s{si}_f{f}_gt_boxes"]) for f in range(n)]
+        tr = [(g[f"s{si}_f{f}_tr_ids"], g[f"s{si}_f{f}_tr_boxes"]) for f in range(n)]
+        packs.append(hota.pack(hota.hota_sequence_gpu(gt, tr)))
+        fin = hota.finalize(packs[-1])
+        for k in FIELDS:
+            np.testing.assert_allclose(fin[k], g[f"s{si}_{k}"], rtol=1e-12, atol=1e-12, err_msg=f"seq {si} {k}")
+    comb = hota.finalize(packs[0] + packs[1])
+    for k in FIELDS:
+        np.testing.assert_allclose(comb[k], g[f"comb_{k}"], rtol=1e-12, atol=1e-12, err_msg=f"combined {k}")
+
+
+def test_gpu_hota_on_a_full_stream_equals_the_numpy_restatement(orc):
+    from tracklab_amd import hota
+    from tracklab_amd.synth import SyntheticStream
+    hyper = dict(asso_func="giou", delta_t=1, det_thresh=0, inertia=0.3941737016672115, iou_threshold=0.22136877277096445, max_age=50, min_hits=1, use_byte=False)
+    trk = orc.OCSort(**hyper)
+    gt, tr = [], []
+    for fr in SyntheticStream(3, 100, 600, miss_prob=0.08):
+        out = orc.ocsort_wrapper_step(trk, fr["dets"], 0.4)
+        gt.append((fr["gt_all_ids"], fr["gt_boxes"]))
+        tr.append((out[:, 4].astype(int), out[:, :4]))
+    cpu = hota.hota_sequence(*hota.sequence_from_rows(gt, tr))
+    gpu = hota.hota_sequence_gpu(gt, tr)
+    for k in ("HOTA_TP", "HOTA_FN", "HOTA_FP"):
+        np.testing.assert_array_equal(gpu[k], cpu[k])
+    for k in ("LocA_sum", "AssA", "AssRe", "AssPr"):
+        np.testing.assert_allclose(gpu[k], cpu[k], rtol=1e-12, atol=1e-12)
+    assert 0.5 < hota.finalize(hota.pack(gpu))["summary"]["HOTA"] < 1.0
+
+
+def test_gpu_hota_edge_cases():
+    from tracklab_amd import hota
+    e, z = np.zeros(0, dtype=int), np.zeros((0, 4))
+    assert hota.hota_sequence_gpu([(e, z)] * 2, [(e, z)] * 2)["HOTA_TP"].sum() == 0
+    b = np.array([[0, 0, 10, 10.0], [20, 20, 30, 30]])
+    assert (hota.hota_sequence_gpu([(np.array([0, 1]), b)], [(e, z)])["HOTA_FN"] == 2).all()
+    assert (hota.hota_sequence_gpu([(e, z)], [(np.array([4, 6]), b)])["HOTA_FP"] == 2).all()
+    r = hota.hota_sequence_gpu([(np.array([5, 9]), b), (e, z), (np.array([5, 9]), b)], [(np.array([2, 7]), b), (np.array([2]), b[:1]), (np.array([2, 7]), b)])
+    fin = hota.finalize(hota.pack(r))
+    assert (r["HOTA_TP"] == 4).all() and (r["HOTA_FP"] == 1).all() and abs(fin["summary"]["AssA"] - 1.0) < 1e-12

@@ -53,7 +53,7 @@ def test_fused_pipeline_ids_equal_oracle_at_baseline_config_shapes(orc, detector
             np.testing.assert_array_equal(got["track_id"], exp["track_id"], err_msg=f"frame {k * F + f}")
             np.testing.assert_array_equal(got["matched_name"], exp["matched_name"])
             rows_total += len(exp); tracks = max(tracks, int(exp["track_id"].max()))
-    assert rows_total > 0.95 * F * steps * nobj * 0.97 and 100 <= tracks <= 130
+    assert rows_total > 0.9 * F * steps * nobj and 100 <= tracks <= 130
     pipe.close()
 
 

@@ -125,3 +125,29 @@ def sequence_from_rows(gt_frames, tracker_frames):
         ti.append(np.array([tmap.setdefault(int(x), len(tmap)) for x in t], dtype=int))
         sims.append(box_iou_matrix(np.asarray(gb, dtype=float).reshape(-1, 4), np.asarray(tb, dtype=float).reshape(-1, 4)))
     return gi, ti, sims
+
+
+def hota_sequence_gpu(gt_frames, tracker_frames):
+    """`hota_sequence(*sequence_from_rows(...))` on the device (tlk_hota_sequence_f64: similarity, global alignment, per-frame Hungarian
+    matching and the 19-threshold counts as four kernel launches). Same dict of per-threshold arrays; no CPU fallback."""
+    import ctypes as C
+    from . import _lib
+    L = _lib.lib()
+    gmap, tmap = {}, {}
+    gid, tid, gb, tb, goff, toff = [], [], [], [], [0], [0]
+    for (g, gbox), (t, tbox) in zip(gt_frames, tracker_frames):
+        gid.extend(gmap.setdefault(int(x), len(gmap)) for x in g)
+        tid.extend(tmap.setdefault(int(x), len(tmap)) for x in t)
+        gb.append(np.asarray(gbox, dtype=np.float64).reshape(-1, 4)); tb.append(np.asarray(tbox, dtype=np.float64).reshape(-1, 4))
+        goff.append(len(gid)); toff.append(len(tid))
+    gid, tid = np.asarray(gid, dtype=np.int32), np.asarray(tid, dtype=np.int32)
+    gb = np.ascontiguousarray(np.concatenate(gb)) if gb else np.zeros((0, 4))
+    tb = np.ascontiguousarray(np.concatenate(tb)) if tb else np.zeros((0, 4))
+    goff, toff = np.asarray(goff, dtype=np.int64), np.asarray(toff, dtype=np.int64)
+    stats = np.zeros((7, len(ALPHAS)))
+    alphas = np.ascontiguousarray(ALPHAS, dtype=np.float64)
+    vp = C.c_void_p
+    L.tlk_hota_sequence_f64.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    _lib.check(L.tlk_hota_sequence_f64(gid.ctypes.data, gb.ctypes.data, goff.ctypes.data, tid.ctypes.data, tb.ctypes.data, toff.ctypes.data,
+                                       len(goff) - 1, len(gmap), len(tmap), alphas.ctypes.data, stats.ctypes.data))
+    return {k: stats[i].copy() for i, k in enumerate(("HOTA_TP", "HOTA_FN", "HOTA_FP", "LocA_sum", "AssA", "AssRe", "AssPr"))}
