@@ -54,6 +54,9 @@ def test_gpu_hota_edge_cases():
     b = np.array([[0, 0, 10, 10.0], [20, 20, 30, 30]])
     assert (hota.hota_sequence_gpu([(np.array([0, 1]), b)], [(e, z)])["HOTA_FN"] == 2).all()
     assert (hota.hota_sequence_gpu([(e, z)], [(np.array([4, 6]), b)])["HOTA_FP"] == 2).all()
-    r = hota.hota_sequence_gpu([(np.array([5, 9]), b), (e, z), (np.array([5, 9]), b)], [(np.array([2, 7]), b), (np.array([2]), b[:1]), (np.array([2, 7]), b)])
-    fin = hota.finalize(hota.pack(r))
-    assert (r["HOTA_TP"] == 4).all() and (r["HOTA_FP"] == 1).all() and abs(fin["summary"]["AssA"] - 1.0) < 1e-12
+    gt = [(np.array([5, 9]), b), (e, z), (np.array([5, 9]), b)]
+    tr = [(np.array([2, 7]), b), (np.array([2]), b[:1]), (np.array([2, 7]), b)]        # a frame without ground truth: its tracker box is a false positive
+    r, c = hota.hota_sequence_gpu(gt, tr), hota.hota_sequence(*hota.sequence_from_rows(gt, tr))
+    assert (r["HOTA_TP"] == 4).all() and (r["HOTA_FP"] == 1).all()
+    for k in r:
+        np.testing.assert_allclose(r[k], c[k], rtol=1e-14, atol=1e-14)
