@@ -536,7 +536,7 @@ def main():
     esz = torch.empty((), dtype=tdtype).element_size()
     cnt_mean = float(np.mean([len(g["dets"]) for g in gts[0][:total_steps * F]]))
     if is3:
-        kname, tfile = ("pil_crop_kernel", "pil_crop_traffic.json") if ssort else ("crop_lds_kernel", "crop_traffic.json")
+        kname, tfile = ("pil_crop_kernel", "pil_crop_traffic.json") if ssort else ("crop_fat_kernel", "crop_traffic.json")
         # mean crop of the synthetic stream: w~U(40,120), h=w*U(1.8,2.6) -> E[w*h] = E[w^2]*2.2; only the cnt_mean REAL crops of a
         # frame count (the padding slots up to max_dets are not algorithmic bytes)
         ew2 = (120 ** 3 - 40 ** 3) / (3 * 80)
@@ -554,6 +554,8 @@ def main():
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_src = "static: profiles/%s (%s) -- rocprofv3 --pmc passes of this command on an earlier box, not measured by this run" % (
                 tfile, tj.get("round", "r01"))
+            if tj.get("kernel") != kname:
+                traffic, traffic_src = None, None             # counters of another kernel generation: not this kernel's traffic
         except Exception:
             traffic = None
     roofline = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -39,12 +39,14 @@ def test_engine_table_export_equals_dataframe_export(tmp_path):
     from tracklab_amd.engine import DetectionTable
     rng = np.random.default_rng(3)
     t = DetectionTable(capacity=4)
-    for f in range(30):
-        m = int(rng.integers(0, 6))
-        ids = 1000 * f + np.arange(m)
-        base = t.append_frame(500 + f, ids, rng.uniform(0, 800, (m, 4)).astype(np.float32), 1.0, 1)
-        has = rng.random(m) > 0.3
-        t.set_tracks(base, ids, ids[has], rng.integers(1, 9, int(has.sum())).astype(np.float64), rng.uniform(0, 800, (int(has.sum()), 4)), np.ones(int(has.sum())))
+    maxd = 8
+    for step in range(10):                                     # 10 steps of 3 frames: image ids 500..529
+        dcnt = rng.integers(0, 6, 3)
+        ltwh = rng.uniform(0, 800, (3, maxd, 4)).astype(np.float32)
+        id_base = 1000 * step
+        tf, tdet = np.nonzero((np.arange(maxd)[None, :] < dcnt[:, None]) & (rng.random((3, maxd)) > 0.3))
+        trk = (tf, id_base + tf * maxd + tdet, rng.integers(1, 9, len(tf)).astype(np.float64), rng.uniform(0, 800, (len(tf), 4)), np.ones(len(tf)))
+        t.append_step(500 + 3 * step, 3, id_base, maxd, ltwh, dcnt, trk)
     df = t.to_dataframe(video_id=4)
     imgs = pd.DataFrame({"frame": np.arange(30), "video_id": 4}, index=pd.Index(500 + np.arange(30), name="id"))
     video = pd.DataFrame({"name": ["v"]}, index=pd.Index([4], name="id"))
