@@ -526,6 +526,29 @@ int tlk_cmc_apply(tlk_cmc *c, const uint8_t *frame_host, double *warp6_host, int
 int tlk_cmc_debug_get(tlk_cmc *c, int what, void *host_buf, size_t cap_bytes, int *n_out);
 
 /* ------------------------------------------------------------------------------------------
+ * StrongSORT's camera-motion estimator on the device. Replaces Track.ECC(previous_frame, next_frame) of
+ * plugins/track/strong_sort/sort/track.py:129-211 (= plugins/track/bpbreid_strong_sort/ecc.py:4-99): BGR2GRAY, cv2.resize(0.1),
+ * cv2.findTransformECC(MOTION_EUCLIDEAN, 100 iterations, eps 1e-5, gaussFiltSize 1), translation / 0.1. Third-party OpenCV in the
+ * reference -- PARITY UNPINNED; the kernel follows oracle/src/ecc.c operation for operation (incl. its summation order).
+ * One handle = one video stream (it keeps the previous frame's 0.1-scaled grey image).
+ *   warp6: [[cos, -sin, tx], [sin, cos, ty]] as doubles of the float32 values the reference's numpy array holds, ready for
+ *     tlk_ssort_camera_update. status: 0 on the first frame (identity; the reference has no previous frame and skips the update),
+ *     n >= 1 = Gauss-Newton iterations run, -1 where cv2 raises (NaN correlation / non-positive lambda denominator): the reference
+ *     catches it and skips the camera update -- so must the caller.
+ *   tlk_ecc_apply_dev: frame (h, w, 3) uint8, warp6 and status in device memory; asynchronous on hip_stream.
+ *   tlk_ecc_apply: host frame, host results (rho = final correlation coefficient, may be NULL).
+ *   tlk_ecc_find_transform (tests): findTransformECC alone on two (h, w) uint8 host images, translation not rescaled.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tlk_ecc tlk_ecc;
+int tlk_ecc_create(int h, int w, int device, tlk_ecc **out);
+int tlk_ecc_destroy(tlk_ecc *c);
+int tlk_ecc_reset(tlk_ecc *c);                        /* new video: forget the previous frame */
+int tlk_ecc_apply_dev(tlk_ecc *c, const uint8_t *frame_dev, double *warp6_dev, int *status_dev, void *hip_stream);
+int tlk_ecc_apply(tlk_ecc *c, const uint8_t *frame_host, double *warp6_host, int *status, double *rho);
+int tlk_ecc_find_transform(const uint8_t *templ_host, const uint8_t *image_host, int h, int w, int max_iter, double eps,
+                           double *warp6_host, int *status, double *rho, int device);
+
+/* ------------------------------------------------------------------------------------------
  * HOTA of one sequence on the device. Replaces HOTA.eval_sequence of the TrackEval copy the reference vendors
  * (plugins/eval/PoseTrack21/posetrack21/posetrack21/trackeval/metrics/hota.py:30-155; official path: pip trackeval behind
  * tracklab/wrappers/eval/trackeval_evaluator.py:28-110). HOST buffers: gt_ids / tr_ids (ids re-labelled 0..n-1 like TrackEval's

@@ -123,3 +123,63 @@ def test_video_engine_runs_the_global_feature_trackers(tracker):
     ltwh = np.stack(late.track_bbox_ltwh.to_list())
     assert np.isfinite(ltwh).all() and (ltwh[:, 2:] > 0).all() and np.isfinite(late.track_bbox_conf.to_numpy()).all()
     pipe.close()
+
+
+class _Recorder:
+    def __init__(self, per_image):
+        self.events = []
+        if per_image:
+            self.on_image_loop_end = lambda engine, image_metadata, image, image_idx, detections: self.events.append(("image", int(image_idx), len(detections)))
+
+    def on_dataset_track_start(self, engine): self.events.append(("dataset_start",))
+    def on_dataset_track_end(self, engine): self.events.append(("dataset_end",))
+    def on_video_loop_start(self, engine, video_metadata, video_idx, index): self.events.append(("video_start", int(video_idx)))
+    def on_video_loop_end(self, engine, video_metadata, video_idx, detections, image_pred): self.events.append(("video_end", int(video_idx), len(detections)))
+    def on_module_step_start(self, engine, task, batch): self.events.append(("step_start", task))
+    def on_module_step_end(self, engine, task, batch, detections): self.events.append(("step_end", task, len(detections)))
+
+
+def test_tracking_engine_fires_the_callback_hooks_and_online_equals_resident():
+    """HipTrackingEngine.track_dataset over two videos (engine/engine.py:105-126): hook order, image ids mapped back to the dataset's,
+    and the `online` drain (per-image callbacks, engine/video.py:93-117) produces the same table as the HBM-resident mode."""
+    import pandas as pd
+    from types import SimpleNamespace
+    from tracklab_amd import gpu_pipeline as gp
+    from tracklab_amd.engine import HipTrackingEngine
+    F, T = 4, 10
+    pipe = gp.DetTrackPipeline("s", n_streams=1, frames_per_step=F, max_dets=64, use_graph=False)
+    streams = {7: _inputs(41, 10, T, pipe.ratio), 9: _inputs(42, 8, T, pipe.ratio)}
+    imgs = pd.DataFrame({"video_id": [7] * T + [9] * T, "frame": list(range(T)) * 2, "file_path": [f"{v}/{f}" for v in (7, 9) for f in range(T)]},
+                        index=pd.Index(list(range(700, 700 + T)) + list(range(900, 900 + T)), name="id"))
+    videos = pd.DataFrame({"name": ["a", "b"]}, index=pd.Index([7, 9], name="id"))
+    state = SimpleNamespace(image_metadatas=imgs, video_metadatas=videos)
+    load = lambda p: streams[int(p.split("/")[0])][1][int(p.split("/")[1])]               # noqa: E731
+    heads = lambda vid, t0, n: streams[vid][0][t0:t0 + n]                                # noqa: E731
+    tables = {}
+    for per_image in (False, True):
+        rec = _Recorder(per_image)
+        got = {}
+        rec_end = rec.on_video_loop_end
+        rec.on_video_loop_end = lambda engine, video_metadata, video_idx, detections, image_pred: (got.__setitem__(int(video_idx), detections), rec_end(engine, video_metadata, video_idx, detections, image_pred))
+        eng = HipTrackingEngine(modules=[], tracker_state=state, num_workers=0, callbacks={"rec": rec}, pipeline=pipe, image_loader=load, synth_heads=heads)
+        eng.track_dataset()
+        ev = rec.events
+        assert ev[0] == ("dataset_start",) and ev[-1] == ("dataset_end",)
+        assert [e for e in ev if e[0] in ("video_start", "video_end")] == [("video_start", 7), ("video_end", 7, len(got[7])), ("video_start", 9), ("video_end", 9, len(got[9]))]
+        assert sum(e[0] == "step_start" for e in ev) == 2 * 3                        # ceil(10 / 4) fused steps per video
+        if per_image:
+            assert [e[1] for e in ev if e[0] == "image"] == list(imgs.index)            # every image, in order, ids of the dataset
+            assert sum(e[2] for e in ev if e[0] == "image") == len(got[7]) + len(got[9])
+            assert sum(e[0] == "step_end" for e in ev) == 6
+        else:
+            assert sum(e[0] == "step_end" for e in ev) == 2                          # resident: one table per video
+        for v in (7, 9):
+            assert set(got[v].image_id) == set(imgs.index[imgs.video_id == v]) and got[v].track_id.notna().sum() > 40
+        tables[per_image] = got
+    for v in (7, 9):
+        a, b = tables[False][v], tables[True][v]
+        np.testing.assert_array_equal(a.index.to_numpy(), b.index.to_numpy())
+        np.testing.assert_array_equal(a.image_id.to_numpy(), b.image_id.to_numpy())
+        np.testing.assert_array_equal(a.track_id.to_numpy(), b.track_id.to_numpy())
+        np.testing.assert_array_equal(np.stack(a.bbox_ltwh.to_list()), np.stack(b.bbox_ltwh.to_list()))
+    pipe.close()

@@ -138,8 +138,6 @@ def test_strongsort_module_host_logic_with_oracle_backend(orc):
 
     m = HipStrongSORT(NS(min_confidence=0.4, ecc=False, hyperparams=hyper), "cuda:0", tracking_dataset=None)
     assert m.level == "image" and m.batch_size == 1 and m.output_columns == ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
-    with pytest.raises(NotImplementedError):
-        HipStrongSORT(NS(ecc=True, hyperparams=hyper), "cuda:0")
     m._make_backend = lambda dim, h, w: Backend()
     ref = orc.PlainStrongSORT(D, **hyper, img_w=1920, img_h=1080)
     frame = np.zeros((1080, 1920, 3), np.uint8)
@@ -168,38 +166,41 @@ def test_strongsort_module_host_logic_with_oracle_backend(orc):
 
 
 def test_strongsort_module_ecc_flow_with_a_stand_in_estimator(orc, monkeypatch):
-    """`ecc: true`: the module asks OpenCV for one warp per frame (Track.ECC's parameters) from the second frame on, also on frames
-    without detections, and hands it to the bank's camera_update before the update -- checked with a stand-in cv2 (OpenCV is not
-    installed here) and the oracle as the bank, against the oracle driven directly in the reference's order (strong_sort_api.py:60-72)."""
-    import sys
-    import types
+    """`ecc: true`: the module asks the estimator (tlk_ecc_*, on the GPU) for one warp per frame, also on frames without detections, and
+    hands it to the bank's camera_update before the update; no warp on the first frame of a video or where the estimator gives up --
+    checked with a stand-in estimator (no GPU here) and the oracle as the bank, against the oracle driven directly in the reference's
+    order (strong_sort_api.py:60-72)."""
+    from tracklab_amd import _lib
     from tracklab_amd._lib import SSORT_ROW
     from tracklab_amd.wrappers import HipStrongSORT
     hyper = dict(ema_alpha=0.9, max_age=10, max_dist=0.2, max_iou_dist=0.7, max_unmatched_preds=7, mc_lambda=0.995, n_init=2, nn_budget=10)
     D = 16
-    with pytest.raises(NotImplementedError):                   # no OpenCV: said loudly, not skipped
-        HipStrongSORT(NS(ecc=True, hyperparams=hyper), "cuda:0")
     rng = np.random.default_rng(3)
     calls = []
 
-    class CvError(Exception):
-        pass
+    class Estimator:                                 # same surface as tracklab_amd._lib.EccEstimator
+        made = 0
 
-    def find_transform_ecc(src, dst, warp, mode, criteria, mask, gauss):
-        assert src.shape == (108, 192) and warp.dtype == np.float32 and mode == 1 and criteria == (3, 100, 1e-5) and gauss == 1
-        if len(calls) == 4:
-            calls.append(None)
-            raise CvError("did not converge")
-        w = np.array([[1, -0.002, rng.normal(0, 0.3)], [0.002, 1, rng.normal(0, 0.2)]], dtype=np.float32)
-        calls.append(w.copy())
-        return 0.99, w
-    cv2 = types.ModuleType("cv2")
-    cv2.COLOR_BGR2GRAY, cv2.INTER_LINEAR, cv2.MOTION_EUCLIDEAN, cv2.TERM_CRITERIA_EPS, cv2.TERM_CRITERIA_COUNT = 6, 1, 1, 2, 1
-    cv2.error = CvError
-    cv2.cvtColor = lambda img, code: img[..., 0]
-    cv2.resize = lambda img, size, fx, fy, interpolation: img[::10, ::10]
-    cv2.findTransformECC = find_transform_ecc
-    monkeypatch.setitem(sys.modules, "cv2", cv2)
+        def __init__(self, h, w, device=0):
+            assert (h, w) == (1080, 1920)
+            self.h, self.w, self.first = h, w, True
+            Estimator.made += 1
+
+        def apply(self, frame):
+            assert frame.shape == (1080, 1920, 3) and frame.dtype == np.uint8
+            if self.first:
+                self.first = False
+                return None
+            if len(calls) == 4:
+                calls.append(None)                   # cv2.error in the reference: no camera update for this frame
+                return None
+            w = np.array([[1, -0.002, rng.normal(0, 3)], [0.002, 1, rng.normal(0, 2)]], dtype=np.float32)
+            calls.append(w.copy())
+            return w
+
+        def reset(self):
+            self.first = True
+    monkeypatch.setattr(_lib, "EccEstimator", Estimator)
 
     class Backend:
         def __init__(self):
@@ -232,8 +233,6 @@ def test_strongsort_module_ecc_flow_with_a_stand_in_estimator(orc, monkeypatch):
         if fr["frame"] >= 1:                                   # strong_sort_api.py:62-65: from the second frame on
             w = calls[k]; k += 1
             if w is not None:
-                w = w.copy()
-                w[0, 2] = w[0, 2] / 0.1; w[1, 2] = w[1, 2] / 0.1       # Track.ECC rescales the translation to full resolution (float32)
                 ref.camera_update(w)
         keep = sample["input"][:, 4] > 0.4
         exp = ref.update(sample["input"][keep], emb[keep])
@@ -242,9 +241,9 @@ def test_strongsort_module_ecc_flow_with_a_stand_in_estimator(orc, monkeypatch):
             np.testing.assert_array_equal(out.track_id.to_numpy(), exp[:, 4])
             np.testing.assert_array_equal(np.stack(out.track_bbox_ltwh.to_list())[:, :2], exp[:, :2])
             seen += len(exp)
-    assert seen > 60 and k == len(calls) == 11 and calls[4] is None
+    assert seen > 60 and k == len(calls) == 11 and calls[4] is None and Estimator.made == 1
     m.reset()
-    assert m._prev_frame is None
+    assert m._ecc_est.first                                   # new video: the previous frame is forgotten
 
 
 def test_botsort_module_host_logic_with_oracle_backend(orc):

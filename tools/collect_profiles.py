@@ -98,14 +98,14 @@ def write_traffic():
 
 
 write_summary("config3", "config3 (YOLOX-m + ReID + BPBReID-StrongSORT), 24 frames/step",
-              "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload config3 --steps 10 --warmup 2 --no-cpu-baseline --check-frames 0")
+              "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload config3 --steps 10 --warmup 3 --no-cpu-baseline --no-latency-leg --check-frames 0")
 write_summary("config2", "config2 (YOLOX-s + OC-SORT), 32 frames/step",
-              "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload config2 --steps 10 --warmup 2 --no-cpu-baseline --check-frames 0")
-for wl in ("config1", "config4", "config5", "config3s", "config3b", "config3d", "config2b"):
+              "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload config2 --steps 10 --warmup 3 --no-cpu-baseline --no-latency-leg --check-frames 0")
+for wl in ("config1", "config4", "config5", "config3s", "config3b", "config3d", "config2b", "config3_f32"):
     if os.path.exists(os.path.join(src, f"bench_{wl}.json")):
         shutil.copy(os.path.join(src, f"bench_{wl}.json"), os.path.join(dst, f"{tag}_bench_{wl}.json"))
 write_summary("config3s", "config3s (YOLOX-m + 512-d ReID + plain StrongSORT: cosine gallery on MFMA), 24 frames/step",
-              "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload config3s --steps 10 --warmup 2 --no-cpu-baseline --check-frames 0")
+              "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload config3s --steps 10 --warmup 3 --no-cpu-baseline --no-latency-leg --check-frames 0")
 rows, paths = stats_rows(os.path.join(src, "kt_probe"))
 if paths:
     shutil.copy(paths[0], os.path.join(dst, f"{tag}_probe_kernels_kernel_stats.csv"))

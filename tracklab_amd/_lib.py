@@ -1003,6 +1003,74 @@ def pyset_difference_order(a, b, force_table=False):
 # ------------------------------------------------------------------------------------------------
 # camera-motion estimation on the device (tlk_cmc_*): GMC.applySparseOptFlow of BoT-SORT (gmc.py:239-303)
 # ------------------------------------------------------------------------------------------------
+class EccEstimator:
+    """One video stream's StrongSORT camera-motion estimator (Track.ECC, strong_sort/sort/track.py:129-211): ``apply(frame)`` -> the
+    (2, 3) float32 warp for ``SsortBank.camera_update``, or None where the reference skips the update (first frame; cv2.error).
+    ``apply_dev(frame_cuda_tensor)`` leaves warp (6 doubles) and status (int32) in device memory. OpenCV's findTransformECC restated:
+    PARITY UNPINNED (tlk_ecc.hip, oracle/src/ecc.c)."""
+
+    def __init__(self, height, width, device=0):
+        L = lib()
+        vp, ci = C.c_void_p, C.c_int
+        L.tlk_ecc_create.argtypes = [ci, ci, ci, C.POINTER(vp)]
+        L.tlk_ecc_destroy.argtypes = [vp]
+        L.tlk_ecc_reset.argtypes = [vp]
+        L.tlk_ecc_apply_dev.argtypes = [vp, vp, vp, vp, vp]
+        L.tlk_ecc_apply.argtypes = [vp, vp, vp, C.POINTER(ci), C.POINTER(C.c_double)]
+        self.h, self.w = int(height), int(width)
+        h = vp()
+        check(L.tlk_ecc_create(self.h, self.w, device, C.byref(h)))
+        self._h = h
+        self.iterations, self.rho = 0, 0.0
+        self.warp_dev = self.status_dev = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tlk_ecc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        check(lib().tlk_ecc_reset(self._h))
+
+    def apply(self, frame):
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        assert frame.shape == (self.h, self.w, 3)
+        H = np.zeros(6)
+        n, rho = C.c_int(0), C.c_double(0.0)
+        check(lib().tlk_ecc_apply(self._h, frame.ctypes.data, H.ctypes.data, C.byref(n), C.byref(rho)))
+        self.iterations, self.rho = n.value, rho.value
+        return H.reshape(2, 3).astype(np.float32) if n.value >= 1 else None
+
+    def apply_dev(self, frame, stream_ptr=None):
+        import torch
+        assert frame.is_cuda and frame.dtype == torch.uint8 and frame.is_contiguous() and tuple(frame.shape) == (self.h, self.w, 3)
+        if self.warp_dev is None:
+            self.warp_dev = torch.zeros(6, dtype=torch.float64, device=frame.device)
+            self.status_dev = torch.zeros(1, dtype=torch.int32, device=frame.device)
+        check(lib().tlk_ecc_apply_dev(self._h, frame.data_ptr(), self.warp_dev.data_ptr(), self.status_dev.data_ptr(),
+                                      stream_ptr if stream_ptr is not None else current_stream_ptr()))
+        return self.warp_dev, self.status_dev
+
+
+def ecc_find_transform(templ, image, max_iter=100, eps=1e-5, device=0):
+    """cv2.findTransformECC (Euclidean, from the identity) alone on two (h, w) uint8 images -> (warp (2,3) float32, iterations | -1, rho)."""
+    templ = np.ascontiguousarray(templ, dtype=np.uint8); image = np.ascontiguousarray(image, dtype=np.uint8)
+    assert templ.shape == image.shape and templ.ndim == 2
+    L = lib()
+    L.tlk_ecc_find_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int]
+    H = np.zeros(6)
+    n, rho = C.c_int(0), C.c_double(0.0)
+    check(L.tlk_ecc_find_transform(templ.ctypes.data, image.ctypes.data, templ.shape[0], templ.shape[1], int(max_iter), float(eps), H.ctypes.data, C.byref(n),
+                                   C.byref(rho), device))
+    return H.reshape(2, 3).astype(np.float32), n.value, rho.value
+
+
 class CmcEstimator:
     """One video stream's camera-motion estimator: ``apply(frame)`` -> (2, 3) float64 warp for ``BoTSORTBank.update(..., warp=)``;
     ``apply_dev(frame_cuda_tensor)`` leaves the warp in device memory (``.warp_dev``: 6 doubles) for ``update_dev(..., warps=)`` with

@@ -34,6 +34,7 @@ class DetTrackPipeline:
                  use_graph: bool = True, tracker: str = "oc_sort"):
         """tracker: "oc_sort" (configs[1]) or "byte_track" (same detector, ByteTrack association)."""
         self.tracker = tracker
+        dtype = getattr(torch, dtype) if isinstance(dtype, str) else dtype        # yaml: "float16" / "float32"
         self.S, self.F, self.maxd = n_streams, frames_per_step, max_dets
         self.H, self.W, self.size, self.dtype, self.layout = height, width, size, dtype, layout
         self.nms_thr, self.score_thr = nms_thr, score_thr
@@ -242,6 +243,7 @@ class DetReidTrackPipeline:
         tlk_simcc_decode) between detector and ReID; its keypoints drive the tracker's OKS motion cost (motion_criterium "oks")."""
         from .backbones.reid import part_based_reid
         self.tracker = tracker
+        dtype = getattr(torch, dtype) if isinstance(dtype, str) else dtype        # yaml: "float16" / "float32"
         # trackers that own a global-feature ReID net on Pillow-semantics 256x128 crops (ReIDDetectMultiBackend): same stages, other bank
         self.global_feat = tracker in ("strong_sort", "bot_sort", "deep_oc_sort")
         if self.global_feat:

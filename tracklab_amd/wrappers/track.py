@@ -295,52 +295,30 @@ class HipStrongSORT(ImageLevelModule, _ReidTrackerBase):
         self._model = None
         self._img_hw = None
         self._ecc = bool(cfg_get(cfg, "ecc", False))
-        self._prev_frame = None
-        if self._ecc:
-            try:
-                import cv2  # noqa: F401  (the estimator is OpenCV's, exactly as in the reference; only its result goes to the GPU)
-            except ImportError as e:
-                raise NotImplementedError("ecc: true needs OpenCV for the estimator (cv2.findTransformECC, sort/track.py:130-211); the warp is "
-                                          "applied on the GPU (tlk_ssort_camera_update). Install opencv-python or set ecc: false") from e
+        self._ecc_est = None        # _lib.EccEstimator, created with the first frame's size
 
     def reset(self):
-        self._prev_frame = None
+        if self._ecc_est is not None:
+            self._ecc_est.reset()
         if self._bank is not None:
             self._bank.reset(-1)
 
-    @staticmethod
-    def _ecc_warp(src, dst, scale=0.1, eps=1e-5, max_iter=100):
-        """Track.ECC (strong_sort/sort/track.py:130-211) with its defaults: grey, 0.1-scaled frames, Euclidean model, translation
-        rescaled. One estimate per frame (the reference recomputes the same one for every track). None when cv2 gives up."""
-        import cv2
-        if src.shape != dst.shape:
-            return None
-        if src.ndim == 3:
-            src, dst = cv2.cvtColor(src, cv2.COLOR_BGR2GRAY), cv2.cvtColor(dst, cv2.COLOR_BGR2GRAY)
-        src_r = cv2.resize(src, (0, 0), fx=scale, fy=scale, interpolation=cv2.INTER_LINEAR)
-        dst_r = cv2.resize(dst, (0, 0), fx=scale, fy=scale, interpolation=cv2.INTER_LINEAR)
-        warp = np.eye(2, 3, dtype=np.float32)
-        criteria = (cv2.TERM_CRITERIA_EPS | cv2.TERM_CRITERIA_COUNT, max_iter, eps)
-        try:
-            _, warp = cv2.findTransformECC(src_r, dst_r, warp, cv2.MOTION_EUCLIDEAN, criteria, None, 1)
-        except cv2.error:
-            return None
-        warp[0, 2] = warp[0, 2] / scale
-        warp[1, 2] = warp[1, 2] / scale
-        return warp
-
     def _camera_step(self, image, metadatas):
+        """strong_sort_api.py:61-65: tracker.camera_update(previous frame, current frame) ahead of the update. Track.ECC (sort/track.py:129-211:
+        grey, 0.1-scaled frames, Euclidean model, translation rescaled) runs on the GPU (tlk_ecc_*: cv2.findTransformECC restated, parity
+        unpinned -- DESIGN.md); one estimate per frame (the reference recomputes the same one for every track)."""
         if not self._ecc:
             return
         if image is None:                                                    # strong_sort_api.py:61: the frame is read before the empty check
             from PIL import Image
             image = np.asarray(Image.open(metadatas["file_path"].values[0]).convert("RGB"))
         img = np.ascontiguousarray(to_numpy(image))
-        if self._prev_frame is not None and self._bank is not None:          # strong_sort_api.py:62-65
-            warp = self._ecc_warp(self._prev_frame, img)
-            if warp is not None:
-                self._bank.camera_update(warp, 0)
-        self._prev_frame = img
+        if self._ecc_est is None or (self._ecc_est.h, self._ecc_est.w) != img.shape[:2]:
+            from .. import _lib
+            self._ecc_est = _lib.EccEstimator(img.shape[0], img.shape[1], device=_device_index(self.device))
+        warp = self._ecc_est.apply(img)                                      # None on the first frame of a video and where cv2 raises
+        if warp is not None and self._bank is not None:
+            self._bank.camera_update(warp, 0)
 
     def _make_backend(self, dim, img_h, img_w):
         from .._lib import SsortBank
