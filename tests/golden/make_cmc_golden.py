@@ -5,7 +5,8 @@ which is why oracle/src/cmc.c and tlk_cmc.hip are "parity unpinned"). Writes tes
   * two seeded synthetic frames related by a known similarity (the generator of tests/test_oracle_cmc.py),
   * every intermediate of GMC.applySparseOptFlow (plugins/track/bot_sort/gmc.py:239-303) computed by OpenCV itself: grey image,
     downscaled image, corners of goodFeaturesToTrack, points / status of calcOpticalFlowPyrLK, matrix / inliers of
-    estimateAffinePartial2D, and -- when /root/reference is importable -- the matrix GMC(method="sparseOptFlow").apply returns.
+    estimateAffinePartial2D, and -- when /root/reference is importable -- the matrix GMC(method="sparseOptFlow").apply returns,
+  * a frame pair with its 0.1-scaled grey images and cv2.findTransformECC's warp (full run and after 1 / 2 / 5 iterations): Track.ECC.
 
 tests/test_oracle_cmc.py::test_oracle_against_opencv_fixture (skipped while the file is absent) then pins oracle/src/cmc.c stage by
 stage; the GPU tests pin tlk_cmc.hip on the oracle. Usage: python tests/golden/make_cmc_golden.py
@@ -52,6 +53,19 @@ def main():
         out["gmc_apply"] = g.apply(f1)
     except Exception as e:                                   # the reference tree is optional here
         print("reference GMC not importable:", e)
+    # StrongSORT's estimator: Track.ECC of plugins/track/strong_sort/sort/track.py:129-211 (oracle/src/ecc.c, tlk_ecc.hip)
+    from test_oracle_ecc import ecc_pair
+    e0, e1 = ecc_pair(5, 0.004, 13.0, -8.0, 540, 960)
+    s0 = cv2.resize(cv2.cvtColor(e0, cv2.COLOR_BGR2GRAY), (0, 0), fx=0.1, fy=0.1, interpolation=cv2.INTER_LINEAR)
+    s1 = cv2.resize(cv2.cvtColor(e1, cv2.COLOR_BGR2GRAY), (0, 0), fx=0.1, fy=0.1, interpolation=cv2.INTER_LINEAR)
+    crit = (cv2.TERM_CRITERIA_EPS | cv2.TERM_CRITERIA_COUNT, 100, 1e-5)
+    rho, wm = cv2.findTransformECC(s0, s1, np.eye(2, 3, dtype=np.float32), cv2.MOTION_EUCLIDEAN, crit, None, 1)
+    out["ecc_f0"], out["ecc_f1"], out["ecc_small0"], out["ecc_small1"], out["ecc_warp_small"], out["ecc_rho"] = e0, e1, s0, s1, wm.copy(), np.array(rho)
+    wm[0, 2] = wm[0, 2] / 0.1; wm[1, 2] = wm[1, 2] / 0.1
+    out["ecc_warp"] = wm
+    for iters in (1, 2, 5):                                   # early iterates: pin the per-iteration arithmetic, not only the fixed point
+        _, wi = cv2.findTransformECC(s0, s1, np.eye(2, 3, dtype=np.float32), cv2.MOTION_EUCLIDEAN, (cv2.TERM_CRITERIA_COUNT, iters, -1), None, 1)
+        out[f"ecc_warp_small_it{iters}"] = wi
     np.savez_compressed(os.path.join(HERE, "cmc_opencv.npz"), **out)
     print("wrote cmc_opencv.npz with OpenCV", cv2.__version__)
 

@@ -29,7 +29,7 @@ def test_ecc_recovers_a_known_euclidean_motion(orc):
     theta, tx, ty = 0.004, 13.0, -8.0
     f0, f1 = ecc_pair(5, theta, tx, ty, 540, 960)
     warp, it = orc.ecc_frames(f0, f1)
-    assert warp is not None and warp.dtype == np.float32 and 2 <= it < 100
+    assert warp is not None and warp.dtype == np.float32 and 2 <= it <= 100      # (eps 1e-5 is below the jitter of the 1/32 px warp grid: often all 100)
     # template = previous frame, input = current: current(W x) = previous(x), and the content moved by x -> R x + t, so W = (R, t)
     np.testing.assert_allclose(warp[:, :2], [[np.cos(theta), -np.sin(theta)], [np.sin(theta), np.cos(theta)]], atol=5e-4)
     np.testing.assert_allclose(warp[:, 2], [tx, ty], atol=0.6)
@@ -57,10 +57,10 @@ def test_ecc_iteration_cap_and_epsilon(orc):
     w1, it1, _ = orc.ecc_find_transform(a, b, max_iter=1)
     w3, it3, _ = orc.ecc_find_transform(a, b, max_iter=3)
     wf, itf, rho = orc.ecc_find_transform(a, b)
-    assert it1 == 1 and it3 == 3 and 3 < itf < 100 and rho > 0.9
+    assert it1 == 1 and it3 == 3 and 3 < itf <= 100 and rho > 0.9
     assert np.abs(w1 - wf).max() > np.abs(w3 - wf).max()                    # more iterations: closer to the converged warp
     _, it_loose, _ = orc.ecc_find_transform(a, b, eps=1e-2)
-    assert it_loose < itf
+    assert it_loose < 10 and it_loose <= itf
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "cmc_opencv.npz")), reason="needs the OpenCV fixture (tests/golden/make_cmc_golden.py, run where cv2 is installed)")
@@ -69,5 +69,7 @@ def test_oracle_against_opencv_ecc_fixture(orc):
     if "ecc_warp" not in g:
         pytest.skip("fixture predates the ECC entries")
     w, it, rho = orc.ecc_find_transform(g["ecc_small0"], g["ecc_small1"])
+    for iters in (1, 2, 5):
+        np.testing.assert_allclose(orc.ecc_find_transform(g["ecc_small0"], g["ecc_small1"], max_iter=iters, eps=-1)[0], g[f"ecc_warp_small_it{iters}"], atol=1e-5)
     np.testing.assert_allclose(w, g["ecc_warp_small"], atol=1e-5)
     assert abs(rho - float(g["ecc_rho"])) < 1e-6

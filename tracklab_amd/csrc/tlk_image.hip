@@ -877,6 +877,7 @@ __global__ void __launch_bounds__(BLOCK) crop_fat_kernel(const unsigned char *__
 constexpr int PIL_BITS = 32 - 8 - 2;
 constexpr int PIL_BAND = 32;                          // (16 rows measured slower: 428 vs 356 us -- twice the per-band set-up)
 constexpr int PIL_KMAX = 5;                           // taps per axis handled from LDS tables: scale <= 2
+constexpr int PIL_KPAD = 8;                           // coefficient rows padded to 32 bytes: one ds_read_b128 + one b32 per row
 constexpr int PIL_ROWS = 40;                          // staged source rows per band
 constexpr int PIL_ROW_BYTES = 544;                    // as CROP_LDS_ROW_BYTES: crops up to 170 px wide
 constexpr int PIL_OW_MAX = 128;
@@ -945,17 +946,25 @@ __device__ __forceinline__ void pil_hsample(const unsigned char *__restrict__ ro
     o[0] = pil_clip8(s0); o[1] = pil_clip8(s1); o[2] = pil_clip8(s2);
 }
 
-template <typename T, int LAYOUT>
+// byte q of a little-endian word array (constant q: the shift folds into an SDWA byte select of the multiply)
+template <int NW> __device__ __forceinline__ int byte_of(const unsigned (&w)[NW], int q) { return (int)((w[q >> 2] >> ((q & 3) * 8)) & 0xffu); }
+
+// OWC: the output width as a compile-time constant (128: the ReID input of every tracker here), 0 = the run-time OW
+template <typename T, int LAYOUT, int OWC>
 __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
                                                          const double *__restrict__ boxes, int box_stride, const int *__restrict__ counts,
-                                                         int max_n, int OH, int OW, float m0, float m1, float m2, float d0, float d1, float d2,
+                                                         int max_n, int OH, int OW_rt, float m0, float m1, float m2, float d0, float d1, float d2,
                                                          T *__restrict__ out, int swap_rb)
 {
+    const int OW = OWC ? OWC : OW_rt;
     // the source rows; afterwards the band's output on its way to coalesced stores (PIL_BAND rows x 128 px x 3 two-byte elements)
     __shared__ __attribute__((aligned(16))) unsigned char s_rows[PIL_ROWS * PIL_ROW_BYTES > PIL_BAND * PIL_OW_MAX * 6 ? PIL_ROWS * PIL_ROW_BYTES : PIL_BAND * PIL_OW_MAX * 6];
-    __shared__ __attribute__((aligned(16))) unsigned char s_h[PIL_ROWS * (PIL_OW_MAX * 3 + 16)];
-    __shared__ int s_hmin[PIL_OW_MAX], s_hmax[PIL_OW_MAX], s_hk[PIL_OW_MAX][PIL_KMAX];
-    __shared__ int s_vmin[PIL_BAND], s_vmax[PIL_BAND], s_vk[PIL_BAND][PIL_KMAX];
+    // (+ PIL_KMAX - 1 rows: the vertical pass reads all of its taps unconditionally, the ones past a row's support with weight 0)
+    __shared__ __attribute__((aligned(16))) unsigned char s_h[(PIL_ROWS + PIL_KMAX - 1) * (PIL_OW_MAX * 3 + 16)];
+    __shared__ int s_hmin[PIL_OW_MAX];
+    __shared__ __attribute__((aligned(16))) int s_hk[PIL_OW_MAX][PIL_KPAD];
+    __shared__ int s_vmin[PIL_BAND];
+    __shared__ __attribute__((aligned(16))) int s_vk[PIL_BAND][PIL_KPAD];
     // ToTensor + Normalize of an 8-bit value, per SOURCE channel, with exactly the reference's float32 arithmetic ((v / 255) - mean) / std:
     // one table entry per (channel, value) instead of two IEEE divisions per output element
     __shared__ T s_lut[3][256];
@@ -1005,7 +1014,7 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
             int xmin, xmax;
             pil_bounds(ax, cw, tid, xmin, xmax);
             const double ww = pil_wsum(ax, tid, xmin, xmax);
-            s_hmin[tid] = xmin * 3; s_hmax[tid] = xmax;
+            s_hmin[tid] = xmin * 3;
             for (int k = 0; k < PIL_KMAX; ++k) s_hk[tid][k] = k < xmax ? pil_fixed(ax, tid, xmin, k, ww) : 0;
         }
         if (tid >= BLOCK - PIL_BAND && tid - (BLOCK - PIL_BAND) < nb) {         // vertical coefficient rows (last wavefront's lanes)
@@ -1013,19 +1022,30 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
             int ymin, ymax;
             pil_bounds(ay, ch, y_base + ry, ymin, ymax);
             const double ww = pil_wsum(ay, y_base + ry, ymin, ymax);
-            s_vmin[ry] = ymin - r_lo; s_vmax[ry] = ymax;
+            s_vmin[ry] = ymin - r_lo;
             for (int k = 0; k < PIL_KMAX; ++k) s_vk[ry][k] = k < ymax ? pil_fixed(ay, y_base + ry, ymin, k, ww) : 0;
         }
         __syncthreads();
-        for (int idx = tid; idx < nrows * OW; idx += BLOCK) {                   // horizontal pass -> 8-bit plane
+        // horizontal pass -> 8-bit plane. Every tap is read (taps past a column's support carry weight 0), so the loop has no divergent
+        // branches and no serialised LDS round trips: ONE unaligned 16-byte read brings the 3 x 5 source bytes of the pixel, one 16-byte +
+        // one 4-byte read its weights (r01 form: a branch and 3 narrow reads per tap, ~115 instructions and 5 LDS latencies per pixel)
+        const unsigned a_lo = (unsigned)(uintptr_t)(frames + ((size_t)b * H * W + (size_t)(y1 + r_lo) * W + x1) * 3) & 15u, row_step = ((unsigned)W * 3u) & 15u;
+        const bool wide_h = ax.ksize > 3;                                       // (uniform: support > 1, i.e. the crop is wider than OW)
+        for (int idx = tid; idx < nrows * OW; idx += BLOCK) {
             const int rr = idx / OW, x = idx - rr * OW;
-            const uintptr_t g0 = (uintptr_t)(frames + ((size_t)b * H * W + (size_t)(y1 + r_lo + rr) * W + x1) * 3);
-            const unsigned char *p = s_rows + rr * PIL_ROW_BYTES + (int)(g0 & 15) + s_hmin[x];
-            const int n = s_hmax[x];
+            const unsigned char *p = s_rows + rr * PIL_ROW_BYTES + (int)((a_lo + (unsigned)rr * row_step) & 15u) + s_hmin[x];
+            unsigned w[4];
+            __builtin_memcpy(w, p, 16);
+            const int4 c03 = *reinterpret_cast<const int4 *>(&s_hk[x][0]);
             int s0 = 1 << (PIL_BITS - 1), s1 = s0, s2 = s0;
-#pragma unroll
-            for (int k = 0; k < PIL_KMAX; ++k)
-                if (k < n) { const int kv = s_hk[x][k]; s0 += __mul24((int)p[k * 3], kv); s1 += __mul24((int)p[k * 3 + 1], kv); s2 += __mul24((int)p[k * 3 + 2], kv); }
+            s0 += __mul24(byte_of(w, 0), c03.x); s1 += __mul24(byte_of(w, 1), c03.x); s2 += __mul24(byte_of(w, 2), c03.x);
+            s0 += __mul24(byte_of(w, 3), c03.y); s1 += __mul24(byte_of(w, 4), c03.y); s2 += __mul24(byte_of(w, 5), c03.y);
+            s0 += __mul24(byte_of(w, 6), c03.z); s1 += __mul24(byte_of(w, 7), c03.z); s2 += __mul24(byte_of(w, 8), c03.z);
+            if (wide_h) {
+                const int c4 = s_hk[x][4];
+                s0 += __mul24(byte_of(w, 9), c03.w); s1 += __mul24(byte_of(w, 10), c03.w); s2 += __mul24(byte_of(w, 11), c03.w);
+                s0 += __mul24(byte_of(w, 12), c4); s1 += __mul24(byte_of(w, 13), c4); s2 += __mul24(byte_of(w, 14), c4);
+            }
             unsigned char *o = s_h + rr * HS + x * 3;
             o[0] = (unsigned char)pil_clip8(s0); o[1] = (unsigned char)pil_clip8(s1); o[2] = (unsigned char)pil_clip8(s2);
         }
@@ -1039,18 +1059,21 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
         if (y >= OH) continue;
         T px[8][3];
         if (valid && staged) {
-            const unsigned char *p = s_h + s_vmin[ry] * HS + x_base * 3;
-            const int n = s_vmax[ry];
+            const unsigned char *p = s_h + s_vmin[ry] * HS + x_base * 3;      // 8-byte aligned: HS and 24 are multiples of 8
+            const int4 c03 = *reinterpret_cast<const int4 *>(&s_vk[ry][0]);
+            const int c4 = s_vk[ry][4];
+            const int kv[PIL_KMAX] = {c03.x, c03.y, c03.z, c03.w, c4};
+            const int ks = ay.ksize;                                            // (uniform per crop; taps past a row's support weigh 0)
             int acc[24];
 #pragma unroll
             for (int q = 0; q < 24; ++q) acc[q] = 1 << (PIL_BITS - 1);
 #pragma unroll
             for (int k = 0; k < PIL_KMAX; ++k)
-                if (k < n) {
-                    const int kv = s_vk[ry][k];
-                    const unsigned char *r = p + k * HS;
+                if (k < 3 || k < ks) {
+                    unsigned w[6];
+                    __builtin_memcpy(w, __builtin_assume_aligned(p + k * HS, 8), 24);
 #pragma unroll
-                    for (int q = 0; q < 24; ++q) acc[q] += __mul24((int)r[q], kv);
+                    for (int q = 0; q < 24; ++q) acc[q] += __mul24(byte_of(w, q), kv[k]);
                 }
 #pragma unroll
             for (int k = 0; k < 8; ++k)
@@ -1585,12 +1608,11 @@ int launch_pil_crop(const unsigned char *frames, int B, int H, int W, const doub
 {
     const int sw0 = swap_rb ? 2 : 0, sw2 = swap_rb ? 0 : 2;
     const dim3 grid((unsigned)((long long)B * max_n * ((OH + PIL_BAND - 1) / PIL_BAND)));
-    if (layout == LAYOUT_NCHW)
-        hipLaunchKernelGGL((pil_crop_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, box_stride, counts, max_n, OH, OW,
-                           mean[sw0], mean[1], mean[sw2], stdv[sw0], stdv[1], stdv[sw2], (T *)out, swap_rb);
-    else
-        hipLaunchKernelGGL((pil_crop_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, box_stride, counts, max_n, OH, OW,
-                           mean[sw0], mean[1], mean[sw2], stdv[sw0], stdv[1], stdv[sw2], (T *)out, swap_rb);
+#define TLK_PIL_LAUNCH(LAY, OWC) hipLaunchKernelGGL((pil_crop_kernel<T, LAY, OWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, box_stride, counts, max_n, OH, OW, \
+                                                  mean[sw0], mean[1], mean[sw2], stdv[sw0], stdv[1], stdv[sw2], (T *)out, swap_rb)
+    if (layout == LAYOUT_NCHW) { if (OW == 128) TLK_PIL_LAUNCH(LAYOUT_NCHW, 128); else TLK_PIL_LAUNCH(LAYOUT_NCHW, 0); }
+    else { if (OW == 128) TLK_PIL_LAUNCH(LAYOUT_NHWC, 128); else TLK_PIL_LAUNCH(LAYOUT_NHWC, 0); }
+#undef TLK_PIL_LAUNCH
     return TLK_OK;
 }
 

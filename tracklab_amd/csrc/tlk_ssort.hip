@@ -231,14 +231,36 @@ ssort_assoc_kernel(SsDev Dv, SsP P, SsIn in, tlk_ssort_row *__restrict__ rows_al
     const int nu = block_compact(T, [&](int p) { return trk_at(order[p]).i(SI_STATE) != ST_CONFIRMED; }, [&](int p, int pos) { L.bc[pos] = p; }, L.scan);
     double *cm = ((size_t)nc * N <= (size_t)Dv.cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
     // gated_metric: cosine gallery minimum + gate_cost_matrix (linear_assignment.py:131-174) + thresholding (:54)
-    for (int e = tid; e < nc * N; e += BLOCK) {
-        const int r = e / N, j = e - r * N;
-        const int p = L.cand[r];
-        double c = reid[(size_t)p * MAXD + L.sel[j]];
-        const double gd = gating_from(gl + (size_t)p * SGL, L.dxyah + j * 4, 4);
-        if (gd > CHI2_4) c = INFTY_COST;
-        c = P.mc_lambda * c + (1 - P.mc_lambda) * gd;
-        cm[e] = c > P.max_dist ? P.max_dist + 1e-5 : c;
+    // one wavefront per track row, lanes over the detections; the row's gate factors are prefetched into registers one row ahead
+    // (the flat (row, det) sweep re-read 20 doubles of global memory per entry: as in tlk_bpbss.hip, 70 -> 31 us for 110 x 98)
+    {
+        const int wv = tid >> 6, lane = tid & 63;
+        double gA[20];
+        int r = wv;
+        if (r < nc) {
+            const double *g = gl + (size_t)L.cand[r] * SGL;
+#pragma unroll
+            for (int q = 0; q < 20; ++q) gA[q] = g[q];
+        }
+        for (; r < nc; r += NWAVES) {
+            const int p = L.cand[r];
+            double gB[20];
+            const int rn = r + NWAVES;
+            if (rn < nc) {
+                const double *g = gl + (size_t)L.cand[rn] * SGL;
+#pragma unroll
+                for (int q = 0; q < 20; ++q) gB[q] = g[q];
+            }
+            for (int j = lane; j < N; j += WAVE) {
+                double c = reid[(size_t)p * MAXD + L.sel[j]];
+                const double gd = gating_reg<4>(gA, L.dxyah + j * 4);
+                if (gd > CHI2_4) c = INFTY_COST;
+                c = P.mc_lambda * c + (1 - P.mc_lambda) * gd;
+                cm[(size_t)r * N + j] = c > P.max_dist ? P.max_dist + 1e-5 : c;
+            }
+#pragma unroll
+            for (int q = 0; q < 20; ++q) gA[q] = gB[q];
+        }
     }
     for (int j = tid; j < N; j += BLOCK) L.um_db[j] = j;
     __syncthreads();
