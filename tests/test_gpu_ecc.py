@@ -28,8 +28,8 @@ def test_find_transform_on_device_equals_the_oracle(orc):
             assert it_g == it_e, (seed, max_iter, it_g, it_e)
             np.testing.assert_allclose(got, exp, rtol=0, atol=2e-6, err_msg=str((seed, max_iter)))
             assert abs(rho_g - rho_e) < 1e-9
-    flat = np.full((40, 60), 90, np.uint8)
-    assert _lib.ecc_find_transform(flat, a[:40, :60].copy())[1] == -1        # NaN correlation: where cv2 raises
+    flat = np.full(a.shape, 90, np.uint8)
+    assert _lib.ecc_find_transform(flat, a)[1] == -1                         # zero-variance template -> NaN correlation: where cv2 raises
 
 
 def test_estimator_on_frames_equals_the_oracle_and_recovers_the_motion(orc):
