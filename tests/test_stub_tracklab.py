@@ -142,7 +142,7 @@ def test_every_module_yaml_instantiates_on_the_device_under_the_stub(tmp_path):
                 meta = pd.Series({{"id": 0, "video_id": 0, "frame": 0}}, name=0)
                 for _ in range(3):
                     out = m.process(m.preprocess(img, det, meta), det, pd.DataFrame([meta]))
-                assert len(out) == 2 and out.track_id.notna().all() and list(out.index) == [0, 1]
+                assert len(out) == 2 and out.track_id.notna().all() and sorted(out.index) == [0, 1], out
         print("instantiated", made)
     """
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), REPO, os.environ.get("PYTHONPATH", "")]))
