@@ -45,7 +45,7 @@ def test_estimator_on_frames_equals_the_oracle_and_recovers_the_motion(orc):
     np.testing.assert_allclose(got, exp, rtol=0, atol=2e-5)
     np.testing.assert_allclose(got[:, 2], [tx, ty], atol=0.6)
     np.testing.assert_allclose(got[1, 0], np.sin(theta), atol=5e-4)
-    warp_dev, status_dev = est.apply_dev(torch.from_numpy(f0).cuda())          # device entry: f1 -> f0, results stay in HBM
+    warp_dev, status_dev = est.apply_dev(torch.from_numpy(np.ascontiguousarray(f0)).cuda())          # device entry: f1 -> f0, results stay in HBM
     back, it_b = orc.ecc_frames(f1, f0)
     torch.cuda.synchronize()
     assert int(status_dev.item()) == it_b
