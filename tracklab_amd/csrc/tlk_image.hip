@@ -691,7 +691,6 @@ __global__ void __launch_bounds__(BLOCK) crop_fat_kernel(const unsigned char *__
     constexpr int OW = 128, HS = OW * 3, GROUPS = OW / 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     __shared__ int s_y[CF_BANDS * CS_BAND * 2];         // per output row of the chunk: (source row y0 | y1 << 16) relative to the crop, (b0 | b1 << 16)
-    __shared__ int s_rsh[CS_ROWS];
     __shared__ CropPar s_par;
     const int tid = threadIdx.x;
     int wg;
@@ -781,21 +780,39 @@ __global__ void __launch_bounds__(BLOCK) crop_fat_kernel(const unsigned char *__
                 const int rr = rsub + 8 * j;
                 if (rr < nrows) *reinterpret_cast<uint4 *>(s_rows + rr * CS_ROW_BYTES + c16 * 16) = stage[j];
             }
-            if (tid < nrows) s_rsh[tid] = (int)((uintptr_t)(frames + frame_off + ((size_t)(par.t + r_lo + tid) * W + par.l) * 3) & 15);
         }
         __syncthreads();
-        if (staged) {                                   // horizontal pass: thread = one x, every second staged row
+        if (staged) {
+            // horizontal pass: thread = one x, every second staged row. The two taps of the three channels are 6 consecutive bytes (3 when the
+            // right tap is clamped onto the left one): ONE unaligned 8-byte LDS read per (row, x), the (left, right) pairs built by v_perm_b32
+            // with per-thread selectors, three rows in flight per iteration (r02a: six byte reads in three dependent LDS round trips per row
+            // plus a fourth for the row's alignment shift -- ~30 % of a band's time was that latency chain)
             const int x = tid & 127;
             const int2 xc = s_xc[x];
-            const int o0 = xc.x & 0xffff, o1 = o0 + (xc.x >> 16);
+            const int o0 = xc.x & 0xffff;
+            const unsigned int d1 = (unsigned int)(xc.x >> 16);                  // 3, or 0 when x + 1 is clamped
+            const unsigned int sel0 = 0x0c000c00u | (d1 << 16), sel1 = sel0 + 0x00010001u, sel2 = sel0 + 0x00020002u;
             const us2_t A = __builtin_bit_cast(us2_t, xc.y);
-            for (int rr = tid >> 7; rr < nrows; rr += 2) {
-                const unsigned char *p = s_rows + rr * CS_ROW_BYTES + s_rsh[rr];
-                unsigned short *o = s_h + rr * HS + x * 3;
+            // alignment shift of staged row rr: (address of the crop's first byte in source row r_lo + rr) & 15
+            const unsigned int a_lo = (unsigned int)(uintptr_t)(frames + frame_off + ((size_t)(par.t + r_lo) * W + par.l) * 3) & 15u, a_step = ((unsigned int)W * 3u) & 15u;
+            for (int r0 = tid >> 7; r0 < nrows; r0 += 6) {
+                unsigned int lo[3], hi[3];
 #pragma unroll
-                for (int c3 = 0; c3 < 3; ++c3) {
-                    const unsigned int P = (unsigned int)p[o0 + c3] | ((unsigned int)p[o1 + c3] << 16);
-                    o[c3] = (unsigned short)(__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, P), A, 0u, false) >> 4);
+                for (int u = 0; u < 3; ++u) {
+                    const int rr = r0 + 2 * u;                                     // (rows past nrows: read but not used)
+                    unsigned int w[2];
+                    __builtin_memcpy(w, s_rows + rr * CS_ROW_BYTES + (int)((a_lo + (unsigned int)rr * a_step) & 15u) + o0, 8);
+                    lo[u] = w[0]; hi[u] = w[1];
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int rr = r0 + 2 * u;
+                    if (rr < nrows) {
+                        unsigned short *o = s_h + rr * HS + x * 3;
+                        o[0] = (unsigned short)(__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(hi[u], lo[u], sel0)), A, 0u, false) >> 4);
+                        o[1] = (unsigned short)(__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(hi[u], lo[u], sel1)), A, 0u, false) >> 4);
+                        o[2] = (unsigned short)(__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(hi[u], lo[u], sel2)), A, 0u, false) >> 4);
+                    }
                 }
             }
         }
@@ -877,6 +894,7 @@ __global__ void __launch_bounds__(BLOCK) crop_fat_kernel(const unsigned char *__
 constexpr int PIL_BITS = 32 - 8 - 2;
 constexpr int PIL_BAND = 32;                          // (16 rows measured slower: 428 vs 356 us -- twice the per-band set-up)
 constexpr int PIL_KMAX = 5;                           // taps per axis handled from LDS tables: scale <= 2
+constexpr int PIL_BPW = 4;                            // bands per workgroup
 constexpr int PIL_KPAD = 8;                           // coefficient rows padded to 32 bytes: one ds_read_b128 + one b32 per row
 constexpr int PIL_ROWS = 40;                          // staged source rows per band
 constexpr int PIL_ROW_BYTES = 544;                    // as CROP_LDS_ROW_BYTES: crops up to 170 px wide
@@ -972,10 +990,11 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
     const int HS = OW * 3 + 16;
     const int tid = threadIdx.x;
     const int bands = (OH + PIL_BAND - 1) / PIL_BAND;
-    const int slot = blockIdx.x / bands, band = blockIdx.x - slot * bands;
+    // workgroup = (crop, PIL_BPW consecutive bands): the look-up table, the geometry and the horizontal coefficient rows (fp64, one IEEE
+    // division per tap) are set up ONCE and shared by the bands (r02a: per band -- ~30 % of the kernel's VALU instructions)
+    const int chunks = (bands + PIL_BPW - 1) / PIL_BPW;
+    const int slot = blockIdx.x / chunks, chunk = blockIdx.x - slot * chunks;
     const int b = slot / max_n, i = slot - b * max_n;
-    const int y_base = band * PIL_BAND;
-    const int nb = min(PIL_BAND, OH - y_base);
     const int groups_per_row = OW / 8;
     const float mean[3] = {m0, m1, m2}, stdv[3] = {d0, d1, d2};
     bool valid = i < counts[b];
@@ -986,6 +1005,17 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
     if (valid) { ssort_crop_box(boxes + ((size_t)b * max_n + i) * box_stride, W, H, x1, y1, x2, y2); valid = (x2 > x1) && (y2 > y1); }
     const int cw = x2 - x1, ch = y2 - y1;
     const PilAxis ax = pil_axis(valid ? cw : 1, OW), ay = pil_axis(valid ? ch : 1, OH);
+    const bool h_ok = valid && OW <= PIL_OW_MAX && cw * 3 + STAGE_PAD <= PIL_ROW_BYTES && ax.ksize <= PIL_KMAX && ay.ksize <= PIL_KMAX;
+    if (h_ok && tid < OW) {                                                     // horizontal coefficient rows
+        int xmin, xmax;
+        pil_bounds(ax, cw, tid, xmin, xmax);
+        const double ww = pil_wsum(ax, tid, xmin, xmax);
+        s_hmin[tid] = xmin * 3;
+        for (int k = 0; k < PIL_KMAX; ++k) s_hk[tid][k] = k < xmax ? pil_fixed(ax, tid, xmin, k, ww) : 0;
+    }
+    for (int band = chunk * PIL_BPW; band < min(bands, (chunk + 1) * PIL_BPW); ++band) {
+    const int y_base = band * PIL_BAND;
+    const int nb = min(PIL_BAND, OH - y_base);
     bool staged = false;
     int r_lo = 0, nrows = 0;
     if (valid) {
@@ -993,7 +1023,7 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
         pil_bounds(ay, ch, y_base, lo0, n0_);
         pil_bounds(ay, ch, y_base + nb - 1, lo1, n1_);
         r_lo = lo0; nrows = lo1 + n1_ - lo0;
-        staged = OW <= PIL_OW_MAX && nrows <= PIL_ROWS && cw * 3 + STAGE_PAD <= PIL_ROW_BYTES && ax.ksize <= PIL_KMAX && ay.ksize <= PIL_KMAX;
+        staged = h_ok && nrows <= PIL_ROWS;
     }
     if (valid && staged) {
         const unsigned char *gend = frames + (size_t)B * H * W * 3;
@@ -1009,13 +1039,6 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
                 if (p + 16 <= gend) *reinterpret_cast<uint4 *>(lds) = *reinterpret_cast<const uint4 *>(p);
                 else for (int k = 0; k < 16 && p + k < gend; ++k) lds[k] = p[k];
             }
-        }
-        if (tid < OW) {                                                         // horizontal coefficient rows
-            int xmin, xmax;
-            pil_bounds(ax, cw, tid, xmin, xmax);
-            const double ww = pil_wsum(ax, tid, xmin, xmax);
-            s_hmin[tid] = xmin * 3;
-            for (int k = 0; k < PIL_KMAX; ++k) s_hk[tid][k] = k < xmax ? pil_fixed(ax, tid, xmin, k, ww) : 0;
         }
         if (tid >= BLOCK - PIL_BAND && tid - (BLOCK - PIL_BAND) < nb) {         // vertical coefficient rows (last wavefront's lanes)
             const int ry = tid - (BLOCK - PIL_BAND);
@@ -1143,6 +1166,8 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
         uint4 *g = reinterpret_cast<uint4 *>(out + ((size_t)slot * OH + y_base) * OW * 3);
         const uint4 *l4 = reinterpret_cast<const uint4 *>(s_rows);
         for (int c = tid; c < n16; c += BLOCK) g[c] = l4[c];
+    }
+    __syncthreads();                                    // the next band re-uses every LDS area
     }
 }
 
@@ -1607,7 +1632,8 @@ int launch_pil_crop(const unsigned char *frames, int B, int H, int W, const doub
                     int OH, int OW, const float *mean, const float *stdv, int layout, void *out, hipStream_t st, int swap_rb)
 {
     const int sw0 = swap_rb ? 2 : 0, sw2 = swap_rb ? 0 : 2;
-    const dim3 grid((unsigned)((long long)B * max_n * ((OH + PIL_BAND - 1) / PIL_BAND)));
+    const int pil_bands = (OH + PIL_BAND - 1) / PIL_BAND;
+    const dim3 grid((unsigned)((long long)B * max_n * ((pil_bands + PIL_BPW - 1) / PIL_BPW)));
 #define TLK_PIL_LAUNCH(LAY, OWC) hipLaunchKernelGGL((pil_crop_kernel<T, LAY, OWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, box_stride, counts, max_n, OH, OW, \
                                                   mean[sw0], mean[1], mean[sw2], stdv[sw0], stdv[1], stdv[sw2], (T *)out, swap_rb)
     if (layout == LAYOUT_NCHW) { if (OW == 128) TLK_PIL_LAUNCH(LAYOUT_NCHW, 128); else TLK_PIL_LAUNCH(LAYOUT_NCHW, 0); }
