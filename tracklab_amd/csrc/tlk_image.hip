@@ -784,7 +784,7 @@ __global__ void __launch_bounds__(BLOCK) crop_fat_kernel(const unsigned char *__
         __syncthreads();
         if (staged) {
             // horizontal pass: thread = one x, every second staged row. The two taps of the three channels are 6 consecutive bytes (3 when the
-            // right tap is clamped onto the left one): ONE unaligned 8-byte LDS read per (row, x), the (left, right) pairs built by v_perm_b32
+            // right tap is clamped onto the left one): three aligned dword reads + v_alignbyte per (row, x), the (left, right) pairs built by v_perm_b32
             // with per-thread selectors, three rows in flight per iteration (r02a: six byte reads in three dependent LDS round trips per row
             // plus a fourth for the row's alignment shift -- ~30 % of a band's time was that latency chain)
             const int x = tid & 127;
@@ -800,9 +800,13 @@ __global__ void __launch_bounds__(BLOCK) crop_fat_kernel(const unsigned char *__
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
                     const int rr = r0 + 2 * u;                                     // (rows past nrows: read but not used)
-                    unsigned int w[2];
-                    __builtin_memcpy(w, s_rows + rr * CS_ROW_BYTES + (int)((a_lo + (unsigned int)rr * a_step) & 15u) + o0, 8);
-                    lo[u] = w[0]; hi[u] = w[1];
+                    // (measured, tools/micro/lds_unaligned.hip: per wavefront a byte-granular 6 x ds_read_u8 costs 133 LDS cycles, ONE unaligned
+                    // ds_read_b64 66 -- it is serialised per lane --, three ALIGNED dwords + v_alignbyte 15)
+                    const int addr = rr * CS_ROW_BYTES + (int)((a_lo + (unsigned int)rr * a_step) & 15u) + o0;
+                    const unsigned int *q = reinterpret_cast<const unsigned int *>(s_rows + (addr & ~3));
+                    const unsigned int d0 = q[0], d1 = q[1], d2 = q[2];
+                    lo[u] = __builtin_amdgcn_alignbyte(d1, d0, (unsigned int)addr & 3u);
+                    hi[u] = __builtin_amdgcn_alignbyte(d2, d1, (unsigned int)addr & 3u);
                 }
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
@@ -1050,15 +1054,23 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
         }
         __syncthreads();
         // horizontal pass -> 8-bit plane. Every tap is read (taps past a column's support carry weight 0), so the loop has no divergent
-        // branches and no serialised LDS round trips: ONE unaligned 16-byte read brings the 3 x 5 source bytes of the pixel, one 16-byte +
+        // branches and no serialised LDS round trips: five aligned dword reads bring the 3 x 5 source bytes of the pixel, one 16-byte +
         // one 4-byte read its weights (r01 form: a branch and 3 narrow reads per tap, ~115 instructions and 5 LDS latencies per pixel)
         const unsigned a_lo = (unsigned)(uintptr_t)(frames + ((size_t)b * H * W + (size_t)(y1 + r_lo) * W + x1) * 3) & 15u, row_step = ((unsigned)W * 3u) & 15u;
         const bool wide_h = ax.ksize > 3;                                       // (uniform: support > 1, i.e. the crop is wider than OW)
         for (int idx = tid; idx < nrows * OW; idx += BLOCK) {
             const int rr = idx / OW, x = idx - rr * OW;
             const unsigned char *p = s_rows + rr * PIL_ROW_BYTES + (int)((a_lo + (unsigned)rr * row_step) & 15u) + s_hmin[x];
+            // 15 bytes from a byte-granular address: five ALIGNED dwords + v_alignbyte (an unaligned 16-byte LDS read is serialised per lane:
+            // 65 vs 17 LDS cycles per wavefront, tools/micro/lds_unaligned.hip)
             unsigned w[4];
-            __builtin_memcpy(w, p, 16);
+            {
+                const unsigned *q = reinterpret_cast<const unsigned *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3);
+                const unsigned sh = (unsigned)reinterpret_cast<uintptr_t>(p) & 3u;
+                const unsigned d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+                w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh); w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh); w[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+            }
             const int4 c03 = *reinterpret_cast<const int4 *>(&s_hk[x][0]);
             int s0 = 1 << (PIL_BITS - 1), s1 = s0, s2 = s0;
             s0 += __mul24(byte_of(w, 0), c03.x); s1 += __mul24(byte_of(w, 1), c03.x); s2 += __mul24(byte_of(w, 2), c03.x);
