@@ -691,6 +691,7 @@ __global__ void __launch_bounds__(BLOCK) crop_fat_kernel(const unsigned char *__
     constexpr int OW = 128, HS = OW * 3, GROUPS = OW / 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     __shared__ int s_y[CF_BANDS * CS_BAND * 2];         // per output row of the chunk: (source row y0 | y1 << 16) relative to the crop, (b0 | b1 << 16)
+    __shared__ int s_rsh[CS_ROWS];
     __shared__ CropPar s_par;
     const int tid = threadIdx.x;
     int wg;
@@ -780,40 +781,21 @@ __global__ void __launch_bounds__(BLOCK) crop_fat_kernel(const unsigned char *__
                 const int rr = rsub + 8 * j;
                 if (rr < nrows) *reinterpret_cast<uint4 *>(s_rows + rr * CS_ROW_BYTES + c16 * 16) = stage[j];
             }
+            if (tid < nrows) s_rsh[tid] = (int)((uintptr_t)(frames + frame_off + ((size_t)(par.t + r_lo + tid) * W + par.l) * 3) & 15);
         }
         __syncthreads();
-        if (staged) {
-            // horizontal pass into a PLANAR 16-bit LDS plane s_h[row][channel][x]: thread = two adjacent x of every fourth staged row, so that
-            // each channel's pair goes out as ONE aligned ds_write_b32. The two taps of the three channels are 6 consecutive bytes (3 when
-            // the right tap is clamped onto the left one): three ALIGNED dword reads + v_alignbyte per (row, x), the (left, right) pairs
-            // built by v_perm_b32 with per-thread selectors. (tools/micro/lds_unaligned.hip: a wavefront's byte-granular 6 x ds_read_u8 costs
-            // 133 LDS cycles, one unaligned ds_read_b64 66 -- misaligned LDS accesses are serialised per lane, stores too --, three aligned
-            // dwords 15; r02a read bytes in three dependent round trips per row plus a fourth for the row's alignment shift.)
-            const int xp = tid & 63;
-            const int4 xc2 = *reinterpret_cast<const int4 *>(&s_xc[2 * xp]);      // (x table entries of x = 2 xp and 2 xp + 1)
-            const int oA = xc2.x & 0xffff, oB = xc2.z & 0xffff;
-            const unsigned int selA0 = 0x0c000c00u | ((unsigned int)(xc2.x >> 16) << 16), selB0 = 0x0c000c00u | ((unsigned int)(xc2.z >> 16) << 16);
-            const us2_t A = __builtin_bit_cast(us2_t, xc2.y), Bw = __builtin_bit_cast(us2_t, xc2.w);
-            // alignment shift of staged row rr: (address of the crop's first byte in source row r_lo + rr) & 15
-            const unsigned int a_lo = (unsigned int)(uintptr_t)(frames + frame_off + ((size_t)(par.t + r_lo) * W + par.l) * 3) & 15u, a_step = ((unsigned int)W * 3u) & 15u;
-            auto taps = [&](int base, int o, unsigned int &lo, unsigned int &hi) {
-                const int addr = base + o;
-                const unsigned int *q = reinterpret_cast<const unsigned int *>(s_rows + (addr & ~3));
-                const unsigned int d0 = q[0], d1 = q[1], d2 = q[2];
-                lo = __builtin_amdgcn_alignbyte(d1, d0, (unsigned int)addr & 3u);
-                hi = __builtin_amdgcn_alignbyte(d2, d1, (unsigned int)addr & 3u);
-            };
-            for (int rr = tid >> 6; rr < nrows; rr += 4) {
-                const int base = rr * CS_ROW_BYTES + (int)((a_lo + (unsigned int)rr * a_step) & 15u);
-                unsigned int loA, hiA, loB, hiB;
-                taps(base, oA, loA, hiA);
-                taps(base, oB, loB, hiB);
-                unsigned int *o = reinterpret_cast<unsigned int *>(s_h + rr * HS) + xp;
+        if (staged) {                                   // horizontal pass: thread = one x, every second staged row
+            const int x = tid & 127;
+            const int2 xc = s_xc[x];
+            const int o0 = xc.x & 0xffff, o1 = o0 + (xc.x >> 16);
+            const us2_t A = __builtin_bit_cast(us2_t, xc.y);
+            for (int rr = tid >> 7; rr < nrows; rr += 2) {
+                const unsigned char *p = s_rows + rr * CS_ROW_BYTES + s_rsh[rr];
+                unsigned short *o = s_h + rr * HS + x * 3;
 #pragma unroll
                 for (int c3 = 0; c3 < 3; ++c3) {
-                    const unsigned int va = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(hiA, loA, selA0 + 0x00010001u * c3)), A, 0u, false) >> 4;
-                    const unsigned int vb = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(hiB, loB, selB0 + 0x00010001u * c3)), Bw, 0u, false) >> 4;
-                    o[c3 * (OW / 2)] = va | (vb << 16);
+                    const unsigned int P = (unsigned int)p[o0 + c3] | ((unsigned int)p[o1 + c3] << 16);
+                    o[c3] = (unsigned short)(__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, P), A, 0u, false) >> 4);
                 }
             }
         }
@@ -837,25 +819,24 @@ __global__ void __launch_bounds__(BLOCK) crop_fat_kernel(const unsigned char *__
             {
                 const int row = kb * CS_BAND + ry;
                 const unsigned int yi = (unsigned int)s_y[row * 2], yw = (unsigned int)s_y[row * 2 + 1];
-                const unsigned short *h0 = s_h + ((yi & 0xffffu) - r_lo) * HS + x_base;       // planar: [channel][x]
-                const unsigned short *h1 = s_h + ((yi >> 16) - r_lo) * HS + x_base;
+                const uint4 *h0 = reinterpret_cast<const uint4 *>(s_h + ((yi & 0xffffu) - r_lo) * HS + x_base * 3);
+                const uint4 *h1 = reinterpret_cast<const uint4 *>(s_h + ((yi >> 16) - r_lo) * HS + x_base * 3);
                 const unsigned int b0 = yw & 0xffffu, b1 = yw >> 16;
                 unsigned int w0[12], w1[12];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const uint4 u = *reinterpret_cast<const uint4 *>(h0 + c * OW), v = *reinterpret_cast<const uint4 *>(h1 + c * OW);
-                    w0[c * 4] = u.x; w0[c * 4 + 1] = u.y; w0[c * 4 + 2] = u.z; w0[c * 4 + 3] = u.w;
-                    w1[c * 4] = v.x; w1[c * 4 + 1] = v.y; w1[c * 4 + 2] = v.z; w1[c * 4 + 3] = v.w;
+                for (int k = 0; k < 3; ++k) {
+                    const uint4 u = h0[k], v = h1[k];
+                    w0[k * 4] = u.x; w0[k * 4 + 1] = u.y; w0[k * 4 + 2] = u.z; w0[k * 4 + 3] = u.w;
+                    w1[k * 4] = v.x; w1[k * 4 + 1] = v.y; w1[k * 4 + 2] = v.z; w1[k * 4 + 3] = v.w;
                 }
 #pragma unroll
                 for (int q = 0; q < 24; ++q) {
-                    const int c = q >> 3, k = q & 7;                            // channel plane, pixel of the group
-                    const unsigned int a = (k & 1) ? (w0[c * 4 + (k >> 1)] >> 16) : (w0[c * 4 + (k >> 1)] & 0xffffu);
-                    const unsigned int c1 = (k & 1) ? (w1[c * 4 + (k >> 1)] >> 16) : (w1[c * 4 + (k >> 1)] & 0xffffu);
+                    const unsigned int a = (q & 1) ? (w0[q >> 1] >> 16) : (w0[q >> 1] & 0xffffu);
+                    const unsigned int c1 = (q & 1) ? (w1[q >> 1] >> 16) : (w1[q >> 1] & 0xffffu);
                     const unsigned int xa = __umul24(b0, a), xb = __umul24(b1, c1);
                     unsigned int t;                     // t <= 1020 always (see crop_sep_kernel)
                     asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t) : "v"(xa), "v"(xb));
-                    px[k][c] = s_lut[c * CS_LUT_N + t];
+                    px[q / 3][q % 3] = s_lut[(q % 3) * CS_LUT_N + t];
                 }
             }
             if (swap_rb) {
