@@ -559,6 +559,17 @@ int tlk_ecc_find_transform(const uint8_t *templ_host, const uint8_t *image_host,
 int tlk_hota_sequence_f64(const int32_t *gt_ids, const double *gt_ltrb, const int64_t *gt_off, const int32_t *tr_ids, const double *tr_ltrb,
                           const int64_t *tr_off, int n_frames, int n_gt, int n_tr, const double *alphas19, double *stats);
 
+/* CLEAR-MOT and ID counts of one sequence on the device. Replaces MOTAccumulator.update per frame + the measures of the
+ * py-motmetrics copy the reference vendors for its PoseTrack21 MOT evaluator (plugins/eval/PoseTrack21/posetrack21_mot/posetrack21_mot/
+ * motmetrics: mot.py:134-345, metrics.py:342-728 incl. id_global_assignment :610-653, distances.py:83-129 iou_matrix(max_iou),
+ * lap.py:79-130). HOST buffers like tlk_hota_sequence_f64, except: ids dense 0..n-1 in the SORTED order of the original ids, boxes
+ * (x, y, w, h). counts19: num_frames, num_matches, num_switches, num_transfer, num_ascend, num_migrate, num_false_positives, num_misses,
+ * num_objects, num_predictions, num_unique_objects, mostly_tracked, partially_tracked, mostly_lost, num_fragmentations, sum_distance,
+ * idtp, idfp, idfn -- the summable fields (tracklab_amd.clearmot.SUM_FIELDS) the ranks SUM all-reduce; MOTA / MOTP / IDF1 ... are
+ * ratios of them (clearmot.finalize). At most 512 boxes per frame and side. */
+int tlk_clear_sequence_f64(const int32_t *gt_ids, const double *gt_ltwh, const int64_t *gt_off, const int32_t *tr_ids, const double *tr_ltwh,
+                           const int64_t *tr_off, int n_frames, int n_gt, int n_tr, double max_iou, double *counts19);
+
 /* ------------------------------------------------------------------------------------------
  * Fused convolution epilogue for the PyTorch-ROCm backbones (not a reference function: the reference's
  * backbones run inside third-party ONNXRuntime / torchreid): x = act(x + bias[c] (+ residual)) in place on a

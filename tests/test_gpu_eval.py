@@ -60,3 +60,65 @@ def test_gpu_hota_edge_cases():
     assert (r["HOTA_TP"] == 4).all() and (r["HOTA_FP"] == 1).all()
     for k in r:
         np.testing.assert_allclose(r[k], c[k], rtol=1e-14, atol=1e-14)
+
+
+def _clear_frames(g, s):
+    og, oh = g[f"s{s}_offsets_gt"], g[f"s{s}_offsets_hyp"]
+    return [(g[f"s{s}_gt_ids"][og[f]:og[f + 1]], g[f"s{s}_gt_ltwh"][og[f]:og[f + 1]], g[f"s{s}_hyp_ids"][oh[f]:oh[f + 1]], g[f"s{s}_hyp_ltwh"][oh[f]:oh[f + 1]])
+            for f in range(len(og) - 1)]
+
+
+def test_gpu_clearmot_matches_vendored_motmetrics():
+    """tlk_clear_sequence_f64 on the four sequences of the py-motmetrics fixture: every measure per sequence and OVERALL as the vendored
+    motmetrics computed them (<= 1e-12), and count for count equal to the host accumulator."""
+    from conftest import GOLDEN
+    from tracklab_amd import clearmot
+    g = np.load(os.path.join(GOLDEN, "clearmot.npz"))
+    names, rows = [str(n) for n in g["metric_names"]], [str(r) for r in g["row_names"]]
+    counts = []
+    for s in range(len(rows) - 1):
+        frames = _clear_frames(g, s)
+        c = clearmot.sequence_counts_gpu(frames, max_iou=0.5)
+        acc = clearmot.MOTAccumulator()
+        for fr in frames:
+            acc.update_boxes(*fr, max_iou=0.5)
+        ref = acc.counts()
+        for k in clearmot.SUM_FIELDS:
+            assert c[k] == ref[k] or abs(c[k] - ref[k]) <= 1e-12 * max(1.0, abs(ref[k])), (rows[s], k, c[k], ref[k])
+        assert c["sum_distance"] == ref["sum_distance"]                         # same additions in the same order
+        m = clearmot.finalize(c)
+        for k, exp in zip(names, g["summary"][s]):
+            np.testing.assert_allclose(m[k], exp, rtol=1e-12, atol=1e-12, err_msg=f"{rows[s]} {k}")
+        counts.append(c)
+    tot = clearmot.merge(counts)
+    for k, exp in zip(names, g["summary"][-1]):
+        np.testing.assert_allclose(tot[k], exp, rtol=1e-12, atol=1e-12, err_msg=f"OVERALL {k}")
+
+
+def test_gpu_clearmot_on_a_tracked_stream_and_edge_cases(orc):
+    """A 100-object stream tracked by the C oracle (id switches, misses, late births) and the degenerate sequences."""
+    from tracklab_amd import clearmot
+    from tracklab_amd.synth import SyntheticStream
+    hyper = dict(asso_func="iou", delta_t=3, det_thresh=0.3, inertia=0.2, iou_threshold=0.3, max_age=5, min_hits=1, use_byte=False)
+    trk = orc.OCSort(**hyper)
+    frames = []
+    for fr in SyntheticStream(17, 100, 120, miss_prob=0.15, churn_period=30):
+        rows = orc.ocsort_wrapper_step(trk, fr["dets"], 0.4)
+        gt = fr["gt_boxes"]
+        g_ltwh = np.column_stack([gt[:, 0], gt[:, 1], gt[:, 2] - gt[:, 0], gt[:, 3] - gt[:, 1]])
+        h_ltwh = np.column_stack([rows[:, 0], rows[:, 1], rows[:, 2] - rows[:, 0], rows[:, 3] - rows[:, 1]]) if len(rows) else np.zeros((0, 4))
+        frames.append((fr["gt_all_ids"], g_ltwh, rows[:, 4].astype(np.int64) if len(rows) else np.zeros(0, np.int64), h_ltwh))
+    c = clearmot.sequence_counts_gpu(frames)
+    acc = clearmot.MOTAccumulator()
+    for fr in frames:
+        acc.update_boxes(*fr, max_iou=0.5)
+    ref = acc.counts()
+    assert ref["num_switches"] > 0 and ref["num_misses"] > 100 and ref["num_fragmentations"] > 0
+    for k in clearmot.SUM_FIELDS:
+        assert c[k] == ref[k], (k, c[k], ref[k])
+    # degenerate sequences
+    assert clearmot.sequence_counts_gpu([])["num_frames"] == 0
+    e = clearmot.sequence_counts_gpu([([], np.zeros((0, 4)), [], np.zeros((0, 4))), ([1, 2], np.array([[0., 0, 10, 10], [50, 50, 10, 10]]), [], np.zeros((0, 4))),
+                                      ([], np.zeros((0, 4)), [7], np.array([[0., 0, 10, 10]])), ([1], np.array([[0., 0, 10, 10]]), [7], np.array([[100., 100, 10, 10]]))])
+    assert (e["num_frames"], e["num_misses"], e["num_false_positives"], e["num_matches"]) == (4, 3, 2, 0)
+    assert clearmot.finalize(e)["idf1"] == 0.0

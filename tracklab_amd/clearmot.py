@@ -199,6 +199,34 @@ def finalize(c: dict) -> dict:
     return out
 
 
+def sequence_counts_gpu(frames, max_iou: float = 0.5) -> dict:
+    """The counts of one sequence on the device (tlk_clear_sequence_f64: one workgroup walks the frames -- the accumulator is sequential --
+    and solves the global ID assignment at the end). frames: iterable of (gt_ids, gt_ltwh, hyp_ids, hyp_ltwh), what ``update_boxes``
+    takes. Same dict as ``MOTAccumulator.counts()``; ``finalize`` / ``merge`` / ``pack`` apply unchanged. No CPU fallback."""
+    import ctypes as C
+    from . import _lib
+    gi, hi, gb, hb, goff, hoff = [], [], [], [], [0], [0]
+    for g, gbox, h, hbox in frames:
+        gi.extend(int(x) for x in g); hi.extend(int(x) for x in h)
+        gb.append(np.asarray(gbox, dtype=np.float64).reshape(-1, 4)); hb.append(np.asarray(hbox, dtype=np.float64).reshape(-1, 4))
+        goff.append(len(gi)); hoff.append(len(hi))
+    # dense ids in the SORTED order of the original ids: the ID assignment's matrix is ordered by id (metrics.py:616-617)
+    gu, gd = np.unique(np.asarray(gi, dtype=np.int64), return_inverse=True) if gi else (np.zeros(0, np.int64), np.zeros(0, np.int64))
+    hu, hd = np.unique(np.asarray(hi, dtype=np.int64), return_inverse=True) if hi else (np.zeros(0, np.int64), np.zeros(0, np.int64))
+    gd, hd = np.ascontiguousarray(gd, dtype=np.int32), np.ascontiguousarray(hd, dtype=np.int32)
+    gb = np.ascontiguousarray(np.concatenate(gb)) if gb else np.zeros((0, 4))
+    hb = np.ascontiguousarray(np.concatenate(hb)) if hb else np.zeros((0, 4))
+    goff, hoff = np.asarray(goff, dtype=np.int64), np.asarray(hoff, dtype=np.int64)
+    out = np.zeros(len(SUM_FIELDS))
+    vp = C.c_void_p
+    L = _lib.lib()
+    L.tlk_clear_sequence_f64.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, vp]
+    _lib.check(L.tlk_clear_sequence_f64(gd.ctypes.data, gb.ctypes.data, goff.ctypes.data, hd.ctypes.data, hb.ctypes.data, hoff.ctypes.data,
+                                        len(goff) - 1, len(gu), len(hu), float(max_iou), out.ctypes.data))
+    c = {k: (float(v) if k in ("sum_distance", "idtp", "idfp", "idfn") else int(v)) for k, v in zip(SUM_FIELDS, out)}
+    return c
+
+
 def pack(c: dict) -> np.ndarray:
     """Counts as a float64 vector for a SUM all-reduce over ranks (tracklab_amd.dist)."""
     return np.array([float(c[k]) for k in SUM_FIELDS], dtype=np.float64)

@@ -151,6 +151,255 @@ __global__ void __launch_bounds__(BLOCK) hota_final_kernel(HotaIn in, const int 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// CLEAR-MOT and ID measures of one sequence (py-motmetrics copy vendored by the reference: posetrack21_mot/motmetrics/mot.py:134-345,
+// metrics.py:342-728, distances.py:52-129, lap.py:79-130), in the form tracklab_amd/clearmot.py pins on it (<= 1e-12).
+// The event accumulator is SEQUENTIAL in the frames (a frame first carries the previous correspondences forward, then assigns the rest), so
+// the sequence is ONE workgroup walking the frames: all threads build the frame's distance matrix and the masked cost matrix, wavefront 0 runs
+// the order-dependent parts (carry-forward in object order, scipy's assignment, the pair events in row order with the float64 distance sum in
+// exactly the accumulator's order). Afterwards: track ratios / fragmentations per object, and the global ID assignment (one Hungarian
+// problem of size n_gt + n_tr on the NaN-edged fp + fn matrix).
+struct ClearDev {
+    const int *gid, *tid; const double *gbox, *tbox; const long long *goff, *toff;      // ids dense 0..n-1 IN SORTED ORDER of the original ids; boxes ltwh
+    int T, n_gt, n_tr; double max_iou;
+    double *D, *Cm;                         // frame matrices (512 x 512)
+    int *m, *res_m, *last_occ, *last_match, *hyp_hist, *ocs, *hcs, *tps, *hits, *prev_ev, *pend, *frag;
+    unsigned char *om, *hm;
+    int *mrows, *mcols;
+    // ID assignment
+    double *fpm, *fnm, *idc; LsaWork idw; int *idr, *idcol;
+    double *out;                            // SUM_FIELDS order of tracklab_amd/clearmot.py (19 doubles)
+    int *err;
+};
+enum { C_FRAMES, C_MATCHES, C_SWITCHES, C_TRANSFER, C_ASCEND, C_MIGRATE, C_FP, C_MISSES, C_OBJECTS, C_PREDS, C_UNIQUE, C_MT, C_PT, C_ML, C_FRAG, C_SUMD, C_IDTP, C_IDFP, C_IDFN, C_N };
+
+__device__ __forceinline__ bool finite_d(double v) { return v - v == 0.0; }
+
+// lap.lsa_solve_scipy's cost substitution: non-finite entries -> 2 * min(shape) * (max |finite| + 1) + 1 (all finite: as is; none: zeros)
+__device__ void masked_cost(const double *D, double *Cm, int nr, int nc, double *s_red, int *s_flag)
+{
+    const int tid = threadIdx.x, n = nr * nc;
+    double mx = 0.0; int nvalid = 0;
+    for (int e = tid; e < n; e += BLOCK) { const double v = D[e]; if (finite_d(v)) { ++nvalid; const double a = fabs(v); mx = a > mx ? a : mx; } }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(mx, off); mx = o > mx ? o : mx; nvalid += __shfl_xor(nvalid, off); }
+    __syncthreads();
+    if ((tid & 63) == 0) { s_red[tid >> 6] = mx; s_flag[tid >> 6] = nvalid; }
+    __syncthreads();
+    mx = 0.0; nvalid = 0;
+    for (int w = 0; w < NWAVES; ++w) { mx = s_red[w] > mx ? s_red[w] : mx; nvalid += s_flag[w]; }
+    const double big = 2.0 * (double)(nr < nc ? nr : nc) * (mx + 1.0) + 1.0;
+    for (int e = tid; e < n; e += BLOCK) { const double v = D[e]; Cm[e] = nvalid == 0 ? 0.0 : (finite_d(v) ? v : big); }
+    __threadfence_block();
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(BLOCK) clear_seq_kernel(ClearDev A)
+{
+    __shared__ double s_u[512];
+    __shared__ int s_c4r[512];
+    __shared__ double s_red[NWAVES];
+    __shared__ int s_flag[NWAVES];
+    __shared__ double s_cnt[C_N];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < C_N) s_cnt[tid] = 0.0;
+    for (int k = tid; k < A.n_gt; k += BLOCK) { A.m[k] = -1; A.last_occ[k] = -1; A.last_match[k] = -1; A.ocs[k] = 0; A.hits[k] = 0; A.prev_ev[k] = -1; A.pend[k] = 0; A.frag[k] = 0; }
+    for (int k = tid; k < A.n_tr; k += BLOCK) { A.res_m[k] = -1; A.hyp_hist[k] = -1; A.hcs[k] = 0; }
+    for (size_t k = tid; k < (size_t)A.n_gt * A.n_tr; k += BLOCK) A.tps[k] = 0;
+    __threadfence_block();
+    __syncthreads();
+    LsaWork W;
+    W.u = s_u; W.col4row = s_c4r; W.v = W.spc = nullptr; W.path = W.row4col = W.remaining = nullptr; W.SR = W.SC = nullptr;
+    for (int f = 0; f < A.T; ++f) {
+        const long long g0 = A.goff[f], t0 = A.toff[f];
+        const int no = (int)(A.goff[f + 1] - g0), nh = (int)(A.toff[f + 1] - t0);
+        if (no > 512 || nh > 512) { if (tid == 0) *A.err = TLK_ECAPACITY; return; }
+        const int *oid = A.gid + g0, *hid = A.tid + t0;
+        // distances.iou_matrix(max_iou): 1 - IoU of (x, y, w, h) rectangles with numpy's operation order, NaN above max_iou; raw events
+        for (int e = tid; e < no * nh; e += BLOCK) {
+            const int i = e / nh, j = e - i * nh;
+            const double *a = A.gbox + (g0 + i) * 4, *b = A.tbox + (t0 + j) * 4;
+            const double ax1 = a[0] + a[2], ay1 = a[1] + a[3], bx1 = b[0] + b[2], by1 = b[1] + b[3];
+            double dx = (ax1 < bx1 ? ax1 : bx1) - (a[0] > b[0] ? a[0] : b[0]), dy = (ay1 < by1 ? ay1 : by1) - (a[1] > b[1] ? a[1] : b[1]);
+            dx = dx > 0.0 ? dx : 0.0; dy = dy > 0.0 ? dy : 0.0;
+            const double iv = dx * dy;
+            double aw = ax1 - a[0], ah = ay1 - a[1], bw = bx1 - b[0], bh = by1 - b[1];
+            aw = aw > 0.0 ? aw : 0.0; ah = ah > 0.0 ? ah : 0.0; bw = bw > 0.0 ? bw : 0.0; bh = bh > 0.0 ? bh : 0.0;
+            const double uv = aw * ah + bw * bh - iv;
+            const double iou = iv == 0.0 ? 0.0 : iv / uv;
+            double d = 1.0 - iou;
+            if (d > A.max_iou) d = __builtin_nan("");
+            A.D[e] = d;
+            if (finite_d(d)) A.tps[(size_t)oid[i] * A.n_tr + hid[j]] += 1;      // (ids are unique within a frame)
+        }
+        for (int i = tid; i < no; i += BLOCK) { A.ocs[oid[i]] += 1; A.om[i] = 0; }
+        for (int j = tid; j < nh; j += BLOCK) { A.hcs[hid[j]] += 1; A.hm[j] = 0; }
+        __threadfence_block();
+        __syncthreads();
+        if (no > 0 && nh > 0) {
+            if (wv == 0) {                                   // 1. carry established correspondences forward, in object order
+                double sumd = s_cnt[C_SUMD]; int nmatch = 0;
+                for (int i = 0; i < no; ++i) {
+                    const int o = oid[i], mo = A.m[o];
+                    if (mo < 0) continue;
+                    int jf = -1;
+                    for (int j0 = 0; j0 < nh && jf < 0; j0 += WAVE) {
+                        const int j = j0 + lane;
+                        const bool hit = j < nh && !A.hm[j] && hid[j] == mo;
+                        const unsigned long long b = __ballot(hit);
+                        if (b) jf = j0 + __builtin_ctzll(b);
+                    }
+                    if (jf < 0) continue;
+                    const double d = A.D[(size_t)i * nh + jf];
+                    if (!finite_d(d)) continue;
+                    if (lane == 0) {
+                        A.om[i] = 1; A.hm[jf] = 1;
+                        A.last_match[o] = f; A.hyp_hist[hid[jf]] = f;
+                        A.hits[o] += 1; A.frag[o] += A.pend[o]; A.pend[o] = 0; A.prev_ev[o] = 0;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    sumd += d; ++nmatch;
+                }
+                if (lane == 0) { s_cnt[C_SUMD] = sumd; s_cnt[C_MATCHES] += nmatch; }
+            }
+            __threadfence_block();
+            __syncthreads();
+            for (int e = tid; e < no * nh; e += BLOCK) {    // 2. the rest: rows / columns already matched leave the problem
+                const int i = e / nh, j = e - i * nh;
+                if (A.om[i] || A.hm[j]) A.D[e] = __builtin_nan("");
+            }
+            __threadfence_block();
+            __syncthreads();
+            masked_cost(A.D, A.Cm, no, nh, s_red, s_flag);
+            if (wv == 0) {
+                const int np = wave_lsa(A.Cm, no, nh, (size_t)nh, (size_t)1, W, A.mrows, A.mcols);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {                             // pair events in row order (mot.py:262-300)
+                    double sumd = s_cnt[C_SUMD];
+                    for (int k = 0; k < np; ++k) {
+                        const int i = A.mrows[k], j = A.mcols[k];
+                        const double d = A.D[(size_t)i * nh + j];
+                        if (!finite_d(d)) continue;
+                        const int o = oid[i], h = hid[j];
+                        const bool is_switch = A.m[o] >= 0 && A.m[o] != h;                  // max_switch_time = inf
+                        if (is_switch && A.hyp_hist[h] < 0) s_cnt[C_ASCEND] += 1;
+                        if (A.res_m[h] >= 0 && A.res_m[h] != o) { if (A.last_match[o] < 0) s_cnt[C_MIGRATE] += 1; s_cnt[C_TRANSFER] += 1; }
+                        A.hyp_hist[h] = f; A.last_match[o] = f;
+                        s_cnt[is_switch ? C_SWITCHES : C_MATCHES] += 1;
+                        sumd += d;
+                        A.hits[o] += 1; A.frag[o] += A.pend[o]; A.pend[o] = 0; A.prev_ev[o] = 0;
+                        A.om[i] = 1; A.hm[j] = 1;
+                        A.m[o] = h; A.res_m[h] = o;
+                    }
+                    s_cnt[C_SUMD] = sumd;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        // 3. misses, 4. false alarms, 5. occurrence state
+        int nmiss = 0, nfp = 0;
+        for (int i = tid; i < no; i += BLOCK) {
+            const int o = oid[i];
+            if (!A.om[i]) { ++nmiss; if (A.prev_ev[o] == 0) A.pend[o] += 1; A.prev_ev[o] = 1; }
+            A.last_occ[o] = f;
+        }
+        for (int j = tid; j < nh; j += BLOCK) nfp += A.hm[j] ? 0 : 1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { nmiss += __shfl_xor(nmiss, off); nfp += __shfl_xor(nfp, off); }
+        if (lane == 0) { s_flag[wv] = nmiss; s_red[wv] = (double)nfp; }
+        __threadfence_block();
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 0; w < NWAVES; ++w) { s_cnt[C_MISSES] += s_flag[w]; s_cnt[C_FP] += s_red[w]; }
+            s_cnt[C_FRAMES] += 1;
+        }
+        __syncthreads();
+    }
+    // ---- per-object measures (metrics.py:455-506): tracked ratio classes, fragmentations; totals
+    {
+        double v[6] = {0, 0, 0, 0, 0, 0};                   // objects, unique, mt, pt, ml, frag
+        for (int o = tid; o < A.n_gt; o += BLOCK) {
+            const int n = A.ocs[o];
+            if (n == 0) continue;
+            const double ratio = (double)A.hits[o] / (double)n;
+            v[0] += n; v[1] += 1; v[2] += ratio >= 0.8 ? 1 : 0; v[3] += (ratio >= 0.2 && ratio < 0.8) ? 1 : 0; v[4] += ratio < 0.2 ? 1 : 0; v[5] += A.frag[o];
+        }
+        double np_ = 0;
+        for (int h = tid; h < A.n_tr; h += BLOCK) np_ += A.hcs[h];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { for (int q = 0; q < 6; ++q) v[q] += __shfl_xor(v[q], off); np_ += __shfl_xor(np_, off); }
+        __syncthreads();
+        if (lane == 0) { atomicAdd(&s_cnt[C_OBJECTS], v[0]); atomicAdd(&s_cnt[C_UNIQUE], v[1]); atomicAdd(&s_cnt[C_MT], v[2]); atomicAdd(&s_cnt[C_PT], v[3]);
+                         atomicAdd(&s_cnt[C_ML], v[4]); atomicAdd(&s_cnt[C_FRAG], v[5]); atomicAdd(&s_cnt[C_PREDS], np_); }       // (integers: any order is exact)
+        __syncthreads();
+    }
+    // ---- id_global_assignment (metrics.py:610-653): objects / hypotheses that occur, in id order
+    {
+        // compact the ids that occur (ocs / hcs > 0) -- dense ids are already in sorted order
+        // (prefix positions by one thread: a few hundred ids)
+        int *oi = A.idr, *hi = A.idcol;                      // reused below as LSA outputs after the matrices are built; positions first
+        __shared__ int s_no, s_nh;
+        if (tid == 0) {
+            int c = 0; for (int o = 0; o < A.n_gt; ++o) { oi[o] = A.ocs[o] > 0 ? c++ : -1; } s_no = c;
+            c = 0; for (int h = 0; h < A.n_tr; ++h) { hi[h] = A.hcs[h] > 0 ? c++ : -1; } s_nh = c;
+        }
+        __threadfence_block();
+        __syncthreads();
+        const int no = s_no, nh = s_nh, n = no + nh;
+        const double nan = __builtin_nan("");
+        for (size_t e = tid; e < (size_t)n * n; e += BLOCK) {
+            const int r = (int)(e / n), c = (int)(e - (size_t)r * n);
+            A.fpm[e] = (r >= no && c < nh) ? nan : 0.0;
+            A.fnm[e] = (r < no && c >= nh) ? nan : 0.0;
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int o = tid; o < A.n_gt; o += BLOCK) if (oi[o] >= 0) { const int r = oi[o]; const double oc = A.ocs[o]; for (int c = 0; c < nh; ++c) A.fnm[(size_t)r * n + c] = oc; A.fnm[(size_t)r * n + nh + r] = oc; }
+        __threadfence_block();
+        __syncthreads();
+        for (int h = tid; h < A.n_tr; h += BLOCK) if (hi[h] >= 0) { const int c = hi[h]; const double hc = A.hcs[h]; for (int r = 0; r < no; ++r) A.fpm[(size_t)r * n + c] = hc; A.fpm[(size_t)(c + no) * n + c] = hc; }
+        __threadfence_block();
+        __syncthreads();
+        for (size_t e = tid; e < (size_t)A.n_gt * A.n_tr; e += BLOCK) {
+            const int ex = A.tps[e];
+            if (!ex) continue;
+            const int o = (int)(e / A.n_tr), h = (int)(e - (size_t)o * A.n_tr);
+            const size_t k = (size_t)oi[o] * n + hi[h];
+            A.fpm[k] -= ex; A.fnm[k] -= ex;
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (size_t e = tid; e < (size_t)n * n; e += BLOCK) A.D[e] = A.fpm[e] + A.fnm[e];       // (A.D is sized for it by the host)
+        __threadfence_block();
+        __syncthreads();
+        double idfp = 0.0, idfn = 0.0;
+        if (n > 0) {
+            masked_cost(A.D, A.idc, n, n, s_red, s_flag);
+            if (wv == 0) {
+                LsaWork Wg = n <= 512 ? W : A.idw;
+                const int np = wave_lsa(A.idc, n, n, (size_t)n, (size_t)1, Wg, A.mrows, A.mcols);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                for (int k = lane; k < np; k += WAVE) {
+                    const size_t e = (size_t)A.mrows[k] * n + A.mcols[k];
+                    if (finite_d(A.D[e])) { idfp += A.fpm[e]; idfn += A.fnm[e]; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { idfp += __shfl_xor(idfp, off); idfn += __shfl_xor(idfn, off); }
+                if (lane == 0) { s_cnt[C_IDFP] = idfp; s_cnt[C_IDFN] = idfn; }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_cnt[C_IDTP] = s_cnt[C_OBJECTS] - s_cnt[C_IDFN];
+        __syncthreads();
+    }
+    if (tid < C_N) A.out[tid] = s_cnt[tid];
+}
+
 }  // namespace
 
 // HOST buffers. gt_ids / tr_ids: per-frame ids re-labelled 0..n-1 (TrackEval's preprocessing), concatenated; *_ltrb (., 4) float64
@@ -222,5 +471,68 @@ extern "C" int tlk_hota_sequence_f64(const int32_t *gt_ids, const double *gt_ltr
     hipFree(d);
     if (e != hipSuccess) return fail(TLK_EHIP, std::string("tlk_hota_sequence_f64: ") + hipGetErrorString(e));
     if (err) return fail(err, "tlk_hota_sequence_f64: a frame exceeds the solver's capacity");
+    return TLK_OK;
+}
+
+// CLEAR-MOT + ID counts of one sequence. HOST buffers as tlk_hota_sequence_f64, except: ids dense 0..n-1 in the SORTED order of the original
+// ids (np.unique's inverse: the global ID assignment orders its matrix by id), boxes (x, y, w, h). counts19: the SUM_FIELDS of
+// tracklab_amd/clearmot.py in that order (what its pack() all-reduces); clearmot.finalize() derives MOTA / MOTP / IDF1 ... from them.
+extern "C" int tlk_clear_sequence_f64(const int32_t *gt_ids, const double *gt_ltwh, const int64_t *gt_off, const int32_t *tr_ids, const double *tr_ltwh,
+                                      const int64_t *tr_off, int n_frames, int n_gt, int n_tr, double max_iou, double *counts19)
+{
+    if (n_frames < 0 || n_gt < 0 || n_tr < 0 || !gt_off || !tr_off || !counts19) return fail(TLK_EINVAL, "tlk_clear_sequence_f64: bad argument");
+    const long long ng = n_frames ? gt_off[n_frames] : 0, nt = n_frames ? tr_off[n_frames] : 0;
+    if ((ng && (!gt_ids || !gt_ltwh)) || (nt && (!tr_ids || !tr_ltwh))) return fail(TLK_EINVAL, "tlk_clear_sequence_f64: null pointer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(TLK_ENODEVICE, "tlk_clear_sequence_f64: no HIP device (libtlk has no CPU fallback)");
+    for (int f = 0; f < n_frames; ++f) {
+        const long long g = gt_off[f + 1] - gt_off[f], t = tr_off[f + 1] - tr_off[f];
+        if (g < 0 || t < 0) return fail(TLK_EINVAL, "tlk_clear_sequence_f64: offsets must ascend");
+        if (g > 512 || t > 512) return fail(TLK_ECAPACITY, "tlk_clear_sequence_f64: at most 512 boxes per frame and side");
+    }
+    const size_t n = (size_t)n_gt + n_tr, nn = n * n > 512 * 512 ? n * n : 512 * 512, ngt = n_gt ? n_gt : 1, ntr = n_tr ? n_tr : 1;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_gid = carve(sizeof(int) * (ng + 1)), o_tid = carve(sizeof(int) * (nt + 1)), o_gb = carve(sizeof(double) * 4 * (ng + 1)), o_tb = carve(sizeof(double) * 4 * (nt + 1));
+    const size_t o_goff = carve(sizeof(long long) * (n_frames + 1)), o_toff = carve(sizeof(long long) * (n_frames + 1));
+    const size_t o_D = carve(sizeof(double) * nn), o_C = carve(sizeof(double) * nn), o_fp = carve(sizeof(double) * (n * n + 1)), o_fn = carve(sizeof(double) * (n * n + 1));
+    const size_t o_g = carve(sizeof(int) * 8 * ngt), o_t = carve(sizeof(int) * 3 * ntr), o_tps = carve(sizeof(int) * ngt * ntr);
+    const size_t o_om = carve(512), o_hm = carve(512), o_mr = carve(sizeof(int) * (n + 512)), o_mc = carve(sizeof(int) * (n + 512));
+    const size_t o_idr = carve(sizeof(int) * (n + 1)), o_idc = carve(sizeof(int) * (n + 1));
+    const size_t o_wu = carve(sizeof(double) * 3 * (n + 1)), o_wi = carve(sizeof(int) * 4 * (n + 1)), o_wb = carve(2 * (n + 1));
+    const size_t o_out = carve(sizeof(double) * C_N), o_err = carve(sizeof(int));
+    unsigned char *d = nullptr;
+    TLK_HIP(hipMalloc((void **)&d, off));
+    hipError_t e = hipMemset(d + o_err, 0, sizeof(int));
+    if (e == hipSuccess && ng) e = hipMemcpy(d + o_gid, gt_ids, sizeof(int) * ng, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nt) e = hipMemcpy(d + o_tid, tr_ids, sizeof(int) * nt, hipMemcpyHostToDevice);
+    if (e == hipSuccess && ng) e = hipMemcpy(d + o_gb, gt_ltwh, sizeof(double) * 4 * ng, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nt) e = hipMemcpy(d + o_tb, tr_ltwh, sizeof(double) * 4 * nt, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + o_goff, gt_off, sizeof(long long) * (n_frames + 1), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + o_toff, tr_off, sizeof(long long) * (n_frames + 1), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(d); return fail(TLK_EHIP, std::string("tlk_clear_sequence_f64: ") + hipGetErrorString(e)); }
+    ClearDev A;
+    A.gid = (const int *)(d + o_gid); A.tid = (const int *)(d + o_tid); A.gbox = (const double *)(d + o_gb); A.tbox = (const double *)(d + o_tb);
+    A.goff = (const long long *)(d + o_goff); A.toff = (const long long *)(d + o_toff);
+    A.T = n_frames; A.n_gt = n_gt; A.n_tr = n_tr; A.max_iou = max_iou;
+    A.D = (double *)(d + o_D); A.Cm = (double *)(d + o_C); A.fpm = (double *)(d + o_fp); A.fnm = (double *)(d + o_fn); A.idc = (double *)(d + o_C);
+    int *gi = (int *)(d + o_g), *ti = (int *)(d + o_t);
+    A.m = gi; A.last_occ = gi + ngt; A.last_match = gi + 2 * ngt; A.ocs = gi + 3 * ngt; A.hits = gi + 4 * ngt; A.prev_ev = gi + 5 * ngt; A.pend = gi + 6 * ngt; A.frag = gi + 7 * ngt;
+    A.res_m = ti; A.hyp_hist = ti + ntr; A.hcs = ti + 2 * ntr;
+    A.tps = (int *)(d + o_tps); A.om = d + o_om; A.hm = d + o_hm; A.mrows = (int *)(d + o_mr); A.mcols = (int *)(d + o_mc);
+    A.idr = (int *)(d + o_idr); A.idcol = (int *)(d + o_idc);
+    double *wu = (double *)(d + o_wu); int *wi = (int *)(d + o_wi);
+    A.idw.u = wu; A.idw.v = wu + (n + 1); A.idw.spc = wu + 2 * (n + 1);
+    A.idw.path = wi; A.idw.row4col = wi + (n + 1); A.idw.remaining = wi + 2 * (n + 1); A.idw.col4row = wi + 3 * (n + 1);
+    A.idw.SR = d + o_wb; A.idw.SC = d + o_wb + (n + 1);
+    A.out = (double *)(d + o_out); A.err = (int *)(d + o_err);
+    hipLaunchKernelGGL(clear_seq_kernel, dim3(1), dim3(BLOCK), 0, 0, A);
+    e = hipGetLastError();
+    int err = 0;
+    if (e == hipSuccess) e = hipMemcpy(&err, d + o_err, sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(counts19, d + o_out, sizeof(double) * C_N, hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) return fail(TLK_EHIP, std::string("tlk_clear_sequence_f64: ") + hipGetErrorString(e));
+    if (err) return fail(err, "tlk_clear_sequence_f64: a frame exceeds the solver's capacity");
     return TLK_OK;
 }
