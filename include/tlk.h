@@ -198,7 +198,7 @@ typedef struct {
     int32_t matching_strategy;   /* 0 strong_sort_matching, 1 bot_sort_matching */
     int32_t wrapper_mode;        /* 1: skip the tracker entirely on a frame with 0 detections */
     int32_t parts, dim;          /* K, D of the embeddings */
-    int32_t max_tracks;          /* <= 512 */
+    int32_t max_tracks;          /* <= 1024 (live + coasting tracks per stream; TLK_ECAPACITY beyond, where the reference's lists grow) */
     int32_t max_dets;            /* <= 256 */
     int32_t motion_criterium;    /* 0 "iou" (sort/iou_matching.py), 1 "oks" (sort/oks_matching.py; needs keypoints) */
     int32_t reserved_;

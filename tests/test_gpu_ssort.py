@@ -102,3 +102,26 @@ def test_plain_strongsort_rejects_bad_configuration():
     b = SsortBank(64, max_dets=8)
     with pytest.raises(TlkError):
         b.update(np.zeros((9, 7)), np.ones((9, 64), np.float32))
+
+
+def test_plain_strongsort_beyond_512_tracks(orc):
+    """max_tracks up to 1024: three 230-object scenes in turn (n_init 1, max_age 100) leave ~690 tracks -- more rows than the register-resident
+    Hungarian solver holds; rows and Kalman state stay identical to the oracle, the first scene is re-identified when it returns."""
+    from tracklab_amd.synth import SyntheticStream
+    hp = dict(max_dist=0.2, max_iou_dist=0.7, max_age=100, max_unmatched_preds=7, n_init=1, nn_budget=4, mc_lambda=0.995, ema_alpha=0.9)
+    D = 32
+    gpu, cpu = GpuTracker(D, hp, max_tracks=1024, max_dets=256), orc.PlainStrongSORT(D, **hp)
+    scenes = [iter(SyntheticStream(80 + k, 230, 8, parts=1, dim=D, with_embeddings=True, miss_prob=0.1)) for k in range(3)]
+    most = 0
+    for f, k in enumerate([0, 0, 0, 1, 1, 1, 2, 2, 2, 0, 0, 1, 1, 2, 2]):
+        fr = next(scenes[k])
+        dets, emb = fr["dets"].copy(), fr["embeddings"][:, 0, :].astype(np.float32)
+        dets[:, 6] += 100000 * k
+        a, b = gpu.update(dets, emb), cpu.update(dets, emb)
+        np.testing.assert_array_equal(a, b, err_msg=f"frame {f}")
+        gi, gm, gc, _, gs, gg = gpu.tracks()
+        ci, cm, cc, _, cs, cg = cpu.tracks()
+        np.testing.assert_array_equal(gi, ci); np.testing.assert_array_equal(gs, cs); np.testing.assert_array_equal(gg, cg)
+        np.testing.assert_array_equal(gm, cm); np.testing.assert_array_equal(gc, cc)
+        most = max(most, len(gi))
+    assert most > 540

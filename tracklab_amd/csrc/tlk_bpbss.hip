@@ -765,7 +765,8 @@ extern "C" int tlk_bpbss_create(const tlk_bpbss_params *p, int n_streams, int de
     if (p->dim < 16 || p->dim % 16 != 0) return fail(TLK_EINVAL, "tlk_bpbss_create: dim must be a positive multiple of 16");
     if (p->matching_strategy < 0 || p->matching_strategy > 1) return fail(TLK_EINVAL, "tlk_bpbss_create: unknown matching_strategy");
     const int MAXT = p->max_tracks > 0 ? p->max_tracks : 256, MAXD = p->max_dets > 0 ? p->max_dets : 128;
-    if (MAXT > 512 || MAXD > 256) return fail(TLK_ECAPACITY, "tlk_bpbss_create: max_tracks <= 512 and max_dets <= 256");
+    // (above 512 tracks the Hungarian solver keeps its column state in LDS instead of registers: wave_lsa_lds)
+    if (MAXT > 1024 || MAXD > 256) return fail(TLK_ECAPACITY, "tlk_bpbss_create: max_tracks <= 1024 and max_dets <= 256");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(TLK_ENODEVICE, "tlk_bpbss_create: no HIP device (libtlk has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(TLK_EINVAL, "tlk_bpbss_create: bad device index");

@@ -563,7 +563,8 @@ extern "C" int tlk_ssort_create(const tlk_ssort_params *p, int n_streams, int de
         return fail(TLK_EINVAL, "tlk_ssort_create: nn_budget must be in [1, 1024] (the gallery ring is preallocated; the reference's unbounded budget=None is not supported)");
     if (p->img_w < 1 || p->img_h < 1) return fail(TLK_EINVAL, "tlk_ssort_create: image size must be positive");
     const int MAXT = p->max_tracks > 0 ? p->max_tracks : 256, MAXD = p->max_dets > 0 ? p->max_dets : 128;
-    if (MAXT > 512 || MAXD > 256) return fail(TLK_ECAPACITY, "tlk_ssort_create: max_tracks <= 512 and max_dets <= 256");
+    // (above 512 tracks the Hungarian solver keeps its column state in LDS instead of registers: wave_lsa_lds)
+    if (MAXT > 1024 || MAXD > 256) return fail(TLK_ECAPACITY, "tlk_ssort_create: max_tracks <= 1024 and max_dets <= 256");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(TLK_ENODEVICE, "tlk_ssort_create: no HIP device (libtlk has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(TLK_EINVAL, "tlk_ssort_create: bad device index");
