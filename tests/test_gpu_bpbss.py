@@ -131,16 +131,16 @@ def test_partdist_mfma_matches_oracle(orc, T, N, K, D):
 
 
 def test_hip_bpbss_beyond_512_tracks(orc):
-    """max_tracks up to 1024 (the reference's track list grows; max_age 300 keeps every lost track for 10 s): three
-    different 230-object scenes shown in turn leave ~690 live + coasting tracks, so the first-stage matrix has more rows than the
+    """max_tracks up to 1024 (the reference's track list grows; max_age 300 keeps every lost track for 10 s): four
+    different 230-object scenes shown in turn leave ~650 live + coasting tracks, so the first-stage matrix has more rows than the
     register-resident Hungarian solver holds (512) and wave_lsa_lds takes over; then the first scene returns and is re-identified."""
     from tracklab_amd.synth import SyntheticStream, ltrb_to_ltwh_rows
     K, D = 6, 32
     bank = _bank(YAML, K, D, max_tracks=1024, max_dets=256)
     ref = orc.StrongSORT(K, D, **YAML)
-    scenes = [iter(SyntheticStream(70 + k, 230, 8, parts=K, dim=D, with_embeddings=True, miss_prob=0.1)) for k in range(3)]
+    scenes = [iter(SyntheticStream(70 + k, 230, 8, parts=K, dim=D, with_embeddings=True, miss_prob=0.1)) for k in range(4)]
     most = 0
-    for f, k in enumerate([0, 0, 0, 1, 1, 1, 2, 2, 2, 0, 0, 1]):
+    for f, k in enumerate([0, 0, 1, 1, 2, 2, 3, 3, 0, 0, 1, 2, 3]):
         fr = next(scenes[k])
         d = fr["dets"]
         ltwh, conf, ids = ltrb_to_ltwh_rows(d[:, :4]), d[:, 4], (d[:, 6] + 100000 * k).astype(np.int64)
