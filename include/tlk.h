@@ -390,8 +390,10 @@ int tlk_botsort_get_tracks(tlk_botsort *h, int stream, int which, int64_t *ids, 
  * (sort/kalman_filter.py:50-214), NearestNeighborDistanceMetric("cosine") with budget (sort/nn_matching.py:94-161),
  * and the output loop with _tlwh_to_xyxy (strong_sort.py:62-79, :111-122).
  * Hyper-parameter names = configs/modules/track/strong_sort.yaml `hyperparams` (+ the wrapper's min_confidence).
- * nn_budget must be in [1, 1024] (preallocated ring); the reference's budget=None is not supported. ECC
- * (cfg.ecc, sort/track.py:130-239) is out of scope.
+ * nn_budget in [1, 1024] = the reference's budget (ring of that many rows per track in HBM); nn_budget = -rows (rows <= 65536) = the
+ * reference's budget=None: every sample is kept, with room for `rows` per track -- outgrowing it is TLK_ECAPACITY, never a dropped sample
+ * (288 GB of HBM: 256 tracks x 8192 rows x 512 floats = 4.3 GB per stream). ECC (cfg.ecc, sort/track.py:130-239): tlk_ecc_* estimates the
+ * warp, tlk_ssort_camera_update applies it.
  * ------------------------------------------------------------------------------------------ */
 typedef struct tlk_ssort_params {
     double max_dist, max_iou_dist;      /* strong_sort.py:24-25 */

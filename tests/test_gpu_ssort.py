@@ -97,8 +97,8 @@ def test_plain_strongsort_rejects_bad_configuration():
     from tracklab_amd._lib import SsortBank, TlkError
     with pytest.raises(TlkError):
         SsortBank(48)                       # dim not supported by the MFMA tile
-    with pytest.raises(ValueError):
-        SsortBank(64, nn_budget=None)
+    with pytest.raises(TlkError):
+        SsortBank(64, nn_budget=0)
     b = SsortBank(64, max_dets=8)
     with pytest.raises(TlkError):
         b.update(np.zeros((9, 7)), np.ones((9, 64), np.float32))
@@ -125,3 +125,29 @@ def test_plain_strongsort_beyond_512_tracks(orc):
         np.testing.assert_array_equal(gm, cm); np.testing.assert_array_equal(gc, cc)
         most = max(most, len(gi))
     assert most > 540
+
+
+def test_plain_strongsort_unbounded_gallery(orc):
+    """nn_budget=None (the reference keeps every sample, nn_matching.py:124-142): same rows, state and gallery lengths as the oracle while the
+    galleries fit the rows reserved per track; a track that outgrows them is a loud error, never a silently dropped sample."""
+    from tracklab_amd._lib import TlkError
+    from tracklab_amd.synth import SyntheticStream
+    hp = dict(max_dist=0.2, max_iou_dist=0.7, max_age=15, max_unmatched_preds=7, n_init=1, nn_budget=None, mc_lambda=0.995, ema_alpha=0.9)
+    D = 64
+    gpu, cpu = GpuTracker(D, hp, gallery_rows=64), orc.PlainStrongSORT(D, **hp)
+    small = GpuTracker(D, hp, gallery_rows=5)
+    failed_at = None
+    for fr in SyntheticStream(12, 20, 30, parts=1, dim=D, with_embeddings=True, miss_prob=0.05):
+        dets, emb = fr["dets"], fr["embeddings"][:, 0, :].astype(np.float32)
+        a, b = gpu.update(dets, emb), cpu.update(dets, emb)
+        np.testing.assert_array_equal(a, b)
+        gi, gm, gc, _, gs, gg = gpu.tracks()
+        ci, cm, cc, _, cs, cg = cpu.tracks()
+        np.testing.assert_array_equal(gi, ci); np.testing.assert_array_equal(gg, cg); np.testing.assert_array_equal(gm, cm)
+        if failed_at is None:
+            try:
+                small.update(dets, emb)
+            except TlkError:
+                failed_at = fr["frame"]
+    assert gg.max() > 20                                   # far beyond any of the budgets the other tests use: nothing was dropped
+    assert failed_at is not None and 4 <= failed_at <= 8   # the sixth sample of a track does not fit 5 rows

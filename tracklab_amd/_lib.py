@@ -473,9 +473,9 @@ class SsortBank:
 
     def __init__(self, dim, max_dist=0.2, max_iou_dist=0.7, max_age=70, max_unmatched_preds=7, n_init=3, nn_budget=100,
                  mc_lambda=0.995, ema_alpha=0.9, *, min_confidence=-np.inf, wrapper_mode=False, img_w=1920, img_h=1080,
-                 n_streams=1, device=0, max_tracks=256, max_dets=128):
-        if nn_budget is None:
-            raise ValueError("nn_budget=None (unbounded gallery) is not supported by the preallocated HBM ring; give a budget")
+                 n_streams=1, device=0, max_tracks=256, max_dets=128, gallery_rows=4096):
+        if nn_budget is None:          # the reference's unbounded gallery: every sample kept, room for `gallery_rows` per track (TlkError beyond)
+            nn_budget = -int(gallery_rows)
         L = lib()
         _bind_ssort(L)
         self.params = SsortParams(max_dist, max_iou_dist, max_age, max_unmatched_preds, n_init, int(nn_budget), mc_lambda, ema_alpha,

@@ -37,7 +37,7 @@ struct SsDev {
     double *gl;              // S x MAXT x SGL
     double *cost_g;          // S x MAXT x MAXD     cost-matrix spill
     int *ps_ws;              // S x 4 x ps_cap       hash tables of the set-order emulation when they do not fit the LDS cost area
-    int S, MAXT, MAXD, D, B, cost_lds_entries, ps_cap;
+    int S, MAXT, MAXD, D, B, cost_lds_entries, ps_cap, unbounded;      // unbounded: budget=None -- B rows of room, overflow is an error
 };
 
 struct SsP {
@@ -417,6 +417,7 @@ ssort_assoc_kernel(SsDev Dv, SsP P, SsIn in, tlk_ssort_row *__restrict__ rows_al
             gnormS[(size_t)slot * B + pos] = sqrtf(ss);
             Kt.i(SI_GPOS) = pos + 1 == B ? 0 : pos + 1;
             const int gl_ = Kt.i(SI_GLEN);
+            if (Dv.unbounded && gl_ == B) hdr[H_ERR] = TLK_ECAPACITY;       // budget=None: the oldest sample may not be overwritten
             Kt.i(SI_GLEN) = gl_ < B ? gl_ + 1 : B;
         }
     }
@@ -437,7 +438,7 @@ ssort_assoc_kernel(SsDev Dv, SsP P, SsIn in, tlk_ssort_row *__restrict__ rows_al
                                         r.conf = Kt.d(SD_CONF); r.class_id = Kt.i(SI_CLS); r.time_since_update = Kt.i(SI_TSU);
                                         rows[pos] = r;
                                     }, L.scan);
-    if (tid == 0) *out_count = nrows > out_cap ? TLK_ECAPACITY : nrows;
+    if (tid == 0) *out_count = (nrows > out_cap || hdr[H_ERR] != 0) ? TLK_ECAPACITY : nrows;
 }
 
 __global__ void ssort_reset_kernel(SsDev D, int stream)
@@ -559,8 +560,10 @@ extern "C" int tlk_ssort_create(const tlk_ssort_params *p, int n_streams, int de
     if (n_streams < 1) return fail(TLK_EINVAL, "tlk_ssort_create: n_streams must be >= 1");
     if (p->dim != 32 && p->dim != 64 && p->dim != 128 && p->dim != 256 && p->dim != 512)
         return fail(TLK_EINVAL, "tlk_ssort_create: dim must be one of 32, 64, 128, 256, 512");
-    if (p->nn_budget < 1 || p->nn_budget > 1024)
-        return fail(TLK_EINVAL, "tlk_ssort_create: nn_budget must be in [1, 1024] (the gallery ring is preallocated; the reference's unbounded budget=None is not supported)");
+    // nn_budget > 0: the reference's budget (a ring of that many rows per track). nn_budget < 0: the reference's budget=None -- every feature is
+    // kept -- with room for -nn_budget rows per track in HBM; a track that outgrows it is a loud TLK_ECAPACITY, never a dropped sample.
+    if (p->nn_budget == 0 || p->nn_budget > 1024 || p->nn_budget < -65536)
+        return fail(TLK_EINVAL, "tlk_ssort_create: nn_budget must be in [1, 1024], or -rows (rows <= 65536) for the reference's unbounded budget=None");
     if (p->img_w < 1 || p->img_h < 1) return fail(TLK_EINVAL, "tlk_ssort_create: image size must be positive");
     const int MAXT = p->max_tracks > 0 ? p->max_tracks : 256, MAXD = p->max_dets > 0 ? p->max_dets : 128;
     // (above 512 tracks the Hungarian solver keeps its column state in LDS instead of registers: wave_lsa_lds)
@@ -575,7 +578,7 @@ extern "C" int tlk_ssort_create(const tlk_ssort_params *p, int n_streams, int de
     h->P = SsP{p->max_dist, p->max_iou_dist, p->mc_lambda, p->ema_alpha, p->min_confidence, p->max_age, p->max_unmatched_preds, p->n_init,
                p->wrapper_mode, p->img_w, p->img_h};
     SsDev &D = h->D;
-    D.S = n_streams; D.MAXT = MAXT; D.MAXD = MAXD; D.D = p->dim; D.B = p->nn_budget;
+    D.S = n_streams; D.MAXT = MAXT; D.MAXD = MAXD; D.D = p->dim; D.B = p->nn_budget > 0 ? p->nn_budget : -p->nn_budget; D.unbounded = p->nn_budget < 0;
     const size_t fixed = blds_fixed(MAXT, MAXD), budget = 160 * 1024 - 256;
     if (fixed + 4096 > budget) { delete h; return fail(TLK_ECAPACITY, "tlk_ssort_create: LDS budget exceeded"); }
     D.cost_lds_entries = (int)((budget - fixed) / sizeof(double));

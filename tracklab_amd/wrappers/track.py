@@ -325,7 +325,8 @@ class HipStrongSORT(ImageLevelModule, _ReidTrackerBase):
         hyper = dict(cfg_get(self.cfg, "hyperparams"))
         return SsortBank(dim, **hyper, min_confidence=float(cfg_get(self.cfg, "min_confidence", 0.0)), wrapper_mode=True,
                          img_w=int(img_w), img_h=int(img_h), device=_device_index(self.device),
-                         max_tracks=int(cfg_get(self.cfg, "max_tracks", 256)), max_dets=int(cfg_get(self.cfg, "max_dets", 128)))
+                         max_tracks=int(cfg_get(self.cfg, "max_tracks", 256)), max_dets=int(cfg_get(self.cfg, "max_dets", 128)),
+                         gallery_rows=int(cfg_get(self.cfg, "gallery_rows", 4096)))     # rows per track when hyperparams.nn_budget is null
 
 
 class HipBoTSORT(ImageLevelModule, _ReidTrackerBase):
