@@ -313,10 +313,12 @@ def main():
     from tracklab_amd import dist as tdist
     from tracklab_amd.synth import HEIGHT, WIDTH, render_frame
     world, rank, local_rank = tdist.env_world()
-    dist = tdist.init("nccl") if world > 1 else None
+    # under a torchrun launch the collectives run on RCCL even at world size 1 (the driver's N=1 line comes without torchrun: no process group)
+    use_dist = world > 1 or ("WORLD_SIZE" in os.environ and os.environ.get("TLK_BENCH_DIST_AT_1") == "1")
+    dist = tdist.init("nccl") if use_dist else None
     if dist is None:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if use_dist else 0)
     if args.workload == "config1":
         return main_config1(args, world, rank, dist, dev)
     wl = WORKLOADS[args.workload]
@@ -616,7 +618,7 @@ def main():
                        "detector": f"yolox-{detector}", "streams_per_gpu": S, "frames_per_step": F,
                        "frames_per_gpu_per_step": B, "parallelism": f"stream-parallel x{world}", "hip_graphs": not args.no_graph,
                        "backbone_dtype": args.dtype},
-            "per_gpu_fps": value / world, "per_rank_fps": per_rank, "ranks_seen": seen, "hota_allreduce": hota_all,
+            "per_gpu_fps": value / world, "per_rank_fps": per_rank, "ranks_seen": seen, "collectives": "nccl" if dist is not None else None, "hota_allreduce": hota_all,
             "latency": latency, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(line), flush=True)

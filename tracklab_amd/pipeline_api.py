@@ -4,14 +4,13 @@ When TrackLab is installed we subclass ITS classes (``tracklab.pipeline``), so t
 ``level`` / ``name`` logic sees ordinary modules. When it is not importable (this build container, the GPU
 box) we fall back to mirrors with the same names and contracts:
 
-* ``level`` = first-base class name lower-cased up to the first "_" (tracklab/pipeline/module.py:33-37) --
-  hence the mirrors MUST be called ``ImageLevelModule`` / ``DetectionLevelModule``;
-* ``name`` = class name (module.py:28-31); ``input_columns`` / ``output_columns`` list-or-dict contract
-  (module.py:51-61); ``batch_size`` + ``collate_fn`` class attribute (imagelevel_module.py:34-47,92-100).
+* ``level`` comes from the FIRST base class (tracklab/pipeline/module.py:33-37) -- hence the mirrors are called
+  ``ImageLevelModule`` / ``DetectionLevelModule`` and the Hip* modules list them first;
+* ``name`` = class name (module.py:28-31); ``input_columns`` / ``output_columns`` class attributes; ``batch_size`` +
+  ``collate_fn`` class attribute (imagelevel_module.py:34-47,92-100). Nothing else of TrackLab's Module is mirrored.
 """
 from __future__ import annotations
 
-import re
 from abc import ABCMeta, abstractmethod
 
 try:  # pragma: no cover - exercised only where TrackLab is installed
@@ -25,32 +24,19 @@ except Exception:  # ImportError, or one of its heavy dependencies missing
         return default_collate(batch)
 
     class Module(metaclass=ABCMeta):
+        """What the Hip* modules themselves rely on when TrackLab is absent (tests, the GPU box): a module's display name and its level
+        (TrackLab derives the level from the FIRST base class, pipeline/module.py:33-37). The column bookkeeping of TrackLab's Module
+        (get_input_columns / get_output_columns, training hooks) belongs to TrackLab's Pipeline and comes with the real base class."""
         input_columns = None
         output_columns = None
-        training_enabled = False
-        forget_columns = []
 
         @property
         def name(self):
-            return self.__class__.__name__
+            return type(self).__name__
 
         @property
         def level(self):
-            name = self.__class__.__bases__[0].__name__
-            name = re.sub("([a-z0-9])([A-Z])", r"\1_\2", name).lower()
-            return name.split("_")[0]
-
-        def get_input_columns(self, level):
-            if isinstance(self.input_columns, list):
-                return self.input_columns if level == "detection" else []
-            elif isinstance(self.input_columns, dict):
-                return self.input_columns.get(level, [])
-
-        def get_output_columns(self, level):
-            if isinstance(self.output_columns, list):
-                return self.output_columns if level == "detection" else []
-            elif isinstance(self.output_columns, dict):
-                return self.output_columns.get(level, [])
+            return "image" if "Image" in type(self).__bases__[0].__name__ else "detection"
 
     class ImageLevelModule(Module):
         collate_fn = staticmethod(_default_collate)
