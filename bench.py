@@ -47,6 +47,9 @@ WORKLOADS = {
     "config1": dict(detector=None, objects=30, frames_per_step=100, max_dets=64,
                     name="BASELINE configs[0] shape (the reference's CPU-runnable plumbing case): ground-truth detections + IoU-only SORT "
                          "(oc_sort with inertia 0, asso_func iou), association only, synthetic 1080p 30-obj stream"),
+    "config3h": dict(detector="m", objects=100, frames_per_step=24, max_dets=104, reid_arch="hrnet32",
+                     name="config3 with the ReID backbone tracklab/configs/modules/reid/bpbreid.yaml:53 names: YOLOX-m + part-based ReID on HRNet-W32 "
+                          "(384x128, 6x256, 1/4-resolution 480-channel head) + BPBReID-StrongSORT, synthetic 1080p 100-obj stream"),
     "config5": dict(detector="l", objects=100, frames_per_step=24, max_dets=104,
                     name="BASELINE configs[4] per-GPU unit: YOLOX-l + part-based ReID + BPBReID-StrongSORT, one synthetic 1080p 100-obj stream "
                          "per GPU (--gpus 8 = the 8-stream configuration)"),
@@ -328,7 +331,7 @@ def main():
     S, F = args.streams, args.frames_per_step or wl["frames_per_step"]
     B = S * F
     total_steps = args.warmup + args.steps
-    is3 = args.workload in ("config3", "config4", "config3s", "config3b", "config3d", "config5")
+    is3 = args.workload in ("config3", "config3h", "config4", "config3s", "config3b", "config3d", "config5")
     ssort = wl.get("tracker") in ("strong_sort", "bot_sort", "deep_oc_sort")      # global-feature trackers: (n,7) rows + (n,D) features
     check_frames = args.check_frames if args.check_frames is not None else (96 if ssort else 600)
     parity_steps = min(64, max(1, (check_frames + F - 1) // F)) if check_frames > 0 else 0
@@ -349,6 +352,8 @@ def main():
     def make_pipe(frames_per_step, n_streams=S):
         if is3:
             kw = dict(dim=wl["dim"]) if "dim" in wl else {}
+            if "reid_arch" in wl:
+                kw["reid_arch"] = wl["reid_arch"]
             return gp.DetReidTrackPipeline(detector, n_streams=n_streams, frames_per_step=frames_per_step, max_dets=wl["max_dets"], device=dev.index,
                                            use_graph=not args.no_graph, pose=wl.get("pose"), tracker=wl.get("tracker", "bpbreid"), dtype=tdtype, **kw)
         return gp.DetTrackPipeline(detector, n_streams=n_streams, frames_per_step=frames_per_step, max_dets=wl["max_dets"], device=dev.index,
@@ -636,7 +641,7 @@ def cpu_baseline(args, wl, pipe, detector, is3, ssort, byte, gfeat_oracle, gfeat
     from tracklab_amd.synth import HEIGHT, WIDTH, render_frame
     oracle.build()
     cpu_det = yolox(detector, device="cpu", dtype=torch.float32, channels_last=False)
-    cpu_reid = part_based_reid(pipe.K, pipe.D, device="cpu", dtype=torch.float32, channels_last=False) if is3 else None
+    cpu_reid = part_based_reid(pipe.K, pipe.D, device="cpu", dtype=torch.float32, channels_last=False, arch=getattr(pipe, "reid_arch", "resnet50")) if is3 else None
     cpu_pose = None
     if is3 and wl.get("pose"):
         from tracklab_amd.backbones.rtmpose import rtmpose

@@ -17,14 +17,14 @@ def _detector_rows(orc, head, ratio):
     return np.stack([l, t, r - l, b - t], axis=1)
 
 
-@pytest.mark.parametrize("detector,pose,dim", [("m", None, 256), ("l", None, 256), ("m", "m", 512)],
-                         ids=["config3_yolox_m_bpbreid", "config5_yolox_l_bpbreid", "config4_yolox_m_rtmpose_kpr512_oks"])
-def test_fused_pipeline_ids_equal_oracle_at_baseline_config_shapes(orc, detector, pose, dim):
+@pytest.mark.parametrize("detector,pose,dim,reid_arch", [("m", None, 256, "resnet50"), ("l", None, 256, "resnet50"), ("m", "m", 512, "resnet50"), ("m", None, 256, "hrnet32")],
+                         ids=["config3_yolox_m_bpbreid", "config5_yolox_l_bpbreid", "config4_yolox_m_rtmpose_kpr512_oks", "config3h_hrnet32_reid"])
+def test_fused_pipeline_ids_equal_oracle_at_baseline_config_shapes(orc, detector, pose, dim, reid_arch):
     import torch
     from tracklab_amd import gpu_pipeline as gp
     from tracklab_amd.synth import SyntheticStream, render_frame, synth_yolox_head
     F, steps, nobj, maxd = 8, 6, 100, 104
-    pipe = gp.DetReidTrackPipeline(detector, n_streams=1, frames_per_step=F, max_dets=maxd, dim=dim, pose=pose, use_graph=False)
+    pipe = gp.DetReidTrackPipeline(detector, n_streams=1, frames_per_step=F, max_dets=maxd, dim=dim, pose=pose, use_graph=False, reid_arch=reid_arch)
     rng = np.random.default_rng(31)
     stream = list(SyntheticStream(41, nobj, F * steps))
     heads = np.stack([synth_yolox_head(rng, fr["dets"][:, :4], ratio=pipe.ratio) for fr in stream])
@@ -39,6 +39,7 @@ def test_fused_pipeline_ids_equal_oracle_at_baseline_config_shapes(orc, detector
         pipe.synchronize()
         rows, cnt = pipe.rows_numpy(h_rows, h_cnt)
         emb = pipe.last["emb"].cpu().numpy().reshape(F, maxd, pipe.K, pipe.D)
+        assert np.isfinite(emb).all()                                      # (fp16 activations of the random-init network stay in range)
         vis = pipe.last["vis"].cpu().numpy().reshape(F, maxd, pipe.K)
         kps = pipe.last["kps"].cpu().numpy().reshape(F, maxd, 17, 3) if pose else None
         for f in range(F):

@@ -1,4 +1,4 @@
-"""Part-based ReID network in the shape of BPBReID (ResNet-50, last stride 1, 1x1 dim-reduce,
+"""Part-based ReID network in the shape of BPBReID (ResNet-50 with last stride 1, or HRNet-W32; 1x1 dim-reduce,
 pixel-wise part classifier, attention-weighted pooling per part).
 
 The reference runs this through the third-party torchreid fork
@@ -33,8 +33,89 @@ def _layer(cin, planes, n, stride):
     return nn.Sequential(*blocks)
 
 
-class PartBasedReID(nn.Module):
-    def __init__(self, parts=6, dim=256, vis_threshold=0.5):
+class _BasicBlock(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.c1 = ConvBiasAct(c, c, 3, 1, "relu")
+        self.c2 = ConvBiasAct(c, c, 3, 1, "relu")                           # ReLU applied after the residual add
+
+    def forward(self, x):
+        return self.c2(self.c1(x), residual=x)
+
+
+class _HRModule(nn.Module):
+    """One HRNet exchange unit: four basic blocks per branch, then every branch receives the sum of all branches brought to its resolution
+    (higher resolution: 1x1 conv + nearest up-sampling; lower: a chain of stride-2 3x3 convs), ReLU."""
+
+    def __init__(self, chans):
+        super().__init__()
+        n = len(chans)
+        self.branches = nn.ModuleList([nn.Sequential(*[_BasicBlock(c) for _ in range(4)]) for c in chans])
+        self.fuse = nn.ModuleList()
+        for i in range(n):
+            row = nn.ModuleList()
+            for j in range(n):
+                if j == i:
+                    row.append(nn.Identity())
+                elif j > i:
+                    row.append(ConvBiasAct(chans[j], chans[i], 1, 1, None))
+                else:
+                    steps = [ConvBiasAct(chans[j], chans[j] if k < i - j - 1 else chans[i], 3, 2, "relu" if k < i - j - 1 else None) for k in range(i - j)]
+                    row.append(nn.Sequential(*steps))
+            self.fuse.append(row)
+
+    def forward(self, xs):
+        xs = [b(x) for b, x in zip(self.branches, xs)]
+        out = []
+        for i, row in enumerate(self.fuse):
+            y = None
+            for j, f in enumerate(row):
+                t = f(xs[j])
+                if j > i:
+                    t = nn.functional.interpolate(t, size=xs[i].shape[-2:], mode="nearest")
+                y = t if y is None else y + t
+            out.append(torch.relu_(y) if y is not xs[i] else torch.relu(y))
+        return out
+
+
+class HRNetW32(nn.Module):
+    """HRNet-W32 (Sun et al., CVPR 2019; the `backbone: "hrnet32"` of tracklab/configs/modules/reid/bpbreid.yaml:53, built by the third-party
+    torchreid fork -- not vendored, so the definition follows the paper: stem to 1/4 resolution, a bottleneck stage, then 1 + 4 + 3 exchange
+    modules over 2 / 3 / 4 branches of 32 / 64 / 128 / 256 channels). Output: all branches up-sampled to 1/4 resolution and concatenated,
+    480 channels -- the high-resolution representation the part-based head pools over."""
+    out_channels = 480
+
+    def __init__(self):
+        super().__init__()
+        self.stem = nn.Sequential(ConvBiasAct(3, 64, 3, 2, "relu"), ConvBiasAct(64, 64, 3, 2, "relu"))
+        self.layer1 = nn.Sequential(_Bottleneck(64, 64, 1, True), *[_Bottleneck(256, 64) for _ in range(3)])
+        c = (32, 64, 128, 256)
+        self.t1 = nn.ModuleList([ConvBiasAct(256, c[0], 3, 1, "relu"), ConvBiasAct(256, c[1], 3, 2, "relu")])
+        self.stage2 = nn.ModuleList([_HRModule(c[:2])])
+        self.t2 = ConvBiasAct(c[1], c[2], 3, 2, "relu")
+        self.stage3 = nn.ModuleList([_HRModule(c[:3]) for _ in range(4)])
+        self.t3 = ConvBiasAct(c[2], c[3], 3, 2, "relu")
+        self.stage4 = nn.ModuleList([_HRModule(c) for _ in range(3)])
+
+    def forward(self, x):
+        x = self.layer1(self.stem(x))
+        xs = [t(x) for t in self.t1]
+        for m in self.stage2:
+            xs = m(xs)
+        xs = xs + [self.t2(xs[-1])]
+        for m in self.stage3:
+            xs = m(xs)
+        xs = xs + [self.t3(xs[-1])]
+        for m in self.stage4:
+            xs = m(xs)
+        size = xs[0].shape[-2:]
+        return torch.cat([xs[0]] + [nn.functional.interpolate(t, size=size, mode="nearest") for t in xs[1:]], dim=1)
+
+
+class _ResNet50(nn.Module):
+    out_channels = 2048
+
+    def __init__(self):
         super().__init__()
         self.conv1 = ConvBiasAct(3, 64, 7, 2, "relu")
         self.pool = nn.MaxPool2d(3, 2, 1)
@@ -42,14 +123,26 @@ class PartBasedReID(nn.Module):
         self.layer2 = _layer(256, 128, 4, 2)
         self.layer3 = _layer(512, 256, 6, 2)
         self.layer4 = _layer(1024, 512, 3, 1)          # last_stride = 1 (BPBReID)
-        self.reduce = ConvBiasAct(2048, dim, 1, 1, None)
-        self.part_cls = nn.Conv2d(dim, parts, 1, bias=True)   # foreground + (parts-1) body parts
-        self.parts, self.dim, self.vis_threshold = parts, dim, vis_threshold
 
     def forward(self, x):
         x = self.pool(self.conv1(x))
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
-        f = self.reduce(x)                                   # (N, D, h, w)
+        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+
+
+class PartBasedReID(nn.Module):
+    """arch "resnet50" (default: what the benches are quoted on) or "hrnet32" (the backbone bpbreid.yaml names)."""
+
+    def __init__(self, parts=6, dim=256, vis_threshold=0.5, arch="resnet50"):
+        super().__init__()
+        if arch not in ("resnet50", "hrnet32"):
+            raise ValueError(f"PartBasedReID: unknown backbone {arch!r} (resnet50, hrnet32)")
+        self.backbone = _ResNet50() if arch == "resnet50" else HRNetW32()
+        self.reduce = ConvBiasAct(self.backbone.out_channels, dim, 1, 1, None)
+        self.part_cls = nn.Conv2d(dim, parts, 1, bias=True)   # foreground + (parts-1) body parts
+        self.parts, self.dim, self.vis_threshold, self.arch = parts, dim, vis_threshold, arch
+
+    def forward(self, x):
+        f = self.reduce(self.backbone(x))                    # (N, D, h, w)
         att = torch.softmax(self.part_cls(f).float(), dim=1)  # (N, K, h, w) pixel-wise part attention
         ff = f.float().flatten(2)                            # (N, D, hw)
         a = att.flatten(2)                                   # (N, K, hw)
@@ -59,5 +152,5 @@ class PartBasedReID(nn.Module):
         return emb.contiguous(), vis
 
 
-def part_based_reid(parts=6, dim=256, device="cuda", dtype=torch.float16, channels_last=True, seed=0):
-    return finalize(random_init_(PartBasedReID(parts, dim), seed), device, dtype, channels_last)
+def part_based_reid(parts=6, dim=256, device="cuda", dtype=torch.float16, channels_last=True, seed=0, arch="resnet50"):
+    return finalize(random_init_(PartBasedReID(parts, dim, arch=arch), seed), device, dtype, channels_last)

@@ -236,8 +236,9 @@ class DetReidTrackPipeline:
                  height: int = 1080, width: int = 1920, size: int = 640, dtype=torch.float16, device: int = 0,
                  parts: int = 6, dim: int = 256, reid_hw=(384, 128), tracker_cfg: dict | None = None,
                  nms_thr: float = 0.45, score_thr: float = 0.7, max_tracks: int = 512, use_graph: bool = True,
-                 pose: str | None = None, tracker: str = "bpbreid"):
-        """tracker = "strong_sort": plain StrongSORT (strong_sort.StrongSORT: Pillow-semantics 256x128 crops of the int-truncated
+                 pose: str | None = None, tracker: str = "bpbreid", reid_arch: str = "resnet50"):
+        """reid_arch: "resnet50" (default) or "hrnet32" (the backbone tracklab/configs/modules/reid/bpbreid.yaml:53 names).
+        tracker = "strong_sort": plain StrongSORT (strong_sort.StrongSORT: Pillow-semantics 256x128 crops of the int-truncated
         boxes, one global 512-d feature per crop, cosine gallery on MFMA, tlk_ssort bank) instead of BPBReID-StrongSORT.
         pose = "t"/"s"/"m"/"l": BASELINE.json configs[3] -- a top-down RTMPose stage (tlk_pose_crop_warp_norm -> network ->
         tlk_simcc_decode) between detector and ReID; its keypoints drive the tracker's OKS motion cost (motion_criterium "oks")."""
@@ -275,7 +276,8 @@ class DetReidTrackPipeline:
             self.tracker_cfg = dict(self.tracker_cfg, motion_criterium="oks")
             self.pose = rtmpose(pose, device=self.dev, dtype=dtype, channels_last=True)
         self.model = yolox(detector, 1, device=self.dev, dtype=dtype, channels_last=True)
-        self.reid = part_based_reid(parts, dim, device=self.dev, dtype=dtype, channels_last=True)
+        self.reid_arch = reid_arch
+        self.reid = part_based_reid(parts, dim, device=self.dev, dtype=dtype, channels_last=True, arch=reid_arch)
         if tracker == "strong_sort":
             self.bank = _lib.SsortBank(dim, **self.tracker_cfg, min_confidence=0.4, wrapper_mode=True, img_w=width, img_h=height,
                                        n_streams=n_streams, device=device, max_tracks=min(max_tracks, 256), max_dets=max_dets)

@@ -25,6 +25,7 @@ class HipPartReID(ImageLevelModule):
         self.dim = int(cfg_get(cfg, "dim", 256))
         self.max_dets = int(cfg_get(cfg, "max_dets", 128))
         self.checkpoint = cfg_get(cfg, "checkpoint", None)
+        self.backbone = str(cfg_get(cfg, "backbone", "resnet50"))       # or "hrnet32" (bpbreid.yaml:53)
         self._model = None
 
     def _ensure_model(self):
@@ -32,7 +33,7 @@ class HipPartReID(ImageLevelModule):
             import torch
             from ..backbones.reid import part_based_reid
             self._torch = torch
-            self._model = part_based_reid(self.parts, self.dim, device=self.device, dtype=torch.float16, channels_last=True)
+            self._model = part_based_reid(self.parts, self.dim, device=self.device, dtype=torch.float16, channels_last=True, arch=self.backbone)
             if self.checkpoint:
                 self._model.load_state_dict(torch.load(self.checkpoint, map_location=self.device))
 
