@@ -317,7 +317,7 @@ def main():
     from tracklab_amd.synth import HEIGHT, WIDTH, render_frame
     world, rank, local_rank = tdist.env_world()
     # under a torchrun launch the collectives run on RCCL even at world size 1 (the driver's N=1 line comes without torchrun: no process group)
-    use_dist = world > 1 or ("WORLD_SIZE" in os.environ and os.environ.get("TLK_BENCH_DIST_AT_1") == "1")
+    use_dist = world > 1 or ("WORLD_SIZE" in os.environ and os.environ.get("TLK_FORCE_DIST") == "1")
     dist = tdist.init("nccl") if use_dist else None
     if dist is None:
         torch.cuda.set_device(0)

@@ -20,7 +20,7 @@ def test_bench_under_torchrun_with_rccl_collectives():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(PYTHONPATH=REPO, TLK_BENCH_DIST_AT_1="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(PYTHONPATH=REPO, TLK_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(REPO, "bench.py"), "--gpus", "1", "--workload", "config2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-latency-leg",
            "--check-frames", "32"]
