@@ -505,6 +505,13 @@ int tlk_yolox_decode_nms(const float *pred_dev, int batch, int size, int num_cla
                          float *scores_dev, int32_t *cls_dev, int32_t *counts_dev, double *trk_in_dev,
                          int64_t det_id_base, double category_id, void *hip_stream);
 
+/* non_max_suppression(boxes, max_bbox_overlap, scores=None) of plugins/track/strong_sort/sort/preprocessing.py:6-73 (same file in
+ * bpbreid_strong_sort/sort/; dead code in the reference: never called). boxes (n, 4) float64 (x, y, w, h) and scores (n) float64 or NULL
+ * (then the order is by the bottom edge) in device memory; pick (n) int32 receives the kept indices in the order the reference appends
+ * them, *n_pick their number. n <= 1024. Equal keys keep ascending index order (np.argsort's default sort is not stable). */
+int tlk_deepsort_nms_f64(const double *boxes_xywh_dev, const double *scores_dev, int n, double max_bbox_overlap, int32_t *pick_dev,
+                         int32_t *n_pick_dev, void *hip_stream);
+
 /* ------------------------------------------------------------------------------------------
  * Camera-motion estimation on the device. Replaces GMC(method="sparseOptFlow", downscale).apply(frame) of
  * plugins/track/bot_sort/gmc.py:239-303 (cv2.cvtColor -> resize -> goodFeaturesToTrack(1000, 0.01, 1, 3) ->

@@ -1323,11 +1323,40 @@ def gen_ssort_setorder(out_dir):
     print(f"setorder_ssort: rows_out={out_off[-1]} python {sys.version.split()[0]}")
 
 
+def gen_nms(out_dir):
+    """G2: non_max_suppression of strong_sort/sort/preprocessing.py:6-73 -- dead code in the reference (never called; `np.float` was removed from
+    NumPy 1.24), run here with np.float restored. Distinct keys (np.argsort's default sort is not stable)."""
+    _install_cv2_stub()
+    had = hasattr(np, "float")
+    if not had:
+        np.float = float
+    try:
+        import strong_sort.sort.preprocessing as pre
+        rng = np.random.default_rng(61)
+        blobs = {}
+        for ci, (n, thr, with_scores) in enumerate([(60, 0.5, True), (60, 0.5, False), (200, 0.3, True), (1, 0.5, True), (300, 0.8, False), (128, 1.0, True)]):
+            c = rng.uniform(100, 1500, (max(n // 3, 1), 2))
+            base = np.concatenate([c, rng.uniform(40, 120, (len(c), 1)), rng.uniform(90, 300, (len(c), 1))], 1)
+            boxes = np.concatenate([base[rng.integers(0, len(base), n)][:, :2] + rng.normal(0, 12, (n, 2)), base[rng.integers(0, len(base), n)][:, 2:] * rng.uniform(0.8, 1.2, (n, 2))], 1)
+            scores = rng.permutation(n).astype(np.float64) / n + 0.001 if with_scores else None
+            pick = pre.non_max_suppression(boxes.copy(), thr, scores)
+            blobs[f"c{ci}_boxes"], blobs[f"c{ci}_thr"], blobs[f"c{ci}_pick"] = boxes, np.array(thr), np.asarray(pick, dtype=np.int64)
+            if with_scores:
+                blobs[f"c{ci}_scores"] = scores
+        blobs["n_cases"] = np.array(6)
+        assert pre.non_max_suppression(np.zeros((0, 4)), 0.5) == []
+    finally:
+        if not had:
+            del np.float
+    np.savez_compressed(os.path.join(out_dir, "deepsort_nms.npz"), **blobs)
+    print("deepsort_nms.npz", {k: v.shape for k, v in blobs.items() if k.endswith("pick")})
+
+
 def main():
     out_dir = HERE
     only = set(sys.argv[1:])
     gens = {"ocsort": gen_ocsort, "iou": gen_iou_family, "kf7": gen_kf7, "lsa": gen_lsa,
-            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack, "botsort": gen_botsort, "deepocsort": gen_deepocsort, "clearmot": gen_clearmot, "mot_io": gen_mot_io, "ssort_camera": gen_ssort_camera, "botsort_gmc": gen_botsort_gmc, "deepocsort_cmc": gen_deepocsort_cmc, "ssort_setorder": gen_ssort_setorder}
+            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack, "botsort": gen_botsort, "deepocsort": gen_deepocsort, "clearmot": gen_clearmot, "mot_io": gen_mot_io, "ssort_camera": gen_ssort_camera, "botsort_gmc": gen_botsort_gmc, "deepocsort_cmc": gen_deepocsort_cmc, "ssort_setorder": gen_ssort_setorder, "nms": gen_nms}
     for k, fn in gens.items():
         if not only or k in only:
             fn(out_dir)

@@ -236,3 +236,24 @@ def test_fused_gemm_bias_act_matches_fp32_reference(dtype_name, act, residual):
         torch.testing.assert_close(out.float(), ref, rtol=tol, atol=tol * 4)
         again = _lib.gemm_bias_act(x, w, b, act, r)                  # cached plan: identical result
         assert torch.equal(out, again)
+
+
+def test_deepsort_nms_matches_the_reference_vectors_and_oracle(orc):
+    """SURVEY 8a G2 (sort/preprocessing.py:6-73, dead code in the reference): kept indices and their order."""
+    import torch
+    from test_oracle_nms import nms_cases
+    from tracklab_amd import _lib
+    for boxes, thr, scores, pick in nms_cases():
+        got = _lib.deepsort_nms(torch.from_numpy(boxes).cuda(), thr, None if scores is None else torch.from_numpy(scores).cuda())
+        assert got.cpu().tolist() == pick
+    rng = np.random.default_rng(5)
+    for n in (2, 63, 64, 65, 500, 1024):
+        boxes = np.concatenate([rng.uniform(0, 900, (n, 2)), rng.uniform(20, 200, (n, 2))], 1)
+        scores = rng.permutation(n) / n
+        for sc in (scores, None):
+            exp = orc.deepsort_nms(boxes, 0.45, sc)
+            got = _lib.deepsort_nms(torch.from_numpy(boxes).cuda(), 0.45, None if sc is None else torch.from_numpy(sc).cuda())
+            assert got.cpu().tolist() == exp, (n, sc is None)
+    assert _lib.deepsort_nms(torch.zeros((0, 4), dtype=torch.float64, device="cuda"), 0.5).numel() == 0
+    with pytest.raises(_lib.TlkError):
+        _lib.deepsort_nms(torch.zeros((1025, 4), dtype=torch.float64, device="cuda"), 0.5)

@@ -1003,6 +1003,24 @@ def pyset_difference_order(a, b, force_table=False):
 # ------------------------------------------------------------------------------------------------
 # camera-motion estimation on the device (tlk_cmc_*): GMC.applySparseOptFlow of BoT-SORT (gmc.py:239-303)
 # ------------------------------------------------------------------------------------------------
+def deepsort_nms(boxes, max_bbox_overlap, scores=None):
+    """sort/preprocessing.py:6-73 non_max_suppression on the device (tlk_deepsort_nms_f64): cuda tensors (n, 4) float64 xywh [+ (n,) float64
+    scores] -> int32 cuda tensor of the kept indices, in pick order."""
+    import torch
+    assert boxes.is_cuda and boxes.dtype == torch.float64 and boxes.is_contiguous() and boxes.dim() == 2 and boxes.shape[1] == 4
+    n = boxes.shape[0]
+    pick = torch.zeros(max(n, 1), dtype=torch.int32, device=boxes.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=boxes.device)
+    sp = None
+    if scores is not None:
+        assert scores.is_cuda and scores.dtype == torch.float64 and scores.is_contiguous() and scores.numel() == n
+        sp = scores.data_ptr()
+    L = lib()
+    L.tlk_deepsort_nms_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    check(L.tlk_deepsort_nms_f64(boxes.data_ptr() if n else None, sp, n, float(max_bbox_overlap), pick.data_ptr(), cnt.data_ptr(), current_stream_ptr()))
+    return pick[:int(cnt.item())]
+
+
 class EccEstimator:
     """One video stream's StrongSORT camera-motion estimator (Track.ECC, strong_sort/sort/track.py:129-211): ``apply(frame)`` -> the
     (2, 3) float32 warp for ``SsortBank.camera_update``, or None where the reference skips the update (first frame; cv2.error).

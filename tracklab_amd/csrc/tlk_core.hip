@@ -247,3 +247,94 @@ extern "C" int tlk_pyset_difference_order(const int32_t *a, int na, const int32_
     if (e != hipSuccess) return fail(TLK_EHIP, std::string("tlk_pyset_difference_order: ") + hipGetErrorString(e));
     return TLK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// non_max_suppression(boxes, max_bbox_overlap, scores) of plugins/track/strong_sort/sort/preprocessing.py:6-73
+// (identical in bpbreid_strong_sort/sort/preprocessing.py; dead code in the reference -- the live NMS is the detector's,
+// tlk_yolox_decode_nms). One workgroup: (key, index) pairs sorted ascending by a bitonic network in LDS (key = score, or the bottom edge y2
+// without scores; equal keys keep ascending index order -- np.argsort's default sort is not stable, the reference's order for ties is
+// implementation-defined), then the greedy loop from the top of the order: the pick's overlap (w * h) / area[other] with every box still in the
+// list is evaluated by all threads at once. fp64 throughout, operation for operation what the numpy code computes.
+namespace {
+constexpr int NMS_MAX = 1024;
+
+__global__ void __launch_bounds__(BLOCK) deepsort_nms_kernel(const double *__restrict__ boxes, const double *__restrict__ scores, int n, double thr,
+                                                             int *__restrict__ pick, int *__restrict__ n_pick)
+{
+    __shared__ double s_key[NMS_MAX], s_x2[NMS_MAX], s_y2[NMS_MAX], s_area[NMS_MAX];
+    __shared__ int s_idx[NMS_MAX];
+    __shared__ unsigned char s_alive[NMS_MAX];
+    __shared__ int s_top;
+    const int tid = threadIdx.x;
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int i = tid; i < np2; i += BLOCK) {
+        if (i < n) {
+            const double *b = boxes + (size_t)i * 4;
+            const double x2 = b[2] + b[0], y2 = b[3] + b[1];
+            s_x2[i] = x2; s_y2[i] = y2; s_area[i] = (x2 - b[0] + 1) * (y2 - b[1] + 1);
+            s_key[i] = scores ? scores[i] : y2; s_idx[i] = i;
+        } else { s_key[i] = INFINITY; s_idx[i] = 0x7fffffff; }                 // padding sorts behind every real entry
+    }
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += BLOCK) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const bool up = (i & k) == 0;
+                    const double ka = s_key[i], kb = s_key[p];
+                    const int ia = s_idx[i], ib = s_idx[p];
+                    const bool a_gt_b = ka > kb || (ka == kb && ia > ib);
+                    if (a_gt_b == up) { s_key[i] = kb; s_key[p] = ka; s_idx[i] = ib; s_idx[p] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < n; i += BLOCK) s_alive[i] = 1;
+    if (tid == 0) s_top = n - 1;
+    __syncthreads();
+    int np_ = 0;
+    for (;;) {
+        const int top = s_top;                                                // position (in the sorted order) of the pick
+        if (top < 0) break;
+        const int i = s_idx[top];
+        if (tid == 0) pick[np_] = i;
+        ++np_;
+        const double x1i = boxes[(size_t)i * 4], y1i = boxes[(size_t)i * 4 + 1], x2i = s_x2[i], y2i = s_y2[i];
+        for (int p = tid; p < top; p += BLOCK) {
+            if (!s_alive[p]) continue;
+            const int j = s_idx[p];
+            const double x1j = boxes[(size_t)j * 4], y1j = boxes[(size_t)j * 4 + 1];
+            const double xx1 = x1i > x1j ? x1i : x1j, yy1 = y1i > y1j ? y1i : y1j;
+            const double xx2 = x2i < s_x2[j] ? x2i : s_x2[j], yy2 = y2i < s_y2[j] ? y2i : s_y2[j];
+            double w = xx2 - xx1 + 1, h = yy2 - yy1 + 1;
+            w = w > 0 ? w : 0; h = h > 0 ? h : 0;
+            if ((w * h) / s_area[j] > thr) s_alive[p] = 0;
+        }
+        __syncthreads();
+        if (tid < WAVE) {                                                     // next pick: the highest position still alive below `top`
+            int nxt = -1;
+            for (int hi = top - 1; hi >= 0 && nxt < 0; hi -= WAVE) {
+                const int p = hi - tid;
+                const unsigned long long m = __ballot(p >= 0 && s_alive[p]);
+                if (m) nxt = hi - (__ffsll((long long)m) - 1);
+            }
+            if (tid == 0) s_top = nxt;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *n_pick = np_;
+}
+}  // namespace
+
+extern "C" int tlk_deepsort_nms_f64(const double *boxes_xywh_dev, const double *scores_dev, int n, double max_bbox_overlap, int32_t *pick_dev, int32_t *n_pick_dev,
+                                    void *hip_stream)
+{
+    if (n < 0 || !pick_dev || !n_pick_dev || (n > 0 && !boxes_xywh_dev)) return fail(TLK_EINVAL, "tlk_deepsort_nms_f64: bad argument");
+    if (n > NMS_MAX) return fail(TLK_ECAPACITY, "tlk_deepsort_nms_f64: at most 1024 boxes");
+    if (n == 0) { TLK_HIP(hipMemsetAsync(n_pick_dev, 0, sizeof(int32_t), (hipStream_t)hip_stream)); return TLK_OK; }
+    hipLaunchKernelGGL(deepsort_nms_kernel, dim3(1), dim3(BLOCK), 0, (hipStream_t)hip_stream, boxes_xywh_dev, scores_dev, n, max_bbox_overlap, pick_dev, n_pick_dev);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
