@@ -235,10 +235,9 @@ constexpr int STAGE_PAD = 32;           // bytes of slack per staged row (alignm
 __device__ __forceinline__ void stage_row(const unsigned char *__restrict__ g0, int len, unsigned char *lds, const unsigned char *gend,
                                           int tid, int nthreads)
 {
-    const uintptr_t a0 = (uintptr_t)g0 & ~(uintptr_t)15;
-    const int shift = (int)((uintptr_t)g0 - a0);
+    const int shift = (int)((uintptr_t)g0 & 15);
     const int chunks = (shift + len + 15) >> 4;
-    const unsigned char *src = (const unsigned char *)a0;
+    const unsigned char *src = g0 - shift;            // (pointer arithmetic: the loads stay global_load)
     for (int c = tid; c < chunks; c += nthreads) {
         const unsigned char *p = src + (size_t)c * 16;
         if (p + 16 <= gend) *reinterpret_cast<uint4 *>(lds + c * 16) = *reinterpret_cast<const uint4 *>(p);
@@ -293,10 +292,10 @@ __global__ void __launch_bounds__(BLOCK) crop_lds_kernel(const unsigned char *__
             for (int idx = tid; idx < nrows * cmax; idx += BLOCK) {
                 const int rr = idx / cmax, c = idx - rr * cmax;
                 const unsigned char *g0 = frames + ((size_t)b * H * W + (size_t)(t + r_lo + rr) * W + l) * 3;
-                const uintptr_t a0 = (uintptr_t)g0 & ~(uintptr_t)15;
-                const int chunks = ((int)((uintptr_t)g0 - a0) + cw * 3 + 15) >> 4;
+                const int mis = (int)((uintptr_t)g0 & 15);          // pointer ARITHMETIC keeps the global address space (an integer round trip makes the loads flat_load, which also count against lgkmcnt)
+                const int chunks = (mis + cw * 3 + 15) >> 4;
                 if (c < chunks) {
-                    const unsigned char *p = (const unsigned char *)a0 + (size_t)c * 16;
+                    const unsigned char *p = g0 - mis + (size_t)c * 16;
                     unsigned char *lds = s_rows + rr * CROP_LDS_ROW_BYTES + c * 16;
                     if (p + 16 <= gend) *reinterpret_cast<uint4 *>(lds) = *reinterpret_cast<const uint4 *>(p);
                     else for (int k = 0; k < 16 && p + k < gend; ++k) lds[k] = p[k];
@@ -519,10 +518,10 @@ __global__ void __launch_bounds__(BLOCK) crop_sep_kernel(const unsigned char *__
         const int c = tid & 31;
         for (int rr = tid >> 5; rr < par.nrows; rr += 8) {
             const unsigned char *g0 = frames + frame_off + ((size_t)(par.t + par.r_lo + rr) * W + par.l) * 3;
-            const uintptr_t a0 = (uintptr_t)g0 & ~(uintptr_t)15;
-            const int chunks = ((int)((uintptr_t)g0 - a0) + par.cw * 3 + 15) >> 4;
+            const int mis = (int)((uintptr_t)g0 & 15);          // pointer ARITHMETIC keeps the global address space (an integer round trip makes the loads flat_load, which also count against lgkmcnt)
+            const int chunks = (mis + par.cw * 3 + 15) >> 4;
             if (c < chunks) {
-                const unsigned char *p = (const unsigned char *)a0 + (size_t)c * 16;
+                const unsigned char *p = g0 - mis + (size_t)c * 16;
                 unsigned char *lds = s_rows + rr * CS_ROW_BYTES + c * 16;
                 if (p + 16 <= gend) *reinterpret_cast<uint4 *>(lds) = *reinterpret_cast<const uint4 *>(p);
                 else for (int k = 0; k < 16 && p + k < gend; ++k) lds[k] = p[k];
@@ -760,9 +759,9 @@ __global__ void __launch_bounds__(BLOCK) crop_fat_kernel(const unsigned char *__
             stage[j] = make_uint4(0, 0, 0, 0);
             if (rr < nrows_next) {
                 const unsigned char *g0 = frames + frame_off + ((size_t)(par.t + r_lo_next + rr) * W + par.l) * 3;
-                const uintptr_t a0 = (uintptr_t)g0 & ~(uintptr_t)15;
-                const int nchunks = ((int)((uintptr_t)g0 - a0) + par.cw * 3 + 15) >> 4;
-                const unsigned char *p = (const unsigned char *)a0 + (size_t)c16 * 16;
+                const int mis = (int)((uintptr_t)g0 & 15);          // pointer ARITHMETIC keeps the global address space (an integer round trip makes the loads flat_load, which also count against lgkmcnt)
+                const int nchunks = (mis + par.cw * 3 + 15) >> 4;
+                const unsigned char *p = g0 - mis + (size_t)c16 * 16;
                 if (c16 < nchunks) {
                     if (p + 16 <= gend) stage[j] = *reinterpret_cast<const uint4 *>(p);
                     else stage[j] = load16_clipped(p, gend);
@@ -1014,10 +1013,10 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
         for (int idx = tid; idx < nrows * cmax; idx += BLOCK) {                 // source rows of the band, one flat sweep
             const int rr = idx / cmax, c = idx - rr * cmax;
             const unsigned char *g0 = frames + ((size_t)b * H * W + (size_t)(y1 + r_lo + rr) * W + x1) * 3;
-            const uintptr_t a0 = (uintptr_t)g0 & ~(uintptr_t)15;
-            const int chunks = ((int)((uintptr_t)g0 - a0) + cw * 3 + 15) >> 4;
+            const int mis = (int)((uintptr_t)g0 & 15);          // pointer ARITHMETIC keeps the global address space (an integer round trip makes the loads flat_load, which also count against lgkmcnt)
+            const int chunks = (mis + cw * 3 + 15) >> 4;
             if (c < chunks) {
-                const unsigned char *p = (const unsigned char *)a0 + (size_t)c * 16;
+                const unsigned char *p = g0 - mis + (size_t)c * 16;
                 unsigned char *lds = s_rows + rr * PIL_ROW_BYTES + c * 16;
                 if (p + 16 <= gend) *reinterpret_cast<uint4 *>(lds) = *reinterpret_cast<const uint4 *>(p);
                 else for (int k = 0; k < 16 && p + k < gend; ++k) lds[k] = p[k];
@@ -1039,13 +1038,14 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
         const bool wide_h = ax.ksize > 3;                                       // (uniform: support > 1, i.e. the crop is wider than OW)
         for (int idx = tid; idx < nrows * OW; idx += BLOCK) {
             const int rr = idx / OW, x = idx - rr * OW;
-            const unsigned char *p = s_rows + rr * PIL_ROW_BYTES + (int)((a_lo + (unsigned)rr * row_step) & 15u) + s_hmin[x];
+            const int off = rr * PIL_ROW_BYTES + (int)((a_lo + (unsigned)rr * row_step) & 15u) + s_hmin[x];
             // 15 bytes from a byte-granular address: five ALIGNED dwords + v_alignbyte (an unaligned 16-byte LDS read is serialised per lane:
-            // 65 vs 17 LDS cycles per wavefront, tools/micro/lds_unaligned.hip)
+            // 65 vs 17 LDS cycles per wavefront, tools/micro/lds_unaligned.hip). The address stays an offset into s_rows: through a pointer ->
+            // integer -> pointer round trip the compiler loses the LDS address space and emits flat loads.
             unsigned w[4];
             {
-                const unsigned *q = reinterpret_cast<const unsigned *>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3);
-                const unsigned sh = (unsigned)reinterpret_cast<uintptr_t>(p) & 3u;
+                const unsigned *q = reinterpret_cast<const unsigned *>(s_rows + (off & ~3));
+                const unsigned sh = (unsigned)off & 3u;
                 const unsigned d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
                 w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh); w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
                 w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh); w[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
@@ -1214,10 +1214,10 @@ __global__ void __launch_bounds__(BLOCK) letterbox_lds_kernel(const unsigned cha
             if (idx >= total) return;
             const int j = idx / cmax, c = idx - j * cmax;
             const unsigned char *g0 = img + (size_t)s_src[j] * W * 3;
-            const uintptr_t a0 = (uintptr_t)g0 & ~(uintptr_t)15;
-            const int chunks = ((int)((uintptr_t)g0 - a0) + W * 3 + 15) >> 4;
+            const int mis = (int)((uintptr_t)g0 & 15);          // pointer ARITHMETIC keeps the global address space (an integer round trip makes the loads flat_load, which also count against lgkmcnt)
+            const int chunks = (mis + W * 3 + 15) >> 4;
             if (c >= chunks) return;
-            const unsigned char *p = (const unsigned char *)a0 + (size_t)c * 16;
+            const unsigned char *p = g0 - mis + (size_t)c * 16;
             const int d = s_dst[j] * row_bytes_lds + c * 16;
             if (p + 16 <= gend) { v = *reinterpret_cast<const uint4 *>(p); dst = d; }
             else for (int k = 0; k < 16 && p + k < gend; ++k) s_dyn[d + k] = p[k];
