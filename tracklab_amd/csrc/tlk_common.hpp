@@ -34,8 +34,7 @@ __device__ __forceinline__ double dmin_(double a, double b) { return a < b ? a :
 // Similarity of two xyxy boxes; same operation order as oc_sort/association.py:5-147 so that the
 // fp64 result is bit-identical to numpy's (compiled with -ffp-contract=off). TLK_CT returns the raw
 // centre distance; the matrix-wide rescale of association.py:169-171 is applied by the caller.
-template <typename APtr, typename BPtr>
-__device__ __forceinline__ double box_similarity(int variant, APtr a, BPtr b)      // (pointer types as given: LDS / global / generic)
+__device__ __forceinline__ double box_similarity(int variant, const double *a, const double *b)
 {
     if (variant == TLK_CT) {
         double cx1 = (a[0] + a[2]) / 2.0, cy1 = (a[1] + a[3]) / 2.0;

@@ -410,18 +410,12 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
         int n_mi = 0;
         if (T > 0 && N > 0) {
             const double PI = 3.141592653589793;
-            // LDS arrays through LDS-qualified pointers (via the generic members of the LDS struct every access -- the atomics too -- is a FLAT
-            // instruction that counts against vmcnt and lgkmcnt alike and serialises behind the global loads of the detection rows)
-            TLK_LDS const int *hi_l = (TLK_LDS const int *)L.hi_idx;
-            TLK_LDS const double *kobs_l = (TLK_LDS const double *)L.kobs, *tbox_l = (TLK_LDS const double *)L.trk_box, *velp_l = (TLK_LDS const double *)L.velp;
-            TLK_LDS int *rowcnt_l = (TLK_LDS int *)L.rowcnt, *colcnt_l = (TLK_LDS int *)L.colcnt, *rowhit_l = (TLK_LDS int *)L.rowhit;
-            auto fill = [&](auto costq) {
 #pragma unroll 4
             for (int e = tid; e < N * T; e += BLOCK) {
                 const int d = e / T, t = e - d * T;
-                const double *de = dets + (size_t)hi_l[d] * 7;
-                TLK_LDS const double *ko = kobs_l + t * 5;
-                const double iou = box_similarity(TLK_IOU, de, tbox_l + t * 4);
+                const double *de = dets + (size_t)L.hi_idx[d] * 7;
+                const double *ko = L.kobs + (size_t)t * 5;
+                const double iou = box_similarity(TLK_IOU, de, L.trk_box + (size_t)t * 4);
                 const double valid = ko[4] < 0 ? 0.0 : 1.0;
                 double adc = 0.0;       // ((valid*ang)*w)*cls is an exact (signed) zero when any factor is zero
                 if (valid != 0.0 && P.inertia != 0.0 && de[5] != 0.0) {
@@ -430,17 +424,15 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
                     double dx = cx1 - cx2, dy = cy1 - cy2;
                     const double norm = sqrt(dx * dx + dy * dy) + 1e-6;
                     dx = dx / norm; dy = dy / norm;
-                    double c = velp_l[t * 2 + 1] * dx + velp_l[t * 2] * dy;
+                    double c = L.velp[t * 2 + 1] * dx + L.velp[t * 2] * dy;
                     c = c < -1 ? -1 : (c > 1 ? 1 : c);
                     double ang = acos(c);
                     ang = (PI / 2.0 - fabs(ang)) / PI;
                     adc = ((valid * ang) * P.inertia) * de[5];              // "scores" = class column (dets[:, :-1][:, -1])
                 }
-                costq[e] = -(iou + adc);
-                if (iou > P.iou_threshold) { __hip_atomic_fetch_add(rowcnt_l + d, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_add(colcnt_l + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); rowhit_l[d] = t; }
+                cost[e] = -(iou + adc);
+                if (iou > P.iou_threshold) { atomicAdd(&L.rowcnt[d], 1); atomicAdd(&L.colcnt[t], 1); L.rowhit[d] = t; }
             }
-            };
-            if (cost == L.cost) fill((TLK_LDS double *)cost); else fill((TLK_GLOBAL double *)cost);
             __syncthreads();
             // a.sum(1).max() == 1 and a.sum(0).max() == 1
             int mx = 0;

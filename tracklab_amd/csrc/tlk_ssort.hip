@@ -235,39 +235,32 @@ ssort_assoc_kernel(SsDev Dv, SsP P, SsIn in, tlk_ssort_row *__restrict__ rows_al
     // (the flat (row, det) sweep re-read 20 doubles of global memory per entry: as in tlk_bpbss.hip, 70 -> 31 us for 110 x 98)
     {
         const int wv = tid >> 6, lane = tid & 63;
-        // LDS arrays through LDS-qualified pointers: via the generic BLds members every access is a flat_load / flat_store, which counts against
-        // vmcnt AND lgkmcnt -- the first of them drained the global prefetch of the next row's gate factors before the row had begun
-        TLK_LDS const int *sel_l = (TLK_LDS const int *)L.sel, *cand_l = (TLK_LDS const int *)L.cand;
-        TLK_LDS const double *dx_l = (TLK_LDS const double *)L.dxyah;
-        auto fill_rows = [&](auto cmq) {
         double gA[20];
         int r = wv;
         if (r < nc) {
-            const double *g = gl + (size_t)cand_l[r] * SGL;
+            const double *g = gl + (size_t)L.cand[r] * SGL;
 #pragma unroll
             for (int q = 0; q < 20; ++q) gA[q] = g[q];
         }
         for (; r < nc; r += NWAVES) {
-            const int p = cand_l[r];
+            const int p = L.cand[r];
             double gB[20];
             const int rn = r + NWAVES;
             if (rn < nc) {
-                const double *g = gl + (size_t)cand_l[rn] * SGL;
+                const double *g = gl + (size_t)L.cand[rn] * SGL;
 #pragma unroll
                 for (int q = 0; q < 20; ++q) gB[q] = g[q];
             }
             for (int j = lane; j < N; j += WAVE) {
-                double c = reid[(size_t)p * MAXD + sel_l[j]];
-                const double gd = gating_reg<4>(gA, dx_l + j * 4);
+                double c = reid[(size_t)p * MAXD + L.sel[j]];
+                const double gd = gating_reg<4>(gA, L.dxyah + j * 4);
                 if (gd > CHI2_4) c = INFTY_COST;
                 c = P.mc_lambda * c + (1 - P.mc_lambda) * gd;
-                cmq[(unsigned)(r * N + j)] = c > P.max_dist ? P.max_dist + 1e-5 : c;
+                cm[(size_t)r * N + j] = c > P.max_dist ? P.max_dist + 1e-5 : c;
             }
 #pragma unroll
             for (int q = 0; q < 20; ++q) gA[q] = gB[q];
         }
-        };
-        if (cm == L.cost) fill_rows((TLK_LDS double *)cm); else fill_rows((TLK_GLOBAL double *)cm);
     }
     for (int j = tid; j < N; j += BLOCK) L.um_db[j] = j;
     __syncthreads();

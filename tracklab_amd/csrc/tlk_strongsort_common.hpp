@@ -133,8 +133,8 @@ __device__ __forceinline__ double gating_from(const double *glrow, const double 
 }
 
 // the same with the track's gate row in registers (fully unrolled: no dynamic indexing, same operation order)
-template <int DIM, typename MPtr>
-__device__ __forceinline__ double gating_reg(const double (&g)[20], MPtr m)
+template <int DIM>
+__device__ __forceinline__ double gating_reg(const double (&g)[20], const double *m)
 {
     double zz[DIM], acc = 0;
 #pragma unroll
