@@ -680,187 +680,6 @@ __device__ __noinline__ void crop_direct_unit(const unsigned char *__restrict__ 
         }
 }
 
-// Fast-path prefetch of a band's source rows into three registers per thread (lane = 16-byte chunk of a row; rows rsub, rsub + 8, rsub + 16).
-// The loads are unconditional -- lanes past the row's chunks and rows past the band re-read chunk 0 of the band's first row, which is never
-// written to LDS -- so no divergent region surrounds them and nothing forces a wait before the data is needed.
-__device__ __forceinline__ void crop_fat_fetch_fast(const unsigned char *__restrict__ row0, int W, int cw, int nrows, int rsub, int c16, uint4 &s0, uint4 &s1, uint4 &s2)
-{
-    auto one = [&](int rr) {
-        const unsigned char *g0 = row0 + (size_t)(rr < nrows ? rr : 0) * W * 3;
-        const int mis = (int)((uintptr_t)g0 & 15);
-        const int nchunks = (mis + cw * 3 + 15) >> 4;
-        return *reinterpret_cast<const uint4 *>(g0 - mis + (size_t)(c16 < nchunks ? c16 : 0) * 16);
-    };
-    s0 = one(rsub); s1 = one(rsub + 8); s2 = one(rsub + 16);
-}
-
-// The band loop of crop_fat_kernel. FAST: every band of the chunk is staged and no load can touch the end of the frame buffer -- the loop then
-// contains NO function call, so the compiler's s_waitcnt placement is exact: the next band's loads are issued right after the horizontal pass and
-// the wait at the next band's LDS write counts only the three output stores issued after them (vmcnt(3)). With the rare paths (clipped loads,
-// direct sampling: __noinline__ calls) inside the same loop, every iteration began with s_waitcnt vmcnt(0): the prefetch waited for the previous
-// band's output stores to drain and 70 % of a workgroup's time was load latency + barrier (phase timers, profiles/r02_crop_fat_phases.txt).
-template <typename T> struct FatCtx {
-    const unsigned char *frames, *gend; size_t frame_off, slot; int W, OH, band0, nbands, valid, swap_rb; CropPar par;
-    unsigned char *s_rows; unsigned short *s_h; const int2 *s_xc; const T *s_lut; const int *s_y; int *s_rsh;
-    T *out; float m0, m1, m2, d0, d1, d2;
-};
-template <typename T, int LAYOUT, bool FAST>
-__device__ __forceinline__ void crop_fat_bands(const FatCtx<T> &C)
-{
-    constexpr int OW = 128, HS = OW * 3, GROUPS = OW / 8;
-    const int tid = threadIdx.x;
-    const unsigned char *frames = C.frames, *gend = C.gend;
-    const size_t frame_off = C.frame_off, slot = C.slot;
-    const int W = C.W, OH = C.OH, band0 = C.band0, nbands = C.nbands, swap_rb = C.swap_rb;
-    const bool valid = C.valid != 0;
-    const CropPar par = C.par;
-    unsigned char *s_rows = C.s_rows; unsigned short *s_h = C.s_h; const int2 *s_xc = C.s_xc; const T *s_lut = C.s_lut; const int *s_y = C.s_y; int *s_rsh = C.s_rsh;
-    T *out = C.out;
-    const float m0 = C.m0, m1 = C.m1, m2 = C.m2, d0 = C.d0, d1 = C.d1, d2 = C.d2;
-    const int c16 = tid & 31, rsub = tid >> 5;
-    uint4 stage[3];                                       // (slow path)
-    uint4 st0 = make_uint4(0, 0, 0, 0), st1 = st0, st2 = st0;  // (fast path: named registers)
-    int r_lo_next = 0, nrows_next = 0;
-    bool staged_next = false;
-    // source rows of band kb -> registers (lane = 16-byte chunk of a row, rows rsub, rsub + 8, rsub + 16)
-    auto fetch = [&](int kb) {
-        const int row_first = kb * CS_BAND, row_last = min(kb * CS_BAND + CS_BAND, OH - band0 * CS_BAND) - 1;
-        r_lo_next = s_y[row_first * 2] & 0xffff;
-        nrows_next = (int)((unsigned int)s_y[row_last * 2] >> 16) - r_lo_next + 1;
-        staged_next = FAST || (par.staged && nrows_next <= CS_ROWS);
-        if (!staged_next) return;
-        if (FAST) { crop_fat_fetch_fast(frames + frame_off + ((size_t)(par.t + r_lo_next) * W + par.l) * 3, W, par.cw, nrows_next, rsub, c16, st0, st1, st2); return; }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int rr = rsub + 8 * j;
-            stage[j] = make_uint4(0, 0, 0, 0);
-            if (rr < nrows_next) {
-                const unsigned char *g0 = frames + frame_off + ((size_t)(par.t + r_lo_next + rr) * W + par.l) * 3;
-                const int mis = (int)((uintptr_t)g0 & 15);          // pointer ARITHMETIC keeps the global address space (an integer round trip makes the loads flat_load, which also count against lgkmcnt)
-                const int nchunks = (mis + par.cw * 3 + 15) >> 4;
-                const unsigned char *p = g0 - mis + (size_t)c16 * 16;
-                if (c16 < nchunks) {
-                    if (FAST || p + 16 <= gend) stage[j] = *reinterpret_cast<const uint4 *>(p);
-                    else stage[j] = load16_clipped(p, gend);
-                }
-            }
-        }
-    };
-    // the prefetched rows of a band (registers) -> LDS, + the alignment shift of every staged row
-    auto write_stage_fast = [&](int r_lo_w, int nrows_w) {
-        if (rsub < nrows_w) *reinterpret_cast<uint4 *>(s_rows + rsub * CS_ROW_BYTES + c16 * 16) = st0;
-        if (rsub + 8 < nrows_w) *reinterpret_cast<uint4 *>(s_rows + (rsub + 8) * CS_ROW_BYTES + c16 * 16) = st1;
-        if (rsub + 16 < nrows_w) *reinterpret_cast<uint4 *>(s_rows + (rsub + 16) * CS_ROW_BYTES + c16 * 16) = st2;
-        if (tid < nrows_w) s_rsh[tid] = (int)((uintptr_t)(frames + frame_off + ((size_t)(par.t + r_lo_w + tid) * W + par.l) * 3) & 15);
-    };
-    if (valid) fetch(0);
-    if (FAST) { write_stage_fast(r_lo_next, nrows_next); __syncthreads(); }
-    for (int kb = 0; kb < nbands; ++kb) {
-        const int y_base = (band0 + kb) * CS_BAND, nb = min(CS_BAND, OH - y_base);
-        const int r_lo = r_lo_next, nrows = nrows_next;
-        const bool staged = FAST || (valid && staged_next);
-        // FAST: the loop is rotated -- band kb's rows were written to LDS at the end of the previous iteration (the prologue for kb = 0), so that
-        // the wait for the prefetch sits in straight-line code after this band's output stores and is exact (vmcnt(3)); at the loop head the
-        // compiler's merge of the entry and back-edge counter states would turn it into vmcnt(0), draining the stores every band
-        if (!FAST) {
-            if (staged) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int rr = rsub + 8 * j;
-                    if (rr < nrows) *reinterpret_cast<uint4 *>(s_rows + rr * CS_ROW_BYTES + c16 * 16) = stage[j];
-                }
-                if (tid < nrows) s_rsh[tid] = (int)((uintptr_t)(frames + frame_off + ((size_t)(par.t + r_lo + tid) * W + par.l) * 3) & 15);
-            }
-            __syncthreads();
-        }
-        if (staged) {                                   // horizontal pass: thread = one x, every second staged row
-            const int x = tid & 127;
-            const int2 xc = s_xc[x];
-            const int o0 = xc.x & 0xffff, o1 = o0 + (xc.x >> 16);
-            const us2_t A = __builtin_bit_cast(us2_t, xc.y);
-            for (int rr = tid >> 7; rr < nrows; rr += 2) {
-                const unsigned char *p = s_rows + rr * CS_ROW_BYTES + s_rsh[rr];
-                unsigned short *o = s_h + rr * HS + x * 3;
-#pragma unroll
-                for (int c3 = 0; c3 < 3; ++c3) {
-                    const unsigned int P = (unsigned int)p[o0 + c3] | ((unsigned int)p[o1 + c3] << 16);
-                    o[c3] = (unsigned short)(__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, P), A, 0u, false) >> 4);
-                }
-            }
-        }
-        __syncthreads();
-        if (valid && kb + 1 < nbands) fetch(kb + 1);    // in flight during the vertical pass
-        const int ry = tid >> 4, x_base = (tid & (GROUPS - 1)) * 8;
-        const int y = y_base + ry;
-        if (!FAST && ry < nb && !staged) {
-            // crops too tall / wide for the staged path: direct sampling (mean / std per SOURCE channel were swapped on the host for swap_rb)
-            if (valid) crop_direct_unit<T, LAYOUT>(frames + frame_off + ((size_t)par.t * W + par.l) * 3, W, par.ch, par.cw, OH, OW, y, x_base, m0, m1, m2, d0, d1, d2,
-                                                   swap_rb, out, (size_t)slot);
-            else {
-                for (int k = 0; k < 8; ++k)
-                    for (int c = 0; c < 3; ++c) {
-                        if (LAYOUT == LAYOUT_NCHW) out[(((size_t)slot * 3 + c) * OH + y) * OW + x_base + k] = cvt<T>(0.f);
-                        else out[(((size_t)slot * OH + y) * OW + x_base + k) * 3 + c] = cvt<T>(0.f);
-                    }
-            }
-        } else if (ry < nb) {
-            T px[8][3];
-            {
-                const int row = kb * CS_BAND + ry;
-                const unsigned int yi = (unsigned int)s_y[row * 2], yw = (unsigned int)s_y[row * 2 + 1];
-                const uint4 *h0 = reinterpret_cast<const uint4 *>(s_h + ((yi & 0xffffu) - r_lo) * HS + x_base * 3);
-                const uint4 *h1 = reinterpret_cast<const uint4 *>(s_h + ((yi >> 16) - r_lo) * HS + x_base * 3);
-                const unsigned int b0 = yw & 0xffffu, b1 = yw >> 16;
-                unsigned int w0[12], w1[12];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const uint4 u = h0[k], v = h1[k];
-                    w0[k * 4] = u.x; w0[k * 4 + 1] = u.y; w0[k * 4 + 2] = u.z; w0[k * 4 + 3] = u.w;
-                    w1[k * 4] = v.x; w1[k * 4 + 1] = v.y; w1[k * 4 + 2] = v.z; w1[k * 4 + 3] = v.w;
-                }
-#pragma unroll
-                for (int q = 0; q < 24; ++q) {
-                    const unsigned int a = (q & 1) ? (w0[q >> 1] >> 16) : (w0[q >> 1] & 0xffffu);
-                    const unsigned int c1 = (q & 1) ? (w1[q >> 1] >> 16) : (w1[q >> 1] & 0xffffu);
-                    const unsigned int xa = __umul24(b0, a), xb = __umul24(b1, c1);
-                    unsigned int t;                     // t <= 1020 always (see crop_sep_kernel)
-                    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t) : "v"(xa), "v"(xb));
-                    px[q / 3][q % 3] = s_lut[(q % 3) * CS_LUT_N + t];
-                }
-            }
-            if (swap_rb) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { const T t0 = px[k][0]; px[k][0] = px[k][2]; px[k][2] = t0; }
-            }
-            // FAST: the next band's prefetched rows go to LDS HERE -- after this band's arithmetic (the loads had that long to arrive), BEFORE its
-            // output stores: reads and writes of a wavefront complete out of order with respect to each other, so a wait for loads that has stores
-            // issued after them is satisfied only when some of those stores have completed too (the compiler emits vmcnt(<= 2)); with the stores
-            // issued afterwards only the previous band's -- a whole iteration old -- are in the way. (Every band that has a successor has all 16
-            // rows: all threads are here.)
-            if (FAST && kb + 1 < nbands) write_stage_fast(r_lo_next, nrows_next);
-            if (LAYOUT == LAYOUT_NCHW) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    Pack<T, 8> p;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) p.v[k] = px[k][c];
-                    *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)slot * 3 + c) * OH + y) * OW + x_base) = p;
-                }
-            } else {
-                T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    Pack<T, 8> p;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
-                    *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
-                }
-            }
-        }
-        if (FAST && kb + 1 < nbands) __syncthreads();       // next band's rows are in LDS (written inside the vertical pass, below); also separates this vertical pass from the next horizontal pass
-    }
-}
-
 template <typename T, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK) crop_fat_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
                                                          const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
@@ -923,24 +742,128 @@ __global__ void __launch_bounds__(BLOCK) crop_fat_kernel(const unsigned char *__
     const CropPar par = s_par;
     const bool valid = par.valid != 0;
     const unsigned char *gend = frames + (size_t)B * H * W * 3;
-    // rare cases leave the fast loop: an invalid / too wide crop, a band with more source rows than the staging area, loads that could touch the
-    // end of the frame buffer (the last rows of the last frame)
-    int slow = !valid || !par.staged;
-    if (!slow) {
-        if (tid < nbands) {
-            const int row_first = tid * CS_BAND, row_last = min(tid * CS_BAND + CS_BAND, OH - band0 * CS_BAND) - 1;
-            slow = (int)((unsigned int)s_y[row_last * 2] >> 16) - (s_y[row_first * 2] & 0xffff) + 1 > CS_ROWS;
+    const int c16 = tid & 31, rsub = tid >> 5;
+    uint4 stage[3];
+    int r_lo_next = 0, nrows_next = 0;
+    bool staged_next = false;
+    // source rows of band kb -> registers (lane = 16-byte chunk of a row, rows rsub, rsub + 8, rsub + 16)
+    auto fetch = [&](int kb) {
+        const int row_first = kb * CS_BAND, row_last = min(kb * CS_BAND + CS_BAND, OH - band0 * CS_BAND) - 1;
+        r_lo_next = s_y[row_first * 2] & 0xffff;
+        nrows_next = (int)((unsigned int)s_y[row_last * 2] >> 16) - r_lo_next + 1;
+        staged_next = par.staged && nrows_next <= CS_ROWS;
+        if (!staged_next) return;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int rr = rsub + 8 * j;
+            stage[j] = make_uint4(0, 0, 0, 0);
+            if (rr < nrows_next) {
+                const unsigned char *g0 = frames + frame_off + ((size_t)(par.t + r_lo_next + rr) * W + par.l) * 3;
+                const int mis = (int)((uintptr_t)g0 & 15);          // pointer ARITHMETIC keeps the global address space (an integer round trip makes the loads flat_load, which also count against lgkmcnt)
+                const int nchunks = (mis + par.cw * 3 + 15) >> 4;
+                const unsigned char *p = g0 - mis + (size_t)c16 * 16;
+                if (c16 < nchunks) {
+                    if (p + 16 <= gend) stage[j] = *reinterpret_cast<const uint4 *>(p);
+                    else stage[j] = load16_clipped(p, gend);
+                }
+            }
         }
-        slow |= frames + frame_off + ((size_t)(par.t + par.ch - 1) * W + par.l) * 3 + 34 * 16 > gend;
+    };
+    if (valid) fetch(0);
+    for (int kb = 0; kb < nbands; ++kb) {
+        const int y_base = (band0 + kb) * CS_BAND, nb = min(CS_BAND, OH - y_base);
+        const int r_lo = r_lo_next, nrows = nrows_next;
+        const bool staged = valid && staged_next;
+        if (staged) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int rr = rsub + 8 * j;
+                if (rr < nrows) *reinterpret_cast<uint4 *>(s_rows + rr * CS_ROW_BYTES + c16 * 16) = stage[j];
+            }
+            if (tid < nrows) s_rsh[tid] = (int)((uintptr_t)(frames + frame_off + ((size_t)(par.t + r_lo + tid) * W + par.l) * 3) & 15);
+        }
+        __syncthreads();
+        if (staged) {                                   // horizontal pass: thread = one x, every second staged row
+            const int x = tid & 127;
+            const int2 xc = s_xc[x];
+            const int o0 = xc.x & 0xffff, o1 = o0 + (xc.x >> 16);
+            const us2_t A = __builtin_bit_cast(us2_t, xc.y);
+            for (int rr = tid >> 7; rr < nrows; rr += 2) {
+                const unsigned char *p = s_rows + rr * CS_ROW_BYTES + s_rsh[rr];
+                unsigned short *o = s_h + rr * HS + x * 3;
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    const unsigned int P = (unsigned int)p[o0 + c3] | ((unsigned int)p[o1 + c3] << 16);
+                    o[c3] = (unsigned short)(__builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, P), A, 0u, false) >> 4);
+                }
+            }
+        }
+        __syncthreads();
+        if (valid && kb + 1 < nbands) fetch(kb + 1);    // in flight during the vertical pass
+        const int ry = tid >> 4, x_base = (tid & (GROUPS - 1)) * 8;
+        const int y = y_base + ry;
+        if (ry < nb && !staged) {
+            // crops too tall / wide for the staged path: direct sampling (mean / std per SOURCE channel were swapped on the host for swap_rb)
+            if (valid) crop_direct_unit<T, LAYOUT>(frames + frame_off + ((size_t)par.t * W + par.l) * 3, W, par.ch, par.cw, OH, OW, y, x_base, m0, m1, m2, d0, d1, d2,
+                                                   swap_rb, out, (size_t)slot);
+            else {
+                for (int k = 0; k < 8; ++k)
+                    for (int c = 0; c < 3; ++c) {
+                        if (LAYOUT == LAYOUT_NCHW) out[(((size_t)slot * 3 + c) * OH + y) * OW + x_base + k] = cvt<T>(0.f);
+                        else out[(((size_t)slot * OH + y) * OW + x_base + k) * 3 + c] = cvt<T>(0.f);
+                    }
+            }
+        } else if (ry < nb) {
+            T px[8][3];
+            {
+                const int row = kb * CS_BAND + ry;
+                const unsigned int yi = (unsigned int)s_y[row * 2], yw = (unsigned int)s_y[row * 2 + 1];
+                const uint4 *h0 = reinterpret_cast<const uint4 *>(s_h + ((yi & 0xffffu) - r_lo) * HS + x_base * 3);
+                const uint4 *h1 = reinterpret_cast<const uint4 *>(s_h + ((yi >> 16) - r_lo) * HS + x_base * 3);
+                const unsigned int b0 = yw & 0xffffu, b1 = yw >> 16;
+                unsigned int w0[12], w1[12];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const uint4 u = h0[k], v = h1[k];
+                    w0[k * 4] = u.x; w0[k * 4 + 1] = u.y; w0[k * 4 + 2] = u.z; w0[k * 4 + 3] = u.w;
+                    w1[k * 4] = v.x; w1[k * 4 + 1] = v.y; w1[k * 4 + 2] = v.z; w1[k * 4 + 3] = v.w;
+                }
+#pragma unroll
+                for (int q = 0; q < 24; ++q) {
+                    const unsigned int a = (q & 1) ? (w0[q >> 1] >> 16) : (w0[q >> 1] & 0xffffu);
+                    const unsigned int c1 = (q & 1) ? (w1[q >> 1] >> 16) : (w1[q >> 1] & 0xffffu);
+                    const unsigned int xa = __umul24(b0, a), xb = __umul24(b1, c1);
+                    unsigned int t;                     // t <= 1020 always (see crop_sep_kernel)
+                    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t) : "v"(xa), "v"(xb));
+                    px[q / 3][q % 3] = s_lut[(q % 3) * CS_LUT_N + t];
+                }
+            }
+            if (swap_rb) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const T t0 = px[k][0]; px[k][0] = px[k][2]; px[k][2] = t0; }
+            }
+            if (LAYOUT == LAYOUT_NCHW) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    Pack<T, 8> p;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) p.v[k] = px[k][c];
+                    *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)slot * 3 + c) * OH + y) * OW + x_base) = p;
+                }
+            } else {
+                T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    Pack<T, 8> p;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
+                    *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+                }
+            }
+        }
     }
-    slow = __syncthreads_or(slow);
-    FatCtx<T> C;
-    C.frames = frames; C.gend = gend; C.frame_off = frame_off; C.slot = (size_t)slot; C.W = W; C.OH = OH; C.band0 = band0; C.nbands = nbands;
-    C.valid = valid; C.swap_rb = swap_rb; C.par = par; C.s_rows = s_rows; C.s_h = s_h; C.s_xc = s_xc; C.s_lut = s_lut; C.s_y = s_y; C.s_rsh = s_rsh;
-    C.out = out; C.m0 = m0; C.m1 = m1; C.m2 = m2; C.d0 = d0; C.d1 = d1; C.d2 = d2;
-    if (slow) crop_fat_bands<T, LAYOUT, false>(C);         // (inlined, in its own branch: as a separate function it would be free to take 250 VGPRs, which count for the kernel)
-    else crop_fat_bands<T, LAYOUT, true>(C);
 }
+
 // ---------------------------------------------------------------------------------------------
 // Plain StrongSORT's ReID input: crop ori_img[y1:y2, x1:x2] of the int-truncated, clipped box
 // (strong_sort.py:102-108, :135-141) -> Pillow Image.resize(BILINEAR) -> ToTensor -> Normalize
