@@ -1600,7 +1600,7 @@ __global__ void __launch_bounds__(BLOCK) letterbox_lds_kernel(const unsigned cha
         uint4 *gout = reinterpret_cast<uint4 *>(out + ((size_t)b * S2 + y_base / 2) * S2 * 12);
         for (int c = tid; c < units_total * 6; c += BLOCK) {
             const int u = c / 6, piece = c - u * 6;
-            stream_store(gout + c, *reinterpret_cast<const uint4 *>(s_out + u * OUT_STRIDE_W + piece * 4));       // whole cache lines: streaming store
+            gout[c] = *reinterpret_cast<const uint4 *>(s_out + u * OUT_STRIDE_W + piece * 4);       // (the streaming hint makes no difference here: 56 us either way)
         }
     }
 }
