@@ -215,3 +215,16 @@ def test_swap_rb_reads_the_frame_as_bgr(layout):
         pa, ma = _lib.pose_crop_warp_norm(d, xyxy, counts, 192, 256, layout, dtype, swap_rb=True)
         pb, mb = _lib.pose_crop_warp_norm(dflip, xyxy, counts, 192, 256, layout, dtype)
         assert torch.equal(pa, pb) and torch.equal(ma, mb)
+
+
+@pytest.mark.parametrize("env", [{"TLK_CROP_WAVE": "0"}, {"TLK_CROP_WAVE": "0", "TLK_CROP_FAT": "0"}, {"TLK_CROP_WAVE": "0", "TLK_CROP_FAT": "0", "TLK_CROP_KERNEL": "1"}],
+                         ids=["crop_fat_kernel", "crop_sep_kernel", "crop_lds_kernel"])
+def test_the_older_crop_kernels_stay_bit_exact(env):
+    """crop_wave_kernel is the default for 128-wide targets; the kernels it replaced stay selectable for A/B runs (the switches are read once per
+    process, hence the subprocess) and must keep producing the oracle's bits."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_image.py"), "-m", "gpu", "-q", "-x", "-k", "test_crop_resize_norm_matches_oracle and 128"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
