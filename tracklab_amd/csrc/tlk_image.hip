@@ -1626,7 +1626,7 @@ __global__ void __launch_bounds__(BLOCK) yolox_decode_nms_kernel(const float *__
     __shared__ float barea[NMS_CAP];
     __shared__ unsigned long long alive[NMS_CAP / 64];
     __shared__ int s_scan[NWAVES];
-    __shared__ int s_n, s_out, s_err;
+    __shared__ int s_out, s_err;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int n8 = (S / 8) * (S / 8), n16 = (S / 16) * (S / 16), n32 = (S / 32) * (S / 32);
     const int A = n8 + n16 + n32, F = 5 + C;
