@@ -52,3 +52,39 @@ def test_capacity_errors_are_loud():
     with pytest.raises(RuntimeError):
         t.append_step(0, 1, 0, 4, np.zeros((1, 4, 4), np.float32), np.array([-4], np.int32),
                       (np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0), np.zeros((0, 4)), np.zeros(0)))
+
+
+def test_tracking_engine_decodes_ahead_in_order_with_worker_threads():
+    """HipTrackingEngine._decode_ahead: frames come back in video order, several decodes are in flight at once, and no more than the window runs ahead."""
+    import threading
+    import time
+    from types import SimpleNamespace
+    from tracklab_amd.engine import HipTrackingEngine
+    eng = HipTrackingEngine.__new__(HipTrackingEngine)                    # host logic only: no pipeline, no device
+    eng.video_engine = SimpleNamespace(F=4)
+    lock, state = threading.Lock(), {"live": 0, "peak": 0, "started": 0}
+
+    def loader(p):
+        with lock:
+            state["live"] += 1; state["started"] += 1
+            state["peak"] = max(state["peak"], state["live"])
+        time.sleep(0.01 * (1 + int(p) % 3))                               # uneven decode times: completion order != submission order
+        with lock:
+            state["live"] -= 1
+        return int(p)
+    eng.image_loader = loader
+    paths = [str(k) for k in range(40)]
+    for workers in (0, 4):
+        eng.num_workers = workers
+        state.update(live=0, peak=0, started=0)
+        got, ahead = [], 0
+        for k, v in enumerate(eng._decode_ahead(paths)):
+            got.append(v)
+            ahead = max(ahead, state["started"] - (k + 1))
+        assert got == list(range(40))
+        if workers:
+            assert 2 <= state["peak"] <= workers and ahead <= max(2 * 4, workers)
+        else:
+            assert state["peak"] == 1 and ahead == 0
+    eng.num_workers = 4
+    assert list(eng._decode_ahead([])) == []

@@ -122,3 +122,36 @@ def test_gpu_clearmot_on_a_tracked_stream_and_edge_cases(orc):
                                       ([], np.zeros((0, 4)), [7], np.array([[0., 0, 10, 10]])), ([1], np.array([[0., 0, 10, 10]]), [7], np.array([[100., 100, 10, 10]]))])
     assert (e["num_frames"], e["num_misses"], e["num_false_positives"], e["num_matches"]) == (4, 3, 2, 0)
     assert clearmot.finalize(e)["idf1"] == 0.0
+
+
+def test_evaluate_folders_on_the_device_equals_the_host_path(tmp_path):
+    """python -m tracklab_amd.evaluate --gpu: MOT files -> HOTA + CLEAR-MOT / ID measures with both evaluators on the device, per sequence and
+    combined, equal to the host path (counts exactly, HOTA's sums to 1e-12)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    from test_evaluate import _write
+    from tracklab_amd import evaluate
+    gt_dir, pr_dir = tmp_path / "gt", tmp_path / "pred"
+    gt_dir.mkdir(); pr_dir.mkdir()
+    rng = np.random.default_rng(1)
+    for name, nobj, nfr in (("a", 12, 40), ("b", 30, 25)):
+        base = rng.uniform(100, 1500, (nobj, 2))
+        frames = [[(i + 1, (base[i, 0] + 4 * f, base[i, 1] + 2 * f, 60.0, 140.0)) for i in range(nobj)] for f in range(nfr)]
+        _write(gt_dir / f"{name}.txt", frames)
+        pred = [[(tid + (100 if (f >= nfr // 2 and tid % 5 == 0) else 0), (l + rng.normal(0, 6), t + rng.normal(0, 6), w, h)) for tid, (l, t, w, h) in rows if rng.random() > 0.1]
+                for f, rows in enumerate(frames)]
+        _write(pr_dir / f"{name}.txt", pred)
+    cpu = evaluate.evaluate_folders(str(gt_dir), str(pr_dir))
+    gpu = evaluate.evaluate_folders(str(gt_dir), str(pr_dir), device="gpu")
+    assert cpu["combined"]["num_switches"] > 0 and cpu["combined"]["num_misses"] > 0
+    for scope in ("a", "b"):
+        for k, v in cpu["sequences"][scope].items():
+            assert abs(gpu["sequences"][scope][k] - v) <= 1e-12 * max(1.0, abs(v)) or (np.isnan(v) and np.isnan(gpu["sequences"][scope][k])), (scope, k)
+    for k, v in cpu["combined"].items():
+        assert abs(gpu["combined"][k] - v) <= 1e-12 * max(1.0, abs(v)), k
+    out = subprocess.run([sys.executable, "-m", "tracklab_amd.evaluate", str(gt_dir), str(pr_dir), "--gpu"], capture_output=True, text=True, cwd=REPO,
+                         env=dict(os.environ, PYTHONPATH=REPO))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert abs(json.loads(out.stdout)["combined"]["HOTA"] - cpu["combined"]["HOTA"]) < 1e-12

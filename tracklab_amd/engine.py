@@ -291,7 +291,7 @@ class HipTrackingEngine(_EngineBase):
         after = [c for c in cbs if getattr(c, "after_saved_state", False)]
         self.fabric = _CallbackList(before + ([tracker_state] if tracker_state is not None else []) + after)
         self.callback = lambda name, **kw: self.fabric.call(name, engine=self, **kw)
-        self.num_workers = num_workers
+        self.num_workers = int(num_workers) if isinstance(num_workers, (int, float)) or str(num_workers).lstrip("-").isdigit() else 0
         self.tracker_state = tracker_state
         self.img_metadatas = getattr(tracker_state, "image_metadatas", None)
         self.video_metadatas = getattr(tracker_state, "video_metadatas", None)
@@ -308,6 +308,31 @@ class HipTrackingEngine(_EngineBase):
     def _load_rgb(path):
         from PIL import Image
         return np.asarray(Image.open(path).convert("RGB"))
+
+    def _decode_ahead(self, paths):
+        """The frames of a video in order, decoded by ``num_workers`` threads up to two steps ahead of the GPU (the role of the reference
+        engines' DataLoader workers, engine/engine.py:128-146: image decoding releases the GIL, so threads suffice and no frame is pickled
+        between processes). num_workers <= 0: decode in line."""
+        if self.num_workers <= 0 or len(paths) == 0:
+            for p in paths:
+                yield self.image_loader(p)
+            return
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        depth = max(2 * self.video_engine.F, self.num_workers)
+        with ThreadPoolExecutor(max_workers=self.num_workers) as pool:
+            pending = deque()
+            it = iter(paths)
+            for p in it:
+                pending.append(pool.submit(self.image_loader, p))
+                if len(pending) >= depth:
+                    break
+            while pending:
+                img = pending.popleft().result()
+                nxt = next(it, None)
+                if nxt is not None:
+                    pending.append(pool.submit(self.image_loader, nxt))
+                yield img
 
     def track_dataset(self):
         """engine/engine.py:105-126."""
@@ -328,10 +353,10 @@ class HipTrackingEngine(_EngineBase):
         F = self.video_engine.F
 
         def frames():
-            for j, p in enumerate(paths):
+            for j, img in enumerate(self._decode_ahead(paths)):
                 if j % F == 0:
                     self.callback("on_module_step_start", task="hip_fused_pipeline", batch=(image_ids[j:j + F], None))
-                yield self.image_loader(p)
+                yield img
 
         def on_step(df):
             df = df.assign(image_id=image_ids[df.image_id.to_numpy()])

@@ -4,7 +4,7 @@ and combined the way the two libraries combine them (sums of sufficient statisti
 all-reduces. Mirrors what tracklab/wrappers/eval/trackeval_evaluator.py does with pip `trackeval` on the files
 TrackingDataset.save_for_eval wrote: here the rows can also come straight from tables.
 
-    python -m tracklab_amd.evaluate GT_DIR PRED_DIR        # <name>.txt in both; prints one JSON object
+    python -m tracklab_amd.evaluate GT_DIR PRED_DIR [--gpu]     # <name>.txt in both; prints one JSON object; --gpu: both evaluators on the device
 """
 from __future__ import annotations
 
@@ -29,23 +29,33 @@ def _by_frame(rows: dict):
     return out
 
 
-def evaluate_sequence(gt: dict, pred: dict, n_frames: int | None = None, max_iou: float = 0.5) -> dict:
+def evaluate_sequence(gt: dict, pred: dict, n_frames: int | None = None, max_iou: float = 0.5, device: str = "cpu") -> dict:
     """gt / pred: dicts with 'frame' (1-based), 'track_id', 'ltwh' arrays (what mot_io.load_mot returns).
-    -> {'hota': packed HOTA statistics, 'clear': CLEAR-MOT / ID counts} of this sequence (summable across sequences)."""
+    -> {'hota': packed HOTA statistics, 'clear': CLEAR-MOT / ID counts} of this sequence (summable across sequences).
+    device "gpu": both evaluators run on the MI355X (tlk_hota_sequence_f64, tlk_clear_sequence_f64; at most 512 boxes per frame and side) --
+    same statistics (HOTA's floating-point sums to ~1e-15, every count exactly); there is no silent fall-back to the host path."""
+    if device not in ("cpu", "gpu"):
+        raise ValueError(f"evaluate_sequence: device must be 'cpu' or 'gpu', not {device!r}")
     g, p = _by_frame(gt), _by_frame(pred)
     last = n_frames if n_frames is not None else max([0] + list(g) + list(p))
     empty = (np.zeros(0, np.int64), np.zeros((0, 4)))
     acc = clearmot.MOTAccumulator()
-    gt_fr, pr_fr = [], []
+    gt_fr, pr_fr, clear_fr = [], [], []
     to_ltrb = lambda b: np.column_stack([b[:, 0], b[:, 1], b[:, 0] + b[:, 2], b[:, 1] + b[:, 3]]).reshape(-1, 4)
     for f in range(1, last + 1):
         gi, gb = g.get(f, empty)
         pi, pb = p.get(f, empty)
-        acc.update_boxes(gi, gb, pi, pb, max_iou=max_iou)
+        if device == "cpu":
+            acc.update_boxes(gi, gb, pi, pb, max_iou=max_iou)
+        else:
+            clear_fr.append((gi, gb, pi, pb))
         gt_fr.append((gi, to_ltrb(gb)))
         pr_fr.append((pi, to_ltrb(pb)))
-    h = hota.pack(hota.hota_sequence(*hota.sequence_from_rows(gt_fr, pr_fr)), frames=float(last)) if last else np.zeros(len(hota.ALPHAS) * 7 + 2)
-    return {"hota": h, "clear": acc.counts()}
+    if not last:
+        return {"hota": np.zeros(len(hota.ALPHAS) * 7 + 2), "clear": acc.counts()}
+    if device == "gpu":
+        return {"hota": hota.pack(hota.hota_sequence_gpu(gt_fr, pr_fr), frames=float(last)), "clear": clearmot.sequence_counts_gpu(clear_fr, max_iou=max_iou)}
+    return {"hota": hota.pack(hota.hota_sequence(*hota.sequence_from_rows(gt_fr, pr_fr)), frames=float(last)), "clear": acc.counts()}
 
 
 def combine(per_sequence: dict) -> dict:
@@ -65,15 +75,16 @@ def combine(per_sequence: dict) -> dict:
     return out
 
 
-def evaluate_folders(gt_dir: str, pred_dir: str) -> dict:
+def evaluate_folders(gt_dir: str, pred_dir: str, device: str = "cpu") -> dict:
     res = {}
     for name in sorted(os.listdir(gt_dir)):
         if name.endswith(".txt") and os.path.exists(os.path.join(pred_dir, name)):
-            res[name[:-4]] = evaluate_sequence(mot_io.load_mot(os.path.join(gt_dir, name)), mot_io.load_mot(os.path.join(pred_dir, name)))
+            res[name[:-4]] = evaluate_sequence(mot_io.load_mot(os.path.join(gt_dir, name)), mot_io.load_mot(os.path.join(pred_dir, name)), device=device)
     return combine(res)
 
 
 if __name__ == "__main__":
-    if len(sys.argv) != 3:
+    args = [a for a in sys.argv[1:] if a != "--gpu"]
+    if len(args) != 2:
         sys.exit(__doc__)
-    print(json.dumps(evaluate_folders(sys.argv[1], sys.argv[2]), indent=1))
+    print(json.dumps(evaluate_folders(args[0], args[1], device="gpu" if "--gpu" in sys.argv[1:] else "cpu"), indent=1))
