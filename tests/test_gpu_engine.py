@@ -72,17 +72,20 @@ def test_video_engine_det_reid_strongsort_runs_and_keeps_ids_stable(orc):
     pipe.close()
 
 
-@pytest.mark.parametrize("tracker", ["strong_sort", "bot_sort", "deep_oc_sort"])
+@pytest.mark.parametrize("tracker", ["strong_sort", "bot_sort", "deep_oc_sort", "bot_sort+cmc"])
 def test_pipeline_global_feature_trackers_match_oracle_fed_with_gpu_embeddings(orc, tracker):
     """DetReidTrackPipeline.step with each tracker that owns a global-feature ReID net: the rows the bank produced on the device
     equal the C oracle's for the same detector rows and the embeddings the GPU network produced."""
     import torch
     from tracklab_amd import gpu_pipeline as gp
     F, T = 4, 12
-    pipe = gp.DetReidTrackPipeline("s", n_streams=1, frames_per_step=F, max_dets=32, use_graph=False, tracker=tracker)
+    cmc = tracker.endswith("+cmc")           # the reference's default cmc_method sparseOptFlow, estimated on the device inside the fused step
+    tracker = tracker.split("+")[0]
+    pipe = gp.DetReidTrackPipeline("s", n_streams=1, frames_per_step=F, max_dets=32, use_graph=False, tracker=tracker, camera_motion=cmc)
     heads, frames = _inputs(33, 10, T, pipe.ratio)
+    gmc = orc.SparseOptFlowGMC(1080, 1920, 2) if cmc else None
     cfg = pipe.tracker_cfg
-    ref = {"strong_sort": lambda: orc.PlainStrongSORT(pipe.D, **cfg, img_w=1920, img_h=1080), "bot_sort": lambda: orc.BoTSORT(pipe.D, **cfg),
+    ref = {"strong_sort": lambda: orc.PlainStrongSORT(pipe.D, **cfg, img_w=1920, img_h=1080), "bot_sort": lambda: orc.BoTSORT(pipe.D, **{k: v for k, v in cfg.items() if k != "cmc_method"}),
            "deep_oc_sort": lambda: orc.DeepOCSort(pipe.D, **cfg)}[tracker]()
     n_rows = 0
     for k in range(T // F):
@@ -95,7 +98,11 @@ def test_pipeline_global_feature_trackers_match_oracle_fed_with_gpu_embeddings(o
         dcnt = pipe.last["counts"].cpu().numpy()
         for f in range(F):
             n = int(dcnt[f])
-            exp = ref.update(trk_in[0, f, :n], emb[0, f, :n]) if n else np.zeros((0, 8))
+            warp = gmc.apply(frames[k * F + f]) if cmc else None      # (every frame, also one without detections: the estimator keeps its previous frame)
+            if cmc:
+                exp = ref.update(trk_in[0, f, :n], emb[0, f, :n], warp=warp)
+            else:
+                exp = ref.update(trk_in[0, f, :n], emb[0, f, :n]) if n else np.zeros((0, 8))
             got = rows[0][f]
             assert len(got) == len(exp), (tracker, k, f)
             np.testing.assert_array_equal(got["det_id"].astype(np.int64), exp[:, 7].astype(np.int64))

@@ -1134,13 +1134,17 @@ class CmcEstimator:
         self.inliers = n.value
         return H.reshape(2, 3)
 
-    def apply_dev(self, frame, stream_ptr=None):
+    def apply_dev(self, frame, stream_ptr=None, out=None):
+        """out: optional (6,) float64 cuda tensor (e.g. a row of the (S, F, 6) warps block of ``BoTSORTBank.update_dev``) instead of ``.warp_dev``."""
         import torch
         assert frame.is_cuda and frame.dtype == torch.uint8 and frame.is_contiguous() and tuple(frame.shape) == (self.h, self.w, 3)
-        if self.warp_dev is None:
-            self.warp_dev = torch.zeros(6, dtype=torch.float64, device=frame.device)
-        check(lib().tlk_cmc_apply_dev(self._h, frame.data_ptr(), self.warp_dev.data_ptr(), stream_ptr if stream_ptr is not None else current_stream_ptr()))
-        return self.warp_dev
+        if out is None:
+            if self.warp_dev is None:
+                self.warp_dev = torch.zeros(6, dtype=torch.float64, device=frame.device)
+            out = self.warp_dev
+        assert out.is_cuda and out.dtype == torch.float64 and out.numel() == 6 and out.is_contiguous()
+        check(lib().tlk_cmc_apply_dev(self._h, frame.data_ptr(), out.data_ptr(), stream_ptr if stream_ptr is not None else current_stream_ptr()))
+        return out
 
     def debug(self, what):
         """Stage outputs of the last apply (tlk.h tlk_cmc_debug_get)."""

@@ -97,6 +97,8 @@ class DetTrackPipeline:
     def reset(self):
         torch.cuda.synchronize(self.dev)
         self.bank.reset(-1)
+        for est in (getattr(self, "cmc", None) or []):
+            est.reset()
         self.frames_done = 0
 
     def synchronize(self):
@@ -236,8 +238,11 @@ class DetReidTrackPipeline:
                  height: int = 1080, width: int = 1920, size: int = 640, dtype=torch.float16, device: int = 0,
                  parts: int = 6, dim: int = 256, reid_hw=(384, 128), tracker_cfg: dict | None = None,
                  nms_thr: float = 0.45, score_thr: float = 0.7, max_tracks: int = 512, use_graph: bool = True,
-                 pose: str | None = None, tracker: str = "bpbreid", reid_arch: str = "resnet50"):
-        """reid_arch: "resnet50" (default) or "hrnet32" (the backbone tracklab/configs/modules/reid/bpbreid.yaml:53 names).
+                 pose: str | None = None, tracker: str = "bpbreid", reid_arch: str = "resnet50", camera_motion: bool = False):
+        """camera_motion (tracker "bot_sort"): the reference's default cmc_method sparseOptFlow (configs/modules/track/bot_sort.yaml) -- one
+        estimator per stream (tlk_cmc_*) runs over the step's frames on a side stream under the backbone forwards, its (2,3) warps go to the
+        tracker's frame kernel in device memory (tlk_botsort_update_dev_gmc).
+        reid_arch: "resnet50" (default) or "hrnet32" (the backbone tracklab/configs/modules/reid/bpbreid.yaml:53 names).
         tracker = "strong_sort": plain StrongSORT (strong_sort.StrongSORT: Pillow-semantics 256x128 crops of the int-truncated
         boxes, one global 512-d feature per crop, cosine gallery on MFMA, tlk_ssort bank) instead of BPBReID-StrongSORT.
         pose = "t"/"s"/"m"/"l": BASELINE.json configs[3] -- a top-down RTMPose stage (tlk_pose_crop_warp_norm -> network ->
@@ -283,6 +288,8 @@ class DetReidTrackPipeline:
                                        n_streams=n_streams, device=device, max_tracks=min(max_tracks, 256), max_dets=max_dets)
             self.row_dtype = _lib.SSORT_ROW
         elif tracker == "bot_sort":
+            if camera_motion:
+                self.tracker_cfg = dict(self.tracker_cfg, cmc_method="sparseOptFlow")
             self.bank = _lib.BoTSORTBank(dim, **self.tracker_cfg, min_confidence=0.4, wrapper_mode=True, n_streams=n_streams, device=device,
                                          max_tracks=min(max_tracks, 512 - max_dets), max_dets=max_dets)
             self.row_dtype = _lib.BOTSORT_ROW
@@ -297,6 +304,13 @@ class DetReidTrackPipeline:
         B = n_streams * frames_per_step
         self.B = B
         dev = self.dev
+        self.cmc = None
+        if camera_motion:
+            if tracker != "bot_sort":
+                raise NotImplementedError("DetReidTrackPipeline(camera_motion=True) is wired for tracker='bot_sort' (sparse optical flow); plain StrongSORT's ECC "
+                                          "runs in the module (wrappers.HipStrongSORT, ecc: true)")
+            self.cmc = [_lib.CmcEstimator(height, width, downscale=2, device=device) for _ in range(n_streams)]
+            self.cmc_stream = torch.cuda.Stream(device=dev)
         self.lb = torch.empty((B, size // 2, size // 2, 12), dtype=dtype, device=dev)
         self.crops = torch.zeros((B * max_dets, reid_hw[0], reid_hw[1], 3), dtype=dtype, device=dev)      # padding slots stay as they are
         self.det = {"ltwh": torch.zeros((B, max_dets, 4), dtype=torch.float32, device=dev),
@@ -334,6 +348,10 @@ class DetReidTrackPipeline:
                 "h_ltwh": torch.zeros((B, max_dets, 4), dtype=torch.float64).pin_memory(),
                 "h_dcnt": torch.zeros((B,), dtype=torch.int32).pin_memory(),
                 "ready": torch.cuda.Event(), "done": torch.cuda.Event()})
+        if self.cmc is not None:
+            for b_ in self.bufs:
+                b_["warps"] = torch.zeros((n_streams, frames_per_step, 6), dtype=torch.float64, device=dev)
+                b_["cmc_done"] = torch.cuda.Event()
         self.trk_stream = torch.cuda.Stream(device=dev, priority=int(__import__("os").environ.get("TLK_TRK_PRIO", "0")))
         self.use_graph = use_graph
         self.det_graphs, self.reid_graph = {}, None
@@ -346,6 +364,8 @@ class DetReidTrackPipeline:
     def reset(self):
         torch.cuda.synchronize(self.dev)
         self.bank.reset(-1)
+        for est in (getattr(self, "cmc", None) or []):
+            est.reset()
         self.frames_done = 0
 
     def synchronize(self):
@@ -410,8 +430,22 @@ class DetReidTrackPipeline:
             self.xyxy64.copy_(self.xyxy32)
             pcrops, _ = _lib.pose_crop_warp_norm(frames, self.xyxy64, self.det["counts"], 192, 256, "nhwc", self.dtype,
                                                  out=self.pose_crops, meta=self.pose_meta, swap_rb=True)
-        self.frames_free = torch.cuda.Event()       # the crop kernels were the last readers of `frames`
-        self.frames_free.record(main)
+        self.frames_free = torch.cuda.Event()       # the crop kernels were the last readers of `frames` ...
+        if self.cmc is not None:
+            # ... unless the camera-motion estimators read them too: frame by frame per stream, on their own stream (about 25 small launches per frame
+            # that would otherwise sit on the main stream between the backbone launches)
+            fed = torch.cuda.Event()
+            fed.record(main)
+            with torch.cuda.stream(self.cmc_stream):
+                self.cmc_stream.wait_event(fed)
+                sp = C.c_void_p(self.cmc_stream.cuda_stream)
+                for s_ in range(S):
+                    for f_ in range(F):
+                        self.cmc[s_].apply_dev(frames[s_ * F + f_], stream_ptr=sp, out=buf["warps"][s_, f_])
+                buf["cmc_done"].record(self.cmc_stream)
+                self.frames_free.record(self.cmc_stream)
+        else:
+            self.frames_free.record(main)
         if self.pose is not None:
             if self.use_graph:
                 sx, sy = self._graphed(self.__dict__.setdefault("_pg", {}), 0, lambda: self.pose(pcrops))
@@ -433,7 +467,11 @@ class DetReidTrackPipeline:
         self.frames_done += S * F
         with torch.cuda.stream(self.trk_stream):
             self.trk_stream.wait_event(buf["ready"])
-            if self.global_feat:
+            if self.cmc is not None:
+                self.trk_stream.wait_event(buf["cmc_done"])
+                self.bank.update_dev(buf["trk_in"].data_ptr(), buf["emb"].data_ptr(), buf["counts"].data_ptr(), F, buf["rows"].data_ptr(),
+                                     maxd, buf["ocnt"].data_ptr(), C.c_void_p(self.trk_stream.cuda_stream), warps=buf["warps"].data_ptr())
+            elif self.global_feat:
                 self.bank.update_dev(buf["trk_in"].data_ptr(), buf["emb"].data_ptr(), buf["counts"].data_ptr(), F, buf["rows"].data_ptr(),
                                      maxd, buf["ocnt"].data_ptr(), C.c_void_p(self.trk_stream.cuda_stream))
             else:
@@ -484,4 +522,6 @@ class DetReidTrackPipeline:
         self.det_graphs.clear()
         self.__dict__.pop("_rg", None)
         self.__dict__.pop("_pg", None)
+        for est in (getattr(self, "cmc", None) or []):
+            est.close()
         self.bank.close()
