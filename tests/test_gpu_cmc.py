@@ -132,3 +132,44 @@ def test_botsort_module_with_sparse_optical_flow_matches_the_oracle_chain(orc):
             np.testing.assert_array_equal(got.track_id.to_numpy(), exp[order, 4])
             rows += len(exp)
     assert rows > 60
+
+
+def test_cmc_is_exact_while_a_resnet_forward_runs_on_another_stream():
+    """The estimator runs on its own stream under the ReID forward in the fused step (gpu_pipeline.DetReidTrackPipeline(camera_motion=True)).
+    With packed-FP32 code in the LK kernel (v_pk_mul_f32 / v_pk_add_f32 for its dx, dy update) ~5 % of the tracked points came out different
+    whenever bf16 convolutions shared the compute units, and exact alone (profiles/r02_pk_f32_overlap.md); csrc/build.sh now compiles every
+    side-stream kernel without packed-FP32 instructions.  Here: the same frames through an estimator under load and one on the idle GPU."""
+    import ctypes as C
+    import torch
+    from tracklab_amd._lib import CmcEstimator
+    from tracklab_amd.backbones.reid import part_based_reid
+    H_, W_ = 1080, 1920
+    rng = np.random.default_rng(11)
+    frames = []
+    for k in range(3):                                        # unrelated noisy frames: every LK point iterates to its limit
+        f0, f1 = _pair(20 + k, H_, W_, np.cos(0.004 * k), np.sin(0.004 * k), 3.0 + k, -2.0)
+        frames += [f0, f1]
+    frames = [np.ascontiguousarray(np.clip(f.astype(np.int16) + rng.integers(-12, 13, f.shape), 0, 255).astype(np.uint8)) for f in frames]
+    reid = part_based_reid(1, 128, device="cuda", dtype=torch.bfloat16, channels_last=True)
+    crops = torch.randn(96, 3, 256, 128, device="cuda", dtype=torch.bfloat16).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        reid(crops)
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    busy, idle = CmcEstimator(H_, W_, 2), CmcEstimator(H_, W_, 2)
+    side = torch.cuda.Stream()
+    out = torch.zeros(len(frames), 6, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    n_pts = 0
+    for k in range(len(frames)):
+        with torch.no_grad():
+            for _ in range(2):
+                reid(crops)                                   # queued first: the estimator's kernels run under it
+        busy.apply_dev(dev[k], stream_ptr=C.c_void_p(side.cuda_stream), out=out[k])
+        torch.cuda.synchronize()
+        w = idle.apply(frames[k])
+        np.testing.assert_array_equal(busy.debug(3), idle.debug(3), err_msg=f"LK points of frame {k}")
+        np.testing.assert_array_equal(busy.debug(4), idle.debug(4))
+        np.testing.assert_array_equal(out[k].cpu().numpy().reshape(2, 3), w)
+        n_pts += len(idle.debug(3))
+    assert n_pts > 500                                        # the comparison covered the tracked points of five frame pairs
+    busy.close(), idle.close()

@@ -6,6 +6,13 @@ OUT="$HERE/../lib"
 mkdir -p "$OUT" "$HERE/.obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I"$HERE/../../include" -I"$HERE" -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result)
+# No packed-FP32 VALU code (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) in kernels that may share compute units with the networks'
+# MFMA kernels, i.e. everything launched on a side stream (trackers, camera-motion estimators, evaluation): measured on MI355X, the
+# LK kernel of tlk_cmc.hip, whose dx/dy update the compiler had packed, gave lane-dependent results in ~0.1 % of its iterations while a
+# ResNet-50 forward ran on another stream and exact ones alone (profiles/r02_pk_f32_overlap.md); without packed code it is exact in both.
+# The pre/post-processing kernels below run in stream order with the networks and keep the default code generation they were measured with.
+PACKED_OK="tlk_image tlk_epilogue tlk_pose tlk_gemm"
+NOPK=(-fno-slp-vectorize -Xclang -target-feature -Xclang -packed-fp32-ops)
 objs=()
 pids=()
 for src in "$HERE"/*.hip; do
@@ -13,9 +20,11 @@ for src in "$HERE"/*.hip; do
   objs+=("$obj")
   stale=0
   [[ ! -f "$obj" || "$src" -nt "$obj" ]] && stale=1
-  for h in "$HERE"/*.hpp "$HERE/../../include/tlk.h"; do [[ "$h" -nt "$obj" ]] && stale=1; done
+  for h in "$HERE"/*.hpp "$HERE/../../include/tlk.h" "$HERE/build.sh"; do [[ "$h" -nt "$obj" ]] && stale=1; done
   if [[ $stale == 1 ]]; then
-    "$HIPCC" "${FLAGS[@]}" -c "$src" -o "$obj" &
+    extra=("${NOPK[@]}")
+    for ok in $PACKED_OK; do [[ "$(basename "${src%.hip}")" == "$ok" ]] && extra=(); done
+    "$HIPCC" "${FLAGS[@]}" "${extra[@]}" -c "$src" -o "$obj" &
     pids+=($!)
   fi
 done

@@ -138,7 +138,15 @@ __global__ void __launch_bounds__(BLOCK) scharr_kernel(const unsigned char *__re
 struct LkLevel { const unsigned char *img; const short *der; int h, w; };
 struct LkPyr { LkLevel L[LK_LEVELS]; int nlev; };
 
-__device__ __forceinline__ int lk_img(const LkLevel &L, int y, int x) { return L.img[(size_t)reflect101(y, L.h) * L.w + reflect101(x, L.w)]; }
+// The window reaches at most LK_WIN pixels outside a level: with every level at least LK_WIN + 1 pixels wide and high one reflection
+// is enough and the taps are branch-free (SMALL = false); images smaller than that keep the general loop.
+__device__ __forceinline__ int reflect101_once(int p, int n) { p = p < 0 ? -p : p; return p >= n ? 2 * n - 2 - p : p; }
+template <bool SMALL>
+__device__ __forceinline__ int lk_img(const LkLevel &L, int y, int x)
+{
+    if constexpr (SMALL) return L.img[(size_t)reflect101(y, L.h) * L.w + reflect101(x, L.w)];
+    else return L.img[(size_t)reflect101_once(y, L.h) * L.w + reflect101_once(x, L.w)];
+}
 __device__ __forceinline__ int lk_der(const LkLevel &L, int y, int x, int c) { return (y < 0 || y >= L.h || x < 0 || x >= L.w) ? 0 : L.der[((size_t)y * L.w + x) * 2 + c]; }
 __device__ __forceinline__ long long wave_sum_i64(long long v)
 {
@@ -148,6 +156,7 @@ __device__ __forceinline__ long long wave_sum_i64(long long v)
 }
 
 // cv::calcOpticalFlowPyrLK with its defaults, one wavefront per point; lane l owns window pixels l, l + 64, ... (7 of 441)
+template <bool SMALL>
 __global__ void __launch_bounds__(BLOCK) lk_kernel(LkPyr A, LkPyr Bp, const float *__restrict__ pts, const int *__restrict__ n_pts,
                                                    float *__restrict__ next_pts, unsigned char *__restrict__ status)
 {
@@ -178,7 +187,7 @@ __global__ void __launch_bounds__(BLOCK) lk_kernel(LkPyr A, LkPyr Bp, const floa
             Iw[q] = 0; dIx[q] = 0; dIy[q] = 0;
             if (k < LK_WIN * LK_WIN) {
                 const int y = k / LK_WIN, x = k - y * LK_WIN, yy = ipy + y, xx = ipx + x;
-                const int iv = DESCALE(lk_img(I, yy, xx) * iw00 + lk_img(I, yy, xx + 1) * iw01 + lk_img(I, yy + 1, xx) * iw10 + lk_img(I, yy + 1, xx + 1) * iw11, 14 - 5);
+                const int iv = DESCALE(lk_img<SMALL>(I, yy, xx) * iw00 + lk_img<SMALL>(I, yy, xx + 1) * iw01 + lk_img<SMALL>(I, yy + 1, xx) * iw10 + lk_img<SMALL>(I, yy + 1, xx + 1) * iw11, 14 - 5);
                 const int ix = DESCALE(lk_der(I, yy, xx, 0) * iw00 + lk_der(I, yy, xx + 1, 0) * iw01 + lk_der(I, yy + 1, xx, 0) * iw10 + lk_der(I, yy + 1, xx + 1, 0) * iw11, 14);
                 const int iy = DESCALE(lk_der(I, yy, xx, 1) * iw00 + lk_der(I, yy, xx + 1, 1) * iw01 + lk_der(I, yy + 1, xx, 1) * iw10 + lk_der(I, yy + 1, xx + 1, 1) * iw11, 14);
                 Iw[q] = (short)iv; dIx[q] = (short)ix; dIy[q] = (short)iy;
@@ -205,7 +214,7 @@ __global__ void __launch_bounds__(BLOCK) lk_kernel(LkPyr A, LkPyr Bp, const floa
                 const int k = q * WAVE + lane;
                 if (k < LK_WIN * LK_WIN) {
                     const int y = k / LK_WIN, x = k - y * LK_WIN, yy = iny + y, xx = inx + x;
-                    const int diff = DESCALE(lk_img(J, yy, xx) * iw00 + lk_img(J, yy, xx + 1) * iw01 + lk_img(J, yy + 1, xx) * iw10 + lk_img(J, yy + 1, xx + 1) * iw11, 14 - 5) - Iw[q];
+                    const int diff = DESCALE(lk_img<SMALL>(J, yy, xx) * iw00 + lk_img<SMALL>(J, yy, xx + 1) * iw01 + lk_img<SMALL>(J, yy + 1, xx) * iw10 + lk_img<SMALL>(J, yy + 1, xx + 1) * iw11, 14 - 5) - Iw[q];
                     sb1 += (long long)(diff * dIx[q]); sb2 += (long long)(diff * dIy[q]);
                 }
             }
@@ -457,7 +466,10 @@ extern "C" int tlk_cmc_apply_dev(tlk_cmc *c, const uint8_t *frame_dev, double *w
         LkPyr A, Bp;
         A.nlev = Bp.nlev = c->nlev;
         for (int l = 0; l < c->nlev; ++l) { A.L[l] = LkLevel{c->gray[pb][l], c->der[pb][l], c->lh[l], c->lw[l]}; Bp.L[l] = LkLevel{c->gray[b][l], c->der[b][l], c->lh[l], c->lw[l]}; }
-        hipLaunchKernelGGL(lk_kernel, dim3((c->max_corners + NWAVES - 1) / NWAVES), dim3(BLOCK), 0, st, A, Bp, (const float *)c->pts[pb], (const int *)c->n_pts[pb], c->next_pts, c->status);
+        const bool small = c->dh <= LK_WIN || c->dw <= LK_WIN;      // (levels above 0 are only built when larger than the window)
+        const dim3 lg((c->max_corners + NWAVES - 1) / NWAVES);
+        if (small) hipLaunchKernelGGL(lk_kernel<true>, lg, dim3(BLOCK), 0, st, A, Bp, (const float *)c->pts[pb], (const int *)c->n_pts[pb], c->next_pts, c->status);
+        else hipLaunchKernelGGL(lk_kernel<false>, lg, dim3(BLOCK), 0, st, A, Bp, (const float *)c->pts[pb], (const int *)c->n_pts[pb], c->next_pts, c->status);
         hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(BLOCK), 0, st, (const float *)c->pts[pb], (const float *)c->next_pts, (const unsigned char *)c->status, (const int *)c->n_pts[pb], c->from, c->to, c->m);
         hipLaunchKernelGGL(ransac_subsets_kernel, dim3(1), dim3(64), 0, st, (const int *)c->m, c->ids, c->n_drawn);
         hipLaunchKernelGGL(ransac_eval_kernel, dim3((RANSAC_ITERS + NWAVES - 1) / NWAVES), dim3(BLOCK), 0, st, (const float *)c->from, (const float *)c->to, (const int *)c->m, (const int *)c->ids,
