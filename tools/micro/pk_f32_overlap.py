@@ -7,6 +7,8 @@ from tracklab_amd.backbones.reid import part_based_reid
 
 L = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpk_f32_overlap.so"))
 L.pk_launch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+L2 = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpk_f32_lk_sequence.so"))
+L2.lkseq_launch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 reid = part_based_reid(1, 128, device="cuda", dtype=torch.bfloat16, channels_last=True)
 crops = torch.randn(96, 3, 256, 128, device="cuda", dtype=torch.bfloat16).to(memory_format=torch.channels_last)
 with torch.no_grad():
@@ -25,3 +27,15 @@ for mode in ("alone", "under a ResNet-50 forward on another stream", "alone"):
     n, bad_pk, bad_sc, bad_cmp = cnt.tolist()
     print(f"{mode:46s}: passes {n}  packed result not identical in all lanes {bad_pk}  scalar result not identical in all lanes {bad_sc}  "
           f"packed != scalar {bad_cmp}", flush=True)
+
+for mode in ("alone", "under a ResNet-50 forward on another stream", "alone"):
+    cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
+    for rep in range(8):
+        if mode != "alone":
+            with torch.no_grad():
+                for _ in range(2):
+                    reid(crops)
+        L2.lkseq_launch(512, 20000, cnt.data_ptr(), C.c_void_p(side.cuda_stream))
+        torch.cuda.synchronize()
+    n, bad = cnt.tolist()[:2]
+    print(f"LK dx/dy sequence, {mode:46s}: passes {n}  result not identical in all lanes {bad}", flush=True)
