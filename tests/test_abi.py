@@ -40,3 +40,16 @@ def test_no_cpu_fallback_without_device():
         pytest.skip("GPU present")
     with pytest.raises(_lib.TlkError):
         _lib.OCSortBank(0.0)
+
+
+def test_integration_md_indexes_every_entry_point_with_its_header_section():
+    """INTEGRATION.md's appendix (tools/gen_abi_index.py) lists every declared entry point next to the header section that cites the reference
+    code it replaces, and is regenerated whenever tlk.h changes."""
+    import subprocess
+    import sys
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    index = text[text.index("abi-index:begin"):text.index("abi-index:end")]
+    missing = [s for s in _declared_symbols() if f"`{s}`" not in index]
+    assert not missing, f"not in the C ABI index: {missing}"
+    assert subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_abi_index.py"), "--check"]).returncode == 0, \
+        "INTEGRATION.md's C ABI index is stale: python tools/gen_abi_index.py"
