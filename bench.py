@@ -59,6 +59,10 @@ WORKLOADS = {
     "config3b": dict(detector="m", objects=100, frames_per_step=24, max_dets=104, tracker="bot_sort",
                      name="YOLOX-m + 512-d ReID on Pillow-semantics 256x128 crops + BoT-SORT (cmc none: embedding + Mahalanobis first stage), "
                           "synthetic 1080p 100-obj stream"),
+    "config3c": dict(detector="m", objects=100, frames_per_step=24, max_dets=104, tracker="bot_sort", camera_motion=True,
+                     name="config3b with the reference's default cmc_method sparseOptFlow (configs/modules/track/bot_sort.yaml): one camera-motion "
+                          "estimator per stream on its own HIP stream under the ReID forward, its warps applied inside the BoT-SORT frame kernel, "
+                          "synthetic 1080p 100-obj stream (r02: built and parity-tested, not yet profiled)"),
     "config3d": dict(detector="m", objects=100, frames_per_step=24, max_dets=104, tracker="deep_oc_sort",
                      name="YOLOX-m + 512-d ReID on Pillow-semantics 256x128 crops + Deep-OC-SORT (cmc off: IoU + angle + adaptive-weighted "
                           "embedding cost), synthetic 1080p 100-obj stream"),
@@ -331,7 +335,7 @@ def main():
     S, F = args.streams, args.frames_per_step or wl["frames_per_step"]
     B = S * F
     total_steps = args.warmup + args.steps
-    is3 = args.workload in ("config3", "config3h", "config4", "config3s", "config3b", "config3d", "config5")
+    is3 = args.workload in ("config3", "config3h", "config4", "config3s", "config3b", "config3c", "config3d", "config5")
     ssort = wl.get("tracker") in ("strong_sort", "bot_sort", "deep_oc_sort")      # global-feature trackers: (n,7) rows + (n,D) features
     check_frames = args.check_frames if args.check_frames is not None else (96 if ssort else 600)
     parity_steps = min(64, max(1, (check_frames + F - 1) // F)) if check_frames > 0 else 0
@@ -339,8 +343,8 @@ def main():
     n_frames = input_steps * F
 
     def gfeat_oracle(oracle, pipe):
-        if wl["tracker"] == "bot_sort":
-            return oracle.BoTSORT(pipe.D, **pipe.tracker_cfg)
+        if wl["tracker"] == "bot_sort":       # (the estimator is a stage of its own in the oracle chain: SparseOptFlowGMC -> update(warp=))
+            return oracle.BoTSORT(pipe.D, **{k_: v_ for k_, v_ in pipe.tracker_cfg.items() if k_ != "cmc_method"})
         if wl["tracker"] == "deep_oc_sort":
             return oracle.DeepOCSort(pipe.D, **pipe.tracker_cfg)
         return oracle.PlainStrongSORT(pipe.D, **pipe.tracker_cfg, img_w=WIDTH, img_h=HEIGHT)
@@ -354,6 +358,8 @@ def main():
             kw = dict(dim=wl["dim"]) if "dim" in wl else {}
             if "reid_arch" in wl:
                 kw["reid_arch"] = wl["reid_arch"]
+            if wl.get("camera_motion"):
+                kw["camera_motion"] = True
             return gp.DetReidTrackPipeline(detector, n_streams=n_streams, frames_per_step=frames_per_step, max_dets=wl["max_dets"], device=dev.index,
                                            use_graph=not args.no_graph, pose=wl.get("pose"), tracker=wl.get("tracker", "bpbreid"), dtype=tdtype, **kw)
         return gp.DetTrackPipeline(detector, n_streams=n_streams, frames_per_step=frames_per_step, max_dets=wl["max_dets"], device=dev.index,
@@ -393,6 +399,7 @@ def main():
         from tracklab_amd import hota
         if is3:
             ref = gfeat_oracle(oracle, pipe) if ssort else oracle.StrongSORT(pipe.K, pipe.D, **pipe.tracker_cfg)
+            gmc = oracle.SparseOptFlowGMC(HEIGHT, WIDTH, 2) if wl.get("camera_motion") else None
             ids_ok, tracks, frames_checked, first_bad = True, 0, 0, None
             gt_fr, gpu_fr, orc_fr = [], [], []
             for k in range(parity_steps):
@@ -411,7 +418,10 @@ def main():
                         d7[:, 0], d7[:, 1] = ltwh32[:, 0], ltwh32[:, 1]
                         d7[:, 2], d7[:, 3] = (ltwh32[:, 0] + ltwh32[:, 2]).astype(np.float32), (ltwh32[:, 1] + ltwh32[:, 3]).astype(np.float32)
                         d7[:, 4], d7[:, 5], d7[:, 6] = 1.0, 1.0, ids
-                        e8 = ref.update(d7, emb[0, f, :n, 0, :]) if n else np.zeros((0, 8))
+                        if gmc is not None:      # every frame goes through the estimator, also one without detections
+                            e8 = ref.update(d7, emb[0, f, :n, 0, :], warp=gmc.apply(hp[k % pool_steps, f]))
+                        else:
+                            e8 = ref.update(d7, emb[0, f, :n, 0, :]) if n else np.zeros((0, 8))
                         exp = np.zeros(len(e8), dtype=[("det_id", "<i8"), ("track_id", "<i8"), ("kf_ltwh", "<f8", (4,))])
                         exp["det_id"], exp["track_id"] = e8[:, 7], e8[:, 4]
                         exp["kf_ltwh"] = np.stack([e8[:, 0], e8[:, 1], e8[:, 2] - e8[:, 0], e8[:, 3] - e8[:, 1]], axis=1).reshape(-1, 4)
@@ -650,7 +660,9 @@ def cpu_baseline(args, wl, pipe, detector, is3, ssort, byte, gfeat_oracle, gfeat
 
     def make_tracker():
         if ssort:
-            return gfeat_oracle(oracle, pipe)
+            t_ = gfeat_oracle(oracle, pipe)
+            t_._gmc = oracle.SparseOptFlowGMC(HEIGHT, WIDTH, 2) if wl.get("camera_motion") else None     # the estimator belongs to the tracker's stream
+            return t_
         if is3:
             return oracle.StrongSORT(pipe.K, pipe.D, **pipe.tracker_cfg)
         return oracle.ByteTrack(**pipe.tracker_cfg["hyper"]) if byte else oracle.OCSort(**pipe.tracker_cfg["hyper"])
@@ -671,7 +683,10 @@ def cpu_baseline(args, wl, pipe, detector, is3, ssort, byte, gfeat_oracle, gfeat
                 emb_cache[f] = emb
             else:
                 emb = np.resize(emb_cache[f % len(emb_cache)], (n, pipe.D))
-            trk.update(d7, np.ascontiguousarray(emb, dtype=np.float32))
+            if getattr(trk, "_gmc", None) is not None:
+                trk.update(d7, np.ascontiguousarray(emb, dtype=np.float32), warp=trk._gmc.apply(frame))
+            else:
+                trk.update(d7, np.ascontiguousarray(emb, dtype=np.float32))
         elif is3:
             ltrb = oracle.ltwh_to_crop_ltrb(ltwh.astype(np.float64), WIDTH, HEIGHT)
             crops = oracle.crop_resize_norm(frame, ltrb, 384, 128)
@@ -719,7 +734,8 @@ def cpu_baseline(args, wl, pipe, detector, is3, ssort, byte, gfeat_oracle, gfeat
     cpu_t = time.perf_counter() - tc0
     chain = ("oracle C letterbox + YOLOX-%s fp32 (torch CPU, batch 1) + oracle C decode/NMS" % detector) + \
             ((" + oracle C affine pose crops + RTMPose-%s fp32 (torch CPU) + oracle C SimCC decode" % wl["pose"]) if is3 and wl.get("pose") else "") + \
-            (" + oracle C Pillow-semantics crops + ReID R50 fp32 512-d (torch CPU, 100 crops/batch) + oracle C " + gfeat_name if ssort else
+            (" + oracle C Pillow-semantics crops + ReID R50 fp32 512-d (torch CPU, 100 crops/batch) + " +
+             ("oracle C sparse-optical-flow camera-motion estimate + " if wl.get("camera_motion") else "") + "oracle C " + gfeat_name if ssort else
              " + oracle C crop-resize-normalize + part-based ReID R50 fp32 (torch CPU, 100 crops/batch) + oracle C BPBReID-StrongSORT"
              if is3 else (" + oracle C ByteTrack" if byte else " + oracle C OC-SORT"))
     out = {"value": done / cpu_t, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",

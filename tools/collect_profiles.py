@@ -87,7 +87,7 @@ def write_traffic():
                    "hbm_bytes_per_launch": (2 * f + w) * 1024}, open(os.path.join(dst, fname), "w"), indent=1)
         print(fname, "read MiB", 2 * f / 1024, "write MiB", w / 1024)
         # the bench of this same GPU call read the PREVIOUS traffic file: stamp the copy kept in profiles/ with this call's counters
-        for wl in {"crop_wave_kernel": ("config3", "config3h", "config4", "config5"), "pil_crop_kernel": ("config3s", "config3b", "config3d")}.get(kern, ("config2", "config2b")):
+        for wl in {"crop_wave_kernel": ("config3", "config3h", "config4", "config5"), "pil_crop_kernel": ("config3s", "config3b", "config3c", "config3d")}.get(kern, ("config2", "config2b")):
             bp = os.path.join(dst, f"{tag}_bench_{wl}.json")
             if os.path.exists(bp):
                 line = json.loads(open(bp).read().strip().splitlines()[-1])
@@ -101,7 +101,7 @@ write_summary("config3", "config3 (YOLOX-m + ReID + BPBReID-StrongSORT), 24 fram
               "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload config3 --steps 10 --warmup 3 --no-cpu-baseline --no-latency-leg --check-frames 0")
 write_summary("config2", "config2 (YOLOX-s + OC-SORT), 32 frames/step",
               "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --workload config2 --steps 10 --warmup 3 --no-cpu-baseline --no-latency-leg --check-frames 0")
-for wl in ("config1", "config4", "config5", "config3h", "config3s", "config3b", "config3d", "config2b", "config3_f32"):
+for wl in ("config1", "config4", "config5", "config3h", "config3s", "config3b", "config3c", "config3d", "config2b", "config3_f32"):
     if os.path.exists(os.path.join(src, f"bench_{wl}.json")):
         shutil.copy(os.path.join(src, f"bench_{wl}.json"), os.path.join(dst, f"{tag}_bench_{wl}.json"))
 write_summary("config3s", "config3s (YOLOX-m + 512-d ReID + plain StrongSORT: cosine gallery on MFMA), 24 frames/step",

@@ -11,7 +11,7 @@ cd "$R"
 python bench.py --workload config3 --steps 20 --warmup 5 > "$OUT/bench_config3.json" 2> "$OUT/bench_config3.err"
 python bench.py --workload config3 --dtype f32 --steps 8 --warmup 3 --no-cpu-baseline --no-latency-leg --check-frames 96 > "$OUT/bench_config3_f32.json" 2> "$OUT/bench_config3_f32.err"
 python bench.py --workload config2 --steps 20 --warmup 5 > "$OUT/bench_config2.json" 2> "$OUT/bench_config2.err"
-for wl in config1 config4 config5 config3h config3s config3b config3d config2b; do
+for wl in config1 config4 config5 config3h config3s config3b config3c config3d config2b; do
   python bench.py --workload $wl --steps 8 --warmup 3 --no-cpu-baseline --no-latency-leg --check-frames 96 > "$OUT/bench_$wl.json" 2> "$OUT/bench_$wl.err"
 done
 cd /tmp && export TMPDIR=/tmp
