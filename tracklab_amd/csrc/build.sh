@@ -24,7 +24,8 @@ for src in "$HERE"/*.hip; do
   if [[ $stale == 1 ]]; then
     extra=("${NOPK[@]}")
     for ok in $PACKED_OK; do [[ "$(basename "${src%.hip}")" == "$ok" ]] && extra=(); done
-    "$HIPCC" "${FLAGS[@]}" "${extra[@]}" -c "$src" -o "$obj" &
+    # (the host pass of the same command does not know the AMDGPU feature and says so: filtered, everything else is shown)
+    "$HIPCC" "${FLAGS[@]}" "${extra[@]}" -c "$src" -o "$obj" 2> >(grep -v "is not a recognized feature for this target" >&2) &
     pids+=($!)
   fi
 done
