@@ -147,6 +147,33 @@ class _Recorder:
     def on_module_step_end(self, engine, task, batch, detections): self.events.append(("step_end", task, len(detections)))
 
 
+class _ProgressLike:
+    """The hooks of tracklab.callbacks.Progressbar with its signatures and its bookkeeping (callbacks/progress.py:40-78): the per-task bar is
+    created in on_module_start from engine.models[task] / len(dataloader) and indexed in on_module_step_end / on_module_end -- an engine that
+    emits step hooks without on_module_start raises KeyError there."""
+
+    def __init__(self):
+        self.task_pbars, self.closed, self.video_id = {}, [], None
+
+    def on_video_loop_start(self, engine, video_metadata, video_idx, index):
+        self.video_id = video_idx
+
+    def on_module_start(self, engine, task, dataloader):
+        if hasattr(engine.models[task], "process_video"):
+            length = len(engine.img_metadatas[engine.img_metadatas.video_id == self.video_id])
+        else:
+            length = len(dataloader)
+        self.task_pbars[task] = {"total": length, "n": 0}
+
+    def on_module_step_end(self, engine, task, batch, detections):
+        self.task_pbars[task]["n"] += 1
+
+    def on_module_end(self, engine, task, detections):
+        bar = self.task_pbars[task]
+        assert bar["n"] == bar["total"], bar
+        self.closed.append(task)
+
+
 def test_tracking_engine_fires_the_callback_hooks_and_online_equals_resident():
     """HipTrackingEngine.track_dataset over two videos (engine/engine.py:105-126): hook order, image ids mapped back to the dataset's,
     and the `online` drain (per-image callbacks, engine/video.py:93-117) produces the same table as the HBM-resident mode."""
@@ -169,8 +196,11 @@ def test_tracking_engine_fires_the_callback_hooks_and_online_equals_resident():
         got = {}
         rec_end = rec.on_video_loop_end
         rec.on_video_loop_end = lambda engine, video_metadata, video_idx, detections, image_pred: (got.__setitem__(int(video_idx), detections), rec_end(engine, video_metadata, video_idx, detections, image_pred))
-        eng = HipTrackingEngine(modules=[], tracker_state=state, num_workers=0, callbacks={"rec": rec}, pipeline=pipe, image_loader=load, synth_heads=heads)
+        bar = _ProgressLike()
+        eng = HipTrackingEngine(modules=[], tracker_state=state, num_workers=0, callbacks={"rec": rec, "progress": bar}, pipeline=pipe, image_loader=load,
+                                synth_heads=heads)
         eng.track_dataset()
+        assert bar.closed == ["hip_fused_pipeline"] * 2                              # one module start / end pair per video, every bar complete
         ev = rec.events
         assert ev[0] == ("dataset_start",) and ev[-1] == ("dataset_end",)
         assert [e for e in ev if e[0] in ("video_start", "video_end")] == [("video_start", 7), ("video_end", 7, len(got[7])), ("video_start", 9), ("video_end", 9, len(got[9]))]
@@ -183,6 +213,8 @@ def test_tracking_engine_fires_the_callback_hooks_and_online_equals_resident():
             assert sum(e[0] == "step_end" for e in ev) == 2                          # resident: one table per video
         for v in (7, 9):
             assert set(got[v].image_id) == set(imgs.index[imgs.video_id == v]) and got[v].track_id.notna().sum() > 40
+        assert not set(got[7].index) & set(got[9].index)                             # detection ids are dataset-global
+        assert got[9].index.min() >= 3 * F * 64
         tables[per_image] = got
     for v in (7, 9):
         a, b = tables[False][v], tables[True][v]

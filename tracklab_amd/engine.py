@@ -180,15 +180,17 @@ class HipVideoEngine:
             yield buf[:n], True
 
     @torch.no_grad()
-    def video_loop(self, frames, video_id=0, synth_heads=None, online=False, on_step=None) -> pd.DataFrame:
+    def video_loop(self, frames, video_id=0, synth_heads=None, online=False, on_step=None, keep_ids=False) -> pd.DataFrame:
         """frames: (T, H, W, 3) uint8 RGB array, an iterable of (H, W, 3) frames, or an iterable of pinned (n <= F, H, W, 3) uint8
         tensors (uploaded without a staging copy). RGB like TrackLab's cv2_load_image (channel contract: gpu_pipeline docstring).
         synth_heads: optional callable(first_frame, n) -> (n, A, 6) float32 detector-head activations (numpy, or a cuda tensor of
         a full step) replacing the network's (random-init detectors produce no boxes; benchmarks and tests feed a head that encodes
         known boxes). online: drain every step to the host while the next one runs and call on_step(detections_of_the_step: DataFrame)
-        -- the per-image hook of the reference's online engine; otherwise the table stays in HBM until the video ends."""
+        -- the per-image hook of the reference's online engine; otherwise the table stays in HBM until the video ends.
+        keep_ids: the tracker is reset for the video but ByteTrack's / BoT-SORT's id counter keeps counting, like the reference's class-level
+        BaseTrack._count (the other trackers restart at 1 per video in the reference too: their counters are re-created with the tracker)."""
         pipe, F, maxd = self.pipe, self.F, self.maxd
-        pipe.reset()
+        pipe.reset(keep_ids=keep_ids)
         table = DetectionTable()
         log = None if online else DeviceStepLog()
         main = torch.cuda.current_stream(pipe.dev)
@@ -280,10 +282,16 @@ class HipTrackingEngine(_EngineBase):
     step (task = "hip_fused_pipeline"), and -- when a callback defines ``on_image_loop_end`` -- the per-image hooks of the online
     engine (engine/video.py:93-117), fed from the ``online`` drain. ``modules`` may be empty: the pipeline replaces them.
 
-    image_loader(file_path) -> (H, W, 3) uint8 RGB array (default: Pillow, like cv2_load_image's RGB output)."""
+    image_loader(file_path) -> (H, W, 3) uint8 RGB array (default: Pillow, like cv2_load_image's RGB output).
+    The fused pipeline is announced to the callbacks like a module of the reference (``on_module_start`` with a sized stand-in for the
+    dataloader, one ``on_module_step_end`` per drained step, ``on_module_end``), so ``tracklab.callbacks.Progressbar`` works unchanged.
+    ``reset_ids_per_video`` (default false): detection ids keep counting across the videos of a dataset like the reference detector's
+    counter, and ByteTrack / BoT-SORT track ids like ``BaseTrack._count``; true restarts both per video."""
+
+    TASK = "hip_fused_pipeline"
 
     def __init__(self, modules=None, tracker_state=None, num_workers: int = 0, callbacks=None, pipeline=None, image_loader=None,
-                 synth_heads=None, **_unused):
+                 synth_heads=None, reset_ids_per_video: bool = False, **_unused):
         self.module_names = [m.name for m in (modules or [])]
         self.callbacks = dict(callbacks or {})
         cbs = list(self.callbacks.values())
@@ -296,9 +304,12 @@ class HipTrackingEngine(_EngineBase):
         self.img_metadatas = getattr(tracker_state, "image_metadatas", None)
         self.video_metadatas = getattr(tracker_state, "video_metadatas", None)
         self.models = {m.name: m for m in (modules or [])}
+        self.reset_ids_per_video = bool(reset_ids_per_video)
+        self._det_id_offset = 0          # detection ids are dataset-global like the reference detector's running counter (rtmlib_api.py self.id)
         if pipeline is None:
             raise ValueError("HipTrackingEngine needs a gpu_pipeline.DetTrackPipeline / DetReidTrackPipeline (engine.pipeline in the yaml)")
         self.pipeline = pipeline
+        self.models[self.TASK] = pipeline         # callbacks look the task up here (callbacks/progress.py:59-75 reads engine.models[task])
         self.video_engine = HipVideoEngine(pipeline)
         self.image_loader = image_loader or self._load_rgb
         self.synth_heads = synth_heads
@@ -352,15 +363,23 @@ class HipTrackingEngine(_EngineBase):
         paths = imgs.file_path.to_list()
         F = self.video_engine.F
 
+        task = self.TASK
+        n_steps = (len(paths) + F - 1) // F
+        # one tick per drained step in the online form, one per video otherwise (the table crosses PCIe once)
+        self.callback("on_module_start", task=task, dataloader=range(n_steps if self._per_image else 1))
+
         def frames():
             for j, img in enumerate(self._decode_ahead(paths)):
                 if j % F == 0:
-                    self.callback("on_module_step_start", task="hip_fused_pipeline", batch=(image_ids[j:j + F], None))
+                    self.callback("on_module_step_start", task=task, batch=(image_ids[j:j + F], None))
                 yield img
+
+        off = self._det_id_offset
 
         def on_step(df):
             df = df.assign(image_id=image_ids[df.image_id.to_numpy()])
-            self.callback("on_module_step_end", task="hip_fused_pipeline", batch=None, detections=df)
+            df.index = df.index + off
+            self.callback("on_module_step_end", task=task, batch=None, detections=df)
             for img_id, sub in df.groupby("image_id"):
                 self.callback("on_image_loop_end", image_metadata=imgs.loc[img_id], image=None, image_idx=img_id, detections=sub)
 
@@ -368,10 +387,14 @@ class HipTrackingEngine(_EngineBase):
         if self.synth_heads is not None:
             heads = lambda t0, n: self.synth_heads(video_id, t0, n)      # noqa: E731
         det = self.video_engine.video_loop(frames(), video_id=video_id, synth_heads=heads, online=self._per_image,
-                                           on_step=on_step if self._per_image else None)
+                                           on_step=on_step if self._per_image else None, keep_ids=not self.reset_ids_per_video)
         det["image_id"] = image_ids[det.image_id.to_numpy()] if len(det) else det.image_id
+        det.index = det.index + off
+        if not self.reset_ids_per_video:
+            self._det_id_offset += n_steps * F * self.video_engine.maxd      # the id space one video occupies (id = frame * max_dets + i)
         if not self._per_image:
-            self.callback("on_module_step_end", task="hip_fused_pipeline", batch=None, detections=det)
+            self.callback("on_module_step_end", task=task, batch=None, detections=det)
+        self.callback("on_module_end", task=task, detections=det)
         return det, imgs
 
 

@@ -94,9 +94,14 @@ class DetTrackPipeline:
         self.kernel_events = []         # (start, end) torch events around the letterbox launch
         self.record_kernel_events = False
 
-    def reset(self):
+    def reset(self, keep_ids: bool = False):
+        """keep_ids: ByteTrack / BoT-SORT keep their id counter (the reference's class-level BaseTrack._count); the other trackers' counters are
+        re-created with the tracker in the reference, so they restart at 1 either way."""
         torch.cuda.synchronize(self.dev)
-        self.bank.reset(-1)
+        if keep_ids and self.tracker in ("byte_track", "bot_sort"):
+            self.bank.reset(-1, keep_ids=True)
+        else:
+            self.bank.reset(-1)
         for est in (getattr(self, "cmc", None) or []):
             est.reset()
         self.frames_done = 0
@@ -361,9 +366,14 @@ class DetReidTrackPipeline:
         self.kernel_events = []
         self.record_kernel_events = False
 
-    def reset(self):
+    def reset(self, keep_ids: bool = False):
+        """keep_ids: ByteTrack / BoT-SORT keep their id counter (the reference's class-level BaseTrack._count); the other trackers' counters are
+        re-created with the tracker in the reference, so they restart at 1 either way."""
         torch.cuda.synchronize(self.dev)
-        self.bank.reset(-1)
+        if keep_ids and self.tracker in ("byte_track", "bot_sort"):
+            self.bank.reset(-1, keep_ids=True)
+        else:
+            self.bank.reset(-1)
         for est in (getattr(self, "cmc", None) or []):
             est.reset()
         self.frames_done = 0
