@@ -15,6 +15,7 @@
  * float32 product) until multi_predict / multi_gmc / update turn them into float64 arrays.
  */
 #include "orc.h"
+#include "lapack_order.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -106,21 +107,6 @@ static void kf_predict(strk *k, int all_f32)            /* multi_predict :155-19
     for (int i = 0; i < 4; ++i) k->mean[i] = k->mean[i] + k->mean[i + 4];
     k->f32 = 0;
 }
-static void chol_lower4(const double *a, double *L)
-{
-    memset(L, 0, sizeof(double) * 16);
-    for (int j = 0; j < 4; ++j) {
-        double s = a[j * 4 + j];
-        for (int k = 0; k < j; ++k) s -= L[j * 4 + k] * L[j * 4 + k];
-        const double d = sqrt(s);
-        L[j * 4 + j] = d;
-        for (int i = j + 1; i < 4; ++i) {
-            double v = a[i * 4 + j];
-            for (int k = 0; k < j; ++k) v -= L[i * 4 + k] * L[j * 4 + k];
-            L[i * 4 + j] = v / d;
-        }
-    }
-}
 static void kf_project(const strk *k, double *pm, double *S)             /* :126-153 */
 {
     double d[4];
@@ -134,41 +120,23 @@ static void kf_project(const strk *k, double *pm, double *S)             /* :126
     }
     for (int i = 0; i < 4; ++i) { pm[i] = k->mean[i]; for (int j = 0; j < 4; ++j) S[i * 4 + j] = k->cov[i * 8 + j] + (i == j ? d[i] : 0.0); }
 }
-static void kf_update(strk *k, const float *z32)                         /* :195-224 */
+static void kf_update(strk *k, const float *z32)                         /* :195-224; library operation order: lapack_order.h */
 {
-    double *mean = k->mean, *cov = k->cov;
-    double pm[4], S[16], L[16], X[32], K[32], Bm[32];
+    double pm[4], S[16];
     kf_project(k, pm, S);
-    chol_lower4(S, L);
-    for (int c = 0; c < 8; ++c) {
-        double y[4];
-        for (int i = 0; i < 4; ++i) { double v = cov[c * 8 + i]; for (int q = 0; q < i; ++q) v -= L[i * 4 + q] * y[q]; y[i] = v / L[i * 4 + i]; }
-        for (int i = 3; i >= 0; --i) { double v = y[i]; for (int q = i + 1; q < 4; ++q) v -= L[q * 4 + i] * X[q * 8 + c]; X[i * 8 + c] = v / L[i * 4 + i]; }
-    }
-    for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) K[i * 4 + j] = X[j * 8 + i];
-    double inn[4];
-    for (int j = 0; j < 4; ++j) inn[j] = (double)z32[j] - pm[j];
-    for (int i = 0; i < 8; ++i) { double s = 0; for (int j = 0; j < 4; ++j) s += inn[j] * K[i * 4 + j]; mean[i] = mean[i] + s; }
-    for (int j = 0; j < 4; ++j) for (int c = 0; c < 8; ++c) { double s = 0; for (int q = 0; q < 4; ++q) s += S[j * 4 + q] * K[c * 4 + q]; Bm[j * 8 + c] = s; }
-    for (int i = 0; i < 8; ++i) for (int c = 0; c < 8; ++c) { double s = 0; for (int j = 0; j < 4; ++j) s += K[i * 4 + j] * Bm[j * 8 + c]; cov[i * 8 + c] = cov[i * 8 + c] - s; }
+    const double z[4] = {(double)z32[0], (double)z32[1], (double)z32[2], (double)z32[3]};
+    lo_kf8_update(k->mean, k->cov, z, pm, S);
     k->f32 = 0;
 }
 /* gating_distance(..., metric="maha") :226-270 against float32 xywh measurements */
 static void kf_gating(const strk *k, const float *meas, int n, double *out)
 {
-    double pm[4], S[16], L[16];
+    double pm[4], S[16];
     kf_project(k, pm, S);
-    chol_lower4(S, L);
-    for (int m = 0; m < n; ++m) {
-        double zz[4], acc = 0;
-        for (int i = 0; i < 4; ++i) {
-            double v = (double)meas[m * 4 + i] - pm[i];
-            for (int q = 0; q < i; ++q) v -= L[i * 4 + q] * zz[q];
-            zz[i] = v / L[i * 4 + i];
-        }
-        for (int i = 0; i < 4; ++i) acc += zz[i] * zz[i];
-        out[m] = acc;
-    }
+    double *m64 = malloc(sizeof(double) * 4 * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < 4 * n; ++i) m64[i] = (double)meas[i];
+    lo_kf8_gating(pm, S, 4, m64, n, out);
+    free(m64);
 }
 
 /* ---- boxes ---- */
@@ -260,10 +228,12 @@ static void gmc_apply(strk *k, const double *H)
         m[2 * b + 1] = R[2] * k->mean[2 * b] + R[3] * k->mean[2 * b + 1];
     }
     m[0] += t[0]; m[1] += t[1];
+    /* R8x8.dot(cov).dot(R8x8.T): two dgemm calls, every element an fma chain over k ascending from 0 (lapack_order.h); the zero blocks of
+     * kron(I4, R) leave fma(r_b, c_b, r_a * c_a) with a < b */
     for (int i = 0; i < 8; ++i)                 /* t1 = R8 cov: row i mixes rows 2*(i/2), 2*(i/2)+1 */
-        for (int j = 0; j < 8; ++j) { const int r0 = i & ~1; t1[i * 8 + j] = R[(i & 1) * 2] * k->cov[r0 * 8 + j] + R[(i & 1) * 2 + 1] * k->cov[(r0 + 1) * 8 + j]; }
+        for (int j = 0; j < 8; ++j) { const int r0 = i & ~1; t1[i * 8 + j] = fma(R[(i & 1) * 2 + 1], k->cov[(r0 + 1) * 8 + j], R[(i & 1) * 2] * k->cov[r0 * 8 + j]); }
     for (int i = 0; i < 8; ++i)                 /* c2 = t1 R8^T: column j mixes columns 2*(j/2), 2*(j/2)+1 */
-        for (int j = 0; j < 8; ++j) { const int c0 = j & ~1; c2[i * 8 + j] = t1[i * 8 + c0] * R[(j & 1) * 2] + t1[i * 8 + c0 + 1] * R[(j & 1) * 2 + 1]; }
+        for (int j = 0; j < 8; ++j) { const int c0 = j & ~1; c2[i * 8 + j] = fma(t1[i * 8 + c0 + 1], R[(j & 1) * 2 + 1], t1[i * 8 + c0] * R[(j & 1) * 2]); }
     memcpy(k->mean, m, sizeof(m)); memcpy(k->cov, c2, sizeof(c2));
 }
 

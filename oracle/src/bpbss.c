@@ -1,6 +1,7 @@
 /* CPU ORACLE (test infrastructure) -- see orc.h.
  * BPBReID-StrongSORT restated from plugins/track/bpbreid_strong_sort/(strong_sort.py and the sort package). */
 #include "orc.h"
+#include "lapack_order.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -38,59 +39,18 @@ void orc_kf8_project(const double *mean, const double *cov, double conf, double 
     }
 }
 
-static void chol_lower(const double *a, int n, double *L)     /* LAPACK dpotrf (lower), row-by-row form */
+void orc_kf8_update(double *mean, double *cov, const double *z, double conf)    /* :154-187; library operation order: lapack_order.h */
 {
-    memset(L, 0, sizeof(double) * (size_t)n * n);
-    for (int j = 0; j < n; ++j) {
-        double s = a[j * n + j];
-        for (int k = 0; k < j; ++k) s -= L[j * n + k] * L[j * n + k];
-        double d = sqrt(s);
-        L[j * n + j] = d;
-        for (int i = j + 1; i < n; ++i) {
-            double v = a[i * n + j];
-            for (int k = 0; k < j; ++k) v -= L[i * n + k] * L[j * n + k];
-            L[i * n + j] = v / d;
-        }
-    }
-}
-
-void orc_kf8_update(double *mean, double *cov, const double *z, double conf)    /* :154-187 */
-{
-    double pm[4], S[16], L[16], B[32], X[32], K[32];
+    double pm[4], S[16];
     orc_kf8_project(mean, cov, conf, pm, S);
-    chol_lower(S, 4, L);
-    /* cho_solve(S, (cov H^T)^T): columns of B^T = rows of cov[:, :4] */
-    for (int c = 0; c < 8; ++c) {
-        double y[4];
-        for (int i = 0; i < 4; ++i) { double v = cov[c * 8 + i]; for (int k = 0; k < i; ++k) v -= L[i * 4 + k] * y[k]; y[i] = v / L[i * 4 + i]; }
-        for (int i = 3; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < 4; ++k) v -= L[k * 4 + i] * X[k * 8 + c]; X[i * 8 + c] = v / L[i * 4 + i]; }
-    }
-    for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) K[i * 4 + j] = X[j * 8 + i];
-    double inn[4];
-    for (int j = 0; j < 4; ++j) inn[j] = z[j] - pm[j];
-    for (int i = 0; i < 8; ++i) { double s = 0; for (int j = 0; j < 4; ++j) s += inn[j] * K[i * 4 + j]; mean[i] = mean[i] + s; }
-    /* cov - K (S K^T) */
-    for (int j = 0; j < 4; ++j) for (int c = 0; c < 8; ++c) { double s = 0; for (int k = 0; k < 4; ++k) s += S[j * 4 + k] * K[c * 4 + k]; B[j * 8 + c] = s; }
-    for (int i = 0; i < 8; ++i) for (int c = 0; c < 8; ++c) { double s = 0; for (int j = 0; j < 4; ++j) s += K[i * 4 + j] * B[j * 8 + c]; cov[i * 8 + c] = cov[i * 8 + c] - s; }
+    lo_kf8_update(mean, cov, z, pm, S);
 }
 
 void orc_kf8_gating(const double *mean, const double *cov, const double *meas, int n, int only_position, double *out)   /* :189-227 */
 {
-    double pm[4], S[16], Sd[16], L[16];
+    double pm[4], S[16];
     orc_kf8_project(mean, cov, 0.0, pm, S);
-    int d = only_position ? 2 : 4;
-    for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) Sd[i * d + j] = S[i * 4 + j];
-    chol_lower(Sd, d, L);
-    for (int m = 0; m < n; ++m) {
-        double zz[4], acc = 0;
-        for (int i = 0; i < d; ++i) {
-            double v = meas[m * 4 + i] - pm[i];
-            for (int k = 0; k < i; ++k) v -= L[i * d + k] * zz[k];
-            zz[i] = v / L[i * d + i];
-        }
-        for (int i = 0; i < d; ++i) acc += zz[i] * zz[i];
-        out[m] = acc;
-    }
+    lo_kf8_gating(pm, S, only_position ? 2 : 4, meas, n, out);
 }
 
 /* ------------------------------------------------------------------ nn_matching.py:99-135 (+ restated torchreid fn) */

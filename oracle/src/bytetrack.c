@@ -17,6 +17,7 @@
  * track's mean stays float32 until its first predict or update, and noise terms taken from a float32 mean are float32 products.
  */
 #include "orc.h"
+#include "lapack_order.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -85,41 +86,16 @@ static void kf_predict(btrk *k, int all_f32)
     for (int i = 0; i < 4; ++i) k->mean[i] = k->mean[i] + k->mean[i + 4];
     k->f32 = 0;
 }
-static void chol_lower4(const double *a, double *L)
-{
-    memset(L, 0, sizeof(double) * 16);
-    for (int j = 0; j < 4; ++j) {
-        double s = a[j * 4 + j];
-        for (int k = 0; k < j; ++k) s -= L[j * 4 + k] * L[j * 4 + k];
-        const double d = sqrt(s);
-        L[j * 4 + j] = d;
-        for (int i = j + 1; i < 4; ++i) {
-            double v = a[i * 4 + j];
-            for (int k = 0; k < j; ++k) v -= L[i * 4 + k] * L[j * 4 + k];
-            L[i * 4 + j] = v / d;
-        }
-    }
-}
 static void kf_update(btrk *k, const float *z32)         /* :195-224 with project :126-153 */
 {
     double *mean = k->mean, *cov = k->cov;
     double sp;
     if (k->f32) { const float s = (float)WP * (float)mean[3]; sp = s; } else sp = WP * mean[3];
     const double std[4] = {sp, sp, 1e-1, sp};
-    double pm[4], S[16], L[16], X[32], K[32], Bm[32];
+    double pm[4], S[16];
     for (int i = 0; i < 4; ++i) { pm[i] = mean[i]; for (int j = 0; j < 4; ++j) S[i * 4 + j] = cov[i * 8 + j] + (i == j ? std[i] * std[i] : 0.0); }
-    chol_lower4(S, L);
-    for (int c = 0; c < 8; ++c) {
-        double y[4];
-        for (int i = 0; i < 4; ++i) { double v = cov[c * 8 + i]; for (int q = 0; q < i; ++q) v -= L[i * 4 + q] * y[q]; y[i] = v / L[i * 4 + i]; }
-        for (int i = 3; i >= 0; --i) { double v = y[i]; for (int q = i + 1; q < 4; ++q) v -= L[q * 4 + i] * X[q * 8 + c]; X[i * 8 + c] = v / L[i * 4 + i]; }
-    }
-    for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) K[i * 4 + j] = X[j * 8 + i];
-    double inn[4];
-    for (int j = 0; j < 4; ++j) inn[j] = (double)z32[j] - pm[j];
-    for (int i = 0; i < 8; ++i) { double s = 0; for (int j = 0; j < 4; ++j) s += inn[j] * K[i * 4 + j]; mean[i] = mean[i] + s; }
-    for (int j = 0; j < 4; ++j) for (int c = 0; c < 8; ++c) { double s = 0; for (int q = 0; q < 4; ++q) s += S[j * 4 + q] * K[c * 4 + q]; Bm[j * 8 + c] = s; }
-    for (int i = 0; i < 8; ++i) for (int c = 0; c < 8; ++c) { double s = 0; for (int j = 0; j < 4; ++j) s += K[i * 4 + j] * Bm[j * 8 + c]; cov[i * 8 + c] = cov[i * 8 + c] - s; }
+    const double z[4] = {(double)z32[0], (double)z32[1], (double)z32[2], (double)z32[3]};
+    lo_kf8_update(mean, cov, z, pm, S);          /* cho_factor / cho_solve / np.dot / multi_dot in the libraries' operation order (lapack_order.h) */
     k->f32 = 0;
 }
 

@@ -20,6 +20,7 @@
  *   iou(): candidates are float32 -> their bottom-right corner and area are float32 sums/products.
  */
 #include "orc.h"
+#include "lapack_order.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -100,53 +101,17 @@ static void kf_project(const double *mean, const double *cov, double conf, doubl
         for (int j = 0; j < 4; ++j) pc[i * 4 + j] = cov[i * 8 + j] + (i == j ? s * s : 0.0);
     }
 }
-static void chol_lower(const double *a, int n, double *L)
+static void kf_update(double *mean, double *cov, const double *z, double conf)                    /* :154-187; library operation order: lapack_order.h */
 {
-    memset(L, 0, sizeof(double) * (size_t)n * n);
-    for (int j = 0; j < n; ++j) {
-        double s = a[j * n + j];
-        for (int k = 0; k < j; ++k) s -= L[j * n + k] * L[j * n + k];
-        double d = sqrt(s);
-        L[j * n + j] = d;
-        for (int i = j + 1; i < n; ++i) {
-            double v = a[i * n + j];
-            for (int k = 0; k < j; ++k) v -= L[i * n + k] * L[j * n + k];
-            L[i * n + j] = v / d;
-        }
-    }
-}
-static void kf_update(double *mean, double *cov, const double *z, double conf)                    /* :154-187 */
-{
-    double pm[4], S[16], L[16], X[32], K[32], B[32];
+    double pm[4], S[16];
     kf_project(mean, cov, conf, pm, S);
-    chol_lower(S, 4, L);
-    for (int c = 0; c < 8; ++c) {
-        double y[4];
-        for (int i = 0; i < 4; ++i) { double v = cov[c * 8 + i]; for (int k = 0; k < i; ++k) v -= L[i * 4 + k] * y[k]; y[i] = v / L[i * 4 + i]; }
-        for (int i = 3; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < 4; ++k) v -= L[k * 4 + i] * X[k * 8 + c]; X[i * 8 + c] = v / L[i * 4 + i]; }
-    }
-    for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) K[i * 4 + j] = X[j * 8 + i];
-    double inn[4];
-    for (int j = 0; j < 4; ++j) inn[j] = z[j] - pm[j];
-    for (int i = 0; i < 8; ++i) { double s = 0; for (int j = 0; j < 4; ++j) s += inn[j] * K[i * 4 + j]; mean[i] = mean[i] + s; }
-    for (int j = 0; j < 4; ++j) for (int c = 0; c < 8; ++c) { double s = 0; for (int k = 0; k < 4; ++k) s += S[j * 4 + k] * K[c * 4 + k]; B[j * 8 + c] = s; }
-    for (int i = 0; i < 8; ++i) for (int c = 0; c < 8; ++c) { double s = 0; for (int j = 0; j < 4; ++j) s += K[i * 4 + j] * B[j * 8 + c]; cov[i * 8 + c] = cov[i * 8 + c] - s; }
+    lo_kf8_update(mean, cov, z, pm, S);
 }
 static void kf_gating(const double *mean, const double *cov, const double *meas, int n, double *out)   /* :189-214, 4 dof */
 {
-    double pm[4], S[16], L[16];
+    double pm[4], S[16];
     kf_project(mean, cov, 0.0, pm, S);
-    chol_lower(S, 4, L);
-    for (int m = 0; m < n; ++m) {
-        double zz[4], acc = 0;
-        for (int i = 0; i < 4; ++i) {
-            double v = meas[m * 4 + i] - pm[i];
-            for (int k = 0; k < i; ++k) v -= L[i * 4 + k] * zz[k];
-            zz[i] = v / L[i * 4 + i];
-        }
-        for (int i = 0; i < 4; ++i) acc += zz[i] * zz[i];
-        out[m] = acc;
-    }
+    lo_kf8_gating(pm, S, 4, meas, n, out);
 }
 
 static void trk_tlwh(const strk *k, double *o)          /* track.py:99-111 */
@@ -403,8 +368,10 @@ void orc_ssort_camera_update(orc_ssort *t, const double *warp6)
             r2 *= r3; r0 -= r2 / 2; r1 -= r3 / 2;
             x1 = r0; y1 = r1; x2 = r0 + r2; y2 = r1 + r3;
         }
-        const double x1_ = M[0] * x1 + M[1] * y1 + M[2] * 1.0, y1_ = M[3] * x1 + M[4] * y1 + M[5] * 1.0;
-        const double x2_ = M[0] * x2 + M[1] * y2 + M[2] * 1.0, y2_ = M[3] * x2 + M[4] * y2 + M[5] * 1.0;
+        /* matrix @ [x, y, 1]: numpy's 3 x 3 matrix-vector product evaluates fma(m0, x, m1 * y) + m2 * 1 (identified against numpy itself,
+         * tools/blas_order_probe.py) */
+        const double x1_ = fma(M[0], x1, M[1] * y1) + M[2] * 1.0, y1_ = fma(M[3], x1, M[4] * y1) + M[5] * 1.0;
+        const double x2_ = fma(M[0], x2, M[1] * y2) + M[2] * 1.0, y2_ = fma(M[3], x2, M[4] * y2) + M[5] * 1.0;
         const double w = x2_ - x1_, h = y2_ - y1_, cx = x1_ + w / 2, cy = y1_ + h / 2;
         const double nm[4] = {cx, cy, w / h, h};
         for (int q = 0; q < 4; ++q) k->mean[q] = k->f32_state ? (double)(float)nm[q] : nm[q];

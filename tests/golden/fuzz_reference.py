@@ -20,6 +20,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 WHICH = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else {"ocsort", "bpbss", "bytetrack", "botsort", "deepocsort", "ssort"}
 IMG = np.zeros((1080, 1920, 3), np.uint8)
 BIG = int(os.environ.get("FUZZ_MAX_OBJECTS", "0"))          # > 0: streams with up to this many objects (crowded scenes)
+FIRST = int(os.environ.get("FUZZ_FIRST", "0"))              # first trial index (trials are seeded by their index: ranges can run in parallel)
+EXACT = {"rows": 0, "kf_bits_equal": 0}                     # r03: how many Kalman boxes are BIT-identical to the reference's (bpbss)
 
 
 def nobj(rng, lo, hi):
@@ -197,7 +199,9 @@ def fuzz_bpbss(trial, rng):
         exp_tid = np.array([int(t) for t in df.track_id], dtype=np.int64) if len(df) else np.zeros(0, np.int64)
         ok = len(got) == len(df) and np.array_equal(got["det_id"], exp_idx) and np.array_equal(got["track_id"], exp_tid)
         if ok and len(df):
-            ok = np.allclose(got["kf_ltwh"], np.stack([np.asarray(b, dtype=np.float64) for b in df.track_bbox_kf_ltwh]), rtol=1e-7, atol=1e-7) and \
+            ref_kf = np.stack([np.asarray(b, dtype=np.float64) for b in df.track_bbox_kf_ltwh])
+            EXACT["rows"] += len(df); EXACT["kf_bits_equal"] += int((got["kf_ltwh"] == ref_kf).all(axis=1).sum())
+            ok = np.allclose(got["kf_ltwh"], ref_kf, rtol=1e-7, atol=1e-7) and \
                 np.array_equal(got["hits"], df.hits.to_numpy().astype(np.int32)) and np.array_equal(got["tsu"], df.time_since_update.to_numpy().astype(np.int32))
         if not ok:
             print(f"DIVERGENCE bpbss trial {trial} frame {fr['frame']} cfg {cfg}")
@@ -324,9 +328,10 @@ def fuzz_deepocsort_cmc(trial, rng):
 FUZZ = {"ssort_cam": fuzz_ssort_cam, "botsort_gmc": fuzz_botsort_gmc, "deepocsort_cmc": fuzz_deepocsort_cmc, "ocsort": fuzz_ocsort, "bpbss": fuzz_bpbss, "bytetrack": fuzz_bytetrack, "botsort": fuzz_botsort, "deepocsort": fuzz_deepocsort, "ssort": fuzz_ssort}
 for name in sorted(WHICH):
     ok = 0
-    for t in range(N):
+    for t in range(FIRST, FIRST + N):
         try:
             ok += bool(FUZZ[name](t, np.random.default_rng(9000 + t)))
         except Exception as ex:                             # a reference-side crash on odd hyper-parameters is reported, not fatal
             print(f"EXCEPTION {name} trial {t}: {type(ex).__name__}: {ex}")
-    print(f"{name}: {ok}/{N} trials identical to the reference")
+    print(f"{name}: {ok}/{N} trials identical to the reference" + (f" (trials {FIRST}..{FIRST + N - 1})" if FIRST else "") +
+          (f"; Kalman boxes bit-identical: {EXACT['kf_bits_equal']}/{EXACT['rows']} rows" if name == "bpbss" else ""))

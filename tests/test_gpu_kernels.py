@@ -136,7 +136,7 @@ def test_kf8_stateless_golden_and_oracle(orc):
     n = 32
     mean, cov = _lib.kf8_initiate(_cuda(g["meas"]))
     np.testing.assert_array_equal(mean.cpu().numpy(), g["init_mean"])
-    np.testing.assert_allclose(cov.cpu().numpy(), g["init_cov"], rtol=1e-15)
+    np.testing.assert_array_equal(cov.cpu().numpy(), g["init_cov"])
     # case i is predicted i % 4 + 1 times: run 4 rounds, freezing the cases that are done
     m_np, c_np = mean.cpu().numpy().copy(), cov.cpu().numpy().copy()
     for rnd in range(4):
@@ -145,21 +145,24 @@ def test_kf8_stateless_golden_and_oracle(orc):
         _lib.kf8_predict_(ms, cs)
         m_np[sel], c_np[sel] = ms.cpu().numpy(), cs.cpu().numpy()
     np.testing.assert_array_equal(m_np, g["pred_mean"])
-    np.testing.assert_allclose(c_np, g["pred_cov"], rtol=1e-14, atol=1e-14)
+    np.testing.assert_array_equal(c_np, g["pred_cov"])
     mean, cov, conf = _cuda(m_np), _cuda(c_np), _cuda(g["conf"])
     pm, pc = _lib.kf8_project(mean, cov, conf)
     np.testing.assert_array_equal(pm.cpu().numpy(), g["proj_mean"])
-    np.testing.assert_allclose(pc.cpu().numpy(), g["proj_cov"], rtol=1e-14, atol=1e-14)
+    np.testing.assert_array_equal(pc.cpu().numpy(), g["proj_cov"])
     z = np.stack([g[f"z{i}"] for i in range(n)])
     for only_pos, key in ((False, "gate4"), (True, "gate2")):
         gate = _lib.kf8_gate(mean, cov, _cuda(z), only_pos).cpu().numpy()          # (32 filters) x (32 measurements)
         for i in range(n):
-            np.testing.assert_allclose(gate[i, i], g[key][i][i % 50], rtol=1e-9)
+            assert gate[i, i] == g[key][i][i % 50]        # bit-exact since r03 (LAPACK operation order, tlk_strongsort_common.hpp); both calls have >= 2 measurements
             np.testing.assert_array_equal(gate[i], orc.kf8_gating(m_np[i], c_np[i], z, only_pos))
+        one = _lib.kf8_gate(mean, cov, _cuda(z[:1]), only_pos).cpu().numpy()        # ONE measurement: the library's trsv path (division, dot form)
+        for i in range(n):
+            np.testing.assert_array_equal(one[i], orc.kf8_gating(m_np[i], c_np[i], z[:1], only_pos))
     _lib.kf8_update_(mean, cov, _cuda(z), conf)
     mu, cu = mean.cpu().numpy(), cov.cpu().numpy()
-    np.testing.assert_allclose(mu, g["upd_mean"], rtol=1e-11, atol=1e-11)
-    np.testing.assert_allclose(cu, g["upd_cov"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_array_equal(mu, g["upd_mean"])           # bit-exact against the reference since r03
+    np.testing.assert_array_equal(cu, g["upd_cov"])
     for i in range(n):
         om, oc = orc.kf8_update(m_np[i], c_np[i], z[i], g["conf"][i])
         np.testing.assert_array_equal(mu[i], om); np.testing.assert_array_equal(cu[i], oc)

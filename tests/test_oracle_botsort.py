@@ -46,8 +46,8 @@ def check_lists_exact(trk, g, f):
         ids, mean, cov, st, feat = trk.tracks(which)
         np.testing.assert_array_equal(ids, g[f"f{f}_{ln}_ids"])          # list membership AND order
         np.testing.assert_array_equal(st, g[f"f{f}_{ln}_state"])         # state, is_activated, frame_id, start_frame, tracklet_len
-        np.testing.assert_allclose(mean, g[f"f{f}_{ln}_mean"], rtol=1e-11, atol=1e-11)
-        np.testing.assert_allclose(cov, g[f"f{f}_{ln}_cov"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(mean, g[f"f{f}_{ln}_mean"], rtol=0, atol=0)
+        np.testing.assert_allclose(cov, g[f"f{f}_{ln}_cov"], rtol=0, atol=0)
         np.testing.assert_allclose(feat, g[f"f{f}_{ln}_feat"], rtol=0, atol=5e-7)    # float32 EMA + renorm, summation order of the norm
 
 
@@ -67,10 +67,10 @@ def test_botsort_oracle_with_camera_motion_warps_matches_reference(orc):
         exp = g["rows"][oo[f]:oo[f + 1]]
         assert out.shape == exp.shape, f
         np.testing.assert_array_equal(out[:, 4:], exp[:, 4:], err_msg=f"frame {f}")
-        np.testing.assert_allclose(out[:, :4], exp[:, :4], rtol=1e-11, atol=1e-9, err_msg=f"frame {f}")
+        np.testing.assert_allclose(out[:, :4], exp[:, :4], rtol=0, atol=0, err_msg=f"frame {f}")
         if f"f{f}_trk_ids" in g.files:
             for which, ln in ((0, "trk"), (1, "lost")):
                 ids, mean, cov = trk.tracks(which)[:3]
                 np.testing.assert_array_equal(ids, g[f"f{f}_{ln}_ids"])
-                np.testing.assert_allclose(mean, g[f"f{f}_{ln}_mean"], rtol=1e-11, atol=1e-10)
-                np.testing.assert_allclose(cov, g[f"f{f}_{ln}_cov"], rtol=1e-9, atol=1e-9)
+                np.testing.assert_allclose(mean, g[f"f{f}_{ln}_mean"], rtol=0, atol=0)
+                np.testing.assert_allclose(cov, g[f"f{f}_{ln}_cov"], rtol=0, atol=0)

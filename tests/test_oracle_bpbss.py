@@ -43,7 +43,7 @@ def bpbss_inputs(g):
     return frames
 
 
-def check_bpbss_rows(g, f, rows, rtol=1e-7, atol=1e-7):
+def check_bpbss_rows(g, f, rows, rtol=0, atol=0):
     oo = g["out_offsets"]
     a, b = oo[f], oo[f + 1]
     assert len(rows) == b - a, f"frame {f}: {len(rows)} rows vs {b - a}"
@@ -74,34 +74,56 @@ def test_bpbss_oracle_matches_reference(orc, path):
         if f"f{f}_track_ids" in g:
             tid, mean, cov, feat, fvis = trk.tracks()
             np.testing.assert_array_equal(tid, g[f"f{f}_track_ids"])
-            np.testing.assert_allclose(mean, g[f"f{f}_mean"], rtol=1e-8, atol=1e-8)
-            np.testing.assert_allclose(cov, g[f"f{f}_cov"], rtol=1e-7, atol=1e-9)
+            np.testing.assert_allclose(mean, g[f"f{f}_mean"], rtol=0, atol=0)
+            np.testing.assert_allclose(cov, g[f"f{f}_cov"], rtol=0, atol=0)
             np.testing.assert_array_equal(feat, g[f"f{f}_feat"])                 # fp32 EMA: same op order -> bit-exact
             np.testing.assert_array_equal(fvis.astype(bool), g[f"f{f}_fvis"].astype(bool))
 
 
 def test_kf8_unit_vectors(orc):
+    """Every stage of the reference's KalmanFilter (initiate, predict, project, gating_distance against its evolving 50-candidate set in 4 and 2
+    dimensions, update) BIT-exact since r03 (oracle/src/lapack_order.h reproduces the operation order of the LAPACK / BLAS routines behind
+    scipy.linalg.cho_factor / cho_solve / solve_triangular and np.dot / np.linalg.cholesky)."""
     g = np.load(os.path.join(GOLDEN, "kf8_cases.npz"))
-    cand = None
-    rng_cand = np.random.default_rng(21)     # replay of make_golden.gen_kf8's candidate evolution is stored per case
+    rng = np.random.default_rng(21)          # replay of make_golden.gen_kf8's draws: measurements, confidences, the initial candidate set
+    meas = np.stack([rng.uniform(100, 1800, 32), rng.uniform(100, 1000, 32), rng.uniform(0.3, 0.6, 32), rng.uniform(80, 300, 32)], 1)
+    confs = rng.uniform(0.3, 1.0, 32)
+    cand = np.stack([rng.uniform(100, 1800, 50), rng.uniform(100, 1000, 50), rng.uniform(0.3, 0.6, 50), rng.uniform(80, 300, 50)], 1)
+    np.testing.assert_array_equal(meas, g["meas"]); np.testing.assert_array_equal(confs, g["conf"])
     for i in range(32):
         mean, cov = orc.kf8_initiate(g["meas"][i])
-        np.testing.assert_array_equal(mean, g["init_mean"][i])
-        np.testing.assert_allclose(cov, g["init_cov"][i], rtol=1e-15)
+        np.testing.assert_array_equal(mean, g["init_mean"][i]); np.testing.assert_array_equal(cov, g["init_cov"][i])
         for _ in range(i % 4 + 1):
             mean, cov = orc.kf8_predict(mean, cov)
-        np.testing.assert_array_equal(mean, g["pred_mean"][i])
-        np.testing.assert_allclose(cov, g["pred_cov"][i], rtol=1e-14, atol=1e-14)
+        np.testing.assert_array_equal(mean, g["pred_mean"][i]); np.testing.assert_array_equal(cov, g["pred_cov"][i])
         pm, pc = orc.kf8_project(mean, cov, g["conf"][i])
-        np.testing.assert_array_equal(pm, g["proj_mean"][i])
-        np.testing.assert_allclose(pc, g["proj_cov"][i], rtol=1e-14, atol=1e-14)
+        np.testing.assert_array_equal(pm, g["proj_mean"][i]); np.testing.assert_array_equal(pc, g["proj_cov"][i])
         z = g[f"z{i}"]
-        # gating: the measurement itself and a far point; the golden stores the distances of its evolving candidate
-        # set, of which entry i%50 is z
-        d4 = orc.kf8_gating(mean, cov, z[None], False)[0]
-        d2 = orc.kf8_gating(mean, cov, z[None], True)[0]
-        np.testing.assert_allclose(d4, g["gate4"][i][i % 50], rtol=1e-9)
-        np.testing.assert_allclose(d2, g["gate2"][i][i % 50], rtol=1e-9)
+        cand[i % 50] = z                     # the golden's candidate set evolves: entry i % 50 becomes this case's measurement
+        np.testing.assert_array_equal(orc.kf8_gating(mean, cov, cand.copy(), False), g["gate4"][i])
+        np.testing.assert_array_equal(orc.kf8_gating(mean, cov, cand.copy(), True), g["gate2"][i])
         m2, c2 = orc.kf8_update(mean, cov, z, g["conf"][i])
-        np.testing.assert_allclose(m2, g["upd_mean"][i], rtol=1e-11, atol=1e-11)
-        np.testing.assert_allclose(c2, g["upd_cov"][i], rtol=1e-9, atol=1e-10)
+        np.testing.assert_array_equal(m2, g["upd_mean"][i]); np.testing.assert_array_equal(c2, g["upd_cov"][i])
+    np.testing.assert_array_equal(cand, g["cand_last"])
+
+
+def test_kf8_gating_with_a_single_measurement_follows_the_trsv_path(orc):
+    """scipy.linalg.solve_triangular with ONE right-hand side takes OpenBLAS's trsv (dot form, division) instead of trsm (column form, reciprocal):
+    the values differ in the last bit, so the oracle switches on the number of measurements like the library does. Checked against the two
+    library calls of kalman_filter.py:189-227 themselves (numpy / scipy are installed wherever the CPU suite runs)."""
+    import scipy.linalg
+    rng = np.random.default_rng(5)
+    for d, only in ((4, False), (2, True)):
+        for _ in range(50):
+            mean, cov = orc.kf8_initiate(np.array([rng.uniform(100, 1800), rng.uniform(100, 1000), rng.uniform(0.3, 0.6), rng.uniform(80, 300)]))
+            for _ in range(3):
+                mean, cov = orc.kf8_predict(mean, cov)
+            mean, cov = orc.kf8_update(mean, cov, mean[:4] + rng.normal(0, 2, 4) * [1, 1, 0.01, 1], 0.5)
+            z = mean[:4] + rng.normal(0, 3, 4) * [1, 1, 0.01, 1]
+            pm, S = orc.kf8_project(mean, cov, 0.0)
+            L = np.linalg.cholesky(S[:d, :d])
+            zz = scipy.linalg.solve_triangular(L, (z[None, :d] - pm[:d]).T, lower=True, check_finite=False, overwrite_b=True)
+            np.testing.assert_array_equal(orc.kf8_gating(mean, cov, z[None], only), np.sum(zz * zz, axis=0))
+            two = np.stack([z, z + 1.0])
+            zz = scipy.linalg.solve_triangular(L, (two[:, :d] - pm[:d]).T, lower=True, check_finite=False, overwrite_b=True)
+            np.testing.assert_array_equal(orc.kf8_gating(mean, cov, two, only), np.sum(zz * zz, axis=0))

@@ -25,7 +25,7 @@ def replay(name, make_tracker, check_lists=None):
         exp = g["rows"][oo[f]:oo[f + 1]]
         assert out.shape == exp.shape, f"{name} frame {f}"
         np.testing.assert_array_equal(out[:, 4:], exp[:, 4:], err_msg=f"{name} frame {f}")        # track id, class, score, tracklab id
-        np.testing.assert_allclose(out[:, :4], exp[:, :4], rtol=1e-11, atol=1e-10, err_msg=f"{name} frame {f}")
+        np.testing.assert_allclose(out[:, :4], exp[:, :4], rtol=0, atol=0, err_msg=f"{name} frame {f}")
         if check_lists is not None and f"f{f}_trk_ids" in g.files:
             check_lists(trk, g, f)
 
@@ -35,8 +35,8 @@ def check_lists_exact(trk, g, f):
         ids, mean, cov, st = trk.tracks(which)
         np.testing.assert_array_equal(ids, g[f"f{f}_{ln}_ids"])          # list membership AND order
         np.testing.assert_array_equal(st, g[f"f{f}_{ln}_state"])         # state, is_activated, frame_id, start_frame, tracklet_len
-        np.testing.assert_allclose(mean, g[f"f{f}_{ln}_mean"], rtol=1e-11, atol=1e-11)
-        np.testing.assert_allclose(cov, g[f"f{f}_{ln}_cov"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(mean, g[f"f{f}_{ln}_mean"], rtol=0, atol=0)
+        np.testing.assert_allclose(cov, g[f"f{f}_{ln}_cov"], rtol=0, atol=0)
 
 
 @pytest.mark.parametrize("name", RUNS)

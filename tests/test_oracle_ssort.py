@@ -46,8 +46,8 @@ def check_state_oracle(trk, g, f):
     np.testing.assert_array_equal(ids, g[f"f{f}_track_ids"])
     np.testing.assert_array_equal(st, g[f"f{f}_state"])          # hits, age, time_since_update, state, updates_wo_assignment
     np.testing.assert_array_equal(gl, g[f"f{f}_gallery"])        # len(metric.samples[track_id])
-    np.testing.assert_allclose(mean, g[f"f{f}_mean"], rtol=1e-11, atol=1e-11)
-    np.testing.assert_allclose(cov, g[f"f{f}_cov"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(mean, g[f"f{f}_mean"], rtol=0, atol=0)
+    np.testing.assert_allclose(cov, g[f"f{f}_cov"], rtol=0, atol=0)
     np.testing.assert_allclose(feat, g[f"f{f}_feat"], rtol=0, atol=5e-7)      # float32 EMA + renorm, summation order of the norm
 
 
@@ -73,4 +73,4 @@ def test_plain_strongsort_camera_update_matches_reference(orc):
         if f"f{f}_track_ids" in g.files:
             ids, mean = trk.tracks()[:2]
             np.testing.assert_array_equal(ids, g[f"f{f}_track_ids"])
-            np.testing.assert_allclose(mean, g[f"f{f}_mean"], rtol=1e-11, atol=1e-10)
+            np.testing.assert_allclose(mean, g[f"f{f}_mean"], rtol=0, atol=0)

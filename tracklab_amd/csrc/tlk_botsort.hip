@@ -59,11 +59,11 @@ __device__ __forceinline__ void bo_gmc_apply(double (&mean)[8], double (&cov)[64
 #pragma unroll
     for (int i = 0; i < 8; ++i)                 // t1 = R8 cov: row i mixes rows 2*(i/2), 2*(i/2)+1
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const int r0 = i & ~1; t1[i * 8 + j] = R[(i & 1) * 2] * cov[r0 * 8 + j] + R[(i & 1) * 2 + 1] * cov[(r0 + 1) * 8 + j]; }
+        for (int j = 0; j < 8; ++j) { const int r0 = i & ~1; t1[i * 8 + j] = fma(R[(i & 1) * 2 + 1], cov[(r0 + 1) * 8 + j], R[(i & 1) * 2] * cov[r0 * 8 + j]); }   // dgemm: fma chain over k
 #pragma unroll
     for (int i = 0; i < 8; ++i)                 // cov = t1 R8^T: column j mixes columns 2*(j/2), 2*(j/2)+1
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const int c0 = j & ~1; cov[i * 8 + j] = t1[i * 8 + c0] * R[(j & 1) * 2] + t1[i * 8 + c0 + 1] * R[(j & 1) * 2 + 1]; }
+        for (int j = 0; j < 8; ++j) { const int c0 = j & ~1; cov[i * 8 + j] = fma(t1[i * 8 + c0 + 1], R[(j & 1) * 2 + 1], t1[i * 8 + c0] * R[(j & 1) * 2]); }
 #pragma unroll
     for (int k = 0; k < 8; ++k) mean[k] = m[k];
 }
@@ -353,14 +353,17 @@ botsort_kernel(BoDev Dv, BoP P, BoIn in, tlk_botsort_row *__restrict__ rows_all,
     };
 
     // ---- first association: embedding distance fused with the Mahalanobis gate (:346-379) ----
-    for (int p = tid; p < n_pool; p += BLOCK) L.pre[p] = trk_at(L.pool[p]).i(OI_STATE);
+    // fuse_motion (matching.py:188-233) solves its triangular systems for all nhi measurements in one scipy.linalg.solve_triangular call, whose
+    // operation order depends on nhi == 1 (tlk_strongsort_common.hpp): finish the gate rows for this frame's count
+    const bool gate_single = nhi == 1;
+    for (int p = tid; p < n_pool; p += BLOCK) { L.pre[p] = trk_at(L.pool[p]).i(OI_STATE); gate_row_finish(gl + (size_t)p * GLD, 4, gate_single); }
     __syncthreads();
     const AsgOut A1 = lapjv_assign(n_pool, nhi, P.match_thresh, [&](int r, int c) {
         const int j = L.hi[c];
         double m[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) m[k] = (double)L.dxyah[j * 4 + k];
-        const double gd = gating_from(gl + (size_t)r * GLD, m, 4);
+        const double gd = gating_from(gl + (size_t)r * GLD, m, 4, gate_single);
         double e = dist[(size_t)L.ppos[r] * MAXD + L.sel[j]];
         if (gd > CHI2_4) e = INFINITY;
         return P.lambda_ * e + (1 - P.lambda_) * gd;

@@ -303,7 +303,10 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             L.dxyah[j * 4] = b[0] + b[2] / 2; L.dxyah[j * 4 + 1] = b[1] + b[3] / 2; L.dxyah[j * 4 + 2] = b[2] / b[3]; L.dxyah[j * 4 + 3] = b[3];
             L.d_mname[j] = 0; L.d_mdist[j] = 0.0;
         }
-        // per-track gating factors: projected mean + Cholesky of the projected covariance (conf = 0)
+        // per-track gating factors: projected mean + Cholesky of the projected covariance (conf = 0). Every gating_distance call of the frame
+        // (gate_cost_matrix / _full_cost_metric through the single-level matching_cascade) sees all N filtered detections: one
+        // solve_triangular call per track whose operation order depends on N == 1 (tlk_strongsort_common.hpp)
+        const bool gate_single = N == 1;
         for (int p = tid; p < T; p += BLOCK) {
             const BTrk Kt = trk_at(order[p]);
             const double h = Kt.d(BD_MEAN + 3);
@@ -315,6 +318,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             double *g = gl + (size_t)p * GLN;
             for (int i = 0; i < 4; ++i) g[i] = Kt.d(BD_MEAN + i);
             for (int q = 0; q < 16; ++q) g[4 + q] = Lc[q];
+            gate_row_finish(g, gdim, gate_single);
             if (use_oks) { int nv; g[20] = oks_scale([&](int q) { return Kt.d(BD_KP + q); }, &nv); g[21] = (double)nv; }
         }
         __syncthreads();
@@ -353,7 +357,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
                     }
                     for (int j = lane; j < N; j += WAVE) {
                         double c = reid[(size_t)p * MAXD + L.sel[j]];
-                        const double gd = gdim == 4 ? gating_reg<4>(gA, L.dxyah + j * 4) : gating_reg<2>(gA, L.dxyah + j * 4);
+                        const double gd = gdim == 4 ? gating_reg<4>(gA, L.dxyah + j * 4, gate_single) : gating_reg<2>(gA, L.dxyah + j * 4, gate_single);
                         if (gd > chi) c = INFTY_COST;
                         c = P.mc_lambda * c + (1 - P.mc_lambda) * gd;
                         cm[(size_t)r * N + j] = c > P.max_dist ? P.max_dist + 1e-5 : c;
@@ -372,7 +376,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
                 for (int k = tid; k < A.nm; k += BLOCK) {       // add_matching_information "R": un-thresholded gated cost (tracker.py:409-425)
                     const int p = L.m_t[k], j = L.m_d[k];
                     double c = reid[(size_t)p * MAXD + L.sel[j]];
-                    const double gd = gating_from(gl + (size_t)p * GLN, L.dxyah + j * 4, gdim);
+                    const double gd = gating_from(gl + (size_t)p * GLN, L.dxyah + j * 4, gdim, gate_single);
                     if (gd > CHI2INV95[gdim]) c = INFTY_COST;
                     L.d_mname[j] = 1; L.d_mdist[j] = P.mc_lambda * c + (1 - P.mc_lambda) * gd;
                 }
@@ -421,7 +425,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             const double GT = sqrt(CHI2INV95[gdim]);
             const double wsum = P.w_kfgd + P.w_reid + P.w_st;
             auto full_cost = [&](int p, int j) {
-                const double gd = gating_from(gl + (size_t)p * GLN, L.dxyah + j * 4, gdim);
+                const double gd = gating_from(gl + (size_t)p * GLN, L.dxyah + j * 4, gdim, gate_single);
                 const double pos = sqrt(gd) / (GT * P.gating_thres_factor);
                 const double app = reid[(size_t)p * MAXD + L.sel[j]];
                 const double st = motion_cost(p, j);
@@ -701,7 +705,8 @@ __global__ void __launch_bounds__(BLOCK) kf8_gate_kernel(const double *__restric
     for (int a = 0; a < 4; ++a) gl[a] = m[a];
 #pragma unroll
     for (int q = 0; q < 16; ++q) gl[4 + q] = Lc[q];
-    for (int j = threadIdx.x; j < N; j += BLOCK) out[(size_t)t * N + j] = gating_from(gl, meas + (size_t)j * 4, d);
+    gate_row_finish(gl, d, N == 1);
+    for (int j = threadIdx.x; j < N; j += BLOCK) out[(size_t)t * N + j] = gating_from(gl, meas + (size_t)j * 4, d, N == 1);
 }
 __global__ void __launch_bounds__(BLOCK) iou_ltwh_cost_kernel(const double *__restrict__ trk, int T, const double *__restrict__ det, int N,
                                                               double *__restrict__ out)

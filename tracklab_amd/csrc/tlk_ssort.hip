@@ -213,7 +213,9 @@ ssort_assoc_kernel(SsDev Dv, SsP P, SsIn in, tlk_ssort_row *__restrict__ rows_al
         L.dxyah[j * 4] = z0; L.dxyah[j * 4 + 1] = z1; L.dxyah[j * 4 + 2] = z2; L.dxyah[j * 4 + 3] = b3;
     }
     __syncthreads();
-    // per-track gating factors: projected mean + Cholesky of the projected covariance (confidence 0), kalman_filter.py:189-214
+    // per-track gating factors: projected mean + Cholesky of the projected covariance (confidence 0), kalman_filter.py:189-214; gate_cost_matrix
+    // hands all N detections to one solve_triangular call per track, whose operation order depends on N == 1 (tlk_strongsort_common.hpp)
+    const bool gate_single = N == 1;
     for (int p = tid; p < T; p += BLOCK) {
         const BTrk Kt = trk_at(order[p]);
         double sd[4], Sd[16], Lc[16];
@@ -224,6 +226,7 @@ ssort_assoc_kernel(SsDev Dv, SsP P, SsIn in, tlk_ssort_row *__restrict__ rows_al
         double *g = gl + (size_t)p * SGL;
         for (int i = 0; i < 4; ++i) g[i] = Kt.d(SD_MEAN + i);
         for (int q = 0; q < 16; ++q) g[4 + q] = Lc[q];
+        gate_row_finish(g, 4, gate_single);
     }
     __syncthreads();
     // ---------------- Tracker._match (tracker.py:152-188) ----------------
@@ -253,7 +256,7 @@ ssort_assoc_kernel(SsDev Dv, SsP P, SsIn in, tlk_ssort_row *__restrict__ rows_al
             }
             for (int j = lane; j < N; j += WAVE) {
                 double c = reid[(size_t)p * MAXD + L.sel[j]];
-                const double gd = gating_reg<4>(gA, L.dxyah + j * 4);
+                const double gd = gating_reg<4>(gA, L.dxyah + j * 4, gate_single);
                 if (gd > CHI2_4) c = INFTY_COST;
                 c = P.mc_lambda * c + (1 - P.mc_lambda) * gd;
                 cm[(size_t)r * N + j] = c > P.max_dist ? P.max_dist + 1e-5 : c;
@@ -484,8 +487,9 @@ __global__ void ssort_camera_kernel(SsDev D, int stream, SsWarp W)
                 r2 *= r3; r0 -= r2 / 2; r1 -= r3 / 2;
                 x1 = r0; y1 = r1; x2 = r0 + r2; y2 = r1 + r3;
             }
-            const double x1_ = M[0] * x1 + M[1] * y1 + M[2] * 1.0, y1_ = M[3] * x1 + M[4] * y1 + M[5] * 1.0;
-            const double x2_ = M[0] * x2 + M[1] * y2 + M[2] * 1.0, y2_ = M[3] * x2 + M[4] * y2 + M[5] * 1.0;
+            // numpy's 3 x 3 matrix-vector product: fma(m0, x, m1 * y) + m2 * 1 (oracle/src/ssort.c, identified against numpy itself)
+            const double x1_ = fma(M[0], x1, M[1] * y1) + M[2] * 1.0, y1_ = fma(M[3], x1, M[4] * y1) + M[5] * 1.0;
+            const double x2_ = fma(M[0], x2, M[1] * y2) + M[2] * 1.0, y2_ = fma(M[3], x2, M[4] * y2) + M[5] * 1.0;
             const double w = x2_ - x1_, h = y2_ - y1_, cx = x1_ + w / 2, cy = y1_ + h / 2;
             const double nm[4] = {cx, cy, w / h, h};
 #pragma unroll

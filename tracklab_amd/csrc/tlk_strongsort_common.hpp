@@ -11,19 +11,28 @@ constexpr double INFTY_COST = 1e+5;                    // sort/linear_assignment
 __device__ __constant__ double CHI2INV95[10] = {0, 3.8415, 5.9915, 7.8147, 9.4877, 11.070, 12.592, 14.067, 15.507, 16.919};
 constexpr double W_POS = 1. / 20, W_VEL = 1. / 160;   // sort/kalman_filter.py:50-51
 
-__device__ __forceinline__ void chol4(const double (&a)[16], int n, double (&L)[16])   // lower Cholesky of the leading n x n (stride n)
+// The small dense linear algebra below follows the OPERATION ORDER of the libraries the reference calls (scipy.linalg.cho_factor / cho_solve,
+// np.linalg.cholesky, scipy.linalg.solve_triangular, np.dot, np.linalg.multi_dot; kalman_filter.py:121-227 of both StrongSORT plugins), identified
+// by differential testing and restated in oracle/src/lapack_order.h, so that Kalman states are BIT-identical to the reference's (r03; before:
+// <= 1e-9, which in crowded scenes could re-order the Hungarian solver's choice among equal clamped costs):
+//   dpotrf (OpenBLAS potf2, lower): d_j = sqrt(a_jj - fma-chain dot), column below = (a_ij - fma-chain dot) * (1 / d_j)
+//   dtrsm  (cho_solve; solve_triangular with >= 2 right-hand sides): column-oriented, x_k *= 1 / l_kk, x_i = fma(-l_ik, x_k, x_i)
+//   dtrsv  (solve_triangular with ONE right-hand side): x_i = (b_i - fma-chain dot) / l_ii
+//   dgemm: fma chain over k from 0; dgemv of the 4-vector innovation: (p0 + p2) + (p1 + p3)
+__device__ __forceinline__ void chol4(const double (&a)[16], int n, double (&L)[16])   // lower Cholesky of the leading n x n (stride n), lower triangle read
 {
 #pragma unroll
     for (int q = 0; q < 16; ++q) L[q] = 0.0;
+    for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) L[i * n + j] = a[i * n + j];
     for (int j = 0; j < n; ++j) {
-        double sacc = a[j * n + j];
-        for (int k = 0; k < j; ++k) sacc -= L[j * n + k] * L[j * n + k];
-        const double d = sqrt(sacc);
+        double acc = 0.0;
+        for (int k = 0; k < j; ++k) acc = fma(L[j * n + k], L[j * n + k], acc);
+        const double d = sqrt(L[j * n + j] - acc), r = 1.0 / d;
         L[j * n + j] = d;
         for (int i = j + 1; i < n; ++i) {
-            double v = a[i * n + j];
-            for (int k = 0; k < j; ++k) v -= L[i * n + k] * L[j * n + k];
-            L[i * n + j] = v / d;
+            double t = 0.0;
+            for (int k = 0; k < j; ++k) t = fma(L[i * n + k], L[j * n + k], t);
+            L[i * n + j] = (L[i * n + j] - t) * r;
         }
     }
 }
@@ -34,17 +43,17 @@ __device__ __forceinline__ void chol4_full(const double (&a)[16], double (&L)[16
     for (int q = 0; q < 16; ++q) L[q] = 0.0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        double sacc = a[j * 4 + j];
+        double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (k < j) sacc -= L[j * 4 + k] * L[j * 4 + k];
-        const double d = sqrt(sacc);
+        for (int k = 0; k < 4; ++k) if (k < j) acc = fma(L[j * 4 + k], L[j * 4 + k], acc);
+        const double d = sqrt(a[j * 4 + j] - acc), r = 1.0 / d;
         L[j * 4 + j] = d;
 #pragma unroll
         for (int i = 0; i < 4; ++i) if (i > j) {
-            double v = a[i * 4 + j];
+            double t = 0.0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (k < j) v -= L[i * 4 + k] * L[j * 4 + k];
-            L[i * 4 + j] = v / d;
+            for (int k = 0; k < 4; ++k) if (k < j) t = fma(L[i * 4 + k], L[j * 4 + k], t);
+            L[i * 4 + j] = (a[i * 4 + j] - t) * r;
         }
     }
 }
@@ -52,7 +61,7 @@ __device__ __forceinline__ void chol4_full(const double (&a)[16], double (&L)[16
 // update with measurement-noise standard deviations sd[4] (kalman_filter.py project + update)
 __device__ __forceinline__ void kf8_update_sd(double (&mean)[8], double (&cov)[64], const double *z, const double (&sd)[4])
 {
-    double pm[4], S[16], L[16], X[32], Kg[32], B[32];
+    double pm[4], S[16], L[16], Kg[32], B[32], inv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         pm[i] = mean[i];
@@ -61,36 +70,34 @@ __device__ __forceinline__ void kf8_update_sd(double (&mean)[8], double (&cov)[6
     }
     chol4_full(S, L);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        double y[4];
+    for (int k = 0; k < 4; ++k) inv[k] = 1.0 / L[k * 4 + k];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            double v = cov[c * 8 + i];
+    for (int c = 0; c < 8; ++c) {                      // cho_solve: row c of the gain
+        double x[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (k < i) v -= L[i * 4 + k] * y[k];
-            y[i] = v / L[i * 4 + i];
+        for (int i = 0; i < 4; ++i) x[i] = cov[c * 8 + i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            x[k] = x[k] * inv[k];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i > k) x[i] = fma(-L[i * 4 + k], x[k], x[i]);
         }
 #pragma unroll
-        for (int i = 3; i >= 0; --i) {
-            double v = y[i];
+        for (int k = 3; k >= 0; --k) {
+            x[k] = x[k] * inv[k];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (k > i) v -= L[k * 4 + i] * X[k * 8 + c];
-            X[i * 8 + c] = v / L[i * 4 + i];
+            for (int i = 0; i < 4; ++i) if (i < k) x[i] = fma(-L[k * 4 + i], x[k], x[i]);
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Kg[c * 4 + j] = x[j];
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Kg[i * 4 + j] = X[j * 8 + i];
     double inn[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) inn[j] = z[j] - pm[j];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        double sacc = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sacc += inn[j] * Kg[i * 4 + j];
-        mean[i] = mean[i] + sacc;
+        const double p0 = inn[0] * Kg[i * 4], p1 = inn[1] * Kg[i * 4 + 1], p2 = inn[2] * Kg[i * 4 + 2], p3 = inn[3] * Kg[i * 4 + 3];
+        mean[i] = mean[i] + ((p0 + p2) + (p1 + p3));
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -98,7 +105,7 @@ __device__ __forceinline__ void kf8_update_sd(double (&mean)[8], double (&cov)[6
         for (int c = 0; c < 8; ++c) {
             double sacc = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sacc += S[j * 4 + k] * Kg[c * 4 + k];
+            for (int k = 0; k < 4; ++k) sacc = fma(S[j * 4 + k], Kg[c * 4 + k], sacc);
             B[j * 8 + c] = sacc;
         }
 #pragma unroll
@@ -107,7 +114,7 @@ __device__ __forceinline__ void kf8_update_sd(double (&mean)[8], double (&cov)[6
         for (int c = 0; c < 8; ++c) {
             double sacc = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sacc += Kg[i * 4 + j] * B[j * 8 + c];
+            for (int j = 0; j < 4; ++j) sacc = fma(Kg[i * 4 + j], B[j * 8 + c], sacc);
             cov[i * 8 + c] = cov[i * 8 + c] - sacc;
         }
 }
@@ -119,14 +126,29 @@ __device__ __forceinline__ void kf8_update(double (&mean)[8], double (&cov)[64],
     kf8_update_sd(mean, cov, z, sd);
 }
 
-// squared Mahalanobis distance of measurement m (xyah) to the track whose (pm, L) were prepared (:189-227)
-__device__ __forceinline__ double gating_from(const double *glrow, const double *m, int d)
+// Gate row of a track: projected mean (4) + lower Cholesky factor of the projected covariance (d x d, stride d).  solve_triangular's operation
+// order depends on the number of measurements of the call (above): with >= 2 the row holds the RECIPROCAL of the diagonal (`gate_row_finish`),
+// with exactly one the diagonal itself.
+__device__ __forceinline__ void gate_row_finish(double *g, int d, bool single)
+{
+    if (!single) for (int k = 0; k < d; ++k) g[4 + k * d + k] = 1.0 / g[4 + k * d + k];
+}
+// squared Mahalanobis distance of measurement m (xyah) to the track whose gate row was prepared (:189-227)
+__device__ __forceinline__ double gating_from(const double *glrow, const double *m, int d, bool single)
 {
     double zz[4], acc = 0;
-    for (int i = 0; i < d; ++i) {
-        double v = m[i] - glrow[i];
-        for (int k = 0; k < i; ++k) v -= glrow[4 + i * d + k] * zz[k];
-        zz[i] = v / glrow[4 + i * d + i];
+    for (int i = 0; i < d; ++i) zz[i] = m[i] - glrow[i];
+    if (single) {
+        for (int i = 0; i < d; ++i) {
+            double t = 0.0;
+            for (int k = 0; k < i; ++k) t = fma(glrow[4 + i * d + k], zz[k], t);
+            zz[i] = (zz[i] - t) / glrow[4 + i * d + i];
+        }
+    } else {
+        for (int k = 0; k < d; ++k) {
+            zz[k] = zz[k] * glrow[4 + k * d + k];
+            for (int i = k + 1; i < d; ++i) zz[i] = fma(-glrow[4 + i * d + k], zz[k], zz[i]);
+        }
     }
     for (int i = 0; i < d; ++i) acc += zz[i] * zz[i];
     return acc;
@@ -134,15 +156,26 @@ __device__ __forceinline__ double gating_from(const double *glrow, const double 
 
 // the same with the track's gate row in registers (fully unrolled: no dynamic indexing, same operation order)
 template <int DIM>
-__device__ __forceinline__ double gating_reg(const double (&g)[20], const double *m)
+__device__ __forceinline__ double gating_reg(const double (&g)[20], const double *m, bool single)
 {
     double zz[DIM], acc = 0;
 #pragma unroll
-    for (int i = 0; i < DIM; ++i) {
-        double v = m[i] - g[i];
+    for (int i = 0; i < DIM; ++i) zz[i] = m[i] - g[i];
+    if (single) {
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) if (k < i) v -= g[4 + i * DIM + k] * zz[k];
-        zz[i] = v / g[4 + i * DIM + i];
+        for (int i = 0; i < DIM; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) if (k < i) t = fma(g[4 + i * DIM + k], zz[k], t);
+            zz[i] = (zz[i] - t) / g[4 + i * DIM + i];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            zz[k] = zz[k] * g[4 + k * DIM + k];
+#pragma unroll
+            for (int i = 0; i < DIM; ++i) if (i > k) zz[i] = fma(-g[4 + i * DIM + k], zz[k], zz[i]);
+        }
     }
 #pragma unroll
     for (int i = 0; i < DIM; ++i) acc += zz[i] * zz[i];
