@@ -92,7 +92,9 @@ def parse(argv=None):
     ap.add_argument("--check-frames", type=int, default=None,
                     help="frames verified against the oracle (untimed); default 600 (a full SURVEY 8d stream) where the oracle runs "
                          "faster than ~50 frames/s, 96 for the plain StrongSORT / BoT-SORT / Deep-OC-SORT oracles")
-    ap.add_argument("--no-latency-leg", action="store_true", help="skip the frames_per_step=1 measurement")
+    ap.add_argument("--no-latency-leg", action="store_true", help="skip the small-step legs (frames_per_step 1 / 2 / 4 and 4 streams x 1 frame)")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the reference-precision (fp32 backbones) leg of the default f16 run")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the rocprofv3 --pmc passes for roofline.traffic (static file instead)")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the H2D-inclusive leg (value = value_resident)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test without a GPU: spawn, rendezvous (gloo), stream partition, barrier, reductions and the JSON line, "
@@ -124,17 +126,18 @@ def maybe_self_spawn(args) -> None:
 
 
 def gather_ranks(dist, dev, fps_local: float):
-    """(per-rank fps list, ranks seen [(rank, device)]) through one all_gather on the job's backend."""
+    """(per-rank fps list, ranks seen [(rank, device)], host placement [(rank, numa node, cpus)]) through one all_gather on the job's backend."""
     import torch
     from tracklab_amd import dist as tdist
     world, rank, local_rank = tdist.env_world()
+    aff = json.loads(os.environ.get("TLK_BENCH_AFFINITY", "null")) or [-1, len(os.sched_getaffinity(0))]
     if dist is None:
-        return [fps_local], [[0, int(dev.index or 0) if dev.type == "cuda" else -1]]
-    t = torch.tensor([float(rank), float(dev.index if dev.type == "cuda" else -1), fps_local], dtype=torch.float64, device=dev)
+        return [fps_local], [[0, int(dev.index or 0) if dev.type == "cuda" else -1]], [[0, aff[0], aff[1]]]
+    t = torch.tensor([float(rank), float(dev.index if dev.type == "cuda" else -1), fps_local, float(aff[0]), float(aff[1])], dtype=torch.float64, device=dev)
     out = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(out, t)
     rows = [o.cpu().numpy() for o in out]
-    return [float(r[2]) for r in rows], [[int(r[0]), int(r[1])] for r in rows]
+    return [float(r[2]) for r in rows], [[int(r[0]), int(r[1])] for r in rows], [[int(r[0]), int(r[3]), int(r[4])] for r in rows]
 
 
 # ------------------------------------------------------------------------------------------------------------ inputs
@@ -210,14 +213,14 @@ def main_dry_run(args):
     elapsed_local = time.perf_counter() - t0
     elapsed = tdist.allreduce_max(elapsed_local, dist, dev)
     total = tdist.allreduce_sum(vec, dist, dev)
-    per_rank, seen = gather_ranks(dist, dev, args.steps * S * F / elapsed_local)
+    per_rank, seen, placement = gather_ranks(dist, dev, args.steps * S * F / elapsed_local)
     if rank == 0:
         fin = hota.finalize(total)
         print(json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": args.dtype, "data": "dry run: no GPU work, ground truth returned as tracker output", "dry_run": True,
                           "config": {"workload": wl["name"], "streams_per_gpu": S, "frames_per_step": F, "parallelism": f"stream-parallel x{world}"},
-                          "per_rank_fps": per_rank, "ranks_seen": seen, "streams_of_rank0": streams,
+                          "per_rank_fps": per_rank, "ranks_seen": seen, "rank_placement": placement, "streams_of_rank0": streams,
                           "hota_allreduce": {"HOTA": fin["summary"]["HOTA"], "frames": fin["frames"]}}), flush=True)
     if dist is not None:
         dist.barrier()
@@ -278,7 +281,7 @@ def main_config1(args, world, rank, dist, dev):
     elapsed_local = time.perf_counter() - t0
     elapsed = tdist.allreduce_max(elapsed_local, dist, dev)
     fps = args.steps * S * F * world / elapsed
-    per_rank, seen = gather_ranks(dist, dev, args.steps * S * F / elapsed_local)
+    per_rank, seen, placement = gather_ranks(dist, dev, args.steps * S * F / elapsed_local)
     k_ms = ev0.elapsed_time(ev1) / args.steps
     alg = S * F * nobj * (7 + 49) * 8 * 2.0                     # KF state read + written once per track and frame
     cpu = None
@@ -298,7 +301,7 @@ def main_config1(args, world, rank, dist, dev):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic 1080p ground-truth boxes resident in HBM (no detector, no frames in this configuration)",
             "config": {"workload": wl["name"].replace("30-obj", f"{nobj}-obj"), "streams_per_gpu": S, "frames_per_step": F, "parallelism": f"stream-parallel x{world}"},
-            "per_rank_fps": per_rank, "ranks_seen": seen,
+            "per_rank_fps": per_rank, "ranks_seen": seen, "rank_placement": placement,
             "roofline": {"kernel": "ocsort_frames_kernel", "bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": alg,
                          "note": "one workgroup per stream, sequential in frames: latency-bound by construction, the HBM fraction is ~0"},
@@ -308,6 +311,80 @@ def main_config1(args, world, rank, dist, dev):
         dist.barrier()
         dist.destroy_process_group()
 
+
+
+# ------------------------------------------------------------------------------------------------------------ host placement
+def pin_rank_to_gpu_numa_node(dev_index: int, local_rank: int, local_world: int):
+    """host contention and the pinned H2D stream are the only scaling limiters of the stream-parallel job, so every rank stays on
+    the CPUs of ITS GPU's NUMA node (ranks that share a node split its CPUs evenly). Returns [numa_node, n_cpus] or None where /sys does
+    not say (containers without the PCI tree): the job then runs unpinned, and says so in `ranks_seen`."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        base = f"/sys/bus/pci/devices/{bdf}"
+        node = int(open(base + "/numa_node").read().strip())
+        cpus = []
+        for part in open(base + "/local_cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus += list(range(int(a), int(b or a) + 1))
+        allowed = sorted(set(cpus) & os.sched_getaffinity(0))
+        if not allowed:
+            return None
+        # ranks on the same node: split by the order of their local ranks among the GPUs of that node
+        same = []
+        for i in range(torch.cuda.device_count()):
+            q = torch.cuda.get_device_properties(i)
+            b2 = "%04x:%02x:%02x.0" % (getattr(q, "pci_domain_id", 0), q.pci_bus_id, q.pci_device_id)
+            try:
+                if int(open(f"/sys/bus/pci/devices/{b2}/numa_node").read().strip()) == node and i < local_world:
+                    same.append(i)
+            except Exception:
+                pass
+        if dev_index in same and len(same) > 1:
+            per = max(1, len(allowed) // len(same))
+            k = same.index(dev_index)
+            allowed = allowed[k * per:(k + 1) * per] or allowed
+        os.sched_setaffinity(0, allowed)
+        return [node, len(allowed)]
+    except Exception:
+        return None
+
+
+def live_hbm_traffic(kernel: str, probe: str):
+    """roofline.traffic measured by THIS run: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE -- separate passes, --kernel-trace only, as
+    MI355X_MICROARCH.md prescribes) over tools/probe_traffic.py, which launches the same kernel on the same launch shape. gfx950
+    correction (profiles/crop_traffic.json calibration: a 1 GiB copy and a read-once letterbox): FETCH_SIZE counts KB and reports half of
+    the bytes fetched, WRITE_SIZE counts KB. Returns (bytes per launch, description) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable,
+                                os.path.join(REPO, "tools", "probe_traffic.py"), probe], cwd="/tmp", env=env, timeout=240,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            except Exception as ex:                             # noqa: BLE001
+                return None, f"rocprofv3 --pmc {ctr} failed: {type(ex).__name__}"
+            got = []
+            for path in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if kernel in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                        got.append(float(row["Counter_Value"]))
+            if not got:
+                return None, f"no {ctr} rows for {kernel}"
+            vals[ctr] = float(np.mean(got))
+    return (vals["FETCH_SIZE"] * 2.0 + vals["WRITE_SIZE"]) * 1024.0, \
+        ("measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/probe_traffic.py (same kernel, same "
+         "launch shape); gfx950 correction FETCH x2 (KB), WRITE x1 (KB)")
 
 # ------------------------------------------------------------------------------------------------------------ main
 def main():
@@ -326,6 +403,9 @@ def main():
     if dist is None:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if use_dist else 0)
+    # one rank alone has the host to itself (and runs the all-cores CPU baseline): pinning is for the multi-GPU job
+    affinity = pin_rank_to_gpu_numa_node(dev.index or 0, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None
+    os.environ["TLK_BENCH_AFFINITY"] = json.dumps(affinity)
     if args.workload == "config1":
         return main_config1(args, world, rank, dist, dev)
     wl = WORKLOADS[args.workload]
@@ -536,7 +616,7 @@ def main():
         fin = hota.finalize(tdist.allreduce_sum(vec, dist, dev))
         hota_all = {"HOTA": fin["summary"]["HOTA"], "DetA": fin["summary"]["DetA"], "AssA": fin["summary"]["AssA"], "frames": fin["frames"],
                     "rows": int(len(df)), "tracked_rows": int(df.track_id.notna().sum())}
-    per_rank, seen = gather_ranks(dist, dev, fps_local)
+    per_rank, seen, placement = gather_ranks(dist, dev, fps_local)
 
     # ---- roofline of the dominant byte-moving libtlk kernel: HIP events on the launch stream around every launch of
     # K further steps of the same workload ----
@@ -553,7 +633,7 @@ def main():
     esz = torch.empty((), dtype=tdtype).element_size()
     cnt_mean = float(np.mean([len(g["dets"]) for g in gts[0][:total_steps * F]]))
     if is3:
-        kname, tfile = ("pil_crop_kernel", "pil_crop_traffic.json") if ssort else ("crop_wave_kernel", "crop_traffic.json")
+        kname, tfile = ("pil_crop_kernel", "pil_crop_traffic.json") if ssort else ("crop_wave2_kernel", "crop_traffic.json")
         # mean crop of the synthetic stream: w~U(40,120), h=w*U(1.8,2.6) -> E[w*h] = E[w^2]*2.2; only the cnt_mean REAL crops of a
         # frame count (the padding slots up to max_dets are not algorithmic bytes)
         ew2 = (120 ** 3 - 40 ** 3) / (3 * 80)
@@ -565,13 +645,17 @@ def main():
     achieved = alg_bytes / (k_ms_avg * 1e-3) / 1e9 if k_ms else None
     traffic, traffic_src = None, None
     tpath = os.path.join(REPO, "profiles", tfile)
-    if os.path.exists(tpath) and args.dtype == "f16" and F == wl["frames_per_step"]:
+    same_launch = args.dtype == "f16" and F == wl["frames_per_step"] and S == 1
+    if rank == 0 and world == 1 and same_launch and not args.no_live_traffic:
+        traffic, traffic_src = live_hbm_traffic(kname, "pil" if kname.startswith("pil") else ("letterbox" if kname.startswith("letterbox") else "crop"))
+    if traffic is None and os.path.exists(tpath) and same_launch:
+        why = traffic_src
         try:
             tj = json.load(open(tpath))
             traffic = tj.get("hbm_bytes_per_launch")
-            traffic_src = "static: profiles/%s (%s) -- rocprofv3 --pmc passes of this command on an earlier box, not measured by this run" % (
-                tfile, tj.get("round", "r01"))
-            if tj.get("kernel") != kname:
+            traffic_src = "static: profiles/%s (%s) -- rocprofv3 --pmc passes of this launch shape on an earlier box, not measured by this run%s" % (
+                tfile, tj.get("round", "r01"), f" ({why})" if why else "")
+            if not kname.startswith(tj.get("kernel", "?")[:9]):
                 traffic, traffic_src = None, None             # counters of another kernel generation: not this kernel's traffic
         except Exception:
             traffic = None
@@ -579,38 +663,108 @@ def main():
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": k_ms_avg, "algorithmic_bytes_per_launch": alg_bytes, "units_per_launch": f"{B} frames x {cnt_mean:.1f} crops" if is3 else f"{B} frames"}
 
-    # ---- latency leg: the same chain at frames_per_step = 1 (one frame in, its rows out) ----
+    # ---- small-step legs: the same chain at frames_per_step 1 / 2 / 4 and at 4 streams x 1 frame (what an online consumer sees; the
+    # reference's online engine is per-frame, engine/video.py:67-117). Each: pipelined frames/s, un-overlapped frame-in -> rows-out time,
+    # and for the BPBReID workloads the ids of up to 48 frames per checked stream against the oracle chain ----
     latency = None
     if rank == 0 and world == 1 and not args.no_latency_leg and F > 1:
         pipe.reset()
-        p1 = make_pipe(1, 1)
-        n1 = min(input_steps * F, 120)
-        d_h1 = torch.from_numpy(np.ascontiguousarray(heads_np[0][:n1, None])).to(dev)
-        fr1 = d_pool[0][:1]                                  # one fixed frame buffer -> one hipGraph
-        stp = lambda j: p1.step(fr1, d_h1[j % n1])                        # noqa: E731
-        for j in range(10):
-            stp(j)
-        p1.synchronize(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for j in range(10, n1):
-            stp(j)
-        p1.synchronize(); torch.cuda.synchronize()
-        el1 = time.perf_counter() - t0
-        # true per-frame latency: one frame, wait for its rows
-        lat = []
-        for j in range(20):
-            t1 = time.perf_counter(); stp(j); p1.synchronize(); lat.append(time.perf_counter() - t1)
-        latency = {"frames_per_step": 1, "fps": (n1 - 10) / el1, "ms_per_frame_pipelined": el1 / (n1 - 10) * 1e3,
-                   "ms_frame_in_to_rows_out": float(np.median(lat) * 1e3), "frames": n1 - 10,
-                   "note": "frames resident in HBM; steps overlap (association of frame t under the forwards of t+1) in the fps figure, "
-                           "the in-to-out latency is one un-overlapped step"}
-        p1.close()
-        del p1
+        shapes = [(1, 1), (1, 2), (1, 4), (4, 1)] if is3 else [(1, 1), (1, 4)]
+        latency = []
+        for S_, F_ in shapes:
+            if S_ * F_ > B:
+                continue
+            p1 = make_pipe(F_, S_)
+            T_ = 48 if S_ * F_ > 1 else 36
+            hs = [heads_np[0][:T_]] + [build_stream_inputs(5000 + s_, n_objects, T_, ratio)[0] for s_ in range(1, S_)]
+            hsteps = np.ascontiguousarray(np.stack(hs).reshape(S_, T_ // F_, F_, -1, heads_np.shape[-1]).transpose(1, 0, 2, 3, 4)).reshape(
+                T_ // F_, S_ * F_, -1, heads_np.shape[-1])
+            d_h1 = torch.from_numpy(hsteps).to(dev)
+            fr1 = d_pool[0][:S_ * F_]                            # one fixed frame buffer -> one hipGraph
+            n1 = T_ // F_
+            stp = lambda j: p1.step(fr1, d_h1[j % n1])                        # noqa: E731
+            leg_parity = None
+            if is3 and not ssort and wl.get("pose") is None:
+                import oracle
+                refs = {s_: oracle.StrongSORT(p1.K, p1.D, **p1.tracker_cfg) for s_ in sorted({0, S_ - 1})}
+                okl, nfr = True, 0
+                for j in range(n1):
+                    h_rows, h_cnt = stp(j)
+                    p1.synchronize()
+                    rws, _ = p1.rows_numpy(h_rows, h_cnt)
+                    emb = p1.last["emb"].cpu().numpy().reshape(S_, F_, p1.maxd, p1.K, p1.D)
+                    vis = p1.last["vis"].cpu().numpy().reshape(S_, F_, p1.maxd, p1.K)
+                    for s_, ref_ in refs.items():
+                        for f in range(F_):
+                            ltwh32 = detector_rows(oracle, hs[s_][j * F_ + f], ratio)
+                            n = len(ltwh32)
+                            ids = (j * S_ * F_ + s_ * F_ + f) * p1.maxd + np.arange(n)
+                            exp = ref_.update(ids, ltwh32.astype(np.float64), emb[s_, f, :n], vis[s_, f, :n], np.ones(n)) if n else []
+                            got = rws[s_][f]
+                            okl &= len(got) == len(exp) and (len(exp) == 0 or (np.array_equal(got["det_id"], exp["det_id"]) and
+                                                                               np.array_equal(got["track_id"], exp["track_id"])))
+                            nfr += 1
+                leg_parity = {"frames": nfr, "streams_checked": sorted(refs), "track_ids_equal_oracle": bool(okl)}
+                p1.reset()
+            for j in range(8):
+                stp(j)
+            p1.synchronize(); torch.cuda.synchronize()
+            nrun = max(n1, 40)
+            t0 = time.perf_counter()
+            for j in range(nrun):
+                stp(j)
+            p1.synchronize(); torch.cuda.synchronize()
+            el1 = time.perf_counter() - t0
+            lat = []
+            for j in range(15):                                  # true in-to-out latency: one step, wait for its rows
+                t1 = time.perf_counter(); stp(j); p1.synchronize(); lat.append(time.perf_counter() - t1)
+            latency.append({"n_streams": S_, "frames_per_step": F_, "fps": nrun * S_ * F_ / el1, "ms_per_step_pipelined": el1 / nrun * 1e3,
+                            "ms_frame_in_to_rows_out": float(np.median(lat) * 1e3), "parity": leg_parity})
+            p1.close()
+            del p1, d_h1
+        lat_main = []
+        for j in range(4):
+            pipe.synchronize(); t1 = time.perf_counter(); run_step(j); pipe.synchronize(); lat_main.append(time.perf_counter() - t1)
+        latency.append({"n_streams": S, "frames_per_step": F, "fps": fps_res, "ms_per_step_pipelined": el_res / args.steps * 1e3,
+                        "ms_frame_in_to_rows_out": float(np.median(lat_main) * 1e3), "parity": "see `parity`"})
+        pipe.reset()
+
+    # ---- reference-precision leg: the default f16 run also times 3 steps with fp32 backbones (the reference runs its
+    # networks in fp32: ONNXRuntime / torchreid, strong_sort.yaml:10 fp16: false) and checks 48 frames of ids against the oracle chain ----
+    f32_leg = None
+    if rank == 0 and world == 1 and is3 and args.dtype == "f16" and not args.no_f32_leg and not ssort and wl.get("pose") is None:
+        import oracle
+        saved = tdtype
+        tdtype = torch.float32
+        pf = make_pipe(F)
+        tdtype = saved
+        ref_ = oracle.StrongSORT(pf.K, pf.D, **pf.tracker_cfg)
+        okf, nfr = True, 0
+        for k in range(2):
+            h_rows, h_cnt = run_step(k, p=pf)
+            pf.synchronize()
+            rws, _ = pf.rows_numpy(h_rows, h_cnt)
+            emb = pf.last["emb"].cpu().numpy().reshape(S, F, pf.maxd, pf.K, pf.D)
+            vis = pf.last["vis"].cpu().numpy().reshape(S, F, pf.maxd, pf.K)
+            for f in range(F):
+                ltwh32 = detector_rows(oracle, heads_np[0][k * F + f], ratio)
+                n = len(ltwh32)
+                exp = ref_.update((k * B + f) * pf.maxd + np.arange(n), ltwh32.astype(np.float64), emb[0, f, :n], vis[0, f, :n], np.ones(n)) if n else []
+                got = rws[0][f]
+                okf &= len(got) == len(exp) and (len(exp) == 0 or (np.array_equal(got["det_id"], exp["det_id"]) and np.array_equal(got["track_id"], exp["track_id"])))
+                nfr += 1
+        pf.reset()
+        el32 = timed_resident(pf, 3, 1)
+        f32_leg = {"value_f32": 3 * B / el32, "ms_per_step_f32": el32 / 3 * 1e3, "steps": 3, "warmup": 1, "frames_resident": True,
+                   "parity": {"frames": nfr, "track_ids_equal_oracle": bool(okf)},
+                   "note": "fp32 backbones = the reference's precision; the hand-written kernels are fp64 / fp32 / integer in both legs"}
+        pf.close()
+        del pf
 
     # ---- CPU baseline: (a) the same chain on host cores (oracle C port + torch CPU fp32 forwards), warm, bounded sample;
     # (b) SURVEY 8d's form: the hand-written stages only (oracle C twins, backbones excluded), one thread and all cores ----
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # rank 0 at N = 1 only (the other ranks would wait in the barrier for it)
         cpu = cpu_baseline(args, wl, pipe, detector, is3, ssort, byte, gfeat_oracle, gfeat_name, heads_np, gts, ratio, n_frames)
 
     if rank == 0:
@@ -633,8 +787,11 @@ def main():
                        "detector": f"yolox-{detector}", "streams_per_gpu": S, "frames_per_step": F,
                        "frames_per_gpu_per_step": B, "parallelism": f"stream-parallel x{world}", "hip_graphs": not args.no_graph,
                        "backbone_dtype": args.dtype},
-            "per_gpu_fps": value / world, "per_rank_fps": per_rank, "ranks_seen": seen, "collectives": "nccl" if dist is not None else None, "hota_allreduce": hota_all,
-            "latency": latency, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+            "per_gpu_fps": value / world, "per_rank_fps": per_rank, "ranks_seen": seen,
+            "rank_placement": placement, "rank_placement_note": "[rank, NUMA node of its GPU, host CPUs it is pinned to]; node -1 = unpinned (a single rank, or /sys did not say)",
+            "collectives": "nccl" if dist is not None else None, "hota_allreduce": hota_all,
+            "latency": latency, "value_f32": f32_leg["value_f32"] if f32_leg else None, "ms_per_step_f32": f32_leg["ms_per_step_f32"] if f32_leg else None,
+            "f32_leg": f32_leg, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(line), flush=True)
     pipe.close()

@@ -272,16 +272,18 @@ __device__ __forceinline__ int wave_max_i32(int v)
 
 // (mov_dpp, i.e. an UNDEFINED old operand, is what lets the compiler fold the lane rotation into the min / max itself:
 //  v_min_u32_dpp, one instruction per level instead of copy + rotate + min)
+// r03: the cross-row step stays in the VALU too -- row_bcast15 hands every row the minimum of the row before it, row_bcast31 hands rows 2-3 the minimum
+// of rows 0-1, so lane 63 holds the wave minimum after six DPP-folded v_min / v_max and ONE v_readlane (was: four v_readlane + s_min + two
+// v_mov + v_min3, a VALU -> SALU -> VALU round trip with its wait states inside the Hungarian solver's dependent chain)
 __device__ __forceinline__ unsigned int wave_min_u32(unsigned int v)      // wave-uniform result
 {
     v = min(v, (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0x121, 0xf, 0xf, true));
     v = min(v, (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0x122, 0xf, 0xf, true));
     v = min(v, (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xf, 0xf, true));
     v = min(v, (unsigned int)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, true));
-    const unsigned int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-    const unsigned int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-    const unsigned int ab = a < b ? a : b, cd = c < d ? c : d;
-    return ab < cd ? ab : cd;
+    v = min(v, (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));      // row_bcast15 -> rows 1, 3
+    v = min(v, (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));      // row_bcast31 -> rows 2, 3
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ int wave_max_i32_fast(int v)
 {
@@ -289,10 +291,9 @@ __device__ __forceinline__ int wave_max_i32_fast(int v)
     v = max(v, __builtin_amdgcn_mov_dpp(v, 0x122, 0xf, 0xf, true));
     v = max(v, __builtin_amdgcn_mov_dpp(v, 0x124, 0xf, 0xf, true));
     v = max(v, __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, true));
-    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-    const int ab = a > b ? a : b, cd = c > d ? c : d;
-    return ab > cd ? ab : cd;
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 // order-preserving map double -> (hi, lo) unsigned pair: numeric < on non-NaN doubles == lexicographic unsigned < on (hi, lo)
 __device__ __forceinline__ void f64_key(double x, unsigned int &hi, unsigned int &lo)
@@ -365,7 +366,11 @@ __device__ __noinline__ int wave_lsa_reg(CostPtr cost, int nr0, int nc0, unsigne
             unsigned int khi, klo;
             f64_key(best + 0.0, khi, klo);                          // + 0.0: -0.0 and +0.0 compare equal, so must their keys
             const unsigned int mhi = wave_min_u32(khi);
-            const unsigned int mlo = wave_min_u32(khi == mhi ? klo : 0xffffffffu);
+            // r03: distinct shortest-path costs almost always differ in their upper 32 bits already -- then ONE lane carries the minimum and its
+            // lower word is read with one v_readlane; the second reduction runs only for equal upper words (exact ties: clamped / gated costs)
+            const unsigned long long m_hi = __ballot(khi == mhi);
+            const unsigned int mlo = __popcll(m_hi) == 1 ? (unsigned int)__builtin_amdgcn_readlane((int)klo, __ffsll((long long)m_hi) - 1)
+                                                        : wave_min_u32(khi == mhi ? klo : 0xffffffffu);
             minval = f64_unkey(mhi, mlo);
             if (!(minval < INFINITY)) return -1;                    // infeasible
             const bool is_min = khi == mhi && klo == mlo;
