@@ -217,11 +217,13 @@ def test_swap_rb_reads_the_frame_as_bgr(layout):
         assert torch.equal(pa, pb) and torch.equal(ma, mb)
 
 
-@pytest.mark.parametrize("env", [{"TLK_CROP_WAVE": "0"}, {"TLK_CROP_WAVE": "0", "TLK_CROP_FAT": "0"}, {"TLK_CROP_WAVE": "0", "TLK_CROP_FAT": "0", "TLK_CROP_KERNEL": "1"}],
-                         ids=["crop_fat_kernel", "crop_sep_kernel", "crop_lds_kernel"])
+@pytest.mark.parametrize("env", [{"TLK_CROP_WAVE": "4"}, {"TLK_CROP_WAVE": "2"}, {"TLK_CROP_WAVE": "1"}, {"TLK_CROP_WAVE": "0"}, {"TLK_CROP_WAVE": "0", "TLK_CROP_FAT": "0"},
+                                 {"TLK_CROP_WAVE": "0", "TLK_CROP_FAT": "0", "TLK_CROP_KERNEL": "1"}],
+                         ids=["crop_pw_kernel", "crop_wave2_kernel", "crop_wave_kernel", "crop_fat_kernel", "crop_sep_kernel", "crop_lds_kernel"])
 def test_the_older_crop_kernels_stay_bit_exact(env):
-    """crop_wave_kernel is the default for 128-wide targets; the kernels it replaced stay selectable for A/B runs (the switches are read once per
-    process, hence the subprocess) and must keep producing the oracle's bits."""
+    """crop_wave3_kernel is the default for 128-wide 16-bit targets (crop_wave2_kernel for fp32); the persistent-wavefront variant and the kernels
+    they replaced stay selectable for A/B runs (the switches are read once per process, hence the subprocess) and must keep producing the oracle's
+    bits."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))

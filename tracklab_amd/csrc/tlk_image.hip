@@ -1426,6 +1426,578 @@ __global__ void __launch_bounds__(BLOCK) crop_wave2_kernel(const unsigned char *
 }
 
 
+// crop_wave3_kernel (r03): crop_wave2_kernel with a SLIDING WINDOW over the source rows. PMC of crop_wave2_kernel (profiles/r03_crop_pmc.txt):
+// VALU 63 % and LDS 68 % busy, no memory stall left to remove -- the kernel is bound by its own instruction count. A wavefront walks its eight
+// mini-bands top to bottom and consecutive mini-bands share source rows; here the 16-bit plane is a ring of WV_SRC rows addressed by
+// (source row mod WV_SRC), so a source row is fetched, staged and taken through the horizontal pass ONCE per wavefront range.
+template <typename T, int LAYOUT>
+__global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
+                                                          const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
+                                                          int OH, const T *__restrict__ lut_g, float m0, float m1, float m2,
+                                                          float d0, float d1, float d2, T *__restrict__ out, int swap_rb, int nwg)
+{
+    constexpr int OW = 128, HS = OW * 3, GROUPS = OW / 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    __shared__ int s_y[CF_BANDS * CS_BAND * 2];         // per output row of the chunk: (source row y0 | y1 << 16) relative to the crop, (b0 | b1 << 16)
+    __shared__ CropPar s_par;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the mini-band loop is scalar control flow
+    int wg;
+    {
+        const int orig = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int bands = (OH + CS_BAND - 1) / CS_BAND, chunks = (bands + CF_BANDS - 1) / CF_BANDS;
+    const int slot = wg / chunks, chunk = wg - slot * chunks;
+    const int b = slot / max_n, i = slot - b * max_n;
+    if (i >= counts[b]) return;                         // padding slot: left untouched
+    const int band0 = chunk * CF_BANDS, nbands = min(CF_BANDS, bands - band0);
+    int2 *s_xc = reinterpret_cast<int2 *>(s_dyn);
+    T *s_lut = reinterpret_cast<T *>(s_dyn + OW * 8);
+    unsigned char *s_rows = s_dyn + OW * 8 + ((3 * CS_LUT_N * sizeof(T) + 15) & ~(size_t)15) + (size_t)wv * WV_WAVE_LDS;      // this wavefront's staging area ...
+    unsigned short *s_h = reinterpret_cast<unsigned short *>(s_rows + WV_SRC * CS_ROW_BYTES);                                  // ... and 16-bit plane
+    const size_t frame_off = (size_t)b * H * W * 3;
+    // ---- set-up, once per workgroup: wave 0 geometry + x table, waves 1-2 the y tables of the chunk, wave 3 the normalisation table
+    if (tid < WAVE) {
+        int l, t, r, bt;
+        crop_ltrb(boxes + ((size_t)b * max_n + i) * 4, W, H, l, t, r, bt);
+        const bool valid = (r > l) && (bt > t);
+        const int cw = r - l, ch = bt - t;
+        const bool wide_ok = cw * 3 + STAGE_PAD <= CS_ROW_BYTES;
+        if (valid && wide_ok) {
+            const double scale_x = (double)cw / (double)OW;
+            for (int x = tid; x < OW; x += WAVE) {
+                const Coef cx = cv_coef_s(x, cw, scale_x, true);
+                s_xc[x] = make_int2((cx.s * 3) | ((cx.s + 1 < cw ? 3 : 0) << 16), (cx.w0 & 0xffff) | (cx.w1 << 16));
+            }
+        }
+        if (tid == 0) { CropPar p; p.l = l; p.t = t; p.cw = cw; p.ch = ch; p.r_lo = 0; p.nrows = 0; p.staged = wide_ok; p.valid = valid; s_par = p; }
+    } else if (tid < 3 * WAVE) {
+        int l, t, r, bt;
+        crop_ltrb(boxes + ((size_t)b * max_n + i) * 4, W, H, l, t, r, bt);
+        const int ch = bt - t, row = tid - WAVE, y = band0 * CS_BAND + row;
+        if (bt > t && r > l && y < OH && row < nbands * CS_BAND) {
+            const Coef cy = cv_coef_s(y, ch, (double)ch / (double)OH, false);
+            const int y0 = clampi(cy.s, 0, ch - 1), y1 = clampi(cy.s + 1, 0, ch - 1);      // < 2048: bits 12-14 / 28-30 carry the rows' slots in the ring plane
+            s_y[row * 2] = y0 | ((y0 % WV_SRC) << 12) | (y1 << 16) | ((y1 % WV_SRC) << 28);
+            s_y[row * 2 + 1] = (cy.w0 & 0xffff) | (cy.w1 << 16);
+        }
+    } else {
+        const int n16 = (int)(3 * CS_LUT_N * sizeof(T) / 16);
+        const uint4 *g = reinterpret_cast<const uint4 *>(lut_g);
+        uint4 *d = reinterpret_cast<uint4 *>(s_lut);
+        for (int c = tid - 3 * WAVE; c < n16; c += WAVE) d[c] = g[c];
+    }
+    __syncthreads();
+    const CropPar par = s_par;
+    const bool valid = par.valid != 0;
+    const unsigned char *gend = frames + (size_t)B * H * W * 3;
+    const int row0 = band0 * CS_BAND, rows_chunk = min(nbands * CS_BAND, OH - row0);       // output rows of this workgroup
+    // mini-bands of 4 rows while the crop is not taller than the output (<= 6 source rows each), of 2 rows up to twice as tall
+    const int mbh = par.ch <= OH ? WV_ROWS : 2;
+    const int n_mb = (rows_chunk + mbh - 1) / mbh, mb_per_wave = (n_mb + NWAVES - 1) / NWAVES;
+    const int mb_lo = wv * mb_per_wave, mb_hi = min(n_mb, mb_lo + mb_per_wave);
+    const int cmax = (par.cw * 3 + 30) >> 4;             // 16-byte chunks per staged row
+    // ---- is every mini-band of this wavefront on the fast path? (staged crop, <= WV_SRC source rows, <= 3 x 64 chunks, no load near the end of the frames)
+    bool fast = valid && par.staged && par.ch <= 2 * OH;
+    if (fast) {
+        fast = frames + frame_off + ((size_t)(par.t + par.ch - 1) * W + par.l) * 3 + 34 * 16 <= gend;
+        for (int mb = mb_lo + lane; mb < mb_hi; mb += WAVE) {
+            const int ra = mb * mbh, rb = min(ra + mbh, rows_chunk) - 1;
+            const int n = (int)(((unsigned int)s_y[rb * 2] >> 16) & 0x7ffu) - (s_y[ra * 2] & 0x7ff) + 1;
+            if (n > WV_SRC || n * cmax > 3 * WAVE) fast = false;
+        }
+        fast = __all(fast);
+    }
+    if (!fast) {
+        // rare: invalid / very tall / very wide crops, the last rows of the last frame -- direct sampling, a unit (row, 8 px) per lane
+        for (int mb = mb_lo; mb < mb_hi; ++mb)
+            for (int u = lane; u < mbh * GROUPS; u += WAVE) {
+                const int ry = u >> 4, x_base = (u & (GROUPS - 1)) * 8, y = row0 + mb * mbh + ry;
+                if (y >= OH || mb * mbh + ry >= rows_chunk) continue;
+                if (valid) crop_direct_unit<T, LAYOUT>(frames + frame_off + ((size_t)par.t * W + par.l) * 3, W, par.ch, par.cw, OH, OW, y, x_base, m0, m1, m2, d0, d1, d2,
+                                                       swap_rb, out, (size_t)slot);
+                else
+                    for (int k = 0; k < 8; ++k)
+                        for (int c = 0; c < 3; ++c) {
+                            if (LAYOUT == LAYOUT_NCHW) out[(((size_t)slot * 3 + c) * OH + y) * OW + x_base + k] = cvt<T>(0.f);
+                            else out[(((size_t)slot * OH + y) * OW + x_base + k) * 3 + c] = cvt<T>(0.f);
+                        }
+            }
+        return;
+    }
+    // ---- fast path: no call, no workgroup barrier below this line
+    const unsigned char *crop0 = frames + frame_off + ((size_t)par.t * W + par.l) * 3;
+    const unsigned int a_step = ((unsigned int)W * 3u) & 15u;
+    // horizontal pass: this lane's two adjacent x (2 lane, 2 lane + 1). The two taps of the three channels of an x are 6 consecutive source bytes
+    // (3 when the right tap is clamped onto the left one): three ALIGNED dword reads + v_alignbyte bring them, v_perm_b32 with per-lane selectors
+    // builds the (left, right) pairs for v_dot2 -- byte-granular ds_read_u8 taps cost 9 x the LDS time (profiles/r02_lds_microbench.txt), and in this
+    // kernel the LDS pipe is the shared resource the sixteen free-running wavefronts of a CU compete for
+    // source rows of a mini-band -> three registers per lane (flat sweep over (row, chunk)); unconditional loads: lanes past the band re-read its first
+    // chunk. TWO mini-bands are kept in flight (register sets X and Y): the wait for the rows of mini-band m then has the loads of m + 1 behind it, and
+    // the rule "reads and writes complete out of order with respect to each other" no longer forces it to drain the stores of m - 1 just issued
+    struct RowRegs { tlk_u32x4 a, b, c; int r_lo, nrows; };
+    RowRegs X{tlk_u32x4{0, 0, 0, 0}, tlk_u32x4{0, 0, 0, 0}, tlk_u32x4{0, 0, 0, 0}, 0, 0}, Y = X;
+    // The three loads of a mini-band are inline asm: the compiler does not track them, so it cannot turn the wait for them into the
+    // `s_waitcnt vmcnt(0)` it must use whenever loads AND stores are pending on the one counter gfx950 has for both (that full drain at the top of
+    // every mini-band -- the stores of the previous one included -- was the un-overlapped "skeleton" of crop_wave_kernel, r03 ISA reading).
+    // wait_rows() is the hand-placed wait: loads return in order among themselves, so with three younger loads always issued (the next
+    // fetch; past the end a repeat of the last one) "at most 3 operations outstanding" implies this set has landed, whatever the stores do.
+    // lane -> (source row of the mini-band, 16-byte chunk of that row) for its three load slots: fixed for the whole chunk of the crop, so the
+    // two integer divisions per slot are done ONCE here, not in every fetch and every stage (r03: they were a fifth of the kernel's instructions)
+    int sl_rr[3], sl_c[3], sl_lds[3];
+    unsigned int sl_goff[3];
+    const unsigned int W3 = (unsigned int)W * 3u;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int idx = lane + q * WAVE;
+        sl_rr[q] = idx / cmax; sl_c[q] = idx - sl_rr[q] * cmax;
+        sl_lds[q] = sl_rr[q] * CS_ROW_BYTES + sl_c[q] * 16;
+        sl_goff[q] = (unsigned int)sl_rr[q] * W3;           // <= 5 rows: fits 32 bits
+    }
+    const int cw3 = par.cw * 3;
+    auto fetch = [&](int mb_req, RowRegs &R) {
+        const int mb = min(mb_req, mb_hi - 1);           // past the wavefront's last mini-band: fetch that one again (L2 hits) -- every wait then has its three younger loads
+        const int ra = mb * mbh, rb = min(ra + mbh, rows_chunk) - 1;
+        // sliding window: the rows this wavefront's PREVIOUS mini-band already took through the horizontal pass are still in the ring plane
+        // (consecutive mini-bands share one or two source rows; up-scaling crops 30-40 % of them)
+        const int r_first = __builtin_amdgcn_readfirstlane(s_y[ra * 2] & 0x7ff);
+        const int r_last = __builtin_amdgcn_readfirstlane((int)(((unsigned int)s_y[rb * 2] >> 16) & 0x7ffu));
+        const int done = mb > mb_lo ? __builtin_amdgcn_readfirstlane((int)(((unsigned int)s_y[(ra - 1) * 2] >> 16) & 0x7ffu)) : -1;
+        const int r_lo_n = max(r_first, done + 1);
+        const int nrows_n = r_last - r_lo_n + 1;          // 0 .. WV_SRC new rows
+        const unsigned char *rowp = crop0 + (size_t)r_lo_n * W3;      // wave-uniform
+        auto addr = [&](int q) {
+            const bool in = sl_rr[q] < nrows_n;
+            const unsigned char *g0 = rowp + (in ? sl_goff[q] : 0u);
+            const int mis = (int)((uintptr_t)g0 & 15);
+            return g0 - mis + (size_t)((in && sl_c[q] < ((mis + cw3 + 15) >> 4)) ? sl_c[q] : 0) * 16;
+        };
+        const unsigned char *p0 = addr(0), *p1 = addr(1), *p2 = addr(2);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(R.a) : "v"(p0));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(R.b) : "v"(p1));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(R.c) : "v"(p2));
+        R.r_lo = r_lo_n; R.nrows = nrows_n;
+    };
+    auto wait_rows = [&](RowRegs &R) {                   // ONE form of the wait (two forms would meet in a phi: register copies of loads still in flight)
+        asm volatile("s_waitcnt vmcnt(3)" : "+v"(R.a), "+v"(R.b), "+v"(R.c));
+    };
+    int st_r_lo = 0, st_nrows = 0;                       // the mini-band whose rows are in this wavefront's staging area
+    auto stage = [&](const RowRegs &R) {
+        const int nrows = R.nrows;
+        if (sl_rr[0] < nrows) *reinterpret_cast<tlk_u32x4 *>(s_rows + sl_lds[0]) = R.a;
+        if (sl_rr[1] < nrows) *reinterpret_cast<tlk_u32x4 *>(s_rows + sl_lds[1]) = R.b;
+        if (sl_rr[2] < nrows) *reinterpret_cast<tlk_u32x4 *>(s_rows + sl_lds[2]) = R.c;
+        st_r_lo = R.r_lo; st_nrows = nrows;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    const int4 xc2 = *reinterpret_cast<const int4 *>(&s_xc[2 * lane]);
+    const int oA = xc2.x & 0xffff, oB = xc2.z & 0xffff;
+    const unsigned int selA = 0x0c000c00u | ((unsigned int)(xc2.x >> 16) << 16), selB = 0x0c000c00u | ((unsigned int)(xc2.z >> 16) << 16);
+    const us2_t wA = __builtin_bit_cast(us2_t, xc2.y), wB = __builtin_bit_cast(us2_t, xc2.w);
+    // one mini-band: rows of `mb` are staged; N holds (or will hold) the rows of mb + 1. Order: horizontal pass, vertical pass, output block
+    // assembled in LDS and read back into registers, THEN wait for N + stage it + issue the fetch of mb + 3, and only then the stores of mb:
+    // a store has a whole mini-band of arithmetic to complete before the next wait can stall on it
+    auto mini_band = [&](int mb, RowRegs &N) {
+        const int r_lo = st_r_lo, nrows = st_nrows;
+        {
+            const unsigned int a_lo = (unsigned int)(uintptr_t)(crop0 + (size_t)r_lo * W * 3) & 15u;
+            auto taps = [&](int addr, unsigned int &lo, unsigned int &hi) {
+                const unsigned int *q = reinterpret_cast<const unsigned int *>(s_rows + (addr & ~3));
+                const unsigned int d0 = q[0], d1 = q[1], d2 = q[2];
+                lo = __builtin_amdgcn_alignbyte(d1, d0, (unsigned int)addr & 3u);
+                hi = __builtin_amdgcn_alignbyte(d2, d1, (unsigned int)addr & 3u);
+            };
+            for (int rr = 0; rr < nrows; ++rr) {
+                const int base = rr * CS_ROW_BYTES + (int)((a_lo + (unsigned int)rr * a_step) & 15u);
+                unsigned int loA, hiA, loB, hiB;
+                taps(base + oA, loA, hiA);
+                taps(base + oB, loB, hiB);
+                unsigned int *o = reinterpret_cast<unsigned int *>(s_h + ((r_lo + rr) % WV_SRC) * HS) + lane;
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    const unsigned int va = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(hiA, loA, selA + 0x00010001u * c3)), wA, 0u, false) >> 4;
+                    const unsigned int vb = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(hiB, loB, selB + 0x00010001u * c3)), wB, 0u, false) >> 4;
+                    o[c3 * (OW / 2)] = va | (vb << 16);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int ry = lane >> 4, x_base = (lane & (GROUPS - 1)) * 8;
+        const int row = mb * mbh + ry, y = row0 + row;
+        const bool act = ry < mbh && row < rows_chunk;
+        static_assert(sizeof(T) == 2, "crop_wave3_kernel assembles its 3 KB output block in the staging rows only: 16-bit element types");
+        const bool block = LAYOUT == LAYOUT_NHWC && mbh == WV_ROWS && (mb + 1) * mbh <= rows_chunk;      // wave-uniform: one contiguous output block
+        T px[8][3];
+        if (act) {
+            const unsigned int yi = (unsigned int)s_y[row * 2], yw = (unsigned int)s_y[row * 2 + 1];
+            const unsigned short *h0 = s_h + ((yi >> 12) & 7u) * HS + x_base;             // planar: [channel][x]; row = its ring slot
+            const unsigned short *h1 = s_h + ((yi >> 28) & 7u) * HS + x_base;
+            const unsigned int b0 = yw & 0xffffu, b1 = yw >> 16;
+            unsigned int w0[12], w1[12];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const uint4 u = *reinterpret_cast<const uint4 *>(h0 + c * OW), v = *reinterpret_cast<const uint4 *>(h1 + c * OW);
+                w0[c * 4] = u.x; w0[c * 4 + 1] = u.y; w0[c * 4 + 2] = u.z; w0[c * 4 + 3] = u.w;
+                w1[c * 4] = v.x; w1[c * 4 + 1] = v.y; w1[c * 4 + 2] = v.z; w1[c * 4 + 3] = v.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 24; ++q) {
+                const int c = q >> 3, kk = q & 7;
+                const unsigned int a = (kk & 1) ? (w0[c * 4 + (kk >> 1)] >> 16) : (w0[c * 4 + (kk >> 1)] & 0xffffu);
+                const unsigned int c1 = (kk & 1) ? (w1[c * 4 + (kk >> 1)] >> 16) : (w1[c * 4 + (kk >> 1)] & 0xffffu);
+                const unsigned int xa = __umul24(b0, a), xb = __umul24(b1, c1);
+                unsigned int t;                     // t <= 1020 always (see crop_sep_kernel)
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t) : "v"(xa), "v"(xb));
+                px[kk][c] = s_lut[c * CS_LUT_N + t];
+            }
+            if (swap_rb) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const T t0 = px[k][0]; px[k][0] = px[k][2]; px[k][2] = t0; }
+            }
+        }
+        constexpr int NST = 3 * (int)sizeof(T) / 2;      // 16-byte stores per lane of a full mini-band block
+        uint4 blk[NST];
+        if (block) {
+            // assemble the mini-band's contiguous block in the (now dead) staging rows + plane, read it back as whole cache lines per instruction
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            T *o = reinterpret_cast<T *>(s_rows) + ((size_t)ry * OW + x_base) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Pack<T, 8> p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
+                *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint4 *l4 = reinterpret_cast<const uint4 *>(s_rows);
+#pragma unroll
+            for (int k = 0; k < NST; ++k) blk[k] = l4[k * WAVE + lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // staging rows and plane are dead from here
+        __builtin_amdgcn_wave_barrier();
+        if (mb + 1 < mb_hi) {
+            wait_rows(N);
+            stage(N);
+            fetch(mb + 3, N);
+        }
+        if (block) {
+            uint4 *g = reinterpret_cast<uint4 *>(out + ((size_t)slot * OH + row0 + mb * mbh) * OW * 3);
+#pragma unroll
+            for (int k = 0; k < NST; ++k) stream_store(g + k * WAVE + lane, blk[k]);
+        } else if (act) {
+            if (LAYOUT == LAYOUT_NCHW) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    Pack<T, 8> p;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) p.v[k] = px[k][c];
+                    *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)slot * 3 + c) * OH + y) * OW + x_base) = p;
+                }
+            } else {
+                T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    Pack<T, 8> p;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
+                    *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+                }
+            }
+        }
+    };
+    if (mb_lo < mb_hi) {
+        fetch(mb_lo, X);
+        fetch(mb_lo + 1, Y);
+        wait_rows(X);
+        stage(X);
+        fetch(mb_lo + 2, X);
+    }
+    for (int mb = mb_lo; mb < mb_hi; mb += 2) {
+        mini_band(mb, Y);
+        if (mb + 1 < mb_hi) mini_band(mb + 1, X);
+    }
+}
+
+
+
+// ---------------------------------------------------------------------------------------------
+// crop_pw_kernel (r03, TLK_CROP_WAVE=4; measured EQUAL to crop_wave3_kernel -- 187-196 vs 187-191 us -- and therefore not the default): PERSISTENT WAVEFRONTS. Every earlier crop kernel launched a workgroup per (crop, 128 output rows): 7 000 workgroups
+// each paid geometry + two tables + a 6 KB table copy behind a barrier before its first byte moved, and resident wavefronts averaged 62 % of
+// the 16 per CU (PMC, profiles/r03_crop_pmc.txt). Here the grid is 2 workgroups of 8 wavefronts per CU for the whole launch; the
+// normalisation table is copied ONCE per workgroup (the only barrier of the kernel); the VALID crops of the batch (counts[] prefix, padding
+// slots are never visited) are cut into 4-row mini-bands and every wavefront owns ONE contiguous range of them -- about 55 mini-bands, i.e.
+// half a crop, so geometry and the x table are rebuilt once or twice per wavefront, the y coefficients live in a 64-row ring refilled 32 rows
+// ahead, and the sliding window of crop_wave3_kernel (a source row is fetched, staged and taken through the horizontal pass once) runs
+// uninterrupted over the whole range. Mini-band arithmetic, hand-placed waits and store order are crop_wave3_kernel's. 16-bit outputs.
+// ---------------------------------------------------------------------------------------------
+constexpr int PW_WAVES = 8, PW_BLOCK = PW_WAVES * WAVE;
+constexpr int PW_XTAB = 128 * 8, PW_YTAB = 64 * 8, PW_ROWS = WV_SRC * CS_ROW_BYTES, PW_PLANE = WV_SRC * 128 * 6;
+constexpr int PW_WAVE_LDS = PW_XTAB + PW_YTAB + PW_ROWS + PW_PLANE;
+
+template <typename T, int LAYOUT>
+__global__ void __launch_bounds__(PW_BLOCK, 4) crop_pw_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
+                                                           const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
+                                                           int OH, const T *__restrict__ lut_g, float m0, float m1, float m2,
+                                                           float d0, float d1, float d2, T *__restrict__ out, int swap_rb)
+{
+    static_assert(sizeof(T) == 2, "the 3 KB output block of a mini-band is assembled in the staging rows: 16-bit element types");
+    constexpr int OW = 128, HS = OW * 3, GROUPS = OW / 8;
+    constexpr int LUT_BYTES = (3 * CS_LUT_N * (int)sizeof(T) + 15) & ~15;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    T *s_lut = reinterpret_cast<T *>(s_dyn);
+    unsigned char *wbase = s_dyn + LUT_BYTES + (size_t)wv * PW_WAVE_LDS;
+    int2 *s_xc = reinterpret_cast<int2 *>(wbase);
+    int *s_y = reinterpret_cast<int *>(wbase + PW_XTAB);                         // ring of 64 output rows: [(row & 63) * 2] = y0 | slot0 << 12 | y1 << 16 | slot1 << 28, [+ 1] = b0 | b1 << 16
+    unsigned char *s_rows = wbase + PW_XTAB + PW_YTAB;
+    unsigned short *s_h = reinterpret_cast<unsigned short *>(s_rows + PW_ROWS);
+    {   // the only workgroup-wide step: the (u8 -> normalised T) table
+        const int n16 = LUT_BYTES / 16;
+        const uint4 *g = reinterpret_cast<const uint4 *>(lut_g);
+        uint4 *d = reinterpret_cast<uint4 *>(s_lut);
+        for (int c = tid; c < n16; c += PW_BLOCK) d[c] = g[c];
+    }
+    __syncthreads();
+    int n_valid = 0;
+    for (int b = 0; b < B; ++b) n_valid += counts[b];
+    const int mbpc = OH / WV_ROWS;                                                 // 4-row units per crop (the host guarantees OH % 4 == 0)
+    const long long total = (long long)n_valid * mbpc;
+    const int nw = (int)gridDim.x * PW_WAVES, wg = (int)blockIdx.x * PW_WAVES + wv;
+    long long u = total * wg / nw;
+    const long long u_end = total * (wg + 1) / nw;
+    const unsigned char *gend = frames + (size_t)B * H * W * 3;
+    const unsigned int W3 = (unsigned int)W * 3u, a_step = W3 & 15u;
+    while (u < u_end) {
+        const int v = (int)(u / mbpc), ua = (int)(u - (long long)v * mbpc);
+        const int ue = (int)min((long long)mbpc, ua + (u_end - u));                // units [ua, ue) of valid crop v
+        u += ue - ua;
+        int b = 0, rem = v;
+        while (rem >= counts[b]) { rem -= counts[b]; ++b; }
+        const int slot = b * max_n + rem;
+        int l, t, r, bt;
+        crop_ltrb(boxes + (size_t)slot * 4, W, H, l, t, r, bt);
+        l = __builtin_amdgcn_readfirstlane(l); t = __builtin_amdgcn_readfirstlane(t);
+        r = __builtin_amdgcn_readfirstlane(r); bt = __builtin_amdgcn_readfirstlane(bt);
+        const int cw = r - l, ch = bt - t;
+        const bool valid = cw > 0 && ch > 0;
+        const size_t frame_off = (size_t)b * H * W * 3;
+        const unsigned char *crop0 = frames + frame_off + ((size_t)t * W + l) * 3;
+        const bool fast = valid && cw * 3 + STAGE_PAD <= CS_ROW_BYTES && ch <= 2 * OH &&
+                          frames + frame_off + ((size_t)(t + ch - 1) * W + l) * 3 + 34 * 16 <= gend;
+        const int row_a = ua * WV_ROWS, row_e = ue * WV_ROWS;
+        if (!fast) {
+            // rare: invalid / very tall / very wide crops, the last rows of the last frame -- direct sampling, a unit (row, 8 px) per lane
+            for (int row = row_a + (lane >> 4); row < row_e; row += WAVE / GROUPS) {
+                const int x_base = (lane & (GROUPS - 1)) * 8;
+                if (valid) crop_direct_unit<T, LAYOUT>(crop0, W, ch, cw, OH, OW, row, x_base, m0, m1, m2, d0, d1, d2, swap_rb, out, (size_t)slot);
+                else
+                    for (int k = 0; k < 8; ++k)
+                        for (int c = 0; c < 3; ++c) {
+                            if (LAYOUT == LAYOUT_NCHW) out[(((size_t)slot * 3 + c) * OH + row) * OW + x_base + k] = cvt<T>(0.f);
+                            else out[(((size_t)slot * OH + row) * OW + x_base + k) * 3 + c] = cvt<T>(0.f);
+                        }
+            }
+            continue;
+        }
+        // ---- per crop range: x table, first 64 rows of the y ring, lane -> (row, chunk) map of the three load slots
+        const double scale_x = (double)cw / (double)OW, scale_y = (double)ch / (double)OH;
+        for (int x = lane; x < OW; x += WAVE) {
+            const Coef cx = cv_coef_s(x, cw, scale_x, true);
+            s_xc[x] = make_int2((cx.s * 3) | ((cx.s + 1 < cw ? 3 : 0) << 16), (cx.w0 & 0xffff) | (cx.w1 << 16));
+        }
+        auto fill_y = [&](int first) {               // ring entries of output rows [first, first + 64) (first % 32 == 0: lanes 0..31 overwrite the older half when called for 32)
+            const int y = first + lane;
+            if (y < OH) {
+                const Coef cy = cv_coef_s(y, ch, scale_y, false);
+                const int y0 = clampi(cy.s, 0, ch - 1), y1 = clampi(cy.s + 1, 0, ch - 1);
+                s_y[(y & 63) * 2] = y0 | ((y0 % WV_SRC) << 12) | (y1 << 16) | ((y1 % WV_SRC) << 28);
+                s_y[(y & 63) * 2 + 1] = (cy.w0 & 0xffff) | (cy.w1 << 16);
+            }
+        };
+        int y_tab = row_a & ~31;                      // the ring holds rows [y_tab, y_tab + 64)
+        fill_y(y_tab);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int mbh = ch <= OH ? WV_ROWS : 2;       // mini-bands of 4 rows (<= 6 source rows each while the crop is not taller than the output), of 2 rows up to twice as tall
+        const int mb_lo = row_a / mbh, mb_hi = row_e / mbh;
+        const int cmax = (cw * 3 + 30) >> 4;          // 16-byte chunks per staged row (<= 32: three load slots cover 6 rows)
+        const int cw3 = cw * 3;
+        int sl_rr[3], sl_c[3], sl_lds[3];
+        unsigned int sl_goff[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int idx = lane + q * WAVE;
+            sl_rr[q] = idx / cmax; sl_c[q] = idx - sl_rr[q] * cmax;
+            sl_lds[q] = sl_rr[q] * CS_ROW_BYTES + sl_c[q] * 16;
+            sl_goff[q] = (unsigned int)sl_rr[q] * W3;
+        }
+        auto ytab = [&](int row) -> const int * { return s_y + (row & 63) * 2; };
+        struct RowRegs { tlk_u32x4 a, b, c; int r_lo, nrows; };
+        RowRegs X{tlk_u32x4{0, 0, 0, 0}, tlk_u32x4{0, 0, 0, 0}, tlk_u32x4{0, 0, 0, 0}, 0, 0}, Y = X;
+        auto fetch = [&](int mb_req, RowRegs &R) {    // inline-asm loads + hand-placed vmcnt(3): see crop_wave2_kernel; only the NEW source rows: see crop_wave3_kernel
+            const int mb = min(mb_req, mb_hi - 1);
+            const int ra = mb * mbh, rb = ra + mbh - 1;
+            const int r_first = __builtin_amdgcn_readfirstlane(ytab(ra)[0] & 0x7ff);
+            const int r_last = __builtin_amdgcn_readfirstlane((int)(((unsigned int)ytab(rb)[0] >> 16) & 0x7ffu));
+            const int done = mb > mb_lo ? __builtin_amdgcn_readfirstlane((int)(((unsigned int)ytab(ra - 1)[0] >> 16) & 0x7ffu)) : -1;
+            const int r_lo_n = max(r_first, done + 1);
+            const int nrows_n = r_last - r_lo_n + 1;
+            const unsigned char *rowp = crop0 + (size_t)r_lo_n * W3;
+            auto addr = [&](int q) {
+                const bool in = sl_rr[q] < nrows_n;
+                const unsigned char *g0 = rowp + (in ? sl_goff[q] : 0u);
+                const int mis = (int)((uintptr_t)g0 & 15);
+                return g0 - mis + (size_t)((in && sl_c[q] < ((mis + cw3 + 15) >> 4)) ? sl_c[q] : 0) * 16;
+            };
+            const unsigned char *p0 = addr(0), *p1 = addr(1), *p2 = addr(2);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(R.a) : "v"(p0));
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(R.b) : "v"(p1));
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(R.c) : "v"(p2));
+            R.r_lo = r_lo_n; R.nrows = nrows_n;
+        };
+        auto wait_rows = [&](RowRegs &R) { asm volatile("s_waitcnt vmcnt(3)" : "+v"(R.a), "+v"(R.b), "+v"(R.c)); };
+        int st_r_lo = 0, st_nrows = 0;
+        auto stage = [&](const RowRegs &R) {
+            const int nrows = R.nrows;
+            if (sl_rr[0] < nrows) *reinterpret_cast<tlk_u32x4 *>(s_rows + sl_lds[0]) = R.a;
+            if (sl_rr[1] < nrows) *reinterpret_cast<tlk_u32x4 *>(s_rows + sl_lds[1]) = R.b;
+            if (sl_rr[2] < nrows) *reinterpret_cast<tlk_u32x4 *>(s_rows + sl_lds[2]) = R.c;
+            st_r_lo = R.r_lo; st_nrows = nrows;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        const int4 xc2 = *reinterpret_cast<const int4 *>(&s_xc[2 * lane]);
+        const int oA = xc2.x & 0xffff, oB = xc2.z & 0xffff;
+        const unsigned int selA = 0x0c000c00u | ((unsigned int)(xc2.x >> 16) << 16), selB = 0x0c000c00u | ((unsigned int)(xc2.z >> 16) << 16);
+        const us2_t wA = __builtin_bit_cast(us2_t, xc2.y), wB = __builtin_bit_cast(us2_t, xc2.w);
+        auto mini_band = [&](int mb, RowRegs &N) {
+            const int r_lo = st_r_lo, nrows = st_nrows;
+            {
+                const unsigned int a_lo = (unsigned int)(uintptr_t)(crop0 + (size_t)r_lo * W3) & 15u;
+                auto taps = [&](int addr, unsigned int &lo, unsigned int &hi) {
+                    const unsigned int *q = reinterpret_cast<const unsigned int *>(s_rows + (addr & ~3));
+                    const unsigned int e0 = q[0], e1 = q[1], e2 = q[2];
+                    lo = __builtin_amdgcn_alignbyte(e1, e0, (unsigned int)addr & 3u);
+                    hi = __builtin_amdgcn_alignbyte(e2, e1, (unsigned int)addr & 3u);
+                };
+                for (int rr = 0; rr < nrows; ++rr) {
+                    const int base = rr * CS_ROW_BYTES + (int)((a_lo + (unsigned int)rr * a_step) & 15u);
+                    unsigned int loA, hiA, loB, hiB;
+                    taps(base + oA, loA, hiA);
+                    taps(base + oB, loB, hiB);
+                    unsigned int *o = reinterpret_cast<unsigned int *>(s_h + ((r_lo + rr) % WV_SRC) * HS) + lane;
+#pragma unroll
+                    for (int c3 = 0; c3 < 3; ++c3) {
+                        const unsigned int va = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(hiA, loA, selA + 0x00010001u * c3)), wA, 0u, false) >> 4;
+                        const unsigned int vb = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(hiB, loB, selB + 0x00010001u * c3)), wB, 0u, false) >> 4;
+                        o[c3 * (OW / 2)] = va | (vb << 16);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int ry = lane >> 4, x_base = (lane & (GROUPS - 1)) * 8;
+            const int y = mb * mbh + ry;
+            const bool act = ry < mbh;
+            const bool block = LAYOUT == LAYOUT_NHWC && mbh == WV_ROWS;                   // wave-uniform: the mini-band is one contiguous 3 KB output block
+            T px[8][3];
+            if (act) {
+                const unsigned int yi = (unsigned int)ytab(y)[0], yw = (unsigned int)ytab(y)[1];
+                const unsigned short *h0 = s_h + ((yi >> 12) & 7u) * HS + x_base;             // planar: [channel][x]; row = its ring slot
+                const unsigned short *h1 = s_h + ((yi >> 28) & 7u) * HS + x_base;
+                const unsigned int b0 = yw & 0xffffu, b1 = yw >> 16;
+                unsigned int w0[12], w1[12];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const uint4 p = *reinterpret_cast<const uint4 *>(h0 + c * OW), q = *reinterpret_cast<const uint4 *>(h1 + c * OW);
+                    w0[c * 4] = p.x; w0[c * 4 + 1] = p.y; w0[c * 4 + 2] = p.z; w0[c * 4 + 3] = p.w;
+                    w1[c * 4] = q.x; w1[c * 4 + 1] = q.y; w1[c * 4 + 2] = q.z; w1[c * 4 + 3] = q.w;
+                }
+#pragma unroll
+                for (int q = 0; q < 24; ++q) {
+                    const int c = q >> 3, kk = q & 7;
+                    const unsigned int a = (kk & 1) ? (w0[c * 4 + (kk >> 1)] >> 16) : (w0[c * 4 + (kk >> 1)] & 0xffffu);
+                    const unsigned int c1 = (kk & 1) ? (w1[c * 4 + (kk >> 1)] >> 16) : (w1[c * 4 + (kk >> 1)] & 0xffffu);
+                    const unsigned int xa = __umul24(b0, a), xb = __umul24(b1, c1);
+                    unsigned int tt;                    // <= 1020 always (see crop_sep_kernel)
+                    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(tt) : "v"(xa), "v"(xb));
+                    px[kk][c] = s_lut[c * CS_LUT_N + tt];
+                }
+                if (swap_rb) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const T t0 = px[k][0]; px[k][0] = px[k][2]; px[k][2] = t0; }
+                }
+            }
+            constexpr int NST = 3 * (int)sizeof(T) / 2;
+            uint4 blk[NST];
+            if (block) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                T *o = reinterpret_cast<T *>(s_rows) + ((size_t)ry * OW + x_base) * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    Pack<T, 8> p;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
+                    *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint4 *l4 = reinterpret_cast<const uint4 *>(s_rows);
+#pragma unroll
+                for (int k = 0; k < NST; ++k) blk[k] = l4[k * WAVE + lane];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the staging rows are dead from here (the ring plane lives on)
+            __builtin_amdgcn_wave_barrier();
+            if (mb + 1 < mb_hi) {
+                const int nxt = (mb + 1) * mbh;                         // entering the second half of the y ring: refill the half behind (rows 32 ahead of it)
+                if (nxt >= y_tab + 32) { y_tab += 32; if (lane < 32) fill_y(y_tab + 32); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+                wait_rows(N);
+                stage(N);
+                fetch(mb + 3, N);
+            }
+            if (block) {
+                uint4 *g = reinterpret_cast<uint4 *>(out + ((size_t)slot * OH + (size_t)mb * mbh) * OW * 3);
+#pragma unroll
+                for (int k = 0; k < NST; ++k) stream_store(g + k * WAVE + lane, blk[k]);
+            } else if (act) {
+                if (LAYOUT == LAYOUT_NCHW) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        Pack<T, 8> p;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) p.v[k] = px[k][c];
+                        *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)slot * 3 + c) * OH + y) * OW + x_base) = p;
+                    }
+                } else {
+                    T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        Pack<T, 8> p;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
+                        *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+                    }
+                }
+            }
+        };
+        fetch(mb_lo, X);
+        fetch(mb_lo + 1, Y);
+        wait_rows(X);
+        stage(X);
+        fetch(mb_lo + 2, X);
+        for (int mb = mb_lo; mb < mb_hi; mb += 2) {
+            mini_band(mb, Y);
+            if (mb + 1 < mb_hi) mini_band(mb + 1, X);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain before the next range re-uses the register sets (its waits count from a clean slate)
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Plain StrongSORT's ReID input: crop ori_img[y1:y2, x1:x2] of the int-truncated, clipped box
 // (strong_sort.py:102-108, :135-141) -> Pillow Image.resize(BILINEAR) -> ToTensor -> Normalize
@@ -2112,8 +2684,35 @@ int launch_crop(const unsigned char *frames, int B, int H, int W, const float *b
             const int bands = (OH + CS_BAND - 1) / CS_BAND, chunks = (bands + CF_BANDS - 1) / CF_BANDS;
             const int nwg2 = (int)((long long)B * max_n * chunks);
             const size_t smem2 = (size_t)CS_ROWS * CS_ROW_BYTES + (size_t)CS_ROWS * 128 * 6 + 128 * 8 + (size_t)3 * CS_LUT_N * sizeof(T);
-            static const int wave = [] { const char *e = getenv("TLK_CROP_WAVE"); return e ? atoi(e) : 2; }();       // 2 (default): crop_wave2_kernel (hand-placed waits); 1: crop_wave_kernel; 0: crop_fat_kernel
+            static const int wave = [] { const char *e = getenv("TLK_CROP_WAVE"); return e ? atoi(e) : 3; }();       // 3 (default; 16-bit outputs): crop_wave3_kernel (sliding window); 4: crop_pw_kernel (persistent wavefronts, measured equal); 2: crop_wave2_kernel (hand-placed waits; fp32 outputs); 1: crop_wave_kernel; 0: crop_fat_kernel
             const size_t smem3 = (size_t)128 * 8 + ((3 * CS_LUT_N * sizeof(T) + 15) & ~(size_t)15) + (size_t)NWAVES * WV_WAVE_LDS;
+            if constexpr (sizeof(T) == 2) {
+                if (wave >= 4 && OH % WV_ROWS == 0) {       // persistent wavefronts: 2 workgroups of 8 per CU walk the valid crops
+                    static int n_cu = 0;
+                    if (n_cu == 0) {
+                        int dev = 0, v = 0;
+                        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+                        n_cu = v;
+                    }
+                    const size_t smem4 = ((3 * CS_LUT_N * sizeof(T) + 15) & ~(size_t)15) + (size_t)PW_WAVES * PW_WAVE_LDS;
+                    static bool attr_nchw = false, attr_nhwc = false;
+                    if (layout == LAYOUT_NCHW) {
+                        if (!attr_nchw) { if (hipFuncSetAttribute((const void *)crop_pw_kernel<T, LAYOUT_NCHW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4) != hipSuccess) return TLK_EHIP; attr_nchw = true; }
+                        hipLaunchKernelGGL((crop_pw_kernel<T, LAYOUT_NCHW>), dim3(2 * n_cu), dim3(PW_BLOCK), smem4, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb);
+                    } else {
+                        if (!attr_nhwc) { if (hipFuncSetAttribute((const void *)crop_pw_kernel<T, LAYOUT_NHWC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4) != hipSuccess) return TLK_EHIP; attr_nhwc = true; }
+                        hipLaunchKernelGGL((crop_pw_kernel<T, LAYOUT_NHWC>), dim3(2 * n_cu), dim3(PW_BLOCK), smem4, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb);
+                    }
+                    return TLK_OK;
+                }
+                if (wave >= 3) {
+                    if (layout == LAYOUT_NCHW)
+                        hipLaunchKernelGGL((crop_wave3_kernel<T, LAYOUT_NCHW>), dim3(nwg2), dim3(BLOCK), smem3, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg2);
+                    else
+                        hipLaunchKernelGGL((crop_wave3_kernel<T, LAYOUT_NHWC>), dim3(nwg2), dim3(BLOCK), smem3, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg2);
+                    return TLK_OK;
+                }
+            }
             if (wave >= 2 && layout == LAYOUT_NCHW)
                 hipLaunchKernelGGL((crop_wave2_kernel<T, LAYOUT_NCHW>), dim3(nwg2), dim3(BLOCK), smem3, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg2);
             else if (wave >= 2)
