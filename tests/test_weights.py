@@ -172,3 +172,43 @@ def test_resnet50_batchnorm_checkpoint_folds_into_the_reid_backbone():
         a, b = ref(x), own(x)
     assert a.shape == b.shape
     np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_load_checkpoint_entry_point(tmp_path):
+    """What cfg.checkpoint of the Hip* modules accepts: an ONNX file, this repo's state_dict, a BatchNorm ResNet-50 checkpoint; a missing file is loud."""
+    from tracklab_amd.backbones.reid import PartBasedReID
+    src, dst = _yolox(0), _yolox(3)
+    x = torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    onnx_path = tmp_path / "det.onnx"
+    onnx_path.write_bytes(W.export_onnx_bytes(src, (x,)))
+    rep = W.load_checkpoint(dst, onnx_path, (x,))
+    assert rep["format"] == "onnx" and rep["tensors"] == len(src.state_dict())
+    with torch.no_grad():
+        assert torch.equal(dst(x), src(x))
+    pt = tmp_path / "det.pt"
+    torch.save({"state_dict": src.state_dict()}, pt)
+    dst2 = _yolox(4)
+    assert W.load_checkpoint(dst2, pt)["format"] == "state_dict"
+    with torch.no_grad():
+        assert torch.equal(dst2(x), src(x))
+    with pytest.raises(FileNotFoundError):
+        W.load_checkpoint(dst, tmp_path / "nope.onnx", (x,))
+    # torchreid-style file: BatchNorm ResNet-50 under a prefix + head keys this network does not have
+    import torch.nn as nn
+    reid = PartBasedReID(6, 64).eval()
+    sd = {}
+    g = torch.Generator().manual_seed(0)
+    for conv, bn, tw, tb in W.resnet50_bn_pairs("module.backbone."):
+        w = reid.backbone.state_dict()[tw]
+        sd[conv + ".weight"] = torch.randn(w.shape, generator=g) * 0.05
+        for k, v in (("weight", 1.0), ("bias", 0.0), ("running_mean", 0.0), ("running_var", 1.0)):
+            sd[f"{bn}.{k}"] = torch.full((w.shape[0],), v) + torch.rand(w.shape[0], generator=g) * 0.1
+    sd["module.classifier.weight"] = torch.zeros(10, 2048)
+    ck = tmp_path / "reid.pth.tar"
+    torch.save({"state_dict": sd, "epoch": 3}, ck)
+    rep = W.load_checkpoint(reid, ck)
+    assert rep["format"] == "resnet50+batchnorm" and rep["unmapped_keys"] == ["module.classifier.weight"]
+    exp_w, exp_b = W.fold_batchnorm(sd["module.backbone.conv1.weight"], sd["module.backbone.bn1.weight"], sd["module.backbone.bn1.bias"],
+                                    sd["module.backbone.bn1.running_mean"], sd["module.backbone.bn1.running_var"])
+    np.testing.assert_array_equal(reid.backbone.conv1.conv.weight.detach().numpy(), exp_w)
+    np.testing.assert_array_equal(reid.backbone.conv1.bias.detach().numpy(), exp_b)

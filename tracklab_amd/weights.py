@@ -550,3 +550,50 @@ def resnet50_bn_pairs(prefix=""):
             if b == 0:
                 pairs.append((f"{src}.downsample.0", f"{src}.downsample.1", f"{dst}.down.conv.weight", f"{dst}.down.bias"))
     return pairs
+
+
+# ------------------------------------------------------------------------------------------------ one entry point for the plugin modules
+def load_checkpoint(module, path, example_inputs=None, backbone_attr="backbone"):
+    """What `cfg.checkpoint` / `cfg.model_weights` of the Hip* modules accepts:
+
+    * ``*.onnx`` -- the artefact the reference itself loads for its detector / pose estimator (rtmlib model zoo,
+      configs/modules/bbox_detector/yolox_rtmlib.yaml:1-7): imported structurally (`import_onnx_weights`) through a CPU fp32 twin of `module`;
+      `example_inputs` = a tuple with one input of the network's shape.
+    * a torch checkpoint whose keys are `module`'s own -> `load_state_dict`.
+    * a torch checkpoint of a ResNet-50 WITH BatchNorm layers in torchvision / torchreid naming (optionally under a prefix, optionally wrapped in
+      {"state_dict": ...}; tracklab/wrappers/reid/kpreid_api.py:133-161 loads such files through torchreid): the backbone is folded
+      (`fold_batchnorm_state_dict`) into ``getattr(module, backbone_attr)``; keys outside the backbone that do not exist here are returned.
+
+    A path that does not exist raises FileNotFoundError -- never a silent fall-back to random weights. Returns a dict with what was done."""
+    import copy
+    import os
+    import torch
+    path = str(path)
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"checkpoint {path!r} does not exist; use null for random-init weights (throughput only)")
+    if path.lower().endswith(".onnx"):
+        if example_inputs is None:
+            raise ValueError("load_checkpoint: an ONNX file needs example_inputs (one input tensor of the network's shape)")
+        twin = copy.deepcopy(module).to(device="cpu", dtype=torch.float32).to(memory_format=torch.contiguous_format)
+        n = import_onnx_weights(twin, tuple(t.detach().to("cpu", torch.float32) for t in example_inputs), path)
+        module.load_state_dict(twin.state_dict())
+        return {"format": "onnx", "tensors": n}
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
+        sd = sd["state_dict"]
+    own = module.state_dict()
+    if set(sd) == set(own):
+        module.load_state_dict(sd)
+        return {"format": "state_dict", "tensors": len(sd)}
+    bn_key = next((k for k in sd if k.endswith("layer1.0.bn1.running_mean")), None)
+    if bn_key is not None and hasattr(module, backbone_attr):
+        prefix = bn_key[:-len("layer1.0.bn1.running_mean")]
+        folded = fold_batchnorm_state_dict(sd, resnet50_bn_pairs(prefix))
+        bb = getattr(module, backbone_attr)
+        bb.load_state_dict({k: torch.from_numpy(v) for k, v in folded.items()})
+        used = {p[0] + s for p in resnet50_bn_pairs(prefix) for s in (".weight", ".bias")} | \
+               {p[1] + s for p in resnet50_bn_pairs(prefix) for s in (".weight", ".bias", ".running_mean", ".running_var", ".num_batches_tracked")}
+        left = sorted(k for k in sd if k not in used)
+        return {"format": "resnet50+batchnorm", "tensors": len(folded), "unmapped_keys": left}
+    missing = sorted(set(own) - set(sd))[:5]
+    raise ValueError(f"checkpoint {path!r}: neither this module's state_dict (missing e.g. {missing}) nor a ResNet-50 with BatchNorm layers")

@@ -34,8 +34,9 @@ class HipYOLOX(ImageLevelModule):
             from ..backbones.yolox import yolox
             self._torch = torch
             self._model = yolox(self.arch, 1, device=self.device, dtype=torch.float16, channels_last=True)
-            if self.checkpoint:
-                self._model.load_state_dict(torch.load(self.checkpoint, map_location=self.device))
+            if self.checkpoint:          # state_dict, the reference's own ONNX artefact, or a BatchNorm ResNet-50 checkpoint (tracklab_amd/weights.py)
+                from ..weights import load_checkpoint
+                self.checkpoint_report = load_checkpoint(self._model, self.checkpoint, (torch.zeros(1, 3, self.size, self.size),))
 
     def preprocess(self, image, detections: pd.DataFrame, metadata: pd.Series):
         # TrackLab hands RGB (cv2_load_image); the reference detector re-reads the file as BGR (rtmlib_api.py:28): the frame stays RGB

@@ -32,8 +32,9 @@ class HipRTMPose(ImageLevelModule):
             from ..backbones.rtmpose import rtmpose
             self._torch = torch
             self._model = rtmpose(self.arch, device=self.device, dtype=torch.float16, channels_last=True)
-            if self.checkpoint:
-                self._model.load_state_dict(torch.load(self.checkpoint, map_location=self.device))
+            if self.checkpoint:          # state_dict, the reference's own ONNX artefact, or a BatchNorm ResNet-50 checkpoint (tracklab_amd/weights.py)
+                from ..weights import load_checkpoint
+                self.checkpoint_report = load_checkpoint(self._model, self.checkpoint, (torch.zeros(1, 3, self.in_h, self.in_w),))
 
     def preprocess(self, image, detections: pd.DataFrame, metadata: pd.Series):
         n = len(detections)

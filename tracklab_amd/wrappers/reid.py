@@ -34,8 +34,9 @@ class HipPartReID(ImageLevelModule):
             from ..backbones.reid import part_based_reid
             self._torch = torch
             self._model = part_based_reid(self.parts, self.dim, device=self.device, dtype=torch.float16, channels_last=True, arch=self.backbone)
-            if self.checkpoint:
-                self._model.load_state_dict(torch.load(self.checkpoint, map_location=self.device))
+            if self.checkpoint:          # state_dict, the reference's own ONNX artefact, or a BatchNorm ResNet-50 checkpoint (tracklab_amd/weights.py)
+                from ..weights import load_checkpoint
+                self.checkpoint_report = load_checkpoint(self._model, self.checkpoint, (torch.zeros(1, 3, self.height, self.width),))
 
     def preprocess(self, image, detections: pd.DataFrame, metadata: pd.Series):
         n = len(detections)

@@ -229,7 +229,8 @@ class _ReidTrackerBase:
                 if not os.path.exists(str(ckpt)):       # never fall back to random weights silently (the reference's OSNet / BPBReID
                     raise FileNotFoundError(             # checkpoints are not loadable either: INTEGRATION.md "checkpoints")
                         f"model_weights {ckpt!r} does not exist; set model_weights: null to run with random-init weights (throughput only)")
-                self._model.load_state_dict(torch.load(str(ckpt), map_location=self.device))
+                from ..weights import load_checkpoint
+                self.checkpoint_report = load_checkpoint(self._model, ckpt, (torch.zeros(1, 3, 256, 128),))
         frames = (image if hasattr(image, "detach") else torch.from_numpy(np.asarray(image))).to(self.device)
         if frames.dim() == 3:
             frames = frames[None]
