@@ -139,6 +139,8 @@ def test_strongsort_module_host_logic_with_oracle_backend(orc):
     m = HipStrongSORT(NS(min_confidence=0.4, ecc=False, hyperparams=hyper), "cuda:0", tracking_dataset=None)
     assert m.level == "image" and m.batch_size == 1 and m.output_columns == ["track_id", "track_bbox_ltwh", "track_bbox_conf"]
     m._make_backend = lambda dim, h, w: Backend()
+    import torch
+    m._frame_on_device = lambda image: torch.from_numpy(np.ascontiguousarray(np.asarray(image)).reshape(1080, 1920, 3))     # no GPU here: the "device" frame stays on the host
     ref = orc.PlainStrongSORT(D, **hyper, img_w=1920, img_h=1080)
     frame = np.zeros((1080, 1920, 3), np.uint8)
     seen = 0
@@ -186,17 +188,18 @@ def test_strongsort_module_ecc_flow_with_a_stand_in_estimator(orc, monkeypatch):
             self.h, self.w, self.first = h, w, True
             Estimator.made += 1
 
-        def apply(self, frame):
-            assert frame.shape == (1080, 1920, 3) and frame.dtype == np.uint8
+        def apply_dev(self, frame, stream_ptr=None):             # (warp (6,) float64, status) tensors, as tlk_ecc_apply_dev leaves them in HBM
+            import torch
+            assert tuple(frame.shape) == (1080, 1920, 3) and frame.dtype == torch.uint8
             if self.first:
                 self.first = False
-                return None
+                return torch.zeros(6, dtype=torch.float64), torch.tensor([0], dtype=torch.int32)
             if len(calls) == 4:
                 calls.append(None)                   # cv2.error in the reference: no camera update for this frame
-                return None
+                return torch.zeros(6, dtype=torch.float64), torch.tensor([-1], dtype=torch.int32)
             w = np.array([[1, -0.002, rng.normal(0, 3)], [0.002, 1, rng.normal(0, 2)]], dtype=np.float32)
             calls.append(w.copy())
-            return w
+            return torch.from_numpy(w.astype(np.float64).reshape(6)), torch.tensor([7], dtype=torch.int32)
 
         def reset(self):
             self.first = True
@@ -221,6 +224,8 @@ def test_strongsort_module_ecc_flow_with_a_stand_in_estimator(orc, monkeypatch):
 
     m = HipStrongSORT(NS(min_confidence=0.4, ecc=True, hyperparams=hyper), "cuda:0", tracking_dataset=None)
     m._make_backend = lambda dim, h, w: Backend()
+    import torch
+    m._frame_on_device = lambda image: torch.from_numpy(np.ascontiguousarray(np.asarray(image)).reshape(1080, 1920, 3))     # no GPU here: the "device" frame stays on the host
     ref = orc.PlainStrongSORT(D, **hyper, img_w=1920, img_h=1080)
     frame = np.zeros((1080, 1920, 3), np.uint8)
     seen, k = 0, 0

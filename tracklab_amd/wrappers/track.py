@@ -215,6 +215,21 @@ class _ReidTrackerBase:
         out[:, 6] = detections.index.to_numpy().astype(np.int64)
         return {"input": out, "image": np.ascontiguousarray(image)}         # the frame travels with the batch instead of a second disk read
 
+    def _frame_on_device(self, image):
+        """The frame of the current `process` call as a (H, W, 3) uint8 device tensor -- uploaded ONCE and shared by the ReID crop-out and the
+        camera-motion estimator (the estimator used to copy the host frame a second time, synchronously)."""
+        import torch
+        if hasattr(image, "detach") and image.is_cuda:
+            return image[0] if image.dim() == 4 else image
+        arr = np.asarray(to_numpy(image) if hasattr(image, "detach") else image)
+        if arr.ndim == 4:
+            arr = arr[0]
+        key = (arr.__array_interface__["data"][0], arr.shape)
+        cached = getattr(self, "_dev_frame", None)
+        if cached is None or cached[0] != key:
+            self._dev_frame = (key, torch.from_numpy(np.ascontiguousarray(arr)).to(self.device))
+        return self._dev_frame[1]
+
     def _features(self, image, dets):
         """StrongSORT._get_features (strong_sort.py:135-145) for all rows of `dets` (n, 7) on the GPU -> (n, D) float32 numpy."""
         import torch
@@ -231,9 +246,7 @@ class _ReidTrackerBase:
                         f"model_weights {ckpt!r} does not exist; set model_weights: null to run with random-init weights (throughput only)")
                 from ..weights import load_checkpoint
                 self.checkpoint_report = load_checkpoint(self._model, ckpt, (torch.zeros(1, 3, 256, 128),))
-        frames = (image if hasattr(image, "detach") else torch.from_numpy(np.asarray(image))).to(self.device)
-        if frames.dim() == 3:
-            frames = frames[None]
+        frames = self._frame_on_device(image)[None]
         n = len(dets)
         boxes = torch.from_numpy(np.ascontiguousarray(dets, dtype=np.float64)[None]).to(self.device)
         counts = torch.tensor([n], dtype=torch.int32, device=self.device)
@@ -313,11 +326,17 @@ class HipStrongSORT(ImageLevelModule, _ReidTrackerBase):
         if image is None:                                                    # strong_sort_api.py:61: the frame is read before the empty check
             from PIL import Image
             image = np.asarray(Image.open(metadatas["file_path"].values[0]).convert("RGB"))
-        img = np.ascontiguousarray(to_numpy(image))
-        if self._ecc_est is None or (self._ecc_est.h, self._ecc_est.w) != img.shape[:2]:
+        dev = self._frame_on_device(image)
+        if self._ecc_est is None or (self._ecc_est.h, self._ecc_est.w) != tuple(dev.shape[:2]):
             from .. import _lib
-            self._ecc_est = _lib.EccEstimator(img.shape[0], img.shape[1], device=_device_index(self.device))
-        warp = self._ecc_est.apply(img)                                      # None on the first frame of a video and where cv2 raises
+            if self._ecc_est is not None:
+                import logging
+                logging.getLogger(__name__).warning("HipStrongSORT: frame size changed inside a video (%s -> %s): the ECC estimator restarts without a "
+                                                    "previous frame", (self._ecc_est.h, self._ecc_est.w), tuple(dev.shape[:2]))
+            self._ecc_est = _lib.EccEstimator(int(dev.shape[0]), int(dev.shape[1]), device=_device_index(self.device))
+        warp_dev, status_dev = self._ecc_est.apply_dev(dev.contiguous())     # on the current stream, from the frame that is already in HBM
+        status = int(status_dev.item())                                      # one 4-byte read-back: >= 1 iterations run, -1 where cv2 raises, 0 first frame
+        warp = warp_dev.cpu().numpy().reshape(2, 3).astype(np.float32) if status >= 1 else None
         if warp is not None and self._bank is not None:
             self._bank.camera_update(warp, 0)
 
@@ -369,10 +388,14 @@ class HipBoTSORT(ImageLevelModule, _ReidTrackerBase):
         warp = None
         if self._cmc_method == "sparseOptFlow":              # bot_sort.py:341: warp = self.gmc.apply(img, dets)
             from .._lib import CmcEstimator
-            frame = to_numpy(image) if hasattr(image, "detach") else np.asarray(image)
-            if self._cmc is None or (self._cmc.h, self._cmc.w) != frame.shape[:2]:
-                self._cmc = CmcEstimator(frame.shape[0], frame.shape[1], downscale=2, device=_device_index(self.device))
-            warp = self._cmc.apply(frame)
+            dev = self._frame_on_device(image)
+            if self._cmc is None or (self._cmc.h, self._cmc.w) != tuple(dev.shape[:2]):
+                if self._cmc is not None:
+                    import logging
+                    logging.getLogger(__name__).warning("HipBoTSORT: frame size changed inside a video (%s -> %s): the camera-motion estimator restarts "
+                                                        "without a previous frame", (self._cmc.h, self._cmc.w), tuple(dev.shape[:2]))
+                self._cmc = CmcEstimator(int(dev.shape[0]), int(dev.shape[1]), downscale=2, device=_device_index(self.device))
+            warp = self._cmc.apply_dev(dev.contiguous()).cpu().numpy().reshape(2, 3)      # estimated from the frame already in HBM; 48 bytes back
         return self._bank.update(inputs, feats, 0, warp=warp)
 
     def _make_backend(self, dim, img_h, img_w):
