@@ -15,6 +15,7 @@
  * compute_aw_max_metric's row / column weights are float32 arithmetic on it. Everything else is float64.
  */
 #include "orc.h"
+#include "lapack_order.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -28,37 +29,6 @@ typedef struct {
     double last_z[4];
     int gap;
 } kfn;
-
-static void mm(const double *A, const double *B, double *C, int n, int k, int m)
-{
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < m; ++j) {
-            double s = 0;
-            for (int t = 0; t < k; ++t) s += A[i * k + t] * B[t * m + j];
-            C[i * m + j] = s;
-        }
-}
-static void inv4(const double *S, double *SI)    /* np.linalg.inv: LU with partial pivoting */
-{
-    double a[4][8];
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { a[i][j] = S[i * 4 + j]; a[i][4 + j] = (i == j); }
-    for (int c = 0; c < 4; ++c) {
-        int p = c;
-        for (int r = c + 1; r < 4; ++r) if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
-        if (p != c) for (int j = 0; j < 8; ++j) { double t = a[c][j]; a[c][j] = a[p][j]; a[p][j] = t; }
-        for (int r = c + 1; r < 4; ++r) {
-            double f = a[r][c] / a[c][c];
-            for (int j = c; j < 8; ++j) a[r][j] -= f * a[c][j];
-        }
-    }
-    for (int c = 3; c >= 0; --c)
-        for (int j = 4; j < 8; ++j) {
-            double s = a[c][j];
-            for (int t = c + 1; t < 4; ++t) s -= a[c][t] * a[t][j];
-            a[c][j] = s / a[c][c];
-        }
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) SI[i * 4 + j] = a[i][4 + j];
-}
 
 static void noise8(double w, double h, double *q)          /* new_kf_process_noise (ocsort.py:77-82) */
 {
@@ -79,10 +49,10 @@ static void kfn_predict(kfn *k, const double *qdiag)       /* kalmanfilter.py:34
     for (int i = 0; i < 8; ++i) F[i * 9] = 1;
     for (int i = 0; i < 4; ++i) F[i * 8 + i + 4] = 1;
     for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) Ft[i * 8 + j] = F[j * 8 + i];
-    mm(F, k->x, nx, 8, 8, 1);
+    lo_gemm(F, k->x, nx, 8, 8, 1);
     memcpy(k->x, nx, sizeof(nx));
-    mm(F, k->P, t1, 8, 8, 8);
-    mm(t1, Ft, t2, 8, 8, 8);
+    lo_gemm(F, k->P, t1, 8, 8, 8);
+    lo_gemm(t1, Ft, t2, 8, 8, 8);
     for (int i = 0; i < 64; ++i) k->P[i] = 1.0 * t2[i];
     for (int i = 0; i < 8; ++i) k->P[i * 9] += qdiag[i];
 }
@@ -92,19 +62,17 @@ static void kfn_update_core(kfn *k, const double *z, const double *rdiag)       
     for (int i = 0; i < 4; ++i) y[i] = z[i] - k->x[i];
     for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) PHT[i * 4 + j] = k->P[i * 8 + j];
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) S[i * 4 + j] = PHT[i * 4 + j] + (i == j ? rdiag[i] : 0.0);
-    inv4(S, SI);
-    mm(PHT, SI, K, 8, 4, 4);
+    lo_inv4(S, SI);                /* np.linalg.inv in LAPACK's operation order (lapack_order.h) */
+    lo_gemm(PHT, SI, K, 8, 4, 4);
     for (int i = 0; i < 8; ++i) {
-        double s = 0;
-        for (int j = 0; j < 4; ++j) s += K[i * 4 + j] * y[j];
-        k->x[i] = k->x[i] + s;
+        k->x[i] = k->x[i] + lo_dot4_h2(K + i * 4, y);          /* x + dot(K, y): dgemv order */
     }
     for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) IKH[i * 8 + j] = (i == j ? 1.0 : 0.0) - (j < 4 ? K[i * 4 + j] : 0.0);
     for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) IKHt[i * 8 + j] = IKH[j * 8 + i];
-    mm(IKH, k->P, t1, 8, 8, 8);
-    mm(t1, IKHt, t2, 8, 8, 8);
+    lo_gemm(IKH, k->P, t1, 8, 8, 8);
+    lo_gemm(t1, IKHt, t2, 8, 8, 8);
     for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) { KR[i * 4 + j] = K[i * 4 + j] * rdiag[j]; Kt[j * 8 + i] = K[i * 4 + j]; }
-    mm(KR, Kt, t3, 8, 4, 8);
+    lo_gemm(KR, Kt, t3, 8, 4, 8);
     for (int i = 0; i < 64; ++i) k->P[i] = t2[i] + t3[i];
 }
 static void kfn_update(kfn *k, const double *z /* or NULL */, const double *rdiag)

@@ -1,6 +1,7 @@
 /* CPU ORACLE (test infrastructure) -- see orc.h.
  * OC-SORT restated from plugins/track/oc_sort/{ocsort,association,kalmanfilter}.py. */
 #include "orc.h"
+#include "lapack_order.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -34,52 +35,19 @@ static void kf7_Q(double *q)   /* ocsort.py:83-84 */
     for (int i = 4; i < 7; ++i) q[i] *= 0.01;
 }
 
-static void mat_mul(const double *A, const double *B, double *C, int n, int k, int m)
-{
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < m; ++j) {
-            double s = 0;
-            for (int t = 0; t < k; ++t) s += A[i * k + t] * B[t * m + j];
-            C[i * m + j] = s;
-        }
-}
-
 static void kf7_predict(kf7 *k)   /* kalmanfilter.py:368-379 with F of ocsort.py:75-76 */
 {
     static const double F[49] = {1,0,0,0,1,0,0, 0,1,0,0,0,1,0, 0,0,1,0,0,0,1, 0,0,0,1,0,0,0,
                                  0,0,0,0,1,0,0, 0,0,0,0,0,1,0, 0,0,0,0,0,0,1};
     double Ft[49], t1[49], t2[49], nx[7], q[7];
     for (int i = 0; i < 7; ++i) for (int j = 0; j < 7; ++j) Ft[i * 7 + j] = F[j * 7 + i];
-    mat_mul(F, k->x, nx, 7, 7, 1);
+    lo_gemm(F, k->x, nx, 7, 7, 1);
     memcpy(k->x, nx, sizeof(nx));
-    mat_mul(F, k->P, t1, 7, 7, 7);
-    mat_mul(t1, Ft, t2, 7, 7, 7);
+    lo_gemm(F, k->P, t1, 7, 7, 7);
+    lo_gemm(t1, Ft, t2, 7, 7, 7);
     kf7_Q(q);
     for (int i = 0; i < 49; ++i) k->P[i] = 1.0 * t2[i];      /* _alpha_sq = 1 */
     for (int i = 0; i < 7; ++i) k->P[i * 7 + i] += q[i];
-}
-
-static void inv4(const double *S, double *SI)    /* np.linalg.inv: LU with partial pivoting */
-{
-    double a[4][8];
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { a[i][j] = S[i * 4 + j]; a[i][4 + j] = (i == j); }
-    for (int c = 0; c < 4; ++c) {
-        int p = c;
-        for (int r = c + 1; r < 4; ++r) if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
-        if (p != c) for (int j = 0; j < 8; ++j) { double t = a[c][j]; a[c][j] = a[p][j]; a[p][j] = t; }
-        for (int r = c + 1; r < 4; ++r) {
-            double f = a[r][c] / a[c][c];
-            for (int j = c; j < 8; ++j) a[r][j] -= f * a[c][j];
-        }
-    }
-    for (int c = 3; c >= 0; --c) {
-        for (int j = 4; j < 8; ++j) {
-            double s = a[c][j];
-            for (int t = c + 1; t < 4; ++t) s -= a[c][t] * a[t][j];
-            a[c][j] = s / a[c][c];
-        }
-    }
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) SI[i * 4 + j] = a[i][4 + j];
 }
 
 static void kf7_update_core(kf7 *k, const double *z)    /* kalmanfilter.py:480-526, H of ocsort.py:77-78 */
@@ -88,20 +56,18 @@ static void kf7_update_core(kf7 *k, const double *z)    /* kalmanfilter.py:480-5
     for (int i = 0; i < 4; ++i) y[i] = z[i] - k->x[i];
     for (int i = 0; i < 7; ++i) for (int j = 0; j < 4; ++j) PHT[i * 4 + j] = k->P[i * 7 + j];
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) S[i * 4 + j] = PHT[i * 4 + j] + (i == j ? R_DIAG[i] : 0.0);
-    inv4(S, SI);
-    mat_mul(PHT, SI, K, 7, 4, 4);
+    lo_inv4(S, SI);                /* np.linalg.inv in LAPACK's operation order (lapack_order.h) */
+    lo_gemm(PHT, SI, K, 7, 4, 4);
     for (int i = 0; i < 7; ++i) {
-        double s = 0;
-        for (int j = 0; j < 4; ++j) s += K[i * 4 + j] * y[j];
-        k->x[i] = k->x[i] + s;
+        k->x[i] = k->x[i] + lo_dot4_h2(K + i * 4, y);          /* x + dot(K, y): dgemv order */
     }
     for (int i = 0; i < 7; ++i) for (int j = 0; j < 7; ++j)
         IKH[i * 7 + j] = (i == j ? 1.0 : 0.0) - (j < 4 ? K[i * 4 + j] : 0.0);
     for (int i = 0; i < 7; ++i) for (int j = 0; j < 7; ++j) IKHt[i * 7 + j] = IKH[j * 7 + i];
-    mat_mul(IKH, k->P, t1, 7, 7, 7);
-    mat_mul(t1, IKHt, t2, 7, 7, 7);
+    lo_gemm(IKH, k->P, t1, 7, 7, 7);
+    lo_gemm(t1, IKHt, t2, 7, 7, 7);
     for (int i = 0; i < 7; ++i) for (int j = 0; j < 4; ++j) { KR[i * 4 + j] = K[i * 4 + j] * R_DIAG[j]; Kt[j * 7 + i] = K[i * 4 + j]; }
-    mat_mul(KR, Kt, t3, 7, 4, 7);
+    lo_gemm(KR, Kt, t3, 7, 4, 7);
     for (int i = 0; i < 49; ++i) k->P[i] = t2[i] + t3[i];
 }
 

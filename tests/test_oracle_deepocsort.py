@@ -32,14 +32,17 @@ def replay(name, make_tracker, check_state=None):
             check_state(trk, g, f)
 
 
-def check_state(trk, g, f, x_tol=1e-9, emb_tol=1e-6):
+def check_state(trk, g, f, x_tol=1e-12, emb_tol=1e-6):
+    # r03: np.linalg.inv / np.dot are reproduced in library operation order (lapack_order.h), which leaves ONE source of last-bit differences:
+    # new_kf_process_noise / new_kf_measurement_noise (ocsort.py:82-93) square with `** 2`, i.e. libm pow(x, 2), which rounds differently from
+    # x * x in 0.08 % of the cases on this glibc; oracle and kernels use x * x (a GPU cannot reproduce one libm's mis-roundings).
     ids, x, P, emb, st, vel, last = trk.tracks()
     np.testing.assert_array_equal(ids, g[f"f{f}_ids"])
     np.testing.assert_array_equal(st, g[f"f{f}_state"])        # time_since_update, hits, hit_streak, age, frozen, kf.observed
     np.testing.assert_array_equal(last, g[f"f{f}_last"])
     np.testing.assert_allclose(vel, g[f"f{f}_vel"], rtol=0, atol=1e-15)
     np.testing.assert_allclose(x, g[f"f{f}_x"], rtol=x_tol, atol=x_tol)
-    np.testing.assert_allclose(P, g[f"f{f}_P"], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(P, g[f"f{f}_P"], rtol=1e-12, atol=1e-12)
     assert not g[f"f{f}_emb_f64"].any()                        # the reference's embeddings stay float32 tensors
     np.testing.assert_allclose(emb, g[f"f{f}_emb"], rtol=0, atol=emb_tol)         # float32 EMA + renorm, summation order of the norm
 

@@ -106,15 +106,12 @@ __device__ __forceinline__ void kf7_update_core(double (&x)[7], double (&P)[49],
         for (int j = 0; j < 4; ++j) {
             double s = 0;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) s += P[i * 7 + t] * SI[t * 4 + j];
+            for (int t = 0; t < 4; ++t) s = fma(P[i * 7 + t], SI[t * 4 + j], s);      // every np.dot of two matrices: fma chain over k (dgemm order, r03)
             K[i * 4 + j] = s;
         }
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-        double s = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s += K[i * 4 + j] * y[j];
-        x[i] = x[i] + s;
+        x[i] = x[i] + dot4_h2(K + i * 4, y);
     }
 #pragma unroll
     for (int i = 0; i < 7; ++i)
@@ -127,7 +124,7 @@ __device__ __forceinline__ void kf7_update_core(double (&x)[7], double (&P)[49],
         for (int j = 0; j < 7; ++j) {
             double s = 0;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) s += IKH[i * 4 + t] * P[t * 7 + j];
+            for (int t = 0; t < 4; ++t) s = fma(IKH[i * 4 + t], P[t * 7 + j], s);
             if (i >= 4) s += P[i * 7 + j];
             t1[i * 7 + j] = s;
         }
@@ -138,11 +135,11 @@ __device__ __forceinline__ void kf7_update_core(double (&x)[7], double (&P)[49],
         for (int j = 0; j < 7; ++j) {
             double s = 0;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) s += t1[i * 7 + t] * IKH[j * 4 + t];
+            for (int t = 0; t < 4; ++t) s = fma(t1[i * 7 + t], IKH[j * 4 + t], s);
             if (j >= 4) s += t1[i * 7 + j];
             double s3 = 0;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) s3 += (K[i * 4 + t] * R[t]) * K[j * 4 + t];
+            for (int t = 0; t < 4; ++t) s3 = fma(K[i * 4 + t] * R[t], K[j * 4 + t], s3);
             P[i * 7 + j] = s + s3;
         }
 }
