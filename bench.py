@@ -633,7 +633,7 @@ def main():
     esz = torch.empty((), dtype=tdtype).element_size()
     cnt_mean = float(np.mean([len(g["dets"]) for g in gts[0][:total_steps * F]]))
     if is3:
-        kname, tfile = ("pil_crop_kernel", "pil_crop_traffic.json") if ssort else ("crop_wave2_kernel", "crop_traffic.json")
+        kname, tfile = ("pil_crop_kernel", "pil_crop_traffic.json") if ssort else ("crop_wave3_kernel" if esz == 2 else "crop_wave2_kernel", "crop_traffic.json")
         # mean crop of the synthetic stream: w~U(40,120), h=w*U(1.8,2.6) -> E[w*h] = E[w^2]*2.2; only the cnt_mean REAL crops of a
         # frame count (the padding slots up to max_dets are not algorithmic bytes)
         ew2 = (120 ** 3 - 40 ** 3) / (3 * 80)

@@ -230,3 +230,36 @@ def test_the_older_crop_kernels_stay_bit_exact(env):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_image.py"), "-m", "gpu", "-q", "-x", "-k", "test_crop_resize_norm_matches_oracle and 128"],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
+
+
+def test_the_older_letterbox_kernel_stays_bit_exact():
+    """letterbox_wave_kernel (r03) is the default for the detector's input format (Focus layout, 16-bit elements); letterbox_lds_kernel stays
+    selectable with TLK_LETTERBOX_WAVE=0 (read once per process, hence the subprocess) and must keep producing the oracle's bits."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_image.py"), "-m", "gpu", "-q", "-x", "-k", "test_letterbox_matches_oracle and focus"],
+                       env=dict(os.environ, TLK_LETTERBOX_WAVE="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("H,W,S", [(1080, 1920, 640), (1080, 1918, 640), (719, 1279, 640), (2160, 3840, 640), (540, 960, 1280), (97, 2000, 416), (2000, 97, 416), (6, 8, 64)])
+def test_letterbox_focus_f16_odd_shapes(orc, H, W, S):
+    """Shapes that stress letterbox_wave_kernel's edges: source rows that are not multiples of 16 bytes, an odd number of real rows (the bottom
+    row of the last real pair is padding), a real width that ends inside / before a 256-column range, frames too wide for its staging rows
+    (4K: falls back to letterbox_lds_kernel), up-scaling, tiny frames; 3 frames so that the last frame's last rows end at the end of the buffer."""
+    import torch
+    from tracklab_amd import _lib
+    rng = np.random.default_rng(H * 7 + W)
+    frames = _frames(rng, 3, H, W)
+    d = torch.from_numpy(frames).cuda()
+    for dtype in (torch.float16, torch.bfloat16):
+        out, ratio = _lib.letterbox(d, S, "focus_nhwc", dtype)
+        torch.cuda.synchronize()
+        got = out.float().cpu().numpy()
+        g = np.empty((3, 3, S, S), dtype=np.float32)
+        g[:, :, 0::2, 0::2] = got[:, 0:3]; g[:, :, 1::2, 0::2] = got[:, 3:6]; g[:, :, 0::2, 1::2] = got[:, 6:9]; g[:, :, 1::2, 1::2] = got[:, 9:12]
+        for b in range(3):
+            exp, eratio = orc.letterbox(frames[b], S)
+            assert ratio == eratio
+            np.testing.assert_array_equal(g[b], exp)

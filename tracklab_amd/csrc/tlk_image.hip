@@ -2469,6 +2469,235 @@ __global__ void __launch_bounds__(BLOCK) letterbox_lds_kernel(const unsigned cha
     }
 }
 
+// letterbox_wave_kernel (r03; FOCUS layout, 16-bit elements = the detector's input): the recipe that took the crop kernels from 0.32 to 0.53 of the
+// HBM peak, applied to the letterbox -- wavefronts that never meet at a barrier after set-up, source rows prefetched TWO items ahead into registers by
+// inline-asm loads behind a hand-placed `s_waitcnt vmcnt(N)` (gfx950 counts loads and stores on one counter: a compiler-placed wait drains the
+// stores just issued, see crop_wave2_kernel), the item's contiguous output block assembled in the dead staging rows and written as whole cache lines.
+// letterbox_lds_kernel (workgroup = 4 output rows, two workgroup barriers, x table of the whole row per workgroup, 160 of 256 threads computing, byte
+// LDS taps) measured 0.32: every workgroup's load -> compute -> store phases were serialised behind its barriers.
+//   item  = (frame, range of LW_XR = 256 output columns, output row PAIR = one row of the Focus tensor): 3072 contiguous output bytes
+//   wave  = LW_PPW consecutive row pairs of one (frame, range); workgroup = 4 wavefronts sharing only the x table of the range (one barrier)
+//   ROWS  = staged source rows per pair: 2 when every vertical tap-1 weight of the launch is 0 (1080p -> 640: ratio exactly 1/3), else 4
+// arithmetic = letterbox_lds_kernel's (cv2 INTER_LINEAR fixed point, 114 padding), bit for bit.
+constexpr int LW_XR = 256, LW_PPW = 4, LW_CPL = 3, LW_RB = LW_CPL * 64 * 16 + 16;        // 256 columns = 64 units of 4: one unit per lane
+template <typename T, int ROWS>
+__global__ void __launch_bounds__(BLOCK, (ROWS == 2 ? 4 : 2)) letterbox_wave_kernel(const unsigned char *__restrict__ frames, int B, int H, int W, int S, int rh, int rw,
+                                                               T *__restrict__ out, int swap_rb)
+{
+    static_assert(sizeof(T) == 2 && LW_XR == 4 * WAVE, "16-bit elements; one unit of 4 columns per lane");
+    constexpr int NL = ROWS * LW_CPL;                    // 16-byte loads per lane and item
+    __shared__ __attribute__((aligned(16))) int2 s_xc[LW_XR];
+    __shared__ __attribute__((aligned(16))) unsigned char s_stage[NWAVES * ROWS * LW_RB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_xr = (S + LW_XR - 1) / LW_XR, pairs = S >> 1, S2 = S >> 1;
+    // heavy (real) row groups of every frame first: group-major workgroup order
+    const int wg = blockIdx.x, grp = wg / (B * n_xr), rem = wg - grp * (B * n_xr), b = rem / n_xr, xr = rem - b * n_xr;
+    const int xs = xr * LW_XR, xe = min(S, xs + LW_XR);
+    const int units = (xe - xs) >> 2, npieces = units * 3;                       // unit = 4 x of both rows = 48 output bytes
+    const int nreal_x = max(0, min(rw, xe) - xs);
+    const int p_lo = (grp * NWAVES + wv) * LW_PPW, p_hi = min(pairs, p_lo + LW_PPW);
+    const int p_real_hi = nreal_x > 0 ? min(p_hi, (rh + 1) >> 1) : p_lo;
+    uint4 *gout0 = reinterpret_cast<uint4 *>(out + ((size_t)b * S2 * S2 + (size_t)(xs >> 1)) * 12);      // + pair * S2 * 12 elements
+    const size_t pair_stride16 = (size_t)S2 * 12 * sizeof(T) / 16;
+    auto fill_pairs = [&](int pa, int pb) {              // padding rows / columns: 114 everywhere
+        const T v114 = cvt<T>(114.f);
+        Pack<T, 8> pk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pk.v[e] = v114;
+        const uint4 u = __builtin_bit_cast(uint4, pk);
+        for (int p = pa; p < pb; ++p)
+            for (int j = lane; j < npieces; j += WAVE) gout0[(size_t)p * pair_stride16 + j] = u;
+    };
+    const bool wg_real = nreal_x > 0 && 2 * (grp * NWAVES * LW_PPW) < rh;       // workgroup-uniform
+    if (!wg_real) { fill_pairs(p_lo, p_hi); return; }
+    const int xb0 = cv_coef(xs, W, rw, true).s * 3;
+    const int nbytes = cv_coef(xs + nreal_x - 1, W, rw, true).s * 3 + 6 - xb0;
+    for (int xl = tid; xl < xe - xs; xl += BLOCK) {
+        int2 e = make_int2(0, 0);
+        if (xl < nreal_x) {
+            const Coef cx = cv_coef(xs + xl, W, rw, true);
+            e = make_int2((cx.s * 3 - xb0) | ((cx.s + 1 < W ? 3 : 0) << 16), (cx.w0 & 0xffff) | (cx.w1 << 16));
+        }
+        s_xc[xl] = e;
+    }
+    __syncthreads();
+    // ---- no workgroup barrier below this line
+    if (p_real_hi <= p_lo) { fill_pairs(p_lo, p_hi); return; }
+    unsigned char *s_rows = s_stage + (size_t)wv * ROWS * LW_RB;
+    const unsigned char *img = frames + (size_t)b * H * W * 3;
+    const unsigned char *gend = frames + (size_t)B * H * W * 3;
+    const unsigned int W3 = (unsigned int)W * 3u;
+    struct Item { tlk_u32x4 v[NL]; int sr[ROWS]; int bw[4]; int pad1; unsigned int tail; };
+    Item X, Y;
+#pragma unroll
+    for (int q = 0; q < NL; ++q) { X.v[q] = tlk_u32x4{0, 0, 0, 0}; Y.v[q] = tlk_u32x4{0, 0, 0, 0}; }
+    auto fetch = [&](int p_req, Item &R) {
+        const int p = min(p_req, p_real_hi - 1);         // past the wavefront's last real pair: that one again (L2 hits) -- every wait then has NL younger loads
+        const int y0 = 2 * p, y1 = 2 * p + 1;
+        const Coef c0 = cv_coef(y0, H, rh, false);
+        const bool pad1 = y1 >= rh;
+        const Coef c1 = pad1 ? c0 : cv_coef(y1, H, rh, false);
+        R.pad1 = pad1 ? 1 : 0;
+        R.bw[0] = __builtin_amdgcn_readfirstlane(c0.w0); R.bw[1] = __builtin_amdgcn_readfirstlane(c0.w1);
+        R.bw[2] = __builtin_amdgcn_readfirstlane(c1.w0); R.bw[3] = __builtin_amdgcn_readfirstlane(c1.w1);
+        if constexpr (ROWS == 2) {
+            R.sr[0] = __builtin_amdgcn_readfirstlane(clampi(c0.s, 0, H - 1)); R.sr[1] = __builtin_amdgcn_readfirstlane(clampi(c1.s, 0, H - 1));
+        } else {
+            R.sr[0] = __builtin_amdgcn_readfirstlane(clampi(c0.s, 0, H - 1)); R.sr[1] = __builtin_amdgcn_readfirstlane(clampi(c0.s + 1, 0, H - 1));
+            R.sr[ROWS - 2] = __builtin_amdgcn_readfirstlane(clampi(c1.s, 0, H - 1)); R.sr[ROWS - 1] = __builtin_amdgcn_readfirstlane(clampi(c1.s + 1, 0, H - 1));
+        }
+        unsigned int tail = 0;
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            const unsigned char *g0 = img + (size_t)R.sr[k] * W3 + xb0;           // wave-uniform
+            const int mis = (int)((uintptr_t)g0 & 15);
+            const int nch = (mis + nbytes + 15) >> 4;
+#pragma unroll
+            for (int q = 0; q < LW_CPL; ++q) {
+                const int c = lane + q * WAVE;
+                const unsigned char *pp = g0 - mis + (size_t)(c < nch ? c : 0) * 16;
+                if (pp + 16 > gend) { tail |= 1u << (k * LW_CPL + q); pp = frames; }      // the last bytes of the last frame: fixed up byte-wise in stage()
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(R.v[k * LW_CPL + q]) : "v"(pp));
+            }
+        }
+        R.tail = tail;
+    };
+    auto wait_rows = [&](Item &R) {                      // ONE form of the wait (see crop_wave2_kernel)
+        if constexpr (ROWS == 2)
+            asm volatile("s_waitcnt vmcnt(6)" : "+v"(R.v[0]), "+v"(R.v[1]), "+v"(R.v[2]), "+v"(R.v[3]), "+v"(R.v[4]), "+v"(R.v[5]));
+        else
+            asm volatile("s_waitcnt vmcnt(12)" : "+v"(R.v[0]), "+v"(R.v[1]), "+v"(R.v[2]), "+v"(R.v[3]), "+v"(R.v[4]), "+v"(R.v[5]),
+                         "+v"(R.v[6]), "+v"(R.v[7]), "+v"(R.v[8]), "+v"(R.v[9]), "+v"(R.v[10]), "+v"(R.v[11]));
+    };
+    int st_mis[ROWS], st_bw[4] = {0, 0, 0, 0}, st_pad1 = 0;
+    auto stage = [&](const Item &R) {
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            const unsigned char *g0 = img + (size_t)R.sr[k] * W3 + xb0;
+            const int mis = (int)((uintptr_t)g0 & 15);
+            const int nch = (mis + nbytes + 15) >> 4;
+            st_mis[k] = mis;
+#pragma unroll
+            for (int q = 0; q < LW_CPL; ++q) {
+                const int c = lane + q * WAVE;
+                if (c < nch) *reinterpret_cast<tlk_u32x4 *>(s_rows + k * LW_RB + c * 16) = R.v[k * LW_CPL + q];
+            }
+        }
+        if (__builtin_expect(__any(R.tail != 0), 0)) {
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) {
+                const unsigned char *g0 = img + (size_t)R.sr[k] * W3 + xb0;
+                const int mis = (int)((uintptr_t)g0 & 15);
+#pragma unroll
+                for (int q = 0; q < LW_CPL; ++q)
+                    if (R.tail & (1u << (k * LW_CPL + q))) {
+                        const int c = lane + q * WAVE;
+                        const unsigned char *pp = g0 - mis + (size_t)c * 16;
+                        for (int e = 0; e < 16 && pp + e < gend; ++e) s_rows[k * LW_RB + c * 16 + e] = pp[e];
+                    }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st_bw[k] = (k >= 2 && R.pad1) ? 0 : R.bw[k];
+        st_pad1 = R.pad1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // one unit: 4 x of both rows of the pair -> 24 elements in Focus order (per x pair: top-left, bottom-left, top-right, bottom-right channel triples)
+    auto unit = [&](int u, Pack<T, 8> (&res)[3]) {
+        const int4 e01 = *reinterpret_cast<const int4 *>(&s_xc[u * 4]), e23 = *reinterpret_cast<const int4 *>(&s_xc[u * 4 + 2]);
+        const int ex[4] = {e01.x, e01.z, e23.x, e23.z}, ew[4] = {e01.y, e01.w, e23.y, e23.w};
+        T val[2][4][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o0 = ex[j] & 0xffff;
+            const unsigned int sel = 0x0c000c00u | ((unsigned int)(ex[j] >> 16) << 16);
+            const us2_t wx = __builtin_bit_cast(us2_t, ew[j]);
+            // padding is arithmetic, not control flow: a padded column has zero weights in the x table, a padded bottom row zero vertical weights
+            // (stage()), so t = 0 there and the rounding constant carries the 114: ((0 + 2 + 4 * 114) >> 2) = 114
+            const bool xpad = u * 4 + j >= nreal_x;
+            const unsigned int rnd[2] = {xpad ? 2u + 4u * 114u : 2u, (xpad || st_pad1) ? 2u + 4u * 114u : 2u};
+            unsigned int hs[ROWS][3];                    // horizontally interpolated, >> 4
+#pragma unroll
+            for (int k = 0; k < ROWS; ++k) {
+                const int addr = k * LW_RB + st_mis[k] + o0;
+                const unsigned int *q = reinterpret_cast<const unsigned int *>(s_rows + (addr & ~3));
+                const unsigned int d0 = q[0], d1 = q[1], d2 = q[2];
+                const unsigned int lo = __builtin_amdgcn_alignbyte(d1, d0, (unsigned int)addr & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, (unsigned int)addr & 3u);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    hs[k][c] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2_t, __builtin_amdgcn_perm(hi, lo, sel + 0x00010001u * c)), wx, 0u, false) >> 4;
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    unsigned int t;
+                    if constexpr (ROWS == 2) t = __umul24((unsigned int)st_bw[r * 2], hs[r][c]) >> 16;
+                    else t = (__umul24((unsigned int)st_bw[r * 2], hs[r * 2][c]) >> 16) + (__umul24((unsigned int)st_bw[r * 2 + 1], hs[r * 2 + 1][c]) >> 16);
+                    const int v = (int)((t + rnd[r]) >> 2);   // t <= 1020: v <= 255 always
+                    val[r][j][c] = cvt<T>((float)v);
+                }
+            if (swap_rb) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) { const T t0 = val[r][j][0]; val[r][j][0] = val[r][j][2]; val[r][j][2] = t0; }
+            }
+            __builtin_amdgcn_sched_barrier(0);           // one x at a time: interleaving all four costs 50 more registers (and with them a wavefront per SIMD)
+        }
+#pragma unroll
+        for (int idx = 0; idx < 24; ++idx) {
+            const int fp = idx / 12, chn = idx % 12, g = chn / 3, c = chn % 3, xo = g >> 1, yo = g & 1;
+            res[idx >> 3].v[idx & 7] = val[yo][fp * 2 + xo][c];
+        }
+    };
+    auto pair_step = [&](int p, Item &N) {
+        Pack<T, 8> r0[3];
+        unit(lane < units ? lane : 0, r0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // every tap of the pair has been read: the staging rows become the output block
+        __builtin_amdgcn_wave_barrier();
+        if (lane < units) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) *reinterpret_cast<Pack<T, 8> *>(s_rows + (size_t)lane * 48 + k * 16) = r0[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // (named registers: as an array these went to scratch memory -- whose loads and stores count on vmcnt like everything else)
+        const uint4 *l4 = reinterpret_cast<const uint4 *>(s_rows);
+        const uint4 blk0 = l4[min(lane, npieces - 1)], blk1 = l4[min(WAVE + lane, npieces - 1)], blk2 = l4[min(2 * WAVE + lane, npieces - 1)];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // staging rows are dead from here
+        __builtin_amdgcn_wave_barrier();
+        if (p + 1 < p_real_hi) {
+            wait_rows(N);
+            stage(N);
+            fetch(p + 3, N);
+        }
+        uint4 *g = gout0 + (size_t)p * pair_stride16;
+        if (lane < npieces) g[lane] = blk0;
+        if (WAVE + lane < npieces) g[WAVE + lane] = blk1;
+        if (2 * WAVE + lane < npieces) g[2 * WAVE + lane] = blk2;
+    };
+    fetch(p_lo, X);
+    fetch(p_lo + 1, Y);
+    wait_rows(X);
+    stage(X);
+    fetch(p_lo + 2, X);
+    for (int p = p_lo; p < p_real_hi; p += 2) {
+        pair_step(p, Y);
+        if (p + 1 < p_real_hi) pair_step(p + 1, X);
+    }
+    // the clamped prefetches of the last pairs are still in flight: keep their registers allocated until they have landed
+    if constexpr (ROWS == 2)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(X.v[0]), "+v"(X.v[1]), "+v"(X.v[2]), "+v"(X.v[3]), "+v"(X.v[4]), "+v"(X.v[5]),
+                     "+v"(Y.v[0]), "+v"(Y.v[1]), "+v"(Y.v[2]), "+v"(Y.v[3]), "+v"(Y.v[4]), "+v"(Y.v[5]));
+    else {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(X.v[0]), "+v"(X.v[1]), "+v"(X.v[2]), "+v"(X.v[3]), "+v"(X.v[4]), "+v"(X.v[5]),
+                     "+v"(X.v[6]), "+v"(X.v[7]), "+v"(X.v[8]), "+v"(X.v[9]), "+v"(X.v[10]), "+v"(X.v[11]));
+        asm volatile("" : "+v"(Y.v[0]), "+v"(Y.v[1]), "+v"(Y.v[2]), "+v"(Y.v[3]), "+v"(Y.v[4]), "+v"(Y.v[5]),
+                     "+v"(Y.v[6]), "+v"(Y.v[7]), "+v"(Y.v[8]), "+v"(Y.v[9]), "+v"(Y.v[10]), "+v"(Y.v[11]));
+    }
+    fill_pairs(p_real_hi, p_hi);
+}
+
 // ---------------------------------------------------------------------------------------------
 // YOLOX decode + per-class greedy NMS (rtmlib YOLOX.postprocess / multiclass_nms / nms), one workgroup
 // per frame. Candidates (score = obj*cls > score_thr) are compacted, sorted by (score desc, anchor desc)
@@ -2621,6 +2850,26 @@ int launch_letterbox(const unsigned char *frames, int B, int H, int W, int S, in
         const size_t need = (size_t)units * 28 * 4;
         if (units <= BLOCK && (size_t)max_rows * row_bytes >= need) out_off = 0;
         else { out_off = (int)smem; smem += need; }
+    }
+    // r03: free-running wavefronts for the detector's input format (Focus layout, 16-bit elements); TLK_LETTERBOX_WAVE=0: letterbox_lds_kernel
+    if constexpr (sizeof(T) == 2) {
+        static const int wave = [] { const char *e = getenv("TLK_LETTERBOX_WAVE"); return e ? atoi(e) : 1; }();
+        if (wave && layout == LAYOUT_FOCUS_NHWC && S % 8 == 0 && rh >= 1 && rw >= 1) {
+            bool ok = true, two_rows = true;
+            for (int xs = 0; xs < S && xs < rw && ok; xs += LW_XR) {
+                const int nreal = (rw < xs + LW_XR ? rw : xs + LW_XR) - xs;
+                const int nbytes = cv_coef(xs + nreal - 1, W, rw, true).s * 3 + 6 - cv_coef(xs, W, rw, true).s * 3;
+                if (((15 + nbytes + 15) >> 4) > LW_CPL * 64) ok = false;
+            }
+            for (int y = 0; y < rh && two_rows; ++y) two_rows = cv_coef(y, H, rh, false).w1 == 0;
+            if (ok) {
+                const int groups = (S / 2 + NWAVES * LW_PPW - 1) / (NWAVES * LW_PPW), n_xr = (S + LW_XR - 1) / LW_XR;
+                const dim3 grid((unsigned)(groups * B * n_xr));
+                if (two_rows) hipLaunchKernelGGL((letterbox_wave_kernel<T, 2>), grid, dim3(BLOCK), 0, st, frames, B, H, W, S, rh, rw, (T *)out, swap_rb);
+                else hipLaunchKernelGGL((letterbox_wave_kernel<T, 4>), grid, dim3(BLOCK), 0, st, frames, B, H, W, S, rh, rw, (T *)out, swap_rb);
+                return TLK_OK;
+            }
+        }
     }
     if (smem <= 64 * 1024 && S % LB_BAND == 0) {          // LDS-staged fast path
         const dim3 grid((unsigned)(B * (S / LB_BAND)));
