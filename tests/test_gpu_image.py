@@ -263,3 +263,64 @@ def test_letterbox_focus_f16_odd_shapes(orc, H, W, S):
             exp, eratio = orc.letterbox(frames[b], S)
             assert ratio == eratio
             np.testing.assert_array_equal(g[b], exp)
+
+
+def _pil_wave_cases(rng, B, H, W, MAXN):
+    xyxy = np.zeros((B, MAXN, 7))
+    for b in range(B):
+        w = rng.uniform(3, 200, MAXN); h = rng.uniform(3, 620, MAXN)
+        x = rng.uniform(-20, W - 10, MAXN); y = rng.uniform(-20, H - 10, MAXN)
+        xyxy[b, :, :4] = np.stack([x, y, x + w, y + h], 1)
+    xyxy[0, 0, :4] = [10, 10, 138, 266]               # exactly the target size
+    xyxy[0, 1, :4] = [10, 10, 74, 138]                # exactly half: 2x up-scaling on both axes
+    xyxy[0, 2, :4] = [100, 100, 260, 612]             # 160 x 512: the widest / tallest staged crop, scale 2 vertically (2-row mini-bands)
+    xyxy[0, 3, :4] = [100, 100, 261, 300]             # 161 px: one too wide for the staging rows -> direct path
+    xyxy[0, 4, :4] = [100, 100, 200, 613]             # scale just above 2 vertically -> direct path
+    xyxy[0, 5, :4] = [W - 60, H - 200, W + 50, H + 50]      # clipped bottom-right corner
+    xyxy[0, 6, :4] = [500, 500, 500.4, 500.9]         # empty -> zeros
+    xyxy[0, 7, :4] = [300, 300, 303, 304]             # 3 x 4 px
+    xyxy[0, 8, :4] = [300, 300, 420, 607]             # vertical scale 1.199 (4-row mini-bands, 8 source rows)
+    xyxy[0, 9, :4] = [300, 300, 420, 608]             # vertical scale 1.203 (2-row mini-bands)
+    xyxy[B - 1, 0, :4] = [W - 130, H - 300, W - 1, H - 1]   # the last rows of the last frame: loads end at the end of the buffer
+    xyxy[B - 1, 1, :4] = [0, H - 9, 100, H - 1]
+    return xyxy
+
+
+@pytest.mark.parametrize("oh", [256, 384, 130])
+def test_pil_wave_kernel_16bit_nhwc_equals_the_fp32_kernel_and_the_oracle(orc, oh):
+    """pil_wave_kernel (r03: 128-wide NHWC 16-bit targets) against pil_crop_kernel's fp32 output (itself pinned by the Pillow-made golden and the
+    oracle above) rounded to the 16-bit type, over up- and down-scaling, clipped, tiny, too-wide / too-tall (direct path), 2-row mini-band and
+    end-of-buffer crops; and against the oracle directly for the first frame."""
+    import torch
+    from tracklab_amd import _lib
+    rng = np.random.default_rng(oh)
+    B, H, W, MAXN = 3, 1080, 1920, 40
+    frames = _frames(rng, B, H, W)
+    xyxy = _pil_wave_cases(rng, B, H, W, MAXN)
+    counts = np.array([MAXN, 29, MAXN], dtype=np.int32)
+    d, dx, dc = torch.from_numpy(frames).cuda(), torch.from_numpy(xyxy).cuda(), torch.from_numpy(counts).cuda()
+    ref32 = _lib.roi_crop_pil_resize_norm(d, dx, dc, oh, 128, "nhwc", torch.float32)
+    for dtype in (torch.float16, torch.bfloat16):
+        for swap in (False, True):
+            got = _lib.roi_crop_pil_resize_norm(d, dx, dc, oh, 128, "nhwc", dtype, swap_rb=swap)
+            exp = _lib.roi_crop_pil_resize_norm(d, dx, dc, oh, 128, "nhwc", torch.float32, swap_rb=swap).to(dtype)
+            torch.cuda.synchronize()
+            assert torch.equal(got, exp), (dtype, swap, int((got != exp).sum()))
+    got = ref32.cpu().numpy()                            # (B * MAXN, 3, oh, 128) logical NCHW view of NHWC memory
+    for i in range(12):
+        exp, _ = orc.ssort_reid_preprocess(frames[0], xyxy[0, i, :4], oh, 128)
+        np.testing.assert_array_equal(got[i], exp, err_msg=f"crop {i}")
+    h16 = _lib.roi_crop_pil_resize_norm(d, dx, dc, oh, 128, "nhwc", torch.float16).cpu().numpy()
+    for i in range(12):
+        exp, _ = orc.ssort_reid_preprocess(frames[0], xyxy[0, i, :4], oh, 128)
+        np.testing.assert_array_equal(h16[i], exp.astype(np.float16), err_msg=f"crop {i} f16")
+
+
+def test_the_older_pil_crop_kernel_stays_bit_exact():
+    """pil_crop_kernel stays selectable with TLK_PIL_WAVE=0 (read once per process, hence the subprocess)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_image.py"), "-m", "gpu", "-q", "-x", "-k", "test_pil_ and not older"],
+                       env=dict(os.environ, TLK_PIL_WAVE="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]

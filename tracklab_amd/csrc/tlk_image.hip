@@ -1565,7 +1565,7 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
         const int done = mb > mb_lo ? __builtin_amdgcn_readfirstlane((int)(((unsigned int)s_y[(ra - 1) * 2] >> 16) & 0x7ffu)) : -1;
         const int r_lo_n = max(r_first, done + 1);
         const int nrows_n = r_last - r_lo_n + 1;          // 0 .. WV_SRC new rows
-        const unsigned char *rowp = crop0 + (size_t)r_lo_n * W3;      // wave-uniform
+        const unsigned char *rowp = crop0 + (size_t)min(r_lo_n, par.ch - 1) * W3;      // wave-uniform (no new row: r_lo_n may be one past the crop -- never address it)
         auto addr = [&](int q) {
             const bool in = sl_rr[q] < nrows_n;
             const unsigned char *g0 = rowp + (in ? sl_goff[q] : 0u);
@@ -1846,7 +1846,7 @@ __global__ void __launch_bounds__(PW_BLOCK, 4) crop_pw_kernel(const unsigned cha
             const int done = mb > mb_lo ? __builtin_amdgcn_readfirstlane((int)(((unsigned int)ytab(ra - 1)[0] >> 16) & 0x7ffu)) : -1;
             const int r_lo_n = max(r_first, done + 1);
             const int nrows_n = r_last - r_lo_n + 1;
-            const unsigned char *rowp = crop0 + (size_t)r_lo_n * W3;
+            const unsigned char *rowp = crop0 + (size_t)min(r_lo_n, ch - 1) * W3;      // (no new row: r_lo_n may be one past the crop -- never address it)
             auto addr = [&](int q) {
                 const bool in = sl_rr[q] < nrows_n;
                 const unsigned char *g0 = rowp + (in ? sl_goff[q] : 0u);
@@ -2293,6 +2293,342 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
         for (int c = tid; c < n16; c += BLOCK) stream_store(g + c, l4[c]);
     }
     __syncthreads();                                    // the next band re-uses every LDS area
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pil_wave_kernel (r03; 128-wide NHWC 16-bit targets = the ReID input of plain StrongSORT / BoT-SORT / Deep-OC-SORT): Pillow's resample with the
+// structure of crop_wave3_kernel -- wavefronts that never meet after set-up, source rows prefetched two mini-bands ahead by inline-asm loads behind a
+// hand-placed `s_waitcnt vmcnt(4)`, a RING of 8-bit rows so that every source row goes through the horizontal pass once per wavefront, the mini-band's
+// contiguous 3 KB output block assembled in the dead staging rows and written as whole cache lines -- and the tap loops specialised on the wave-uniform
+// tap counts (an up-scaled axis has exactly 2 taps per output pixel; pil_crop_kernel always ran 3 and 5). pil_crop_kernel (workgroup barriers between
+// the staging, horizontal and vertical phases of a 32-row band) measured 0.32-0.35 of the HBM peak.
+//   workgroup = (crop, 128 output rows): wave 0 the horizontal coefficient rows (fp64, one IEEE division per tap: Pillow's own arithmetic), waves 1-2 the
+//   vertical ones of the 128 rows, wave 3 the (u8 -> normalised T) table; ONE barrier; then every wavefront owns 8 mini-bands of 4 output rows.
+// Arithmetic = Resample.c's, bit for bit: 22-bit coefficients, uint8 rounding between the passes; the results of both passes cannot leave [0, 255]
+// (non-negative weights whose rounded sum exceeds 2^22 by at most 3), so the clip is a no-op and is not executed.
+// ---------------------------------------------------------------------------------------------
+constexpr int PWV_SRC = 8;                            // ring slots = staged rows per mini-band at most
+constexpr int PWV_NL = 4;                             // 16-byte loads per lane and fetch
+constexpr int PWV_PLANE = 128 * 3;                    // bytes per ring row: planar [channel][x]
+constexpr int PWV_WAVE_LDS = PWV_SRC * CS_ROW_BYTES + PWV_SRC * PWV_PLANE;
+struct PilTab { int4 a, b; };                         // a = (first tap: byte offset | ring slot << 12 ... see users, k0, k1, k2), b = (k3, k4, taps, 0)
+
+template <typename T>
+__device__ __noinline__ void pil_direct_unit_nhwc(const unsigned char *__restrict__ base, int W, int cw, int ch, int OH, int OW, int y, int x_base,
+                                                  float m0, float m1, float m2, float d0, float d1, float d2, int swap_rb, T *__restrict__ out, size_t slot)
+{
+    // every vertical tap recomputes its horizontally resampled (and uint8-rounded) sample from global memory (the direct branch of pil_crop_kernel)
+    const PilAxis ax = pil_axis(cw, OW), ay = pil_axis(ch, OH);
+    const float mean[3] = {m0, m1, m2}, stdv[3] = {d0, d1, d2};
+    int ymin, ymax;
+    pil_bounds(ay, ch, y, ymin, ymax);
+    const double wwy = pil_wsum(ay, y, ymin, ymax);
+    T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
+#pragma nounroll
+    for (int k = 0; k < 8; ++k) {                        // (rolled on purpose: a rare path must not set the register budget of the kernel that calls it)
+        int s[3] = {1 << (PIL_BITS - 1), 1 << (PIL_BITS - 1), 1 << (PIL_BITS - 1)};
+#pragma nounroll
+        for (int t = 0; t < ymax; ++t) {
+            const int kv = pil_fixed(ay, y, ymin, t, wwy);
+            int hv[3];
+            pil_hsample(base + (size_t)(ymin + t) * W * 3, ax, cw, x_base + k, hv);
+            s[0] += hv[0] * kv; s[1] += hv[1] * kv; s[2] += hv[2] * kv;
+        }
+        T px[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float f = (float)pil_clip8(s[c]) / 255.0f; f = f - mean[c]; f = f / stdv[c];
+            px[c] = cvt<T>(f);
+        }
+        if (swap_rb) { const T t0 = px[0]; px[0] = px[2]; px[2] = t0; }
+        o[k * 3] = px[0]; o[k * 3 + 1] = px[1]; o[k * 3 + 2] = px[2];
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) pil_wave_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
+                                                        const double *__restrict__ boxes, int box_stride, const int *__restrict__ counts, int max_n,
+                                                        int OH, float m0, float m1, float m2, float d0, float d1, float d2,
+                                                        T *__restrict__ out, int swap_rb, int nwg)
+{
+    static_assert(sizeof(T) == 2, "16-bit element types");
+    constexpr int OW = 128, GROUPS = OW / 8, CHUNK_ROWS = CF_BANDS * CS_BAND;
+    __shared__ PilTab s_xt[OW];                          // horizontal coefficient rows
+    __shared__ PilTab s_yt[CHUNK_ROWS];                  // vertical coefficient rows of this workgroup's output rows
+    __shared__ T s_lut[3][256];
+    __shared__ int s_nt[3];                              // tap counts: horizontal; vertical (two halves of the chunk)
+    __shared__ __attribute__((aligned(16))) unsigned char s_wave[NWAVES * PWV_WAVE_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int wg;
+    {
+        const int orig = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int chunks = (OH + CHUNK_ROWS - 1) / CHUNK_ROWS;
+    const int slot = wg / chunks, chunk = wg - slot * chunks;
+    const int b = slot / max_n, i = slot - b * max_n;
+    if (i >= counts[b]) return;                         // padding slot: left untouched
+    const int row0 = chunk * CHUNK_ROWS, rows_chunk = min(CHUNK_ROWS, OH - row0);
+    int x1, y1, x2, y2;
+    ssort_crop_box(boxes + ((size_t)b * max_n + i) * box_stride, W, H, x1, y1, x2, y2);
+    const bool valid = (x2 > x1) && (y2 > y1);
+    const int cw = x2 - x1, ch = y2 - y1;
+    const PilAxis ax = pil_axis(valid ? cw : 1, OW), ay = pil_axis(valid ? ch : 1, OH);
+    const bool tabs_ok = valid && cw * 3 + STAGE_PAD <= CS_ROW_BYTES && ax.ksize <= PIL_KMAX && ay.ksize <= PIL_KMAX;
+    auto wave_max = [](int v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+        return v;
+    };
+    if (wv == 0) {
+        int nt = 0;
+        if (tabs_ok)
+            for (int x = lane; x < OW; x += WAVE) {
+                int xmin, xmax;
+                pil_bounds(ax, cw, x, xmin, xmax);
+                const double ww = pil_wsum(ax, x, xmin, xmax);
+                int k[PIL_KMAX];
+#pragma unroll
+                for (int t = 0; t < PIL_KMAX; ++t) k[t] = t < xmax ? pil_fixed(ax, x, xmin, t, ww) : 0;
+                s_xt[x].a = make_int4(xmin * 3, k[0], k[1], k[2]);
+                s_xt[x].b = make_int4(k[3], k[4], xmax, 0);
+                nt = max(nt, xmax);
+            }
+        nt = wave_max(nt);
+        if (lane == 0) s_nt[0] = nt;
+    } else if (wv < 3) {
+        int nt = 0;
+        const int row = (wv - 1) * WAVE + lane, y = row0 + row;
+        if (tabs_ok && row < rows_chunk) {
+            int ymin, ymax;
+            pil_bounds(ay, ch, y, ymin, ymax);
+            const double ww = pil_wsum(ay, y, ymin, ymax);
+            int k[PIL_KMAX];
+#pragma unroll
+            for (int t = 0; t < PIL_KMAX; ++t) k[t] = t < ymax ? pil_fixed(ay, y, ymin, t, ww) : 0;
+            s_yt[row].a = make_int4(ymin | ((ymin % PWV_SRC) << 12) | ((ymin + ymax - 1) << 16), k[0], k[1], k[2]);      // first row (< 2048), its ring slot, last row
+            s_yt[row].b = make_int4(k[3], k[4], ymax, 0);
+            nt = ymax;
+        }
+        nt = wave_max(nt);
+        if (lane == 0) s_nt[wv] = nt;
+    } else {
+        const float mean[3] = {m0, m1, m2}, stdv[3] = {d0, d1, d2};
+        for (int v = lane; v < 256; v += WAVE)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { float f = (float)v / 255.0f; f = f - mean[c]; f = f / stdv[c]; s_lut[c][v] = cvt<T>(f); }
+    }
+    __syncthreads();
+    // ---- no workgroup barrier below this line
+    const int nth = s_nt[0], ntv = max(s_nt[1], s_nt[2]);
+    const unsigned char *gend = frames + (size_t)B * H * W * 3;
+    const size_t frame_off = (size_t)b * H * W * 3;
+    const int mbh = ch * 5 <= OH * 6 ? WV_ROWS : 2;      // 4-row mini-bands up to a vertical scale of 1.2 (<= 8 source rows), 2-row ones up to 2
+    const int n_mb = (rows_chunk + mbh - 1) / mbh, mb_per_wave = (n_mb + NWAVES - 1) / NWAVES;
+    const int mb_lo = wv * mb_per_wave, mb_hi = min(n_mb, mb_lo + mb_per_wave);
+    const int cmax = (cw * 3 + 30) >> 4;
+    auto first_row = [&](int row) { return s_yt[row].a.x & 0x7ff; };
+    auto last_row = [&](int row) { return (int)(((unsigned int)s_yt[row].a.x >> 16) & 0x7ffu); };
+    bool fast = tabs_ok;
+    if (fast) {
+        fast = frames + frame_off + ((size_t)(y1 + ch - 1) * W + x1) * 3 + 34 * 16 <= gend;
+        for (int mb = mb_lo + lane; mb < mb_hi; mb += WAVE) {
+            const int ra = mb * mbh, rb = min(ra + mbh, rows_chunk) - 1;
+            const int n = last_row(rb) - first_row(ra) + 1;
+            if (n > PWV_SRC || n * cmax > PWV_NL * WAVE) fast = false;
+        }
+        fast = __all(fast);
+    }
+    if (!fast) {
+        for (int mb = mb_lo; mb < mb_hi; ++mb)
+            for (int u = lane; u < mbh * GROUPS; u += WAVE) {
+                const int ry = u >> 4, x_base = (u & (GROUPS - 1)) * 8, y = row0 + mb * mbh + ry;
+                if (y >= OH || mb * mbh + ry >= rows_chunk) continue;
+                if (valid) pil_direct_unit_nhwc<T>(frames + frame_off + ((size_t)y1 * W + x1) * 3, W, cw, ch, OH, OW, y, x_base, m0, m1, m2, d0, d1, d2, swap_rb, out, (size_t)slot);
+                else
+                    for (int k = 0; k < 24; ++k) out[(((size_t)slot * OH + y) * OW + x_base) * 3 + k] = cvt<T>(0.f);
+            }
+        return;
+    }
+    unsigned char *s_rows = s_wave + (size_t)wv * PWV_WAVE_LDS;          // this wavefront's staging rows ...
+    unsigned char *s_h = s_rows + PWV_SRC * CS_ROW_BYTES;                // ... and its ring of 8-bit rows
+    const unsigned char *crop0 = frames + frame_off + ((size_t)y1 * W + x1) * 3;
+    const unsigned int W3 = (unsigned int)W * 3u, a_step = W3 & 15u;
+    struct RowRegs { tlk_u32x4 v[PWV_NL]; int r_lo, nrows; };
+    RowRegs X, Y;
+#pragma unroll
+    for (int q = 0; q < PWV_NL; ++q) { X.v[q] = tlk_u32x4{0, 0, 0, 0}; Y.v[q] = tlk_u32x4{0, 0, 0, 0}; }
+    X.r_lo = X.nrows = Y.r_lo = Y.nrows = 0;
+    int sl_rr[PWV_NL], sl_c[PWV_NL], sl_lds[PWV_NL];
+    unsigned int sl_goff[PWV_NL];
+#pragma unroll
+    for (int q = 0; q < PWV_NL; ++q) {
+        const int idx = lane + q * WAVE;
+        sl_rr[q] = idx / cmax; sl_c[q] = idx - sl_rr[q] * cmax;
+        sl_lds[q] = sl_rr[q] * CS_ROW_BYTES + sl_c[q] * 16;
+        sl_goff[q] = (unsigned int)sl_rr[q] * W3;
+    }
+    const int cw3 = cw * 3;
+    auto fetch = [&](int mb_req, RowRegs &R) {
+        const int mb = min(mb_req, mb_hi - 1);           // past the last mini-band: that one again -- every wait has its PWV_NL younger loads
+        const int ra = mb * mbh, rb = min(ra + mbh, rows_chunk) - 1;
+        const int r_first = __builtin_amdgcn_readfirstlane(first_row(ra));
+        const int r_last = __builtin_amdgcn_readfirstlane(last_row(rb));
+        const int done = mb > mb_lo ? __builtin_amdgcn_readfirstlane(last_row(ra - 1)) : -1;       // sliding window: rows the previous mini-band already put into the ring
+        const int r_lo_n = max(r_first, done + 1);
+        const int nrows_n = max(0, r_last - r_lo_n + 1);
+        const unsigned char *rowp = crop0 + (size_t)min(r_lo_n, ch - 1) * W3;      // (no new row: r_lo_n may be one past the crop -- never address it)
+#pragma unroll
+        for (int q = 0; q < PWV_NL; ++q) {
+            const bool in = sl_rr[q] < nrows_n;
+            const unsigned char *g0 = rowp + (in ? sl_goff[q] : 0u);
+            const int mis = (int)((uintptr_t)g0 & 15);
+            const unsigned char *pp = g0 - mis + (size_t)((in && sl_c[q] < ((mis + cw3 + 15) >> 4)) ? sl_c[q] : 0) * 16;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(R.v[q]) : "v"(pp));
+        }
+        R.r_lo = r_lo_n; R.nrows = nrows_n;
+    };
+    auto wait_rows = [&](RowRegs &R) {
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(R.v[0]), "+v"(R.v[1]), "+v"(R.v[2]), "+v"(R.v[3]));
+    };
+    int st_r_lo = 0, st_nrows = 0;
+    auto stage = [&](const RowRegs &R) {
+        const int nrows = R.nrows;
+#pragma unroll
+        for (int q = 0; q < PWV_NL; ++q)
+            if (sl_rr[q] < nrows) *reinterpret_cast<tlk_u32x4 *>(s_rows + sl_lds[q]) = R.v[q];
+        st_r_lo = R.r_lo; st_nrows = nrows;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // this lane's two adjacent output columns (2 lane, 2 lane + 1): first-tap byte offset and the five 22-bit coefficients of each
+    const PilTab xa = s_xt[2 * lane], xb = s_xt[2 * lane + 1];
+    const int oA = xa.a.x, oB = xb.a.x;
+    const int kA[PIL_KMAX] = {xa.a.y, xa.a.z, xa.a.w, xa.b.x, xa.b.y}, kB[PIL_KMAX] = {xb.a.y, xb.a.z, xb.a.w, xb.b.x, xb.b.y};
+    // horizontal pass of the staged (= new) rows into the ring; NT taps (wave-uniform): 3 NT source bytes per column from NW + 1 aligned dwords
+    auto hpass = [&](auto nt_tag) {
+        constexpr int NT = decltype(nt_tag)::value, NW = (3 * NT + 3) / 4;
+        const int r_lo = st_r_lo, nrows = st_nrows;
+        const unsigned int a_lo = (unsigned int)(uintptr_t)(crop0 + (size_t)r_lo * W3) & 15u;
+        for (int rr = 0; rr < nrows; ++rr) {
+            const int base = rr * CS_ROW_BYTES + (int)((a_lo + (unsigned int)rr * a_step) & 15u);
+            unsigned int wa[NW], wb[NW];
+            {
+                const int addr = base + oA;
+                const unsigned int *q = reinterpret_cast<const unsigned int *>(s_rows + (addr & ~3));
+                unsigned int d[NW + 1];
+#pragma unroll
+                for (int j = 0; j <= NW; ++j) d[j] = q[j];
+#pragma unroll
+                for (int j = 0; j < NW; ++j) wa[j] = __builtin_amdgcn_alignbyte(d[j + 1], d[j], (unsigned int)addr & 3u);
+            }
+            {
+                const int addr = base + oB;
+                const unsigned int *q = reinterpret_cast<const unsigned int *>(s_rows + (addr & ~3));
+                unsigned int d[NW + 1];
+#pragma unroll
+                for (int j = 0; j <= NW; ++j) d[j] = q[j];
+#pragma unroll
+                for (int j = 0; j < NW; ++j) wb[j] = __builtin_amdgcn_alignbyte(d[j + 1], d[j], (unsigned int)addr & 3u);
+            }
+            unsigned char *o = s_h + ((r_lo + rr) % PWV_SRC) * PWV_PLANE + 2 * lane;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                int sa = 1 << (PIL_BITS - 1), sb = 1 << (PIL_BITS - 1);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { sa += __mul24(byte_of(wa, 3 * t + c), kA[t]); sb += __mul24(byte_of(wb, 3 * t + c), kB[t]); }
+                *reinterpret_cast<unsigned short *>(o + c * OW) = (unsigned short)(((unsigned int)sa >> PIL_BITS) | (((unsigned int)sb >> PIL_BITS) << 8));
+            }
+        }
+    };
+    auto mini_band = [&](int mb, RowRegs &N) {
+        if (nth <= 2) hpass(std::integral_constant<int, 2>{});
+        else if (nth <= 3) hpass(std::integral_constant<int, 3>{});
+        else hpass(std::integral_constant<int, 5>{});
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int ry = lane >> 4, x_base = (lane & (GROUPS - 1)) * 8;
+        const int row = mb * mbh + ry;
+        const bool act = ry < mbh && row < rows_chunk;
+        const bool block = mbh == WV_ROWS && (mb + 1) * mbh <= rows_chunk;        // wave-uniform: one contiguous output block
+        T px[8][3];
+        if (act) {
+            const PilTab yt = s_yt[row];
+            const int slot0 = (yt.a.x >> 12) & 7;
+            const int kv[PIL_KMAX] = {yt.a.y, yt.a.z, yt.a.w, yt.b.x, yt.b.y};
+            int acc[24];
+#pragma unroll
+            for (int q = 0; q < 24; ++q) acc[q] = 1 << (PIL_BITS - 1);
+#pragma unroll
+            for (int t = 0; t < PIL_KMAX; ++t)
+                if (t < 2 || t < ntv) {                  // (wave-uniform; taps past a row's own support weigh 0 and read a stale ring row)
+                    const unsigned char *p = s_h + ((slot0 + t) & (PWV_SRC - 1)) * PWV_PLANE + x_base;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const uint2 u = *reinterpret_cast<const uint2 *>(p + c * OW);
+                        const unsigned int w[2] = {u.x, u.y};
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc[c * 8 + k] += __mul24(byte_of(w, k), kv[t]);
+                    }
+                }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) px[k][c] = s_lut[c][(unsigned int)acc[c * 8 + k] >> PIL_BITS];
+            if (swap_rb) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const T t0 = px[k][0]; px[k][0] = px[k][2]; px[k][2] = t0; }
+            }
+        }
+        uint4 blk0 = make_uint4(0, 0, 0, 0), blk1 = blk0, blk2 = blk0;
+        if (block) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            T *o = reinterpret_cast<T *>(s_rows) + ((size_t)ry * OW + x_base) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Pack<T, 8> p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
+                *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint4 *l4 = reinterpret_cast<const uint4 *>(s_rows);
+            blk0 = l4[lane]; blk1 = l4[WAVE + lane]; blk2 = l4[2 * WAVE + lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // staging rows are dead from here (the ring lives on)
+        __builtin_amdgcn_wave_barrier();
+        if (mb + 1 < mb_hi) {
+            wait_rows(N);
+            stage(N);
+            fetch(mb + 3, N);
+        }
+        if (block) {
+            uint4 *g = reinterpret_cast<uint4 *>(out + ((size_t)slot * OH + row0 + mb * mbh) * OW * 3);
+            stream_store(g + lane, blk0); stream_store(g + WAVE + lane, blk1); stream_store(g + 2 * WAVE + lane, blk2);
+        } else if (act) {
+            T *o = out + (((size_t)slot * OH + row0 + row) * OW + x_base) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Pack<T, 8> p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
+                *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+            }
+        }
+    };
+    if (mb_lo < mb_hi) {
+        fetch(mb_lo, X);
+        fetch(mb_lo + 1, Y);
+        wait_rows(X);
+        stage(X);
+        fetch(mb_lo + 2, X);
+    }
+    for (int mb = mb_lo; mb < mb_hi; mb += 2) {
+        mini_band(mb, Y);
+        if (mb + 1 < mb_hi) mini_band(mb + 1, X);
     }
 }
 
@@ -3043,6 +3379,17 @@ int launch_pil_crop(const unsigned char *frames, int B, int H, int W, const doub
                     int OH, int OW, const float *mean, const float *stdv, int layout, void *out, hipStream_t st, int swap_rb)
 {
     const int sw0 = swap_rb ? 2 : 0, sw2 = swap_rb ? 0 : 2;
+    // r03: free-running wavefronts for the ReID input format (128 wide, NHWC, 16-bit elements); TLK_PIL_WAVE=0: pil_crop_kernel
+    if constexpr (sizeof(T) == 2) {
+        static const int wave = [] { const char *e = getenv("TLK_PIL_WAVE"); return e ? atoi(e) : 1; }();
+        if (wave && layout == LAYOUT_NHWC && OW == 128) {
+            const int chunks = (OH + CF_BANDS * CS_BAND - 1) / (CF_BANDS * CS_BAND);
+            const int nwg = B * max_n * chunks;
+            hipLaunchKernelGGL((pil_wave_kernel<T>), dim3((unsigned)nwg), dim3(BLOCK), 0, st, frames, B, H, W, boxes, box_stride, counts, max_n, OH,
+                               mean[sw0], mean[1], mean[sw2], stdv[sw0], stdv[1], stdv[sw2], (T *)out, swap_rb, nwg);
+            return TLK_OK;
+        }
+    }
     const int pil_bands = (OH + PIL_BAND - 1) / PIL_BAND;
     const dim3 grid((unsigned)((long long)B * max_n * ((pil_bands + PIL_BPW - 1) / PIL_BPW)));
 #define TLK_PIL_LAUNCH(LAY, OWC) hipLaunchKernelGGL((pil_crop_kernel<T, LAY, OWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, box_stride, counts, max_n, OH, OW, \
