@@ -362,9 +362,22 @@ def live_hbm_traffic(kernel: str, probe: str):
     import subprocess
     import tempfile
     if shutil.which("rocprofv3") is None:
-        return None, "rocprofv3 not on PATH"
+        return None, "rocprofv3 not on PATH", None
     vals = {}
+    dur_ms = None
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        # the same kernel's duration as rocprofv3 sees it (no counters in this pass), next to the HIP-event number of the timed loop
+        try:
+            out = os.path.join(tmp, "kt")
+            subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "--", sys.executable,
+                            os.path.join(REPO, "tools", "probe_traffic.py"), probe], cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=240,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            for path in glob.glob(out + "/**/*kernel_stats.csv", recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if kernel in row.get("Name", ""):
+                        dur_ms = float(row["AverageNs"]) * 1e-6
+        except Exception:                                       # noqa: BLE001
+            dur_ms = None
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
             env = dict(os.environ, TMPDIR="/tmp")
@@ -373,18 +386,18 @@ def live_hbm_traffic(kernel: str, probe: str):
                                 os.path.join(REPO, "tools", "probe_traffic.py"), probe], cwd="/tmp", env=env, timeout=240,
                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             except Exception as ex:                             # noqa: BLE001
-                return None, f"rocprofv3 --pmc {ctr} failed: {type(ex).__name__}"
+                return None, f"rocprofv3 --pmc {ctr} failed: {type(ex).__name__}", dur_ms
             got = []
             for path in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
                 for row in csv.DictReader(open(path)):
                     if kernel in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
                         got.append(float(row["Counter_Value"]))
             if not got:
-                return None, f"no {ctr} rows for {kernel}"
+                return None, f"no {ctr} rows for {kernel}", dur_ms
             vals[ctr] = float(np.mean(got))
     return (vals["FETCH_SIZE"] * 2.0 + vals["WRITE_SIZE"]) * 1024.0, \
         ("measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/probe_traffic.py (same kernel, same "
-         "launch shape); gfx950 correction FETCH x2 (KB), WRITE x1 (KB)")
+         "launch shape); gfx950 correction FETCH x2 (KB), WRITE x1 (KB)"), dur_ms
 
 # ------------------------------------------------------------------------------------------------------------ main
 def main():
@@ -623,31 +636,38 @@ def main():
     pipe.reset()
     pipe.record_kernel_events = True
     pipe.kernel_events.clear()
+    pipe.null_events.clear()
     for k in range(args.warmup, total_steps):
         run_step(k)
     pipe.synchronize()
     pipe.record_kernel_events = False
     k_ms = [e0.elapsed_time(e1) for e0, e1 in pipe.kernel_events]
-    k_ms_avg = float(np.mean(k_ms)) if k_ms else float("nan")
+    null_ms = [e0.elapsed_time(e1) for e0, e1 in pipe.null_events]
+    k_ms_raw = float(np.mean(k_ms)) if k_ms else float("nan")
+    # an event pair costs a few us by itself (two barrier packets): measured by an EMPTY pair recorded right before every timed pair and
+    # subtracted -- beside a 30 us letterbox launch it is a third of the raw number, and rocprofv3's kernel durations do not contain it
+    null_avg = float(np.mean(null_ms)) if null_ms else 0.0
+    k_ms_avg = k_ms_raw - null_avg
     from tracklab_amd import roofline as rl
     esz = torch.empty((), dtype=tdtype).element_size()
     cnt_mean = float(np.mean([len(g["dets"]) for g in gts[0][:total_steps * F]]))
     if is3:
-        kname, tfile = ("pil_crop_kernel", "pil_crop_traffic.json") if ssort else ("crop_wave3_kernel" if esz == 2 else "crop_wave2_kernel", "crop_traffic.json")
+        kname, tfile = ("pil_wave_kernel" if esz == 2 else "pil_crop_kernel", "pil_crop_traffic.json") if ssort else (
+            "crop_wave3_kernel" if esz == 2 else "crop_wave2_kernel", "crop_traffic.json")
         # mean crop of the synthetic stream: w~U(40,120), h=w*U(1.8,2.6) -> E[w*h] = E[w^2]*2.2; only the cnt_mean REAL crops of a
         # frame count (the padding slots up to max_dets are not algorithmic bytes)
         ew2 = (120 ** 3 - 40 ** 3) / (3 * 80)
         alg_bytes = B * cnt_mean * (ew2 * 2.2 * 3 + 3 * pipe.reid_hw[0] * pipe.reid_hw[1] * esz)
     else:
-        kname, tfile = "letterbox_lds_kernel", "letterbox_traffic.json"
+        kname, tfile = ("letterbox_wave_kernel" if esz == 2 else "letterbox_lds_kernel"), "letterbox_traffic.json"
         rh, rw = int(HEIGHT * ratio), int(WIDTH * ratio)
         alg_bytes = rl.letterbox_bytes(HEIGHT, WIDTH, 640, rh, rw, elem_bytes=esz) * B
     achieved = alg_bytes / (k_ms_avg * 1e-3) / 1e9 if k_ms else None
-    traffic, traffic_src = None, None
+    traffic, traffic_src, rocprof_ms = None, None, None
     tpath = os.path.join(REPO, "profiles", tfile)
     same_launch = args.dtype == "f16" and F == wl["frames_per_step"] and S == 1
     if rank == 0 and world == 1 and same_launch and not args.no_live_traffic:
-        traffic, traffic_src = live_hbm_traffic(kname, "pil" if kname.startswith("pil") else ("letterbox" if kname.startswith("letterbox") else "crop"))
+        traffic, traffic_src, rocprof_ms = live_hbm_traffic(kname, "pil" if kname.startswith("pil") else ("letterbox" if kname.startswith("letterbox") else "crop"))
     if traffic is None and os.path.exists(tpath) and same_launch:
         why = traffic_src
         try:
@@ -655,13 +675,14 @@ def main():
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_src = "static: profiles/%s (%s) -- rocprofv3 --pmc passes of this launch shape on an earlier box, not measured by this run%s" % (
                 tfile, tj.get("round", "r01"), f" ({why})" if why else "")
-            if not kname.startswith(tj.get("kernel", "?")[:9]):
+            if kname != tj.get("kernel", "?"):
                 traffic, traffic_src = None, None             # counters of another kernel generation: not this kernel's traffic
         except Exception:
             traffic = None
     roofline = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": k_ms_avg, "algorithmic_bytes_per_launch": alg_bytes, "units_per_launch": f"{B} frames x {cnt_mean:.1f} crops" if is3 else f"{B} frames"}
+                "avg_launch_ms": k_ms_avg, "avg_launch_ms_events_raw": k_ms_raw, "event_pair_overhead_ms": null_avg,
+                "rocprofv3_avg_launch_ms": rocprof_ms, "algorithmic_bytes_per_launch": alg_bytes, "units_per_launch": f"{B} frames x {cnt_mean:.1f} crops" if is3 else f"{B} frames"}
 
     # ---- small-step legs: the same chain at frames_per_step 1 / 2 / 4 and at 4 streams x 1 frame (what an online consumer sees; the
     # reference's online engine is per-frame, engine/video.py:67-117). Each: pipelined frames/s, un-overlapped frame-in -> rows-out time,

@@ -182,3 +182,72 @@ def test_rtmpose_module_on_device_matches_oracle_pre_and_post_processing(orc):
         got = out.keypoints_xyc.iloc[i]
         np.testing.assert_allclose(got[:, :2], kp, rtol=1e-12, atol=1e-9)
         np.testing.assert_array_equal(got[:, 2].astype(np.float32), score.astype(np.float32))
+
+
+def test_detector_to_tracker_path_with_the_networks_own_head_activations(orc):
+    """the bench replaces the random-init detector's head activations by a synthetic head (disclosed in its line), and nothing tested
+    frames -> letterbox -> forward -> decode + NMS -> tracker with the activations the network itself produced. Here the head's objectness / class
+    biases are raised so that a random-init YOLOX-s fires on a few hundred anchors per frame, no synthetic head is passed, and every stage after the
+    forward is replayed by the oracle from the SAME head tensor: detections (count, class, score exact; boxes to the 1-2 ulp of expf) and the
+    OC-SORT rows the fused step hands out (ids exact)."""
+    import torch
+    from tracklab_amd import gpu_pipeline as gp
+    from tracklab_amd.synth import SyntheticStream, render_frame
+    torch.manual_seed(3)
+    F = 4
+    pipe = gp.DetTrackPipeline("s", n_streams=1, frames_per_step=F, max_dets=128, use_graph=False)
+    head = pipe.model.head
+    rng = np.random.default_rng(5)
+    stream = SyntheticStream(9, 30, 3 * F + F)
+    from tracklab_amd import _lib
+    calib = torch.from_numpy(np.stack([render_frame(rng, stream.step()["gt_boxes"]) for _ in range(F)])).cuda()
+    x, _ = _lib.letterbox(calib, pipe.size, pipe.layout, pipe.dtype, swap_rb=True)
+    chosen = None
+    with torch.no_grad():
+        for k in range(len(head.obj_preds)):
+            head.reg_preds[k].bias.copy_(torch.tensor([0.0, 0.0, 1.2, 1.6]))         # boxes of ~3.3 x 5 cells: neighbours overlap, NMS has work to do
+        for bias in np.arange(0.6, 4.01, 0.1):                                        # the lowest bias at which every frame has 60 .. 3000 candidates
+            for k in range(len(head.obj_preds)):
+                head.obj_preds[k].bias.fill_(float(bias)); head.cls_preds[k].bias.fill_(float(bias))
+            p = pipe.model(x, focused=(pipe.layout == "focus_nhwc")).float()
+            cand = ((p[..., 4] * p[..., 5]) > 0.7).sum(dim=1)
+            if int(cand.min()) >= 60:
+                chosen = (float(bias), cand.cpu().tolist())
+                break
+    assert chosen is not None and max(chosen[1]) <= 3000, chosen
+    stash = {}
+    fwd = pipe.model.forward
+
+    def spy(x, **kw):
+        stash["pred"] = fwd(x, **kw)
+        return stash["pred"]
+    pipe.model.forward = spy
+    ref = orc.OCSort(**pipe.tracker_cfg["hyper"])
+    total = 0
+    for step in range(3):
+        frames = np.stack([render_frame(rng, stream.step()["gt_boxes"]) for _ in range(F)])
+        pipe.step(torch.from_numpy(frames).cuda())
+        pipe.synchronize()
+        pred = stash["pred"].float().cpu().numpy()
+        assert np.isfinite(pred).all()
+        res = pipe.host_results(pipe.last)
+        det = pipe.last["det"]
+        counts = det["counts"].cpu().numpy()
+        for f in range(F):
+            eb, es, ec = orc.yolox_postprocess(pred[f], 640, float(np.float32(pipe.ratio)))
+            eb, es, ec = eb[:pipe.maxd], es[:pipe.maxd], ec[:pipe.maxd]
+            n = int(counts[f])
+            assert n == len(eb) and n > 0, (step, f, n, len(eb))
+            total += n
+            np.testing.assert_array_equal(det["cls"][f, :n].cpu().numpy(), ec)
+            np.testing.assert_array_equal(det["scores"][f, :n].cpu().numpy(), es)
+            np.testing.assert_allclose(det["xyxy"][f, :n].cpu().numpy(), eb, rtol=2e-6, atol=1e-4)
+            # the tracker is fed with the GPU's own detector rows (their last bits are expf's): its rows must be the oracle's on those rows
+            trk_in = pipe.last["trk_in"].view(F, pipe.maxd, 7)[f, :n].cpu().numpy()
+            exp = orc.ocsort_wrapper_step(ref, trk_in, pipe.tracker_cfg["min_confidence"])
+            got = res["rows"][f, :int(res["ocnt"][f])]
+            assert got.shape == exp.shape, (step, f, got.shape, exp.shape)
+            np.testing.assert_array_equal(got[:, [4, 5, 7]], exp[:, [4, 5, 7]])
+            np.testing.assert_array_equal(got, exp)
+    assert total > 40
+    pipe.close()

@@ -71,14 +71,14 @@ def write_traffic():
         print("no PMC data"); return
     cal = {"copy_1GiB_FETCH_SIZE_KB": pick(fetch, "elementwise") or pick(fetch, "copy"),
            "copy_1GiB_WRITE_SIZE_KB": pick(write, "elementwise") or pick(write, "copy"),
-           "letterbox_640to640_FETCH_SIZE_KB": pick(fetch, "letterbox_lds_kernel", 0),
+           "letterbox_640to640_FETCH_SIZE_KB": pick(fetch, "letterbox_wave_kernel", 0),
            "letterbox_640to640_expected_read_KB": 32 * 640 * 640 * 3 / 1024,
            "note": "gfx950: FETCH_SIZE reports 1/2 of the bytes fetched (a wide copy AND our 16-byte staging loads calibrate to x2); "
                    "WRITE_SIZE calibrates to x1 (KB)"}
     for kern, frag, which, launch, fname in (
-            ("letterbox_lds_kernel", "letterbox_lds_kernel", 1, "32 frames 1080p -> 640 focus_nhwc f16 (= one config2 bench launch)", "letterbox_traffic.json"),
+            ("letterbox_wave_kernel", "letterbox_wave_kernel", 1, "32 frames 1080p -> 640 focus_nhwc f16 (= one config2 bench launch)", "letterbox_traffic.json"),
             ("crop_wave3_kernel", "crop_wave3_kernel", None, "24 frames x 104 slots (~98 real crops per frame) -> 384x128 nhwc f16 (= one config3 bench launch)", "crop_traffic.json"),
-            ("pil_crop_kernel", "pil_crop_kernel", None, "24 frames x 104 slots -> 256x128 nhwc f16, Pillow semantics (= one config3s/3b/3d bench launch)",
+            ("pil_wave_kernel", "pil_wave_kernel", None, "24 frames x 104 slots -> 256x128 nhwc f16, Pillow semantics (= one config3s/3b/3d bench launch)",
              "pil_crop_traffic.json")):
         f, w = pick(fetch, frag, which), pick(write, frag, which)
         if f is None or w is None:
@@ -87,7 +87,7 @@ def write_traffic():
                    "hbm_bytes_per_launch": (2 * f + w) * 1024}, open(os.path.join(dst, fname), "w"), indent=1)
         print(fname, "read MiB", 2 * f / 1024, "write MiB", w / 1024)
         # the bench of this same GPU call read the PREVIOUS traffic file: stamp the copy kept in profiles/ with this call's counters
-        for wl in {"crop_wave3_kernel": ("config3", "config3h", "config4", "config5"), "pil_crop_kernel": ("config3s", "config3b", "config3c", "config3d")}.get(kern, ("config2", "config2b")):
+        for wl in {"crop_wave3_kernel": ("config3", "config3h", "config4", "config5"), "pil_wave_kernel": ("config3s", "config3b", "config3c", "config3d")}.get(kern, ("config2", "config2b")):
             bp = os.path.join(dst, f"{tag}_bench_{wl}.json")
             if os.path.exists(bp):
                 line = json.loads(open(bp).read().strip().splitlines()[-1])

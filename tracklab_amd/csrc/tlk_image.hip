@@ -2314,8 +2314,10 @@ constexpr int PWV_PLANE = 128 * 3;                    // bytes per ring row: pla
 constexpr int PWV_WAVE_LDS = PWV_SRC * CS_ROW_BYTES + PWV_SRC * PWV_PLANE;
 struct PilTab { int4 a, b; };                         // a = (first tap: byte offset | ring slot << 12 ... see users, k0, k1, k2), b = (k3, k4, taps, 0)
 
+// (inlined with ROLLED loops: as a call its 130-register frame became the register count of pil_wave_kernel -- a callee's need is the caller's -- and
+// cost the kernel its fourth wavefront per SIMD; rolled and inline it stays below the fast path's own 124)
 template <typename T>
-__device__ __noinline__ void pil_direct_unit_nhwc(const unsigned char *__restrict__ base, int W, int cw, int ch, int OH, int OW, int y, int x_base,
+__device__ __forceinline__ void pil_direct_unit_nhwc(const unsigned char *__restrict__ base, int W, int cw, int ch, int OH, int OW, int y, int x_base,
                                                   float m0, float m1, float m2, float d0, float d1, float d2, int swap_rb, T *__restrict__ out, size_t slot)
 {
     // every vertical tap recomputes its horizontally resampled (and uint8-rounded) sample from global memory (the direct branch of pil_crop_kernel)

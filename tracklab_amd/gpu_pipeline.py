@@ -26,7 +26,16 @@ from . import _lib
 from .backbones.yolox import yolox
 
 
+def _record_null_pair(self):
+    """Two timing events with nothing between them on the current stream: the cost of an event pair itself (a few us on this stack -- not negligible
+    beside a 30 us kernel). bench.py subtracts its mean from the mean of the kernel's own event pairs and prints both."""
+    n0, n1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n0.record(); n1.record()
+    self.null_events.append((n0, n1))
+
+
 class DetTrackPipeline:
+    _record_null_pair = _record_null_pair
     def __init__(self, detector: str = "s", n_streams: int = 1, frames_per_step: int = 16, max_dets: int = 128,
                  height: int = 1080, width: int = 1920, size: int = 640, dtype=torch.float16,
                  layout: str = "focus_nhwc", device: int = 0, tracker_cfg: dict | None = None,
@@ -92,6 +101,7 @@ class DetTrackPipeline:
         self.ratio = min(size / height, size / width)
         self.frames_done = 0
         self.kernel_events = []         # (start, end) torch events around the letterbox launch
+        self.null_events = []           # (start, end) with nothing between them, recorded just before: what an event pair itself costs on this stream
         self.record_kernel_events = False
 
     def reset(self, keep_ids: bool = False):
@@ -127,6 +137,7 @@ class DetTrackPipeline:
         main = torch.cuda.current_stream(self.dev)
         main.wait_event(buf["trk_done"])      # buffer reuse: tracker of step k-nbuf has consumed it
         if self.record_kernel_events:
+            self._record_null_pair()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         ratio = self.ratio
@@ -231,6 +242,7 @@ class DetTrackPipeline:
 
 
 class DetReidTrackPipeline:
+    _record_null_pair = _record_null_pair
     """BASELINE.json configs[2]/[4]: YOLOX -> part-based ReID -> BPBReID-StrongSORT, GPU-resident.
 
     A step = ``frames_per_step`` consecutive frames of each of ``n_streams`` streams:
@@ -364,6 +376,7 @@ class DetReidTrackPipeline:
         self.frames_done = 0
         self.ratio = min(size / height, size / width)
         self.kernel_events = []
+        self.null_events = []
         self.record_kernel_events = False
 
     def reset(self, keep_ids: bool = False):
@@ -419,6 +432,7 @@ class DetReidTrackPipeline:
         _lib.yolox_decode_nms(pred, self.size, float(np.float32(self.ratio)), self.W, self.H, maxd, self.nms_thr,
                               self.score_thr, out=self.det, trk_in=buf["trk_in"], det_id_base=self.frames_done * maxd, category_id=1.0)
         if self.record_kernel_events:
+            self._record_null_pair()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if self.global_feat:                    # StrongSORT._get_features: int-truncated boxes, Pillow resize, ImageNet normalisation
