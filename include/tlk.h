@@ -528,6 +528,11 @@ int tlk_cmc_create(int h, int w, int downscale, int max_corners, int device, tlk
 int tlk_cmc_destroy(tlk_cmc *c);
 int tlk_cmc_reset(tlk_cmc *c);                        /* new video: forget the previous frame */
 int tlk_cmc_apply_dev(tlk_cmc *c, const uint8_t *frame_dev, double *warp6_dev, void *hip_stream);
+/* The same for a caller whose "does this frame reach the tracker?" lives in device memory: the reference returns BEFORE GMC.apply on a frame
+ * without detections (wrappers/track/bot_sort_api.py:59-60), so its next warp spans the frames either side of it. If *count_dev == 0 when the
+ * chain has run, the estimator's state (previous pyramid, derivatives, corners) is put back to what it was before the call, on the device and
+ * in stream order -- no host synchronisation; warp6_dev of such a frame is not meaningful (the tracker banks skip the frame). */
+int tlk_cmc_apply_dev_gated(tlk_cmc *c, const uint8_t *frame_dev, double *warp6_dev, const int32_t *count_dev, void *hip_stream);
 int tlk_cmc_apply(tlk_cmc *c, const uint8_t *frame_host, double *warp6_host, int *n_inliers);
 /* debug / test: stage outputs of the last tlk_cmc_apply*: what = 0 downscaled grey image, 1 eigenvalue image (float32), 2 corners
  * (n, 2) float32, 3 tracked positions of the previous corners, 4 their status bytes, 10 + l pyramid image l, 20 + l its int16

@@ -1101,6 +1101,7 @@ class CmcEstimator:
         L.tlk_cmc_destroy.argtypes = [vp]
         L.tlk_cmc_reset.argtypes = [vp]
         L.tlk_cmc_apply_dev.argtypes = [vp, vp, vp, vp]
+        L.tlk_cmc_apply_dev_gated.argtypes = [vp, vp, vp, vp, vp]
         L.tlk_cmc_apply.argtypes = [vp, vp, vp, C.POINTER(ci)]
         L.tlk_cmc_debug_get.argtypes = [vp, ci, vp, C.c_size_t, C.POINTER(ci)]
         self.h, self.w, self.downscale = int(height), int(width), max(1, int(downscale))
@@ -1134,8 +1135,10 @@ class CmcEstimator:
         self.inliers = n.value
         return H.reshape(2, 3)
 
-    def apply_dev(self, frame, stream_ptr=None, out=None):
-        """out: optional (6,) float64 cuda tensor (e.g. a row of the (S, F, 6) warps block of ``BoTSORTBank.update_dev``) instead of ``.warp_dev``."""
+    def apply_dev(self, frame, stream_ptr=None, out=None, count=None):
+        """out: optional (6,) float64 cuda tensor (e.g. a row of the (S, F, 6) warps block of ``BoTSORTBank.update_dev``) instead of ``.warp_dev``.
+        count: optional 1-element int32 cuda tensor = the frame's detection count; when it is 0 the estimator's state is rolled back on the device
+        (the reference does not call GMC.apply on a frame without detections, bot_sort_api.py:59-60): tlk_cmc_apply_dev_gated."""
         import torch
         assert frame.is_cuda and frame.dtype == torch.uint8 and frame.is_contiguous() and tuple(frame.shape) == (self.h, self.w, 3)
         if out is None:
@@ -1143,7 +1146,12 @@ class CmcEstimator:
                 self.warp_dev = torch.zeros(6, dtype=torch.float64, device=frame.device)
             out = self.warp_dev
         assert out.is_cuda and out.dtype == torch.float64 and out.numel() == 6 and out.is_contiguous()
-        check(lib().tlk_cmc_apply_dev(self._h, frame.data_ptr(), out.data_ptr(), stream_ptr if stream_ptr is not None else current_stream_ptr()))
+        sp = stream_ptr if stream_ptr is not None else current_stream_ptr()
+        if count is None:
+            check(lib().tlk_cmc_apply_dev(self._h, frame.data_ptr(), out.data_ptr(), sp))
+        else:
+            assert count.is_cuda and count.dtype == torch.int32 and count.numel() == 1
+            check(lib().tlk_cmc_apply_dev_gated(self._h, frame.data_ptr(), out.data_ptr(), count.data_ptr(), sp))
         return out
 
     def debug(self, what):

@@ -436,7 +436,15 @@ extern "C" int tlk_cmc_create(int h, int w, int downscale, int max_corners, int 
 }
 
 extern "C" int tlk_cmc_destroy(tlk_cmc *c) { cmc_free(c); return TLK_OK; }
-extern "C" int tlk_cmc_reset(tlk_cmc *c) { if (!c) return fail(TLK_EINVAL, "tlk_cmc_reset: null handle"); c->have_prev = 0; c->cur = 0; return TLK_OK; }
+extern "C" int tlk_cmc_reset(tlk_cmc *c)
+{
+    if (!c) return fail(TLK_EINVAL, "tlk_cmc_reset: null handle");
+    TLK_HIP(hipSetDevice(c->device));
+    c->have_prev = 0; c->cur = 0;
+    // (no corners of an earlier video: a gated first frame without detections rolls back onto THIS state, and the frame after it must find nothing to track)
+    TLK_HIP(hipMemset(c->n_pts[0], 0, sizeof(int))); TLK_HIP(hipMemset(c->n_pts[1], 0, sizeof(int)));
+    return TLK_OK;
+}
 
 extern "C" int tlk_cmc_apply_dev(tlk_cmc *c, const uint8_t *frame_dev, double *warp6_dev, void *hip_stream)
 {
@@ -479,6 +487,42 @@ extern "C" int tlk_cmc_apply_dev(tlk_cmc *c, const uint8_t *frame_dev, double *w
                        (const int *)c->good, c->have_prev, (double)c->downscale, warp6_dev, c->n_inl);
     TLK_HIP(hipGetLastError());
     c->have_prev = 1; c->cur = pb;
+    return TLK_OK;
+}
+
+// state of one ping-pong side copied onto the other when the gate is closed: <= 2 * LK_LEVELS + 2 buffers
+struct CmcCopyTab { const unsigned char *src[2 * LK_LEVELS + 2]; unsigned char *dst[2 * LK_LEVELS + 2]; unsigned int bytes[2 * LK_LEVELS + 2]; int n; };
+__global__ void __launch_bounds__(BLOCK) cmc_rollback_kernel(const int *__restrict__ count, CmcCopyTab tab)
+{
+    if (*count != 0) return;
+    const unsigned int tid = blockIdx.x * BLOCK + threadIdx.x, nthr = gridDim.x * BLOCK;
+    for (int i = 0; i < tab.n; ++i) {
+        const unsigned int n16 = tab.bytes[i] >> 4;                      // (hipMalloc'ed buffers: 256-byte aligned)
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(tab.src[i]);
+        uint4 *d4 = reinterpret_cast<uint4 *>(tab.dst[i]);
+        for (unsigned int k = tid; k < n16; k += nthr) d4[k] = s4[k];
+        for (unsigned int k = (n16 << 4) + tid; k < tab.bytes[i]; k += nthr) tab.dst[i][k] = tab.src[i][k];
+    }
+}
+
+extern "C" int tlk_cmc_apply_dev_gated(tlk_cmc *c, const uint8_t *frame_dev, double *warp6_dev, const int32_t *count_dev, void *hip_stream)
+{
+    if (!count_dev) return fail(TLK_EINVAL, "tlk_cmc_apply_dev_gated: null pointer");
+    const int rc = tlk_cmc_apply_dev(c, frame_dev, warp6_dev, hip_stream);
+    if (rc != TLK_OK) return rc;
+    // the frame just processed sits in side `now` (= the next call's "previous"); the state before the call is side `old`
+    const int now = 1 - c->cur, old = c->cur;
+    CmcCopyTab tab;
+    tab.n = 0;
+    auto add = [&](const void *s, void *d, size_t bytes) { tab.src[tab.n] = (const unsigned char *)s; tab.dst[tab.n] = (unsigned char *)d; tab.bytes[tab.n] = (unsigned int)bytes; ++tab.n; };
+    for (int l = 0; l < c->nlev; ++l) {
+        add(c->gray[old][l], c->gray[now][l], (size_t)c->lh[l] * c->lw[l]);
+        add(c->der[old][l], c->der[now][l], sizeof(short) * 2 * (size_t)c->lh[l] * c->lw[l]);
+    }
+    add(c->pts[old], c->pts[now], sizeof(float) * 2 * MAX_CORNERS_CAP);
+    add(c->n_pts[old], c->n_pts[now], sizeof(int));
+    hipLaunchKernelGGL(cmc_rollback_kernel, dim3(256), dim3(BLOCK), 0, (hipStream_t)hip_stream, (const int *)count_dev, tab);
+    TLK_HIP(hipGetLastError());
     return TLK_OK;
 }
 

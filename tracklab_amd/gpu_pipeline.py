@@ -369,6 +369,7 @@ class DetReidTrackPipeline:
             for b_ in self.bufs:
                 b_["warps"] = torch.zeros((n_streams, frames_per_step, 6), dtype=torch.float64, device=dev)
                 b_["cmc_done"] = torch.cuda.Event()
+                b_["gate"] = torch.zeros((B,), dtype=torch.int32, device=dev)
         self.trk_stream = torch.cuda.Stream(device=dev, priority=int(__import__("os").environ.get("TLK_TRK_PRIO", "0")))
         self.use_graph = use_graph
         self.det_graphs, self.reid_graph = {}, None
@@ -458,6 +459,7 @@ class DetReidTrackPipeline:
         if self.cmc is not None:
             # ... unless the camera-motion estimators read them too: frame by frame per stream, on their own stream (about 25 small launches per frame
             # that would otherwise sit on the main stream between the backbone launches)
+            buf["gate"].copy_(self.det["counts"])       # (this step's own copy: the next step's decode overwrites det["counts"] while the estimators may still run)
             fed = torch.cuda.Event()
             fed.record(main)
             with torch.cuda.stream(self.cmc_stream):
@@ -465,7 +467,8 @@ class DetReidTrackPipeline:
                 sp = C.c_void_p(self.cmc_stream.cuda_stream)
                 for s_ in range(S):
                     for f_ in range(F):
-                        self.cmc[s_].apply_dev(frames[s_ * F + f_], stream_ptr=sp, out=buf["warps"][s_, f_])
+                        # gated on the frame's detection count, on the device: the reference skips GMC.apply for a frame without detections
+                        self.cmc[s_].apply_dev(frames[s_ * F + f_], stream_ptr=sp, out=buf["warps"][s_, f_], count=buf["gate"][s_ * F + f_:s_ * F + f_ + 1])
                 buf["cmc_done"].record(self.cmc_stream)
                 self.frames_free.record(self.cmc_stream)
         else:
