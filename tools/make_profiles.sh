@@ -9,15 +9,15 @@ OUT="$R/gpurun_out/round"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$R"
 python bench.py --workload config3 --steps 20 --warmup 5 > "$OUT/bench_config3.json" 2> "$OUT/bench_config3.err"
-python bench.py --workload config3 --dtype f32 --steps 8 --warmup 3 --no-cpu-baseline --no-latency-leg --check-frames 96 > "$OUT/bench_config3_f32.json" 2> "$OUT/bench_config3_f32.err"
-python bench.py --workload config2 --steps 20 --warmup 5 > "$OUT/bench_config2.json" 2> "$OUT/bench_config2.err"
+python bench.py --workload config3 --dtype f32 --steps 8 --warmup 3 --no-cpu-baseline --no-latency-leg --no-f32-leg --no-live-traffic --check-frames 96 > "$OUT/bench_config3_f32.json" 2> "$OUT/bench_config3_f32.err"
+python bench.py --workload config2 --steps 20 --warmup 5 --no-f32-leg > "$OUT/bench_config2.json" 2> "$OUT/bench_config2.err"
 for wl in config1 config4 config5 config3h config3s config3b config3c config3d config2b; do
-  python bench.py --workload $wl --steps 8 --warmup 3 --no-cpu-baseline --no-latency-leg --check-frames 96 > "$OUT/bench_$wl.json" 2> "$OUT/bench_$wl.err"
+  python bench.py --workload $wl --steps 8 --warmup 3 --no-cpu-baseline --no-latency-leg --no-f32-leg --no-live-traffic --check-frames 96 > "$OUT/bench_$wl.json" 2> "$OUT/bench_$wl.err"
 done
 cd /tmp && export TMPDIR=/tmp
 for wl in config3 config2 config3s; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$wl" -- \
-    python "$R/bench.py" --workload $wl --steps 10 --warmup 3 --no-cpu-baseline --no-latency-leg --check-frames 0 > "$OUT/prof_$wl.json" 2> "$OUT/prof_$wl.err"
+    python "$R/bench.py" --workload $wl --steps 10 --warmup 3 --no-cpu-baseline --no-latency-leg --no-f32-leg --no-live-traffic --check-frames 0 > "$OUT/prof_$wl.json" 2> "$OUT/prof_$wl.err"
   find "$OUT/prof_$wl" -name '*kernel_trace.csv' -delete       # keep the stats, drop the raw trace (size)
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_probe" -- python "$R/tools/probe_kernels.py" > "$OUT/kt_probe.log" 2>&1
