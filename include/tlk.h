@@ -572,6 +572,13 @@ int tlk_ecc_find_transform(const uint8_t *templ_host, const uint8_t *image_host,
  * ------------------------------------------------------------------------------------------ */
 int tlk_hota_sequence_f64(const int32_t *gt_ids, const double *gt_ltrb, const int64_t *gt_off, const int32_t *tr_ids, const double *tr_ltrb,
                           const int64_t *tr_off, int n_frames, int n_gt, int n_tr, const double *alphas19, double *stats);
+/* The same with all six arrays already in DEVICE memory -- the tracker side straight from the engine's HBM-resident per-video table
+ * (tracklab_amd.evaluate.evaluate_device_log: no host round trip of the table), the ground truth uploaded once by the caller. n_gt_boxes /
+ * n_tr_boxes (the totals) and n_match (>= sum over the frames of gt boxes x tracker boxes: it sizes the similarity matrices) are host
+ * scalars; alphas19 and stats stay host buffers (stats is valid on return: the call synchronises hip_stream). */
+int tlk_hota_sequence_dev_f64(const int32_t *gt_ids_dev, const double *gt_ltrb_dev, const int64_t *gt_off_dev, const int32_t *tr_ids_dev,
+                              const double *tr_ltrb_dev, const int64_t *tr_off_dev, int n_frames, int n_gt, int n_tr, int64_t n_gt_boxes,
+                              int64_t n_tr_boxes, int64_t n_match, const double *alphas19, double *stats, void *hip_stream);
 
 /* CLEAR-MOT and ID counts of one sequence on the device. Replaces MOTAccumulator.update per frame + the measures of the
  * py-motmetrics copy the reference vendors for its PoseTrack21 MOT evaluator (plugins/eval/PoseTrack21/posetrack21_mot/posetrack21_mot/
@@ -583,6 +590,10 @@ int tlk_hota_sequence_f64(const int32_t *gt_ids, const double *gt_ltrb, const in
  * ratios of them (clearmot.finalize). At most 512 boxes per frame and side. */
 int tlk_clear_sequence_f64(const int32_t *gt_ids, const double *gt_ltwh, const int64_t *gt_off, const int32_t *tr_ids, const double *tr_ltwh,
                            const int64_t *tr_off, int n_frames, int n_gt, int n_tr, double max_iou, double *counts19);
+/* The same with all six arrays already in DEVICE memory (see tlk_hota_sequence_dev_f64); counts19 is a host buffer, valid on return. */
+int tlk_clear_sequence_dev_f64(const int32_t *gt_ids_dev, const double *gt_ltwh_dev, const int64_t *gt_off_dev, const int32_t *tr_ids_dev,
+                               const double *tr_ltwh_dev, const int64_t *tr_off_dev, int n_frames, int n_gt, int n_tr, double max_iou,
+                               double *counts19, void *hip_stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused convolution epilogue for the PyTorch-ROCm backbones (not a reference function: the reference's

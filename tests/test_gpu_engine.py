@@ -230,3 +230,55 @@ def test_tracking_engine_fires_the_callback_hooks_and_online_equals_resident():
         np.testing.assert_array_equal(a.track_id.to_numpy(), b.track_id.to_numpy())
         np.testing.assert_array_equal(np.stack(a.bbox_ltwh.to_list()), np.stack(b.bbox_ltwh.to_list()))
     pipe.close()
+
+
+@pytest.mark.parametrize("kind", ["oc_sort", "byte_track", "bpbreid", "strong_sort"])
+def test_evaluators_fed_from_the_hbm_resident_table_equal_the_host_fed_ones(kind):
+    """HOTA and the CLEAR-MOT / ID counts of a video computed from the per-video table WHERE THE ENGINE LEFT IT (engine.DeviceStepLog in
+    HBM; evaluate.evaluate_device_log -> tlk_hota_sequence_dev_f64 / tlk_clear_sequence_dev_f64) equal the same evaluators fed with the fetched
+    table through host arrays, and the host (numpy) evaluators: every count exactly, HOTA's floating-point sums to 1e-12. A partial last step,
+    frames without detections and (BPBReID) rows without a track are in the stream."""
+    from tracklab_amd import evaluate, gpu_pipeline as gp
+    from tracklab_amd.engine import HipVideoEngine
+    from tracklab_amd.synth import SyntheticStream, render_frame, synth_yolox_head
+    F, T = 4, 22
+    if kind in ("oc_sort", "byte_track"):
+        pipe = gp.DetTrackPipeline("s", n_streams=1, frames_per_step=F, max_dets=64, use_graph=False, tracker=kind)
+    elif kind == "bpbreid":
+        pipe = gp.DetReidTrackPipeline("s", n_streams=1, frames_per_step=F, max_dets=32, dim=64, use_graph=False)
+    else:
+        pipe = gp.DetReidTrackPipeline("s", n_streams=1, frames_per_step=F, max_dets=32, use_graph=False, tracker=kind)
+    rng = np.random.default_rng(41)
+    heads, frames, gt = [], [], {"frame": [], "track_id": [], "ltwh": []}
+    for t, fr in enumerate(SyntheticStream(41, 14, T, miss_prob=0.15, churn_period=6)):
+        heads.append(synth_yolox_head(rng, fr["dets"][:, :4], ratio=pipe.ratio))
+        frames.append(render_frame(rng, fr["gt_boxes"]))
+        b = np.asarray(fr["gt_boxes"], dtype=np.float64)
+        gt["frame"].extend([t + 1] * len(b)); gt["track_id"].extend(int(i) for i in fr["gt_all_ids"])
+        gt["ltwh"].extend(np.column_stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]]).tolist())
+    heads = np.stack(heads)
+    heads[9][:, 4] = 0.0; heads[10][:, 4] = 0.0                # two frames without detections
+    gt = {"frame": np.asarray(gt["frame"]), "track_id": np.asarray(gt["track_id"]), "ltwh": np.asarray(gt["ltwh"], dtype=np.float64).reshape(-1, 4)}
+    eng = HipVideoEngine(pipe)
+    df = eng.video_loop(frames, synth_heads=lambda t0, n: heads[t0:t0 + n])
+    from_dev = evaluate.evaluate_device_log(gt, eng.last_log, pipe)
+    tracked = df[df.track_id.notna()]
+    assert len(tracked) > 100
+    if kind == "bpbreid":
+        assert df.track_id.isna().any() or len(tracked) == len(df)
+    pred = {"frame": tracked.image_id.to_numpy().astype(np.int64) + 1, "track_id": tracked.track_id.to_numpy().astype(np.int64),
+            "ltwh": np.stack(tracked.track_bbox_ltwh.to_list()).astype(np.float64)}
+    for device in ("gpu", "cpu"):
+        ref = evaluate.evaluate_sequence(gt, pred, n_frames=T, device=device)
+        np.testing.assert_allclose(from_dev["hota"], ref["hota"], rtol=1e-12, atol=1e-12, err_msg=device)
+        for k, v in ref["clear"].items():
+            if isinstance(v, float):
+                np.testing.assert_allclose(from_dev["clear"][k], v, rtol=1e-12, atol=1e-12, err_msg=f"{device} {k}")
+            else:
+                assert from_dev["clear"][k] == v, (device, k, from_dev["clear"][k], v)
+    # without fetching the table at all
+    assert eng.video_loop(frames, synth_heads=lambda t0, n: heads[t0:t0 + n], fetch_table=False) is None
+    again = evaluate.evaluate_device_log(gt, eng.last_log, pipe)
+    np.testing.assert_array_equal(again["hota"], from_dev["hota"])
+    assert again["clear"] == from_dev["clear"]
+    pipe.close()

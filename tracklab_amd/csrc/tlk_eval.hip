@@ -405,6 +405,71 @@ __global__ void __launch_bounds__(BLOCK) clear_seq_kernel(ClearDev A)
 // HOST buffers. gt_ids / tr_ids: per-frame ids re-labelled 0..n-1 (TrackEval's preprocessing), concatenated; *_ltrb (., 4) float64
 // x0 y0 x1 y1; *_off (n_frames + 1) offsets of the frames; alphas19: the thresholds (np.arange(0.05, 0.99, 0.05), passed in so that they
 // are numpy's own bits). stats (7, 19): HOTA_TP, HOTA_FN, HOTA_FP, LocA sum, AssA, AssRe, AssPr -- the fields of hota.hota_sequence.
+// match-matrix offsets of the frames (exclusive prefix sum of gt boxes x tracker boxes) when the caller's offsets live in device memory
+__global__ void __launch_bounds__(BLOCK) eval_moff_kernel(const long long *__restrict__ goff, const long long *__restrict__ toff, int n_frames, long long *__restrict__ moff)
+{
+    __shared__ long long s_part[BLOCK];
+    const int tid = threadIdx.x, per = (n_frames + BLOCK - 1) / BLOCK, lo = min(n_frames, tid * per), hi = min(n_frames, lo + per);
+    long long sum = 0;
+    for (int f = lo; f < hi; ++f) sum += (goff[f + 1] - goff[f]) * (toff[f + 1] - toff[f]);
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) { long long run = 0; for (int k = 0; k < BLOCK; ++k) { const long long v = s_part[k]; s_part[k] = run; run += v; } moff[n_frames] = run; }
+    __syncthreads();
+    long long run = s_part[tid];
+    for (int f = lo; f < hi; ++f) { moff[f] = run; run += (goff[f + 1] - goff[f]) * (toff[f + 1] - toff[f]); }
+}
+
+// the four kernels on arrays that are ALL in device memory (moff == nullptr: computed here); scratch is one allocation, carved
+static int hota_run(const int *gid, const int *tid, const double *gb, const double *tb, const long long *goff, const long long *toff, const long long *moff_in,
+                    int n_frames, int n_gt, int n_tr, long long ng, long long nt, long long nm_in, const double *alphas19, double *stats, hipStream_t st, const char *who)
+{
+    const long long nm = nm_in > 0 ? nm_in : 1, npair = (long long)n_gt * n_tr;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_moff = carve(sizeof(long long) * (n_frames + 1));
+    const size_t o_sim = carve(sizeof(double) * nm), o_score = carve(sizeof(double) * nm), o_rs = carve(sizeof(double) * ng), o_cs = carve(sizeof(double) * nt);
+    const size_t o_posg = carve(sizeof(int) * (size_t)n_frames * n_gt), o_post = carve(sizeof(int) * (size_t)n_frames * n_tr);
+    const size_t o_gcnt = carve(sizeof(int) * n_gt), o_tcnt = carve(sizeof(int) * n_tr), o_gas = carve(sizeof(double) * npair);
+    const size_t o_mr = carve(sizeof(int) * (ng < nt ? ng : nt) + 64), o_mc = carve(sizeof(int) * (ng < nt ? ng : nt) + 64);
+    const size_t o_cnt3 = carve(sizeof(unsigned long long) * 3 * NA + sizeof(double) * NA), o_loc = carve(sizeof(double) * (size_t)n_frames * NA);
+    const size_t o_match = carve(sizeof(int) * NA * (size_t)npair), o_err = carve(sizeof(int)), o_out = carve(sizeof(double) * 7 * NA);
+    unsigned char *d = nullptr;
+    TLK_HIP(hipMalloc((void **)&d, off));
+    hipError_t e = hipMemsetAsync(d + o_posg, 0xff, sizeof(int) * (size_t)n_frames * n_gt, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d + o_post, 0xff, sizeof(int) * (size_t)n_frames * n_tr, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d + o_gcnt, 0, sizeof(int) * n_gt, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d + o_tcnt, 0, sizeof(int) * n_tr, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d + o_cnt3, 0, sizeof(unsigned long long) * 3 * NA, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d + o_match, 0, sizeof(int) * NA * (size_t)npair, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d + o_err, 0, sizeof(int), st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_cnt3 + sizeof(unsigned long long) * 3 * NA, alphas19, sizeof(double) * NA, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        if (moff_in) e = hipMemcpyAsync(d + o_moff, moff_in, sizeof(long long) * (n_frames + 1), hipMemcpyDeviceToDevice, st);
+        else hipLaunchKernelGGL(eval_moff_kernel, dim3(1), dim3(BLOCK), 0, st, goff, toff, n_frames, (long long *)(d + o_moff));
+    }
+    if (e != hipSuccess) { hipFree(d); return fail(TLK_EHIP, std::string(who) + ": " + hipGetErrorString(e)); }
+    HotaIn in{gid, tid, gb, tb, goff, toff, (const long long *)(d + o_moff), n_frames, n_gt, n_tr};
+    hipLaunchKernelGGL(hota_sim_kernel, dim3(n_frames), dim3(BLOCK), 0, st, in, (double *)(d + o_sim), (double *)(d + o_rs), (double *)(d + o_cs), (int *)(d + o_posg),
+                       (int *)(d + o_post), (int *)(d + o_gcnt), (int *)(d + o_tcnt));
+    hipLaunchKernelGGL(hota_potential_kernel, dim3((unsigned)((npair + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, in, (const double *)(d + o_sim), (const double *)(d + o_rs),
+                       (const double *)(d + o_cs), (const int *)(d + o_posg), (const int *)(d + o_post), (const int *)(d + o_gcnt), (const int *)(d + o_tcnt), (double *)(d + o_gas));
+    hipLaunchKernelGGL(hota_match_kernel, dim3((n_frames + NWAVES - 1) / NWAVES), dim3(BLOCK), NWAVES * 512 * (sizeof(double) + sizeof(int)), st, in, (const double *)(d + o_sim),
+                       (const double *)(d + o_gas), (double *)(d + o_score), (int *)(d + o_mr), (int *)(d + o_mc), (unsigned long long *)(d + o_cnt3), (double *)(d + o_loc),
+                       (int *)(d + o_match), (int *)(d + o_err));
+    hipLaunchKernelGGL(hota_final_kernel, dim3(NA), dim3(BLOCK), 0, st, in, (const int *)(d + o_match), (const int *)(d + o_gcnt), (const int *)(d + o_tcnt),
+                       (const unsigned long long *)(d + o_cnt3), (const double *)(d + o_loc), (double *)(d + o_out));
+    e = hipGetLastError();
+    int err = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&err, d + o_err, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(stats, d + o_out, sizeof(double) * 7 * NA, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d);
+    if (e != hipSuccess) return fail(TLK_EHIP, std::string(who) + ": " + hipGetErrorString(e));
+    if (err) return fail(err, std::string(who) + ": a frame exceeds the solver's capacity (512 boxes per frame and side)");
+    return TLK_OK;
+}
+
 extern "C" int tlk_hota_sequence_f64(const int32_t *gt_ids, const double *gt_ltrb, const int64_t *gt_off, const int32_t *tr_ids, const double *tr_ltrb,
                                      const int64_t *tr_off, int n_frames, int n_gt, int n_tr, const double *alphas19, double *stats)
 {
@@ -423,60 +488,90 @@ extern "C" int tlk_hota_sequence_f64(const int32_t *gt_ids, const double *gt_ltr
         if (g > 512 || t > 512) return fail(TLK_ECAPACITY, "tlk_hota_sequence_f64: at most 512 boxes per frame and side");
         moff[f + 1] = moff[f] + g * t;
     }
-    const long long nm = moff[n_frames] ? moff[n_frames] : 1, npair = (long long)n_gt * n_tr;
-    // one allocation, carved
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     const size_t o_gid = carve(sizeof(int) * ng), o_tid = carve(sizeof(int) * nt), o_gb = carve(sizeof(double) * 4 * ng), o_tb = carve(sizeof(double) * 4 * nt);
     const size_t o_goff = carve(sizeof(long long) * (n_frames + 1)), o_toff = carve(sizeof(long long) * (n_frames + 1)), o_moff = carve(sizeof(long long) * (n_frames + 1));
-    const size_t o_sim = carve(sizeof(double) * nm), o_score = carve(sizeof(double) * nm), o_rs = carve(sizeof(double) * ng), o_cs = carve(sizeof(double) * nt);
-    const size_t o_posg = carve(sizeof(int) * (size_t)n_frames * n_gt), o_post = carve(sizeof(int) * (size_t)n_frames * n_tr);
-    const size_t o_gcnt = carve(sizeof(int) * n_gt), o_tcnt = carve(sizeof(int) * n_tr), o_gas = carve(sizeof(double) * npair);
-    const size_t o_mr = carve(sizeof(int) * (ng < nt ? ng : nt) + 64), o_mc = carve(sizeof(int) * (ng < nt ? ng : nt) + 64);
-    const size_t o_cnt3 = carve(sizeof(unsigned long long) * 3 * NA + sizeof(double) * NA), o_loc = carve(sizeof(double) * (size_t)n_frames * NA);
-    const size_t o_match = carve(sizeof(int) * NA * (size_t)npair), o_err = carve(sizeof(int)), o_out = carve(sizeof(double) * 7 * NA);
     unsigned char *d = nullptr;
     TLK_HIP(hipMalloc((void **)&d, off));
-    hipError_t e = hipMemset(d + o_posg, 0xff, sizeof(int) * (size_t)n_frames * n_gt);
-    if (e == hipSuccess) e = hipMemset(d + o_post, 0xff, sizeof(int) * (size_t)n_frames * n_tr);
-    if (e == hipSuccess) e = hipMemset(d + o_gcnt, 0, sizeof(int) * n_gt);
-    if (e == hipSuccess) e = hipMemset(d + o_tcnt, 0, sizeof(int) * n_tr);
-    if (e == hipSuccess) e = hipMemset(d + o_cnt3, 0, sizeof(unsigned long long) * 3 * NA);
-    if (e == hipSuccess) e = hipMemset(d + o_match, 0, sizeof(int) * NA * (size_t)npair);
-    if (e == hipSuccess) e = hipMemset(d + o_err, 0, sizeof(int));
-    if (e == hipSuccess) e = hipMemcpy(d + o_gid, gt_ids, sizeof(int) * ng, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpy(d + o_gid, gt_ids, sizeof(int) * ng, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d + o_tid, tr_ids, sizeof(int) * nt, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d + o_gb, gt_ltrb, sizeof(double) * 4 * ng, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d + o_tb, tr_ltrb, sizeof(double) * 4 * nt, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d + o_goff, gt_off, sizeof(long long) * (n_frames + 1), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d + o_toff, tr_off, sizeof(long long) * (n_frames + 1), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d + o_moff, moff.data(), sizeof(long long) * (n_frames + 1), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d + o_cnt3 + sizeof(unsigned long long) * 3 * NA, alphas19, sizeof(double) * NA, hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(d); return fail(TLK_EHIP, std::string("tlk_hota_sequence_f64: ") + hipGetErrorString(e)); }
-    HotaIn in{(const int *)(d + o_gid), (const int *)(d + o_tid), (const double *)(d + o_gb), (const double *)(d + o_tb), (const long long *)(d + o_goff),
-              (const long long *)(d + o_toff), (const long long *)(d + o_moff), n_frames, n_gt, n_tr};
-    hipLaunchKernelGGL(hota_sim_kernel, dim3(n_frames), dim3(BLOCK), 0, 0, in, (double *)(d + o_sim), (double *)(d + o_rs), (double *)(d + o_cs), (int *)(d + o_posg),
-                       (int *)(d + o_post), (int *)(d + o_gcnt), (int *)(d + o_tcnt));
-    hipLaunchKernelGGL(hota_potential_kernel, dim3((unsigned)((npair + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, 0, in, (const double *)(d + o_sim), (const double *)(d + o_rs),
-                       (const double *)(d + o_cs), (const int *)(d + o_posg), (const int *)(d + o_post), (const int *)(d + o_gcnt), (const int *)(d + o_tcnt), (double *)(d + o_gas));
-    hipLaunchKernelGGL(hota_match_kernel, dim3((n_frames + NWAVES - 1) / NWAVES), dim3(BLOCK), NWAVES * 512 * (sizeof(double) + sizeof(int)), 0, in, (const double *)(d + o_sim),
-                       (const double *)(d + o_gas), (double *)(d + o_score), (int *)(d + o_mr), (int *)(d + o_mc), (unsigned long long *)(d + o_cnt3), (double *)(d + o_loc),
-                       (int *)(d + o_match), (int *)(d + o_err));
-    hipLaunchKernelGGL(hota_final_kernel, dim3(NA), dim3(BLOCK), 0, 0, in, (const int *)(d + o_match), (const int *)(d + o_gcnt), (const int *)(d + o_tcnt),
-                       (const unsigned long long *)(d + o_cnt3), (const double *)(d + o_loc), (double *)(d + o_out));
-    e = hipGetLastError();
-    int err = 0;
-    if (e == hipSuccess) e = hipMemcpy(&err, d + o_err, sizeof(int), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(stats, d + o_out, sizeof(double) * 7 * NA, hipMemcpyDeviceToHost);
+    const int rc = hota_run((const int *)(d + o_gid), (const int *)(d + o_tid), (const double *)(d + o_gb), (const double *)(d + o_tb), (const long long *)(d + o_goff),
+                            (const long long *)(d + o_toff), (const long long *)(d + o_moff), n_frames, n_gt, n_tr, ng, nt, moff[n_frames], alphas19, stats, (hipStream_t)0,
+                            "tlk_hota_sequence_f64");
     hipFree(d);
-    if (e != hipSuccess) return fail(TLK_EHIP, std::string("tlk_hota_sequence_f64: ") + hipGetErrorString(e));
-    if (err) return fail(err, "tlk_hota_sequence_f64: a frame exceeds the solver's capacity");
-    return TLK_OK;
+    return rc;
+}
+
+// The same with every array already in device memory -- the tracker side straight from the engine's HBM-resident per-video table
+// (tracklab_amd.evaluate.evaluate_device_log), the ground truth uploaded once by the caller. n_gt_boxes / n_tr_boxes / n_match are host scalars
+// (totals; n_match >= sum over the frames of gt boxes x tracker boxes -- it sizes the similarity matrices).
+extern "C" int tlk_hota_sequence_dev_f64(const int32_t *gt_ids_dev, const double *gt_ltrb_dev, const int64_t *gt_off_dev, const int32_t *tr_ids_dev,
+                                         const double *tr_ltrb_dev, const int64_t *tr_off_dev, int n_frames, int n_gt, int n_tr, int64_t n_gt_boxes,
+                                         int64_t n_tr_boxes, int64_t n_match, const double *alphas19, double *stats, void *hip_stream)
+{
+    if (n_frames < 0 || n_gt < 0 || n_tr < 0 || n_gt_boxes < 0 || n_tr_boxes < 0 || n_match < 0 || !gt_off_dev || !tr_off_dev || !alphas19 || !stats)
+        return fail(TLK_EINVAL, "tlk_hota_sequence_dev_f64: bad argument");
+    for (int k = 0; k < 7 * NA; ++k) stats[k] = 0.0;
+    if (n_tr_boxes == 0) { for (int a = 0; a < NA; ++a) stats[NA + a] = (double)n_gt_boxes; return TLK_OK; }
+    if (n_gt_boxes == 0) { for (int a = 0; a < NA; ++a) stats[2 * NA + a] = (double)n_tr_boxes; return TLK_OK; }
+    if (!gt_ids_dev || !tr_ids_dev || !gt_ltrb_dev || !tr_ltrb_dev) return fail(TLK_EINVAL, "tlk_hota_sequence_dev_f64: null pointer");
+    return hota_run((const int *)gt_ids_dev, (const int *)tr_ids_dev, gt_ltrb_dev, tr_ltrb_dev, (const long long *)gt_off_dev, (const long long *)tr_off_dev, nullptr,
+                    n_frames, n_gt, n_tr, n_gt_boxes, n_tr_boxes, n_match, alphas19, stats, (hipStream_t)hip_stream, "tlk_hota_sequence_dev_f64");
 }
 
 // CLEAR-MOT + ID counts of one sequence. HOST buffers as tlk_hota_sequence_f64, except: ids dense 0..n-1 in the SORTED order of the original
 // ids (np.unique's inverse: the global ID assignment orders its matrix by id), boxes (x, y, w, h). counts19: the SUM_FIELDS of
 // tracklab_amd/clearmot.py in that order (what its pack() all-reduces); clearmot.finalize() derives MOTA / MOTP / IDF1 ... from them.
+// the accumulator kernel on arrays that are ALL in device memory
+static int clear_run(const int *gid, const int *tid, const double *gb, const double *tb, const long long *goff, const long long *toff, int n_frames, int n_gt, int n_tr,
+                     double max_iou, double *counts19, hipStream_t st, const char *who)
+{
+    const size_t n = (size_t)n_gt + n_tr, nn = n * n > 512 * 512 ? n * n : 512 * 512, ngt = n_gt ? n_gt : 1, ntr = n_tr ? n_tr : 1;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_D = carve(sizeof(double) * nn), o_C = carve(sizeof(double) * nn), o_fp = carve(sizeof(double) * (n * n + 1)), o_fn = carve(sizeof(double) * (n * n + 1));
+    const size_t o_g = carve(sizeof(int) * 8 * ngt), o_t = carve(sizeof(int) * 3 * ntr), o_tps = carve(sizeof(int) * ngt * ntr);
+    const size_t o_om = carve(512), o_hm = carve(512), o_mr = carve(sizeof(int) * (n + 512)), o_mc = carve(sizeof(int) * (n + 512));
+    const size_t o_idr = carve(sizeof(int) * (n + 1)), o_idc = carve(sizeof(int) * (n + 1));
+    const size_t o_wu = carve(sizeof(double) * 3 * (n + 1)), o_wi = carve(sizeof(int) * 4 * (n + 1)), o_wb = carve(2 * (n + 1));
+    const size_t o_out = carve(sizeof(double) * C_N), o_err = carve(sizeof(int));
+    unsigned char *d = nullptr;
+    TLK_HIP(hipMalloc((void **)&d, off));
+    hipError_t e = hipMemsetAsync(d + o_err, 0, sizeof(int), st);
+    if (e != hipSuccess) { hipFree(d); return fail(TLK_EHIP, std::string(who) + ": " + hipGetErrorString(e)); }
+    ClearDev A;
+    A.gid = gid; A.tid = tid; A.gbox = gb; A.tbox = tb; A.goff = goff; A.toff = toff;
+    A.T = n_frames; A.n_gt = n_gt; A.n_tr = n_tr; A.max_iou = max_iou;
+    A.D = (double *)(d + o_D); A.Cm = (double *)(d + o_C); A.fpm = (double *)(d + o_fp); A.fnm = (double *)(d + o_fn); A.idc = (double *)(d + o_C);
+    int *gi = (int *)(d + o_g), *ti = (int *)(d + o_t);
+    A.m = gi; A.last_occ = gi + ngt; A.last_match = gi + 2 * ngt; A.ocs = gi + 3 * ngt; A.hits = gi + 4 * ngt; A.prev_ev = gi + 5 * ngt; A.pend = gi + 6 * ngt; A.frag = gi + 7 * ngt;
+    A.res_m = ti; A.hyp_hist = ti + ntr; A.hcs = ti + 2 * ntr;
+    A.tps = (int *)(d + o_tps); A.om = d + o_om; A.hm = d + o_hm; A.mrows = (int *)(d + o_mr); A.mcols = (int *)(d + o_mc);
+    A.idr = (int *)(d + o_idr); A.idcol = (int *)(d + o_idc);
+    double *wu = (double *)(d + o_wu); int *wi = (int *)(d + o_wi);
+    A.idw.u = wu; A.idw.v = wu + (n + 1); A.idw.spc = wu + 2 * (n + 1);
+    A.idw.path = wi; A.idw.row4col = wi + (n + 1); A.idw.remaining = wi + 2 * (n + 1); A.idw.col4row = wi + 3 * (n + 1);
+    A.idw.SR = d + o_wb; A.idw.SC = d + o_wb + (n + 1);
+    A.out = (double *)(d + o_out); A.err = (int *)(d + o_err);
+    hipLaunchKernelGGL(clear_seq_kernel, dim3(1), dim3(BLOCK), 0, st, A);
+    e = hipGetLastError();
+    int err = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&err, d + o_err, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(counts19, d + o_out, sizeof(double) * C_N, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d);
+    if (e != hipSuccess) return fail(TLK_EHIP, std::string(who) + ": " + hipGetErrorString(e));
+    if (err) return fail(err, std::string(who) + ": a frame exceeds the solver's capacity (512 boxes per frame and side)");
+    return TLK_OK;
+}
+
 extern "C" int tlk_clear_sequence_f64(const int32_t *gt_ids, const double *gt_ltwh, const int64_t *gt_off, const int32_t *tr_ids, const double *tr_ltwh,
                                       const int64_t *tr_off, int n_frames, int n_gt, int n_tr, double max_iou, double *counts19)
 {
@@ -490,49 +585,33 @@ extern "C" int tlk_clear_sequence_f64(const int32_t *gt_ids, const double *gt_lt
         if (g < 0 || t < 0) return fail(TLK_EINVAL, "tlk_clear_sequence_f64: offsets must ascend");
         if (g > 512 || t > 512) return fail(TLK_ECAPACITY, "tlk_clear_sequence_f64: at most 512 boxes per frame and side");
     }
-    const size_t n = (size_t)n_gt + n_tr, nn = n * n > 512 * 512 ? n * n : 512 * 512, ngt = n_gt ? n_gt : 1, ntr = n_tr ? n_tr : 1;
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     const size_t o_gid = carve(sizeof(int) * (ng + 1)), o_tid = carve(sizeof(int) * (nt + 1)), o_gb = carve(sizeof(double) * 4 * (ng + 1)), o_tb = carve(sizeof(double) * 4 * (nt + 1));
     const size_t o_goff = carve(sizeof(long long) * (n_frames + 1)), o_toff = carve(sizeof(long long) * (n_frames + 1));
-    const size_t o_D = carve(sizeof(double) * nn), o_C = carve(sizeof(double) * nn), o_fp = carve(sizeof(double) * (n * n + 1)), o_fn = carve(sizeof(double) * (n * n + 1));
-    const size_t o_g = carve(sizeof(int) * 8 * ngt), o_t = carve(sizeof(int) * 3 * ntr), o_tps = carve(sizeof(int) * ngt * ntr);
-    const size_t o_om = carve(512), o_hm = carve(512), o_mr = carve(sizeof(int) * (n + 512)), o_mc = carve(sizeof(int) * (n + 512));
-    const size_t o_idr = carve(sizeof(int) * (n + 1)), o_idc = carve(sizeof(int) * (n + 1));
-    const size_t o_wu = carve(sizeof(double) * 3 * (n + 1)), o_wi = carve(sizeof(int) * 4 * (n + 1)), o_wb = carve(2 * (n + 1));
-    const size_t o_out = carve(sizeof(double) * C_N), o_err = carve(sizeof(int));
     unsigned char *d = nullptr;
     TLK_HIP(hipMalloc((void **)&d, off));
-    hipError_t e = hipMemset(d + o_err, 0, sizeof(int));
-    if (e == hipSuccess && ng) e = hipMemcpy(d + o_gid, gt_ids, sizeof(int) * ng, hipMemcpyHostToDevice);
+    hipError_t e = hipSuccess;
+    if (ng) e = hipMemcpy(d + o_gid, gt_ids, sizeof(int) * ng, hipMemcpyHostToDevice);
     if (e == hipSuccess && nt) e = hipMemcpy(d + o_tid, tr_ids, sizeof(int) * nt, hipMemcpyHostToDevice);
     if (e == hipSuccess && ng) e = hipMemcpy(d + o_gb, gt_ltwh, sizeof(double) * 4 * ng, hipMemcpyHostToDevice);
     if (e == hipSuccess && nt) e = hipMemcpy(d + o_tb, tr_ltwh, sizeof(double) * 4 * nt, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d + o_goff, gt_off, sizeof(long long) * (n_frames + 1), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d + o_toff, tr_off, sizeof(long long) * (n_frames + 1), hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(d); return fail(TLK_EHIP, std::string("tlk_clear_sequence_f64: ") + hipGetErrorString(e)); }
-    ClearDev A;
-    A.gid = (const int *)(d + o_gid); A.tid = (const int *)(d + o_tid); A.gbox = (const double *)(d + o_gb); A.tbox = (const double *)(d + o_tb);
-    A.goff = (const long long *)(d + o_goff); A.toff = (const long long *)(d + o_toff);
-    A.T = n_frames; A.n_gt = n_gt; A.n_tr = n_tr; A.max_iou = max_iou;
-    A.D = (double *)(d + o_D); A.Cm = (double *)(d + o_C); A.fpm = (double *)(d + o_fp); A.fnm = (double *)(d + o_fn); A.idc = (double *)(d + o_C);
-    int *gi = (int *)(d + o_g), *ti = (int *)(d + o_t);
-    A.m = gi; A.last_occ = gi + ngt; A.last_match = gi + 2 * ngt; A.ocs = gi + 3 * ngt; A.hits = gi + 4 * ngt; A.prev_ev = gi + 5 * ngt; A.pend = gi + 6 * ngt; A.frag = gi + 7 * ngt;
-    A.res_m = ti; A.hyp_hist = ti + ntr; A.hcs = ti + 2 * ntr;
-    A.tps = (int *)(d + o_tps); A.om = d + o_om; A.hm = d + o_hm; A.mrows = (int *)(d + o_mr); A.mcols = (int *)(d + o_mc);
-    A.idr = (int *)(d + o_idr); A.idcol = (int *)(d + o_idc);
-    double *wu = (double *)(d + o_wu); int *wi = (int *)(d + o_wi);
-    A.idw.u = wu; A.idw.v = wu + (n + 1); A.idw.spc = wu + 2 * (n + 1);
-    A.idw.path = wi; A.idw.row4col = wi + (n + 1); A.idw.remaining = wi + 2 * (n + 1); A.idw.col4row = wi + 3 * (n + 1);
-    A.idw.SR = d + o_wb; A.idw.SC = d + o_wb + (n + 1);
-    A.out = (double *)(d + o_out); A.err = (int *)(d + o_err);
-    hipLaunchKernelGGL(clear_seq_kernel, dim3(1), dim3(BLOCK), 0, 0, A);
-    e = hipGetLastError();
-    int err = 0;
-    if (e == hipSuccess) e = hipMemcpy(&err, d + o_err, sizeof(int), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(counts19, d + o_out, sizeof(double) * C_N, hipMemcpyDeviceToHost);
+    const int rc = clear_run((const int *)(d + o_gid), (const int *)(d + o_tid), (const double *)(d + o_gb), (const double *)(d + o_tb), (const long long *)(d + o_goff),
+                             (const long long *)(d + o_toff), n_frames, n_gt, n_tr, max_iou, counts19, (hipStream_t)0, "tlk_clear_sequence_f64");
     hipFree(d);
-    if (e != hipSuccess) return fail(TLK_EHIP, std::string("tlk_clear_sequence_f64: ") + hipGetErrorString(e));
-    if (err) return fail(err, "tlk_clear_sequence_f64: a frame exceeds the solver's capacity");
-    return TLK_OK;
+    return rc;
+}
+
+// The same with every array already in device memory (see tlk_hota_sequence_dev_f64). Offsets must ascend; ids dense in the sorted order of the originals.
+extern "C" int tlk_clear_sequence_dev_f64(const int32_t *gt_ids_dev, const double *gt_ltwh_dev, const int64_t *gt_off_dev, const int32_t *tr_ids_dev,
+                                          const double *tr_ltwh_dev, const int64_t *tr_off_dev, int n_frames, int n_gt, int n_tr, double max_iou, double *counts19,
+                                          void *hip_stream)
+{
+    if (n_frames < 0 || n_gt < 0 || n_tr < 0 || !gt_off_dev || !tr_off_dev || !counts19 || !gt_ids_dev || !tr_ids_dev || !gt_ltwh_dev || !tr_ltwh_dev)
+        return fail(TLK_EINVAL, "tlk_clear_sequence_dev_f64: bad argument");
+    return clear_run((const int *)gt_ids_dev, (const int *)tr_ids_dev, gt_ltwh_dev, tr_ltwh_dev, (const long long *)gt_off_dev, (const long long *)tr_off_dev, n_frames, n_gt,
+                     n_tr, max_iou, counts19, (hipStream_t)hip_stream, "tlk_clear_sequence_dev_f64");
 }

@@ -180,7 +180,7 @@ class HipVideoEngine:
             yield buf[:n], True
 
     @torch.no_grad()
-    def video_loop(self, frames, video_id=0, synth_heads=None, online=False, on_step=None, keep_ids=False) -> pd.DataFrame:
+    def video_loop(self, frames, video_id=0, synth_heads=None, online=False, on_step=None, keep_ids=False, fetch_table=True) -> pd.DataFrame:
         """frames: (T, H, W, 3) uint8 RGB array, an iterable of (H, W, 3) frames, or an iterable of pinned (n <= F, H, W, 3) uint8
         tensors (uploaded without a staging copy). RGB like TrackLab's cv2_load_image (channel contract: gpu_pipeline docstring).
         synth_heads: optional callable(first_frame, n) -> (n, A, 6) float32 detector-head activations (numpy, or a cuda tensor of
@@ -233,8 +233,11 @@ class HipVideoEngine:
             pending = step
         if pending is not None:
             self._drain(table, pending, video_id, on_step)
+        self.last_log = log                     # the video's table where it was written: HBM (tracklab_amd.evaluate.evaluate_device_log reads it there)
         if log is not None:
             pipe.synchronize()                  # the appends ran on the association stream: they must be complete before the ONE fetch
+            if not fetch_table:
+                return None
             for first, n, idb, res in log.fetch():
                 table.append_step(first, n, idb, maxd, res["ltwh"], res["dcnt"], self._trk_columns(res))
         return table.to_dataframe(video_id)

@@ -58,6 +58,104 @@ def evaluate_sequence(gt: dict, pred: dict, n_frames: int | None = None, max_iou
     return {"hota": hota.pack(hota.hota_sequence(*hota.sequence_from_rows(gt_fr, pr_fr)), frames=float(last)), "clear": acc.counts()}
 
 
+def _device_field(rows_u8, row_dtype, name):
+    """Field `name` of a (frames, cap, row bytes) uint8 device block laid out like numpy structured dtype `row_dtype` -> float64 tensor
+    (frames, cap[, k]); a strided byte view turned contiguous on the device, no host copy."""
+    import torch
+    dt, off = row_dtype.fields[name][:2]
+    base, shape = (dt.subdtype[0], dt.subdtype[1]) if dt.subdtype else (dt, ())
+    n = int(np.prod(shape)) if shape else 1
+    tdt = {np.dtype("float64"): torch.float64, np.dtype("float32"): torch.float32, np.dtype("int64"): torch.int64, np.dtype("int32"): torch.int32}[np.dtype(base)]
+    v = rows_u8[..., off:off + n * base.itemsize].contiguous().view(tdt).to(torch.float64)
+    return v if n > 1 else v[..., 0]
+
+
+def device_log_tracks(log, pipe):
+    """The tracker side of an HBM-resident per-video table (engine.DeviceStepLog) in the evaluators' layout, built ON THE DEVICE: frames in
+    order, a frame's tracked rows (track_id not NaN) in table order; ids dense 0..n-1 in the sorted order of the track ids (what np.unique's
+    inverse gives the host path); boxes as ltwh and ltrb float64; int64 frame offsets. The only host traffic is ONE fetch of three scalars
+    (rows, distinct ids, frames) -- never the table. -> dict of device tensors + those scalars."""
+    import torch
+    steps = [(log.chunks[k // log.chunk], k % log.chunk, n) for k, (_, n, _) in enumerate(log.meta)]
+    rows = torch.cat([ch["rows"][si][:n] for ch, si, n in steps])                      # (frames, cap, 8 doubles | row bytes)
+    ocnt = torch.cat([ch["ocnt"][si][:n] for ch, si, n in steps]).to(torch.int64)
+    T, cap = rows.shape[0], rows.shape[1]
+    rd = pipe.row_dtype
+    if rd is None:                                                                     # OC-SORT rows: 8 doubles [x1, y1, x2, y2, track_id, cls, conf, det]
+        tid, ltrb = rows[..., 4], rows[..., :4]
+    else:
+        u8 = rows.view(torch.uint8).reshape(T, cap, -1)
+        tid = _device_field(u8, rd, "track_id")
+        if "kf_ltwh" in rd.names:                                                      # BPBReID-StrongSORT: the Kalman box, ltwh
+            b = _device_field(u8, rd, "kf_ltwh")
+            ltrb = torch.stack([b[..., 0], b[..., 1], b[..., 0] + b[..., 2], b[..., 1] + b[..., 3]], dim=-1)
+        else:
+            ltrb = _device_field(u8, rd, "ltrb")
+    valid = (torch.arange(cap, device=rows.device)[None, :] < ocnt[:, None]) & ~torch.isnan(tid)
+    cnt = valid.sum(dim=1)
+    off = torch.zeros(T + 1, dtype=torch.int64, device=rows.device)
+    torch.cumsum(cnt, 0, out=off[1:])
+    # stable compaction without a data-dependent shape: destination = rank among the valid rows, invalid rows go to a dump slot
+    flat = valid.reshape(-1)
+    dest = torch.where(flat, torch.cumsum(flat, 0) - 1, torch.full_like(flat, T * cap, dtype=torch.int64))
+    ids_raw = torch.zeros(T * cap + 1, dtype=torch.int64, device=rows.device).scatter_(0, dest, torch.nan_to_num(tid).reshape(-1).to(torch.int64))
+    box = torch.zeros((T * cap + 1, 4), dtype=torch.float64, device=rows.device).index_copy_(0, dest, ltrb.reshape(-1, 4).contiguous())
+    # dense ids in sorted order: presence flags over [0, id bound) -> exclusive scan (track ids are small positive integers: < frames * cap + 2)
+    bound = T * cap + 2
+    present = torch.zeros(bound, dtype=torch.int64, device=rows.device)
+    present.scatter_(0, torch.where(flat, torch.nan_to_num(tid).reshape(-1).to(torch.int64).clamp_(0, bound - 1), torch.zeros_like(dest)), flat.to(torch.int64))
+    # (slot 0 only ever collects the invalid rows' zeros: every bank numbers its tracks from 1)
+    rank = torch.cumsum(present.clamp_(max=1), 0) - 1
+    dense = rank[ids_raw.clamp(0, bound - 1)].to(torch.int32)
+    nt, n_ids = (int(v) for v in torch.stack([off[-1], present.sum()]).tolist())       # the ONE host fetch (two scalars)
+    ltwh = torch.stack([box[:, 0], box[:, 1], box[:, 2] - box[:, 0], box[:, 3] - box[:, 1]], dim=-1)
+    return {"ids": dense[:max(nt, 1)].contiguous(), "ltrb": box[:max(nt, 1)].contiguous(), "ltwh": ltwh[:max(nt, 1)].contiguous(), "off": off, "count": cnt,
+            "n_boxes": nt, "n_ids": n_ids, "n_frames": T, "cap": cap}
+
+
+def evaluate_device_log(gt: dict, log, pipe, max_iou: float = 0.5) -> dict:
+    """evaluate_sequence(gt, <the table>, device="gpu") WITHOUT fetching the table: the tracker side is read where HipVideoEngine left it (the
+    HBM-resident DeviceStepLog of the video), re-arranged on the device (device_log_tracks) and handed to
+    tlk_hota_sequence_dev_f64 / tlk_clear_sequence_dev_f64; only the ground truth (an input that lives on the host) is uploaded and only the
+    two result vectors come back. Frames are the table's frames 0..T-1 = MOT frames 1..T. Same dict as evaluate_sequence."""
+    import ctypes as C
+
+    import torch
+    from . import _lib
+    tr = device_log_tracks(log, pipe)
+    T, dev = tr["n_frames"], tr["off"].device
+    g = _by_frame(gt)
+    empty = (np.zeros(0, np.int64), np.zeros((0, 4)))
+    gi, gb, goff = [], [], [0]
+    for f in range(1, T + 1):
+        i, b = g.get(f, empty)
+        gi.append(np.asarray(i, dtype=np.int64)); gb.append(np.asarray(b, dtype=np.float64).reshape(-1, 4)); goff.append(goff[-1] + len(i))
+    gi = np.concatenate(gi) if gi else np.zeros(0, np.int64)
+    gb = np.concatenate(gb) if gb else np.zeros((0, 4))
+    gu, gd = np.unique(gi, return_inverse=True) if len(gi) else (np.zeros(0, np.int64), np.zeros(0, np.int64))
+    ng = int(goff[-1])
+    d_gid = torch.from_numpy(np.ascontiguousarray(gd, dtype=np.int32) if ng else np.zeros(1, np.int32)).to(dev)
+    d_gwh = torch.from_numpy(np.ascontiguousarray(gb) if ng else np.zeros((1, 4))).to(dev)
+    d_gbr = torch.stack([d_gwh[:, 0], d_gwh[:, 1], d_gwh[:, 0] + d_gwh[:, 2], d_gwh[:, 1] + d_gwh[:, 3]], dim=-1).contiguous()
+    d_goff = torch.from_numpy(np.asarray(goff, dtype=np.int64)).to(dev)
+    n_match = int((np.diff(goff) * tr["cap"]).sum())                                  # upper bound known on the host: gt boxes x table capacity per frame
+    L = _lib.lib()
+    vp, ci, i64 = C.c_void_p, C.c_int, C.c_int64
+    L.tlk_hota_sequence_dev_f64.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, i64, i64, i64, vp, vp, vp]
+    L.tlk_clear_sequence_dev_f64.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, C.c_double, vp, vp]
+    stats = np.zeros((7, len(hota.ALPHAS)))
+    alphas = np.ascontiguousarray(hota.ALPHAS, dtype=np.float64)
+    sp = _lib.current_stream_ptr()
+    _lib.check(L.tlk_hota_sequence_dev_f64(d_gid.data_ptr(), d_gbr.data_ptr(), d_goff.data_ptr(), tr["ids"].data_ptr(), tr["ltrb"].data_ptr(), tr["off"].data_ptr(),
+                                           T, len(gu), tr["n_ids"], ng, tr["n_boxes"], n_match, alphas.ctypes.data, stats.ctypes.data, sp))
+    res = {k: stats[i].copy() for i, k in enumerate(("HOTA_TP", "HOTA_FN", "HOTA_FP", "LocA_sum", "AssA", "AssRe", "AssPr"))}
+    counts = np.zeros(len(clearmot.SUM_FIELDS))
+    _lib.check(L.tlk_clear_sequence_dev_f64(d_gid.data_ptr(), d_gwh.data_ptr(), d_goff.data_ptr(), tr["ids"].data_ptr(), tr["ltwh"].data_ptr(), tr["off"].data_ptr(),
+                                            T, len(gu), tr["n_ids"], float(max_iou), counts.ctypes.data, sp))
+    c = {k: (float(v) if k in ("sum_distance", "idtp", "idfp", "idfn") else int(v)) for k, v in zip(clearmot.SUM_FIELDS, counts)}
+    return {"hota": hota.pack(res, frames=float(T)), "clear": c}
+
+
 def combine(per_sequence: dict) -> dict:
     """{name: evaluate_sequence(...)} -> {'sequences': {name: metrics}, 'combined': metrics} (float summaries only)."""
     def metrics(h, c):
