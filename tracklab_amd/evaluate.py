@@ -107,7 +107,9 @@ def device_log_tracks(log, pipe):
     # (slot 0 only ever collects the invalid rows' zeros: every bank numbers its tracks from 1)
     rank = torch.cumsum(present.clamp_(max=1), 0) - 1
     dense = rank[ids_raw.clamp(0, bound - 1)].to(torch.int32)
-    nt, n_ids = (int(v) for v in torch.stack([off[-1], present.sum()]).tolist())       # the ONE host fetch (two scalars)
+    nt, n_ids, worst = (int(v) for v in torch.stack([off[-1], present.sum(), ocnt.min() if T else off[-1]]).tolist())      # the ONE host fetch (three scalars)
+    if worst < 0:
+        raise RuntimeError("evaluate_device_log: a step of this video overflowed the tracker's capacity (negative row count in the table)")
     ltwh = torch.stack([box[:, 0], box[:, 1], box[:, 2] - box[:, 0], box[:, 3] - box[:, 1]], dim=-1)
     return {"ids": dense[:max(nt, 1)].contiguous(), "ltrb": box[:max(nt, 1)].contiguous(), "ltwh": ltwh[:max(nt, 1)].contiguous(), "off": off, "count": cnt,
             "n_boxes": nt, "n_ids": n_ids, "n_frames": T, "cap": cap}
