@@ -71,40 +71,64 @@ def _device_field(rows_u8, row_dtype, name):
 
 
 def device_log_tracks(log, pipe):
-    """The tracker side of an HBM-resident per-video table (engine.DeviceStepLog) in the evaluators' layout, built ON THE DEVICE: frames in
-    order, a frame's tracked rows (track_id not NaN) in table order; ids dense 0..n-1 in the sorted order of the track ids (what np.unique's
-    inverse gives the host path); boxes as ltwh and ltrb float64; int64 frame offsets. The only host traffic is ONE fetch of three scalars
-    (rows, distinct ids, frames) -- never the table. -> dict of device tensors + those scalars."""
+    """The tracker side of an HBM-resident per-video table (engine.DeviceStepLog) in the evaluators' layout, built ON THE DEVICE with the
+    semantics of engine.DetectionTable.append_step (= the reference's merge of a module's rows into the detections by index): a tracker row
+    belongs to the DETECTION its det_id names -- (det_id - id_base of the step) // max_dets is the frame inside the step, % max_dets the slot;
+    rows that name a detection outside the step or beyond the frame's count are dropped; when several rows name one detection (a coasting
+    plain-StrongSORT track reports its previous detection's id) the LAST one in table order wins, like a fancy-index assignment. Output:
+    frames in order, a frame's tracked detections in slot order; ids dense 0..n-1 in the sorted order of the track ids (np.unique's inverse);
+    boxes as ltwh and ltrb float64; int64 frame offsets. The only host traffic is ONE fetch of three scalars (rows, distinct ids, smallest
+    row count) -- never the table. -> dict of device tensors + those scalars."""
     import torch
     steps = [(log.chunks[k // log.chunk], k % log.chunk, n) for k, (_, n, _) in enumerate(log.meta)]
     rows = torch.cat([ch["rows"][si][:n] for ch, si, n in steps])                      # (frames, cap, 8 doubles | row bytes)
     ocnt = torch.cat([ch["ocnt"][si][:n] for ch, si, n in steps]).to(torch.int64)
-    T, cap = rows.shape[0], rows.shape[1]
+    dcnt = torch.cat([ch["dcnt"][si][:n] for ch, si, n in steps]).to(torch.int64) if "dcnt" in steps[0][0] else None
+    dev = rows.device
+    T, cap, maxd = rows.shape[0], rows.shape[1], int(pipe.maxd)
+    # per frame (host-known step geometry): first frame of its step, frames in its step, id_base of its step
+    first = torch.tensor(np.concatenate([np.full(n, f0, np.int64) for f0, n, _ in log.meta]), device=dev)
+    nstep = torch.tensor(np.concatenate([np.full(n, n, np.int64) for _, n, _ in log.meta]), device=dev)
+    idb = torch.tensor(np.concatenate([np.full(n, ib, np.int64) for _, n, ib in log.meta]), device=dev)
+    first = first - int(log.meta[0][0])                                                # frame index inside this table
     rd = pipe.row_dtype
     if rd is None:                                                                     # OC-SORT rows: 8 doubles [x1, y1, x2, y2, track_id, cls, conf, det]
-        tid, ltrb = rows[..., 4], rows[..., :4]
+        tid, ltrb, det = rows[..., 4], rows[..., :4], rows[..., 7]
     else:
         u8 = rows.view(torch.uint8).reshape(T, cap, -1)
-        tid = _device_field(u8, rd, "track_id")
+        tid, det = _device_field(u8, rd, "track_id"), _device_field(u8, rd, "det_id")
         if "kf_ltwh" in rd.names:                                                      # BPBReID-StrongSORT: the Kalman box, ltwh
             b = _device_field(u8, rd, "kf_ltwh")
             ltrb = torch.stack([b[..., 0], b[..., 1], b[..., 0] + b[..., 2], b[..., 1] + b[..., 3]], dim=-1)
         else:
             ltrb = _device_field(u8, rd, "ltrb")
-    valid = (torch.arange(cap, device=rows.device)[None, :] < ocnt[:, None]) & ~torch.isnan(tid)
-    cnt = valid.sum(dim=1)
-    off = torch.zeros(T + 1, dtype=torch.int64, device=rows.device)
+    slot_ok = (torch.arange(cap, device=dev)[None, :] < ocnt[:, None]) & ~torch.isnan(tid)
+    rel = torch.nan_to_num(det).to(torch.int64) - idb[:, None]
+    rf, ri = torch.div(rel, maxd, rounding_mode="floor"), torch.remainder(rel, maxd)
+    tgt_frame = first[:, None] + rf
+    ok = slot_ok & (rel >= 0) & (rf < nstep[:, None])
+    if dcnt is not None:
+        ok = ok & (ri < dcnt[tgt_frame.clamp(0, T - 1)])
+    # one winner per detection: the last row (table order) that names it -- scatter-max of the row index, deterministic
+    key = torch.where(ok, tgt_frame * maxd + ri, torch.full_like(rel, T * maxd)).reshape(-1)
+    src = torch.arange(T * cap, device=dev, dtype=torch.int64)
+    winner = torch.full((T * maxd + 1,), -1, dtype=torch.int64, device=dev).scatter_reduce_(0, key, src, reduce="amax", include_self=True)[:T * maxd]
+    has = winner >= 0                                                                  # (frames * maxd,) in frame-major, slot-minor order
+    cnt = has.reshape(T, maxd).sum(dim=1)
+    off = torch.zeros(T + 1, dtype=torch.int64, device=dev)
     torch.cumsum(cnt, 0, out=off[1:])
-    # stable compaction without a data-dependent shape: destination = rank among the valid rows, invalid rows go to a dump slot
-    flat = valid.reshape(-1)
-    dest = torch.where(flat, torch.cumsum(flat, 0) - 1, torch.full_like(flat, T * cap, dtype=torch.int64))
-    ids_raw = torch.zeros(T * cap + 1, dtype=torch.int64, device=rows.device).scatter_(0, dest, torch.nan_to_num(tid).reshape(-1).to(torch.int64))
-    box = torch.zeros((T * cap + 1, 4), dtype=torch.float64, device=rows.device).index_copy_(0, dest, ltrb.reshape(-1, 4).contiguous())
-    # dense ids in sorted order: presence flags over [0, id bound) -> exclusive scan (track ids are small positive integers: < frames * cap + 2)
-    bound = T * cap + 2
-    present = torch.zeros(bound, dtype=torch.int64, device=rows.device)
-    present.scatter_(0, torch.where(flat, torch.nan_to_num(tid).reshape(-1).to(torch.int64).clamp_(0, bound - 1), torch.zeros_like(dest)), flat.to(torch.int64))
-    # (slot 0 only ever collects the invalid rows' zeros: every bank numbers its tracks from 1)
+    w = winner.clamp(min=0)
+    ids_all = torch.nan_to_num(tid).reshape(-1).to(torch.int64)[w]
+    box_all = ltrb.reshape(-1, 4)[w]
+    # stable compaction without a data-dependent shape: destination = rank among the tracked detections, the others go to a dump slot
+    dest = torch.where(has, torch.cumsum(has, 0) - 1, torch.full_like(w, T * maxd))
+    ids_raw = torch.zeros(T * maxd + 1, dtype=torch.int64, device=dev).scatter_(0, dest, ids_all)
+    box = torch.zeros((T * maxd + 1, 4), dtype=torch.float64, device=dev).index_copy_(0, dest, box_all.contiguous())
+    # dense ids in sorted order: presence flags over [0, id bound) -> scan (track ids are small positive integers: every bank numbers from 1,
+    # so slot 0 only ever collects the untracked slots' zeros)
+    bound = T * max(cap, maxd) + 2
+    present = torch.zeros(bound, dtype=torch.int64, device=dev)
+    present.scatter_(0, torch.where(has, ids_all.clamp(0, bound - 1), torch.zeros_like(w)), has.to(torch.int64))
     rank = torch.cumsum(present.clamp_(max=1), 0) - 1
     dense = rank[ids_raw.clamp(0, bound - 1)].to(torch.int32)
     nt, n_ids, worst = (int(v) for v in torch.stack([off[-1], present.sum(), ocnt.min() if T else off[-1]]).tolist())      # the ONE host fetch (three scalars)
@@ -112,7 +136,7 @@ def device_log_tracks(log, pipe):
         raise RuntimeError("evaluate_device_log: a step of this video overflowed the tracker's capacity (negative row count in the table)")
     ltwh = torch.stack([box[:, 0], box[:, 1], box[:, 2] - box[:, 0], box[:, 3] - box[:, 1]], dim=-1)
     return {"ids": dense[:max(nt, 1)].contiguous(), "ltrb": box[:max(nt, 1)].contiguous(), "ltwh": ltwh[:max(nt, 1)].contiguous(), "off": off, "count": cnt,
-            "n_boxes": nt, "n_ids": n_ids, "n_frames": T, "cap": cap}
+            "n_boxes": nt, "n_ids": n_ids, "n_frames": T, "cap": maxd}
 
 
 def evaluate_device_log(gt: dict, log, pipe, max_iou: float = 0.5) -> dict:

@@ -265,6 +265,9 @@ class _ReidTrackerBase:
         return self._bank.update(inputs, feats, 0)
 
     def process(self, batch, detections: pd.DataFrame, metadatas: pd.DataFrame):
+        # the uploaded frame is shared by the stages of THIS call only: a host buffer's address says nothing about its content in the next call
+        # (an allocator hands the address of the previous frame's freed buffer to the next frame -- a stale hit fed the estimator the old frame)
+        self._dev_frame = None
         if len(detections) == 0:
             self._camera_step(None, metadatas)               # the reference compensates before its empty-frame return too
             return []
@@ -460,6 +463,7 @@ class HipDeepOCSORT(ImageLevelModule, _ReidTrackerBase):
         return feats
 
     def process(self, batch, detections: pd.DataFrame, metadatas: pd.DataFrame):
+        self._dev_frame = None                               # (the uploaded frame is shared within one call only: _ReidTrackerBase.process)
         if len(detections) == 0:
             return []
         inputs = to_numpy(batch["input"])
