@@ -217,9 +217,37 @@ def test_swap_rb_reads_the_frame_as_bgr(layout):
         assert torch.equal(pa, pb) and torch.equal(ma, mb)
 
 
-@pytest.mark.parametrize("env", [{"TLK_CROP_WAVE": "4"}, {"TLK_CROP_WAVE": "2"}, {"TLK_CROP_WAVE": "1"}, {"TLK_CROP_WAVE": "0"}, {"TLK_CROP_WAVE": "0", "TLK_CROP_FAT": "0"},
+@pytest.mark.parametrize("W", [1918, 1284, 854])
+def test_crop_resize_norm_on_row_pitches_that_are_not_multiples_of_16_bytes(orc, W):
+    """crop_wave3_kernel has a specialisation for frames whose row pitch W * 3 is a multiple of 16 bytes (every 1080p / 720p test above); these
+    widths take its general-pitch code: per-row misalignment of the staged rows, per-row tap window shifts."""
+    import torch
+    from tracklab_amd import _lib
+    rng = np.random.default_rng(W)
+    B, H, MAXN = 2, 720, 20
+    frames = _frames(rng, B, H, W)
+    boxes = np.zeros((B, MAXN, 4), dtype=np.float32)
+    counts = np.array([MAXN, 13], dtype=np.int32)
+    for b in range(B):
+        boxes[b] = np.stack([rng.uniform(-20, W - 20, MAXN), rng.uniform(-20, H - 20, MAXN), rng.uniform(2, 150, MAXN), rng.uniform(2, 400, MAXN)], 1)
+    boxes[1, 0] = [W - 90, H - 200, 150, 300]           # the last rows of the last frame
+    d, db, dc = torch.from_numpy(frames).cuda(), torch.from_numpy(boxes).cuda(), torch.from_numpy(counts).cuda()
+    for swap in (False, True):
+        out16 = _lib.roi_crop_resize_norm(d, db, dc, 384, 128, "nhwc", torch.float16, swap_rb=swap)
+        out32 = _lib.roi_crop_resize_norm(d, db, dc, 384, 128, "nhwc", torch.float32, swap_rb=swap)
+        torch.cuda.synchronize()
+        assert torch.equal(out16, out32.half())
+    got = _lib.roi_crop_resize_norm(d, db, dc, 384, 128, "nhwc", torch.float16).cpu().numpy()
+    for b in range(B):
+        ltrb = orc.ltwh_to_crop_ltrb(boxes[b].astype(np.float64), W, H)
+        exp = orc.crop_resize_norm(frames[b], ltrb, 384, 128)
+        n = counts[b]
+        np.testing.assert_array_equal(got[b * MAXN:b * MAXN + n], torch.from_numpy(exp[:n]).half().numpy())
+
+
+@pytest.mark.parametrize("env", [{"TLK_CROP_P16": "0"}, {"TLK_CROP_WAVE": "4"}, {"TLK_CROP_WAVE": "2"}, {"TLK_CROP_WAVE": "1"}, {"TLK_CROP_WAVE": "0"}, {"TLK_CROP_WAVE": "0", "TLK_CROP_FAT": "0"},
                                  {"TLK_CROP_WAVE": "0", "TLK_CROP_FAT": "0", "TLK_CROP_KERNEL": "1"}],
-                         ids=["crop_pw_kernel", "crop_wave2_kernel", "crop_wave_kernel", "crop_fat_kernel", "crop_sep_kernel", "crop_lds_kernel"])
+                         ids=["crop_wave3_kernel_general_pitch", "crop_pw_kernel", "crop_wave2_kernel", "crop_wave_kernel", "crop_fat_kernel", "crop_sep_kernel", "crop_lds_kernel"])
 def test_the_older_crop_kernels_stay_bit_exact(env):
     """crop_wave3_kernel is the default for 128-wide 16-bit targets (crop_wave2_kernel for fp32); the persistent-wavefront variant and the kernels
     they replaced stay selectable for A/B runs (the switches are read once per process, hence the subprocess) and must keep producing the oracle's

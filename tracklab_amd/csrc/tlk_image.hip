@@ -1430,7 +1430,12 @@ __global__ void __launch_bounds__(BLOCK) crop_wave2_kernel(const unsigned char *
 // VALU 63 % and LDS 68 % busy, no memory stall left to remove -- the kernel is bound by its own instruction count. A wavefront walks its eight
 // mini-bands top to bottom and consecutive mini-bands share source rows; here the 16-bit plane is a ring of WV_SRC rows addressed by
 // (source row mod WV_SRC), so a source row is fetched, staged and taken through the horizontal pass ONCE per wavefront range.
-template <typename T, int LAYOUT>
+// P16 (r03 late): the frames' row pitch W * 3 is a multiple of 16 bytes (1920-, 1280-, 640-wide frames): every source row of a crop then has the SAME
+// misalignment, so (1) a lane's global offset for each of its load slots is a constant of the crop and the loads take the SGPR-base + 32-bit-VGPR-offset
+// form (three 64-bit pointer computations per fetch gone), (2) the tap windows' aligned LDS offsets and byte shifts are constants of the crop (ten address
+// instructions per staged row gone); and the R/B swap is done by the order in which the output block is assembled, not by register copies. The kernel is
+// VALU-issue bound (profiles/r03_crop_pmc.txt): these are ~60 of its ~375 vector instructions per mini-band.
+template <typename T, int LAYOUT, bool P16>
 __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
                                                           const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
                                                           int OH, const T *__restrict__ lut_g, float m0, float m1, float m2,
@@ -1555,6 +1560,10 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
         sl_goff[q] = (unsigned int)sl_rr[q] * W3;           // <= 5 rows: fits 32 bits
     }
     const int cw3 = par.cw * 3;
+    const int mis0 = (int)((uintptr_t)crop0 & 15);       // P16: the misalignment of EVERY source row of this crop
+    unsigned int sl_off[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) sl_off[q] = sl_c[q] < ((mis0 + cw3 + 15) >> 4) ? sl_goff[q] + (unsigned int)sl_c[q] * 16u : 0u;
     auto fetch = [&](int mb_req, RowRegs &R) {
         const int mb = min(mb_req, mb_hi - 1);           // past the wavefront's last mini-band: fetch that one again (L2 hits) -- every wait then has its three younger loads
         const int ra = mb * mbh, rb = min(ra + mbh, rows_chunk) - 1;
@@ -1566,6 +1575,15 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
         const int r_lo_n = max(r_first, done + 1);
         const int nrows_n = r_last - r_lo_n + 1;          // 0 .. WV_SRC new rows
         const unsigned char *rowp = crop0 + (size_t)min(r_lo_n, par.ch - 1) * W3;      // wave-uniform (no new row: r_lo_n may be one past the crop -- never address it)
+        if constexpr (P16) {
+            const unsigned char *base = rowp - mis0;     // SGPR pair, 16-byte aligned; lane offsets are constants of the crop
+            const unsigned int o0 = sl_rr[0] < nrows_n ? sl_off[0] : 0u, o1 = sl_rr[1] < nrows_n ? sl_off[1] : 0u, o2 = sl_rr[2] < nrows_n ? sl_off[2] : 0u;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(R.a) : "v"(o0), "s"(base));
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(R.b) : "v"(o1), "s"(base));
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(R.c) : "v"(o2), "s"(base));
+            R.r_lo = r_lo_n; R.nrows = nrows_n;
+            return;
+        }
         auto addr = [&](int q) {
             const bool in = sl_rr[q] < nrows_n;
             const unsigned char *g0 = rowp + (in ? sl_goff[q] : 0u);
@@ -1593,6 +1611,8 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
     };
     const int4 xc2 = *reinterpret_cast<const int4 *>(&s_xc[2 * lane]);
     const int oA = xc2.x & 0xffff, oB = xc2.z & 0xffff;
+    const int oA4 = (oA + mis0) & ~3, oB4 = (oB + mis0) & ~3;                      // P16: aligned LDS offset and byte shift of the two tap windows
+    const unsigned int shA = (unsigned int)(oA + mis0) & 3u, shB = (unsigned int)(oB + mis0) & 3u;
     const unsigned int selA = 0x0c000c00u | ((unsigned int)(xc2.x >> 16) << 16), selB = 0x0c000c00u | ((unsigned int)(xc2.z >> 16) << 16);
     const us2_t wA = __builtin_bit_cast(us2_t, xc2.y), wB = __builtin_bit_cast(us2_t, xc2.w);
     // one mini-band: rows of `mb` are staged; N holds (or will hold) the rows of mb + 1. Order: horizontal pass, vertical pass, output block
@@ -1609,10 +1629,18 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
                 hi = __builtin_amdgcn_alignbyte(d2, d1, (unsigned int)addr & 3u);
             };
             for (int rr = 0; rr < nrows; ++rr) {
-                const int base = rr * CS_ROW_BYTES + (int)((a_lo + (unsigned int)rr * a_step) & 15u);
                 unsigned int loA, hiA, loB, hiB;
-                taps(base + oA, loA, hiA);
-                taps(base + oB, loB, hiB);
+                if constexpr (P16) {
+                    const unsigned int *qa = reinterpret_cast<const unsigned int *>(s_rows + rr * CS_ROW_BYTES + oA4);
+                    const unsigned int *qb = reinterpret_cast<const unsigned int *>(s_rows + rr * CS_ROW_BYTES + oB4);
+                    const unsigned int a0 = qa[0], a1 = qa[1], a2 = qa[2], b0_ = qb[0], b1_ = qb[1], b2_ = qb[2];
+                    loA = __builtin_amdgcn_alignbyte(a1, a0, shA); hiA = __builtin_amdgcn_alignbyte(a2, a1, shA);
+                    loB = __builtin_amdgcn_alignbyte(b1_, b0_, shB); hiB = __builtin_amdgcn_alignbyte(b2_, b1_, shB);
+                } else {
+                    const int base = rr * CS_ROW_BYTES + (int)((a_lo + (unsigned int)rr * a_step) & 15u);
+                    taps(base + oA, loA, hiA);
+                    taps(base + oB, loB, hiB);
+                }
                 unsigned int *o = reinterpret_cast<unsigned int *>(s_h + ((r_lo + rr) % WV_SRC) * HS) + lane;
 #pragma unroll
                 for (int c3 = 0; c3 < 3; ++c3) {
@@ -1652,7 +1680,7 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
                 asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t) : "v"(xa), "v"(xb));
                 px[kk][c] = s_lut[c * CS_LUT_N + t];
             }
-            if (swap_rb) {
+            if (swap_rb && !block) {                     // (the block path swaps by the order in which it assembles the block: no register copies)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const T t0 = px[k][0]; px[k][0] = px[k][2]; px[k][2] = t0; }
             }
@@ -1664,12 +1692,22 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             T *o = reinterpret_cast<T *>(s_rows) + ((size_t)ry * OW + x_base) * 3;
+            if (swap_rb) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                Pack<T, 8> p;
+                for (int k = 0; k < 3; ++k) {
+                    Pack<T, 8> p;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
-                *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+                    for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][2 - idx % 3]; }
+                    *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    Pack<T, 8> p;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
+                    *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -3293,10 +3331,12 @@ int launch_crop(const unsigned char *frames, int B, int H, int W, const float *b
                     return TLK_OK;
                 }
                 if (wave >= 3) {
-                    if (layout == LAYOUT_NCHW)
-                        hipLaunchKernelGGL((crop_wave3_kernel<T, LAYOUT_NCHW>), dim3(nwg2), dim3(BLOCK), smem3, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg2);
-                    else
-                        hipLaunchKernelGGL((crop_wave3_kernel<T, LAYOUT_NHWC>), dim3(nwg2), dim3(BLOCK), smem3, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg2);
+                    static const int p16_on = [] { const char *e = getenv("TLK_CROP_P16"); return e ? atoi(e) : 1; }();     // 0: the general-pitch code also for 16-byte-multiple row pitches
+                    const bool p16 = p16_on && ((long long)W * 3) % 16 == 0;
+#define TLK_CW3(LAY, P) hipLaunchKernelGGL((crop_wave3_kernel<T, LAY, P>), dim3(nwg2), dim3(BLOCK), smem3, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg2)
+                    if (layout == LAYOUT_NCHW) { if (p16) TLK_CW3(LAYOUT_NCHW, true); else TLK_CW3(LAYOUT_NCHW, false); }
+                    else { if (p16) TLK_CW3(LAYOUT_NHWC, true); else TLK_CW3(LAYOUT_NHWC, false); }
+#undef TLK_CW3
                     return TLK_OK;
                 }
             }
