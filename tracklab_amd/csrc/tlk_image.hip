@@ -1663,26 +1663,23 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
             const unsigned short *h0 = s_h + ((yi >> 12) & 7u) * HS + x_base;             // planar: [channel][x]; row = its ring slot
             const unsigned short *h1 = s_h + ((yi >> 28) & 7u) * HS + x_base;
             const unsigned int b0 = yw & 0xffffu, b1 = yw >> 16;
-            unsigned int w0[12], w1[12];
+            // output channel co <- source channel cs: the R/B swap is a wave-uniform choice of plane and table row, not a register shuffle afterwards
+            // (the compiler had turned the swap into 16 selects + 8 copies per mini-band)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const uint4 u = *reinterpret_cast<const uint4 *>(h0 + c * OW), v = *reinterpret_cast<const uint4 *>(h1 + c * OW);
-                w0[c * 4] = u.x; w0[c * 4 + 1] = u.y; w0[c * 4 + 2] = u.z; w0[c * 4 + 3] = u.w;
-                w1[c * 4] = v.x; w1[c * 4 + 1] = v.y; w1[c * 4 + 2] = v.z; w1[c * 4 + 3] = v.w;
-            }
+            for (int co = 0; co < 3; ++co) {
+                const int cs = swap_rb ? 2 - co : co;
+                const uint4 u = *reinterpret_cast<const uint4 *>(h0 + cs * OW), v = *reinterpret_cast<const uint4 *>(h1 + cs * OW);
+                const unsigned int w0[4] = {u.x, u.y, u.z, u.w}, w1[4] = {v.x, v.y, v.z, v.w};
+                const T *lut_c = s_lut + cs * CS_LUT_N;
 #pragma unroll
-            for (int q = 0; q < 24; ++q) {
-                const int c = q >> 3, kk = q & 7;
-                const unsigned int a = (kk & 1) ? (w0[c * 4 + (kk >> 1)] >> 16) : (w0[c * 4 + (kk >> 1)] & 0xffffu);
-                const unsigned int c1 = (kk & 1) ? (w1[c * 4 + (kk >> 1)] >> 16) : (w1[c * 4 + (kk >> 1)] & 0xffffu);
-                const unsigned int xa = __umul24(b0, a), xb = __umul24(b1, c1);
-                unsigned int t;                     // t <= 1020 always (see crop_sep_kernel)
-                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t) : "v"(xa), "v"(xb));
-                px[kk][c] = s_lut[c * CS_LUT_N + t];
-            }
-            if (swap_rb && !block) {                     // (the block path swaps by the order in which it assembles the block: no register copies)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { const T t0 = px[k][0]; px[k][0] = px[k][2]; px[k][2] = t0; }
+                for (int kk = 0; kk < 8; ++kk) {
+                    const unsigned int a = (kk & 1) ? (w0[kk >> 1] >> 16) : (w0[kk >> 1] & 0xffffu);
+                    const unsigned int c1 = (kk & 1) ? (w1[kk >> 1] >> 16) : (w1[kk >> 1] & 0xffffu);
+                    const unsigned int xa = __umul24(b0, a), xb = __umul24(b1, c1);
+                    unsigned int t;                     // t <= 1020 always (see crop_sep_kernel)
+                    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t) : "v"(xa), "v"(xb));
+                    px[kk][co] = lut_c[t];
+                }
             }
         }
         constexpr int NST = 3 * (int)sizeof(T) / 2;      // 16-byte stores per lane of a full mini-band block
@@ -1692,22 +1689,12 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             T *o = reinterpret_cast<T *>(s_rows) + ((size_t)ry * OW + x_base) * 3;
-            if (swap_rb) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    Pack<T, 8> p;
+            for (int k = 0; k < 3; ++k) {
+                Pack<T, 8> p;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][2 - idx % 3]; }
-                    *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    Pack<T, 8> p;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
-                    *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
-                }
+                for (int e = 0; e < 8; ++e) { const int idx = k * 8 + e; p.v[e] = px[idx / 3][idx % 3]; }
+                *reinterpret_cast<Pack<T, 8> *>(o + k * 8) = p;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -2605,20 +2592,18 @@ __global__ void __launch_bounds__(BLOCK) pil_wave_kernel(const unsigned char *__
                 if (t < 2 || t < ntv) {                  // (wave-uniform; taps past a row's own support weigh 0 and read a stale ring row)
                     const unsigned char *p = s_h + ((slot0 + t) & (PWV_SRC - 1)) * PWV_PLANE + x_base;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const uint2 u = *reinterpret_cast<const uint2 *>(p + c * OW);
+                    for (int co = 0; co < 3; ++co) {         // output channel co <- source plane (R/B swap: a wave-uniform choice, no register shuffle)
+                        const uint2 u = *reinterpret_cast<const uint2 *>(p + (swap_rb ? 2 - co : co) * OW);
                         const unsigned int w[2] = {u.x, u.y};
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) acc[c * 8 + k] += __mul24(byte_of(w, k), kv[t]);
+                        for (int k = 0; k < 8; ++k) acc[co * 8 + k] += __mul24(byte_of(w, k), kv[t]);
                     }
                 }
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+            for (int co = 0; co < 3; ++co) {
+                const T *lut_c = s_lut[swap_rb ? 2 - co : co];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) px[k][c] = s_lut[c][(unsigned int)acc[c * 8 + k] >> PIL_BITS];
-            if (swap_rb) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { const T t0 = px[k][0]; px[k][0] = px[k][2]; px[k][2] = t0; }
+                for (int k = 0; k < 8; ++k) px[k][co] = lut_c[(unsigned int)acc[co * 8 + k] >> PIL_BITS];
             }
         }
         uint4 blk0 = make_uint4(0, 0, 0, 0), blk1 = blk0, blk2 = blk0;
