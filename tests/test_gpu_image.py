@@ -344,11 +344,13 @@ def test_pil_wave_kernel_16bit_nhwc_equals_the_fp32_kernel_and_the_oracle(orc, o
         np.testing.assert_array_equal(h16[i], exp.astype(np.float16), err_msg=f"crop {i} f16")
 
 
-def test_the_older_pil_crop_kernel_stays_bit_exact():
-    """pil_crop_kernel stays selectable with TLK_PIL_WAVE=0 (read once per process, hence the subprocess)."""
+@pytest.mark.parametrize("env", [{"TLK_PIL_WAVE": "0"}, {"TLK_CROP_P16": "0"}], ids=["pil_crop_kernel", "pil_wave_kernel_general_pitch"])
+def test_the_older_pil_crop_kernel_stays_bit_exact(env):
+    """pil_crop_kernel stays selectable with TLK_PIL_WAVE=0, pil_wave_kernel's general-pitch code with TLK_CROP_P16=0 (the 1080p frames of the tests take
+    the 16-byte-pitch specialisation otherwise); both are read once per process, hence the subprocess."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_image.py"), "-m", "gpu", "-q", "-x", "-k", "test_pil_ and not older"],
-                       env=dict(os.environ, TLK_PIL_WAVE="0"), capture_output=True, text=True, timeout=600)
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]

@@ -2373,7 +2373,8 @@ __device__ __forceinline__ void pil_direct_unit_nhwc(const unsigned char *__rest
     }
 }
 
-template <typename T>
+// P16: the frames' row pitch is a multiple of 16 bytes -> constant lane offsets (SGPR-base loads) and constant tap-window shifts, as in crop_wave3_kernel
+template <typename T, bool P16>
 __global__ void __launch_bounds__(BLOCK) pil_wave_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
                                                         const double *__restrict__ boxes, int box_stride, const int *__restrict__ counts, int max_n,
                                                         int OH, float m0, float m1, float m2, float d0, float d1, float d2,
@@ -2497,6 +2498,10 @@ __global__ void __launch_bounds__(BLOCK) pil_wave_kernel(const unsigned char *__
         sl_goff[q] = (unsigned int)sl_rr[q] * W3;
     }
     const int cw3 = cw * 3;
+    const int mis0 = (int)((uintptr_t)crop0 & 15);       // P16: the misalignment of EVERY source row of this crop
+    unsigned int sl_off[PWV_NL];
+#pragma unroll
+    for (int q = 0; q < PWV_NL; ++q) sl_off[q] = sl_c[q] < ((mis0 + cw3 + 15) >> 4) ? sl_goff[q] + (unsigned int)sl_c[q] * 16u : 0u;
     auto fetch = [&](int mb_req, RowRegs &R) {
         const int mb = min(mb_req, mb_hi - 1);           // past the last mini-band: that one again -- every wait has its PWV_NL younger loads
         const int ra = mb * mbh, rb = min(ra + mbh, rows_chunk) - 1;
@@ -2506,13 +2511,22 @@ __global__ void __launch_bounds__(BLOCK) pil_wave_kernel(const unsigned char *__
         const int r_lo_n = max(r_first, done + 1);
         const int nrows_n = max(0, r_last - r_lo_n + 1);
         const unsigned char *rowp = crop0 + (size_t)min(r_lo_n, ch - 1) * W3;      // (no new row: r_lo_n may be one past the crop -- never address it)
+        if constexpr (P16) {
+            const unsigned char *base = rowp - mis0;     // SGPR pair, 16-byte aligned
 #pragma unroll
-        for (int q = 0; q < PWV_NL; ++q) {
-            const bool in = sl_rr[q] < nrows_n;
-            const unsigned char *g0 = rowp + (in ? sl_goff[q] : 0u);
-            const int mis = (int)((uintptr_t)g0 & 15);
-            const unsigned char *pp = g0 - mis + (size_t)((in && sl_c[q] < ((mis + cw3 + 15) >> 4)) ? sl_c[q] : 0) * 16;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(R.v[q]) : "v"(pp));
+            for (int q = 0; q < PWV_NL; ++q) {
+                const unsigned int o = sl_rr[q] < nrows_n ? sl_off[q] : 0u;
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(R.v[q]) : "v"(o), "s"(base));
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PWV_NL; ++q) {
+                const bool in = sl_rr[q] < nrows_n;
+                const unsigned char *g0 = rowp + (in ? sl_goff[q] : 0u);
+                const int mis = (int)((uintptr_t)g0 & 15);
+                const unsigned char *pp = g0 - mis + (size_t)((in && sl_c[q] < ((mis + cw3 + 15) >> 4)) ? sl_c[q] : 0) * 16;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(R.v[q]) : "v"(pp));
+            }
         }
         R.r_lo = r_lo_n; R.nrows = nrows_n;
     };
@@ -2539,7 +2553,8 @@ __global__ void __launch_bounds__(BLOCK) pil_wave_kernel(const unsigned char *__
         const int r_lo = st_r_lo, nrows = st_nrows;
         const unsigned int a_lo = (unsigned int)(uintptr_t)(crop0 + (size_t)r_lo * W3) & 15u;
         for (int rr = 0; rr < nrows; ++rr) {
-            const int base = rr * CS_ROW_BYTES + (int)((a_lo + (unsigned int)rr * a_step) & 15u);
+            // (P16: a_step == 0 and a_lo == mis0 for every row, so the aligned offsets and byte shifts below are loop invariants the compiler hoists)
+            const int base = rr * CS_ROW_BYTES + (P16 ? mis0 : (int)((a_lo + (unsigned int)rr * a_step) & 15u));
             unsigned int wa[NW], wb[NW];
             {
                 const int addr = base + oA;
@@ -3412,8 +3427,13 @@ int launch_pil_crop(const unsigned char *frames, int B, int H, int W, const doub
         if (wave && layout == LAYOUT_NHWC && OW == 128) {
             const int chunks = (OH + CF_BANDS * CS_BAND - 1) / (CF_BANDS * CS_BAND);
             const int nwg = B * max_n * chunks;
-            hipLaunchKernelGGL((pil_wave_kernel<T>), dim3((unsigned)nwg), dim3(BLOCK), 0, st, frames, B, H, W, boxes, box_stride, counts, max_n, OH,
-                               mean[sw0], mean[1], mean[sw2], stdv[sw0], stdv[1], stdv[sw2], (T *)out, swap_rb, nwg);
+            static const int p16_on = [] { const char *e = getenv("TLK_CROP_P16"); return e ? atoi(e) : 1; }();
+            if (p16_on && ((long long)W * 3) % 16 == 0)
+                hipLaunchKernelGGL((pil_wave_kernel<T, true>), dim3((unsigned)nwg), dim3(BLOCK), 0, st, frames, B, H, W, boxes, box_stride, counts, max_n, OH,
+                                   mean[sw0], mean[1], mean[sw2], stdv[sw0], stdv[1], stdv[sw2], (T *)out, swap_rb, nwg);
+            else
+                hipLaunchKernelGGL((pil_wave_kernel<T, false>), dim3((unsigned)nwg), dim3(BLOCK), 0, st, frames, B, H, W, boxes, box_stride, counts, max_n, OH,
+                                   mean[sw0], mean[1], mean[sw2], stdv[sw0], stdv[1], stdv[sw2], (T *)out, swap_rb, nwg);
             return TLK_OK;
         }
     }
