@@ -33,8 +33,14 @@ def stream_kw(rng):
                 churn_period=int(rng.choice([20, 40, 1000])))
 
 
+BOX_BITS = {}                                               # r03: per tracker, (output rows, rows whose four box coordinates are BIT-identical to the reference's)
+
+
 def compare(name, trial, f, got, exp, tol=1e-9):
     exp = np.asarray(exp, dtype=np.float64).reshape(-1, 8)
+    if got.shape == exp.shape and len(exp):
+        c = BOX_BITS.setdefault(name, [0, 0])
+        c[0] += len(exp); c[1] += int((got[:, :4] == exp[:, :4]).all(axis=1).sum())
     if got.shape != exp.shape or not np.array_equal(got[:, 4:], exp[:, 4:]) or not np.allclose(got[:, :4], exp[:, :4], rtol=tol, atol=tol):
         print(f"DIVERGENCE {name} trial {trial} frame {f}: shapes {got.shape} {exp.shape}")
         return False
@@ -334,4 +340,5 @@ for name in sorted(WHICH):
         except Exception as ex:                             # a reference-side crash on odd hyper-parameters is reported, not fatal
             print(f"EXCEPTION {name} trial {t}: {type(ex).__name__}: {ex}")
     print(f"{name}: {ok}/{N} trials identical to the reference" + (f" (trials {FIRST}..{FIRST + N - 1})" if FIRST else "") +
-          (f"; Kalman boxes bit-identical: {EXACT['kf_bits_equal']}/{EXACT['rows']} rows" if name == "bpbss" else ""))
+          (f"; Kalman boxes bit-identical: {EXACT['kf_bits_equal']}/{EXACT['rows']} rows" if name == "bpbss" else "") +
+          (f"; output boxes bit-identical: {BOX_BITS[name][1]}/{BOX_BITS[name][0]} rows" if name in BOX_BITS else ""))
