@@ -82,3 +82,9 @@ def test_device_log_tracks_refuses_an_overflowed_step():
     log.sink(0, 2, 0)({"rows": torch.zeros((2, 4, 8), dtype=torch.float64), "ocnt": torch.tensor([1, -3], dtype=torch.int32), "dcnt": torch.tensor([4, 4], dtype=torch.int32)})
     with pytest.raises(RuntimeError, match="capacity"):
         evaluate.device_log_tracks(log, pipe)
+
+
+def test_an_empty_video_evaluates_to_zero_counts():
+    pipe = _Pipe(None, 4)
+    res = evaluate.evaluate_device_log({"frame": np.zeros(0, int), "track_id": np.zeros(0, int), "ltwh": np.zeros((0, 4))}, DeviceStepLog(), pipe)
+    assert not res["hota"].any() and res["clear"]["num_frames"] == 0

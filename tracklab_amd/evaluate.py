@@ -80,6 +80,10 @@ def device_log_tracks(log, pipe):
     boxes as ltwh and ltrb float64; int64 frame offsets. The only host traffic is ONE fetch of three scalars (rows, distinct ids, smallest
     row count) -- never the table. -> dict of device tensors + those scalars."""
     import torch
+    if not log.meta:                                                                   # a video without a single step
+        z = torch.zeros(1, dtype=torch.int64)
+        return {"ids": z.to(torch.int32), "ltrb": torch.zeros((1, 4), dtype=torch.float64), "ltwh": torch.zeros((1, 4), dtype=torch.float64), "off": z, "count": z[:0],
+                "n_boxes": 0, "n_ids": 0, "n_frames": 0, "cap": int(pipe.maxd)}
     steps = [(log.chunks[k // log.chunk], k % log.chunk, n) for k, (_, n, _) in enumerate(log.meta)]
     rows = torch.cat([ch["rows"][si][:n] for ch, si, n in steps])                      # (frames, cap, 8 doubles | row bytes)
     ocnt = torch.cat([ch["ocnt"][si][:n] for ch, si, n in steps]).to(torch.int64)
@@ -150,6 +154,8 @@ def evaluate_device_log(gt: dict, log, pipe, max_iou: float = 0.5) -> dict:
     from . import _lib
     tr = device_log_tracks(log, pipe)
     T, dev = tr["n_frames"], tr["off"].device
+    if T == 0:
+        return {"hota": np.zeros(len(hota.ALPHAS) * 7 + 2), "clear": clearmot.MOTAccumulator().counts()}
     g = _by_frame(gt)
     empty = (np.zeros(0, np.int64), np.zeros((0, 4)))
     gi, gb, goff = [], [], [0]
