@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Differential fuzz ON THE GPU BOX of the byte-moving kernels (letterbox, ReID crops with cv2 semantics, ReID crops with Pillow semantics) against
+"""Differential fuzz ON THE GPU BOX of the byte-moving kernels (letterbox, ReID crops with cv2 semantics, ReID crops with Pillow semantics, pose crops + SimCC decode) against
 the C oracle on random frame sizes, box sets, output sizes, layouts and element types -- the r03 kernels (letterbox_wave_kernel, crop_wave3_kernel
 with its 16-byte-pitch specialisation, pil_wave_kernel with its tap-count specialisations) have many shape-dependent paths. Pixels must be EQUAL
 (integers 0..255 / the normalisation table are exact in f16 / bf16; fp32 bit for bit). The oracle is the checker here, never the product.
 
-    python tools/fuzz_gpu_image.py [trials]      # per kernel family
+    python tools/fuzz_gpu_image.py [trials [family ...]]      # per kernel family: letterbox crop pil pose simcc
 """
 import json
 import os
@@ -108,8 +108,57 @@ def fuzz_pil(t, rng):
     return True
 
 
+def fuzz_pose(t, rng):
+    H, W = int(rng.integers(200, 1100)), int(rng.choice([640, 960, 1280, 1920, 1918, int(rng.integers(300, 2000))]))
+    B, MAXN = int(rng.integers(1, 3)), int(rng.integers(1, 16))
+    dt, layout = str(rng.choice(["f16", "f32"])), str(rng.choice(["nhwc", "nchw"]))
+    if dt == "f16":
+        layout = "nhwc"
+    fr = frames_of(rng, B, H, W)
+    xyxy = np.zeros((B, MAXN, 7))
+    counts = rng.integers(0, MAXN + 1, B).astype(np.int32)
+    for b in range(B):
+        w, h = rng.uniform(4, 0.5 * W, MAXN), rng.uniform(4, 0.9 * H, MAXN)
+        x, y = rng.uniform(-0.3 * w, W - 0.5 * w), rng.uniform(-0.3 * h, H - 0.5 * h)        # boxes that leave the image: constant-0 border
+        xyxy[b, :, :4] = np.stack([x, y, x + w, y + h], 1)
+    out, meta = _lib.pose_crop_warp_norm(torch.from_numpy(fr).cuda(), torch.from_numpy(xyxy).cuda(), torch.from_numpy(counts).cuda(), 192, 256, layout, DT[dt])
+    got, meta = out.float().cpu().numpy(), meta.cpu().numpy()
+    for b in range(B):
+        for i in range(int(counts[b])):
+            exp, c, sc = oracle.rtmpose_preprocess(fr[b], xyxy[b, i, :4])
+            slot = b * MAXN + i
+            if not (np.array_equal(meta[slot, :2], c) and np.array_equal(meta[slot, 2:4], sc) and np.array_equal(got[slot], cast(exp, dt))):
+                print(f"DIVERGENCE pose trial {t}: H {H} W {W} {layout} {dt} frame {b} box {i} {xyxy[b, i, :4]}")
+                return False
+        if got[b * MAXN + int(counts[b]):(b + 1) * MAXN].any():
+            print(f"DIVERGENCE pose trial {t}: padding slots written"); return False
+    return True
+
+
+def fuzz_simcc(t, rng):
+    n, K, Wx, Wy = int(rng.integers(1, 60)), 17, 384, 512
+    sx = rng.normal(0, 1, (n, K, Wx)).astype(np.float32); sy = rng.normal(0, 1, (n, K, Wy)).astype(np.float32)
+    for _ in range(int(rng.integers(0, 4))):                                   # ties and non-positive maxima
+        i, k = int(rng.integers(0, n)), int(rng.integers(0, K))
+        if rng.random() < 0.5:
+            sx[i, k] = -np.abs(sx[i, k])
+        else:
+            a, b2 = sorted(rng.integers(0, Wx, 2)); sx[i, k, a] = sx[i, k].max() + 1; sx[i, k, b2] = sx[i, k, a]
+    meta = np.zeros((n, 10)); meta[:, 0] = rng.uniform(0, 1920, n); meta[:, 1] = rng.uniform(0, 1080, n)
+    meta[:, 3] = rng.uniform(20, 900, n); meta[:, 2] = meta[:, 3] * 0.75
+    out = _lib.simcc_decode(torch.from_numpy(sx).cuda(), torch.from_numpy(sy).cuda(), torch.from_numpy(meta).cuda())
+    kps, scv = out["kps_xyc"].cpu().numpy(), out["scores"].cpu().numpy()
+    for i in range(n):
+        ek, es = oracle.simcc_decode(sx[i], sy[i], meta[i, :2], meta[i, 2:4])
+        if not (np.array_equal(kps[i, :, :2], ek) and np.array_equal(scv[i], es)):
+            print(f"DIVERGENCE simcc trial {t}: box {i}"); return False
+    return True
+
+
 out = {}
-for name, fn in (("letterbox", fuzz_letterbox), ("crop", fuzz_crop), ("pil", fuzz_pil)):
+for name, fn in (("letterbox", fuzz_letterbox), ("crop", fuzz_crop), ("pil", fuzz_pil), ("pose", fuzz_pose), ("simcc", fuzz_simcc)):
+    if len(sys.argv) > 2 and name not in sys.argv[2:]:
+        continue
     t0 = time.time()
     ok = sum(bool(fn(t, np.random.default_rng(70000 + t))) for t in range(N))
     out[name] = {"trials": N, "identical": ok, "seconds": round(time.time() - t0, 1)}
