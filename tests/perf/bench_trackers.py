@@ -18,6 +18,7 @@ from tracklab_amd.synth import SyntheticStream, ltrb_to_ltwh_rows  # noqa: E402
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 S_MANY = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+ONLY = set(sys.argv[3:])                                    # optional tracker names: run only these
 NOBJ, MAXD = 100, 128
 oracle.build()
 
@@ -42,6 +43,8 @@ results = []
 
 
 def run(name, make_bank, make_oracle, pack, step_dev, step_cpu, row_dtype, **skw):
+    if ONLY and name not in ONLY:
+        return
     for S in (1, S_MANY):
         data = streams(S, **skw)
         bank = make_bank(S)

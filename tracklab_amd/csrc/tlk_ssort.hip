@@ -84,6 +84,24 @@ __global__ void __launch_bounds__(BLOCK) ssort_cosine_kernel(SsDev Dv, SsIn in)
                             Dv.dnorm + (size_t)s * Dv.MAXD, Dv.reid + ((size_t)s * Dv.MAXT + t) * Dv.MAXD, s_min);
 }
 
+// r03: workgroup = one track, wavefronts own detection tiles (cosine_gallery_track): the gallery crosses HBM once per frame instead of once per detection tile
+template <int DS>
+__global__ void __launch_bounds__(BLOCK) ssort_cosine_track_kernel(SsDev Dv, SsIn in)
+{
+    const int s = blockIdx.y, t = blockIdx.x;
+    const int T = Dv.hdr[(size_t)s * H_COUNT + H_NTRK];
+    const int N = in.counts[(size_t)s * in.count_stride];
+    if (t >= T || N <= 0 || N > Dv.MAXD) return;
+    const int slot = Dv.order[(size_t)s * Dv.MAXT + t];
+    const size_t stride = (size_t)Dv.S * Dv.MAXT, at = (size_t)s * Dv.MAXT + slot;
+    if (Dv.fi[(size_t)SI_STATE * stride + at] != ST_CONFIRMED) return;          // only confirmed tracks enter the appearance stage
+    const int glen = Dv.fi[(size_t)SI_GLEN * stride + at];
+    if (glen <= 0) return;
+    const int g_lo = (int)(at * Dv.B);
+    cosine_gallery_track<DS>(Dv.gal, g_lo, g_lo + glen, Dv.gnorm, in.feat + (size_t)s * in.stream_stride_dets * Dv.D, N,
+                             Dv.dnorm + (size_t)s * Dv.MAXD, Dv.reid + ((size_t)s * Dv.MAXT + t) * Dv.MAXD);
+}
+
 // ------------------------------------------------------------------------------------------------ KF pieces that differ from bpbreid's
 // predict (kalman_filter.py:85-119): process noise relative to x, y, a, h; float32 arithmetic while the state is still the
 // float32 one initiate() made
@@ -544,13 +562,25 @@ static int ss_launch_frame(tlk_ssort *h, const SsDev &Dv, int n_streams, const S
                            int out_cap, int *out_counts, size_t oc_stride, hipStream_t st)
 {
     hipLaunchKernelGGL(ssort_detnorm_kernel, dim3((Dv.MAXD + NWAVES - 1) / NWAVES, n_streams), dim3(BLOCK), 0, st, Dv, in);
-    const dim3 grid((Dv.MAXD + 15) / 16, Dv.MAXT, n_streams);
-    switch (Dv.D) {
-    case 512: hipLaunchKernelGGL((ssort_cosine_kernel<32>), grid, dim3(BLOCK), 0, st, Dv, in); break;
-    case 256: hipLaunchKernelGGL((ssort_cosine_kernel<16>), grid, dim3(BLOCK), 0, st, Dv, in); break;
-    case 128: hipLaunchKernelGGL((ssort_cosine_kernel<8>), grid, dim3(BLOCK), 0, st, Dv, in); break;
-    case 64: hipLaunchKernelGGL((ssort_cosine_kernel<4>), grid, dim3(BLOCK), 0, st, Dv, in); break;
-    default: hipLaunchKernelGGL((ssort_cosine_kernel<2>), grid, dim3(BLOCK), 0, st, Dv, in); break;      // D == 32
+    static const int by_track = [] { const char *e = getenv("TLK_SSORT_COSINE"); return e ? atoi(e) : 1; }();     // 0: the (track, 16 detections) workgroups of r01 / r02
+    if (by_track) {
+        const dim3 gt(Dv.MAXT, n_streams);
+        switch (Dv.D) {
+        case 512: hipLaunchKernelGGL((ssort_cosine_track_kernel<32>), gt, dim3(BLOCK), 0, st, Dv, in); break;
+        case 256: hipLaunchKernelGGL((ssort_cosine_track_kernel<16>), gt, dim3(BLOCK), 0, st, Dv, in); break;
+        case 128: hipLaunchKernelGGL((ssort_cosine_track_kernel<8>), gt, dim3(BLOCK), 0, st, Dv, in); break;
+        case 64: hipLaunchKernelGGL((ssort_cosine_track_kernel<4>), gt, dim3(BLOCK), 0, st, Dv, in); break;
+        default: hipLaunchKernelGGL((ssort_cosine_track_kernel<2>), gt, dim3(BLOCK), 0, st, Dv, in); break;      // D == 32
+        }
+    } else {
+        const dim3 grid((Dv.MAXD + 15) / 16, Dv.MAXT, n_streams);
+        switch (Dv.D) {
+        case 512: hipLaunchKernelGGL((ssort_cosine_kernel<32>), grid, dim3(BLOCK), 0, st, Dv, in); break;
+        case 256: hipLaunchKernelGGL((ssort_cosine_kernel<16>), grid, dim3(BLOCK), 0, st, Dv, in); break;
+        case 128: hipLaunchKernelGGL((ssort_cosine_kernel<8>), grid, dim3(BLOCK), 0, st, Dv, in); break;
+        case 64: hipLaunchKernelGGL((ssort_cosine_kernel<4>), grid, dim3(BLOCK), 0, st, Dv, in); break;
+        default: hipLaunchKernelGGL((ssort_cosine_kernel<2>), grid, dim3(BLOCK), 0, st, Dv, in); break;      // D == 32
+        }
     }
     hipLaunchKernelGGL(ssort_assoc_kernel, dim3(n_streams), dim3(BLOCK), h->smem, st, Dv, h->P, in, rows, rows_stream_stride, out_cap,
                        out_counts, oc_stride);
