@@ -1435,7 +1435,7 @@ __global__ void __launch_bounds__(BLOCK) crop_wave2_kernel(const unsigned char *
 // form (three 64-bit pointer computations per fetch gone), (2) the tap windows' aligned LDS offsets and byte shifts are constants of the crop (ten address
 // instructions per staged row gone); and the R/B swap is done by the order in which the output block is assembled, not by register copies. The kernel is
 // VALU-issue bound (profiles/r03_crop_pmc.txt): these are ~60 of its ~375 vector instructions per mini-band.
-template <typename T, int LAYOUT, bool P16>
+template <typename T, int LAYOUT, bool P16, bool PREFETCH3 = false>
 __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
                                                           const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
                                                           int OH, const T *__restrict__ lut_g, float m0, float m1, float m2,
@@ -1541,7 +1541,11 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
     // chunk. TWO mini-bands are kept in flight (register sets X and Y): the wait for the rows of mini-band m then has the loads of m + 1 behind it, and
     // the rule "reads and writes complete out of order with respect to each other" no longer forces it to drain the stores of m - 1 just issued
     struct RowRegs { tlk_u32x4 a, b, c; int r_lo, nrows; };
-    RowRegs X{tlk_u32x4{0, 0, 0, 0}, tlk_u32x4{0, 0, 0, 0}, tlk_u32x4{0, 0, 0, 0}, 0, 0}, Y = X;
+    RowRegs X{tlk_u32x4{0, 0, 0, 0}, tlk_u32x4{0, 0, 0, 0}, tlk_u32x4{0, 0, 0, 0}, 0, 0}, Y = X, Z = X;
+    // DEPTH mini-bands of source rows in flight (register sets X, Y[, Z]). Counters with COLD sources (profiles/r03_bytekernels_pmc.txt: waves wait 54 % of
+    // their cycles, 33 % warm) say the kernel waits for memory inside the pipeline: the 16-byte-pitch variant, whose address arithmetic left room in the
+    // register file, keeps three sets in flight
+    constexpr int DEPTH = PREFETCH3 ? 3 : 2;
     // The three loads of a mini-band are inline asm: the compiler does not track them, so it cannot turn the wait for them into the
     // `s_waitcnt vmcnt(0)` it must use whenever loads AND stores are pending on the one counter gfx950 has for both (that full drain at the top of
     // every mini-band -- the stores of the previous one included -- was the un-overlapped "skeleton" of crop_wave_kernel, r03 ISA reading).
@@ -1597,7 +1601,8 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
         R.r_lo = r_lo_n; R.nrows = nrows_n;
     };
     auto wait_rows = [&](RowRegs &R) {                   // ONE form of the wait (two forms would meet in a phi: register copies of loads still in flight)
-        asm volatile("s_waitcnt vmcnt(3)" : "+v"(R.a), "+v"(R.b), "+v"(R.c));
+        if constexpr (DEPTH == 3) asm volatile("s_waitcnt vmcnt(6)" : "+v"(R.a), "+v"(R.b), "+v"(R.c));
+        else asm volatile("s_waitcnt vmcnt(3)" : "+v"(R.a), "+v"(R.b), "+v"(R.c));
     };
     int st_r_lo = 0, st_nrows = 0;                       // the mini-band whose rows are in this wavefront's staging area
     auto stage = [&](const RowRegs &R) {
@@ -1707,7 +1712,7 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
         if (mb + 1 < mb_hi) {
             wait_rows(N);
             stage(N);
-            fetch(mb + 3, N);
+            fetch(mb + 1 + DEPTH, N);
         }
         if (block) {
             uint4 *g = reinterpret_cast<uint4 *>(out + ((size_t)slot * OH + row0 + mb * mbh) * OW * 3);
@@ -1737,13 +1742,22 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
     if (mb_lo < mb_hi) {
         fetch(mb_lo, X);
         fetch(mb_lo + 1, Y);
+        if constexpr (DEPTH == 3) fetch(mb_lo + 2, Z);
         wait_rows(X);
         stage(X);
-        fetch(mb_lo + 2, X);
+        fetch(mb_lo + DEPTH, X);
     }
-    for (int mb = mb_lo; mb < mb_hi; mb += 2) {
-        mini_band(mb, Y);
-        if (mb + 1 < mb_hi) mini_band(mb + 1, X);
+    if constexpr (DEPTH == 3) {
+        for (int mb = mb_lo; mb < mb_hi; mb += 3) {
+            mini_band(mb, Y);
+            if (mb + 1 < mb_hi) mini_band(mb + 1, Z);
+            if (mb + 2 < mb_hi) mini_band(mb + 2, X);
+        }
+    } else {
+        for (int mb = mb_lo; mb < mb_hi; mb += 2) {
+            mini_band(mb, Y);
+            if (mb + 1 < mb_hi) mini_band(mb + 1, X);
+        }
     }
 }
 
@@ -3333,9 +3347,11 @@ int launch_crop(const unsigned char *frames, int B, int H, int W, const float *b
                 if (wave >= 3) {
                     static const int p16_on = [] { const char *e = getenv("TLK_CROP_P16"); return e ? atoi(e) : 1; }();     // 0: the general-pitch code also for 16-byte-multiple row pitches
                     const bool p16 = p16_on && ((long long)W * 3) % 16 == 0;
-#define TLK_CW3(LAY, P) hipLaunchKernelGGL((crop_wave3_kernel<T, LAY, P>), dim3(nwg2), dim3(BLOCK), smem3, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg2)
-                    if (layout == LAYOUT_NCHW) { if (p16) TLK_CW3(LAYOUT_NCHW, true); else TLK_CW3(LAYOUT_NCHW, false); }
-                    else { if (p16) TLK_CW3(LAYOUT_NHWC, true); else TLK_CW3(LAYOUT_NHWC, false); }
+                    static const int depth3 = [] { const char *e = getenv("TLK_CROP_DEPTH"); return e ? atoi(e) : 2; }() == 3;       // 3: three mini-bands of source rows in flight (NHWC, 16-byte pitch)
+#define TLK_CW3(LAY, P, D3) hipLaunchKernelGGL((crop_wave3_kernel<T, LAY, P, D3>), dim3(nwg2), dim3(BLOCK), smem3, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg2)
+                    if (layout == LAYOUT_NCHW) { if (p16) TLK_CW3(LAYOUT_NCHW, true, false); else TLK_CW3(LAYOUT_NCHW, false, false); }
+                    else if (p16 && depth3) TLK_CW3(LAYOUT_NHWC, true, true);
+                    else { if (p16) TLK_CW3(LAYOUT_NHWC, true, false); else TLK_CW3(LAYOUT_NHWC, false, false); }
 #undef TLK_CW3
                     return TLK_OK;
                 }
