@@ -1439,8 +1439,10 @@ template <typename T, int LAYOUT, bool P16, bool PREFETCH3 = false>
 __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
                                                           const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
                                                           int OH, const T *__restrict__ lut_g, float m0, float m1, float m2,
-                                                          float d0, float d1, float d2, T *__restrict__ out, int swap_rb, int nwg)
+                                                          float d0, float d1, float d2, T *__restrict__ out, int swap_flags, int nwg)
 {
+    const int swap_rb = swap_flags & 1;                  // bit 1 of swap_flags (experiment, TLK_CROP_NT=0): plain instead of streaming stores
+    const bool plain_stores = (swap_flags & 2) != 0;
     constexpr int OW = 128, HS = OW * 3, GROUPS = OW / 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     __shared__ int s_y[CF_BANDS * CS_BAND * 2];         // per output row of the chunk: (source row y0 | y1 << 16) relative to the crop, (b0 | b1 << 16)
@@ -1716,8 +1718,13 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
         }
         if (block) {
             uint4 *g = reinterpret_cast<uint4 *>(out + ((size_t)slot * OH + row0 + mb * mbh) * OW * 3);
+            if (plain_stores) {
 #pragma unroll
-            for (int k = 0; k < NST; ++k) stream_store(g + k * WAVE + lane, blk[k]);
+                for (int k = 0; k < NST; ++k) g[k * WAVE + lane] = blk[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < NST; ++k) stream_store(g + k * WAVE + lane, blk[k]);
+            }
         } else if (act) {
             if (LAYOUT == LAYOUT_NCHW) {
 #pragma unroll
@@ -3348,7 +3355,8 @@ int launch_crop(const unsigned char *frames, int B, int H, int W, const float *b
                     static const int p16_on = [] { const char *e = getenv("TLK_CROP_P16"); return e ? atoi(e) : 1; }();     // 0: the general-pitch code also for 16-byte-multiple row pitches
                     const bool p16 = p16_on && ((long long)W * 3) % 16 == 0;
                     static const int depth3 = [] { const char *e = getenv("TLK_CROP_DEPTH"); return e ? atoi(e) : 2; }() == 3;       // 3: three mini-bands of source rows in flight (NHWC, 16-byte pitch)
-#define TLK_CW3(LAY, P, D3) hipLaunchKernelGGL((crop_wave3_kernel<T, LAY, P, D3>), dim3(nwg2), dim3(BLOCK), smem3, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg2)
+                    static const int nt_off = [] { const char *e = getenv("TLK_CROP_NT"); return e ? (atoi(e) == 0 ? 2 : 0) : 0; }();
+#define TLK_CW3(LAY, P, D3) hipLaunchKernelGGL((crop_wave3_kernel<T, LAY, P, D3>), dim3(nwg2), dim3(BLOCK), smem3, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, (swap_rb ? 1 : 0) | nt_off, nwg2)
                     if (layout == LAYOUT_NCHW) { if (p16) TLK_CW3(LAYOUT_NCHW, true, false); else TLK_CW3(LAYOUT_NCHW, false, false); }
                     else if (p16 && depth3) TLK_CW3(LAYOUT_NHWC, true, true);
                     else { if (p16) TLK_CW3(LAYOUT_NHWC, true, false); else TLK_CW3(LAYOUT_NHWC, false, false); }
