@@ -629,6 +629,25 @@ def main():
         fin = hota.finalize(tdist.allreduce_sum(vec, dist, dev))
         hota_all = {"HOTA": fin["summary"]["HOTA"], "DetA": fin["summary"]["DetA"], "AssA": fin["summary"]["AssA"], "frames": fin["frames"],
                     "rows": int(len(df)), "tracked_rows": int(df.track_id.notna().sum())}
+        # the same statistics (+ the CLEAR-MOT / ID counts) straight from the video's table where the engine left it, in HBM: nothing but the ground
+        # truth goes up and two result vectors come down (evaluate.evaluate_device_log -> tlk_{hota,clear}_sequence_dev_f64); untimed, rank 0
+        if rank == 0:
+            try:
+                from tracklab_amd import clearmot, evaluate
+                nfr = args.steps * F
+                gfr, gid, gbx = [], [], []
+                for f in range(nfr):
+                    b = np.asarray(gts[0][f]["gt_boxes"], dtype=np.float64).reshape(-1, 4)
+                    gfr.extend([f + 1] * len(b)); gid.extend(int(i) for i in gts[0][f]["gt_all_ids"])
+                    gbx.append(np.column_stack([b[:, 0], b[:, 1], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]]).reshape(-1, 4))
+                gt_rows = {"frame": np.asarray(gfr, dtype=np.int64), "track_id": np.asarray(gid, dtype=np.int64), "ltwh": np.concatenate(gbx) if gbx else np.zeros((0, 4))}
+                dev_eval = evaluate.evaluate_device_log(gt_rows, eng.last_log, pipe)
+                cm = clearmot.finalize(dev_eval["clear"])
+                hota_all["from_device_table"] = {"HOTA": hota.finalize(dev_eval["hota"])["summary"]["HOTA"], "MOTA": float(cm["mota"]), "IDF1": float(cm["idf1"]),
+                                                 "num_switches": int(cm["num_switches"]),
+                                                 "hota_statistics_equal_host_fed": bool(np.allclose(dev_eval["hota"], vec, rtol=1e-9, atol=1e-9))}
+            except Exception as ex:                             # noqa: BLE001  (an evaluator problem must not cost the run its line)
+                hota_all["from_device_table"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     per_rank, seen, placement = gather_ranks(dist, dev, fps_local)
 
     # ---- roofline of the dominant byte-moving libtlk kernel: HIP events on the launch stream around every launch of
