@@ -89,8 +89,10 @@ def test_every_yaml_target_resolves_and_accepts_its_keys():
                 continue                                           # tracklab.callbacks.*: the reference's own classes
             cls = _resolve(n["_target_"])
             kw = {k: v for k, v in n.items() if k != "_target_"}
-            if "wrappers" in n["_target_"]:
+            if "wrappers" in n["_target_"] and "Evaluator" not in n["_target_"]:
                 kw.setdefault("device", "cuda"); kw.setdefault("batch_size", 1)     # what main.py's instantiate adds (main.py:36-39)
+            if n["_target_"].endswith("Evaluator"):
+                kw.update(tracking_dataset=None)                                    # main.py: instantiate(cfg.eval, tracking_dataset=...)
             if n["_target_"].endswith("HipTrackingEngine"):
                 kw.update(modules=[], tracker_state=None)                          # main.py:55-59
             inspect.signature(cls.__init__).bind(None, **kw)                        # TypeError = a key the constructor does not take
@@ -130,7 +132,7 @@ def test_every_module_yaml_instantiates_on_the_device_under_the_stub(tmp_path):
         made = 0
         for y in _yamls():
             node = yaml.safe_load(open(y))
-            if "engine" in y.split("/")[-2]:
+            if y.split("/")[-2] in ("engine", "eval"):
                 continue
             m = _instantiate(node, device="cuda", batch_size=1)
             assert isinstance(m, tp.ImageLevelModule) and m.level == "image" and m.name == node["_target_"].rsplit(".", 1)[1], y

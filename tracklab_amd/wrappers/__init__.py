@@ -2,3 +2,4 @@ from .track import HipBoTSORT, HipDeepOCSORT, HipBPBReIDStrongSORT, HipByteTrack
 from .detect import HipYOLOX  # noqa: F401
 from .reid import HipPartReID  # noqa: F401
 from .pose import HipRTMPose  # noqa: F401
+from .eval import HipTrackEvalEvaluator  # noqa: F401
