@@ -35,7 +35,8 @@ def _state(seed=3):
                                     "bbox_ltwh": np.array([b[i, 0], b[i, 1], b[i, 2] - b[i, 0], b[i, 3] - b[i, 1]])})
                 d = fr["dets"]
                 for i in range(len(d)):
-                    tid = float(d[i, 6] % 7 + 1) if rng.random() < 0.85 else np.nan      # some detections stay without a track
+                    # ids unique inside a frame (an evaluator input must be), drifting every five frames so that switches occur; some detections stay without a track
+                    tid = float((i + f // 5) % len(d) + 1) if rng.random() < 0.85 else np.nan
                     box = np.array([d[i, 0], d[i, 1], d[i, 2] - d[i, 0], d[i, 3] - d[i, 1]], dtype=np.float32) + rng.normal(0, 2, 4).astype(np.float32)
                     pr_rows.append({"image_id": img_id, "video_id": vid, "track_id": tid, "bbox_conf": float(d[i, 4]), "category_id": 1, "bbox_ltwh": box,
                                     "track_bbox_kf_ltwh": box + 1})

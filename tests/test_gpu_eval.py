@@ -155,3 +155,21 @@ def test_evaluate_folders_on_the_device_equals_the_host_path(tmp_path):
                          env=dict(os.environ, PYTHONPATH=REPO))
     assert out.returncode == 0, out.stderr[-2000:]
     assert abs(json.loads(out.stdout)["combined"]["HOTA"] - cpu["combined"]["HOTA"]) < 1e-12
+
+
+def test_evaluator_plugin_on_the_device_equals_its_host_path():
+    """HipTrackEvalEvaluator (the plugin in the place of tracklab.wrappers.TrackEvalEvaluator) with cfg.device gpu (its default) and cpu on the same
+    tracker state: every count equal, HOTA's sums to 1e-12."""
+    from types import SimpleNamespace as NS
+
+    from test_eval_plugin import _state
+    from tracklab_amd.wrappers import HipTrackEvalEvaluator
+    st = _state(5)
+    gpu = HipTrackEvalEvaluator(NS(device="gpu"), "val", False, "unused", None).run(st)
+    cpu = HipTrackEvalEvaluator(NS(device="cpu"), "val", False, "unused", None).run(st)
+    assert set(gpu["sequences"]) == set(cpu["sequences"])
+    for name, m in cpu["sequences"].items():
+        for k, v in m.items():
+            assert gpu["sequences"][name][k] == pytest.approx(v, rel=1e-12, abs=1e-12, nan_ok=True), (name, k)      # (ratios of the video without boxes are NaN on both sides)
+    for k, v in cpu["combined"].items():
+        assert gpu["combined"][k] == pytest.approx(v, rel=1e-12, abs=1e-12, nan_ok=True), k
