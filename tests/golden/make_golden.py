@@ -128,6 +128,7 @@ OCSORT_RUNS = [  # (name, config, seed, n_objects, n_frames, stream kwargs)
     ("ciou_s4_n20", "ciou", 4, 20, 120, {"miss_prob": 0.2, "churn_period": 10}),
     ("ct_s5_n20", "ct", 5, 20, 120, {"miss_prob": 0.1, "churn_period": 10}),
     ("yaml_s6_n100_cls2", "yaml", 6, 100, 100, {"cls": 2.0, "miss_prob": 0.05}),
+    ("yaml_s7_n120_crowded", "yaml", 7, 120, 120, {"miss_prob": 0.1, "churn_period": 15}),                     # r03: the crowded regime, LSA path every frame
 ]
 
 
@@ -767,6 +768,7 @@ BT_RUNS = [  # name, hyperparams, seed, objects, frames, stream kwargs
     ("defaults_s1_n50", dict(track_thresh=0.45, match_thresh=0.8, track_buffer=25, frame_rate=30), 1, 50, 150, dict(miss_prob=0.08, churn_period=40, low_conf_frac=0.3)),
     ("short_buffer_s2_n20", dict(track_thresh=0.5, match_thresh=0.7, track_buffer=5, frame_rate=30), 2, 20, 200, dict(miss_prob=0.15, churn_period=25, low_conf_frac=0.3)),
     ("fps15_s3_n30", dict(track_thresh=0.6, match_thresh=0.9, track_buffer=30, frame_rate=15), 3, 30, 150, dict(miss_prob=0.1, churn_period=30, low_conf_frac=0.4)),
+    ("crowded_s4_n120", dict(track_thresh=0.6, track_buffer=30, match_thresh=0.8, frame_rate=30), 4, 120, 100, dict(miss_prob=0.1, churn_period=15, low_conf_frac=0.25)),      # r03
 ]
 
 
@@ -866,6 +868,7 @@ BOT_RUNS = [  # name, hyperparams, seed, objects, frames, D, stream kwargs
     ("short_s2_n20_d32", dict(BOT_DEFAULTS, track_buffer=6, match_thresh=0.6, appearance_thresh=0.4), 2, 20, 200, 32,
      dict(low_conf_frac=0.3, miss_prob=0.15, churn_period=25)),
     ("classes_s3_n25_d32", dict(BOT_DEFAULTS, new_track_thresh=0.5), 3, 25, 120, 32, dict(low_conf_frac=0.25, miss_prob=0.1, churn_period=30)),
+    ("crowded_s4_n110_d64", BOT_YAML, 4, 110, 100, 64, dict(low_conf_frac=0.2, miss_prob=0.1, churn_period=15)),                                 # r03
 ]
 
 
