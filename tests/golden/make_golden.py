@@ -620,6 +620,7 @@ SS_RUNS = [  # name, hyperparams, seed, objects, frames, D, store embeddings, st
     ("ninit1_s3_n20_d32", dict(SS_DEFAULTS, n_init=1, max_unmatched_preds=0, max_age=8, max_dist=0.3), 3, 20, 160, 32, True,
      dict(miss_prob=0.1, churn_period=25)),
     ("lowconf_s4_n30_d64", dict(SS_DEFAULTS, max_iou_dist=0.5), 4, 30, 120, 64, False, dict(miss_prob=0.05, churn_period=40, low_conf_frac=0.3)),
+    ("crowded_s5_n110_d64", dict(SS_YAML, nn_budget=30), 5, 110, 80, 64, False, dict(miss_prob=0.1, churn_period=15)),                              # r03
 ]
 
 
@@ -946,6 +947,7 @@ DOC_RUNS = [  # name, hyperparams, seed, objects, frames, D, normalise the detec
      dict(miss_prob=0.2, churn_period=25)),
     ("classes_s3_n25_d32", dict(DOC_YAML, asso_func="ciou", w_association_emb=0.4, aw_param=0.7, alpha_fixed_emb=0.8), 3, 25, 120, 32, True,
      dict(miss_prob=0.1, churn_period=30)),
+    ("crowded_s4_n110_d64", DOC_YAML, 4, 110, 100, 64, True, dict(miss_prob=0.1, churn_period=15)),                                                 # r03
 ]
 
 
