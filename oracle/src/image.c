@@ -227,8 +227,8 @@ static int pil_coeffs(int inSize, int outSize, int **bounds_out, int32_t **kk_ou
 }
 static inline uint8_t pil_clip8(int v) { v >>= PIL_PRECISION_BITS; return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
-/* Image.resize((dw, dh), BILINEAR) of an RGB image src (sh, sw, 3) with row stride sstride bytes -> dst (dh, dw, 3) */
-void orc_pil_resize_bilinear_rgb(const uint8_t *src, int sh, int sw, int sstride, uint8_t *dst, int dh, int dw)
+/* self.im.resize(size, BILINEAR, box) (ImagingResample): horizontal pass into an 8-bit intermediate, then the vertical pass */
+static void pil_resample_core(const uint8_t *src, int sh, int sw, int sstride, uint8_t *dst, int dh, int dw)
 {
     if (sh == dh && sw == dw) {                              /* Image.resize returns self.copy() when nothing changes */
         for (int y = 0; y < sh; ++y) memcpy(dst + (size_t)y * dw * 3, src + (size_t)y * sstride, (size_t)sw * 3);
@@ -273,6 +273,23 @@ void orc_pil_resize_bilinear_rgb(const uint8_t *src, int sh, int sw, int sstride
         for (int y = 0; y < dh; ++y) memcpy(dst + (size_t)y * dw * 3, in + (size_t)y * in_stride, (size_t)dw * 3);
     }
     free(tmp); free(bh); free(bv); free(kh); free(kv);
+}
+
+/* Image.resize((dw, dh), BILINEAR) of an RGB image src (sh, sw, 3) with row stride sstride bytes -> dst (dh, dw, 3).
+ * Image.resize itself (PIL/Image.py, Pillow 12.2.0): `if self.size[1] > self.size[0] * 100 and size[1] < self.size[1]` the image is resized
+ * VERTICALLY first (to (sw, dh)) and horizontally afterwards -- two core calls, i.e. the uint8 rounding between the passes happens in the other order.
+ * Only crops more than 100 times taller than wide that are being reduced in height: a 3 x 301 px box. Found by the r03 sweep fixture (pil_sweep.npz). */
+void orc_pil_resize_bilinear_rgb(const uint8_t *src, int sh, int sw, int sstride, uint8_t *dst, int dh, int dw)
+{
+    if (sh == dh && sw == dw) { pil_resample_core(src, sh, sw, sstride, dst, dh, dw); return; }      /* Image.resize returns self.copy() */
+    if (sh > sw * 100 && dh < sh) {
+        uint8_t *mid = malloc((size_t)dh * sw * 3);
+        pil_resample_core(src, sh, sw, sstride, mid, dh, sw);               /* width unchanged: vertical pass only */
+        pil_resample_core(mid, dh, sw, sw * 3, dst, dh, dw);                /* height unchanged: horizontal pass only */
+        free(mid);
+        return;
+    }
+    pil_resample_core(src, sh, sw, sstride, dst, dh, dw);
 }
 
 /* strong_sort.py:43-51 + :102-108: xyxy (float64) -> xywh -> int-truncated, clipped x1,y1,x2,y2 */

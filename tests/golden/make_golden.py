@@ -764,6 +764,59 @@ def gen_pil_preprocess(out_dir):
     print("pil preprocess ok", len(boxes))
 
 
+def pil_sweep_image(w_img, H=720):
+    """The sweep's frame, from arithmetic only (no random generator: the tests rebuild it instead of storing 2.7 MB): gradients, a hash-like
+    texture of +-6 and flat rectangles."""
+    yy, xx = np.mgrid[0:H, 0:w_img].astype(np.int64)
+    tex = ((xx * 1103515245 + yy * 12345 + xx * yy * 7) >> 3) % 13 - 6
+    img = np.stack([(xx * 255 // w_img) + tex, (yy * 255 // H) - tex, ((xx * 3 + yy * 5) % 256) + tex // 2], axis=2)
+    for k in range(60):
+        x, y = (k * 197) % (w_img - 90), (k * 113) % (H - 170)
+        w, h = 10 + (k * 31) % 70, 10 + (k * 53) % 150
+        img[y:y + h, x:x + w] = [(k * 37) % 256, (k * 91) % 256, (k * 151) % 256]
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+PIL_SWEEP_SIZES = [(20, 40), (64, 128), (100, 250), (127, 255), (128, 256), (129, 257), (140, 300), (150, 306), (153, 307), (154, 308), (155, 310), (160, 400),
+                   (160, 512), (161, 513), (100, 600), (200, 300), (3, 500), (128, 10), (97, 193), (50, 511), (159, 2), (2, 2), (120, 270), (80, 330), (33, 77),
+                   (145, 290), (111, 222), (90, 180), (60, 500), (158, 316)]
+
+
+def gen_pil_sweep(out_dir):
+    """r03: a sweep of crop sizes through Pillow itself for the specialised paths of pil_wave_kernel (tap counts 2 / 3 / 5 per axis, 4- and 2-row
+    mini-bands around a vertical scale of 1.2, staged vs direct crops around 160 px width and 2x height, tiny and clipped crops, row pitches that
+    are / are not multiples of 16 bytes): same chain as gen_pil_preprocess (crop of the int-truncated clipped box -> Image.resize((128, 256),
+    BILINEAR)). The fixture holds, per crop, the SHA-256 of Pillow's resized uint8 array and every 8th of its rows; the frames are rebuilt by the tests."""
+    import hashlib
+
+    from PIL import Image
+    out = {}
+    for tag, w_img in (("a", 1280), ("b", 1283)):
+        H = 720
+        img = pil_sweep_image(w_img, H)
+        boxes, ints, shas, rows = [], [], [], []
+        for k, (cw, ch) in enumerate(PIL_SWEEP_SIZES if tag == "a" else PIL_SWEEP_SIZES[::3]):
+            x1, y1 = (k * 211) % max(1, w_img - cw - 1), (k * 97) % max(1, H - ch - 1)
+            if k % 7 == 6:                                     # clipped at the bottom-right corner: the last rows of the frame
+                x1, y1 = w_img - 1 - cw // 2, H - 1 - ch // 2
+            b = np.array([x1 + 0.3, y1 + 0.6, x1 + cw + 0.4, y1 + ch + 0.2])
+            x, y, w, h = (b[0] + b[2]) / 2, (b[1] + b[3]) / 2, b[2] - b[0], b[3] - b[1]
+            ix1, iy1, ix2, iy2 = max(int(x - w / 2), 0), max(int(y - h / 2), 0), min(int(x + w / 2), w_img - 1), min(int(y + h / 2), H - 1)
+            crop = img[iy1:iy2, ix1:ix2]
+            if crop.shape[0] == 0 or crop.shape[1] == 0:
+                continue
+            r = np.ascontiguousarray(np.asarray(Image.fromarray(np.ascontiguousarray(crop)).resize((128, 256), Image.BILINEAR)))
+            boxes.append(b); ints.append([ix1, iy1, ix2, iy2]); shas.append(hashlib.sha256(r.tobytes()).hexdigest()); rows.append(r[::8])
+        out[f"boxes_{tag}"] = np.array(boxes); out[f"boxes_int_{tag}"] = np.array(ints, dtype=np.int64)
+        out[f"sha_{tag}"] = np.array(shas); out[f"rows_{tag}"] = np.stack(rows); out[f"width_{tag}"] = np.int64(w_img)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+    lut = torch.arange(256, dtype=torch.uint8).view(1, 256, 1).repeat(3, 1, 1).to(torch.float32).div(255).sub_(mean).div_(std)
+    path = os.path.join(out_dir, "pil_sweep.npz")
+    np.savez_compressed(path, norm_lut=lut.numpy()[:, :, 0], pillow=np.array(Image.__version__), **out)
+    print("pil sweep ok", len(out["boxes_a"]), len(out["boxes_b"]), os.path.getsize(path))
+
+
 BT_RUNS = [  # name, hyperparams, seed, objects, frames, stream kwargs
     ("yaml_s0_n100", dict(track_thresh=0.6, track_buffer=30, match_thresh=0.8, frame_rate=30), 0, 100, 80, dict(low_conf_frac=0.2)),
     ("defaults_s1_n50", dict(track_thresh=0.45, match_thresh=0.8, track_buffer=25, frame_rate=30), 1, 50, 150, dict(miss_prob=0.08, churn_period=40, low_conf_frac=0.3)),
@@ -1361,7 +1414,7 @@ def main():
     out_dir = HERE
     only = set(sys.argv[1:])
     gens = {"ocsort": gen_ocsort, "iou": gen_iou_family, "kf7": gen_kf7, "lsa": gen_lsa,
-            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "bytetrack": gen_bytetrack, "botsort": gen_botsort, "deepocsort": gen_deepocsort, "clearmot": gen_clearmot, "mot_io": gen_mot_io, "ssort_camera": gen_ssort_camera, "botsort_gmc": gen_botsort_gmc, "deepocsort_cmc": gen_deepocsort_cmc, "ssort_setorder": gen_ssort_setorder, "nms": gen_nms}
+            "coords": gen_coords, "bpbss": gen_bpbss, "kf8": gen_kf8, "hota": gen_hota, "cosine": gen_cosine, "motion": gen_motion_costs, "ssort": gen_ssort, "pil": gen_pil_preprocess, "pil_sweep": gen_pil_sweep, "bytetrack": gen_bytetrack, "botsort": gen_botsort, "deepocsort": gen_deepocsort, "clearmot": gen_clearmot, "mot_io": gen_mot_io, "ssort_camera": gen_ssort_camera, "botsort_gmc": gen_botsort_gmc, "deepocsort_cmc": gen_deepocsort_cmc, "ssort_setorder": gen_ssort_setorder, "nms": gen_nms}
     for k, fn in gens.items():
         if not only or k in only:
             fn(out_dir)

@@ -354,3 +354,36 @@ def test_the_older_pil_crop_kernel_stays_bit_exact(env):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_image.py"), "-m", "gpu", "-q", "-x", "-k", "test_pil_ and not older"],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_pil_wave_kernel_against_pillow_over_a_sweep_of_crop_sizes(tag):
+    """r03 fixture pil_sweep.npz, made by Pillow itself: 40 crops of 2 .. 200 x 2 .. 600 px (2 / 3 / 5 taps per axis, scales around 1.2 and 2, staged and
+    direct crops, clipped and tiny ones, a 3 x 500 crop that Pillow's Image.resize resizes VERTICALLY first; frame widths 1280 and 1283). The 16-bit NHWC
+    output (pil_wave_kernel) is mapped back to uint8 through the normalisation table and compared by SHA-256 and every 8th row; fp32 NCHW (pil_crop_kernel) too."""
+    import hashlib
+
+    import torch
+    from test_oracle_motion import _pil_sweep_frame
+    from tracklab_amd import _lib
+    g = np.load(os.path.join(GOLDEN, "pil_sweep.npz"))
+    img = _pil_sweep_frame(int(g[f"width_{tag}"]))
+    n = len(g[f"boxes_{tag}"])
+    boxes = torch.zeros((1, n, 7), dtype=torch.float64, device="cuda")
+    boxes[0, :, :4] = torch.from_numpy(g[f"boxes_{tag}"]).cuda()
+    counts = torch.tensor([n], dtype=torch.int32, device="cuda")
+    d = torch.from_numpy(img).cuda()[None].contiguous()
+    lut = g["norm_lut"]                                     # (3, 256) float32, strictly increasing per channel
+    for dtype, layout in ((torch.float16, "nhwc"), (torch.bfloat16, "nhwc"), (torch.float32, "nchw")):
+        out = _lib.roi_crop_pil_resize_norm(d, boxes, counts, 256, 128, layout, dtype).float().cpu().numpy()       # logical (n, 3, 256, 128)
+        table = torch.from_numpy(lut).to(dtype).float().numpy()
+        assert all(len(np.unique(table[c])) == 256 for c in range(3)) or dtype == torch.bfloat16
+        for i in range(n):
+            if dtype == torch.bfloat16:                    # 8 mantissa bits do not separate the 256 levels: compare the values themselves on the stored rows
+                exp = np.stack([table[c][g[f"rows_{tag}"][i][:, :, c]] for c in range(3)])
+                np.testing.assert_array_equal(out[i][:, ::8], exp, err_msg=f"box {i} bf16")
+                continue
+            u8 = np.stack([np.searchsorted(table[c], out[i, c]) for c in range(3)], axis=-1).astype(np.uint8)    # (256, 128, 3)
+            np.testing.assert_array_equal(np.stack([table[c][u8[:, :, c]] for c in range(3)]), out[i], err_msg=f"box {i}: not table values")
+            np.testing.assert_array_equal(u8[::8], g[f"rows_{tag}"][i], err_msg=f"box {i} {dtype} {g[f'boxes_int_{tag}'][i]}")
+            assert hashlib.sha256(np.ascontiguousarray(u8).tobytes()).hexdigest() == str(g[f"sha_{tag}"][i]), f"box {i} {dtype}"

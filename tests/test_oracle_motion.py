@@ -3,6 +3,7 @@
 import os
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN
 
@@ -57,4 +58,32 @@ def test_pil_reid_preprocess_matches_pillow(orc):
         if f"norm{i}" in g.files:
             np.testing.assert_array_equal(out, g[f"norm{i}"])
         for c in range(3):                         # every crop: normalisation = the (value, channel) table torch produced
+            np.testing.assert_array_equal(out[c], g["norm_lut"][c][u8[:, :, c]])
+
+
+def _pil_sweep_frame(w_img, H=720):
+    """tests/golden/make_golden.py::pil_sweep_image restated (the fixture stores hashes, not the 2.7 MB frames)."""
+    yy, xx = np.mgrid[0:H, 0:w_img].astype(np.int64)
+    tex = ((xx * 1103515245 + yy * 12345 + xx * yy * 7) >> 3) % 13 - 6
+    img = np.stack([(xx * 255 // w_img) + tex, (yy * 255 // H) - tex, ((xx * 3 + yy * 5) % 256) + tex // 2], axis=2)
+    for k in range(60):
+        x, y = (k * 197) % (w_img - 90), (k * 113) % (H - 170)
+        w, h = 10 + (k * 31) % 70, 10 + (k * 53) % 150
+        img[y:y + h, x:x + w] = [(k * 37) % 256, (k * 91) % 256, (k * 151) % 256]
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_pil_reid_preprocess_matches_pillow_over_a_sweep_of_crop_sizes(orc, tag):
+    """r03 fixture pil_sweep.npz: 40 crops of 2 .. 200 x 2 .. 600 px through Pillow itself (2 / 3 / 5 taps per axis, scales around 1.2 and 2, clipped
+    and tiny crops; frame widths 1280 and 1283): SHA-256 of the full resized array and every 8th row equal."""
+    import hashlib
+    g = np.load(os.path.join(GOLDEN, "pil_sweep.npz"))
+    img = _pil_sweep_frame(int(g[f"width_{tag}"]))
+    np.testing.assert_array_equal(orc.ssort_crop_box(g[f"boxes_{tag}"], img.shape[1], img.shape[0]), g[f"boxes_int_{tag}"])
+    for i, b in enumerate(g[f"boxes_{tag}"]):
+        out, u8 = orc.ssort_reid_preprocess(img, b)
+        np.testing.assert_array_equal(u8[::8], g[f"rows_{tag}"][i], err_msg=f"box {i}")
+        assert hashlib.sha256(np.ascontiguousarray(u8).tobytes()).hexdigest() == str(g[f"sha_{tag}"][i]), f"box {i}"
+        for c in range(3):
             np.testing.assert_array_equal(out[c], g["norm_lut"][c][u8[:, :, c]])

@@ -2126,6 +2126,49 @@ __device__ __forceinline__ void pil_hsample(const unsigned char *__restrict__ ro
     o[0] = pil_clip8(s0); o[1] = pil_clip8(s1); o[2] = pil_clip8(s2);
 }
 
+// Image.resize's own rule (PIL/Image.py, Pillow 12.2.0: `if self.size[1] > self.size[0] * 100 and size[1] < self.size[1]`): an image more than 100
+// times taller than wide that shrinks vertically is resized VERTICALLY first and horizontally afterwards -- the uint8 rounding between the passes
+// happens in the other order. A 3 x 301 px box; found by the r03 sweep fixture (tests/golden/pil_sweep.npz). Such crops take the direct path.
+__host__ __device__ __forceinline__ bool pil_vertical_first(int cw, int ch, int OH) { return ch > cw * 100 && OH < ch; }
+
+// one output pixel (3 channels, already clipped to 0..255) of the direct path, in Pillow's pass order for this crop; rolled loops on purpose
+__device__ __forceinline__ void pil_direct_px(const unsigned char *__restrict__ base, int W, const PilAxis &ax, const PilAxis &ay, int cw, int ch, int OH,
+                                              int y, int x, int (&s)[3])
+{
+    int ymin, ymax;
+    pil_bounds(ay, ch, y, ymin, ymax);
+    const double wwy = pil_wsum(ay, y, ymin, ymax);
+    s[0] = s[1] = s[2] = 1 << (PIL_BITS - 1);
+    if (!pil_vertical_first(cw, ch, OH)) {
+        // every vertical tap recomputes its horizontally resampled (and uint8-rounded) sample from global memory
+#pragma nounroll
+        for (int t = 0; t < ymax; ++t) {
+            const int kv = pil_fixed(ay, y, ymin, t, wwy);
+            int hv[3];
+            pil_hsample(base + (size_t)(ymin + t) * W * 3, ax, cw, x, hv);
+            s[0] += hv[0] * kv; s[1] += hv[1] * kv; s[2] += hv[2] * kv;
+        }
+    } else {
+        // every horizontal tap recomputes its vertically resampled (and uint8-rounded) sample
+        int xmin, xmax;
+        pil_bounds(ax, cw, x, xmin, xmax);
+        const double wwx = pil_wsum(ax, x, xmin, xmax);
+#pragma nounroll
+        for (int xt = 0; xt < xmax; ++xt) {
+            const int kh = pil_fixed(ax, x, xmin, xt, wwx);
+            int v0 = 1 << (PIL_BITS - 1), v1 = v0, v2 = v0;
+#pragma nounroll
+            for (int t = 0; t < ymax; ++t) {
+                const int kv = pil_fixed(ay, y, ymin, t, wwy);
+                const unsigned char *p = base + ((size_t)(ymin + t) * W + (xmin + xt)) * 3;
+                v0 += (int)p[0] * kv; v1 += (int)p[1] * kv; v2 += (int)p[2] * kv;
+            }
+            s[0] += pil_clip8(v0) * kh; s[1] += pil_clip8(v1) * kh; s[2] += pil_clip8(v2) * kh;
+        }
+    }
+    s[0] = pil_clip8(s[0]); s[1] = pil_clip8(s[1]); s[2] = pil_clip8(s[2]);
+}
+
 // byte q of a little-endian word array (constant q: the shift folds into an SDWA byte select of the multiply)
 template <int NW> __device__ __forceinline__ int byte_of(const unsigned (&w)[NW], int q) { return (int)((w[q >> 2] >> ((q & 3) * 8)) & 0xffu); }
 
@@ -2167,7 +2210,8 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
     if (valid) { ssort_crop_box(boxes + ((size_t)b * max_n + i) * box_stride, W, H, x1, y1, x2, y2); valid = (x2 > x1) && (y2 > y1); }
     const int cw = x2 - x1, ch = y2 - y1;
     const PilAxis ax = pil_axis(valid ? cw : 1, OW), ay = pil_axis(valid ? ch : 1, OH);
-    const bool h_ok = valid && OW <= PIL_OW_MAX && cw * 3 + STAGE_PAD <= PIL_ROW_BYTES && ax.ksize <= PIL_KMAX && ay.ksize <= PIL_KMAX;
+    const bool h_ok = valid && OW <= PIL_OW_MAX && cw * 3 + STAGE_PAD <= PIL_ROW_BYTES && ax.ksize <= PIL_KMAX && ay.ksize <= PIL_KMAX &&
+                      !pil_vertical_first(cw, ch, OH);        // (Pillow resizes such a crop vertically first: direct branch)
     if (h_ok && tid < OW) {                                                     // horizontal coefficient rows
         int xmin, xmax;
         pil_bounds(ax, cw, tid, xmin, xmax);
@@ -2274,22 +2318,14 @@ __global__ void __launch_bounds__(BLOCK) pil_crop_kernel(const unsigned char *__
 #pragma unroll
                 for (int c = 0; c < 3; ++c) px[k][c] = s_lut[c][pil_clip8(acc[k * 3 + c])];
         } else if (valid) {
-            // direct branch: every vertical tap recomputes its horizontally resampled (and uint8-rounded) sample from global memory
-            int ymin, ymax;
-            pil_bounds(ay, ch, y, ymin, ymax);
-            const double wwy = pil_wsum(ay, y, ymin, ymax);
+            // direct branch (pil_direct_px: recompute per output pixel, in Pillow's pass order for this crop)
             const unsigned char *base = frames + ((size_t)b * H * W + (size_t)y1 * W + x1) * 3;
             for (int k = 0; k < 8; ++k) {
-                int s[3] = {1 << (PIL_BITS - 1), 1 << (PIL_BITS - 1), 1 << (PIL_BITS - 1)};
-                for (int t = 0; t < ymax; ++t) {
-                    const int kv = pil_fixed(ay, y, ymin, t, wwy);
-                    int hv[3];
-                    pil_hsample(base + (size_t)(ymin + t) * W * 3, ax, cw, x_base + k, hv);
-                    s[0] += hv[0] * kv; s[1] += hv[1] * kv; s[2] += hv[2] * kv;
-                }
+                int s[3];
+                pil_direct_px(base, W, ax, ay, cw, ch, OH, y, x_base + k, s);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    float f = (float)pil_clip8(s[c]) / 255.0f; f = f - mean[c]; f = f / stdv[c];
+                    float f = (float)s[c] / 255.0f; f = f - mean[c]; f = f / stdv[c];
                     px[k][c] = cvt<T>(f);
                 }
             }
@@ -2366,27 +2402,18 @@ template <typename T>
 __device__ __forceinline__ void pil_direct_unit_nhwc(const unsigned char *__restrict__ base, int W, int cw, int ch, int OH, int OW, int y, int x_base,
                                                   float m0, float m1, float m2, float d0, float d1, float d2, int swap_rb, T *__restrict__ out, size_t slot)
 {
-    // every vertical tap recomputes its horizontally resampled (and uint8-rounded) sample from global memory (the direct branch of pil_crop_kernel)
+    // pil_direct_px: recompute per output pixel, in Pillow's pass order for this crop (the direct branch of pil_crop_kernel)
     const PilAxis ax = pil_axis(cw, OW), ay = pil_axis(ch, OH);
     const float mean[3] = {m0, m1, m2}, stdv[3] = {d0, d1, d2};
-    int ymin, ymax;
-    pil_bounds(ay, ch, y, ymin, ymax);
-    const double wwy = pil_wsum(ay, y, ymin, ymax);
     T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
 #pragma nounroll
     for (int k = 0; k < 8; ++k) {                        // (rolled on purpose: a rare path must not set the register budget of the kernel that calls it)
-        int s[3] = {1 << (PIL_BITS - 1), 1 << (PIL_BITS - 1), 1 << (PIL_BITS - 1)};
-#pragma nounroll
-        for (int t = 0; t < ymax; ++t) {
-            const int kv = pil_fixed(ay, y, ymin, t, wwy);
-            int hv[3];
-            pil_hsample(base + (size_t)(ymin + t) * W * 3, ax, cw, x_base + k, hv);
-            s[0] += hv[0] * kv; s[1] += hv[1] * kv; s[2] += hv[2] * kv;
-        }
+        int s[3];
+        pil_direct_px(base, W, ax, ay, cw, ch, OH, y, x_base + k, s);
         T px[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float f = (float)pil_clip8(s[c]) / 255.0f; f = f - mean[c]; f = f / stdv[c];
+            float f = (float)s[c] / 255.0f; f = f - mean[c]; f = f / stdv[c];
             px[c] = cvt<T>(f);
         }
         if (swap_rb) { const T t0 = px[0]; px[0] = px[2]; px[2] = t0; }
@@ -2424,7 +2451,8 @@ __global__ void __launch_bounds__(BLOCK) pil_wave_kernel(const unsigned char *__
     const bool valid = (x2 > x1) && (y2 > y1);
     const int cw = x2 - x1, ch = y2 - y1;
     const PilAxis ax = pil_axis(valid ? cw : 1, OW), ay = pil_axis(valid ? ch : 1, OH);
-    const bool tabs_ok = valid && cw * 3 + STAGE_PAD <= CS_ROW_BYTES && ax.ksize <= PIL_KMAX && ay.ksize <= PIL_KMAX;
+    const bool tabs_ok = valid && cw * 3 + STAGE_PAD <= CS_ROW_BYTES && ax.ksize <= PIL_KMAX && ay.ksize <= PIL_KMAX &&
+                         !pil_vertical_first(cw, ch, OH);     // (Pillow resizes such a crop vertically first: direct path)
     auto wave_max = [](int v) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
