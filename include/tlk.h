@@ -604,6 +604,23 @@ int tlk_clear_sequence_dev_f64(const int32_t *gt_ids_dev, const double *gt_ltwh_
 int tlk_bias_act_nhwc(void *x_dev, const void *bias_dev, const void *residual_dev, long long rows, int channels,
                       int act_kind, int dtype, void *hip_stream);
 
+/* fp32 convolution of a channels-last activation with the convolution epilogue inside -- the backbones at the REFERENCE's precision
+ * (the reference runs them in fp32: configs/modules/track/strong_sort.yaml:10 `fp16: false`; ONNXRuntime fp32 behind
+ * wrappers/bbox_detector/rtmlib_api.py:21 and wrappers/pose_estimator/rtmlib_api.py:21; torchreid fp32 behind wrappers/reid/kpreid_api.py:147-182):
+ *   y[n,ho,wo,co] = act( sum_{kh,kw,ci} x[n, ho*stride+kh-pad, wo*stride+kw-pad, ci] * w[co,kh,kw,ci] + bias[co] (+ residual[n,ho,wo,co]) )
+ * x (n,h,w,cin) and y (n,ho,wo,cout) are NHWC (torch channels_last), w is (cout,kh,kw,cin) (torch's channels_last weight), cin % 4 == 0,
+ * x and w 16-byte aligned; bias / residual may be NULL; act 0 none / 1 ReLU / 2 SiLU.  *_pix_stride = floats between two pixels of x / y /
+ * residual (0 = densely packed): a call may read or write a channel slice of a wider tensor (e.g. its part of a concatenation).
+ * Hand-written implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, tlk_conv.hip).  Each output element is ONE fmaf chain over
+ * k = (kh,kw,ci) in the order 0,4,1,5,2,6,3,7 within every group of 8 (groups ascending, zero terms where the tap is outside the image),
+ * then + bias, + residual, activation: bit-identical for every tile configuration and to oracle/src/conv.c. */
+int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev, float *y_dev,
+                        int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int act_kind,
+                        int x_pix_stride, int y_pix_stride, int res_pix_stride, void *hip_stream);
+/* Probes / tests: force one of the kernel's tile configurations (0: 128x128, 1: 256x64, 2: 256x128, 3: 256x96, 4: 256x32, 5: 64x128
+ * pixels x output channels); -1 = the heuristic.  Results do not depend on it. */
+int tlk_conv2d_set_config(int cfg);
+
 /* 1x1 convolution of a channels-last tensor as ONE GEMM with the convolution epilogue inside:
  *   out[M,N] = act(x[M,K] . w[N,K]^T + bias[N] (+ residual[M,N])),  act 0 none / 1 ReLU / 2 SiLU, dtype TLK_F16 or TLK_BF16.
  * hipBLASLt (library GEMM, taken from the process with dlopen) with its BIAS / RELU_BIAS / SWISH_BIAS epilogue and beta*C for

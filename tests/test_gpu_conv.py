@@ -1,0 +1,112 @@
+"""tlk_conv2d_nhwc_f32 (csrc/tlk_conv.hip): the fp32 MFMA convolution with fused epilogue.
+  * bit-exact against oracle/src/conv.c (same fmaf chain) for every tile configuration, ragged shapes, strides, taps outside the image,
+    residual, channel-sliced input / output;
+  * within fp32 round-off of torch's own convolution (the reference's backbones are third-party fp32 networks: tolerance, stated here);
+  * the fp32 ReID / detector forward through the kernel == the same modules on torch's library route, to that tolerance."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # n, h, w, cin, cout, k, stride, act, residual
+    (2, 9, 7, 8, 5, 3, 1, "relu", False),
+    (1, 12, 10, 4, 64, 7, 2, "relu", False),        # the ResNet stem with the input padded to 4 channels
+    (3, 8, 8, 64, 64, 1, 1, "relu", True),
+    (2, 11, 5, 32, 96, 3, 2, None, True),
+    (1, 6, 6, 36, 130, 3, 1, "relu", False),        # K = 324: not a multiple of 32; Cout ragged
+    (2, 5, 9, 128, 256, 1, 2, None, False),         # strided 1x1 (downsample branch)
+    (1, 16, 16, 12, 48, 3, 1, "none", False),       # YOLOX Focus stem shape
+    (5, 4, 3, 8, 33, 5, 1, "relu", True),
+]
+
+
+def _run(case, cfg):
+    import oracle
+    from tracklab_amd import _lib
+    n, h, w, cin, cout, k, s, act, res = case
+    rng = np.random.default_rng(hash(case[:7]) & 0xffff)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((cout, k, k, cin)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    exp = oracle.conv2d_nhwc_f32(x, wt, b, None, stride=s, act=act)
+    r = rng.standard_normal(exp.shape).astype(np.float32) if res else None
+    if res:
+        exp = oracle.conv2d_nhwc_f32(x, wt, b, r, stride=s, act=act)
+    xt = torch.from_numpy(x).cuda().permute(0, 3, 1, 2)
+    wtt = torch.from_numpy(wt).cuda().permute(0, 3, 1, 2)
+    rt = torch.from_numpy(r).cuda().permute(0, 3, 1, 2) if res else None
+    _lib.lib(); _lib.conv2d_nhwc_f32(xt[:0], wtt, None)          # binds the symbols
+    _lib.check(_lib.lib().tlk_conv2d_set_config(cfg))
+    try:
+        y = _lib.conv2d_nhwc_f32(xt, wtt, torch.from_numpy(b).cuda(), act, rt, stride=s)
+    finally:
+        _lib.lib().tlk_conv2d_set_config(-1)
+    return y.permute(0, 2, 3, 1).cpu().numpy(), exp
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_is_bit_exact_with_the_oracle_chain(case, cfg):
+    got, exp = _run(case, cfg)
+    assert got.shape == exp.shape
+    assert np.array_equal(got, exp), f"max |diff| {np.abs(got - exp).max()}"
+
+
+def test_silu_within_exp_roundoff():
+    got, exp = _run((2, 10, 10, 16, 40, 3, 1, "silu", False), -1)
+    np.testing.assert_allclose(got, exp, rtol=2e-6, atol=1e-6)      # device exp vs libm expf
+
+
+def test_channel_slices_in_and_out():
+    """reads a channel slice of a wider tensor and writes into a slice of a concatenation buffer (pixel strides)"""
+    import oracle
+    from tracklab_amd import _lib
+    rng = np.random.default_rng(3)
+    wide = torch.from_numpy(rng.standard_normal((2, 7, 6, 24)).astype(np.float32)).cuda().permute(0, 3, 1, 2)
+    x = wide[:, 8:16]
+    wt = (rng.standard_normal((12, 3, 3, 8)) * 0.1).astype(np.float32)
+    cat = torch.zeros((2, 7, 6, 20), device="cuda").permute(0, 3, 1, 2)
+    _lib.conv2d_nhwc_f32(x, torch.from_numpy(wt).cuda().permute(0, 3, 1, 2), None, "relu", out=cat[:, 4:16])
+    exp = oracle.conv2d_nhwc_f32(x.permute(0, 2, 3, 1).cpu().numpy(), wt, None, None, act="relu")
+    got = cat.permute(0, 2, 3, 1).cpu().numpy()
+    assert np.array_equal(got[..., 4:16], exp) and not got[..., :4].any() and not got[..., 16:].any()
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 96, 32, 64, 3, 1), (64, 256, 48, 16, 128, 1, 1), (32, 512, 24, 8, 512, 3, 1), (4, 96, 80, 80, 96, 3, 2)])
+def test_conv_within_fp32_roundoff_of_torch(shape):
+    """tolerance vs torch's fp64 convolution: |err| <= 2e-6 * (|x| conv |w|) -- a few fp32 ulps of the absolute-value sum, K up to 4608"""
+    from tracklab_amd import _lib
+    n, cin, h, w, cout, k, s = shape
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn((n, cin, h, w), device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn((cout, cin, k, k), device="cuda", generator=g) * 0.05).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(cout, device="cuda", generator=g)
+    y = _lib.conv2d_nhwc_f32(x, wt, b, "relu", stride=s)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), b.double(), s, k // 2))
+    bound = F.conv2d(x.double().abs(), wt.double().abs(), b.double().abs(), s, k // 2)
+    assert y.shape == ref.shape
+    assert bool(((y.double() - ref).abs() <= 2e-6 * bound + 1e-30).all()), float(((y.double() - ref).abs() / bound).max())
+
+
+def test_fp32_networks_on_the_kernel_match_the_library_route():
+    """ReID ResNet-50 and YOLOX-s forward in fp32: hand-written convolutions vs torch / MIOpen convolutions, same weights"""
+    from tracklab_amd.backbones import common
+    from tracklab_amd.backbones.reid import part_based_reid
+    from tracklab_amd.backbones.yolox import yolox
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for net, x in ((part_based_reid(dtype=torch.float32), torch.randn((6, 4, 384, 128), device="cuda", generator=g)[:, :3]),
+                   (yolox("s", dtype=torch.float32), torch.rand((2, 3, 640, 640), device="cuda", generator=g) * 255)):
+        x = x.contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            got = net(x)
+            common.USE_TLK_CONV_F32 = False
+            try:
+                exp = net(x)
+            finally:
+                common.USE_TLK_CONV_F32 = True
+        got, exp = (got[0], exp[0]) if isinstance(got, tuple) else (got, exp)
+        scale = float(exp.abs().max())
+        assert float((got - exp).abs().max()) <= 2e-4 * scale, (float((got - exp).abs().max()), scale)

@@ -968,6 +968,41 @@ def bias_act_(x, bias, act="relu", residual=None):
     return x
 
 
+def conv2d_nhwc_f32(x, weight, bias=None, act=None, residual=None, stride=1, pad=None, out=None):
+    """fp32 convolution + bias + residual + activation in ONE hand-written MFMA kernel (tlk_conv2d_nhwc_f32).
+    x: (N, Cin, H, W) float32 cuda tensor in channels_last memory (or a channel slice of one); weight: (Cout, Cin, KH, KW) channels_last;
+    residual / out: (N, Cout, Ho, Wo) channels_last (or channel slices).  Returns out (allocated channels_last when None)."""
+    import torch
+    L = lib()
+    if not getattr(L, "_conv_bound", False):
+        L.tlk_conv2d_nhwc_f32.argtypes = [C.c_void_p] * 5 + [C.c_int] * 13 + [C.c_void_p]
+        L.tlk_conv2d_set_config.argtypes = [C.c_int]
+        L._conv_bound = True
+    N, Cin, H, W = x.shape
+    Cout, Cw, KH, KW = weight.shape
+    if pad is None:
+        pad = (KH - 1) // 2
+    assert x.dtype == torch.float32 and weight.dtype == torch.float32 and Cw == Cin
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+
+    def pix(t, c, h, w):       # pixel stride (floats) of an NHWC tensor or channel slice of one
+        sn, sc, sh, sw = t.stride()
+        if t.shape[0] == 0:
+            return c
+        assert (sc == 1 or c == 1) and sh == w * sw and (sn == h * sh or t.shape[0] == 1), "tensor must be channels_last (or a channel slice of one)"
+        return sw
+    wk = weight if weight.is_contiguous(memory_format=torch.channels_last) or (KH == 1 and KW == 1 and weight.is_contiguous()) \
+        else weight.contiguous(memory_format=torch.channels_last)
+    if out is None:
+        out = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    check(L.tlk_conv2d_nhwc_f32(x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                residual.data_ptr() if residual is not None else None, out.data_ptr(),
+                                N, H, W, Cin, Cout, KH, KW, stride, pad, ACT[act],
+                                pix(x, Cin, H, W), pix(out, Cout, Ho, Wo), pix(residual, Cout, Ho, Wo) if residual is not None else 0,
+                                current_stream_ptr()))
+    return out
+
+
 def cosine_gallery_min(gallery, offsets, dets):
     """gallery (G, D) f32, offsets (T+1,) int32 (CSR per track), dets (N, D) f32 cuda tensors -> (T, N) f64."""
     import torch

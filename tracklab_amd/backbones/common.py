@@ -10,6 +10,9 @@ import os as _os
 
 USE_GEMM_1X1 = _os.environ.get("TLK_CONV1X1_GEMM", "1") != "0"
 USE_FUSED_GEMM = _os.environ.get("TLK_FUSED_GEMM", "1") != "0"
+# fp32 (the reference's precision): every convolution + its epilogue is ONE launch of libtlk's hand-written fp32 MFMA kernel
+# (tlk_conv2d_nhwc_f32, csrc/tlk_conv.hip); TLK_CONV_F32=0 restores the library route (MIOpen + separate torch epilogue passes) for A/B runs.
+USE_TLK_CONV_F32 = _os.environ.get("TLK_CONV_F32", "1") != "0"
 
 
 def epilogue_(x: torch.Tensor, bias: torch.Tensor, act: str | None, residual: torch.Tensor | None = None) -> torch.Tensor:
@@ -42,6 +45,12 @@ class ConvBiasAct(nn.Module):
         self.act = act
 
     def forward(self, x, residual=None):
+        if USE_TLK_CONV_F32 and x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 \
+                and x.is_contiguous(memory_format=torch.channels_last):
+            from .. import _lib
+            if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
+                residual = residual.contiguous(memory_format=torch.channels_last)
+            return _lib.conv2d_nhwc_f32(x, self.conv.weight, self.bias, self.act, residual, self.conv.stride[0], self.conv.padding[0])
         if USE_GEMM_1X1 and self.conv.kernel_size == (1, 1) and self.conv.stride == (1, 1) and x.is_cuda \
                 and x.is_contiguous(memory_format=torch.channels_last):
             # a channels-last 1x1 convolution IS a plain GEMM (rows = N*H*W): hand it to hipBLASLt

@@ -1,0 +1,260 @@
+// tlk_conv.hip -- fp32 convolution of the backbones at the REFERENCE's precision, hand-written for gfx950:
+// implicit GEMM on v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit-for-bit a k-ordered fmaf chain, no reduced-precision
+// path exists on this chip) with the convolution epilogue -- bias, residual add, ReLU / SiLU -- fused into the store.
+//
+// The reference runs its detector / ReID / pose networks in fp32 (tracklab/configs/modules/track/strong_sort.yaml:10 `fp16: false`;
+// ONNXRuntime fp32 models behind wrappers/bbox_detector/rtmlib_api.py:21 and wrappers/pose_estimator/rtmlib_api.py:21; torchreid fp32
+// behind wrappers/reid/kpreid_api.py:147-182).  In fp32 the library route of r01-r03 (MIOpen igemm / CK grouped conv + separate
+// bias / activation / residual passes) ran the config-3 step at 375 ms; this kernel is what the fp32 step runs on from r04.
+//
+// GEMM view (channels-last activations, weights (Cout, KH, KW, Cin) = torch's channels_last weight):
+//     Y[m][co] = act( sum_k A[m][k] * Wt[co][k] + bias[co] (+ R[m][co]) ),   m = (n, ho, wo),  k = (kh, kw, ci)
+// A is gathered on the fly (zero outside the image / beyond K / beyond M), never materialised.
+//   * workgroup tile BM x BN = (WGM*TM*32) x (WGN*TN*32), K step 32; 4 wavefronts; each wavefront owns TM x TN MFMA tiles of 32x32;
+//   * global -> registers -> LDS, 16 B per lane both ways; the LDS rows are padded to 36 floats so that the ds_read_b128 fragment reads
+//     (16-lane groups of the wide read) and the ds_write_b128 staging writes touch every bank once;
+//   * LDS double-buffered: the global loads of step s+1 are in flight while step s runs its 16 * TM * TN MFMAs (64 cycles each), one
+//     barrier per step;
+//   * one ds_read_b128 feeds FOUR MFMAs: lane l holds k = 8j + 4*(l>>5) + r for r = 0..3, so MFMA r of group j multiplies the k pair
+//     (8j + r, 8j + 4 + r) -- the summation order over k is therefore 0,4,1,5,2,6,3,7 within every group of 8, groups ascending.  That
+//     order is part of the contract: oracle/src/conv.c walks the same chain with fmaf and the results are BIT-IDENTICAL for every tile
+//     configuration (no split-K, one accumulator chain per output element);
+//   * blockIdx -> tile mapping is XCD-aware: consecutive tiles (same rows of A, neighbouring column tiles of W) land on one XCD's L2.
+#include "tlk_common.hpp"
+
+using namespace tlk;
+
+namespace {
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+constexpr int BK = 32;            // K step (floats)
+constexpr int LDK = BK + 4;       // padded LDS row: 36 floats = 144 B
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+    const float *x, *w, *bias, *res;
+    float *y;
+    long long M;                  // N * Ho * Wo
+    int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, K;
+    int x_pix, y_pix, r_pix;      // floats between two pixels of x / y / residual (>= channel count: lets a call read or write a channel
+                                  // slice of a wider tensor, e.g. write straight into its part of a concatenation)
+    int tiles_n;
+    long long tiles;
+};
+
+template <int ACT> __device__ __forceinline__ float act_f32(float v)
+{
+    if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ACT == ACT_SILU) return v / (1.f + __expf(-v));
+    return v;
+}
+
+template <int TM, int TN, int WGM, int WGN, int ACT, bool RES>
+__global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const ConvArgs p)
+{
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int ROWS_PER_PASS = NT / 8;                 // 8 lanes x 16 B cover one 32-float row slice
+    constexpr int PA = BM / ROWS_PER_PASS, PB = BN / ROWS_PER_PASS;
+    static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile rows must be a multiple of the loader pass");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *As = lds;                                       // [2][BM][LDK]
+    float *Bs = lds + 2 * BM * LDK;                        // [2][BN][LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // XCD-aware tile order: hardware deals consecutive workgroups round-robin to the 8 XCDs; give each XCD a contiguous run of tiles
+    long long tile;
+    {
+        const long long b = blockIdx.x, q = p.tiles >> 3;
+        const int r = (int)(p.tiles & 7), xcd = (int)(b & 7);
+        tile = (long long)xcd * q + (xcd < r ? xcd : r) + (b >> 3);
+    }
+    const long long m0 = (tile / p.tiles_n) * BM;
+    const int n0 = (int)(tile % p.tiles_n) * BN;
+
+    // ---- loader geometry: this lane moves chunk `lc` (4 floats of k) of row `lr + pass * ROWS_PER_PASS`
+    const int lr = tid >> 3, lc = tid & 7;
+    int a_hi0[PA], a_wi0[PA];
+    long long a_base[PA];                                  // pixel index of (n, 0, 0); -1 = row beyond M
+#pragma unroll
+    for (int ps = 0; ps < PA; ++ps) {
+        const long long m = m0 + lr + ps * ROWS_PER_PASS;
+        if (m < p.M) {
+            const long long n = m / ((long long)p.Ho * p.Wo);
+            const int rem = (int)(m - n * (long long)p.Ho * p.Wo);
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            a_hi0[ps] = ho * p.stride - p.pad; a_wi0[ps] = wo * p.stride - p.pad; a_base[ps] = n * (long long)p.H * p.W;
+        } else { a_hi0[ps] = 0; a_wi0[ps] = 0; a_base[ps] = -1; }
+    }
+    const float *b_row[PB];
+#pragma unroll
+    for (int ps = 0; ps < PB; ++ps) {
+        const int co = n0 + lr + ps * ROWS_PER_PASS;
+        b_row[ps] = co < p.Cout ? p.w + (long long)co * p.K : nullptr;
+    }
+
+    float4 ra[PA], rb[PB];
+    auto load_global = [&](int k0) {
+        const int k = k0 + lc * 4;
+        const bool kin = k < p.K;
+        int kh = 0, kw = 0, ci = k;
+        if (p.KH * p.KW != 1) { const int tap = k / p.Cin; ci = k - tap * p.Cin; kh = tap / p.KW; kw = tap - kh * p.KW; }
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) {
+            const int hi = a_hi0[ps] + kh, wi = a_wi0[ps] + kw;
+            const bool ok = kin && a_base[ps] >= 0 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            ra[ps] = ok ? *reinterpret_cast<const float4 *>(p.x + (a_base[ps] + (long long)hi * p.W + wi) * p.x_pix + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int ps = 0; ps < PB; ++ps)
+            rb[ps] = (kin && b_row[ps]) ? *reinterpret_cast<const float4 *>(b_row[ps] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_lds = [&](int buf) {
+        float *a = As + buf * BM * LDK + lr * LDK + lc * 4, *b = Bs + buf * BN * LDK + lr * LDK + lc * 4;
+#pragma unroll
+        for (int ps = 0; ps < PA; ++ps) *reinterpret_cast<float4 *>(a + ps * ROWS_PER_PASS * LDK) = ra[ps];
+#pragma unroll
+        for (int ps = 0; ps < PB; ++ps) *reinterpret_cast<float4 *>(b + ps * ROWS_PER_PASS * LDK) = rb[ps];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int steps = (p.K + BK - 1) / BK;
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    const int frag_off = (lane & 31) * LDK + (lane >> 5) * 4;
+    for (int s = 0; s < steps; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < steps) load_global((s + 1) * BK);
+        const float *a = As + cur * BM * LDK + (wm * TM * 32) * LDK + frag_off;
+        const float *b = Bs + cur * BN * LDK + (wn * TN * 32) * LDK + frag_off;
+#pragma unroll
+        for (int j = 0; j < BK / 8; ++j) {
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4 *>(a + i * 32 * LDK + j * 8);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) fb[i] = *reinterpret_cast<const float4 *>(b + i * 32 * LDK + j * 8);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj) {
+                        const float av = r == 0 ? fa[i].x : r == 1 ? fa[i].y : r == 2 ? fa[i].z : fa[i].w;
+                        const float bv = r == 0 ? fb[jj].x : r == 1 ? fb[jj].y : r == 2 ? fb[jj].z : fb[jj].w;
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][jj], 0, 0, 0);
+                    }
+        }
+        if (s + 1 < steps) store_lds(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D map of the 32x32 tile: column (= cout) = lane & 31, row (= pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj) {
+        const int co = n0 + (wn * TN + jj) * 32 + (lane & 31);
+        if (co >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const long long mrow = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = mrow + (r & 3) + 8 * (r >> 2);
+                if (m >= p.M) continue;
+                float v = acc[i][jj][r] + bv;
+                if (RES) v += p.res[m * p.r_pix + co];
+                p.y[m * p.y_pix + co] = act_f32<ACT>(v);
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int WGM, int WGN> int launch_cfg(ConvArgs &a, int act, hipStream_t st)
+{
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, NT = 64 * WGM * WGN;
+    constexpr size_t LDS_BYTES = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+    a.tiles_n = (a.Cout + BN - 1) / BN;
+    a.tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
+    if (a.tiles > 0x7fffffffLL) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: too many tiles for one launch");
+    const bool res = a.res != nullptr;
+#define TLK_CONV_LAUNCH(A, R)                                                                                                              \
+    do {                                                                                                                                   \
+        auto kern = conv_f32_mfma_kernel<TM, TN, WGM, WGN, A, R>;                                                                          \
+        static bool attr_set = false;                                                                                                      \
+        if (!attr_set) { TLK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES)); attr_set = true; } \
+        hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles), dim3(NT), LDS_BYTES, st, a);                                                     \
+    } while (0)
+    if (res) { if (act == 0) TLK_CONV_LAUNCH(ACT_NONE, true); else if (act == 1) TLK_CONV_LAUNCH(ACT_RELU, true); else TLK_CONV_LAUNCH(ACT_SILU, true); }
+    else { if (act == 0) TLK_CONV_LAUNCH(ACT_NONE, false); else if (act == 1) TLK_CONV_LAUNCH(ACT_RELU, false); else TLK_CONV_LAUNCH(ACT_SILU, false); }
+#undef TLK_CONV_LAUNCH
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
+
+int g_force_cfg = -1;     // tlk_conv2d_set_config (probes / tests): -1 = heuristic
+
+}  // namespace
+
+extern "C" int tlk_conv2d_set_config(int cfg)
+{
+    if (cfg < -1 || cfg > 5) return fail(TLK_EINVAL, "tlk_conv2d_set_config: cfg must be -1 (heuristic) or 0..5");
+    g_force_cfg = cfg;
+    return TLK_OK;
+}
+
+extern "C" int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev, float *y_dev,
+                                   int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int act_kind,
+                                   int x_pix_stride, int y_pix_stride, int res_pix_stride, void *hip_stream)
+{
+    if (n < 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0)
+        return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: bad shape");
+    if (cin % 4 != 0) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: Cin must be a multiple of 4 (pad the input channels with zeros)");
+    if (act_kind < 0 || act_kind > 2) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: act_kind is 0 (none), 1 (ReLU) or 2 (SiLU)");
+    const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+    if (ho <= 0 || wo <= 0) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: empty output");
+    if (n == 0) return TLK_OK;
+    if (!x_dev || !w_dev || !y_dev) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: null pointer");
+    ConvArgs a;
+    a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.res = residual_dev; a.y = y_dev;
+    a.M = (long long)n * ho * wo;
+    a.H = h; a.W = w; a.Cin = cin; a.Ho = ho; a.Wo = wo; a.Cout = cout; a.KH = kh; a.KW = kw; a.stride = stride; a.pad = pad;
+    a.K = kh * kw * cin;
+    a.x_pix = x_pix_stride > 0 ? x_pix_stride : cin;
+    a.y_pix = y_pix_stride > 0 ? y_pix_stride : cout;
+    a.r_pix = res_pix_stride > 0 ? res_pix_stride : cout;
+    if (a.x_pix < cin || a.y_pix < cout || a.r_pix < cout || a.x_pix % 4 != 0)
+        return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: pixel strides must cover the channels (x stride a multiple of 4)");
+    if (((uintptr_t)x_dev | (uintptr_t)w_dev) & 15) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: x and w must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)hip_stream;
+    // tile configuration: column tile = the smallest of 32 / 64 / 96 / 128 that wastes least of Cout; rows 128 or 256
+    int cfg = g_force_cfg;
+    if (cfg < 0) {
+        const int c = cout;
+        const int w128 = ((c + 127) / 128) * 128, w96 = ((c + 95) / 96) * 96, w64 = ((c + 63) / 64) * 64;
+        if (c <= 32) cfg = 4;
+        else if (w64 < w128 && w64 <= w96) cfg = 1;         // Cout = 64, 192 (3 x 64), 320 ...
+        else if (w96 < w128) cfg = 3;                        // Cout = 96, 288 ...
+        else cfg = 0;
+        if (cfg == 0 && a.M >= 256 * 1024 && cout % 128 == 0) cfg = 2;
+    }
+    switch (cfg) {
+    case 0: return launch_cfg<2, 2, 2, 2>(a, act_kind, st);    // 128 x 128
+    case 1: return launch_cfg<2, 2, 4, 1>(a, act_kind, st);    // 256 x 64
+    case 2: return launch_cfg<4, 2, 2, 2>(a, act_kind, st);    // 256 x 128
+    case 3: return launch_cfg<2, 3, 4, 1>(a, act_kind, st);    // 256 x 96
+    case 4: return launch_cfg<2, 1, 4, 1>(a, act_kind, st);    // 256 x 32
+    default: return launch_cfg<1, 2, 2, 2>(a, act_kind, st);   // 64 x 128 (small M)
+    }
+}
