@@ -84,8 +84,9 @@ def parse(argv=None):
     ap.add_argument("--frames-per-step", type=int, default=None)
     ap.add_argument("--objects", type=int, default=None)
     ap.add_argument("--detector", default=None)
-    ap.add_argument("--dtype", default="f16", choices=list(DTYPES),
-                    help="backbone compute dtype (f32 = the reference's: ONNXRuntime / torchreid fp32; f16 default, tolerance in tests/test_gpu_precision.py)")
+    ap.add_argument("--dtype", default="f32", choices=list(DTYPES),
+                    help="backbone compute dtype. f32 (default) = the reference's precision (ONNXRuntime / torchreid fp32): every convolution runs on "
+                         "libtlk's hand-written fp32 MFMA kernel; f16 / bf16 = the narrower legs (tolerance in tests/test_gpu_precision.py)")
     ap.add_argument("--no-graph", action="store_true", help="eager backbone launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -93,7 +94,8 @@ def parse(argv=None):
                     help="frames verified against the oracle (untimed); default 600 (a full SURVEY 8d stream) where the oracle runs "
                          "faster than ~50 frames/s, 96 for the plain StrongSORT / BoT-SORT / Deep-OC-SORT oracles")
     ap.add_argument("--no-latency-leg", action="store_true", help="skip the small-step legs (frames_per_step 1 / 2 / 4 and 4 streams x 1 frame)")
-    ap.add_argument("--no-f32-leg", action="store_true", help="skip the reference-precision (fp32 backbones) leg of the default f16 run")
+    ap.add_argument("--no-f32-leg", "--no-alt-leg", dest="no_f32_leg", action="store_true",
+                    help="skip the other-precision leg (f16 backbones beside the default fp32 run; fp32 beside an f16 run)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the rocprofv3 --pmc passes for roofline.traffic (static file instead)")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the H2D-inclusive leg (value = value_resident)")
     ap.add_argument("--dry-run", action="store_true",
@@ -703,6 +705,39 @@ def main():
                 "avg_launch_ms": k_ms_avg, "avg_launch_ms_events_raw": k_ms_raw, "event_pair_overhead_ms": null_avg,
                 "rocprofv3_avg_launch_ms": rocprof_ms, "algorithmic_bytes_per_launch": alg_bytes, "units_per_launch": f"{B} frames x {cnt_mean:.1f} crops" if is3 else f"{B} frames"}
 
+    # ---- fp32 runs: the step is bound by the fp32 convolution kernel (csrc/tlk_conv.hip, v_mfma_f32_32x32x2_f32), not by a byte kernel.  Its
+    # roofline: ALGORITHMIC flops of every convolution of one step (2 * pixels * Cout * Cin * KH * KW, the RGB stem counted with 3 channels)
+    # / the sum of their launch durations, HIP events on the launch stream around every launch of two eager passes of both networks over
+    # the step's own buffers (the timed legs replay the same launches from hipGraphs, where events cannot be placed); peak = dense fp32 MFMA.
+    roofline_hbm = None
+    if args.dtype == "f32" and is3:
+        from tracklab_amd.backbones import common as bc
+        if bc.USE_TLK_CONV_F32:
+            with torch.no_grad():
+                pipe.model(pipe.lb, focused=True); pipe.reid(pipe.crops)           # warm (eager)
+                torch.cuda.synchronize()
+                bc.CONV_TIMER = []
+                for _ in range(2):
+                    pipe.model(pipe.lb, focused=True); pipe.reid(pipe.crops)
+                    if pipe.pose is not None:
+                        pipe.pose(pipe.pose_crops)
+                torch.cuda.synchronize()
+                recs, bc.CONV_TIMER = bc.CONV_TIMER, None
+            c_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _, _ in recs)
+            c_null = sum(n0.elapsed_time(n1) for _, _, n0, n1, _ in recs)
+            c_flop = sum(r[4] for r in recs)
+            tf = c_flop / ((c_ms - c_null) * 1e-3) / 1e12
+            roofline_hbm = roofline
+            roofline = {"kernel": "conv_f32_mfma_kernel (tlk_conv2d_nhwc_f32: implicit GEMM on v_mfma_f32_32x32x2_f32, bias / residual / activation fused)",
+                        "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None,
+                        "launches_per_step": len(recs) // 2, "avg_launch_ms": (c_ms - c_null) / len(recs), "avg_launch_ms_events_raw": c_ms / len(recs),
+                        "event_pair_overhead_ms": c_null / len(recs), "algorithmic_flops_per_launch": c_flop / len(recs),
+                        "algorithmic_tflop_per_step": c_flop / 2 / 1e12, "conv_ms_per_step": (c_ms - c_null) / 2,
+                        "units_per_launch": f"one convolution of the step: {B} frames (detector) or {B} x {pipe.maxd} crop slots (ReID); mean over the "
+                                            f"{len(recs) // 2} convolutions of a step, flop-weighted",
+                        "peak_source": "MI355X_MICROARCH.md: fp32-input MFMA 157.3 TFLOP/s dense (no reduced-precision fp32 path on gfx950)",
+                        "rocprofv3": "profiles/r04_config3_f32_rocprof.md: total duration / calls of conv_f32_mfma_kernel<...> of the same command"}
+
     # ---- small-step legs: the same chain at frames_per_step 1 / 2 / 4 and at 4 streams x 1 frame (what an online consumer sees; the
     # reference's online engine is per-frame, engine/video.py:67-117). Each: pipelined frames/s, un-overlapped frame-in -> rows-out time,
     # and for the BPBReID workloads the ids of up to 48 frames per checked stream against the oracle chain ----
@@ -769,13 +804,15 @@ def main():
                         "ms_frame_in_to_rows_out": float(np.median(lat_main) * 1e3), "parity": "see `parity`"})
         pipe.reset()
 
-    # ---- reference-precision leg: the default f16 run also times 3 steps with fp32 backbones (the reference runs its
-    # networks in fp32: ONNXRuntime / torchreid, strong_sort.yaml:10 fp16: false) and checks 48 frames of ids against the oracle chain ----
-    f32_leg = None
-    if rank == 0 and world == 1 and is3 and args.dtype == "f16" and not args.no_f32_leg and not ssort and wl.get("pose") is None:
+    # ---- other-precision leg: the default fp32 run (the reference's precision: ONNXRuntime / torchreid fp32, strong_sort.yaml:10 fp16: false)
+    # also times the f16 backbones (tolerance: tests/test_gpu_precision.py) at the same steps / warm-up, frames resident; an f16 run times fp32.
+    # Either way 48 frames of ids are checked against the oracle chain ----
+    alt_leg = None
+    alt_name = "f16" if args.dtype == "f32" else "f32"
+    if rank == 0 and world == 1 and is3 and args.dtype in ("f16", "f32") and not args.no_f32_leg and not ssort and wl.get("pose") is None:
         import oracle
         saved = tdtype
-        tdtype = torch.float32
+        tdtype = getattr(torch, DTYPES[alt_name])
         pf = make_pipe(F)
         tdtype = saved
         ref_ = oracle.StrongSORT(pf.K, pf.D, **pf.tracker_cfg)
@@ -794,12 +831,17 @@ def main():
                 okf &= len(got) == len(exp) and (len(exp) == 0 or (np.array_equal(got["det_id"], exp["det_id"]) and np.array_equal(got["track_id"], exp["track_id"])))
                 nfr += 1
         pf.reset()
-        el32 = timed_resident(pf, 3, 1)
-        f32_leg = {"value_f32": 3 * B / el32, "ms_per_step_f32": el32 / 3 * 1e3, "steps": 3, "warmup": 1, "frames_resident": True,
+        n_alt, w_alt = (args.steps, args.warmup) if alt_name == "f16" else (max(3, args.steps // 4), 2)
+        ela = timed_resident(pf, n_alt, w_alt)
+        alt_leg = {"dtype": alt_name, "value": n_alt * B / ela, "ms_per_step": ela / n_alt * 1e3, "steps": n_alt, "warmup": w_alt, "frames_resident": True,
                    "parity": {"frames": nfr, "track_ids_equal_oracle": bool(okf)},
-                   "note": "fp32 backbones = the reference's precision; the hand-written kernels are fp64 / fp32 / integer in both legs"}
+                   "note": ("f16 backbones: narrower than the reference's fp32 -- NOT the headline; embeddings agree with the fp32 ones to cos 1e-5 / "
+                            "part-distance 2e-3 on this network (tests/test_gpu_precision.py); the hand-written pre / post-processing and tracker kernels "
+                            "are fp64 / fp32 / integer in both legs") if alt_name == "f16" else
+                           "fp32 backbones = the reference's precision; the hand-written kernels are fp64 / fp32 / integer in both legs"}
         pf.close()
         del pf
+    f32_leg = alt_leg if alt_leg and alt_name == "f32" else None
 
     # ---- CPU baseline: (a) the same chain on host cores (oracle C port + torch CPU fp32 forwards), warm, bounded sample;
     # (b) SURVEY 8d's form: the hand-written stages only (oracle C twins, backbones excluded), one thread and all cores ----
@@ -830,8 +872,18 @@ def main():
             "per_gpu_fps": value / world, "per_rank_fps": per_rank, "ranks_seen": seen,
             "rank_placement": placement, "rank_placement_note": "[rank, NUMA node of its GPU, host CPUs it is pinned to]; node -1 = unpinned (a single rank, or /sys did not say)",
             "collectives": "nccl" if dist is not None else None, "hota_allreduce": hota_all,
-            "latency": latency, "value_f32": f32_leg["value_f32"] if f32_leg else None, "ms_per_step_f32": f32_leg["ms_per_step_f32"] if f32_leg else None,
-            "f32_leg": f32_leg, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+            "latency": latency, "value_f32": (f32_leg["value"] if f32_leg else (value if args.dtype == "f32" else None)),
+            "ms_per_step_f32": (f32_leg["ms_per_step"] if f32_leg else (el / args.steps * 1e3 if args.dtype == "f32" else None)),
+            "f32_leg": f32_leg,
+            "value_f16": alt_leg["value"] if alt_leg and alt_name == "f16" else None,
+            "ms_per_step_f16": alt_leg["ms_per_step"] if alt_leg and alt_name == "f16" else None,
+            "f16_leg": alt_leg if alt_leg and alt_name == "f16" else None,
+            "precision_note": ("value is measured with fp32 backbones, the reference's precision (configs/modules/track/strong_sort.yaml:10 fp16: false; "
+                               "ONNXRuntime / torchreid fp32): exact fp32 MFMA, no reduced-precision path exists on gfx950. One step is "
+                               "~32 TFLOP of convolutions, so 157.3 TFLOP/s (the chip's dense fp32 peak) bounds this configuration at "
+                               "~118 frames/s; roofline.frac says how close the kernel is") if args.dtype == "f32" else
+                              "value is measured with backbones narrower than the reference's fp32; value_f32 is the reference-precision number",
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(line), flush=True)
     pipe.close()

@@ -13,6 +13,8 @@ USE_FUSED_GEMM = _os.environ.get("TLK_FUSED_GEMM", "1") != "0"
 # fp32 (the reference's precision): every convolution + its epilogue is ONE launch of libtlk's hand-written fp32 MFMA kernel
 # (tlk_conv2d_nhwc_f32, csrc/tlk_conv.hip); TLK_CONV_F32=0 restores the library route (MIOpen + separate torch epilogue passes) for A/B runs.
 USE_TLK_CONV_F32 = _os.environ.get("TLK_CONV_F32", "1") != "0"
+# bench.py's roofline pass: a list here makes every fp32 convolution record (start event, end event, algorithmic flops) around its launch
+CONV_TIMER = None
 
 
 def epilogue_(x: torch.Tensor, bias: torch.Tensor, act: str | None, residual: torch.Tensor | None = None) -> torch.Tensor:
@@ -45,12 +47,33 @@ class ConvBiasAct(nn.Module):
         self.act = act
 
     def forward(self, x, residual=None):
-        if USE_TLK_CONV_F32 and x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0 \
+        if USE_TLK_CONV_F32 and x.is_cuda and x.dtype == torch.float32 and (x.shape[1] % 4 == 0 or x.shape[1] == 3) \
                 and x.is_contiguous(memory_format=torch.channels_last):
             from .. import _lib
+            if x.shape[1] == 3:
+                # RGB stem: the kernel gathers 16 B per tap, so the image gets a zero 4th channel (one small pass) and the weight a zero 4th
+                # input channel (cached): zero terms in the fmaf chain, the sum is unchanged
+                w4 = getattr(self, "_w4", None)
+                if w4 is None or w4.device != x.device:
+                    w4 = F.pad(self.conv.weight, (0, 0, 0, 0, 0, 1)).contiguous(memory_format=torch.channels_last)
+                    self._w4 = w4
+                x4 = F.pad(x, (0, 0, 0, 0, 0, 1)).contiguous(memory_format=torch.channels_last)
+                x, weight = x4, w4
+            else:
+                weight = self.conv.weight
             if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
                 residual = residual.contiguous(memory_format=torch.channels_last)
-            return _lib.conv2d_nhwc_f32(x, self.conv.weight, self.bias, self.act, residual, self.conv.stride[0], self.conv.padding[0])
+            if CONV_TIMER is not None:
+                n0, n1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n0.record(); n1.record()                   # an empty pair first: what the pair itself costs on this stream
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            y = _lib.conv2d_nhwc_f32(x, weight, self.bias, self.act, residual, self.conv.stride[0], self.conv.padding[0])
+            if CONV_TIMER is not None:
+                e1.record()
+                cout, cin, kh, kw = self.conv.weight.shape       # the algorithmic count: 3 input channels for the RGB stem, not the padded 4
+                CONV_TIMER.append((e0, e1, n0, n1, 2.0 * y.shape[0] * y.shape[2] * y.shape[3] * cout * cin * kh * kw))
+            return y
         if USE_GEMM_1X1 and self.conv.kernel_size == (1, 1) and self.conv.stride == (1, 1) and x.is_cuda \
                 and x.is_contiguous(memory_format=torch.channels_last):
             # a channels-last 1x1 convolution IS a plain GEMM (rows = N*H*W): hand it to hipBLASLt

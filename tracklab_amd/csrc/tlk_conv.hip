@@ -97,6 +97,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
     }
 
     float4 ra[PA], rb[PB];
+    // branch-free: a lane whose chunk is outside the image / beyond K / beyond M still loads (from the tensor's first 16 bytes) and the value is
+    // replaced by zero, so the 8 loads of a step issue back to back instead of one exec-masked branch each
     auto load_global = [&](int k0) {
         const int k = k0 + lc * 4;
         const bool kin = k < p.K;
@@ -106,11 +108,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
         for (int ps = 0; ps < PA; ++ps) {
             const int hi = a_hi0[ps] + kh, wi = a_wi0[ps] + kw;
             const bool ok = kin && a_base[ps] >= 0 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            ra[ps] = ok ? *reinterpret_cast<const float4 *>(p.x + (a_base[ps] + (long long)hi * p.W + wi) * p.x_pix + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const long long off = ok ? (a_base[ps] + (long long)hi * p.W + wi) * p.x_pix + ci : 0;
+            const float4 v = *reinterpret_cast<const float4 *>(p.x + off);
+            ra[ps] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int ps = 0; ps < PB; ++ps)
-            rb[ps] = (kin && b_row[ps]) ? *reinterpret_cast<const float4 *>(b_row[ps] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ps = 0; ps < PB; ++ps) {
+            const bool ok = kin && b_row[ps] != nullptr;
+            const float4 v = *reinterpret_cast<const float4 *>(ok ? b_row[ps] + k : p.w);
+            rb[ps] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     };
     auto store_lds = [&](int buf) {
         float *a = As + buf * BM * LDK + lr * LDK + lc * 4, *b = Bs + buf * BN * LDK + lr * LDK + lc * 4;
@@ -138,21 +145,29 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
         if (s + 1 < steps) load_global((s + 1) * BK);
         const float *a = As + cur * BM * LDK + (wm * TM * 32) * LDK + frag_off;
         const float *b = Bs + cur * BN * LDK + (wn * TN * 32) * LDK + frag_off;
+        // fragments of group j+1 are read from LDS while the MFMAs of group j run (two register sets)
+        float4 fa[2][TM], fb[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const float4 *>(a + i * 32 * LDK);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fb[0][i] = *reinterpret_cast<const float4 *>(b + i * 32 * LDK);
 #pragma unroll
         for (int j = 0; j < BK / 8; ++j) {
-            float4 fa[TM], fb[TN];
+            const int c = j & 1, n = c ^ 1;
+            if (j + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4 *>(a + i * 32 * LDK + j * 8);
+                for (int i = 0; i < TM; ++i) fa[n][i] = *reinterpret_cast<const float4 *>(a + i * 32 * LDK + (j + 1) * 8);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fb[i] = *reinterpret_cast<const float4 *>(b + i * 32 * LDK + j * 8);
+                for (int i = 0; i < TN; ++i) fb[n][i] = *reinterpret_cast<const float4 *>(b + i * 32 * LDK + (j + 1) * 8);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int jj = 0; jj < TN; ++jj) {
-                        const float av = r == 0 ? fa[i].x : r == 1 ? fa[i].y : r == 2 ? fa[i].z : fa[i].w;
-                        const float bv = r == 0 ? fb[jj].x : r == 1 ? fb[jj].y : r == 2 ? fb[jj].z : fb[jj].w;
+                        const float av = r == 0 ? fa[c][i].x : r == 1 ? fa[c][i].y : r == 2 ? fa[c][i].z : fa[c][i].w;
+                        const float bv = r == 0 ? fb[c][jj].x : r == 1 ? fb[c][jj].y : r == 2 ? fb[c][jj].z : fb[c][jj].w;
                         acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][jj], 0, 0, 0);
                     }
         }
@@ -160,22 +175,55 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
         __syncthreads();
     }
 
-    // ---- epilogue: C/D map of the 32x32 tile: column (= cout) = lane & 31, row (= pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // ---- epilogue.  C/D map of the 32x32 tile: column (= cout) = lane & 31, row (= pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // The tile goes through LDS (free after the last barrier) so that every lane then moves 16 contiguous bytes: rows of BN floats leave as
+    // 512-byte runs, the residual arrives the same way, instead of 64 scalar stores per lane.
+    constexpr int LDC = BN + 4;
+    float *Cs = lds;                                       // [BM][LDC]
 #pragma unroll
-    for (int jj = 0; jj < TN; ++jj) {
-        const int co = n0 + (wn * TN + jj) * 32 + (lane & 31);
-        if (co >= p.Cout) continue;
-        const float bv = p.bias ? p.bias[co] : 0.f;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const long long mrow = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+        for (int jj = 0; jj < TN; ++jj) {
+            float *c = Cs + ((wm * TM + i) * 32 + 4 * (lane >> 5)) * LDC + (wn * TN + jj) * 32 + (lane & 31);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = mrow + (r & 3) + 8 * (r >> 2);
-                if (m >= p.M) continue;
-                float v = acc[i][jj][r] + bv;
-                if (RES) v += p.res[m * p.r_pix + co];
-                p.y[m * p.y_pix + co] = act_f32<ACT>(v);
+            for (int r = 0; r < 16; ++r) c[((r & 3) + 8 * (r >> 2)) * LDC] = acc[i][jj][r];
+        }
+    __syncthreads();
+    const float *__restrict__ resp = p.res;
+    float *__restrict__ yp = p.y;
+    constexpr int V_PER_ROW = BN / 4, NVEC = BM * V_PER_ROW, ITS = (NVEC + NT - 1) / NT;
+    const bool vec = ((p.Cout | p.y_pix | p.r_pix) & 3) == 0 && (((uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.bias) & 15) == 0;
+    if (vec) {
+#pragma unroll 4
+        for (int it = 0; it < ITS; ++it) {
+            const int idx = it * NT + tid;
+            const int row = idx / V_PER_ROW, ec = (idx - row * V_PER_ROW) * 4;
+            const long long m = m0 + row;
+            const int co = n0 + ec;
+            if ((NVEC % NT != 0 && idx >= NVEC) || m >= p.M || co >= p.Cout) continue;
+            float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec);
+            if (p.bias) { const float4 bv = *reinterpret_cast<const float4 *>(p.bias + co); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+            else { v.x += 0.f; v.y += 0.f; v.z += 0.f; v.w += 0.f; }
+            if (RES) {
+                const float4 rv = *reinterpret_cast<const float4 *>(resp + m * p.r_pix + co);
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
+            v.x = act_f32<ACT>(v.x); v.y = act_f32<ACT>(v.y); v.z = act_f32<ACT>(v.z); v.w = act_f32<ACT>(v.w);
+            *reinterpret_cast<float4 *>(yp + m * p.y_pix + co) = v;
+        }
+    } else {
+        for (int it = 0; it < ITS; ++it) {
+            const int idx = it * NT + tid;
+            const int row = idx / V_PER_ROW, ec = (idx - row * V_PER_ROW) * 4;
+            const long long m = m0 + row;
+            const int co = n0 + ec;
+            if ((NVEC % NT != 0 && idx >= NVEC) || m >= p.M) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (co + e >= p.Cout) break;
+                float v = Cs[row * LDC + ec + e] + (p.bias ? p.bias[co + e] : 0.f);
+                if (RES) v += resp[m * p.r_pix + co + e];
+                yp[m * p.y_pix + co + e] = act_f32<ACT>(v);
             }
         }
     }
@@ -184,7 +232,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
 template <int TM, int TN, int WGM, int WGN> int launch_cfg(ConvArgs &a, int act, hipStream_t st)
 {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, NT = 64 * WGM * WGN;
-    constexpr size_t LDS_BYTES = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+    constexpr size_t LDS_STAGE = (size_t)2 * (BM + BN) * LDK * sizeof(float), LDS_C = (size_t)BM * (BN + 4) * sizeof(float);
+    constexpr size_t LDS_BYTES = LDS_STAGE > LDS_C ? LDS_STAGE : LDS_C;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     a.tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
     if (a.tiles > 0x7fffffffLL) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: too many tiles for one launch");
@@ -238,21 +287,21 @@ extern "C" int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const
         return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: pixel strides must cover the channels (x stride a multiple of 4)");
     if (((uintptr_t)x_dev | (uintptr_t)w_dev) & 15) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: x and w must be 16-byte aligned");
     hipStream_t st = (hipStream_t)hip_stream;
-    // tile configuration: column tile = the smallest of 32 / 64 / 96 / 128 that wastes least of Cout; rows 128 or 256
+    // tile configuration (measured on MI355X, profiles/r04_conv_f32_shapes.md): 128 x 128 wherever Cout fills it; 256 x 64 for Cout <= 64;
+    // 256 x 96 for multiples of 96 (YOLOX-m widths); 64 x 128 when 128-row tiles would not fill the chip twice over
     int cfg = g_force_cfg;
     if (cfg < 0) {
         const int c = cout;
-        const int w128 = ((c + 127) / 128) * 128, w96 = ((c + 95) / 96) * 96, w64 = ((c + 63) / 64) * 64;
         if (c <= 32) cfg = 4;
-        else if (w64 < w128 && w64 <= w96) cfg = 1;         // Cout = 64, 192 (3 x 64), 320 ...
-        else if (w96 < w128) cfg = 3;                        // Cout = 96, 288 ...
+        else if (c <= 64) cfg = 1;
+        else if (c % 96 == 0 && c % 128 != 0 && a.M >= 64 * 1024) cfg = 3;
         else cfg = 0;
-        if (cfg == 0 && a.M >= 256 * 1024 && cout % 128 == 0) cfg = 2;
+        if (cfg == 0 && ((a.M + 127) / 128) * ((cout + 127) / 128) < 1024) cfg = 5;
     }
     switch (cfg) {
     case 0: return launch_cfg<2, 2, 2, 2>(a, act_kind, st);    // 128 x 128
     case 1: return launch_cfg<2, 2, 4, 1>(a, act_kind, st);    // 256 x 64
-    case 2: return launch_cfg<4, 2, 2, 2>(a, act_kind, st);    // 256 x 128
+    case 2: return launch_cfg<2, 1, 2, 2>(a, act_kind, st);    // 128 x 64
     case 3: return launch_cfg<2, 3, 4, 1>(a, act_kind, st);    // 256 x 96
     case 4: return launch_cfg<2, 1, 4, 1>(a, act_kind, st);    // 256 x 32
     default: return launch_cfg<1, 2, 2, 2>(a, act_kind, st);   // 64 x 128 (small M)
