@@ -713,14 +713,15 @@ def main():
     if args.dtype == "f32" and is3:
         from tracklab_amd.backbones import common as bc
         if bc.USE_TLK_CONV_F32:
+            lb_v, crops_v = pipe.lb.permute(0, 3, 1, 2), pipe.crops.permute(0, 3, 1, 2)     # logical NCHW views of the step's channels-last buffers
             with torch.no_grad():
-                pipe.model(pipe.lb, focused=True); pipe.reid(pipe.crops)           # warm (eager)
+                pipe.model(lb_v, focused=True); pipe.reid(crops_v)                 # warm (eager)
                 torch.cuda.synchronize()
                 bc.CONV_TIMER = []
                 for _ in range(2):
-                    pipe.model(pipe.lb, focused=True); pipe.reid(pipe.crops)
+                    pipe.model(lb_v, focused=True); pipe.reid(crops_v)
                     if pipe.pose is not None:
-                        pipe.pose(pipe.pose_crops)
+                        pipe.pose(pipe.pose_crops.permute(0, 3, 1, 2))
                 torch.cuda.synchronize()
                 recs, bc.CONV_TIMER = bc.CONV_TIMER, None
             c_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _, _ in recs)

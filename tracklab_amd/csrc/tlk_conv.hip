@@ -31,6 +31,7 @@ constexpr int BK = 32;            // K step (floats)
 constexpr int LDK = BK + 4;       // padded LDS row: 36 floats = 144 B
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
     const float *x, *w, *bias, *res;
@@ -75,56 +76,70 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
     const long long m0 = (tile / p.tiles_n) * BM;
     const int n0 = (int)(tile % p.tiles_n) * BN;
 
-    // ---- loader geometry: this lane moves chunk `lc` (4 floats of k) of row `lr + pass * ROWS_PER_PASS`
+    // ---- loader geometry: this lane moves chunk `lc` (4 floats of k) of row `lr + pass * ROWS_PER_PASS`.
+    // Loads are BUFFER loads (raw buffer descriptor, 32-bit byte offsets): a lane whose chunk is outside the image / beyond K / beyond M
+    // uses an offset past num_records and the hardware returns zeros -- no branch, no select, so the whole K step is one basic block the
+    // scheduler barriers below can shape.  The A descriptor is re-based per workgroup (a tensor may exceed the 4 GB a 32-bit offset spans;
+    // the rows of one tile never do): base = first input row any tap of the tile's first output row can touch.
     const int lr = tid >> 3, lc = tid & 7;
-    int a_hi0[PA], a_wi0[PA];
-    long long a_base[PA];                                  // pixel index of (n, 0, 0); -1 = row beyond M
+    constexpr int OOB = (int)0x80000000;                   // beyond every num_records below (< 2^31)
+    long long base_pix;
+    {
+        const long long hw = (long long)p.Ho * p.Wo, n = m0 / hw;
+        const int rem = (int)(m0 - n * hw), ho = rem / p.Wo;
+        const int hi = ho * p.stride - p.pad;
+        base_pix = n * (long long)p.H * p.W + (long long)(hi > 0 ? hi : 0) * p.W;
+    }
+    const long long total_pix = (p.M / ((long long)p.Ho * p.Wo)) * (long long)p.H * p.W;
+    long long a_bytes = ((total_pix - base_pix - 1) * p.x_pix + p.Cin) * 4;
+    if (a_bytes > 0x7ffffff0LL) a_bytes = 0x7ffffff0LL;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + base_pix * p.x_pix), 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)((long long)p.Cout * p.K * 4), 0x00020000);
+    int a_hi0[PA], a_wi0[PA], a_rel[PA];                   // a_rel: pixel index of tap (0,0) relative to base_pix (may be negative: masked then)
+    bool a_ok[PA];
 #pragma unroll
     for (int ps = 0; ps < PA; ++ps) {
         const long long m = m0 + lr + ps * ROWS_PER_PASS;
-        if (m < p.M) {
-            const long long n = m / ((long long)p.Ho * p.Wo);
-            const int rem = (int)(m - n * (long long)p.Ho * p.Wo);
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            a_hi0[ps] = ho * p.stride - p.pad; a_wi0[ps] = wo * p.stride - p.pad; a_base[ps] = n * (long long)p.H * p.W;
-        } else { a_hi0[ps] = 0; a_wi0[ps] = 0; a_base[ps] = -1; }
+        a_ok[ps] = m < p.M;
+        const long long mm = a_ok[ps] ? m : m0;
+        const long long n = mm / ((long long)p.Ho * p.Wo);
+        const int rem = (int)(mm - n * (long long)p.Ho * p.Wo);
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        a_hi0[ps] = ho * p.stride - p.pad; a_wi0[ps] = wo * p.stride - p.pad;
+        a_rel[ps] = (int)(n * (long long)p.H * p.W - base_pix) + a_hi0[ps] * p.W + a_wi0[ps];
     }
-    const float *b_row[PB];
+    int b_off[PB];                                         // byte offset of (co, k = 0), OOB for rows beyond Cout
 #pragma unroll
     for (int ps = 0; ps < PB; ++ps) {
         const int co = n0 + lr + ps * ROWS_PER_PASS;
-        b_row[ps] = co < p.Cout ? p.w + (long long)co * p.K : nullptr;
+        b_off[ps] = co < p.Cout ? co * p.K * 4 : OOB;
     }
 
-    float4 ra[PA], rb[PB];
-    // branch-free: a lane whose chunk is outside the image / beyond K / beyond M still loads (from the tensor's first 16 bytes) and the value is
-    // replaced by zero, so the 8 loads of a step issue back to back instead of one exec-masked branch each
-    auto load_global = [&](int k0) {
-        const int k = k0 + lc * 4;
-        const bool kin = k < p.K;
-        int kh = 0, kw = 0, ci = k;
-        if (p.KH * p.KW != 1) { const int tap = k / p.Cin; ci = k - tap * p.Cin; kh = tap / p.KW; kw = tap - kh * p.KW; }
-#pragma unroll
-        for (int ps = 0; ps < PA; ++ps) {
-            const int hi = a_hi0[ps] + kh, wi = a_wi0[ps] + kw;
-            const bool ok = kin && a_base[ps] >= 0 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const long long off = ok ? (a_base[ps] + (long long)hi * p.W + wi) * p.x_pix + ci : 0;
-            const float4 v = *reinterpret_cast<const float4 *>(p.x + off);
-            ra[ps] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int ps = 0; ps < PB; ++ps) {
-            const bool ok = kin && b_row[ps] != nullptr;
-            const float4 v = *reinterpret_cast<const float4 *>(ok ? b_row[ps] + k : p.w);
-            rb[ps] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int NL = PA + PB;                            // 16-byte loads per lane and K step
+    i32x4 rg[NL];                                          // staging registers: global -> LDS
+    int t_kh = 0, t_kw = 0, t_ci = 0, t_k = 0;             // tap of this lane's chunk in the step being loaded
+    bool t_in = false;
+    auto set_tap = [&](int k0) {
+        t_k = k0 + lc * 4;
+        t_in = t_k < p.K;
+        t_kh = 0; t_kw = 0; t_ci = t_k;
+        if (p.KH * p.KW != 1) { const int tap = t_k / p.Cin; t_ci = t_k - tap * p.Cin; t_kh = tap / p.KW; t_kw = tap - t_kh * p.KW; }
+    };
+    auto issue_load = [&](int i) {
+        if (i < PA) {
+            const int hi = a_hi0[i] + t_kh, wi = a_wi0[i] + t_kw;
+            const bool ok = t_in && a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const int off = ((a_rel[i] + t_kh * p.W + t_kw) * p.x_pix + t_ci) * 4;
+            rg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, ok ? off : OOB, 0, 0);
+        } else {
+            const int bo = b_off[i - PA];
+            rg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (t_in && bo != OOB) ? bo + t_k * 4 : OOB, 0, 0);
         }
     };
-    auto store_lds = [&](int buf) {
-        float *a = As + buf * BM * LDK + lr * LDK + lc * 4, *b = Bs + buf * BN * LDK + lr * LDK + lc * 4;
-#pragma unroll
-        for (int ps = 0; ps < PA; ++ps) *reinterpret_cast<float4 *>(a + ps * ROWS_PER_PASS * LDK) = ra[ps];
-#pragma unroll
-        for (int ps = 0; ps < PB; ++ps) *reinterpret_cast<float4 *>(b + ps * ROWS_PER_PASS * LDK) = rb[ps];
+    auto issue_store = [&](int i, int buf) {
+        float *dst = i < PA ? As + buf * BM * LDK + (lr + i * ROWS_PER_PASS) * LDK + lc * 4
+                            : Bs + buf * BN * LDK + (lr + (i - PA) * ROWS_PER_PASS) * LDK + lc * 4;
+        *reinterpret_cast<i32x4 *>(dst) = rg[i];
     };
 
     f32x16 acc[TM][TN];
@@ -136,44 +151,53 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int steps = (p.K + BK - 1) / BK;
-    load_global(0);
-    store_lds(0);
+    set_tap(0);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) issue_load(i);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) issue_store(i, 0);
     __syncthreads();
     const int frag_off = (lane & 31) * LDK + (lane >> 5) * 4;
+    const float *a_frag = As + (wm * TM * 32) * LDK + frag_off, *b_frag = Bs + (wn * TN * 32) * LDK + frag_off;
+    float4 fa[2][TM], fb[2][TN];
+    auto read_frags = [&](int buf, int j, int set) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const float4 *>(a_frag + buf * BM * LDK + i * 32 * LDK + j * 8);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fb[set][i] = *reinterpret_cast<const float4 *>(b_frag + buf * BN * LDK + i * 32 * LDK + j * 8);
+    };
+    read_frags(0, 0, 0);
+    // One K step = 16 chunks of TM*TN MFMAs (64 cycles each).  The step is software-pipelined INSIDE the wavefront, chunk by chunk, with
+    // scheduling barriers between the chunks so the order below is the order issued: the loads of the next step (address arithmetic + buffer
+    // load) ride under chunks 0-7, their LDS stores under chunks 8-15 (>= 2048 cycles after the load), the fragment reads of group j+1 under
+    // the first chunk of group j.  A wavefront keeps the MFMA pipe busy on its own, whatever its neighbour on the SIMD does.
+    constexpr int NCH = 4 * (BK / 8);
     for (int s = 0; s < steps; ++s) {
         const int cur = s & 1;
-        if (s + 1 < steps) load_global((s + 1) * BK);
-        const float *a = As + cur * BM * LDK + (wm * TM * 32) * LDK + frag_off;
-        const float *b = Bs + cur * BN * LDK + (wn * TN * 32) * LDK + frag_off;
-        // fragments of group j+1 are read from LDS while the MFMAs of group j run (two register sets)
-        float4 fa[2][TM], fb[2][TN];
+        set_tap((s + 1) * BK);                             // beyond K on the last step: every load returns zeros, the stores hit a dead buffer
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const float4 *>(a + i * 32 * LDK);
+        for (int c = 0; c < NCH; ++c) {
+            const int j = c >> 2, r = c & 3, set = j & 1;
+            if (r == 0 && j + 1 < BK / 8) read_frags(cur, j + 1, set ^ 1);
 #pragma unroll
-        for (int i = 0; i < TN; ++i) fb[0][i] = *reinterpret_cast<const float4 *>(b + i * 32 * LDK);
-#pragma unroll
-        for (int j = 0; j < BK / 8; ++j) {
-            const int c = j & 1, n = c ^ 1;
-            if (j + 1 < BK / 8) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[n][i] = *reinterpret_cast<const float4 *>(a + i * 32 * LDK + (j + 1) * 8);
-#pragma unroll
-                for (int i = 0; i < TN; ++i) fb[n][i] = *reinterpret_cast<const float4 *>(b + i * 32 * LDK + (j + 1) * 8);
+            for (int i = 0; i < NL; ++i) {
+                if (c < NCH / 2 && (i * (NCH / 2)) / NL == c) issue_load(i);
+                if (c >= NCH / 2 && (i * (NCH / 2)) / NL == c - NCH / 2) issue_store(i, cur ^ 1);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < TN; ++jj) {
-                        const float av = r == 0 ? fa[c][i].x : r == 1 ? fa[c][i].y : r == 2 ? fa[c][i].z : fa[c][i].w;
-                        const float bv = r == 0 ? fb[c][jj].x : r == 1 ? fb[c][jj].y : r == 2 ? fb[c][jj].z : fb[c][jj].w;
-                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][jj], 0, 0, 0);
-                    }
+                for (int jj = 0; jj < TN; ++jj) {
+                    const float av = r == 0 ? fa[set][i].x : r == 1 ? fa[set][i].y : r == 2 ? fa[set][i].z : fa[set][i].w;
+                    const float bv = r == 0 ? fb[set][jj].x : r == 1 ? fb[set][jj].y : r == 2 ? fb[set][jj].z : fb[set][jj].w;
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][jj], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (s + 1 < steps) store_lds(cur ^ 1);
         __syncthreads();
+        read_frags(cur ^ 1, 0, 0);                         // (after the last step: reads the dead buffer, unused)
     }
+    __syncthreads();                                       // nobody still reads fragments when the tile is staged below
 
     // ---- epilogue.  C/D map of the 32x32 tile: column (= cout) = lane & 31, row (= pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     // The tile goes through LDS (free after the last barrier) so that every lane then moves 16 contiguous bytes: rows of BN floats leave as
