@@ -724,11 +724,21 @@ def main():
                         pipe.pose(pipe.pose_crops.permute(0, 3, 1, 2))
                 torch.cuda.synchronize()
                 recs, bc.CONV_TIMER = bc.CONV_TIMER, None
-            c_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _, _ in recs)
-            c_null = sum(n0.elapsed_time(n1) for _, _, n0, n1, _ in recs)
+            c_ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            c_null = sum(r[2].elapsed_time(r[3]) for r in recs)
             c_flop = sum(r[4] for r in recs)
             tf = c_flop / ((c_ms - c_null) * 1e-3) / 1e12
             roofline_hbm = roofline
+            # the same timings per kernel instantiation (rocprofv3 names them conv_f32_mfma_kernel<TM, TN, WGM, WGN, ACT, RES>): the rows of
+            # profiles/r04_config3_f32_rocprof.md to compare with
+            tmpl = {0: "2, 2, 2, 2", 1: "2, 2, 4, 1", 2: "2, 1, 2, 2", 3: "2, 3, 4, 1", 4: "2, 1, 4, 1", 5: "1, 2, 2, 2", 6: "1, 2, 4, 1"}
+            per = {}
+            for r in recs:
+                cfg_, act_, res_ = r[5]
+                e = per.setdefault(f"conv_f32_mfma_kernel<{tmpl.get(cfg_, '?')}, {act_}, {'true' if res_ else 'false'}>", [0, 0.0, 0.0])
+                e[0] += 1; e[1] += r[0].elapsed_time(r[1]) - r[2].elapsed_time(r[3]); e[2] += r[4]
+            per_inst = [{"kernel": k_, "launches_per_step": v_[0] // 2, "avg_launch_ms": v_[1] / v_[0], "tflops": v_[2] / (v_[1] * 1e-3) / 1e12}
+                        for k_, v_ in sorted(per.items(), key=lambda kv: -kv[1][1])]
             roofline = {"kernel": "conv_f32_mfma_kernel (tlk_conv2d_nhwc_f32: implicit GEMM on v_mfma_f32_32x32x2_f32, bias / residual / activation fused)",
                         "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None,
                         "launches_per_step": len(recs) // 2, "avg_launch_ms": (c_ms - c_null) / len(recs), "avg_launch_ms_events_raw": c_ms / len(recs),
@@ -737,7 +747,9 @@ def main():
                         "units_per_launch": f"one convolution of the step: {B} frames (detector) or {B} x {pipe.maxd} crop slots (ReID); mean over the "
                                             f"{len(recs) // 2} convolutions of a step, flop-weighted",
                         "peak_source": "MI355X_MICROARCH.md: fp32-input MFMA 157.3 TFLOP/s dense (no reduced-precision fp32 path on gfx950)",
-                        "rocprofv3": "profiles/r04_config3_f32_rocprof.md: total duration / calls of conv_f32_mfma_kernel<...> of the same command"}
+                        "per_instantiation": per_inst,
+                        "rocprofv3": "profiles/r04_config3_f32_rocprof.md: average duration of the same instantiations in the rocprofv3 --kernel-trace "
+                                     "--stats run of the same command (the ReLU / linear ones are launched by the ReID network only, same mix per step)"}
 
     # ---- small-step legs: the same chain at frames_per_step 1 / 2 / 4 and at 4 streams x 1 frame (what an online consumer sees; the
     # reference's online engine is per-frame, engine/video.py:67-117). Each: pipelined frames/s, un-overlapped frame-in -> rows-out time,

@@ -617,9 +617,11 @@ int tlk_bias_act_nhwc(void *x_dev, const void *bias_dev, const void *residual_de
 int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev, float *y_dev,
                         int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int act_kind,
                         int x_pix_stride, int y_pix_stride, int res_pix_stride, void *hip_stream);
-/* Probes / tests: force one of the kernel's tile configurations (0: 128x128, 1: 256x64, 2: 128x64, 3: 256x96, 4: 256x32, 5: 64x128
+/* Probes / tests: force one of the kernel's tile configurations (0: 128x128, 1: 256x64, 2: 128x64, 3: 256x96, 4: 256x32, 5: 64x128, 6: 128x64 (waves stacked)
  * pixels x output channels); -1 = the heuristic.  Results do not depend on it. */
 int tlk_conv2d_set_config(int cfg);
+/* Tile configuration (0..6) the most recent tlk_conv2d_nhwc_f32 call of this process launched, -1 before the first. */
+int tlk_conv2d_last_config(void);
 
 /* 1x1 convolution of a channels-last tensor as ONE GEMM with the convolution epilogue inside:
  *   out[M,N] = act(x[M,K] . w[N,K]^T + bias[N] (+ residual[M,N])),  act 0 none / 1 ReLU / 2 SiLU, dtype TLK_F16 or TLK_BF16.

@@ -47,7 +47,7 @@ def _run(case, cfg):
     return y.permute(0, 2, 3, 1).cpu().numpy(), exp
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("case", CASES)
 def test_conv_is_bit_exact_with_the_oracle_chain(case, cfg):
     got, exp = _run(case, cfg)

@@ -1,0 +1,35 @@
+"""rocprofv3 --kernel-trace --stats (csv) -> profiles/<name>.md + <name>_kernel_stats.csv, with the libtlk convolution kernel's template
+instantiations also summed into one row (the bench line's roofline figure is over all of them).
+    python tools/rocprof_csv_md.py <dir with *_kernel_stats.csv> profiles/r04_config3_f32_rocprof "<command>" [bench line json]"""
+import csv
+import glob
+import json
+import shutil
+import sys
+
+src, dst, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
+path = sorted(glob.glob(src + "/**/*kernel_stats.csv", recursive=True))[0]
+rows = list(csv.DictReader(open(path)))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+out = [f"# {dst.split('/')[-1]}", "", f"command: `{cmd}`", ""]
+if len(sys.argv) > 4:
+    d = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
+    out += [f"bench line of this profiled run: value = {d['value']:.1f} frames/s ({d['dtype']}), ms_per_step = {d['ms_per_step']:.2f}; "
+            f"roofline (HIP events): {d['roofline']['achieved']:.1f} {d['roofline']['unit']} = {d['roofline']['frac']:.3f} of peak, "
+            f"avg launch {d['roofline']['avg_launch_ms']:.4f} ms", ""]
+conv = [r for r in rows if "conv_f32_mfma_kernel" in r["Name"]]
+if conv:
+    c_calls = sum(int(r["Calls"]) for r in conv)
+    c_ns = sum(float(r["TotalDurationNs"]) for r in conv)
+    out += [f"**conv_f32_mfma_kernel, all template instantiations together: {c_calls} calls, {c_ns / 1e6:.2f} ms, average {c_ns / c_calls / 1e3:.2f} us, "
+            f"{100 * c_ns / tot:.2f} % of the GPU time** (includes the warm-up, parity and roofline passes of the command, whose launches are the same)", ""]
+out += ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
+for r in rows[:45]:
+    n = r["Name"]
+    n = n if len(n) < 100 else n[:97] + "..."
+    out.append(f"| `{n}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['MinNs']) / 1e3:.2f} | "
+               f"{float(r['MaxNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} |")
+out.append(f"\ntotal kernel time: {tot / 1e6:.2f} ms over {len(rows)} kernels")
+open(dst + ".md", "w").write("\n".join(out) + "\n")
+shutil.copy(path, dst + "_kernel_stats.csv")
+print("\n".join(out[:30]))

@@ -72,7 +72,8 @@ class ConvBiasAct(nn.Module):
             if CONV_TIMER is not None:
                 e1.record()
                 cout, cin, kh, kw = self.conv.weight.shape       # the algorithmic count: 3 input channels for the RGB stem, not the padded 4
-                CONV_TIMER.append((e0, e1, n0, n1, 2.0 * y.shape[0] * y.shape[2] * y.shape[3] * cout * cin * kh * kw))
+                CONV_TIMER.append((e0, e1, n0, n1, 2.0 * y.shape[0] * y.shape[2] * y.shape[3] * cout * cin * kh * kw,
+                                   (_lib.lib().tlk_conv2d_last_config(), _lib.ACT[self.act], residual is not None)))
             return y
         if USE_GEMM_1X1 and self.conv.kernel_size == (1, 1) and self.conv.stride == (1, 1) and x.is_cuda \
                 and x.is_contiguous(memory_format=torch.channels_last):

@@ -85,12 +85,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
     constexpr int OOB = (int)0x80000000;                   // beyond every num_records below (< 2^31)
     long long base_pix;
     {
-        const long long hw = (long long)p.Ho * p.Wo, n = m0 / hw;
-        const int rem = (int)(m0 - n * hw), ho = rem / p.Wo;
+        const unsigned hw = (unsigned)(p.Ho * p.Wo), n = (unsigned)m0 / hw;         // M < 2^31 (checked by the host side): 32-bit divisions
+        const int rem = (int)((unsigned)m0 - n * hw), ho = rem / p.Wo;
         const int hi = ho * p.stride - p.pad;
         base_pix = n * (long long)p.H * p.W + (long long)(hi > 0 ? hi : 0) * p.W;
     }
-    const long long total_pix = (p.M / ((long long)p.Ho * p.Wo)) * (long long)p.H * p.W;
+    const long long total_pix = (long long)((unsigned)p.M / (unsigned)(p.Ho * p.Wo)) * p.H * p.W;
     long long a_bytes = ((total_pix - base_pix - 1) * p.x_pix + p.Cin) * 4;
     if (a_bytes > 0x7ffffff0LL) a_bytes = 0x7ffffff0LL;
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + base_pix * p.x_pix), 0, (int)a_bytes, 0x00020000);
@@ -102,8 +102,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
         const long long m = m0 + lr + ps * ROWS_PER_PASS;
         a_ok[ps] = m < p.M;
         const long long mm = a_ok[ps] ? m : m0;
-        const long long n = mm / ((long long)p.Ho * p.Wo);
-        const int rem = (int)(mm - n * (long long)p.Ho * p.Wo);
+        const unsigned n = (unsigned)mm / (unsigned)(p.Ho * p.Wo);
+        const int rem = (int)((unsigned)mm - n * (unsigned)(p.Ho * p.Wo));
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
         a_hi0[ps] = ho * p.stride - p.pad; a_wi0[ps] = wo * p.stride - p.pad;
         a_rel[ps] = (int)(n * (long long)p.H * p.W - base_pix) + a_hi0[ps] * p.W + a_wi0[ps];
@@ -260,7 +260,7 @@ template <int TM, int TN, int WGM, int WGN> int launch_cfg(ConvArgs &a, int act,
     constexpr size_t LDS_BYTES = LDS_STAGE > LDS_C ? LDS_STAGE : LDS_C;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     a.tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
-    if (a.tiles > 0x7fffffffLL) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: too many tiles for one launch");
+    if (a.tiles > 0x7fffffffLL || a.M > 0x7fffffffLL) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: more than 2^31 - 1 output pixels in one launch");
     const bool res = a.res != nullptr;
 #define TLK_CONV_LAUNCH(A, R)                                                                                                              \
     do {                                                                                                                                   \
@@ -277,15 +277,18 @@ template <int TM, int TN, int WGM, int WGN> int launch_cfg(ConvArgs &a, int act,
 }
 
 int g_force_cfg = -1;     // tlk_conv2d_set_config (probes / tests): -1 = heuristic
+int g_last_cfg = -1;      // configuration of the most recent launch (tlk_conv2d_last_config: bench.py groups its event timings by kernel instantiation)
 
 }  // namespace
 
 extern "C" int tlk_conv2d_set_config(int cfg)
 {
-    if (cfg < -1 || cfg > 5) return fail(TLK_EINVAL, "tlk_conv2d_set_config: cfg must be -1 (heuristic) or 0..5");
+    if (cfg < -1 || cfg > 6) return fail(TLK_EINVAL, "tlk_conv2d_set_config: cfg must be -1 (heuristic) or 0..6");
     g_force_cfg = cfg;
     return TLK_OK;
 }
+
+extern "C" int tlk_conv2d_last_config(void) { return g_last_cfg; }
 
 extern "C" int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev, float *y_dev,
                                    int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int act_kind,
@@ -311,23 +314,26 @@ extern "C" int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const
         return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: pixel strides must cover the channels (x stride a multiple of 4)");
     if (((uintptr_t)x_dev | (uintptr_t)w_dev) & 15) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: x and w must be 16-byte aligned");
     hipStream_t st = (hipStream_t)hip_stream;
-    // tile configuration (measured on MI355X, profiles/r04_conv_f32_shapes.md): 128 x 128 wherever Cout fills it; 256 x 64 for Cout <= 64;
-    // 256 x 96 for multiples of 96 (YOLOX-m widths); 64 x 128 when 128-row tiles would not fill the chip twice over
+    // tile configuration (measured on MI355X, profiles/r04_conv_f32_shapes.md): 128 x 128 wherever Cout fills it (130-135 TFLOP/s on the
+    // K >= 512 layers); 128 x 64 for Cout <= 64 and the other widths that are not multiples of 128 (two workgroups per CU fit, which the
+    // 256 x 64 tile's 92 KB of LDS do not); 256 x 96 for odd multiples of 96 (YOLOX-m widths); 64 x 128 when 128-row tiles would leave CUs idle
     int cfg = g_force_cfg;
     if (cfg < 0) {
         const int c = cout;
         if (c <= 32) cfg = 4;
-        else if (c <= 64) cfg = 1;
-        else if (c % 96 == 0 && c % 128 != 0 && a.M >= 64 * 1024) cfg = 3;
-        else cfg = 0;
-        if (cfg == 0 && ((a.M + 127) / 128) * ((cout + 127) / 128) < 1024) cfg = 5;
+        else if (c % 128 == 0) cfg = 0;
+        else if (c % 96 == 0 && (c / 96) % 2 == 1 && a.M >= 64 * 1024) cfg = 3;
+        else cfg = 2;
+        if (cfg == 0 && ((a.M + 127) / 128) * (cout / 128) < 1024) cfg = 5;
     }
+    g_last_cfg = cfg;
     switch (cfg) {
     case 0: return launch_cfg<2, 2, 2, 2>(a, act_kind, st);    // 128 x 128
     case 1: return launch_cfg<2, 2, 4, 1>(a, act_kind, st);    // 256 x 64
     case 2: return launch_cfg<2, 1, 2, 2>(a, act_kind, st);    // 128 x 64
     case 3: return launch_cfg<2, 3, 4, 1>(a, act_kind, st);    // 256 x 96
     case 4: return launch_cfg<2, 1, 4, 1>(a, act_kind, st);    // 256 x 32
+    case 6: return launch_cfg<1, 2, 4, 1>(a, act_kind, st);    // 128 x 64, wavefronts stacked in M
     default: return launch_cfg<1, 2, 2, 2>(a, act_kind, st);   // 64 x 128 (small M)
     }
 }
