@@ -81,3 +81,32 @@ def test_the_eval_yaml_instantiates_with_the_arguments_main_passes():
     assert node.pop("_target_") == "tracklab_amd.wrappers.HipTrackEvalEvaluator"
     ev = HipTrackEvalEvaluator(**node, tracking_dataset=NS())           # main.py: instantiate(cfg.eval, tracking_dataset=tracking_dataset)
     assert ev.device == "gpu" and ev.cfg["bbox_column_for_eval"] == "bbox_ltwh"
+
+
+def test_plugin_hands_the_trackeval_layout_to_the_dataset_hook():
+    """the reference always calls tracking_dataset.process_trackeval_results(results, dataset_config, eval_config) with TrackEval's
+    output_res[dataset][tracker] (trackeval_evaluator.py:106-110); a hook written like wrappers/dataset/mot_like/common.py:242-258 must work"""
+    seen = {}
+
+    class Dataset:
+        def process_trackeval_results(self, results, dataset_config, eval_config):
+            assert "SUMMARIES" in results and "pedestrian" in results["SUMMARIES"]
+            seen["flat"] = {k: float(v) if "." in v else int(v) for _, metrics in results["SUMMARIES"]["pedestrian"].items() for k, v in metrics.items()}
+            seen["by_video"] = {}
+            for video_name, video_data in results.items():
+                if video_name != "SUMMARIES":
+                    for category, metrics in video_data["pedestrian"].items():
+                        for metric_name, metric_value in metrics.items():
+                            if not isinstance(metric_value, np.ndarray):
+                                seen["by_video"][f"{video_name}/{metric_name}"] = metric_value
+
+    ev = HipTrackEvalEvaluator(NS(device="cpu", bbox_column_for_eval="bbox_ltwh"), eval_set="val", show_progressbar=False, dataset_path="unused",
+                               tracking_dataset=Dataset())
+    res = ev.run(_state())
+    te = res["trackeval"]
+    assert {"seqA", "seqB", "empty", "COMBINED_SEQ", "SUMMARIES"} == set(te)
+    assert {"HOTA", "MOTA", "IDF1", "IDSW", "CLR_TP", "MT", "ML"} <= set(seen["flat"])
+    assert seen["by_video"]["seqA/MOTA"] == te["seqA"]["pedestrian"]["CLEAR"]["MOTA"]
+    comb = te["COMBINED_SEQ"]["pedestrian"]
+    assert float(np.mean(comb["HOTA"]["HOTA"])) == pytest.approx(res["combined"]["HOTA"], rel=1e-12)       # same HOTA in both blocks
+    assert comb["CLEAR"]["CLR_TP"] + comb["CLEAR"]["CLR_FN"] == res["combined"]["num_objects"]

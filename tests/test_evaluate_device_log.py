@@ -25,8 +25,11 @@ class _Pipe:
         return cls.track_columns(self, rows, ocnt)
 
 
+@pytest.mark.parametrize("id_offset", [0, 5_000_000])
 @pytest.mark.parametrize("name", list(FORMATS))
-def test_device_log_tracks_equals_the_detection_table(name):
+def test_device_log_tracks_equals_the_detection_table(name, id_offset):
+    """id_offset: a LATER video of a run with `reset_ids_per_video: false` -- ByteTrack / BoT-SORT keep counting, so the ids of a short video
+    start far above the number of tracks the video itself can hold (they used to collapse into one dense id)"""
     rd = FORMATS[name]
     F, cap, maxd = 3, 10, 8
     pipe = _Pipe(rd, maxd)
@@ -42,7 +45,7 @@ def test_device_log_tracks_equals_the_detection_table(name):
             ocnt[1] = 0                                        # a frame without rows
         for f in range(F):
             for i in range(cap):
-                tid = float(rng.integers(1, 40))
+                tid = float(id_offset + rng.integers(1, 40))
                 b = rng.uniform(0, 100, 4); b[2:] += b[:2]
                 u = rng.random()
                 tf = f if u < 0.7 else (max(f - 1, 0) if u < 0.85 else (f - 4 if u < 0.93 else f + 1))      # this frame / the previous one / an earlier step / a later frame
@@ -74,6 +77,18 @@ def test_device_log_tracks_equals_the_detection_table(name):
     np.testing.assert_allclose(tr["ltrb"].numpy()[:len(inv)], np.column_stack([exp_ltwh[:, 0], exp_ltwh[:, 1], exp_ltwh[:, 0] + exp_ltwh[:, 2], exp_ltwh[:, 1] + exp_ltwh[:, 3]]),
                                rtol=0, atol=1e-12)
     np.testing.assert_array_equal(tr["off"].numpy(), exp_off)
+
+
+def test_device_log_tracks_refuses_ids_that_span_more_than_one_video_can_create():
+    """never clamp an id into another one: ids 1 and 10 000 in a 2-frame, 4-slot table cannot both come from this video"""
+    pipe = _Pipe(None, 4)
+    rows = torch.zeros((2, 4, 8), dtype=torch.float64)
+    rows[0, 0, 4], rows[0, 0, 7] = 1.0, 0.0
+    rows[1, 0, 4], rows[1, 0, 7] = 10_000.0, 4.0
+    log = DeviceStepLog(chunk=2)
+    log.sink(0, 2, 0)({"rows": rows, "ocnt": torch.tensor([1, 1], dtype=torch.int32), "dcnt": torch.tensor([4, 4], dtype=torch.int32)})
+    with pytest.raises(RuntimeError, match="span"):
+        evaluate.device_log_tracks(log, pipe)
 
 
 def test_device_log_tracks_refuses_an_overflowed_step():

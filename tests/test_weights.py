@@ -206,8 +206,13 @@ def test_load_checkpoint_entry_point(tmp_path):
     sd["module.classifier.weight"] = torch.zeros(10, 2048)
     ck = tmp_path / "reid.pth.tar"
     torch.save({"state_dict": sd, "epoch": 3}, ck)
-    rep = W.load_checkpoint(reid, ck)
+    with pytest.warns(RuntimeWarning, match="RANDOM initialisation"):                  # the part-based head is NOT in such a file: said loudly
+        rep = W.load_checkpoint(reid, ck)
     assert rep["format"] == "resnet50+batchnorm" and rep["unmapped_keys"] == ["module.classifier.weight"]
+    assert rep["uninitialised_parameters"] == sorted(k for k in reid.state_dict() if not k.startswith("backbone."))
+    assert "reduce.conv.weight" in rep["uninitialised_parameters"] and "part_cls.weight" in rep["uninitialised_parameters"]
+    with pytest.raises(ValueError, match="RANDOM initialisation"):
+        W.load_checkpoint(PartBasedReID(6, 64).eval(), ck, strict_heads=True)
     exp_w, exp_b = W.fold_batchnorm(sd["module.backbone.conv1.weight"], sd["module.backbone.bn1.weight"], sd["module.backbone.bn1.bias"],
                                     sd["module.backbone.bn1.running_mean"], sd["module.backbone.bn1.running_var"])
     np.testing.assert_array_equal(reid.backbone.conv1.conv.weight.detach().numpy(), exp_w)

@@ -128,14 +128,25 @@ def device_log_tracks(log, pipe):
     dest = torch.where(has, torch.cumsum(has, 0) - 1, torch.full_like(w, T * maxd))
     ids_raw = torch.zeros(T * maxd + 1, dtype=torch.int64, device=dev).scatter_(0, dest, ids_all)
     box = torch.zeros((T * maxd + 1, 4), dtype=torch.float64, device=dev).index_copy_(0, dest, box_all.contiguous())
-    # dense ids in sorted order: presence flags over [0, id bound) -> scan (track ids are small positive integers: every bank numbers from 1,
-    # so slot 0 only ever collects the untracked slots' zeros)
+    # dense ids in sorted order: presence flags over [0, id bound) -> scan.  The ids are taken RELATIVE to the smallest id of this video: with
+    # `reset_ids_per_video: false` (ByteTrack / BoT-SORT keep the reference's class-level counter across videos) a later video's ids start far
+    # above 1, but their RANGE inside one video is bounded by the tracks one video can create (at most one per detection slot and frame), which
+    # is what `bound` holds.  An id beyond the bound is an error, never clamped into another id.
     bound = T * max(cap, maxd) + 2
+    big = torch.iinfo(torch.int64).max
+    id_min = torch.where(has, ids_all, torch.full_like(ids_all, big)).min() if T else torch.zeros((), dtype=torch.int64, device=dev)
+    id_min = torch.where(id_min == big, torch.zeros_like(id_min), id_min)            # no tracked detection at all
+    rel_all = ids_all - id_min + 1                                                    # >= 1 where `has`; slot 0 collects the untracked slots
+    id_over = torch.where(has, rel_all, torch.zeros_like(rel_all)).max() if T else id_min
     present = torch.zeros(bound, dtype=torch.int64, device=dev)
-    present.scatter_(0, torch.where(has, ids_all.clamp(0, bound - 1), torch.zeros_like(w)), has.to(torch.int64))
+    present.scatter_(0, torch.where(has, rel_all.clamp(0, bound - 1), torch.zeros_like(w)), has.to(torch.int64))
     rank = torch.cumsum(present.clamp_(max=1), 0) - 1
-    dense = rank[ids_raw.clamp(0, bound - 1)].to(torch.int32)
-    nt, n_ids, worst = (int(v) for v in torch.stack([off[-1], present.sum(), ocnt.min() if T else off[-1]]).tolist())      # the ONE host fetch (three scalars)
+    rel_raw = torch.where(ids_raw > 0, ids_raw - id_min + 1, torch.zeros_like(ids_raw))
+    dense = rank[rel_raw.clamp(0, bound - 1)].to(torch.int32)
+    nt, n_ids, worst, over = (int(v) for v in torch.stack([off[-1], present.sum(), ocnt.min() if T else off[-1], id_over]).tolist())   # the ONE host fetch (four scalars)
+    if over >= bound:
+        raise RuntimeError(f"evaluate_device_log: track ids of this video span {over} values, more than the {bound - 2} tracks one video of {T} frames "
+                           "can create -- the table does not hold one video")
     if worst < 0:
         raise RuntimeError("evaluate_device_log: a step of this video overflowed the tracker's capacity (negative row count in the table)")
     ltwh = torch.stack([box[:, 0], box[:, 1], box[:, 2] - box[:, 0], box[:, 3] - box[:, 1]], dim=-1)

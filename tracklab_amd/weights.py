@@ -553,7 +553,7 @@ def resnet50_bn_pairs(prefix=""):
 
 
 # ------------------------------------------------------------------------------------------------ one entry point for the plugin modules
-def load_checkpoint(module, path, example_inputs=None, backbone_attr="backbone"):
+def load_checkpoint(module, path, example_inputs=None, backbone_attr="backbone", strict_heads=False):
     """What `cfg.checkpoint` / `cfg.model_weights` of the Hip* modules accepts:
 
     * ``*.onnx`` -- the artefact the reference itself loads for its detector / pose estimator (rtmlib model zoo,
@@ -562,7 +562,9 @@ def load_checkpoint(module, path, example_inputs=None, backbone_attr="backbone")
     * a torch checkpoint whose keys are `module`'s own -> `load_state_dict`.
     * a torch checkpoint of a ResNet-50 WITH BatchNorm layers in torchvision / torchreid naming (optionally under a prefix, optionally wrapped in
       {"state_dict": ...}; tracklab/wrappers/reid/kpreid_api.py:133-161 loads such files through torchreid): the backbone is folded
-      (`fold_batchnorm_state_dict`) into ``getattr(module, backbone_attr)``; keys outside the backbone that do not exist here are returned.
+      (`fold_batchnorm_state_dict`) into ``getattr(module, backbone_attr)``; keys outside the backbone that do not exist here are returned,
+      the module's own tensors outside the backbone (the part-based head) are reported as ``uninitialised_parameters`` with a WARNING
+      (``strict_heads=True``: an error instead).
 
     A path that does not exist raises FileNotFoundError -- never a silent fall-back to random weights. Returns a dict with what was done."""
     import copy
@@ -594,6 +596,22 @@ def load_checkpoint(module, path, example_inputs=None, backbone_attr="backbone")
         used = {p[0] + s for p in resnet50_bn_pairs(prefix) for s in (".weight", ".bias")} | \
                {p[1] + s for p in resnet50_bn_pairs(prefix) for s in (".weight", ".bias", ".running_mean", ".running_var", ".num_batches_tracked")}
         left = sorted(k for k in sd if k not in used)
-        return {"format": "resnet50+batchnorm", "tensors": len(folded), "unmapped_keys": left}
+        # Only the backbone can be mapped: the part-based head of the reference lives in the third-party torchreid fork (not vendored, its key
+        # names are not in the reference tree), so `module`'s own head stays as it was initialised.  That must never pass silently
+        # (ADVICE r03): the report lists it, a WARNING is logged and warned, and strict_heads=True turns it into an error.
+        uninit = sorted(k for k in own if not k.startswith(backbone_attr + "."))
+        report = {"format": "resnet50+batchnorm", "tensors": len(folded), "unmapped_keys": left, "uninitialised_parameters": uninit}
+        if uninit:
+            msg = (f"checkpoint {path!r}: the ResNet-50 backbone was loaded ({len(folded)} tensors, BatchNorm folded) but {len(uninit)} tensors of "
+                   f"{type(module).__name__} outside `{backbone_attr}` keep their RANDOM initialisation: {uninit[:6]}{' ...' if len(uninit) > 6 else ''}; "
+                   f"{len(left)} checkpoint tensors were not used: {left[:6]}{' ...' if len(left) > 6 else ''}. Embeddings of this module are NOT the "
+                   "reference model's until the head is loaded too (save this module's own state_dict, or an ONNX export).")
+            if strict_heads:
+                raise ValueError(msg)
+            import logging
+            import warnings
+            logging.getLogger("tracklab_amd.weights").warning(msg)
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
+        return report
     missing = sorted(set(own) - set(sd))[:5]
     raise ValueError(f"checkpoint {path!r}: neither this module's state_dict (missing e.g. {missing}) nor a ResNet-50 with BatchNorm layers")

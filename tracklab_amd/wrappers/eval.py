@@ -1,7 +1,12 @@
 """Evaluator plugin: the place of tracklab.wrappers.TrackEvalEvaluator (wrappers/eval/trackeval_evaluator.py:14-110) in a TrackLab run
--- same constructor arguments, `run(tracker_state)` -- with HOTA and the CLEAR-MOT / ID measures computed by tracklab_amd's own evaluators
-(tracklab_amd.hota: TrackEval's HOTA definition; tracklab_amd.clearmot: py-motmetrics' definitions) instead of pip `trackeval`, on the MI355X by
-default (`cfg.device: gpu` -> tlk_hota_sequence_f64 / tlk_clear_sequence_f64; `cpu`: the numpy restatements, bit-compatible statistics).
+-- same constructor arguments, `run(tracker_state)` -- with the three metric families of configs/eval/trackeval.yaml:11-14 computed by tracklab_amd:
+  * ``results["trackeval"]``: TrackEval's RESULT LAYOUT ({sequence: {"pedestrian": {"HOTA" | "CLEAR" | "Identity": fields}}, "COMBINED_SEQ", "SUMMARIES"})
+    with TrackEval's DEFINITIONS -- HOTA (tracklab_amd.hota, on the MI355X with `cfg.device: gpu`), CLEAR and Identity
+    (tracklab_amd.trackeval_metrics: TrackEval's per-frame 1000x-continuity Hungarian, id switches against the last id ever matched, MT / ML at
+    > 0.8 / < 0.2; host numpy) -- this is what goes to ``tracking_dataset.process_trackeval_results`` as in the reference;
+  * ``results["sequences"] / results["combined"]``: flat float summaries with HOTA and the py-motmetrics CLEAR-MOT / ID measures
+    (tracklab_amd.clearmot; both on the device with `cfg.device: gpu` -> tlk_hota_sequence_f64 / tlk_clear_sequence_f64).  MOTA / IDSW / MT / ML of
+    this block follow py-motmetrics (what the reference's PoseTrack21 MOT evaluator uses) and can differ from TrackEval's for the same tracks.
 
 What it takes from the tracker state is exactly what the reference's evaluator writes to its MOTChallenge files before TrackEval reads them back
 (TrackingDataset.save_for_eval -> _mot_encoding, datastruct/tracking_dataset.py:161-236): per video, the rows with a track id, a box in
@@ -68,6 +73,7 @@ class HipTrackEvalEvaluator(_EvaluatorBase):
 
     def run(self, tracker_state):
         from .. import evaluate, mot_io
+        from .. import trackeval_metrics as te_metrics
         bbox_col = str(cfg_get(self.cfg, "bbox_column_for_eval", "bbox_ltwh"))
         gt_all = getattr(tracker_state, "detections_gt", None)
         if gt_all is None or len(gt_all) == 0:                  # trackeval_evaluator.py:46-49
@@ -78,23 +84,45 @@ class HipTrackEvalEvaluator(_EvaluatorBase):
         if cfg_get(self.cfg, "save_files", False) and folder:
             mot_io.save_for_eval(tracker_state.detections_pred, im, vm, os.path.join(str(folder), "pred"), bbox_col, False)
             mot_io.save_for_eval(gt_all, im, vm, os.path.join(str(folder), "gt"), "bbox_ltwh", True)
-        pred, gt = _mot_rows(tracker_state.detections_pred, im, bbox_col), _mot_rows(gt_all, im, "bbox_ltwh")
+        # the reference writes BOTH sides with cfg.bbox_column_for_eval (trackeval_evaluator.py:36-63); a ground truth without that column (e.g.
+        # `track_bbox_kf_ltwh`, which only predictions have) falls back to bbox_ltwh with a warning instead of evaluating nothing
+        gt_col = bbox_col if bbox_col in gt_all.columns else "bbox_ltwh"
+        if gt_col != bbox_col:
+            log.warning("ground truth has no column %r: evaluating it with bbox_ltwh", bbox_col)
+        pred, gt = _mot_rows(tracker_state.detections_pred, im, bbox_col), _mot_rows(gt_all, im, gt_col)
         empty = {"frame": np.zeros(0, np.int64), "track_id": np.zeros(0, np.int64), "ltwh": np.zeros((0, 4))}
-        per_seq = {}
+        metrics = tuple(cfg_get(self.cfg, "metrics", ("CLEAR", "HOTA", "Identity")))
+        thr = 1.0 - float(cfg_get(self.cfg, "max_iou", 0.5))             # TrackEval's THRESHOLD on the IoU = 1 - motmetrics' max distance
+        per_seq, te_seq = {}, {}
         for vid, video in vm.iterrows():
             n_frames = int(video["nframes"]) if "nframes" in video.index and not pd.isna(video["nframes"]) else None
-            per_seq[str(video["name"])] = evaluate.evaluate_sequence(gt.get(vid, empty), pred.get(vid, empty), n_frames=n_frames,
-                                                                     max_iou=float(cfg_get(self.cfg, "max_iou", 0.5)), device=self.device)
+            g_, p_ = gt.get(vid, empty), pred.get(vid, empty)
+            r = evaluate.evaluate_sequence(g_, p_, n_frames=n_frames, max_iou=float(cfg_get(self.cfg, "max_iou", 0.5)), device=self.device)
+            per_seq[str(video["name"])] = r
+            # TrackEval's own CLEAR / Identity (host: one Hungarian per frame + one global one; the device evaluators above implement HOTA and the
+            # py-motmetrics definitions)
+            gb, pb = evaluate._by_frame(g_), evaluate._by_frame(p_)
+            last = n_frames if n_frames is not None else max([0] + list(gb) + list(pb))
+            none = (np.zeros(0, np.int64), np.zeros((0, 4)))
+            to_ltrb = lambda b: np.column_stack([b[:, 0], b[:, 1], b[:, 0] + b[:, 2], b[:, 1] + b[:, 3]]).reshape(-1, 4)      # noqa: E731
+            gfr = [(gb.get(f, none)[0], to_ltrb(gb.get(f, none)[1])) for f in range(1, last + 1)]
+            pfr = [(pb.get(f, none)[0], to_ltrb(pb.get(f, none)[1])) for f in range(1, last + 1)]
+            te = te_metrics.evaluate_sequence_frames(gfr, pfr, thr) if last else \
+                {"CLEAR": dict({k: 0 for k in te_metrics.CLEAR_SUMMED}, MOTP_sum=0.0), "Identity": {k: 0 for k in te_metrics.ID_INT}}
+            te_seq[str(video["name"])] = dict(te, hota=r["hota"])
         self.results = evaluate.combine(per_seq)
-        if self.results.get("combined"):
-            c = self.results["combined"]
-            keys = [k for k in ("HOTA", "DetA", "AssA", "MOTA", "MOTP", "IDF1", "num_switches", "num_false_positives", "num_misses") if k in c]
+        # TrackEval's result layout with TrackEval's definitions -- what the reference hands to tracking_dataset.process_trackeval_results
+        self.results["trackeval"] = te_metrics.trackeval_layout(te_seq, str(cfg_get(self.cfg, "class_name", "pedestrian")), metrics)
+        summ = self.results["trackeval"].get("SUMMARIES", {})
+        for cls_, fams in summ.items():
             try:
                 from tabulate import tabulate
-                log.info("tracklab_amd evaluation (%s)\n%s", self.device, tabulate([[f"{c[k]:.4f}" if isinstance(c[k], float) and abs(c[k]) <= 1 else c[k] for k in keys]],
-                                                                                   headers=keys, tablefmt="plain"))
+                for fam, fields in fams.items():
+                    log.info("tracklab_amd evaluation (%s) %s / %s, COMBINED_SEQ\n%s", self.device, cls_, fam,
+                             tabulate([list(fields.values())], headers=list(fields.keys()), tablefmt="plain"))
             except Exception:                                   # noqa: BLE001
-                log.info("tracklab_amd evaluation (%s): %s", self.device, {k: c[k] for k in keys})
-        if hasattr(self.tracking_dataset, "process_trackeval_results") and cfg_get(self.cfg, "forward_to_dataset", False):
-            self.tracking_dataset.process_trackeval_results(self.results, {}, {})
+                log.info("tracklab_amd evaluation (%s): %s", self.device, fams)
+        if hasattr(self.tracking_dataset, "process_trackeval_results") and cfg_get(self.cfg, "forward_to_dataset", True):
+            self.tracking_dataset.process_trackeval_results(self.results["trackeval"], dict(cfg_get(self.cfg, "dataset", {}) or {}),
+                                                            dict(cfg_get(self.cfg, "eval", {}) or {}))
         return self.results

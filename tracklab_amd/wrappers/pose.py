@@ -35,6 +35,8 @@ class HipRTMPose(ImageLevelModule):
             if self.checkpoint:          # state_dict, the reference's own ONNX artefact, or a BatchNorm ResNet-50 checkpoint (tracklab_amd/weights.py)
                 from ..weights import load_checkpoint
                 self.checkpoint_report = load_checkpoint(self._model, self.checkpoint, (torch.zeros(1, 3, self.in_h, self.in_w),))
+                import logging
+                logging.getLogger(__name__).info("%s: checkpoint %s -> %s", type(self).__name__, self.checkpoint, self.checkpoint_report)
 
     def preprocess(self, image, detections: pd.DataFrame, metadata: pd.Series):
         n = len(detections)

@@ -246,6 +246,8 @@ class _ReidTrackerBase:
                         f"model_weights {ckpt!r} does not exist; set model_weights: null to run with random-init weights (throughput only)")
                 from ..weights import load_checkpoint
                 self.checkpoint_report = load_checkpoint(self._model, ckpt, (torch.zeros(1, 3, 256, 128),))
+                import logging
+                logging.getLogger(__name__).info("%s: checkpoint %s -> %s", type(self).__name__, ckpt, self.checkpoint_report)
         frames = self._frame_on_device(image)[None]
         n = len(dets)
         boxes = torch.from_numpy(np.ascontiguousarray(dets, dtype=np.float64)[None]).to(self.device)
