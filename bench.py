@@ -195,6 +195,12 @@ def main_dry_run(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist = tdist.init("gloo")
     dev = torch.device("cpu")
+    if world > 1:                      # the placement a real multi-GPU run reports, in its no-NUMA-information form (disjoint CPU slices per rank)
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        sl = tdist.even_cpu_slice(int(os.environ.get("LOCAL_RANK", rank)), lw)
+        if sl:
+            os.sched_setaffinity(0, sl)
+            os.environ["TLK_BENCH_AFFINITY"] = json.dumps([-1, len(sl)])
     wl = WORKLOADS[args.workload]
     S, F = args.streams, args.frames_per_step or wl["frames_per_step"]
     nobj = args.objects or wl["objects"]
@@ -343,13 +349,20 @@ def pin_rank_to_gpu_numa_node(dev_index: int, local_rank: int, local_world: int)
                     same.append(i)
             except Exception:
                 pass
-        if dev_index in same and len(same) > 1:
-            per = max(1, len(allowed) // len(same))
-            k = same.index(dev_index)
-            allowed = allowed[k * per:(k + 1) * per] or allowed
+        from tracklab_amd import dist as tdist
+        allowed = tdist.numa_cpu_slice(cpus, same, dev_index)
         os.sched_setaffinity(0, allowed)
         return [node, len(allowed)]
     except Exception:
+        # no NUMA information (containers without the PCI tree): still give every rank its own slice of the host CPUs, reported with node -1
+        try:
+            from tracklab_amd import dist as tdist
+            sl = tdist.even_cpu_slice(local_rank, local_world)
+            if sl and local_world > 1:
+                os.sched_setaffinity(0, sl)
+                return [-1, len(sl)]
+        except Exception:
+            pass
         return None
 
 

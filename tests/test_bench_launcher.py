@@ -53,3 +53,31 @@ def test_bench_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "64", "--steps", "1"], capture_output=True, text=True,
                        timeout=300, env=_env(), cwd=REPO)
     assert r.returncode != 0 and "--gpus 64" in (r.stderr + r.stdout)
+
+
+def test_eight_ranks_like_the_drivers_scaling_run():
+    """world size 8 on gloo through the bench entry point: one stream per rank, all eight rates and placements gathered, the HOTA
+    statistics of all eight streams summed, every rank on its own slice of the host CPUs"""
+    args = [a if a != "2" or i != 2 else "8" for i, a in enumerate(ARGS)]
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, timeout=600, env=_env(), cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and sorted(x for x, _ in j["ranks_seen"]) == list(range(8)) and len(j["per_rank_fps"]) == 8
+    assert j["hota_allreduce"]["frames"] == 8 * 3 * 4 and abs(j["hota_allreduce"]["HOTA"] - 1.0) < 1e-12
+    assert j["config"]["parallelism"] == "stream-parallel x8" and j["streams_of_rank0"] == [0]
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= 8:
+        assert all(p[2] == ncpu // 8 for p in j["rank_placement"]), j["rank_placement"]      # [rank, node, cpus]: eight equal, disjoint slices
+
+
+def test_cpu_slices_are_disjoint_and_numa_local():
+    from tracklab_amd import dist as tdist
+    cpus = list(range(64))
+    sl = [tdist.even_cpu_slice(r, 8, cpus) for r in range(8)]
+    assert all(len(s_) == 8 for s_ in sl) and sorted(sum(sl, [])) == cpus
+    assert tdist.even_cpu_slice(0, 1, cpus) == cpus and tdist.even_cpu_slice(3, 8, [0, 1]) == [0, 1]
+    node1 = list(range(32, 64))                                # GPUs 4..7 hang off NUMA node 1
+    got = [tdist.numa_cpu_slice(node1, [4, 5, 6, 7], d, allowed=range(64)) for d in (4, 5, 6, 7)]
+    assert got[0] == list(range(32, 40)) and got[3] == list(range(56, 64)) and sorted(sum(got, [])) == node1

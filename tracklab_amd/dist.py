@@ -50,3 +50,23 @@ def allreduce_max(value: float, dist=None, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def even_cpu_slice(local_rank: int, local_world: int, cpus=None) -> list[int]:
+    """Host CPUs of one rank when the GPU's NUMA node is not known (/sys without the PCI tree): the allowed CPUs split evenly, in order, among
+    the node's ranks -- disjoint slices, so that 8 ranks' loader / pinned-memory threads do not all roam over every core."""
+    cpus = sorted(os.sched_getaffinity(0)) if cpus is None else sorted(cpus)
+    if local_world <= 1 or len(cpus) < local_world:
+        return cpus
+    per = len(cpus) // local_world
+    return cpus[local_rank * per:(local_rank + 1) * per]
+
+
+def numa_cpu_slice(node_cpus, peers_on_node: list[int], me: int, allowed=None) -> list[int]:
+    """CPUs of rank `me` among the ranks `peers_on_node` (sorted device indices) that share one NUMA node's `node_cpus`."""
+    allowed = sorted(set(node_cpus) & (set(allowed) if allowed is not None else os.sched_getaffinity(0)))
+    if not allowed or me not in peers_on_node or len(peers_on_node) <= 1:
+        return allowed
+    per = max(1, len(allowed) // len(peers_on_node))
+    k = peers_on_node.index(me)
+    return allowed[k * per:(k + 1) * per] or allowed
