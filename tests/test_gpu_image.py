@@ -119,6 +119,38 @@ def test_yolox_decode_nms_matches_oracle(orc, num_classes, nobj):
         np.testing.assert_allclose(out["ltwh"][b, :n].cpu().numpy(), exp_ltwh, rtol=2e-6, atol=2e-4)
 
 
+@pytest.mark.parametrize("frac,dup", [(0.04, 3), (0.10, 8), (0.20, 3), (0.40, 3)])
+def test_yolox_decode_nms_with_many_candidates(orc, frac, dup):
+    """r04 NMS (rank sort up to 1024 candidates, bitonic beyond; 64-row suppression bitmask blocks): hundreds to thousands of candidates per frame,
+    heavy overlap -- a fraction of ALL anchors is lifted above the score threshold on top of 100 objects with `dup` near-duplicates each; kept
+    set and order equal the oracle's sequential greedy loop (338, 850, 1700 and 3400 candidates: both sort paths, up to 54 blocks)"""
+    import torch
+    from tracklab_amd import _lib
+    from tracklab_amd.synth import SyntheticStream
+    rng = np.random.default_rng(int(frac * 100) + dup)
+    preds = []
+    for b in range(2):
+        fr = SyntheticStream(300 + b, 100, 1).step()
+        h = synth_head(rng, fr["dets"][:, :4], dup=dup)
+        lift = rng.random(len(h)) < frac
+        h[lift, 4] = rng.uniform(0.85, 1.0, int(lift.sum())).astype(np.float32)
+        h[lift, 5] = rng.uniform(0.85, 1.0, int(lift.sum())).astype(np.float32)
+        h[lift, 2:4] = rng.normal(1.2, 0.5, (int(lift.sum()), 2)).astype(np.float32)      # larger boxes: they overlap
+        preds.append(h)
+    preds = np.stack(preds)
+    ratio = np.float32(640 / 1920)
+    out = _lib.yolox_decode_nms(torch.from_numpy(preds).cuda(), 640, float(ratio), 1920, 1080, max_out=4096)
+    counts = out["counts"].cpu().numpy()
+    for b in range(2):
+        eb, es, ec = orc.yolox_postprocess(preds[b], 640, float(ratio))
+        ncand = int(((preds[b][:, 4] * preds[b][:, 5]) > 0.7).sum())
+        assert ncand > (200 if frac < 0.1 else 1024 if frac >= 0.2 else 600) and len(eb) < ncand
+        assert counts[b] == len(eb), (b, counts[b], len(eb), ncand)
+        n = counts[b]
+        np.testing.assert_array_equal(out["scores"][b, :n].cpu().numpy(), es)
+        np.testing.assert_allclose(out["xyxy"][b, :n].cpu().numpy(), eb, rtol=2e-6, atol=1e-4)
+
+
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
 @pytest.mark.parametrize("act", ["relu", "silu", None])
 def test_fused_bias_act_epilogue_matches_torch(dtype_name, act):
