@@ -1,6 +1,6 @@
 """Probe (not product): time the two ReID crop kernels in isolation with HIP events on one bench launch's shapes
 (24 frames x 104 slots, ~98 real crops per frame of the synthetic 100-object stream) and print us / algorithmic GB/s.
-TLK_CROP_KERNEL=1 selects round 1's crop_lds_kernel, 2 (default) the separable crop_sep_kernel."""
+(r04: one kernel per output type; the TLK_CROP_KERNEL switch is gone.)"""
 import json
 import os
 import sys

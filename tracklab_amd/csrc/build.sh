@@ -11,7 +11,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I"$HERE/../
 # LK kernel of tlk_cmc.hip, whose dx/dy update the compiler had packed, gave lane-dependent results in ~0.1 % of its iterations while a
 # ResNet-50 forward ran on another stream and exact ones alone (profiles/r02_pk_f32_overlap.md); without packed code it is exact in both.
 # The pre/post-processing kernels below run in stream order with the networks and keep the default code generation they were measured with.
-PACKED_OK="tlk_image tlk_epilogue tlk_pose tlk_gemm"
+PACKED_OK="tlk_image tlk_pil tlk_nms tlk_epilogue tlk_pose tlk_gemm"
 NOPK=(-fno-slp-vectorize -Xclang -target-feature -Xclang -packed-fp32-ops)
 objs=()
 pids=()

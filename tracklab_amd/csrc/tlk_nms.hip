@@ -1,0 +1,227 @@
+// tlk_nms.hip -- detector post-processing: YOLOX decode + per-class greedy NMS (rtmlib YOLOX.postprocess / multiclass_nms / nms behind
+// tracklab/wrappers/bbox_detector/rtmlib_api.py:27-46), emitting the detector's rows AND the tracker's input rows in one launch.
+// (r04: moved out of tlk_image.hip, which keeps the byte-moving pre-processing kernels.)
+#include "tlk_common.hpp"
+
+using namespace tlk;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// YOLOX decode + per-class greedy NMS (rtmlib YOLOX.postprocess / multiclass_nms / nms), one workgroup
+// per frame. Candidates (score = obj*cls > score_thr) are compacted and sorted by (score desc, anchor desc): up to 1024 of them by RANK
+// (every candidate counts the keys above its own -- m*m/256 comparisons per lane, no barrier ladder), more by a bitonic network in LDS.
+// Greedy NMS (r04, VERDICT r03 #4: 163 -> ~25 us per 24-frame launch): candidates are taken 64 at a time; all four wavefronts first build
+// the block's suppression bitmask rows in parallel (row i, word w = __ballot over 64 later candidates of "IoU(i, j) > thr"), then ONE
+// wavefront walks the 64 rows in order with the alive words in registers (lane = word): alive &= ~row -- the sequential part is one LDS
+// read and one AND per candidate instead of an IoU sweep.  Same kept set and order as the sweep: a row is only applied when its candidate
+// is still alive at its turn.  fp32 arithmetic in the reference's operation order ("+1" pixel convention, ovr <= thr keeps).
+// ---------------------------------------------------------------------------------------------
+constexpr int NMS_CAP = 4096;      // max candidates per (frame, class)
+constexpr int NMS_RANK_CAP = 1024; // up to here the candidates are sorted by rank, beyond by the bitonic network
+
+__global__ void __launch_bounds__(BLOCK) yolox_decode_nms_kernel(const float *__restrict__ pred_all, int S, int C, float ratio,
+                                                                 float nms_thr, float score_thr, int img_w, int img_h,
+                                                                 int max_out, float *__restrict__ ltwh_out,
+                                                                 float *__restrict__ xyxy_out, float *__restrict__ score_out,
+                                                                 int *__restrict__ cls_out, int *__restrict__ count_out,
+                                                                 double *__restrict__ trk_in, long long id_base, double category_id)
+{
+    __shared__ unsigned long long key[NMS_CAP];
+    __shared__ float bx[NMS_CAP][4];
+    __shared__ float barea[NMS_CAP];
+    __shared__ unsigned long long alive[NMS_CAP / 64];
+    __shared__ unsigned long long rowmask[64][NMS_CAP / 64];     // suppression rows of the current block of 64 candidates (32 KB)
+    __shared__ unsigned long long srt[NMS_RANK_CAP];            // rank-sort destination; afterwards the list of kept candidates (u16)
+    __shared__ int s_cnt, s_out, s_err, s_kept, s_emit;
+    unsigned short *kept = reinterpret_cast<unsigned short *>(srt);              // NMS_CAP entries = 8 KB = sizeof(srt)
+    static_assert(sizeof(srt) >= NMS_CAP * sizeof(unsigned short), "kept list aliases the sort buffer");
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n8 = (S / 8) * (S / 8), n16 = (S / 16) * (S / 16), n32 = (S / 32) * (S / 32);
+    const int A = n8 + n16 + n32, F = 5 + C;
+    const float *pred = pred_all + (size_t)b * A * F;
+    if (tid == 0) { s_out = 0; s_err = 0; }
+    for (int c = 0; c < C; ++c) {
+        if (tid == 0) { s_cnt = 0; s_kept = 0; s_emit = 0; }
+        __syncthreads();
+        // 1. candidates: appended in arrival order (the sort below orders them: the anchor is part of the key, keys are distinct)
+        // (the loads of 16 anchors per lane are issued together: one round trip to memory per 4096 anchors instead of one per 256)
+        for (int a0 = tid; a0 < A; a0 += 16 * BLOCK) {
+            float so[16], sc[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int a = a0 + u * BLOCK;
+                const size_t o = (size_t)(a < A ? a : 0) * F;
+                so[u] = pred[o + 4]; sc[u] = pred[o + 5 + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int a = a0 + u * BLOCK;
+                const float s = so[u] * sc[u];
+                if (a < A && s > score_thr) {
+                    const int pos = atomicAdd(&s_cnt, 1);
+                    if (pos < NMS_CAP) key[pos] = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned int)a;
+                }
+            }
+        }
+        __syncthreads();
+        const int n = s_cnt;
+        if (n > NMS_CAP) { if (tid == 0) s_err = 1; }
+        const int m = n < NMS_CAP ? n : NMS_CAP;
+        // 2. sort, descending by (score bits, anchor)
+        if (m <= NMS_RANK_CAP) {
+            for (int i = tid; i < m; i += BLOCK) {
+                const unsigned long long mine = key[i];
+                int above = 0;
+#pragma unroll 8
+                for (int j = 0; j < m; ++j) above += key[j] > mine ? 1 : 0;      // every lane reads the same word: LDS broadcast
+                srt[above] = mine;
+            }
+            __syncthreads();
+            for (int i = tid; i < m; i += BLOCK) key[i] = srt[i];
+            __syncthreads();
+        } else {
+            int p2 = 1;
+            while (p2 < m) p2 <<= 1;
+            for (int k = m + tid; k < p2; k += BLOCK) key[k] = 0ull;      // pad: sorts last (scores > 0)
+            __syncthreads();
+            for (int k = 2; k <= p2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < p2; i += BLOCK) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const unsigned long long a = key[i], bb = key[ixj];
+                            const bool desc = (i & k) == 0;
+                            if (desc ? (a < bb) : (a > bb)) { key[i] = bb; key[ixj] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+        }
+        // 3. decode the candidates (rtmlib: (xy+grid)*stride, exp(wh)*stride, /ratio)
+        for (int k = tid; k < m; k += BLOCK) {
+            const int a = (int)(key[k] & 0xffffffffull);
+            int st, loc, ws;
+            if (a < n8) { st = 8; loc = a; ws = S / 8; }
+            else if (a < n8 + n16) { st = 16; loc = a - n8; ws = S / 16; }
+            else { st = 32; loc = a - n8 - n16; ws = S / 32; }
+            const int gy = loc / ws, gx = loc - gy * ws;
+            const float *p = pred + (size_t)a * F;
+            const float fs = (float)st;
+            const float cx = (p[0] + (float)gx) * fs, cy = (p[1] + (float)gy) * fs;
+            const float w = expf(p[2]) * fs, h = expf(p[3]) * fs;
+            float x1 = cx - w / 2.f, y1 = cy - h / 2.f, x2 = cx + w / 2.f, y2 = cy + h / 2.f;
+            x1 /= ratio; y1 /= ratio; x2 /= ratio; y2 /= ratio;
+            bx[k][0] = x1; bx[k][1] = y1; bx[k][2] = x2; bx[k][3] = y2;
+            barea[k] = (x2 - x1 + 1) * (y2 - y1 + 1);
+        }
+        for (int k = tid; k < NMS_CAP / 64; k += BLOCK) {
+            const int lo = k * 64;
+            alive[k] = (lo + 64 <= m) ? ~0ull : (lo >= m ? 0ull : ((1ull << (m - lo)) - 1ull));
+        }
+        __syncthreads();
+        // 4. greedy NMS, 64 candidates (one block of rows) at a time
+        const int nwords = (m + 63) >> 6;
+        for (int blk = 0; blk < nwords; ++blk) {
+            // 4a. all wavefronts: suppression rows of the block's candidates that are still alive, against every later candidate
+            const unsigned long long alive_blk = alive[blk];
+            for (int r = wave; r < 64; r += NWAVES) {
+                const int i = blk * 64 + r;
+                if (i >= m || !((alive_blk >> r) & 1ull)) continue;           // uniform per wavefront (a row killed later inside the block is built in vain, never applied)
+                const float ix1 = bx[i][0], iy1 = bx[i][1], ix2 = bx[i][2], iy2 = bx[i][3], ia = barea[i];
+                for (int w = blk; w < nwords; ++w) {
+                    const int j = w * 64 + lane;
+                    bool kill = false;
+                    if (j > i && j < m) {
+                        const float xx1 = fmaxf(ix1, bx[j][0]), yy1 = fmaxf(iy1, bx[j][1]);
+                        const float xx2 = fminf(ix2, bx[j][2]), yy2 = fminf(iy2, bx[j][3]);
+                        const float w_ = fmaxf(0.0f, xx2 - xx1 + 1), h_ = fmaxf(0.0f, yy2 - yy1 + 1);
+                        const float inter = w_ * h_;
+                        const float ovr = inter / (ia + barea[j] - inter);
+                        kill = !(ovr <= nms_thr);
+                    }
+                    const unsigned long long km = __ballot(kill);
+                    if (lane == 0) rowmask[r][w] = km;
+                }
+            }
+            __syncthreads();
+            // 4b. wavefront 0.  Lane r holds the block-diagonal word of row r, so who survives INSIDE the block is resolved with scalar
+            // bit operations and readlane (no memory access in the sequential chain); the survivors' rows are then OR-ed into every
+            // later word in parallel (lane = word) and the survivors are appended to the kept list.
+            if (tid < WAVE) {
+                const unsigned long long diag = rowmask[lane][blk];             // (rows not rebuilt this block are never selected below)
+                const unsigned int dlo = (unsigned int)diag, dhi = (unsigned int)(diag >> 32);
+                unsigned long long a0 = alive_blk, keep = 0ull;
+                while (a0) {                                                    // uniform: a0 is the same in every lane
+                    const int r = __builtin_ctzll(a0);
+                    keep |= 1ull << r;
+                    a0 &= ~(1ull << r);
+                    const unsigned long long row = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, r) << 32) |
+                                                   (unsigned int)__builtin_amdgcn_readlane((int)dlo, r);
+                    a0 &= ~row;
+                }
+                const int w = blk + 1 + lane;                                   // later words
+                if (w < nwords) {
+                    unsigned long long aw = alive[w], kk = keep;
+                    while (kk) {
+                        const int r = __builtin_ctzll(kk);
+                        kk &= kk - 1;
+                        aw &= ~rowmask[r][w];
+                    }
+                    alive[w] = aw;
+                }
+                const int base = s_kept;
+                if ((keep >> lane) & 1ull) kept[base + __builtin_popcountll(keep & ((1ull << lane) - 1ull))] = (unsigned short)(blk * 64 + lane);
+                if (lane == 0) s_kept = base + __builtin_popcountll(keep);
+            }
+            __syncthreads();
+        }
+        // 5. emission, in parallel: the kept candidates with a final score above 0.3 (rtmlib: final_scores > 0.3) are a prefix of the kept
+        // list (scores descend along it)
+        const int nk = s_kept, out0 = s_out;
+        for (int k = tid; k < nk; k += BLOCK)
+            if (__uint_as_float((unsigned int)(key[kept[k]] >> 32)) > 0.3f) atomicMax(&s_emit, k + 1);
+        __syncthreads();
+        const int ne = s_emit;
+        for (int k = tid; k < ne; k += BLOCK) {
+            const int i = kept[k], n_out = out0 + k;
+            if (n_out >= max_out) continue;
+            const size_t o = (size_t)b * max_out + n_out;
+            float l = bx[i][0], t = bx[i][1], r = bx[i][2], bt = bx[i][3];
+            xyxy_out[o * 4] = l; xyxy_out[o * 4 + 1] = t; xyxy_out[o * 4 + 2] = r; xyxy_out[o * 4 + 3] = bt;
+            // RTMLibDetector: ltrb_to_ltwh(bbox, (W,H)) -> sanitize_bbox_ltrb (coordinates.py:270-295,318-328), float32
+            l = fmaxf(0.f, fminf(l, (float)(img_w - 2))); t = fmaxf(0.f, fminf(t, (float)(img_h - 2)));
+            r = fmaxf(1.f, fminf(r, (float)(img_w - 1))); bt = fmaxf(1.f, fminf(bt, (float)(img_h - 1)));
+            ltwh_out[o * 4] = l; ltwh_out[o * 4 + 1] = t; ltwh_out[o * 4 + 2] = r - l; ltwh_out[o * 4 + 3] = bt - t;
+            score_out[o] = __uint_as_float((unsigned int)(key[i] >> 32)); cls_out[o] = c;
+            if (trk_in) {   // row the tracker wrapper would build (oc_sort_api.py:37-45): float32 ltwh -> ltrb,
+                            // bbox_conf = 1.0 and category_id as set by RTMLibDetector (rtmlib_api.py:36-41)
+                double *q = trk_in + o * 7;
+                const float w = r - l, h = bt - t;
+                q[0] = (double)l; q[1] = (double)t; q[2] = (double)(l + w); q[3] = (double)(t + h);
+                q[4] = 1.0; q[5] = category_id; q[6] = (double)(id_base + (long long)b * max_out + n_out);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_out = out0 + ne;
+        __syncthreads();
+    }
+    if (tid == 0) count_out[b] = s_err ? TLK_ECAPACITY : (s_out > max_out ? TLK_ECAPACITY : s_out);
+}
+
+}  // namespace
+
+extern "C" int tlk_yolox_decode_nms(const float *pred_dev, int batch, int size, int num_classes, float ratio, float nms_thr,
+                                    float score_thr, int img_w, int img_h, int max_out, float *ltwh_dev, float *xyxy_dev,
+                                    float *scores_dev, int32_t *cls_dev, int32_t *counts_dev, double *trk_in_dev,
+                                    int64_t det_id_base, double category_id, void *hip_stream)
+{
+    if (batch < 0 || size <= 0 || size % 32 != 0 || num_classes < 1 || max_out < 0) return fail(TLK_EINVAL, "tlk_yolox_decode_nms: bad size");
+    if (batch == 0) return TLK_OK;
+    if (!pred_dev || !ltwh_dev || !xyxy_dev || !scores_dev || !cls_dev || !counts_dev) return fail(TLK_EINVAL, "tlk_yolox_decode_nms: null pointer");
+    hipLaunchKernelGGL(yolox_decode_nms_kernel, dim3(batch), dim3(BLOCK), 0, (hipStream_t)hip_stream, pred_dev, size, num_classes,
+                       ratio, nms_thr, score_thr, img_w, img_h, max_out, ltwh_dev, xyxy_dev, scores_dev, (int *)cls_dev, (int *)counts_dev,
+                       trk_in_dev, (long long)det_id_base, category_id);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
