@@ -198,8 +198,10 @@ typedef struct {
     int32_t matching_strategy;   /* 0 strong_sort_matching, 1 bot_sort_matching */
     int32_t wrapper_mode;        /* 1: skip the tracker entirely on a frame with 0 detections */
     int32_t parts, dim;          /* K, D of the embeddings */
-    int32_t max_tracks;          /* <= 1024 (live + coasting tracks per stream; TLK_ECAPACITY beyond, where the reference's lists grow) */
-    int32_t max_dets;            /* <= 256 */
+    int32_t max_tracks;          /* allocation per stream, <= 16384 (live + coasting tracks; the reference's lists grow: sort/tracker.py:427-441).  Track state lives in
+                                  * HBM at this capacity; a frame's lists and Hungarian work area use LDS while tracks + detections <= 1024 and detections <= 256
+                                  * (tiers 256 x 128 and 1024 x 256), HBM beyond.  TLK_ECAPACITY only past the allocation */
+    int32_t max_dets;            /* detections per frame, <= 1024 (same tiers) */
     int32_t motion_criterium;    /* 0 "iou" (sort/iou_matching.py), 1 "oks" (sort/oks_matching.py; needs keypoints) */
     int32_t reserved_;
     double max_oks_distance;

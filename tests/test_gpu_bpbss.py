@@ -153,5 +153,32 @@ def test_hip_bpbss_beyond_512_tracks(orc):
         most = max(most, len(bank.tracks()[0]))
     assert most > 600
     with pytest.raises(Exception):
-        _bank(YAML, K, D, max_tracks=1025)
+        _bank(YAML, K, D, max_tracks=16385)
+    bank.close()
+
+
+def test_hip_bpbss_2000_tracks_400_detections(orc):
+    """Capacity is an allocation size (r04; the reference's lists grow: sort/tracker.py:427-441): twelve different 400-object
+    scenes shown in turn leave > 2000 live + coasting tracks, 400 detections per frame -- beyond every LDS tier, so the per-frame lists and
+    the Hungarian solver's work area are carved out of HBM -- and the rows still equal the oracle's, every frame; then a SMALL scene in the
+    same bank (back in the LDS tier) and the return of the first scene (re-identification across 2000 tracks)."""
+    from tracklab_amd.synth import SyntheticStream, ltrb_to_ltwh_rows
+    K, D = 6, 32
+    bank = _bank(YAML, K, D, max_tracks=4096, max_dets=512)
+    ref = orc.StrongSORT(K, D, **YAML)
+    scenes = [iter(SyntheticStream(170 + k, 400, 6, parts=K, dim=D, with_embeddings=True, miss_prob=0.05)) for k in range(12)]
+    small = iter(SyntheticStream(990, 20, 4, parts=K, dim=D, with_embeddings=True))
+    most = 0
+    for f, k in enumerate([0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, -1, -1, 0]):
+        fr = next(small) if k < 0 else next(scenes[k])
+        d = fr["dets"]
+        ltwh, conf, ids = ltrb_to_ltwh_rows(d[:, :4]), d[:, 4], (d[:, 6] + 100000 * (k + 1)).astype(np.int64)
+        exp = ref.update(ids, ltwh, fr["embeddings"], fr["visibility"], conf)
+        got = bank.update(ids, ltwh, fr["embeddings"], fr["visibility"], conf)
+        assert len(got) == len(exp), f
+        for name in ("det_id", "track_id", "hits", "age", "tsu", "state", "matched_name", "pred_valid"):
+            np.testing.assert_array_equal(got[name], exp[name], err_msg=f"{name} frame {f}")
+        np.testing.assert_array_equal(got["kf_ltwh"], exp["kf_ltwh"])
+        most = max(most, len(bank.tracks()[0]))
+    assert most > 2000
     bank.close()

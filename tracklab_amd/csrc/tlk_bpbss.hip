@@ -37,7 +37,9 @@ struct BpbDev {
     int *ema_list, *ema_n;   // S x MAXD x 2 (slot, input detection index) / S: matches of the frame, consumed by bpbss_ema_kernel
     long long *prof;         // optional S x 16 phase accumulators in 100 MHz ticks (diagnostics: TLK_BPBSS_PROF)
     int *ps_ws;              // S x 4 x ps_cap      hash tables of the set-order emulation when they do not fit the LDS cost area
-    int S, MAXT, MAXD, K, D, cost_lds_entries, ps_cap;
+    unsigned char *big_ws;   // S x big_stride      list / solver work area of the big-scene tier (scenes beyond what the LDS lists hold)
+    size_t big_stride;
+    int S, MAXT, MAXD, K, D, lds_bytes, ps_cap;
 };
 
 struct BpbP {
@@ -60,8 +62,7 @@ __global__ void __launch_bounds__(BLOCK) partnorm_kernel(BpbDev Dv, FrameIn in, 
     const int T = Dv.hdr[(size_t)s * H_COUNT + H_NTRK];
     const int N = in.counts[(size_t)s * in.count_stride];
     if (N <= 0 || N > Dv.MAXD) return;
-    const int vec = blockIdx.x * NWAVES + w;             // [0, (T+N)*K)
-    if (vec >= (T + N) * K) return;
+    for (int vec = blockIdx.x * NWAVES + w; vec < (T + N) * K; vec += gridDim.x * NWAVES) {        // [0, (T+N)*K): the grid is bounded, the capacity is not
     const bool is_trk = vec < T * K;
     const int row = is_trk ? vec / K : (vec - T * K) / K, k = is_trk ? vec % K : (vec - T * K) % K;
     const float *x = is_trk ? Dv.feat + (((size_t)s * Dv.MAXT + Dv.order[(size_t)s * Dv.MAXT + row]) * K + k) * D
@@ -80,6 +81,7 @@ __global__ void __launch_bounds__(BLOCK) partnorm_kernel(BpbDev Dv, FrameIn in, 
         float *o = is_trk ? Dv.tnorm + (((size_t)s * Dv.MAXT + row) * K + k) * 2 : Dv.dnorm + (((size_t)s * Dv.MAXD + row) * K + k) * 2;
         o[0] = nrm; o[1] = s2;
     }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ MFMA distance
@@ -95,8 +97,10 @@ __global__ void __launch_bounds__(512) partdist_kernel(BpbDev Dv, FrameIn in)
     const int T = Dv.hdr[(size_t)s * H_COUNT + H_NTRK];
     const int N = in.counts[(size_t)s * in.count_stride];
     if (N <= 0 || N > Dv.MAXD) return;
-    const int t0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
-    if (t0 >= T || n0 >= N) return;
+    const int tiles_n = (N + 15) >> 4, tiles = ((T + 15) >> 4) * tiles_n;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {          // bounded grid over the (track tile, detection tile) pairs of the frame
+    const int t0 = (tile / tiles_n) * 16, n0 = (tile % tiles_n) * 16;
+    __syncthreads();                                                        // s_dist / s_valid of the previous tile have been read
     const int i = lane & 15, g = lane >> 4;
     const int tp = min(t0 + i, T - 1), dn = min(n0 + i, N - 1);
     const int slot = Dv.order[(size_t)s * Dv.MAXT + tp];
@@ -143,6 +147,7 @@ __global__ void __launch_bounds__(512) partdist_kernel(BpbDev Dv, FrameIn in)
             if (t0 + row < T && n0 + col < N)
                 Dv.reid[((size_t)s * Dv.MAXT + t0 + row) * Dv.MAXD + n0 + col] = (double)(pair / 2);
         }
+    }
     }
 }
 
@@ -231,9 +236,29 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
     const int s = blockIdx.x, tid = threadIdx.x;
     const int MAXT = Dv.MAXT, MAXD = Dv.MAXD, K = Dv.K, D = Dv.D;
     const size_t FD = (size_t)K * D;
-    BLds L;
-    bcarve(smem, MAXT, MAXD, L);
     int *hdr = Dv.hdr + (size_t)s * H_COUNT;
+    // List / solver work area of this frame.  The lists are sized by (tracks before the frame + detections, detections): the SMALLEST tier that
+    // holds them is used -- 256 x 128 or 1024 x 256 carved out of LDS (what r01-r03 ran on; the rest of the LDS is the cost matrix), or, for a
+    // scene beyond that, the bank's full capacity carved out of HBM (r04: the reference's lists simply grow, tracker.py:427-441; here the
+    // arrays are allocated at capacity in the 288 GB of HBM and only this frame's lists move out of LDS).  Same code, generic pointers.
+    BLds L;
+    int cost_lds_entries = 0;
+    {
+        const int t_now = hdr[H_NTRK], n_now = in.counts[(size_t)s * in.count_stride];
+        const int need_t = t_now + (n_now > 0 ? n_now : 0);
+        int ct = 0, cd = 0;
+        const int tiers[2][2] = {{256, 128}, {1024, 256}};
+        for (int k = 0; k < 2 && ct == 0; ++k) {
+            const int tt = MAXT < tiers[k][0] ? MAXT : tiers[k][0], td = MAXD < tiers[k][1] ? MAXD : tiers[k][1];
+            if (need_t <= tt && n_now <= td && blds_fixed(tt, td) + 4096 <= (size_t)Dv.lds_bytes) { ct = tt; cd = td; }
+        }
+        if (ct) {
+            bcarve(smem, ct, cd, L);
+            cost_lds_entries = (int)(((size_t)Dv.lds_bytes - blds_fixed(ct, cd)) / sizeof(double));
+        } else {
+            bcarve(Dv.big_ws + (size_t)s * Dv.big_stride, MAXT, MAXD, L);           // (L.cost is never used with cost_lds_entries = 0: matrices go to cost_g)
+        }
+    }
     int *order = Dv.order + (size_t)s * MAXT;
     int *freestk = Dv.freestk + (size_t)s * MAXT;
     const size_t stride = (size_t)Dv.S * MAXT;
@@ -331,7 +356,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
                                          [&](int p, int pos) { L.cand[pos] = p; }, L.scan);
             const int nu = block_compact(T, [&](int p) { return trk_at(order[p]).i(BI_STATE) != ST_CONFIRMED; },
                                          [&](int p, int pos) { L.bc[pos] = p; }, L.scan);
-            double *cm = ((size_t)nc * N <= (size_t)Dv.cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
+            double *cm = ((size_t)nc * N <= (size_t)cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
             // gate_cost_matrix (linear_assignment.py:132-175) + thresholding (:54-55). One wavefront per track row: the row's gate
             // (projected mean + Cholesky factor, 20 doubles in HBM) sits in registers and the NEXT row's is already in flight while
             // this one is computed -- the entry-per-thread loop re-read it for every entry and ran at the latency of ~25 dependent
@@ -387,7 +412,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             for (int k = tid; k < A.nm; k += BLOCK) L.rowf[L.m_t[k]] = 1;     // by track position
             __syncthreads();
             // ... in CPython's set-iteration order (cm has been consumed: the LDS cost area doubles as the hash-table scratch)
-            int *psw = ((size_t)Dv.cost_lds_entries * sizeof(double) >= (size_t)16 * Dv.ps_cap) ? (int *)L.cost : Dv.ps_ws + (size_t)s * 4 * Dv.ps_cap;
+            int *psw = ((size_t)cost_lds_entries * sizeof(double) >= (size_t)16 * Dv.ps_cap) ? (int *)L.cost : Dv.ps_ws + (size_t)s * 4 * Dv.ps_cap;
             const int n_unm = cascade_unmatched_tracks(L.cand, nc, A.nm, L.tmp, psw, (unsigned)Dv.ps_cap, L);
             // split by time_since_update == 1 (tracker.py:308-313), order kept
             const int nb_extra = block_compact(n_unm, [&](int r) { return trk_at(order[L.tmp[r]]).i(BI_TSU) == 1; },
@@ -396,7 +421,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
                                             [&](int r, int pos) { L.um_t[pos] = L.tmp[r]; }, L.scan);
             const int nb = nu + nb_extra, n_uda = A.n_um_d;
             __syncthreads();
-            double *cb = ((size_t)nb * n_uda <= (size_t)Dv.cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
+            double *cb = ((size_t)nb * n_uda <= (size_t)cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
             for (int e = tid; e < nb * n_uda; e += BLOCK) {          // iou_cost (iou_matching.py:42-78) + thresholding
                 const int r = e / n_uda, c = e - r * n_uda;
                 const double v = motion_cost(L.bc[r], L.um_da[c]);
@@ -421,7 +446,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             // ---------------- bot_sort_matching (tracker.py:335-363, _full_cost_metric :169-240) ----------------
             for (int p = tid; p < T; p += BLOCK) L.cand[p] = p;
             for (int j = tid; j < N; j += BLOCK) L.um_db[j] = j;
-            double *cm = ((size_t)T * N <= (size_t)Dv.cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
+            double *cm = ((size_t)T * N <= (size_t)cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
             const double GT = sqrt(CHI2INV95[gdim]);
             const double wsum = P.w_kfgd + P.w_reid + P.w_st;
             auto full_cost = [&](int p, int j) {
@@ -742,7 +767,7 @@ static void bpb_free(tlk_bpbss *h)
     if (!h) return;
     hipSetDevice(h->device);
     BpbDev &D = h->D;
-    void *ptrs[] = {D.fd, D.fi, D.detid, D.hdr, D.order, D.freestk, D.feat, D.fvis, D.tnorm, D.dnorm, D.reid, D.gl, D.cost_g, D.ps_ws, D.prof, D.ema_list, D.ema_n,
+    void *ptrs[] = {D.fd, D.fi, D.detid, D.hdr, D.order, D.freestk, D.feat, D.fvis, D.tnorm, D.dnorm, D.reid, D.gl, D.cost_g, D.big_ws, D.ps_ws, D.prof, D.ema_list, D.ema_n,
                     h->d_ids, h->d_ltwh, h->d_emb, h->d_vis, h->d_conf, h->d_kps, h->d_cnt, h->d_ocnt, h->d_rows};
     for (void *p : ptrs) if (p) hipFree(p);
     delete h;
@@ -753,8 +778,10 @@ static int launch_frame(tlk_bpbss *h, const BpbDev &Dv, int n_streams, const Fra
 {
     const int K = Dv.K;
     const int nvec = (Dv.MAXT + Dv.MAXD) * K;
-    hipLaunchKernelGGL(partnorm_kernel, dim3((nvec + NWAVES - 1) / NWAVES, n_streams), dim3(BLOCK), 0, st, Dv, in, h->P.wrapper_mode);
-    hipLaunchKernelGGL(partdist_kernel, dim3((Dv.MAXD + 15) / 16, (Dv.MAXT + 15) / 16, n_streams), dim3(64 * K), 0, st, Dv, in);
+    // bounded grids (the kernels loop): a bank created with room for thousands of tracks launches no more idle workgroups than a small one
+    const int nb_norm = (nvec + NWAVES - 1) / NWAVES, nb_dist = ((Dv.MAXD + 15) / 16) * ((Dv.MAXT + 15) / 16);
+    hipLaunchKernelGGL(partnorm_kernel, dim3(nb_norm < 512 ? nb_norm : 512, n_streams), dim3(BLOCK), 0, st, Dv, in, h->P.wrapper_mode);
+    hipLaunchKernelGGL(partdist_kernel, dim3(nb_dist < 256 ? nb_dist : 256, 1, n_streams), dim3(64 * K), 0, st, Dv, in);
     hipLaunchKernelGGL(bpbss_assoc_kernel, dim3(n_streams), dim3(BLOCK), h->smem, st, Dv, h->P, in, rows, rows_stream_stride, out_cap,
                        out_counts, oc_stride);
     hipLaunchKernelGGL(bpbss_ema_kernel, dim3((Dv.MAXD * K + NWAVES - 1) / NWAVES, n_streams), dim3(BLOCK), 0, st, Dv, h->P, in);
@@ -770,8 +797,9 @@ extern "C" int tlk_bpbss_create(const tlk_bpbss_params *p, int n_streams, int de
     if (p->dim < 16 || p->dim % 16 != 0) return fail(TLK_EINVAL, "tlk_bpbss_create: dim must be a positive multiple of 16");
     if (p->matching_strategy < 0 || p->matching_strategy > 1) return fail(TLK_EINVAL, "tlk_bpbss_create: unknown matching_strategy");
     const int MAXT = p->max_tracks > 0 ? p->max_tracks : 256, MAXD = p->max_dets > 0 ? p->max_dets : 128;
-    // (above 512 tracks the Hungarian solver keeps its column state in LDS instead of registers: wave_lsa_lds)
-    if (MAXT > 1024 || MAXD > 256) return fail(TLK_ECAPACITY, "tlk_bpbss_create: max_tracks <= 1024 and max_dets <= 256");
+    // Capacity is an ALLOCATION size now (r04): per-track state lives in HBM at capacity; the per-frame lists use LDS while the scene fits a
+    // 256 x 128 or 1024 x 256 tier and HBM beyond (bpbss_assoc_kernel).  The bounds below only keep one stream's arrays below a few GB.
+    if (MAXT > 16384 || MAXD > 1024) return fail(TLK_ECAPACITY, "tlk_bpbss_create: max_tracks <= 16384 and max_dets <= 1024");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(TLK_ENODEVICE, "tlk_bpbss_create: no HIP device (libtlk has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(TLK_EINVAL, "tlk_bpbss_create: bad device index");
@@ -785,10 +813,10 @@ extern "C" int tlk_bpbss_create(const tlk_bpbss_params *p, int n_streams, int de
     if (p->motion_criterium < 0 || p->motion_criterium > 1) { delete h; return fail(TLK_EINVAL, "tlk_bpbss_create: motion_criterium must be 0 (iou) or 1 (oks)"); }
     BpbDev &D = h->D;
     D.S = n_streams; D.MAXT = MAXT; D.MAXD = MAXD; D.K = p->parts; D.D = p->dim;
-    const size_t fixed = blds_fixed(MAXT, MAXD), budget = 160 * 1024 - 256;
-    if (fixed + 4096 > budget) { delete h; return fail(TLK_ECAPACITY, "tlk_bpbss_create: LDS budget exceeded"); }
-    D.cost_lds_entries = (int)((budget - fixed) / sizeof(double));
-    h->smem = fixed + (size_t)D.cost_lds_entries * sizeof(double);
+    const size_t budget = 160 * 1024 - 256;
+    D.lds_bytes = (int)(budget & ~(size_t)15);
+    h->smem = (size_t)D.lds_bytes;
+    D.big_stride = (blds_fixed(MAXT, MAXD) + 255) & ~(size_t)255;
     const size_t slots = (size_t)n_streams * MAXT, FD = (size_t)D.K * D.D;
     h->out_cap = MAXD;
 #define BPB_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void **)&(ptr), (bytes)); \
@@ -806,6 +834,7 @@ extern "C" int tlk_bpbss_create(const tlk_bpbss_params *p, int n_streams, int de
     BPB_ALLOC(D.reid, sizeof(double) * slots * MAXD);
     BPB_ALLOC(D.gl, sizeof(double) * GLN * slots);
     BPB_ALLOC(D.cost_g, sizeof(double) * slots * MAXD);
+    BPB_ALLOC(D.big_ws, D.big_stride * (size_t)n_streams);
     D.ps_cap = (int)pyset::table_capacity((unsigned)MAXT);
     BPB_ALLOC(D.ps_ws, sizeof(int) * 4 * (size_t)D.ps_cap * n_streams);
     BPB_ALLOC(D.ema_list, sizeof(int) * 2 * (size_t)MAXD * n_streams);
@@ -908,7 +937,7 @@ extern "C" int tlk_bpbss_update(tlk_bpbss *h, int stream, const int64_t *ids, co
     const size_t sl = (size_t)stream * V.MAXT;
     V.fd += sl; V.fi += sl; V.detid += sl; V.hdr += (size_t)stream * H_COUNT; V.order += sl; V.freestk += sl;
     V.feat += sl * FD; V.fvis += sl * V.K; V.tnorm += sl * V.K * 2; V.dnorm += (size_t)stream * V.MAXD * V.K * 2;
-    V.reid += sl * V.MAXD; V.gl += sl * GLN; V.cost_g += sl * V.MAXD; V.ps_ws += (size_t)stream * 4 * V.ps_cap; if (V.prof) V.prof += (size_t)stream * 16;
+    V.reid += sl * V.MAXD; V.gl += sl * GLN; V.cost_g += sl * V.MAXD; V.big_ws += (size_t)stream * V.big_stride; V.ps_ws += (size_t)stream * 4 * V.ps_cap; if (V.prof) V.prof += (size_t)stream * 16;
     V.ema_list += (size_t)stream * V.MAXD * 2; V.ema_n += stream;
     FrameIn in;
     in.ids = h->d_ids; in.ltwh = h->d_ltwh; in.emb = h->d_emb; in.vis = h->d_vis; in.conf = h->d_conf; in.counts = h->d_cnt;

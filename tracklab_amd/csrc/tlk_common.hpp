@@ -464,7 +464,10 @@ __device__ __forceinline__ int wave_lsa(const double *cost, int nr0, int nc0, si
 {
     if (nr0 == 0 || nc0 == 0) return 0;
     const int mx = nr0 > nc0 ? nr0 : nc0;
-    if (mx > 512) return wave_lsa_lds(cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);
+    // (the register-resident solver keeps u / col4row behind LDS-qualified pointers: a work area carved out of HBM -- the big-scene tier of
+    //  the StrongSORT banks -- takes the generic-pointer solver whatever the size)
+    if (mx > 512 || !__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)W.u))
+        return wave_lsa_lds(cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);
     if (__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)cost))       // wave-uniform: the matrix sits in LDS ...
         return wave_lsa_reg_cpl((const TLK_LDS double *)cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);
     return wave_lsa_reg_cpl((const TLK_GLOBAL double *)cost, nr0, nc0, rs0, cs0, W, rows_out, cols_out);       // ... or spilled to HBM

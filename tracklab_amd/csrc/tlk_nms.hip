@@ -123,24 +123,26 @@ __global__ void __launch_bounds__(BLOCK) yolox_decode_nms_kernel(const float *__
         // 4. greedy NMS, 64 candidates (one block of rows) at a time
         const int nwords = (m + 63) >> 6;
         for (int blk = 0; blk < nwords; ++blk) {
-            // 4a. all wavefronts: suppression rows of the block's candidates that are still alive, against every later candidate
+            // 4a. all wavefronts: suppression rows of the block's candidates that are still alive, against every later candidate.  A wavefront
+            // owns WORDS (64 later candidates each): lane j keeps its candidate's box in registers, the rows' boxes arrive as LDS broadcasts,
+            // so the loop over the rows carries no per-lane memory access.
             const unsigned long long alive_blk = alive[blk];
-            for (int r = wave; r < 64; r += NWAVES) {
-                const int i = blk * 64 + r;
-                if (i >= m || !((alive_blk >> r) & 1ull)) continue;           // uniform per wavefront (a row killed later inside the block is built in vain, never applied)
-                const float ix1 = bx[i][0], iy1 = bx[i][1], ix2 = bx[i][2], iy2 = bx[i][3], ia = barea[i];
-                for (int w = blk; w < nwords; ++w) {
-                    const int j = w * 64 + lane;
-                    bool kill = false;
-                    if (j > i && j < m) {
-                        const float xx1 = fmaxf(ix1, bx[j][0]), yy1 = fmaxf(iy1, bx[j][1]);
-                        const float xx2 = fminf(ix2, bx[j][2]), yy2 = fminf(iy2, bx[j][3]);
-                        const float w_ = fmaxf(0.0f, xx2 - xx1 + 1), h_ = fmaxf(0.0f, yy2 - yy1 + 1);
-                        const float inter = w_ * h_;
-                        const float ovr = inter / (ia + barea[j] - inter);
-                        kill = !(ovr <= nms_thr);
-                    }
-                    const unsigned long long km = __ballot(kill);
+            for (int w = blk + wave; w < nwords; w += NWAVES) {
+                const int j = w * 64 + lane;
+                const bool jin = j < m;
+                const float jx1 = jin ? bx[j][0] : 0.f, jy1 = jin ? bx[j][1] : 0.f, jx2 = jin ? bx[j][2] : 0.f, jy2 = jin ? bx[j][3] : 0.f;
+                const float ja = jin ? barea[j] : 1.f;
+                unsigned long long rows = alive_blk;
+                while (rows) {                                                  // uniform
+                    const int r = __builtin_ctzll(rows);
+                    rows &= rows - 1;
+                    const int i = blk * 64 + r;
+                    const float xx1 = fmaxf(bx[i][0], jx1), yy1 = fmaxf(bx[i][1], jy1);
+                    const float xx2 = fminf(bx[i][2], jx2), yy2 = fminf(bx[i][3], jy2);
+                    const float w_ = fmaxf(0.0f, xx2 - xx1 + 1), h_ = fmaxf(0.0f, yy2 - yy1 + 1);
+                    const float inter = w_ * h_;
+                    const float ovr = inter / (barea[i] + ja - inter);
+                    const unsigned long long km = __ballot(jin && j > i && !(ovr <= nms_thr));
                     if (lane == 0) rowmask[r][w] = km;
                 }
             }

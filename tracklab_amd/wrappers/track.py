@@ -99,7 +99,7 @@ class HipBPBReIDStrongSORT(ImageLevelModule):
                  "max_kalman_prediction_without_update", "matching_strategy", "gating_thres_factor", "w_kfgd", "w_reid", "w_st")
         kw = {n: cfg_get(c, n) for n in names if cfg_get(c, n) is not None}
         return BpbssBank(parts, dim, **kw, wrapper_mode=True, device=_device_index(self.device),
-                         max_tracks=int(cfg_get(c, "max_tracks", 512)), max_dets=int(cfg_get(c, "max_dets", 128)))
+                         max_tracks=int(cfg_get(c, "max_tracks", 4096)), max_dets=int(cfg_get(c, "max_dets", 128)))
 
     def reset(self):
         if self._bank is not None:
