@@ -90,8 +90,8 @@ typedef struct {
     int32_t use_byte;
     int32_t wrapper_mode;    /* 1: OCSORT.process semantics (skip the tracker on an empty frame,
                                 filter conf > min_confidence); 0: bare OCSort.update */
-    int32_t max_tracks;      /* capacity per stream (live + coasting tracks), <= 512 */
-    int32_t max_dets;        /* capacity per frame, <= 256 */
+    int32_t max_tracks;      /* allocation per stream (live + coasting tracks), <= 16384: the reference's list grows (oc_sort/ocsort.py:312-314); per-frame lists in LDS while tracks + detections <= 512, HBM beyond */
+    int32_t max_dets;        /* detections per frame, <= 1024 */
 } tlk_ocsort_params;
 
 int tlk_ocsort_create(const tlk_ocsort_params *p, int n_streams, int device, tlk_ocsort **out);

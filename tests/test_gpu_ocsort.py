@@ -128,3 +128,27 @@ def test_hip_ocsort_capacity_error_is_loud():
     with pytest.raises(TlkError):
         bank.update(np.zeros((17, 7)), 0)
     bank.close()
+
+
+def test_hip_ocsort_800_tracks_400_detections(orc):
+    """Capacity is an allocation size (r04; the reference's list of trackers grows, oc_sort/ocsort.py:312-314): 400-object scenes shown in turn
+    with max_age 60 leave over 800 live + coasting trackers and 400 detections per frame -- past both LDS tiers, lists and Hungarian work
+    area in HBM -- rows and counts equal the oracle every frame; a small scene in the same bank afterwards runs in the LDS tier again."""
+    from tracklab_amd._lib import OCSortBank
+    from tracklab_amd.synth import SyntheticStream
+    hyper = dict(asso_func="giou", delta_t=1, det_thresh=0.1, inertia=0.2, iou_threshold=0.3, max_age=60, min_hits=1, use_byte=True)
+    bank = OCSortBank(**hyper, max_tracks=4096, max_dets=512)
+    ref = orc.OCSort(**hyper)
+    scenes = [iter(SyntheticStream(400 + k, 400, 4, miss_prob=0.05)) for k in range(6)]
+    small = iter(SyntheticStream(77, 20, 3))
+    most = 0
+    for f, k in enumerate([0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, -1, -1, 0]):
+        d = (next(small) if k < 0 else next(scenes[k]))["dets"]
+        exp = ref.update(d)
+        got = bank.update(d, 0)
+        assert got.shape == exp.shape, (f, got.shape, exp.shape)
+        np.testing.assert_array_equal(got[:, [4, 5, 7]], exp[:, [4, 5, 7]], err_msg=f"ids frame {f}")
+        np.testing.assert_allclose(got, exp, rtol=1e-11, atol=1e-9)
+        most = max(most, len(bank.tracks()[0]))
+    assert most > 700, most          # beyond the 512 x 256 LDS tier
+    bank.close()

@@ -47,7 +47,9 @@ struct OcsDev {
     double *lastb;   // S x MAXT x 5   last_boxes snapshot by position (ocsort.py:248)
     double *cost_g;  // S x MAXD x MAXT   cost-matrix spill when it does not fit LDS
     long long *prof; // optional S x 16 cycle accumulators (diagnostics)
-    int S, MAXT, MAXD, cost_lds_entries;
+    unsigned char *big_ws;   // S x big_stride: list / solver work area of the big-scene tier (see ocsort_frames_kernel)
+    size_t big_stride;
+    int S, MAXT, MAXD, lds_bytes;
 };
 
 struct OcsP {
@@ -292,7 +294,7 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
     const int tid = threadIdx.x;
     const int MAXT = D.MAXT, MAXD = D.MAXD, S = D.S;
     Lds L;
-    carve(smem, MAXT, MAXD, L);
+    int cost_lds_entries = 0;
     int *hdr = D.hdr + (size_t)s * H_COUNT;
     int *order = D.order + (size_t)s * MAXT;
     int *freestk = D.freestk + (size_t)s * MAXT;
@@ -315,6 +317,20 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
         if (hdr[H_ERR] != 0) { if (tid == 0) *out_count = hdr[H_ERR]; continue; }
         if (n_in > MAXD || n_in < 0) { if (tid == 0) { hdr[H_ERR] = TLK_ECAPACITY; *out_count = TLK_ECAPACITY; } continue; }
         if (P.wrapper_mode && n_in == 0) { if (tid == 0) *out_count = 0; continue; }   // oc_sort_api.py:51-52
+        // List / solver work area of THIS frame: the smallest tier that holds (tracks + detections, detections) -- 256 x 128 or 512 x 256 carved
+        // out of LDS (the rest of the LDS is the cost matrix), or the bank's full capacity carved out of HBM for a scene beyond that (r04: the
+        // reference's list of trackers just grows, oc_sort/ocsort.py:312-314; track state sits in HBM at capacity either way).
+        {
+            const int need_t = hdr[H_NTRK] + n_in;
+            int ct = 0, cd = 0;
+            const int tiers[2][2] = {{256, 128}, {512, 256}};
+            for (int k = 0; k < 2 && ct == 0; ++k) {
+                const int tt = MAXT < tiers[k][0] ? MAXT : tiers[k][0], td = MAXD < tiers[k][1] ? MAXD : tiers[k][1];
+                if (need_t <= tt && n_in <= td && lds_fixed_bytes(tt, td) + 4096 <= (size_t)D.lds_bytes) { ct = tt; cd = td; }
+            }
+            if (ct) { carve(smem, ct, cd, L); cost_lds_entries = (int)(((size_t)D.lds_bytes - lds_fixed_bytes(ct, cd)) / sizeof(double)); }
+            else { carve(D.big_ws + (size_t)s * D.big_stride, MAXT, MAXD, L); cost_lds_entries = 0; }
+        }
 
         // ---- split detections (ocsort.py:226-231), after the wrapper's conf filter (oc_sort_api.py:54)
         auto passes = [&](int i) { return !P.wrapper_mode || dets[(size_t)i * 7 + 4] > P.min_confidence; };
@@ -403,7 +419,7 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
 
         PROF(3);
         // ---- first association (association.py:242-298)
-        double *cost = ((size_t)N * T <= (size_t)D.cost_lds_entries) ? L.cost : (D.cost_g + (size_t)s * MAXD * MAXT);
+        double *cost = ((size_t)N * T <= (size_t)cost_lds_entries) ? L.cost : (D.cost_g + (size_t)s * MAXD * MAXT);
         int n_mi = 0;
         if (T > 0 && N > 0) {
             const double PI = 3.141592653589793;
@@ -492,7 +508,7 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
         auto second_round = [&](bool byte_round) {
             const int nrow = byte_round ? N2 : nud;
             const int ncol = nut;
-            double *mat = ((size_t)nrow * ncol <= (size_t)D.cost_lds_entries) ? L.cost : (D.cost_g + (size_t)s * MAXD * MAXT);
+            double *mat = ((size_t)nrow * ncol <= (size_t)cost_lds_entries) ? L.cost : (D.cost_g + (size_t)s * MAXD * MAXT);
             double lmax = -INFINITY; bool lnan = false;
             for (int e = tid; e < nrow * ncol; e += BLOCK) {
                 const int r = e / ncol, c = e - r * ncol;
@@ -677,7 +693,7 @@ static int ocs_free(tlk_ocsort *h)
     if (!h) return TLK_OK;
     hipSetDevice(h->device);
     hipFree(h->D.fd); hipFree(h->D.fi); hipFree(h->D.hdr); hipFree(h->D.order); hipFree(h->D.freestk);
-    hipFree(h->D.lastb); hipFree(h->D.cost_g); if (h->D.prof) hipFree(h->D.prof); hipFree(h->d_dets); hipFree(h->d_out); hipFree(h->d_cnt); hipFree(h->d_ocnt);
+    hipFree(h->D.lastb); hipFree(h->D.cost_g); hipFree(h->D.big_ws); if (h->D.prof) hipFree(h->D.prof); hipFree(h->d_dets); hipFree(h->d_out); hipFree(h->d_cnt); hipFree(h->d_ocnt);
     if (h->h_pin) hipHostFree(h->h_pin);
     if (h->h_cnt) hipHostFree(h->h_cnt);
     delete h;
@@ -691,7 +707,8 @@ extern "C" int tlk_ocsort_create(const tlk_ocsort_params *p, int n_streams, int 
     if (p->asso_func < TLK_IOU || p->asso_func > TLK_CT) return fail(TLK_EINVAL, "tlk_ocsort_create: unknown asso_func");
     if (p->delta_t < 0 || p->delta_t >= RINGN) return fail(TLK_EINVAL, "tlk_ocsort_create: delta_t must be in [0, 8)");
     const int MAXT = p->max_tracks > 0 ? p->max_tracks : 256, MAXD = p->max_dets > 0 ? p->max_dets : 128;
-    if (MAXT > 512 || MAXD > 256) return fail(TLK_ECAPACITY, "tlk_ocsort_create: max_tracks <= 512 and max_dets <= 256");
+    // capacity = allocation size (r04): LDS tiers while the scene fits, HBM lists beyond (ocsort_frames_kernel)
+    if (MAXT > 16384 || MAXD > 1024) return fail(TLK_ECAPACITY, "tlk_ocsort_create: max_tracks <= 16384 and max_dets <= 1024");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(TLK_ENODEVICE, "tlk_ocsort_create: no HIP device (libtlk has no CPU fallback)");
@@ -704,11 +721,10 @@ extern "C" int tlk_ocsort_create(const tlk_ocsort_params *p, int n_streams, int 
                 p->asso_func, p->use_byte, p->wrapper_mode};
     OcsDev &D = h->D;
     D.S = n_streams; D.MAXT = MAXT; D.MAXD = MAXD;
-    const size_t fixed = lds_fixed_bytes(MAXT, MAXD);
     const size_t budget = 160 * 1024 - 256;
-    if (fixed + 4096 > budget) { delete h; return fail(TLK_ECAPACITY, "tlk_ocsort_create: LDS budget exceeded"); }
-    D.cost_lds_entries = (int)((budget - fixed) / sizeof(double));
-    h->smem = fixed + (size_t)D.cost_lds_entries * sizeof(double);
+    D.lds_bytes = (int)(budget & ~(size_t)15);
+    h->smem = (size_t)D.lds_bytes;
+    D.big_stride = (lds_fixed_bytes(MAXT, MAXD) + 255) & ~(size_t)255;
     const size_t slots = (size_t)n_streams * MAXT;
 #define OCS_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void **)&(ptr), (bytes)); \
         if (e_ != hipSuccess) { ocs_free(h); return fail(TLK_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e_)); } } while (0)
@@ -719,6 +735,7 @@ extern "C" int tlk_ocsort_create(const tlk_ocsort_params *p, int n_streams, int 
     OCS_ALLOC(D.freestk, sizeof(int) * slots);
     OCS_ALLOC(D.lastb, sizeof(double) * 5 * slots);
     OCS_ALLOC(D.cost_g, sizeof(double) * (size_t)n_streams * MAXD * MAXT);
+    OCS_ALLOC(D.big_ws, D.big_stride * (size_t)n_streams);
     D.prof = nullptr;
     if (getenv("TLK_OCSORT_PROF")) { OCS_ALLOC(D.prof, sizeof(long long) * 16 * n_streams); hipMemset(D.prof, 0, sizeof(long long) * 16 * n_streams); }
     h->out_cap = MAXT + MAXD;
@@ -787,7 +804,7 @@ extern "C" int tlk_ocsort_update(tlk_ocsort *h, int stream, const double *dets, 
     OcsDev V = h->D;
     V.fd += (size_t)stream * V.MAXT; V.fi += (size_t)stream * V.MAXT;
     V.hdr += (size_t)stream * H_COUNT; V.order += (size_t)stream * V.MAXT; V.freestk += (size_t)stream * V.MAXT;
-    V.lastb += (size_t)stream * V.MAXT * 5; V.cost_g += (size_t)stream * V.MAXD * V.MAXT;
+    V.lastb += (size_t)stream * V.MAXT * 5; V.cost_g += (size_t)stream * V.MAXD * V.MAXT; V.big_ws += (size_t)stream * V.big_stride;
     if (V.prof) V.prof += (size_t)stream * 16;
     hipLaunchKernelGGL(ocsort_frames_kernel, dim3(1), dim3(BLOCK), h->smem, st, V, h->P, (const double *)h->d_dets,
                        (const int *)h->d_cnt, 1, (size_t)0, (size_t)0, h->d_out, h->out_cap, h->d_ocnt);
