@@ -11,8 +11,11 @@
  * pyramids.cpp, video/lkpyramid.cpp, calib3d/ptsetreg.cpp, core/rand.cpp) as closely as they can be restated from their
  * documentation; tests/golden/make_cmc_golden.py produces fixtures wherever OpenCV is installed. What IS pinned: the HIP kernels
  * (tracklab_amd/csrc/tlk_cmc.hip) against this file, and the recovered warp against the known transform of synthetic frame pairs.
- * Known simplification: the 10 Levenberg-Marquardt refinement iterations on the inliers are replaced by the closed-form
- * least-squares similarity they converge to (the model is linear in its four parameters).
+ * r04: the refinement on the inliers is OpenCV's own -- cv::LMSolver (Nash's Levenberg-Marquardt: lambda on diag(J^T J), gain-ratio
+ * thresholds 0.25 / 0.75, at most 10 iterations) from the RANSAC winner's 2-point model -- instead of the closed-form least-squares similarity
+ * of r02-r03.  Measured (tests/test_oracle_cmc.py): the model being linear, the first step's gain ratio exceeds 0.75, lambda falls to 0 and
+ * the second step lands on the least-squares solution, so the two agree to ~1e-12 -- the shortcut was numerically harmless, but the code
+ * path is now the library's.  Still a restatement: the 4 x 4 solve is a Cholesky where OpenCV runs an SVD.
  */
 #include "orc.h"
 #include <math.h>
@@ -317,6 +320,100 @@ static int count_inliers(const float *f, const float *t, int n, const double *M,
     return good;
 }
 
+/* x = A^-1 b for the symmetric positive definite 4 x 4 system of the LM step (Cholesky).  OpenCV calls cv::solve(Ap, v, d, DECOMP_SVD) here
+ * (DECOMP_EIG before 4.5.x): the same solution to ~1e-15 relative; which of the two it is cannot be pinned without cv2. */
+static int solve4_spd(const double *A, const double *b, double *x)
+{
+    double L[16] = {0};
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i * 4 + j];
+            for (int k = 0; k < j; ++k) s -= L[i * 4 + k] * L[j * 4 + k];
+            if (i == j) { if (!(s > 0)) return 0; L[i * 4 + i] = sqrt(s); }
+            else L[i * 4 + j] = s / L[j * 4 + j];
+        }
+    double y[4];
+    for (int i = 0; i < 4; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L[i * 4 + k] * y[k]; y[i] = s / L[i * 4 + i]; }
+    for (int i = 3; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < 4; ++k) s -= L[k * 4 + i] * x[k]; x[i] = s / L[i * 4 + i]; }
+    return 1;
+}
+
+/* AffinePartial2DRefineCallback::compute (calib3d/src/ptsetreg.cpp): residuals r (2 per inlier) of h = (a, b, tx, ty) and, with want_v,
+ * v = J^T r for J rows (x, -y, 1, 0), (y, x, 0, 1).  Returns S = |r|^2.  Sums run over the inliers in index order. */
+static double partial_residuals(const float *f, const float *t, const uint8_t *in, int n, const double *h, double *v)
+{
+    double S = 0;
+    if (v) v[0] = v[1] = v[2] = v[3] = 0;
+    for (int i = 0; i < n; ++i) if (in[i]) {
+        const double Mx = f[2 * i], My = f[2 * i + 1];
+        const double rx = h[0] * Mx - h[1] * My + h[2] - t[2 * i], ry = h[1] * Mx + h[0] * My + h[3] - t[2 * i + 1];
+        S += rx * rx; S += ry * ry;
+        if (v) { v[0] += Mx * rx; v[1] += -My * rx; v[2] += rx; v[0] += My * ry; v[1] += Mx * ry; v[3] += ry; }
+    }
+    return S;
+}
+
+/* cv::LMSolver::run (calib3d/src/levmarq.cpp, Nash's variant: lambda scales diag(A) of the FIRST linearisation, gain-ratio thresholds 0.25 /
+ * 0.75, lambda halved or multiplied by nu in [2, 10], eps = FLT_EPSILON on |d|_inf and |r|_inf) on the four parameters of the partial affine
+ * model, as cv::estimateAffinePartial2D calls it with refineIters = 10.  The model is linear in its parameters, so J -- and A = J^T J -- are
+ * the same in every iteration; OpenCV recomputes them, with the same values.  M (2 x 3) in / out. */
+static void lm_refine_partial(const float *f, const float *t, const uint8_t *in, int n, double *M, int max_iters)
+{
+    double x[4] = {M[0], M[3], M[2], M[5]}, xd[4], v[4], vd[4], d[4], A[16] = {0}, D[4];
+    double sxx = 0, sx = 0, sy = 0, cnt = 0;
+    for (int i = 0; i < n; ++i) if (in[i]) {
+        const double Mx = f[2 * i], My = f[2 * i + 1];
+        sxx += Mx * Mx; sxx += My * My; sx += Mx; sy += My; cnt += 1.0;
+    }
+    A[0] = sxx; A[5] = sxx; A[2] = A[8] = sx; A[3] = A[12] = sy; A[6] = A[9] = -sy; A[7] = A[13] = sx; A[10] = cnt; A[15] = cnt;
+    double S = partial_residuals(f, t, in, n, x, v);
+    for (int i = 0; i < 4; ++i) D[i] = A[i * 5];
+    const double Rlo = 0.25, Rhi = 0.75, eps = 1.1920928955078125e-07;
+    double lambda = 1, lc = 0.75;
+    double rinf = 0;
+    for (int iter = 0;;) {
+        double Ap[16];
+        memcpy(Ap, A, sizeof(Ap));
+        for (int i = 0; i < 4; ++i) Ap[i * 5] += lambda * D[i];
+        if (!solve4_spd(Ap, v, d)) break;
+        for (int i = 0; i < 4; ++i) xd[i] = x[i] - d[i];
+        const double Sd = partial_residuals(f, t, in, n, xd, vd);
+        double dS = 0, tdot = 0;
+        for (int i = 0; i < 4; ++i) { double td = 2 * v[i]; for (int k = 0; k < 4; ++k) td -= A[i * 4 + k] * d[k]; dS += d[i] * td; tdot += d[i] * v[i]; }
+        const double R = (S - Sd) / (fabs(dS) > 2.220446049250313e-16 ? dS : 1);
+        if (R > Rhi) { lambda *= 0.5; if (lambda < lc) lambda = 0; }
+        else if (R < Rlo) {
+            double nu = (Sd - S) / (fabs(tdot) > 2.220446049250313e-16 ? tdot : 1) + 2;
+            nu = nu < 2. ? 2. : (nu > 10. ? 10. : nu);
+            if (lambda == 0) {
+                double maxval = 2.220446049250313e-16;
+                for (int c = 0; c < 4; ++c) {                 /* diag of A^-1 (invert(A, Ap, DECOMP_EIG)) */
+                    double e[4] = {0, 0, 0, 0}, col[4];
+                    e[c] = 1;
+                    if (solve4_spd(A, e, col) && fabs(col[c]) > maxval) maxval = fabs(col[c]);
+                }
+                lambda = lc = 1. / maxval;
+                nu *= 0.5;
+            }
+            lambda *= nu;
+        }
+        if (Sd < S) { S = Sd; memcpy(x, xd, sizeof(x)); memcpy(v, vd, sizeof(v)); }
+        ++iter;
+        /* |r|_inf of the CURRENT x (OpenCV keeps r of the last accepted point) */
+        rinf = 0;
+        for (int i = 0; i < n; ++i) if (in[i]) {
+            const double Mx = f[2 * i], My = f[2 * i + 1];
+            const double rx = fabs(x[0] * Mx - x[1] * My + x[2] - t[2 * i]), ry = fabs(x[1] * Mx + x[0] * My + x[3] - t[2 * i + 1]);
+            if (rx > rinf) rinf = rx;
+            if (ry > rinf) rinf = ry;
+        }
+        double dinf = 0;
+        for (int i = 0; i < 4; ++i) if (fabs(d[i]) > dinf) dinf = fabs(d[i]);
+        if (!(iter < max_iters && dinf >= eps && rinf >= eps)) break;
+    }
+    M[0] = x[0]; M[4] = x[0]; M[1] = -x[1]; M[3] = x[1]; M[2] = x[2]; M[5] = x[3];
+}
+
 /* cv::estimateAffinePartial2D(from, to, RANSAC, 3.0, 2000, 0.99, refineIters): M (2, 3) float64, inliers (n). Returns 0 when no
  * model was found (OpenCV returns an empty matrix then). */
 int orc_cmc_estimate_affine_partial(const float *from, const float *to, int n, double *M, uint8_t *inliers)
@@ -342,19 +439,9 @@ int orc_cmc_estimate_affine_partial(const float *from, const float *to, int n, d
     }
     int ok = max_good > 0;
     if (ok) {
-        /* refinement on the inliers: least-squares similarity (what the Levenberg-Marquardt iterations converge to) */
-        double cx = 0, cy = 0, qx = 0, qy = 0; int m = 0;
-        for (int i = 0; i < n; ++i) if (best[i]) { cx += from[2 * i]; cy += from[2 * i + 1]; qx += to[2 * i]; qy += to[2 * i + 1]; ++m; }
-        cx /= m; cy /= m; qx /= m; qy /= m;
-        double spp = 0, dot = 0, crs = 0;
-        for (int i = 0; i < n; ++i) if (best[i]) {
-            const double px = from[2 * i] - cx, py = from[2 * i + 1] - cy, ux = to[2 * i] - qx, uy = to[2 * i + 1] - qy;
-            spp += px * px + py * py; dot += px * ux + py * uy; crs += px * uy - py * ux;
-        }
-        if (spp > 0) {
-            const double a = dot / spp, b = crs / spp;
-            bestM[0] = a; bestM[1] = -b; bestM[2] = qx - (a * cx - b * cy); bestM[3] = b; bestM[4] = a; bestM[5] = qy - (b * cx + a * cy);
-        }
+        /* refinement on the inliers, as OpenCV does it (r04; r02-r03 used the closed-form least-squares similarity instead): 10 iterations of
+         * cv::LMSolver from the RANSAC winner's 2-point model */
+        if (n > 2) lm_refine_partial(from, to, best, n, bestM, 10);            /* ptsetreg.cpp: `if (result && count > 2 && refineIters)`, count = all points */
         memcpy(M, bestM, sizeof(bestM));
         if (inliers) memcpy(inliers, best, (size_t)n);
     }

@@ -344,10 +344,11 @@ __global__ void __launch_bounds__(BLOCK) ransac_pick_kernel(const float *__restr
     double M[6];
     partial_from_two(from, to, ids[2 * s_best], ids[2 * s_best + 1], M);
     const float F[6] = {(float)M[0], (float)M[1], (float)M[2], (float)M[3], (float)M[4], (float)M[5]};
-    // centroids of the inliers, then the closed-form least-squares similarity
-    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = tid; i < m; i += BLOCK)
-        if (is_inlier(from, to, i, F)) { v[0] += from[2 * i]; v[1] += from[2 * i + 1]; v[2] += to[2 * i]; v[3] += to[2 * i + 1]; v[4] += 1.0; }
+    // Refinement on the inliers = OpenCV's: <= 10 iterations of cv::LMSolver (Nash's Levenberg-Marquardt) on h = (a, b, tx, ty) from the 2-point
+    // model (oracle/src/cmc.c::lm_refine_partial is the sequential statement).  The model is linear in h, so J^T J is built once; every
+    // iteration is ONE pass over the points (residuals of the trial point, their J^T r and |r|^2, |r|_inf) reduced across the workgroup in a
+    // fixed order, then a 4 x 4 Cholesky solve that every thread repeats for itself.  Sums are block-parallel (the oracle's are sequential):
+    // warp equal to ~1e-12, as with the closed form this replaces.
     auto block_sum8 = [&](double (&x)[8]) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -359,17 +360,101 @@ __global__ void __launch_bounds__(BLOCK) ransac_pick_kernel(const float *__restr
         __syncthreads();
         for (int k = 0; k < 8; ++k) { double t = 0; for (int q = 0; q < NWAVES; ++q) t += s_red[q][k]; x[k] = t; }
     };
-    block_sum8(v);
-    const double cnt = v[4], cx = v[0] / cnt, cy = v[1] / cnt, qx = v[2] / cnt, qy = v[3] / cnt;
-    double u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = tid; i < m; i += BLOCK)
+    auto block_max = [&](double x) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(x, off); x = o > x ? o : x; }
+        __syncthreads();
+        if ((tid & 63) == 0) s_red[tid >> 6][0] = x;
+        __syncthreads();
+        double t = 0;
+        for (int q = 0; q < NWAVES; ++q) t = s_red[q][0] > t ? s_red[q][0] : t;
+        return t;
+    };
+    // this thread's inliers: points tid, tid + BLOCK, ... (m <= 1000: at most 4 per thread, kept in registers)
+    double px[4], py[4], qx_[4], qy_[4];
+    int nmine = 0;
+    double v0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < m && nmine < 4; i += BLOCK)
         if (is_inlier(from, to, i, F)) {
-            const double px = from[2 * i] - cx, py = from[2 * i + 1] - cy, ux = to[2 * i] - qx, uy = to[2 * i + 1] - qy;
-            u[0] += px * px + py * py; u[1] += px * ux + py * uy; u[2] += px * uy - py * ux;
+            px[nmine] = from[2 * i]; py[nmine] = from[2 * i + 1]; qx_[nmine] = to[2 * i]; qy_[nmine] = to[2 * i + 1];
+            v0[0] += px[nmine] * px[nmine]; v0[0] += py[nmine] * py[nmine]; v0[1] += px[nmine]; v0[2] += py[nmine]; v0[3] += 1.0;
+            ++nmine;
         }
-    block_sum8(u);
+    block_sum8(v0);
+    const double sxx = v0[0], sx = v0[1], sy = v0[2], cnt = v0[3];
+    double A[16] = {sxx, 0, sx, sy,  0, sxx, -sy, sx,  sx, -sy, cnt, 0,  sy, sx, 0, cnt};
+    auto solve4 = [&](const double *Am, const double *bv, double *xo) -> bool {
+        double L[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) L[i] = 0;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double sacc = Am[i * 4 + j];
+                for (int k = 0; k < j; ++k) sacc -= L[i * 4 + k] * L[j * 4 + k];
+                if (i == j) { if (!(sacc > 0)) return false; L[i * 4 + i] = sqrt(sacc); }
+                else L[i * 4 + j] = sacc / L[j * 4 + j];
+            }
+        double y[4];
+        for (int i = 0; i < 4; ++i) { double sacc = bv[i]; for (int k = 0; k < i; ++k) sacc -= L[i * 4 + k] * y[k]; y[i] = sacc / L[i * 4 + i]; }
+        for (int i = 3; i >= 0; --i) { double sacc = y[i]; for (int k = i + 1; k < 4; ++k) sacc -= L[k * 4 + i] * xo[k]; xo[i] = sacc / L[i * 4 + i]; }
+        return true;
+    };
+    // one pass: S = |r|^2, v = J^T r, |r|_inf of parameters h
+    auto residual_pass = [&](const double *h, double &S, double *v, double &rinf) {
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double mx = 0;
+        for (int q = 0; q < nmine; ++q) {
+            const double rx = h[0] * px[q] - h[1] * py[q] + h[2] - qx_[q], ry = h[1] * px[q] + h[0] * py[q] + h[3] - qy_[q];
+            acc[4] += rx * rx; acc[4] += ry * ry;
+            acc[0] += px[q] * rx; acc[1] += -py[q] * rx; acc[2] += rx; acc[0] += py[q] * ry; acc[1] += px[q] * ry; acc[3] += ry;
+            mx = fabs(rx) > mx ? fabs(rx) : mx; mx = fabs(ry) > mx ? fabs(ry) : mx;
+        }
+        block_sum8(acc);
+        rinf = block_max(mx);
+        S = acc[4]; v[0] = acc[0]; v[1] = acc[1]; v[2] = acc[2]; v[3] = acc[3];
+    };
+    if (m > 2) {
+        double x[4] = {M[0], M[3], M[2], M[5]}, xd[4], v[4], vd[4], d[4], S, Sd, rinf, rinf_d;
+        residual_pass(x, S, v, rinf);
+        const double Dg[4] = {A[0], A[5], A[10], A[15]};
+        const double Rlo = 0.25, Rhi = 0.75, eps = 1.1920928955078125e-07, DEPS = 2.220446049250313e-16;
+        double lambda = 1, lc = 0.75;
+        for (int iter = 0;;) {
+            double Ap[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Ap[i] = A[i];
+            for (int i = 0; i < 4; ++i) Ap[i * 5] += lambda * Dg[i];
+            if (!solve4(Ap, v, d)) break;
+            for (int i = 0; i < 4; ++i) xd[i] = x[i] - d[i];
+            residual_pass(xd, Sd, vd, rinf_d);
+            double dS = 0, tdot = 0;
+            for (int i = 0; i < 4; ++i) { double td = 2 * v[i]; for (int k = 0; k < 4; ++k) td -= A[i * 4 + k] * d[k]; dS += d[i] * td; tdot += d[i] * v[i]; }
+            const double R = (S - Sd) / (fabs(dS) > DEPS ? dS : 1);
+            if (R > Rhi) { lambda *= 0.5; if (lambda < lc) lambda = 0; }
+            else if (R < Rlo) {
+                double nu = (Sd - S) / (fabs(tdot) > DEPS ? tdot : 1) + 2;
+                nu = nu < 2. ? 2. : (nu > 10. ? 10. : nu);
+                if (lambda == 0) {
+                    double maxval = DEPS;
+                    for (int c = 0; c < 4; ++c) {
+                        double e[4] = {0, 0, 0, 0}, col[4];
+                        e[c] = 1;
+                        if (solve4(A, e, col) && fabs(col[c]) > maxval) maxval = fabs(col[c]);
+                    }
+                    lambda = lc = 1. / maxval;
+                    nu *= 0.5;
+                }
+                lambda *= nu;
+            }
+            if (Sd < S) { S = Sd; rinf = rinf_d; for (int i = 0; i < 4; ++i) { x[i] = xd[i]; v[i] = vd[i]; } }
+            ++iter;
+            double dinf = 0;
+            for (int i = 0; i < 4; ++i) dinf = fabs(d[i]) > dinf ? fabs(d[i]) : dinf;
+            if (!(iter < 10 && dinf >= eps && rinf >= eps)) break;
+        }
+        M[0] = x[0]; M[4] = x[0]; M[1] = -x[1]; M[3] = x[1]; M[2] = x[2]; M[5] = x[3];
+    }
     if (tid == 0) {
-        if (u[0] > 0) { const double a = u[1] / u[0], b = u[2] / u[0]; M[0] = a; M[1] = -b; M[2] = qx - (a * cx - b * cy); M[3] = b; M[4] = a; M[5] = qy - (b * cx + a * cy); }
         if (downscale > 1.0) { M[2] *= downscale; M[5] *= downscale; }
         for (int k = 0; k < 6; ++k) warp[k] = M[k];
         *n_inliers = (int)cnt;

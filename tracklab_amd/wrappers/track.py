@@ -313,7 +313,7 @@ class HipStrongSORT(ImageLevelModule, _ReidTrackerBase):
         self._bank = None
         self._model = None
         self._img_hw = None
-        self._ecc = bool(cfg_get(cfg, "ecc", False))
+        self._ecc = bool(cfg_get(cfg, "ecc", True))        # the reference's default (configs/modules/track/strong_sort.yaml:13)
         self._ecc_est = None        # _lib.EccEstimator, created with the first frame's size
 
     def reset(self):
