@@ -625,6 +625,24 @@ int tlk_conv2d_set_config(int cfg);
 /* Tile configuration (0..6) the most recent tlk_conv2d_nhwc_f32 call of this process launched, -1 before the first. */
 int tlk_conv2d_last_config(void);
 
+/* The same convolution on the 16-bit MFMA (v_mfma_f32_32x32x16_f16; tlk_conv16.hip), two modes selected by the pointers given:
+ *   f16 mode   (x_lo_dev == NULL): x, w, residual, y are f16 NHWC / (cout,kh,kw,cin); fp32 accumulation and epilogue; bias fp32.
+ *   split mode (x_lo_dev != NULL): every tensor is a PAIR of f16 planes (hi, lo) with value = hi + lo * 2^-11 -- an fp32 number to a relative
+ *              2^-22; three MFMAs per operand pair (hi*hi, hi*lo, lo*hi), two fp32 accumulators: fp32-class results (|err| <= ~3 * 2^-22 *
+ *              sum|a||b| + fp32 accumulation round-off; tests/test_gpu_conv16.py holds it to the SAME fp64 bound as tlk_conv2d_nhwc_f32)
+ *              at ~5x the fp32-input MFMA peak.  Range |x| <= 65504.  tlk_split_f32_planes / tlk_merge_planes_f32 convert.
+ * y_f32_dev != NULL: the output is written as plain fp32 there instead of y_dev (/ y_lo_dev).  cin % 8 == 0, cout % 8 == 0, all pointers
+ * 16-byte aligned; pixel strides in ELEMENTS (0 = dense).  Same reference role as tlk_conv2d_nhwc_f32 (the backbones of
+ * wrappers/bbox_detector/rtmlib_api.py:21, wrappers/reid/kpreid_api.py:147-182, wrappers/pose_estimator/rtmlib_api.py:21). */
+int tlk_conv2d_nhwc_16(const void *x_dev, const void *x_lo_dev, const void *w_dev, const void *w_lo_dev, const float *bias_dev,
+                       const void *res_dev, const void *res_lo_dev, void *y_dev, void *y_lo_dev, float *y_f32_dev,
+                       int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int act_kind,
+                       int x_pix_stride, int y_pix_stride, int res_pix_stride, void *hip_stream);
+/* fp32 NHWC pixels (c_in channels, x_pix_stride floats apart, 0 = dense) -> (hi, lo) f16 planes with c_out >= c_in channels, zero padded. */
+int tlk_split_f32_planes(const float *x_dev, long long pixels, int c_in, int x_pix_stride, int c_out, void *hi_dev, void *lo_dev, void *hip_stream);
+/* y[i] = hi[i] + lo[i] * 2^-11 for n elements. */
+int tlk_merge_planes_f32(const void *hi_dev, const void *lo_dev, long long n, float *y_dev, void *hip_stream);
+
 /* 1x1 convolution of a channels-last tensor as ONE GEMM with the convolution epilogue inside:
  *   out[M,N] = act(x[M,K] . w[N,K]^T + bias[N] (+ residual[M,N])),  act 0 none / 1 ReLU / 2 SiLU, dtype TLK_F16 or TLK_BF16.
  * hipBLASLt (library GEMM, taken from the process with dlopen) with its BIAS / RELU_BIAS / SWISH_BIAS epilogue and beta*C for

@@ -1,0 +1,97 @@
+"""tlk_conv2d_nhwc_16 (csrc/tlk_conv16.hip): convolutions on the 16-bit MFMA.
+  * split mode (fp32 values as (hi, lo) f16 pairs, three MFMAs per product pair): within the SAME fp64 bound as the exact-fp32 kernel
+    (tests/test_gpu_conv.py: |err| <= 2e-6 * (|x| conv |w|)) -- fp32-class -- on ragged shapes, strides, residuals, K up to 4608;
+  * f16 mode: equal to an fp32-accumulated convolution of the f16 operands rounded once to f16 (1 ulp of f16);
+  * split / merge are exact inverses to 2^-22;
+  * the ReID network in split precision agrees with the exact-fp32 network far below the f16 leg's distance."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(8, 64, 24, 8, 64, 3, 1, True), (4, 8, 40, 24, 64, 7, 2, False), (6, 256, 12, 8, 128, 1, 2, False), (3, 512, 24, 8, 512, 3, 1, True),
+          (2, 128, 17, 9, 72, 3, 1, False), (5, 2048, 6, 4, 256, 1, 1, False), (2, 72, 11, 7, 200, 3, 2, True)]
+
+
+def _inputs(shape, seed=1):
+    n, cin, h, w, cout, k, s, res = shape
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn((n, cin, h, w), device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn((cout, cin, k, k), device="cuda", generator=g) * 0.05).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(cout, device="cuda", generator=g)
+    ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+    r = torch.randn((n, cout, ho, wo), device="cuda", generator=g).contiguous(memory_format=torch.channels_last) if res else None
+    return x, wt, b, r, k, s
+
+
+def test_split_and_merge_round_trip():
+    from tracklab_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = (torch.randn((3, 16, 9, 5), device="cuda", generator=g) * torch.logspace(-4, 3, 16, device="cuda").view(1, -1, 1, 1)).contiguous(memory_format=torch.channels_last)
+    hi, lo = _lib.split_planes(x)
+    y = _lib.merge_planes(hi, lo)
+    rel = ((y - x).abs() / x.abs().clamp_min(1e-30)).max().item()
+    assert rel <= 2.0 ** -21, rel
+    hi8, lo8 = _lib.split_planes(x[:, :3], 8)                       # channel slice in, zero-padded channels out
+    assert hi8.shape == (3, 8, 9, 5) and not hi8[:, 3:].any() and not lo8[:, 3:].any()
+    assert torch.equal(hi8[:, :3], hi[:, :3]) and torch.equal(lo8[:, :3], lo[:, :3])
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_split_mode_is_fp32_class(shape):
+    from tracklab_amd import _lib
+    x, wt, b, r, k, s = _inputs(shape)
+    xh, xl = _lib.split_planes(x)
+    wh, wl = _lib.split_planes(wt)
+    rh, rl = _lib.split_planes(r) if r is not None else (None, None)
+    y32 = _lib.conv2d_nhwc_16(xh, wh, b, "relu", rh, stride=s, x_lo=xl, weight_lo=wl, residual_lo=rl, out_f32=True)
+    yh, yl = _lib.conv2d_nhwc_16(xh, wh, b, "relu", rh, stride=s, x_lo=xl, weight_lo=wl, residual_lo=rl)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), s, k // 2)
+    bound = F.conv2d(x.double().abs(), wt.double().abs(), b.double().abs(), s, k // 2)
+    if r is not None:
+        ref, bound = ref + r.double(), bound + r.double().abs()
+    ref = F.relu(ref)
+    assert y32.shape == ref.shape
+    err = (y32.double() - ref).abs()
+    assert bool((err <= 2e-6 * bound + 1e-30).all()), float((err / bound).max())      # the exact-fp32 kernel's bound (tests/test_gpu_conv.py)
+    merged = _lib.merge_planes(yh, yl)
+    assert float(((merged - y32).abs() / y32.abs().clamp_min(1e-6)).max()) <= 2.0 ** -20      # the (hi, lo) output is y32 to the pair's precision
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_f16_mode_is_an_fp32_accumulated_f16_convolution(shape):
+    from tracklab_amd import _lib
+    x, wt, b, r, k, s = _inputs(shape, seed=2)
+    xh, wh = x.half(), wt.half()
+    rh = r.half() if r is not None else None
+    y = _lib.conv2d_nhwc_16(xh, wh, b, "relu", rh, stride=s)
+    ref = F.conv2d(xh.double(), wh.double(), b.double(), s, k // 2)
+    if r is not None:
+        ref = ref + rh.double()
+    ref = F.relu(ref)
+    bound = F.conv2d(xh.double().abs(), wh.double().abs(), b.double().abs(), s, k // 2)
+    err = (y.double() - ref).abs()
+    # one f16 rounding of the result (2^-11 relative) + fp32 accumulation round-off of the sum
+    assert bool((err <= ref.abs() * 2.0 ** -11 + 2e-6 * bound + 1e-7).all()), float((err / (ref.abs() + 1e-3)).max())
+
+
+def test_reid_network_in_split_precision_tracks_the_exact_fp32_network():
+    from tracklab_amd.backbones.reid import part_based_reid
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((6, 4, 384, 128), device="cuda", generator=g)[:, :3].contiguous(memory_format=torch.channels_last)
+    exact = part_based_reid(dtype=torch.float32)
+    split = part_based_reid(dtype=torch.float32, split_precision=True)
+    half = part_based_reid(dtype=torch.float16)
+    with torch.no_grad():
+        e0, v0 = exact(x)
+        e1, v1 = split(x)
+        e2, _ = half(x.half())
+    scale = float(e0.abs().max())
+    d_split, d_half = float((e1 - e0).abs().max()) / scale, float((e2.float() - e0).abs().max()) / scale
+    assert d_split <= 2e-5, d_split                       # fp32-class: the two fp32 routes differ by summation order and 2^-22 operand error
+    assert d_split * 20 < d_half, (d_split, d_half)       # ... an order of magnitude or more below the f16 leg's distance
+    assert torch.equal(v0, v1)
+    cos = F.cosine_similarity(e0.flatten(1), e1.flatten(1)).min().item()
+    assert cos > 1 - 1e-9

@@ -1003,6 +1003,83 @@ def conv2d_nhwc_f32(x, weight, bias=None, act=None, residual=None, stride=1, pad
     return out
 
 
+def _pix16(t, c, h, w):
+    """pixel stride (elements) of an NHWC tensor or channel slice of one, logical shape (N, C, H, W)"""
+    sn, sc, sh, sw = t.stride()
+    if t.shape[0] == 0:
+        return c
+    assert (sc == 1 or c == 1) and sh == w * sw and (sn == h * sh or t.shape[0] == 1), "tensor must be channels_last (or a channel slice of one)"
+    return sw
+
+
+def _bind_conv16(L):
+    if not getattr(L, "_conv16_bound", False):
+        L.tlk_conv2d_nhwc_16.argtypes = [C.c_void_p] * 10 + [C.c_int] * 13 + [C.c_void_p]
+        L.tlk_split_f32_planes.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tlk_merge_planes_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
+        L._conv16_bound = True
+
+
+def conv2d_nhwc_16(x, weight, bias=None, act=None, residual=None, stride=1, pad=None, x_lo=None, weight_lo=None, residual_lo=None,
+                   out_f32=False):
+    """Convolution + bias + residual + activation on the 16-bit MFMA (tlk_conv2d_nhwc_16).  f16 mode: x / weight / residual float16
+    channels_last, returns float16.  Split mode (x_lo given): every tensor a (hi, lo) pair of float16 planes, returns (hi, lo).
+    out_f32: returns one float32 tensor instead.  bias float32."""
+    import torch
+    L = lib()
+    _bind_conv16(L)
+    N, Cin, H, W = x.shape
+    Cout, Cw, KH, KW = weight.shape
+    if pad is None:
+        pad = (KH - 1) // 2
+    assert x.dtype == torch.float16 and weight.dtype == torch.float16 and Cw == Cin
+    assert bias is None or bias.dtype == torch.float32
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    split = x_lo is not None
+
+    def cl(wt):
+        return wt if wt.is_contiguous(memory_format=torch.channels_last) or (KH == 1 and KW == 1 and wt.is_contiguous()) \
+            else wt.contiguous(memory_format=torch.channels_last)
+    wk, wkl = cl(weight), (cl(weight_lo) if split else None)
+    mk = lambda dt: torch.empty((N, Cout, Ho, Wo), dtype=dt, device=x.device, memory_format=torch.channels_last)      # noqa: E731
+    y32 = mk(torch.float32) if out_f32 else None
+    yh = None if out_f32 else mk(torch.float16)
+    yl = mk(torch.float16) if (split and not out_f32) else None
+    ptr = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
+    check(L.tlk_conv2d_nhwc_16(x.data_ptr(), ptr(x_lo), wk.data_ptr(), ptr(wkl), ptr(bias), ptr(residual), ptr(residual_lo),
+                               ptr(yh), ptr(yl), ptr(y32), N, H, W, Cin, Cout, KH, KW, stride, pad, ACT[act],
+                               _pix16(x, Cin, H, W), Cout, _pix16(residual, Cout, Ho, Wo) if residual is not None else 0, current_stream_ptr()))
+    if out_f32:
+        return y32
+    return (yh, yl) if split else yh
+
+
+def split_planes(x, c_out=None):
+    """float32 (N, C, H, W) channels_last (or a channel slice of one) -> (hi, lo) float16 planes (N, c_out, H, W) channels_last, zero-padded
+    channels: value = hi + lo * 2**-11."""
+    import torch
+    L = lib()
+    _bind_conv16(L)
+    N, Cc, H, W = x.shape
+    c_out = c_out or Cc
+    assert x.dtype == torch.float32
+    hi = torch.empty((N, c_out, H, W), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    lo = torch.empty_like(hi)
+    check(L.tlk_split_f32_planes(x.data_ptr(), N * H * W, Cc, _pix16(x, Cc, H, W), c_out, hi.data_ptr(), lo.data_ptr(), current_stream_ptr()))
+    return hi, lo
+
+
+def merge_planes(hi, lo):
+    import torch
+    L = lib()
+    _bind_conv16(L)
+    assert hi.dtype == torch.float16 and lo.dtype == torch.float16 and hi.shape == lo.shape
+    assert hi.is_contiguous(memory_format=torch.channels_last) and lo.is_contiguous(memory_format=torch.channels_last)
+    y = torch.empty(hi.shape, dtype=torch.float32, device=hi.device, memory_format=torch.channels_last)
+    check(L.tlk_merge_planes_f32(hi.data_ptr(), lo.data_ptr(), hi.numel(), y.data_ptr(), current_stream_ptr()))
+    return y
+
+
 def cosine_gallery_min(gallery, offsets, dets):
     """gallery (G, D) f32, offsets (T+1,) int32 (CSR per track), dets (N, D) f32 cuda tensors -> (T, N) f64."""
     import torch

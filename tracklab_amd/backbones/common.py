@@ -13,6 +13,9 @@ USE_FUSED_GEMM = _os.environ.get("TLK_FUSED_GEMM", "1") != "0"
 # fp32 (the reference's precision): every convolution + its epilogue is ONE launch of libtlk's hand-written fp32 MFMA kernel
 # (tlk_conv2d_nhwc_f32, csrc/tlk_conv.hip); TLK_CONV_F32=0 restores the library route (MIOpen + separate torch epilogue passes) for A/B runs.
 USE_TLK_CONV_F32 = _os.environ.get("TLK_CONV_F32", "1") != "0"
+# f16 convolutions with the epilogue inside on libtlk's 16-bit MFMA kernel (tlk_conv2d_nhwc_16, csrc/tlk_conv16.hip) instead of MIOpen / CK /
+# hipBLASLt + a separate epilogue pass; TLK_CONV_F16=0 restores the library route for A/B runs.
+USE_TLK_CONV_F16 = _os.environ.get("TLK_CONV_F16", "1") != "0"
 # bench.py's roofline pass: a list here makes every fp32 convolution record (start event, end event, algorithmic flops) around its launch
 CONV_TIMER = None
 
@@ -37,6 +40,29 @@ def epilogue_(x: torch.Tensor, bias: torch.Tensor, act: str | None, residual: to
     return y
 
 
+class SplitAct:
+    """An fp32 activation travelling as two float16 planes: value = hi + lo * 2**-11 (relative 2**-22), both (N, C, H, W) channels_last.
+    What the split-precision convolutions (tlk_conv2d_nhwc_16, split mode: three f16 MFMAs per product pair, fp32 accumulation) read and
+    write; `merge()` gives the fp32 tensor back."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi, lo):
+        self.hi, self.lo = hi, lo
+
+    @staticmethod
+    def from_f32(x, c_out=None):
+        from .. import _lib
+        return SplitAct(*_lib.split_planes(x, c_out))
+
+    def merge(self):
+        from .. import _lib
+        return _lib.merge_planes(self.hi, self.lo)
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+
 class ConvBiasAct(nn.Module):
     """Conv2d (BatchNorm folded into weight + bias) followed by the fused epilogue."""
 
@@ -46,7 +72,38 @@ class ConvBiasAct(nn.Module):
         self.bias = nn.Parameter(torch.zeros(cout))
         self.act = act
 
+    def _split_weights(self, cin):
+        """(hi, lo) float16 planes of the fp32 weight, input channels zero-padded to `cin` (the RGB stem arrives with 8); cached"""
+        c = getattr(self, "_w_split", None)
+        if c is None or c[0].device != self.conv.weight.device or c[0].shape[1] != cin:
+            from .. import _lib
+            w = self.conv.weight.detach().float()
+            if w.shape[1] != cin:
+                w = F.pad(w, (0, 0, 0, 0, 0, cin - w.shape[1]))
+            c = _lib.split_planes(w.contiguous(memory_format=torch.channels_last))
+            self._w_split = c
+        return c
+
     def forward(self, x, residual=None):
+        if isinstance(x, SplitAct):
+            # split-precision route (fp32-class results on the 16-bit MFMA): input, residual and output are (hi, lo) plane pairs
+            from .. import _lib
+            wh, wl = self._split_weights(x.hi.shape[1])
+            out = _lib.conv2d_nhwc_16(x.hi, wh, self.bias.float() if self.bias.dtype != torch.float32 else self.bias, self.act,
+                                      residual.hi if residual is not None else None, self.conv.stride[0], self.conv.padding[0],
+                                      x_lo=x.lo, weight_lo=wl, residual_lo=residual.lo if residual is not None else None,
+                                      out_f32=getattr(self, "out_f32", False))
+            return out if getattr(self, "out_f32", False) else SplitAct(*out)
+        if USE_TLK_CONV_F16 and x.is_cuda and x.dtype == torch.float16 and x.shape[1] % 8 == 0 and self.conv.out_channels % 8 == 0 \
+                and x.is_contiguous(memory_format=torch.channels_last) and self.conv.weight.dtype == torch.float16:
+            from .. import _lib
+            b32 = getattr(self, "_bias32", None)
+            if b32 is None or b32.device != x.device:
+                b32 = self.bias.detach().float()
+                self._bias32 = b32
+            if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
+                residual = residual.contiguous(memory_format=torch.channels_last)
+            return _lib.conv2d_nhwc_16(x, self.conv.weight, b32, self.act, residual, self.conv.stride[0], self.conv.padding[0])
         if USE_TLK_CONV_F32 and x.is_cuda and x.dtype == torch.float32 and (x.shape[1] % 4 == 0 or x.shape[1] == 3) \
                 and x.is_contiguous(memory_format=torch.channels_last):
             from .. import _lib

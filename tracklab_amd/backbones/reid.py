@@ -12,7 +12,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .common import ConvBiasAct, finalize, random_init_
+from .common import ConvBiasAct, SplitAct, finalize, random_init_
 
 
 class _Bottleneck(nn.Module):
@@ -125,7 +125,11 @@ class _ResNet50(nn.Module):
         self.layer4 = _layer(1024, 512, 3, 1)          # last_stride = 1 (BPBReID)
 
     def forward(self, x):
-        x = self.pool(self.conv1(x))
+        x = self.conv1(x)
+        if isinstance(x, SplitAct):            # split-precision route: the max-pool runs on the merged fp32 tensor (exact: max commutes with the split)
+            x = SplitAct.from_f32(self.pool(x.merge()))
+        else:
+            x = self.pool(x)
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
 
@@ -142,6 +146,11 @@ class PartBasedReID(nn.Module):
         self.parts, self.dim, self.vis_threshold, self.arch = parts, dim, vis_threshold, arch
 
     def forward(self, x):
+        if getattr(self, "split_precision", False) and self.arch == "resnet50" and x.is_cuda and x.dtype == torch.float32:
+            # fp32 weights, fp32-class arithmetic on the 16-bit MFMA: every convolution of the backbone in split mode (csrc/tlk_conv16.hip),
+            # the image enters as (hi, lo) planes with 8 channels (5 of them zero), `reduce` hands fp32 back to the head below
+            self.reduce.out_f32 = True
+            x = SplitAct.from_f32(x, 8)
         f = self.reduce(self.backbone(x))                    # (N, D, h, w)
         att = torch.softmax(self.part_cls(f).float(), dim=1)  # (N, K, h, w) pixel-wise part attention
         ff = f.float().flatten(2)                            # (N, D, hw)
@@ -152,5 +161,9 @@ class PartBasedReID(nn.Module):
         return emb.contiguous(), vis
 
 
-def part_based_reid(parts=6, dim=256, device="cuda", dtype=torch.float16, channels_last=True, seed=0, arch="resnet50"):
-    return finalize(random_init_(PartBasedReID(parts, dim, arch=arch), seed), device, dtype, channels_last)
+def part_based_reid(parts=6, dim=256, device="cuda", dtype=torch.float16, channels_last=True, seed=0, arch="resnet50", split_precision=False):
+    """split_precision (with dtype float32, ResNet-50): the backbone's convolutions run in split mode -- fp32 values as (hi, lo) float16 pairs,
+    three f16 MFMAs per product pair, fp32 accumulation: fp32-class results at ~5x the fp32 MFMA rate (csrc/tlk_conv16.hip)."""
+    m = finalize(random_init_(PartBasedReID(parts, dim, arch=arch), seed), device, dtype, channels_last)
+    m.split_precision = bool(split_precision)
+    return m

@@ -1,0 +1,411 @@
+// tlk_conv16.hip -- the backbones' convolutions on the 16-bit MFMA (v_mfma_f32_32x32x16_f16, 16x the rate of the fp32-input MFMA), two modes:
+//
+//   MODE_F16   activations / weights f16, fp32 accumulation, epilogue (bias, residual, ReLU / SiLU) in fp32, output f16: the f16 leg, with the
+//              epilogue INSIDE the convolution (r01-r03 ran MIOpen / CK / hipBLASLt + a separate bias_act pass for the 3x3 ones).
+//   MODE_SPLIT every fp32 value x travels as TWO f16 numbers, hi = f16(x) and lo = f16((x - hi) * 2^11): x = hi + lo * 2^-11 to a relative 2^-22
+//              (an f16 significand is 11 bits, so the pair holds 22; the scale keeps lo a NORMAL f16 whenever hi is).  A product a*b is
+//              a_hi*b_hi + 2^-11 (a_hi*b_lo + a_lo*b_hi) + O(2^-22 |ab|): THREE MFMAs per operand pair, two fp32 accumulators (the head and
+//              the cross terms), merged as acc_hh + 2^-11 acc_x in the epilogue.  Every f16 x f16 product is exact in fp32 (22 bits) and the
+//              sums are fp32, so the result carries fp32-class error -- |err| <= ~3 * 2^-22 * sum|a||b| representation error plus the same
+//              accumulation round-off as any fp32 kernel -- at a third of the f16 MFMA rate = ~5x the fp32-input MFMA peak.  gfx950 has no
+//              TF32 / xf32 path; this is how fp32-grade convolutions get onto the fast matrix pipe.  Range: |x| <= 65504 (values beyond
+//              saturate to f16 infinity, as they would in the f16 leg); the tests compare with fp64 at the SAME bound as the exact-fp32 kernel.
+//              Inputs, outputs and residuals are (hi, lo) plane pairs of the same NHWC shape; OUT_F32 writes plain fp32 instead.
+//
+// Kernel structure = tlk_conv.hip's, byte for byte where it can be: implicit GEMM, 128-byte K slices per LDS row (64 f16 of one plane, or
+// 32 hi | 32 lo), rows padded to 144 B (conflict-free ds_read_b128 / ds_write_b128), buffer loads with hardware zero-fill so a K step is one
+// basic block, LDS double-buffered, scheduling barriers between MFMA chunks.  The 16-bit MFMA is 2-5x shorter per K step than the fp32 one, so
+// the global loads run TWO steps ahead in two register sets (issued in step s-1, written to LDS in the second half of step s, read in step s+1).
+#include <hip/hip_fp16.h>
+
+#include "tlk_common.hpp"
+
+using namespace tlk;
+
+namespace {
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+enum { MODE_F16 = 0, MODE_SPLIT = 1 };
+constexpr int ROW_BYTES = 128, LDB = ROW_BYTES + 16;      // LDS row: 128 data bytes + 16 pad
+constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+struct Conv16Args {
+    const _Float16 *x, *x_lo, *w, *w_lo, *res, *res_lo;
+    const float *bias;
+    _Float16 *y, *y_lo;
+    float *y32;
+    long long M;
+    int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, K;
+    int x_pix, y_pix, r_pix;      // elements between two pixels of x / y / residual
+    int tiles_n;
+    long long tiles;
+};
+
+template <int ACT> __device__ __forceinline__ float act16(float v)
+{
+    if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ACT == ACT_SILU) return v / (1.f + __expf(-v));
+    return v;
+}
+
+__device__ __forceinline__ void split_f32(float v, _Float16 &hi, _Float16 &lo)
+{
+    hi = (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * LO_SCALE);
+}
+
+template <int TM, int TN, int WGM, int WGN, int ACT, bool RES, int MODE, bool OUT_F32>
+__global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv16Args p)
+{
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int PLANES = MODE == MODE_SPLIT ? 2 : 1;
+    constexpr int BKE = MODE == MODE_SPLIT ? 32 : 64;                 // K elements per step
+    constexpr int CH = ROW_BYTES / 16 / PLANES;                       // 16-byte chunks per row and plane: 8 or 4
+    constexpr int ROWS_PER_PASS = NT / CH;
+    constexpr int PA = BM / ROWS_PER_PASS, PB = BN / ROWS_PER_PASS;   // passes per plane
+    static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile rows must be a multiple of the loader pass");
+    constexpr int NL = PLANES * (PA + PB);                            // 16-byte loads per lane and K step
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *As = lds;                                          // [2][BM][LDB]
+    unsigned char *Bs = lds + 2 * BM * LDB;                           // [2][BN][LDB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    long long tile;
+    {
+        const long long b = blockIdx.x, q = p.tiles >> 3;
+        const int r = (int)(p.tiles & 7), xcd = (int)(b & 7);
+        tile = (long long)xcd * q + (xcd < r ? xcd : r) + (b >> 3);
+    }
+    const long long m0 = (tile / p.tiles_n) * BM;
+    const int n0 = (int)(tile % p.tiles_n) * BN;
+
+    // ---- loader geometry (see tlk_conv.hip): lane = chunk `lc` of row `lr + pass * ROWS_PER_PASS` of one plane
+    const int lr = tid / CH, lc = tid % CH;
+    constexpr int OOB = (int)0x80000000;
+    long long base_pix;
+    {
+        const unsigned hw = (unsigned)(p.Ho * p.Wo), n = (unsigned)m0 / hw;
+        const int rem = (int)((unsigned)m0 - n * hw), ho = rem / p.Wo;
+        const int hi = ho * p.stride - p.pad;
+        base_pix = (long long)n * p.H * p.W + (long long)(hi > 0 ? hi : 0) * p.W;
+    }
+    const long long total_pix = (long long)((unsigned)p.M / (unsigned)(p.Ho * p.Wo)) * p.H * p.W;
+    long long a_bytes = ((total_pix - base_pix - 1) * p.x_pix + p.Cin) * 2;
+    if (a_bytes > 0x7ffffff0LL) a_bytes = 0x7ffffff0LL;
+    const int w_bytes = (int)((long long)p.Cout * p.K * 2);
+    __amdgpu_buffer_rsrc_t rs_a[PLANES], rs_b[PLANES];
+    rs_a[0] = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x + base_pix * p.x_pix), 0, (int)a_bytes, 0x00020000);
+    rs_b[0] = __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, w_bytes, 0x00020000);
+    if (MODE == MODE_SPLIT) {
+        rs_a[PLANES - 1] = __builtin_amdgcn_make_buffer_rsrc((void *)(p.x_lo + base_pix * p.x_pix), 0, (int)a_bytes, 0x00020000);
+        rs_b[PLANES - 1] = __builtin_amdgcn_make_buffer_rsrc((void *)p.w_lo, 0, w_bytes, 0x00020000);
+    }
+    int a_hi0[PA], a_wi0[PA], a_rel[PA];
+    bool a_ok[PA];
+#pragma unroll
+    for (int ps = 0; ps < PA; ++ps) {
+        const long long m = m0 + lr + ps * ROWS_PER_PASS;
+        a_ok[ps] = m < p.M;
+        const long long mm = a_ok[ps] ? m : m0;
+        const unsigned n = (unsigned)mm / (unsigned)(p.Ho * p.Wo);
+        const int rem = (int)((unsigned)mm - n * (unsigned)(p.Ho * p.Wo));
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        a_hi0[ps] = ho * p.stride - p.pad; a_wi0[ps] = wo * p.stride - p.pad;
+        a_rel[ps] = (int)((long long)n * p.H * p.W - base_pix) + a_hi0[ps] * p.W + a_wi0[ps];
+    }
+    int b_off[PB];
+#pragma unroll
+    for (int ps = 0; ps < PB; ++ps) {
+        const int co = n0 + lr + ps * ROWS_PER_PASS;
+        b_off[ps] = co < p.Cout ? co * p.K * 2 : OOB;
+    }
+
+    i32x4 rg[2][NL];                                       // two staging register sets: loads run two K steps ahead of the MFMAs
+    int t_kh = 0, t_kw = 0, t_ci = 0, t_k = 0;
+    bool t_in = false;
+    auto set_tap = [&](int k0) {
+        t_k = k0 + lc * 8;
+        t_in = t_k < p.K;
+        t_kh = 0; t_kw = 0; t_ci = t_k;
+        if (p.KH * p.KW != 1) { const int tap = t_k / p.Cin; t_ci = t_k - tap * p.Cin; t_kh = tap / p.KW; t_kw = tap - t_kh * p.KW; }
+    };
+    // load i of a step: i = plane * (PA + PB) + (pass of A | PA + pass of B)
+    auto issue_load = [&](int set, int i) {
+        const int plane = i / (PA + PB), j = i % (PA + PB);
+        if (j < PA) {
+            const int hi = a_hi0[j] + t_kh, wi = a_wi0[j] + t_kw;
+            const bool ok = t_in && a_ok[j] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const int off = ((a_rel[j] + t_kh * p.W + t_kw) * p.x_pix + t_ci) * 2;
+            rg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_a[plane], ok ? off : OOB, 0, 0);
+        } else {
+            const int bo = b_off[j - PA];
+            rg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_b[plane], (t_in && bo != OOB) ? bo + t_k * 2 : OOB, 0, 0);
+        }
+    };
+    auto issue_store = [&](int set, int i, int buf) {
+        const int plane = i / (PA + PB), j = i % (PA + PB);
+        unsigned char *dst = j < PA ? As + (buf * BM + lr + j * ROWS_PER_PASS) * LDB : Bs + (buf * BN + lr + (j - PA) * ROWS_PER_PASS) * LDB;
+        *reinterpret_cast<i32x4 *>(dst + plane * (ROW_BYTES / 2) + lc * 16) = rg[set][i];
+    };
+
+    constexpr int NACC = MODE == MODE_SPLIT ? 2 : 1;
+    f32x16 acc[NACC][TM][TN];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
+
+    const int steps = (p.K + BKE - 1) / BKE;
+    // prologue: step 0 straight into LDS, step 1 into register set 1
+    set_tap(0);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) issue_load(0, i);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) issue_store(0, i, 0);
+    set_tap(BKE);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) issue_load(1, i);
+    __syncthreads();
+
+    // fragments: lane l holds row (l & 31), 8 consecutive k starting at 8 * (l >> 5) of a 16-wide slice
+    const int frag_off = (lane & 31) * LDB + (lane >> 5) * 16;
+    const unsigned char *a_frag = As + (wm * TM * 32) * LDB + frag_off, *b_frag = Bs + (wn * TN * 32) * LDB + frag_off;
+    constexpr int NJ = BKE / 16;                           // 16-wide slices per step: 4 (f16) or 2 (split)
+    h16x8 fa[2][PLANES][TM], fb[2][PLANES][TN];
+    auto read_frags = [&](int buf, int j, int set) {
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[set][pl][i] = *reinterpret_cast<const h16x8 *>(a_frag + (buf * BM + i * 32) * LDB + pl * (ROW_BYTES / 2) + j * 32);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) fb[set][pl][i] = *reinterpret_cast<const h16x8 *>(b_frag + (buf * BN + i * 32) * LDB + pl * (ROW_BYTES / 2) + j * 32);
+        }
+    };
+    read_frags(0, 0, 0);
+
+    // One K step.  P = parity of the step = LDS buffer it reads = register set it REFILLS (with the loads of step s + 2) in its first half;
+    // in its second half it writes the other set (loaded during step s - 1, for step s + 1) to the other LDS buffer.
+    auto k_step = [&](auto parity, int s) {
+        constexpr int P = decltype(parity)::value;
+        set_tap((s + 2) * BKE);                            // beyond K near the end: the loads return zeros and land in a dead buffer
+        constexpr int NCH = 4;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int j = MODE == MODE_SPLIT ? (c >> 1) : c, fset = j & 1;
+            const bool first_of_j = MODE == MODE_SPLIT ? (c & 1) == 0 : true;
+            if (first_of_j && j + 1 < NJ) read_frags(P, j + 1, fset ^ 1);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                if (c < NCH / 2 && (i * (NCH / 2)) / NL == c) issue_load(P, i);
+                if (c >= NCH / 2 && (i * (NCH / 2)) / NL == c - NCH / 2) issue_store(P ^ 1, i, P ^ 1);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) {
+                    if (MODE == MODE_F16) {
+                        acc[0][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fset][0][i], fb[fset][0][jj], acc[0][i][jj], 0, 0, 0);
+                    } else if ((c & 1) == 0) {
+                        acc[0][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fset][0][i], fb[fset][0][jj], acc[0][i][jj], 0, 0, 0);
+                    } else {
+                        acc[NACC - 1][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fset][0][i], fb[fset][PLANES - 1][jj], acc[NACC - 1][i][jj], 0, 0, 0);
+                        acc[NACC - 1][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[fset][PLANES - 1][i], fb[fset][0][jj], acc[NACC - 1][i][jj], 0, 0, 0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        read_frags(P ^ 1, 0, 0);
+    };
+    for (int s = 0; s < steps; s += 2) {
+        k_step(std::integral_constant<int, 0>{}, s);
+        if (s + 1 < steps) k_step(std::integral_constant<int, 1>{}, s + 1);
+    }
+    __syncthreads();
+
+    // ---- epilogue through LDS (fp32 tile), 8 output elements per lane
+    constexpr int LDC = BN + 4;
+    float *Cs = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj) {
+            float *c = Cs + ((wm * TM + i) * 32 + 4 * (lane >> 5)) * LDC + (wn * TN + jj) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[0][i][jj][r];
+                if (MODE == MODE_SPLIT) v = v + acc[NACC - 1][i][jj][r] * LO_INV;
+                c[((r & 3) + 8 * (r >> 2)) * LDC] = v;
+            }
+        }
+    __syncthreads();
+    constexpr int V_PER_ROW = BN / 8, NVEC = BM * V_PER_ROW, ITS = (NVEC + NT - 1) / NT;
+    for (int it = 0; it < ITS; ++it) {
+        const int idx = it * NT + tid;
+        const int row = idx / V_PER_ROW, ec = (idx - row * V_PER_ROW) * 8;
+        const long long m = m0 + row;
+        const int co = n0 + ec;
+        if ((NVEC % NT != 0 && idx >= NVEC) || m >= p.M || co >= p.Cout) continue;      // Cout % 8 == 0 (checked by the host side)
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = Cs[row * LDC + ec + e] + (p.bias ? p.bias[co + e] : 0.f);
+        if (RES) {
+            const h16x8 rh = *reinterpret_cast<const h16x8 *>(p.res + m * p.r_pix + co);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)rh[e];
+            if (MODE == MODE_SPLIT) {
+                const h16x8 rl = *reinterpret_cast<const h16x8 *>(p.res_lo + m * p.r_pix + co);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rl[e] * LO_INV;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = act16<ACT>(v[e]);
+        if (OUT_F32) {
+            float *o = p.y32 + m * p.y_pix + co;
+            *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else if (MODE == MODE_SPLIT) {
+            h16x8 oh, ol;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f32(v[e], h, l); oh[e] = h; ol[e] = l; }
+            *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
+            *reinterpret_cast<h16x8 *>(p.y_lo + m * p.y_pix + co) = ol;
+        } else {
+            h16x8 oh;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) oh[e] = (_Float16)v[e];
+            *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
+        }
+    }
+}
+
+template <int TM, int TN, int WGM, int WGN, int MODE, bool OUT_F32> int launch16(Conv16Args &a, int act, hipStream_t st)
+{
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, NT = 64 * WGM * WGN;
+    constexpr size_t LDS_STAGE = (size_t)2 * (BM + BN) * LDB, LDS_C = (size_t)BM * (BN + 4) * sizeof(float);
+    constexpr size_t LDS_BYTES = LDS_STAGE > LDS_C ? LDS_STAGE : LDS_C;
+    a.tiles_n = (a.Cout + BN - 1) / BN;
+    a.tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
+    if (a.tiles > 0x7fffffffLL || a.M > 0x7fffffffLL) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: more than 2^31 - 1 output pixels in one launch");
+    const bool res = a.res != nullptr;
+#define TLK_C16_LAUNCH(A, R)                                                                                                               \
+    do {                                                                                                                                   \
+        auto kern = conv16_mfma_kernel<TM, TN, WGM, WGN, A, R, MODE, OUT_F32>;                                                             \
+        static bool attr_set = false;                                                                                                      \
+        if (!attr_set) { TLK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES)); attr_set = true; } \
+        hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles), dim3(NT), LDS_BYTES, st, a);                                                     \
+    } while (0)
+    if (res) { if (act == 0) TLK_C16_LAUNCH(ACT_NONE, true); else if (act == 1) TLK_C16_LAUNCH(ACT_RELU, true); else TLK_C16_LAUNCH(ACT_SILU, true); }
+    else { if (act == 0) TLK_C16_LAUNCH(ACT_NONE, false); else if (act == 1) TLK_C16_LAUNCH(ACT_RELU, false); else TLK_C16_LAUNCH(ACT_SILU, false); }
+#undef TLK_C16_LAUNCH
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
+
+// Tile choice.  Both modes move 4 (split) or 2 (f16) bytes per element through L2 -> LDS at 5x / 16x the fp32 MFMA rate, so the 128 x 128 tile
+// is the smallest that keeps the CU's L2 traffic (~40-60 B/clk) below what the L2 delivers; the split mode carries two accumulators per
+// tile, so it spreads the 128 x 128 tile over EIGHT wavefronts of 32 x 64 (one workgroup per CU, two wavefronts per SIMD) where the f16 mode
+// uses four of 64 x 64 (two workgroups per CU).
+template <int MODE, bool OUT_F32> int dispatch16(Conv16Args &a, int act, hipStream_t st)
+{
+    if (MODE == MODE_SPLIT) {
+        if (a.Cout > 64) return launch16<1, 2, 4, 2, MODE, OUT_F32>(a, act, st);         // 128 x 128, 8 wavefronts
+        return launch16<1, 2, 4, 1, MODE, OUT_F32>(a, act, st);                          // 128 x 64, 4 wavefronts
+    }
+    if (a.Cout > 64) return launch16<2, 2, 2, 2, MODE, OUT_F32>(a, act, st);             // 128 x 128, 4 wavefronts
+    return launch16<2, 1, 2, 2, MODE, OUT_F32>(a, act, st);                              // 128 x 64
+}
+
+// fp32 NHWC (c_in channels) -> (hi, lo) f16 planes with c_out >= c_in channels (zero padded): the entry of a split-precision network
+__global__ void __launch_bounds__(BLOCK) split_planes_kernel(const float *__restrict__ x, long long pixels, int c_in, int x_pix, int c_out,
+                                                             _Float16 *__restrict__ hi, _Float16 *__restrict__ lo)
+{
+    const long long n = pixels * c_out;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) {
+        const long long px = i / c_out;
+        const int c = (int)(i - px * c_out);
+        _Float16 h = (_Float16)0.f, l = (_Float16)0.f;
+        if (c < c_in) split_f32(x[px * x_pix + c], h, l);
+        hi[i] = h; lo[i] = l;
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) merge_planes_kernel(const _Float16 *__restrict__ hi, const _Float16 *__restrict__ lo, long long n, float *__restrict__ y)
+{
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) y[i] = (float)hi[i] + (float)lo[i] * LO_INV;
+}
+
+}  // namespace
+
+extern "C" int tlk_conv2d_nhwc_16(const void *x_dev, const void *x_lo_dev, const void *w_dev, const void *w_lo_dev, const float *bias_dev,
+                                  const void *res_dev, const void *res_lo_dev, void *y_dev, void *y_lo_dev, float *y_f32_dev,
+                                  int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int act_kind,
+                                  int x_pix_stride, int y_pix_stride, int res_pix_stride, void *hip_stream)
+{
+    if (n < 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0)
+        return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: bad shape");
+    if (cin % 8 != 0 || cout % 8 != 0) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: Cin and Cout must be multiples of 8 (pad with zero channels)");
+    if (act_kind < 0 || act_kind > 2) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: act_kind is 0 (none), 1 (ReLU) or 2 (SiLU)");
+    const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+    if (ho <= 0 || wo <= 0) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: empty output");
+    if (n == 0) return TLK_OK;
+    const bool split = x_lo_dev != nullptr;
+    if (!x_dev || !w_dev || (split && !w_lo_dev) || (!split && w_lo_dev)) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: x / w planes do not match");
+    if (res_dev && split != (res_lo_dev != nullptr)) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: residual planes do not match the mode");
+    const bool out32 = y_f32_dev != nullptr;
+    if (!out32 && (!y_dev || (split && !y_lo_dev))) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: no output");
+    Conv16Args a;
+    a.x = (const _Float16 *)x_dev; a.x_lo = (const _Float16 *)x_lo_dev; a.w = (const _Float16 *)w_dev; a.w_lo = (const _Float16 *)w_lo_dev;
+    a.res = (const _Float16 *)res_dev; a.res_lo = (const _Float16 *)res_lo_dev; a.bias = bias_dev;
+    a.y = (_Float16 *)y_dev; a.y_lo = (_Float16 *)y_lo_dev; a.y32 = y_f32_dev;
+    a.M = (long long)n * ho * wo;
+    a.H = h; a.W = w; a.Cin = cin; a.Ho = ho; a.Wo = wo; a.Cout = cout; a.KH = kh; a.KW = kw; a.stride = stride; a.pad = pad; a.K = kh * kw * cin;
+    a.x_pix = x_pix_stride > 0 ? x_pix_stride : cin;
+    a.y_pix = y_pix_stride > 0 ? y_pix_stride : cout;
+    a.r_pix = res_pix_stride > 0 ? res_pix_stride : cout;
+    if (a.x_pix < cin || a.y_pix < cout || a.r_pix < cout || (a.x_pix | a.y_pix | a.r_pix) % 8 != 0)
+        return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: pixel strides must cover the channels and be multiples of 8");
+    if (((uintptr_t)x_dev | (uintptr_t)x_lo_dev | (uintptr_t)w_dev | (uintptr_t)w_lo_dev | (uintptr_t)res_dev | (uintptr_t)res_lo_dev | (uintptr_t)y_dev |
+         (uintptr_t)y_lo_dev | (uintptr_t)y_f32_dev | (uintptr_t)bias_dev) & 15)
+        return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: every pointer must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (split) return out32 ? dispatch16<MODE_SPLIT, true>(a, act_kind, st) : dispatch16<MODE_SPLIT, false>(a, act_kind, st);
+    return out32 ? dispatch16<MODE_F16, true>(a, act_kind, st) : dispatch16<MODE_F16, false>(a, act_kind, st);
+}
+
+extern "C" int tlk_split_f32_planes(const float *x_dev, long long pixels, int c_in, int x_pix_stride, int c_out, void *hi_dev, void *lo_dev, void *hip_stream)
+{
+    if (pixels < 0 || c_in <= 0 || c_out < c_in) return fail(TLK_EINVAL, "tlk_split_f32_planes: bad shape");
+    if (pixels == 0) return TLK_OK;
+    if (!x_dev || !hi_dev || !lo_dev) return fail(TLK_EINVAL, "tlk_split_f32_planes: null pointer");
+    const long long n = pixels * c_out;
+    long long blocks = (n + BLOCK - 1) / BLOCK;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)hip_stream, x_dev, pixels, c_in,
+                       x_pix_stride > 0 ? x_pix_stride : c_in, c_out, (_Float16 *)hi_dev, (_Float16 *)lo_dev);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
+
+extern "C" int tlk_merge_planes_f32(const void *hi_dev, const void *lo_dev, long long n, float *y_dev, void *hip_stream)
+{
+    if (n < 0) return fail(TLK_EINVAL, "tlk_merge_planes_f32: bad size");
+    if (n == 0) return TLK_OK;
+    if (!hi_dev || !lo_dev || !y_dev) return fail(TLK_EINVAL, "tlk_merge_planes_f32: null pointer");
+    long long blocks = (n + BLOCK - 1) / BLOCK;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)hip_stream, (const _Float16 *)hi_dev, (const _Float16 *)lo_dev, n, y_dev);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
