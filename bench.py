@@ -830,25 +830,28 @@ def main():
                         "ms_frame_in_to_rows_out": float(np.median(lat_main) * 1e3), "parity": "see `parity`"})
         pipe.reset()
 
-    # ---- other-precision leg: the default fp32 run (the reference's precision: ONNXRuntime / torchreid fp32, strong_sort.yaml:10 fp16: false)
-    # also times the f16 backbones (tolerance: tests/test_gpu_precision.py) at the same steps / warm-up, frames resident; an f16 run times fp32.
-    # Either way 48 frames of ids are checked against the oracle chain ----
-    alt_leg = None
-    alt_name = "f16" if args.dtype == "f32" else "f32"
-    if rank == 0 and world == 1 and is3 and args.dtype in ("f16", "f32") and not args.no_f32_leg and not ssort and wl.get("pose") is None:
+    # ---- other-precision legs.  The default fp32 run (the reference's precision: ONNXRuntime / torchreid fp32, strong_sort.yaml:10 fp16: false)
+    # also times (a) the f16 backbones (tolerance: tests/test_gpu_precision.py) and (b) the SPLIT-PRECISION ReID network: fp32 weights and
+    # activations carried as (hi, lo) f16 pairs, three f16 MFMAs per product pair, fp32 accumulation -- fp32-class results (the same fp64
+    # bound as the exact kernel, tests/test_gpu_conv16.py) at a multiple of the fp32 MFMA rate; an f16 run times fp32.  Every leg: same
+    # steps / warm-up policy, frames resident, 48 frames of ids checked against the oracle chain ----
+    def precision_leg(name, dtype_name, split):
         import oracle
-        saved = tdtype
-        tdtype = getattr(torch, DTYPES[alt_name])
-        pf = make_pipe(F)
-        tdtype = saved
+        kw = {k_: wl[k_] for k_ in ("dim", "reid_arch") if k_ in wl}
+        pf = gp.DetReidTrackPipeline(detector, n_streams=S, frames_per_step=F, max_dets=wl["max_dets"], device=dev.index, use_graph=not args.no_graph,
+                                     pose=wl.get("pose"), tracker=wl.get("tracker", "bpbreid"), dtype=getattr(torch, DTYPES[dtype_name]),
+                                     reid_split_precision=split, **kw)
         ref_ = oracle.StrongSORT(pf.K, pf.D, **pf.tracker_cfg)
         okf, nfr = True, 0
+        emb_first = None
         for k in range(2):
             h_rows, h_cnt = run_step(k, p=pf)
             pf.synchronize()
             rws, _ = pf.rows_numpy(h_rows, h_cnt)
             emb = pf.last["emb"].cpu().numpy().reshape(S, F, pf.maxd, pf.K, pf.D)
             vis = pf.last["vis"].cpu().numpy().reshape(S, F, pf.maxd, pf.K)
+            if k == 0:
+                emb_first = emb.copy()
             for f in range(F):
                 ltwh32 = detector_rows(oracle, heads_np[0][k * F + f], ratio)
                 n = len(ltwh32)
@@ -857,16 +860,37 @@ def main():
                 okf &= len(got) == len(exp) and (len(exp) == 0 or (np.array_equal(got["det_id"], exp["det_id"]) and np.array_equal(got["track_id"], exp["track_id"])))
                 nfr += 1
         pf.reset()
-        n_alt, w_alt = (args.steps, args.warmup) if alt_name == "f16" else (max(3, args.steps // 4), 2)
+        n_alt, w_alt = (args.steps, args.warmup) if dtype_name != "f32" or split else (max(3, args.steps // 4), 2)
         ela = timed_resident(pf, n_alt, w_alt)
-        alt_leg = {"dtype": alt_name, "value": n_alt * B / ela, "ms_per_step": ela / n_alt * 1e3, "steps": n_alt, "warmup": w_alt, "frames_resident": True,
-                   "parity": {"frames": nfr, "track_ids_equal_oracle": bool(okf)},
-                   "note": ("f16 backbones: narrower than the reference's fp32 -- NOT the headline; embeddings agree with the fp32 ones to cos 1e-5 / "
-                            "part-distance 2e-3 on this network (tests/test_gpu_precision.py); the hand-written pre / post-processing and tracker kernels "
-                            "are fp64 / fp32 / integer in both legs") if alt_name == "f16" else
-                           "fp32 backbones = the reference's precision; the hand-written kernels are fp64 / fp32 / integer in both legs"}
+        leg = {"dtype": name, "value": n_alt * B / ela, "ms_per_step": ela / n_alt * 1e3, "steps": n_alt, "warmup": w_alt, "frames_resident": True,
+               "parity": {"frames": nfr, "track_ids_equal_oracle": bool(okf)}}
         pf.close()
         del pf
+        return leg, emb_first
+
+    alt_leg = split_leg = None
+    alt_name = "f16" if args.dtype == "f32" else "f32"
+    if rank == 0 and world == 1 and is3 and args.dtype in ("f16", "f32") and not args.no_f32_leg and not ssort and wl.get("pose") is None:
+        alt_leg, emb_alt = precision_leg(alt_name, alt_name, False)
+        alt_leg["note"] = ("f16 backbones: narrower than the reference's fp32 -- NOT the headline; embeddings agree with the fp32 ones to cos 1e-5 / "
+                           "part-distance 2e-3 on this network (tests/test_gpu_precision.py); the hand-written pre / post-processing and tracker kernels "
+                           "are fp64 / fp32 / integer in both legs") if alt_name == "f16" else \
+            "fp32 backbones = the reference's precision; the hand-written kernels are fp64 / fp32 / integer in both legs"
+        if args.dtype == "f32" and wl.get("reid_arch", "resnet50") == "resnet50":
+            split_leg, emb_split = precision_leg("f32 weights and activations as (hi, lo) f16 pairs, 3 f16 MFMAs per product pair, fp32 accumulation "
+                                                 "(ReID ResNet-50; detector exact fp32)", "f32", True)
+            # how far the legs' embeddings are from the EXACT fp32 run's, same crops (first step of stream 0)
+            h_rows, h_cnt = run_step(0)
+            pipe.synchronize()
+            e0 = pipe.last["emb"].cpu().numpy().reshape(S, F, pipe.maxd, pipe.K, pipe.D)[0].astype(np.float64)
+            pipe.reset()
+            sc = float(np.abs(e0).max()) or 1.0
+            split_leg["max_abs_embedding_difference_vs_exact_fp32"] = float(np.abs(emb_split[0] - e0).max() / sc)
+            alt_leg["max_abs_embedding_difference_vs_exact_fp32"] = float(np.abs(emb_alt[0].astype(np.float64) - e0).max() / sc)
+            split_leg["note"] = ("fp32-class arithmetic on the 16-bit MFMA (csrc/tlk_conv16.hip, split mode): operands exact to 2^-22, every product exact "
+                                 "in fp32, fp32 sums; tests/test_gpu_conv16.py holds it to the same fp64 bound as the exact-fp32 kernel "
+                                 "(|err| <= 2e-6 * |x| conv |w|).  Reported BESIDE the exact-fp32 `value`, not instead of it: `value` stays the number "
+                                 "computed with v_mfma_f32_32x32x2_f32")
     f32_leg = alt_leg if alt_leg and alt_name == "f32" else None
 
     # ---- CPU baseline: (a) the same chain on host cores (oracle C port + torch CPU fp32 forwards), warm, bounded sample;
@@ -904,6 +928,9 @@ def main():
             "value_f16": alt_leg["value"] if alt_leg and alt_name == "f16" else None,
             "ms_per_step_f16": alt_leg["ms_per_step"] if alt_leg and alt_name == "f16" else None,
             "f16_leg": alt_leg if alt_leg and alt_name == "f16" else None,
+            "value_f32_split": split_leg["value"] if split_leg else None,
+            "ms_per_step_f32_split": split_leg["ms_per_step"] if split_leg else None,
+            "f32_split_leg": split_leg,
             "precision_note": ("value is measured with fp32 backbones, the reference's precision (configs/modules/track/strong_sort.yaml:10 fp16: false; "
                                "ONNXRuntime / torchreid fp32): exact fp32 MFMA, no reduced-precision path exists on gfx950. One step is "
                                "~32 TFLOP of convolutions, so 157.3 TFLOP/s (the chip's dense fp32 peak) bounds this configuration at "

@@ -1008,8 +1008,11 @@ def _pix16(t, c, h, w):
     sn, sc, sh, sw = t.stride()
     if t.shape[0] == 0:
         return c
-    assert (sc == 1 or c == 1) and sh == w * sw and (sn == h * sh or t.shape[0] == 1), "tensor must be channels_last (or a channel slice of one)"
-    return sw
+    # (strides of size-1 dimensions are arbitrary in torch: the pixel stride is read from the first spatial dimension that has extent)
+    pix = sw if w > 1 else (sh if h > 1 else (sn if t.shape[0] > 1 else c))
+    assert (sc == 1 or c == 1) and (w == 1 or h == 1 or sh == w * sw) and (t.shape[0] == 1 or sn == h * w * pix), \
+        "tensor must be channels_last (or a channel slice of one)"
+    return pix
 
 
 def _bind_conv16(L):

@@ -15,7 +15,7 @@ USE_FUSED_GEMM = _os.environ.get("TLK_FUSED_GEMM", "1") != "0"
 USE_TLK_CONV_F32 = _os.environ.get("TLK_CONV_F32", "1") != "0"
 # f16 convolutions with the epilogue inside on libtlk's 16-bit MFMA kernel (tlk_conv2d_nhwc_16, csrc/tlk_conv16.hip) instead of MIOpen / CK /
 # hipBLASLt + a separate epilogue pass; TLK_CONV_F16=0 restores the library route for A/B runs.
-USE_TLK_CONV_F16 = _os.environ.get("TLK_CONV_F16", "1") != "0"
+USE_TLK_CONV_F16 = _os.environ.get("TLK_CONV_F16", "0") != "0"      # r04: measured 72 ms vs the library route's ~55 ms on the ReID forward -- opt-in until it wins
 # bench.py's roofline pass: a list here makes every fp32 convolution record (start event, end event, algorithmic flops) around its launch
 CONV_TIMER = None
 

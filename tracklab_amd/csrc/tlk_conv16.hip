@@ -3,7 +3,8 @@
 //   MODE_F16   activations / weights f16, fp32 accumulation, epilogue (bias, residual, ReLU / SiLU) in fp32, output f16: the f16 leg, with the
 //              epilogue INSIDE the convolution (r01-r03 ran MIOpen / CK / hipBLASLt + a separate bias_act pass for the 3x3 ones).
 //   MODE_SPLIT every fp32 value x travels as TWO f16 numbers, hi = f16(x) and lo = f16((x - hi) * 2^11): x = hi + lo * 2^-11 to a relative 2^-22
-//              (an f16 significand is 11 bits, so the pair holds 22; the scale keeps lo a NORMAL f16 whenever hi is).  A product a*b is
+//              (an f16 significand is 11 bits, so the pair holds 22; the scale keeps lo a NORMAL f16 whenever hi is; for |x| < 2^-14, where
+//              hi is subnormal, the pair is exact to an absolute 2^-35).  A product a*b is
 //              a_hi*b_hi + 2^-11 (a_hi*b_lo + a_lo*b_hi) + O(2^-22 |ab|): THREE MFMAs per operand pair, two fp32 accumulators (the head and
 //              the cross terms), merged as acc_hh + 2^-11 acc_x in the epilogue.  Every f16 x f16 product is exact in fp32 (22 bits) and the
 //              sums are fp32, so the result carries fp32-class error -- |err| <= ~3 * 2^-22 * sum|a||b| representation error plus the same
@@ -127,13 +128,25 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
     }
 
     i32x4 rg[2][NL];                                       // two staging register sets: loads run two K steps ahead of the MFMAs
+    // Tap of the step being loaded.  The 16-bit MFMA leaves only a few hundred cycles per K step, so the integer work per load matters: when
+    // Cin is a multiple of the step (every layer but an RGB stem) the whole step lies inside ONE tap, (kh, kw, ci0) advance by increments
+    // (wave-uniform, scalar unit) and a load's offset is one vector add; otherwise the general form divides.
+    const bool tap_uniform = p.Cin % BKE == 0;
+    int u_kh = 0, u_kw = 0, u_ci0 = 0, u_k0 = 0;           // uniform: tap and first channel of the step (valid when tap_uniform)
     int t_kh = 0, t_kw = 0, t_ci = 0, t_k = 0;
     bool t_in = false;
-    auto set_tap = [&](int k0) {
-        t_k = k0 + lc * 8;
-        t_in = t_k < p.K;
-        t_kh = 0; t_kw = 0; t_ci = t_k;
-        if (p.KH * p.KW != 1) { const int tap = t_k / p.Cin; t_ci = t_k - tap * p.Cin; t_kh = tap / p.KW; t_kw = tap - t_kh * p.KW; }
+    bool first_tap = true;
+    auto set_tap = [&](int k0) {                           // called with k0 = 0, BKE, 2 BKE, ... in order
+        if (tap_uniform) {
+            if (!first_tap) { u_k0 += BKE; u_ci0 += BKE; if (u_ci0 >= p.Cin) { u_ci0 = 0; if (++u_kw == p.KW) { u_kw = 0; ++u_kh; } } }
+            first_tap = false;
+            t_k = u_k0 + lc * 8; t_in = u_k0 < p.K; t_kh = u_kh; t_kw = u_kw; t_ci = u_ci0 + lc * 8;
+        } else {
+            t_k = k0 + lc * 8;
+            t_in = t_k < p.K;
+            t_kh = 0; t_kw = 0; t_ci = t_k;
+            if (p.KH * p.KW != 1) { const int tap = t_k / p.Cin; t_ci = t_k - tap * p.Cin; t_kh = tap / p.KW; t_kw = tap - t_kh * p.KW; }
+        }
     };
     // load i of a step: i = plane * (PA + PB) + (pass of A | PA + pass of B)
     auto issue_load = [&](int set, int i) {
@@ -257,8 +270,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
         const int co = n0 + ec;
         if ((NVEC % NT != 0 && idx >= NVEC) || m >= p.M || co >= p.Cout) continue;      // Cout % 8 == 0 (checked by the host side)
         float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = Cs[row * LDC + ec + e] + (p.bias ? p.bias[co + e] : 0.f);
+        {
+            const float4 c0 = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec), c1 = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec + 4);
+            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+            if (p.bias) { b0 = *reinterpret_cast<const float4 *>(p.bias + co); b1 = *reinterpret_cast<const float4 *>(p.bias + co + 4); }
+            v[0] = c0.x + b0.x; v[1] = c0.y + b0.y; v[2] = c0.z + b0.z; v[3] = c0.w + b0.w;
+            v[4] = c1.x + b1.x; v[5] = c1.y + b1.y; v[6] = c1.z + b1.z; v[7] = c1.w + b1.w;
+        }
         if (RES) {
             const h16x8 rh = *reinterpret_cast<const h16x8 *>(p.res + m * p.r_pix + co);
 #pragma unroll
