@@ -150,6 +150,22 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // The residual of this lane's output vectors is fetched NOW and waits in registers: the 1x1 expansions that carry it are short in K
+    // (2-16 steps), their epilogue used to sit on HBM latency with four loads in flight; here all of them ride under the main loop.
+    constexpr int EV_PER_ROW = BN / 4, ENVEC = BM * EV_PER_ROW, EITS = (ENVEC + NT - 1) / NT;
+    const bool evec = ((p.Cout | p.y_pix | p.r_pix) & 3) == 0 && (((uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.bias) & 15) == 0;
+    float4 rres[RES ? EITS : 1];
+    if (RES && evec) {
+#pragma unroll
+        for (int it = 0; it < EITS; ++it) {
+            const int idx = it * NT + tid;
+            const int row = idx / EV_PER_ROW, ec = (idx - row * EV_PER_ROW) * 4;
+            const long long m = m0 + row;
+            const int co = n0 + ec;
+            const bool ok = !(ENVEC % NT != 0 && idx >= ENVEC) && m < p.M && co < p.Cout;
+            rres[it] = ok ? *reinterpret_cast<const float4 *>(p.res + m * p.r_pix + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     const int steps = (p.K + BK - 1) / BK;
     set_tap(0);
 #pragma unroll
@@ -216,9 +232,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
     const float *__restrict__ resp = p.res;
     float *__restrict__ yp = p.y;
     constexpr int V_PER_ROW = BN / 4, NVEC = BM * V_PER_ROW, ITS = (NVEC + NT - 1) / NT;
-    const bool vec = ((p.Cout | p.y_pix | p.r_pix) & 3) == 0 && (((uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.bias) & 15) == 0;
+    static_assert(V_PER_ROW == EV_PER_ROW && ITS == EITS, "the residual prefetch uses the epilogue's geometry");
+    const bool vec = evec;
     if (vec) {
-#pragma unroll 4
+#pragma unroll
         for (int it = 0; it < ITS; ++it) {
             const int idx = it * NT + tid;
             const int row = idx / V_PER_ROW, ec = (idx - row * V_PER_ROW) * 4;
@@ -228,10 +245,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
             float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec);
             if (p.bias) { const float4 bv = *reinterpret_cast<const float4 *>(p.bias + co); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
             else { v.x += 0.f; v.y += 0.f; v.z += 0.f; v.w += 0.f; }
-            if (RES) {
-                const float4 rv = *reinterpret_cast<const float4 *>(resp + m * p.r_pix + co);
-                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-            }
+            if (RES) { const float4 rv = rres[it]; v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
             v.x = act_f32<ACT>(v.x); v.y = act_f32<ACT>(v.y); v.z = act_f32<ACT>(v.z); v.w = act_f32<ACT>(v.w);
             *reinterpret_cast<float4 *>(yp + m * p.y_pix + co) = v;
         }
