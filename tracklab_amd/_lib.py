@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtlk.so")
+# TLK_LIB_PATH: another build of the same library (tests/test_gpu_canary.py loads the guard-word build, tools/build_canary.sh)
+LIB_PATH = os.environ.get("TLK_LIB_PATH") or os.path.join(_HERE, "lib", "libtlk.so")
 
 ASSO = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3, "ct_dist": 4}
 

@@ -403,6 +403,9 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
     const int MAXT = D.MAXT, MAXD = D.MAXD, S = D.S, DIM = D.D;
     Lds L;
     carve(smem, MAXT, MAXD, L);
+#ifdef TLK_LDS_CANARY
+    canary_fill(L, (unsigned char *)(L.cost + (D.cost_lds_entries > 16 ? D.cost_lds_entries - 16 : 0)));
+#endif
     int *hdr = D.hdr + (size_t)s * H_COUNT;
     int *order = D.order + (size_t)s * MAXT;
     int *freestk = D.freestk + (size_t)s * MAXT;
@@ -425,6 +428,9 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
         int *out_count = out_counts + (size_t)s * n_frames + f;
         const int n_in = counts[(size_t)s * n_frames + f];
         __syncthreads();
+#ifdef TLK_LDS_CANARY
+        { const int bad = canary_check(L); if (bad && tid == 0) hdr[H_ERR] = -100 - bad; __syncthreads(); }
+#endif
         if (hdr[H_ERR] != 0) { if (tid == 0) *out_count = hdr[H_ERR]; continue; }
         if (n_in > MAXD || n_in < 0) { if (tid == 0) { hdr[H_ERR] = TLK_ECAPACITY; *out_count = TLK_ECAPACITY; } continue; }
         if (P.wrapper_mode && n_in == 0) { if (tid == 0) *out_count = 0; continue; }   // deep_oc_sort_api.py:59-60
@@ -515,7 +521,7 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
 
         PROF(3);
         // ---- first association (association.py:291-364)
-        double *cost = ((size_t)N * T <= (size_t)D.cost_lds_entries) ? L.cost : (D.cost_g + (size_t)s * MAXD * MAXT);
+        double *cost = ((size_t)N * T <= (size_t)(D.cost_lds_entries - TLK_CANARY_BYTES_TOTAL / 24 / 8 * 2)) ? L.cost : (D.cost_g + (size_t)s * MAXD * MAXT);
         // until the cost fill, cost[e] holds the float32 embedding cost of the pair (exact in a double): no second N x T array
         int n_mi = 0;
         if (T > 0 && N > 0) {
@@ -651,7 +657,7 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
         // ---- second round by OCR on the last observations (ocsort.py:480-513)
         if (nud > 0 && nut > 0) {
             const int nrow = nud, ncol = nut;
-            double *mat = ((size_t)nrow * ncol <= (size_t)D.cost_lds_entries) ? L.cost : (D.cost_g + (size_t)s * MAXD * MAXT);
+            double *mat = ((size_t)nrow * ncol <= (size_t)(D.cost_lds_entries - TLK_CANARY_BYTES_TOTAL / 24 / 8 * 2)) ? L.cost : (D.cost_g + (size_t)s * MAXD * MAXT);
             double lmax = -INFINITY; bool lnan = false;
             for (int e = tid; e < nrow * ncol; e += BLOCK) {
                 const int r = e / ncol, c = e - r * ncol;
@@ -757,6 +763,9 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
         __threadfence_block();
         __syncthreads();
     }
+#ifdef TLK_LDS_CANARY
+    { const int bad = canary_check(L); if (bad && tid == 0) { hdr[H_ERR] = -100 - bad; out_counts[(size_t)s * n_frames + n_frames - 1] = -100 - bad; } }
+#endif
 }
 
 // KalmanBoxTracker.apply_affine_correction + KalmanFilterNew.apply_affine_correction (ocsort.py:261-281, kalmanfilter.py:387-405, new_kf

@@ -284,6 +284,9 @@ __device__ __noinline__ void kbt_init(const Trk &T, const double *det, int id)  
 }
 
 // ------------------------------------------------------------------ the fused per-frame kernel
+#ifdef TLK_LDS_CANARY
+__device__ int g_canary_poke = 0;      // positive control of the guard-word build: 1 = write one word past L.rowcnt in the next frames
+#endif
 __global__ void __launch_bounds__(BLOCK, 1)
 ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, const int *__restrict__ counts, int n_frames,
                      size_t det_stream_stride, size_t det_frame_stride, double *__restrict__ out_all, int out_cap,
@@ -295,6 +298,9 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
     const int MAXT = D.MAXT, MAXD = D.MAXD, S = D.S;
     Lds L;
     int cost_lds_entries = 0;
+#ifdef TLK_LDS_CANARY
+    bool can_live = false;
+#endif
     int *hdr = D.hdr + (size_t)s * H_COUNT;
     int *order = D.order + (size_t)s * MAXT;
     int *freestk = D.freestk + (size_t)s * MAXT;
@@ -314,6 +320,9 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
         int *out_count = out_counts + (size_t)s * n_frames + f;
         const int n_in = counts[(size_t)s * n_frames + f];
         __syncthreads();
+#ifdef TLK_LDS_CANARY
+        if (can_live) { const int bad = canary_check(L); can_live = false; if (bad && tid == 0) hdr[H_ERR] = -100 - bad; __syncthreads(); }
+#endif
         if (hdr[H_ERR] != 0) { if (tid == 0) *out_count = hdr[H_ERR]; continue; }
         if (n_in > MAXD || n_in < 0) { if (tid == 0) { hdr[H_ERR] = TLK_ECAPACITY; *out_count = TLK_ECAPACITY; } continue; }
         if (P.wrapper_mode && n_in == 0) { if (tid == 0) *out_count = 0; continue; }   // oc_sort_api.py:51-52
@@ -330,6 +339,12 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
             }
             if (ct) { carve(smem, ct, cd, L); cost_lds_entries = (int)(((size_t)D.lds_bytes - lds_fixed_bytes(ct, cd)) / sizeof(double)); }
             else { carve(D.big_ws + (size_t)s * D.big_stride, MAXT, MAXD, L); cost_lds_entries = 0; }
+#ifdef TLK_LDS_CANARY
+            if (cost_lds_entries > 16) cost_lds_entries -= 16;          // room for the guard after the cost area
+            canary_fill(L, (unsigned char *)(L.cost + cost_lds_entries));
+            can_live = true;
+            if (g_canary_poke && tid == 0) L.rowcnt[ct ? cd : MAXD] = 1;      // one int past the array's MAXD entries: lands in its guard
+#endif
         }
 
         // ---- split detections (ocsort.py:226-231), after the wrapper's conf filter (oc_sort_api.py:54)
@@ -614,6 +629,12 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
         }
         __syncthreads();
     }
+#ifdef TLK_LDS_CANARY
+    if (can_live) {
+        const int bad = canary_check(L);
+        if (bad && tid == 0) { hdr[H_ERR] = -100 - bad; out_counts[(size_t)s * n_frames + n_frames - 1] = -100 - bad; }
+    }
+#endif
 }
 
 __global__ void ocsort_reset_kernel(OcsDev D, int stream)
@@ -756,6 +777,14 @@ extern "C" int tlk_ocsort_create(const tlk_ocsort_params *p, int n_streams, int 
     *out = h;
     return TLK_OK;
 }
+
+#ifdef TLK_LDS_CANARY
+extern "C" int tlk_canary_selftest(int poke)
+{
+    TLK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_canary_poke), &poke, sizeof(int)));
+    return TLK_OK;
+}
+#endif
 
 extern "C" int tlk_ocsort_destroy(tlk_ocsort *h) { return ocs_free(h); }
 

@@ -121,7 +121,21 @@ struct Lds {
     int *scan;                        // NWAVES
     double *red;                      // NWAVES
     int *sc;                          // 32 scalars
+#ifdef TLK_LDS_CANARY
+    unsigned *can[24];                // guard words between the arrays (debug build: tools/build_canary.sh, tests/test_gpu_canary.py)
+    int ncan;
+#endif
 };
+#ifdef TLK_LDS_CANARY
+constexpr int CANARY_WORDS = 16;      // 64 bytes between any two arrays and after the last one
+constexpr unsigned CANARY_PATTERN = 0xA5C3F00Du;
+#define TLK_CANARY_BYTES_TOTAL (24 * CANARY_WORDS * 4)
+#else
+#define TLK_CANARY_BYTES_TOTAL 0
+#endif
+#ifndef TLK_LDS_PREPAD
+#define TLK_LDS_PREPAD 0          // debug builds: bytes of unused LDS AHEAD of the arrays (the layout change under which deepocsort_frames_kernel faulted in r01)
+#endif
 enum : int { SC_N = 0, SC_N2, SC_T, SC_NMI, SC_NM, SC_NUD, SC_NUT, SC_FLAG, SC_NL, SC_NREM };
 
 __host__ __device__ inline size_t lds_fixed_bytes(int MAXT, int MAXD)
@@ -135,34 +149,65 @@ __host__ __device__ inline size_t lds_fixed_bytes(int MAXT, int MAXD)
                         + (size_t)MAXD * 2 + (size_t)MAXT + (size_t)MAXX * 2 + NWAVES + 32);
     b = (b + 15) & ~(size_t)15;
     b += sizeof(double) * NWAVES;
-    return (b + 15) & ~(size_t)15;
+    return ((b + 15) & ~(size_t)15) + TLK_CANARY_BYTES_TOTAL + TLK_LDS_PREPAD;
 }
 
 __device__ inline void carve(unsigned char *smem, int MAXT, int MAXD, Lds &L)
 {
     const int MAXX = MAXT > MAXD ? MAXT : MAXD;
-    double *d = (double *)smem;
-    L.trk_box = d; d += (size_t)MAXT * 4;
-    L.kobs = d; d += (size_t)MAXT * 5;
-    L.velp = d; d += (size_t)MAXT * 2;
-    L.W.u = d; d += MAXX; L.W.v = d; d += MAXX; L.W.spc = d; d += MAXX;
+#ifdef TLK_LDS_CANARY
+    L.ncan = 0;
+    // a guard of CANARY_WORDS words after the array that ends at p (kept 16-byte aligned): returns the first byte after the guard
+    auto guard = [&](void *p) { unsigned char *q = (unsigned char *)(((uintptr_t)p + 15) & ~(uintptr_t)15); L.can[L.ncan++] = (unsigned *)q; return q + CANARY_WORDS * 4; };
+#define TLK_G(ptr, T) ptr = (T *)guard(ptr)
+#else
+#define TLK_G(ptr, T) (void)0
+#endif
+    double *d = (double *)(smem + TLK_LDS_PREPAD);
+    L.trk_box = d; d += (size_t)MAXT * 4; TLK_G(d, double);
+    L.kobs = d; d += (size_t)MAXT * 5; TLK_G(d, double);
+    L.velp = d; d += (size_t)MAXT * 2; TLK_G(d, double);
+    L.W.u = d; d += MAXX; TLK_G(d, double); L.W.v = d; d += MAXX; TLK_G(d, double); L.W.spc = d; d += MAXX; TLK_G(d, double);
     int *ip = (int *)d;
-    L.W.path = ip; ip += MAXX; L.W.row4col = ip; ip += MAXX; L.W.remaining = ip; ip += MAXX; L.W.col4row = ip; ip += MAXX;
+    L.W.path = ip; ip += MAXX; TLK_G(ip, int); L.W.row4col = ip; ip += MAXX; TLK_G(ip, int); L.W.remaining = ip; ip += MAXX; TLK_G(ip, int);
+    L.W.col4row = ip; ip += MAXX; TLK_G(ip, int);
     unsigned char *bp = (unsigned char *)ip;
-    L.W.SR = bp; bp += MAXX; L.W.SC = bp; bp += MAXX;
+    L.W.SR = bp; bp += MAXX; L.W.SC = bp; bp += MAXX; TLK_G(bp, unsigned char);
     bp = (unsigned char *)(((uintptr_t)bp + 15) & ~(uintptr_t)15);
     ip = (int *)bp;
-    L.hi_idx = ip; ip += MAXD; L.lo_idx = ip; ip += MAXD;
+    L.hi_idx = ip; ip += MAXD; TLK_G(ip, int); L.lo_idx = ip; ip += MAXD; TLK_G(ip, int);
+    // (mi_r .. um_t stay contiguous: Deep-OC-SORT overlays its pair list on them, tlk_deepocsort.hip)
     L.mi_r = ip; ip += MAXX; L.mi_c = ip; ip += MAXX; L.m_d = ip; ip += MAXX; L.m_t = ip; ip += MAXX;
-    L.um_d = ip; ip += MAXD + MAXX; L.um_t = ip; ip += MAXT + MAXX;
-    L.rowcnt = ip; ip += MAXD; L.rowhit = ip; ip += MAXD; L.colcnt = ip; ip += MAXT;
-    L.tmp_a = ip; ip += MAXX; L.tmp_b = ip; ip += MAXX;
-    L.scan = ip; ip += NWAVES; L.sc = ip; ip += 32;
+    L.um_d = ip; ip += MAXD + MAXX; L.um_t = ip; ip += MAXT + MAXX; TLK_G(ip, int);
+    L.rowcnt = ip; ip += MAXD; TLK_G(ip, int); L.rowhit = ip; ip += MAXD; TLK_G(ip, int); L.colcnt = ip; ip += MAXT; TLK_G(ip, int);
+    L.tmp_a = ip; ip += MAXX; TLK_G(ip, int); L.tmp_b = ip; ip += MAXX; TLK_G(ip, int);
+    L.scan = ip; ip += NWAVES; L.sc = ip; ip += 32; TLK_G(ip, int);
     bp = (unsigned char *)(((uintptr_t)ip + 15) & ~(uintptr_t)15);
-    L.red = (double *)bp; bp += sizeof(double) * NWAVES;
+    L.red = (double *)bp; bp += sizeof(double) * NWAVES; TLK_G(bp, unsigned char);
     bp = (unsigned char *)(((uintptr_t)bp + 15) & ~(uintptr_t)15);
     L.cost = (double *)bp;
+#undef TLK_G
 }
+
+#ifdef TLK_LDS_CANARY
+// Debug build only.  fill: after carve (all threads call; barrier inside).  check: returns the index + 1 of the first damaged guard, 0 if intact
+// (thread 0's view after a barrier).  The last guard sits after the cost area (cost_end): an over-long matrix or list shows up there.
+__device__ inline void canary_fill(Lds &L, unsigned char *cost_end)
+{
+    L.can[L.ncan++] = (unsigned *)(((uintptr_t)cost_end + 15) & ~(uintptr_t)15);      // (every thread holds its own, identical copy of L)
+    __syncthreads();
+    for (int c = threadIdx.x / CANARY_WORDS; c < L.ncan; c += BLOCK / CANARY_WORDS) L.can[c][threadIdx.x % CANARY_WORDS] = CANARY_PATTERN;
+    __syncthreads();
+}
+__device__ inline int canary_check(const Lds &L)
+{
+    __syncthreads();
+    int bad = 0;
+    for (int c = 0; c < L.ncan && !bad; ++c)
+        for (int w = 0; w < CANARY_WORDS; ++w) if (L.can[c][w] != CANARY_PATTERN) { bad = c + 1; break; }
+    return bad;
+}
+#endif
 
 // sorted-unique set difference on a small int list held in LDS (np.setdiff1d). All threads call.
 // list[0..n) -> list[0..ret) sorted ascending without members of rem[0..nrem). Uses tmp (>= n).
