@@ -638,6 +638,9 @@ int tlk_conv2d_nhwc_16(const void *x_dev, const void *x_lo_dev, const void *w_de
                        const void *res_dev, const void *res_lo_dev, void *y_dev, void *y_lo_dev, float *y_f32_dev,
                        int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int act_kind,
                        int x_pix_stride, int y_pix_stride, int res_pix_stride, void *hip_stream);
+/* Probes / tests: 0 = the register-staged kernel for every shape, 1 (default; env TLK_CONV16_GLDS) = the direct-to-LDS kernel where it applies
+ * (Cout > 64, Cin a multiple of the K step).  Results do not depend on it beyond fp32 summation order inside a 16-wide slice (none: same order). */
+int tlk_conv16_set_glds(int on);
 /* fp32 NHWC pixels (c_in channels, x_pix_stride floats apart, 0 = dense) -> (hi, lo) f16 planes with c_out >= c_in channels, zero padded. */
 int tlk_split_f32_planes(const float *x_dev, long long pixels, int c_in, int x_pix_stride, int c_out, void *hi_dev, void *lo_dev, void *hip_stream);
 /* y[i] = hi[i] + lo[i] * 2^-11 for n elements. */

@@ -308,6 +308,233 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Direct-to-LDS variant (r04b): the layers whose input-channel count is a multiple of the K step (every layer but an RGB stem).
+// `global_load_lds_dwordx4` moves 16 bytes per lane from global memory straight into LDS -- no staging registers, no ds_write pass -- but
+// its destination is wave-uniform base + lane * 16, so the LDS rows are UNPADDED (128 B) and the bank spreading comes from an XOR swizzle:
+// logical 16-byte chunk q of row i is stored at chunk position q ^ ((i >> 1) & 7).  The swizzle is applied on the SOURCE side (a lane
+// fetches the logical chunk that belongs at its position) and again when the fragments are read.  One wavefront-instruction fills 8 rows.
+// 128 x 128 tile, 4 wavefronts of 64 x 64, two LDS stages (64 KB -> two workgroups per CU in both modes, which the register-staged split
+// kernel could not have): the loads of step s + 1 are in flight while step s computes; masked lanes read a 16-byte zero page.
+template <int ACT, bool RES, int MODE, bool OUT_F32>
+__global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p, const unsigned char *__restrict__ zeros)
+{
+    constexpr int TM = 2, TN = 2, WGN = 2, NT = 256, BM = 128, BN = 128;
+    constexpr int PLANES = MODE == MODE_SPLIT ? 2 : 1;
+    constexpr int BKE = MODE == MODE_SPLIT ? 32 : 64;
+    constexpr int STAGE = (BM + BN) * ROW_BYTES;                       // 32 KB
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    long long tile;
+    {
+        const long long b = blockIdx.x, q = p.tiles >> 3;
+        const int r = (int)(p.tiles & 7), xcd = (int)(b & 7);
+        tile = (long long)xcd * q + (xcd < r ? xcd : r) + (b >> 3);
+    }
+    const long long m0 = (tile / p.tiles_n) * BM;
+    const int n0 = (int)(tile % p.tiles_n) * BN;
+
+    // ---- loader: instruction q (0..3) of this wavefront fills rows [(q * 4 + wave) * 8, + 8) of A and of B; lane = (row r8 = lane >> 3, position pc)
+    const int r8 = lane >> 3, pc = lane & 7;
+    const unsigned char *a_ptr[4][PLANES > 1 ? 1 : 1];
+    const unsigned char *a_row[4], *b_row[4];          // global address of the lane's LOGICAL chunk at tap (0, 0) / k = 0; nullptr = row masked
+    int a_hi0[4], a_wi0[4];
+    (void)a_ptr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (q * 4 + wave) * 8 + r8;
+        const int lcq = pc ^ ((row >> 1) & 7);                          // logical chunk stored at this lane's position
+        const int plane = MODE == MODE_SPLIT ? (lcq >> 2) : 0, kc = MODE == MODE_SPLIT ? (lcq & 3) : lcq;
+        const long long m = m0 + row;
+        a_row[q] = nullptr; a_hi0[q] = 0; a_wi0[q] = 0;
+        if (m < p.M) {
+            const unsigned n = (unsigned)m / (unsigned)(p.Ho * p.Wo);
+            const int rem = (int)((unsigned)m - n * (unsigned)(p.Ho * p.Wo));
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            a_hi0[q] = ho * p.stride - p.pad; a_wi0[q] = wo * p.stride - p.pad;
+            const _Float16 *base = plane ? p.x_lo : p.x;
+            a_row[q] = reinterpret_cast<const unsigned char *>(base + ((long long)n * p.H * p.W + (long long)a_hi0[q] * p.W + a_wi0[q]) * p.x_pix + kc * 8);
+        }
+        const int co = n0 + row;
+        b_row[q] = co < p.Cout ? reinterpret_cast<const unsigned char *>((plane ? p.w_lo : p.w) + (long long)co * p.K + kc * 8) : nullptr;
+    }
+    const bool no_halo = p.KH == 1 && p.KW == 1 && p.pad == 0;
+    int u_kh = 0, u_kw = 0, u_ci0 = 0, u_k0 = 0;                       // tap of the step being loaded (wave-uniform)
+    auto issue_stage = [&](int buf) {
+        const long long a_add = ((long long)(u_kh * p.W + u_kw) * p.x_pix + u_ci0) * 2, b_add = (long long)u_k0 * 2;
+        unsigned char *la = lds + buf * STAGE, *lb = la + BM * ROW_BYTES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bool ok = a_row[q] != nullptr;
+            if (!no_halo) { const int hi = a_hi0[q] + u_kh, wi = a_wi0[q] + u_kw; ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W; }
+            const unsigned char *ga = ok ? a_row[q] + a_add : zeros;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)ga,
+                                             (__attribute__((address_space(3))) void *)(la + (q * 4 + wave) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned char *gb = b_row[q] ? b_row[q] + b_add : zeros;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gb,
+                                             (__attribute__((address_space(3))) void *)(lb + (q * 4 + wave) * 1024), 16, 0, 0);
+        }
+        u_k0 += BKE; u_ci0 += BKE;
+        if (u_ci0 >= p.Cin) { u_ci0 = 0; if (++u_kw == p.KW) { u_kw = 0; ++u_kh; } }
+    };
+
+    constexpr int NACC = MODE == MODE_SPLIT ? 2 : 1;
+    f32x16 acc[NACC][TM][TN];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
+
+    // fragment addressing: lane l reads row (l & 31) (+ 32 per tile: the swizzle term (row >> 1) & 7 is the same), logical chunk 2 j + (l >> 5)
+    // (+ 4 for the lo plane), stored at that chunk XOR the row's swizzle
+    const int sw = ((lane & 31) >> 1) & 7, hsel = lane >> 5;
+    const int row_a = (wm * TM * 32 + (lane & 31)) * ROW_BYTES, row_b = BM * ROW_BYTES + (wn * TN * 32 + (lane & 31)) * ROW_BYTES;
+    constexpr int NJ = BKE / 16;
+    auto chunk_off = [&](int q) { return ((q ^ sw) << 4); };
+
+    const int steps = p.K / BKE;
+    issue_stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < steps) issue_stage(cur ^ 1);
+        const unsigned char *sa = lds + cur * STAGE + row_a, *sb = lds + cur * STAGE + row_b;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            h16x8 fa[PLANES][TM], fb[PLANES][TN];
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl) {
+                const int off = chunk_off(pl * 4 + 2 * j + hsel);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[pl][i] = *reinterpret_cast<const h16x8 *>(sa + i * 32 * ROW_BYTES + off);
+#pragma unroll
+                for (int i = 0; i < TN; ++i) fb[pl][i] = *reinterpret_cast<const h16x8 *>(sb + i * 32 * ROW_BYTES + off);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) {
+                    acc[0][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][jj], acc[0][i][jj], 0, 0, 0);
+                    if (MODE == MODE_SPLIT) {
+                        acc[NACC - 1][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[PLANES - 1][jj], acc[NACC - 1][i][jj], 0, 0, 0);
+                        acc[NACC - 1][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[PLANES - 1][i], fb[0][jj], acc[NACC - 1][i][jj], 0, 0, 0);
+                    }
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the next stage has landed (it had the whole step to do so)
+        __syncthreads();
+    }
+
+    // ---- epilogue (as conv16_mfma_kernel): fp32 tile through LDS, 8 output elements per lane
+    constexpr int LDC = BN + 4;
+    float *Cs = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj) {
+            float *c = Cs + ((wm * TM + i) * 32 + 4 * (lane >> 5)) * LDC + (wn * TN + jj) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[0][i][jj][r];
+                if (MODE == MODE_SPLIT) v = v + acc[NACC - 1][i][jj][r] * LO_INV;
+                c[((r & 3) + 8 * (r >> 2)) * LDC] = v;
+            }
+        }
+    __syncthreads();
+    constexpr int V_PER_ROW = BN / 8, NVEC = BM * V_PER_ROW, ITS = NVEC / NT;
+#pragma unroll 2
+    for (int it = 0; it < ITS; ++it) {
+        const int idx = it * NT + tid;
+        const int row = idx / V_PER_ROW, ec = (idx - row * V_PER_ROW) * 8;
+        const long long m = m0 + row;
+        const int co = n0 + ec;
+        if (m >= p.M || co >= p.Cout) continue;
+        float v[8];
+        {
+            const float4 c0 = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec), c1 = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec + 4);
+            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+            if (p.bias) { b0 = *reinterpret_cast<const float4 *>(p.bias + co); b1 = *reinterpret_cast<const float4 *>(p.bias + co + 4); }
+            v[0] = c0.x + b0.x; v[1] = c0.y + b0.y; v[2] = c0.z + b0.z; v[3] = c0.w + b0.w;
+            v[4] = c1.x + b1.x; v[5] = c1.y + b1.y; v[6] = c1.z + b1.z; v[7] = c1.w + b1.w;
+        }
+        if (RES) {
+            const h16x8 rh = *reinterpret_cast<const h16x8 *>(p.res + m * p.r_pix + co);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)rh[e];
+            if (MODE == MODE_SPLIT) {
+                const h16x8 rl = *reinterpret_cast<const h16x8 *>(p.res_lo + m * p.r_pix + co);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rl[e] * LO_INV;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = act16<ACT>(v[e]);
+        if (OUT_F32) {
+            float *o = p.y32 + m * p.y_pix + co;
+            *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else if (MODE == MODE_SPLIT) {
+            h16x8 oh, ol;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f32(v[e], h, l); oh[e] = h; ol[e] = l; }
+            *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
+            *reinterpret_cast<h16x8 *>(p.y_lo + m * p.y_pix + co) = ol;
+        } else {
+            h16x8 oh;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) oh[e] = (_Float16)v[e];
+            *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
+        }
+    }
+}
+
+const unsigned char *zero_page()
+{
+    static unsigned char *z[16] = {nullptr};          // per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!z[dev]) {
+        if (hipMalloc((void **)&z[dev], 256) != hipSuccess) return nullptr;
+        if (hipMemset(z[dev], 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { hipFree(z[dev]); z[dev] = nullptr; return nullptr; }
+    }
+    return z[dev];
+}
+
+int g_glds = -1;          // -1: read TLK_CONV16_GLDS once (default on); tlk_conv16_set_glds for A/B runs in one process
+
+template <int MODE, bool OUT_F32> int launch16_glds(Conv16Args &a, int act, hipStream_t st)
+{
+    constexpr size_t LDS_STAGE = (size_t)2 * 256 * ROW_BYTES, LDS_C = (size_t)128 * 132 * sizeof(float);
+    constexpr size_t LDS_BYTES = LDS_STAGE > LDS_C ? LDS_STAGE : LDS_C;
+    const unsigned char *z = zero_page();
+    if (!z) return fail(TLK_EHIP, "tlk_conv2d_nhwc_16: cannot allocate the zero page");
+    a.tiles_n = (a.Cout + 127) / 128;
+    a.tiles = ((a.M + 127) / 128) * a.tiles_n;
+    if (a.tiles > 0x7fffffffLL || a.M > 0x7fffffffLL) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: more than 2^31 - 1 output pixels in one launch");
+    const bool res = a.res != nullptr;
+#define TLK_G16_LAUNCH(A, R)                                                                                                               \
+    do {                                                                                                                                   \
+        auto kern = conv16_glds_kernel<A, R, MODE, OUT_F32>;                                                                               \
+        static bool attr_set = false;                                                                                                      \
+        if (!attr_set) { TLK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES)); attr_set = true; } \
+        hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles), dim3(256), LDS_BYTES, st, a, z);                                                 \
+    } while (0)
+    if (res) { if (act == 0) TLK_G16_LAUNCH(ACT_NONE, true); else if (act == 1) TLK_G16_LAUNCH(ACT_RELU, true); else TLK_G16_LAUNCH(ACT_SILU, true); }
+    else { if (act == 0) TLK_G16_LAUNCH(ACT_NONE, false); else if (act == 1) TLK_G16_LAUNCH(ACT_RELU, false); else TLK_G16_LAUNCH(ACT_SILU, false); }
+#undef TLK_G16_LAUNCH
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
+
 template <int TM, int TN, int WGM, int WGN, int MODE, bool OUT_F32> int launch16(Conv16Args &a, int act, hipStream_t st)
 {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, NT = 64 * WGM * WGN;
@@ -337,6 +564,8 @@ template <int TM, int TN, int WGM, int WGN, int MODE, bool OUT_F32> int launch16
 // uses four of 64 x 64 (two workgroups per CU).
 template <int MODE, bool OUT_F32> int dispatch16(Conv16Args &a, int act, hipStream_t st)
 {
+    if (g_glds < 0) { const char *e = getenv("TLK_CONV16_GLDS"); g_glds = e ? atoi(e) : 1; }
+    if (g_glds && a.Cout > 64 && a.Cin % (MODE == MODE_SPLIT ? 32 : 64) == 0) return launch16_glds<MODE, OUT_F32>(a, act, st);
     if (MODE == MODE_SPLIT) {
         if (a.Cout > 64) return launch16<1, 2, 4, 2, MODE, OUT_F32>(a, act, st);         // 128 x 128, 8 wavefronts
         return launch16<1, 2, 4, 1, MODE, OUT_F32>(a, act, st);                          // 128 x 64, 4 wavefronts
@@ -401,6 +630,8 @@ extern "C" int tlk_conv2d_nhwc_16(const void *x_dev, const void *x_lo_dev, const
     if (split) return out32 ? dispatch16<MODE_SPLIT, true>(a, act_kind, st) : dispatch16<MODE_SPLIT, false>(a, act_kind, st);
     return out32 ? dispatch16<MODE_F16, true>(a, act_kind, st) : dispatch16<MODE_F16, false>(a, act_kind, st);
 }
+
+extern "C" int tlk_conv16_set_glds(int on) { g_glds = on ? 1 : 0; return TLK_OK; }
 
 extern "C" int tlk_split_f32_planes(const float *x_dev, long long pixels, int c_in, int x_pix_stride, int c_out, void *hi_dev, void *lo_dev, void *hip_stream)
 {
