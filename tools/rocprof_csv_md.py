@@ -23,6 +23,22 @@ if conv:
     c_ns = sum(float(r["TotalDurationNs"]) for r in conv)
     out += [f"**conv_f32_mfma_kernel, all template instantiations together: {c_calls} calls, {c_ns / 1e6:.2f} ms, average {c_ns / c_calls / 1e3:.2f} us, "
             f"{100 * c_ns / tot:.2f} % of the GPU time** (includes the warm-up, parity and roofline passes of the command, whose launches are the same)", ""]
+if len(sys.argv) > 4 and d["roofline"].get("per_instantiation"):
+    out += ["Per instantiation, HIP events of the bench line (its roofline pass) beside rocprofv3's average over the whole command -- the ReLU / linear",
+            "instantiations (5th template argument 1 / 0) are launched by the ReID network only, with the same mix of layers in every step, so the two",
+            "averages are over the same set of shapes; the SiLU ones (2) also run in the detector's extra graph captures, whose small launches pull",
+            "rocprofv3's average down:", "",
+            "| instantiation | launches / step | bench: avg ms (events) | bench: TFLOP/s | rocprofv3: calls | rocprofv3: avg ms | events / rocprofv3 |", "|---|---|---|---|---|---|---|"]
+    for e in d["roofline"]["per_instantiation"]:
+        key = e["kernel"].replace("conv_f32_mfma_kernel", "")
+        match = [r for r in rows if "conv_f32_mfma_kernel" + key in r["Name"]]
+        if match:
+            r = match[0]
+            ravg = float(r["AverageNs"]) / 1e6
+            out.append(f"| `{e['kernel']}` | {e['launches_per_step']} | {e['avg_launch_ms']:.4f} | {e['tflops']:.1f} | {r['Calls']} | {ravg:.4f} | {e['avg_launch_ms'] / ravg:.3f} |")
+        else:
+            out.append(f"| `{e['kernel']}` | {e['launches_per_step']} | {e['avg_launch_ms']:.4f} | {e['tflops']:.1f} | - | - | - |")
+    out.append("")
 out += ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
 for r in rows[:45]:
     n = r["Name"]
