@@ -7,7 +7,7 @@ OUT="$R/gpurun_out/round4"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$R"
 python bench.py --steps 20 --warmup 5 > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-for wl in config2 config4 config5 config3h config3s config3b config3d config2b config1; do
+for wl in config2 config4 config5 config3h config1; do
   python bench.py --workload $wl --steps 6 --warmup 2 --no-cpu-baseline --no-latency-leg --no-f32-leg --no-live-traffic --check-frames 96 > "$OUT/bench_$wl.json" 2> "$OUT/bench_$wl.err"
 done
 python bench.py --workload config2 --dtype f16 --steps 20 --warmup 5 --no-cpu-baseline --no-latency-leg --no-f32-leg --no-live-traffic --check-frames 96 > "$OUT/bench_config2_f16.json" 2> "$OUT/bench_config2_f16.err"
