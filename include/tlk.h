@@ -646,6 +646,27 @@ int tlk_split_f32_planes(const float *x_dev, long long pixels, int c_in, int x_p
 /* y[i] = hi[i] + lo[i] * 2^-11 for n elements. */
 int tlk_merge_planes_f32(const void *hi_dev, const void *lo_dev, long long n, float *y_dev, void *hip_stream);
 
+/* Depthwise k x k convolution (k = 3 or 5, stride 1, pad k/2) of a channels-last activation with bias + activation inside -- the depthwise
+ * halves of RTMPose's CSPNeXt blocks (mmdet DepthwiseSeparableConvModule; the reference runs the network in ONNXRuntime behind
+ * tracklab/wrappers/pose_estimator/rtmlib_api.py:21-36, configs/modules/pose_estimator/rtmpose_rtmlib.yaml):
+ *   y[n,oy,ox,ch] = act( sum_{ky,kx} x[n, oy+ky-k/2, ox+kx-k/2, ch] * w[ky,kx,ch] + bias[ch] )
+ * x, y (n,h,w,c) NHWC of `dtype` (TLK_F32 or TLK_F16), w (k,k,c) of `dtype` (torch's (c,1,k,k) weight permuted to taps-major), bias fp32 or
+ * NULL, c a multiple of 16 bytes of elements, x / w / y 16-byte aligned, pixel strides in elements (0 = dense; a call may read or write a
+ * channel slice of a wider tensor).  fp32 accumulation for both types; each output element is ONE fmaf chain over ky then kx ascending
+ * (rows outside the image skipped, columns outside as zero terms): bit-identical to oracle/src/conv.c orc_dwconv2d_nhwc_f32 in fp32.
+ * HBM-bound: every input element read once from HBM, every output written once (tlk_dwconv.hip). */
+int tlk_dwconv2d_nhwc(const void *x_dev, const void *w_dev, const float *bias_dev, void *y_dev, int n, int h, int w, int c, int k,
+                      int act_kind, int dtype, int x_pix_stride, int y_pix_stride, void *hip_stream);
+
+/* The pooling half of an SPPBottleneck (YOLOX CSPDarknet / RTMPose CSPNeXt; kernel sizes 5, 9, 13, stride 1, -inf padding; the reference runs
+ * both networks in ONNXRuntime behind tracklab/wrappers/bbox_detector/rtmlib_api.py:21 and wrappers/pose_estimator/rtmlib_api.py:21):
+ *   y[n,y,x, 0:c] = x,  y[.., c:2c] = max over the 5 x 5 window,  y[.., 2c:3c] = 9 x 9,  y[.., 3c:4c] = 13 x 13
+ * x (n,h,w,c) and y (n,h,w,4c) NHWC of `dtype` (TLK_F32 or TLK_F16), c a multiple of 16 bytes of elements, 16-byte aligned, pixel strides in
+ * elements (0 = dense).  One pass: the map is read once and the concatenation written once (tlk_spp.hip); max is exact, the result equals
+ * torch's max_pool2d + cat bit for bit on NaN-free input (oracle/src/conv.c orc_spp_maxpool_nhwc_f32). */
+int tlk_spp_maxpool_nhwc(const void *x_dev, void *y_dev, int n, int h, int w, int c, int dtype, int x_pix_stride, int y_pix_stride,
+                         void *hip_stream);
+
 /* 1x1 convolution of a channels-last tensor as ONE GEMM with the convolution epilogue inside:
  *   out[M,N] = act(x[M,K] . w[N,K]^T + bias[N] (+ residual[M,N])),  act 0 none / 1 ReLU / 2 SiLU, dtype TLK_F16 or TLK_BF16.
  * hipBLASLt (library GEMM, taken from the process with dlopen) with its BIAS / RELU_BIAS / SWISH_BIAS epilogue and beta*C for

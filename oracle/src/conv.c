@@ -47,3 +47,58 @@ void orc_conv2d_nhwc_f32(const float *x, const float *w, const float *bias, cons
                 }
             }
 }
+
+/* The depthwise halves of RTMPose's CSPNeXt blocks (mmdet DepthwiseSeparableConvModule, run by the reference inside ONNXRuntime behind
+ * tracklab/wrappers/pose_estimator/rtmlib_api.py:21-36): y[n,oy,ox,c] = act( sum_{ky,kx} x[n, oy+ky-k/2, ox+kx-k/2, c] * w[ky,kx,c] + bias[c] ).
+ * Summation contract of tlk_dwconv2d_nhwc (tlk_dwconv.hip): one fmaf chain per output element, ky ascending then kx ascending; a row outside
+ * the image contributes nothing, a column outside the image enters as a zero term.  Parity with the reference: tolerance against torch's
+ * own depthwise convolution in the tests (no reference summation order exists). */
+void orc_dwconv2d_nhwc_f32(const float *x, const float *w, const float *bias, float *y, int n, int h, int wd, int c, int k, int act)
+{
+    const int pad = k / 2;
+    for (int in = 0; in < n; ++in)
+        for (int oy = 0; oy < h; ++oy)
+            for (int ox = 0; ox < wd; ++ox)
+                for (int ch = 0; ch < c; ++ch) {
+                    float acc = 0.f;
+                    for (int ky = 0; ky < k; ++ky) {
+                        const int iy = oy + ky - pad;
+                        if (iy < 0 || iy >= h) continue;
+                        for (int kx = 0; kx < k; ++kx) {
+                            const int ix = ox + kx - pad;
+                            const float a = (ix >= 0 && ix < wd) ? x[(((size_t)in * h + iy) * wd + ix) * c + ch] : 0.f;
+                            acc = fmaf(a, w[((size_t)ky * k + kx) * c + ch], acc);
+                        }
+                    }
+                    float v = acc + (bias ? bias[ch] : 0.f);
+                    if (act == 1) v = v > 0.f ? v : 0.f;
+                    else if (act == 2) v = v / (1.f + expf(-v));
+                    y[(((size_t)in * h + oy) * wd + ox) * c + ch] = v;
+                }
+}
+
+/* The pooling half of an SPPBottleneck (YOLOX CSPDarknet / RTMPose CSPNeXt, inside ONNXRuntime in the reference: wrappers/bbox_detector/
+ * rtmlib_api.py:21, wrappers/pose_estimator/rtmlib_api.py:21): y (n,h,w,4c) = [x | max 5x5 | max 9x9 | max 13x13], stride 1, windows clipped at
+ * the border (-inf padding).  Checker of tlk_spp_maxpool_nhwc; max is exact, so this equals torch's max_pool2d + cat bit for bit. */
+void orc_spp_maxpool_nhwc_f32(const float *x, float *y, int n, int h, int wd, int c)
+{
+    static const int rad[3] = {2, 4, 6};
+    for (int in = 0; in < n; ++in)
+        for (int oy = 0; oy < h; ++oy)
+            for (int ox = 0; ox < wd; ++ox) {
+                float *yo = y + (((size_t)in * h + oy) * wd + ox) * 4 * c;
+                for (int ch = 0; ch < c; ++ch) {
+                    yo[ch] = x[(((size_t)in * h + oy) * wd + ox) * c + ch];
+                    for (int r = 0; r < 3; ++r) {
+                        float m = -INFINITY;
+                        for (int iy = oy - rad[r]; iy <= oy + rad[r]; ++iy)
+                            for (int ix = ox - rad[r]; ix <= ox + rad[r]; ++ix)
+                                if (iy >= 0 && iy < h && ix >= 0 && ix < wd) {
+                                    const float v = x[(((size_t)in * h + iy) * wd + ix) * c + ch];
+                                    if (v > m) m = v;
+                                }
+                        yo[(r + 1) * c + ch] = m;
+                    }
+                }
+            }
+}

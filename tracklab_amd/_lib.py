@@ -1016,6 +1016,43 @@ def _pix16(t, c, h, w):
     return pix
 
 
+def dwconv2d_nhwc(x, weight_kkc, bias32=None, act=None, out=None):
+    """Depthwise k x k convolution (stride 1, pad k // 2) + bias + activation in ONE hand-written kernel (tlk_dwconv2d_nhwc).
+    x: (N, C, H, W) float32 / float16 cuda tensor in channels_last memory (or a channel slice of one); weight_kkc: (k, k, C) contiguous, the
+    dtype of x (torch's (C, 1, k, k) depthwise weight as `w.permute(2, 3, 0, 1).reshape(k, k, C)`); bias32: (C,) float32 or None."""
+    import torch
+    L = lib()
+    if not getattr(L, "_dwconv_bound", False):
+        L.tlk_dwconv2d_nhwc.argtypes = [C.c_void_p] * 4 + [C.c_int] * 9 + [C.c_void_p]
+        L._dwconv_bound = True
+    N, Cc, H, W = x.shape
+    k = weight_kkc.shape[0]
+    assert weight_kkc.shape == (k, k, Cc) and weight_kkc.is_contiguous() and weight_kkc.dtype == x.dtype
+    assert x.dtype in (torch.float32, torch.float16) and (bias32 is None or (bias32.dtype == torch.float32 and bias32.is_contiguous()))
+    if out is None:
+        out = torch.empty((N, Cc, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    check(L.tlk_dwconv2d_nhwc(x.data_ptr(), weight_kkc.data_ptr(), bias32.data_ptr() if bias32 is not None else None, out.data_ptr(),
+                              N, H, W, Cc, k, ACT[act], _dtype_code(x.dtype), _pix16(x, Cc, H, W), _pix16(out, Cc, H, W), current_stream_ptr()))
+    return out
+
+
+def spp_maxpool_nhwc(x, out=None):
+    """[x | maxpool5(x) | maxpool9(x) | maxpool13(x)] (stride 1, same size) along the channels in ONE pass (tlk_spp_maxpool_nhwc).
+    x: (N, C, H, W) float32 / float16 cuda tensor in channels_last memory (or a channel slice of one) -> (N, 4C, H, W) channels_last."""
+    import torch
+    L = lib()
+    if not getattr(L, "_spp_bound", False):
+        L.tlk_spp_maxpool_nhwc.argtypes = [C.c_void_p] * 2 + [C.c_int] * 7 + [C.c_void_p]
+        L._spp_bound = True
+    N, Cc, H, W = x.shape
+    assert x.dtype in (torch.float32, torch.float16)
+    if out is None:
+        out = torch.empty((N, 4 * Cc, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    check(L.tlk_spp_maxpool_nhwc(x.data_ptr(), out.data_ptr(), N, H, W, Cc, _dtype_code(x.dtype), _pix16(x, Cc, H, W), _pix16(out, 4 * Cc, H, W),
+                                 current_stream_ptr()))
+    return out
+
+
 def _bind_conv16(L):
     if not getattr(L, "_conv16_bound", False):
         L.tlk_conv2d_nhwc_16.argtypes = [C.c_void_p] * 10 + [C.c_int] * 13 + [C.c_void_p]

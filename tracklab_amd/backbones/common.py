@@ -40,6 +40,20 @@ def epilogue_(x: torch.Tensor, bias: torch.Tensor, act: str | None, residual: to
     return y
 
 
+# the pooling half of an SPPBottleneck (5 / 9 / 13 max pools + concatenation) as ONE libtlk pass (tlk_spp_maxpool_nhwc); TLK_SPP=0 restores
+# the library route (three max_pool2d launches + cat) for A/B runs
+USE_TLK_SPP = _os.environ.get("TLK_SPP", "1") != "0"
+
+
+def spp_concat(x: torch.Tensor, ks=(5, 9, 13)) -> torch.Tensor:
+    """[x | maxpool_k(x) for k in ks] along the channels (stride 1, same size): what the second 1 x 1 convolution of an SPPBottleneck reads"""
+    if USE_TLK_SPP and tuple(ks) == (5, 9, 13) and x.is_cuda and x.dtype in (torch.float16, torch.float32) \
+            and x.shape[1] % (8 if x.dtype == torch.float16 else 4) == 0 and x.is_contiguous(memory_format=torch.channels_last):
+        from .. import _lib
+        return _lib.spp_maxpool_nhwc(x)
+    return torch.cat([x] + [F.max_pool2d(x, k, 1, k // 2) for k in ks], 1)
+
+
 class SplitAct:
     """An fp32 activation travelling as two float16 planes: value = hi + lo * 2**-11 (relative 2**-22), both (N, C, H, W) channels_last.
     What the split-precision convolutions (tlk_conv2d_nhwc_16, split mode: three f16 MFMAs per product pair, fp32 accumulation) read and

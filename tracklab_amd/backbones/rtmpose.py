@@ -14,7 +14,14 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .common import ConvBiasAct, epilogue_, finalize, random_init_
+import os as _os
+
+from .common import ConvBiasAct, epilogue_, finalize, random_init_, spp_concat
+
+# depthwise 5 x 5 (+ bias + SiLU) on libtlk's hand-written kernel (tlk_dwconv2d_nhwc); TLK_DWCONV=0 restores the library route for A/B runs
+USE_TLK_DWCONV = _os.environ.get("TLK_DWCONV", "1") != "0"
+# the 7 x 7 keypoint-map convolution on the 8 x 6 map as one dense GEMM (RTMPoseNet._final_maps); TLK_POSE_FINAL_GEMM=0 = the convolution
+USE_FINAL_GEMM = _os.environ.get("TLK_POSE_FINAL_GEMM", "1") != "0"
 
 
 class DWConvBiasAct(nn.Module):
@@ -26,7 +33,24 @@ class DWConvBiasAct(nn.Module):
         self.dw_bias = nn.Parameter(torch.zeros(cin))
         self.pw = ConvBiasAct(cin, cout, 1, 1, "silu")
 
+    def _taps(self):
+        """(k, k, C) taps-major weight + fp32 bias for libtlk's depthwise kernel; cached per device / dtype"""
+        c = getattr(self, "_dw_taps", None)
+        w = self.dw.weight
+        if c is None or c[0].device != w.device or c[0].dtype != w.dtype:
+            k = w.shape[-1]
+            c = (w.detach().permute(2, 3, 0, 1).reshape(k, k, w.shape[0]).contiguous(), self.dw_bias.detach().float().contiguous())
+            self._dw_taps = c
+        return c
+
     def forward(self, x, residual=None):
+        if USE_TLK_DWCONV and x.is_cuda and x.dtype in (torch.float16, torch.float32) and x.is_contiguous(memory_format=torch.channels_last) \
+                and x.shape[1] % (8 if x.dtype == torch.float16 else 4) == 0:
+            # ONE launch of libtlk's depthwise kernel (bias + SiLU inside, every byte moved once) instead of MIOpen's grouped convolution +
+            # an epilogue pass: 33 of the 76 ms of the f16 pose forward of config 4 were spent in those two
+            from .. import _lib
+            wk, b32 = self._taps()
+            return self.pw(_lib.dwconv2d_nhwc(x, wk, b32, "silu"), residual)
         return self.pw(epilogue_(self.dw(x), self.dw_bias, "silu"), residual)
 
 
@@ -78,7 +102,7 @@ class SPPBottleneck(nn.Module):
 
     def forward(self, x):
         x = self.conv1(x)
-        return self.conv2(torch.cat([x] + [F.max_pool2d(x, k, 1, k // 2) for k in self.ks], 1))
+        return self.conv2(spp_concat(x, self.ks))
 
 
 class ScaleNorm(nn.Module):
@@ -139,10 +163,32 @@ class RTMPoseNet(nn.Module):
         self.cls_x = nn.Linear(256, int(input_hw[1] * simcc_split), bias=False)
         self.cls_y = nn.Linear(256, int(input_hw[0] * simcc_split), bias=False)
 
+    def _final_maps(self, f):
+        """final_layer (7 x 7 convolution, 768 -> 17 keypoint maps) on the 8 x 6 map, flattened to (N, K, 48).  A 7 x 7 window on an 8 x 6 map
+        covers nearly all of it, so on the GPU the convolution is ONE dense GEMM of the flattened NHWC map (N, 48 * 768) with the Toeplitz form
+        of the weight (K * 48, 48 * 768; zeros where a tap falls outside the map) -- the same multiply-adds, handed to hipBLASLt instead of a
+        17-output-channel convolution (1.3 ms of the f16 pose forward of config 4); the output rows are (k, y, x): already the layout wanted."""
+        if not (USE_FINAL_GEMM and f.is_cuda and f.is_contiguous(memory_format=torch.channels_last)):
+            return self.final_layer(f).flatten(2)
+        n, c, h, w = f.shape
+        cache = getattr(self, "_final_gemm", None)
+        wt = self.final_layer.weight
+        if cache is None or cache[0].device != wt.device or cache[0].dtype != wt.dtype or cache[2] != (h, w):
+            k, _, kh, kw = wt.shape
+            big = torch.zeros(k, h, w, h, w, c, device=wt.device, dtype=wt.dtype)        # [k, y, x, y', x', c]
+            for y in range(h):
+                for x in range(w):
+                    y0, y1 = max(0, y - kh // 2), min(h, y + kh // 2 + 1)
+                    x0, x1 = max(0, x - kw // 2), min(w, x + kw // 2 + 1)
+                    big[:, y, x, y0:y1, x0:x1, :] = wt[:, :, y0 - y + kh // 2:y1 - y + kh // 2, x0 - x + kw // 2:x1 - x + kw // 2].permute(0, 2, 3, 1)
+            cache = (big.reshape(k * h * w, h * w * c).contiguous(), self.final_layer.bias.detach().repeat_interleave(h * w).contiguous(), (h, w))
+            self._final_gemm = cache
+        return F.linear(f.permute(0, 2, 3, 1).reshape(n, h * w * c), cache[0], cache[1]).view(n, self.K, h * w)
+
     def forward(self, x):
         """x (N, 3, 256, 192) normalised crops -> (simcc_x (N, K, 384), simcc_y (N, K, 512)) float32."""
         f = self.stages(self.stem(x))
-        t = self.final_layer(f).flatten(2)                       # (N, K, 48)
+        t = self._final_maps(f)                                  # (N, K, 48)
         t = self.gau(self.mlp(t))
         return self.cls_x(t).float().contiguous(), self.cls_y(t).float().contiguous()
 

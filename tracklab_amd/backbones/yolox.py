@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from .common import ConvBiasAct as Conv
-from .common import finalize, random_init_
+from .common import finalize, random_init_, spp_concat
 
 SIZES = {"tiny": (0.33, 0.375), "s": (0.33, 0.50), "m": (0.67, 0.75), "l": (1.0, 1.0), "x": (1.33, 1.25)}
 
@@ -51,12 +51,12 @@ class SPPBottleneck(nn.Module):
         super().__init__()
         hidden = cin // 2
         self.conv1 = Conv(cin, hidden, 1)
-        self.m = nn.ModuleList([nn.MaxPool2d(k, 1, k // 2) for k in ks])
+        self.ks = tuple(ks)
         self.conv2 = Conv(hidden * (len(ks) + 1), cout, 1)
 
     def forward(self, x):
         x = self.conv1(x)
-        return self.conv2(torch.cat([x] + [m(x) for m in self.m], dim=1))
+        return self.conv2(spp_concat(x, self.ks))
 
 
 class Focus(nn.Module):

@@ -1,0 +1,101 @@
+// tlk_spp.hip -- the spatial-pyramid-pooling block of YOLOX's CSPDarknet and RTMPose's CSPNeXt (SPPBottleneck, kernel sizes 5 / 9 / 13, stride
+// 1, "same" padding with -inf): ONE pass that reads the activation once and writes the concatenation [x | max5 | max9 | max13] the following
+// 1 x 1 convolution consumes.  The reference runs both networks inside ONNXRuntime (tracklab/wrappers/bbox_detector/rtmlib_api.py:21,
+// wrappers/pose_estimator/rtmlib_api.py:21); the library route here was three max-pool launches + a concatenation copy (3.9 of the 45 ms of
+// the config-4 pose forward on 8 x 6 maps).
+//
+// HBM-bound: algorithmic bytes = 1 read + 4 writes of the map.  One lane owns 16 bytes of channels of one pixel; lanes are laid out
+// (pixel, channel group) with the channel group fastest, so loads and stores are contiguous NHWC runs; the 13 x 13 window is walked once
+// (neighbours re-read the same lines from L1), rows / columns that no lane of the wavefront needs are skipped.  max is exact in every
+// precision, so the result is bit-identical to any other evaluation order (inputs must be NaN-free: the hardware max returns the number).
+#include "tlk_common.hpp"
+
+using namespace tlk;
+
+namespace {
+
+struct SppArgs {
+    const void *x;
+    void *y;
+    int N, H, W, C, CG;
+    int x_pix, y_pix;            // elements between two pixels of x / y (y_pix >= 4 * C)
+    long long items;             // N * H * W * CG
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename V> __device__ __forceinline__ V vmax(V a, V b) { return __builtin_elementwise_max(a, b); }
+
+template <typename T, typename V, int VN>
+__global__ void __launch_bounds__(256) spp_kernel(const SppArgs p)
+{
+    const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = item < p.items;
+    const long long it = live ? item : p.items - 1;
+    const int cg = (int)(it % p.CG);
+    long long t = it / p.CG;
+    const int x = (int)(t % p.W);
+    t /= p.W;
+    const int y = (int)(t % p.H);
+    const long long n = t / p.H;
+    const T *xb = (const T *)p.x + (n * p.H * p.W) * p.x_pix + cg * VN;
+    V ninf;
+#pragma unroll
+    for (int c = 0; c < VN; ++c) ninf[c] = (T)(-__builtin_inff());
+    V m5 = ninf, m9 = ninf, m13 = ninf, ctr = ninf;
+#pragma unroll
+    for (int dy = -6; dy <= 6; ++dy) {
+        const int iy = y + dy;
+        const bool rowok = live && (unsigned)iy < (unsigned)p.H;
+        if (__builtin_amdgcn_ballot_w64(rowok) == 0) continue;
+        V h5 = ninf, h9 = ninf, h13 = ninf;
+#pragma unroll
+        for (int dx = -6; dx <= 6; ++dx) {
+            const int ix = x + dx;
+            const bool ok = rowok && (unsigned)ix < (unsigned)p.W;
+            if (__builtin_amdgcn_ballot_w64(ok) == 0) continue;
+            V v = ninf;
+            if (ok) v = *(const V *)(xb + ((long long)iy * p.W + ix) * p.x_pix);
+            h13 = vmax(h13, v);
+            if (dx >= -4 && dx <= 4) h9 = vmax(h9, v);
+            if (dx >= -2 && dx <= 2) h5 = vmax(h5, v);
+            if (dx == 0 && dy == 0) ctr = v;
+        }
+        m13 = vmax(m13, h13);
+        if (dy >= -4 && dy <= 4) m9 = vmax(m9, h9);
+        if (dy >= -2 && dy <= 2) m5 = vmax(m5, h5);
+    }
+    if (!live) return;
+    T *yo = (T *)p.y + ((n * p.H + y) * p.W + x) * p.y_pix + cg * VN;
+    *(V *)(yo) = ctr;
+    *(V *)(yo + p.C) = m5;
+    *(V *)(yo + 2 * p.C) = m9;
+    *(V *)(yo + 3 * p.C) = m13;
+}
+
+}  // namespace
+
+extern "C" int tlk_spp_maxpool_nhwc(const void *x_dev, void *y_dev, int n, int h, int w, int c, int dtype, int x_pix_stride, int y_pix_stride,
+                                    void *hip_stream)
+{
+    if (!x_dev || !y_dev) return fail(TLK_EINVAL, "tlk_spp_maxpool_nhwc: null pointer");
+    if (dtype != TLK_F32 && dtype != TLK_F16) return fail(TLK_EINVAL, "tlk_spp_maxpool_nhwc: dtype must be TLK_F32 or TLK_F16");
+    const int v = dtype == TLK_F16 ? 8 : 4;
+    if (n < 0 || h <= 0 || w <= 0 || c <= 0 || c % v != 0) return fail(TLK_EINVAL, "tlk_spp_maxpool_nhwc: channels must be a positive multiple of 16 bytes");
+    const int xp = x_pix_stride ? x_pix_stride : c, yp = y_pix_stride ? y_pix_stride : 4 * c;
+    if (xp < c || yp < 4 * c || xp % v != 0 || yp % v != 0)
+        return fail(TLK_EINVAL, "tlk_spp_maxpool_nhwc: pixel strides must be >= channels (x) / 4 * channels (y) and multiples of 16 bytes");
+    if (((uintptr_t)x_dev | (uintptr_t)y_dev) & 15) return fail(TLK_EINVAL, "tlk_spp_maxpool_nhwc: x, y must be 16-byte aligned");
+    if (n == 0) return TLK_OK;
+    SppArgs a;
+    a.x = x_dev; a.y = y_dev; a.N = n; a.H = h; a.W = w; a.C = c; a.CG = c / v; a.x_pix = xp; a.y_pix = yp;
+    a.items = (long long)n * h * w * a.CG;
+    const long long blocks = (a.items + 255) / 256;
+    if (blocks > 0x7fffffffLL) return fail(TLK_EINVAL, "tlk_spp_maxpool_nhwc: more than 2^31 - 1 workgroups");
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (dtype == TLK_F16) hipLaunchKernelGGL((spp_kernel<_Float16, f16x8, 8>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((spp_kernel<float, f32x4, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
