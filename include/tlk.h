@@ -250,7 +250,8 @@ int tlk_bpbss_get_tracks(tlk_bpbss *h, int stream, int64_t *ids, double *mean, d
  * :171-217) and KalmanFilter (byte_track/kalman_filter.py:55-270). Hyper-parameter names =
  * configs/modules/track/byte_track.yaml `hyperparams` (+ the wrapper's min_confidence, byte_track_api.py:58).
  * The id counter (class-level BaseTrack._count in the reference) is per stream and restarts at 1 on reset.
- * max_tracks (live = tracked + lost) + max_dets <= 512.
+ * max_tracks <= 16384 (tracked + lost), max_dets <= 1024: allocation sizes -- the per-frame lists and the assignment problem sit in LDS
+ * while tracked + lost + detections <= 384 (128 detections), in HBM beyond (the reference's lists simply grow).
  * ------------------------------------------------------------------------------------------ */
 typedef struct tlk_bytetrack_params {
     double track_thresh, match_thresh, frame_rate;
@@ -293,7 +294,8 @@ int tlk_bytetrack_get_tracks(tlk_bytetrack *h, int stream, int which, int64_t *i
  * second round, update_emb, births / deaths and the output rows.
  * Hyper-parameter names = configs/modules/track/deep_oc_sort.yaml `hyperparams` (+ the wrapper's min_confidence,
  * deep_oc_sort_api.py:62). cmc_off must be 1 (cmc.py is cv2), embedding_off and new_kf_off must be 0:
- * tlk_deepocsort_create answers TLK_EUNSUPPORTED otherwise. delta_t < 8, max_tracks <= 512, max_dets <= 256.
+ * tlk_deepocsort_create answers TLK_EUNSUPPORTED otherwise. delta_t < 8.
+ * max_tracks <= 16384, max_dets <= 1024: allocation sizes -- per-frame lists in LDS while tracks + detections <= 512 (256 detections), HBM beyond.
  * ------------------------------------------------------------------------------------------ */
 typedef struct tlk_deepocsort_params {
     double det_thresh, iou_threshold, inertia, w_association_emb, alpha_fixed_emb, aw_param;
@@ -339,7 +341,8 @@ int tlk_deepocsort_get_profile(tlk_deepocsort *h, int stream, long long *cycles1
  * Hyper-parameter names = configs/modules/track/bot_sort.yaml `hyperparams` (+ the wrapper's min_confidence,
  * bot_sort_api.py:62). cmc_method must be 0 ("none", gmc.py:75-78): the other estimators are cv2 (out of scope) and
  * tlk_botsort_create answers TLK_EUNSUPPORTED for them. A track may collect at most 16 distinct classes (cls_hist).
- * max_tracks (live = tracked + lost) + max_dets <= 512; dim % 4 == 0.
+ * max_tracks <= 16384 (tracked + lost), max_dets <= 1024: allocation sizes -- the per-frame lists and the assignment problem sit in LDS
+ * while tracked + lost + detections <= 384 (128 detections), in HBM beyond (the reference's lists simply grow). dim % 4 == 0.
  * ------------------------------------------------------------------------------------------ */
 typedef struct tlk_botsort_params {
     double track_high_thresh, new_track_thresh, match_thresh, proximity_thresh, appearance_thresh, frame_rate, lambda_;
@@ -396,6 +399,8 @@ int tlk_botsort_get_tracks(tlk_botsort *h, int stream, int which, int64_t *ids, 
  * reference's budget=None: every sample is kept, with room for `rows` per track -- outgrowing it is TLK_ECAPACITY, never a dropped sample
  * (288 GB of HBM: 256 tracks x 8192 rows x 512 floats = 4.3 GB per stream). ECC (cfg.ecc, sort/track.py:130-239): tlk_ecc_* estimates the
  * warp, tlk_ssort_camera_update applies it.
+ * max_tracks <= 16384, max_dets <= 1024: allocation sizes (gallery = max_tracks x |nn_budget| x dim floats per stream) -- per-frame lists and
+ * the Hungarian work area in LDS while tracks + detections <= 1024 (256 detections), HBM beyond (the reference's track list grows).
  * ------------------------------------------------------------------------------------------ */
 typedef struct tlk_ssort_params {
     double max_dist, max_iou_dist;      /* strong_sort.py:24-25 */

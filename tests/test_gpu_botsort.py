@@ -98,7 +98,7 @@ def test_botsort_bank_batched_frames_and_reset():
 def test_botsort_rejects_bad_configuration():
     from tracklab_amd._lib import BoTSORTBank, TlkError
     with pytest.raises(TlkError):
-        BoTSORTBank(64, max_tracks=400, max_dets=200)
+        BoTSORTBank(64, max_tracks=20000)           # capacity is an allocation size up to 16384 tracks / 1024 detections per stream
     b = BoTSORTBank(64, cmc_method="sparseOptFlow")            # the reference's default: accepted, but every update must bring the frame's warp
     with pytest.raises(TlkError):
         b.update(np.zeros((1, 7)), np.zeros((1, 64), np.float32))
@@ -107,3 +107,32 @@ def test_botsort_rejects_bad_configuration():
     b = BoTSORTBank(32, max_dets=8)
     with pytest.raises(TlkError):
         b.update(np.zeros((9, 7)), np.zeros((9, 32), np.float32))
+
+
+def test_botsort_600_tracks_300_detections(orc):
+    """Capacity is an allocation size (r04; the reference's lists grow, bot_sort.py:279-440): 300-object scenes shown in turn with a long track
+    buffer leave over 600 tracked + lost tracks and 300 detections per frame -- past both LDS tiers -- rows, lists, Kalman state and
+    features equal the oracle every frame; a small scene afterwards runs in the LDS tier again."""
+    from tracklab_amd.synth import SyntheticStream
+    D = 32
+    hp = dict(track_high_thresh=0.5, new_track_thresh=0.6, track_buffer=60, match_thresh=0.8, proximity_thresh=0.5, appearance_thresh=0.25,
+              frame_rate=30, lambda_=0.98)
+    gpu, cpu = GpuTracker(D, hp, max_tracks=4096, max_dets=512), orc.BoTSORT(D, **hp)
+    scenes = [iter(SyntheticStream(300 + k, 300, 4, parts=1, dim=D, with_embeddings=True, miss_prob=0.05, low_conf_frac=0.2)) for k in range(4)]
+    small = iter(SyntheticStream(77, 20, 3, parts=1, dim=D, with_embeddings=True))
+    most = 0
+    for f, k in enumerate([0, 0, 1, 1, 2, 2, 3, 3, 0, -1, -1, 1]):
+        fr = next(small) if k < 0 else next(scenes[k])
+        d, e = fr["dets"], fr["embeddings"][:, 0, :].astype(np.float32)
+        a, b = gpu.update(d, e), cpu.update(d, e)
+        np.testing.assert_array_equal(a, b, err_msg=f"frame {f}")
+        n = 0
+        for which in (0, 1):
+            gi, gm, gc, gs, gf = gpu.tracks(which)
+            ci, cm, cc, cs, cf = cpu.tracks(which)
+            np.testing.assert_array_equal(gi, ci); np.testing.assert_array_equal(gs, cs)
+            np.testing.assert_array_equal(gm, cm); np.testing.assert_array_equal(gc, cc)
+            np.testing.assert_allclose(gf, cf, rtol=0, atol=5e-7)
+            n += len(gi)
+        most = max(most, n)
+    assert most > 600, most

@@ -86,7 +86,34 @@ def test_bytetrack_bank_batched_frames_and_reset():
 def test_bytetrack_rejects_bad_configuration():
     from tracklab_amd._lib import ByteTrackBank, TlkError
     with pytest.raises(TlkError):
-        ByteTrackBank(max_tracks=400, max_dets=200)
+        ByteTrackBank(max_tracks=20000)             # capacity is an allocation size up to 16384 tracks / 1024 detections per stream
+    with pytest.raises(TlkError):
+        ByteTrackBank(max_dets=2000)
     b = ByteTrackBank(max_dets=8)
     with pytest.raises(TlkError):
         b.update(np.zeros((9, 7)))
+
+
+def test_bytetrack_400_tracks_300_detections(orc):
+    """Capacity is an allocation size (r04; the reference's lists grow, byte_tracker.py:167-320): 300-object scenes shown in turn with a long
+    track buffer leave almost 400 tracked + lost tracks beside 300 detections per frame -- past both LDS tiers, lists and the assignment problem
+    in HBM -- rows, lists and Kalman state equal the oracle every frame; a small scene afterwards runs in the LDS tier again."""
+    from tracklab_amd.synth import SyntheticStream
+    hp = dict(track_thresh=0.5, match_thresh=0.8, track_buffer=60, frame_rate=30)
+    gpu, cpu = GpuTracker(hp, max_tracks=4096, max_dets=512), orc.ByteTrack(**hp)
+    scenes = [iter(SyntheticStream(300 + k, 300, 4, miss_prob=0.05, low_conf_frac=0.2)) for k in range(4)]
+    small = iter(SyntheticStream(77, 20, 3))
+    most = 0
+    for f, k in enumerate([0, 0, 1, 1, 2, 2, 3, 3, 0, -1, -1, 1]):
+        d = (next(small) if k < 0 else next(scenes[k]))["dets"]
+        a, b = gpu.update(d), cpu.update(d)
+        np.testing.assert_array_equal(a, b, err_msg=f"frame {f}")
+        n = 0
+        for which in (0, 1):
+            gi, gm, gc, gs = gpu.tracks(which)
+            ci, cm, cc, cs = cpu.tracks(which)
+            np.testing.assert_array_equal(gi, ci); np.testing.assert_array_equal(gs, cs)
+            np.testing.assert_array_equal(gm, cm); np.testing.assert_array_equal(gc, cc)
+            n += len(gi)
+        most = max(most, n)
+    assert most > 350, most          # tracked + lost + 300 detections: beyond the 384 x 128 LDS tier

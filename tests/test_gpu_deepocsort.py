@@ -86,9 +86,39 @@ def test_deepocsort_bank_batched_frames_and_reset():
 def test_deepocsort_rejects_bad_configuration():
     from tracklab_amd._lib import DeepOCSortBank, TlkError
     for bad in (dict(cmc_off=False), dict(cmc_off=True, embedding_off=True), dict(cmc_off=True, new_kf_off=True), dict(cmc_off=True, delta_t=9),
-                dict(cmc_off=True, max_tracks=1024)):
+                dict(cmc_off=True, max_tracks=20000)):
         with pytest.raises(TlkError):
             DeepOCSortBank(64, **bad)
     b = DeepOCSortBank(32, cmc_off=True, max_dets=8)
     with pytest.raises(TlkError):
         b.update(np.zeros((9, 7)), np.zeros((9, 32), np.float32))
+
+
+def test_deepocsort_800_tracks_400_detections(orc):
+    """Capacity is an allocation size (r04; the reference's list of trackers grows, deep_oc_sort/ocsort.py:563-574): 400-object scenes shown in
+    turn with max_age 60 leave over 700 live + coasting trackers and 400 detections per frame -- past both LDS tiers, lists and Hungarian
+    work area in HBM -- rows, ids and Kalman state equal the oracle every frame; a small scene afterwards runs in the LDS tier again."""
+    import os
+    from tracklab_amd.synth import SyntheticStream
+    if "canary" in os.environ.get("TLK_LIB_PATH", ""):
+        pytest.skip("the guard-word debug build keeps ONE LDS layout at the bank's capacity (tools/build_canary.sh): no big-scene tier")
+    D = 32
+    hp = dict(det_thresh=0.3, max_age=60, min_hits=1, iou_threshold=0.3, delta_t=1, asso_func="giou", inertia=0.2, w_association_emb=0.5,
+              alpha_fixed_emb=0.95, aw_param=0.5, embedding_off=False, cmc_off=True, aw_off=False, new_kf_off=False)
+    gpu, cpu = GpuTracker(D, hp, max_tracks=4096, max_dets=512), orc.DeepOCSort(D, **hp)
+    scenes = [iter(SyntheticStream(400 + k, 400, 4, parts=1, dim=D, with_embeddings=True, miss_prob=0.05)) for k in range(6)]
+    small = iter(SyntheticStream(77, 20, 3, parts=1, dim=D, with_embeddings=True))
+    most = 0
+    for f, k in enumerate([0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, -1, -1, 0, 0, 1, 1, 5, 5]):
+        fr = next(small) if k < 0 else next(scenes[k])
+        d, e = fr["dets"], fr["embeddings"][:, 0, :].astype(np.float32)
+        e = e / np.linalg.norm(e, axis=1, keepdims=True)
+        a, b = gpu.update(d, e), cpu.update(d, e)
+        np.testing.assert_array_equal(a, b, err_msg=f"frame {f}")
+        gi, gx, gP, ge, gs, gv, gl = gpu.tracks()
+        ci, cx, cP, ce, cs, cv, cl = cpu.tracks()
+        np.testing.assert_array_equal(gi, ci, err_msg=f"frame {f}"); np.testing.assert_array_equal(gs, cs, err_msg=f"counters / freeze flags frame {f}")
+        np.testing.assert_array_equal(gx, cx, err_msg=f"frame {f}"); np.testing.assert_array_equal(gP, cP, err_msg=f"frame {f}")
+        np.testing.assert_allclose(ge, ce, rtol=0, atol=1e-6)
+        most = max(most, len(gi))
+    assert most > 700, most          # beyond the 512 x 256 LDS tier

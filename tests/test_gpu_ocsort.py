@@ -142,13 +142,18 @@ def test_hip_ocsort_800_tracks_400_detections(orc):
     scenes = [iter(SyntheticStream(400 + k, 400, 4, miss_prob=0.05)) for k in range(6)]
     small = iter(SyntheticStream(77, 20, 3))
     most = 0
-    for f, k in enumerate([0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, -1, -1, 0]):
+    for f, k in enumerate([0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, -1, -1, 0, 0, 1, 1, 5, 5]):
         d = (next(small) if k < 0 else next(scenes[k]))["dets"]
         exp = ref.update(d)
         got = bank.update(d, 0)
         assert got.shape == exp.shape, (f, got.shape, exp.shape)
         np.testing.assert_array_equal(got[:, [4, 5, 7]], exp[:, [4, 5, 7]], err_msg=f"ids frame {f}")
         np.testing.assert_allclose(got, exp, rtol=1e-11, atol=1e-9)
-        most = max(most, len(bank.tracks()[0]))
+        gx, gP, gi = bank.tracks()
+        cx, cP, ci = ref.tracks()
+        np.testing.assert_array_equal(gi, ci, err_msg=f"track ids frame {f}")
+        np.testing.assert_array_equal(gx, cx, err_msg=f"Kalman state frame {f}")      # also what update(None) / freeze left behind for EVERY unmatched tracker
+        np.testing.assert_array_equal(gP, cP, err_msg=f"Kalman covariance frame {f}")
+        most = max(most, len(gi))
     assert most > 700, most          # beyond the 512 x 256 LDS tier
     bank.close()

@@ -39,7 +39,10 @@ struct BoDev {
     double *dist;            // S x MAXT x MAXD  embedding distance, row = position in [tracked list, lost list], col = input index
     double *gl;              // S x MAXT x GLD   gate of pool track p
     double *ebuf;            // S x MAXT x MAXD  assignment problem spill
-    int S, MAXT, MAXD, NX, D, cost_lds_entries;
+    int *alive;              // S x MAXT   slot-indexed marks of the end-of-frame free-slot sweep
+    unsigned char *big_ws;   // S x big_stride: list / solver work area of the big-scene tier (by_carve_frame)
+    size_t big_stride;
+    int S, MAXT, MAXD, D, lds_bytes;
 };
 struct BoP { double track_high, new_track, match_thresh, proximity, appearance, lambda_, min_conf; int max_time_lost, wrapper_mode; };
 struct BoIn { const double *dets; const float *feats; const int *counts; size_t stream_stride_dets, count_stride;
@@ -211,9 +214,8 @@ botsort_kernel(BoDev Dv, BoP P, BoIn in, tlk_botsort_row *__restrict__ rows_all,
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int s = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const int MAXT = Dv.MAXT, MAXD = Dv.MAXD, NX = Dv.NX, D = Dv.D;
+    const int MAXT = Dv.MAXT, MAXD = Dv.MAXD, D = Dv.D;
     ByLds L;
-    bycarve(smem, MAXT, MAXD, NX, L);
     int *hdr = Dv.hdr + (size_t)s * OH_COUNT;
     int *tracked = Dv.tracked + (size_t)s * MAXT, *lost = Dv.lost + (size_t)s * MAXT, *freestk = Dv.freestk + (size_t)s * MAXT;
     double *ebuf = Dv.ebuf + (size_t)s * MAXT * MAXD;
@@ -232,6 +234,8 @@ botsort_kernel(BoDev Dv, BoP P, BoIn in, tlk_botsort_row *__restrict__ rows_all,
     if (P.wrapper_mode && n_in == 0) { if (tid == 0) *out_count = 0; return; }      // bot_sort_api.py:59-60
     const int fid = hdr[OH_FRAME] + 1;
     int n_trk = hdr[OH_NTRK], n_lost = hdr[OH_NLOST], nfree = hdr[OH_NFREE], next_id = hdr[OH_COUNT_ID];
+    const int cost_lds_entries = by_carve_frame(smem, Dv.lds_bytes, Dv.big_ws + (size_t)s * Dv.big_stride, MAXT, MAXD, n_trk + n_lost + n_in, n_in,
+                                                Dv.alive + (size_t)s * MAXT, L);
 
     // wrapper filter inputs[:, 4] > min_confidence (bot_sort_api.py:62), then the score split (:293-309)
     const int N = block_compact(n_in, [&](int i) { return in.dets[(dbase + i) * 7 + 4] > P.min_conf; }, [&](int i, int pos) { L.sel[pos] = i; }, L.scan);
@@ -367,7 +371,7 @@ botsort_kernel(BoDev Dv, BoP P, BoIn in, tlk_botsort_row *__restrict__ rows_all,
         double e = dist[(size_t)L.ppos[r] * MAXD + L.sel[j]];
         if (gd > CHI2_4) e = INFINITY;
         return P.lambda_ * e + (1 - P.lambda_) * gd;
-    }, ebuf, L.cost, Dv.cost_lds_entries, L);
+    }, ebuf, L.cost, cost_lds_entries, L);
     for (int k = tid; k < A1.nm; k += BLOCK) apply(L.pool[L.m_r[k]], L.hi[L.m_c[k]], L.pre[L.m_r[k]] != OT_TRACKED);
     smooth(A1.nm, [&](int k) { return L.pool[L.m_r[k]]; }, [&](int k) { return L.hi[L.m_c[k]]; });
     const int n_ref = block_compact(A1.nm, [&](int k) { return L.pre[L.m_r[k]] != OT_TRACKED; }, [&](int k, int pos) { L.refind[pos] = L.pool[L.m_r[k]]; }, L.scan);
@@ -380,7 +384,7 @@ botsort_kernel(BoDev Dv, BoP P, BoIn in, tlk_botsort_row *__restrict__ rows_all,
     __syncthreads();
     const AsgOut A2 = lapjv_assign(n_rtr, nlo, 0.5, [&](int r, int c) {
         return (double)(float)(1 - bbox_iou32(L.tbox + r * 4, L.dbox + L.lo[c] * 4));
-    }, ebuf, L.cost, Dv.cost_lds_entries, L);
+    }, ebuf, L.cost, cost_lds_entries, L);
     for (int k = tid; k < A2.nm; k += BLOCK) apply(L.rtr[L.m_r[k]], L.lo[L.m_c[k]], false);
     for (int k = tid; k < A2.n_ur; k += BLOCK) { const int slot = L.rtr[L.u_r[k]]; trk_at(slot).i(OI_STATE) = OT_LOST; L.newlost[k] = slot; }   // mark_lost
     const int n_newlost = A2.n_ur;
@@ -397,7 +401,7 @@ botsort_kernel(BoDev Dv, BoP P, BoIn in, tlk_botsort_row *__restrict__ rows_all,
         if (e > P.appearance) e = 1.0;
         if (c32 > (float)P.proximity) e = 1.0;                                   // ious_dists_mask on the float32 distances
         return iou_d < e ? iou_d : e;
-    }, ebuf, L.cost, Dv.cost_lds_entries, L);
+    }, ebuf, L.cost, cost_lds_entries, L);
     for (int k = tid; k < A3.nm; k += BLOCK) apply(L.unconf[L.m_r[k]], L.udet1[L.m_c[k]], false);
     smooth(A3.nm, [&](int k) { return L.unconf[L.m_r[k]]; }, [&](int k) { return L.udet1[L.m_c[k]]; });
     for (int k = tid; k < A3.n_ur; k += BLOCK) { const int slot = L.unconf[L.u_r[k]]; trk_at(slot).i(OI_STATE) = OT_REMOVED; L.removed[k] = slot; }
@@ -559,7 +563,7 @@ static void bo_free(tlk_botsort *h)
 {
     if (!h) return;
     hipSetDevice(h->device);
-    void *ptrs[] = {h->D.fd, h->D.fi, h->D.hdr, h->D.tracked, h->D.lost, h->D.freestk, h->D.feat, h->D.dfeat, h->D.dist, h->D.gl, h->D.ebuf,
+    void *ptrs[] = {h->D.fd, h->D.fi, h->D.hdr, h->D.tracked, h->D.lost, h->D.freestk, h->D.feat, h->D.dfeat, h->D.dist, h->D.gl, h->D.ebuf, h->D.alive, h->D.big_ws,
                     h->d_dets, h->d_feats, h->d_cnt, h->d_ocnt, h->d_rows, h->d_warp};
     for (void *p : ptrs) if (p) hipFree(p);
     delete h;
@@ -582,7 +586,8 @@ extern "C" int tlk_botsort_create(const tlk_botsort_params *p, int n_streams, in
     if (p->dim < 4 || p->dim > 4096 || p->dim % 4) return fail(TLK_EINVAL, "tlk_botsort_create: dim must be a multiple of 4 in [4, 4096]");
     if (p->cmc_method < 0 || p->cmc_method > 5) return fail(TLK_EINVAL, "tlk_botsort_create: cmc_method out of range (gmc.py:18-78: 0 none, 1 orb, 2 sift, 3 ecc, 4 sparseOptFlow, 5 file)");
     const int MAXT = p->max_tracks > 0 ? p->max_tracks : 256, MAXD = p->max_dets > 0 ? p->max_dets : 128;
-    if (MAXT + MAXD > 512) return fail(TLK_ECAPACITY, "tlk_botsort_create: max_tracks + max_dets <= 512");
+    // capacity = allocation size (r04): LDS tiers while the scene fits, HBM lists beyond (by_carve_frame)
+    if (MAXT > 16384 || MAXD > 1024) return fail(TLK_ECAPACITY, "tlk_botsort_create: max_tracks <= 16384 and max_dets <= 1024");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(TLK_ENODEVICE, "tlk_botsort_create: no HIP device (libtlk has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(TLK_EINVAL, "tlk_botsort_create: bad device index");
@@ -594,11 +599,11 @@ extern "C" int tlk_botsort_create(const tlk_botsort_params *p, int n_streams, in
     h->P = BoP{p->track_high_thresh, p->new_track_thresh, p->match_thresh, p->proximity_thresh, p->appearance_thresh, p->lambda_, p->min_confidence,
                (int)(p->frame_rate / 30.0 * p->track_buffer), p->wrapper_mode};
     BoDev &D = h->D;
-    D.S = n_streams; D.MAXT = MAXT; D.MAXD = MAXD; D.NX = MAXT + MAXD; D.D = p->dim;
-    const size_t fixed = bylds_bytes(MAXT, MAXD, D.NX) + 16, budget = 160 * 1024 - 256;
-    if (fixed + 4096 > budget) { delete h; return fail(TLK_ECAPACITY, "tlk_botsort_create: LDS budget exceeded"); }
-    D.cost_lds_entries = (int)((budget - fixed) / sizeof(double));
-    h->smem = fixed + (size_t)D.cost_lds_entries * sizeof(double);
+    D.S = n_streams; D.MAXT = MAXT; D.MAXD = MAXD; D.D = p->dim;
+    const size_t budget = 160 * 1024 - 256;
+    D.lds_bytes = (int)(budget & ~(size_t)15);
+    D.big_stride = (bylds_bytes(MAXT, MAXD, MAXT + MAXD) + 16 + 255) & ~(size_t)255;
+    h->smem = (size_t)D.lds_bytes;
     const size_t slots = (size_t)n_streams * MAXT;
     h->out_cap = MAXT;
 #define BO_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void **)&(ptr), (bytes)); \
@@ -614,6 +619,8 @@ extern "C" int tlk_botsort_create(const tlk_botsort_params *p, int n_streams, in
     BO_ALLOC(D.dist, sizeof(double) * slots * MAXD);
     BO_ALLOC(D.gl, sizeof(double) * slots * GLD);
     BO_ALLOC(D.ebuf, sizeof(double) * slots * MAXD);
+    BO_ALLOC(D.alive, sizeof(int) * slots);
+    BO_ALLOC(D.big_ws, D.big_stride * (size_t)n_streams);
     BO_ALLOC(h->d_dets, sizeof(double) * 7 * MAXD);
     BO_ALLOC(h->d_feats, sizeof(float) * (size_t)MAXD * D.D);
     BO_ALLOC(h->d_cnt, sizeof(int));
@@ -698,7 +705,7 @@ extern "C" int tlk_botsort_update_gmc(tlk_botsort *h, int stream, const double *
     BoDev V = h->D;
     const size_t sl = (size_t)stream * V.MAXT;
     V.fd += sl; V.fi += sl; V.hdr += (size_t)stream * OH_COUNT; V.tracked += sl; V.lost += sl; V.freestk += sl;
-    V.feat += sl * V.D; V.dfeat += (size_t)stream * V.MAXD * V.D; V.dist += sl * V.MAXD; V.gl += sl * GLD; V.ebuf += sl * V.MAXD;
+    V.feat += sl * V.D; V.dfeat += (size_t)stream * V.MAXD * V.D; V.dist += sl * V.MAXD; V.gl += sl * GLD; V.ebuf += sl * V.MAXD; V.alive += sl; V.big_ws += (size_t)stream * V.big_stride;
     BoIn in;
     in.dets = h->d_dets; in.feats = h->d_feats; in.counts = h->d_cnt; in.stream_stride_dets = 0; in.count_stride = 0;
     in.warps = warp6 ? h->d_warp : nullptr; in.warp_stride = 0;

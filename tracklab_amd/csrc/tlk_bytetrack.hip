@@ -24,8 +24,11 @@ struct ByDev {
     double *fd;              // YD_COUNT x S x MAXT
     int *fi;                 // YI_COUNT x S x MAXT
     int *hdr, *tracked, *lost, *freestk;      // lists hold slots, in list order
-    double *ebuf;            // S x NX x NX   spill area of the assignment problem when it does not fit the LDS cost area
-    int S, MAXT, MAXD, NX, cost_lds_entries;
+    double *ebuf;            // S x MAXT x MAXD   spill area of the assignment problem when it does not fit the LDS cost area
+    int *alive;              // S x MAXT   slot-indexed marks of the end-of-frame free-slot sweep
+    unsigned char *big_ws;   // S x big_stride: list / solver work area of the big-scene tier (by_carve_frame)
+    size_t big_stride;
+    int S, MAXT, MAXD, lds_bytes;
 };
 struct ByP { double track_thresh, match_thresh, det_thresh, min_conf; int max_time_lost, wrapper_mode; };
 struct ByIn { const double *dets; const int *counts; size_t stream_stride_dets, count_stride; };
@@ -80,12 +83,11 @@ bytetrack_kernel(ByDev Dv, ByP P, ByIn in, tlk_bytetrack_row *__restrict__ rows_
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int s = blockIdx.x, tid = threadIdx.x;
-    const int MAXT = Dv.MAXT, MAXD = Dv.MAXD, NX = Dv.NX;
+    const int MAXT = Dv.MAXT, MAXD = Dv.MAXD;
     ByLds L;
-    bycarve(smem, MAXT, MAXD, NX, L);
     int *hdr = Dv.hdr + (size_t)s * YH_COUNT;
     int *tracked = Dv.tracked + (size_t)s * MAXT, *lost = Dv.lost + (size_t)s * MAXT, *freestk = Dv.freestk + (size_t)s * MAXT;
-    double *ebuf = Dv.ebuf + (size_t)s * NX * NX;
+    double *ebuf = Dv.ebuf + (size_t)s * MAXT * MAXD;
     const size_t stride = (size_t)Dv.S * MAXT;
     auto trk_at = [&](int slot) { BTrk T; T.fd = Dv.fd + (size_t)s * MAXT + slot; T.fi = Dv.fi + (size_t)s * MAXT + slot; T.stride = stride; return T; };
     tlk_bytetrack_row *rows = rows_all + (size_t)s * rows_stream_stride;
@@ -98,6 +100,8 @@ bytetrack_kernel(ByDev Dv, ByP P, ByIn in, tlk_bytetrack_row *__restrict__ rows_
     if (P.wrapper_mode && n_in == 0) { if (tid == 0) *out_count = 0; return; }      // byte_track_api.py:55-56
     const int fid = hdr[YH_FRAME] + 1;                                                  // self.frame_id += 1
     int n_trk = hdr[YH_NTRK], n_lost = hdr[YH_NLOST], nfree = hdr[YH_NFREE], next_id = hdr[YH_COUNT_ID];
+    const int cost_lds_entries = by_carve_frame(smem, Dv.lds_bytes, Dv.big_ws + (size_t)s * Dv.big_stride, MAXT, MAXD, n_trk + n_lost + n_in, n_in,
+                                                Dv.alive + (size_t)s * MAXT, L);
 
     // wrapper filter inputs[:, 4] > min_confidence (byte_track_api.py:58), then the score split (:176-195)
     const int N = block_compact(n_in, [&](int i) { return in.dets[(dbase + i) * 7 + 4] > P.min_conf; }, [&](int i, int pos) { L.sel[pos] = i; }, L.scan);
@@ -175,7 +179,7 @@ bytetrack_kernel(ByDev Dv, ByP P, ByIn in, tlk_bytetrack_row *__restrict__ rows_
         const float c32 = 1 - bbox_iou32(L.tbox + r * 4, L.dbox + j * 4);        // iou_distance (float32)
         const float sim = 1 - c32;                                               // fuse_score: (1 - cost) * score in float64
         return 1 - (double)sim * L.dscore[j];
-    }, ebuf, L.cost, Dv.cost_lds_entries, L);
+    }, ebuf, L.cost, cost_lds_entries, L);
     for (int k = tid; k < A1.nm; k += BLOCK) apply(L.pool[L.m_r[k]], L.hi[L.m_c[k]], L.pre[L.m_r[k]] != BT_TRACKED);
     const int n_ref = block_compact(A1.nm, [&](int k) { return L.pre[L.m_r[k]] != BT_TRACKED; }, [&](int k, int pos) { L.refind[pos] = L.pool[L.m_r[k]]; }, L.scan);
     for (int k = tid; k < A1.n_uc; k += BLOCK) L.udet1[k] = L.hi[L.u_c[k]];     // remaining high-score detections (filtered index)
@@ -187,7 +191,7 @@ bytetrack_kernel(ByDev Dv, ByP P, ByIn in, tlk_bytetrack_row *__restrict__ rows_
     __syncthreads();
     const AsgOut A2 = lapjv_assign(n_rtr, nlo, 0.5, [&](int r, int c) {
         return (double)(float)(1 - bbox_iou32(L.tbox + r * 4, L.dbox + L.lo[c] * 4));
-    }, ebuf, L.cost, Dv.cost_lds_entries, L);
+    }, ebuf, L.cost, cost_lds_entries, L);
     for (int k = tid; k < A2.nm; k += BLOCK) apply(L.rtr[L.m_r[k]], L.lo[L.m_c[k]], false);
     for (int k = tid; k < A2.n_ur; k += BLOCK) { const int slot = L.rtr[L.u_r[k]]; trk_at(slot).i(YI_STATE) = BT_LOST; L.newlost[k] = slot; }   // mark_lost
     const int n_newlost = A2.n_ur;
@@ -200,7 +204,7 @@ bytetrack_kernel(ByDev Dv, ByP P, ByIn in, tlk_bytetrack_row *__restrict__ rows_
         const float c32 = 1 - bbox_iou32(L.tbox + r * 4, L.dbox + j * 4);
         const float sim = 1 - c32;
         return 1 - (double)sim * L.dscore[j];
-    }, ebuf, L.cost, Dv.cost_lds_entries, L);
+    }, ebuf, L.cost, cost_lds_entries, L);
     for (int k = tid; k < A3.nm; k += BLOCK) apply(L.unconf[L.m_r[k]], L.udet1[L.m_c[k]], false);
     for (int k = tid; k < A3.n_ur; k += BLOCK) { const int slot = L.unconf[L.u_r[k]]; trk_at(slot).i(YI_STATE) = BT_REMOVED; L.removed[k] = slot; }
     int n_removed = A3.n_ur;
@@ -351,7 +355,7 @@ static void by_free(tlk_bytetrack *h)
 {
     if (!h) return;
     hipSetDevice(h->device);
-    void *ptrs[] = {h->D.fd, h->D.fi, h->D.hdr, h->D.tracked, h->D.lost, h->D.freestk, h->D.ebuf, h->d_dets, h->d_cnt, h->d_ocnt, h->d_rows};
+    void *ptrs[] = {h->D.fd, h->D.fi, h->D.hdr, h->D.tracked, h->D.lost, h->D.freestk, h->D.ebuf, h->D.alive, h->D.big_ws, h->d_dets, h->d_cnt, h->d_ocnt, h->d_rows};
     for (void *p : ptrs) if (p) hipFree(p);
     delete h;
 }
@@ -361,7 +365,8 @@ extern "C" int tlk_bytetrack_create(const tlk_bytetrack_params *p, int n_streams
     if (!p || !out) return fail(TLK_EINVAL, "tlk_bytetrack_create: null pointer");
     if (n_streams < 1) return fail(TLK_EINVAL, "tlk_bytetrack_create: n_streams must be >= 1");
     const int MAXT = p->max_tracks > 0 ? p->max_tracks : 256, MAXD = p->max_dets > 0 ? p->max_dets : 128;
-    if (MAXT + MAXD > 512) return fail(TLK_ECAPACITY, "tlk_bytetrack_create: max_tracks + max_dets <= 512 (embedded assignment problem)");
+    // capacity = allocation size (r04): LDS tiers while the scene fits, HBM lists beyond (by_carve_frame)
+    if (MAXT > 16384 || MAXD > 1024) return fail(TLK_ECAPACITY, "tlk_bytetrack_create: max_tracks <= 16384 and max_dets <= 1024");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(TLK_ENODEVICE, "tlk_bytetrack_create: no HIP device (libtlk has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(TLK_EINVAL, "tlk_bytetrack_create: bad device index");
@@ -371,11 +376,11 @@ extern "C" int tlk_bytetrack_create(const tlk_bytetrack_params *p, int n_streams
     h->device = device;
     h->P = ByP{p->track_thresh, p->match_thresh, p->track_thresh + 0.1, p->min_confidence, (int)(p->frame_rate / 30.0 * p->track_buffer), p->wrapper_mode};
     ByDev &D = h->D;
-    D.S = n_streams; D.MAXT = MAXT; D.MAXD = MAXD; D.NX = MAXT + MAXD;
-    const size_t fixed = bylds_bytes(MAXT, MAXD, D.NX) + 16, budget = 160 * 1024 - 256;
-    if (fixed + 4096 > budget) { delete h; return fail(TLK_ECAPACITY, "tlk_bytetrack_create: LDS budget exceeded"); }
-    D.cost_lds_entries = (int)((budget - fixed) / sizeof(double));
-    h->smem = fixed + (size_t)D.cost_lds_entries * sizeof(double);
+    D.S = n_streams; D.MAXT = MAXT; D.MAXD = MAXD;
+    const size_t budget = 160 * 1024 - 256;
+    D.lds_bytes = (int)(budget & ~(size_t)15);
+    h->smem = (size_t)D.lds_bytes;
+    D.big_stride = (bylds_bytes(MAXT, MAXD, MAXT + MAXD) + 16 + 255) & ~(size_t)255;
     const size_t slots = (size_t)n_streams * MAXT;
     h->out_cap = MAXT;
 #define BY_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void **)&(ptr), (bytes)); \
@@ -386,7 +391,9 @@ extern "C" int tlk_bytetrack_create(const tlk_bytetrack_params *p, int n_streams
     BY_ALLOC(D.tracked, sizeof(int) * slots);
     BY_ALLOC(D.lost, sizeof(int) * slots);
     BY_ALLOC(D.freestk, sizeof(int) * slots);
-    BY_ALLOC(D.ebuf, sizeof(double) * (size_t)n_streams * D.NX * D.NX);
+    BY_ALLOC(D.ebuf, sizeof(double) * slots * MAXD);
+    BY_ALLOC(D.alive, sizeof(int) * slots);
+    BY_ALLOC(D.big_ws, D.big_stride * (size_t)n_streams);
     BY_ALLOC(h->d_dets, sizeof(double) * 7 * MAXD);
     BY_ALLOC(h->d_cnt, sizeof(int));
     BY_ALLOC(h->d_ocnt, sizeof(int));
@@ -451,7 +458,7 @@ extern "C" int tlk_bytetrack_update(tlk_bytetrack *h, int stream, const double *
     TLK_HIP(hipMemcpyAsync(h->d_cnt, &n, sizeof(int), hipMemcpyHostToDevice, st));
     ByDev V = h->D;
     const size_t sl = (size_t)stream * V.MAXT;
-    V.fd += sl; V.fi += sl; V.hdr += (size_t)stream * YH_COUNT; V.tracked += sl; V.lost += sl; V.freestk += sl; V.ebuf += (size_t)stream * V.NX * V.NX;
+    V.fd += sl; V.fi += sl; V.hdr += (size_t)stream * YH_COUNT; V.tracked += sl; V.lost += sl; V.freestk += sl; V.ebuf += sl * V.MAXD; V.alive += sl; V.big_ws += (size_t)stream * V.big_stride;
     ByIn in;
     in.dets = h->d_dets; in.counts = h->d_cnt; in.stream_stride_dets = 0; in.count_stride = 0;
     hipLaunchKernelGGL(bytetrack_kernel, dim3(1), dim3(BLOCK), h->smem, st, V, h->P, in, h->d_rows, (size_t)0, h->out_cap, h->d_ocnt, (size_t)0);

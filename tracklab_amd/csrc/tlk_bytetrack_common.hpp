@@ -48,6 +48,29 @@ __device__ inline void bycarve(unsigned char *smem, int MAXT, int MAXD, int NX, 
     L.cost = (double *)(((uintptr_t)bp + 15) & ~(uintptr_t)15);
 }
 
+// List / solver work area of ONE frame (r04: capacity is an allocation size, the reference's lists simply grow -- byte_tracker.py:167-320):
+// the SMALLEST tier that holds (tracked + lost + detections, detections) -- 256 x 128 or 384 x 128 carved out of LDS, the rest of the LDS being
+// the cost matrix -- or, for a scene beyond that, the bank's full capacity carved out of HBM (`big_ws`; matrices then go to the HBM spill
+// area).  Same code either way, generic pointers.  Returns the number of cost entries that fit the LDS (0 in the HBM tier).  `alive` is
+// indexed by SLOT, not by list position, so it always lives in HBM at capacity.
+__device__ inline int by_carve_frame(unsigned char *smem, int lds_bytes, unsigned char *big_ws, int MAXT, int MAXD, int need_t, int n_in,
+                                     int *alive_g, ByLds &L)
+{
+    const int tiers[2][2] = {{256, 128}, {384, 128}};
+    int entries = -1;
+    for (int k = 0; k < 2 && entries < 0; ++k) {
+        const int tt = MAXT < tiers[k][0] ? MAXT : tiers[k][0], td = MAXD < tiers[k][1] ? MAXD : tiers[k][1];
+        const size_t fixed = bylds_bytes(tt, td, tt + td) + 16;
+        if (need_t <= tt && n_in <= td && fixed + 4096 <= (size_t)lds_bytes) {
+            bycarve(smem, tt, td, tt + td, L);
+            entries = (int)(((size_t)lds_bytes - fixed) / sizeof(double));
+        }
+    }
+    if (entries < 0) { bycarve(big_ws, MAXT, MAXD, MAXT + MAXD, L); entries = 0; }
+    L.alive = alive_g;
+    return entries;
+}
+
 __device__ __forceinline__ float bbox_iou32(const float *b, const float *q)       // matching.py:181-217
 {
     const float box_area = (q[2] - q[0] + 1) * (q[3] - q[1] + 1);

@@ -50,7 +50,9 @@ struct DocDev {
     double *cost_g;  // S x MAXD x MAXT   cost-matrix spill
     long long *prof; // optional S x 16 cycle accumulators (diagnostics)
     int *pairs;      // S x MAXD x MAXT   spill of the (detection, track) pairs with IoU > 0 that do not fit the LDS list
-    int S, MAXT, MAXD, D, cost_lds_entries;
+    unsigned char *big_ws;   // S x big_stride: list / solver work area of the big-scene tier (see deepocsort_frames_kernel)
+    size_t big_stride;
+    int S, MAXT, MAXD, D, cost_lds_entries, lds_bytes;      // cost_lds_entries: the guard-word debug build only (one layout at capacity)
 };
 struct DocP {
     double det_thresh, iou_threshold, inertia, w_emb, alpha_fixed, aw_param, min_confidence;
@@ -402,8 +404,12 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
     const int s = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int MAXT = D.MAXT, MAXD = D.MAXD, S = D.S, DIM = D.D;
     Lds L;
-    carve(smem, MAXT, MAXD, L);
+    int lds_t = MAXT, lds_d = MAXD;          // capacity of the list / solver work area in use (a tier, or the bank's capacity)
+    int cost_lds_entries = 0;
 #ifdef TLK_LDS_CANARY
+    // guard-word debug build: ONE layout at the bank's capacity (created small), guards written once and checked every frame
+    carve(smem, MAXT, MAXD, L);
+    cost_lds_entries = D.cost_lds_entries - TLK_CANARY_BYTES_TOTAL / 24 / 8 * 2;
     canary_fill(L, (unsigned char *)(L.cost + (D.cost_lds_entries > 16 ? D.cost_lds_entries - 16 : 0)));
 #endif
     int *hdr = D.hdr + (size_t)s * H_COUNT;
@@ -434,6 +440,22 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
         if (hdr[H_ERR] != 0) { if (tid == 0) *out_count = hdr[H_ERR]; continue; }
         if (n_in > MAXD || n_in < 0) { if (tid == 0) { hdr[H_ERR] = TLK_ECAPACITY; *out_count = TLK_ECAPACITY; } continue; }
         if (P.wrapper_mode && n_in == 0) { if (tid == 0) *out_count = 0; continue; }   // deep_oc_sort_api.py:59-60
+#ifndef TLK_LDS_CANARY
+        // List / solver work area of THIS frame: the smallest tier that holds (tracks + detections, detections) -- 256 x 128 or 512 x 256 carved
+        // out of LDS (the rest of the LDS is the cost matrix), or the bank's full capacity carved out of HBM for a scene beyond that (r04: the
+        // reference's list of trackers just grows, deep_oc_sort/ocsort.py:563-574; track state sits in HBM at capacity either way).
+        {
+            const int need_t = hdr[H_NTRK] + n_in;
+            int ct = 0, cd = 0;
+            const int tiers[2][2] = {{256, 128}, {512, 256}};
+            for (int k = 0; k < 2 && ct == 0; ++k) {
+                const int tt = MAXT < tiers[k][0] ? MAXT : tiers[k][0], td = MAXD < tiers[k][1] ? MAXD : tiers[k][1];
+                if (need_t <= tt && n_in <= td && lds_fixed_bytes(tt, td) + 4096 <= (size_t)D.lds_bytes) { ct = tt; cd = td; }
+            }
+            if (ct) { carve(smem, ct, cd, L); cost_lds_entries = (int)(((size_t)D.lds_bytes - lds_fixed_bytes(ct, cd)) / sizeof(double)); lds_t = ct; lds_d = cd; }
+            else { carve(D.big_ws + (size_t)s * D.big_stride, MAXT, MAXD, L); cost_lds_entries = 0; lds_t = MAXT; lds_d = MAXD; }
+        }
+#endif
 
         // wrapper filter (deep_oc_sort_api.py:62), then scores > det_thresh (ocsort.py:407-408)
         const int N = block_compact(n_in, [&](int i) { const double c = dets[(size_t)i * 7 + 4]; return (!P.wrapper_mode || c > P.min_confidence) && c > P.det_thresh; },
@@ -516,12 +538,12 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
         if (tid == 0) L.sc[SC_NREM] = 0;
         // list of the pairs with IoU > 0: the assignment scratch lists (mi_r .. um_t, contiguous, unused until the LSA) first, HBM beyond
         int *plist = L.mi_r;
-        const int plist_cap = 6 * (MAXT > MAXD ? MAXT : MAXD) + MAXD + MAXT;
+        const int plist_cap = 6 * (lds_t > lds_d ? lds_t : lds_d) + lds_d + lds_t;
         __syncthreads();
 
         PROF(3);
         // ---- first association (association.py:291-364)
-        double *cost = ((size_t)N * T <= (size_t)(D.cost_lds_entries - TLK_CANARY_BYTES_TOTAL / 24 / 8 * 2)) ? L.cost : (D.cost_g + (size_t)s * MAXD * MAXT);
+        double *cost = ((size_t)N * T <= (size_t)cost_lds_entries) ? L.cost : (D.cost_g + (size_t)s * MAXD * MAXT);
         // until the cost fill, cost[e] holds the float32 embedding cost of the pair (exact in a double): no second N x T array
         int n_mi = 0;
         if (T > 0 && N > 0) {
@@ -657,7 +679,7 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
         // ---- second round by OCR on the last observations (ocsort.py:480-513)
         if (nud > 0 && nut > 0) {
             const int nrow = nud, ncol = nut;
-            double *mat = ((size_t)nrow * ncol <= (size_t)(D.cost_lds_entries - TLK_CANARY_BYTES_TOTAL / 24 / 8 * 2)) ? L.cost : (D.cost_g + (size_t)s * MAXD * MAXT);
+            double *mat = ((size_t)nrow * ncol <= (size_t)cost_lds_entries) ? L.cost : (D.cost_g + (size_t)s * MAXD * MAXT);
             double lmax = -INFINITY; bool lnan = false;
             for (int e = tid; e < nrow * ncol; e += BLOCK) {
                 const int r = e / ncol, c = e - r * ncol;
@@ -896,7 +918,7 @@ static int doc_free(tlk_deepocsort *h)
 {
     if (!h) return TLK_OK;
     hipSetDevice(h->device);
-    void *ptrs[] = {h->D.fd, h->D.fi, h->D.hdr, h->D.order, h->D.freestk, h->D.emb, h->D.lastb, h->D.cost_g, h->D.prof, h->D.pairs,
+    void *ptrs[] = {h->D.fd, h->D.fi, h->D.hdr, h->D.order, h->D.freestk, h->D.emb, h->D.lastb, h->D.cost_g, h->D.big_ws, h->D.prof, h->D.pairs,
                     h->d_dets, h->d_out, h->d_embs, h->d_cnt, h->d_ocnt};
     for (void *p : ptrs) if (p) hipFree(p);
     delete h;
@@ -914,7 +936,8 @@ extern "C" int tlk_deepocsort_create(const tlk_deepocsort_params *p, int n_strea
     if (p->embedding_off) return fail(TLK_EUNSUPPORTED, "tlk_deepocsort_create: embedding_off is not supported (the reference itself fails on it: ocsort.py:429 get_emb)");
     if (p->new_kf_off) return fail(TLK_EUNSUPPORTED, "tlk_deepocsort_create: new_kf_off (the 7-state filter) is not built; use tlk_ocsort for it");
     const int MAXT = p->max_tracks > 0 ? p->max_tracks : 256, MAXD = p->max_dets > 0 ? p->max_dets : 128;
-    if (MAXT > 512 || MAXD > 256) return fail(TLK_ECAPACITY, "tlk_deepocsort_create: max_tracks <= 512 and max_dets <= 256");
+    // capacity = allocation size (r04): LDS tiers while the scene fits, HBM lists beyond (deepocsort_frames_kernel)
+    if (MAXT > 16384 || MAXD > 1024) return fail(TLK_ECAPACITY, "tlk_deepocsort_create: max_tracks <= 16384 and max_dets <= 1024");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(TLK_ENODEVICE, "tlk_deepocsort_create: no HIP device (libtlk has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(TLK_EINVAL, "tlk_deepocsort_create: bad device index");
@@ -926,10 +949,18 @@ extern "C" int tlk_deepocsort_create(const tlk_deepocsort_params *p, int n_strea
                 p->max_age, p->min_hits, p->delta_t, p->asso_func, p->aw_off, p->wrapper_mode};
     DocDev &D = h->D;
     D.S = n_streams; D.MAXT = MAXT; D.MAXD = MAXD; D.D = p->dim;
-    const size_t fixed = lds_fixed_bytes(MAXT, MAXD), budget = 160 * 1024 - 256;
-    if (fixed + 4096 > budget) { delete h; return fail(TLK_ECAPACITY, "tlk_deepocsort_create: LDS budget exceeded"); }
+    const size_t budget = 160 * 1024 - 256;
+#ifdef TLK_LDS_CANARY
+    const size_t fixed = lds_fixed_bytes(MAXT, MAXD);
+    if (fixed + 4096 > budget) { delete h; return fail(TLK_ECAPACITY, "tlk_deepocsort_create: LDS budget exceeded (guard-word build: one layout at capacity)"); }
     D.cost_lds_entries = (int)((budget - fixed) / sizeof(double));
     h->smem = fixed + (size_t)D.cost_lds_entries * sizeof(double);
+#else
+    D.cost_lds_entries = 0;
+    h->smem = budget & ~(size_t)15;
+#endif
+    D.lds_bytes = (int)h->smem;
+    D.big_stride = (lds_fixed_bytes(MAXT, MAXD) + 255) & ~(size_t)255;
     const size_t slots = (size_t)n_streams * MAXT;
     h->out_cap = MAXT + MAXD;
 #define DOC_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void **)&(ptr), (bytes)); \
@@ -942,6 +973,7 @@ extern "C" int tlk_deepocsort_create(const tlk_deepocsort_params *p, int n_strea
     DOC_ALLOC(D.emb, sizeof(float) * slots * D.D);
     DOC_ALLOC(D.lastb, sizeof(double) * 5 * slots);
     DOC_ALLOC(D.cost_g, sizeof(double) * (size_t)n_streams * MAXD * MAXT);
+    DOC_ALLOC(D.big_ws, D.big_stride * (size_t)n_streams);
     DOC_ALLOC(D.pairs, sizeof(int) * (size_t)n_streams * MAXD * MAXT);
     if (getenv("TLK_DEEPOCSORT_PROF")) { DOC_ALLOC(D.prof, sizeof(long long) * 16 * n_streams); hipMemset(D.prof, 0, sizeof(long long) * 16 * n_streams); }
     DOC_ALLOC(h->d_dets, sizeof(double) * 7 * MAXD);
@@ -1018,7 +1050,7 @@ extern "C" int tlk_deepocsort_update(tlk_deepocsort *h, int stream, const double
     DocDev V = h->D;
     const size_t sl = (size_t)stream * V.MAXT;
     V.fd += sl; V.fi += sl; V.hdr += (size_t)stream * H_COUNT; V.order += sl; V.freestk += sl; V.emb += sl * V.D; V.lastb += sl * 5;
-    V.cost_g += (size_t)stream * V.MAXD * V.MAXT; V.pairs += (size_t)stream * V.MAXD * V.MAXT; if (V.prof) V.prof += (size_t)stream * 16;
+    V.cost_g += (size_t)stream * V.MAXD * V.MAXT; V.big_ws += (size_t)stream * V.big_stride; V.pairs += (size_t)stream * V.MAXD * V.MAXT; if (V.prof) V.prof += (size_t)stream * 16;
     hipLaunchKernelGGL(deepocsort_frames_kernel, dim3(1), dim3(BLOCK), h->smem, st, V, h->P, (const double *)h->d_dets, (const float *)h->d_embs,
                        (const int *)h->d_cnt, 1, (size_t)0, (size_t)0, h->d_out, h->out_cap, h->d_ocnt);
     TLK_HIP(hipGetLastError());

@@ -209,31 +209,36 @@ __device__ inline int canary_check(const Lds &L)
 }
 #endif
 
-// sorted-unique set difference on a small int list held in LDS (np.setdiff1d). All threads call.
-// list[0..n) -> list[0..ret) sorted ascending without members of rem[0..nrem). Uses tmp (>= n).
+// sorted-unique set difference on an int list (np.setdiff1d). All threads call.
+// list[0..n) -> list[0..ret) sorted ascending, duplicates dropped, without members of rem[0..nrem). Uses tmp (>= n ints).  Any n (r04: the
+// r01-r03 version kept each thread's elements in two registers and silently lost everything beyond 512 entries -- reachable once the
+// capacity tiers let a frame hold more unmatched trackers than that); values must be in [0, 65536), n < 32768.
 __device__ int block_setdiff_sorted(int *list, int n, const int *rem, int nrem, int *tmp, int *s_scan)
 {
-    // rank sort (n is tiny): position = #elements smaller, duplicates dropped
+    // rank = number of smaller elements (the final order); a duplicate (not its first occurrence) or a member of rem is dropped.
+    // tmp[k] = rank << 16 | value: from here on `list` itself is free to be overwritten.
     for (int k = threadIdx.x; k < n; k += BLOCK) {
         const int v = list[k];
         int rank = 0; bool dup = false, drop = false;
         for (int q = 0; q < n; ++q) { const int o = list[q]; rank += (o < v); dup |= (o == v && q < k); }
         for (int q = 0; q < nrem; ++q) drop |= (rem[q] == v);
-        tmp[k] = (dup || drop) ? -1 : rank;
+        tmp[k] = (dup || drop) ? -1 : ((rank << 16) | v);
     }
+    __threadfence_block();
     __syncthreads();
-    // values with their ranks: emit in rank order -> compaction over rank space [0,n)
-    // invert: slot[rank] = value
-    int *inv = tmp + 0;   // reuse after reading: do in two steps via registers
-    int myv[2], myr[2], cnt = 0;
-    for (int k = threadIdx.x; k < n && cnt < 2; k += BLOCK) { myv[cnt] = list[k]; myr[cnt] = tmp[k]; ++cnt; }
+    // list[r] = the kept value of rank r, INT32_MIN where no kept value has that rank
+    for (int r = threadIdx.x; r < n; r += BLOCK) {
+        int val = INT32_MIN;
+        for (int q = 0; q < n; ++q) { const int t = tmp[q]; if (t >= 0 && (t >> 16) == r) val = t & 0xffff; }
+        list[r] = val;
+    }
+    __threadfence_block();
     __syncthreads();
-    for (int k = threadIdx.x; k < n; k += BLOCK) inv[k] = INT32_MIN;
+    for (int r = threadIdx.x; r < n; r += BLOCK) tmp[r] = list[r];
+    __threadfence_block();
     __syncthreads();
-    for (int c = 0; c < cnt; ++c) if (myr[c] >= 0) inv[myr[c]] = myv[c];
-    __syncthreads();
-    const int kept = block_compact(n, [&](int r) { return inv[r] != INT32_MIN; },
-                                   [&](int r, int pos) { list[pos] = inv[r]; }, s_scan);
+    const int kept = block_compact(n, [&](int r) { return tmp[r] != INT32_MIN; }, [&](int r, int pos) { list[pos] = tmp[r]; }, s_scan);
+    __threadfence_block();
     __syncthreads();
     return kept;
 }

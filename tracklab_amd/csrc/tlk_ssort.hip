@@ -37,7 +37,9 @@ struct SsDev {
     double *gl;              // S x MAXT x SGL
     double *cost_g;          // S x MAXT x MAXD     cost-matrix spill
     int *ps_ws;              // S x 4 x ps_cap       hash tables of the set-order emulation when they do not fit the LDS cost area
-    int S, MAXT, MAXD, D, B, cost_lds_entries, ps_cap, unbounded;      // unbounded: budget=None -- B rows of room, overflow is an error
+    unsigned char *big_ws;   // S x big_stride: list / solver work area of the big-scene tier (see ssort_assoc_kernel)
+    size_t big_stride;
+    int S, MAXT, MAXD, D, B, lds_bytes, ps_cap, unbounded;      // unbounded: budget=None -- B rows of room, overflow is an error
 };
 
 struct SsP {
@@ -177,9 +179,25 @@ ssort_assoc_kernel(SsDev Dv, SsP P, SsIn in, tlk_ssort_row *__restrict__ rows_al
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int s = blockIdx.x, tid = threadIdx.x;
     const int MAXT = Dv.MAXT, MAXD = Dv.MAXD, D = Dv.D, B = Dv.B;
-    BLds L;
-    bcarve(smem, MAXT, MAXD, L);
     int *hdr = Dv.hdr + (size_t)s * H_COUNT;
+    // List / solver work area of this frame: the SMALLEST tier that holds (tracks before the frame + detections, detections) -- 256 x 128 or
+    // 1024 x 256 carved out of LDS (the rest of the LDS is the cost matrix), or, for a scene beyond that, the bank's full capacity carved out
+    // of HBM (r04: the reference's track list simply grows, strong_sort/sort/tracker.py:130-141; the arrays are allocated at capacity in
+    // HBM and only this frame's lists move out of LDS).  Same code, generic pointers.
+    BLds L;
+    int cost_lds_entries = 0;
+    {
+        const int t_now = hdr[H_NTRK], n_now = in.counts[(size_t)s * in.count_stride];
+        const int need_t = t_now + (n_now > 0 ? n_now : 0);
+        int ct = 0, cd = 0;
+        const int tiers[2][2] = {{256, 128}, {1024, 256}};
+        for (int k = 0; k < 2 && ct == 0; ++k) {
+            const int tt = MAXT < tiers[k][0] ? MAXT : tiers[k][0], td = MAXD < tiers[k][1] ? MAXD : tiers[k][1];
+            if (need_t <= tt && n_now <= td && blds_fixed(tt, td) + 4096 <= (size_t)Dv.lds_bytes) { ct = tt; cd = td; }
+        }
+        if (ct) { bcarve(smem, ct, cd, L); cost_lds_entries = (int)(((size_t)Dv.lds_bytes - blds_fixed(ct, cd)) / sizeof(double)); }
+        else bcarve(Dv.big_ws + (size_t)s * Dv.big_stride, MAXT, MAXD, L);      // (cost_lds_entries = 0: matrices go to cost_g, the set table to ps_ws)
+    }
     int *order = Dv.order + (size_t)s * MAXT;
     int *freestk = Dv.freestk + (size_t)s * MAXT;
     const size_t stride = (size_t)Dv.S * MAXT;
@@ -250,7 +268,7 @@ ssort_assoc_kernel(SsDev Dv, SsP P, SsIn in, tlk_ssort_row *__restrict__ rows_al
     // ---------------- Tracker._match (tracker.py:152-188) ----------------
     const int nc = block_compact(T, [&](int p) { return trk_at(order[p]).i(SI_STATE) == ST_CONFIRMED; }, [&](int p, int pos) { L.cand[pos] = p; }, L.scan);
     const int nu = block_compact(T, [&](int p) { return trk_at(order[p]).i(SI_STATE) != ST_CONFIRMED; }, [&](int p, int pos) { L.bc[pos] = p; }, L.scan);
-    double *cm = ((size_t)nc * N <= (size_t)Dv.cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
+    double *cm = ((size_t)nc * N <= (size_t)cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
     // gated_metric: cosine gallery minimum + gate_cost_matrix (linear_assignment.py:131-174) + thresholding (:54)
     // one wavefront per track row, lanes over the detections; the row's gate factors are prefetched into registers one row ahead
     // (the flat (row, det) sweep re-read 20 doubles of global memory per entry: as in tlk_bpbss.hip, 70 -> 31 us for 110 x 98)
@@ -292,7 +310,7 @@ ssort_assoc_kernel(SsDev Dv, SsP P, SsIn in, tlk_ssort_row *__restrict__ rows_al
     __syncthreads();
     // unmatched confirmed tracks = list(set(track_indices) - matched) in CPython's set-iteration order (linear_assignment.py:126-127;
     // cm has been consumed: the LDS cost area doubles as the hash-table scratch), split by time_since_update == 1 (tracker.py:174-179)
-    int *psw = ((size_t)Dv.cost_lds_entries * sizeof(double) >= (size_t)16 * Dv.ps_cap) ? (int *)L.cost : Dv.ps_ws + (size_t)s * 4 * Dv.ps_cap;
+    int *psw = ((size_t)cost_lds_entries * sizeof(double) >= (size_t)16 * Dv.ps_cap) ? (int *)L.cost : Dv.ps_ws + (size_t)s * 4 * Dv.ps_cap;
     const int n_unm = cascade_unmatched_tracks(L.cand, nc, A.nm, L.tmp, psw, (unsigned)Dv.ps_cap, L);
     const int nb_extra = block_compact(n_unm, [&](int r) { return trk_at(order[L.tmp[r]]).i(SI_TSU) == 1; },
                                        [&](int r, int pos) { L.bc[nu + pos] = L.tmp[r]; }, L.scan);
@@ -300,7 +318,7 @@ ssort_assoc_kernel(SsDev Dv, SsP P, SsIn in, tlk_ssort_row *__restrict__ rows_al
                                     [&](int r, int pos) { L.um_t[pos] = L.tmp[r]; }, L.scan);
     const int nb = nu + nb_extra, n_uda = A.n_um_d;
     __syncthreads();
-    double *cb = ((size_t)nb * n_uda <= (size_t)Dv.cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
+    double *cb = ((size_t)nb * n_uda <= (size_t)cost_lds_entries) ? L.cost : (Dv.cost_g + (size_t)s * MAXT * MAXD);
     for (int e = tid; e < nb * n_uda; e += BLOCK) {          // iou_cost (iou_matching.py:42-82) + thresholding
         const int r = e / n_uda, c = e - r * n_uda;
         const BTrk Kt = trk_at(order[L.bc[r]]);
@@ -552,7 +570,7 @@ static void ss_free(tlk_ssort *h)
     if (!h) return;
     hipSetDevice(h->device);
     SsDev &D = h->D;
-    void *ptrs[] = {D.fd, D.fi, D.hdr, D.order, D.freestk, D.feat, D.gal, D.gnorm, D.dnorm, D.reid, D.gl, D.cost_g, D.ps_ws,
+    void *ptrs[] = {D.fd, D.fi, D.hdr, D.order, D.freestk, D.feat, D.gal, D.gnorm, D.dnorm, D.reid, D.gl, D.cost_g, D.ps_ws, D.big_ws,
                     h->d_dets, h->d_feat, h->d_cnt, h->d_ocnt, h->d_rows};
     for (void *p : ptrs) if (p) hipFree(p);
     delete h;
@@ -600,8 +618,11 @@ extern "C" int tlk_ssort_create(const tlk_ssort_params *p, int n_streams, int de
         return fail(TLK_EINVAL, "tlk_ssort_create: nn_budget must be in [1, 1024], or -rows (rows <= 65536) for the reference's unbounded budget=None");
     if (p->img_w < 1 || p->img_h < 1) return fail(TLK_EINVAL, "tlk_ssort_create: image size must be positive");
     const int MAXT = p->max_tracks > 0 ? p->max_tracks : 256, MAXD = p->max_dets > 0 ? p->max_dets : 128;
-    // (above 512 tracks the Hungarian solver keeps its column state in LDS instead of registers: wave_lsa_lds)
-    if (MAXT > 1024 || MAXD > 256) return fail(TLK_ECAPACITY, "tlk_ssort_create: max_tracks <= 1024 and max_dets <= 256");
+    // capacity = allocation size (r04): LDS tiers while the scene fits, HBM lists beyond (ssort_assoc_kernel); the gallery is
+    // max_tracks x |nn_budget| x dim floats per stream, the caller's choice of HBM
+    if (MAXT > 16384 || MAXD > 1024) return fail(TLK_ECAPACITY, "tlk_ssort_create: max_tracks <= 16384 and max_dets <= 1024");
+    if ((unsigned long long)n_streams * MAXT * (unsigned long long)(p->nn_budget > 0 ? p->nn_budget : -p->nn_budget) > 0x7fffffffULL)
+        return fail(TLK_ECAPACITY, "tlk_ssort_create: n_streams x max_tracks x gallery rows must stay below 2^31");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(TLK_ENODEVICE, "tlk_ssort_create: no HIP device (libtlk has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(TLK_EINVAL, "tlk_ssort_create: bad device index");
@@ -613,10 +634,10 @@ extern "C" int tlk_ssort_create(const tlk_ssort_params *p, int n_streams, int de
                p->wrapper_mode, p->img_w, p->img_h};
     SsDev &D = h->D;
     D.S = n_streams; D.MAXT = MAXT; D.MAXD = MAXD; D.D = p->dim; D.B = p->nn_budget > 0 ? p->nn_budget : -p->nn_budget; D.unbounded = p->nn_budget < 0;
-    const size_t fixed = blds_fixed(MAXT, MAXD), budget = 160 * 1024 - 256;
-    if (fixed + 4096 > budget) { delete h; return fail(TLK_ECAPACITY, "tlk_ssort_create: LDS budget exceeded"); }
-    D.cost_lds_entries = (int)((budget - fixed) / sizeof(double));
-    h->smem = fixed + (size_t)D.cost_lds_entries * sizeof(double);
+    const size_t budget = 160 * 1024 - 256;
+    D.lds_bytes = (int)(budget & ~(size_t)15);
+    h->smem = (size_t)D.lds_bytes;
+    D.big_stride = (blds_fixed(MAXT, MAXD) + 255) & ~(size_t)255;
     const size_t slots = (size_t)n_streams * MAXT;
     h->out_cap = MAXT;
 #define SS_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void **)&(ptr), (bytes)); \
@@ -633,6 +654,7 @@ extern "C" int tlk_ssort_create(const tlk_ssort_params *p, int n_streams, int de
     SS_ALLOC(D.reid, sizeof(double) * slots * MAXD);
     SS_ALLOC(D.gl, sizeof(double) * SGL * slots);
     SS_ALLOC(D.cost_g, sizeof(double) * slots * MAXD);
+    SS_ALLOC(D.big_ws, D.big_stride * (size_t)n_streams);
     D.ps_cap = (int)pyset::table_capacity((unsigned)MAXT);
     SS_ALLOC(D.ps_ws, sizeof(int) * 4 * (size_t)D.ps_cap * n_streams);
     SS_ALLOC(h->d_dets, sizeof(double) * 7 * MAXD);
@@ -717,7 +739,7 @@ extern "C" int tlk_ssort_update(tlk_ssort *h, int stream, const double *dets, co
     const size_t sl = (size_t)stream * V.MAXT;
     V.fd += sl; V.fi += sl; V.hdr += (size_t)stream * H_COUNT; V.order += sl; V.freestk += sl;
     V.feat += sl * V.D; V.gal += sl * V.B * V.D; V.gnorm += sl * V.B; V.dnorm += (size_t)stream * V.MAXD;
-    V.reid += sl * V.MAXD; V.gl += sl * SGL; V.cost_g += sl * V.MAXD; V.ps_ws += (size_t)stream * 4 * V.ps_cap;
+    V.reid += sl * V.MAXD; V.gl += sl * SGL; V.cost_g += sl * V.MAXD; V.ps_ws += (size_t)stream * 4 * V.ps_cap; V.big_ws += (size_t)stream * V.big_stride;
     SsIn in;
     in.dets = h->d_dets; in.feat = h->d_feat; in.counts = h->d_cnt; in.stream_stride_dets = 0; in.count_stride = 0;
     const int rc = ss_launch_frame(h, V, 1, in, h->d_rows, 0, h->out_cap, h->d_ocnt, 0, st);
