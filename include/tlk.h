@@ -611,6 +611,11 @@ int tlk_clear_sequence_dev_f64(const int32_t *gt_ids_dev, const double *gt_ltwh_
 int tlk_bias_act_nhwc(void *x_dev, const void *bias_dev, const void *residual_dev, long long rows, int channels,
                       int act_kind, int dtype, void *hip_stream);
 
+/* act_kind of the convolution entry points below: 0 none / 1 ReLU / 2 SiLU, optionally OR-ed with TLK_ACT_RES_AFTER: the residual is then added
+ * AFTER the activation, y = act(conv + bias) + residual (the identity add of a CSPNeXt block, mmdet CSPNeXtBlock.forward), instead of before it
+ * (y = act(conv + bias + residual): the ResNet bottleneck). */
+#define TLK_ACT_RES_AFTER 0x100
+
 /* fp32 convolution of a channels-last activation with the convolution epilogue inside -- the backbones at the REFERENCE's precision
  * (the reference runs them in fp32: configs/modules/track/strong_sort.yaml:10 `fp16: false`; ONNXRuntime fp32 behind
  * wrappers/bbox_detector/rtmlib_api.py:21 and wrappers/pose_estimator/rtmlib_api.py:21; torchreid fp32 behind wrappers/reid/kpreid_api.py:147-182):

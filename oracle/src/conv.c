@@ -39,10 +39,12 @@ void orc_conv2d_nhwc_f32(const float *x, const float *w, const float *bias, cons
                             }
                             acc = fmaf(a, b, acc);
                         }
+                    const int res_post = act & 0x100, a = act & 0xff;      /* 0x100 = TLK_ACT_RES_AFTER: the residual joins after the activation */
                     float v = acc + (bias ? bias[co] : 0.f);
-                    if (ro) v += ro[co];
-                    if (act == 1) v = v > 0.f ? v : 0.f;
-                    else if (act == 2) v = v / (1.f + expf(-v));
+                    if (ro && !res_post) v += ro[co];
+                    if (a == 1) v = v > 0.f ? v : 0.f;
+                    else if (a == 2) v = v / (1.f + expf(-v));
+                    if (ro && res_post) v += ro[co];
                     yo[co] = v;
                 }
             }

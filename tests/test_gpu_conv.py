@@ -55,6 +55,23 @@ def test_conv_is_bit_exact_with_the_oracle_chain(case, cfg):
     assert np.array_equal(got, exp), f"max |diff| {np.abs(got - exp).max()}"
 
 
+def test_residual_after_the_activation_is_bit_exact_with_the_oracle():
+    """TLK_ACT_RES_AFTER: y = act(conv + bias) + r -- CSPNeXt's identity add riding in the pointwise convolution's epilogue"""
+    import oracle
+    from tracklab_amd import _lib
+    rng = np.random.default_rng(9)
+    for n, h, w, cin, cout, k in ((2, 9, 7, 48, 48, 1), (1, 6, 5, 96, 96, 1), (2, 5, 5, 16, 130, 3)):
+        x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+        wt = (rng.standard_normal((cout, k, k, cin)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        r = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+        exp = oracle.conv2d_nhwc_f32(x, wt, b, r, act="relu", res_after_act=True)
+        assert np.array_equal(exp, np.maximum(oracle.conv2d_nhwc_f32(x, wt, b, None), 0) + r)
+        got = _lib.conv2d_nhwc_f32(torch.from_numpy(x).cuda().permute(0, 3, 1, 2), torch.from_numpy(wt).cuda().permute(0, 3, 1, 2), torch.from_numpy(b).cuda(),
+                                   "relu", torch.from_numpy(r).cuda().permute(0, 3, 1, 2), residual_after_act=True)
+        assert np.array_equal(got.permute(0, 2, 3, 1).cpu().numpy(), exp)
+
+
 def test_silu_within_exp_roundoff():
     got, exp = _run((2, 10, 10, 16, 40, 3, 1, "silu", False), -1)
     np.testing.assert_allclose(got, exp, rtol=2e-6, atol=1e-6)      # device exp vs libm expf

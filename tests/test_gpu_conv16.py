@@ -95,3 +95,19 @@ def test_reid_network_in_split_precision_tracks_the_exact_fp32_network():
     assert torch.equal(v0, v1)
     cos = F.cosine_similarity(e0.double().flatten(1), e1.double().flatten(1)).min().item()
     assert cos > 1 - 1e-9, cos
+
+
+@pytest.mark.parametrize("shape", [(3, 48, 16, 12, 48, 1, 1, True), (2, 96, 9, 7, 96, 1, 1, True), (2, 256, 6, 5, 192, 3, 1, True)])
+def test_residual_after_the_activation(shape):
+    """TLK_ACT_RES_AFTER: y = act(conv + bias) + r (CSPNeXt's identity add) in f16 and split mode, through both kernels (register-staged for
+    Cout <= 64 / ragged Cin, direct-to-LDS otherwise)"""
+    from tracklab_amd import _lib
+    x, wt, b, r, k, s = _inputs(shape, seed=3)
+    ref = F.silu(F.conv2d(x.half().double(), wt.half().double(), b.double(), s, k // 2)) + r.half().double()
+    y = _lib.conv2d_nhwc_16(x.half(), wt.half(), b, "silu", r.half(), stride=s, residual_after_act=True)
+    assert bool(((y.double() - ref).abs() <= 2e-3 * ref.abs() + 2e-3).all())
+    xh, xl = _lib.split_planes(x); wh, wl = _lib.split_planes(wt); rh, rl = _lib.split_planes(r)
+    y32 = _lib.conv2d_nhwc_16(xh, wh, b, "silu", rh, stride=s, x_lo=xl, weight_lo=wl, residual_lo=rl, out_f32=True, residual_after_act=True)
+    ref = F.silu(F.conv2d(x.double(), wt.double(), b.double(), s, k // 2)) + r.double()
+    bound = F.conv2d(x.double().abs(), wt.double().abs(), b.double().abs(), s, k // 2) + r.double().abs()
+    assert bool(((y32.double() - ref).abs() <= 4e-6 * bound + 1e-30).all())

@@ -103,20 +103,26 @@ def test_dwconv_rejects_what_it_does_not_implement():
 def _pose_outputs(dtype, x):
     import importlib
     R = importlib.import_module("tracklab_amd.backbones.rtmpose")
+    Cm = importlib.import_module("tracklab_amd.backbones.common")
     net = R.rtmpose("m", "cuda", dtype)                      # seeded: the same weights for every dtype before the cast
+    switches = ((R, "USE_TLK_DWCONV"), (R, "USE_SLICE_CONCAT"), (R, "USE_FINAL_GEMM"), (Cm, "USE_TLK_SPP"), (Cm, "USE_TLK_CONV_F16_NARROW"))
     with torch.no_grad():
         mine = net(x.to(dtype))
-        old = R.USE_TLK_DWCONV
-        R.USE_TLK_DWCONV = False
+        old = [getattr(m, k) for m, k in switches]
+        for m, k in switches:
+            setattr(m, k, False)                             # library route: MIOpen / hipBLASLt + separate passes (fp32: libtlk's convolution stays)
         try:
             lib = net(x.to(dtype))
         finally:
-            R.USE_TLK_DWCONV = old
+            for (m, k), v in zip(switches, old):
+                setattr(m, k, v)
     return mine, lib
 
 
 def test_rtmpose_forward_equals_the_library_route():
-    """fp32: the forward through the depthwise kernel == the library route to fp32 round-off.  f16: two f16 evaluations of a 60-layer random
+    """Every libtlk piece of the pose network on (depthwise kernel, SPP pass, narrow pointwise convolutions with the identity add and the
+    concatenation written in place, final layer as a GEMM) against all of them off.
+    fp32: the forward through the depthwise kernel == the library route to fp32 round-off.  f16: two f16 evaluations of a 60-layer random
     network differ by their accumulated roundings, so both are measured against the fp32 network: the kernel's route (fp32 accumulation
     inside the depthwise convolution) must not be further from it than the library route is."""
     x = torch.randn(6, 3, 256, 192, device="cuda").contiguous(memory_format=torch.channels_last)

@@ -46,6 +46,7 @@ def test_residual_and_activations():
     assert np.array_equal(oracle.conv2d_nhwc_f32(x, wt, None, r, act="relu"), np.maximum(base + r, 0))
     v = base + r
     np.testing.assert_allclose(oracle.conv2d_nhwc_f32(x, wt, None, r, act="silu"), v / (1 + np.exp(-v)), rtol=1e-6)
+    assert np.array_equal(oracle.conv2d_nhwc_f32(x, wt, None, r, act="relu", res_after_act=True), np.maximum(base, 0) + r)      # TLK_ACT_RES_AFTER
 
 
 @pytest.mark.parametrize("case", [(2, 9, 7, 8, 5), (1, 3, 2, 4, 5), (3, 6, 11, 12, 3), (1, 1, 1, 8, 3)])

@@ -44,9 +44,10 @@ for name, cin, cout, k, s, H, W, cnt, res in R50:
     r = torch.randn(B, cout, Ho, Wo, device="cuda").contiguous(memory_format=torch.channels_last) if res else None
     xh, xl = _lib.split_planes(x); wh, wl = _lib.split_planes(w)
     rh, rl = _lib.split_planes(r) if res else (None, None)
-    t_split = timed(lambda: _lib.conv2d_nhwc_16(xh, wh, b, "relu", rh, stride=s, x_lo=xl, weight_lo=wl, residual_lo=rl))
+    only32 = os.environ.get("PROBE_ONLY") == "f32"          # A/B runs of the exact kernel alone
+    t_split = float("nan") if only32 else timed(lambda: _lib.conv2d_nhwc_16(xh, wh, b, "relu", rh, stride=s, x_lo=xl, weight_lo=wl, residual_lo=rl))
     x16, w16, r16 = x.half(), w.half(), (r.half() if res else None)
-    t_f16 = timed(lambda: _lib.conv2d_nhwc_16(x16, w16, b, "relu", r16, stride=s))
+    t_f16 = float("nan") if only32 else timed(lambda: _lib.conv2d_nhwc_16(x16, w16, b, "relu", r16, stride=s))
     t_f32 = timed(lambda: _lib.conv2d_nhwc_f32(x, w, b, "relu", r, stride=s)) if cin % 4 == 0 else float("nan")
     for key, t in (("split", t_split), ("f16", t_f16), ("f32", t_f32)):
         tot[key] += t * cnt

@@ -951,6 +951,7 @@ def oks_cost(track_kps, det_kps):
 # fused conv epilogue (bias + activation (+ residual)) for channels-last backbones
 # ------------------------------------------------------------------------------------------------
 ACT = {None: 0, "none": 0, "relu": 1, "silu": 2}
+ACT_RES_AFTER = 0x100          # TLK_ACT_RES_AFTER: y = act(conv + bias) + residual instead of act(conv + bias + residual)
 
 
 def bias_act_(x, bias, act="relu", residual=None):
@@ -969,7 +970,7 @@ def bias_act_(x, bias, act="relu", residual=None):
     return x
 
 
-def conv2d_nhwc_f32(x, weight, bias=None, act=None, residual=None, stride=1, pad=None, out=None):
+def conv2d_nhwc_f32(x, weight, bias=None, act=None, residual=None, stride=1, pad=None, out=None, residual_after_act=False):
     """fp32 convolution + bias + residual + activation in ONE hand-written MFMA kernel (tlk_conv2d_nhwc_f32).
     x: (N, Cin, H, W) float32 cuda tensor in channels_last memory (or a channel slice of one); weight: (Cout, Cin, KH, KW) channels_last;
     residual / out: (N, Cout, Ho, Wo) channels_last (or channel slices).  Returns out (allocated channels_last when None)."""
@@ -998,7 +999,7 @@ def conv2d_nhwc_f32(x, weight, bias=None, act=None, residual=None, stride=1, pad
         out = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     check(L.tlk_conv2d_nhwc_f32(x.data_ptr(), wk.data_ptr(), bias.data_ptr() if bias is not None else None,
                                 residual.data_ptr() if residual is not None else None, out.data_ptr(),
-                                N, H, W, Cin, Cout, KH, KW, stride, pad, ACT[act],
+                                N, H, W, Cin, Cout, KH, KW, stride, pad, ACT[act] | (ACT_RES_AFTER if residual_after_act else 0),
                                 pix(x, Cin, H, W), pix(out, Cout, Ho, Wo), pix(residual, Cout, Ho, Wo) if residual is not None else 0,
                                 current_stream_ptr()))
     return out
@@ -1062,10 +1063,11 @@ def _bind_conv16(L):
 
 
 def conv2d_nhwc_16(x, weight, bias=None, act=None, residual=None, stride=1, pad=None, x_lo=None, weight_lo=None, residual_lo=None,
-                   out_f32=False):
+                   out_f32=False, residual_after_act=False, out=None):
     """Convolution + bias + residual + activation on the 16-bit MFMA (tlk_conv2d_nhwc_16).  f16 mode: x / weight / residual float16
     channels_last, returns float16.  Split mode (x_lo given): every tensor a (hi, lo) pair of float16 planes, returns (hi, lo).
-    out_f32: returns one float32 tensor instead.  bias float32."""
+    out_f32: returns one float32 tensor instead.  bias float32.  out (f16 mode): a float16 channels_last tensor, or a channel slice of one
+    (e.g. this layer's part of a concatenation), to write into."""
     import torch
     L = lib()
     _bind_conv16(L)
@@ -1084,12 +1086,15 @@ def conv2d_nhwc_16(x, weight, bias=None, act=None, residual=None, stride=1, pad=
     wk, wkl = cl(weight), (cl(weight_lo) if split else None)
     mk = lambda dt: torch.empty((N, Cout, Ho, Wo), dtype=dt, device=x.device, memory_format=torch.channels_last)      # noqa: E731
     y32 = mk(torch.float32) if out_f32 else None
-    yh = None if out_f32 else mk(torch.float16)
+    if out is not None:
+        assert not split and not out_f32 and out.dtype == torch.float16 and out.shape == (N, Cout, Ho, Wo)
+    yh = None if out_f32 else (out if out is not None else mk(torch.float16))
     yl = mk(torch.float16) if (split and not out_f32) else None
     ptr = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
     check(L.tlk_conv2d_nhwc_16(x.data_ptr(), ptr(x_lo), wk.data_ptr(), ptr(wkl), ptr(bias), ptr(residual), ptr(residual_lo),
-                               ptr(yh), ptr(yl), ptr(y32), N, H, W, Cin, Cout, KH, KW, stride, pad, ACT[act],
-                               _pix16(x, Cin, H, W), Cout, _pix16(residual, Cout, Ho, Wo) if residual is not None else 0, current_stream_ptr()))
+                               ptr(yh), ptr(yl), ptr(y32), N, H, W, Cin, Cout, KH, KW, stride, pad, ACT[act] | (ACT_RES_AFTER if residual_after_act else 0),
+                               _pix16(x, Cin, H, W), _pix16(out, Cout, Ho, Wo) if out is not None else Cout,
+                               _pix16(residual, Cout, Ho, Wo) if residual is not None else 0, current_stream_ptr()))
     if out_f32:
         return y32
     return (yh, yl) if split else yh

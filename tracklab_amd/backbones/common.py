@@ -15,7 +15,10 @@ USE_FUSED_GEMM = _os.environ.get("TLK_FUSED_GEMM", "1") != "0"
 USE_TLK_CONV_F32 = _os.environ.get("TLK_CONV_F32", "1") != "0"
 # f16 convolutions with the epilogue inside on libtlk's 16-bit MFMA kernel (tlk_conv2d_nhwc_16, csrc/tlk_conv16.hip) instead of MIOpen / CK /
 # hipBLASLt + a separate epilogue pass; TLK_CONV_F16=0 restores the library route for A/B runs.
-USE_TLK_CONV_F16 = _os.environ.get("TLK_CONV_F16", "0") != "0"      # r04: measured 72 ms vs the library route's ~55 ms on the ReID forward -- opt-in until it wins
+USE_TLK_CONV_F16 = _os.environ.get("TLK_CONV_F16", "0") != "0"      # r04: measured 67 ms vs the library route's ~55 ms on the ReID forward -- opt-in until it wins
+# ... except the narrow 1 x 1 convolutions (Cin, Cout <= 96: CSPNeXt / CSPDarknet stage 1-2 pointwise layers, HBM-bound), where the kernel with
+# the epilogue inside beats GEMM + library epilogue (RTMPose-m, 2400 crops: 0.68 vs 1.02 ms at 48 -> 48); TLK_CONV_F16_NARROW=0 opts out
+USE_TLK_CONV_F16_NARROW = _os.environ.get("TLK_CONV_F16_NARROW", "1") != "0"
 # bench.py's roofline pass: a list here makes every fp32 convolution record (start event, end event, algorithmic flops) around its launch
 CONV_TIMER = None
 
@@ -98,7 +101,22 @@ class ConvBiasAct(nn.Module):
             self._w_split = c
         return c
 
-    def forward(self, x, residual=None):
+    def writes_slices(self, x):
+        """True when forward(x, out=...) writes straight into `out` (a channel slice of a wider tensor): the libtlk convolution routes"""
+        if not x.is_cuda or not x.is_contiguous(memory_format=torch.channels_last):
+            return False
+        if x.dtype == torch.float32:
+            return USE_TLK_CONV_F32 and x.shape[1] % 4 == 0
+        narrow = USE_TLK_CONV_F16_NARROW and self.conv.kernel_size == (1, 1) and self.conv.in_channels <= 96 and self.conv.out_channels <= 96
+        return x.dtype == torch.float16 and (USE_TLK_CONV_F16 or narrow) and x.shape[1] % 8 == 0 and self.conv.out_channels % 8 == 0 \
+            and self.conv.weight.dtype == torch.float16
+
+    def forward(self, x, residual=None, residual_after_act=False, out=None):
+        """residual_after_act: y = act(conv + bias) + residual (CSPNeXt's identity add) instead of act(conv + bias + residual) (ResNet).
+        out: a channels_last tensor or channel slice of one to write into (see writes_slices; other routes compute, then copy)"""
+        if out is not None and not (isinstance(x, torch.Tensor) and self.writes_slices(x)):
+            out.copy_(self.forward(x, residual, residual_after_act))
+            return out
         if isinstance(x, SplitAct):
             # split-precision route (fp32-class results on the 16-bit MFMA): input, residual and output are (hi, lo) plane pairs
             from .. import _lib
@@ -106,9 +124,10 @@ class ConvBiasAct(nn.Module):
             out = _lib.conv2d_nhwc_16(x.hi, wh, self.bias.float() if self.bias.dtype != torch.float32 else self.bias, self.act,
                                       residual.hi if residual is not None else None, self.conv.stride[0], self.conv.padding[0],
                                       x_lo=x.lo, weight_lo=wl, residual_lo=residual.lo if residual is not None else None,
-                                      out_f32=getattr(self, "out_f32", False))
+                                      out_f32=getattr(self, "out_f32", False), residual_after_act=residual_after_act)
             return out if getattr(self, "out_f32", False) else SplitAct(*out)
-        if USE_TLK_CONV_F16 and x.is_cuda and x.dtype == torch.float16 and x.shape[1] % 8 == 0 and self.conv.out_channels % 8 == 0 \
+        narrow = USE_TLK_CONV_F16_NARROW and self.conv.kernel_size == (1, 1) and self.conv.in_channels <= 96 and self.conv.out_channels <= 96
+        if (USE_TLK_CONV_F16 or narrow) and x.is_cuda and x.dtype == torch.float16 and x.shape[1] % 8 == 0 and self.conv.out_channels % 8 == 0 \
                 and x.is_contiguous(memory_format=torch.channels_last) and self.conv.weight.dtype == torch.float16:
             from .. import _lib
             b32 = getattr(self, "_bias32", None)
@@ -117,7 +136,8 @@ class ConvBiasAct(nn.Module):
                 self._bias32 = b32
             if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
                 residual = residual.contiguous(memory_format=torch.channels_last)
-            return _lib.conv2d_nhwc_16(x, self.conv.weight, b32, self.act, residual, self.conv.stride[0], self.conv.padding[0])
+            return _lib.conv2d_nhwc_16(x, self.conv.weight, b32, self.act, residual, self.conv.stride[0], self.conv.padding[0],
+                                       residual_after_act=residual_after_act, out=out)
         if USE_TLK_CONV_F32 and x.is_cuda and x.dtype == torch.float32 and (x.shape[1] % 4 == 0 or x.shape[1] == 3) \
                 and x.is_contiguous(memory_format=torch.channels_last):
             from .. import _lib
@@ -139,13 +159,16 @@ class ConvBiasAct(nn.Module):
                 n0.record(); n1.record()                   # an empty pair first: what the pair itself costs on this stream
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            y = _lib.conv2d_nhwc_f32(x, weight, self.bias, self.act, residual, self.conv.stride[0], self.conv.padding[0])
+            y = _lib.conv2d_nhwc_f32(x, weight, self.bias, self.act, residual, self.conv.stride[0], self.conv.padding[0],
+                                     residual_after_act=residual_after_act, out=out)
             if CONV_TIMER is not None:
                 e1.record()
                 cout, cin, kh, kw = self.conv.weight.shape       # the algorithmic count: 3 input channels for the RGB stem, not the padded 4
                 CONV_TIMER.append((e0, e1, n0, n1, 2.0 * y.shape[0] * y.shape[2] * y.shape[3] * cout * cin * kh * kw,
                                    (_lib.lib().tlk_conv2d_last_config(), _lib.ACT[self.act], residual is not None)))
             return y
+        if residual_after_act and residual is not None:
+            return self.forward(x) + residual                 # library routes fuse the residual only ahead of the activation
         if USE_GEMM_1X1 and self.conv.kernel_size == (1, 1) and self.conv.stride == (1, 1) and x.is_cuda \
                 and x.is_contiguous(memory_format=torch.channels_last):
             # a channels-last 1x1 convolution IS a plain GEMM (rows = N*H*W): hand it to hipBLASLt

@@ -22,6 +22,8 @@ from .common import ConvBiasAct, epilogue_, finalize, random_init_, spp_concat
 USE_TLK_DWCONV = _os.environ.get("TLK_DWCONV", "1") != "0"
 # the 7 x 7 keypoint-map convolution on the 8 x 6 map as one dense GEMM (RTMPoseNet._final_maps); TLK_POSE_FINAL_GEMM=0 = the convolution
 USE_FINAL_GEMM = _os.environ.get("TLK_POSE_FINAL_GEMM", "1") != "0"
+# CSPLayer: the two halves of the concatenation written in place by the convolutions that produce them (libtlk routes); 0 = torch.cat
+USE_SLICE_CONCAT = _os.environ.get("TLK_SLICE_CONCAT", "1") != "0"
 
 
 class DWConvBiasAct(nn.Module):
@@ -43,15 +45,15 @@ class DWConvBiasAct(nn.Module):
             self._dw_taps = c
         return c
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, residual_after_act=False, out=None):
         if USE_TLK_DWCONV and x.is_cuda and x.dtype in (torch.float16, torch.float32) and x.is_contiguous(memory_format=torch.channels_last) \
                 and x.shape[1] % (8 if x.dtype == torch.float16 else 4) == 0:
             # ONE launch of libtlk's depthwise kernel (bias + SiLU inside, every byte moved once) instead of MIOpen's grouped convolution +
             # an epilogue pass: 33 of the 76 ms of the f16 pose forward of config 4 were spent in those two
             from .. import _lib
             wk, b32 = self._taps()
-            return self.pw(_lib.dwconv2d_nhwc(x, wk, b32, "silu"), residual)
-        return self.pw(epilogue_(self.dw(x), self.dw_bias, "silu"), residual)
+            return self.pw(_lib.dwconv2d_nhwc(x, wk, b32, "silu"), residual, residual_after_act, out)
+        return self.pw(epilogue_(self.dw(x), self.dw_bias, "silu"), residual, residual_after_act, out)
 
 
 class CSPNeXtBlock(nn.Module):
@@ -61,9 +63,10 @@ class CSPNeXtBlock(nn.Module):
         self.conv2 = DWConvBiasAct(c, c, 5)
         self.add = add_identity
 
-    def forward(self, x):
-        y = self.conv2(self.conv1(x))
-        return y + x if self.add else y
+    def forward(self, x, out=None):
+        # mmdet CSPNeXtBlock.forward: out = conv2(conv1(x)); out + identity -- the add rides in the pointwise convolution's epilogue where that is a
+        # libtlk kernel (after its activation), a separate pass otherwise
+        return self.conv2(self.conv1(x), x if self.add else None, residual_after_act=True, out=out)
 
 
 class ChannelAttention(nn.Module):
@@ -86,7 +89,18 @@ class CSPLayer(nn.Module):
         self.att = ChannelAttention(2 * mid) if attention else None
 
     def forward(self, x):
-        y = torch.cat([self.blocks(self.main(x)), self.short(x)], 1)
+        if USE_SLICE_CONCAT and self.short.writes_slices(x) and len(self.blocks) > 0:
+            # the concatenation is never copied: the last block's pointwise convolution and the shortcut write their halves of it directly
+            n, _, h, w = x.shape
+            mid = self.short.conv.out_channels
+            y = torch.empty((n, 2 * mid, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            t = self.main(x)
+            for blk in list(self.blocks)[:-1]:
+                t = blk(t)
+            self.blocks[-1](t, out=y[:, :mid])
+            self.short(x, out=y[:, mid:])
+        else:
+            y = torch.cat([self.blocks(self.main(x)), self.short(x)], 1)
         if self.att is not None:
             y = self.att(y)
         return self.final(y)

@@ -42,6 +42,7 @@ struct ConvArgs {
                                   // slice of a wider tensor, e.g. write straight into its part of a concatenation)
     int tiles_n;
     long long tiles;
+    int res_post;                 // 1: the residual is added AFTER the activation (y = act(conv + bias) + r: CSPNeXt's identity add)
 };
 
 template <int ACT> __device__ __forceinline__ float act_f32(float v)
@@ -245,8 +246,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
             float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec);
             if (p.bias) { const float4 bv = *reinterpret_cast<const float4 *>(p.bias + co); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
             else { v.x += 0.f; v.y += 0.f; v.z += 0.f; v.w += 0.f; }
-            if (RES) { const float4 rv = rres[it]; v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+            if (RES && !p.res_post) { const float4 rv = rres[it]; v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
             v.x = act_f32<ACT>(v.x); v.y = act_f32<ACT>(v.y); v.z = act_f32<ACT>(v.z); v.w = act_f32<ACT>(v.w);
+            if (RES && p.res_post) { const float4 rv = rres[it]; v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
             *reinterpret_cast<float4 *>(yp + m * p.y_pix + co) = v;
         }
     } else {
@@ -260,8 +262,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
             for (int e = 0; e < 4; ++e) {
                 if (co + e >= p.Cout) break;
                 float v = Cs[row * LDC + ec + e] + (p.bias ? p.bias[co + e] : 0.f);
-                if (RES) v += resp[m * p.r_pix + co + e];
-                yp[m * p.y_pix + co + e] = act_f32<ACT>(v);
+                if (RES && !p.res_post) v += resp[m * p.r_pix + co + e];
+                v = act_f32<ACT>(v);
+                if (RES && p.res_post) v += resp[m * p.r_pix + co + e];
+                yp[m * p.y_pix + co + e] = v;
             }
         }
     }
@@ -311,7 +315,9 @@ extern "C" int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const
     if (n < 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0)
         return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: bad shape");
     if (cin % 4 != 0) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: Cin must be a multiple of 4 (pad the input channels with zeros)");
-    if (act_kind < 0 || act_kind > 2) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: act_kind is 0 (none), 1 (ReLU) or 2 (SiLU)");
+    const int res_post = (act_kind & TLK_ACT_RES_AFTER) ? 1 : 0;
+    act_kind &= ~TLK_ACT_RES_AFTER;
+    if (act_kind < 0 || act_kind > 2) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: act_kind is 0 (none), 1 (ReLU) or 2 (SiLU), optionally | TLK_ACT_RES_AFTER");
     const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
     if (ho <= 0 || wo <= 0) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: empty output");
     if (n == 0) return TLK_OK;
@@ -324,6 +330,7 @@ extern "C" int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const
     a.x_pix = x_pix_stride > 0 ? x_pix_stride : cin;
     a.y_pix = y_pix_stride > 0 ? y_pix_stride : cout;
     a.r_pix = res_pix_stride > 0 ? res_pix_stride : cout;
+    a.res_post = res_post;
     if (a.x_pix < cin || a.y_pix < cout || a.r_pix < cout || a.x_pix % 4 != 0)
         return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: pixel strides must cover the channels (x stride a multiple of 4)");
     if (((uintptr_t)x_dev | (uintptr_t)w_dev) & 15) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: x and w must be 16-byte aligned");

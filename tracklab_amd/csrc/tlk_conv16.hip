@@ -44,6 +44,7 @@ struct Conv16Args {
     int x_pix, y_pix, r_pix;      // elements between two pixels of x / y / residual
     int tiles_n;
     long long tiles;
+    int res_post;                 // 1: the residual is added AFTER the activation (y = act(conv + bias) + r)
 };
 
 template <int ACT> __device__ __forceinline__ float act16(float v)
@@ -277,18 +278,27 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
             v[0] = c0.x + b0.x; v[1] = c0.y + b0.y; v[2] = c0.z + b0.z; v[3] = c0.w + b0.w;
             v[4] = c1.x + b1.x; v[5] = c1.y + b1.y; v[6] = c1.z + b1.z; v[7] = c1.w + b1.w;
         }
+        float rv[8];
         if (RES) {
             const h16x8 rh = *reinterpret_cast<const h16x8 *>(p.res + m * p.r_pix + co);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)rh[e];
+            for (int e = 0; e < 8; ++e) rv[e] = (float)rh[e];
             if (MODE == MODE_SPLIT) {
                 const h16x8 rl = *reinterpret_cast<const h16x8 *>(p.res_lo + m * p.r_pix + co);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)rl[e] * LO_INV;
+                for (int e = 0; e < 8; ++e) rv[e] += (float)rl[e] * LO_INV;
+            }
+            if (!p.res_post) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
             }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = act16<ACT>(v[e]);
+        if (RES && p.res_post) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
         if (OUT_F32) {
             float *o = p.y32 + m * p.y_pix + co;
             *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -466,18 +476,27 @@ __global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p,
             v[0] = c0.x + b0.x; v[1] = c0.y + b0.y; v[2] = c0.z + b0.z; v[3] = c0.w + b0.w;
             v[4] = c1.x + b1.x; v[5] = c1.y + b1.y; v[6] = c1.z + b1.z; v[7] = c1.w + b1.w;
         }
+        float rv[8];
         if (RES) {
             const h16x8 rh = *reinterpret_cast<const h16x8 *>(p.res + m * p.r_pix + co);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)rh[e];
+            for (int e = 0; e < 8; ++e) rv[e] = (float)rh[e];
             if (MODE == MODE_SPLIT) {
                 const h16x8 rl = *reinterpret_cast<const h16x8 *>(p.res_lo + m * p.r_pix + co);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)rl[e] * LO_INV;
+                for (int e = 0; e < 8; ++e) rv[e] += (float)rl[e] * LO_INV;
+            }
+            if (!p.res_post) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
             }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = act16<ACT>(v[e]);
+        if (RES && p.res_post) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
         if (OUT_F32) {
             float *o = p.y32 + m * p.y_pix + co;
             *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -603,7 +622,9 @@ extern "C" int tlk_conv2d_nhwc_16(const void *x_dev, const void *x_lo_dev, const
     if (n < 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0)
         return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: bad shape");
     if (cin % 8 != 0 || cout % 8 != 0) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: Cin and Cout must be multiples of 8 (pad with zero channels)");
-    if (act_kind < 0 || act_kind > 2) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: act_kind is 0 (none), 1 (ReLU) or 2 (SiLU)");
+    const int res_post = (act_kind & TLK_ACT_RES_AFTER) ? 1 : 0;
+    act_kind &= ~TLK_ACT_RES_AFTER;
+    if (act_kind < 0 || act_kind > 2) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: act_kind is 0 (none), 1 (ReLU) or 2 (SiLU), optionally | TLK_ACT_RES_AFTER");
     const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
     if (ho <= 0 || wo <= 0) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: empty output");
     if (n == 0) return TLK_OK;
@@ -621,6 +642,7 @@ extern "C" int tlk_conv2d_nhwc_16(const void *x_dev, const void *x_lo_dev, const
     a.x_pix = x_pix_stride > 0 ? x_pix_stride : cin;
     a.y_pix = y_pix_stride > 0 ? y_pix_stride : cout;
     a.r_pix = res_pix_stride > 0 ? res_pix_stride : cout;
+    a.res_post = res_post;
     if (a.x_pix < cin || a.y_pix < cout || a.r_pix < cout || (a.x_pix | a.y_pix | a.r_pix) % 8 != 0)
         return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: pixel strides must cover the channels and be multiples of 8");
     if (((uintptr_t)x_dev | (uintptr_t)x_lo_dev | (uintptr_t)w_dev | (uintptr_t)w_lo_dev | (uintptr_t)res_dev | (uintptr_t)res_lo_dev | (uintptr_t)y_dev |

@@ -4,7 +4,7 @@
 // grouped-convolution kernels + a separate bias / SiLU pass) spent 33 of the 76 ms of the config-4 pose forward (2400 crops, f16) here,
 // 18x above the HBM time of these layers.
 //
-// HBM-bound by construction: every input element is read from HBM once and every output element written once.
+// Every input element is read from HBM once and every output element written once:
 //   * one lane owns 16 bytes of channels (8 x f16 / 4 x f32) of ONE image column and marches down the rows of its strip; lanes are laid
 //     out (column, channel group) with the channel group fastest, so every wave-wide load / store is one contiguous run of the NHWC row;
 //   * the k taps of a row are k loads per lane (neighbouring lanes re-read the same lines: L1 hits, not HBM traffic), issued one row ahead
@@ -13,6 +13,10 @@
 //   * a ring of k partial output rows (fp32) collects the contributions: input row r adds its k taps into output rows r-k+1 .. r, the
 //     oldest of which is then complete -> + bias, activation, 16-byte store.  No halo is re-read inside a strip; strips (blockIdx.y)
 //     exist only to give small batches enough wavefronts and re-read k-1 rows each.
+// What bounds it (measured, profiles/r04_dwconv_spp.txt): 5 x 5 in f16 is 200 fp32-accumulating FMAs per 32 bytes moved -- 6.25 FMA / byte,
+// i.e. 25 TFMA/s at 4 TB/s against the 39 TFMA/s the VALUs issue -- so the kernel sits on VALU issue, not on HBM: 2.0 TB/s in f16 (time is
+// linear in the tap count: 14.8 us per tap + 184 us on 2400 x 64 x 48 x 48), 2.8 TB/s in fp32 (half the FMAs per byte), SiLU's exact
+// division another 14 %.  Still 9x faster than the library route (6.4 ms -> 0.72 ms per stage-1 layer).  Next: v_dot2_f32_f16 on tap pairs.
 // Arithmetic: fp32 accumulation for both element types (f16: v_fma_mix_f32 -- the f16 operands are read straight into an fp32 fma).
 // Each output element is ONE fmaf chain over (ky ascending, kx ascending), rows outside the image skipped, columns outside the image
 // entering as zero terms, then + bias, activation (oracle/src/conv.c: orc_dwconv2d_nhwc_f32 walks the same chain; fp32 results are

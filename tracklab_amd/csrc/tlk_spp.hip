@@ -4,7 +4,9 @@
 // wrappers/pose_estimator/rtmlib_api.py:21); the library route here was three max-pool launches + a concatenation copy (3.9 of the 45 ms of
 // the config-4 pose forward on 8 x 6 maps).
 //
-// HBM-bound: algorithmic bytes = 1 read + 4 writes of the map.  One lane owns 16 bytes of channels of one pixel; lanes are laid out
+// Algorithmic bytes = 1 read + 4 writes of the map; measured 0.5-1.2 TB/s on them (profiles/r04_dwconv_spp.txt: the 169-tap window walk with
+// three running maxima is VALU work, and the maps are small) -- 8.7x (pose, 8 x 6 maps) / 8.4x (YOLOX, 20 x 20) faster than three max_pool2d
+// launches + a concatenation.  One lane owns 16 bytes of channels of one pixel; lanes are laid out
 // (pixel, channel group) with the channel group fastest, so loads and stores are contiguous NHWC runs; the 13 x 13 window is walked once
 // (neighbours re-read the same lines from L1), rows / columns that no lane of the wavefront needs are skipped.  max is exact in every
 // precision, so the result is bit-identical to any other evaluation order (inputs must be NaN-free: the hardware max returns the number).
