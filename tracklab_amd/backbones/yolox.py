@@ -17,6 +17,11 @@ import torch.nn as nn
 from .common import ConvBiasAct as Conv
 from .common import finalize, random_init_, spp_concat
 
+import os as _os
+
+# CSPLayer: the two halves of the concatenation written in place by the convolutions that produce them (libtlk routes); 0 = torch.cat
+USE_SLICE_CONCAT = _os.environ.get("TLK_SLICE_CONCAT", "1") != "0"
+
 SIZES = {"tiny": (0.33, 0.375), "s": (0.33, 0.50), "m": (0.67, 0.75), "l": (1.0, 1.0), "x": (1.33, 1.25)}
 
 
@@ -28,9 +33,9 @@ class Bottleneck(nn.Module):
         self.conv2 = Conv(hidden, cout, 3)
         self.add = shortcut and cin == cout
 
-    def forward(self, x):
-        y = self.conv2(self.conv1(x))
-        return y + x if self.add else y
+    def forward(self, x, out=None):
+        # YOLOX Bottleneck: y = conv2(conv1(x)); y + x -- the add rides in conv2's epilogue (after its activation) where that is a libtlk kernel
+        return self.conv2(self.conv1(x), x if self.add else None, residual_after_act=True, out=out)
 
 
 class CSPLayer(nn.Module):
@@ -43,6 +48,17 @@ class CSPLayer(nn.Module):
         self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0) for _ in range(n)])
 
     def forward(self, x):
+        if USE_SLICE_CONCAT and self.conv2.writes_slices(x) and len(self.m) > 0:
+            # the concatenation is never copied: the last bottleneck and the shortcut convolution write their halves of it directly
+            n, _, h, w = x.shape
+            hid = self.conv2.conv.out_channels
+            y = torch.empty((n, 2 * hid, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            t = self.conv1(x)
+            for blk in list(self.m)[:-1]:
+                t = blk(t)
+            self.m[-1](t, out=y[:, :hid])
+            self.conv2(x, out=y[:, hid:])
+            return self.conv3(y)
         return self.conv3(torch.cat((self.m(self.conv1(x)), self.conv2(x)), dim=1))
 
 
