@@ -1,6 +1,7 @@
-"""PyTorch-ROCm backbones the adapters call: detector and ReID networks stay
-PyTorch (MIOpen / hipBLASLt); everything around them is libtlk. Random-init weights of the named
-architectures (no network access for checkpoints); BatchNorm is folded into the convolutions, as any
+"""The backbones the adapters call: network definitions as torch modules (device memory, streams, hipGraph capture); at
+fp32 -- the reference's precision -- every convolution, depthwise convolution and SPP block is a libtlk kernel (csrc/tlk_conv.hip,
+tlk_dwconv.hip, tlk_spp.hip), at f16 the wide layers stay on the tuned library route (MIOpen / CK / hipBLASLt + libtlk's fused epilogue).
+Random-init weights of the named architectures (no network access for checkpoints); BatchNorm is folded into the convolutions, as any
 inference deployment does."""
 import os as _os
 
