@@ -50,3 +50,13 @@ for name, n, c, h, w in ((f"RTMPose-m {B} crops", B, 384, 8, 6), (f"YOLOX-m {FR}
         by = 5.0 * x.numel() * es
         t_lib = timed(lambda: torch.cat([x] + [torch.nn.functional.max_pool2d(x, k, 1, k // 2) for k in (5, 9, 13)], 1))
         print(f"  {name:28s} {str(dt)[6:]:8s}: {t * 1e6:8.1f} us  {by / 1e6:7.1f} MB -> {by / t / 1e9:7.1f} GB/s   (three max_pool2d + cat: {t_lib * 1e6:8.1f} us)")
+
+print("bias + activation (+ residual) epilogue pass of the f16 library route (tlk_bias_act_nhwc, in place): algorithmic bytes = read + write (+ residual read)")
+for name, shape in (("ReID layer1 3x3 out", (B, 64, 96, 32)), ("ReID layer1 expansion out + residual", (B, 256, 96, 32)), ("ReID layer4 3x3 out", (B, 512, 24, 8)),
+                    ("YOLOX-m stem out", (FR, 48, 320, 320))):
+    x = torch.randn(*shape, device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(shape[1], device="cuda", dtype=torch.float16)
+    r = torch.randn_like(x) if "residual" in name else None
+    t = timed(lambda: _lib.bias_act_(x, b, "relu", r))
+    by = (3.0 if r is not None else 2.0) * x.numel() * 2
+    print(f"  {name:38s}: {t * 1e6:8.1f} us  {by / 1e6:8.1f} MB -> {by / t / 1e9:7.1f} GB/s = {by / t / 8e12:.2f} of 8 TB/s")
