@@ -24,6 +24,11 @@ md = ["# r04 -- association kernels alone (tests/perf/bench_trackers.py 120 64):
       "| tracker | streams | us per frame and launch | frames/s | C oracle frames/s (1 thread) |", "|---|---|---|---|---|"]
 for r in rows:
     md.append(f"| {r['tracker']} | {r['streams']} | {r['gpu_us_per_frame_per_launch']:.1f} | {r['gpu_frames_per_s']:.0f} | {r.get('cpu_oracle_frames_per_s', float('nan')):.1f} |")
-open(os.path.join(dst, "r04_trackers.md"), "w").write("\n".join(md) + "\n")
+open(os.path.join(dst, "r04_trackers.md"), "w").write("\n".join(md).replace("| nan |", "| – |") + "\n")
 shutil.copy(os.path.join(src, "decode_nms.txt"), os.path.join(dst, "r04_decode_nms.txt"))
+for name, out, head in (("pose_f16.txt", "r04_pose_forward_f16.txt", "python tools/probe_rtmpose.py 2400 f16 3 -- RTMPose-m forward of config 4 alone (2400 crops, f16), events around the modules (eager)"),
+                        ("fuzz_gpu.txt", "r04_fuzz_gpu.txt", "python tools/fuzz_gpu.py 300; FUZZ_MAX_OBJECTS=320 FUZZ_BIG_CAPACITY=1 python tools/fuzz_gpu.py 20 ocsort bytetrack botsort deepocsort -- "
+                                                              "every tracker bank vs the C oracle on random hyper-parameters x random crowded streams (second command: banks of 4096 x 512, scenes beyond the LDS tiers)")):
+    if os.path.exists(os.path.join(src, name)):
+        open(os.path.join(dst, out), "w").write(head + "\n" + open(os.path.join(src, name)).read())
 print(open(os.path.join(dst, "r04_config3_f32_rocprof.md")).read()[:3000])

@@ -22,6 +22,13 @@ oracle.build()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 WHICH = sys.argv[2:] or ["ocsort", "bytetrack", "bpbss", "botsort", "deepocsort", "ssort"]
 BIG = int(os.environ.get("FUZZ_MAX_OBJECTS", "130"))
+# FUZZ_BIG_CAPACITY=1 (with FUZZ_MAX_OBJECTS of a few hundred): banks allocated at 4096 tracks / 512 detections, so that crowded trials leave the
+# LDS tiers and run their per-frame lists and assignment problems out of HBM (r04 capacity tiers)
+BIGCAP = os.environ.get("FUZZ_BIG_CAPACITY", "0") != "0"
+
+
+def cap(t, d):
+    return dict(max_tracks=4096, max_dets=512) if BIGCAP else dict(max_tracks=t, max_dets=d)
 STATS = {}
 
 
@@ -50,7 +57,7 @@ def fuzz_ocsort(t, rng):
     hp = dict(det_thresh=float(rng.choice([0.0, 0.3, 0.5])), max_age=int(rng.integers(3, 40)), min_hits=int(rng.integers(1, 4)),
               iou_threshold=float(rng.uniform(0.15, 0.4)), delta_t=int(rng.integers(1, 4)), asso_func=str(rng.choice(["iou", "giou", "diou", "ciou", "ct_dist"])),
               inertia=float(rng.uniform(0.0, 0.5)), use_byte=bool(rng.random() < 0.4))
-    bank, ref = _lib.OCSortBank(**hp, min_confidence=0.4, wrapper_mode=True, max_tracks=512, max_dets=256), oracle.OCSort(**hp)
+    bank, ref = _lib.OCSortBank(**hp, min_confidence=0.4, wrapper_mode=True, **cap(512, 256)), oracle.OCSort(**hp)
     try:
         for fr in SyntheticStream(5000 + t, nobj(rng, 5), 120, **stream_kw(rng)):
             d = fr["dets"]
@@ -71,7 +78,7 @@ def fuzz_ocsort(t, rng):
 
 def fuzz_bytetrack(t, rng):
     hp = dict(track_thresh=float(rng.uniform(0.3, 0.7)), match_thresh=float(rng.uniform(0.5, 0.95)), track_buffer=int(rng.integers(3, 40)), frame_rate=int(rng.choice([15, 30])))
-    bank, ref = _lib.ByteTrackBank(**hp, max_tracks=384, max_dets=128), oracle.ByteTrack(**hp)
+    bank, ref = _lib.ByteTrackBank(**hp, **cap(384, 128)), oracle.ByteTrack(**hp)
     try:
         for fr in SyntheticStream(1000 + t, min(nobj(rng, 5), 120), 120, **stream_kw(rng)):
             d = fr["dets"][fr["dets"][:, 4] > 0.4]
@@ -101,7 +108,7 @@ def fuzz_bpbss(t, rng):
                min_bbox_confidence=float(rng.choice([0.0, 0.5])), only_position_for_kf_gating=bool(rng.random() < 0.3),
                max_kalman_prediction_without_update=int(rng.integers(0, 8)), matching_strategy=str(rng.choice(["strong_sort_matching", "bot_sort_matching"])),
                gating_thres_factor=float(rng.choice([1, 1.5])), w_kfgd=1, w_reid=1, w_st=1)
-    bank, ref = _lib.BpbssBank(K, D, **cfg, max_tracks=1024, max_dets=256), oracle.StrongSORT(K, D, **cfg)
+    bank, ref = _lib.BpbssBank(K, D, **cfg, **cap(1024, 256)), oracle.StrongSORT(K, D, **cfg)
     try:
         for fr in SyntheticStream(6000 + t, nobj(rng, 5), 100, parts=K, dim=D, with_embeddings=True, **stream_kw(rng)):
             d = fr["dets"]
@@ -126,7 +133,7 @@ def fuzz_botsort(t, rng):
     hp = dict(track_high_thresh=float(rng.uniform(0.3, 0.7)), new_track_thresh=float(rng.uniform(0.3, 0.8)), track_buffer=int(rng.integers(3, 40)),
               match_thresh=float(rng.uniform(0.3, 0.9)), proximity_thresh=float(rng.uniform(0.3, 0.7)), appearance_thresh=float(rng.uniform(0.1, 0.5)),
               frame_rate=30, lambda_=float(rng.uniform(0.9, 0.995)))
-    bank, ref = _lib.BoTSORTBank(D, **hp, max_tracks=384, max_dets=128), oracle.BoTSORT(D, **hp)
+    bank, ref = _lib.BoTSORTBank(D, **hp, **cap(384, 128)), oracle.BoTSORT(D, **hp)
     try:
         for fr in SyntheticStream(2000 + t, min(nobj(rng, 5), 120), 120, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
             keep = fr["dets"][:, 4] > 0.4
@@ -156,7 +163,7 @@ def fuzz_deepocsort(t, rng):
               iou_threshold=float(rng.uniform(0.15, 0.4)), delta_t=int(rng.integers(1, 4)), asso_func=str(rng.choice(["iou", "giou", "diou", "ciou"])),
               inertia=float(rng.uniform(0.0, 0.5)), w_association_emb=float(rng.uniform(0.2, 1.0)), alpha_fixed_emb=float(rng.uniform(0.8, 0.98)),
               aw_param=float(rng.uniform(0.3, 0.7)), embedding_off=False, cmc_off=True, aw_off=bool(rng.random() < 0.3), new_kf_off=False)
-    bank, ref = _lib.DeepOCSortBank(D, **hp, max_tracks=384, max_dets=128), oracle.DeepOCSort(D, **hp)
+    bank, ref = _lib.DeepOCSortBank(D, **hp, **cap(384, 128)), oracle.DeepOCSort(D, **hp)
     normed = rng.random() < 0.7
     try:
         for fr in SyntheticStream(3000 + t, min(nobj(rng, 5), 120), 120, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):
@@ -184,7 +191,7 @@ def fuzz_ssort(t, rng):
     hp = dict(max_dist=float(rng.uniform(0.1, 0.4)), max_iou_dist=float(rng.uniform(0.5, 0.9)), max_age=int(rng.integers(3, 40)),
               max_unmatched_preds=int(rng.integers(0, 8)), n_init=int(rng.integers(1, 4)), nn_budget=int(rng.integers(2, 30)),
               mc_lambda=float(rng.uniform(0.9, 0.999)), ema_alpha=float(rng.uniform(0.8, 0.95)))
-    bank, ref = _lib.SsortBank(D, **hp, max_tracks=512, max_dets=256), oracle.PlainStrongSORT(D, **hp, img_w=1920, img_h=1080)
+    bank, ref = _lib.SsortBank(D, **hp, **cap(512, 256)), oracle.PlainStrongSORT(D, **hp, img_w=1920, img_h=1080)
     try:
         for fr in SyntheticStream(4000 + t, min(nobj(rng, 5), 60), 60, parts=1, dim=D, with_embeddings=True, **stream_kw(rng)):      # (the C oracle of this tracker is the slow side)
             d, e = fr["dets"], fr["embeddings"][:, 0, :].astype(np.float32)

@@ -18,6 +18,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_f32" -- \
 find "$OUT" -name '*kernel_trace.csv' -delete
 cd "$R"; python tests/perf/bench_trackers.py 120 64 > "$OUT/trackers.log" 2>&1
 python tools/probe_decode_nms.py > "$OUT/decode_nms.txt" 2>&1
+python tools/probe_rtmpose.py 2400 f16 3 2>&1 | grep -v amdgpu.ids > "$OUT/pose_f16.txt"
+(timeout 400 python tools/fuzz_gpu.py 300; FUZZ_MAX_OBJECTS=320 FUZZ_BIG_CAPACITY=1 timeout 300 python tools/fuzz_gpu.py 20 ocsort bytetrack botsort deepocsort) 2>&1 | grep "trials\|DIVERGENCE" > "$OUT/fuzz_gpu.txt"
+cat "$OUT/fuzz_gpu.txt"
 for f in "$OUT"/bench_*.json; do python - "$f" <<'PY'
 import json, sys, os
 try:
