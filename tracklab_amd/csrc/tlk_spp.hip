@@ -32,7 +32,16 @@ template <typename V> __device__ __forceinline__ V vmax(V a, V b) { return __bui
 template <typename T, typename V, int VN>
 __global__ void __launch_bounds__(256) spp_kernel(const SppArgs p)
 {
-    const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+    // XCD-aware block order: the hardware deals consecutive workgroups round-robin to the 8 XCDs (each with its own L2); give every XCD a
+    // contiguous run of blocks, so that the workgroups sharing a map / neighbouring columns read it through ONE L2 (measured before: the
+    // 8 x 6 pose maps were fetched from memory 8 times, once per XCD)
+    long long blk;
+    {
+        const long long b = blockIdx.x, q = (long long)gridDim.x >> 3;
+        const int r = (int)(gridDim.x & 7), xcd = (int)(b & 7);
+        blk = (long long)xcd * q + (xcd < r ? xcd : r) + (b >> 3);
+    }
+    const long long item = blk * 256 + threadIdx.x;
     const bool live = item < p.items;
     const long long it = live ? item : p.items - 1;
     const int cg = (int)(it % p.CG);
