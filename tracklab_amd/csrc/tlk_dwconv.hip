@@ -203,9 +203,7 @@ extern "C" int tlk_dwconv2d_nhwc(const void *x_dev, const void *w_dev, const flo
     if (n < 0 || h <= 0 || w <= 0 || c <= 0 || c % v != 0) return fail(TLK_EINVAL, "tlk_dwconv2d_nhwc: channels must be a positive multiple of 16 bytes");
     const int xp = x_pix_stride ? x_pix_stride : c, yp = y_pix_stride ? y_pix_stride : c;
     if (xp < c || yp < c || xp % v != 0 || yp % v != 0) return fail(TLK_EINVAL, "tlk_dwconv2d_nhwc: pixel strides must be >= channels and multiples of 16 bytes");
-    const size_t es = dtype == TLK_F16 ? 2 : 4;
     if (((uintptr_t)x_dev | (uintptr_t)w_dev | (uintptr_t)y_dev) & 15) return fail(TLK_EINVAL, "tlk_dwconv2d_nhwc: x, w, y must be 16-byte aligned");
-    (void)es;
     if (n == 0) return TLK_OK;
     DwArgs a;
     a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.y = y_dev;
