@@ -727,12 +727,28 @@ def main():
         from tracklab_amd.backbones import common as bc
         if bc.USE_TLK_CONV_F32:
             lb_v, crops_v = pipe.lb.permute(0, 3, 1, 2), pipe.crops.permute(0, 3, 1, 2)     # logical NCHW views of the step's channels-last buffers
+            # r05: the ReID batch is dense -- the convolutions run on the step's REAL crops (pipe.n_live, read on the device), and the flops counted
+            # below are those crops', not the B x max_dets slots of the buffer
+            dense = bool(getattr(pipe, "dense_reid", False))
+            live_crops = int(pipe.n_live.item()) if dense else B * pipe.maxd
+            from tracklab_amd import _lib as _tl
+
+            def reid_eager():
+                if dense:
+                    _tl.conv_set_dynamic_batch(pipe.n_live)
+                    bc.LIVE_BATCH = (B * pipe.maxd, live_crops)
+                try:
+                    pipe.reid(crops_v)
+                finally:
+                    if dense:
+                        _tl.conv_set_dynamic_batch(None)
+                        bc.LIVE_BATCH = None
             with torch.no_grad():
-                pipe.model(lb_v, focused=True); pipe.reid(crops_v)                 # warm (eager)
+                pipe.model(lb_v, focused=True); reid_eager()                       # warm (eager)
                 torch.cuda.synchronize()
                 bc.CONV_TIMER = []
                 for _ in range(2):
-                    pipe.model(lb_v, focused=True); pipe.reid(crops_v)
+                    pipe.model(lb_v, focused=True); reid_eager()
                     if pipe.pose is not None:
                         pipe.pose(pipe.pose_crops.permute(0, 3, 1, 2))
                 torch.cuda.synchronize()
@@ -757,8 +773,11 @@ def main():
                         "launches_per_step": len(recs) // 2, "avg_launch_ms": (c_ms - c_null) / len(recs), "avg_launch_ms_events_raw": c_ms / len(recs),
                         "event_pair_overhead_ms": c_null / len(recs), "algorithmic_flops_per_launch": c_flop / len(recs),
                         "algorithmic_tflop_per_step": c_flop / 2 / 1e12, "conv_ms_per_step": (c_ms - c_null) / 2,
-                        "units_per_launch": f"one convolution of the step: {B} frames (detector) or {B} x {pipe.maxd} crop slots (ReID); mean over the "
-                                            f"{len(recs) // 2} convolutions of a step, flop-weighted",
+                        "units_per_launch": (f"one convolution of the step: {B} frames (detector) or the step's {live_crops} REAL crops (ReID, dense batch: "
+                                             f"{live_crops / B:.1f} per frame of {pipe.maxd} slots)" if dense else
+                                             f"one convolution of the step: {B} frames (detector) or {B} x {pipe.maxd} crop slots (ReID)") +
+                                            f"; mean over the {len(recs) // 2} convolutions of a step, flop-weighted",
+                        "reid_crops_per_step": live_crops, "reid_crop_slots_per_step": B * pipe.maxd,
                         "peak_source": "MI355X_MICROARCH.md: fp32-input MFMA 157.3 TFLOP/s dense (no reduced-precision fp32 path on gfx950)",
                         "per_instantiation": per_inst,
                         "rocprofv3": "profiles/r04_config3_f32_rocprof.md: average duration of the same instantiations in the rocprofv3 --kernel-trace "

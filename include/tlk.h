@@ -30,6 +30,7 @@ extern "C" {
 #define TLK_ECAPACITY (-3)  /* more tracks / detections than the handle was created for */
 #define TLK_ENODEVICE (-4)  /* no usable gfx950 device */
 #define TLK_EUNSUPPORTED (-5) /* an optional library route is not available (callers keep their other GPU route) */
+#define TLK_EINTERNAL (-6)  /* a bounded device loop hit its bound: solver / tracker state no consistent run can produce (r05) */
 
 const char *tlk_last_error(void);
 int tlk_version(void);               /* 10000*major + 100*minor + patch */
@@ -51,10 +52,18 @@ int tlk_iou_matrix_f64(int variant, const double *b1_dev, int n, const double *b
  * plugins/track/bpbreid_strong_sort/sort/linear_assignment.py:56.
  * Batched: `batch` independent problems, cost_dev (batch, nr, nc). rows/cols_dev
  * (batch, min(nr,nc)) int32, pairs sorted by row; n_pairs_dev (batch) int32 (= min(nr,nc), or
- * -1 infeasible / -2 NaN or -inf in the input). One wavefront solves one problem.
+ * -1 infeasible / -2 NaN or -inf in the input / -3 the solver hit a loop bound no consistent state reaches, see below).
+ * One wavefront solves one problem.
  * ------------------------------------------------------------------------------------------ */
 int tlk_lsa_f64(const double *cost_dev, int batch, int nr, int nc, int32_t *rows_dev, int32_t *cols_dev,
                 int32_t *n_pairs_dev, void *hip_stream);
+
+/* Every data-dependent loop of the device-side assignment solver is bounded (r05): the column scan by the number of columns, the
+ * augmenting-path walk by the number of rows, every index it follows by its range.  A bound that trips means the solver's work area
+ * was corrupted under it; tlk_lsa_f64 then reports n_pairs = -3 and the tracker banks poison the stream: tlk_*_update returns
+ * TLK_EINTERNAL (tlk_*_update_dev writes it to out_counts) until the stream is reset.  This TEST HOOK lowers the walk's cap to
+ * `hops` steps for tlk_lsa_f64 (0 restores the natural bound) so the exit can be exercised on purpose. */
+int tlk_debug_lsa_hop_limit(int hops);
 
 /* `list(set(a) - set(b))` in the order CPython 3.10 iterates the result set -- how both StrongSORT plugins build the
  * unmatched-track list of their matching cascade (plugins/track/strong_sort/sort/linear_assignment.py:126-127,
@@ -469,6 +478,17 @@ int tlk_letterbox_u8(const uint8_t *frames_dev, int batch, int h, int w, int siz
 int tlk_roi_crop_resize_norm(const uint8_t *frames_dev, int batch, int h, int w, const float *boxes_ltwh_dev,
                              const int32_t *counts_dev, int max_n, int out_h, int out_w, const float *mean3,
                              const float *std3, int layout, int dtype, void *out_dev, void *hip_stream);
+
+/* The same crops written as a DENSE batch (r05; the reference's ReID wrapper batches real detections only,
+ * tracklab/wrappers/reid/kpreid_api.py:147-182): crop i of frame b lands at slot slot_base_dev[b] + i, padding slots are not written anywhere.
+ * tlk_crop_slot_bases fills base_dev (batch) = exclusive prefix sums of the counts (clamped to [0, max_n]), total_dev (1) = their sum, and --
+ * when slot_of_dev is not NULL -- slot_of_dev (batch * max_n) int64 = position of (b, i) in the dense batch (a valid position for padding
+ * slots too: consumers gather rows through it and ignore i >= counts[b]). The ReID convolutions then run on total_dev[0] images
+ * (tlk_conv_set_dynamic_batch) instead of batch * max_n slots. */
+int tlk_crop_slot_bases(const int32_t *counts_dev, int batch, int max_n, int32_t *base_dev, int32_t *total_dev, int64_t *slot_of_dev, void *hip_stream);
+int tlk_roi_crop_resize_norm_compact(const uint8_t *frames_dev, int batch, int h, int w, const float *boxes_ltwh_dev,
+                                     const int32_t *counts_dev, const int32_t *slot_base_dev, int max_n, int out_h, int out_w, const float *mean3,
+                                     const float *std3, int layout, int dtype, void *out_dev, void *hip_stream);
 
 /* Plain StrongSORT's ReID input. Replaces StrongSORT._get_features' crop loop
  * (plugins/track/strong_sort/strong_sort.py:135-141 with _xywh_to_xyxy :102-108: int-truncated box clipped to

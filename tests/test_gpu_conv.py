@@ -55,6 +55,44 @@ def test_conv_is_bit_exact_with_the_oracle_chain(case, cfg):
     assert np.array_equal(got, exp), f"max |diff| {np.abs(got - exp).max()}"
 
 
+@pytest.mark.parametrize("live", [0, 1, 5, 12, 13, 40])
+def test_dynamic_batch_computes_the_live_images_only(live):
+    """r05 (dense ReID batch): with tlk_conv_set_dynamic_batch the kernels take the image count from device memory when they RUN; the n of the
+    call is the capacity.  The live images' outputs are bit-identical to a static launch, nothing beyond them is written, and a count beyond
+    the capacity is clamped to it.  fp32 kernel and both 16-bit modes."""
+    from tracklab_amd import _lib
+    torch.manual_seed(live)
+    n, h, w, cin, cout = 13, 12, 9, 64, 128
+    x = torch.randn(n, cin, h, w, device="cuda").contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cout, cin, 3, 3, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(cout, device="cuda")
+    r = torch.randn(n, cout, h, w, device="cuda").contiguous(memory_format=torch.channels_last)
+    full = _lib.conv2d_nhwc_f32(x, wt, b, "relu", r, stride=1, pad=1)
+    n_live = torch.tensor([live], dtype=torch.int32, device="cuda")
+    out = torch.full_like(full, -3.0)
+    _lib.conv_set_dynamic_batch(n_live)
+    try:
+        _lib.conv2d_nhwc_f32(x, wt, b, "relu", r, stride=1, pad=1, out=out)
+    finally:
+        _lib.conv_set_dynamic_batch(None)
+    torch.cuda.synchronize()
+    k = min(live, n)
+    assert torch.equal(out[:k], full[:k])
+    assert (out[k:] == -3.0).all()
+    # 16-bit kernels (f16 mode): same contract
+    xh, wh = x.half(), wt.half()
+    full16 = _lib.conv2d_nhwc_16(xh, wh, b, "relu", r.half(), stride=1, pad=1)
+    out16 = torch.full_like(full16, -3.0)
+    _lib.conv_set_dynamic_batch(n_live)
+    try:
+        _lib.conv2d_nhwc_16(xh, wh, b, "relu", r.half(), stride=1, pad=1, out=out16)
+    finally:
+        _lib.conv_set_dynamic_batch(None)
+    torch.cuda.synchronize()
+    assert torch.equal(out16[:k], full16[:k])
+    assert (out16[k:] == -3.0).all()
+
+
 def test_residual_after_the_activation_is_bit_exact_with_the_oracle():
     """TLK_ACT_RES_AFTER: y = act(conv + bias) + r -- CSPNeXt's identity add riding in the pointwise convolution's epilogue"""
     import oracle

@@ -80,6 +80,52 @@ def test_crop_resize_norm_matches_oracle(orc, oh, ow, layout):
         np.testing.assert_array_equal(outbf[b * MAXN:b * MAXN + n].float().cpu().numpy(), ebf)
 
 
+@pytest.mark.parametrize("oh,ow,dtype_name", [(384, 128, "float32"), (384, 128, "float16"), (256, 192, "float32")])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_dense_crop_batch_equals_the_slot_layout_row_for_row(oh, ow, dtype_name, layout):
+    """r05: tlk_roi_crop_resize_norm_compact writes crop i of frame b at slot_base[b] + i (tlk_crop_slot_bases) -- the same pixels as the
+    slot layout (itself bit-exact against the oracle above), no write outside the dense rows; every crop kernel (wave2 fp32, wave3 16-bit,
+    the general one at 192 columns)."""
+    import torch
+    from tracklab_amd import _lib
+    rng = np.random.default_rng(91)
+    B, H, W, MAXN = 5, 1080, 1920, 24
+    dtype = getattr(torch, dtype_name)
+    frames = torch.from_numpy(_frames(rng, B, H, W)).cuda()
+    boxes = np.stack([np.stack([rng.uniform(-30, W - 20, MAXN), rng.uniform(-30, H - 20, MAXN), rng.uniform(2, 300, MAXN), rng.uniform(2, 500, MAXN)], 1)
+                      for _ in range(B)]).astype(np.float32)
+    counts = np.array([MAXN, 0, 17, 1, 9], dtype=np.int32)
+    db, dc = torch.from_numpy(boxes).cuda(), torch.from_numpy(counts).cuda()
+    base, total, slot_of = _lib.crop_slot_bases(dc, MAXN)
+    assert base.cpu().tolist() == [0, 24, 24, 41, 42] and int(total.item()) == 51
+    so = slot_of.cpu().numpy().reshape(B, MAXN)
+    for b in range(B):
+        np.testing.assert_array_equal(so[b, :counts[b]], base[b].item() + np.arange(counts[b]))
+        assert (so[b, counts[b]:] == 50).all()                    # padding slots point at a valid row
+    slots = _lib.roi_crop_resize_norm(frames, db, dc, oh, ow, layout, dtype)
+    dense = torch.full_like(slots, 7.0)
+    _lib.roi_crop_resize_norm(frames, db, dc, oh, ow, layout, dtype, out=dense if layout == "nchw" else dense.permute(0, 2, 3, 1), slot_base=base)
+    torch.cuda.synchronize()
+    for b in range(B):
+        n, b0 = int(counts[b]), int(base[b])
+        assert torch.equal(dense[b0:b0 + n], slots[b * MAXN:b * MAXN + n])
+    assert (dense[51:] == 7.0).all()
+
+
+def test_crop_slot_bases_counts_beyond_one_wavefront():
+    import torch
+    from tracklab_amd import _lib
+    rng = np.random.default_rng(3)
+    counts = rng.integers(-2, 140, 200).astype(np.int32)          # negative / beyond max_n are clamped
+    base, total, slot_of = _lib.crop_slot_bases(torch.from_numpy(counts).cuda(), 104)
+    c = np.clip(counts, 0, 104)
+    np.testing.assert_array_equal(base.cpu().numpy(), np.cumsum(c) - c)
+    assert int(total.item()) == int(c.sum())
+    so = slot_of.cpu().numpy().reshape(200, 104)
+    for b in (0, 63, 64, 199):
+        np.testing.assert_array_equal(so[b, :c[b]], (np.cumsum(c) - c)[b] + np.arange(c[b]))
+
+
 from tracklab_amd.synth import synth_yolox_head as synth_head  # noqa: E402
 
 

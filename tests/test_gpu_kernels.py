@@ -67,6 +67,36 @@ def test_lsa_golden_and_known_answers():
         assert list(r[0, :n[0]]) == case["rows"] and list(cc[0, :n[0]]) == case["cols"]
 
 
+def test_lsa_bounded_walk_trips_loudly_instead_of_spinning():
+    """r05: every data-dependent loop of the device-side solver is bounded; the augmenting-path walk gives up with
+    n_pairs = -3 (TLK_EINTERNAL in the tracker banks) when it exceeds its bound.  The natural bound (number of rows) cannot trip on a
+    consistent state, so the test hook lowers it: with a cap of 1 hop every problem whose augmentation re-assigns more than one row must
+    report -3 -- and return, not hang -- while the others still give scipy's answer; cap 0 restores the solver."""
+    from scipy.optimize import linear_sum_assignment
+    from tracklab_amd._lib import check, lib
+    rng = np.random.default_rng(5)
+    costs = rng.uniform(0, 1, (32, 100, 100))
+    # (600 x 600: the LDS-array solver tier, 100 x 100: the register tier)
+    big = rng.uniform(0, 1, (4, 600, 600))
+    try:
+        check(lib().tlk_debug_lsa_hop_limit(1))
+        for batch in (costs, big):
+            r, c, n = _lsa_gpu(batch)
+            assert (n == -3).any(), "no augmenting path longer than one hop in random problems?"
+            for b in np.nonzero(n >= 0)[0]:
+                rr, cc = linear_sum_assignment(batch[b])
+                np.testing.assert_array_equal(c[b, :n[b]], cc)
+    finally:
+        check(lib().tlk_debug_lsa_hop_limit(0))
+    r, c, n = _lsa_gpu(costs)
+    assert (n == 100).all()
+    for b in range(len(costs)):
+        rr, cc = linear_sum_assignment(costs[b])
+        np.testing.assert_array_equal(c[b], cc)
+    with pytest.raises(Exception):
+        check(lib().tlk_debug_lsa_hop_limit(-1))
+
+
 @pytest.mark.parametrize("shape", [(100, 100), (100, 130), (130, 100), (7, 200), (256, 256)])
 def test_lsa_batched_vs_scipy(shape):
     from scipy.optimize import linear_sum_assignment

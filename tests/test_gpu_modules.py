@@ -155,3 +155,50 @@ def test_hip_botsort_module_end_to_end_on_device(orc):
             np.testing.assert_array_equal(np.stack(out.track_bbox_ltwh.to_list())[:, :2], exp[:, :2])
             n_rows += len(exp)
     assert n_rows > 50
+
+
+def test_weight_derived_caches_follow_a_checkpoint_loaded_after_the_first_forward():
+    """the padded RGB stem weight, the fp32 bias of the f16 route, the split-precision weight planes, the depthwise taps and
+    the Toeplitz form of RTMPose's last layer are cached per module.  The caches are keyed on the parameters' storage and version counter: a
+    state dict loaded AFTER a forward (or a deepcopy of a warmed-up module) must give what a fresh module with those weights gives."""
+    import copy
+    import torch
+    from tracklab_amd.backbones.common import ConvBiasAct, SplitAct
+    from tracklab_amd.backbones.rtmpose import DWConvBiasAct, rtmpose
+    torch.manual_seed(0)
+
+    def rand_state(m):
+        return {k: torch.randn_like(v) * 0.2 for k, v in m.state_dict().items()}
+
+    def check(make, x, prep=lambda t: t, post=lambda y: y):
+        m = make()
+        y0 = post(m(prep(x)))
+        sd = rand_state(m)
+        m.load_state_dict(sd)
+        y1 = post(m(prep(x)))
+        fresh = make()
+        fresh.load_state_dict(sd)
+        y2 = post(fresh(prep(x)))
+        assert torch.equal(y1, y2), "stale weight-derived cache after load_state_dict"
+        assert not torch.equal(y0, y1)
+        m2 = copy.deepcopy(m)
+        m2.load_state_dict(rand_state(m2))
+        assert not torch.equal(post(m2(prep(x))), y1), "deepcopy carried a stale cache"
+
+    x3 = torch.randn(2, 3, 16, 12, device="cuda").contiguous(memory_format=torch.channels_last)
+    check(lambda: ConvBiasAct(3, 16, 3, 1, "relu").cuda().to(memory_format=torch.channels_last), x3)                      # _w4 (RGB stem, fp32)
+    x16 = torch.randn(2, 16, 8, 8, device="cuda").half().contiguous(memory_format=torch.channels_last)
+    check(lambda: ConvBiasAct(16, 16, 1, 1, "silu").cuda().half().to(memory_format=torch.channels_last), x16)             # _bias32 (narrow f16 route)
+    x32 = torch.randn(2, 32, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
+    check(lambda: ConvBiasAct(32, 64, 3, 1, "relu").cuda().to(memory_format=torch.channels_last), x32,
+          prep=lambda t: SplitAct.from_f32(t, 32), post=lambda y: y.merge())   # _w_split
+    check(lambda: DWConvBiasAct(16, 16, 5).cuda().half().to(memory_format=torch.channels_last), x16)                      # _dw_taps
+    net = rtmpose("t", device="cuda", dtype=torch.float16)
+    xin = torch.randn(2, 3, 256, 192, device="cuda").half().contiguous(memory_format=torch.channels_last)
+    a0 = net(xin)[0].clone()
+    sd = {k: (v + 0.05 * torch.randn_like(v.float()).to(v.dtype)) if v.is_floating_point() else v for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    a1 = net(xin)[0]
+    fresh = rtmpose("t", device="cuda", dtype=torch.float16)
+    fresh.load_state_dict(sd)
+    assert torch.equal(a1, fresh(xin)[0]) and not torch.equal(a0, a1)                                                     # _final_gemm + every cache above

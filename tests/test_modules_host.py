@@ -415,3 +415,22 @@ def test_bytetrack_module_host_logic_with_oracle_backend(orc):
         np.testing.assert_array_equal(np.stack(out.track_bbox_ltwh.to_list()),
                                       np.stack([exp[:, 0], exp[:, 1], exp[:, 2] - exp[:, 0], exp[:, 3] - exp[:, 1]], axis=1))
     assert n_rows > 300
+
+
+def test_unpinned_camera_motion_warns_once_per_estimator(caplog):
+    """the shipped yamls carry the reference's camera-motion defaults while the OpenCV restatement is unpinned in this image: the
+    wrapper says so once per process and estimator, and stays silent where the cv2 fixture exists."""
+    import logging
+    import os
+    from tracklab_amd.wrappers import track
+    fixture = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "cmc_opencv.npz")
+    track._CAMERA_MOTION_WARNED.clear()
+    with caplog.at_level(logging.WARNING, logger=track.__name__):
+        track._warn_unpinned_camera_motion("HipBoTSORT")
+        track._warn_unpinned_camera_motion("HipBoTSORT")
+        track._warn_unpinned_camera_motion("HipStrongSORT")
+    msgs = [r.getMessage() for r in caplog.records]
+    if os.path.exists(fixture):
+        assert msgs == []
+    else:
+        assert len(msgs) == 2 and "UNPINNED" in msgs[0] and "cmc_method: none" in msgs[0] and "ecc: false" in msgs[1]

@@ -116,3 +116,21 @@ def test_layout_is_what_process_trackeval_results_reads():
         for k, v in fields.items():
             assert isinstance(v, str) and (float(v) if "." in v else int(float(v))) is not None, (fam, k, v)
     assert float(res["SUMMARIES"]["pedestrian"]["HOTA"]["HOTA"]) == pytest.approx(100 * float(np.mean(ped["HOTA"]["HOTA"])), rel=1e-4)
+
+
+def test_summaries_carry_trackevals_summary_fields_only():
+    """TrackEval's CLEAR.summary_fields are the main float + main integer fields; CLR_F1, FP_per_frame, MOTAL, MOTP_sum and CLR_Frames are
+    per-sequence detail and do not reach the SUMMARIES block (which process_trackeval_results forwards to the loggers).  CLR_Frames is set on
+    the full path of eval_sequence only: TrackEval's two early returns leave it at 0."""
+    gt_fr, pr_fr = _stream(5)
+    g, t, sims = hota.sequence_from_rows(gt_fr, pr_fr)
+    seqs = {"s": dict(te.evaluate_sequence_frames(gt_fr, pr_fr), hota=hota.pack(hota.hota_sequence(g, t, sims), frames=len(gt_fr)))}
+    summ = te.trackeval_layout(seqs)["SUMMARIES"]["pedestrian"]
+    assert list(summ["CLEAR"]) == ["MOTA", "MOTP", "MODA", "CLR_Re", "CLR_Pr", "MTR", "PTR", "MLR", "sMOTA", "CLR_TP", "CLR_FN", "CLR_FP", "IDSW", "MT", "PT",
+                                   "ML", "Frag"]
+    assert list(summ["Identity"]) == ["IDF1", "IDR", "IDP", "IDTP", "IDFN", "IDFP"]
+    assert list(summ["HOTA"]) == ["HOTA", "DetA", "AssA", "DetRe", "DetPr", "AssRe", "AssPr", "LocA", "OWTA", "HOTA(0)", "LocA(0)", "HOTALocA(0)"]
+    e = np.zeros(0, np.int64)
+    assert te.clear_eval_sequence([np.array([0, 1])] * 3, [e] * 3, [np.zeros((2, 0))] * 3)["CLR_Frames"] == 0
+    assert te.clear_eval_sequence([e] * 3, [np.array([0])] * 3, [np.zeros((0, 1))] * 3)["CLR_Frames"] == 0
+    assert seqs["s"]["CLEAR"]["CLR_Frames"] == len(gt_fr)

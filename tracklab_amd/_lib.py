@@ -174,6 +174,11 @@ def _bind_image(L):
     L.tlk_roi_crop_resize_norm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
                                            C.c_int, C.c_void_p, C.c_void_p]
+    L.tlk_roi_crop_resize_norm_compact.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                   C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
+                                                   C.c_int, C.c_void_p, C.c_void_p]
+    L.tlk_crop_slot_bases.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tlk_conv_set_dynamic_batch.argtypes = [C.c_void_p]
     L.tlk_yolox_decode_nms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_void_p]
@@ -207,9 +212,40 @@ def letterbox(frames, size=640, layout="nchw", dtype=None, out=None, swap_rb=Fal
     return out, ratio.value
 
 
+def crop_slot_bases(counts, max_n, base=None, total=None, slot_of=None):
+    """Bookkeeping of a DENSE crop batch (``tlk_crop_slot_bases``): counts (B,) i32 -> base (B,) i32 exclusive prefix sums, total (1,) i32
+    = the number of real crops, slot_of (B*max_n,) i64 = position of crop i of frame b in the dense batch (a valid position for padding
+    slots too).  All on the device, in stream order: nothing here needs the host to know the counts."""
+    import torch
+    L = lib()
+    _bind_image(L)
+    assert counts.is_cuda and counts.dtype == torch.int32 and counts.is_contiguous()
+    B = counts.numel()
+    base = torch.empty(B, dtype=torch.int32, device=counts.device) if base is None else base
+    total = torch.empty(1, dtype=torch.int32, device=counts.device) if total is None else total
+    slot_of = torch.empty(B * max_n, dtype=torch.int64, device=counts.device) if slot_of is None else slot_of
+    assert base.dtype == torch.int32 and total.dtype == torch.int32 and slot_of.dtype == torch.int64 and slot_of.numel() == B * max_n
+    check(L.tlk_crop_slot_bases(counts.data_ptr(), B, max_n, base.data_ptr(), total.data_ptr(), slot_of.data_ptr(), current_stream_ptr()))
+    return base, total, slot_of
+
+
+def conv_set_dynamic_batch(n_images=None):
+    """``tlk_conv_set_dynamic_batch``: every libtlk convolution launched (or captured into a hipGraph) from now on reads its image count
+    from ``n_images[0]`` (1-element int32 CUDA tensor, kept alive by the caller) when the kernel runs; None switches it off."""
+    import torch
+    L = lib()
+    _bind_image(L)
+    if n_images is None:
+        check(L.tlk_conv_set_dynamic_batch(None))
+        return
+    assert n_images.is_cuda and n_images.dtype == torch.int32 and n_images.numel() >= 1
+    check(L.tlk_conv_set_dynamic_batch(n_images.data_ptr()))
+
+
 def roi_crop_resize_norm(frames, boxes_ltwh, counts, out_h, out_w, layout="nchw", dtype=None,
-                         mean=IMAGENET_MEAN, std=IMAGENET_STD, out=None, swap_rb=False):
-    """frames (B,H,W,3) u8, boxes_ltwh (B,max_n,4) f32, counts (B,) i32 -> (B*max_n, 3, out_h, out_w)."""
+                         mean=IMAGENET_MEAN, std=IMAGENET_STD, out=None, swap_rb=False, slot_base=None):
+    """frames (B,H,W,3) u8, boxes_ltwh (B,max_n,4) f32, counts (B,) i32 -> (B*max_n, 3, out_h, out_w).
+    slot_base (B,) i32 (``crop_slot_bases``): write the crops as a dense batch -- crop i of frame b at slot slot_base[b] + i."""
     import torch
     L = lib()
     _bind_image(L)
@@ -223,9 +259,15 @@ def roi_crop_resize_norm(frames, boxes_ltwh, counts, out_h, out_w, layout="nchw"
         out = torch.zeros(shape, dtype=dtype, device=frames.device)
     m = (C.c_float * 3)(*mean)
     s = (C.c_float * 3)(*std)
-    check(L.tlk_roi_crop_resize_norm(frames.data_ptr(), B, H, W, boxes_ltwh.data_ptr(), counts.data_ptr(), max_n,
-                                     out_h, out_w, m, s, LAYOUT[layout] | (SWAP_RB if swap_rb else 0), _dtype_code(dtype), out.data_ptr(),
-                                     current_stream_ptr()))
+    if slot_base is not None:
+        assert slot_base.is_cuda and slot_base.dtype == torch.int32 and slot_base.numel() == B
+        check(L.tlk_roi_crop_resize_norm_compact(frames.data_ptr(), B, H, W, boxes_ltwh.data_ptr(), counts.data_ptr(), slot_base.data_ptr(), max_n,
+                                                 out_h, out_w, m, s, LAYOUT[layout] | (SWAP_RB if swap_rb else 0), _dtype_code(dtype), out.data_ptr(),
+                                                 current_stream_ptr()))
+    else:
+        check(L.tlk_roi_crop_resize_norm(frames.data_ptr(), B, H, W, boxes_ltwh.data_ptr(), counts.data_ptr(), max_n,
+                                         out_h, out_w, m, s, LAYOUT[layout] | (SWAP_RB if swap_rb else 0), _dtype_code(dtype), out.data_ptr(),
+                                         current_stream_ptr()))
     if layout != "nchw":
         out = out.permute(0, 3, 1, 2)
     return out
@@ -987,12 +1029,7 @@ def conv2d_nhwc_f32(x, weight, bias=None, act=None, residual=None, stride=1, pad
     assert x.dtype == torch.float32 and weight.dtype == torch.float32 and Cw == Cin
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
 
-    def pix(t, c, h, w):       # pixel stride (floats) of an NHWC tensor or channel slice of one
-        sn, sc, sh, sw = t.stride()
-        if t.shape[0] == 0:
-            return c
-        assert (sc == 1 or c == 1) and sh == w * sw and (sn == h * sh or t.shape[0] == 1), "tensor must be channels_last (or a channel slice of one)"
-        return sw
+    pix = _pix16               # pixel stride in elements (size-1 dimensions carry arbitrary strides in torch: ADVICE r04)
     wk = weight if weight.is_contiguous(memory_format=torch.channels_last) or (KH == 1 and KW == 1 and weight.is_contiguous()) \
         else weight.contiguous(memory_format=torch.channels_last)
     if out is None:

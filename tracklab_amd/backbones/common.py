@@ -23,6 +23,16 @@ USE_TLK_CONV_F16_NARROW = _os.environ.get("TLK_CONV_F16_NARROW", "1") != "0"
 CONV_TIMER = None
 
 
+def param_key(*tensors):
+    """Identity + content stamp of the parameters a derived tensor was built from: storage address, in-place version counter (load_state_dict /
+    copy_ bump it), device, dtype.  Weight-derived caches (padded stem weight, split planes, fp32 bias, depthwise taps, Toeplitz form of
+    RTMPose's last layer) store it and rebuild when it changes -- ADVICE r04: a checkpoint loaded after a first forward used to leave them stale."""
+    return tuple((t.data_ptr(), t._version, str(t.device), t.dtype) for t in tensors if t is not None)
+# (capacity, live) while a dynamic batch is set (tlk_conv_set_dynamic_batch): a convolution whose batch is `capacity` images computes `live` of
+# them -- CONV_TIMER counts the algorithmic flops of those only
+LIVE_BATCH = None
+
+
 def epilogue_(x: torch.Tensor, bias: torch.Tensor, act: str | None, residual: torch.Tensor | None = None) -> torch.Tensor:
     """x = act(x + bias[c] (+ residual)). On the GPU (fp16/bf16, channels-last) this is one in-place
     ``tlk_bias_act_nhwc`` launch instead of MIOpen's bias op-tensor + activation + add passes; elsewhere
@@ -92,14 +102,15 @@ class ConvBiasAct(nn.Module):
     def _split_weights(self, cin):
         """(hi, lo) float16 planes of the fp32 weight, input channels zero-padded to `cin` (the RGB stem arrives with 8); cached"""
         c = getattr(self, "_w_split", None)
-        if c is None or c[0].device != self.conv.weight.device or c[0].shape[1] != cin:
+        key = param_key(self.conv.weight) + (cin,)
+        if c is None or c[0] != key:
             from .. import _lib
             w = self.conv.weight.detach().float()
             if w.shape[1] != cin:
                 w = F.pad(w, (0, 0, 0, 0, 0, cin - w.shape[1]))
-            c = _lib.split_planes(w.contiguous(memory_format=torch.channels_last))
+            c = (key, _lib.split_planes(w.contiguous(memory_format=torch.channels_last)))
             self._w_split = c
-        return c
+        return c[1]
 
     def writes_slices(self, x):
         """True when forward(x, out=...) writes straight into `out` (a channel slice of a wider tensor): the libtlk convolution routes"""
@@ -130,10 +141,12 @@ class ConvBiasAct(nn.Module):
         if (USE_TLK_CONV_F16 or narrow) and x.is_cuda and x.dtype == torch.float16 and x.shape[1] % 8 == 0 and self.conv.out_channels % 8 == 0 \
                 and x.is_contiguous(memory_format=torch.channels_last) and self.conv.weight.dtype == torch.float16:
             from .. import _lib
-            b32 = getattr(self, "_bias32", None)
-            if b32 is None or b32.device != x.device:
-                b32 = self.bias.detach().float()
-                self._bias32 = b32
+            c = getattr(self, "_bias32", None)
+            key = param_key(self.bias)
+            if c is None or c[0] != key:
+                c = (key, self.bias.detach().float())
+                self._bias32 = c
+            b32 = c[1]
             if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
                 residual = residual.contiguous(memory_format=torch.channels_last)
             return _lib.conv2d_nhwc_16(x, self.conv.weight, b32, self.act, residual, self.conv.stride[0], self.conv.padding[0],
@@ -144,10 +157,12 @@ class ConvBiasAct(nn.Module):
             if x.shape[1] == 3:
                 # RGB stem: the kernel gathers 16 B per tap, so the image gets a zero 4th channel (one small pass) and the weight a zero 4th
                 # input channel (cached): zero terms in the fmaf chain, the sum is unchanged
-                w4 = getattr(self, "_w4", None)
-                if w4 is None or w4.device != x.device:
-                    w4 = F.pad(self.conv.weight, (0, 0, 0, 0, 0, 1)).contiguous(memory_format=torch.channels_last)
-                    self._w4 = w4
+                c = getattr(self, "_w4", None)
+                key = param_key(self.conv.weight)
+                if c is None or c[0] != key:
+                    c = (key, F.pad(self.conv.weight.detach(), (0, 0, 0, 0, 0, 1)).contiguous(memory_format=torch.channels_last))
+                    self._w4 = c
+                w4 = c[1]
                 x4 = F.pad(x, (0, 0, 0, 0, 0, 1)).contiguous(memory_format=torch.channels_last)
                 x, weight = x4, w4
             else:
@@ -164,7 +179,8 @@ class ConvBiasAct(nn.Module):
             if CONV_TIMER is not None:
                 e1.record()
                 cout, cin, kh, kw = self.conv.weight.shape       # the algorithmic count: 3 input channels for the RGB stem, not the padded 4
-                CONV_TIMER.append((e0, e1, n0, n1, 2.0 * y.shape[0] * y.shape[2] * y.shape[3] * cout * cin * kh * kw,
+                nb = LIVE_BATCH[1] if (LIVE_BATCH is not None and y.shape[0] == LIVE_BATCH[0]) else y.shape[0]
+                CONV_TIMER.append((e0, e1, n0, n1, 2.0 * nb * y.shape[2] * y.shape[3] * cout * cin * kh * kw,
                                    (_lib.lib().tlk_conv2d_last_config(), _lib.ACT[self.act], residual is not None)))
             return y
         if residual_after_act and residual is not None:

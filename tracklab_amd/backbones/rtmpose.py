@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 import os as _os
 
-from .common import ConvBiasAct, epilogue_, finalize, random_init_, spp_concat
+from .common import ConvBiasAct, epilogue_, finalize, param_key, random_init_, spp_concat
 
 # depthwise 5 x 5 (+ bias + SiLU) on libtlk's hand-written kernel (tlk_dwconv2d_nhwc); TLK_DWCONV=0 restores the library route for A/B runs
 USE_TLK_DWCONV = _os.environ.get("TLK_DWCONV", "1") != "0"
@@ -39,11 +39,12 @@ class DWConvBiasAct(nn.Module):
         """(k, k, C) taps-major weight + fp32 bias for libtlk's depthwise kernel; cached per device / dtype"""
         c = getattr(self, "_dw_taps", None)
         w = self.dw.weight
-        if c is None or c[0].device != w.device or c[0].dtype != w.dtype:
+        key = param_key(w, self.dw_bias)
+        if c is None or c[0] != key:
             k = w.shape[-1]
-            c = (w.detach().permute(2, 3, 0, 1).reshape(k, k, w.shape[0]).contiguous(), self.dw_bias.detach().float().contiguous())
+            c = (key, (w.detach().permute(2, 3, 0, 1).reshape(k, k, w.shape[0]).contiguous(), self.dw_bias.detach().float().contiguous()))
             self._dw_taps = c
-        return c
+        return c[1]
 
     def forward(self, x, residual=None, residual_after_act=False, out=None):
         if USE_TLK_DWCONV and x.is_cuda and x.dtype in (torch.float16, torch.float32) and x.is_contiguous(memory_format=torch.channels_last) \
@@ -187,7 +188,8 @@ class RTMPoseNet(nn.Module):
         n, c, h, w = f.shape
         cache = getattr(self, "_final_gemm", None)
         wt = self.final_layer.weight
-        if cache is None or cache[0].device != wt.device or cache[0].dtype != wt.dtype or cache[2] != (h, w):
+        key = param_key(wt, self.final_layer.bias) + (h, w)
+        if cache is None or cache[3] != key:
             k, _, kh, kw = wt.shape
             big = torch.zeros(k, h, w, h, w, c, device=wt.device, dtype=wt.dtype)        # [k, y, x, y', x', c]
             for y in range(h):
@@ -195,7 +197,7 @@ class RTMPoseNet(nn.Module):
                     y0, y1 = max(0, y - kh // 2), min(h, y + kh // 2 + 1)
                     x0, x1 = max(0, x - kw // 2), min(w, x + kw // 2 + 1)
                     big[:, y, x, y0:y1, x0:x1, :] = wt[:, :, y0 - y + kh // 2:y1 - y + kh // 2, x0 - x + kw // 2:x1 - x + kw // 2].permute(0, 2, 3, 1)
-            cache = (big.reshape(k * h * w, h * w * c).contiguous(), self.final_layer.bias.detach().repeat_interleave(h * w).contiguous(), (h, w))
+            cache = (big.reshape(k * h * w, h * w * c).contiguous(), self.final_layer.bias.detach().repeat_interleave(h * w).contiguous(), (h, w), key)
             self._final_gemm = cache
         return F.linear(f.permute(0, 2, 3, 1).reshape(n, h * w * c), cache[0], cache[1]).view(n, self.K, h * w)
 

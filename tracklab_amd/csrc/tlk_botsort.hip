@@ -406,6 +406,7 @@ botsort_kernel(BoDev Dv, BoP P, BoIn in, tlk_botsort_row *__restrict__ rows_all,
     smooth(A3.nm, [&](int k) { return L.unconf[L.m_r[k]]; }, [&](int k) { return L.udet1[L.m_c[k]]; });
     for (int k = tid; k < A3.n_ur; k += BLOCK) { const int slot = L.unconf[L.u_r[k]]; trk_at(slot).i(OI_STATE) = OT_REMOVED; L.removed[k] = slot; }
     int n_removed = A3.n_ur;
+    if (A1.err | A2.err | A3.err) { if (tid == 0) { hdr[OH_ERR] = TLK_EINTERNAL; *out_count = TLK_EINTERNAL; } return; }      // uniform: an assignment solver hit its loop bound
     __syncthreads();
     // ---- new tracks from the still unmatched detections with score >= new_track_thresh (:443-450) ----
     const int n_new = block_compact(A3.n_uc, [&](int q) { return !(L.dscore[L.udet1[L.u_c[q]]] < P.new_track); }, [&](int q, int pos) { L.rem[pos] = L.udet1[L.u_c[q]]; }, L.scan);
@@ -714,7 +715,7 @@ extern "C" int tlk_botsort_update_gmc(tlk_botsort *h, int stream, const double *
     int rows_n = 0;
     TLK_HIP(hipMemcpyAsync(&rows_n, h->d_ocnt, sizeof(int), hipMemcpyDeviceToHost, st));
     TLK_HIP(hipStreamSynchronize(st));
-    if (rows_n < 0) return fail(rows_n, "tlk_botsort_update: tracker capacity exceeded (max_tracks / max_dets / 16 classes per track)");
+    if (rows_n < 0) return fail_stream(rows_n, "tlk_botsort_update", "max_tracks / max_dets / 16 classes per track");
     if (rows_n > cap) return fail(TLK_ECAPACITY, "tlk_botsort_update: output buffer too small");
     if (rows_n) TLK_HIP(hipMemcpy(rows, h->d_rows, sizeof(tlk_botsort_row) * rows_n, hipMemcpyDeviceToHost));
     *n_out = rows_n;

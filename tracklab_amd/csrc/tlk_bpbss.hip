@@ -348,7 +348,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
         }
         __syncthreads();
         BPB_PROF(1);                                      // detection + gate preparation
-        int nm = 0, n_umt = 0, n_umd = 0;
+        int nm = 0, n_umt = 0, n_umd = 0, lsa_err = 0;
         int *um_d_final = L.um_db;
         if (P.strategy == 0) {
             // ---------------- strong_sort_matching (tracker.py:242-333) ----------------
@@ -396,6 +396,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             __syncthreads();
             BPB_PROF(2);                                  // appearance cost fill
             const McmOut A = min_cost_matching(cm, nc, N, P.max_dist, L.cand, L.um_db, L.m_t, L.m_d, L.um_ta, L.um_da, L);
+            lsa_err |= A.err;
             BPB_PROF(3);                                  // LSA + match lists, stage A
             if (nc > 0)
                 for (int k = tid; k < A.nm; k += BLOCK) {       // add_matching_information "R": un-thresholded gated cost (tracker.py:409-425)
@@ -431,6 +432,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             BPB_PROF(4);                                  // matched info, set order, motion cost fill
             const McmOut Bm = min_cost_matching(cb, nb, n_uda, motion_max, L.bc, L.um_da, L.m_t + A.nm, L.m_d + A.nm,
                                                 L.um_tb, L.um_db, L);
+            lsa_err |= Bm.err;
             if (nb > 0 && n_uda > 0)
                 for (int k = tid; k < Bm.nm; k += BLOCK) {        // "S"
                     const int p = L.m_t[A.nm + k], j = L.m_d[A.nm + k];
@@ -470,6 +472,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
             }
             __syncthreads();
             const McmOut A = min_cost_matching(cm, T, N, P.max_dist, L.cand, L.um_db, L.m_t, L.m_d, L.um_ta, L.um_da, L);
+            lsa_err |= A.err;
             if (T > 0)
                 for (int k = tid; k < A.nm; k += BLOCK) { const int p = L.m_t[k], j = L.m_d[k]; L.d_mname[j] = 1; L.d_mdist[j] = full_cost(p, j); }
             for (int r = tid; r < T; r += BLOCK) L.rowf[r] = 0;
@@ -523,6 +526,7 @@ bpbss_assoc_kernel(BpbDev Dv, BpbP P, FrameIn in, tlk_bpbss_row *__restrict__ ro
         __syncthreads();
         // _initiate_track (tracker.py:427-441) in the order of unmatched_detections
         int nfree = hdr[H_NFREE], nextid = hdr[H_NEXTID];
+        if (lsa_err) { if (tid == 0) { hdr[H_ERR] = TLK_EINTERNAL; *out_count = TLK_EINTERNAL; Dv.ema_n[s] = 0; } return; }      // uniform: an assignment solver hit its loop bound
         if (T + n_umd > MAXT) { if (tid == 0) { hdr[H_ERR] = TLK_ECAPACITY; *out_count = TLK_ECAPACITY; Dv.ema_n[s] = 0; } return; }
         for (int k = tid; k < n_umd; k += BLOCK) {
             const int j = um_d_final[k];
@@ -949,7 +953,7 @@ extern "C" int tlk_bpbss_update(tlk_bpbss *h, int stream, const int64_t *ids, co
     int rows_n = 0;
     TLK_HIP(hipMemcpyAsync(&rows_n, h->d_ocnt, sizeof(int), hipMemcpyDeviceToHost, st));
     TLK_HIP(hipStreamSynchronize(st));
-    if (rows_n < 0) return fail(rows_n, "tlk_bpbss_update: tracker capacity exceeded (max_tracks/max_dets)");
+    if (rows_n < 0) return fail_stream(rows_n, "tlk_bpbss_update");
     if (rows_n > cap) return fail(TLK_ECAPACITY, "tlk_bpbss_update: output buffer too small");
     if (rows_n) TLK_HIP(hipMemcpy(rows, h->d_rows, sizeof(tlk_bpbss_row) * rows_n, hipMemcpyDeviceToHost));
     *n_out = rows_n;

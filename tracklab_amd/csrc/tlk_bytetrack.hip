@@ -208,6 +208,7 @@ bytetrack_kernel(ByDev Dv, ByP P, ByIn in, tlk_bytetrack_row *__restrict__ rows_
     for (int k = tid; k < A3.nm; k += BLOCK) apply(L.unconf[L.m_r[k]], L.udet1[L.m_c[k]], false);
     for (int k = tid; k < A3.n_ur; k += BLOCK) { const int slot = L.unconf[L.u_r[k]]; trk_at(slot).i(YI_STATE) = BT_REMOVED; L.removed[k] = slot; }
     int n_removed = A3.n_ur;
+    if (A1.err | A2.err | A3.err) { if (tid == 0) { hdr[YH_ERR] = TLK_EINTERNAL; *out_count = TLK_EINTERNAL; } return; }      // uniform: an assignment solver hit its loop bound
     __syncthreads();
     // ---- step 4: new tracks from the still unmatched detections with score >= det_thresh (:265-271) ----
     const int n_new = block_compact(A3.n_uc, [&](int q) { return !(L.dscore[L.udet1[L.u_c[q]]] < P.det_thresh); }, [&](int q, int pos) { L.rem[pos] = L.udet1[L.u_c[q]]; }, L.scan);
@@ -466,7 +467,7 @@ extern "C" int tlk_bytetrack_update(tlk_bytetrack *h, int stream, const double *
     int rows_n = 0;
     TLK_HIP(hipMemcpyAsync(&rows_n, h->d_ocnt, sizeof(int), hipMemcpyDeviceToHost, st));
     TLK_HIP(hipStreamSynchronize(st));
-    if (rows_n < 0) return fail(rows_n, "tlk_bytetrack_update: tracker capacity exceeded (max_tracks/max_dets)");
+    if (rows_n < 0) return fail_stream(rows_n, "tlk_bytetrack_update");
     if (rows_n > cap) return fail(TLK_ECAPACITY, "tlk_bytetrack_update: output buffer too small");
     if (rows_n) TLK_HIP(hipMemcpy(rows, h->d_rows, sizeof(tlk_bytetrack_row) * rows_n, hipMemcpyDeviceToHost));
     *n_out = rows_n;

@@ -85,7 +85,7 @@ __device__ __forceinline__ float bbox_iou32(const float *b, const float *q)     
     return 0.f;
 }
 
-struct AsgOut { int nm, n_ur, n_uc; };
+struct AsgOut { int nm, n_ur, n_uc, err; };      // err: the solver hit a loop bound (LSA_EINTERNAL)
 // linear_assignment (matching.py:37-48): lap.lapjv(extend_cost=True, cost_limit=thresh) on cost(i, j), i < nr, j < nc.
 // lap embeds the problem in an (nr+nc)^2 one with thresh/2 padding; its objective is
 //   sum over matched pairs of c_ij  +  (unmatched rows + unmatched columns) * thresh / 2  =  const + sum over matched (c_ij - thresh),
@@ -96,7 +96,7 @@ struct AsgOut { int nm, n_ur, n_uc; };
 template <class CostFn>
 __device__ AsgOut lapjv_assign(int nr, int nc, double thresh, CostFn cost, double *ebuf, double *lds_cost, int lds_entries, ByLds &L)
 {
-    AsgOut o{0, 0, 0};
+    AsgOut o{0, 0, 0, 0};
     const int tid = threadIdx.x;
     if (nr == 0 || nc == 0) {
         for (int i = tid; i < nr; i += BLOCK) L.u_r[i] = i;
@@ -117,10 +117,11 @@ __device__ AsgOut lapjv_assign(int nr, int nc, double thresh, CostFn cost, doubl
     __syncthreads();
     if (tid < WAVE) {
         const int r = wave_lsa(cm, nr, nc, (size_t)nc, (size_t)1, L.W, L.mi_r, L.mi_c);
-        if (tid == 0) L.sc[0] = r < 0 ? 0 : r;
+        if (tid == 0) L.sc[0] = r == LSA_EINTERNAL ? r : (r < 0 ? 0 : r);
     }
     __syncthreads();
-    const int np = L.sc[0];
+    int np = L.sc[0];
+    if (np < 0) { o.err = 1; np = 0; }
     for (int k = tid; k < np; k += BLOCK) {
         const int r = L.mi_r[k], c = L.mi_c[k];
         if (cm[(size_t)r * nc + c] < 0.0) { L.x[r] = c; L.y[c] = r; }

@@ -14,12 +14,23 @@ namespace tlk {
 // ------------------------------------------------------------------------------------ host errors
 void set_error(const std::string &msg);
 int fail(int code, const std::string &msg);
+// negative per-stream frame count written by a tracker kernel -> status of the update call (`fn`: name of the entry point)
+inline int fail_stream(int code, const char *fn, const char *capacity_detail = "max_tracks/max_dets")
+{
+    if (code == TLK_EINTERNAL)
+        return fail(TLK_EINTERNAL, std::string(fn) + ": a device loop hit its iteration bound (assignment solver state no consistent run can reach); "
+                                   "the stream is poisoned until it is reset");
+    if (code <= -100) return fail(code, std::string(fn) + ": guard word damaged (debug build), array " + std::to_string(-100 - code));
+    return fail(code, std::string(fn) + ": tracker capacity exceeded (" + capacity_detail + ")");
+}
 #define TLK_HIP(expr)                                                                         \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \
         if (_e != hipSuccess)                                                                 \
             return ::tlk::fail(TLK_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
     } while (0)
+
+const int *conv_dynamic_batch();      // tlk_conv_set_dynamic_batch (tlk_conv.hip): device pointer to the live image count, or NULL
 
 constexpr int WAVE = 64;
 constexpr int BLOCK = 256;          // 4 wavefronts, one per SIMD of a CU
@@ -118,11 +129,16 @@ __device__ __forceinline__ double block_max_nan(double v, bool valid, double *s_
     return r;
 }
 
+// Return codes of the wave solvers besides a pair count: -1 = infeasible (scipy raises ValueError there), LSA_EINTERNAL = a loop bound
+// that no consistent solver state can reach was hit (corrupted work area); the banks turn it into TLK_EINTERNAL for the stream.
+constexpr int LSA_EINTERNAL = -3;
+
 // LDS work arrays of one LSA problem (sized for max(nr,nc) entries each).
 struct LsaWork {
     double *u, *v, *spc;
     int *path, *row4col, *remaining, *col4row;
     unsigned char *SR, *SC;
+    int hop_limit = 0;      // > 0: cap on the augmenting walk below its natural bound (tlk_debug_lsa_hop_limit: lets a test trip LSA_EINTERNAL)
 };
 
 // scipy-identical rectangular LSAP solved by ONE wavefront (all 64 lanes must call, converged).
@@ -152,6 +168,7 @@ __device__ __noinline__ int wave_lsa_lds(const double *cost, int nr0, int nc0, s
         double minval = 0.0;
         int num_remaining = nc, i = cur, sink = -1;
         while (sink == -1) {
+            if (num_remaining <= 0 || (unsigned)i >= (unsigned)nr) { ret = LSA_EINTERNAL; break; }      // every pass removes one column: <= nc passes
             if (lane == 0) W.SR[i] = 1;
             const double ui = W.u[i];
             double best = INFINITY;
@@ -194,10 +211,14 @@ __device__ __noinline__ int wave_lsa_lds(const double *cost, int nr0, int nc0, s
             if (W.SC[k]) W.v[k] -= minval - W.spc[k];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        // augment (uniform across lanes; lane 0 writes)
+        // augment (uniform across lanes; lane 0 writes).  An alternating path visits every row at most once: a walk longer than nr steps
+        // (or one that leaves the index range) means the work area was corrupted under the solver -- give up with LSA_EINTERNAL instead
+        // of walking garbage for ever (r05: every data-dependent device loop of the trackers is bounded)
         int j = sink;
-        for (;;) {
+        for (int hops = 0;; ++hops) {
+            if (hops > (W.hop_limit > 0 ? W.hop_limit : nr) || (unsigned)j >= (unsigned)nc) return LSA_EINTERNAL;
             const int pi = W.path[j];
+            if ((unsigned)pi >= (unsigned)nr) return LSA_EINTERNAL;
             const int old = W.col4row[pi];
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) { W.row4col[j] = pi; W.col4row[pi] = j; }
@@ -317,12 +338,13 @@ __device__ __forceinline__ double f64_unkey(unsigned int hi, unsigned int lo)
 
 template <int CPL, typename CostPtr>
 __device__ __noinline__ int wave_lsa_reg(CostPtr cost, int nr0, int nc0, unsigned rs0, unsigned cs0,
-                                         TLK_LDS double *u_lds, TLK_LDS int *col4row, int *rows_out, int *cols_out)
+                                         TLK_LDS double *u_lds, TLK_LDS int *col4row, int *rows_out, int *cols_out, int hop_limit)
 {
     const int lane = threadIdx.x & 63;
     const bool transpose = nc0 < nr0;
     const int nr = transpose ? nc0 : nr0, nc = transpose ? nr0 : nc0;
     const unsigned rs = transpose ? cs0 : rs0, cs = transpose ? rs0 : cs0;
+    const int hop_cap = hop_limit > 0 ? hop_limit : nr;
     double v_[CPL], spc_[CPL];
     int r4c_[CPL], path_[CPL], pos_[CPL];
     unsigned coff_[CPL];                                   // element offset of the lane's columns inside a cost row
@@ -337,6 +359,7 @@ __device__ __noinline__ int wave_lsa_reg(CostPtr cost, int nr0, int nc0, unsigne
         double minval = 0.0;
         int num_remaining = nc, i = cur, sink = -1;
         while (sink == -1) {
+            if (num_remaining <= 0 || (unsigned)i >= (unsigned)nr) return LSA_EINTERNAL;                  // every pass removes one column: <= nc passes
             const double ui = u_lds[i];
             const unsigned rbase = (unsigned)i * rs;
             double cval[CPL];
@@ -409,12 +432,14 @@ __device__ __noinline__ int wave_lsa_reg(CostPtr cost, int nr0, int nc0, unsigne
         if (lane == 0) u_lds[cur] += minval;
         // augment along path[] (uniform walk; owner lanes update their registers)
         int j = sink;
-        for (;;) {
+        for (int hops = 0;; ++hops) {
+            if (hops > hop_cap || (unsigned)j >= (unsigned)nc) return LSA_EINTERNAL;      // (see wave_lsa_lds: bounded walk)
             const int c = j >> 6, l = j & 63;
             int path_sel = 0;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) if (q == c) path_sel = path_[q];
             const int pi = __builtin_amdgcn_readlane(path_sel, l);
+            if ((unsigned)pi >= (unsigned)nr) return LSA_EINTERNAL;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) if (q == c && lane == l) r4c_[q] = pi;
             const int old = col4row[pi];
@@ -453,10 +478,10 @@ __device__ __forceinline__ int wave_lsa_reg_cpl(CostPtr cost, int nr0, int nc0, 
     TLK_LDS double *u = (TLK_LDS double *)W.u;
     TLK_LDS int *c4r = (TLK_LDS int *)W.col4row;
     const int mx = nr0 > nc0 ? nr0 : nc0;
-    if (mx <= 64) return wave_lsa_reg<1>(cost, nr0, nc0, (unsigned)rs0, (unsigned)cs0, u, c4r, rows_out, cols_out);
-    if (mx <= 128) return wave_lsa_reg<2>(cost, nr0, nc0, (unsigned)rs0, (unsigned)cs0, u, c4r, rows_out, cols_out);
-    if (mx <= 256) return wave_lsa_reg<4>(cost, nr0, nc0, (unsigned)rs0, (unsigned)cs0, u, c4r, rows_out, cols_out);
-    return wave_lsa_reg<8>(cost, nr0, nc0, (unsigned)rs0, (unsigned)cs0, u, c4r, rows_out, cols_out);
+    if (mx <= 64) return wave_lsa_reg<1>(cost, nr0, nc0, (unsigned)rs0, (unsigned)cs0, u, c4r, rows_out, cols_out, W.hop_limit);
+    if (mx <= 128) return wave_lsa_reg<2>(cost, nr0, nc0, (unsigned)rs0, (unsigned)cs0, u, c4r, rows_out, cols_out, W.hop_limit);
+    if (mx <= 256) return wave_lsa_reg<4>(cost, nr0, nc0, (unsigned)rs0, (unsigned)cs0, u, c4r, rows_out, cols_out, W.hop_limit);
+    return wave_lsa_reg<8>(cost, nr0, nc0, (unsigned)rs0, (unsigned)cs0, u, c4r, rows_out, cols_out, W.hop_limit);
 }
 
 __device__ __forceinline__ int wave_lsa(const double *cost, int nr0, int nc0, size_t rs0, size_t cs0,

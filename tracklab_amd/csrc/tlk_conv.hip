@@ -43,6 +43,7 @@ struct ConvArgs {
     int tiles_n;
     long long tiles;
     int res_post;                 // 1: the residual is added AFTER the activation (y = act(conv + bias) + r: CSPNeXt's identity add)
+    const int *n_dyn;             // not NULL: the number of images is read from device memory (<= the n of the call): tlk_conv_set_dynamic_batch
 };
 
 template <int ACT> __device__ __forceinline__ float act_f32(float v)
@@ -76,6 +77,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
     }
     const long long m0 = (tile / p.tiles_n) * BM;
     const int n0 = (int)(tile % p.tiles_n) * BN;
+    // dynamic batch (r05): the launch is sized for the n of the call, the rows that exist are n_dyn[0] images' worth; a tile beyond them leaves
+    // at once (before any barrier), a tile across the edge masks its rows exactly like the last tile of a static launch
+    long long M = p.M;
+    if (p.n_dyn) { const long long md = (long long)p.n_dyn[0] * p.Ho * p.Wo; M = md < M ? (md < 0 ? 0 : md) : M; }
+    if (m0 >= M) return;
 
     // ---- loader geometry: this lane moves chunk `lc` (4 floats of k) of row `lr + pass * ROWS_PER_PASS`.
     // Loads are BUFFER loads (raw buffer descriptor, 32-bit byte offsets): a lane whose chunk is outside the image / beyond K / beyond M
@@ -101,7 +107,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
 #pragma unroll
     for (int ps = 0; ps < PA; ++ps) {
         const long long m = m0 + lr + ps * ROWS_PER_PASS;
-        a_ok[ps] = m < p.M;
+        a_ok[ps] = m < M;
         const long long mm = a_ok[ps] ? m : m0;
         const unsigned n = (unsigned)mm / (unsigned)(p.Ho * p.Wo);
         const int rem = (int)((unsigned)mm - n * (unsigned)(p.Ho * p.Wo));
@@ -163,7 +169,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
             const int row = idx / EV_PER_ROW, ec = (idx - row * EV_PER_ROW) * 4;
             const long long m = m0 + row;
             const int co = n0 + ec;
-            const bool ok = !(ENVEC % NT != 0 && idx >= ENVEC) && m < p.M && co < p.Cout;
+            const bool ok = !(ENVEC % NT != 0 && idx >= ENVEC) && m < M && co < p.Cout;
             rres[it] = ok ? *reinterpret_cast<const float4 *>(p.res + m * p.r_pix + co) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
@@ -242,7 +248,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
             const int row = idx / V_PER_ROW, ec = (idx - row * V_PER_ROW) * 4;
             const long long m = m0 + row;
             const int co = n0 + ec;
-            if ((NVEC % NT != 0 && idx >= NVEC) || m >= p.M || co >= p.Cout) continue;
+            if ((NVEC % NT != 0 && idx >= NVEC) || m >= M || co >= p.Cout) continue;
             float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec);
             if (p.bias) { const float4 bv = *reinterpret_cast<const float4 *>(p.bias + co); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
             else { v.x += 0.f; v.y += 0.f; v.z += 0.f; v.w += 0.f; }
@@ -257,7 +263,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
             const int row = idx / V_PER_ROW, ec = (idx - row * V_PER_ROW) * 4;
             const long long m = m0 + row;
             const int co = n0 + ec;
-            if ((NVEC % NT != 0 && idx >= NVEC) || m >= p.M) continue;
+            if ((NVEC % NT != 0 && idx >= NVEC) || m >= M) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (co + e >= p.Cout) break;
@@ -295,6 +301,7 @@ template <int TM, int TN, int WGM, int WGN> int launch_cfg(ConvArgs &a, int act,
 }
 
 int g_force_cfg = -1;     // tlk_conv2d_set_config (probes / tests): -1 = heuristic
+const int *g_dyn_batch = nullptr;      // tlk_conv_set_dynamic_batch
 int g_last_cfg = -1;      // configuration of the most recent launch (tlk_conv2d_last_config: bench.py groups its event timings by kernel instantiation)
 
 }  // namespace
@@ -307,6 +314,17 @@ extern "C" int tlk_conv2d_set_config(int cfg)
 }
 
 extern "C" int tlk_conv2d_last_config(void) { return g_last_cfg; }
+
+const int *tlk::conv_dynamic_batch() { return g_dyn_batch; }
+
+// Dynamic batch for every convolution launched from now on (tlk_conv2d_nhwc_f32, tlk_conv2d_nhwc_16) until it is cleared with NULL:
+// the kernels take the number of images from n_images_dev[0] (device memory, read when the kernel RUNS -- so a captured hipGraph follows it)
+// and treat the `n` of the call as the capacity.  Rows beyond are neither read nor written.
+extern "C" int tlk_conv_set_dynamic_batch(const int32_t *n_images_dev)
+{
+    g_dyn_batch = n_images_dev;
+    return TLK_OK;
+}
 
 extern "C" int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev, float *y_dev,
                                    int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int act_kind,
@@ -331,6 +349,7 @@ extern "C" int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const
     a.y_pix = y_pix_stride > 0 ? y_pix_stride : cout;
     a.r_pix = res_pix_stride > 0 ? res_pix_stride : cout;
     a.res_post = res_post;
+    a.n_dyn = g_dyn_batch;
     if (a.x_pix < cin || a.y_pix < cout || a.r_pix < cout || a.x_pix % 4 != 0)
         return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: pixel strides must cover the channels (x stride a multiple of 4)");
     if (((uintptr_t)x_dev | (uintptr_t)w_dev) & 15) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: x and w must be 16-byte aligned");

@@ -17,48 +17,14 @@
 // 32 hi | 32 lo), rows padded to 144 B (conflict-free ds_read_b128 / ds_write_b128), buffer loads with hardware zero-fill so a K step is one
 // basic block, LDS double-buffered, scheduling barriers between MFMA chunks.  The 16-bit MFMA is 2-5x shorter per K step than the fp32 one, so
 // the global loads run TWO steps ahead in two register sets (issued in step s-1, written to LDS in the second half of step s, read in step s+1).
-#include <hip/hip_fp16.h>
-
-#include "tlk_common.hpp"
+#include "tlk_conv16.hpp"
 
 using namespace tlk;
+using namespace tlk::c16;
 
 namespace {
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
-enum { MODE_F16 = 0, MODE_SPLIT = 1 };
-constexpr int ROW_BYTES = 128, LDB = ROW_BYTES + 16;      // LDS row: 128 data bytes + 16 pad
-constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-
-struct Conv16Args {
-    const _Float16 *x, *x_lo, *w, *w_lo, *res, *res_lo;
-    const float *bias;
-    _Float16 *y, *y_lo;
-    float *y32;
-    long long M;
-    int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, K;
-    int x_pix, y_pix, r_pix;      // elements between two pixels of x / y / residual
-    int tiles_n;
-    long long tiles;
-    int res_post;                 // 1: the residual is added AFTER the activation (y = act(conv + bias) + r)
-};
-
-template <int ACT> __device__ __forceinline__ float act16(float v)
-{
-    if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (ACT == ACT_SILU) return v / (1.f + __expf(-v));
-    return v;
-}
-
-__device__ __forceinline__ void split_f32(float v, _Float16 &hi, _Float16 &lo)
-{
-    hi = (_Float16)v;
-    lo = (_Float16)((v - (float)hi) * LO_SCALE);
-}
+constexpr int LDB = ROW_BYTES + 16;      // LDS row of the register-staged kernel: 128 data bytes + 16 pad
 
 template <int TM, int TN, int WGM, int WGN, int ACT, bool RES, int MODE, bool OUT_F32>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv16Args p)
@@ -86,6 +52,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
     }
     const long long m0 = (tile / p.tiles_n) * BM;
     const int n0 = (int)(tile % p.tiles_n) * BN;
+    const long long M = live_rows(p);
+    if (m0 >= M) return;                                   // dynamic batch: a tile beyond the live rows leaves before any barrier
 
     // ---- loader geometry (see tlk_conv.hip): lane = chunk `lc` of row `lr + pass * ROWS_PER_PASS` of one plane
     const int lr = tid / CH, lc = tid % CH;
@@ -113,7 +81,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
 #pragma unroll
     for (int ps = 0; ps < PA; ++ps) {
         const long long m = m0 + lr + ps * ROWS_PER_PASS;
-        a_ok[ps] = m < p.M;
+        a_ok[ps] = m < M;
         const long long mm = a_ok[ps] ? m : m0;
         const unsigned n = (unsigned)mm / (unsigned)(p.Ho * p.Wo);
         const int rem = (int)((unsigned)mm - n * (unsigned)(p.Ho * p.Wo));
@@ -269,7 +237,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
         const int row = idx / V_PER_ROW, ec = (idx - row * V_PER_ROW) * 8;
         const long long m = m0 + row;
         const int co = n0 + ec;
-        if ((NVEC % NT != 0 && idx >= NVEC) || m >= p.M || co >= p.Cout) continue;      // Cout % 8 == 0 (checked by the host side)
+        if ((NVEC % NT != 0 && idx >= NVEC) || m >= M || co >= p.Cout) continue;      // Cout % 8 == 0 (checked by the host side)
         float v[8];
         {
             const float4 c0 = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec), c1 = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec + 4);
@@ -344,6 +312,8 @@ __global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p,
     }
     const long long m0 = (tile / p.tiles_n) * BM;
     const int n0 = (int)(tile % p.tiles_n) * BN;
+    const long long M = live_rows(p);
+    if (m0 >= M) return;                                   // dynamic batch: a tile beyond the live rows leaves before any barrier
 
     // ---- loader: instruction q (0..3) of this wavefront fills rows [(q * 4 + wave) * 8, + 8) of A and of B; lane = (row r8 = lane >> 3, position pc)
     const int r8 = lane >> 3, pc = lane & 7;
@@ -358,7 +328,7 @@ __global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p,
         const int plane = MODE == MODE_SPLIT ? (lcq >> 2) : 0, kc = MODE == MODE_SPLIT ? (lcq & 3) : lcq;
         const long long m = m0 + row;
         a_row[q] = nullptr; a_hi0[q] = 0; a_wi0[q] = 0;
-        if (m < p.M) {
+        if (m < M) {
             const unsigned n = (unsigned)m / (unsigned)(p.Ho * p.Wo);
             const int rem = (int)((unsigned)m - n * (unsigned)(p.Ho * p.Wo));
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
@@ -467,7 +437,7 @@ __global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p,
         const int row = idx / V_PER_ROW, ec = (idx - row * V_PER_ROW) * 8;
         const long long m = m0 + row;
         const int co = n0 + ec;
-        if (m >= p.M || co >= p.Cout) continue;
+        if (m >= M || co >= p.Cout) continue;
         float v[8];
         {
             const float4 c0 = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec), c1 = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec + 4);
@@ -516,7 +486,9 @@ __global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p,
     }
 }
 
-const unsigned char *zero_page()
+}  // namespace
+
+const unsigned char *tlk::c16::zero_page()
 {
     static unsigned char *z[16] = {nullptr};          // per device
     int dev = 0;
@@ -528,7 +500,10 @@ const unsigned char *zero_page()
     return z[dev];
 }
 
+namespace {
+
 int g_glds = -1;          // -1: read TLK_CONV16_GLDS once (default on); tlk_conv16_set_glds for A/B runs in one process
+int g_cfg16x = 0;         // tlk_conv16_set_config: -1 = r04 kernels only, 0 = the large-tile kernels where their heuristic takes the shape, > 0 = force one
 
 template <int MODE, bool OUT_F32> int launch16_glds(Conv16Args &a, int act, hipStream_t st)
 {
@@ -584,6 +559,10 @@ template <int TM, int TN, int WGM, int WGN, int MODE, bool OUT_F32> int launch16
 template <int MODE, bool OUT_F32> int dispatch16(Conv16Args &a, int act, hipStream_t st)
 {
     if (g_glds < 0) { const char *e = getenv("TLK_CONV16_GLDS"); g_glds = e ? atoi(e) : 1; }
+    if (g_cfg16x >= 0) {
+        const int r = launch16x(a, MODE == MODE_SPLIT, OUT_F32, act, g_cfg16x, st);
+        if (r != 1) return r;                                                            // 1 = "not a shape for the large tiles"
+    }
     if (g_glds && a.Cout > 64 && a.Cin % (MODE == MODE_SPLIT ? 32 : 64) == 0) return launch16_glds<MODE, OUT_F32>(a, act, st);
     if (MODE == MODE_SPLIT) {
         if (a.Cout > 64) return launch16<1, 2, 4, 2, MODE, OUT_F32>(a, act, st);         // 128 x 128, 8 wavefronts
@@ -643,6 +622,7 @@ extern "C" int tlk_conv2d_nhwc_16(const void *x_dev, const void *x_lo_dev, const
     a.y_pix = y_pix_stride > 0 ? y_pix_stride : cout;
     a.r_pix = res_pix_stride > 0 ? res_pix_stride : cout;
     a.res_post = res_post;
+    a.n_dyn = conv_dynamic_batch();
     if (a.x_pix < cin || a.y_pix < cout || a.r_pix < cout || (a.x_pix | a.y_pix | a.r_pix) % 8 != 0)
         return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: pixel strides must cover the channels and be multiples of 8");
     if (((uintptr_t)x_dev | (uintptr_t)x_lo_dev | (uintptr_t)w_dev | (uintptr_t)w_lo_dev | (uintptr_t)res_dev | (uintptr_t)res_lo_dev | (uintptr_t)y_dev |
@@ -654,6 +634,13 @@ extern "C" int tlk_conv2d_nhwc_16(const void *x_dev, const void *x_lo_dev, const
 }
 
 extern "C" int tlk_conv16_set_glds(int on) { g_glds = on ? 1 : 0; return TLK_OK; }
+
+extern "C" int tlk_conv16_set_config(int cfg)
+{
+    if (cfg < -1 || cfg > 6) return fail(TLK_EINVAL, "tlk_conv16_set_config: cfg is -1 (r04 kernels only), 0 (heuristic) or a tile configuration 1..6");
+    g_cfg16x = cfg;
+    return TLK_OK;
+}
 
 extern "C" int tlk_split_f32_planes(const float *x_dev, long long pixels, int c_in, int x_pix_stride, int c_out, void *hi_dev, void *lo_dev, void *hip_stream)
 {

@@ -1,0 +1,120 @@
+// tlk_conv16.hpp -- what the 16-bit MFMA convolution kernels share (tlk_conv16.hip: the register-staged and 128 x 128 direct-to-LDS
+// kernels of r04; tlk_conv16x.hip: the large-tile direct-to-LDS kernels of r05): argument block, modes, epilogue arithmetic.
+#pragma once
+#include <hip/hip_fp16.h>
+
+#include "tlk_common.hpp"
+
+namespace tlk {
+namespace c16 {
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+enum { MODE_F16 = 0, MODE_SPLIT = 1 };
+constexpr int ROW_BYTES = 128;                            // one K slice of a tile row in LDS: 64 f16 of one plane, or 32 hi | 32 lo
+constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+struct Conv16Args {
+    const _Float16 *x, *x_lo, *w, *w_lo, *res, *res_lo;
+    const float *bias;
+    _Float16 *y, *y_lo;
+    float *y32;
+    long long M;
+    int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, K;
+    int x_pix, y_pix, r_pix;      // elements between two pixels of x / y / residual
+    int tiles_n;
+    long long tiles;
+    int res_post;                 // 1: the residual is added AFTER the activation (y = act(conv + bias) + r)
+    const int *n_dyn;             // not NULL: live image count in device memory (tlk_conv_set_dynamic_batch); the call's n is the capacity
+};
+
+#if defined(__HIPCC__)
+template <int ACT> __device__ __forceinline__ float act16(float v)
+{
+    if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ACT == ACT_SILU) return v / (1.f + __expf(-v));
+    return v;
+}
+
+__device__ __forceinline__ void split_f32(float v, _Float16 &hi, _Float16 &lo)
+{
+    hi = (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * LO_SCALE);
+}
+
+// rows of this launch that exist: the static M, or n_dyn[0] images' worth when a dynamic batch is set
+__device__ __forceinline__ long long live_rows(const Conv16Args &p)
+{
+    long long M = p.M;
+    if (p.n_dyn) { const long long md = (long long)p.n_dyn[0] * p.Ho * p.Wo; M = md < M ? (md < 0 ? 0 : md) : M; }
+    return M;
+}
+
+// XCD-aware tile order: hardware deals consecutive workgroups round-robin to the 8 XCDs; give each XCD a contiguous run of tiles
+__device__ __forceinline__ long long xcd_tile(long long tiles)
+{
+    const long long b = blockIdx.x, q = tiles >> 3;
+    const int r = (int)(tiles & 7), xcd = (int)(b & 7);
+    return (long long)xcd * q + (xcd < r ? xcd : r) + (b >> 3);
+}
+
+// 8 consecutive output channels of one pixel: bias, residual (before or after the activation), activation, store in the mode's format.
+// `c` = the 8 fp32 sums (split mode: already merged), m / co = pixel and first channel.
+template <int ACT, bool RES, int MODE, bool OUT_F32>
+__device__ __forceinline__ void epilogue8(const Conv16Args &p, float (&v)[8], long long m, int co)
+{
+    if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + co), b1 = *reinterpret_cast<const float4 *>(p.bias + co + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    float rv[8];
+    if (RES) {
+        const h16x8 rh = *reinterpret_cast<const h16x8 *>(p.res + m * p.r_pix + co);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rv[e] = (float)rh[e];
+        if (MODE == MODE_SPLIT) {
+            const h16x8 rl = *reinterpret_cast<const h16x8 *>(p.res_lo + m * p.r_pix + co);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rv[e] += (float)rl[e] * LO_INV;
+        }
+        if (!p.res_post) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = act16<ACT>(v[e]);
+    if (RES && p.res_post) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+    }
+    if (OUT_F32) {
+        float *o = p.y32 + m * p.y_pix + co;
+        *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else if (MODE == MODE_SPLIT) {
+        h16x8 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f32(v[e], h, l); oh[e] = h; ol[e] = l; }
+        *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
+        *reinterpret_cast<h16x8 *>(p.y_lo + m * p.y_pix + co) = ol;
+    } else {
+        h16x8 oh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) oh[e] = (_Float16)v[e];
+        *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
+    }
+}
+#endif  // __HIPCC__
+
+const unsigned char *zero_page();      // 256 zero bytes on the current device (tlk_conv16.hip)
+
+// tlk_conv16x.hip: the large-tile kernels.  cfg: 0 = choose by shape (may decline: returns 1 = "not mine", the caller keeps its own kernel),
+// > 0 = force that tile configuration (probes).  Returns TLK_OK when launched.
+int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream_t st);
+
+}  // namespace c16
+}  // namespace tlk

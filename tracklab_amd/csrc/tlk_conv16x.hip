@@ -1,0 +1,411 @@
+// tlk_conv16x.hip -- the LARGE-TILE 16-bit MFMA convolution kernels (r05): the compute-bound layers of the backbones (K >= 256, Cout a
+// multiple of 64) in f16 mode and in split-fp32 mode (see tlk_conv16.hip for the two modes' arithmetic, which is unchanged here).
+//
+// Why another kernel.  r04's conv16 kernels compute a 128 x 128 tile with four wavefronts of 64 x 64: every ds_read_b128 feeds two
+// v_mfma_f32_32x32x16_f16 on average, the LDS spends as many cycles delivering fragments (plus absorbing the direct-to-LDS stream) as the
+// matrix pipes spend multiplying, and the kernel sits at 0.18 (ReID forward) / 0.34 (largest layers) of the 2.5 PFLOP/s peak
+// (profiles/r04_conv_kernels_pmc.md: 5.75 cycles of LDS wait per MFMA).  The fix is operand reuse per LDS byte:
+//
+//   * f16: 256 x 256 tile, EIGHT wavefronts (2 in M x 4 in N), each 128 x 64 = 4 x 2 MFMA tiles: 6 fragment reads feed 8 MFMAs per 16-wide
+//     k slice (0.75 reads / MFMA against 1.0), the tile's operand bytes per flop halve against 128 x 128; 128 accumulator registers per lane,
+//     two wavefronts per SIMD.  256 x 128 and 512 x 64 tiles of the same construction cover Cout = 128 and 64.
+//   * split: every product is three MFMAs on two accumulator sets, so a wavefront takes 64 x 64 (2 x 2 tiles x 2 sets = 128 registers): 8
+//     reads feed 12 MFMAs per slice (r04: 6 reads / 6 MFMAs on a 32 x 64 wavefront tile).  The hi and lo planes are SEPARATE LDS regions with
+//     64-byte rows and their own XOR swizzle -- r04's shared 128-byte rows (32 hi | 32 lo) read with 2.69 bank conflicts per MFMA.
+//   * K step = 128 bytes per row (64 f16 of a plane or 32 + 32), two LDS stages: stage s + 1 streams in (direct-to-LDS, 16 B per lane, no
+//     staging registers, no ds_write pass) while stage s is multiplied; one barrier per step of 32 (f16) / 24 (split) MFMAs per wavefront.
+//   * LDS image: unpadded rows, 16-byte chunk q of row i stored at position q ^ ((i >> 1) & 7) (128-byte rows) or q ^ ((i >> 2) & 3)
+//     (64-byte rows): the 16-lane groups of ds_read_b128 {0-3, 12-15, 20-27} ... then touch 16 distinct 16-byte slots of the 256-byte bank
+//     row -- conflict-free; a direct-to-LDS load lands lane-linear, so the swizzle is applied to the SOURCE address each lane fetches.
+//   * addressing: raw buffer loads with 32-bit byte offsets off a descriptor re-based per workgroup; a tap outside the image / a row beyond
+//     M / a column beyond Cout uses an out-of-range offset and the hardware writes zeros (USE_BUF), or -- the r04 form, kept selectable
+//     until the A/B on the GPU is in (tlk_conv16_set_config) -- a 64-bit pointer that falls back to a zero page.
+//   * epilogue: the fp32 tile leaves through the (now idle) LDS stages one MFMA tile row at a time, 8 channels (16 bytes of f16) per lane.
+// Activation kind, residual and output format are run-time (wave-uniform) switches here, not template arguments: the epilogue is a few
+// percent of a compute-bound launch and the instantiation count stays small.
+#include "tlk_conv16.hpp"
+
+using namespace tlk;
+using namespace tlk::c16;
+
+namespace {
+
+constexpr int OOB = (int)0x80000000;                      // beyond every num_records (< 2^31): the hardware returns zeros
+
+// scheduling recipe for one chunk of the K loop: NPAIR x (one instruction of class MASK, one MFMA), then REST MFMAs
+// (LLVM SchedGroupMask: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read)
+template <int NPAIR, int MASK, int REST> __device__ __forceinline__ void interleave()
+{
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k) {
+        __builtin_amdgcn_sched_group_barrier(MASK, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    if (REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, REST, 0);
+}
+
+constexpr int pick_epi(int tm, int wgm, int rows_max)
+{
+    int e = tm;
+    while (e > 1 && (tm % e != 0 || wgm * 32 * e > rows_max)) --e;
+    return e;
+}
+
+template <int WGM, int WGN, int TM, int TN, int MODE, bool USE_BUF>
+__global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Args p, const unsigned char *__restrict__ zeros, const int act)
+{
+    constexpr int NW = WGM * WGN, NT = 64 * NW;
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int PLANES = MODE == MODE_SPLIT ? 2 : 1;
+    constexpr int BKE = 64 / PLANES;                      // K elements per step
+    constexpr int RB = ROW_BYTES / PLANES;                // bytes of one tile row in one plane's LDS region
+    constexpr int CPR = RB / 16;                          // 16-byte chunks per row: 8 / 4
+    constexpr int RPI = 64 / CPR;                         // rows one wavefront-instruction fills: 8 / 16
+    constexpr int SWS = PLANES == 1 ? 1 : 2;              // chunk q of row i sits at position q ^ ((i >> SWS) & (CPR - 1))
+    constexpr int QA = BM / (RPI * NW), QB = BN / (RPI * NW);      // load instructions per wavefront, plane and stage
+    static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "tile rows must be a multiple of the loader pass");
+    constexpr int A_REGION = BM * RB, B_REGION = BN * RB;
+    constexpr int STAGE = PLANES * (A_REGION + B_REGION);          // (BM + BN) * 128 bytes
+    constexpr int NJ = BKE / 16;                          // 16-wide k slices per step: 4 / 2
+    constexpr int NACC = MODE == MODE_SPLIT ? 2 : 1;
+    constexpr int NR = PLANES * (TM + TN);                // fragment reads per slice
+    constexpr int NM = TM * TN * (MODE == MODE_SPLIT ? 3 : 1);     // MFMAs per slice
+    constexpr int NLD = PLANES * (QA + QB);               // direct-to-LDS loads per wavefront and stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const long long tile = xcd_tile(p.tiles);
+    const long long m0 = (tile / p.tiles_n) * BM;
+    const int n0 = (int)(tile % p.tiles_n) * BN;
+    const long long M = live_rows(p);
+    if (m0 >= M) return;                                  // dynamic batch: a tile beyond the live rows leaves before any barrier
+
+    // ---- loader.  Instruction q of this wavefront fills rows [(q * NW + wave) * RPI, + RPI) of A (and of B); lane = (row lrow, position pc) and
+    // fetches the LOGICAL chunk that belongs at its position.  Offsets are bytes relative to the workgroup's base pixel (A) / the weights (B).
+    const int lrow = lane / CPR, pc = lane % CPR;
+    long long base_pix;
+    {
+        const unsigned hw = (unsigned)(p.Ho * p.Wo), n = (unsigned)m0 / hw;
+        const int rem = (int)((unsigned)m0 - n * hw), ho = rem / p.Wo;
+        const int hi = ho * p.stride - p.pad;
+        base_pix = (long long)n * p.H * p.W + (long long)(hi > 0 ? hi : 0) * p.W;
+    }
+    const _Float16 *abase[PLANES];
+    abase[0] = p.x + base_pix * p.x_pix;
+    if (MODE == MODE_SPLIT) abase[PLANES - 1] = p.x_lo + base_pix * p.x_pix;
+    const _Float16 *wbase[PLANES];
+    wbase[0] = p.w;
+    if (MODE == MODE_SPLIT) wbase[PLANES - 1] = p.w_lo;
+    __amdgpu_buffer_rsrc_t rs_a[PLANES], rs_b[PLANES];
+    if (USE_BUF) {
+        const long long total_pix = (long long)((unsigned)p.M / (unsigned)(p.Ho * p.Wo)) * p.H * p.W;
+        long long a_bytes = ((total_pix - base_pix - 1) * p.x_pix + p.Cin) * 2;
+        if (a_bytes > 0x7ffffff0LL) a_bytes = 0x7ffffff0LL;
+        const int w_bytes = (int)((long long)p.Cout * p.K * 2);
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) {
+            rs_a[pl] = __builtin_amdgcn_make_buffer_rsrc((void *)abase[pl], 0, (int)a_bytes, 0x00020000);
+            rs_b[pl] = __builtin_amdgcn_make_buffer_rsrc((void *)wbase[pl], 0, w_bytes, 0x00020000);
+        }
+    }
+    int a_off0[QA], a_hi0[QA], a_wi0[QA], b_off0[QB];
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+        const int row = (q * NW + wave) * RPI + lrow;
+        const int lcq = pc ^ ((row >> SWS) & (CPR - 1));
+        const long long m = m0 + row;
+        a_off0[q] = OOB; a_hi0[q] = 0; a_wi0[q] = 0;
+        if (m < M) {
+            const unsigned n = (unsigned)m / (unsigned)(p.Ho * p.Wo);
+            const int rem = (int)((unsigned)m - n * (unsigned)(p.Ho * p.Wo));
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            a_hi0[q] = ho * p.stride - p.pad; a_wi0[q] = wo * p.stride - p.pad;
+            const int rel = (int)((long long)n * p.H * p.W - base_pix) + a_hi0[q] * p.W + a_wi0[q];
+            a_off0[q] = (rel * p.x_pix + lcq * 8) * 2;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        const int row = (q * NW + wave) * RPI + lrow;
+        const int lcq = pc ^ ((row >> SWS) & (CPR - 1));
+        const int co = n0 + row;
+        b_off0[q] = co < p.Cout ? (co * p.K + lcq * 8) * 2 : OOB;
+    }
+    int u_kh = 0, u_kw = 0, u_ci0 = 0, u_k0 = 0;          // tap of the step being loaded (wave-uniform)
+    auto load16 = [&](const __amdgpu_buffer_rsrc_t &rs, const _Float16 *base, int off, unsigned char *dst) {
+        if (USE_BUF) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)dst, 16, off, 0, 0, 0);
+        } else {
+            const unsigned char *g = off >= 0 ? reinterpret_cast<const unsigned char *>(base) + off : zeros;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+    };
+    auto issue_stage = [&](int buf) {                      // a stage beyond K is all zeros (it lands in a buffer nobody multiplies)
+        const bool in_k = u_k0 < p.K;
+        // (weights stay below 2^30 bytes -- host check -- so "valid offset + 2^30" is out of range for them: a scalar select, no branch)
+        const int a_add = ((u_kh * p.W + u_kw) * p.x_pix + u_ci0) * 2, b_add = (USE_BUF && !in_k) ? 0x40000000 : u_k0 * 2;
+        unsigned char *st = lds + buf * STAGE;
+#pragma unroll
+        for (int q = 0; q < QA; ++q) {
+            int off = a_off0[q] + a_add;                  // (an OOB row stays beyond 2^31: a_add is a small positive number)
+            const int hi = a_hi0[q] + u_kh, wi = a_wi0[q] + u_kw;      // (branch-free on purpose: the step stays one basic block)
+            off = (in_k & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W)) ? off : OOB;
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl) load16(rs_a[pl], abase[pl], off, st + pl * A_REGION + (q * NW + wave) * 1024);
+        }
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            int off = b_off0[q] + b_add;
+            if (!USE_BUF) off = in_k ? off : OOB;
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl) load16(rs_b[pl], wbase[pl], off, st + PLANES * A_REGION + pl * B_REGION + (q * NW + wave) * 1024);
+        }
+        u_k0 += BKE; u_ci0 += BKE;
+        const bool wrap_c = u_ci0 >= p.Cin;
+        u_ci0 = wrap_c ? 0 : u_ci0; u_kw += wrap_c ? 1 : 0;
+        const bool wrap_w = u_kw == p.KW;
+        u_kw = wrap_w ? 0 : u_kw; u_kh += wrap_w ? 1 : 0;
+    };
+
+    f32x16 acc[NACC][TM][TN];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
+
+    // fragment addressing: lane l reads row (l & 31) of an MFMA tile (+ 32 per tile: the swizzle term is the same for every tile), logical
+    // chunk 2 j + (l >> 5) of the step's slice j
+    const int sw = ((lane & 31) >> SWS) & (CPR - 1), hsel = lane >> 5;
+    const int a_lane = (wm * TM * 32 + (lane & 31)) * RB;
+    const int b_lane = PLANES * A_REGION + (wn * TN * 32 + (lane & 31)) * RB;
+    int coff[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) coff[j] = ((2 * j + hsel) ^ sw) << 4;
+    h16x8 fa[2][PLANES][TM], fb[2][PLANES][TN];           // two fragment sets: slice j + 1 is read while slice j is multiplied
+    auto read_frags = [&](int buf, int j, int set) {
+        const unsigned char *sa = lds + buf * STAGE + a_lane + coff[j], *sb = lds + buf * STAGE + b_lane + coff[j];
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[set][pl][i] = *reinterpret_cast<const h16x8 *>(sa + pl * A_REGION + i * 32 * RB);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) fb[set][pl][i] = *reinterpret_cast<const h16x8 *>(sb + pl * B_REGION + i * 32 * RB);
+        }
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) {
+                acc[0][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0][i], fb[set][0][jj], acc[0][i][jj], 0, 0, 0);
+                if (MODE == MODE_SPLIT) {
+                    acc[NACC - 1][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0][i], fb[set][PLANES - 1][jj], acc[NACC - 1][i][jj], 0, 0, 0);
+                    acc[NACC - 1][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][PLANES - 1][i], fb[set][0][jj], acc[NACC - 1][i][jj], 0, 0, 0);
+                }
+            }
+    };
+
+    // Main loop, software-pipelined across the barrier: the LAST slice of a step is multiplied AFTER the step's barrier, behind the reads of the
+    // next step's first fragments and the issue of the stage after next -- so the first thing a wavefront does when the barrier opens is start
+    // memory work, and it has TM * TN (x 3) MFMAs in hand to cover that work's latency.  Scheduling barriers keep the chunks in this order.
+    //   stage s lives in buffer s & 1;  it is loaded during step s - 1 (issued right after barrier s - 2), waited for before barrier s - 1.
+    static_assert(NJ % 2 == 0, "fragment set parity assumes an even number of slices per step");
+    const int steps = p.K / BKE;
+    issue_stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    read_frags(0, 0, 0);
+    issue_stage(1);
+    for (int s = 0; s < steps; ++s) {
+        const int cur = s & 1;
+#pragma unroll
+        for (int j = 0; j + 1 < NJ; ++j) {
+            read_frags(cur, j + 1, (j + 1) & 1);
+            mfmas(j & 1);
+            interleave<NR < NM ? NR : NM, 0x100, NM - (NR < NM ? NR : NM)>();      // fragment read, MFMA, fragment read, MFMA, ... MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // stage s + 1 has landed (it had the whole step to do so)
+        __syncthreads();                                              // ... for everyone, and nobody reads stage s any more
+        read_frags(cur ^ 1, 0, 0);
+        issue_stage(cur);                                             // stage s + 2 overwrites stage s
+        mfmas(1);                                                     // slice NJ - 1 of step s
+        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);           // first the reads, then one direct-to-LDS load per MFMA
+        interleave<NLD < NM ? NLD : NM, 0x020, NM - (NLD < NM ? NLD : NM)>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the stages beyond K: zeros in flight towards LDS)
+    __syncthreads();
+
+    // ---- epilogue: EPI MFMA tile rows of every wavefront at a time through LDS as fp32, then 8 output channels (16 bytes of f16) per lane.
+    // C/D map of the 32x32 tile: column (= cout) = lane & 31, row (= pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    constexpr int LDC = BN + 4;
+    constexpr int EPI = pick_epi(TM, WGM, (2 * STAGE) / (LDC * 4));
+    static_assert(WGM * 32 * EPI * LDC * 4 <= 2 * STAGE, "epilogue pass does not fit the LDS stages");
+    constexpr int PROWS = WGM * 32 * EPI;                 // tile rows per pass
+    constexpr int V_PER_ROW = BN / 8, NVEC = PROWS * V_PER_ROW, ITS = (NVEC + NT - 1) / NT;
+    float *Cs = reinterpret_cast<float *>(lds);
+    const bool has_res = p.res != nullptr, out32 = p.y32 != nullptr;
+#pragma unroll
+    for (int i0 = 0; i0 < TM; i0 += EPI) {
+#pragma unroll
+        for (int ii = 0; ii < EPI; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) {
+                float *c = Cs + ((wm * EPI + ii) * 32 + 4 * (lane >> 5)) * LDC + (wn * TN + jj) * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[0][i0 + ii][jj][r];
+                    if (MODE == MODE_SPLIT) v = v + acc[NACC - 1][i0 + ii][jj][r] * LO_INV;
+                    c[((r & 3) + 8 * (r >> 2)) * LDC] = v;
+                }
+            }
+        __syncthreads();
+#pragma unroll 2
+        for (int it = 0; it < ITS; ++it) {
+            const int idx = it * NT + tid;
+            const int prow = idx / V_PER_ROW, ec = (idx - prow * V_PER_ROW) * 8;
+            const int pw = prow / (32 * EPI), within = prow - pw * (32 * EPI);
+            const long long m = m0 + pw * (TM * 32) + i0 * 32 + within;
+            const int co = n0 + ec;
+            if ((NVEC % NT != 0 && idx >= NVEC) || m >= M || co >= p.Cout) continue;      // Cout % 8 == 0 (checked by the host side)
+            float v[8];
+            {
+                const float4 c0 = *reinterpret_cast<const float4 *>(Cs + prow * LDC + ec), c1 = *reinterpret_cast<const float4 *>(Cs + prow * LDC + ec + 4);
+                v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+            }
+            if (p.bias) {
+                const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + co), b1 = *reinterpret_cast<const float4 *>(p.bias + co + 4);
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+            }
+            float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (has_res) {
+                const h16x8 rh = *reinterpret_cast<const h16x8 *>(p.res + m * p.r_pix + co);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rv[e] = (float)rh[e];
+                if (MODE == MODE_SPLIT) {
+                    const h16x8 rl = *reinterpret_cast<const h16x8 *>(p.res_lo + m * p.r_pix + co);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rv[e] += (float)rl[e] * LO_INV;
+                }
+                if (!p.res_post) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                }
+            }
+            if (act == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = act16<ACT_RELU>(v[e]);
+            } else if (act == ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = act16<ACT_SILU>(v[e]);
+            }
+            if (has_res && p.res_post) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+            }
+            if (out32) {
+                float *o = p.y32 + m * p.y_pix + co;
+                *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else if (MODE == MODE_SPLIT) {
+                h16x8 oh, ol;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f32(v[e], h, l); oh[e] = h; ol[e] = l; }
+                *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
+                *reinterpret_cast<h16x8 *>(p.y_lo + m * p.y_pix + co) = ol;
+            } else {
+                h16x8 oh;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) oh[e] = (_Float16)v[e];
+                *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
+            }
+        }
+        if (i0 + EPI < TM) __syncthreads();
+    }
+}
+
+template <int WGM, int WGN, int TM, int TN, int MODE, bool USE_BUF> int launch_x(Conv16Args &a, int act, hipStream_t st)
+{
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, NT = 64 * WGM * WGN;
+    constexpr size_t LDS_BYTES = (size_t)2 * (BM + BN) * ROW_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "two stages must fit the CU's LDS");
+    const unsigned char *z = zero_page();
+    if (!z) return fail(TLK_EHIP, "tlk_conv2d_nhwc_16: cannot allocate the zero page");
+    a.tiles_n = (a.Cout + BN - 1) / BN;
+    a.tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
+    if (a.tiles > 0x7fffffffLL || a.M > 0x7fffffffLL) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: more than 2^31 - 1 output pixels in one launch");
+    auto kern = conv16x_kernel<WGM, WGN, TM, TN, MODE, USE_BUF>;
+    static bool attr_set = false;
+    if (!attr_set) { TLK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES)); attr_set = true; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles), dim3(NT), LDS_BYTES, st, a, z, act);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
+
+template <bool USE_BUF> int launch_cfg_x(Conv16Args &a, bool split, int act, int cfg, hipStream_t st)
+{
+    if (!split) {
+        switch (cfg) {
+        case 1: return launch_x<2, 4, 4, 2, MODE_F16, USE_BUF>(a, act, st);      // 256 x 256, wavefront 128 x 64
+        case 2: return launch_x<4, 2, 2, 2, MODE_F16, USE_BUF>(a, act, st);      // 256 x 128, wavefront 64 x 64
+        case 3: return launch_x<2, 2, 4, 2, MODE_F16, USE_BUF>(a, act, st);      // 256 x 128, four wavefronts of 128 x 64
+        case 4: return launch_x<8, 1, 2, 2, MODE_F16, USE_BUF>(a, act, st);      // 512 x 64, wavefront 64 x 64
+        case 5: return launch_x<4, 1, 2, 2, MODE_F16, USE_BUF>(a, act, st);      // 256 x 64, four wavefronts of 64 x 64
+        case 6: return launch_x<2, 2, 2, 2, MODE_F16, USE_BUF>(a, act, st);      // 128 x 128 (the r04 shape on this loader: A/B reference)
+        default: return fail(TLK_EINVAL, "tlk_conv16_set_config: f16 configurations are 1..6");
+        }
+    }
+    switch (cfg) {
+    case 1: return launch_x<2, 4, 2, 2, MODE_SPLIT, USE_BUF>(a, act, st);        // 128 x 256, wavefront 64 x 64 (x 2 accumulator sets)
+    case 2: return launch_x<4, 2, 2, 2, MODE_SPLIT, USE_BUF>(a, act, st);        // 256 x 128
+    case 3: return launch_x<2, 2, 2, 2, MODE_SPLIT, USE_BUF>(a, act, st);        // 128 x 128, four wavefronts
+    case 4: return launch_x<4, 1, 2, 2, MODE_SPLIT, USE_BUF>(a, act, st);        // 256 x 64, four wavefronts of 64 x 64
+    default: return fail(TLK_EINVAL, "tlk_conv16_set_config: split configurations are 1..4");
+    }
+}
+
+int g_use_buf = 1;        // tlk_conv16_set_loader: 1 = buffer loads with hardware zero fill, 0 = 64-bit pointers + zero page
+
+}  // namespace
+
+namespace tlk {
+namespace c16 {
+
+int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream_t st)
+{
+    (void)out32;
+    const int bke = split ? 32 : 64;
+    if (a.Cin % bke != 0 || a.K % bke != 0) return cfg > 0 ? fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: the large-tile kernels need Cin to be a multiple of the K step") : 1;
+    // every offset the loader forms stays below 2^31: the rows of one tile + their halo, and the weights
+    {
+        const long long span_rows = 512 / (a.Wo > 0 ? a.Wo : 1) + a.KH + 2;
+        const long long a_span = (span_rows * a.stride + a.KH) * (long long)a.W * a.x_pix * 2 + (long long)a.H * a.W * a.x_pix * 2;
+        if (a_span >= 0x7fffffffLL || (long long)a.Cout * a.K * 2 >= 0x3fffffffLL) return cfg > 0 ? fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: tensor rows too long for 32-bit tile offsets") : 1;
+    }
+    if (cfg <= 0) {
+        // heuristic (profiles/r05_conv16x_shapes.txt): the large tiles pay off where the launch is compute-bound and fills the chip
+        const long long tiles256 = ((a.M + 255) / 256) * ((a.Cout + 255) / 256);
+        if (!split) {
+            if (a.Cout % 256 == 0 && a.K >= 256 && tiles256 >= 192) cfg = 1;
+            else if (a.Cout % 128 == 0 && a.K >= 256 && ((a.M + 255) / 256) * (a.Cout / 128) >= 192) cfg = 2;
+            else return 1;
+        } else {
+            if (a.Cout % 256 == 0 && a.K >= 128 && ((a.M + 127) / 128) * (a.Cout / 256) >= 192) cfg = 1;
+            else if (a.Cout % 128 == 0 && a.K >= 128 && ((a.M + 255) / 256) * (a.Cout / 128) >= 192) cfg = 2;
+            else return 1;
+        }
+    }
+    return g_use_buf ? launch_cfg_x<true>(a, split, act, cfg, st) : launch_cfg_x<false>(a, split, act, cfg, st);
+}
+
+}  // namespace c16
+}  // namespace tlk
+
+extern "C" int tlk_conv16_set_loader(int use_buffer_loads) { g_use_buf = use_buffer_loads ? 1 : 0; return TLK_OK; }

@@ -73,9 +73,11 @@ extern "C" int tlk_iou_matrix_f64(int variant, const double *b1, int n, const do
 // Batched LSA: one wavefront per problem, 4 problems per 256-thread workgroup, work arrays in LDS,
 // cost rows read from HBM/L2 (each row scan is one coalesced 64-lane read).
 // ---------------------------------------------------------------------------------------------
+static int g_debug_hop_limit = 0;       // tlk_debug_lsa_hop_limit
+
 __global__ void __launch_bounds__(BLOCK) lsa_kernel(const double *__restrict__ cost, int batch, int nr, int nc,
                                                     int *__restrict__ rows, int *__restrict__ cols,
-                                                    int *__restrict__ n_pairs, int maxdim)
+                                                    int *__restrict__ n_pairs, int maxdim, int hop_limit)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -93,6 +95,7 @@ __global__ void __launch_bounds__(BLOCK) lsa_kernel(const double *__restrict__ c
     W.col4row = W.remaining + maxdim;
     W.SR = (unsigned char *)(W.col4row + maxdim);
     W.SC = W.SR + maxdim;
+    W.hop_limit = hop_limit;
     const double *c = cost + (size_t)prob * nr * nc;
     // scipy: "matrix contains invalid numeric entries" on NaN / -inf
     bool bad = false;
@@ -119,8 +122,17 @@ extern "C" int tlk_lsa_f64(const double *cost, int batch, int nr, int nc, int32_
     if (smem > 160 * 1024) return fail(TLK_ECAPACITY, "tlk_lsa_f64: problem too large for LDS work arrays");
     TLK_HIP(hipFuncSetAttribute((const void *)lsa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(lsa_kernel, dim3((batch + NWAVES - 1) / NWAVES), dim3(BLOCK), smem, st, cost, batch, nr, nc,
-                       rows, cols, n_pairs, maxdim);
+                       rows, cols, n_pairs, maxdim, g_debug_hop_limit);
     TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
+
+// Test hook (tests/test_gpu_kernels.py): cap the augmenting-path walk of tlk_lsa_f64's solver at `hops` steps (0 = the natural bound, the
+// number of rows) so that the bounded-loop exit -- n_pairs = -3, TLK_EINTERNAL in the tracker banks -- can be exercised on purpose.
+extern "C" int tlk_debug_lsa_hop_limit(int hops)
+{
+    if (hops < 0) return fail(TLK_EINVAL, "tlk_debug_lsa_hop_limit: hops >= 0");
+    g_debug_hop_limit = hops;
     return TLK_OK;
 }
 

@@ -631,7 +631,7 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
                 PROF(6);
                 if (tid < WAVE) {
                     const int r = wave_lsa(cost, N, T, (size_t)T, (size_t)1, L.W, L.mi_r, L.mi_c);
-                    if (tid == 0) L.sc[SC_NMI] = r < 0 ? 0 : r;
+                    if (tid == 0) { L.sc[SC_NMI] = r < 0 ? 0 : r; if (r == LSA_EINTERNAL) hdr[H_ERR] = TLK_EINTERNAL; }
                 }
                 __syncthreads();
                 n_mi = L.sc[SC_NMI];
@@ -702,7 +702,7 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
                 __syncthreads();
                 if (tid < WAVE) {
                     const int r = wave_lsa(mat, nrow, ncol, (size_t)ncol, (size_t)1, L.W, L.mi_r, L.mi_c);
-                    if (tid == 0) L.sc[SC_NL] = r < 0 ? 0 : r;
+                    if (tid == 0) { L.sc[SC_NL] = r < 0 ? 0 : r; if (r == LSA_EINTERNAL) hdr[H_ERR] = TLK_EINTERNAL; }
                 }
                 __syncthreads();
                 const int nl = L.sc[SC_NL];
@@ -780,7 +780,7 @@ deepocsort_frames_kernel(DocDev D, DocP P, const double *__restrict__ dets_all, 
         PROF(12);
         if (tid == 0) {
             hdr[H_NTRK] = kept; hdr[H_NFREE] = nfree; hdr[H_NEXTID] = nextid;
-            *out_count = rows > out_cap ? TLK_ECAPACITY : rows;
+            *out_count = hdr[H_ERR] != 0 ? hdr[H_ERR] : (rows > out_cap ? TLK_ECAPACITY : rows);      // (H_ERR: TLK_EINTERNAL from a solver's loop bound)
         }
         __threadfence_block();
         __syncthreads();
@@ -1057,7 +1057,7 @@ extern "C" int tlk_deepocsort_update(tlk_deepocsort *h, int stream, const double
     int rows = 0;
     TLK_HIP(hipMemcpyAsync(&rows, h->d_ocnt, sizeof(int), hipMemcpyDeviceToHost, st));
     TLK_HIP(hipStreamSynchronize(st));
-    if (rows < 0) return fail(rows, "tlk_deepocsort_update: tracker capacity exceeded (max_tracks/max_dets)");
+    if (rows < 0) return fail_stream(rows, "tlk_deepocsort_update");
     if (rows > out_cap) return fail(TLK_ECAPACITY, "tlk_deepocsort_update: output buffer too small");
     if (rows) TLK_HIP(hipMemcpy(out, h->d_out, sizeof(double) * 8 * (size_t)rows, hipMemcpyDeviceToHost));
     *n_out = rows;

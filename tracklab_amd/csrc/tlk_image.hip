@@ -109,7 +109,7 @@ template <typename T, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK) crop_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
                                                      const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
                                                      int OH, int OW, float m0, float m1, float m2, float d0, float d1, float d2,
-                                                     T *__restrict__ out, int swap_rb)
+                                                     T *__restrict__ out, int swap_rb, const int *__restrict__ slot_base)
 {
     const int groups_per_row = OW / 8;
     const int per_crop = groups_per_row * OH;
@@ -119,6 +119,8 @@ __global__ void __launch_bounds__(BLOCK) crop_kernel(const unsigned char *__rest
     const int rem = (int)(gid - (long long)slot * per_crop);
     const int y = rem / groups_per_row, x_base = (rem - y * groups_per_row) * 8;
     const int b = slot / max_n, i = slot - b * max_n;
+    const int oslot = slot_base ? slot_base[b] + i : slot;      // compact output (tlk_roi_crop_resize_norm_compact): crop i of frame b lands at slot_base[b] + i
+    if (slot_base && i >= counts[b]) return;                       // (compact form: a padding slot has no place to be zero-filled)
     const float mean[3] = {m0, m1, m2}, den[3] = {d0, d1, d2};
     T px[8][3];
     bool valid = i < counts[b];
@@ -151,10 +153,10 @@ __global__ void __launch_bounds__(BLOCK) crop_kernel(const unsigned char *__rest
             Pack<T, 8> p;
 #pragma unroll
             for (int k = 0; k < 8; ++k) p.v[k] = px[k][c];
-            *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)slot * 3 + c) * OH + y) * OW + x_base) = p;
+            *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)oslot * 3 + c) * OH + y) * OW + x_base) = p;
         }
     } else {
-        T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
+        T *o = out + (((size_t)oslot * OH + y) * OW + x_base) * 3;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             Pack<T, 8> p;
@@ -266,7 +268,7 @@ template <typename T, int LAYOUT>
 __global__ void __launch_bounds__(BLOCK) crop_wave2_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
                                                           const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
                                                           int OH, const T *__restrict__ lut_g, float m0, float m1, float m2,
-                                                          float d0, float d1, float d2, T *__restrict__ out, int swap_rb, int nwg)
+                                                          float d0, float d1, float d2, T *__restrict__ out, int swap_rb, int nwg, const int *__restrict__ slot_base)
 {
     constexpr int OW = 128, HS = OW * 3, GROUPS = OW / 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -281,6 +283,7 @@ __global__ void __launch_bounds__(BLOCK) crop_wave2_kernel(const unsigned char *
     const int bands = (OH + CS_BAND - 1) / CS_BAND, chunks = (bands + CF_BANDS - 1) / CF_BANDS;
     const int slot = wg / chunks, chunk = wg - slot * chunks;
     const int b = slot / max_n, i = slot - b * max_n;
+    const int oslot = slot_base ? slot_base[b] + i : slot;      // compact output (tlk_roi_crop_resize_norm_compact): crop i of frame b lands at slot_base[b] + i
     if (i >= counts[b]) return;                         // padding slot: left untouched
     const int band0 = chunk * CF_BANDS, nbands = min(CF_BANDS, bands - band0);
     int2 *s_xc = reinterpret_cast<int2 *>(s_dyn);
@@ -346,12 +349,12 @@ __global__ void __launch_bounds__(BLOCK) crop_wave2_kernel(const unsigned char *
                 const int ry = u >> 4, x_base = (u & (GROUPS - 1)) * 8, y = row0 + mb * mbh + ry;
                 if (y >= OH || mb * mbh + ry >= rows_chunk) continue;
                 if (valid) crop_direct_unit<T, LAYOUT>(frames + frame_off + ((size_t)par.t * W + par.l) * 3, W, par.ch, par.cw, OH, OW, y, x_base, m0, m1, m2, d0, d1, d2,
-                                                       swap_rb, out, (size_t)slot);
+                                                       swap_rb, out, (size_t)oslot);
                 else
                     for (int k = 0; k < 8; ++k)
                         for (int c = 0; c < 3; ++c) {
-                            if (LAYOUT == LAYOUT_NCHW) out[(((size_t)slot * 3 + c) * OH + y) * OW + x_base + k] = cvt<T>(0.f);
-                            else out[(((size_t)slot * OH + y) * OW + x_base + k) * 3 + c] = cvt<T>(0.f);
+                            if (LAYOUT == LAYOUT_NCHW) out[(((size_t)oslot * 3 + c) * OH + y) * OW + x_base + k] = cvt<T>(0.f);
+                            else out[(((size_t)oslot * OH + y) * OW + x_base + k) * 3 + c] = cvt<T>(0.f);
                         }
             }
         return;
@@ -510,7 +513,7 @@ __global__ void __launch_bounds__(BLOCK) crop_wave2_kernel(const unsigned char *
             fetch(mb + 3, N);
         }
         if (block) {
-            uint4 *g = reinterpret_cast<uint4 *>(out + ((size_t)slot * OH + row0 + mb * mbh) * OW * 3);
+            uint4 *g = reinterpret_cast<uint4 *>(out + ((size_t)oslot * OH + row0 + mb * mbh) * OW * 3);
 #pragma unroll
             for (int k = 0; k < NST; ++k) stream_store(g + k * WAVE + lane, blk[k]);
         } else if (act) {
@@ -520,10 +523,10 @@ __global__ void __launch_bounds__(BLOCK) crop_wave2_kernel(const unsigned char *
                     Pack<T, 8> p;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) p.v[k] = px[k][c];
-                    *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)slot * 3 + c) * OH + y) * OW + x_base) = p;
+                    *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)oslot * 3 + c) * OH + y) * OW + x_base) = p;
                 }
             } else {
-                T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
+                T *o = out + (((size_t)oslot * OH + y) * OW + x_base) * 3;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     Pack<T, 8> p;
@@ -561,7 +564,7 @@ template <typename T, int LAYOUT, bool P16, bool PREFETCH3 = false>
 __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *__restrict__ frames, int B, int H, int W,
                                                           const float *__restrict__ boxes, const int *__restrict__ counts, int max_n,
                                                           int OH, const T *__restrict__ lut_g, float m0, float m1, float m2,
-                                                          float d0, float d1, float d2, T *__restrict__ out, int swap_flags, int nwg)
+                                                          float d0, float d1, float d2, T *__restrict__ out, int swap_flags, int nwg, const int *__restrict__ slot_base)
 {
     const int swap_rb = swap_flags & 1;                  // bit 1 of swap_flags (experiment, TLK_CROP_NT=0): plain instead of streaming stores
     const bool plain_stores = (swap_flags & 2) != 0;
@@ -578,6 +581,7 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
     const int bands = (OH + CS_BAND - 1) / CS_BAND, chunks = (bands + CF_BANDS - 1) / CF_BANDS;
     const int slot = wg / chunks, chunk = wg - slot * chunks;
     const int b = slot / max_n, i = slot - b * max_n;
+    const int oslot = slot_base ? slot_base[b] + i : slot;      // compact output (tlk_roi_crop_resize_norm_compact): crop i of frame b lands at slot_base[b] + i
     if (i >= counts[b]) return;                         // padding slot: left untouched
     const int band0 = chunk * CF_BANDS, nbands = min(CF_BANDS, bands - band0);
     int2 *s_xc = reinterpret_cast<int2 *>(s_dyn);
@@ -644,12 +648,12 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
                 const int ry = u >> 4, x_base = (u & (GROUPS - 1)) * 8, y = row0 + mb * mbh + ry;
                 if (y >= OH || mb * mbh + ry >= rows_chunk) continue;
                 if (valid) crop_direct_unit<T, LAYOUT>(frames + frame_off + ((size_t)par.t * W + par.l) * 3, W, par.ch, par.cw, OH, OW, y, x_base, m0, m1, m2, d0, d1, d2,
-                                                       swap_rb, out, (size_t)slot);
+                                                       swap_rb, out, (size_t)oslot);
                 else
                     for (int k = 0; k < 8; ++k)
                         for (int c = 0; c < 3; ++c) {
-                            if (LAYOUT == LAYOUT_NCHW) out[(((size_t)slot * 3 + c) * OH + y) * OW + x_base + k] = cvt<T>(0.f);
-                            else out[(((size_t)slot * OH + y) * OW + x_base + k) * 3 + c] = cvt<T>(0.f);
+                            if (LAYOUT == LAYOUT_NCHW) out[(((size_t)oslot * 3 + c) * OH + y) * OW + x_base + k] = cvt<T>(0.f);
+                            else out[(((size_t)oslot * OH + y) * OW + x_base + k) * 3 + c] = cvt<T>(0.f);
                         }
             }
         return;
@@ -839,7 +843,7 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
             fetch(mb + 1 + DEPTH, N);
         }
         if (block) {
-            uint4 *g = reinterpret_cast<uint4 *>(out + ((size_t)slot * OH + row0 + mb * mbh) * OW * 3);
+            uint4 *g = reinterpret_cast<uint4 *>(out + ((size_t)oslot * OH + row0 + mb * mbh) * OW * 3);
             if (plain_stores) {
 #pragma unroll
                 for (int k = 0; k < NST; ++k) g[k * WAVE + lane] = blk[k];
@@ -854,10 +858,10 @@ __global__ void __launch_bounds__(BLOCK) crop_wave3_kernel(const unsigned char *
                     Pack<T, 8> p;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) p.v[k] = px[k][c];
-                    *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)slot * 3 + c) * OH + y) * OW + x_base) = p;
+                    *reinterpret_cast<Pack<T, 8> *>(out + (((size_t)oslot * 3 + c) * OH + y) * OW + x_base) = p;
                 }
             } else {
-                T *o = out + (((size_t)slot * OH + y) * OW + x_base) * 3;
+                T *o = out + (((size_t)oslot * OH + y) * OW + x_base) * 3;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     Pack<T, 8> p;
@@ -1378,7 +1382,7 @@ const void *crop_lut(float m0, float m1, float m2, float d0, float d1, float d2)
 
 template <typename T>
 int launch_crop(const unsigned char *frames, int B, int H, int W, const float *boxes, const int *counts, int max_n, int OH, int OW,
-                const float *mean, const float *stdv, int layout, void *out, hipStream_t st, int swap_rb)
+                const float *mean, const float *stdv, int layout, void *out, hipStream_t st, int swap_rb, const int *slot_base = nullptr)
 {
     const long long units = (long long)B * max_n * OH * (OW / 8);
     const dim3 grid((unsigned)((units + BLOCK - 1) / BLOCK));
@@ -1399,20 +1403,20 @@ int launch_crop(const unsigned char *frames, int B, int H, int W, const float *b
         if constexpr (sizeof(T) == 2) {
             static const int p16_on = [] { const char *e = getenv("TLK_CROP_P16"); return e ? atoi(e) : 1; }();     // 0: the general-pitch code also for 16-byte-multiple row pitches (tests)
             const bool p16 = p16_on && ((long long)W * 3) % 16 == 0;
-#define TLK_CW3(LAY, P) hipLaunchKernelGGL((crop_wave3_kernel<T, LAY, P, false>), dim3(nwg2), dim3(BLOCK), smem3, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, (swap_rb ? 1 : 0), nwg2)
+#define TLK_CW3(LAY, P) hipLaunchKernelGGL((crop_wave3_kernel<T, LAY, P, false>), dim3(nwg2), dim3(BLOCK), smem3, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, (swap_rb ? 1 : 0), nwg2, slot_base)
             if (layout == LAYOUT_NCHW) { if (p16) TLK_CW3(LAYOUT_NCHW, true); else TLK_CW3(LAYOUT_NCHW, false); }
             else { if (p16) TLK_CW3(LAYOUT_NHWC, true); else TLK_CW3(LAYOUT_NHWC, false); }
 #undef TLK_CW3
         } else if (layout == LAYOUT_NCHW)
-            hipLaunchKernelGGL((crop_wave2_kernel<T, LAYOUT_NCHW>), dim3(nwg2), dim3(BLOCK), smem3, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg2);
+            hipLaunchKernelGGL((crop_wave2_kernel<T, LAYOUT_NCHW>), dim3(nwg2), dim3(BLOCK), smem3, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg2, slot_base);
         else
-            hipLaunchKernelGGL((crop_wave2_kernel<T, LAYOUT_NHWC>), dim3(nwg2), dim3(BLOCK), smem3, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg2);
+            hipLaunchKernelGGL((crop_wave2_kernel<T, LAYOUT_NHWC>), dim3(nwg2), dim3(BLOCK), smem3, st, frames, B, H, W, boxes, counts, max_n, OH, lut, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, nwg2, slot_base);
         return TLK_OK;
     }
     if (layout == LAYOUT_NCHW)
-        hipLaunchKernelGGL((crop_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb);
+        hipLaunchKernelGGL((crop_kernel<T, LAYOUT_NCHW>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, slot_base);
     else
-        hipLaunchKernelGGL((crop_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb);
+        hipLaunchKernelGGL((crop_kernel<T, LAYOUT_NHWC>), grid, dim3(BLOCK), 0, st, frames, B, H, W, boxes, counts, max_n, OH, OW, m0, m1, m2, d0, d1, d2, (T *)out, swap_rb, slot_base);
     return TLK_OK;
 }
 
@@ -1439,21 +1443,87 @@ extern "C" int tlk_letterbox_u8(const uint8_t *frames_dev, int batch, int h, int
     return TLK_OK;
 }
 
+namespace {
+int roi_crop_common(const char *fn, const uint8_t *frames_dev, int batch, int h, int w, const float *boxes_ltwh_dev, const int32_t *counts_dev, int max_n,
+                    int out_h, int out_w, const float *mean3, const float *std3, int layout, int dtype, void *out_dev, const int32_t *slot_base_dev,
+                    void *hip_stream);
+
+// slot bookkeeping of the compact crop batch, one wavefront: base[b] = counts[0] + ... + counts[b - 1] (counts clamped to [0, max_n]),
+// total[0] = their sum, slot_of[b * max_n + i] = base[b] + i for i < counts[b] (position of crop i of frame b in the compact batch) and,
+// for the padding slots, total - 1 clamped to 0 (any valid row: consumers gather through slot_of and ignore i >= counts[b])
+__global__ void __launch_bounds__(WAVE) crop_slot_bases_kernel(const int *__restrict__ counts, int batch, int max_n, int *__restrict__ base,
+                                                              int *__restrict__ total, long long *__restrict__ slot_of)
+{
+    const int lane = threadIdx.x;
+    int run = 0;
+    for (int b0 = 0; b0 < batch; b0 += WAVE) {
+        const int b = b0 + lane;
+        int c = b < batch ? counts[b] : 0;
+        c = c < 0 ? 0 : (c > max_n ? max_n : c);
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+        if (b < batch) base[b] = run + incl - c;
+        run += __shfl(incl, WAVE - 1);
+    }
+    if (lane == 0) total[0] = run;
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    if (slot_of) {
+        const int last = run > 0 ? run - 1 : 0;
+        for (int k = lane; k < batch * max_n; k += WAVE) {
+            const int b = k / max_n, i = k - b * max_n;
+            int c = counts[b];
+            c = c < 0 ? 0 : (c > max_n ? max_n : c);
+            slot_of[k] = i < c ? base[b] + i : last;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int tlk_crop_slot_bases(const int32_t *counts_dev, int batch, int max_n, int32_t *base_dev, int32_t *total_dev, int64_t *slot_of_dev, void *hip_stream)
+{
+    if (batch < 0 || max_n < 0) return fail(TLK_EINVAL, "tlk_crop_slot_bases: negative size");
+    if (!counts_dev || !base_dev || !total_dev) return fail(TLK_EINVAL, "tlk_crop_slot_bases: null pointer");
+    hipLaunchKernelGGL(crop_slot_bases_kernel, dim3(1), dim3(WAVE), 0, (hipStream_t)hip_stream, counts_dev, batch, max_n, base_dev, total_dev, (long long *)slot_of_dev);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
+
+extern "C" int tlk_roi_crop_resize_norm_compact(const uint8_t *frames_dev, int batch, int h, int w, const float *boxes_ltwh_dev,
+                                                const int32_t *counts_dev, const int32_t *slot_base_dev, int max_n, int out_h, int out_w, const float *mean3,
+                                                const float *std3, int layout, int dtype, void *out_dev, void *hip_stream)
+{
+    if (!slot_base_dev) return fail(TLK_EINVAL, "tlk_roi_crop_resize_norm_compact: null slot_base_dev");
+    return roi_crop_common("tlk_roi_crop_resize_norm_compact", frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, dtype,
+                           out_dev, slot_base_dev, hip_stream);
+}
+
 extern "C" int tlk_roi_crop_resize_norm(const uint8_t *frames_dev, int batch, int h, int w, const float *boxes_ltwh_dev,
                                         const int32_t *counts_dev, int max_n, int out_h, int out_w, const float *mean3,
                                         const float *std3, int layout, int dtype, void *out_dev, void *hip_stream)
 {
-    if (batch < 0 || h <= 0 || w <= 0 || max_n < 0 || out_h <= 0 || out_w <= 0) return fail(TLK_EINVAL, "tlk_roi_crop_resize_norm: bad size");
-    if (out_w % 8 != 0) return fail(TLK_EINVAL, "tlk_roi_crop_resize_norm: out_w must be a multiple of 8");
+    return roi_crop_common("tlk_roi_crop_resize_norm", frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, dtype, out_dev,
+                           nullptr, hip_stream);
+}
+
+namespace {
+int roi_crop_common(const char *fn, const uint8_t *frames_dev, int batch, int h, int w, const float *boxes_ltwh_dev, const int32_t *counts_dev, int max_n,
+                    int out_h, int out_w, const float *mean3, const float *std3, int layout, int dtype, void *out_dev, const int32_t *slot_base_dev,
+                    void *hip_stream)
+{
+    if (batch < 0 || h <= 0 || w <= 0 || max_n < 0 || out_h <= 0 || out_w <= 0) return fail(TLK_EINVAL, std::string(fn) + ": bad size");
+    if (out_w % 8 != 0) return fail(TLK_EINVAL, std::string(fn) + ": out_w must be a multiple of 8");
     const int swap_rb = (layout & TLK_SWAP_RB) ? 1 : 0;
     layout &= ~TLK_SWAP_RB;
-    if (layout < 0 || layout > 1 || dtype < 0 || dtype > 2) return fail(TLK_EINVAL, "tlk_roi_crop_resize_norm: bad layout/dtype");
+    if (layout < 0 || layout > 1 || dtype < 0 || dtype > 2) return fail(TLK_EINVAL, std::string(fn) + ": bad layout/dtype");
     if (batch == 0 || max_n == 0) return TLK_OK;
-    if (!frames_dev || !boxes_ltwh_dev || !counts_dev || !mean3 || !std3 || !out_dev) return fail(TLK_EINVAL, "tlk_roi_crop_resize_norm: null pointer");
+    if (!frames_dev || !boxes_ltwh_dev || !counts_dev || !mean3 || !std3 || !out_dev) return fail(TLK_EINVAL, std::string(fn) + ": null pointer");
     hipStream_t st = (hipStream_t)hip_stream;
-    if (dtype == 0) launch_crop<float>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st, swap_rb);
-    else if (dtype == 1) launch_crop<__half>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st, swap_rb);
-    else launch_crop<bf16_t>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st, swap_rb);
+    if (dtype == 0) launch_crop<float>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st, swap_rb, slot_base_dev);
+    else if (dtype == 1) launch_crop<__half>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st, swap_rb, slot_base_dev);
+    else launch_crop<bf16_t>(frames_dev, batch, h, w, boxes_ltwh_dev, counts_dev, max_n, out_h, out_w, mean3, std3, layout, out_dev, st, swap_rb, slot_base_dev);
     TLK_HIP(hipGetLastError());
     return TLK_OK;
 }
+}  // namespace

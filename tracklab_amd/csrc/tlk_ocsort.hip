@@ -481,7 +481,7 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
             } else {
                 if (tid < WAVE) {
                     const int r = wave_lsa(cost, N, T, (size_t)T, (size_t)1, L.W, L.mi_r, L.mi_c);
-                    if (tid == 0) L.sc[SC_NMI] = r < 0 ? 0 : r;
+                    if (tid == 0) { L.sc[SC_NMI] = r < 0 ? 0 : r; if (r == LSA_EINTERNAL) hdr[H_ERR] = TLK_EINTERNAL; }
                 }
                 __syncthreads();
                 n_mi = L.sc[SC_NMI];
@@ -548,7 +548,7 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
             __syncthreads();
             if (tid < WAVE) {
                 const int r = wave_lsa(mat, nrow, ncol, (size_t)ncol, (size_t)1, L.W, L.mi_r, L.mi_c);
-                if (tid == 0) L.sc[SC_NL] = r < 0 ? 0 : r;
+                if (tid == 0) { L.sc[SC_NL] = r < 0 ? 0 : r; if (r == LSA_EINTERNAL) hdr[H_ERR] = TLK_EINTERNAL; }
             }
             __syncthreads();
             const int nl = L.sc[SC_NL];
@@ -625,7 +625,7 @@ ocsort_frames_kernel(OcsDev D, OcsP P, const double *__restrict__ dets_all, cons
         PROF(10);
         if (tid == 0) {
             hdr[H_NTRK] = kept; hdr[H_NFREE] = nfree; hdr[H_NEXTID] = nextid;
-            *out_count = rows > out_cap ? TLK_ECAPACITY : rows;
+            *out_count = hdr[H_ERR] != 0 ? hdr[H_ERR] : (rows > out_cap ? TLK_ECAPACITY : rows);      // (H_ERR: TLK_EINTERNAL from a solver's loop bound)
         }
         __syncthreads();
     }
@@ -841,7 +841,7 @@ extern "C" int tlk_ocsort_update(tlk_ocsort *h, int stream, const double *dets, 
     TLK_HIP(hipMemcpyAsync(h->h_cnt + 1, h->d_ocnt, sizeof(int), hipMemcpyDeviceToHost, st));
     TLK_HIP(hipStreamSynchronize(st));
     const int rows = h->h_cnt[1];
-    if (rows < 0) return fail(rows, "tlk_ocsort_update: tracker capacity exceeded (max_tracks/max_dets)");
+    if (rows < 0) return fail_stream(rows, "tlk_ocsort_update");
     if (rows > out_cap) return fail(TLK_ECAPACITY, "tlk_ocsort_update: output buffer too small");
     if (rows) {
         TLK_HIP(hipMemcpyAsync(pin_out, h->d_out, sizeof(double) * 8 * (size_t)rows, hipMemcpyDeviceToHost, st));

@@ -330,6 +330,7 @@ ssort_assoc_kernel(SsDev Dv, SsP P, SsIn in, tlk_ssort_row *__restrict__ rows_al
     __syncthreads();
     const McmOut Bm = min_cost_matching(cb, nb, n_uda, P.max_iou_dist, L.bc, L.um_da, L.m_t + A.nm, L.m_d + A.nm, L.um_tb, L.um_db, L);
     const int nm = A.nm + Bm.nm;
+    if (A.err | Bm.err) { if (tid == 0) { hdr[H_ERR] = TLK_EINTERNAL; *out_count = TLK_EINTERNAL; } return; }      // uniform: an assignment solver hit its loop bound
     for (int k = tid; k < Bm.n_um_t; k += BLOCK) L.um_t[n_uta + k] = L.um_tb[k];
     const int n_umt = n_uta + Bm.n_um_t, n_umd = Bm.n_um_d;
     const int *um_d_final = L.um_db;
@@ -477,7 +478,7 @@ ssort_assoc_kernel(SsDev Dv, SsP P, SsIn in, tlk_ssort_row *__restrict__ rows_al
                                         r.conf = Kt.d(SD_CONF); r.class_id = Kt.i(SI_CLS); r.time_since_update = Kt.i(SI_TSU);
                                         rows[pos] = r;
                                     }, L.scan);
-    if (tid == 0) *out_count = (nrows > out_cap || hdr[H_ERR] != 0) ? TLK_ECAPACITY : nrows;
+    if (tid == 0) *out_count = hdr[H_ERR] != 0 ? hdr[H_ERR] : (nrows > out_cap ? TLK_ECAPACITY : nrows);
 }
 
 __global__ void ssort_reset_kernel(SsDev D, int stream)
@@ -747,7 +748,7 @@ extern "C" int tlk_ssort_update(tlk_ssort *h, int stream, const double *dets, co
     int rows_n = 0;
     TLK_HIP(hipMemcpyAsync(&rows_n, h->d_ocnt, sizeof(int), hipMemcpyDeviceToHost, st));
     TLK_HIP(hipStreamSynchronize(st));
-    if (rows_n < 0) return fail(rows_n, "tlk_ssort_update: tracker capacity exceeded (max_tracks/max_dets)");
+    if (rows_n < 0) return fail_stream(rows_n, "tlk_ssort_update");
     if (rows_n > cap) return fail(TLK_ECAPACITY, "tlk_ssort_update: output buffer too small");
     if (rows_n) TLK_HIP(hipMemcpy(rows, h->d_rows, sizeof(tlk_ssort_row) * rows_n, hipMemcpyDeviceToHost));
     *n_out = rows_n;

@@ -250,11 +250,11 @@ __device__ inline void bcarve(unsigned char *smem, int MAXT, int MAXD, BLds &L)
 // sort/linear_assignment.py:11-73 on a (nt x nd) cost already thresholded in `th` (row-major, ld = nd).
 // trk_idx / det_idx map rows / columns to track positions / filtered detection indices.
 // Appends matches at m_t/m_d[nm0..], writes unmatched lists. All 256 threads call; returns via LDS scalars.
-struct McmOut { int nm, n_um_t, n_um_d; };
+struct McmOut { int nm, n_um_t, n_um_d, err; };      // err: the solver hit a loop bound (LSA_EINTERNAL): the caller poisons the stream
 __device__ McmOut min_cost_matching(const double *th, int nt, int nd, double max_distance, const int *trk_idx, const int *det_idx,
                                     int *m_t, int *m_d, int *um_t, int *um_d, BLds &L)
 {
-    McmOut o{0, 0, 0};
+    McmOut o{0, 0, 0, 0};
     const int tid = threadIdx.x;
     if (nd == 0 || nt == 0) {
         for (int i = tid; i < nt; i += BLOCK) um_t[i] = trk_idx[i];
@@ -266,10 +266,11 @@ __device__ McmOut min_cost_matching(const double *th, int nt, int nd, double max
     __syncthreads();
     if (tid < WAVE) {
         const int r = wave_lsa(th, nt, nd, (size_t)nd, (size_t)1, L.W, L.mi_r, L.mi_c);
-        if (tid == 0) L.sc[0] = r < 0 ? 0 : r;
+        if (tid == 0) L.sc[0] = r == LSA_EINTERNAL ? r : (r < 0 ? 0 : r);
     }
     __syncthreads();
-    const int np = L.sc[0];
+    int np = L.sc[0];
+    if (np < 0) { o.err = 1; np = 0; }
     for (int k = tid; k < nt; k += BLOCK) L.rowf[k] = 0;
     for (int k = tid; k < nd; k += BLOCK) L.colf[k] = 0;
     __syncthreads();

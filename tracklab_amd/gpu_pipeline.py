@@ -356,6 +356,14 @@ class DetReidTrackPipeline:
                              "scores": torch.zeros((B * max_dets, 17), dtype=torch.float32, device=dev),
                              "conf": torch.zeros((B * max_dets,), dtype=torch.float32, device=dev)}
         self.id_off = torch.arange(B * max_dets, dtype=torch.int64, device=dev).reshape(B, max_dets)
+        # r05: the ReID batch is DENSE -- only the real crops of the step are cropped, convolved and pooled (the reference's ReID wrapper batches real
+        # detections only, wrappers/reid/kpreid_api.py:147-182): crop i of frame b sits at slot_base[b] + i, the libtlk convolutions read the live
+        # crop count from n_live when they run (so one captured hipGraph serves every step), and the embeddings are gathered back into the
+        # tracker's (frame, detection) layout through slot_of.  TLK_DENSE_REID=0 keeps the r04 slot layout (every slot convolved).
+        self.dense_reid = (not self.global_feat) and __import__("os").environ.get("TLK_DENSE_REID", "1") != "0"
+        self.slot_base = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.n_live = torch.full((1,), B * max_dets, dtype=torch.int32, device=dev)
+        self.slot_of = torch.arange(B * max_dets, dtype=torch.int64, device=dev)
         self.nbuf = 2
         self.bufs = []
         row_bytes = self.row_dtype.itemsize
@@ -450,8 +458,10 @@ class DetReidTrackPipeline:
             crops = _lib.roi_crop_pil_resize_norm(frames, buf["trk_in"], self.det["counts"], self.reid_hw[0], self.reid_hw[1],
                                                   "nhwc", self.dtype, out=self.crops)
         else:
+            if self.dense_reid:
+                _lib.crop_slot_bases(self.det["counts"], maxd, self.slot_base, self.n_live, self.slot_of)
             crops = _lib.roi_crop_resize_norm(frames, self.det["ltwh"], self.det["counts"], self.reid_hw[0], self.reid_hw[1],
-                                              "nhwc", self.dtype, out=self.crops)
+                                              "nhwc", self.dtype, out=self.crops, slot_base=self.slot_base if self.dense_reid else None)
         if self.record_kernel_events:
             e1.record()
             self.kernel_events.append((e0, e1))
@@ -490,13 +500,23 @@ class DetReidTrackPipeline:
                 sx, sy = self.pose(pcrops)
             _lib.simcc_decode(sx, sy, self.pose_meta, 192, 256, 2.0, out=self.pose_out)
             buf["kps"].copy_(self.pose_out["kps_xyc"].view(self.B, maxd, 17, 3))
-        if self.use_graph:
-            emb, vis = self._graphed(self.__dict__.setdefault("_rg", {}), 0, lambda: self.reid(crops))
-        else:
-            emb, vis = self.reid(crops)
+        if self.dense_reid:
+            _lib.conv_set_dynamic_batch(self.n_live)      # (a captured graph keeps the pointer: every replay reads the step's own count)
+        try:
+            if self.use_graph:
+                emb, vis = self._graphed(self.__dict__.setdefault("_rg", {}), 0, lambda: self.reid(crops))
+            else:
+                emb, vis = self.reid(crops)
+        finally:
+            if self.dense_reid:
+                _lib.conv_set_dynamic_batch(None)
         # hand-off buffers for the association stream (detector ltwh is float32: widen like numpy would)
-        buf["emb"].copy_(emb.view(self.B, maxd, self.K, self.D))
-        buf["vis"].copy_(vis.view(self.B, maxd, self.K))
+        if self.dense_reid:       # dense batch -> (frame, detection) slots; padding slots receive some valid row, the tracker reads counts[b] of them
+            torch.index_select(emb.reshape(self.B * maxd, self.K * self.D), 0, self.slot_of, out=buf["emb"].view(self.B * maxd, self.K * self.D))
+            torch.index_select(vis.reshape(self.B * maxd, self.K).to(torch.uint8), 0, self.slot_of, out=buf["vis"].view(self.B * maxd, self.K))
+        else:
+            buf["emb"].copy_(emb.view(self.B, maxd, self.K, self.D))
+            buf["vis"].copy_(vis.view(self.B, maxd, self.K))
         buf["ltwh"].copy_(self.det["ltwh"])
         buf["counts"].copy_(self.det["counts"])
         torch.add(self.id_off, self.frames_done * maxd, out=buf["ids"])

@@ -37,8 +37,7 @@ def clear_eval_sequence(gt_ids, tracker_ids, similarity, threshold: float = 0.5)
     num_gt_dets = sum(len(g) for g in gt_ids)
     num_tr_dets = sum(len(t) for t in tracker_ids)
     num_gt_ids = int(max([int(g.max()) + 1 for g in gt_ids if len(g)] + [0]))
-    res["CLR_Frames"] = n_frames
-    if num_tr_dets == 0:
+    if num_tr_dets == 0:                                      # (TrackEval's early returns leave CLR_Frames at 0: only the full path sets it)
         res["CLR_FN"] = num_gt_dets
         res["ML"] = num_gt_ids
         return res
@@ -87,6 +86,7 @@ def clear_eval_sequence(gt_ids, tracker_ids, similarity, threshold: float = 0.5)
     res["PT"] = int(np.sum(np.greater_equal(ratio, 0.2))) - res["MT"]
     res["ML"] = num_gt_ids - res["MT"] - res["PT"]
     res["Frag"] = int(np.sum(np.subtract(gt_frag_count[gt_frag_count > 0], 1)))
+    res["CLR_Frames"] = n_frames
     return res
 
 
@@ -161,18 +161,27 @@ def hota_fields(packed: np.ndarray) -> dict:
     return out
 
 
+# TrackEval's `summary_fields` per metric family, in its order (CLEAR: main float + main integer fields -- the "extra" fields CLR_F1, FP_per_frame,
+# MOTAL, MOTP_sum, CLR_Frames are per-sequence detail, not summary; HOTA: the float-array fields + the (0) fields; Identity: all six)
+SUMMARY_FIELDS = {
+    "CLEAR": ("MOTA", "MOTP", "MODA", "CLR_Re", "CLR_Pr", "MTR", "PTR", "MLR", "sMOTA", "CLR_TP", "CLR_FN", "CLR_FP", "IDSW", "MT", "PT", "ML", "Frag"),
+    "HOTA": ("HOTA", "DetA", "AssA", "DetRe", "DetPr", "AssRe", "AssPr", "LocA", "OWTA", "HOTA(0)", "LocA(0)", "HOTALocA(0)"),
+    "Identity": ("IDF1", "IDR", "IDP", "IDTP", "IDFN", "IDFP"),
+}
+
+
 def _summary(family: str, fields: dict) -> dict:
-    """_BaseMetric.summary_results: floats as percentages "{0:1.5g}", integers "%d", float arrays by their mean over the alphas."""
+    """_BaseMetric.summary_results over the family's summary_fields: floats as percentages "{0:1.5g}", integers "%d", float arrays by their
+    mean over the alphas."""
     out = {}
-    for k, v in fields.items():
+    for k in SUMMARY_FIELDS.get(family, tuple(fields)):
+        if k not in fields:
+            continue
+        v = fields[k]
         if isinstance(v, np.ndarray):
-            if k in ("HOTA_TP", "HOTA_FN", "HOTA_FP"):
-                continue
             out[k] = "{0:1.5g}".format(100 * float(np.mean(v)))
         elif isinstance(v, (int, np.integer)):
             out[k] = "%d" % v
-        elif k == "MOTP_sum":
-            continue
         else:
             out[k] = "{0:1.5g}".format(100 * float(v))
     return out

@@ -11,6 +11,29 @@ import pandas as pd
 
 from ..pipeline_api import ImageLevelModule, cfg_get, to_numpy
 
+_CAMERA_MOTION_WARNED = set()
+
+
+def _warn_unpinned_camera_motion(kind: str) -> None:
+    """One WARNING per process and estimator kind when the device camera-motion path is active while its OpenCV fixture has never been
+    checked on this installation: the yaml defaults follow the reference (ecc: true / cmc_method: sparseOptFlow), the estimators
+    restate OpenCV (cv2.findTransformECC; goodFeaturesToTrack + calcOpticalFlowPyrLK + estimateAffinePartial2D with the legacy cv::LMSolver
+    refinement of OpenCV <= 4.6 -- 4.7+ routes it through cv::LevMarq) and no cv2 exists in the build image, so track ids under camera motion can
+    drift from the reference's.  tests/golden/make_cmc_golden.py writes the fixture wherever cv2 is installed; tests/test_gpu_cmc.py then pins it."""
+    if kind in _CAMERA_MOTION_WARNED:
+        return
+    _CAMERA_MOTION_WARNED.add(kind)
+    import logging
+    import os
+    fixture = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "cmc_opencv.npz")
+    if os.path.exists(fixture):
+        return
+    logging.getLogger(__name__).warning(
+        "%s: camera-motion compensation runs on the device restatement of OpenCV (targets the 4.5-4.6 algorithms); parity with cv2 is UNPINNED "
+        "on this installation (tests/golden/cmc_opencv.npz missing: run tests/golden/make_cmc_golden.py where cv2 is installed). Track ids under "
+        "camera motion may differ from the reference's; set %s to switch it off.", kind,
+        "ecc: false" if kind == "HipStrongSORT" else "cmc_method: none")
+
 STATE_CHARS = {0: "t", 1: "c", 2: "d"}       # TrackState, bpbreid_strong_sort/sort/track.py:16-18
 MATCH_NAMES = {1: "R", 2: "S"}
 
@@ -328,6 +351,7 @@ class HipStrongSORT(ImageLevelModule, _ReidTrackerBase):
         unpinned -- DESIGN.md); one estimate per frame (the reference recomputes the same one for every track)."""
         if not self._ecc:
             return
+        _warn_unpinned_camera_motion("HipStrongSORT")
         if image is None:                                                    # strong_sort_api.py:61: the frame is read before the empty check
             from PIL import Image
             image = np.asarray(Image.open(metadatas["file_path"].values[0]).convert("RGB"))
@@ -393,6 +417,7 @@ class HipBoTSORT(ImageLevelModule, _ReidTrackerBase):
         warp = None
         if self._cmc_method == "sparseOptFlow":              # bot_sort.py:341: warp = self.gmc.apply(img, dets)
             from .._lib import CmcEstimator
+            _warn_unpinned_camera_motion("HipBoTSORT")
             dev = self._frame_on_device(image)
             if self._cmc is None or (self._cmc.h, self._cmc.w) != tuple(dev.shape[:2]):
                 if self._cmc is not None:
