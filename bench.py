@@ -206,6 +206,11 @@ def main_dry_run(args):
     nobj = args.objects or wl["objects"]
     streams = tdist.streams_for_rank(S * world, rank, world)
     assert len(streams) == S
+    # the ranks' warm-up sections run one at a time (tdist.serialized): here a stand-in sleep, in a real run graph capture + library tuning
+    warm_order = []
+    if world > 1:
+        with tdist.serialized("warmup", order=warm_order):
+            time.sleep(0.02)
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
@@ -222,6 +227,12 @@ def main_dry_run(args):
     elapsed = tdist.allreduce_max(elapsed_local, dist, dev)
     total = tdist.allreduce_sum(vec, dist, dev)
     per_rank, seen, placement = gather_ranks(dist, dev, args.steps * S * F / elapsed_local)
+    warm_windows = None
+    if dist is not None and warm_order:
+        t = torch.tensor([warm_order[0][1], warm_order[1][1]], dtype=torch.float64)
+        allw = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allw, t)
+        warm_windows = sorted([float(w[0]), float(w[1])] for w in allw)
     if rank == 0:
         fin = hota.finalize(total)
         print(json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -229,6 +240,8 @@ def main_dry_run(args):
                           "dtype": args.dtype, "data": "dry run: no GPU work, ground truth returned as tracker output", "dry_run": True,
                           "config": {"workload": wl["name"], "streams_per_gpu": S, "frames_per_step": F, "parallelism": f"stream-parallel x{world}"},
                           "per_rank_fps": per_rank, "ranks_seen": seen, "rank_placement": placement, "streams_of_rank0": streams,
+                          "rank_placement_sound": tdist.placement_is_sound(placement, int(os.environ.get("LOCAL_WORLD_SIZE", world)), os.cpu_count() or 1),
+                          "warmup_serialized": (all(a[1] <= b[0] + 1e-6 for a, b in zip(warm_windows, warm_windows[1:])) if warm_windows else None),
                           "hota_allreduce": {"HOTA": fin["summary"]["HOTA"], "frames": fin["frames"]}}), flush=True)
     if dist is not None:
         dist.barrier()
@@ -499,6 +512,15 @@ def main():
     def run_step(k, fetch=True, p=None):
         return (p or pipe).step(d_pool[k % pool_steps], d_heads[k], fetch=fetch)
 
+    if world > 1:
+        # multi-GPU job: the first step of every rank (hipGraph capture of both networks, library tuning of the f16 route, pinned allocations)
+        # runs under a node-wide lock, one rank at a time -- untimed; the state it leaves behind is reset
+        with tdist.serialized("warmup"):
+            run_step(0)
+            pipe.synchronize()
+            torch.cuda.synchronize()
+        pipe.reset()
+
     # ---- untimed parity check against the oracle chain (first frames of local stream 0) ----
     parity = None
     if rank == 0 and parity_steps > 0:
@@ -760,11 +782,14 @@ def main():
             roofline_hbm = roofline
             # the same timings per kernel instantiation (rocprofv3 names them conv_f32_mfma_kernel<TM, TN, WGM, WGN, ACT, RES>): the rows of
             # profiles/r04_config3_f32_rocprof.md to compare with
-            tmpl = {0: "2, 2, 2, 2", 1: "2, 2, 4, 1", 2: "2, 1, 2, 2", 3: "2, 3, 4, 1", 4: "2, 1, 4, 1", 5: "1, 2, 2, 2", 6: "1, 2, 4, 1"}
+            tmpl = {0: "2, 2, 2, 2", 1: "2, 2, 4, 1", 2: "2, 1, 2, 2", 3: "2, 3, 4, 1", 4: "2, 1, 4, 1", 5: "1, 2, 2, 2", 6: "1, 2, 4, 1",
+                    7: "2, 2, 2, 2", 8: "2, 1, 2, 2", 9: "1, 2, 2, 2"}
             per = {}
             for r in recs:
                 cfg_, act_, res_ = r[5]
-                e = per.setdefault(f"conv_f32_mfma_kernel<{tmpl.get(cfg_, '?')}, {act_}, {'true' if res_ else 'false'}>", [0, 0.0, 0.0])
+                kn_ = "conv_stem3_kernel (direct RGB stem, tlk_conv_stem.hip)" if cfg_ == 15 else \
+                    f"conv_f32_mfma_kernel<{tmpl.get(cfg_, '?')}, {act_}, {'true' if res_ else 'false'}, {1 if cfg_ in (7, 8, 9) else 2}>"
+                e = per.setdefault(kn_, [0, 0.0, 0.0])
                 e[0] += 1; e[1] += r[0].elapsed_time(r[1]) - r[2].elapsed_time(r[3]); e[2] += r[4]
             per_inst = [{"kernel": k_, "launches_per_step": v_[0] // 2, "avg_launch_ms": v_[1] / v_[0], "tflops": v_[2] / (v_[1] * 1e-3) / 1e12}
                         for k_, v_ in sorted(per.items(), key=lambda kv: -kv[1][1])]
@@ -951,6 +976,8 @@ def main():
                        "backbone_dtype": args.dtype},
             "per_gpu_fps": value / world, "per_rank_fps": per_rank, "ranks_seen": seen,
             "rank_placement": placement, "rank_placement_note": "[rank, NUMA node of its GPU, host CPUs it is pinned to]; node -1 = unpinned (a single rank, or /sys did not say)",
+            "rank_placement_sound": tdist.placement_is_sound(placement, int(os.environ.get("LOCAL_WORLD_SIZE", world)), os.cpu_count() or 1),
+            "warmup_serialized": world > 1,
             "collectives": "nccl" if dist is not None else None, "hota_allreduce": hota_all,
             "latency": latency, "latency_f16": latency_f16, "value_f32": (f32_leg["value"] if f32_leg else (value if args.dtype == "f32" else None)),
             "ms_per_step_f32": (f32_leg["ms_per_step"] if f32_leg else (el / args.steps * 1e3 if args.dtype == "f32" else None)),

@@ -81,3 +81,40 @@ def test_cpu_slices_are_disjoint_and_numa_local():
     node1 = list(range(32, 64))                                # GPUs 4..7 hang off NUMA node 1
     got = [tdist.numa_cpu_slice(node1, [4, 5, 6, 7], d, allowed=range(64)) for d in (4, 5, 6, 7)]
     assert got[0] == list(range(32, 40)) and got[3] == list(range(56, 64)) and sorted(sum(got, [])) == node1
+
+
+def test_warmup_sections_of_the_ranks_do_not_overlap():
+    """r05: every rank's warm-up (graph capture, library tuning, pinned allocations in a real run) passes a
+    node-wide lock one at a time; the dry run exercises the same lock with a stand-in section and reports that the eight windows are disjoint,
+    and that every rank sits on a non-empty CPU slice that can be disjoint from the others'."""
+    args = [a if a != "2" or i != 2 else "8" for i, a in enumerate(ARGS)]
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, timeout=600, env=_env(), cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["warmup_serialized"] is True and j["rank_placement_sound"] is True
+
+
+def test_serialized_lock_excludes_across_processes(tmp_path):
+    import multiprocessing as mp
+    import time
+    from tracklab_amd import dist as tdist
+    os.environ["TLK_LOCK_DIR"] = str(tmp_path)
+    try:
+        def worker(q):
+            order = []
+            with tdist.serialized("t", order=order):
+                time.sleep(0.15)
+            q.put((order[0][1], order[1][1]))
+        ctx = mp.get_context("fork")
+        q = ctx.Queue()
+        ps = [ctx.Process(target=worker, args=(q,)) for _ in range(3)]
+        for p_ in ps:
+            p_.start()
+        wins = sorted(q.get(timeout=30) for _ in ps)
+        for p_ in ps:
+            p_.join(timeout=30)
+        assert all(a[1] <= b[0] + 1e-6 for a, b in zip(wins, wins[1:])), wins
+        assert tdist.placement_is_sound([[0, -1, 8], [1, -1, 8]], 2, 16) and not tdist.placement_is_sound([[0, -1, 0], [1, -1, 8]], 2, 16)
+        assert not tdist.placement_is_sound([[0, -1, 16], [1, -1, 16]], 2, 16)
+    finally:
+        os.environ.pop("TLK_LOCK_DIR", None)

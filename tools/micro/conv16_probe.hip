@@ -2,7 +2,7 @@
 // every tile configuration of tlk_conv16x.hip against the r04 kernels, per layer: milliseconds, TFLOP/s on the algorithmic flops, GB/s on
 // the algorithmic bytes (input + weights + residual + output once), and the largest deviation from a naive fp32-accumulating reference
 // convolution on a small batch of the same shape.
-//   build:  tools/micro/build_conv16_probe.sh      run:  tools/micro/conv16_probe [crops=2400] [mode=f16|split] [loaders=1|0|both] [filter]
+//   build:  tools/micro/build_conv16_probe.sh conv16_probe      run:  tools/micro/conv16_probe [crops=2400] [mode=f16|split] [cfgs=auto|c1,c2,...] [filter]
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
@@ -17,7 +17,6 @@
 #include "tlk.h"
 
 extern "C" int tlk_conv16_set_config(int cfg);
-extern "C" int tlk_conv16_set_loader(int use_buffer_loads);
 
 #define CK(x)                                                                                            \
     do {                                                                                                 \
@@ -102,7 +101,7 @@ int main(int argc, char **argv)
 {
     const int crops = argc > 1 ? atoi(argv[1]) : 2400;
     const bool split = argc > 2 && !strcmp(argv[2], "split");
-    const char *loaders = argc > 3 ? argv[3] : "1";
+    const char *cfg_arg = argc > 3 ? argv[3] : "auto";
     const char *filter = argc > 4 ? argv[4] : "";
     const int check_crops = 3;
     // ReID ResNet-50 (last stride 1) at 384 x 128 crops: the stem's output after max pooling is 96 x 32
@@ -145,7 +144,7 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     fill_f32_kernel<<<64, 256>>>(bias, 4096, 0.5f, 77);
-    printf("# conv16_probe: %d crops, mode %s, loaders %s\n", crops, split ? "split" : "f16", loaders);
+    printf("# conv16_probe: %d crops, mode %s, configurations %s (-1 = the r04 kernels)\n", crops, split ? "split" : "f16", cfg_arg);
     printf("# %-22s %3s %6s %4s | %8s %8s %8s | %9s\n", "layer", "cnt", "GFLOP", "cfg", "ms", "TFLOP/s", "GB/s", "max err");
     double tot_ms[16][2] = {{0}};      // [cfg + 1][loader]: sum over the forward of count * ms (best-of kept separately)
     double best_total = 0, r04_total = 0, flops_total = 0;
@@ -161,26 +160,25 @@ int main(int argc, char **argv)
         fill_kernel<<<256, 256>>>(w, wl, nw, 1.0f / sqrtf((float)K), 1000 + li);
         if (L.res) fill_kernel<<<2048, 256>>>(r, rl, ny, 1.0f, 2000 + li);
         CK(hipDeviceSynchronize());
-        // candidate configurations for this width
-        std::vector<int> cfgs = {-1};
-        if (!split) {
-            if (L.Cout >= 256) cfgs.push_back(1);
-            if (L.Cout >= 128) { cfgs.push_back(2); cfgs.push_back(3); }
-            if (L.Cout == 64) { cfgs.push_back(4); cfgs.push_back(5); }
-            cfgs.push_back(6);
+        // candidate configurations: an explicit list, or every tile whose width fits the layer (BN <= Cout, BN >= Cout / 4)
+        std::vector<int> cfgs;
+        if (strcmp(cfg_arg, "auto")) {
+            for (const char *q = cfg_arg; *q;) { cfgs.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; }
         } else {
-            if (L.Cout >= 256) cfgs.push_back(1);
-            if (L.Cout >= 128) { cfgs.push_back(2); cfgs.push_back(3); }
-            if (L.Cout == 64) cfgs.push_back(4);
-            if (L.Cout < 128) cfgs.push_back(3);
+            cfgs.push_back(-1);
+            cfgs.push_back(0);                          // the library's own choice
+            const int bn_f16[] = {0, 256, 128, 128, 64, 64, 128, 64, 256, 128, 64, 64}, bn_split[] = {0, 256, 128, 128, 64, 128, 128, 128};
+            const int ncfg = split ? 7 : 11;
+            for (int c = 1; c <= ncfg; ++c) {
+                const int bn = split ? bn_split[c] : bn_f16[c];
+                if (bn <= std::max(L.Cout, 64) && (bn >= 128 || L.Cout <= 128)) cfgs.push_back(c);
+            }
         }
         double best = 1e30, r04 = 0;
         for (int cfg : cfgs) {
-            for (int ld = 1; ld >= 0; --ld) {
-                if (cfg < 0 && ld == 0) continue;
-                if (cfg >= 0 && !strcmp(loaders, "1") && ld == 0) continue;
-                if (cfg >= 0 && !strcmp(loaders, "0") && ld == 1) continue;
-                TK(tlk_conv16_set_config(cfg)); TK(tlk_conv16_set_loader(ld));
+            {
+                const int ld = 1;
+                TK(tlk_conv16_set_config(cfg));
                 auto run = [&](int n) {
                     return tlk_conv2d_nhwc_16(x, xl, w, wl, bias, L.res ? r : nullptr, L.res ? rl : nullptr, y, yl, nullptr, n, L.H, L.W, L.Cin, L.Cout, L.k, L.k, L.stride,
                                               L.pad, 1, 0, 0, 0, nullptr);
@@ -208,7 +206,7 @@ int main(int argc, char **argv)
                     ms_best = std::min(ms_best, ms);
                 }
                 const double tol = split ? 2e-6 : 1.5e-3;
-                printf("  %-22s %3d %6.1f %3d%c | %8.3f %8.1f %8.0f | %9.2e %s\n", L.name, L.count, flops / 1e9, cfg, cfg < 0 ? ' ' : (ld ? 'b' : 'p'), ms_best,
+                printf("  %-22s %3d %6.1f %3d%c | %8.3f %8.1f %8.0f | %9.2e %s\n", L.name, L.count, flops / 1e9, cfg, ' ', ms_best,
                        flops / ms_best / 1e9, bytes / ms_best / 1e6, hres[0], hres[0] <= tol ? "" : "  <-- MISMATCH");
                 fflush(stdout);
                 if (cfg < 0) r04 = ms_best;

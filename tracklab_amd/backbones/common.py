@@ -20,6 +20,8 @@ USE_TLK_CONV_F16 = _os.environ.get("TLK_CONV_F16", "0") != "0"      # r04: measu
 # the epilogue inside beats GEMM + library epilogue (RTMPose-m, 2400 crops: 0.68 vs 1.02 ms at 48 -> 48); TLK_CONV_F16_NARROW=0 opts out
 USE_TLK_CONV_F16_NARROW = _os.environ.get("TLK_CONV_F16_NARROW", "1") != "0"
 # bench.py's roofline pass: a list here makes every fp32 convolution record (start event, end event, algorithmic flops) around its launch
+# TLK_STEM=0: the RGB stems through the implicit-GEMM kernel on a 4-channel-padded image (the r04 route) instead of the direct stem kernel
+USE_TLK_STEM = _os.environ.get("TLK_STEM", "1") != "0"
 CONV_TIMER = None
 
 
@@ -154,7 +156,11 @@ class ConvBiasAct(nn.Module):
         if USE_TLK_CONV_F32 and x.is_cuda and x.dtype == torch.float32 and (x.shape[1] % 4 == 0 or x.shape[1] == 3) \
                 and x.is_contiguous(memory_format=torch.channels_last):
             from .. import _lib
-            if x.shape[1] == 3:
+            ks, st = self.conv.kernel_size, self.conv.stride
+            if x.shape[1] == 3 and residual is None and ks in ((7, 7), (3, 3)) and st == (2, 2) and self.conv.out_channels <= 64 and USE_TLK_STEM:
+                # RGB stem, direct kernel (r05, csrc/tlk_conv_stem.hip): reads the 3-channel image as it is; bit-identical to the padded route below
+                weight = self.conv.weight
+            elif x.shape[1] == 3:
                 # RGB stem: the kernel gathers 16 B per tap, so the image gets a zero 4th channel (one small pass) and the weight a zero 4th
                 # input channel (cached): zero terms in the fmaf chain, the sum is unchanged
                 c = getattr(self, "_w4", None)

@@ -30,6 +30,8 @@ inline int fail_stream(int code, const char *fn, const char *capacity_detail = "
             return ::tlk::fail(TLK_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));  \
     } while (0)
 
+int conv_stem3_f32(const float *x, const float *w, const float *bias, float *y, int n, int h, int wd, int cout, int kh, int kw, int stride, int pad, int act,
+                   int x_pix, int y_pix, hipStream_t st);      // tlk_conv_stem.hip: 1 = not a stem it has a kernel for
 const int *conv_dynamic_batch();      // tlk_conv_set_dynamic_batch (tlk_conv.hip): device pointer to the live image count, or NULL
 
 constexpr int WAVE = 64;

@@ -53,7 +53,16 @@ template <int ACT> __device__ __forceinline__ float act_f32(float v)
     return v;
 }
 
-template <int TM, int TN, int WGM, int WGN, int ACT, bool RES>
+constexpr int epi_rows(int tm, int wgm, int rows_max)        // MFMA tile rows of every wavefront per epilogue pass: the most that fit the LDS at hand
+{
+    int e = tm;
+    while (e > 1 && (tm % e != 0 || wgm * 32 * e > rows_max)) --e;
+    return e;
+}
+
+// NST = LDS stages: 2 = double-buffered K loop (the compute-bound layers), 1 = ONE stage and an epilogue in passes -- half the LDS, so a CU
+// holds twice the workgroups: what the memory-bound layers want (r05; the 16-bit kernels' probe showed residency beating an in-workgroup pipeline)
+template <int TM, int TN, int WGM, int WGN, int ACT, bool RES, int NST = 2>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const ConvArgs p)
 {
     constexpr int NT = 64 * WGM * WGN;
@@ -159,27 +168,35 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
 
     // The residual of this lane's output vectors is fetched NOW and waits in registers: the 1x1 expansions that carry it are short in K
     // (2-16 steps), their epilogue used to sit on HBM latency with four loads in flight; here all of them ride under the main loop.
-    constexpr int EV_PER_ROW = BN / 4, ENVEC = BM * EV_PER_ROW, EITS = (ENVEC + NT - 1) / NT;
+    // epilogue geometry: the tile leaves through LDS EPI tile rows of every wavefront at a time (all of it in one pass when the LDS of the
+    // stages holds it: the two-stage configurations)
+    constexpr int LDC = BN + 4;
+    constexpr int STAGE_FLOATS = (BM + BN) * LDK;
+    constexpr int LDS_AVAIL = (NST * STAGE_FLOATS > WGM * 32 * LDC) ? NST * STAGE_FLOATS : WGM * 32 * LDC;      // floats
+    constexpr int EPI = epi_rows(TM, WGM, LDS_AVAIL / LDC);
+    static_assert(WGM * 32 * EPI * LDC <= LDS_AVAIL, "epilogue pass does not fit the LDS");
+    constexpr int PROWS = WGM * 32 * EPI, NPASS = TM / EPI;
+    constexpr int EV_PER_ROW = BN / 4, ENVEC = PROWS * EV_PER_ROW, EITS = (ENVEC + NT - 1) / NT;
     const bool evec = ((p.Cout | p.y_pix | p.r_pix) & 3) == 0 && (((uintptr_t)p.y | (uintptr_t)p.res | (uintptr_t)p.bias) & 15) == 0;
-    float4 rres[RES ? EITS : 1];
+    auto pass_row = [&](int ps, int prow) {        // row of the workgroup tile that row `prow` of pass `ps` holds
+        const int pw = prow / (32 * EPI), within = prow - pw * (32 * EPI);
+        return pw * (TM * 32) + ps * (EPI * 32) + within;
+    };
+    float4 rres[RES ? NPASS : 1][RES ? EITS : 1];
     if (RES && evec) {
 #pragma unroll
-        for (int it = 0; it < EITS; ++it) {
-            const int idx = it * NT + tid;
-            const int row = idx / EV_PER_ROW, ec = (idx - row * EV_PER_ROW) * 4;
-            const long long m = m0 + row;
-            const int co = n0 + ec;
-            const bool ok = !(ENVEC % NT != 0 && idx >= ENVEC) && m < M && co < p.Cout;
-            rres[it] = ok ? *reinterpret_cast<const float4 *>(p.res + m * p.r_pix + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+            for (int it = 0; it < EITS; ++it) {
+                const int idx = it * NT + tid;
+                const int prow = idx / EV_PER_ROW, ec = (idx - prow * EV_PER_ROW) * 4;
+                const long long m = m0 + pass_row(ps, prow);
+                const int co = n0 + ec;
+                const bool ok = !(ENVEC % NT != 0 && idx >= ENVEC) && m < M && co < p.Cout;
+                rres[ps][it] = ok ? *reinterpret_cast<const float4 *>(p.res + m * p.r_pix + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
     }
     const int steps = (p.K + BK - 1) / BK;
-    set_tap(0);
-#pragma unroll
-    for (int i = 0; i < NL; ++i) issue_load(i);
-#pragma unroll
-    for (int i = 0; i < NL; ++i) issue_store(i, 0);
-    __syncthreads();
     const int frag_off = (lane & 31) * LDK + (lane >> 5) * 4;
     const float *a_frag = As + (wm * TM * 32) * LDK + frag_off, *b_frag = Bs + (wn * TN * 32) * LDK + frag_off;
     float4 fa[2][TM], fb[2][TN];
@@ -189,6 +206,41 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
 #pragma unroll
         for (int i = 0; i < TN; ++i) fb[set][i] = *reinterpret_cast<const float4 *>(b_frag + buf * BN * LDK + i * 32 * LDK + j * 8);
     };
+    if (NST == 1) {
+        // ONE stage: load, store, multiply.  Same fmaf chain (groups of 8 ascending, 0,4,1,5,2,6,3,7 inside), so the result is the same bits.
+        for (int s = 0; s < steps; ++s) {
+            set_tap(s * BK);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) issue_load(i);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) issue_store(i, 0);
+            __syncthreads();
+            read_frags(0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < BK / 8; ++j) {
+                const int set = j & 1;
+                if (j + 1 < BK / 8) read_frags(0, j + 1, set ^ 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < TN; ++jj) {
+                            const float av = r == 0 ? fa[set][i].x : r == 1 ? fa[set][i].y : r == 2 ? fa[set][i].z : fa[set][i].w;
+                            const float bv = r == 0 ? fb[set][jj].x : r == 1 ? fb[set][jj].y : r == 2 ? fb[set][jj].z : fb[set][jj].w;
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][jj], 0, 0, 0);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+    } else {
+    set_tap(0);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) issue_load(i);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) issue_store(i, 0);
+    __syncthreads();
     read_frags(0, 0, 0);
     // One K step = 16 chunks of TM*TN MFMAs (64 cycles each).  The step is software-pipelined INSIDE the wavefront, chunk by chunk, with
     // scheduling barriers between the chunks so the order below is the order issued: the loads of the next step (address arithmetic + buffer
@@ -221,74 +273,75 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
         read_frags(cur ^ 1, 0, 0);                         // (after the last step: reads the dead buffer, unused)
     }
     __syncthreads();                                       // nobody still reads fragments when the tile is staged below
+    }
 
     // ---- epilogue.  C/D map of the 32x32 tile: column (= cout) = lane & 31, row (= pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     // The tile goes through LDS (free after the last barrier) so that every lane then moves 16 contiguous bytes: rows of BN floats leave as
     // 512-byte runs, the residual arrives the same way, instead of 64 scalar stores per lane.
-    constexpr int LDC = BN + 4;
-    float *Cs = lds;                                       // [BM][LDC]
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int jj = 0; jj < TN; ++jj) {
-            float *c = Cs + ((wm * TM + i) * 32 + 4 * (lane >> 5)) * LDC + (wn * TN + jj) * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) c[((r & 3) + 8 * (r >> 2)) * LDC] = acc[i][jj][r];
-        }
-    __syncthreads();
+    float *Cs = lds;                                       // [PROWS][LDC]
     const float *__restrict__ resp = p.res;
     float *__restrict__ yp = p.y;
-    constexpr int V_PER_ROW = BN / 4, NVEC = BM * V_PER_ROW, ITS = (NVEC + NT - 1) / NT;
-    static_assert(V_PER_ROW == EV_PER_ROW && ITS == EITS, "the residual prefetch uses the epilogue's geometry");
-    const bool vec = evec;
-    if (vec) {
 #pragma unroll
-        for (int it = 0; it < ITS; ++it) {
-            const int idx = it * NT + tid;
-            const int row = idx / V_PER_ROW, ec = (idx - row * V_PER_ROW) * 4;
-            const long long m = m0 + row;
-            const int co = n0 + ec;
-            if ((NVEC % NT != 0 && idx >= NVEC) || m >= M || co >= p.Cout) continue;
-            float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec);
-            if (p.bias) { const float4 bv = *reinterpret_cast<const float4 *>(p.bias + co); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
-            else { v.x += 0.f; v.y += 0.f; v.z += 0.f; v.w += 0.f; }
-            if (RES && !p.res_post) { const float4 rv = rres[it]; v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
-            v.x = act_f32<ACT>(v.x); v.y = act_f32<ACT>(v.y); v.z = act_f32<ACT>(v.z); v.w = act_f32<ACT>(v.w);
-            if (RES && p.res_post) { const float4 rv = rres[it]; v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
-            *reinterpret_cast<float4 *>(yp + m * p.y_pix + co) = v;
-        }
-    } else {
-        for (int it = 0; it < ITS; ++it) {
-            const int idx = it * NT + tid;
-            const int row = idx / V_PER_ROW, ec = (idx - row * V_PER_ROW) * 4;
-            const long long m = m0 + row;
-            const int co = n0 + ec;
-            if ((NVEC % NT != 0 && idx >= NVEC) || m >= M) continue;
+    for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (co + e >= p.Cout) break;
-                float v = Cs[row * LDC + ec + e] + (p.bias ? p.bias[co + e] : 0.f);
-                if (RES && !p.res_post) v += resp[m * p.r_pix + co + e];
-                v = act_f32<ACT>(v);
-                if (RES && p.res_post) v += resp[m * p.r_pix + co + e];
-                yp[m * p.y_pix + co + e] = v;
+        for (int ii = 0; ii < EPI; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) {
+                float *c = Cs + ((wm * EPI + ii) * 32 + 4 * (lane >> 5)) * LDC + (wn * TN + jj) * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[((r & 3) + 8 * (r >> 2)) * LDC] = acc[ps * EPI + ii][jj][r];
+            }
+        __syncthreads();
+        if (evec) {
+#pragma unroll
+            for (int it = 0; it < EITS; ++it) {
+                const int idx = it * NT + tid;
+                const int prow = idx / EV_PER_ROW, ec = (idx - prow * EV_PER_ROW) * 4;
+                const long long m = m0 + pass_row(ps, prow);
+                const int co = n0 + ec;
+                if ((ENVEC % NT != 0 && idx >= ENVEC) || m >= M || co >= p.Cout) continue;
+                float4 v = *reinterpret_cast<const float4 *>(Cs + prow * LDC + ec);
+                if (p.bias) { const float4 bv = *reinterpret_cast<const float4 *>(p.bias + co); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+                else { v.x += 0.f; v.y += 0.f; v.z += 0.f; v.w += 0.f; }
+                if (RES && !p.res_post) { const float4 rv = rres[RES ? ps : 0][RES ? it : 0]; v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+                v.x = act_f32<ACT>(v.x); v.y = act_f32<ACT>(v.y); v.z = act_f32<ACT>(v.z); v.w = act_f32<ACT>(v.w);
+                if (RES && p.res_post) { const float4 rv = rres[RES ? ps : 0][RES ? it : 0]; v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+                *reinterpret_cast<float4 *>(yp + m * p.y_pix + co) = v;
+            }
+        } else {
+            for (int it = 0; it < EITS; ++it) {
+                const int idx = it * NT + tid;
+                const int prow = idx / EV_PER_ROW, ec = (idx - prow * EV_PER_ROW) * 4;
+                const long long m = m0 + pass_row(ps, prow);
+                const int co = n0 + ec;
+                if ((ENVEC % NT != 0 && idx >= ENVEC) || m >= M) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (co + e >= p.Cout) break;
+                    float v = Cs[prow * LDC + ec + e] + (p.bias ? p.bias[co + e] : 0.f);
+                    if (RES && !p.res_post) v += resp[m * p.r_pix + co + e];
+                    v = act_f32<ACT>(v);
+                    if (RES && p.res_post) v += resp[m * p.r_pix + co + e];
+                    yp[m * p.y_pix + co + e] = v;
+                }
             }
         }
+        if (ps + 1 < NPASS) __syncthreads();
     }
 }
 
-template <int TM, int TN, int WGM, int WGN> int launch_cfg(ConvArgs &a, int act, hipStream_t st)
+template <int TM, int TN, int WGM, int WGN, int NST = 2> int launch_cfg(ConvArgs &a, int act, hipStream_t st)
 {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, NT = 64 * WGM * WGN;
-    constexpr size_t LDS_STAGE = (size_t)2 * (BM + BN) * LDK * sizeof(float), LDS_C = (size_t)BM * (BN + 4) * sizeof(float);
-    constexpr size_t LDS_BYTES = LDS_STAGE > LDS_C ? LDS_STAGE : LDS_C;
+    constexpr size_t LDS_STAGE = (size_t)NST * (BM + BN) * LDK * sizeof(float), LDS_C = (size_t)WGM * 32 * (BN + 4) * sizeof(float);
+    constexpr size_t LDS_BYTES = LDS_STAGE > LDS_C ? LDS_STAGE : LDS_C;      // (the kernel sizes its epilogue passes to this)
     a.tiles_n = (a.Cout + BN - 1) / BN;
     a.tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
     if (a.tiles > 0x7fffffffLL || a.M > 0x7fffffffLL) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: more than 2^31 - 1 output pixels in one launch");
     const bool res = a.res != nullptr;
 #define TLK_CONV_LAUNCH(A, R)                                                                                                              \
     do {                                                                                                                                   \
-        auto kern = conv_f32_mfma_kernel<TM, TN, WGM, WGN, A, R>;                                                                          \
+        auto kern = conv_f32_mfma_kernel<TM, TN, WGM, WGN, A, R, NST>;                                                                       \
         static bool attr_set = false;                                                                                                      \
         if (!attr_set) { TLK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES)); attr_set = true; } \
         hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles), dim3(NT), LDS_BYTES, st, a);                                                     \
@@ -308,7 +361,7 @@ int g_last_cfg = -1;      // configuration of the most recent launch (tlk_conv2d
 
 extern "C" int tlk_conv2d_set_config(int cfg)
 {
-    if (cfg < -1 || cfg > 6) return fail(TLK_EINVAL, "tlk_conv2d_set_config: cfg must be -1 (heuristic) or 0..6");
+    if (cfg < -1 || cfg > 9) return fail(TLK_EINVAL, "tlk_conv2d_set_config: cfg must be -1 (heuristic) or 0..9");
     g_force_cfg = cfg;
     return TLK_OK;
 }
@@ -332,9 +385,18 @@ extern "C" int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const
 {
     if (n < 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0)
         return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: bad shape");
-    if (cin % 4 != 0) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: Cin must be a multiple of 4 (pad the input channels with zeros)");
     const int res_post = (act_kind & TLK_ACT_RES_AFTER) ? 1 : 0;
     act_kind &= ~TLK_ACT_RES_AFTER;
+    if (cin == 3 && !residual_dev && act_kind >= 0 && act_kind <= 2 && n > 0 && x_dev && w_dev && y_dev) {
+        // RGB stems: the direct kernel of tlk_conv_stem.hip (7 x 7 / 3 x 3, stride 2, Cout <= 64) reads the 3-channel image as it is
+        const int ho_ = (h + 2 * pad - kh) / stride + 1, wo_ = (w + 2 * pad - kw) / stride + 1;
+        const int xp = x_pix_stride > 0 ? x_pix_stride : 3, yp = y_pix_stride > 0 ? y_pix_stride : cout;
+        if (ho_ > 0 && wo_ > 0 && xp >= 3 && yp >= cout) {
+            const int r = conv_stem3_f32(x_dev, w_dev, bias_dev, y_dev, n, h, w, cout, kh, kw, stride, pad, act_kind, xp, yp, (hipStream_t)hip_stream);
+            if (r != 1) { if (r == TLK_OK) g_last_cfg = 15; return r; }
+        }
+    }
+    if (cin % 4 != 0) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: Cin must be a multiple of 4 (pad the input channels with zeros), or 3 for a 7x7 / 3x3 stride-2 stem with Cout <= 64");
     if (act_kind < 0 || act_kind > 2) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: act_kind is 0 (none), 1 (ReLU) or 2 (SiLU), optionally | TLK_ACT_RES_AFTER");
     const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
     if (ho <= 0 || wo <= 0) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: empty output");
@@ -374,6 +436,9 @@ extern "C" int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const
     case 3: return launch_cfg<2, 3, 4, 1>(a, act_kind, st);    // 256 x 96
     case 4: return launch_cfg<2, 1, 4, 1>(a, act_kind, st);    // 256 x 32
     case 6: return launch_cfg<1, 2, 4, 1>(a, act_kind, st);    // 128 x 64, wavefronts stacked in M
+    case 7: return launch_cfg<2, 2, 2, 2, 1>(a, act_kind, st); // 128 x 128, ONE LDS stage (37 KB: the memory-bound layers)
+    case 8: return launch_cfg<2, 1, 2, 2, 1>(a, act_kind, st); // 128 x 64, ONE stage (28 KB)
+    case 9: return launch_cfg<1, 2, 2, 2, 1>(a, act_kind, st); // 64 x 128, ONE stage
     default: return launch_cfg<1, 2, 2, 2>(a, act_kind, st);   // 64 x 128 (small M)
     }
 }

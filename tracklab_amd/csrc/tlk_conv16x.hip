@@ -51,9 +51,10 @@ constexpr int pick_epi(int tm, int wgm, int rows_max)
     return e;
 }
 
-template <int WGM, int WGN, int TM, int TN, int MODE, bool USE_BUF>
-__global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Args p, const unsigned char *__restrict__ zeros, const int act)
+template <int WGM, int WGN, int TM, int TN, int MODE, int NST, bool RESPF>
+__global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Args p, const int act)
 {
+    constexpr bool USE_BUF = true;                        // (r05 A/B on the GPU: buffer loads with hardware zero fill >= 64-bit pointers + zero page on every layer)
     constexpr int NW = WGM * WGN, NT = 64 * NW;
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int PLANES = MODE == MODE_SPLIT ? 2 : 1;
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
     wbase[0] = p.w;
     if (MODE == MODE_SPLIT) wbase[PLANES - 1] = p.w_lo;
     __amdgpu_buffer_rsrc_t rs_a[PLANES], rs_b[PLANES];
-    if (USE_BUF) {
+    {
         const long long total_pix = (long long)((unsigned)p.M / (unsigned)(p.Ho * p.Wo)) * p.H * p.W;
         long long a_bytes = ((total_pix - base_pix - 1) * p.x_pix + p.Cin) * 2;
         if (a_bytes > 0x7ffffff0LL) a_bytes = 0x7ffffff0LL;
@@ -134,13 +135,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
         b_off0[q] = co < p.Cout ? (co * p.K + lcq * 8) * 2 : OOB;
     }
     int u_kh = 0, u_kw = 0, u_ci0 = 0, u_k0 = 0;          // tap of the step being loaded (wave-uniform)
-    auto load16 = [&](const __amdgpu_buffer_rsrc_t &rs, const _Float16 *base, int off, unsigned char *dst) {
-        if (USE_BUF) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)dst, 16, off, 0, 0, 0);
-        } else {
-            const unsigned char *g = off >= 0 ? reinterpret_cast<const unsigned char *>(base) + off : zeros;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        }
+    auto load16 = [&](const __amdgpu_buffer_rsrc_t &rs, const _Float16 *, int off, unsigned char *dst) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)dst, 16, off, 0, 0, 0);
     };
     auto issue_stage = [&](int buf) {                      // a stage beyond K is all zeros (it lands in a buffer nobody multiplies)
         const bool in_k = u_k0 < p.K;
@@ -217,6 +213,50 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
     //   stage s lives in buffer s & 1;  it is loaded during step s - 1 (issued right after barrier s - 2), waited for before barrier s - 1.
     static_assert(NJ % 2 == 0, "fragment set parity assumes an even number of slices per step");
     const int steps = p.K / BKE;
+    // The residual of this lane's output vectors is fetched NOW and waits in registers (RESPF: the tile configurations used for the short-K
+    // 1 x 1 expansions, which are memory-bound: their epilogue used to sit on HBM latency)
+    constexpr int LDC = BN + 4;
+    constexpr int LDS_AVAIL = (NST * STAGE > WGM * 32 * LDC * 4) ? NST * STAGE : WGM * 32 * LDC * 4;
+    constexpr int EPI = pick_epi(TM, WGM, LDS_AVAIL / (LDC * 4));
+    static_assert(WGM * 32 * EPI * LDC * 4 <= LDS_AVAIL, "epilogue pass does not fit the LDS");
+    constexpr int PROWS = WGM * 32 * EPI;                 // tile rows per pass
+    constexpr int V_PER_ROW = BN / 8, NVEC = PROWS * V_PER_ROW, ITS = (NVEC + NT - 1) / NT, NPASS = TM / EPI;
+    const bool has_res = p.res != nullptr, out32 = p.y32 != nullptr;
+    h16x8 rpre[RESPF ? NPASS : 1][RESPF ? ITS : 1];
+    if (RESPF && has_res) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+            for (int it = 0; it < ITS; ++it) {
+                const int idx = it * NT + tid;
+                const int prow = idx / V_PER_ROW, ec = (idx - prow * V_PER_ROW) * 8;
+                const int pw = prow / (32 * EPI), within = prow - pw * (32 * EPI);
+                const long long m = m0 + pw * (TM * 32) + ps * EPI * 32 + within;
+                const int co = n0 + ec;
+                const bool ok = !(NVEC % NT != 0 && idx >= NVEC) && m < M && co < p.Cout;
+                h16x8 z;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
+                rpre[ps][it] = ok ? *reinterpret_cast<const h16x8 *>(p.res + m * p.r_pix + co) : z;
+            }
+    }
+    if (NST == 1) {
+        // one LDS stage (the short-K layers: K <= 128, one or two steps): load, wait, multiply -- what hides the latencies is the number of
+        // workgroups a CU holds at 32 KB each, not a pipeline inside one of them
+        for (int s = 0; s < steps; ++s) {
+            issue_stage(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            read_frags(0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (j + 1 < NJ) read_frags(0, j + 1, (j + 1) & 1);
+                mfmas(j & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+    } else {
     issue_stage(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -242,16 +282,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the stages beyond K: zeros in flight towards LDS)
     __syncthreads();
+    }
 
     // ---- epilogue: EPI MFMA tile rows of every wavefront at a time through LDS as fp32, then 8 output channels (16 bytes of f16) per lane.
     // C/D map of the 32x32 tile: column (= cout) = lane & 31, row (= pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-    constexpr int LDC = BN + 4;
-    constexpr int EPI = pick_epi(TM, WGM, (2 * STAGE) / (LDC * 4));
-    static_assert(WGM * 32 * EPI * LDC * 4 <= 2 * STAGE, "epilogue pass does not fit the LDS stages");
-    constexpr int PROWS = WGM * 32 * EPI;                 // tile rows per pass
-    constexpr int V_PER_ROW = BN / 8, NVEC = PROWS * V_PER_ROW, ITS = (NVEC + NT - 1) / NT;
     float *Cs = reinterpret_cast<float *>(lds);
-    const bool has_res = p.res != nullptr, out32 = p.y32 != nullptr;
 #pragma unroll
     for (int i0 = 0; i0 < TM; i0 += EPI) {
 #pragma unroll
@@ -267,7 +302,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
                 }
             }
         __syncthreads();
-#pragma unroll 2
+#pragma unroll
         for (int it = 0; it < ITS; ++it) {
             const int idx = it * NT + tid;
             const int prow = idx / V_PER_ROW, ec = (idx - prow * V_PER_ROW) * 8;
@@ -286,7 +321,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
             }
             float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (has_res) {
-                const h16x8 rh = *reinterpret_cast<const h16x8 *>(p.res + m * p.r_pix + co);
+                const h16x8 rh = RESPF ? rpre[RESPF ? i0 / EPI : 0][RESPF ? it : 0] : *reinterpret_cast<const h16x8 *>(p.res + m * p.r_pix + co);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) rv[e] = (float)rh[e];
                 if (MODE == MODE_SPLIT) {
@@ -331,47 +366,53 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
     }
 }
 
-template <int WGM, int WGN, int TM, int TN, int MODE, bool USE_BUF> int launch_x(Conv16Args &a, int act, hipStream_t st)
+template <int WGM, int WGN, int TM, int TN, int MODE, int NST, bool RESPF> int launch_x(Conv16Args &a, int act, hipStream_t st)
 {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, NT = 64 * WGM * WGN;
-    constexpr size_t LDS_BYTES = (size_t)2 * (BM + BN) * ROW_BYTES;
-    static_assert(LDS_BYTES <= 160 * 1024, "two stages must fit the CU's LDS");
-    const unsigned char *z = zero_page();
-    if (!z) return fail(TLK_EHIP, "tlk_conv2d_nhwc_16: cannot allocate the zero page");
+    constexpr size_t STAGES = (size_t)NST * (BM + BN) * ROW_BYTES, EPI_MIN = (size_t)WGM * 32 * (BN + 4) * 4;
+    constexpr size_t LDS_BYTES = STAGES > EPI_MIN ? STAGES : EPI_MIN;
+    static_assert(LDS_BYTES <= 160 * 1024, "the stages must fit the CU's LDS");
     a.tiles_n = (a.Cout + BN - 1) / BN;
     a.tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
     if (a.tiles > 0x7fffffffLL || a.M > 0x7fffffffLL) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: more than 2^31 - 1 output pixels in one launch");
-    auto kern = conv16x_kernel<WGM, WGN, TM, TN, MODE, USE_BUF>;
+    auto kern = conv16x_kernel<WGM, WGN, TM, TN, MODE, NST, RESPF>;
     static bool attr_set = false;
     if (!attr_set) { TLK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES)); attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles), dim3(NT), LDS_BYTES, st, a, z, act);
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles), dim3(NT), LDS_BYTES, st, a, act);
     TLK_HIP(hipGetLastError());
     return TLK_OK;
 }
 
-template <bool USE_BUF> int launch_cfg_x(Conv16Args &a, bool split, int act, int cfg, hipStream_t st)
+// tile configurations (tlk_conv16_set_config numbers them; the heuristic below picks by shape)
+int launch_cfg_x(Conv16Args &a, bool split, int act, int cfg, hipStream_t st)
 {
     if (!split) {
         switch (cfg) {
-        case 1: return launch_x<2, 4, 4, 2, MODE_F16, USE_BUF>(a, act, st);      // 256 x 256, wavefront 128 x 64
-        case 2: return launch_x<4, 2, 2, 2, MODE_F16, USE_BUF>(a, act, st);      // 256 x 128, wavefront 64 x 64
-        case 3: return launch_x<2, 2, 4, 2, MODE_F16, USE_BUF>(a, act, st);      // 256 x 128, four wavefronts of 128 x 64
-        case 4: return launch_x<8, 1, 2, 2, MODE_F16, USE_BUF>(a, act, st);      // 512 x 64, wavefront 64 x 64
-        case 5: return launch_x<4, 1, 2, 2, MODE_F16, USE_BUF>(a, act, st);      // 256 x 64, four wavefronts of 64 x 64
-        case 6: return launch_x<2, 2, 2, 2, MODE_F16, USE_BUF>(a, act, st);      // 128 x 128 (the r04 shape on this loader: A/B reference)
-        default: return fail(TLK_EINVAL, "tlk_conv16_set_config: f16 configurations are 1..6");
+        case 1: return launch_x<2, 4, 4, 2, MODE_F16, 2, false>(a, act, st);     // 256 x 256, 8 wavefronts of 128 x 64: the compute-bound layers
+        case 2: return launch_x<4, 2, 2, 2, MODE_F16, 2, true>(a, act, st);      // 256 x 128, 8 wavefronts of 64 x 64
+        case 3: return launch_x<2, 2, 2, 2, MODE_F16, 1, true>(a, act, st);      // 128 x 128, 4 wavefronts, ONE stage (K <= 128), residual prefetched
+        case 4: return launch_x<8, 1, 2, 2, MODE_F16, 2, false>(a, act, st);     // 512 x 64, 8 wavefronts of 64 x 64
+        case 5: return launch_x<4, 1, 2, 2, MODE_F16, 2, true>(a, act, st);      // 256 x 64, 4 wavefronts of 64 x 64
+        case 6: return launch_x<2, 2, 2, 2, MODE_F16, 2, true>(a, act, st);      // 128 x 128, 4 wavefronts of 64 x 64, residual prefetched
+        case 7: return launch_x<4, 1, 2, 2, MODE_F16, 1, true>(a, act, st);      // 256 x 64, ONE stage
+        case 8: return launch_x<2, 4, 2, 2, MODE_F16, 2, true>(a, act, st);      // 128 x 256, 8 wavefronts of 64 x 64
+        case 9: return launch_x<2, 2, 2, 2, MODE_F16, 1, false>(a, act, st);     // 128 x 128, ONE stage, residual read in the epilogue (fewer registers)
+        case 10: return launch_x<4, 1, 2, 2, MODE_F16, 1, false>(a, act, st);    // 256 x 64, ONE stage, no residual prefetch
+        case 11: return launch_x<2, 1, 2, 2, MODE_F16, 1, true>(a, act, st);     // 128 x 64, TWO wavefronts, ONE stage
+        default: return fail(TLK_EINVAL, "tlk_conv16_set_config: f16 configurations are 1..11");
         }
     }
     switch (cfg) {
-    case 1: return launch_x<2, 4, 2, 2, MODE_SPLIT, USE_BUF>(a, act, st);        // 128 x 256, wavefront 64 x 64 (x 2 accumulator sets)
-    case 2: return launch_x<4, 2, 2, 2, MODE_SPLIT, USE_BUF>(a, act, st);        // 256 x 128
-    case 3: return launch_x<2, 2, 2, 2, MODE_SPLIT, USE_BUF>(a, act, st);        // 128 x 128, four wavefronts
-    case 4: return launch_x<4, 1, 2, 2, MODE_SPLIT, USE_BUF>(a, act, st);        // 256 x 64, four wavefronts of 64 x 64
-    default: return fail(TLK_EINVAL, "tlk_conv16_set_config: split configurations are 1..4");
+    case 1: return launch_x<2, 4, 2, 2, MODE_SPLIT, 2, false>(a, act, st);       // 128 x 256, wavefront 64 x 64 (x 2 accumulator sets)
+    case 2: return launch_x<4, 2, 2, 2, MODE_SPLIT, 2, false>(a, act, st);       // 256 x 128
+    case 3: return launch_x<2, 2, 2, 2, MODE_SPLIT, 2, false>(a, act, st);       // 128 x 128, four wavefronts
+    case 4: return launch_x<4, 1, 2, 2, MODE_SPLIT, 2, false>(a, act, st);       // 256 x 64, four wavefronts of 64 x 64
+    case 5: return launch_x<2, 2, 2, 2, MODE_SPLIT, 1, false>(a, act, st);       // 128 x 128, ONE stage
+    case 6: return launch_x<4, 2, 1, 2, MODE_SPLIT, 1, false>(a, act, st);       // 128 x 128, 8 wavefronts of 32 x 64, ONE stage
+    case 7: return launch_x<4, 2, 1, 2, MODE_SPLIT, 2, false>(a, act, st);       // 128 x 128, 8 wavefronts of 32 x 64, two stages
+    default: return fail(TLK_EINVAL, "tlk_conv16_set_config: split configurations are 1..7");
     }
 }
-
-int g_use_buf = 1;        // tlk_conv16_set_loader: 1 = buffer loads with hardware zero fill, 0 = 64-bit pointers + zero page
 
 }  // namespace
 
@@ -390,22 +431,26 @@ int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream
         if (a_span >= 0x7fffffffLL || (long long)a.Cout * a.K * 2 >= 0x3fffffffLL) return cfg > 0 ? fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: tensor rows too long for 32-bit tile offsets") : 1;
     }
     if (cfg <= 0) {
-        // heuristic (profiles/r05_conv16x_shapes.txt): the large tiles pay off where the launch is compute-bound and fills the chip
+        // heuristic, from the per-layer table of the standalone probe (profiles/r05_conv16x_shapes.txt):
+        //   * what a CU holds matters more than a pipeline inside one workgroup: the ONE-stage 128 x 128 tile (33 KB of LDS, three workgroups per
+        //     CU) with the residual prefetched wins every memory-bound layer (the 1 x 1 expansions run at 5.2 TB/s, r04: 3.4) and most others;
+        //   * the 256 x 256 tile wins the compute-bound layers -- Cout a multiple of 256, K >= 512, no residual, at least two rounds of tiles
+        //     over the chip (1100 TFLOP/s on the 3 x 3 / 512 layers, r04: 830);
+        //   * Cout <= 64: the 256 x 64 one-stage tile.
         const long long tiles256 = ((a.M + 255) / 256) * ((a.Cout + 255) / 256);
         if (!split) {
-            if (a.Cout % 256 == 0 && a.K >= 256 && tiles256 >= 192) cfg = 1;
-            else if (a.Cout % 128 == 0 && a.K >= 256 && ((a.M + 255) / 256) * (a.Cout / 128) >= 192) cfg = 2;
-            else return 1;
+            if (a.Cout <= 64) cfg = 7;
+            else if (a.Cout % 256 == 0 && a.K >= 512 && !a.res && tiles256 >= 512) cfg = 1;
+            else cfg = 3;
         } else {
-            if (a.Cout % 256 == 0 && a.K >= 128 && ((a.M + 127) / 128) * (a.Cout / 256) >= 192) cfg = 1;
-            else if (a.Cout % 128 == 0 && a.K >= 128 && ((a.M + 255) / 256) * (a.Cout / 128) >= 192) cfg = 2;
+            if (a.Cout % 256 == 0 && a.K >= 256 && !a.res && ((a.M + 127) / 128) * (a.Cout / 256) >= 512) cfg = 1;
+            else if (a.Cout % 128 == 0 && a.K >= 256 && !a.res && ((a.M + 255) / 256) * (a.Cout / 128) >= 512) cfg = 2;
             else return 1;
         }
     }
-    return g_use_buf ? launch_cfg_x<true>(a, split, act, cfg, st) : launch_cfg_x<false>(a, split, act, cfg, st);
+    return launch_cfg_x(a, split, act, cfg, st);
 }
 
 }  // namespace c16
 }  // namespace tlk
 
-extern "C" int tlk_conv16_set_loader(int use_buffer_loads) { g_use_buf = use_buffer_loads ? 1 : 0; return TLK_OK; }

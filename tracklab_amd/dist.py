@@ -70,3 +70,47 @@ def numa_cpu_slice(node_cpus, peers_on_node: list[int], me: int, allowed=None) -
     per = max(1, len(allowed) // len(peers_on_node))
     k = peers_on_node.index(me)
     return allowed[k * per:(k + 1) * per] or allowed
+
+
+class serialized:
+    """Cross-process mutual exclusion on one node (an flock'ed file): ``with serialized("tune"):`` lets the ranks of a job pass ONE AT A TIME.
+    bench.py wraps each rank's warm-up in it when world > 1 -- eight concurrent hipGraph captures, hipBLASLt / MIOpen tuning passes and pinned
+    allocations on one host were never run together on hardware; serial warm-up costs seconds and removes the question.
+    The lock file lives in ``TLK_LOCK_DIR`` (default: the system temp directory) and is keyed by the job's MASTER_PORT so that two jobs on one
+    host do not wait for each other.  ``order`` (a list) receives (event, time) pairs for the tests."""
+
+    def __init__(self, name: str, order=None):
+        import tempfile
+        key = os.environ.get("MASTER_PORT", "solo")
+        self.path = os.path.join(os.environ.get("TLK_LOCK_DIR", tempfile.gettempdir()), f"tlk_{name}_{key}.lock")
+        self.order = order
+        self._f = None
+
+    def __enter__(self):
+        import fcntl
+        import time
+        self._f = open(self.path, "a+")
+        fcntl.flock(self._f, fcntl.LOCK_EX)
+        if self.order is not None:
+            self.order.append(("enter", time.time()))
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        import time
+        if self.order is not None:
+            self.order.append(("exit", time.time()))
+        fcntl.flock(self._f, fcntl.LOCK_UN)
+        self._f.close()
+        self._f = None
+        return False
+
+
+def placement_is_sound(placement, local_world: int, host_cpus: int) -> bool:
+    """rank_placement rows [rank, numa node, cpus]: every rank of a multi-rank job is pinned to a non-empty CPU set, and the sets of one node can
+    be disjoint (their sizes sum to at most the host's CPUs).  bench.py reports it; a False on hardware means ranks roam over each other's cores."""
+    if local_world <= 1:
+        return True
+    if any(p[2] <= 0 for p in placement):
+        return False
+    return sum(p[2] for p in placement) <= max(host_cpus, 1) * max(1, len(placement) // max(local_world, 1))
