@@ -1,6 +1,6 @@
 """-m gpu: the backbones' compute precision. The reference runs its networks in fp32 (ONNXRuntime detector / pose, torchreid ReID;
-`fp16: false` in configs/modules/track/strong_sort.yaml:10); bench.py's default is f16 with `--dtype f32` beside it. This file states the
-tolerance that makes f16 admissible and checks it on the same weights:
+`fp16: false` in configs/modules/track/strong_sort.yaml:10); bench.py's default IS fp32 since r04 (`value`), with the f16 and split-precision legs
+reported beside it. This file states the tolerance that makes the narrower legs admissible and checks it on the same weights:
 
   * part embeddings (N, K, D): per-part cosine distance between the f16 and the f32 network's output <= EMB_COS_TOL, and the
     part-based ReID distance matrix the tracker consumes (tlk_partdist_f32) moves by <= DIST_TOL (its gate `max_dist` is 0.5);
@@ -77,3 +77,110 @@ def test_track_ids_identical_under_f16_and_f32_backbones():
     assert sum(len(r) for r in out[torch.float16]) > 0.9 * nobj * F * steps * 0.95
     for f, (a, b) in enumerate(zip(out[torch.float16], out[torch.float32])):
         np.testing.assert_array_equal(a, b, err_msg=f"frame {f}: f16 and f32 backbones give different tracks")
+
+
+def _scaled_reid(dtype, scale, split=False, heavy_tail=False):
+    """the random-init part-based ReID net with its stem weights multiplied by `scale` (ReLU networks are positively homogeneous up to their
+    biases: every later activation grows by about that factor) and, for heavy_tail, the per-channel scales a BatchNorm fold leaves behind
+    drawn log-uniform over four decades"""
+    import torch
+    from tracklab_amd.backbones.reid import part_based_reid
+    m = part_based_reid(6, 256, dtype=torch.float32, split_precision=False)
+    with torch.no_grad():
+        stem = next(mod for mod in m.backbone.modules() if hasattr(mod, "conv") and mod.conv.in_channels == 3)
+        stem.conv.weight.mul_(scale)
+        stem.bias.mul_(scale)
+        if heavy_tail:
+            # per-channel scales log-uniform over four decades on every bottleneck's 3 x 3 output, undone on the input channels of the 1 x 1
+            # expansion that follows (ReLU commutes with a positive scale): the FUNCTION is unchanged, the intermediate tensors are heavy-tailed
+            g = torch.Generator(device="cpu").manual_seed(3)
+            for blk in m.backbone.modules():
+                if type(blk).__name__ == "_Bottleneck":
+                    f = torch.exp(torch.empty(blk.c2.conv.out_channels).uniform_(-4.6, 4.6, generator=g)).to(blk.c2.conv.weight.device)      # 1e-2 .. 1e2
+                    blk.c2.conv.weight.mul_(f[:, None, None, None]); blk.c2.bias.mul_(f)
+                    blk.c3.conv.weight.div_(f[None, :, None, None])
+    if dtype == torch.float16:
+        m = m.half()
+    m.split_precision = bool(split)
+    return m
+
+
+def test_precision_envelope_of_the_f16_and_split_legs():
+    """WHERE do the narrower legs stop being admissible?  The stem of the (random-init) ReID net is scaled so that
+    the layer-4 activations reach ~1e2 ... ~3e5; per scale: largest |activation| entering the head, f16 and split-precision embeddings against
+    the exact-fp32 run's (max per-part cosine distance), finiteness.  Stated envelope (from this table):
+      * f16:   cosine distance <= 1e-5 while max |activation| <= ~3e4 (relative error is scale-free until the range ends); beyond 65504 the
+               output is NOT finite;
+      * split: fp32-class (<= 1e-6) over the same range; the (hi, lo) pair saturates at the same 65504;
+      * past the range the pipeline raises TlkError (gpu_pipeline: check_finite) instead of tracking on infinities."""
+    import json
+    import torch
+    x32 = _crops(torch.float32, 24)
+    x16 = x32.half()
+    acts = {}
+
+    def run(m, x):
+        h = m.backbone.register_forward_hook(lambda mod, i, o: acts.__setitem__("a", (o.hi if hasattr(o, "hi") else o).detach().float().abs().max().item()))
+        try:
+            with torch.no_grad():
+                e, v = m(x)
+        finally:
+            h.remove()
+        return e.float(), acts["a"]
+
+    base_act = run(_scaled_reid(torch.float32, 1.0), x32)[1]
+    table = []
+    for target in (1e2, 1e3, 1e4, 3e4, 1.2e5, 3e5):
+        sc = target / base_act
+        e32, a32 = run(_scaled_reid(torch.float32, sc), x32)
+        e16, _ = run(_scaled_reid(torch.float16, sc), x16)
+        esp, _ = run(_scaled_reid(torch.float32, sc, split=True), x32)
+
+        def cosd(e):
+            if not torch.isfinite(e).all():
+                return float("inf")
+            a, b = torch.nn.functional.normalize(e, dim=-1), torch.nn.functional.normalize(e32, dim=-1)
+            return (1 - (a * b).sum(-1)).abs().max().item()
+        table.append({"max_activation_f32": a32, "f16_cos": cosd(e16), "split_cos": cosd(esp), "f32_finite": bool(torch.isfinite(e32).all())})
+    # heavy-tailed intermediate tensors at the natural scale: channels of one tensor spread over four decades (what BatchNorm folding can leave)
+    e32h, a32h = run(_scaled_reid(torch.float32, 1.0, heavy_tail=True), x32)
+    e16h, _ = run(_scaled_reid(torch.float16, 1.0, heavy_tail=True), x16)
+    esph, _ = run(_scaled_reid(torch.float32, 1.0, split=True, heavy_tail=True), x32)
+    e32 = e32h
+    heavy = {"heavy_tailed_channels": True, "max_activation_f32": a32h, "f16_cos": cosd(e16h), "split_cos": cosd(esph)}
+    print("precision envelope, heavy-tailed per-channel scales (1e-2 .. 1e2 inside every bottleneck):", json.dumps(heavy))
+    assert heavy["f16_cos"] <= 1e-4 and heavy["split_cos"] <= 1e-6, heavy
+    print("precision envelope (layer-4 |activation| max, f16 cosine distance, split cosine distance):")
+    print(json.dumps(table))
+    inside = [t for t in table if t["max_activation_f32"] <= 3.3e4]
+    outside = [t for t in table if t["max_activation_f32"] >= 1.0e5]
+    assert len(inside) >= 3 and len(outside) >= 1
+    assert all(t["f32_finite"] for t in table)
+    assert all(t["f16_cos"] <= EMB_COS_TOL and t["split_cos"] <= 1e-6 for t in inside), table
+    assert all(t["f16_cos"] == float("inf") for t in outside), "f16 is expected to saturate past its range: the envelope is the range"
+
+
+def test_saturated_embeddings_fail_loudly_in_the_pipeline():
+    """past the envelope the fused pipeline raises instead of associating on infinities"""
+    import torch
+    from tracklab_amd import _lib
+    from tracklab_amd import gpu_pipeline as gp
+    from tracklab_amd.synth import SyntheticStream, render_frame, synth_yolox_head
+    rng = np.random.default_rng(2)
+    fr = SyntheticStream(3, 20, 1).step()
+    ratio = min(640 / 1080, 640 / 1920)
+    head = torch.from_numpy(synth_yolox_head(rng, fr["dets"][:, :4], ratio=ratio)[None]).cuda()
+    frame = torch.from_numpy(render_frame(rng, fr["gt_boxes"])[None]).cuda()
+    pipe = gp.DetReidTrackPipeline("s", n_streams=1, frames_per_step=1, max_dets=32, dim=64, dtype=torch.float16, use_graph=False)
+    try:
+        pipe.step(frame, head)
+        pipe.synchronize()                                   # in range: fine
+        with torch.no_grad():
+            stem = next(mod for mod in pipe.reid.backbone.modules() if hasattr(mod, "conv") and mod.conv.in_channels == 3)
+            stem.conv.weight.mul_(3e4)
+        pipe.step(frame, head)
+        with pytest.raises(_lib.TlkError, match="not finite"):
+            pipe.synchronize()
+        pipe.reset()
+    finally:
+        pipe.close()

@@ -2,7 +2,7 @@
 // every tile configuration of tlk_conv16x.hip against the r04 kernels, per layer: milliseconds, TFLOP/s on the algorithmic flops, GB/s on
 // the algorithmic bytes (input + weights + residual + output once), and the largest deviation from a naive fp32-accumulating reference
 // convolution on a small batch of the same shape.
-//   build:  tools/micro/build_conv16_probe.sh conv16_probe      run:  tools/micro/conv16_probe [crops=2400] [mode=f16|split] [cfgs=auto|c1,c2,...] [filter]
+//   build:  tools/micro/build_conv16_probe.sh conv16_probe      run:  tools/micro/conv16_probe [crops=2400] [mode=f16|split] [cfgs=auto|c1,c2,...] [filter] [yolox]
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
@@ -118,14 +118,28 @@ int main(int argc, char **argv)
         {"l4 1x1 2048>512", 24, 8, 2048, 512, 1, 1, 0, 0, 2},   {"l4 3x3 512", 24, 8, 512, 512, 3, 1, 1, 0, 3},
         {"l4 1x1 512>2048 +res", 24, 8, 512, 2048, 1, 1, 0, 1, 3}, {"reduce 2048>256", 24, 8, 2048, 256, 1, 1, 0, 0, 1},
     };
-    const int nl = sizeof(layers) / sizeof(layers[0]);
+    // YOLOX-m at 640 x 640 (the layers whose input width is a multiple of the 64-element K step; `crops` = frames): H, W = INPUT size
+    const Layer yolox_layers[] = {
+        {"y 3x3 192 @80", 80, 80, 192, 192, 3, 1, 1, 0, 4},        {"y 3x3 192 @40", 40, 40, 192, 192, 3, 1, 1, 0, 14},
+        {"y 3x3 384 @20", 20, 20, 384, 384, 3, 1, 1, 0, 4},        {"y 3x3 s2 192>384 80>40", 80, 80, 192, 384, 3, 2, 1, 0, 1},
+        {"y 3x3 s2 384>768 40>20", 40, 40, 384, 768, 3, 2, 1, 0, 1}, {"y 1x1 192>192 @80", 80, 80, 192, 192, 1, 1, 0, 0, 3},
+        {"y 1x1 384>192 @40", 40, 40, 384, 192, 1, 1, 0, 0, 6},    {"y 1x1 384>384 @40", 40, 40, 384, 384, 1, 1, 0, 0, 3},
+        {"y 1x1 768>384 @20", 20, 20, 768, 384, 1, 1, 0, 0, 6},    {"y 1x1 192>192 @40", 40, 40, 192, 192, 1, 1, 0, 0, 10},
+        {"y 3x3 s2 192 80>40", 80, 80, 192, 192, 3, 2, 1, 0, 1},   {"y 3x3 s2 384 40>20", 40, 40, 384, 384, 3, 2, 1, 0, 1},
+        {"y 3x3 192 @20", 20, 20, 192, 192, 3, 1, 1, 0, 4},        {"y 1x1 1536>768 @20", 20, 20, 1536, 768, 1, 1, 0, 0, 1},
+        {"y 1x1 768>768 @20", 20, 20, 768, 768, 1, 1, 0, 0, 2},    {"y 1x1 768>192 @40", 40, 40, 768, 192, 1, 1, 0, 0, 2},
+        {"y 1x1 384>96 @80", 80, 80, 384, 96, 1, 1, 0, 0, 2},      {"y 1x1 192>96 @80", 80, 80, 192, 96, 1, 1, 0, 0, 2},
+    };
+    const bool yolox = argc > 5 && !strcmp(argv[5], "yolox");
+    const Layer *Ls = yolox ? yolox_layers : layers;
+    const int nl = yolox ? (int)(sizeof(yolox_layers) / sizeof(yolox_layers[0])) : (int)(sizeof(layers) / sizeof(layers[0]));
     // buffers sized for the largest layer
     long long max_x = 0, max_y = 0, max_w = 0;
     for (int i = 0; i < nl; ++i) {
-        const Layer &L = layers[i];
+        const Layer &L = Ls[i];
         const int Ho = (L.H + 2 * L.pad - L.k) / L.stride + 1, Wo = (L.W + 2 * L.pad - L.k) / L.stride + 1;
-        max_x = std::max(max_x, (long long)crops * L.H * L.W * L.Cin);
-        max_y = std::max(max_y, (long long)crops * Ho * Wo * L.Cout);
+        max_x = std::max(max_x, (long long)std::max(crops, 3) * L.H * L.W * L.Cin);
+        max_y = std::max(max_y, (long long)std::max(crops, 3) * Ho * Wo * L.Cout);
         max_w = std::max(max_w, (long long)L.Cout * L.k * L.k * L.Cin);
     }
     _Float16 *x, *xl = nullptr, *w, *wl = nullptr, *y, *yl = nullptr, *r, *rl = nullptr;
@@ -136,7 +150,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&bias, 4096 * 4));
     long long max_ref = 0;
     for (int i = 0; i < nl; ++i) {
-        const Layer &L = layers[i];
+        const Layer &L = Ls[i];
         const int Ho = (L.H + 2 * L.pad - L.k) / L.stride + 1, Wo = (L.W + 2 * L.pad - L.k) / L.stride + 1;
         max_ref = std::max(max_ref, (long long)check_crops * Ho * Wo * L.Cout);
     }
@@ -149,7 +163,7 @@ int main(int argc, char **argv)
     double tot_ms[16][2] = {{0}};      // [cfg + 1][loader]: sum over the forward of count * ms (best-of kept separately)
     double best_total = 0, r04_total = 0, flops_total = 0;
     for (int li = 0; li < nl; ++li) {
-        const Layer &L = layers[li];
+        const Layer &L = Ls[li];
         if (*filter && !strstr(L.name, filter)) continue;
         const int Ho = (L.H + 2 * L.pad - L.k) / L.stride + 1, Wo = (L.W + 2 * L.pad - L.k) / L.stride + 1;
         const long long nx = (long long)crops * L.H * L.W * L.Cin, ny = (long long)crops * Ho * Wo * L.Cout, nw = (long long)L.Cout * L.k * L.k * L.Cin;
@@ -167,11 +181,11 @@ int main(int argc, char **argv)
         } else {
             cfgs.push_back(-1);
             cfgs.push_back(0);                          // the library's own choice
-            const int bn_f16[] = {0, 256, 128, 128, 64, 64, 128, 64, 256, 128, 64, 64}, bn_split[] = {0, 256, 128, 128, 64, 128, 128, 128};
-            const int ncfg = split ? 7 : 11;
+            const int bn_f16[] = {0, 256, 128, 128, 64, 64, 128, 64, 256, 128, 64, 64, 64, 128, 128, 128, 64}, bn_split[] = {0, 256, 128, 128, 64, 128, 128, 128};
+            const int ncfg = split ? 7 : 16;
             for (int c = 1; c <= ncfg; ++c) {
                 const int bn = split ? bn_split[c] : bn_f16[c];
-                if (bn <= std::max(L.Cout, 64) && (bn >= 128 || L.Cout <= 128)) cfgs.push_back(c);
+                if (bn <= std::max(L.Cout, 64) && (bn >= 128 || L.Cout <= 128 || c == 12 || c == 16 || L.Cout % 128 != 0)) cfgs.push_back(c);
             }
         }
         double best = 1e30, r04 = 0;

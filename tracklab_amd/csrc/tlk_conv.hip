@@ -77,20 +77,21 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
 
-    // XCD-aware tile order: hardware deals consecutive workgroups round-robin to the 8 XCDs; give each XCD a contiguous run of tiles
+    // dynamic batch (r05): the launch is sized for the n of the call, the rows that exist are n_dyn[0] images' worth; workgroups beyond the live
+    // tiles leave at once (before any barrier), a tile across the edge masks its rows exactly like the last tile of a static launch
+    long long M = p.M;
+    if (p.n_dyn) { const long long md = (long long)p.n_dyn[0] * p.Ho * p.Wo; M = md < M ? (md < 0 ? 0 : md) : M; }
+    const long long live_tiles = ((M + BM - 1) / BM) * p.tiles_n;
+    if ((long long)blockIdx.x >= live_tiles) return;
+    // XCD-aware tile order: hardware deals consecutive workgroups round-robin to the 8 XCDs; give each XCD a contiguous run of the LIVE tiles
     long long tile;
     {
-        const long long b = blockIdx.x, q = p.tiles >> 3;
-        const int r = (int)(p.tiles & 7), xcd = (int)(b & 7);
+        const long long b = blockIdx.x, q = live_tiles >> 3;
+        const int r = (int)(live_tiles & 7), xcd = (int)(b & 7);
         tile = (long long)xcd * q + (xcd < r ? xcd : r) + (b >> 3);
     }
     const long long m0 = (tile / p.tiles_n) * BM;
     const int n0 = (int)(tile % p.tiles_n) * BN;
-    // dynamic batch (r05): the launch is sized for the n of the call, the rows that exist are n_dyn[0] images' worth; a tile beyond them leaves
-    // at once (before any barrier), a tile across the edge masks its rows exactly like the last tile of a static launch
-    long long M = p.M;
-    if (p.n_dyn) { const long long md = (long long)p.n_dyn[0] * p.Ho * p.Wo; M = md < M ? (md < 0 ? 0 : md) : M; }
-    if (m0 >= M) return;
 
     // ---- loader geometry: this lane moves chunk `lc` (4 floats of k) of row `lr + pass * ROWS_PER_PASS`.
     // Loads are BUFFER loads (raw buffer descriptor, 32-bit byte offsets): a lane whose chunk is outside the image / beyond K / beyond M

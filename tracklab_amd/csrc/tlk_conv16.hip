@@ -44,16 +44,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
-    long long tile;
-    {
-        const long long b = blockIdx.x, q = p.tiles >> 3;
-        const int r = (int)(p.tiles & 7), xcd = (int)(b & 7);
-        tile = (long long)xcd * q + (xcd < r ? xcd : r) + (b >> 3);
-    }
+    const long long M = live_rows(p);                      // dynamic batch: the XCD-aware order is laid over the LIVE tiles (see tlk_conv16x.hip)
+    const long long live_tiles = ((M + BM - 1) / BM) * p.tiles_n;
+    if ((long long)blockIdx.x >= live_tiles) return;
+    const long long tile = xcd_tile(live_tiles);
     const long long m0 = (tile / p.tiles_n) * BM;
     const int n0 = (int)(tile % p.tiles_n) * BN;
-    const long long M = live_rows(p);
-    if (m0 >= M) return;                                   // dynamic batch: a tile beyond the live rows leaves before any barrier
 
     // ---- loader geometry (see tlk_conv.hip): lane = chunk `lc` of row `lr + pass * ROWS_PER_PASS` of one plane
     const int lr = tid / CH, lc = tid % CH;
@@ -304,16 +300,12 @@ __global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p,
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
-    long long tile;
-    {
-        const long long b = blockIdx.x, q = p.tiles >> 3;
-        const int r = (int)(p.tiles & 7), xcd = (int)(b & 7);
-        tile = (long long)xcd * q + (xcd < r ? xcd : r) + (b >> 3);
-    }
+    const long long M = live_rows(p);                      // dynamic batch: the XCD-aware order is laid over the LIVE tiles (see tlk_conv16x.hip)
+    const long long live_tiles = ((M + BM - 1) / BM) * p.tiles_n;
+    if ((long long)blockIdx.x >= live_tiles) return;
+    const long long tile = xcd_tile(live_tiles);
     const long long m0 = (tile / p.tiles_n) * BM;
     const int n0 = (int)(tile % p.tiles_n) * BN;
-    const long long M = live_rows(p);
-    if (m0 >= M) return;                                   // dynamic batch: a tile beyond the live rows leaves before any barrier
 
     // ---- loader: instruction q (0..3) of this wavefront fills rows [(q * 4 + wave) * 8, + 8) of A and of B; lane = (row r8 = lane >> 3, position pc)
     const int r8 = lane >> 3, pc = lane & 7;
@@ -637,7 +629,7 @@ extern "C" int tlk_conv16_set_glds(int on) { g_glds = on ? 1 : 0; return TLK_OK;
 
 extern "C" int tlk_conv16_set_config(int cfg)
 {
-    if (cfg < -1 || cfg > 11) return fail(TLK_EINVAL, "tlk_conv16_set_config: cfg is -1 (r04 kernels only), 0 (heuristic) or a tile configuration 1..11");
+    if (cfg < -1 || cfg > 16) return fail(TLK_EINVAL, "tlk_conv16_set_config: cfg is -1 (r04 kernels only), 0 (heuristic) or a tile configuration 1..16");
     g_cfg16x = cfg;
     return TLK_OK;
 }

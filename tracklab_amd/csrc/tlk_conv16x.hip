@@ -77,11 +77,15 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
-    const long long tile = xcd_tile(p.tiles);
+    // dynamic batch: the launch is sized for the capacity, the tiles that exist are the live rows'; the XCD-aware order is laid over THOSE (a
+    // contiguous run per XCD of the live tiles -- laid over the capacity it would hand all the dead tiles to the last XCDs and leave the work
+    // of the others unchanged), the workgroups beyond them leave before any barrier
+    const long long M = live_rows(p);
+    const long long live_tiles = ((M + BM - 1) / BM) * p.tiles_n;
+    if ((long long)blockIdx.x >= live_tiles) return;
+    const long long tile = xcd_tile(live_tiles);
     const long long m0 = (tile / p.tiles_n) * BM;
     const int n0 = (int)(tile % p.tiles_n) * BN;
-    const long long M = live_rows(p);
-    if (m0 >= M) return;                                  // dynamic batch: a tile beyond the live rows leaves before any barrier
 
     // ---- loader.  Instruction q of this wavefront fills rows [(q * NW + wave) * RPI, + RPI) of A (and of B); lane = (row lrow, position pc) and
     // fetches the LOGICAL chunk that belongs at its position.  Offsets are bytes relative to the workgroup's base pixel (A) / the weights (B).
@@ -257,31 +261,42 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
             __syncthreads();
         }
     } else {
-    issue_stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    read_frags(0, 0, 0);
-    issue_stage(1);
-    for (int s = 0; s < steps; ++s) {
-        const int cur = s & 1;
+        // Ring of NST stages, NST - 1 of them in flight: stage s + NST - 1 is issued the moment stage s - 1's buffer is free and has NST - 1 steps
+        // to land.  The wait is COUNTED -- "all but the youngest (NST - 2) stages' loads have landed" -- and the barrier is the raw s_barrier:
+        // __syncthreads() with a direct-to-LDS load in flight drains the whole queue (it lowers to vmcnt(0)).  NST = 2 is the plain double
+        // buffer; NST = 3 / 4 is what the SMALL launches want (a 64 x 64 tile multiplies for ~130 cycles per step: without several stages in
+        // flight every step costs a full memory round trip).
+        constexpr int INFLIGHT = (NST - 2) * NLD;         // loads of the younger stages that may still be outstanding at the wait
+        static_assert(INFLIGHT <= 60, "vmcnt is a 6-bit counter");
 #pragma unroll
-        for (int j = 0; j + 1 < NJ; ++j) {
-            read_frags(cur, j + 1, (j + 1) & 1);
-            mfmas(j & 1);
-            interleave<NR < NM ? NR : NM, 0x100, NM - (NR < NM ? NR : NM)>();      // fragment read, MFMA, fragment read, MFMA, ... MFMAs
+        for (int k = 0; k < NST - 1; ++k) issue_stage(k);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(0, 0, 0);
+        issue_stage(NST - 1);
+        int cur = 0;
+        for (int s = 0; s < steps; ++s) {
+            const int nxt = cur + 1 == NST ? 0 : cur + 1;
+#pragma unroll
+            for (int j = 0; j + 1 < NJ; ++j) {
+                read_frags(cur, j + 1, (j + 1) & 1);
+                mfmas(j & 1);
+                interleave<NR < NM ? NR : NM, 0x100, NM - (NR < NM ? NR : NM)>();      // fragment read, MFMA, fragment read, MFMA, ... MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");      // stage s + 1 has landed; this wavefront's reads of stage s are done
+            __builtin_amdgcn_s_barrier();                                 // ... for everyone
             __builtin_amdgcn_sched_barrier(0);
+            read_frags(nxt, 0, 0);
+            issue_stage(cur);                                             // stage s + NST overwrites stage s
+            mfmas(1);                                                     // slice NJ - 1 of step s
+            __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);           // first the reads, then one direct-to-LDS load per MFMA
+            interleave<NLD < NM ? NLD : NM, 0x020, NM - (NLD < NM ? NLD : NM)>();
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // stage s + 1 has landed (it had the whole step to do so)
-        __syncthreads();                                              // ... for everyone, and nobody reads stage s any more
-        read_frags(cur ^ 1, 0, 0);
-        issue_stage(cur);                                             // stage s + 2 overwrites stage s
-        mfmas(1);                                                     // slice NJ - 1 of step s
-        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);           // first the reads, then one direct-to-LDS load per MFMA
-        interleave<NLD < NM ? NLD : NM, 0x020, NM - (NLD < NM ? NLD : NM)>();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the stages beyond K: zeros in flight towards LDS)
-    __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the stages beyond K: zeros in flight towards LDS)
+        __syncthreads();
     }
 
     // ---- epilogue: EPI MFMA tile rows of every wavefront at a time through LDS as fp32, then 8 output channels (16 bytes of f16) per lane.
@@ -399,7 +414,12 @@ int launch_cfg_x(Conv16Args &a, bool split, int act, int cfg, hipStream_t st)
         case 9: return launch_x<2, 2, 2, 2, MODE_F16, 1, false>(a, act, st);     // 128 x 128, ONE stage, residual read in the epilogue (fewer registers)
         case 10: return launch_x<4, 1, 2, 2, MODE_F16, 1, false>(a, act, st);    // 256 x 64, ONE stage, no residual prefetch
         case 11: return launch_x<2, 1, 2, 2, MODE_F16, 1, true>(a, act, st);     // 128 x 64, TWO wavefronts, ONE stage
-        default: return fail(TLK_EINVAL, "tlk_conv16_set_config: f16 configurations are 1..11");
+        case 12: return launch_x<2, 2, 1, 1, MODE_F16, 4, true>(a, act, st);     // 64 x 64, 4 wavefronts of 32 x 32, FOUR stages: the small launches
+        case 13: return launch_x<2, 2, 1, 2, MODE_F16, 3, true>(a, act, st);     // 64 x 128, three stages
+        case 14: return launch_x<2, 2, 2, 2, MODE_F16, 3, true>(a, act, st);     // 128 x 128, three stages
+        case 15: return launch_x<4, 2, 2, 2, MODE_F16, 3, false>(a, act, st);    // 256 x 128, 8 wavefronts of 64 x 64, three stages
+        case 16: return launch_x<2, 2, 1, 1, MODE_F16, 2, true>(a, act, st);     // 64 x 64, two stages
+        default: return fail(TLK_EINVAL, "tlk_conv16_set_config: f16 configurations are 1..16");
         }
     }
     switch (cfg) {
@@ -439,9 +459,16 @@ int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream
         //   * Cout <= 64: the 256 x 64 one-stage tile.
         const long long tiles256 = ((a.M + 255) / 256) * ((a.Cout + 255) / 256);
         if (!split) {
-            if (a.Cout <= 64) cfg = 7;
-            else if (a.Cout % 256 == 0 && a.K >= 512 && !a.res && tiles256 >= 512) cfg = 1;
-            else cfg = 3;
+            const long long t128 = ((a.M + 127) / 128) * ((a.Cout + 127) / 128);
+            if (a.Cout <= 64) cfg = ((a.M + 255) / 256 >= 768) ? (a.res ? 7 : 10) : 12;
+            else if (a.Cout % 256 == 0 && a.K >= 1024 && !a.res && tiles256 >= 512) cfg = 1;
+            else if (t128 >= 384) cfg = a.res ? 3 : 9;      // (without a residual to prefetch the tile needs fewer registers: four workgroups per CU)
+            //   * SMALL launches (the online step: one frame, ~100 crops): fewer than 1.5 128 x 128 tiles per CU -> no neighbours to hide a
+            //     workgroup's memory round trips, so the pipeline goes back INSIDE the workgroup (two stages); fewer than one tile per CU ->
+            //     smaller tiles, so that more CUs work, with three / four stages in flight (a 64 x 64 tile multiplies for ~130 cycles per step)
+            else if (t128 >= 256) cfg = 6;
+            else if (((a.M + 63) / 64) * ((a.Cout + 127) / 128) >= 192) cfg = 13;
+            else cfg = 12;
         } else {
             if (a.Cout % 256 == 0 && a.K >= 256 && !a.res && ((a.M + 127) / 128) * (a.Cout / 256) >= 512) cfg = 1;
             else if (a.Cout % 128 == 0 && a.K >= 256 && !a.res && ((a.M + 255) / 256) * (a.Cout / 128) >= 512) cfg = 2;

@@ -61,9 +61,19 @@ __global__ void __launch_bounds__(256) conv_stem3_kernel(const StemArgs p)
     if (p.n_dyn && n >= p.n_dyn[0]) return;
     const int wo0 = ct * TC, wi0 = wo0 * S - p.pad;
     // ---- weights ([cout][tap][3] in global memory = torch's channels_last (Cout, 3, KH, KW)), once per workgroup
-    for (int e = tid; e < 2 * PAIRS * 3 * CO; e += 256) {
-        const int co = e % CO, c = (e / CO) % 3, t = e / (3 * CO);
-        wl[e] = (t < TAPS && co < p.Cout) ? p.w[((size_t)co * TAPS + t) * 3 + c] : 0.f;
+    // (every load is issued before the first store: ONE memory round trip, not one per element -- the first version of this kernel spent more
+    //  time in its two staging loops, a dependent load -> store chain of ~60 links per workgroup, than in its 600 MFMAs)
+    {
+        constexpr int NW_ = 2 * PAIRS * 3 * CO, WI = (NW_ + 255) / 256;
+        float wv[WI];
+#pragma unroll
+        for (int k = 0; k < WI; ++k) {
+            const int e = k * 256 + tid;
+            const int co = e % CO, c = (e / CO) % 3, t = e / (3 * CO);
+            wv[k] = (e < NW_ && t < TAPS && co < p.Cout) ? p.w[((size_t)co * TAPS + t) * 3 + c] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < WI; ++k) { const int e = k * 256 + tid; if (e < NW_) wl[e] = wv[k]; }
     }
     const float *img = p.x + (size_t)n * p.H * p.W * p.x_pix;
     const int half = lane >> 5, pl = lane & 31;
@@ -76,16 +86,25 @@ __global__ void __launch_bounds__(256) conv_stem3_kernel(const StemArgs p)
         const int hi0 = ho0 * S - p.pad;
         if (strip) __syncthreads();                                      // the staging tiles of the previous strip have been read
         // ---- input patch of the strip: zeros outside the image
-        for (int r = 0; r < PR; ++r) {
-            const int hi = hi0 + r;
-            const bool row_ok = (unsigned)hi < (unsigned)p.H;
-            const float *src = img + (size_t)(row_ok ? hi : 0) * p.W * p.x_pix;
-            for (int q = tid; q < PW * 3; q += 256) {
-                const int px = q / 3, c = q - px * 3, wi = wi0 + px;
-                float v = 0.f;
-                if (row_ok && (unsigned)wi < (unsigned)p.W) v = src[(size_t)wi * p.x_pix + c];
-                patch[r * PWF + q] = v;
+        {
+            constexpr int QI = (PW * 3 + 255) / 256;
+            float pv[PR][QI];
+#pragma unroll
+            for (int r = 0; r < PR; ++r) {
+                const int hi = hi0 + r;
+                const bool row_ok = (unsigned)hi < (unsigned)p.H;
+                const float *src = img + (size_t)(row_ok ? hi : 0) * p.W * p.x_pix;
+#pragma unroll
+                for (int k = 0; k < QI; ++k) {
+                    const int q = k * 256 + tid;
+                    const int px = q / 3, c = q - px * 3, wi = wi0 + px;
+                    pv[r][k] = (q < PW * 3 && row_ok && (unsigned)wi < (unsigned)p.W) ? src[(size_t)wi * p.x_pix + c] : 0.f;
+                }
             }
+#pragma unroll
+            for (int r = 0; r < PR; ++r)
+#pragma unroll
+                for (int k = 0; k < QI; ++k) { const int q = k * 256 + tid; if (q < PW * 3) patch[r * PWF + q] = pv[r][k]; }
         }
         __syncthreads();
         const int ho = ho0 + wave;

@@ -364,6 +364,12 @@ class DetReidTrackPipeline:
         self.slot_base = torch.zeros(B, dtype=torch.int32, device=dev)
         self.n_live = torch.full((1,), B * max_dets, dtype=torch.int32, device=dev)
         self.slot_of = torch.arange(B * max_dets, dtype=torch.int64, device=dev)
+        # f16 and split-precision backbones carry activations as float16 (pairs): |x| > 65504 saturates to infinity.  The envelope is stated in
+        # DESIGN.md (tests/test_gpu_precision.py measures it); past it the run must fail LOUDLY, not track on infinities: every step ORs
+        # "an embedding is not finite" into a device flag that travels to pinned memory with the results and is checked in synchronize()
+        self.check_finite = dtype != torch.float32 or bool(reid_split_precision)
+        self.nf_flag = torch.zeros(1, dtype=torch.bool, device=dev)
+        self.h_nf_flag = torch.zeros(1, dtype=torch.bool).pin_memory()
         self.nbuf = 2
         self.bufs = []
         row_bytes = self.row_dtype.itemsize
@@ -409,10 +415,17 @@ class DetReidTrackPipeline:
         for est in (getattr(self, "cmc", None) or []):
             est.reset()
         self.frames_done = 0
+        self.nf_flag.zero_()
+        self.h_nf_flag.zero_()
 
     def synchronize(self):
         self.trk_stream.synchronize()
         torch.cuda.current_stream(self.dev).synchronize()
+        if self.check_finite and bool(self.h_nf_flag[0]):
+            self.nf_flag.zero_()
+            self.h_nf_flag.zero_()
+            raise _lib.TlkError("ReID embeddings are not finite: the float16 / split-precision backbones saturated (an activation beyond +-65504, "
+                                "float16's range); this network needs dtype float32 (the reference's precision) -- DESIGN.md, precision envelope")
 
     def _graphed(self, cache, key, fn):
         ent = cache.get(key)
@@ -517,6 +530,9 @@ class DetReidTrackPipeline:
         else:
             buf["emb"].copy_(emb.view(self.B, maxd, self.K, self.D))
             buf["vis"].copy_(vis.view(self.B, maxd, self.K))
+        if self.check_finite:
+            self.nf_flag.logical_or_(torch.logical_not(torch.isfinite(buf["emb"]).all()))
+            self.h_nf_flag.copy_(self.nf_flag, non_blocking=True)
         buf["ltwh"].copy_(self.det["ltwh"])
         buf["counts"].copy_(self.det["counts"])
         torch.add(self.id_off, self.frames_done * maxd, out=buf["ids"])
