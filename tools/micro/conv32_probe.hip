@@ -45,6 +45,19 @@ __global__ void pad4_kernel(const float *a, float *b, long long pixels)
         b[i] = c < 3 ? a[px * 3 + c] : 0.f;
     }
 }
+__global__ void show_diff_kernel(const float *a, const float *b, long long n, int cout, unsigned long long *slot, const float *x, const float *w, const float *bias,
+                                 const float *res, int cin)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        if (a[i] != b[i] && atomicAdd(slot, 1ull) < 6) {
+            const long long row = i / cout; const int col = (int)(i % cout);
+            double acc = 0, half0 = 0;
+            for (int k = 0; k < cin; ++k) { acc += (double)x[row * cin + k] * w[(long long)col * cin + k]; if (k < 32) half0 = acc; }
+            const double pre = acc + bias[col] + (res ? res[i] : 0.0);
+            printf("      row %lld col %d: this %.9g, cfg 0 %.9g | naive relu(dot + bias + res) = %.9g (dot %.6g, first 32 k %.6g, bias %.4g, res %.4g)\n", row, col, a[i], b[i],
+                   pre > 0 ? pre : 0.0, acc, half0, bias[col], res ? res[i] : 0.f);
+        }
+}
 __global__ void count_diff_kernel(const unsigned *a, const unsigned *b, long long n, unsigned long long *out)
 {
     unsigned long long c = 0;
@@ -107,7 +120,8 @@ int main(int argc, char **argv)
     if (!strcmp(what, "all") || !strcmp(what, "exp")) {
         struct Exp { const char *name; int H, W, Cin, Cout, res; } exps[] = {
             {"l1 1x1 64>256 +res", 96, 32, 64, 256, 1}, {"l2 1x1 128>512 +res", 48, 16, 128, 512, 1}, {"l3 1x1 256>1024 +res", 24, 8, 256, 1024, 1},
-            {"l4 1x1 512>2048 +res", 24, 8, 512, 2048, 1}, {"l1 1x1 256>64", 96, 32, 256, 64, 0}, {"l2 1x1 512>128", 48, 16, 512, 128, 0}};
+            {"l4 1x1 512>2048 +res", 24, 8, 512, 2048, 1}, {"l1 1x1 256>64", 96, 32, 256, 64, 0}, {"l2 1x1 512>128", 48, 16, 512, 128, 0},
+            {"l1 1x1 64>64", 96, 32, 64, 64, 0}, {"l2 1x1 256>128", 96, 32, 256, 128, 0}, {"l3 1x1 1024>256", 24, 8, 1024, 256, 0}, {"l4 1x1 2048>512", 24, 8, 2048, 512, 0}};
         for (const Exp &E : exps) {
             const long long M = (long long)crops * E.H * E.W;
             float *x, *w, *r, *y;
@@ -115,14 +129,26 @@ int main(int argc, char **argv)
             fill_kernel<<<2048, 256>>>(x, M * E.Cin, 1.0f, 31); fill_kernel<<<64, 256>>>(w, (long long)E.Cout * E.Cin, 0.1f, 32); fill_kernel<<<2048, 256>>>(r, M * E.Cout, 1.0f, 33);
             auto run = [&] { TK(tlk_conv2d_nhwc_f32(x, w, bias, E.res ? r : nullptr, y, crops, E.H, E.W, E.Cin, E.Cout, 1, 1, 1, 0, 1, 0, 0, 0, nullptr)); };
             const double flops = 2.0 * M * E.Cout * E.Cin, bytes = (double)(M * E.Cin + M * E.Cout * (E.res ? 2 : 1) + E.Cout * E.Cin) * 4;
-            const int cfgs[] = {-1, 0, 2, 7, 8, 9};      // heuristic; 128 x 128 and 128 x 64 two-stage; the one-stage tiles
+            const int cfgs[] = {-1, 0, 2, 9, 21, 22, 23, 24, 25, 26};      // heuristic; 128 x 128 / 128 x 64 two-stage; 64 x 128 one-stage; the direct-to-LDS kernels
+            float *yref; CK(hipMalloc(&yref, M * E.Cout * 4));
+            TK(tlk_conv2d_set_config(0)); run(); CK(hipMemcpy(yref, y, M * E.Cout * 4, hipMemcpyDeviceToDevice));
             for (int cfg : cfgs) {
                 if (cfg_only >= -1 && cfg != cfg_only) continue;
                 TK(tlk_conv2d_set_config(cfg));
+                CK(hipMemset(y, 0xff, M * E.Cout * 4));
+                if (tlk_conv2d_nhwc_f32(x, w, bias, E.res ? r : nullptr, y, crops, E.H, E.W, E.Cin, E.Cout, 1, 1, 1, 0, 1, 0, 0, 0, nullptr) != 0) {
+                    printf("  %-26s cfg %2d  not applicable (%s)\n", E.name, cfg, tlk_last_error()); continue;
+                }
                 const float ms = time_ms(run, iters);
-                printf("  %-26s cfg %2d  %8.3f ms  %6.1f TFLOP/s  %6.0f GB/s on %.2f GB algorithmic\n", E.name, cfg, ms, flops / ms / 1e9, bytes / ms / 1e6, bytes / 1e9);
+                CK(hipMemset(dcount, 0, 8));
+                count_diff_kernel<<<1024, 256>>>((const unsigned *)y, (const unsigned *)yref, M * E.Cout, dcount);
+                unsigned long long nd; CK(hipMemcpy(&nd, dcount, 8, hipMemcpyDeviceToHost));
+                printf("  %-26s cfg %2d  %8.3f ms  %6.1f TFLOP/s  %6.0f GB/s on %.2f GB algorithmic   bits differing from cfg 0: %llu%s\n", E.name, cfg, ms, flops / ms / 1e9,
+                       bytes / ms / 1e6, bytes / 1e9, nd, nd ? "  <-- MISMATCH" : "");
                 fflush(stdout);
+                if (nd) { CK(hipMemset(dcount, 0, 8)); show_diff_kernel<<<64, 256>>>(y, yref, M * E.Cout, E.Cout, dcount, x, w, bias, E.res ? r : nullptr, E.Cin); CK(hipDeviceSynchronize()); }
             }
+            CK(hipFree(yref));
             TK(tlk_conv2d_set_config(-1));
             CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(r)); CK(hipFree(y));
         }

@@ -21,6 +21,7 @@
 //     configuration (no split-K, one accumulator chain per output element);
 //   * blockIdx -> tile mapping is XCD-aware: consecutive tiles (same rows of A, neighbouring column tiles of W) land on one XCD's L2.
 #include "tlk_common.hpp"
+#include "tlk_conv16.hpp"
 
 using namespace tlk;
 
@@ -71,8 +72,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_f32_mfma_kernel(const Con
     constexpr int PA = BM / ROWS_PER_PASS, PB = BN / ROWS_PER_PASS;
     static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile rows must be a multiple of the loader pass");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *As = lds;                                       // [2][BM][LDK]
-    float *Bs = lds + 2 * BM * LDK;                        // [2][BN][LDK]
+    float *As = lds;                                       // [NST][BM][LDK]
+    float *Bs = lds + NST * BM * LDK;                      // [NST][BN][LDK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -354,6 +355,18 @@ template <int TM, int TN, int WGM, int WGN, int NST = 2> int launch_cfg(ConvArgs
     return TLK_OK;
 }
 
+// which layers the direct-to-LDS kernels take by default (0 = none): filled in from the probe's table (profiles/r05_conv_f32_shapes.txt)
+int pick_x32(const ConvArgs &a, int cout, bool has_res)
+{
+    // measured (tools/micro/conv32_probe, 2400 crops): the one-stage 64 x 128 tile with the residual prefetched takes the short-K expansions
+    // (K <= 128: 4.05 vs 4.5 ms and 2.87 vs 3.13 ms), the one-stage 256 x 64 tile the 64-wide 1 x 1 layers (0.92 vs 1.06 ms); every other
+    // layer is as fast or faster on conv_f32_mfma_kernel
+    if (a.KH != 1 || a.KW != 1 || a.stride != 1) return 0;
+    if (has_res && a.K <= 128 && cout % 128 == 0 && a.M >= 256 * 1024) return 5;
+    if (!has_res && cout == 64 && a.K <= 256 && a.M >= 256 * 1024) return 3;
+    return 0;
+}
+
 int g_force_cfg = -1;     // tlk_conv2d_set_config (probes / tests): -1 = heuristic
 const int *g_dyn_batch = nullptr;      // tlk_conv_set_dynamic_batch
 int g_last_cfg = -1;      // configuration of the most recent launch (tlk_conv2d_last_config: bench.py groups its event timings by kernel instantiation)
@@ -362,7 +375,7 @@ int g_last_cfg = -1;      // configuration of the most recent launch (tlk_conv2d
 
 extern "C" int tlk_conv2d_set_config(int cfg)
 {
-    if (cfg < -1 || cfg > 9) return fail(TLK_EINVAL, "tlk_conv2d_set_config: cfg must be -1 (heuristic) or 0..9");
+    if (cfg < -1 || (cfg > 9 && (cfg < 21 || cfg > 26))) return fail(TLK_EINVAL, "tlk_conv2d_set_config: cfg must be -1 (heuristic), 0..9, or 21..26 (the direct-to-LDS kernels of tlk_conv16x.hip on fp32 tensors)");
     g_force_cfg = cfg;
     return TLK_OK;
 }
@@ -421,6 +434,25 @@ extern "C" int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const
     // K >= 512 layers); 128 x 64 for Cout <= 64 and the other widths that are not multiples of 128 (two workgroups per CU fit, which the
     // 256 x 64 tile's 92 KB of LDS do not); 256 x 96 for odd multiples of 96 (YOLOX-m widths); 64 x 128 when 128-row tiles would leave CUs idle
     int cfg = g_force_cfg;
+    // the direct-to-LDS kernels of tlk_conv16x.hip on fp32 tensors (MODE_F32: same fmaf chain, bit-identical results): the memory-bound layers
+    auto x32 = [&](int xcfg) {
+        c16::Conv16Args b;
+        b.x = (const _Float16 *)x_dev; b.x_lo = nullptr; b.w = (const _Float16 *)w_dev; b.w_lo = nullptr; b.res = (const _Float16 *)residual_dev; b.res_lo = nullptr;
+        b.bias = bias_dev; b.y = nullptr; b.y_lo = nullptr; b.y32 = y_dev;
+        b.M = a.M; b.H = h; b.W = w; b.Cin = cin; b.Ho = ho; b.Wo = wo; b.Cout = cout; b.KH = kh; b.KW = kw; b.stride = stride; b.pad = pad; b.K = a.K;
+        b.x_pix = a.x_pix; b.y_pix = a.y_pix; b.r_pix = a.r_pix; b.res_post = res_post; b.n_dyn = g_dyn_batch;
+        return c16::launch32x(b, act_kind, xcfg, st);
+    };
+    const bool x32_ok = cin % 32 == 0 && cout % 4 == 0 && ((a.y_pix | a.r_pix) & 3) == 0 && (((uintptr_t)y_dev | (uintptr_t)residual_dev | (uintptr_t)bias_dev) & 15) == 0;
+    if (cfg >= 21) {
+        if (!x32_ok) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: this shape cannot take the direct-to-LDS kernels (Cin % 32, Cout % 4, 16-byte aligned rows)");
+        g_last_cfg = cfg;
+        return x32(cfg - 20);
+    }
+    if (cfg < 0 && x32_ok) {
+        const int pick = pick_x32(a, cout, residual_dev != nullptr);
+        if (pick > 0) { const int r = x32(pick); if (r != 1) { if (r == TLK_OK) g_last_cfg = 20 + pick; return r; } }
+    }
     if (cfg < 0) {
         const int c = cout;
         if (c <= 32) cfg = 4;

@@ -9,7 +9,7 @@ namespace tlk {
 namespace c16 {
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
-enum { MODE_F16 = 0, MODE_SPLIT = 1 };
+enum { MODE_F16 = 0, MODE_SPLIT = 1, MODE_F32 = 2 };      // MODE_F32 (tlk_conv16x.hip only): fp32 tensors on the exact fp32-input MFMA, same loader / ring
 constexpr int ROW_BYTES = 128;                            // one K slice of a tile row in LDS: 64 f16 of one plane, or 32 hi | 32 lo
 constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
 
@@ -115,6 +115,8 @@ const unsigned char *zero_page();      // 256 zero bytes on the current device (
 // tlk_conv16x.hip: the large-tile kernels.  cfg: 0 = choose by shape (may decline: returns 1 = "not mine", the caller keeps its own kernel),
 // > 0 = force that tile configuration (probes).  Returns TLK_OK when launched.
 int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream_t st);
+// the same kernels on fp32 tensors (a.x / a.w / a.res / a.y32 hold float pointers): the memory-bound layers of the fp32 networks
+int launch32x(Conv16Args &a, int act, int cfg, hipStream_t st);
 
 }  // namespace c16
 }  // namespace tlk

@@ -30,6 +30,7 @@ using namespace tlk::c16;
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int OOB = (int)0x80000000;                      // beyond every num_records (< 2^31): the hardware returns zeros
 
 // scheduling recipe for one chunk of the K loop: NPAIR x (one instruction of class MASK, one MFMA), then REST MFMAs
@@ -58,7 +59,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
     constexpr int NW = WGM * WGN, NT = 64 * NW;
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int PLANES = MODE == MODE_SPLIT ? 2 : 1;
-    constexpr int BKE = 64 / PLANES;                      // K elements per step
+    constexpr int ES = MODE == MODE_F32 ? 4 : 2;          // bytes per element
+    constexpr int EPC = 16 / ES;                          // elements per 16-byte chunk: 8 / 4
+    constexpr int BKE = ROW_BYTES / PLANES / ES;          // K elements per step: 64 (f16), 32 (split: 32 hi + 32 lo), 32 (fp32)
     constexpr int RB = ROW_BYTES / PLANES;                // bytes of one tile row in one plane's LDS region
     constexpr int CPR = RB / 16;                          // 16-byte chunks per row: 8 / 4
     constexpr int RPI = 64 / CPR;                         // rows one wavefront-instruction fills: 8 / 16
@@ -67,10 +70,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
     static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "tile rows must be a multiple of the loader pass");
     constexpr int A_REGION = BM * RB, B_REGION = BN * RB;
     constexpr int STAGE = PLANES * (A_REGION + B_REGION);          // (BM + BN) * 128 bytes
-    constexpr int NJ = BKE / 16;                          // 16-wide k slices per step: 4 / 2
+    constexpr int NJ = ROW_BYTES / PLANES / 32;           // slices per step (two chunks = one fragment pair each): 4 / 2 / 4
     constexpr int NACC = MODE == MODE_SPLIT ? 2 : 1;
     constexpr int NR = PLANES * (TM + TN);                // fragment reads per slice
-    constexpr int NM = TM * TN * (MODE == MODE_SPLIT ? 3 : 1);     // MFMAs per slice
+    constexpr int NM = TM * TN * (MODE == MODE_SPLIT ? 3 : MODE == MODE_F32 ? 4 : 1);     // MFMAs per slice
     constexpr int NLD = PLANES * (QA + QB);               // direct-to-LDS loads per wavefront and stage
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -97,18 +100,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
         const int hi = ho * p.stride - p.pad;
         base_pix = (long long)n * p.H * p.W + (long long)(hi > 0 ? hi : 0) * p.W;
     }
-    const _Float16 *abase[PLANES];
-    abase[0] = p.x + base_pix * p.x_pix;
-    if (MODE == MODE_SPLIT) abase[PLANES - 1] = p.x_lo + base_pix * p.x_pix;
-    const _Float16 *wbase[PLANES];
-    wbase[0] = p.w;
-    if (MODE == MODE_SPLIT) wbase[PLANES - 1] = p.w_lo;
+    const unsigned char *abase[PLANES], *wbase[PLANES];   // (MODE_F32: the _Float16 * members of the argument block hold float pointers)
+    abase[0] = reinterpret_cast<const unsigned char *>(p.x) + base_pix * p.x_pix * ES;
+    if (MODE == MODE_SPLIT) abase[PLANES - 1] = reinterpret_cast<const unsigned char *>(p.x_lo) + base_pix * p.x_pix * ES;
+    wbase[0] = reinterpret_cast<const unsigned char *>(p.w);
+    if (MODE == MODE_SPLIT) wbase[PLANES - 1] = reinterpret_cast<const unsigned char *>(p.w_lo);
     __amdgpu_buffer_rsrc_t rs_a[PLANES], rs_b[PLANES];
     {
         const long long total_pix = (long long)((unsigned)p.M / (unsigned)(p.Ho * p.Wo)) * p.H * p.W;
-        long long a_bytes = ((total_pix - base_pix - 1) * p.x_pix + p.Cin) * 2;
+        long long a_bytes = ((total_pix - base_pix - 1) * p.x_pix + p.Cin) * ES;
         if (a_bytes > 0x7ffffff0LL) a_bytes = 0x7ffffff0LL;
-        const int w_bytes = (int)((long long)p.Cout * p.K * 2);
+        const int w_bytes = (int)((long long)p.Cout * p.K * ES);
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl) {
             rs_a[pl] = __builtin_amdgcn_make_buffer_rsrc((void *)abase[pl], 0, (int)a_bytes, 0x00020000);
@@ -128,7 +130,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
             const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
             a_hi0[q] = ho * p.stride - p.pad; a_wi0[q] = wo * p.stride - p.pad;
             const int rel = (int)((long long)n * p.H * p.W - base_pix) + a_hi0[q] * p.W + a_wi0[q];
-            a_off0[q] = (rel * p.x_pix + lcq * 8) * 2;
+            a_off0[q] = (rel * p.x_pix + lcq * EPC) * ES;
         }
     }
 #pragma unroll
@@ -136,16 +138,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
         const int row = (q * NW + wave) * RPI + lrow;
         const int lcq = pc ^ ((row >> SWS) & (CPR - 1));
         const int co = n0 + row;
-        b_off0[q] = co < p.Cout ? (co * p.K + lcq * 8) * 2 : OOB;
+        b_off0[q] = co < p.Cout ? (co * p.K + lcq * EPC) * ES : OOB;
     }
     int u_kh = 0, u_kw = 0, u_ci0 = 0, u_k0 = 0;          // tap of the step being loaded (wave-uniform)
-    auto load16 = [&](const __amdgpu_buffer_rsrc_t &rs, const _Float16 *, int off, unsigned char *dst) {
+    auto load16 = [&](const __amdgpu_buffer_rsrc_t &rs, const unsigned char *, int off, unsigned char *dst) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)dst, 16, off, 0, 0, 0);
     };
     auto issue_stage = [&](int buf) {                      // a stage beyond K is all zeros (it lands in a buffer nobody multiplies)
         const bool in_k = u_k0 < p.K;
         // (weights stay below 2^30 bytes -- host check -- so "valid offset + 2^30" is out of range for them: a scalar select, no branch)
-        const int a_add = ((u_kh * p.W + u_kw) * p.x_pix + u_ci0) * 2, b_add = (USE_BUF && !in_k) ? 0x40000000 : u_k0 * 2;
+        const int a_add = ((u_kh * p.W + u_kw) * p.x_pix + u_ci0) * ES, b_add = (USE_BUF && !in_k) ? 0x40000000 : u_k0 * ES;
         unsigned char *st = lds + buf * STAGE;
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
@@ -187,15 +189,15 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
     int coff[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) coff[j] = ((2 * j + hsel) ^ sw) << 4;
-    h16x8 fa[2][PLANES][TM], fb[2][PLANES][TN];           // two fragment sets: slice j + 1 is read while slice j is multiplied
+    i32x4 fa[2][PLANES][TM], fb[2][PLANES][TN];           // two fragment sets (16 bytes each: 8 f16 or 4 floats): slice j + 1 is read while slice j is multiplied
     auto read_frags = [&](int buf, int j, int set) {
         const unsigned char *sa = lds + buf * STAGE + a_lane + coff[j], *sb = lds + buf * STAGE + b_lane + coff[j];
 #pragma unroll
         for (int pl = 0; pl < PLANES; ++pl) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[set][pl][i] = *reinterpret_cast<const h16x8 *>(sa + pl * A_REGION + i * 32 * RB);
+            for (int i = 0; i < TM; ++i) fa[set][pl][i] = *reinterpret_cast<const i32x4 *>(sa + pl * A_REGION + i * 32 * RB);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fb[set][pl][i] = *reinterpret_cast<const h16x8 *>(sb + pl * B_REGION + i * 32 * RB);
+            for (int i = 0; i < TN; ++i) fb[set][pl][i] = *reinterpret_cast<const i32x4 *>(sb + pl * B_REGION + i * 32 * RB);
         }
     };
     auto mfmas = [&](int set) {
@@ -203,10 +205,22 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int jj = 0; jj < TN; ++jj) {
-                acc[0][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0][i], fb[set][0][jj], acc[0][i][jj], 0, 0, 0);
-                if (MODE == MODE_SPLIT) {
-                    acc[NACC - 1][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][0][i], fb[set][PLANES - 1][jj], acc[NACC - 1][i][jj], 0, 0, 0);
-                    acc[NACC - 1][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][PLANES - 1][i], fb[set][0][jj], acc[NACC - 1][i][jj], 0, 0, 0);
+                if (MODE == MODE_F32) {
+                    // lane l holds k = 8 j + 4 (l >> 5) + r, r = 0..3: MFMA r multiplies the k pair (8 j + r, 8 j + 4 + r) -- the fmaf chain
+                    // 0,4,1,5,2,6,3,7 within every group of 8 that oracle/src/conv.c walks (tlk_conv.hip's contract, bit for bit)
+                    const f32x4 af = __builtin_bit_cast(f32x4, fa[set][0][i]), bf = __builtin_bit_cast(f32x4, fb[set][0][jj]);
+                    acc[0][i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[0][i][jj], 0, 0, 0);
+                    acc[0][i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[0][i][jj], 0, 0, 0);
+                    acc[0][i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[0][i][jj], 0, 0, 0);
+                    acc[0][i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[0][i][jj], 0, 0, 0);
+                } else {
+                    acc[0][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, fa[set][0][i]), __builtin_bit_cast(h16x8, fb[set][0][jj]), acc[0][i][jj], 0, 0, 0);
+                    if (MODE == MODE_SPLIT) {
+                        acc[NACC - 1][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, fa[set][0][i]), __builtin_bit_cast(h16x8, fb[set][PLANES - 1][jj]),
+                                                                                      acc[NACC - 1][i][jj], 0, 0, 0);
+                        acc[NACC - 1][i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, fa[set][PLANES - 1][i]), __builtin_bit_cast(h16x8, fb[set][0][jj]),
+                                                                                      acc[NACC - 1][i][jj], 0, 0, 0);
+                    }
                 }
             }
     };
@@ -224,24 +238,23 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
     constexpr int EPI = pick_epi(TM, WGM, LDS_AVAIL / (LDC * 4));
     static_assert(WGM * 32 * EPI * LDC * 4 <= LDS_AVAIL, "epilogue pass does not fit the LDS");
     constexpr int PROWS = WGM * 32 * EPI;                 // tile rows per pass
-    constexpr int V_PER_ROW = BN / 8, NVEC = PROWS * V_PER_ROW, ITS = (NVEC + NT - 1) / NT, NPASS = TM / EPI;
+    constexpr int VW = MODE == MODE_F32 ? 4 : 8;          // output channels per lane and pass: 16 bytes of the tensors' element type
+    constexpr int V_PER_ROW = BN / VW, NVEC = PROWS * V_PER_ROW, ITS = (NVEC + NT - 1) / NT, NPASS = TM / EPI;
     const bool has_res = p.res != nullptr, out32 = p.y32 != nullptr;
-    h16x8 rpre[RESPF ? NPASS : 1][RESPF ? ITS : 1];
+    i32x4 rpre[RESPF ? NPASS : 1][RESPF ? ITS : 1];        // 16 bytes of residual per vector: 8 f16 / 4 floats
     if (RESPF && has_res) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps)
 #pragma unroll
             for (int it = 0; it < ITS; ++it) {
                 const int idx = it * NT + tid;
-                const int prow = idx / V_PER_ROW, ec = (idx - prow * V_PER_ROW) * 8;
+                const int prow = idx / V_PER_ROW, ec = (idx - prow * V_PER_ROW) * VW;
                 const int pw = prow / (32 * EPI), within = prow - pw * (32 * EPI);
                 const long long m = m0 + pw * (TM * 32) + ps * EPI * 32 + within;
                 const int co = n0 + ec;
                 const bool ok = !(NVEC % NT != 0 && idx >= NVEC) && m < M && co < p.Cout;
-                h16x8 z;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
-                rpre[ps][it] = ok ? *reinterpret_cast<const h16x8 *>(p.res + m * p.r_pix + co) : z;
+                const i32x4 z = {0, 0, 0, 0};
+                rpre[ps][it] = ok ? *reinterpret_cast<const i32x4 *>(reinterpret_cast<const unsigned char *>(p.res) + (m * p.r_pix + co) * ES) : z;
             }
     }
     if (NST == 1) {
@@ -320,60 +333,73 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
             const int idx = it * NT + tid;
-            const int prow = idx / V_PER_ROW, ec = (idx - prow * V_PER_ROW) * 8;
+            const int prow = idx / V_PER_ROW, ec = (idx - prow * V_PER_ROW) * VW;
             const int pw = prow / (32 * EPI), within = prow - pw * (32 * EPI);
             const long long m = m0 + pw * (TM * 32) + i0 * 32 + within;
             const int co = n0 + ec;
-            if ((NVEC % NT != 0 && idx >= NVEC) || m >= M || co >= p.Cout) continue;      // Cout % 8 == 0 (checked by the host side)
-            float v[8];
-            {
-                const float4 c0 = *reinterpret_cast<const float4 *>(Cs + prow * LDC + ec), c1 = *reinterpret_cast<const float4 *>(Cs + prow * LDC + ec + 4);
-                v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+            if ((NVEC % NT != 0 && idx >= NVEC) || m >= M || co >= p.Cout) continue;      // Cout % 8 == 0 (checked by the host side; % 4 for fp32)
+            float v[VW];
+#pragma unroll
+            for (int q4 = 0; q4 < VW / 4; ++q4) {
+                const float4 c0 = *reinterpret_cast<const float4 *>(Cs + prow * LDC + ec + 4 * q4);
+                v[4 * q4] = c0.x; v[4 * q4 + 1] = c0.y; v[4 * q4 + 2] = c0.z; v[4 * q4 + 3] = c0.w;
             }
             if (p.bias) {
-                const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + co), b1 = *reinterpret_cast<const float4 *>(p.bias + co + 4);
-                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+#pragma unroll
+                for (int q4 = 0; q4 < VW / 4; ++q4) {
+                    const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + co + 4 * q4);
+                    v[4 * q4] += b0.x; v[4 * q4 + 1] += b0.y; v[4 * q4 + 2] += b0.z; v[4 * q4 + 3] += b0.w;
+                }
             }
-            float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float rv[VW];
+#pragma unroll
+            for (int e = 0; e < VW; ++e) rv[e] = 0.f;
             if (has_res) {
-                const h16x8 rh = RESPF ? rpre[RESPF ? i0 / EPI : 0][RESPF ? it : 0] : *reinterpret_cast<const h16x8 *>(p.res + m * p.r_pix + co);
+                const i32x4 rraw = RESPF ? rpre[RESPF ? i0 / EPI : 0][RESPF ? it : 0]
+                                         : *reinterpret_cast<const i32x4 *>(reinterpret_cast<const unsigned char *>(p.res) + (m * p.r_pix + co) * ES);
+                if (MODE == MODE_F32) {
+                    const f32x4 rf = __builtin_bit_cast(f32x4, rraw);      // (whole-vector cast: a per-element bit_cast inside an unrolled loop read element 0 four times)
+                    rv[0] = rf.x; rv[1] = rf.y; rv[2] = rf.z; rv[3] = rf.w;
+                } else {
+                    const h16x8 rh = __builtin_bit_cast(h16x8, rraw);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) rv[e] = (float)rh[e];
-                if (MODE == MODE_SPLIT) {
-                    const h16x8 rl = *reinterpret_cast<const h16x8 *>(p.res_lo + m * p.r_pix + co);
+                    for (int e = 0; e < VW; ++e) rv[e] = (float)rh[e & 7];
+                    if (MODE == MODE_SPLIT) {
+                        const h16x8 rl = *reinterpret_cast<const h16x8 *>(p.res_lo + m * p.r_pix + co);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) rv[e] += (float)rl[e] * LO_INV;
+                        for (int e = 0; e < VW; ++e) rv[e] += (float)rl[e & 7] * LO_INV;
+                    }
                 }
                 if (!p.res_post) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                    for (int e = 0; e < VW; ++e) v[e] += rv[e];
                 }
             }
             if (act == ACT_RELU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = act16<ACT_RELU>(v[e]);
+                for (int e = 0; e < VW; ++e) v[e] = act16<ACT_RELU>(v[e]);
             } else if (act == ACT_SILU) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = act16<ACT_SILU>(v[e]);
+                for (int e = 0; e < VW; ++e) v[e] = act16<ACT_SILU>(v[e]);
             }
             if (has_res && p.res_post) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                for (int e = 0; e < VW; ++e) v[e] += rv[e];
             }
-            if (out32) {
+            if (out32 || MODE == MODE_F32) {
                 float *o = p.y32 + m * p.y_pix + co;
-                *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+                for (int q4 = 0; q4 < VW / 4; ++q4) *reinterpret_cast<float4 *>(o + 4 * q4) = make_float4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
             } else if (MODE == MODE_SPLIT) {
                 h16x8 oh, ol;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f32(v[e], h, l); oh[e] = h; ol[e] = l; }
+                for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f32(v[e % VW], h, l); oh[e] = h; ol[e] = l; }
                 *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
                 *reinterpret_cast<h16x8 *>(p.y_lo + m * p.y_pix + co) = ol;
             } else {
                 h16x8 oh;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) oh[e] = (_Float16)v[e];
+                for (int e = 0; e < 8; ++e) oh[e] = (_Float16)v[e % VW];
                 *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
             }
         }
@@ -434,10 +460,36 @@ int launch_cfg_x(Conv16Args &a, bool split, int act, int cfg, hipStream_t st)
     }
 }
 
+// fp32 tensors on the same kernels (MODE_F32): the memory-bound layers of the fp32 networks
+int launch_cfg_x32(Conv16Args &a, int act, int cfg, hipStream_t st)
+{
+    switch (cfg) {
+    case 1: return launch_x<2, 2, 2, 2, MODE_F32, 1, true>(a, act, st);      // 128 x 128, ONE stage, residual prefetched (16 floats of it per lane and pass)
+    case 2: return launch_x<2, 2, 2, 2, MODE_F32, 1, false>(a, act, st);     // 128 x 128, ONE stage
+    case 3: return launch_x<4, 1, 2, 2, MODE_F32, 1, false>(a, act, st);     // 256 x 64, ONE stage
+    case 4: return launch_x<2, 2, 2, 2, MODE_F32, 2, true>(a, act, st);      // 128 x 128, two stages
+    case 5: return launch_x<2, 2, 1, 2, MODE_F32, 1, true>(a, act, st);      // 64 x 128, ONE stage
+    case 6: return launch_x<4, 1, 2, 2, MODE_F32, 1, true>(a, act, st);      // 256 x 64, ONE stage, residual prefetched
+    default: return fail(TLK_EINVAL, "tlk_conv2d_set_config: the direct-to-LDS fp32 configurations are 21..26");
+    }
+}
+
 }  // namespace
 
 namespace tlk {
 namespace c16 {
+
+int launch32x(Conv16Args &a, int act, int cfg, hipStream_t st)
+{
+    if (a.Cin % 32 != 0 || a.K % 32 != 0 || a.Cout % 4 != 0) return cfg > 0 ? fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: the direct-to-LDS kernels need Cin % 32 == 0") : 1;
+    {
+        const long long span_rows = 512 / (a.Wo > 0 ? a.Wo : 1) + a.KH + 2;
+        const long long a_span = (span_rows * a.stride + a.KH) * (long long)a.W * a.x_pix * 4 + (long long)a.H * a.W * a.x_pix * 4;
+        if (a_span >= 0x7fffffffLL || (long long)a.Cout * a.K * 4 >= 0x3fffffffLL) return cfg > 0 ? fail(TLK_EINVAL, "tlk_conv2d_nhwc_f32: tensor rows too long for 32-bit tile offsets") : 1;
+    }
+    if (cfg <= 0) return 1;        // (the caller's own heuristic decides when these kernels take a layer)
+    return launch_cfg_x32(a, act, cfg, st);
+}
 
 int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream_t st)
 {
