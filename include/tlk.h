@@ -650,10 +650,19 @@ int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const float *bia
                         int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int act_kind,
                         int x_pix_stride, int y_pix_stride, int res_pix_stride, void *hip_stream);
 /* Probes / tests: force one of the kernel's tile configurations (0: 128x128, 1: 256x64, 2: 128x64, 3: 256x96, 4: 256x32, 5: 64x128, 6: 128x64 (waves stacked)
- * pixels x output channels); -1 = the heuristic.  Results do not depend on it. */
+ * pixels x output channels; r05: 7 / 8 / 9 = 128x128 / 128x64 / 64x128 with ONE LDS stage and the epilogue in passes; 21..26 = the direct-to-LDS
+ * kernels of tlk_conv16x.hip on fp32 tensors (need cin % 32 == 0)); -1 = the heuristic.  Results do not depend on it: one fmaf chain, as above. */
 int tlk_conv2d_set_config(int cfg);
-/* Tile configuration (0..6) the most recent tlk_conv2d_nhwc_f32 call of this process launched, -1 before the first. */
+/* Tile configuration the most recent tlk_conv2d_nhwc_f32 call of this process launched (as above; 15 = the direct RGB stem kernel), -1 before the first. */
 int tlk_conv2d_last_config(void);
+/* r05.  cin == 3 (an RGB stem: 7x7 or 3x3, stride 2, cout <= 64, no residual) is accepted too and goes to a direct kernel (tlk_conv_stem.hip) that
+ * reads the 3-channel image as it is -- its chain is the one above on the image padded to 4 channels, minus the zero terms: bit-identical.
+ * Dynamic batch: every convolution launched (or captured into a hipGraph) while n_images_dev is set reads its image count from
+ * n_images_dev[0] WHEN THE KERNEL RUNS and treats the `n` of the call as the capacity; rows beyond are neither read nor written and the
+ * workgroups beyond them leave at once.  This is how the ReID batch of a step is convolved on its real crops only (the reference batches real
+ * detections only, tracklab/wrappers/reid/kpreid_api.py:147-182) from ONE captured graph.  NULL switches it off.  Applies to
+ * tlk_conv2d_nhwc_f32 and tlk_conv2d_nhwc_16. */
+int tlk_conv_set_dynamic_batch(const int32_t *n_images_dev);
 
 /* The same convolution on the 16-bit MFMA (v_mfma_f32_32x32x16_f16; tlk_conv16.hip), two modes selected by the pointers given:
  *   f16 mode   (x_lo_dev == NULL): x, w, residual, y are f16 NHWC / (cout,kh,kw,cin); fp32 accumulation and epilogue; bias fp32.
@@ -671,6 +680,11 @@ int tlk_conv2d_nhwc_16(const void *x_dev, const void *x_lo_dev, const void *w_de
 /* Probes / tests: 0 = the register-staged kernel for every shape, 1 (default; env TLK_CONV16_GLDS) = the direct-to-LDS kernel where it applies
  * (Cout > 64, Cin a multiple of the K step).  Results do not depend on it beyond fp32 summation order inside a 16-wide slice (none: same order). */
 int tlk_conv16_set_glds(int on);
+/* r05: the large-tile / one-stage / ring kernels of tlk_conv16x.hip (direct-to-LDS buffer loads with hardware zero fill, XOR-swizzled LDS rows,
+ * one to four LDS stages with counted waits, residual prefetched into registers).  cfg 0 (default) = they take the shapes their launch-size
+ * heuristic claims (cin a multiple of the K step: 64 in f16 mode, 32 in split mode) and the r04 kernels the rest; -1 = r04 kernels only;
+ * 1..16 (f16) / 1..7 (split) = force one tile configuration (probes / tests).  Same arithmetic contract as above in every configuration. */
+int tlk_conv16_set_config(int cfg);
 /* fp32 NHWC pixels (c_in channels, x_pix_stride floats apart, 0 = dense) -> (hi, lo) f16 planes with c_out >= c_in channels, zero padded. */
 int tlk_split_f32_planes(const float *x_dev, long long pixels, int c_in, int x_pix_stride, int c_out, void *hi_dev, void *lo_dev, void *hip_stream);
 /* y[i] = hi[i] + lo[i] * 2^-11 for n elements. */
@@ -696,6 +710,13 @@ int tlk_dwconv2d_nhwc(const void *x_dev, const void *w_dev, const float *bias_de
  * torch's max_pool2d + cat bit for bit on NaN-free input (oracle/src/conv.c orc_spp_maxpool_nhwc_f32). */
 int tlk_spp_maxpool_nhwc(const void *x_dev, void *y_dev, int n, int h, int w, int c, int dtype, int x_pix_stride, int y_pix_stride,
                          void *hip_stream);
+
+/* r05: plain k x k max pooling with stride and -inf padding (pad <= k / 2) of a channels-last map, NHWC in and out: the pool behind ResNet-50's
+ * stem in the ReID networks (3 x 3, stride 2, pad 1; torchreid behind tracklab/wrappers/reid/kpreid_api.py:147-182).  Same tensor conventions as
+ * tlk_spp_maxpool_nhwc; max is exact, so the result equals torch's max_pool2d bit for bit on NaN-free input.  Honours
+ * tlk_conv_set_dynamic_batch (images beyond the live count are not written). */
+int tlk_maxpool2d_nhwc(const void *x_dev, void *y_dev, int n, int h, int w, int c, int k, int stride, int pad, int dtype, int x_pix_stride,
+                       int y_pix_stride, void *hip_stream);
 
 /* 1x1 convolution of a channels-last tensor as ONE GEMM with the convolution epilogue inside:
  *   out[M,N] = act(x[M,K] . w[N,K]^T + bias[N] (+ residual[M,N])),  act 0 none / 1 ReLU / 2 SiLU, dtype TLK_F16 or TLK_BF16.

@@ -47,7 +47,9 @@ def _run(case, cfg):
     return y.permute(0, 2, 3, 1).cpu().numpy(), exp
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6])
+# 0-6: two-stage tiles of conv_f32_mfma_kernel; 7-9: its one-stage tiles (r05); 21-26: the direct-to-LDS kernels of tlk_conv16x.hip on fp32 tensors
+# (r05, MODE_F32: they need Cin % 32 == 0 and say so otherwise)
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("case", CASES)
 def test_conv_is_bit_exact_with_the_oracle_chain(case, cfg):
     got, exp = _run(case, cfg)
@@ -91,6 +93,48 @@ def test_dynamic_batch_computes_the_live_images_only(live):
     torch.cuda.synchronize()
     assert torch.equal(out16[:k], full16[:k])
     assert (out16[k:] == -3.0).all()
+
+
+X32_CASES = [
+    # n, h, w, cin, cout, k, stride, act, residual  (Cin a multiple of the 32-float K step)
+    (3, 8, 8, 64, 64, 1, 1, "relu", True),
+    (2, 11, 5, 32, 96, 3, 2, None, True),
+    (2, 5, 9, 128, 256, 1, 2, None, False),
+    (5, 13, 7, 64, 260, 1, 1, "relu", True),        # Cout ragged against every tile width
+    (1, 24, 8, 256, 128, 3, 1, "relu", False),
+]
+
+
+@pytest.mark.parametrize("cfg", [21, 22, 23, 24, 25, 26])
+@pytest.mark.parametrize("case", X32_CASES)
+def test_direct_to_lds_fp32_kernels_are_bit_exact_with_the_oracle_chain(case, cfg):
+    got, exp = _run(case, cfg)
+    assert got.shape == exp.shape
+    assert np.array_equal(got, exp), f"max |diff| {np.abs(got - exp).max()}"
+
+
+@pytest.mark.parametrize("case", [(2, 24, 16, 3, 64, 7, 2, "relu", False), (3, 17, 13, 3, 32, 3, 2, "relu", False), (1, 40, 130, 3, 48, 3, 2, None, False),
+                                  (2, 9, 70, 3, 64, 7, 2, "relu", False)])
+def test_direct_rgb_stem_kernel_is_bit_exact_with_the_oracle_on_the_padded_problem(case):
+    """r05, csrc/tlk_conv_stem.hip: Cin = 3 goes to the direct stem kernel; its chain is the implicit-GEMM kernel's on the 4-channel-padded
+    problem minus the zero terms, which is what oracle/src/conv.c computes on the padded input -- bit for bit (ragged widths beyond one
+    64-column strip, rows beyond a 4-row strip pair, Cout below a 32-wide tile)"""
+    import oracle
+    from tracklab_amd import _lib
+    n, h, w, cin, cout, k, s, act, _ = case
+    rng = np.random.default_rng(k * 100 + cout)
+    x = rng.standard_normal((n, h, w, 3)).astype(np.float32)
+    wt = (rng.standard_normal((cout, k, k, 3)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    x4 = np.concatenate([x, np.zeros((n, h, w, 1), np.float32)], -1)
+    w4 = np.concatenate([wt, np.zeros((cout, k, k, 1), np.float32)], -1)
+    exp = oracle.conv2d_nhwc_f32(x4, w4, b, None, stride=s, act=act)
+    xt = torch.from_numpy(x).cuda().permute(0, 3, 1, 2)
+    wtt = torch.from_numpy(wt).cuda().permute(0, 3, 1, 2)
+    y = _lib.conv2d_nhwc_f32(xt, wtt, torch.from_numpy(b).cuda(), act, None, stride=s)
+    assert _lib.lib().tlk_conv2d_last_config() == 15, "the call did not reach the direct stem kernel"
+    got = y.permute(0, 2, 3, 1).cpu().numpy()
+    assert got.shape == exp.shape and np.array_equal(got, exp), f"max |diff| {np.abs(got - exp).max()}"
 
 
 def test_residual_after_the_activation_is_bit_exact_with_the_oracle():

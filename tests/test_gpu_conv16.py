@@ -111,3 +111,80 @@ def test_residual_after_the_activation(shape):
     ref = F.silu(F.conv2d(x.double(), wt.double(), b.double(), s, k // 2)) + r.double()
     bound = F.conv2d(x.double().abs(), wt.double().abs(), b.double().abs(), s, k // 2) + r.double().abs()
     assert bool(((y32.double() - ref).abs() <= 4e-6 * bound + 1e-30).all())
+
+
+# ---- r05: the large-tile / one-stage / ring kernels of tlk_conv16x.hip (tlk_conv16_set_config forces a tile configuration) -------------------
+X_SHAPES = [(5, 64, 24, 8, 64, 3, 1, True), (3, 256, 12, 8, 256, 1, 1, True), (2, 128, 17, 9, 200, 3, 2, False), (7, 512, 6, 4, 512, 3, 1, False),
+            (2, 192, 11, 7, 72, 1, 1, True), (1, 64, 40, 24, 256, 1, 1, True)]
+
+
+def _force16(cfg):
+    from tracklab_amd import _lib
+    L = _lib.lib()
+    _lib.conv2d_nhwc_16(torch.zeros((0, 8, 2, 2), device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last),
+                        torch.zeros((8, 8, 1, 1), device="cuda", dtype=torch.float16))          # binds the symbols
+    _lib.check(L.tlk_conv16_set_config(cfg))
+
+
+@pytest.mark.parametrize("cfg", list(range(1, 17)))
+@pytest.mark.parametrize("shape", X_SHAPES)
+def test_every_f16_tile_configuration_of_the_direct_to_lds_kernels(shape, cfg):
+    """one / two / three / four LDS stages, 64 x 64 ... 256 x 256 tiles, residual prefetched or not: the same fp32-accumulated f16 convolution
+    (ragged M and Cout, taps outside the image, strides), to the bound of the r04 kernels' test above"""
+    from tracklab_amd import _lib
+    x, wt, b, r, k, s = _inputs(shape, seed=cfg)
+    xh, wh = x.half(), wt.half()
+    rh = r.half() if r is not None else None
+    try:
+        _force16(cfg)
+        y = _lib.conv2d_nhwc_16(xh, wh, b, "relu", rh, stride=s)
+    finally:
+        _force16(0)
+    ref = F.conv2d(xh.double(), wh.double(), b.double(), s, k // 2)
+    if r is not None:
+        ref = ref + rh.double()
+    ref = F.relu(ref)
+    bound = F.conv2d(xh.double().abs(), wh.double().abs(), b.double().abs(), s, k // 2)
+    err = (y.double() - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -11 + 2e-6 * bound + 1e-7).all()), float((err / (ref.abs() + 1e-3)).max())
+
+
+@pytest.mark.parametrize("cfg", list(range(1, 8)))
+@pytest.mark.parametrize("shape", [X_SHAPES[0], X_SHAPES[1], X_SHAPES[2], X_SHAPES[3]])
+def test_every_split_tile_configuration_is_fp32_class(shape, cfg):
+    from tracklab_amd import _lib
+    x, wt, b, r, k, s = _inputs(shape, seed=10 + cfg)
+    xh, xl = _lib.split_planes(x)
+    wh, wl = _lib.split_planes(wt)
+    rh, rl = _lib.split_planes(r) if r is not None else (None, None)
+    try:
+        _force16(cfg)
+        y32 = _lib.conv2d_nhwc_16(xh, wh, b, "relu", rh, stride=s, x_lo=xl, weight_lo=wl, residual_lo=rl, out_f32=True)
+        yh, yl = _lib.conv2d_nhwc_16(xh, wh, b, "relu", rh, stride=s, x_lo=xl, weight_lo=wl, residual_lo=rl)
+    finally:
+        _force16(0)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), s, k // 2)
+    bound = F.conv2d(x.double().abs(), wt.double().abs(), b.double().abs(), s, k // 2)
+    if r is not None:
+        ref, bound = ref + r.double(), bound + r.double().abs()
+    ref = F.relu(ref)
+    err = (y32.double() - ref).abs()
+    assert bool((err <= 2e-6 * bound + 1e-30).all()), float((err / bound).max())
+    merged = _lib.merge_planes(yh, yl)
+    assert float(((merged - y32).abs() / y32.abs().clamp_min(1e-6)).max()) <= 2.0 ** -20
+
+
+def test_the_default_route_picks_by_launch_size_and_stays_correct():
+    """the heuristic of launch16x over the launch sizes it distinguishes: one frame / one hundred crops / a full step"""
+    from tracklab_amd import _lib
+    for n in (1, 8, 300):
+        for shape in ((n, 192, 20, 20, 192, 3, 1, False), (n, 256, 24, 8, 1024, 1, 1, True), (n, 64, 96, 32, 64, 3, 1, False), (n, 1024, 24, 8, 512, 1, 1, False)):
+            x, wt, b, r, k, s = _inputs(shape, seed=n)
+            xh, wh = x.half(), wt.half()
+            rh = r.half() if r is not None else None
+            y = _lib.conv2d_nhwc_16(xh, wh, b, "silu", rh, stride=s)
+            ref = F.conv2d(xh.double(), wh.double(), b.double(), s, k // 2)
+            if r is not None:
+                ref = ref + rh.double()
+            ref = F.silu(ref)
+            assert bool(((y.double() - ref).abs() <= 2e-3 * ref.abs() + 2e-3).all()), shape

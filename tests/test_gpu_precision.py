@@ -81,7 +81,7 @@ def test_track_ids_identical_under_f16_and_f32_backbones():
 
 def _scaled_reid(dtype, scale, split=False, heavy_tail=False):
     """the random-init part-based ReID net with its stem weights multiplied by `scale` (ReLU networks are positively homogeneous up to their
-    biases: every later activation grows by about that factor) and, for heavy_tail, the per-channel scales a BatchNorm fold leaves behind
+    biases: every activation of the backbone grows by about that factor) and, for heavy_tail, the per-channel scales a BatchNorm fold leaves behind
     drawn log-uniform over four decades"""
     import torch
     from tracklab_amd.backbones.reid import part_based_reid
@@ -90,6 +90,9 @@ def _scaled_reid(dtype, scale, split=False, heavy_tail=False):
         stem = next(mod for mod in m.backbone.modules() if hasattr(mod, "conv") and mod.conv.in_channels == 3)
         stem.conv.weight.mul_(scale)
         stem.bias.mul_(scale)
+        # ... and the 1 x 1 reduction behind the backbone undoes it, so the HEAD sees the natural scale: scaled logits would turn the part softmax
+        # into an arg-max and amplify a 1e-3 relative difference into flipped attention maps -- a temperature effect, not a precision one
+        m.reduce.conv.weight.div_(scale)
         if heavy_tail:
             # per-channel scales log-uniform over four decades on every bottleneck's 3 x 3 output, undone on the input channels of the 1 x 1
             # expansion that follows (ReLU commutes with a positive scale): the FUNCTION is unchanged, the intermediate tensors are heavy-tailed
@@ -107,57 +110,66 @@ def _scaled_reid(dtype, scale, split=False, heavy_tail=False):
 
 def test_precision_envelope_of_the_f16_and_split_legs():
     """WHERE do the narrower legs stop being admissible?  The stem of the (random-init) ReID net is scaled so that
-    the layer-4 activations reach ~1e2 ... ~3e5; per scale: largest |activation| entering the head, f16 and split-precision embeddings against
-    the exact-fp32 run's (max per-part cosine distance), finiteness.  Stated envelope (from this table):
-      * f16:   cosine distance <= 1e-5 while max |activation| <= ~3e4 (relative error is scale-free until the range ends); beyond 65504 the
-               output is NOT finite;
+    the LARGEST activation anywhere in the backbone (every convolution's output, fp32 run) reaches ~1e3 ... ~3e5; per scale: that maximum, the
+    f16 and split-precision embeddings against the exact-fp32 run's (max per-part cosine distance), finiteness.  Stated envelope (DESIGN.md
+    section 2, from this table):
+      * f16:   cosine distance <= 1e-5 while every activation stays inside float16's range (relative error is scale-free until the range ends
+               at 65504); beyond it an activation saturates to infinity and the embeddings are NOT finite;
       * split: fp32-class (<= 1e-6) over the same range; the (hi, lo) pair saturates at the same 65504;
-      * past the range the pipeline raises TlkError (gpu_pipeline: check_finite) instead of tracking on infinities."""
+      * past the range nothing is silently wrong: ReLU lets NaN through (r05: it used to turn the NaN of inf - inf into 0, and a saturated net
+        produced finite garbage) and the pipeline raises TlkError (gpu_pipeline: check_finite) instead of tracking on infinities."""
     import json
     import torch
+    from tracklab_amd.backbones.common import ConvBiasAct
     x32 = _crops(torch.float32, 24)
     x16 = x32.half()
-    acts = {}
 
-    def run(m, x):
-        h = m.backbone.register_forward_hook(lambda mod, i, o: acts.__setitem__("a", (o.hi if hasattr(o, "hi") else o).detach().float().abs().max().item()))
+    def run(m, x, track=False):
+        peak = [0.0]
+        hooks = []
+        if track:
+            def hook(mod, i, o):
+                t = o.hi if hasattr(o, "hi") else o
+                peak[0] = max(peak[0], float(t.detach().float().abs().max()))
+            hooks = [mod.register_forward_hook(hook) for mod in m.backbone.modules() if isinstance(mod, ConvBiasAct)]
         try:
             with torch.no_grad():
                 e, v = m(x)
         finally:
-            h.remove()
-        return e.float(), acts["a"]
+            for h in hooks:
+                h.remove()
+        return e.float(), peak[0]
 
-    base_act = run(_scaled_reid(torch.float32, 1.0), x32)[1]
+    def cosd(e, ref):
+        if not torch.isfinite(e).all():
+            return float("inf")
+        a, b = torch.nn.functional.normalize(e, dim=-1), torch.nn.functional.normalize(ref, dim=-1)
+        return (1 - (a * b).sum(-1)).abs().max().item()
+
+    base_peak = run(_scaled_reid(torch.float32, 1.0), x32, track=True)[1]
     table = []
-    for target in (1e2, 1e3, 1e4, 3e4, 1.2e5, 3e5):
-        sc = target / base_act
-        e32, a32 = run(_scaled_reid(torch.float32, sc), x32)
+    for target in (1e3, 1e4, 3e4, 5e4, 1.5e5, 4e5):
+        sc = target / base_peak
+        e32, a32 = run(_scaled_reid(torch.float32, sc), x32, track=True)
         e16, _ = run(_scaled_reid(torch.float16, sc), x16)
         esp, _ = run(_scaled_reid(torch.float32, sc, split=True), x32)
-
-        def cosd(e):
-            if not torch.isfinite(e).all():
-                return float("inf")
-            a, b = torch.nn.functional.normalize(e, dim=-1), torch.nn.functional.normalize(e32, dim=-1)
-            return (1 - (a * b).sum(-1)).abs().max().item()
-        table.append({"max_activation_f32": a32, "f16_cos": cosd(e16), "split_cos": cosd(esp), "f32_finite": bool(torch.isfinite(e32).all())})
+        table.append({"max_activation_f32": a32, "f16_cos": cosd(e16, e32), "split_cos": cosd(esp, e32), "f32_finite": bool(torch.isfinite(e32).all())})
     # heavy-tailed intermediate tensors at the natural scale: channels of one tensor spread over four decades (what BatchNorm folding can leave)
-    e32h, a32h = run(_scaled_reid(torch.float32, 1.0, heavy_tail=True), x32)
+    e32h, a32h = run(_scaled_reid(torch.float32, 1.0, heavy_tail=True), x32, track=True)
     e16h, _ = run(_scaled_reid(torch.float16, 1.0, heavy_tail=True), x16)
     esph, _ = run(_scaled_reid(torch.float32, 1.0, split=True, heavy_tail=True), x32)
-    e32 = e32h
-    heavy = {"heavy_tailed_channels": True, "max_activation_f32": a32h, "f16_cos": cosd(e16h), "split_cos": cosd(esph)}
+    heavy = {"heavy_tailed_channels": True, "max_activation_f32": a32h, "f16_cos": cosd(e16h, e32h), "split_cos": cosd(esph, e32h)}
     print("precision envelope, heavy-tailed per-channel scales (1e-2 .. 1e2 inside every bottleneck):", json.dumps(heavy))
     assert heavy["f16_cos"] <= 1e-4 and heavy["split_cos"] <= 1e-6, heavy
-    print("precision envelope (layer-4 |activation| max, f16 cosine distance, split cosine distance):")
+    print("precision envelope (largest |activation| of the backbone, f16 cosine distance, split cosine distance), natural peak %.3g:" % base_peak)
     print(json.dumps(table))
-    inside = [t for t in table if t["max_activation_f32"] <= 3.3e4]
-    outside = [t for t in table if t["max_activation_f32"] >= 1.0e5]
-    assert len(inside) >= 3 and len(outside) >= 1
+    inside = [t for t in table if t["max_activation_f32"] <= 5.5e4]
+    outside = [t for t in table if t["max_activation_f32"] >= 1.2e5]
+    assert len(inside) >= 4 and len(outside) >= 2
     assert all(t["f32_finite"] for t in table)
-    assert all(t["f16_cos"] <= EMB_COS_TOL and t["split_cos"] <= 1e-6 for t in inside), table
-    assert all(t["f16_cos"] == float("inf") for t in outside), "f16 is expected to saturate past its range: the envelope is the range"
+    # (at the 5e4 point the test's own 1 / scale on the reduction weights pushes them into float16's subnormals: 1.2e-5 there is the experiment, not the range)
+    assert all(t["f16_cos"] <= (EMB_COS_TOL if t["max_activation_f32"] <= 3.3e4 else 2e-5) and t["split_cos"] <= 1e-6 for t in inside), table
+    assert all(t["f16_cos"] == float("inf") and t["split_cos"] == float("inf") for t in outside), "past float16's range the output must be NON-finite, never finite garbage"
 
 
 def test_saturated_embeddings_fail_loudly_in_the_pipeline():
@@ -177,7 +189,7 @@ def test_saturated_embeddings_fail_loudly_in_the_pipeline():
         pipe.synchronize()                                   # in range: fine
         with torch.no_grad():
             stem = next(mod for mod in pipe.reid.backbone.modules() if hasattr(mod, "conv") and mod.conv.in_channels == 3)
-            stem.conv.weight.mul_(3e4)
+            stem.conv.weight.mul_(1e5)
         pipe.step(frame, head)
         with pytest.raises(_lib.TlkError, match="not finite"):
             pipe.synchronize()

@@ -76,3 +76,25 @@ def test_pose_final_layer_as_one_gemm(dtype, tol):
         ref = net.final_layer(f).flatten(2)
     assert got.shape == ref.shape == (5, 17, 48)
     assert (got.float() - ref.float()).abs().max().item() <= tol * ref.float().abs().max().item()
+
+
+@pytest.mark.parametrize("dtype_name", ["float32", "float16"])
+@pytest.mark.parametrize("shape,k,s,p", [((3, 64, 192, 64), 3, 2, 1), ((2, 16, 7, 5), 3, 2, 1), ((2, 8, 9, 9), 2, 2, 0), ((1, 32, 6, 11), 5, 1, 2)])
+def test_maxpool2d_equals_torch_bit_for_bit(shape, k, s, p, dtype_name):
+    """tlk_maxpool2d_nhwc (r05): ResNet-50's stem pool in one hand-written pass; max is exact -> torch.equal.  With a dynamic batch set, the
+    images beyond the live count are not written."""
+    import torch
+    import torch.nn.functional as F
+    from tracklab_amd import _lib
+    dt = getattr(torch, dtype_name)
+    x = torch.randn(shape, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
+    y = _lib.maxpool2d_nhwc(x, k, s, p)
+    assert torch.equal(y, F.max_pool2d(x, k, s, p))
+    live = torch.tensor([1], dtype=torch.int32, device="cuda")
+    out = torch.full_like(y, -5.0)
+    _lib.conv_set_dynamic_batch(live)
+    try:
+        _lib.maxpool2d_nhwc(x, k, s, p, out=out)
+    finally:
+        _lib.conv_set_dynamic_batch(None)
+    assert torch.equal(out[:1], y[:1]) and bool((out[1:] == -5.0).all())

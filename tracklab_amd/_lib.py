@@ -1091,6 +1091,24 @@ def spp_maxpool_nhwc(x, out=None):
     return out
 
 
+def maxpool2d_nhwc(x, k=3, stride=2, pad=1, out=None):
+    """k x k max pooling (stride, -inf padding) of a channels_last (N, C, H, W) float32 / float16 tensor in ONE hand-written pass
+    (tlk_maxpool2d_nhwc); C a multiple of 16 bytes of elements."""
+    import torch
+    L = lib()
+    if not getattr(L, "_maxpool_bound", False):
+        L.tlk_maxpool2d_nhwc.argtypes = [C.c_void_p] * 2 + [C.c_int] * 10 + [C.c_void_p]
+        L._maxpool_bound = True
+    N, Cc, H, W = x.shape
+    assert x.dtype in (torch.float32, torch.float16)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if out is None:
+        out = torch.empty((N, Cc, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    check(L.tlk_maxpool2d_nhwc(x.data_ptr(), out.data_ptr(), N, H, W, Cc, k, stride, pad, _dtype_code(x.dtype), _pix16(x, Cc, H, W),
+                               _pix16(out, Cc, Ho, Wo), current_stream_ptr()))
+    return out
+
+
 def _bind_conv16(L):
     if not getattr(L, "_conv16_bound", False):
         L.tlk_conv2d_nhwc_16.argtypes = [C.c_void_p] * 10 + [C.c_int] * 13 + [C.c_void_p]

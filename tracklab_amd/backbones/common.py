@@ -15,7 +15,9 @@ USE_FUSED_GEMM = _os.environ.get("TLK_FUSED_GEMM", "1") != "0"
 USE_TLK_CONV_F32 = _os.environ.get("TLK_CONV_F32", "1") != "0"
 # f16 convolutions with the epilogue inside on libtlk's 16-bit MFMA kernel (tlk_conv2d_nhwc_16, csrc/tlk_conv16.hip) instead of MIOpen / CK /
 # hipBLASLt + a separate epilogue pass; TLK_CONV_F16=0 restores the library route for A/B runs.
-USE_TLK_CONV_F16 = _os.environ.get("TLK_CONV_F16", "0") != "0"      # r04: measured 67 ms vs the library route's ~55 ms on the ReID forward -- opt-in until it wins
+# r05: ON by default -- the direct-to-LDS kernels of csrc/tlk_conv16x.hip win the A/B at 24 frames per step (417 vs 356 frames/s) and at 1 (219 vs
+# 200): profiles/r05_f16_route_ab.txt
+USE_TLK_CONV_F16 = _os.environ.get("TLK_CONV_F16", "1") != "0"
 # ... except the narrow 1 x 1 convolutions (Cin, Cout <= 96: CSPNeXt / CSPDarknet stage 1-2 pointwise layers, HBM-bound), where the kernel with
 # the epilogue inside beats GEMM + library epilogue (RTMPose-m, 2400 crops: 0.68 vs 1.02 ms at 48 -> 48); TLK_CONV_F16_NARROW=0 opts out
 USE_TLK_CONV_F16_NARROW = _os.environ.get("TLK_CONV_F16_NARROW", "1") != "0"

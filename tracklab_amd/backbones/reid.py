@@ -14,6 +14,9 @@ import torch.nn as nn
 
 from .common import ConvBiasAct, SplitAct, finalize, random_init_
 
+import os as _os
+USE_TLK_MAXPOOL = _os.environ.get("TLK_MAXPOOL", "1") != "0"       # 0: torch's max_pool2d (A/B runs)
+
 
 class _Bottleneck(nn.Module):
     def __init__(self, cin, planes, stride=1, down=False):
@@ -128,6 +131,9 @@ class _ResNet50(nn.Module):
         x = self.conv1(x)
         if isinstance(x, SplitAct):            # split-precision route: the max-pool runs on the merged fp32 tensor (exact: max commutes with the split)
             x = SplitAct.from_f32(self.pool(x.merge()))
+        elif USE_TLK_MAXPOOL and x.is_cuda and x.dtype in (torch.float32, torch.float16) and x.is_contiguous(memory_format=torch.channels_last):
+            from .. import _lib
+            x = _lib.maxpool2d_nhwc(x, 3, 2, 1)            # r05: one hand-written pass (torch's nhwc max-pool took 2.4-2.6 ms of a step)
         else:
             x = self.pool(x)
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))

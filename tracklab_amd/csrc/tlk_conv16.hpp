@@ -34,7 +34,7 @@ struct Conv16Args {
 #if defined(__HIPCC__)
 template <int ACT> __device__ __forceinline__ float act16(float v)
 {
-    if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ACT == ACT_RELU) return v < 0.f ? 0.f : v;          // (this form lets NaN through, like torch.relu: an overflow upstream must stay visible, r05)
     if (ACT == ACT_SILU) return v / (1.f + __expf(-v));
     return v;
 }

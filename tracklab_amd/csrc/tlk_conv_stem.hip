@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) conv_stem3_kernel(const StemArgs p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[i][jj][r] + bias[jj];
-                    if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
+                    if (p.act == ACT_RELU) v = v < 0.f ? 0.f : v;
                     else if (p.act == ACT_SILU) v = v / (1.f + __expf(-v));
                     stg[((r & 3) + 8 * (r >> 2) + 4 * half) * OST + pl] = v;
                 }
