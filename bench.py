@@ -784,10 +784,18 @@ def main():
             # profiles/r04_config3_f32_rocprof.md to compare with
             tmpl = {0: "2, 2, 2, 2", 1: "2, 2, 4, 1", 2: "2, 1, 2, 2", 3: "2, 3, 4, 1", 4: "2, 1, 4, 1", 5: "1, 2, 2, 2", 6: "1, 2, 4, 1",
                     7: "2, 2, 2, 2", 8: "2, 1, 2, 2", 9: "1, 2, 2, 2"}
+            # 21..33: the direct-to-LDS kernels of tlk_conv16x.hip on fp32 tensors, conv16x_kernel<WGM, WGN, TM, TN, MODE_F32 = 2, NST, RESPF, PATCH>
+            # (activation and residual are run-time switches there: one row per instantiation)
+            tmpl_x = {21: "2, 2, 2, 2, 2, 1, true, false", 22: "2, 2, 2, 2, 2, 1, false, false", 23: "4, 1, 2, 2, 2, 1, false, false",
+                      24: "2, 2, 2, 2, 2, 2, true, false", 25: "2, 2, 1, 2, 2, 1, true, false", 26: "4, 1, 2, 2, 2, 1, true, false",
+                      27: "4, 1, 2, 1, 2, 1, true, false", 28: "4, 1, 2, 1, 2, 2, true, false", 29: "4, 1, 4, 1, 2, 1, true, false",
+                      30: "4, 1, 2, 1, 2, 1, true, true", 31: "4, 1, 2, 1, 2, 1, false, true", 32: "4, 1, 1, 1, 2, 1, true, true",
+                      33: "2, 1, 2, 1, 2, 1, true, true"}
             per = {}
             for r in recs:
                 cfg_, act_, res_ = r[5]
                 kn_ = "conv_stem3_kernel (direct RGB stem, tlk_conv_stem.hip)" if cfg_ == 15 else \
+                    f"conv16x_kernel<{tmpl_x[cfg_]}>" if cfg_ in tmpl_x else \
                     f"conv_f32_mfma_kernel<{tmpl.get(cfg_, '?')}, {act_}, {'true' if res_ else 'false'}, {1 if cfg_ in (7, 8, 9) else 2}>"
                 e = per.setdefault(kn_, [0, 0.0, 0.0])
                 e[0] += 1; e[1] += r[0].elapsed_time(r[1]) - r[2].elapsed_time(r[3]); e[2] += r[4]

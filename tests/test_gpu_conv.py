@@ -113,6 +113,55 @@ def test_direct_to_lds_fp32_kernels_are_bit_exact_with_the_oracle_chain(case, cf
     assert np.array_equal(got, exp), f"max |diff| {np.abs(got - exp).max()}"
 
 
+@pytest.mark.parametrize("cfg", [27, 28, 29])
+@pytest.mark.parametrize("case", X32_CASES[:3] + [(3, 9, 9, 64, 32, 3, 1, "relu", True)])
+def test_32_wide_direct_to_lds_fp32_tiles_are_bit_exact_with_the_oracle_chain(case, cfg):
+    got, exp = _run(case, cfg)
+    assert got.shape == exp.shape
+    assert np.array_equal(got, exp), f"max |diff| {np.abs(got - exp).max()}"
+
+
+PATCH_CASES = [
+    # 3 x 3 / stride 1 / pad 1 on 32 channels, whole image rows per 256- (128-) pixel tile: Wo = 32, 16, 64, 8; with / without residual
+    (3, 16, 32, 32, 32, 3, 1, "relu", True),
+    (2, 32, 16, 32, 64, 3, 1, None, False),
+    (2, 8, 64, 32, 32, 3, 1, "relu", False),
+    (1, 64, 8, 32, 36, 3, 1, "relu", True),           # Cout ragged against the 32-wide tile
+]
+
+
+@pytest.mark.parametrize("cfg", [30, 31, 32, 33])
+@pytest.mark.parametrize("case", PATCH_CASES)
+def test_patch_resident_3x3_kernel_is_bit_exact_with_the_oracle_chain(case, cfg):
+    """r05, conv16x_kernel<..., PATCH = true>: the tile's input rows + halo land in LDS once and the nine taps are nine shifted fragment
+    reads; the k order (kh, kw, ci) and the fmaf chain are the implicit GEMM's, so the bits are oracle/src/conv.c's"""
+    got, exp = _run(case, cfg)
+    assert got.shape == exp.shape
+    assert np.array_equal(got, exp), f"max |diff| {np.abs(got - exp).max()}"
+
+
+def test_patch_kernel_refuses_a_shape_outside_its_contract_and_the_heuristic_routes_the_32_channel_layers_to_it():
+    from tracklab_amd import _lib
+    L = _lib.lib()
+    x = torch.randn(2, 24, 20, 32, device="cuda").permute(0, 3, 1, 2)          # Wo = 20: 256 % 20 != 0
+    w = (torch.randn(32, 3, 3, 32, device="cuda") * 0.1).permute(0, 3, 1, 2)
+    assert L.tlk_conv2d_set_config(31) == 0
+    try:
+        with pytest.raises(_lib.TlkError, match="patch kernel"):
+            _lib.conv2d_nhwc_f32(x, w, None, "relu", None, stride=1)
+    finally:
+        L.tlk_conv2d_set_config(-1)
+    x = torch.randn(32, 96, 32, 32, device="cuda").permute(0, 3, 1, 2)          # HRNet-W32's high-resolution branch: 32 crops x 96 x 32 = 98304 pixels
+    y = _lib.conv2d_nhwc_f32(x, w, None, "relu", None, stride=1)
+    assert L.tlk_conv2d_last_config() == 31
+    L.tlk_conv2d_set_config(0)
+    try:
+        y0 = _lib.conv2d_nhwc_f32(x, w, None, "relu", None, stride=1)
+    finally:
+        L.tlk_conv2d_set_config(-1)
+    assert torch.equal(y, y0)
+
+
 @pytest.mark.parametrize("case", [(2, 24, 16, 3, 64, 7, 2, "relu", False), (3, 17, 13, 3, 32, 3, 2, "relu", False), (1, 40, 130, 3, 48, 3, 2, None, False),
                                   (2, 9, 70, 3, 64, 7, 2, "relu", False)])
 def test_direct_rgb_stem_kernel_is_bit_exact_with_the_oracle_on_the_padded_problem(case):

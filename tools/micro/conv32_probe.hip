@@ -117,36 +117,48 @@ int main(int argc, char **argv)
             CK(hipFree(x3)); CK(hipFree(x4)); CK(hipFree(w3)); CK(hipFree(w4)); CK(hipFree(ya)); CK(hipFree(yb));
         }
     }
-    if (!strcmp(what, "all") || !strcmp(what, "exp")) {
-        struct Exp { const char *name; int H, W, Cin, Cout, res; } exps[] = {
+    if (!strcmp(what, "all") || !strcmp(what, "exp") || !strcmp(what, "hrnet")) {
+        struct Exp { const char *name; int H, W, Cin, Cout, res, k; };
+        const Exp hr[] = {{"hr 3x3 32>32 @96x32", 96, 32, 32, 32, 0, 3}, {"hr 3x3 32>32 +res", 96, 32, 32, 32, 1, 3}, {"hr 3x3 64>64 @48x16", 48, 16, 64, 64, 0, 3},
+                          {"hr 3x3 64>64 +res", 48, 16, 64, 64, 1, 3}, {"hr 3x3 128>128 @24x8", 24, 8, 128, 128, 1, 3}, {"hr 3x3 256>256 @12x4", 12, 4, 256, 256, 1, 3},
+                          {"hr 1x1 64>32 @48x16", 48, 16, 64, 32, 0, 1}, {"hr 3x3 s2 32>64", 96, 32, 32, 64, 0, 3}};
+        const Exp exps_[] = {
             {"l1 1x1 64>256 +res", 96, 32, 64, 256, 1}, {"l2 1x1 128>512 +res", 48, 16, 128, 512, 1}, {"l3 1x1 256>1024 +res", 24, 8, 256, 1024, 1},
             {"l4 1x1 512>2048 +res", 24, 8, 512, 2048, 1}, {"l1 1x1 256>64", 96, 32, 256, 64, 0}, {"l2 1x1 512>128", 48, 16, 512, 128, 0},
             {"l1 1x1 64>64", 96, 32, 64, 64, 0}, {"l2 1x1 256>128", 96, 32, 256, 128, 0}, {"l3 1x1 1024>256", 24, 8, 1024, 256, 0}, {"l4 1x1 2048>512", 24, 8, 2048, 512, 0}};
-        for (const Exp &E : exps) {
+        const bool hrnet = !strcmp(what, "hrnet");
+        const Exp *exps = hrnet ? hr : exps_;
+        const int nexp = hrnet ? (int)(sizeof(hr) / sizeof(hr[0])) : (int)(sizeof(exps_) / sizeof(exps_[0]));
+        for (int ei = 0; ei < nexp; ++ei) {
+            Exp E = exps[ei];
+            if (!hrnet) E.k = 1;
             const long long M = (long long)crops * E.H * E.W;
             float *x, *w, *r, *y;
-            CK(hipMalloc(&x, M * E.Cin * 4)); CK(hipMalloc(&w, (size_t)E.Cout * E.Cin * 4)); CK(hipMalloc(&r, M * E.Cout * 4)); CK(hipMalloc(&y, M * E.Cout * 4));
-            fill_kernel<<<2048, 256>>>(x, M * E.Cin, 1.0f, 31); fill_kernel<<<64, 256>>>(w, (long long)E.Cout * E.Cin, 0.1f, 32); fill_kernel<<<2048, 256>>>(r, M * E.Cout, 1.0f, 33);
-            auto run = [&] { TK(tlk_conv2d_nhwc_f32(x, w, bias, E.res ? r : nullptr, y, crops, E.H, E.W, E.Cin, E.Cout, 1, 1, 1, 0, 1, 0, 0, 0, nullptr)); };
-            const double flops = 2.0 * M * E.Cout * E.Cin, bytes = (double)(M * E.Cin + M * E.Cout * (E.res ? 2 : 1) + E.Cout * E.Cin) * 4;
-            const int cfgs[] = {-1, 0, 2, 9, 21, 22, 23, 24, 25, 26};      // heuristic; 128 x 128 / 128 x 64 two-stage; 64 x 128 one-stage; the direct-to-LDS kernels
+            CK(hipMalloc(&x, M * E.Cin * 4)); CK(hipMalloc(&w, (size_t)E.Cout * E.Cin * E.k * E.k * 4)); CK(hipMalloc(&r, M * E.Cout * 4)); CK(hipMalloc(&y, M * E.Cout * 4));
+            fill_kernel<<<2048, 256>>>(x, M * E.Cin, 1.0f, 31); fill_kernel<<<64, 256>>>(w, (long long)E.Cout * E.Cin * E.k * E.k, 0.1f / E.k, 32); fill_kernel<<<2048, 256>>>(r, M * E.Cout, 1.0f, 33);
+            const int stride = strstr(E.name, " s2 ") ? 2 : 1, pad = E.k / 2;
+            const int Ho = (E.H + 2 * pad - E.k) / stride + 1, Wo = (E.W + 2 * pad - E.k) / stride + 1;
+            const long long Mo = (long long)crops * Ho * Wo;
+            auto run = [&] { TK(tlk_conv2d_nhwc_f32(x, w, bias, E.res ? r : nullptr, y, crops, E.H, E.W, E.Cin, E.Cout, E.k, E.k, stride, pad, 1, 0, 0, 0, nullptr)); };
+            const double flops = 2.0 * Mo * E.Cout * E.Cin * E.k * E.k, bytes = (double)(M * E.Cin + Mo * E.Cout * (E.res ? 2 : 1) + E.Cout * E.Cin * E.k * E.k) * 4;
+            const int cfgs[] = {-1, 0, 2, 4, 9, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33};      // heuristic; two-stage tiles; 64 x 128 one-stage; the direct-to-LDS kernels
             float *yref; CK(hipMalloc(&yref, M * E.Cout * 4));
             TK(tlk_conv2d_set_config(0)); run(); CK(hipMemcpy(yref, y, M * E.Cout * 4, hipMemcpyDeviceToDevice));
             for (int cfg : cfgs) {
                 if (cfg_only >= -1 && cfg != cfg_only) continue;
                 TK(tlk_conv2d_set_config(cfg));
                 CK(hipMemset(y, 0xff, M * E.Cout * 4));
-                if (tlk_conv2d_nhwc_f32(x, w, bias, E.res ? r : nullptr, y, crops, E.H, E.W, E.Cin, E.Cout, 1, 1, 1, 0, 1, 0, 0, 0, nullptr) != 0) {
+                if (tlk_conv2d_nhwc_f32(x, w, bias, E.res ? r : nullptr, y, crops, E.H, E.W, E.Cin, E.Cout, E.k, E.k, stride, pad, 1, 0, 0, 0, nullptr) != 0) {
                     printf("  %-26s cfg %2d  not applicable (%s)\n", E.name, cfg, tlk_last_error()); continue;
                 }
                 const float ms = time_ms(run, iters);
                 CK(hipMemset(dcount, 0, 8));
-                count_diff_kernel<<<1024, 256>>>((const unsigned *)y, (const unsigned *)yref, M * E.Cout, dcount);
+                count_diff_kernel<<<1024, 256>>>((const unsigned *)y, (const unsigned *)yref, Mo * E.Cout, dcount);
                 unsigned long long nd; CK(hipMemcpy(&nd, dcount, 8, hipMemcpyDeviceToHost));
                 printf("  %-26s cfg %2d  %8.3f ms  %6.1f TFLOP/s  %6.0f GB/s on %.2f GB algorithmic   bits differing from cfg 0: %llu%s\n", E.name, cfg, ms, flops / ms / 1e9,
                        bytes / ms / 1e6, bytes / 1e9, nd, nd ? "  <-- MISMATCH" : "");
                 fflush(stdout);
-                if (nd) { CK(hipMemset(dcount, 0, 8)); show_diff_kernel<<<64, 256>>>(y, yref, M * E.Cout, E.Cout, dcount, x, w, bias, E.res ? r : nullptr, E.Cin); CK(hipDeviceSynchronize()); }
+                if (nd && E.k == 1) { CK(hipMemset(dcount, 0, 8)); show_diff_kernel<<<64, 256>>>(y, yref, M * E.Cout, E.Cout, dcount, x, w, bias, E.res ? r : nullptr, E.Cin); CK(hipDeviceSynchronize()); }
             }
             CK(hipFree(yref));
             TK(tlk_conv2d_set_config(-1));

@@ -358,12 +358,22 @@ template <int TM, int TN, int WGM, int WGN, int NST = 2> int launch_cfg(ConvArgs
 // which layers the direct-to-LDS kernels take by default (0 = none): filled in from the probe's table (profiles/r05_conv_f32_shapes.txt)
 int pick_x32(const ConvArgs &a, int cout, bool has_res)
 {
-    // measured (tools/micro/conv32_probe, 2400 crops): the one-stage 64 x 128 tile with the residual prefetched takes the short-K expansions
-    // (K <= 128: 4.05 vs 4.5 ms and 2.87 vs 3.13 ms), the one-stage 256 x 64 tile the 64-wide 1 x 1 layers (0.92 vs 1.06 ms); every other
-    // layer is as fast or faster on conv_f32_mfma_kernel
-    if (a.KH != 1 || a.KW != 1 || a.stride != 1) return 0;
-    if (has_res && a.K <= 128 && cout % 128 == 0 && a.M >= 256 * 1024) return 5;
-    if (!has_res && cout == 64 && a.K <= 256 && a.M >= 256 * 1024) return 3;
+    // measured (tools/micro/conv32_probe: 2400 crops of ResNet-50, 2211 of HRNet-W32; profiles/r05_conv_f32_shapes.txt)
+    const bool big = a.M >= 256 * 1024;
+    //  * 3 x 3 / stride 1 on 32 channels (HRNet's high-resolution branch): the PATCH kernel -- the tile's input rows land in LDS once instead of
+    //    once per tap: 1.07 vs 1.82 ms (117 vs 69 TFLOP/s), 1.13 vs 2.02 ms with a residual
+    if (a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin == 32 && a.H == a.Ho && a.W == a.Wo && a.Wo >= 8 && a.Wo <= 64 && 256 % a.Wo == 0 &&
+        ((long long)a.Ho * a.Wo) % 256 == 0 && a.M >= 64 * 1024)
+        return 11;
+    //  * other layers that are 32 wide: the one-stage 256 x 32 tile (1 x 1 64 > 32: 0.14 vs 0.21 ms)
+    if (cout == 32 && a.M >= 64 * 1024) return 7;
+    //  * 64 wide: the one-stage 256 x 64 tile on the 1 x 1 layers (0.92 vs 1.06 ms) and the 3 x 3 ones (1.08 vs 1.11 ms; stride 2: 0.63 vs 0.68)
+    if (cout == 64 && big && ((a.KH == 1 && !has_res && a.K <= 256) || (a.KH == 3 && a.K <= 576))) return 3;
+    //  * the short-K 1 x 1 expansions (K <= 128): the one-stage 64 x 128 tile with the residual prefetched (4.05 vs 4.5 ms, 2.87 vs 3.13 ms)
+    if (a.KH == 1 && a.KW == 1 && a.stride == 1 && has_res && a.K <= 128 && cout % 128 == 0 && big) return 5;
+    //  * 3 x 3 basic blocks on 128 / 256 channels with a residual: 128 x 128, two stages, residual prefetched (0.95 vs 0.98 ms, 0.99 vs 1.02 ms)
+    if (a.KH == 3 && a.stride == 1 && has_res && cout % 128 == 0 && a.K >= 1152 && ((a.M + 127) / 128) * (cout / 128) >= 1024) return 4;
+    // every other layer is as fast or faster on conv_f32_mfma_kernel
     return 0;
 }
 
@@ -375,7 +385,7 @@ int g_last_cfg = -1;      // configuration of the most recent launch (tlk_conv2d
 
 extern "C" int tlk_conv2d_set_config(int cfg)
 {
-    if (cfg < -1 || (cfg > 9 && (cfg < 21 || cfg > 26))) return fail(TLK_EINVAL, "tlk_conv2d_set_config: cfg must be -1 (heuristic), 0..9, or 21..26 (the direct-to-LDS kernels of tlk_conv16x.hip on fp32 tensors)");
+    if (cfg < -1 || (cfg > 9 && (cfg < 21 || cfg > 33))) return fail(TLK_EINVAL, "tlk_conv2d_set_config: cfg must be -1 (heuristic), 0..9, or 21..33 (the direct-to-LDS kernels of tlk_conv16x.hip on fp32 tensors)");
     g_force_cfg = cfg;
     return TLK_OK;
 }
