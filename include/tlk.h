@@ -718,6 +718,21 @@ int tlk_spp_maxpool_nhwc(const void *x_dev, void *y_dev, int n, int h, int w, in
 int tlk_maxpool2d_nhwc(const void *x_dev, void *y_dev, int n, int h, int w, int c, int k, int stride, int pad, int dtype, int x_pix_stride,
                        int y_pix_stride, void *hip_stream);
 
+/* r05: the RGB stem of a backbone in f16 -- Cin = 3, 7 x 7 (ResNet-50) or 3 x 3 (HRNet-W32, RTMPose), stride 2, Cout <= 64 and a multiple of 8 --
+ * as ONE direct kernel on v_mfma_f32_32x32x16_f16 with bias + activation inside and, with `pool` != 0, the 3 x 3 / stride 2 / pad 1 max-pool
+ * that follows ResNet-50's stem fused behind it (torchreid's resnet.py conv1 -> bn1 -> relu -> maxpool, behind
+ * tracklab/wrappers/reid/kpreid_api.py:147-182): the full-resolution map is never written.  Same arithmetic as tlk_conv2d_nhwc_16's f16 mode
+ * (f16 operands, fp32 accumulation, fp32 bias, result rounded to f16; max commutes with the rounding, so the fused pool equals the two-pass one).
+ *   x  (n, h, w) pixels of x_pix_stride halfs (0 = 3), channels 0..2 used;
+ *   y  `pool` ? (n, (ho - 1) / 2 + 1, (wo - 1) / 2 + 1, cout) : (n, ho, wo, cout), y_pix_stride halfs per pixel (0 = cout), 16-byte aligned;
+ *   packed_w: the (cout, kh, kw, 3) f16 weight in MFMA fragment order, tlk_conv_stem16_packed_halfs(...) halfs long, written by
+ *      tlk_conv_stem16_pack (once per weight version: the caller caches it).
+ * `pool` needs wo <= 64 (one column strip).  Honours tlk_conv_set_dynamic_batch.  TLK_EINVAL names the violated constraint. */
+long long tlk_conv_stem16_packed_halfs(int cout, int kh, int kw, int stride);
+int tlk_conv_stem16_pack(const void *w_dev, void *packed_dev, int cout, int kh, int kw, int stride, void *hip_stream);
+int tlk_conv_stem16_nhwc(const void *x_dev, const void *packed_w_dev, const float *bias_dev, void *y_dev, int n, int h, int w, int cout, int kh, int kw,
+                         int stride, int pad, int act, int pool, int x_pix_stride, int y_pix_stride, void *hip_stream);
+
 /* 1x1 convolution of a channels-last tensor as ONE GEMM with the convolution epilogue inside:
  *   out[M,N] = act(x[M,K] . w[N,K]^T + bias[N] (+ residual[M,N])),  act 0 none / 1 ReLU / 2 SiLU, dtype TLK_F16 or TLK_BF16.
  * hipBLASLt (library GEMM, taken from the process with dlopen) with its BIAS / RELU_BIAS / SWISH_BIAS epilogue and beta*C for

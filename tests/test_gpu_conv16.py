@@ -188,3 +188,63 @@ def test_the_default_route_picks_by_launch_size_and_stays_correct():
                 ref = ref + rh.double()
             ref = F.silu(ref)
             assert bool(((y.double() - ref).abs() <= 2e-3 * ref.abs() + 2e-3).all()), shape
+
+
+STEM16_CASES = [
+    # n, h, w, cout, k, act, pool
+    (3, 384, 128, 64, 7, "relu", True),         # the ReID crops: 192 x 64 map -> 96 x 32 pooled
+    (2, 41, 27, 64, 7, "relu", True),           # ragged: odd map sizes, strips beyond the image, columns beyond Wo
+    (2, 50, 128, 32, 7, None, True),            # one cout tile, no activation (negative values through the pool's -inf padding)
+    (2, 37, 301, 64, 7, "relu", False),         # no pool: several column strips
+    (3, 64, 48, 32, 3, "silu", False),          # 3 x 3 stem (RTMPose / HRNet)
+    (1, 256, 192, 64, 3, "relu", False),
+    (2, 30, 22, 48, 3, "relu", True),
+]
+
+
+@pytest.mark.parametrize("case", STEM16_CASES)
+def test_f16_rgb_stem_kernel_matches_the_two_pass_route(case):
+    """r05, csrc/tlk_conv_stem16.hip: stem convolution + bias + activation (+ fused 3 x 3 / 2 max-pool) against fp32 arithmetic on the same
+    f16-rounded operands, result rounded to f16 before the pool (max commutes with the rounding): one f16 ulp of slack"""
+    import torch.nn.functional as F
+    from tracklab_amd import _lib
+    n, h, w, cout, k, act, pool = case
+    g = torch.Generator(device="cpu").manual_seed(k * 1000 + cout + h)
+    x = torch.randn(n, h, w, 3, generator=g).half().cuda().permute(0, 3, 1, 2)
+    wt = (torch.randn(cout, k, k, 3, generator=g) * 0.1).half().cuda().permute(0, 3, 1, 2)
+    b = torch.randn(cout, generator=g).cuda()
+    ref = F.conv2d(x.float(), wt.float(), b, stride=2, padding=k // 2)
+    ref = torch.relu(ref) if act == "relu" else (F.silu(ref) if act == "silu" else ref)
+    ref = ref.half().float()
+    if pool:
+        ref = F.max_pool2d(ref, 3, 2, 1)
+    packed = _lib.conv_stem16_pack(wt)
+    y = _lib.conv_stem16(x, packed, cout, k, b, act, pool=pool)
+    assert y.shape == ref.shape and y.dtype == torch.float16 and y.is_contiguous(memory_format=torch.channels_last)
+    err = (y.float() - ref).abs()
+    tol = 2e-3 * ref.abs() + 2e-3
+    assert bool((err <= tol).all()), f"max err {float(err.max())} at {int(err.argmax())}"
+
+
+def test_f16_stem_honours_the_dynamic_batch_and_the_resnet_module_uses_it():
+    from tracklab_amd import _lib
+    from tracklab_amd.backbones import reid
+    x = torch.randn(5, 64, 32, 3).half().cuda().permute(0, 3, 1, 2)
+    wt = (torch.randn(64, 7, 7, 3) * 0.1).half().cuda().permute(0, 3, 1, 2)
+    packed = _lib.conv_stem16_pack(wt)
+    full = _lib.conv_stem16(x, packed, 64, 7, None, "relu", pool=True)
+    live = torch.tensor([3], dtype=torch.int32, device="cuda")
+    out = torch.full_like(full, -3.0)
+    _lib.conv_set_dynamic_batch(live)
+    try:
+        _lib.conv_stem16(x, packed, 64, 7, None, "relu", pool=True, out=out)
+    finally:
+        _lib.conv_set_dynamic_batch(None)
+    assert torch.equal(out[:3], full[:3]) and bool((out[3:] == -3.0).all())
+    net = reid._ResNet50().cuda().half().eval().to(memory_format=torch.channels_last)
+    xin = torch.randn(2, 128, 64, 3).half().cuda().permute(0, 3, 1, 2)
+    with torch.no_grad():
+        y = net.conv1.stem16(xin, pool=True)
+        ref = torch.nn.functional.max_pool2d(torch.relu(torch.nn.functional.conv2d(xin.float(), net.conv1.conv.weight.float(), net.conv1.bias.float(), stride=2, padding=3)).half().float(), 3, 2, 1)
+    assert y is not None and y.shape == ref.shape
+    assert bool(((y.float() - ref).abs() <= 2e-3 * ref.abs() + 2e-3).all())

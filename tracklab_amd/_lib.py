@@ -1109,6 +1109,45 @@ def maxpool2d_nhwc(x, k=3, stride=2, pad=1, out=None):
     return out
 
 
+def conv_stem16_pack(weight):
+    """(Cout, 3, KH, KW) float16 stem weight -> the fragment-order buffer tlk_conv_stem16_nhwc multiplies from (tlk_conv_stem16_pack).  The caller
+    caches the result per weight version."""
+    import torch
+    L = lib()
+    if not getattr(L, "_stem16_bound", False):
+        L.tlk_conv_stem16_packed_halfs.restype = C.c_longlong
+        L.tlk_conv_stem16_packed_halfs.argtypes = [C.c_int] * 4
+        L.tlk_conv_stem16_pack.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
+        L.tlk_conv_stem16_nhwc.argtypes = [C.c_void_p] * 4 + [C.c_int] * 12 + [C.c_void_p]
+        L._stem16_bound = True
+    cout, cin, kh, kw = weight.shape
+    assert cin == 3 and weight.dtype == torch.float16 and weight.is_cuda
+    nh = L.tlk_conv_stem16_packed_halfs(cout, kh, kw, 2)
+    if nh < 0:
+        check(int(nh))
+    w = weight.detach().permute(0, 2, 3, 1).contiguous()                # (Cout, KH, KW, 3)
+    packed = torch.empty(int(nh), dtype=torch.float16, device=weight.device)
+    check(L.tlk_conv_stem16_pack(w.data_ptr(), packed.data_ptr(), cout, kh, kw, 2, current_stream_ptr()))
+    return packed
+
+
+def conv_stem16(x, packed_weight, cout, k, bias32=None, act=None, pool=False, out=None):
+    """RGB stem in f16 (tlk_conv_stem16_nhwc): k x k / stride 2 / pad k // 2 convolution of a channels_last (N, 3, H, W) float16 tensor + bias +
+    activation, with ResNet's 3 x 3 / stride 2 / pad 1 max-pool fused behind it when `pool`.  Returns channels_last float16."""
+    import torch
+    L = lib()
+    N, Cc, H, W = x.shape
+    assert Cc == 3 and x.dtype == torch.float16 and x.is_cuda
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // 2 + 1, (W + 2 * pad - k) // 2 + 1
+    oh, ow = ((Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1) if pool else (Ho, Wo)
+    if out is None:
+        out = torch.empty((N, cout, oh, ow), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    check(L.tlk_conv_stem16_nhwc(x.data_ptr(), packed_weight.data_ptr(), bias32.data_ptr() if bias32 is not None else None, out.data_ptr(), N, H, W, cout,
+                                 k, k, 2, pad, ACT[act], 1 if pool else 0, _pix16(x, 3, H, W), _pix16(out, cout, oh, ow), current_stream_ptr()))
+    return out
+
+
 def _bind_conv16(L):
     if not getattr(L, "_conv16_bound", False):
         L.tlk_conv2d_nhwc_16.argtypes = [C.c_void_p] * 10 + [C.c_int] * 13 + [C.c_void_p]

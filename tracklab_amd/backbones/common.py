@@ -116,6 +116,25 @@ class ConvBiasAct(nn.Module):
             self._w_split = c
         return c[1]
 
+    def stem16(self, x, pool=False):
+        """r05: the RGB stem in f16 as one direct kernel (csrc/tlk_conv_stem16.hip), with ResNet's max-pool fused behind it when `pool`; None when
+        this layer / tensor is not one it takes (the caller goes on as before)"""
+        ks, st = self.conv.kernel_size, self.conv.stride
+        if not (USE_TLK_STEM and USE_TLK_CONV_F16 and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float16 and x.shape[1] == 3
+                and ks in ((7, 7), (3, 3)) and st == (2, 2) and self.conv.padding == (ks[0] // 2, ks[0] // 2) and self.conv.out_channels <= 64
+                and self.conv.out_channels % 8 == 0 and self.conv.weight.dtype == torch.float16
+                and x.is_contiguous(memory_format=torch.channels_last)):
+            return None
+        if pool and (x.shape[3] + 2 * (ks[0] // 2) - ks[0]) // 2 + 1 > 64:
+            return None
+        from .. import _lib
+        c = getattr(self, "_w_stem16", None)
+        key = param_key(self.conv.weight, self.bias)
+        if c is None or c[0] != key:
+            c = (key, _lib.conv_stem16_pack(self.conv.weight), self.bias.detach().float())
+            self._w_stem16 = c
+        return _lib.conv_stem16(x, c[1], self.conv.out_channels, ks[0], c[2], self.act, pool=pool)
+
     def writes_slices(self, x):
         """True when forward(x, out=...) writes straight into `out` (a channel slice of a wider tensor): the libtlk convolution routes"""
         if not x.is_cuda or not x.is_contiguous(memory_format=torch.channels_last):
@@ -141,6 +160,10 @@ class ConvBiasAct(nn.Module):
                                       x_lo=x.lo, weight_lo=wl, residual_lo=residual.lo if residual is not None else None,
                                       out_f32=getattr(self, "out_f32", False), residual_after_act=residual_after_act)
             return out if getattr(self, "out_f32", False) else SplitAct(*out)
+        if x.shape[1] == 3 and residual is None and x.dtype == torch.float16:
+            y = self.stem16(x)
+            if y is not None:
+                return y
         narrow = USE_TLK_CONV_F16_NARROW and self.conv.kernel_size == (1, 1) and self.conv.in_channels <= 96 and self.conv.out_channels <= 96
         if (USE_TLK_CONV_F16 or narrow) and x.is_cuda and x.dtype == torch.float16 and x.shape[1] % 8 == 0 and self.conv.out_channels % 8 == 0 \
                 and x.is_contiguous(memory_format=torch.channels_last) and self.conv.weight.dtype == torch.float16:

@@ -128,6 +128,10 @@ class _ResNet50(nn.Module):
         self.layer4 = _layer(1024, 512, 3, 1)          # last_stride = 1 (BPBReID)
 
     def forward(self, x):
+        if isinstance(x, torch.Tensor) and x.dtype == torch.float16 and USE_TLK_MAXPOOL:
+            y = self.conv1.stem16(x, pool=True)              # r05: stem + bias + ReLU + max-pool in one kernel (the 192 x 64 map is never written)
+            if y is not None:
+                return self.layer4(self.layer3(self.layer2(self.layer1(y))))
         x = self.conv1(x)
         if isinstance(x, SplitAct):            # split-precision route: the max-pool runs on the merged fp32 tensor (exact: max commutes with the split)
             x = SplitAct.from_f32(self.pool(x.merge()))
