@@ -20,7 +20,7 @@ def parse(header):
     out = []
     title, cites = "conventions (header preamble)", []
     last_comment, last_end = "", -1
-    for m in re.finditer(r"/\*(.*?)\*/|^(?:const char \*|int )\s*(tlk_\w+)\s*\(", text, re.S | re.M):
+    for m in re.finditer(r"/\*(.*?)\*/|^(?:const char \*|long long |int )\s*(tlk_\w+)\s*\(", text, re.S | re.M):
         if m.group(2):
             own = []
             if last_end >= 0 and text[last_end:m.start()].strip() == "":        # a comment directly above the declaration
