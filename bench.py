@@ -806,6 +806,7 @@ def main():
                         "launches_per_step": len(recs) // 2, "avg_launch_ms": (c_ms - c_null) / len(recs), "avg_launch_ms_events_raw": c_ms / len(recs),
                         "event_pair_overhead_ms": c_null / len(recs), "algorithmic_flops_per_launch": c_flop / len(recs),
                         "algorithmic_tflop_per_step": c_flop / 2 / 1e12, "conv_ms_per_step": (c_ms - c_null) / 2,
+                        "algorithmic_bytes_per_launch": sum(r[6] for r in recs) / len(recs),
                         "units_per_launch": (f"one convolution of the step: {B} frames (detector) or the step's {live_crops} REAL crops (ReID, dense batch: "
                                              f"{live_crops / B:.1f} per frame of {pipe.maxd} slots)" if dense else
                                              f"one convolution of the step: {B} frames (detector) or {B} x {pipe.maxd} crop slots (ReID)") +
@@ -813,8 +814,23 @@ def main():
                         "reid_crops_per_step": live_crops, "reid_crop_slots_per_step": B * pipe.maxd,
                         "peak_source": "MI355X_MICROARCH.md: fp32-input MFMA 157.3 TFLOP/s dense (no reduced-precision fp32 path on gfx950)",
                         "per_instantiation": per_inst,
-                        "rocprofv3": "profiles/r04_config3_f32_rocprof.md: average duration of the same instantiations in the rocprofv3 --kernel-trace "
+                        # the instantiation the step spends most of its time in, alone (the `frac` above is the flop-weighted mix of ALL the
+                        # step's convolutions, the HBM-bound 1 x 1 expansions and the RGB stem included)
+                        "dominant_instantiation": dict(per_inst[0], frac=per_inst[0]["tflops"] / 157.3,
+                                                       share_of_conv_time=per_inst[0]["avg_launch_ms"] * per_inst[0]["launches_per_step"] / ((c_ms - c_null) / 2)),
+                        "rocprofv3": "profiles/r05_config3_f32_rocprof.md: average duration of the same instantiations in the rocprofv3 --kernel-trace "
                                      "--stats run of the same command (the ReLU / linear ones are launched by the ReID network only, same mix per step)"}
+            # HBM bytes per convolution launch from the PMC passes of the same command (FETCH_SIZE x 2 + WRITE_SIZE, separate passes,
+            # tools/make_profiles_r05.sh pmc): counters cannot be collected from inside this process, so the figure is the committed one
+            try:
+                tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_conv_f32_traffic.json")))
+                if tr.get("workload") == args.workload:
+                    roofline["traffic"] = tr["mean_traffic_bytes_per_conv_launch"]
+                    roofline["traffic_source"] = ("static: profiles/r05_conv_f32_traffic.md -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an "
+                                                  "earlier box (mean over the step's convolution launches), not measured by this run")
+                    roofline["traffic_over_algorithmic_bytes"] = roofline["traffic"] / roofline["algorithmic_bytes_per_launch"]
+            except (OSError, ValueError, KeyError):
+                pass
 
     # ---- small-step legs: the same chain at frames_per_step 1 / 2 / 4 and at 4 streams x 1 frame (what an online consumer sees; the
     # reference's online engine is per-frame, engine/video.py:67-117). Each: pipelined frames/s, un-overlapped frame-in -> rows-out time,

@@ -211,8 +211,11 @@ class ConvBiasAct(nn.Module):
                 e1.record()
                 cout, cin, kh, kw = self.conv.weight.shape       # the algorithmic count: 3 input channels for the RGB stem, not the padded 4
                 nb = LIVE_BATCH[1] if (LIVE_BATCH is not None and y.shape[0] == LIVE_BATCH[0]) else y.shape[0]
+                # algorithmic bytes: input, output (and residual) once, weights once -- fp32, live images only
+                nbytes = 4.0 * (nb * x.shape[2] * x.shape[3] * cin + nb * y.shape[2] * y.shape[3] * cout * (2 if residual is not None else 1)
+                                + cout * cin * kh * kw)
                 CONV_TIMER.append((e0, e1, n0, n1, 2.0 * nb * y.shape[2] * y.shape[3] * cout * cin * kh * kw,
-                                   (_lib.lib().tlk_conv2d_last_config(), _lib.ACT[self.act], residual is not None)))
+                                   (_lib.lib().tlk_conv2d_last_config(), _lib.ACT[self.act], residual is not None), nbytes))
             return y
         if residual_after_act and residual is not None:
             return self.forward(x) + residual                 # library routes fuse the residual only ahead of the activation

@@ -61,53 +61,6 @@ __device__ __forceinline__ long long xcd_tile(long long tiles)
     return (long long)xcd * q + (xcd < r ? xcd : r) + (b >> 3);
 }
 
-// 8 consecutive output channels of one pixel: bias, residual (before or after the activation), activation, store in the mode's format.
-// `c` = the 8 fp32 sums (split mode: already merged), m / co = pixel and first channel.
-template <int ACT, bool RES, int MODE, bool OUT_F32>
-__device__ __forceinline__ void epilogue8(const Conv16Args &p, float (&v)[8], long long m, int co)
-{
-    if (p.bias) {
-        const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + co), b1 = *reinterpret_cast<const float4 *>(p.bias + co + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-    }
-    float rv[8];
-    if (RES) {
-        const h16x8 rh = *reinterpret_cast<const h16x8 *>(p.res + m * p.r_pix + co);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) rv[e] = (float)rh[e];
-        if (MODE == MODE_SPLIT) {
-            const h16x8 rl = *reinterpret_cast<const h16x8 *>(p.res_lo + m * p.r_pix + co);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) rv[e] += (float)rl[e] * LO_INV;
-        }
-        if (!p.res_post) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rv[e];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = act16<ACT>(v[e]);
-    if (RES && p.res_post) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rv[e];
-    }
-    if (OUT_F32) {
-        float *o = p.y32 + m * p.y_pix + co;
-        *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    } else if (MODE == MODE_SPLIT) {
-        h16x8 oh, ol;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f32(v[e], h, l); oh[e] = h; ol[e] = l; }
-        *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
-        *reinterpret_cast<h16x8 *>(p.y_lo + m * p.y_pix + co) = ol;
-    } else {
-        h16x8 oh;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) oh[e] = (_Float16)v[e];
-        *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
-    }
-}
 #endif  // __HIPCC__
 
 const unsigned char *zero_page();      // 256 zero bytes on the current device (tlk_conv16.hip)
