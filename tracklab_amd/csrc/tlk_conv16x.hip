@@ -201,6 +201,22 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
         }
     };
     auto mfmas = [&](int set) {
+        if (MODE == MODE_F32) {
+            // lane l holds k = 8 j + 4 (l >> 5) + r, r = 0..3: MFMA r multiplies the k pair (8 j + r, 8 j + 4 + r) -- the fmaf chain
+            // 0,4,1,5,2,6,3,7 within every group of 8 that oracle/src/conv.c walks (tlk_conv.hip's contract, bit for bit).  r is the OUTER
+            // loop: consecutive MFMAs write different accumulators (each accumulator still sees r = 0, 1, 2, 3 in order)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj) {
+                        const f32x4 af = __builtin_bit_cast(f32x4, fa[set][0][i]), bf = __builtin_bit_cast(f32x4, fb[set][0][jj]);
+                        const float av = r == 0 ? af.x : r == 1 ? af.y : r == 2 ? af.z : af.w, bv = r == 0 ? bf.x : r == 1 ? bf.y : r == 2 ? bf.z : bf.w;
+                        acc[0][i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0][i][jj], 0, 0, 0);
+                    }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
