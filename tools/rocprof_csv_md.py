@@ -17,21 +17,22 @@ if len(sys.argv) > 4:
     out += [f"bench line of this profiled run: value = {d['value']:.1f} frames/s ({d['dtype']}), ms_per_step = {d['ms_per_step']:.2f}; "
             f"roofline (HIP events): {d['roofline']['achieved']:.1f} {d['roofline']['unit']} = {d['roofline']['frac']:.3f} of peak, "
             f"avg launch {d['roofline']['avg_launch_ms']:.4f} ms", ""]
-conv = [r for r in rows if "conv_f32_mfma_kernel" in r["Name"]]
+CONV_NAMES = ("conv_f32_mfma_kernel", "conv16x_kernel", "conv_stem3_kernel", "conv16_mfma_kernel", "conv_stem16_kernel")
+conv = [r for r in rows if any(k in r["Name"] for k in CONV_NAMES)]
 if conv:
     c_calls = sum(int(r["Calls"]) for r in conv)
     c_ns = sum(float(r["TotalDurationNs"]) for r in conv)
-    out += [f"**conv_f32_mfma_kernel, all template instantiations together: {c_calls} calls, {c_ns / 1e6:.2f} ms, average {c_ns / c_calls / 1e3:.2f} us, "
+    out += [f"**libtlk's convolution kernels (conv_f32_mfma_kernel, conv16x_kernel, conv_stem3_kernel, conv16_mfma_kernel, conv_stem16_kernel), all template instantiations together: {c_calls} calls, {c_ns / 1e6:.2f} ms, average {c_ns / c_calls / 1e3:.2f} us, "
             f"{100 * c_ns / tot:.2f} % of the GPU time** (includes the warm-up, parity and roofline passes of the command, whose launches are the same)", ""]
-if len(sys.argv) > 4 and d["roofline"].get("per_instantiation"):
+if len(sys.argv) > 4 and (d.get("roofline") or {}).get("per_instantiation"):
     out += ["Per instantiation, HIP events of the bench line (its roofline pass) beside rocprofv3's average over the whole command -- the ReLU / linear",
             "instantiations (5th template argument 1 / 0) are launched by the ReID network only, with the same mix of layers in every step, so the two",
             "averages are over the same set of shapes; the SiLU ones (2) also run in the detector's extra graph captures, whose small launches pull",
             "rocprofv3's average down:", "",
             "| instantiation | launches / step | bench: avg ms (events) | bench: TFLOP/s | rocprofv3: calls | rocprofv3: avg ms | events / rocprofv3 |", "|---|---|---|---|---|---|---|"]
     for e in d["roofline"]["per_instantiation"]:
-        key = e["kernel"].replace("conv_f32_mfma_kernel", "")
-        match = [r for r in rows if "conv_f32_mfma_kernel" + key in r["Name"]]
+        key = e["kernel"].split(" (")[0]                    # "conv_stem3_kernel (direct RGB stem, ...)" -> the kernel's name
+        match = [r for r in rows if key in r["Name"]]
         if match:
             r = match[0]
             ravg = float(r["AverageNs"]) / 1e6
