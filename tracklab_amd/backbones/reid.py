@@ -127,7 +127,16 @@ class _ResNet50(nn.Module):
         self.layer3 = _layer(512, 256, 6, 2)
         self.layer4 = _layer(1024, 512, 3, 1)          # last_stride = 1 (BPBReID)
 
-    def forward(self, x):
+    def forward(self, x, split=False):
+        if split and USE_TLK_MAXPOOL and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last):
+            # split-precision route, r05: the RGB stem and its pool in EXACT fp32 (direct stem kernel 5.4 ms + one pooling pass; the split-mode
+            # stem -- K = 7 * 7 * 8 padded channels on the r04 kernel, merge, torch's pool, split again -- took ~15 ms and was less exact),
+            # the (hi, lo) planes start behind the pool
+            from .. import _lib
+            y = SplitAct.from_f32(_lib.maxpool2d_nhwc(self.conv1(x), 3, 2, 1))
+            return self.layer4(self.layer3(self.layer2(self.layer1(y))))
+        if split:
+            x = SplitAct.from_f32(x, 8)
         if isinstance(x, torch.Tensor) and x.dtype == torch.float16 and USE_TLK_MAXPOOL:
             y = self.conv1.stem16(x, pool=True)              # r05: stem + bias + ReLU + max-pool in one kernel (the 192 x 64 map is never written)
             if y is not None:
@@ -157,11 +166,12 @@ class PartBasedReID(nn.Module):
 
     def forward(self, x):
         if getattr(self, "split_precision", False) and self.arch == "resnet50" and x.is_cuda and x.dtype == torch.float32:
-            # fp32 weights, fp32-class arithmetic on the 16-bit MFMA: every convolution of the backbone in split mode (csrc/tlk_conv16.hip),
-            # the image enters as (hi, lo) planes with 8 channels (5 of them zero), `reduce` hands fp32 back to the head below
+            # fp32 weights, fp32-class arithmetic on the 16-bit MFMA: every convolution of the backbone behind the stem in split mode
+            # (csrc/tlk_conv16x.hip; the stem + pool in exact fp32), `reduce` hands fp32 back to the head below
             self.reduce.out_f32 = True
-            x = SplitAct.from_f32(x, 8)
-        f = self.reduce(self.backbone(x))                    # (N, D, h, w)
+            f = self.reduce(self.backbone(x, split=True))
+        else:
+            f = self.reduce(self.backbone(x))                # (N, D, h, w)
         att = torch.softmax(self.part_cls(f).float(), dim=1)  # (N, K, h, w) pixel-wise part attention
         ff = f.float().flatten(2)                            # (N, D, hw)
         a = att.flatten(2)                                   # (N, K, hw)
