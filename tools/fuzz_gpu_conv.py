@@ -1,0 +1,127 @@
+"""GPU box: random shapes through the convolution entry points of r05, against the oracle (fp32: bit for bit) / fp32 arithmetic on the
+f16-rounded operands (16-bit kernels: one f16 ulp of slack).  Covers what the parametrized tests fix by hand: every tile configuration that
+accepts the shape, channel slices (pixel strides), residual before / after the activation, the dynamic batch, ragged everything.
+usage: python tools/fuzz_gpu_conv.py [seconds] [seed]"""
+import os
+import sys
+import time
+import numpy as np
+import torch
+import torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle
+from tracklab_amd import _lib
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+L = _lib.lib()
+_lib.conv2d_nhwc_f32(torch.zeros(0, 4, 2, 2, device="cuda").contiguous(memory_format=torch.channels_last),
+                     torch.zeros(4, 4, 1, 1, device="cuda").contiguous(memory_format=torch.channels_last))
+stats = {"f32": 0, "f32_declined": 0, "f16": 0, "stem16": 0, "patch": 0}
+t0 = time.time()
+
+
+def nhwc(a):
+    return torch.from_numpy(a).cuda().permute(0, 3, 1, 2)
+
+
+def fail(msg):
+    print("DIVERGENCE:", msg, flush=True)
+    sys.exit(1)
+
+
+while time.time() - t0 < budget:
+    kind = rng.choice(["f32", "f32", "patch", "f16", "stem16"])
+    act = [None, "relu", "silu"][rng.integers(3)]
+    if kind in ("f32", "patch"):
+        if kind == "patch":                        # shapes the patch-resident kernel takes: 3 x 3 / 1 on 32 channels, whole rows per tile
+            wo = int(rng.choice([8, 16, 32, 64])); h = int(rng.choice([256 // wo, 512 // wo, 768 // wo])); n = int(rng.integers(1, 4))
+            cin, cout, k, s = 32, int(rng.choice([32, 36, 64, 96])), 3, 1
+            w = wo
+        else:
+            n, h, w = int(rng.integers(1, 4)), int(rng.integers(3, 20)), int(rng.integers(3, 20))
+            cin = int(rng.choice([4, 8, 12, 32, 36, 64, 96, 128])); cout = int(rng.choice([4, 17, 32, 48, 64, 96, 130, 256]))
+            k = int(rng.choice([1, 3, 5])); s = int(rng.choice([1, 2]))
+        res = bool(rng.integers(2)); after = res and bool(rng.integers(2))
+        x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+        wt = (rng.standard_normal((cout, k, k, cin)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        exp = oracle.conv2d_nhwc_f32(x, wt, b, None, stride=s, act=act)
+        r = rng.standard_normal(exp.shape).astype(np.float32) if res else None
+        if res:
+            exp = oracle.conv2d_nhwc_f32(x, wt, b, r, stride=s, act=act, res_after_act=after)
+        xt, wtt, rt = nhwc(x), nhwc(wt), (nhwc(r) if res else None)
+        cfgs = [-1] + list(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33], size=4, replace=False))
+        # a channel slice as the output (pixel stride > Cout) and a dynamic batch, sometimes
+        slack = int(rng.choice([0, 0, 4, 16]))
+        live = int(rng.integers(1, n + 1)) if rng.integers(3) == 0 else n
+        for cfg in cfgs:
+            if L.tlk_conv2d_set_config(int(cfg)) != 0:
+                continue
+            wide = torch.full((n, exp.shape[1], exp.shape[2], cout + slack), -7.0, device="cuda").permute(0, 3, 1, 2)
+            out = wide[:, :cout]
+            nl = torch.tensor([live], dtype=torch.int32, device="cuda")
+            try:
+                if live != n:
+                    _lib.conv_set_dynamic_batch(nl)
+                try:
+                    _lib.conv2d_nhwc_f32(xt, wtt, torch.from_numpy(b).cuda(), act, rt, stride=s, out=out, residual_after_act=after)
+                except _lib.TlkError:
+                    stats["f32_declined"] += 1       # a forced configuration that does not take this shape says so
+                    continue
+            finally:
+                _lib.conv_set_dynamic_batch(None)
+                L.tlk_conv2d_set_config(-1)
+            got = wide.permute(0, 2, 3, 1).cpu().numpy()
+            tol_ok = np.array_equal(got[:live, ..., :cout], exp[:live]) if act != "silu" else np.allclose(got[:live, ..., :cout], exp[:live], rtol=2e-6, atol=2e-6)
+            if not tol_ok:
+                fail(f"fp32 cfg {cfg} last {L.tlk_conv2d_last_config()} case {(n, h, w, cin, cout, k, s, act, res, after, slack, live)} max diff {np.abs(got[:live, ..., :cout] - exp[:live]).max()}")
+            if not (got[live:] == -7.0).all() or not (got[..., cout:] == -7.0).all():
+                fail(f"fp32 cfg {cfg}: wrote outside its rows / channels, case {(n, h, w, cin, cout, k, s, slack, live)}")
+            stats[kind] += 1
+    elif kind == "f16":
+        n, h, w = int(rng.integers(1, 4)), int(rng.integers(3, 24)), int(rng.integers(3, 24))
+        cin = int(rng.choice([8, 48, 64, 96, 128, 192])); cout = int(rng.choice([8, 24, 64, 72, 128, 256, 264]))
+        k = int(rng.choice([1, 3])); s = int(rng.choice([1, 2])); res = bool(rng.integers(2))
+        x = torch.from_numpy(rng.standard_normal((n, h, w, cin)).astype(np.float32)).half().cuda().permute(0, 3, 1, 2)
+        wt = torch.from_numpy((rng.standard_normal((cout, k, k, cin)) * 0.1).astype(np.float32)).half().cuda().permute(0, 3, 1, 2)
+        b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).cuda()
+        ref = F.conv2d(x.float(), wt.float(), b, stride=s, padding=k // 2)
+        r = torch.from_numpy(rng.standard_normal(tuple(ref.permute(0, 2, 3, 1).shape)).astype(np.float32)).half().cuda().permute(0, 3, 1, 2) if res else None
+        if res:
+            ref = ref + r.float()
+        ref = torch.relu(ref) if act == "relu" else (F.silu(ref) if act == "silu" else ref)
+        for cfg in [-1] + list(rng.choice(np.arange(1, 17), size=3, replace=False)):
+            if L.tlk_conv16_set_config(int(cfg)) != 0:
+                continue
+            try:
+                try:
+                    y = _lib.conv2d_nhwc_16(x, wt, b, act, r, s, k // 2)
+                except _lib.TlkError:
+                    continue
+            finally:
+                L.tlk_conv16_set_config(-1)
+            err = (y.float() - ref).abs()
+            if not bool((err <= 3e-3 * ref.abs() + 3e-3 * (x.float().abs().max() * wt.float().abs().max() * (cin * k * k) ** 0.5)).all()):
+                fail(f"f16 cfg {cfg} case {(n, h, w, cin, cout, k, s, act, res)} max err {float(err.max())}")
+            stats["f16"] += 1
+    else:
+        n, h, w = int(rng.integers(1, 4)), int(rng.integers(8, 90)), int(rng.integers(8, 150))
+        k = int(rng.choice([7, 3])); cout = int(rng.choice([8, 32, 48, 64])); xp = int(rng.choice([3, 3, 4, 8]))
+        pool = bool(rng.integers(2)) and (w + 2 * (k // 2) - k) // 2 + 1 <= 64
+        xw = torch.from_numpy(rng.standard_normal((n, h, w, xp)).astype(np.float32)).half().cuda()
+        x = xw[..., :3].permute(0, 3, 1, 2)
+        wt = torch.from_numpy((rng.standard_normal((cout, k, k, 3)) * 0.1).astype(np.float32)).half().cuda().permute(0, 3, 1, 2)
+        b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).cuda()
+        ref = F.conv2d(x.float(), wt.float(), b, stride=2, padding=k // 2)
+        ref = torch.relu(ref) if act == "relu" else (F.silu(ref) if act == "silu" else ref)
+        ref = ref.half().float()
+        if pool:
+            ref = F.max_pool2d(ref, 3, 2, 1)
+        y = _lib.conv_stem16(x, _lib.conv_stem16_pack(wt), cout, k, b, act, pool=pool)
+        err = (y.float() - ref).abs()
+        if not bool((err <= 2e-3 * ref.abs() + 2e-3).all()):
+            fail(f"stem16 case {(n, h, w, k, cout, xp, act, pool)} max err {float(err.max())}")
+        stats["stem16"] += 1
+print(f"{sum(stats.values()) - stats['f32_declined']} launches compared in {time.time() - t0:.0f} s, 0 divergences: {stats}")
