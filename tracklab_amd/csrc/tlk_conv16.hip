@@ -629,7 +629,7 @@ extern "C" int tlk_conv16_set_glds(int on) { g_glds = on ? 1 : 0; return TLK_OK;
 
 extern "C" int tlk_conv16_set_config(int cfg)
 {
-    if (cfg < -1 || cfg > 16) return fail(TLK_EINVAL, "tlk_conv16_set_config: cfg is -1 (r04 kernels only), 0 (heuristic) or a tile configuration 1..16");
+    if (cfg < -1 || cfg > 18) return fail(TLK_EINVAL, "tlk_conv16_set_config: cfg is -1 (r04 kernels only), 0 (heuristic) or a tile configuration 1..18");
     g_cfg16x = cfg;
     return TLK_OK;
 }

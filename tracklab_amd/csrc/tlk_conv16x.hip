@@ -551,7 +551,9 @@ int launch_cfg_x(Conv16Args &a, bool split, int act, int cfg, hipStream_t st)
         case 14: return launch_x<2, 2, 2, 2, MODE_F16, 3, true>(a, act, st);     // 128 x 128, three stages
         case 15: return launch_x<4, 2, 2, 2, MODE_F16, 3, false>(a, act, st);    // 256 x 128, 8 wavefronts of 64 x 64, three stages
         case 16: return launch_x<2, 2, 1, 1, MODE_F16, 2, true>(a, act, st);     // 64 x 64, two stages
-        default: return fail(TLK_EINVAL, "tlk_conv16_set_config: f16 configurations are 1..16");
+        case 17: return launch_patch<4, 1, 2, 2, MODE_F16, true>(a, act, st, "tlk_conv2d_nhwc_16");      // 256 x 64 PATCH: 3 x 3 / 1 on 64 channels, input rows resident (see the fp32 form)
+        case 18: return launch_patch<4, 1, 1, 2, MODE_F16, true>(a, act, st, "tlk_conv2d_nhwc_16");      // 128 x 64 PATCH
+        default: return fail(TLK_EINVAL, "tlk_conv16_set_config: f16 configurations are 1..18");
         }
     }
     switch (cfg) {
