@@ -683,7 +683,8 @@ int tlk_conv16_set_glds(int on);
 /* r05: the large-tile / one-stage / ring kernels of tlk_conv16x.hip (direct-to-LDS buffer loads with hardware zero fill, XOR-swizzled LDS rows,
  * one to four LDS stages with counted waits, residual prefetched into registers).  cfg 0 (default) = they take the shapes their launch-size
  * heuristic claims (cin a multiple of the K step: 64 in f16 mode, 32 in split mode) and the r04 kernels the rest; -1 = r04 kernels only;
- * 1..16 (f16) / 1..7 (split) = force one tile configuration (probes / tests).  Same arithmetic contract as above in every configuration. */
+ * 1..18 (f16; 17 / 18 = the patch-resident 3 x 3 kernel: stride 1, exactly 64 channels, whole image rows per tile) / 1..7 (split) = force one
+ * tile configuration (probes / tests).  Same arithmetic contract as above in every configuration. */
 int tlk_conv16_set_config(int cfg);
 /* fp32 NHWC pixels (c_in channels, x_pix_stride floats apart, 0 = dense) -> (hi, lo) f16 planes with c_out >= c_in channels, zero padded. */
 int tlk_split_f32_planes(const float *x_dev, long long pixels, int c_in, int x_pix_stride, int c_out, void *hi_dev, void *lo_dev, void *hip_stream);

@@ -149,6 +149,33 @@ def test_every_f16_tile_configuration_of_the_direct_to_lds_kernels(shape, cfg):
     assert bool((err <= ref.abs() * 2.0 ** -11 + 2e-6 * bound + 1e-7).all()), float((err / (ref.abs() + 1e-3)).max())
 
 
+# (n, cin, h, w, cout, k, stride, residual): 3 x 3 / 1 on exactly 64 channels, whole image rows per 256- / 128-pixel tile
+PATCH16_SHAPES = [(3, 64, 16, 32, 64, 3, 1, True), (2, 64, 32, 16, 128, 3, 1, False), (2, 64, 8, 64, 72, 3, 1, True), (1, 64, 64, 8, 64, 3, 1, False)]
+
+
+@pytest.mark.parametrize("cfg", [0, 17, 18])
+@pytest.mark.parametrize("shape", PATCH16_SHAPES)
+def test_f16_patch_resident_3x3_kernel(shape, cfg):
+    """conv16x_kernel<..., MODE_F16, PATCH>: the tile's input rows + halo land in LDS once, the nine taps are nine shifted fragment reads; cfg 0 =
+    the heuristic, which routes these shapes (ResNet-50's layer 1) to it"""
+    from tracklab_amd import _lib
+    x, wt, b, r, k, s = _inputs(shape, seed=40 + cfg)
+    xh, wh = x.half(), wt.half()
+    rh = r.half() if r is not None else None
+    try:
+        _force16(cfg)
+        y = _lib.conv2d_nhwc_16(xh, wh, b, "relu", rh, stride=s)
+    finally:
+        _force16(0)
+    ref = F.conv2d(xh.double(), wh.double(), b.double(), s, k // 2)
+    if r is not None:
+        ref = ref + rh.double()
+    ref = F.relu(ref)
+    bound = F.conv2d(xh.double().abs(), wh.double().abs(), b.double().abs(), s, k // 2)
+    err = (y.double() - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -11 + 2e-6 * bound + 1e-7).all()), float((err / (ref.abs() + 1e-3)).max())
+
+
 @pytest.mark.parametrize("cfg", list(range(1, 8)))
 @pytest.mark.parametrize("shape", [X_SHAPES[0], X_SHAPES[1], X_SHAPES[2], X_SHAPES[3]])
 def test_every_split_tile_configuration_is_fp32_class(shape, cfg):
