@@ -474,9 +474,11 @@ def main():
 
     from tracklab_amd import gpu_pipeline as gp
 
-    def make_pipe(frames_per_step, n_streams=S, tdtype=tdtype):
+    def make_pipe(frames_per_step, n_streams=S, tdtype=tdtype, overlap=False):
         if is3:
             kw = dict(dim=wl["dim"]) if "dim" in wl else {}
+            if overlap:
+                kw["overlap_stages"] = True
             if "reid_arch" in wl:
                 kw["reid_arch"] = wl["reid_arch"]
             if wl.get("camera_motion"):
@@ -835,13 +837,15 @@ def main():
     # ---- small-step legs: the same chain at frames_per_step 1 / 2 / 4 and at 4 streams x 1 frame (what an online consumer sees; the
     # reference's online engine is per-frame, engine/video.py:67-117). Each: pipelined frames/s, un-overlapped frame-in -> rows-out time,
     # and for the BPBReID workloads the ids of up to 48 frames per checked stream against the oracle chain ----
-    def small_step_legs(dt, with_main):
+    def small_step_legs(dt, with_main, overlap=False):
         shapes = [(1, 1), (1, 2), (1, 4), (4, 1)] if is3 else [(1, 1), (1, 4)]
+        if overlap:           # detector stage of step t + 1 beside the ReID stage of step t (DetReidTrackPipeline(overlap_stages=True), opt-in)
+            shapes = [(1, 1), (4, 1)]
         latency = []
         for S_, F_ in shapes:
             if S_ * F_ > B:
                 continue
-            p1 = make_pipe(F_, S_, dt)
+            p1 = make_pipe(F_, S_, dt, overlap=overlap)
             T_ = 48 if S_ * F_ > 1 else 36
             hs = [heads_np[0][:T_]] + [build_stream_inputs(5000 + s_, n_objects, T_, ratio)[0] for s_ in range(1, S_)]
             hsteps = np.ascontiguousarray(np.stack(hs).reshape(S_, T_ // F_, F_, -1, heads_np.shape[-1]).transpose(1, 0, 2, 3, 4)).reshape(
@@ -886,7 +890,7 @@ def main():
             for j in range(15):                                  # true in-to-out latency: one step, wait for its rows
                 t1 = time.perf_counter(); stp(j); p1.synchronize(); lat.append(time.perf_counter() - t1)
             latency.append({"n_streams": S_, "frames_per_step": F_, "fps": nrun * S_ * F_ / el1, "ms_per_step_pipelined": el1 / nrun * 1e3,
-                            "ms_frame_in_to_rows_out": float(np.median(lat) * 1e3), "parity": leg_parity})
+                            "ms_frame_in_to_rows_out": float(np.median(lat) * 1e3), "parity": leg_parity, "overlap_stages": bool(getattr(p1, "overlap", False))})
             p1.close()
             del p1, d_h1
         if with_main:
@@ -898,12 +902,17 @@ def main():
             pipe.reset()
         return latency
 
-    latency = latency_f16 = None
+    latency = latency_f16 = latency_f16_overlap = None
     if rank == 0 and world == 1 and not args.no_latency_leg and F > 1:
         pipe.reset()
         latency = small_step_legs(tdtype, True)
         if args.dtype == "f32":           # the online target (>= 240 frames/s at small steps) is out of any fp32 path's reach on this chip (one frame = 1.36 TFLOP of
             latency_f16 = small_step_legs(torch.float16, False)          # convolutions = 8.6 ms at the fp32 MFMA peak): the f16 legs are reported beside
+        if is3 and not ssort and wl.get("pose") is None and not wl.get("camera_motion"):
+            try:              # opt-in pipeline mode, reported beside the serial legs (never as them): an exception here must not cost the run its line
+                latency_f16_overlap = small_step_legs(torch.float16, False, overlap=True)
+            except Exception as ex:                             # noqa: BLE001
+                latency_f16_overlap = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
     # ---- other-precision legs.  The default fp32 run (the reference's precision: ONNXRuntime / torchreid fp32, strong_sort.yaml:10 fp16: false)
     # also times (a) the f16 backbones (tolerance: tests/test_gpu_precision.py) and (b) the SPLIT-PRECISION ReID network: fp32 weights and
@@ -1003,7 +1012,7 @@ def main():
             "rank_placement_sound": tdist.placement_is_sound(placement, int(os.environ.get("LOCAL_WORLD_SIZE", world)), os.cpu_count() or 1),
             "warmup_serialized": world > 1,
             "collectives": "nccl" if dist is not None else None, "hota_allreduce": hota_all,
-            "latency": latency, "latency_f16": latency_f16, "value_f32": (f32_leg["value"] if f32_leg else (value if args.dtype == "f32" else None)),
+            "latency": latency, "latency_f16": latency_f16, "latency_f16_overlap": latency_f16_overlap, "value_f32": (f32_leg["value"] if f32_leg else (value if args.dtype == "f32" else None)),
             "ms_per_step_f32": (f32_leg["ms_per_step"] if f32_leg else (el / args.steps * 1e3 if args.dtype == "f32" else None)),
             "f32_leg": f32_leg,
             "value_f16": alt_leg["value"] if alt_leg and alt_name == "f16" else None,

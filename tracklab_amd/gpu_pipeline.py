@@ -256,8 +256,10 @@ class DetReidTrackPipeline:
                  parts: int = 6, dim: int = 256, reid_hw=(384, 128), tracker_cfg: dict | None = None,
                  nms_thr: float = 0.45, score_thr: float = 0.7, max_tracks: int | None = None, use_graph: bool = True,
                  pose: str | None = None, tracker: str = "bpbreid", reid_arch: str = "resnet50", camera_motion: bool = False,
-                 reid_split_precision: bool = False):
-        """camera_motion (tracker "bot_sort"): the reference's default cmc_method sparseOptFlow (configs/modules/track/bot_sort.yaml) -- one
+                 reid_split_precision: bool = False, overlap_stages: bool | None = None):
+        """overlap_stages (r05, default off; env TLK_PIPE_OVERLAP=1): detector stage of step t + 1 and ReID stage of step t on two streams
+        (double-buffered crops): what the ONLINE configuration wants, where a one-frame step's kernels have fewer tiles than the chip has CUs.
+        camera_motion (tracker "bot_sort"): the reference's default cmc_method sparseOptFlow (configs/modules/track/bot_sort.yaml) -- one
         estimator per stream (tlk_cmc_*) runs over the step's frames on a side stream under the backbone forwards, its (2,3) warps go to the
         tracker's frame kernel in device memory (tlk_botsort_update_dev_gmc).
         reid_arch: "resnet50" (default) or "hrnet32" (the backbone tracklab/configs/modules/reid/bpbreid.yaml:53 names).
@@ -364,6 +366,19 @@ class DetReidTrackPipeline:
         self.slot_base = torch.zeros(B, dtype=torch.int32, device=dev)
         self.n_live = torch.full((1,), B * max_dets, dtype=torch.int32, device=dev)
         self.slot_of = torch.arange(B * max_dets, dtype=torch.int64, device=dev)
+        # r05, overlap_stages: stage A (letterbox, detector, decode + NMS, crops) of step t + 1 runs on its own stream beside stage B (ReID
+        # forward, hand-off) of step t; what A writes and B reads -- crops, slot bases, live count -- exists twice, B's results go to the
+        # per-step ring `bufs` as before.  Only the plain BPBReID chain (no pose stage, no camera motion, dense batch) is wired for it.
+        if overlap_stages is None:
+            overlap_stages = __import__("os").environ.get("TLK_PIPE_OVERLAP", "0") == "1"
+        self.overlap = bool(overlap_stages) and self.dense_reid and self.pose is None and not camera_motion
+        self.sets = [{"crops": self.crops, "slot_base": self.slot_base, "n_live": self.n_live, "slot_of": self.slot_of,
+                      "a_done": torch.cuda.Event(), "b_done": torch.cuda.Event()}]
+        if self.overlap:
+            self.sets.append({"crops": torch.zeros_like(self.crops), "slot_base": torch.zeros_like(self.slot_base), "n_live": self.n_live.clone(),
+                              "slot_of": self.slot_of.clone(), "a_done": torch.cuda.Event(), "b_done": torch.cuda.Event()})
+            self.det_stream = torch.cuda.Stream(device=dev)
+            self.reid_stream = torch.cuda.Stream(device=dev)
         # f16 and split-precision backbones carry activations as float16 (pairs): |x| > 65504 saturates to infinity.  The envelope is stated in
         # DESIGN.md (tests/test_gpu_precision.py measures it); past it the run must fail LOUDLY, not track on infinities: every step ORs
         # "an embedding is not finite" into a device flag that travels to pinned memory with the results and is checked in synchronize()
@@ -419,6 +434,9 @@ class DetReidTrackPipeline:
         self.h_nf_flag.zero_()
 
     def synchronize(self):
+        if self.overlap:
+            self.det_stream.synchronize()
+            self.reid_stream.synchronize()
         self.trk_stream.synchronize()
         torch.cuda.current_stream(self.dev).synchronize()
         if self.check_finite and bool(self.h_nf_flag[0]):
@@ -451,92 +469,112 @@ class DetReidTrackPipeline:
         ``DetTrackPipeline.step``."""
         S, F, maxd = self.S, self.F, self.maxd
         buf = self.bufs[self.step_idx % self.nbuf]
+        st = self.sets[self.step_idx % len(self.sets)]
         self.step_idx += 1
         main = torch.cuda.current_stream(self.dev)
-        main.wait_event(buf["done"])
+        if self.overlap:
+            entry = torch.cuda.Event()
+            entry.record(main)                      # the caller's frames are ready at this point of ITS stream (which carries none of our work)
+            sa, sb = self.det_stream, self.reid_stream
+            sa.wait_event(entry)
+            sa.wait_event(buf["done"])              # the tracker is done with this ring entry (two steps ago)
+            sa.wait_event(st["b_done"])             # the ReID stage of two steps ago has read this set of crops
+        else:
+            sa = sb = main
+            main.wait_event(buf["done"])
 
-        def det_fwd():
-            x, _ = _lib.letterbox(frames, self.size, "focus_nhwc", self.dtype, out=self.lb, swap_rb=True)
-            return self.model(x, focused=True)
-        pred = self._graphed(self.det_graphs, frames.data_ptr(), det_fwd) if self.use_graph else det_fwd()
-        if synth_head is not None:
-            pred = torch.add(synth_head, torch.nan_to_num(pred), alpha=0.0)
-        _lib.yolox_decode_nms(pred, self.size, float(np.float32(self.ratio)), self.W, self.H, maxd, self.nms_thr,
-                              self.score_thr, out=self.det, trk_in=buf["trk_in"], det_id_base=self.frames_done * maxd, category_id=1.0)
-        if self.record_kernel_events:
-            self._record_null_pair()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        if self.global_feat:                    # StrongSORT._get_features: int-truncated boxes, Pillow resize, ImageNet normalisation
-            crops = _lib.roi_crop_pil_resize_norm(frames, buf["trk_in"], self.det["counts"], self.reid_hw[0], self.reid_hw[1],
-                                                  "nhwc", self.dtype, out=self.crops)
-        else:
-            if self.dense_reid:
-                _lib.crop_slot_bases(self.det["counts"], maxd, self.slot_base, self.n_live, self.slot_of)
-            crops = _lib.roi_crop_resize_norm(frames, self.det["ltwh"], self.det["counts"], self.reid_hw[0], self.reid_hw[1],
-                                              "nhwc", self.dtype, out=self.crops, slot_base=self.slot_base if self.dense_reid else None)
-        if self.record_kernel_events:
-            e1.record()
-            self.kernel_events.append((e0, e1))
-        if self.pose is not None:
-            # pose stage (rtmlib RTMPose(image, bboxes)): affine crops of every box -> network -> SimCC decode, all in HBM
-            # boxes as RTMPose.process sees them: detections.bbox.ltrb() of the SANITIZED float32 bbox_ltwh the detector stored
-            # (l, t, l + w, t + h in float32, widened), not the decode kernel's unclipped xyxy
-            ltwh32 = self.det["ltwh"]
-            self.xyxy32[..., :2].copy_(ltwh32[..., :2])
-            torch.add(ltwh32[..., :2], ltwh32[..., 2:], out=self.xyxy32[..., 2:])
-            self.xyxy64.copy_(self.xyxy32)
-            pcrops, _ = _lib.pose_crop_warp_norm(frames, self.xyxy64, self.det["counts"], 192, 256, "nhwc", self.dtype,
-                                                 out=self.pose_crops, meta=self.pose_meta, swap_rb=True)
-        self.frames_free = torch.cuda.Event()       # the crop kernels were the last readers of `frames` ...
-        if self.cmc is not None:
-            # ... unless the camera-motion estimators read them too: frame by frame per stream, on their own stream (about 25 small launches per frame
-            # that would otherwise sit on the main stream between the backbone launches)
-            buf["gate"].copy_(self.det["counts"])       # (this step's own copy: the next step's decode overwrites det["counts"] while the estimators may still run)
-            fed = torch.cuda.Event()
-            fed.record(main)
-            with torch.cuda.stream(self.cmc_stream):
-                self.cmc_stream.wait_event(fed)
-                sp = C.c_void_p(self.cmc_stream.cuda_stream)
-                for s_ in range(S):
-                    for f_ in range(F):
-                        # gated on the frame's detection count, on the device: the reference skips GMC.apply for a frame without detections
-                        self.cmc[s_].apply_dev(frames[s_ * F + f_], stream_ptr=sp, out=buf["warps"][s_, f_], count=buf["gate"][s_ * F + f_:s_ * F + f_ + 1])
-                buf["cmc_done"].record(self.cmc_stream)
-                self.frames_free.record(self.cmc_stream)
-        else:
-            self.frames_free.record(main)
-        if self.pose is not None:
-            if self.use_graph:
-                sx, sy = self._graphed(self.__dict__.setdefault("_pg", {}), 0, lambda: self.pose(pcrops))
+        # ---- stage A: letterbox + detector, decode + NMS, crops (everything that reads `frames`)
+        with torch.cuda.stream(sa):
+            def det_fwd():
+                x, _ = _lib.letterbox(frames, self.size, "focus_nhwc", self.dtype, out=self.lb, swap_rb=True)
+                return self.model(x, focused=True)
+            pred = self._graphed(self.det_graphs, frames.data_ptr(), det_fwd) if self.use_graph else det_fwd()
+            if synth_head is not None:
+                pred = torch.add(synth_head, torch.nan_to_num(pred), alpha=0.0)
+            _lib.yolox_decode_nms(pred, self.size, float(np.float32(self.ratio)), self.W, self.H, maxd, self.nms_thr,
+                                  self.score_thr, out=self.det, trk_in=buf["trk_in"], det_id_base=self.frames_done * maxd, category_id=1.0)
+            if self.record_kernel_events:
+                self._record_null_pair()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            if self.global_feat:                    # StrongSORT._get_features: int-truncated boxes, Pillow resize, ImageNet normalisation
+                crops = _lib.roi_crop_pil_resize_norm(frames, buf["trk_in"], self.det["counts"], self.reid_hw[0], self.reid_hw[1],
+                                                      "nhwc", self.dtype, out=st["crops"])
             else:
-                sx, sy = self.pose(pcrops)
-            _lib.simcc_decode(sx, sy, self.pose_meta, 192, 256, 2.0, out=self.pose_out)
-            buf["kps"].copy_(self.pose_out["kps_xyc"].view(self.B, maxd, 17, 3))
-        if self.dense_reid:
-            _lib.conv_set_dynamic_batch(self.n_live)      # (a captured graph keeps the pointer: every replay reads the step's own count)
-        try:
-            if self.use_graph:
-                emb, vis = self._graphed(self.__dict__.setdefault("_rg", {}), 0, lambda: self.reid(crops))
+                if self.dense_reid:
+                    _lib.crop_slot_bases(self.det["counts"], maxd, st["slot_base"], st["n_live"], st["slot_of"])
+                crops = _lib.roi_crop_resize_norm(frames, self.det["ltwh"], self.det["counts"], self.reid_hw[0], self.reid_hw[1],
+                                                  "nhwc", self.dtype, out=st["crops"], slot_base=st["slot_base"] if self.dense_reid else None)
+            if self.record_kernel_events:
+                e1.record()
+                self.kernel_events.append((e0, e1))
+            if self.pose is not None:
+                # pose stage (rtmlib RTMPose(image, bboxes)): affine crops of every box -> network -> SimCC decode, all in HBM
+                # boxes as RTMPose.process sees them: detections.bbox.ltrb() of the SANITIZED float32 bbox_ltwh the detector stored
+                # (l, t, l + w, t + h in float32, widened), not the decode kernel's unclipped xyxy
+                ltwh32 = self.det["ltwh"]
+                self.xyxy32[..., :2].copy_(ltwh32[..., :2])
+                torch.add(ltwh32[..., :2], ltwh32[..., 2:], out=self.xyxy32[..., 2:])
+                self.xyxy64.copy_(self.xyxy32)
+                pcrops, _ = _lib.pose_crop_warp_norm(frames, self.xyxy64, self.det["counts"], 192, 256, "nhwc", self.dtype,
+                                                     out=self.pose_crops, meta=self.pose_meta, swap_rb=True)
+            self.frames_free = torch.cuda.Event()       # the crop kernels were the last readers of `frames` ...
+            if self.cmc is not None:
+                # ... unless the camera-motion estimators read them too: frame by frame per stream, on their own stream (about 25 small launches per frame
+                # that would otherwise sit on the main stream between the backbone launches)
+                buf["gate"].copy_(self.det["counts"])       # (this step's own copy: the next step's decode overwrites det["counts"] while the estimators may still run)
+                fed = torch.cuda.Event()
+                fed.record(sa)
+                with torch.cuda.stream(self.cmc_stream):
+                    self.cmc_stream.wait_event(fed)
+                    sp = C.c_void_p(self.cmc_stream.cuda_stream)
+                    for s_ in range(S):
+                        for f_ in range(F):
+                            # gated on the frame's detection count, on the device: the reference skips GMC.apply for a frame without detections
+                            self.cmc[s_].apply_dev(frames[s_ * F + f_], stream_ptr=sp, out=buf["warps"][s_, f_], count=buf["gate"][s_ * F + f_:s_ * F + f_ + 1])
+                    buf["cmc_done"].record(self.cmc_stream)
+                    self.frames_free.record(self.cmc_stream)
             else:
-                emb, vis = self.reid(crops)
-        finally:
+                self.frames_free.record(sa)
+            # what the association needs of the detector's output leaves the shared `det` arrays here (the next step's decode overwrites them)
+            buf["ltwh"].copy_(self.det["ltwh"])
+            buf["counts"].copy_(self.det["counts"])
+            st["a_done"].record(sa)
+
+        # ---- stage B: pose / ReID forward, hand-off to the association stream
+        with torch.cuda.stream(sb):
+            if self.overlap:
+                sb.wait_event(st["a_done"])
+            if self.pose is not None:
+                if self.use_graph:
+                    sx, sy = self._graphed(self.__dict__.setdefault("_pg", {}), 0, lambda: self.pose(pcrops))
+                else:
+                    sx, sy = self.pose(pcrops)
+                _lib.simcc_decode(sx, sy, self.pose_meta, 192, 256, 2.0, out=self.pose_out)
+                buf["kps"].copy_(self.pose_out["kps_xyc"].view(self.B, maxd, 17, 3))
             if self.dense_reid:
-                _lib.conv_set_dynamic_batch(None)
-        # hand-off buffers for the association stream (detector ltwh is float32: widen like numpy would)
-        if self.dense_reid:       # dense batch -> (frame, detection) slots; padding slots receive some valid row, the tracker reads counts[b] of them
-            torch.index_select(emb.reshape(self.B * maxd, self.K * self.D), 0, self.slot_of, out=buf["emb"].view(self.B * maxd, self.K * self.D))
-            torch.index_select(vis.reshape(self.B * maxd, self.K).to(torch.uint8), 0, self.slot_of, out=buf["vis"].view(self.B * maxd, self.K))
-        else:
-            buf["emb"].copy_(emb.view(self.B, maxd, self.K, self.D))
-            buf["vis"].copy_(vis.view(self.B, maxd, self.K))
-        if self.check_finite:
-            self.nf_flag.logical_or_(torch.logical_not(torch.isfinite(buf["emb"]).all()))
-            self.h_nf_flag.copy_(self.nf_flag, non_blocking=True)
-        buf["ltwh"].copy_(self.det["ltwh"])
-        buf["counts"].copy_(self.det["counts"])
-        torch.add(self.id_off, self.frames_done * maxd, out=buf["ids"])
-        buf["ready"].record(main)
+                _lib.conv_set_dynamic_batch(st["n_live"])      # (a captured graph keeps the pointer: every replay reads the step's own count)
+            try:
+                if self.use_graph:
+                    emb, vis = self._graphed(self.__dict__.setdefault("_rg", {}), id(st), lambda: self.reid(crops))
+                else:
+                    emb, vis = self.reid(crops)
+            finally:
+                if self.dense_reid:
+                    _lib.conv_set_dynamic_batch(None)
+            # hand-off buffers for the association stream (detector ltwh is float32: widen like numpy would)
+            if self.dense_reid:       # dense batch -> (frame, detection) slots; padding slots receive some valid row, the tracker reads counts[b] of them
+                torch.index_select(emb.reshape(self.B * maxd, self.K * self.D), 0, st["slot_of"], out=buf["emb"].view(self.B * maxd, self.K * self.D))
+                torch.index_select(vis.reshape(self.B * maxd, self.K).to(torch.uint8), 0, st["slot_of"], out=buf["vis"].view(self.B * maxd, self.K))
+            else:
+                buf["emb"].copy_(emb.view(self.B, maxd, self.K, self.D))
+                buf["vis"].copy_(vis.view(self.B, maxd, self.K))
+            if self.check_finite:
+                self.nf_flag.logical_or_(torch.logical_not(torch.isfinite(buf["emb"]).all()))
+                self.h_nf_flag.copy_(self.nf_flag, non_blocking=True)
+            torch.add(self.id_off, self.frames_done * maxd, out=buf["ids"])
+            buf["ready"].record(sb)
+            st["b_done"].record(sb)
         self.frames_done += S * F
         with torch.cuda.stream(self.trk_stream):
             self.trk_stream.wait_event(buf["ready"])
