@@ -23,6 +23,17 @@
 //   * epilogue: the fp32 tile leaves through the (now idle) LDS stages one MFMA tile row at a time, 8 channels (16 bytes of f16) per lane.
 // Activation kind, residual and output format are run-time (wave-uniform) switches here, not template arguments: the epilogue is a few
 // percent of a compute-bound launch and the instantiation count stays small.
+//
+// Later in r05 the same kernel grew three more uses (template arguments NST, RESPF, MODE_F32, PATCH):
+//   * NST = 1: ONE LDS stage (33 KB for 128 x 128), 3-4 workgroups per CU -- residency hides the latencies better than a pipeline inside the
+//     workgroup on every memory-bound layer and most large ones; NST = 3 / 4: a ring with counted waits for the small launches of the
+//     online step (64 x 64 tiles); RESPF: the residual of the lane's output vectors prefetched into registers before the main loop;
+//   * MODE_F32: fp32 tensors through the same loader (128-byte rows = 32 floats) on v_mfma_f32_32x32x2_f32, the k order of tlk_conv.hip's
+//     contract (bit-identical results): the memory-bound and narrow layers of the fp32 networks (tlk_conv2d_nhwc_f32 configurations 21-29);
+//   * PATCH: 3 x 3 / stride 1 layers whose Cin is exactly one K step (32 floats / 64 halfs) and whose tiles are whole image rows -- the
+//     tile's input rows + halo land in LDS ONCE and the nine taps are nine shifted fragment reads, instead of nine passes over the input
+//     through an L2 that no longer holds it (fp32 configurations 30-33: HRNet's 32-channel branch, 117 vs 69 TFLOP/s; f16 17 / 18:
+//     ResNet's layer 1, 716 vs 625).
 #include "tlk_conv16.hpp"
 
 using namespace tlk;
