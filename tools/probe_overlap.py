@@ -1,0 +1,32 @@
+"""GPU box: one-frame-per-step f16 chain with DetReidTrackPipeline(overlap_stages=True): frames/s with the detector stage's stream at high
+priority (its own hardware queue) and at normal priority (may share the ReID stage's queue).  usage: python tools/probe_overlap.py [prio ...]"""
+import os
+import sys
+import time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tracklab_amd import gpu_pipeline as gp
+from tracklab_amd.synth import SyntheticStream, render_frame, synth_yolox_head
+
+rng = np.random.default_rng(0)
+T = 6
+heads, frames = [], []
+ratio = min(640 / 1080, 640 / 1920)
+for fr in SyntheticStream(0, 100, T):
+    heads.append(synth_yolox_head(rng, fr["dets"][:, :4], ratio=ratio))
+    frames.append(render_frame(rng, fr["gt_boxes"]))
+dh = torch.from_numpy(np.stack(heads)).cuda()
+fr1 = torch.from_numpy(frames[0][None]).cuda()
+for prio in (sys.argv[1:] or ["-1", "0"]):
+    os.environ["TLK_DET_PRIO"] = prio
+    pipe = gp.DetReidTrackPipeline("m", n_streams=1, frames_per_step=1, max_dets=104, dtype=torch.float16, overlap_stages=prio != "serial")
+    for j in range(8):
+        pipe.step(fr1, dh[j % T:j % T + 1], fetch=False)
+    pipe.synchronize()
+    t0 = time.perf_counter()
+    for j in range(100):
+        pipe.step(fr1, dh[j % T:j % T + 1], fetch=False)
+    pipe.synchronize()
+    print(f"detector-stage stream priority {prio}: {100 / (time.perf_counter() - t0):.1f} frames/s (overlap={pipe.overlap})", flush=True)
+    pipe.close()
