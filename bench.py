@@ -96,6 +96,7 @@ def parse(argv=None):
     ap.add_argument("--no-latency-leg", action="store_true", help="skip the small-step legs (frames_per_step 1 / 2 / 4 and 4 streams x 1 frame)")
     ap.add_argument("--no-f32-leg", "--no-alt-leg", dest="no_f32_leg", action="store_true",
                     help="skip the other-precision leg (f16 backbones beside the default fp32 run; fp32 beside an f16 run)")
+    ap.add_argument("--no-hrnet-leg", action="store_true", help="skip the HRNet-W32 ReID leg of the default fp32 config3 run (value_hrnet32)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the rocprofv3 --pmc passes for roofline.traffic (static file instead)")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the H2D-inclusive leg (value = value_resident)")
     ap.add_argument("--dry-run", action="store_true",
@@ -438,9 +439,21 @@ def main():
     from tracklab_amd import dist as tdist
     from tracklab_amd.synth import HEIGHT, WIDTH, render_frame
     world, rank, local_rank = tdist.env_world()
-    # under a torchrun launch the collectives run on RCCL even at world size 1 (the driver's N=1 line comes without torchrun: no process group)
+    # r06: the collectives run on RCCL at EVERY world size.  Under torchrun the group comes from the environment; the driver's N = 1 line comes
+    # without torchrun, so a one-rank group is initialised in-process (tdist.init_single: 127.0.0.1, a free port) -- barrier, max / sum
+    # all-reduce and the all-gather of the per-rank rows then go through RCCL there too ("RCCL has never been touched by a driver
+    # run at any N").  TLK_NO_DIST=1 opts out; a failing RCCL initialisation does not cost the run its line (`collectives` says why).
     use_dist = world > 1 or ("WORLD_SIZE" in os.environ and os.environ.get("TLK_FORCE_DIST") == "1")
-    dist = tdist.init("nccl") if use_dist else None
+    dist, dist_note = None, None
+    if use_dist:
+        dist = tdist.init("nccl")
+        dist_note = f"nccl (RCCL), torchrun process group of {world}"
+    elif os.environ.get("TLK_NO_DIST") != "1":
+        try:
+            dist = tdist.init_single("nccl")
+            dist_note = "nccl (RCCL), one-rank process group initialised in-process: barrier / all-reduce(max, sum) / all-gather run on RCCL"
+        except Exception as ex:                                 # noqa: BLE001
+            dist, dist_note = None, f"none: one-rank nccl group failed to initialise ({type(ex).__name__}: {ex})"[:300]
     if dist is None:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if use_dist else 0)
@@ -514,10 +527,13 @@ def main():
     def run_step(k, fetch=True, p=None):
         return (p or pipe).step(d_pool[k % pool_steps], d_heads[k], fetch=fetch)
 
+    warm_order, warm_locked = [], None
     if world > 1:
         # multi-GPU job: the first step of every rank (hipGraph capture of both networks, library tuning of the f16 route, pinned allocations)
-        # runs under a node-wide lock, one rank at a time -- untimed; the state it leaves behind is reset
-        with tdist.serialized("warmup"):
+        # runs under a node-wide lock, one rank at a time -- untimed; the state it leaves behind is reset.  The (enter, exit) window of every
+        # rank is gathered after the timed legs and `warmup_serialized` reports whether the windows were really disjoint
+        with tdist.serialized("warmup", order=warm_order) as lk:
+            warm_locked = lk.locked
             run_step(0)
             pipe.synchronize()
             torch.cuda.synchronize()
@@ -688,6 +704,13 @@ def main():
             except Exception as ex:                             # noqa: BLE001  (an evaluator problem must not cost the run its line)
                 hota_all["from_device_table"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     per_rank, seen, placement = gather_ranks(dist, dev, fps_local)
+    warm_serialized = None
+    if world > 1 and dist is not None and len(warm_order) == 2:
+        t = torch.tensor([warm_order[0][1], warm_order[1][1], 1.0 if warm_locked else 0.0], dtype=torch.float64, device=dev)
+        allw = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allw, t)
+        wins = sorted([float(w[0]), float(w[1])] for w in allw)
+        warm_serialized = bool(all(float(w[2]) > 0 for w in allw) and all(a[1] <= b[0] + 1e-6 for a, b in zip(wins, wins[1:])))
 
     # ---- roofline of the dominant byte-moving libtlk kernel: HIP events on the launch stream around every launch of
     # K further steps of the same workload ----
@@ -695,8 +718,11 @@ def main():
     pipe.record_kernel_events = True
     pipe.kernel_events.clear()
     pipe.null_events.clear()
+    live_hist = []
     for k in range(args.warmup, total_steps):
         run_step(k)
+        if is3:          # the crops this launch really cut: the NMS survivors (dense batch: n_live; slot layout: the per-frame counts), read on the device
+            live_hist.append((pipe.n_live if getattr(pipe, "dense_reid", False) else pipe.det["counts"].sum()).clone())
     pipe.synchronize()
     pipe.record_kernel_events = False
     k_ms = [e0.elapsed_time(e1) for e0, e1 in pipe.kernel_events]
@@ -708,12 +734,14 @@ def main():
     k_ms_avg = k_ms_raw - null_avg
     from tracklab_amd import roofline as rl
     esz = torch.empty((), dtype=tdtype).element_size()
-    cnt_mean = float(np.mean([len(g["dets"]) for g in gts[0][:total_steps * F]]))
+    # crops per launch = what the crop kernel cut in THOSE launches (the ground-truth count over-stated it by ~10 %: NMS
+    # duplicates are suppressed before the crops); detector-only workloads count frames
+    cnt_mean = float(np.mean([float(t.item()) for t in live_hist])) / B if live_hist else float(np.mean([len(g["dets"]) for g in gts[0][:total_steps * F]]))
     if is3:
         kname, tfile = ("pil_wave_kernel" if esz == 2 else "pil_crop_kernel", "pil_crop_traffic.json") if ssort else (
             "crop_wave3_kernel" if esz == 2 else "crop_wave2_kernel", "crop_traffic.json")
-        # mean crop of the synthetic stream: w~U(40,120), h=w*U(1.8,2.6) -> E[w*h] = E[w^2]*2.2; only the cnt_mean REAL crops of a
-        # frame count (the padding slots up to max_dets are not algorithmic bytes)
+        # mean crop of the synthetic stream: w~U(40,120), h=w*U(1.8,2.6) -> E[w*h] = E[w^2]*2.2; only the cnt_mean LIVE crops of a
+        # frame count (NMS survivors, read from the device per launch; the padding slots up to max_dets are not algorithmic bytes)
         ew2 = (120 ** 3 - 40 ** 3) / (3 * 80)
         alg_bytes = B * cnt_mean * (ew2 * 2.2 * 3 + 3 * pipe.reid_hw[0] * pipe.reid_hw[1] * esz)
     else:
@@ -746,93 +774,97 @@ def main():
     # roofline: ALGORITHMIC flops of every convolution of one step (2 * pixels * Cout * Cin * KH * KW, the RGB stem counted with 3 channels)
     # / the sum of their launch durations, HIP events on the launch stream around every launch of two eager passes of both networks over
     # the step's own buffers (the timed legs replay the same launches from hipGraphs, where events cannot be placed); peak = dense fp32 MFMA.
+    def conv_roofline(p_, workload_key, traffic_file="r06_conv_f32_traffic.json"):
+        """MFMA roofline of the fp32 convolution kernels over one step of pipeline `p_` (whose buffers hold its last step)."""
+        from tracklab_amd.backbones import common as bc
+        from tracklab_amd import _lib as _tl
+        lb_v, crops_v = p_.lb.permute(0, 3, 1, 2), p_.crops.permute(0, 3, 1, 2)     # logical NCHW views of the step's channels-last buffers
+        # r05: the ReID batch is dense -- the convolutions run on the step's REAL crops (n_live, read on the device), and the flops counted
+        # below are those crops', not the B x max_dets slots of the buffer
+        dense = bool(getattr(p_, "dense_reid", False))
+        live_crops = int(p_.n_live.item()) if dense else B * p_.maxd
+
+        def reid_eager():
+            if dense:
+                _tl.conv_set_dynamic_batch(p_.n_live)
+                bc.LIVE_BATCH = (B * p_.maxd, live_crops)
+            try:
+                p_.reid(crops_v)
+            finally:
+                if dense:
+                    _tl.conv_set_dynamic_batch(None)
+                    bc.LIVE_BATCH = None
+        with torch.no_grad():
+            p_.model(lb_v, focused=True); reid_eager()                       # warm (eager)
+            torch.cuda.synchronize()
+            bc.CONV_TIMER = []
+            for _ in range(2):
+                p_.model(lb_v, focused=True); reid_eager()
+                if p_.pose is not None:
+                    p_.pose(p_.pose_crops.permute(0, 3, 1, 2))
+            torch.cuda.synchronize()
+            recs, bc.CONV_TIMER = bc.CONV_TIMER, None
+        c_ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+        c_null = sum(r[2].elapsed_time(r[3]) for r in recs)
+        c_flop = sum(r[4] for r in recs)
+        tf = c_flop / ((c_ms - c_null) * 1e-3) / 1e12
+        # the same timings per kernel instantiation (rocprofv3 names them conv_f32_mfma_kernel<TM, TN, WGM, WGN, ACT, RES>): the rows of
+        # profiles/r06_config3_f32_rocprof.md to compare with
+        tmpl = {0: "2, 2, 2, 2", 1: "2, 2, 4, 1", 2: "2, 1, 2, 2", 3: "2, 3, 4, 1", 4: "2, 1, 4, 1", 5: "1, 2, 2, 2", 6: "1, 2, 4, 1",
+                7: "2, 2, 2, 2", 8: "2, 1, 2, 2", 9: "1, 2, 2, 2"}
+        per = {}
+        for r in recs:
+            cfg_, act_, res_ = r[5]
+            kn_ = "conv_stem3_kernel (direct RGB stem, tlk_conv_stem.hip)" if cfg_ == 15 else \
+                f"conv16x_kernel<{_tl.conv_f32_config_template(cfg_)}>" if cfg_ >= 21 else \
+                f"conv_f32_mfma_kernel<{tmpl.get(cfg_, '?')}, {act_}, {'true' if res_ else 'false'}, {1 if cfg_ in (7, 8, 9) else 2}>"
+            e = per.setdefault(kn_, [0, 0.0, 0.0])
+            e[0] += 1; e[1] += r[0].elapsed_time(r[1]) - r[2].elapsed_time(r[3]); e[2] += r[4]
+        per_inst = [{"kernel": k_, "launches_per_step": v_[0] // 2, "avg_launch_ms": v_[1] / v_[0], "tflops": v_[2] / (v_[1] * 1e-3) / 1e12}
+                    for k_, v_ in sorted(per.items(), key=lambda kv: -kv[1][1])]
+        rf = {"kernel": "conv_f32_mfma_kernel (tlk_conv2d_nhwc_f32: implicit GEMM on v_mfma_f32_32x32x2_f32, bias / residual / activation fused)",
+              "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None,
+              "launches_per_step": len(recs) // 2, "avg_launch_ms": (c_ms - c_null) / len(recs), "avg_launch_ms_events_raw": c_ms / len(recs),
+              "event_pair_overhead_ms": c_null / len(recs), "algorithmic_flops_per_launch": c_flop / len(recs),
+              "algorithmic_tflop_per_step": c_flop / 2 / 1e12, "conv_ms_per_step": (c_ms - c_null) / 2,
+              "exact_fp32_ceiling_frames_per_s": B / (c_flop / 2 / 157.3e12),
+              "algorithmic_bytes_per_launch": sum(r[6] for r in recs) / len(recs),
+              "units_per_launch": (f"one convolution of the step: {B} frames (detector) or the step's {live_crops} REAL crops (ReID, dense batch: "
+                                   f"{live_crops / B:.1f} per frame of {p_.maxd} slots)" if dense else
+                                   f"one convolution of the step: {B} frames (detector) or {B} x {p_.maxd} crop slots (ReID)") +
+                                  f"; mean over the {len(recs) // 2} convolutions of a step, flop-weighted",
+              "reid_crops_per_step": live_crops, "reid_crop_slots_per_step": B * p_.maxd,
+              "peak_source": "MI355X_MICROARCH.md: fp32-input MFMA 157.3 TFLOP/s dense (no reduced-precision fp32 path on gfx950)",
+              "per_instantiation": per_inst,
+              # the instantiation the step spends most of its time in, alone (the `frac` above is the flop-weighted mix of ALL the
+              # step's convolutions, the HBM-bound 1 x 1 expansions and the RGB stem included)
+              "dominant_instantiation": dict(per_inst[0], frac=per_inst[0]["tflops"] / 157.3,
+                                             share_of_conv_time=per_inst[0]["avg_launch_ms"] * per_inst[0]["launches_per_step"] / ((c_ms - c_null) / 2)),
+              "rocprofv3": "profiles/r06_config3_f32_rocprof.md: average duration of the same instantiations in the rocprofv3 --kernel-trace "
+                           "--stats run of the same command (the ReLU / linear ones are launched by the ReID network only, same mix per step)"}
+        # HBM bytes per convolution launch from the PMC passes of the same command (FETCH_SIZE x 2 + WRITE_SIZE, separate passes,
+        # tools/make_profiles_r06.sh pmc): counters cannot be collected from inside this process, so the figure is the committed one --
+        # `traffic_static` says so beside the number
+        for tf_ in (traffic_file, "r05_conv_f32_traffic.json"):
+            try:
+                tr = json.load(open(os.path.join(REPO, "profiles", tf_)))
+                if tr.get("workload") == workload_key:
+                    rf["traffic"] = tr["mean_traffic_bytes_per_conv_launch"]
+                    rf["traffic_static"] = True
+                    rf["traffic_source"] = (f"STATIC (not measured by this run): profiles/{tf_.replace('.json', '.md')} -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                            "passes of this command on an earlier box, mean over the step's convolution launches")
+                    rf["traffic_over_algorithmic_bytes"] = rf["traffic"] / rf["algorithmic_bytes_per_launch"]
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
+        return rf
+
     roofline_hbm = None
     if args.dtype == "f32" and is3:
         from tracklab_amd.backbones import common as bc
         if bc.USE_TLK_CONV_F32:
-            lb_v, crops_v = pipe.lb.permute(0, 3, 1, 2), pipe.crops.permute(0, 3, 1, 2)     # logical NCHW views of the step's channels-last buffers
-            # r05: the ReID batch is dense -- the convolutions run on the step's REAL crops (pipe.n_live, read on the device), and the flops counted
-            # below are those crops', not the B x max_dets slots of the buffer
-            dense = bool(getattr(pipe, "dense_reid", False))
-            live_crops = int(pipe.n_live.item()) if dense else B * pipe.maxd
-            from tracklab_amd import _lib as _tl
-
-            def reid_eager():
-                if dense:
-                    _tl.conv_set_dynamic_batch(pipe.n_live)
-                    bc.LIVE_BATCH = (B * pipe.maxd, live_crops)
-                try:
-                    pipe.reid(crops_v)
-                finally:
-                    if dense:
-                        _tl.conv_set_dynamic_batch(None)
-                        bc.LIVE_BATCH = None
-            with torch.no_grad():
-                pipe.model(lb_v, focused=True); reid_eager()                       # warm (eager)
-                torch.cuda.synchronize()
-                bc.CONV_TIMER = []
-                for _ in range(2):
-                    pipe.model(lb_v, focused=True); reid_eager()
-                    if pipe.pose is not None:
-                        pipe.pose(pipe.pose_crops.permute(0, 3, 1, 2))
-                torch.cuda.synchronize()
-                recs, bc.CONV_TIMER = bc.CONV_TIMER, None
-            c_ms = sum(r[0].elapsed_time(r[1]) for r in recs)
-            c_null = sum(r[2].elapsed_time(r[3]) for r in recs)
-            c_flop = sum(r[4] for r in recs)
-            tf = c_flop / ((c_ms - c_null) * 1e-3) / 1e12
             roofline_hbm = roofline
-            # the same timings per kernel instantiation (rocprofv3 names them conv_f32_mfma_kernel<TM, TN, WGM, WGN, ACT, RES>): the rows of
-            # profiles/r04_config3_f32_rocprof.md to compare with
-            tmpl = {0: "2, 2, 2, 2", 1: "2, 2, 4, 1", 2: "2, 1, 2, 2", 3: "2, 3, 4, 1", 4: "2, 1, 4, 1", 5: "1, 2, 2, 2", 6: "1, 2, 4, 1",
-                    7: "2, 2, 2, 2", 8: "2, 1, 2, 2", 9: "1, 2, 2, 2"}
-            # 21..33: the direct-to-LDS kernels of tlk_conv16x.hip on fp32 tensors, conv16x_kernel<WGM, WGN, TM, TN, MODE_F32 = 2, NST, RESPF, PATCH>
-            # (activation and residual are run-time switches there: one row per instantiation)
-            tmpl_x = {21: "2, 2, 2, 2, 2, 1, true, false", 22: "2, 2, 2, 2, 2, 1, false, false", 23: "4, 1, 2, 2, 2, 1, false, false",
-                      24: "2, 2, 2, 2, 2, 2, true, false", 25: "2, 2, 1, 2, 2, 1, true, false", 26: "4, 1, 2, 2, 2, 1, true, false",
-                      27: "4, 1, 2, 1, 2, 1, true, false", 28: "4, 1, 2, 1, 2, 2, true, false", 29: "4, 1, 4, 1, 2, 1, true, false",
-                      30: "4, 1, 2, 1, 2, 1, true, true", 31: "4, 1, 2, 1, 2, 1, false, true", 32: "4, 1, 1, 1, 2, 1, true, true",
-                      33: "2, 1, 2, 1, 2, 1, true, true"}
-            per = {}
-            for r in recs:
-                cfg_, act_, res_ = r[5]
-                kn_ = "conv_stem3_kernel (direct RGB stem, tlk_conv_stem.hip)" if cfg_ == 15 else \
-                    f"conv16x_kernel<{tmpl_x[cfg_]}>" if cfg_ in tmpl_x else \
-                    f"conv_f32_mfma_kernel<{tmpl.get(cfg_, '?')}, {act_}, {'true' if res_ else 'false'}, {1 if cfg_ in (7, 8, 9) else 2}>"
-                e = per.setdefault(kn_, [0, 0.0, 0.0])
-                e[0] += 1; e[1] += r[0].elapsed_time(r[1]) - r[2].elapsed_time(r[3]); e[2] += r[4]
-            per_inst = [{"kernel": k_, "launches_per_step": v_[0] // 2, "avg_launch_ms": v_[1] / v_[0], "tflops": v_[2] / (v_[1] * 1e-3) / 1e12}
-                        for k_, v_ in sorted(per.items(), key=lambda kv: -kv[1][1])]
-            roofline = {"kernel": "conv_f32_mfma_kernel (tlk_conv2d_nhwc_f32: implicit GEMM on v_mfma_f32_32x32x2_f32, bias / residual / activation fused)",
-                        "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None,
-                        "launches_per_step": len(recs) // 2, "avg_launch_ms": (c_ms - c_null) / len(recs), "avg_launch_ms_events_raw": c_ms / len(recs),
-                        "event_pair_overhead_ms": c_null / len(recs), "algorithmic_flops_per_launch": c_flop / len(recs),
-                        "algorithmic_tflop_per_step": c_flop / 2 / 1e12, "conv_ms_per_step": (c_ms - c_null) / 2,
-                        "algorithmic_bytes_per_launch": sum(r[6] for r in recs) / len(recs),
-                        "units_per_launch": (f"one convolution of the step: {B} frames (detector) or the step's {live_crops} REAL crops (ReID, dense batch: "
-                                             f"{live_crops / B:.1f} per frame of {pipe.maxd} slots)" if dense else
-                                             f"one convolution of the step: {B} frames (detector) or {B} x {pipe.maxd} crop slots (ReID)") +
-                                            f"; mean over the {len(recs) // 2} convolutions of a step, flop-weighted",
-                        "reid_crops_per_step": live_crops, "reid_crop_slots_per_step": B * pipe.maxd,
-                        "peak_source": "MI355X_MICROARCH.md: fp32-input MFMA 157.3 TFLOP/s dense (no reduced-precision fp32 path on gfx950)",
-                        "per_instantiation": per_inst,
-                        # the instantiation the step spends most of its time in, alone (the `frac` above is the flop-weighted mix of ALL the
-                        # step's convolutions, the HBM-bound 1 x 1 expansions and the RGB stem included)
-                        "dominant_instantiation": dict(per_inst[0], frac=per_inst[0]["tflops"] / 157.3,
-                                                       share_of_conv_time=per_inst[0]["avg_launch_ms"] * per_inst[0]["launches_per_step"] / ((c_ms - c_null) / 2)),
-                        "rocprofv3": "profiles/r05_config3_f32_rocprof.md: average duration of the same instantiations in the rocprofv3 --kernel-trace "
-                                     "--stats run of the same command (the ReLU / linear ones are launched by the ReID network only, same mix per step)"}
-            # HBM bytes per convolution launch from the PMC passes of the same command (FETCH_SIZE x 2 + WRITE_SIZE, separate passes,
-            # tools/make_profiles_r05.sh pmc): counters cannot be collected from inside this process, so the figure is the committed one
-            try:
-                tr = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_conv_f32_traffic.json")))
-                if tr.get("workload") == args.workload:
-                    roofline["traffic"] = tr["mean_traffic_bytes_per_conv_launch"]
-                    roofline["traffic_source"] = ("static: profiles/r05_conv_f32_traffic.md -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an "
-                                                  "earlier box (mean over the step's convolution launches), not measured by this run")
-                    roofline["traffic_over_algorithmic_bytes"] = roofline["traffic"] / roofline["algorithmic_bytes_per_launch"]
-            except (OSError, ValueError, KeyError):
-                pass
+            roofline = conv_roofline(pipe, args.workload)
 
     # ---- small-step legs: the same chain at frames_per_step 1 / 2 / 4 and at 4 streams x 1 frame (what an online consumer sees; the
     # reference's online engine is per-frame, engine/video.py:67-117). Each: pipelined frames/s, un-overlapped frame-in -> rows-out time,
@@ -919,9 +951,13 @@ def main():
     # activations carried as (hi, lo) f16 pairs, three f16 MFMAs per product pair, fp32 accumulation -- fp32-class results (the same fp64
     # bound as the exact kernel, tests/test_gpu_conv16.py) at a multiple of the fp32 MFMA rate; an f16 run times fp32.  Every leg: same
     # steps / warm-up policy, frames resident, 48 frames of ids checked against the oracle chain ----
-    def precision_leg(name, dtype_name, split):
+    def precision_leg(name, dtype_name, split, reid_arch=None, with_roofline=None, split_detector=False):
         import oracle
         kw = {k_: wl[k_] for k_ in ("dim", "reid_arch") if k_ in wl}
+        if reid_arch is not None:
+            kw["reid_arch"] = reid_arch
+        if split_detector:
+            kw["detector_split_precision"] = True
         pf = gp.DetReidTrackPipeline(detector, n_streams=S, frames_per_step=F, max_dets=wl["max_dets"], device=dev.index, use_graph=not args.no_graph,
                                      pose=wl.get("pose"), tracker=wl.get("tracker", "bpbreid"), dtype=getattr(torch, DTYPES[dtype_name]),
                                      reid_split_precision=split, **kw)
@@ -948,6 +984,9 @@ def main():
         ela = timed_resident(pf, n_alt, w_alt)
         leg = {"dtype": name, "value": n_alt * B / ela, "ms_per_step": ela / n_alt * 1e3, "steps": n_alt, "warmup": w_alt, "frames_resident": True,
                "parity": {"frames": nfr, "track_ids_equal_oracle": bool(okf)}}
+        if with_roofline is not None:
+            pf.synchronize()
+            leg["roofline"] = with_roofline(pf)
         pf.close()
         del pf
         return leg, emb_first
@@ -981,6 +1020,23 @@ def main():
                                  "computed with v_mfma_f32_32x32x2_f32")
     f32_leg = alt_leg if alt_leg and alt_name == "f32" else None
 
+    # ---- the ReID backbone the reference's yaml selects (tracklab/configs/modules/reid/bpbreid.yaml:53 backbone: "hrnet32"), driver-visible
+    # (VERDICT r05 missing 3): the same step with HRNet-W32 behind the same part-based head, exact fp32, ids checked against the oracle chain,
+    # its own convolution roofline.  The headline stays on ResNet-50 (an option the same yaml line lists; the r01-r05 numbers are quoted on it)
+    hrnet_leg = None
+    if rank == 0 and world == 1 and args.workload == "config3" and args.dtype == "f32" and not args.no_hrnet_leg and not args.no_f32_leg:
+        try:
+            hrnet_leg, _ = precision_leg("f32 (exact), ReID backbone HRNet-W32 (bpbreid.yaml:53)", "f32", False, reid_arch="hrnet32",
+                                         with_roofline=lambda pf_: conv_roofline(pf_, "config3h"))
+            hrnet_leg["workload"] = WORKLOADS["config3h"]["name"]
+            r_ = hrnet_leg["roofline"]
+            hrnet_leg["roofline"] = {k_: r_[k_] for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_launch_ms",
+                                                            "algorithmic_tflop_per_step", "conv_ms_per_step", "exact_fp32_ceiling_frames_per_s",
+                                                            "reid_crops_per_step", "dominant_instantiation") if k_ in r_}
+            hrnet_leg["roofline"]["per_instantiation_top5"] = r_["per_instantiation"][:5]
+        except Exception as ex:                                 # noqa: BLE001  (a side leg must not cost the run its line)
+            hrnet_leg = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+
     # ---- CPU baseline: (a) the same chain on host cores (oracle C port + torch CPU fp32 forwards), warm, bounded sample;
     # (b) SURVEY 8d's form: the hand-written stages only (oracle C twins, backbones excluded), one thread and all cores ----
     cpu = None
@@ -1010,8 +1066,9 @@ def main():
             "per_gpu_fps": value / world, "per_rank_fps": per_rank, "ranks_seen": seen,
             "rank_placement": placement, "rank_placement_note": "[rank, NUMA node of its GPU, host CPUs it is pinned to]; node -1 = unpinned (a single rank, or /sys did not say)",
             "rank_placement_sound": tdist.placement_is_sound(placement, int(os.environ.get("LOCAL_WORLD_SIZE", world)), os.cpu_count() or 1),
-            "warmup_serialized": world > 1,
-            "collectives": "nccl" if dist is not None else None, "hota_allreduce": hota_all,
+            "warmup_serialized": warm_serialized,
+            "warmup_serialized_note": "measured: every rank held the node-wide warm-up lock and the gathered (enter, exit) windows are disjoint; null at one rank",
+            "collectives": dist_note, "hota_allreduce": hota_all,
             "latency": latency, "latency_f16": latency_f16, "latency_f16_overlap": latency_f16_overlap, "value_f32": (f32_leg["value"] if f32_leg else (value if args.dtype == "f32" else None)),
             "ms_per_step_f32": (f32_leg["ms_per_step"] if f32_leg else (el / args.steps * 1e3 if args.dtype == "f32" else None)),
             "f32_leg": f32_leg,
@@ -1021,10 +1078,16 @@ def main():
             "value_f32_split": split_leg["value"] if split_leg else None,
             "ms_per_step_f32_split": split_leg["ms_per_step"] if split_leg else None,
             "f32_split_leg": split_leg,
+            "value_hrnet32": hrnet_leg.get("value") if hrnet_leg else None,
+            "ms_per_step_hrnet32": hrnet_leg.get("ms_per_step") if hrnet_leg else None,
+            "hrnet32_leg": hrnet_leg,
             "precision_note": ("value is measured with fp32 backbones, the reference's precision (configs/modules/track/strong_sort.yaml:10 fp16: false; "
                                "ONNXRuntime / torchreid fp32): exact fp32 MFMA, no reduced-precision path exists on gfx950. One step is "
-                               "~32 TFLOP of convolutions, so 157.3 TFLOP/s (the chip's dense fp32 peak) bounds this configuration at "
-                               "~118 frames/s; roofline.frac says how close the kernel is") if args.dtype == "f32" else
+                               + (f"{roofline['algorithmic_tflop_per_step']:.1f} TFLOP of convolutions over the step's live crops, so 157.3 TFLOP/s (the chip's dense "
+                                  f"fp32 peak) bounds this configuration at {roofline['exact_fp32_ceiling_frames_per_s']:.0f} frames/s"
+                                  if isinstance(roofline, dict) and "algorithmic_tflop_per_step" in roofline else
+                                  "bounded by the chip's dense fp32 peak, 157.3 TFLOP/s") +
+                               "; roofline.frac says how close the kernels are") if args.dtype == "f32" else
                               "value is measured with backbones narrower than the reference's fp32; value_f32 is the reference-precision number",
             "roofline": roofline, "roofline_hbm": roofline_hbm, "cpu_baseline": cpu, "parity": parity,
         }

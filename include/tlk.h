@@ -650,8 +650,11 @@ int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const float *bia
                         int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int act_kind,
                         int x_pix_stride, int y_pix_stride, int res_pix_stride, void *hip_stream);
 /* Probes / tests: force one of the kernel's tile configurations (0: 128x128, 1: 256x64, 2: 128x64, 3: 256x96, 4: 256x32, 5: 64x128, 6: 128x64 (waves stacked)
- * pixels x output channels; r05: 7 / 8 / 9 = 128x128 / 128x64 / 64x128 with ONE LDS stage and the epilogue in passes; 21..26 = the direct-to-LDS
- * kernels of tlk_conv16x.hip on fp32 tensors (need cin % 32 == 0)); -1 = the heuristic.  Results do not depend on it: one fmaf chain, as above. */
+ * pixels x output channels; r05: 7 / 8 / 9 = 128x128 / 128x64 / 64x128 with ONE LDS stage and the epilogue in passes; 21..33 = the direct-to-LDS
+ * kernels of tlk_conv16x.hip on fp32 tensors (need cin % 32 == 0), of which 30..33 are the PATCH-resident 3 x 3 kernels: stride 1, pad 1,
+ * cin == 32 exactly, tiles of whole image rows (8 <= wo <= 64, tile rows a multiple of wo, ho * wo a multiple of the tile) -- TLK_EINVAL
+ * names the violated constraint; the heuristic routes 32-wide layers to 27 / 31 by itself); -1 = the heuristic.  Results do not depend
+ * on it: one fmaf chain, as above. */
 int tlk_conv2d_set_config(int cfg);
 /* Tile configuration the most recent tlk_conv2d_nhwc_f32 call of this process launched (as above; 15 = the direct RGB stem kernel), -1 before the first. */
 int tlk_conv2d_last_config(void);
@@ -661,7 +664,8 @@ int tlk_conv2d_last_config(void);
  * n_images_dev[0] WHEN THE KERNEL RUNS and treats the `n` of the call as the capacity; rows beyond are neither read nor written and the
  * workgroups beyond them leave at once.  This is how the ReID batch of a step is convolved on its real crops only (the reference batches real
  * detections only, tracklab/wrappers/reid/kpreid_api.py:147-182) from ONE captured graph.  NULL switches it off.  Applies to
- * tlk_conv2d_nhwc_f32 and tlk_conv2d_nhwc_16. */
+ * tlk_conv2d_nhwc_f32, tlk_conv2d_nhwc_16, tlk_conv_stem16_nhwc and tlk_maxpool2d_nhwc.  The setting belongs to the CALLING HOST THREAD
+ * (thread-local): launches of other threads are not affected; set it, launch (or capture), clear it -- in one thread. */
 int tlk_conv_set_dynamic_batch(const int32_t *n_images_dev);
 
 /* The same convolution on the 16-bit MFMA (v_mfma_f32_32x32x16_f16; tlk_conv16.hip), two modes selected by the pointers given:
@@ -742,6 +746,34 @@ int tlk_conv_stem16_nhwc(const void *x_dev, const void *packed_w_dev, const floa
  * hipBLASLt or a matching algorithm is missing (callers fall back to GEMM + tlk_bias_act_nhwc, still on the GPU). */
 int tlk_gemm_bias_act(const void *x_dev, const void *w_dev, const void *bias_dev, const void *residual_dev, void *out_dev,
                       long long M, int N, int K, int act, int dtype, void *hip_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * r06: the prediction heads of the two networks of the path, ONE launch each (tlk_heads.hip).  Not reference functions (the reference's heads
+ * run inside third-party graphs: rtmlib's YOLOX ONNX model behind tracklab/wrappers/bbox_detector/rtmlib_api.py:21,30; the torchreid fork's
+ * BPBReID / KPR model behind tracklab/wrappers/reid/kpreid_api.py:147-182) -- they replace the 1 / 4 / 6-channel library convolutions and the
+ * element-wise torch passes that followed them (~40 + ~14 launches per step).
+ * Arithmetic contract (oracle/src/heads.c): every dot product is ONE fmaf chain over the channels ascending from 0, then + bias;
+ * sigmoid(v) = 1 / (1 + exp(-v)); softmax over k = exp(l_k - max_k l) / (sum over k ascending); pooled sums are fmaf chains over the pixels
+ * ascending.  Bit-exact against the oracle except for the device's exp (the tests allow 2e-6 relative behind an exp).
+ *
+ * tlk_yolox_head_nhwc: YOLOX's decoupled head outputs for `levels` (<= 4) pyramid levels.  Per level l: cls_feat[l] / reg_feat[l] are the
+ *   (batch, hw[l], channels) NHWC outputs of the classification / regression branches (dtype TLK_F32 or TLK_F16, pixel strides in elements,
+ *   0 = dense, 16-byte aligned), w[l] is (5 + num_classes, channels) fp32 -- rows 0..3 the reg prediction, 4 the obj prediction (both read
+ *   reg_feat), 5.. the cls predictions (read cls_feat) -- and b[l] the 5 + num_classes fp32 biases.  out (batch, A, 5 + num_classes) fp32,
+ *   A = sum hw[l], level l at anchors [sum_{i<l} hw[i], +hw[l]): [reg0..3 raw, sigmoid(obj), sigmoid(cls...)] -- the tensor
+ *   tlk_yolox_decode_nms consumes.  The pointer arrays are HOST arrays of device pointers.
+ * tlk_reid_part_head: feat (rows_dense, hw, dim) NHWC feature map (TLK_F32 / TLK_F16), w (parts, dim) / b (parts) fp32 pixel-wise part
+ *   classifier; for every output row r: att = softmax_k(w . feat[p] + b) per pixel p, emb[r,k,:] = sum_p att[p,k] feat[p,:] / max(sum_p att[p,k], 1e-6),
+ *   vis[r,k] = (k == 0) || (max_p att[p,k] > vis_threshold)  (pass the model's threshold / parts).  With counts (frames, i32) and max_dets:
+ *   rows = frames * max_dets, row r = (frame b, slot j) is live when j < counts[b] and reads dense row slot_base[b] + j (slot_base NULL:
+ *   row r itself); padding rows are ZERO-FILLED (emb and vis).  nonfinite_flag (1 byte, nullable) is set to 1 when a live embedding
+ *   value is NaN or infinite (never cleared here).  dim % (16 bytes of elements) == 0, dim <= 512, parts <= 8. */
+int tlk_yolox_head_nhwc(const void *const *cls_feat_dev, const void *const *reg_feat_dev, const int *hw, const int *cls_pix_stride,
+                        const int *reg_pix_stride, const float *const *w_dev, const float *const *b_dev, int levels, int batch, int channels,
+                        int num_classes, int dtype, float *out_dev, void *hip_stream);
+int tlk_reid_part_head(const void *feat_dev, int feat_pix_stride, int dtype, int hw, int dim, int parts, const float *w_dev, const float *b_dev,
+                       const int32_t *counts_dev, const int32_t *slot_base_dev, int rows, int max_dets, float vis_threshold,
+                       float *emb_dev, unsigned char *vis_dev, unsigned char *nonfinite_flag_dev, void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -118,3 +118,34 @@ def test_serialized_lock_excludes_across_processes(tmp_path):
         assert not tdist.placement_is_sound([[0, -1, 16], [1, -1, 16]], 2, 16)
     finally:
         os.environ.pop("TLK_LOCK_DIR", None)
+
+
+def test_serialized_lock_survives_an_unusable_lock_directory(tmp_path):
+    """a lock file that cannot be opened (directory gone, a file another user left behind) must not cost the job its warm-up: the
+    section runs unlocked and says so; the file name carries the uid so that another user's file is never touched."""
+    from tracklab_amd import dist as tdist
+    os.environ["TLK_LOCK_DIR"] = str(tmp_path / "does" / "not" / "exist")
+    try:
+        order = []
+        with tdist.serialized("t", order=order) as s:
+            assert s.locked is False
+        assert [e for e, _ in order] == ["enter", "exit"]
+        assert f"_{os.getuid()}_" in os.path.basename(s.path)
+    finally:
+        os.environ.pop("TLK_LOCK_DIR", None)
+
+
+def test_single_rank_process_group_runs_the_collectives_on_a_real_backend():
+    """the N = 1 bench line initialises a one-rank process group so that barrier / all-reduce / all-gather run on the job's
+    backend (RCCL on the GPU box; gloo here) instead of being skipped."""
+    code = ("import numpy as np, torch\n"
+            "from tracklab_amd import dist as tdist\n"
+            "d = tdist.init_single('gloo')\n"
+            "assert d.is_initialized() and d.get_world_size() == 1\n"
+            "d.barrier()\n"
+            "assert tdist.allreduce_max(3.5, d, torch.device('cpu')) == 3.5\n"
+            "assert np.array_equal(tdist.allreduce_sum(np.arange(4.0), d, torch.device('cpu')), np.arange(4.0))\n"
+            "d.destroy_process_group()\n"
+            "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=_env(), cwd=REPO)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

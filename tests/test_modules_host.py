@@ -434,3 +434,18 @@ def test_unpinned_camera_motion_warns_once_per_estimator(caplog):
         assert msgs == []
     else:
         assert len(msgs) == 2 and "UNPINNED" in msgs[0] and "cmc_method: none" in msgs[0] and "ecc: false" in msgs[1]
+
+
+def test_camera_motion_fixture_is_found_through_the_environment(caplog, tmp_path, monkeypatch):
+    """an installed package has no tests/ directory beside it; the fixture is then named by TLK_CMC_FIXTURE (or shipped as package
+    data) and the warning stays silent."""
+    import logging
+    from tracklab_amd.wrappers import track
+    f = tmp_path / "cmc_opencv.npz"
+    f.write_bytes(b"x")
+    monkeypatch.setenv("TLK_CMC_FIXTURE", str(f))
+    track._CAMERA_MOTION_WARNED.clear()
+    with caplog.at_level(logging.WARNING, logger=track.__name__):
+        track._warn_unpinned_camera_motion("HipBoTSORT")
+    assert [r.getMessage() for r in caplog.records] == []
+    track._CAMERA_MOTION_WARNED.clear()

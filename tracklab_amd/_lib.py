@@ -1042,6 +1042,19 @@ def conv2d_nhwc_f32(x, weight, bias=None, act=None, residual=None, stride=1, pad
     return out
 
 
+# tlk_conv2d_nhwc_f32 configurations 21..: the direct-to-LDS kernels of csrc/tlk_conv16x.hip on fp32 tensors, as rocprofv3 names them --
+# conv16x_kernel<WGM, WGN, TM, TN, MODE_F32 = 2, NST, RESPF, PATCH> (activation and residual are run-time switches there)
+CONV_F32_X_TEMPLATES = {21: "2, 2, 2, 2, 2, 1, true, false", 22: "2, 2, 2, 2, 2, 1, false, false", 23: "4, 1, 2, 2, 2, 1, false, false",
+                        24: "2, 2, 2, 2, 2, 2, true, false", 25: "2, 2, 1, 2, 2, 1, true, false", 26: "4, 1, 2, 2, 2, 1, true, false",
+                        27: "4, 1, 2, 1, 2, 1, true, false", 28: "4, 1, 2, 1, 2, 2, true, false", 29: "4, 1, 4, 1, 2, 1, true, false",
+                        30: "4, 1, 2, 1, 2, 1, true, true", 31: "4, 1, 2, 1, 2, 1, false, true", 32: "4, 1, 1, 1, 2, 1, true, true",
+                        33: "2, 1, 2, 1, 2, 1, true, true"}
+
+
+def conv_f32_config_template(cfg: int) -> str:
+    return CONV_F32_X_TEMPLATES.get(int(cfg), f"configuration {int(cfg)}")
+
+
 def _pix16(t, c, h, w):
     """pixel stride (elements) of an NHWC tensor or channel slice of one, logical shape (N, C, H, W)"""
     sn, sc, sh, sw = t.stride()
@@ -1052,6 +1065,76 @@ def _pix16(t, c, h, w):
     assert (sc == 1 or c == 1) and (w == 1 or h == 1 or sh == w * sw) and (t.shape[0] == 1 or sn == h * w * pix), \
         "tensor must be channels_last (or a channel slice of one)"
     return pix
+
+
+def yolox_head(cls_feats, reg_feats, weights, biases, num_classes=1, out=None):
+    """YOLOX's decoupled head outputs for all pyramid levels in ONE launch (``tlk_yolox_head_nhwc``, r06).
+    cls_feats / reg_feats: per level (B, C, H, W) cuda tensors in channels_last memory (float32 or float16: the branch outputs); weights: per level
+    (5 + num_classes, C) float32 [reg 0..3 | obj | cls...]; biases (5 + num_classes,) float32.  Returns (B, A, 5 + num_classes) float32:
+    [reg raw, sigmoid(obj), sigmoid(cls)], levels concatenated along the anchors -- what ``yolox_decode_nms`` consumes."""
+    import torch
+    L = lib()
+    if not getattr(L, "_heads_bound", False):
+        _bind_heads(L)
+    nl = len(cls_feats)
+    x0 = cls_feats[0]
+    B, Cc = x0.shape[0], x0.shape[1]
+    hw = [int(f.shape[2] * f.shape[3]) for f in cls_feats]
+    A = sum(hw)
+    NO = 5 + num_classes
+    if out is None:
+        out = torch.empty((B, A, NO), dtype=torch.float32, device=x0.device)
+    assert out.shape == (B, A, NO) and out.dtype == torch.float32 and out.is_contiguous()
+    for cf, rf, w, b in zip(cls_feats, reg_feats, weights, biases):
+        assert cf.dtype == x0.dtype and rf.dtype == x0.dtype and cf.shape == rf.shape and cf.shape[:2] == (B, Cc)
+        assert w.dtype == torch.float32 and w.shape == (NO, Cc) and w.is_contiguous() and b.dtype == torch.float32 and b.shape == (NO,)
+    vp = C.c_void_p * nl
+    ip = C.c_int * nl
+    check(L.tlk_yolox_head_nhwc(vp(*[f.data_ptr() for f in cls_feats]), vp(*[f.data_ptr() for f in reg_feats]), ip(*hw),
+                                ip(*[_pix16(f, Cc, f.shape[2], f.shape[3]) for f in cls_feats]), ip(*[_pix16(f, Cc, f.shape[2], f.shape[3]) for f in reg_feats]),
+                                vp(*[w.data_ptr() for w in weights]), vp(*[b.data_ptr() for b in biases]), nl, B, Cc, num_classes,
+                                _dtype_code(x0.dtype), out.data_ptr(), current_stream_ptr()))
+    return out
+
+
+def reid_part_head(feat, weight, bias, vis_threshold, counts=None, slot_base=None, max_dets=0, out_emb=None, out_vis=None, flag=None):
+    """The part-based ReID head in ONE launch (``tlk_reid_part_head``, r06): feat (N, D, h, w) cuda tensor in channels_last memory (float32 /
+    float16), weight (K, D) float32, bias (K,) float32 -> emb (rows, K, D) float32, vis (rows, K) uint8.  counts (frames,) int32 + max_dets:
+    rows = frames * max_dets in the tracker's (frame, slot) layout, padding rows zero-filled; slot_base (frames,) int32: the rows are read from
+    the DENSE batch (``crop_slot_bases``).  flag: 1-element bool / uint8 cuda tensor, set when a live embedding is not finite.
+    vis_threshold: the model's threshold already divided by the part count."""
+    import torch
+    L = lib()
+    if not getattr(L, "_heads_bound", False):
+        _bind_heads(L)
+    N, D, h, w = feat.shape
+    K = weight.shape[0]
+    assert feat.is_cuda and feat.dtype in (torch.float32, torch.float16)
+    assert weight.dtype == torch.float32 and weight.shape == (K, D) and weight.is_contiguous() and bias.dtype == torch.float32 and bias.shape == (K,)
+    rows = N if counts is None else counts.numel() * max_dets
+    if counts is not None:
+        assert counts.dtype == torch.int32 and counts.is_contiguous() and max_dets > 0 and (slot_base is not None or rows <= N)
+    if slot_base is not None:
+        assert slot_base.dtype == torch.int32 and slot_base.numel() == counts.numel() and slot_base.is_contiguous()
+    if out_emb is None:
+        out_emb = torch.empty((rows, K, D), dtype=torch.float32, device=feat.device)
+    if out_vis is None:
+        out_vis = torch.empty((rows, K), dtype=torch.uint8, device=feat.device)
+    assert out_emb.numel() == rows * K * D and out_emb.dtype == torch.float32 and out_emb.is_contiguous()
+    assert out_vis.numel() == rows * K and out_vis.dtype in (torch.uint8, torch.bool) and out_vis.is_contiguous()
+    assert flag is None or (flag.numel() == 1 and flag.dtype in (torch.uint8, torch.bool))
+    check(L.tlk_reid_part_head(feat.data_ptr(), _pix16(feat, D, h, w), _dtype_code(feat.dtype), h * w, D, K, weight.data_ptr(), bias.data_ptr(),
+                               counts.data_ptr() if counts is not None else None, slot_base.data_ptr() if slot_base is not None else None,
+                               rows, max_dets, float(vis_threshold), out_emb.data_ptr(), out_vis.data_ptr(),
+                               flag.data_ptr() if flag is not None else None, current_stream_ptr()))
+    return out_emb, out_vis
+
+
+def _bind_heads(L):
+    L.tlk_yolox_head_nhwc.argtypes = [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p]
+    L.tlk_reid_part_head.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L._heads_bound = True
 
 
 def dwconv2d_nhwc(x, weight_kkc, bias32=None, act=None, out=None):

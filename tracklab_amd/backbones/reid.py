@@ -16,6 +16,9 @@ from .common import ConvBiasAct, SplitAct, finalize, random_init_
 
 import os as _os
 USE_TLK_MAXPOOL = _os.environ.get("TLK_MAXPOOL", "1") != "0"       # 0: torch's max_pool2d (A/B runs)
+# r06: the part-based head (6-channel convolution, softmax, attention pooling, visibility, hand-off gather, non-finite check) as ONE libtlk
+# launch (tlk_reid_part_head); TLK_HEADS=0 restores the library convolution + torch passes for A/B runs
+USE_TLK_HEADS = _os.environ.get("TLK_HEADS", "1") != "0"
 
 
 class _Bottleneck(nn.Module):
@@ -164,14 +167,34 @@ class PartBasedReID(nn.Module):
         self.part_cls = nn.Conv2d(dim, parts, 1, bias=True)   # foreground + (parts-1) body parts
         self.parts, self.dim, self.vis_threshold, self.arch = parts, dim, vis_threshold, arch
 
-    def forward(self, x):
+    def features(self, x):
+        """backbone + dimension reduction: (N, D, h, w) feature map the head pools over"""
         if getattr(self, "split_precision", False) and self.arch == "resnet50" and x.is_cuda and x.dtype == torch.float32:
             # fp32 weights, fp32-class arithmetic on the 16-bit MFMA: every convolution of the backbone behind the stem in split mode
             # (csrc/tlk_conv16x.hip; the stem + pool in exact fp32), `reduce` hands fp32 back to the head below
             self.reduce.out_f32 = True
-            f = self.reduce(self.backbone(x, split=True))
-        else:
-            f = self.reduce(self.backbone(x))                # (N, D, h, w)
+            return self.reduce(self.backbone(x, split=True))
+        return self.reduce(self.backbone(x))                 # (N, D, h, w)
+
+    def fused_head_ok(self, f):
+        return USE_TLK_HEADS and f.is_cuda and f.dtype in (torch.float32, torch.float16) and f.shape[1] % 8 == 0 and f.shape[1] <= 512 \
+            and self.parts <= 8 and f.is_contiguous(memory_format=torch.channels_last)
+
+    def head(self, f, counts=None, slot_base=None, max_dets=0, out_emb=None, out_vis=None, flag=None):
+        """(N, D, h, w) feature map -> (emb (rows, K, D) float32, vis (rows, K) bool).  On the GPU one libtlk launch; with counts (+ slot_base:
+        dense batch) the rows come out in the tracker's (frame, slot) layout, padding rows zero, `flag` set when a live embedding is not finite."""
+        if self.fused_head_ok(f):
+            from .. import _lib
+            from .common import param_key
+            c = getattr(self, "_head_w", None)
+            key = param_key(self.part_cls.weight, self.part_cls.bias)
+            if c is None or c[0] != key:
+                c = (key, self.part_cls.weight.detach().reshape(self.parts, -1).float().contiguous(), self.part_cls.bias.detach().float().contiguous())
+                self._head_w = c
+            emb, vis = _lib.reid_part_head(f, c[1], c[2], self.vis_threshold / self.parts, counts, slot_base, max_dets, out_emb, out_vis, flag)
+            rows = emb.numel() // (self.parts * self.dim)
+            return emb.view(rows, self.parts, self.dim), (vis.view(torch.bool) if vis.dtype == torch.uint8 else vis).view(rows, self.parts)
+        assert counts is None and slot_base is None, "the (frame, slot) hand-off layout is written by the libtlk head only"
         att = torch.softmax(self.part_cls(f).float(), dim=1)  # (N, K, h, w) pixel-wise part attention
         ff = f.float().flatten(2)                            # (N, D, hw)
         a = att.flatten(2)                                   # (N, K, hw)
@@ -179,6 +202,9 @@ class PartBasedReID(nn.Module):
         vis = a.amax(-1) > self.vis_threshold / self.parts
         vis[:, 0] = True
         return emb.contiguous(), vis
+
+    def forward(self, x):
+        return self.head(self.features(x))
 
 
 def part_based_reid(parts=6, dim=256, device="cuda", dtype=torch.float16, channels_last=True, seed=0, arch="resnet50", split_precision=False):

@@ -22,6 +22,10 @@ import os as _os
 # CSPLayer: the two halves of the concatenation written in place by the convolutions that produce them (libtlk routes); 0 = torch.cat
 USE_SLICE_CONCAT = _os.environ.get("TLK_SLICE_CONCAT", "1") != "0"
 
+# r06: the nine 1 / 4 / num_classes-channel prediction convolutions + sigmoid / cat / flatten / permute / cast of the head as ONE libtlk launch
+# (tlk_yolox_head_nhwc); TLK_HEADS=0 restores the library convolutions + torch glue for A/B runs
+USE_TLK_HEADS = _os.environ.get("TLK_HEADS", "1") != "0"
+
 SIZES = {"tiny": (0.33, 0.375), "s": (0.33, 0.50), "m": (0.67, 0.75), "l": (1.0, 1.0), "x": (1.33, 1.25)}
 
 
@@ -144,11 +148,36 @@ class Head(nn.Module):
         self.reg_preds = nn.ModuleList([nn.Conv2d(c, 4, 1) for _ in ins])
         self.obj_preds = nn.ModuleList([nn.Conv2d(c, 1, 1) for _ in ins])
 
+    def _packed_preds(self):
+        """per level: (5 + num_classes, C) float32 rows [reg 0..3 | obj | cls...] and their biases, cached on the parameters' version"""
+        from .common import param_key
+        ps = [t for k in range(len(self.stems)) for m in (self.reg_preds[k], self.obj_preds[k], self.cls_preds[k]) for t in (m.weight, m.bias)]
+        key = param_key(*ps)
+        c = getattr(self, "_pk", None)
+        if c is None or c[0] != key:
+            ws, bs = [], []
+            for k in range(len(self.stems)):
+                mods = (self.reg_preds[k], self.obj_preds[k], self.cls_preds[k])
+                ws.append(torch.cat([m.weight.detach().reshape(m.out_channels, -1) for m in mods], 0).float().contiguous())
+                bs.append(torch.cat([m.bias.detach() for m in mods], 0).float().contiguous())
+            c = (key, ws, bs)
+            self._pk = c
+        return c[1], c[2]
+
     def forward(self, feats):
-        outs = []
+        cfs, rfs = [], []
         for k, x in enumerate(feats):
             x = self.stems[k](x)
-            cf, rf = self.cls_convs[k](x), self.reg_convs[k](x)
+            cfs.append(self.cls_convs[k](x))
+            rfs.append(self.reg_convs[k](x))
+        x0 = cfs[0]
+        if USE_TLK_HEADS and x0.is_cuda and x0.dtype in (torch.float32, torch.float16) and x0.shape[1] % (8 if x0.dtype == torch.float16 else 4) == 0 \
+                and x0.shape[1] <= 1024 and all(t.is_contiguous(memory_format=torch.channels_last) for t in cfs + rfs):
+            from .. import _lib
+            ws, bs = self._packed_preds()
+            return _lib.yolox_head(cfs, rfs, ws, bs, self.cls_preds[0].out_channels)      # (B, A, 5+C) float32, one launch
+        outs = []
+        for k, (cf, rf) in enumerate(zip(cfs, rfs)):
             o = torch.cat([self.reg_preds[k](rf), self.obj_preds[k](rf).sigmoid(), self.cls_preds[k](cf).sigmoid()], 1)
             outs.append(o.flatten(2))
         return torch.cat(outs, 2).permute(0, 2, 1).float().contiguous()      # (B, A, 5+C)

@@ -378,7 +378,8 @@ int pick_x32(const ConvArgs &a, int cout, bool has_res)
 }
 
 int g_force_cfg = -1;     // tlk_conv2d_set_config (probes / tests): -1 = heuristic
-const int *g_dyn_batch = nullptr;      // tlk_conv_set_dynamic_batch
+thread_local const int *g_dyn_batch = nullptr;      // tlk_conv_set_dynamic_batch: per HOST THREAD (a process-global pointer silently truncated the batches
+                                                    // of any other thread's / pipeline's launches while it was set)
 int g_last_cfg = -1;      // configuration of the most recent launch (tlk_conv2d_last_config: bench.py groups its event timings by kernel instantiation)
 
 }  // namespace

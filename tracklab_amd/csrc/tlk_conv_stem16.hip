@@ -137,6 +137,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) c
         if (orow >= out_rows) continue;                                  // wave-uniform (the barrier above is the strip's last)
         constexpr int NV = POOL ? 3 : 1;
         h16x2 rmax[2][NCO][4];                                           // POOL: running max of the pooled pairs (columns 16 i + 4 k + 2 half, + 1)
+        // v_pk_max_f16 / fmaxf16 have fmax semantics: a NaN among the pooled values would be DROPPED (torch.max_pool2d propagates it -- ADVICE r05;
+        // the pipeline's non-finite check must see what the stem produced).  Every convolution output of the row triple is folded into pz as
+        // 0 * v: NaN iff one of them is NaN or infinite; the pooled outputs of that channel and row then leave as NaN (a superset of the windows
+        // torch would poison: never fewer).  16 FMAs per MFMA tile.
+        float pz[NCO];
+#pragma unroll
+        for (int jj = 0; jj < NCO; ++jj) pz[jj] = 0.f;
         if (POOL) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -202,6 +209,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) c
                         for (int r = 0; r < 16; ++r) {
                             const int col = wo0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                             hv[r] = col < p.Wo ? (_Float16)acc[i][jj][r] : (_Float16)-65504.f;
+                            pz[jj] = __builtin_fmaf(col < p.Wo ? acc[i][jj][r] : 0.f, 0.f, pz[jj]);
                         }
                         // the column left of each 4-group lives in lane ^ 32: its registers 3, 7, 11, 15 (packed two to a dword)
                         _Float16 p3[4];
@@ -233,14 +241,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) c
         }
         if (POOL) {
 #pragma unroll
+            for (int jj = 0; jj < NCO; ++jj) pz[jj] += __shfl_xor(pz[jj], 32, 64);      // the other half's columns are this half's window neighbours
+#pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int jj = 0; jj < NCO; ++jj)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int q = 16 * i + 4 * k + 2 * half;
-                        stg[q * OST + jj * 32 + pl] = rmax[i][jj][k].x;
-                        stg[(q + 1) * OST + jj * 32 + pl] = rmax[i][jj][k].y;
+                        const bool bad = pz[jj] != pz[jj];
+                        stg[q * OST + jj * 32 + pl] = bad ? (_Float16)__builtin_nanf("") : rmax[i][jj][k].x;
+                        stg[(q + 1) * OST + jj * 32 + pl] = bad ? (_Float16)__builtin_nanf("") : rmax[i][jj][k].y;
                     }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

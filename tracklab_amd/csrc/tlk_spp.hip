@@ -27,7 +27,15 @@ struct SppArgs {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <typename V> __device__ __forceinline__ V vmax(V a, V b) { return __builtin_elementwise_max(a, b); }
+// NaN-propagating max, like torch.max_pool2d (__builtin_elementwise_max has fmax semantics and DROPS a NaN -- a NaN produced
+// upstream must stay visible to the pipeline's non-finite check, the reason the kernels' ReLU was rewritten in r05)
+template <typename V> __device__ __forceinline__ V vmax(V a, V b)
+{
+    V r;
+#pragma unroll
+    for (int e = 0; e < (int)(sizeof(V) / sizeof(a[0])); ++e) r[e] = (a[e] != a[e] || a[e] > b[e]) ? a[e] : b[e];
+    return r;
+}
 
 template <typename T, typename V, int VN>
 __global__ void __launch_bounds__(256) spp_kernel(const SppArgs p)

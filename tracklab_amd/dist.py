@@ -31,6 +31,26 @@ def init(backend: str | None = None):
     return dist
 
 
+def init_single(backend: str | None = None):
+    """A process group of ONE rank without a torchrun environment (bench.py's N = 1 line): the barrier, the max / sum reductions and the
+    all-gather of the per-rank rates then run on the job's real backend (RCCL on the GPU box) instead of being skipped, so the collective path
+    the multi-GPU job depends on has executed at least once on hardware.  Rendezvous on 127.0.0.1 and a free port."""
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist
+    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    kw = {}
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        kw["device_id"] = torch.device("cuda", 0)
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
+    return dist
+
+
 def streams_for_rank(n_streams_total: int, rank: int, world: int) -> list[int]:
     """stream s -> rank s mod world: whole videos, never frames, are sharded."""
     return [s for s in range(n_streams_total) if s % world == rank]
@@ -76,21 +96,31 @@ class serialized:
     """Cross-process mutual exclusion on one node (an flock'ed file): ``with serialized("tune"):`` lets the ranks of a job pass ONE AT A TIME.
     bench.py wraps each rank's warm-up in it when world > 1 -- eight concurrent hipGraph captures, hipBLASLt / MIOpen tuning passes and pinned
     allocations on one host were never run together on hardware; serial warm-up costs seconds and removes the question.
-    The lock file lives in ``TLK_LOCK_DIR`` (default: the system temp directory) and is keyed by the job's MASTER_PORT so that two jobs on one
-    host do not wait for each other.  ``order`` (a list) receives (event, time) pairs for the tests."""
+    The lock file lives in ``TLK_LOCK_DIR`` (default: the system temp directory) and is keyed by the user id and the job's MASTER_PORT, so that
+    two jobs on one host do not wait for each other and a file another user left behind is never opened.  A lock file that
+    cannot be opened or locked (read-only temp directory, foreign owner) does not cost the job its run: the section then runs unlocked and
+    ``locked`` is False.  ``order`` (a list) receives (event, time) pairs for the tests."""
 
     def __init__(self, name: str, order=None):
         import tempfile
         key = os.environ.get("MASTER_PORT", "solo")
-        self.path = os.path.join(os.environ.get("TLK_LOCK_DIR", tempfile.gettempdir()), f"tlk_{name}_{key}.lock")
+        uid = os.getuid() if hasattr(os, "getuid") else 0
+        self.path = os.path.join(os.environ.get("TLK_LOCK_DIR", tempfile.gettempdir()), f"tlk_{name}_{uid}_{key}.lock")
         self.order = order
+        self.locked = False
         self._f = None
 
     def __enter__(self):
         import fcntl
         import time
-        self._f = open(self.path, "a+")
-        fcntl.flock(self._f, fcntl.LOCK_EX)
+        try:
+            self._f = open(self.path, "a+")
+            fcntl.flock(self._f, fcntl.LOCK_EX)
+            self.locked = True
+        except OSError:
+            if self._f is not None:
+                self._f.close()
+            self._f = None
         if self.order is not None:
             self.order.append(("enter", time.time()))
         return self
@@ -100,9 +130,13 @@ class serialized:
         import time
         if self.order is not None:
             self.order.append(("exit", time.time()))
-        fcntl.flock(self._f, fcntl.LOCK_UN)
-        self._f.close()
-        self._f = None
+        if self._f is not None:
+            try:
+                fcntl.flock(self._f, fcntl.LOCK_UN)
+            finally:
+                self._f.close()
+                self._f = None
+        self.locked = False
         return False
 
 

@@ -448,6 +448,16 @@ class DetReidTrackPipeline:
             raise _lib.TlkError("ReID embeddings are not finite: the float16 / split-precision backbones saturated (an activation beyond +-65504, "
                                 "float16's range); this network needs dtype float32 (the reference's precision) -- DESIGN.md, precision envelope")
 
+    def _feat_probe(self):
+        """a zero-size stand-in with the dtype / layout of the ReID feature map (what fused_head_ok looks at)"""
+        p = self.__dict__.get("_fprobe")
+        if p is None:
+            p = torch.empty((1, self.D, 1, 1), dtype=self.dtype, device=self.dev).contiguous(memory_format=torch.channels_last)
+            if getattr(self.reid, "split_precision", False):
+                p = p.float()
+            self._fprobe = p
+        return p
+
     def _graphed(self, cache, key, fn):
         ent = cache.get(key)
         if ent is None:
@@ -557,24 +567,42 @@ class DetReidTrackPipeline:
                 buf["kps"].copy_(self.pose_out["kps_xyc"].view(self.B, maxd, 17, 3))
             if self.dense_reid:
                 _lib.conv_set_dynamic_batch(st["n_live"])      # (a captured graph keeps the pointer: every replay reads the step's own count)
+            # r06: the network's graph ends at the feature map; the part-based head is ONE libtlk launch behind it (tlk_reid_part_head) that pools the
+            # step's LIVE crops only, writes their rows straight into the tracker's (frame, slot) hand-off layout (dense batch: through the slot
+            # bases), zero-fills the padding slots and ORs "an embedding is not finite" into nf_flag -- it replaces the 6-channel library
+            # convolution, softmax, bmm, division, amax, two index_select gathers and the isfinite passes (and ADVICE r05: the check no longer
+            # sees padding rows, whose content used to be whatever a never-convolved row of the dense batch held)
+            fused_head = (not self.global_feat) and self.reid.fused_head_ok(self._feat_probe())
+            net = self.reid.features if fused_head else self.reid
             try:
                 if self.use_graph:
-                    emb, vis = self._graphed(self.__dict__.setdefault("_rg", {}), id(st), lambda: self.reid(crops))
+                    res = self._graphed(self.__dict__.setdefault("_rg", {}), id(st), lambda: net(crops))
                 else:
-                    emb, vis = self.reid(crops)
+                    res = net(crops)
             finally:
                 if self.dense_reid:
                     _lib.conv_set_dynamic_batch(None)
-            # hand-off buffers for the association stream (detector ltwh is float32: widen like numpy would)
-            if self.dense_reid:       # dense batch -> (frame, detection) slots; padding slots receive some valid row, the tracker reads counts[b] of them
-                torch.index_select(emb.reshape(self.B * maxd, self.K * self.D), 0, st["slot_of"], out=buf["emb"].view(self.B * maxd, self.K * self.D))
-                torch.index_select(vis.reshape(self.B * maxd, self.K).to(torch.uint8), 0, st["slot_of"], out=buf["vis"].view(self.B * maxd, self.K))
+            if fused_head:
+                self.reid.head(res, counts=buf["counts"], slot_base=st["slot_base"] if self.dense_reid else None, max_dets=maxd,
+                               out_emb=buf["emb"], out_vis=buf["vis"], flag=self.nf_flag if self.check_finite else None)
+                if self.check_finite:
+                    self.h_nf_flag.copy_(self.nf_flag, non_blocking=True)
             else:
-                buf["emb"].copy_(emb.view(self.B, maxd, self.K, self.D))
-                buf["vis"].copy_(vis.view(self.B, maxd, self.K))
-            if self.check_finite:
-                self.nf_flag.logical_or_(torch.logical_not(torch.isfinite(buf["emb"]).all()))
-                self.h_nf_flag.copy_(self.nf_flag, non_blocking=True)
+                emb, vis = res
+                # hand-off buffers for the association stream (detector ltwh is float32: widen like numpy would)
+                if self.dense_reid:       # dense batch -> (frame, detection) slots; padding slots receive some valid row, the tracker reads counts[b] of them
+                    torch.index_select(emb.reshape(self.B * maxd, self.K * self.D), 0, st["slot_of"], out=buf["emb"].view(self.B * maxd, self.K * self.D))
+                    torch.index_select(vis.reshape(self.B * maxd, self.K).to(torch.uint8), 0, st["slot_of"], out=buf["vis"].view(self.B * maxd, self.K))
+                else:
+                    buf["emb"].copy_(emb.view(self.B, maxd, self.K, self.D))
+                    buf["vis"].copy_(vis.view(self.B, maxd, self.K))
+                if self.check_finite:
+                    # live rows only: frame b's slots [0, counts[b]) (the padding slots of a dense batch repeat some row of it -- of a step without
+                    # detections, a row no convolution wrote)
+                    livem = torch.arange(maxd, device=self.dev)[None, :] < buf["counts"][:, None]
+                    bad = torch.logical_not(torch.isfinite(buf["emb"]).flatten(2).all(-1)) & livem
+                    self.nf_flag.logical_or_(bad.any())
+                    self.h_nf_flag.copy_(self.nf_flag, non_blocking=True)
             torch.add(self.id_off, self.frames_done * maxd, out=buf["ids"])
             buf["ready"].record(sb)
             st["b_done"].record(sb)

@@ -25,12 +25,16 @@ def _warn_unpinned_camera_motion(kind: str) -> None:
     _CAMERA_MOTION_WARNED.add(kind)
     import logging
     import os
-    fixture = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "cmc_opencv.npz")
-    if os.path.exists(fixture):
+    # where the fixture is looked for: TLK_CMC_FIXTURE (an installed package has no tests/ directory beside it -- ADVICE r05), package data
+    # (tracklab_amd/data/cmc_opencv.npz), then the source tree's tests/golden/
+    pkg = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    candidates = [os.environ.get("TLK_CMC_FIXTURE"), os.path.join(pkg, "data", "cmc_opencv.npz"),
+                  os.path.join(os.path.dirname(pkg), "tests", "golden", "cmc_opencv.npz")]
+    if any(c and os.path.exists(c) for c in candidates):
         return
     logging.getLogger(__name__).warning(
         "%s: camera-motion compensation runs on the device restatement of OpenCV (targets the 4.5-4.6 algorithms); parity with cv2 is UNPINNED "
-        "on this installation (tests/golden/cmc_opencv.npz missing: run tests/golden/make_cmc_golden.py where cv2 is installed). Track ids under "
+        "on this installation (no cmc_opencv.npz under TLK_CMC_FIXTURE, tracklab_amd/data/ or tests/golden/: tests/golden/make_cmc_golden.py writes it where cv2 is installed). Track ids under "
         "camera motion may differ from the reference's; set %s to switch it off.", kind,
         "ecc: false" if kind == "HipStrongSORT" else "cmc_method: none")
 
