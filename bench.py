@@ -487,11 +487,13 @@ def main():
 
     from tracklab_amd import gpu_pipeline as gp
 
-    def make_pipe(frames_per_step, n_streams=S, tdtype=tdtype, overlap=False):
+    def make_pipe(frames_per_step, n_streams=S, tdtype=tdtype, overlap=None):
+        """overlap: None = the pipeline's default (r06: auto -- stage overlap at <= 2 frames per step, with streams measured to be concurrent),
+        False / True = forced"""
         if is3:
             kw = dict(dim=wl["dim"]) if "dim" in wl else {}
-            if overlap:
-                kw["overlap_stages"] = True
+            if overlap is not None:
+                kw["overlap_stages"] = bool(overlap)
             if "reid_arch" in wl:
                 kw["reid_arch"] = wl["reid_arch"]
             if wl.get("camera_motion"):
@@ -869,9 +871,10 @@ def main():
     # ---- small-step legs: the same chain at frames_per_step 1 / 2 / 4 and at 4 streams x 1 frame (what an online consumer sees; the
     # reference's online engine is per-frame, engine/video.py:67-117). Each: pipelined frames/s, un-overlapped frame-in -> rows-out time,
     # and for the BPBReID workloads the ids of up to 48 frames per checked stream against the oracle chain ----
-    def small_step_legs(dt, with_main, overlap=False):
+    def small_step_legs(dt, with_main, overlap=None):
+        """overlap None: the pipeline's default mode (auto); False: serial, forced; True: detector stage of step t + 1 beside the ReID stage of step t"""
         shapes = [(1, 1), (1, 2), (1, 4), (4, 1)] if is3 else [(1, 1), (1, 4)]
-        if overlap:           # detector stage of step t + 1 beside the ReID stage of step t (DetReidTrackPipeline(overlap_stages=True), opt-in)
+        if overlap:
             shapes = [(1, 1), (4, 1)]
         latency = []
         for S_, F_ in shapes:
@@ -922,7 +925,7 @@ def main():
             for j in range(15):                                  # true in-to-out latency: one step, wait for its rows
                 t1 = time.perf_counter(); stp(j); p1.synchronize(); lat.append(time.perf_counter() - t1)
             latency.append({"n_streams": S_, "frames_per_step": F_, "fps": nrun * S_ * F_ / el1, "ms_per_step_pipelined": el1 / nrun * 1e3,
-                            "ms_frame_in_to_rows_out": float(np.median(lat) * 1e3), "parity": leg_parity, "overlap_stages": bool(getattr(p1, "overlap", False))})
+                            "ms_frame_in_to_rows_out": float(np.median(lat) * 1e3), "parity": leg_parity, "overlap_stages": bool(getattr(p1, "overlap", False)), "overlap_note": getattr(p1, "overlap_note", None)})
             p1.close()
             del p1, d_h1
         if with_main:
@@ -937,9 +940,9 @@ def main():
     latency = latency_f16 = latency_f16_overlap = None
     if rank == 0 and world == 1 and not args.no_latency_leg and F > 1:
         pipe.reset()
-        latency = small_step_legs(tdtype, True)
+        latency = small_step_legs(tdtype, True)               # the pipeline's DEFAULT mode (r06: stage overlap is automatic at <= 2 frames per step)
         if args.dtype == "f32":           # the online target (>= 240 frames/s at small steps) is out of any fp32 path's reach on this chip (one frame = 1.36 TFLOP of
-            latency_f16 = small_step_legs(torch.float16, False)          # convolutions = 8.6 ms at the fp32 MFMA peak): the f16 legs are reported beside
+            latency_f16 = small_step_legs(torch.float16, False, overlap=False)      # convolutions = 8.6 ms at the fp32 MFMA peak): the f16 legs are reported beside (serial, forced)
         if is3 and not ssort and wl.get("pose") is None and not wl.get("camera_motion"):
             try:              # opt-in pipeline mode, reported beside the serial legs (never as them): an exception here must not cost the run its line
                 latency_f16_overlap = small_step_legs(torch.float16, False, overlap=True)

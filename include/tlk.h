@@ -681,6 +681,29 @@ int tlk_conv2d_nhwc_16(const void *x_dev, const void *x_lo_dev, const void *w_de
                        const void *res_dev, const void *res_lo_dev, void *y_dev, void *y_lo_dev, float *y_f32_dev,
                        int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int act_kind,
                        int x_pix_stride, int y_pix_stride, int res_pix_stride, void *hip_stream);
+/* r06 -- SCALED split planes: the value of a plane pair is scale * (hi + lo * 2^-11) with `scale` a power of two >= 1 held in device memory
+ * beside the tensor, so that activations beyond float16's range no longer saturate the split-precision networks (the
+ * reference's fp32 networks have fp32's range: tracklab/wrappers/reid/kpreid_api.py:147-182).  Multiplying by a power of two is exact, so a
+ * tensor that fits float16 keeps scale 1 and the planes -- and every result -- of the unscaled call, bit for bit.
+ *   tlk_conv2d_nhwc_16s = tlk_conv2d_nhwc_16 (split mode only) + in_scale (1 float: the scale of the x planes, NULL = 1), res_scale (the residual
+ *     planes'), out_state (2 floats {scale of the planes this call writes, largest |output| recorded by atomic max}; NULL = scale 1, nothing
+ *     recorded; must be NULL with y_f32).  The scale in use is read when the kernel RUNS (a captured hipGraph follows it).
+ *   tlk_split_f32_planes_s / tlk_merge_planes_f32_s: the conversions with a state / scale; pixels_per_image > 0 makes the split honour
+ *     tlk_conv_set_dynamic_batch (live images only are converted and recorded).
+ *   tlk_split_scale_update: n states {scale, recorded maximum} -> scale for the NEXT forward: the smallest power of two >= 1 with
+ *     maximum / scale <= 2^14 when that is larger than the current one (growth at once), twice that value when the maximum fell a factor 8 below
+ *     (hysteresis), else unchanged; maxima cleared.  *changed_dev (nullable) += number of states that grew or recorded a non-finite maximum --
+ *     the calibration loop (run the network, update, repeat while it is non-zero) reads it; in steady state the update is the forward's last
+ *     node and nothing is read. */
+int tlk_conv2d_nhwc_16s(const void *x_dev, const void *x_lo_dev, const void *w_dev, const void *w_lo_dev, const float *bias_dev,
+                        const void *res_dev, const void *res_lo_dev, void *y_dev, void *y_lo_dev, float *y_f32_dev,
+                        int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int act_kind,
+                        int x_pix_stride, int y_pix_stride, int res_pix_stride, const float *in_scale_dev, const float *res_scale_dev,
+                        float *out_state_dev, void *hip_stream);
+int tlk_split_f32_planes_s(const float *x_dev, long long pixels, int c_in, int x_pix_stride, int c_out, void *hi_dev, void *lo_dev, float *state_dev,
+                           long long pixels_per_image, void *hip_stream);
+int tlk_merge_planes_f32_s(const void *hi_dev, const void *lo_dev, long long n, const float *scale_dev, float *y_dev, void *hip_stream);
+int tlk_split_scale_update(float *states_dev, int n_states, int *changed_dev, void *hip_stream);
 /* Probes / tests: 0 = the register-staged kernel for every shape, 1 (default; env TLK_CONV16_GLDS) = the direct-to-LDS kernel where it applies
  * (Cout > 64, Cin a multiple of the K step).  Results do not depend on it beyond fp32 summation order inside a 16-wide slice (none: same order). */
 int tlk_conv16_set_glds(int on);
@@ -688,7 +711,8 @@ int tlk_conv16_set_glds(int on);
  * one to four LDS stages with counted waits, residual prefetched into registers).  cfg 0 (default) = they take the shapes their launch-size
  * heuristic claims (cin a multiple of the K step: 64 in f16 mode, 32 in split mode) and the r04 kernels the rest; -1 = r04 kernels only;
  * 1..18 (f16; 17 / 18 = the patch-resident 3 x 3 kernel: stride 1, exactly 64 channels, whole image rows per tile) / 1..7 (split) = force one
- * tile configuration (probes / tests).  Same arithmetic contract as above in every configuration. */
+ * tile configuration (probes / tests).  Same arithmetic contract as above in every configuration.  r06: in split mode the heuristic also
+ * takes the 1 x 1 expansions WITH residual (128 x 128 tiles of eight 32 x 64 wavefronts, configurations 6 / 7). */
 int tlk_conv16_set_config(int cfg);
 /* fp32 NHWC pixels (c_in channels, x_pix_stride floats apart, 0 = dense) -> (hi, lo) f16 planes with c_out >= c_in channels, zero padded. */
 int tlk_split_f32_planes(const float *x_dev, long long pixels, int c_in, int x_pix_stride, int c_out, void *hi_dev, void *lo_dev, void *hip_stream);

@@ -32,4 +32,4 @@ def test_bench_under_torchrun_with_rccl_collectives():
     assert j["n_gpus"] == 1 and j["ranks_seen"] == [[0, 0]] and len(j["per_rank_fps"]) == 1 and j["value"] > 100
     assert j["hota_allreduce"]["frames"] > 0 and 0.0 < j["hota_allreduce"]["HOTA"] <= 1.0
     assert j["parity"]["track_ids_equal_oracle"] is True
-    assert j.get("collectives") == "nccl"
+    assert str(j.get("collectives")).startswith("nccl")

@@ -251,3 +251,79 @@ def test_detector_to_tracker_path_with_the_networks_own_head_activations(orc):
             np.testing.assert_array_equal(got, exp)
     assert total > 40
     pipe.close()
+
+
+def _ocsort_dets(ltwh, ids):
+    d = np.zeros((len(ltwh), 7))
+    d[:, 0], d[:, 1] = ltwh[:, 0], ltwh[:, 1]
+    d[:, 2], d[:, 3] = (ltwh[:, 0] + ltwh[:, 2]).astype(np.float32), (ltwh[:, 1] + ltwh[:, 3]).astype(np.float32)
+    d[:, 4], d[:, 5], d[:, 6] = 1.0, 1.0, ids
+    return d
+
+
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
+def test_config2_fused_pipeline_at_its_baseline_size(orc, use_graph):
+    """BASELINE.json configs[1] EXACTLY -- YOLOX-s + OC-SORT on a synthetic 1080p 50-object stream, 32 frames per
+    step, max_dets 128 (bench.py WORKLOADS["config2"]) -- through the fused DetTrackPipeline: detection -> track id identical to the oracle
+    chain (C decode / NMS + C OC-SORT) on every frame of 3 steps."""
+    import torch
+    from tracklab_amd import gpu_pipeline as gp
+    from tracklab_amd.synth import SyntheticStream, render_frame, synth_yolox_head
+    F, steps, nobj, maxd = 32, 3, 50, 128
+    pipe = gp.DetTrackPipeline("s", n_streams=1, frames_per_step=F, max_dets=maxd, use_graph=use_graph)
+    rng = np.random.default_rng(77)
+    stream = list(SyntheticStream(2, nobj, F * steps))
+    heads = np.stack([synth_yolox_head(rng, fr["dets"][:, :4], ratio=pipe.ratio) for fr in stream])
+    d_frames = torch.from_numpy(np.stack([render_frame(rng, stream[i]["gt_boxes"]) for i in range(F)])).cuda()
+    d_heads = torch.from_numpy(heads).cuda().reshape(steps, F, -1, 6)
+    ref = orc.OCSort(**pipe.tracker_cfg["hyper"])
+    rows_total = 0
+    for k in range(steps):
+        rows, cnt = pipe.step(d_frames, d_heads[k])
+        pipe.synchronize()
+        rows_a = pipe.rows_array(rows)
+        for f in range(F):
+            ltwh = _detector_rows(orc, heads[k * F + f], pipe.ratio)
+            exp = orc.ocsort_wrapper_step(ref, _ocsort_dets(ltwh, (k * F + f) * maxd + np.arange(len(ltwh))), pipe.tracker_cfg["min_confidence"])
+            got = np.array(rows_a[0, f, :int(cnt[0, f])])
+            assert got.shape == exp.shape, (k, f, got.shape, exp.shape)
+            np.testing.assert_array_equal(got[:, [4, 7]], exp[:, [4, 7]], err_msg=f"frame {k * F + f}")
+            rows_total += len(exp)
+    assert rows_total > 0.85 * F * steps * nobj
+    pipe.close()
+
+
+def test_config5_unit_eight_streams_resident_on_one_gpu(orc):
+    """the per-GPU unit of BASELINE.json configs[4] (YOLOX-l + part-based ReID + BPBReID-StrongSORT) with EIGHT tracker banks
+    resident on one GPU -- n_streams = 8, one frame of every stream per step (the online shape of the 8-stream job folded onto one device):
+    every stream's detection -> track id assignment equals its own oracle chain, i.e. the streams do not leak into each other."""
+    import torch
+    from tracklab_amd import gpu_pipeline as gp
+    from tracklab_amd.synth import SyntheticStream, render_frame, synth_yolox_head
+    S, F, steps, nobj, maxd = 8, 1, 10, 40, 48
+    pipe = gp.DetReidTrackPipeline("l", n_streams=S, frames_per_step=F, max_dets=maxd, use_graph=True)
+    rng = np.random.default_rng(8)
+    streams = [list(SyntheticStream(100 + s, nobj, steps)) for s in range(S)]
+    heads = np.stack([[synth_yolox_head(rng, streams[s][k]["dets"][:, :4], ratio=pipe.ratio) for s in range(S)] for k in range(steps)])     # (steps, S, A, 6)
+    d_frames = torch.from_numpy(np.stack([render_frame(rng, streams[s][0]["gt_boxes"]) for s in range(S)])).cuda()
+    d_heads = torch.from_numpy(heads).cuda()
+    refs = [orc.StrongSORT(pipe.K, pipe.D, **pipe.tracker_cfg) for _ in range(S)]
+    tracks = [0] * S
+    for k in range(steps):
+        h_rows, h_cnt = pipe.step(d_frames, d_heads[k])
+        pipe.synchronize()
+        rows, cnt = pipe.rows_numpy(h_rows, h_cnt)
+        emb = pipe.last["emb"].cpu().numpy().reshape(S, F, maxd, pipe.K, pipe.D)
+        vis = pipe.last["vis"].cpu().numpy().reshape(S, F, maxd, pipe.K)
+        for s in range(S):
+            ltwh = _detector_rows(orc, heads[k, s], pipe.ratio)
+            n = len(ltwh)
+            ids = (k * S * F + s * F) * maxd + np.arange(n)
+            exp = refs[s].update(ids, ltwh.astype(np.float64), emb[s, 0, :n], vis[s, 0, :n], np.ones(n))
+            got = rows[s][0]
+            assert len(got) == len(exp), (k, s)
+            np.testing.assert_array_equal(got["det_id"], exp["det_id"], err_msg=f"step {k} stream {s}")
+            np.testing.assert_array_equal(got["track_id"], exp["track_id"], err_msg=f"step {k} stream {s}")
+            tracks[s] = max(tracks[s], int(exp["track_id"].max()) if len(exp) else 0)
+    assert all(nobj - 4 <= t <= nobj + 12 for t in tracks), tracks          # every bank numbers ITS OWN tracks from 1
+    pipe.close()

@@ -217,3 +217,161 @@ def test_load_checkpoint_entry_point(tmp_path):
                                     sd["module.backbone.bn1.running_mean"], sd["module.backbone.bn1.running_var"])
     np.testing.assert_array_equal(reid.backbone.conv1.conv.weight.detach().numpy(), exp_w)
     np.testing.assert_array_equal(reid.backbone.conv1.bias.detach().numpy(), exp_b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# an ONNX file NOT written by torch's exporter.  The model below is authored node by node in the form mmdeploy gives
+# rtmlib's YOLOX files (tracklab/configs/modules/bbox_detector/yolox_rtmlib.yaml:1-7): BatchNorm folded INTO the convolutions (weight and bias
+# as anonymous initializers `onnx::Conv_NNNN`, the bias as the node's third input), SiLU as Sigmoid + Mul, Focus as eight strided Slice nodes
+# whose `ends` are the concrete extents (torch writes INT64_MAX), mmdet's CSPLayer order (short branch first), Resize for the up-sampling,
+# the head flattened by Reshape + Concat + Transpose, prediction convolutions under mmdet's parameter names.  It is serialised by a protobuf
+# WRITER that exists only in this test; the product's dependency-free reader and structural matcher have never seen its output before.
+def _pb_varint(v):
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _pb(fno, payload):
+    if isinstance(payload, int):
+        return _pb_varint(fno << 3) + _pb_varint(payload)
+    if isinstance(payload, str):
+        payload = payload.encode()
+    return _pb_varint((fno << 3) | 2) + _pb_varint(len(payload)) + bytes(payload)
+
+
+def _pb_tensor(name, a):
+    a = np.ascontiguousarray(a)
+    dt = {np.dtype("float32"): 1, np.dtype("int64"): 7}[a.dtype]
+    return b"".join(_pb(1, int(d)) for d in a.shape) + _pb(2, dt) + _pb(8, name) + _pb(9, a.tobytes())
+
+
+def _pb_attr(name, v):
+    if isinstance(v, (list, tuple)):
+        return _pb(1, name) + b"".join(_pb(8, int(x)) for x in v) + _pb(20, 7)
+    if isinstance(v, float):
+        import struct
+        return _pb(1, name) + _pb_varint((2 << 3) | 5) + struct.pack("<f", v) + _pb(20, 1)
+    if isinstance(v, str):
+        return _pb(1, name) + _pb(4, v) + _pb(20, 3)
+    return _pb(1, name) + _pb(3, int(v)) + _pb(20, 2)
+
+
+class _HandGraph:
+    def __init__(self):
+        self.nodes, self.inits, self.n, self.k = [], [], 0, 1000
+
+    def val(self, op):
+        self.n += 1
+        return f"/{op}_{self.n}_output_0"
+
+    def init(self, a, stem="onnx::Conv"):
+        self.k += 1
+        name = f"{stem}_{self.k}"
+        self.inits.append(_pb_tensor(name, a))
+        return name
+
+    def named(self, name, a):
+        self.inits.append(_pb_tensor(name, a))
+        return name
+
+    def node(self, op, ins, **attrs):
+        out = self.val(op)
+        self.nodes.append(_pb(1, b"") [:0] + b"".join(_pb(1, i) for i in ins) + _pb(2, out) + _pb(3, f"/{op}_{self.n}") + _pb(4, op) +
+                          b"".join(_pb(5, _pb_attr(k, v)) for k, v in attrs.items()))
+        return out
+
+    def serialize(self, inp, out):
+        g = b"".join(_pb(1, n) for n in self.nodes) + _pb(2, "torch_jit") + b"".join(_pb(5, t) for t in self.inits) + _pb(11, _pb(1, inp)) + _pb(12, _pb(1, out))
+        return _pb(1, 7) + _pb(2, "pytorch") + _pb(8, _pb(2, 11)) + _pb(7, g)
+
+
+def _hand_written_rtmlib_style_yolox(m, size):
+    """YOLOX module `m` (this repo's definition, holding the weights to ship) -> bytes of an ONNX model in mmdeploy's style"""
+    G = _HandGraph()
+    i64 = lambda *v: np.asarray(v, np.int64)      # noqa: E731
+
+    def conv(c, x, act=True):                     # c: backbones.common.ConvBiasAct -> Conv (BN folded: bias inside) + Sigmoid + Mul
+        w, b = c.conv.weight.detach().numpy(), c.bias.detach().numpy()
+        k, s = c.conv.kernel_size[0], c.conv.stride[0]
+        y = G.node("Conv", [x, G.init(w), G.init(b)], dilations=[1, 1], group=1, kernel_shape=[k, k], pads=[k // 2] * 4, strides=[s, s])
+        return G.node("Mul", [y, G.node("Sigmoid", [y])]) if act else y
+
+    def csp(layer, x):                            # mmdet CSPLayer.forward: short branch FIRST, then main + blocks; cat(main, short)
+        short = conv(layer.conv2, x)
+        t = conv(layer.conv1, x)
+        for blk in layer.m:
+            u = conv(blk.conv2, conv(blk.conv1, t))
+            t = G.node("Add", [u, t]) if blk.add else u
+        return conv(layer.conv3, G.node("Concat", [t, short], axis=1))
+
+    # Focus: patch_top_left = x[..., ::2, ::2] etc. -- two Slice nodes per phase (H then W), ends = the concrete extent
+    def phase(dy, dx):
+        a = G.node("Slice", ["input", G.init(i64(dy), "onnx::Slice"), G.init(i64(size), "onnx::Slice"), G.init(i64(2), "onnx::Slice"), G.init(i64(2), "onnx::Slice")])
+        return G.node("Slice", [a, G.init(i64(dx), "onnx::Slice"), G.init(i64(size), "onnx::Slice"), G.init(i64(3), "onnx::Slice"), G.init(i64(2), "onnx::Slice")])
+    bb, neck, head = m.backbone, m.neck, m.head
+    x = conv(bb.stem.conv, G.node("Concat", [phase(0, 0), phase(1, 0), phase(0, 1), phase(1, 1)], axis=1))      # tl, bl, tr, br
+    x = csp(bb.dark2[1], conv(bb.dark2[0], x))
+    c3 = csp(bb.dark3[1], conv(bb.dark3[0], x))
+    c4 = csp(bb.dark4[1], conv(bb.dark4[0], c3))
+    t = conv(bb.dark5[1].conv1, conv(bb.dark5[0], c4))
+    pools = [G.node("MaxPool", [t], ceil_mode=0, kernel_shape=[k, k], pads=[k // 2] * 4, strides=[1, 1]) for k in (5, 9, 13)]
+    c5 = csp(bb.dark5[2], conv(bb.dark5[1].conv2, G.node("Concat", [t] + pools, axis=1)))
+    up = lambda v: G.node("Resize", [v, "", G.init(np.asarray([1, 1, 2, 2], np.float32), "onnx::Resize")], coordinate_transformation_mode="asymmetric",   # noqa: E731
+                          mode="nearest", nearest_mode="floor")
+    fpn0 = conv(neck.lateral_conv0, c5)
+    f1 = csp(neck.C3_p4, G.node("Concat", [up(fpn0), c4], axis=1))
+    fpn1 = conv(neck.reduce_conv1, f1)
+    p3 = csp(neck.C3_p3, G.node("Concat", [up(fpn1), c3], axis=1))
+    p4 = csp(neck.C3_n3, G.node("Concat", [conv(neck.bu_conv2, p3), fpn1], axis=1))
+    p5 = csp(neck.C3_n4, G.node("Concat", [conv(neck.bu_conv1, p4), fpn0], axis=1))
+    outs = []
+    for k, f in enumerate((p3, p4, p5)):
+        s = conv(head.stems[k], f)
+        cf, rf = s, s
+        for c in head.cls_convs[k]:
+            cf = conv(c, cf)
+        for c in head.reg_convs[k]:
+            rf = conv(c, rf)
+
+        def pred(mod, v, nm):
+            return G.node("Conv", [v, G.named(f"bbox_head.multi_level_conv_{nm}.{k}.weight", mod.weight.detach().numpy()),
+                                   G.named(f"bbox_head.multi_level_conv_{nm}.{k}.bias", mod.bias.detach().numpy())],
+                          dilations=[1, 1], group=1, kernel_shape=[1, 1], pads=[0, 0, 0, 0], strides=[1, 1])
+        cls, reg, obj = pred(head.cls_preds[k], cf, "cls"), pred(head.reg_preds[k], rf, "reg"), pred(head.obj_preds[k], rf, "obj")
+        o = G.node("Concat", [reg, G.node("Sigmoid", [obj]), G.node("Sigmoid", [cls])], axis=1)
+        outs.append(G.node("Reshape", [o, G.init(i64(0, 0, -1), "onnx::Reshape")]))
+    dets = G.node("Transpose", [G.node("Concat", outs, axis=2)], perm=[0, 2, 1])
+    return G.serialize("input", dets)
+
+
+def test_import_from_a_hand_written_rtmlib_style_onnx_file(tmp_path):
+    src = _yolox(3)
+    x = torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(5))
+    blob = _hand_written_rtmlib_style_yolox(src, 64)
+    path = tmp_path / "yolox_s_hand_written.onnx"
+    path.write_bytes(blob)
+    g = W.read_onnx(str(path))
+    names = [k for k in g.tensors if k.startswith("onnx::Conv_")]
+    convs = [n for n in g.nodes if n.op == "Conv"]
+    assert len(convs) == len([mm for mm in src.modules() if isinstance(mm, torch.nn.Conv2d)]) and len(names) == 2 * (len(convs) - 9)
+    assert all(len(n.inputs) == 3 for n in convs) and sum(n.op == "Slice" for n in g.nodes) == 8 and not set(g.tensors) & set(src.state_dict())
+    dst = _yolox(13)
+    with torch.no_grad():
+        assert not torch.equal(dst(x), src(x))
+    n = W.import_onnx_weights(dst, (x,), str(path))
+    assert n == len(src.state_dict())
+    with torch.no_grad():
+        assert torch.equal(dst(x), src(x))
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    # the entry point the wrappers use takes the same file
+    dst2 = _yolox(17)
+    rep = W.load_checkpoint(dst2, str(path), (x,))
+    with torch.no_grad():
+        assert torch.equal(dst2(x), src(x)), rep

@@ -1236,15 +1236,21 @@ def _bind_conv16(L):
         L.tlk_conv2d_nhwc_16.argtypes = [C.c_void_p] * 10 + [C.c_int] * 13 + [C.c_void_p]
         L.tlk_split_f32_planes.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.tlk_merge_planes_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
+        L.tlk_conv2d_nhwc_16s.argtypes = [C.c_void_p] * 10 + [C.c_int] * 13 + [C.c_void_p] * 4
+        L.tlk_split_f32_planes_s.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
+        L.tlk_merge_planes_f32_s.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tlk_split_scale_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L._conv16_bound = True
 
 
 def conv2d_nhwc_16(x, weight, bias=None, act=None, residual=None, stride=1, pad=None, x_lo=None, weight_lo=None, residual_lo=None,
-                   out_f32=False, residual_after_act=False, out=None):
+                   out_f32=False, residual_after_act=False, out=None, in_scale=None, res_scale=None, out_state=None):
     """Convolution + bias + residual + activation on the 16-bit MFMA (tlk_conv2d_nhwc_16).  f16 mode: x / weight / residual float16
     channels_last, returns float16.  Split mode (x_lo given): every tensor a (hi, lo) pair of float16 planes, returns (hi, lo).
-    out_f32: returns one float32 tensor instead.  bias float32.  out (f16 mode): a float16 channels_last tensor, or a channel slice of one
-    (e.g. this layer's part of a concatenation), to write into."""
+    out_f32: returns one float32 tensor instead.  bias float32.  out: a float16 channels_last tensor, or a channel slice of one (e.g. this
+    layer's part of a concatenation), to write into -- in split mode a (hi, lo) pair of such tensors with equal strides.
+    r06, split mode, SCALED planes (tlk_conv2d_nhwc_16s): in_scale / res_scale = the 1-element float32 scale of the input / residual planes (value =
+    scale * (hi + lo * 2**-11)); out_state = this layer's 2-element float32 state {scale of the planes it writes, largest |output| recorded}."""
     import torch
     L = lib()
     _bind_conv16(L)
@@ -1263,23 +1269,36 @@ def conv2d_nhwc_16(x, weight, bias=None, act=None, residual=None, stride=1, pad=
     wk, wkl = cl(weight), (cl(weight_lo) if split else None)
     mk = lambda dt: torch.empty((N, Cout, Ho, Wo), dtype=dt, device=x.device, memory_format=torch.channels_last)      # noqa: E731
     y32 = mk(torch.float32) if out_f32 else None
+    out_lo = None
     if out is not None:
-        assert not split and not out_f32 and out.dtype == torch.float16 and out.shape == (N, Cout, Ho, Wo)
+        assert not out_f32
+        if split:
+            out, out_lo = out
+            assert out_lo.dtype == torch.float16 and out_lo.shape == (N, Cout, Ho, Wo) and _pix16(out_lo, Cout, Ho, Wo) == _pix16(out, Cout, Ho, Wo)
+        assert out.dtype == torch.float16 and out.shape == (N, Cout, Ho, Wo)
     yh = None if out_f32 else (out if out is not None else mk(torch.float16))
-    yl = mk(torch.float16) if (split and not out_f32) else None
+    yl = (out_lo if out_lo is not None else mk(torch.float16)) if (split and not out_f32) else None
     ptr = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
-    check(L.tlk_conv2d_nhwc_16(x.data_ptr(), ptr(x_lo), wk.data_ptr(), ptr(wkl), ptr(bias), ptr(residual), ptr(residual_lo),
-                               ptr(yh), ptr(yl), ptr(y32), N, H, W, Cin, Cout, KH, KW, stride, pad, ACT[act] | (ACT_RES_AFTER if residual_after_act else 0),
-                               _pix16(x, Cin, H, W), _pix16(out, Cout, Ho, Wo) if out is not None else Cout,
-                               _pix16(residual, Cout, Ho, Wo) if residual is not None else 0, current_stream_ptr()))
+    scaled = in_scale is not None or res_scale is not None or out_state is not None
+    common = (x.data_ptr(), ptr(x_lo), wk.data_ptr(), ptr(wkl), ptr(bias), ptr(residual), ptr(residual_lo),
+              ptr(yh), ptr(yl), ptr(y32), N, H, W, Cin, Cout, KH, KW, stride, pad, ACT[act] | (ACT_RES_AFTER if residual_after_act else 0),
+              _pix16(x, Cin, H, W), _pix16(out, Cout, Ho, Wo) if out is not None else Cout,
+              _pix16(residual, Cout, Ho, Wo) if residual is not None else 0)
+    if scaled:
+        assert split and all(t is None or (t.dtype == torch.float32 and t.is_cuda) for t in (in_scale, res_scale, out_state))
+        assert out_state is None or (out_state.numel() == 2 and out_state.is_contiguous())
+        check(L.tlk_conv2d_nhwc_16s(*common, ptr(in_scale), ptr(res_scale), ptr(out_state), current_stream_ptr()))
+    else:
+        check(L.tlk_conv2d_nhwc_16(*common, current_stream_ptr()))
     if out_f32:
         return y32
     return (yh, yl) if split else yh
 
 
-def split_planes(x, c_out=None):
+def split_planes(x, c_out=None, state=None, dynamic_batch=False):
     """float32 (N, C, H, W) channels_last (or a channel slice of one) -> (hi, lo) float16 planes (N, c_out, H, W) channels_last, zero-padded
-    channels: value = hi + lo * 2**-11."""
+    channels: value = hi + lo * 2**-11.  state (r06): 2-element float32 {scale, largest |x| recorded}: the planes hold x / scale.
+    dynamic_batch: only the live images of tlk_conv_set_dynamic_batch are converted (and recorded)."""
     import torch
     L = lib()
     _bind_conv16(L)
@@ -1288,19 +1307,40 @@ def split_planes(x, c_out=None):
     assert x.dtype == torch.float32
     hi = torch.empty((N, c_out, H, W), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
     lo = torch.empty_like(hi)
-    check(L.tlk_split_f32_planes(x.data_ptr(), N * H * W, Cc, _pix16(x, Cc, H, W), c_out, hi.data_ptr(), lo.data_ptr(), current_stream_ptr()))
+    if state is None and not dynamic_batch:
+        check(L.tlk_split_f32_planes(x.data_ptr(), N * H * W, Cc, _pix16(x, Cc, H, W), c_out, hi.data_ptr(), lo.data_ptr(), current_stream_ptr()))
+    else:
+        assert state is None or (state.dtype == torch.float32 and state.numel() == 2 and state.is_contiguous())
+        check(L.tlk_split_f32_planes_s(x.data_ptr(), N * H * W, Cc, _pix16(x, Cc, H, W), c_out, hi.data_ptr(), lo.data_ptr(),
+                                       state.data_ptr() if state is not None else None, H * W if dynamic_batch else 0, current_stream_ptr()))
     return hi, lo
 
 
-def merge_planes(hi, lo):
+def merge_planes(hi, lo, scale=None):
+    """hi + lo * 2**-11 (times the planes' 1-element float32 scale, r06) as a float32 channels_last tensor"""
     import torch
     L = lib()
     _bind_conv16(L)
     assert hi.dtype == torch.float16 and lo.dtype == torch.float16 and hi.shape == lo.shape
     assert hi.is_contiguous(memory_format=torch.channels_last) and lo.is_contiguous(memory_format=torch.channels_last)
     y = torch.empty(hi.shape, dtype=torch.float32, device=hi.device, memory_format=torch.channels_last)
-    check(L.tlk_merge_planes_f32(hi.data_ptr(), lo.data_ptr(), hi.numel(), y.data_ptr(), current_stream_ptr()))
+    if scale is None:
+        check(L.tlk_merge_planes_f32(hi.data_ptr(), lo.data_ptr(), hi.numel(), y.data_ptr(), current_stream_ptr()))
+    else:
+        assert scale.dtype == torch.float32 and scale.is_cuda
+        check(L.tlk_merge_planes_f32_s(hi.data_ptr(), lo.data_ptr(), hi.numel(), scale.data_ptr(), y.data_ptr(), current_stream_ptr()))
     return y
+
+
+def split_scale_update(states, changed=None):
+    """``tlk_split_scale_update``: states (n, 2) float32 {scale, recorded maximum} -> the scales of the NEXT forward (powers of two >= 1; growth at
+    once, shrinking with hysteresis), maxima cleared; changed (1,) int32 is incremented per state whose scale grew or whose maximum was not finite."""
+    import torch
+    L = lib()
+    _bind_conv16(L)
+    assert states.dtype == torch.float32 and states.is_contiguous() and states.shape[-1] == 2
+    assert changed is None or (changed.dtype == torch.int32 and changed.numel() == 1)
+    check(L.tlk_split_scale_update(states.data_ptr(), states.numel() // 2, changed.data_ptr() if changed is not None else None, current_stream_ptr()))
 
 
 def cosine_gallery_min(gallery, offsets, dets):

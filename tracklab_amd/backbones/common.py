@@ -72,26 +72,76 @@ def spp_concat(x: torch.Tensor, ks=(5, 9, 13)) -> torch.Tensor:
 
 
 class SplitAct:
-    """An fp32 activation travelling as two float16 planes: value = hi + lo * 2**-11 (relative 2**-22), both (N, C, H, W) channels_last.
+    """An fp32 activation travelling as two float16 planes: value = scale * (hi + lo * 2**-11) (relative 2**-22), both (N, C, H, W) channels_last.
     What the split-precision convolutions (tlk_conv2d_nhwc_16, split mode: three f16 MFMAs per product pair, fp32 accumulation) read and
-    write; `merge()` gives the fp32 tensor back."""
-    __slots__ = ("hi", "lo")
+    write; `merge()` gives the fp32 tensor back.  `state` (r06; None = scale 1): the 2-element float32 device tensor {scale, recorded maximum}
+    of the layer that wrote the planes -- a power of two >= 1 chosen so that the planes stay inside float16's range
+    (SplitScales below; include/tlk.h, tlk_conv2d_nhwc_16s)."""
+    __slots__ = ("hi", "lo", "state")
 
-    def __init__(self, hi, lo):
-        self.hi, self.lo = hi, lo
+    def __init__(self, hi, lo, state=None):
+        self.hi, self.lo, self.state = hi, lo, state
 
     @staticmethod
-    def from_f32(x, c_out=None):
+    def from_f32(x, c_out=None, state=None, dynamic_batch=False):
         from .. import _lib
-        return SplitAct(*_lib.split_planes(x, c_out))
+        return SplitAct(*_lib.split_planes(x, c_out, state=state, dynamic_batch=dynamic_batch), state=state)
 
     def merge(self):
         from .. import _lib
-        return _lib.merge_planes(self.hi, self.lo)
+        return _lib.merge_planes(self.hi, self.lo, scale=self.state)
 
     @property
     def shape(self):
         return self.hi.shape
+
+
+class SplitScales:
+    """The plane scales of ONE split-precision network (r06): a contiguous (n, 2) float32 device buffer of layer states {scale, recorded maximum},
+    handed out to the network's ConvBiasAct layers (`_sstate`) and to its fp32 -> planes entry point.
+      * every forward records each layer's largest |output| (an atomic max in the convolution's epilogue) and ends with `update()`
+        (tlk_split_scale_update): the scales the NEXT forward uses -- inside a hipGraph capture it is the graph's last node;
+      * `calibrate(run)`: run the network, update, and repeat while a scale grew or a maximum was not finite (an overflow upstream hides the
+        layers behind it: at most one pass per saturating layer, bounded) -- once, on the first forward outside a capture.
+    Scales are powers of two >= 1: a network whose activations fit float16 keeps every scale at 1 and computes the r05 planes bit for bit."""
+
+    def __init__(self, device):
+        import torch
+        self.device = device
+        self.n = 0
+        self.buf = None
+        self.changed = torch.zeros(1, dtype=torch.int32, device=device)
+        self.calibrated = False
+        self._mods = []
+
+    def attach(self, modules, extra=1):
+        """give every module of `modules` (ConvBiasAct layers that write planes) a state row; `extra` more rows for entry points"""
+        import torch
+        self._mods = list(modules)
+        self.n = len(self._mods) + extra
+        self.buf = torch.zeros((self.n, 2), dtype=torch.float32, device=self.device)
+        self.buf[:, 0] = 1.0
+        for i, m in enumerate(self._mods):
+            m._sstate = self.buf[i]
+        return [self.buf[len(self._mods) + j] for j in range(extra)]
+
+    def update(self, count_changes=False):
+        from .. import _lib
+        _lib.split_scale_update(self.buf, self.changed if count_changes else None)
+
+    def calibrate(self, run, max_passes=12):
+        out = None
+        for _ in range(max_passes):
+            self.changed.zero_()
+            out = run()
+            self.update(count_changes=True)
+            if int(self.changed.item()) == 0:
+                break
+        self.calibrated = True
+        return out
+
+    def scales(self):
+        return self.buf[:, 0].clone()
 
 
 class ConvBiasAct(nn.Module):
@@ -148,18 +198,21 @@ class ConvBiasAct(nn.Module):
     def forward(self, x, residual=None, residual_after_act=False, out=None):
         """residual_after_act: y = act(conv + bias) + residual (CSPNeXt's identity add) instead of act(conv + bias + residual) (ResNet).
         out: a channels_last tensor or channel slice of one to write into (see writes_slices; other routes compute, then copy)"""
-        if out is not None and not (isinstance(x, torch.Tensor) and self.writes_slices(x)):
+        if out is not None and not isinstance(x, SplitAct) and not (isinstance(x, torch.Tensor) and self.writes_slices(x)):
             out.copy_(self.forward(x, residual, residual_after_act))
             return out
         if isinstance(x, SplitAct):
             # split-precision route (fp32-class results on the 16-bit MFMA): input, residual and output are (hi, lo) plane pairs
             from .. import _lib
             wh, wl = self._split_weights(x.hi.shape[1])
-            out = _lib.conv2d_nhwc_16(x.hi, wh, self.bias.float() if self.bias.dtype != torch.float32 else self.bias, self.act,
+            of32 = getattr(self, "out_f32", False)
+            st = None if of32 else getattr(self, "_sstate", None)       # r06: this layer's plane state (SplitScales), None = unscaled planes
+            res = _lib.conv2d_nhwc_16(x.hi, wh, self.bias.float() if self.bias.dtype != torch.float32 else self.bias, self.act,
                                       residual.hi if residual is not None else None, self.conv.stride[0], self.conv.padding[0],
                                       x_lo=x.lo, weight_lo=wl, residual_lo=residual.lo if residual is not None else None,
-                                      out_f32=getattr(self, "out_f32", False), residual_after_act=residual_after_act)
-            return out if getattr(self, "out_f32", False) else SplitAct(*out)
+                                      out_f32=of32, residual_after_act=residual_after_act, out=(out.hi, out.lo) if out is not None else None,
+                                      in_scale=x.state, res_scale=residual.state if residual is not None else None, out_state=st)
+            return res if of32 else SplitAct(*res, state=st)
         if x.shape[1] == 3 and residual is None and x.dtype == torch.float16:
             y = self.stem16(x)
             if y is not None:

@@ -12,13 +12,15 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .common import ConvBiasAct, SplitAct, finalize, random_init_
+from .common import ConvBiasAct, SplitAct, SplitScales, finalize, random_init_
 
 import os as _os
 USE_TLK_MAXPOOL = _os.environ.get("TLK_MAXPOOL", "1") != "0"       # 0: torch's max_pool2d (A/B runs)
 # r06: the part-based head (6-channel convolution, softmax, attention pooling, visibility, hand-off gather, non-finite check) as ONE libtlk
 # launch (tlk_reid_part_head); TLK_HEADS=0 restores the library convolution + torch passes for A/B runs
 USE_TLK_HEADS = _os.environ.get("TLK_HEADS", "1") != "0"
+# r06: power-of-two plane scales in the split-precision route (activations beyond float16's range); TLK_SPLIT_SCALES=0: the unscaled planes of r05
+USE_SPLIT_SCALES = _os.environ.get("TLK_SPLIT_SCALES", "1") != "0"
 
 
 class _Bottleneck(nn.Module):
@@ -136,7 +138,7 @@ class _ResNet50(nn.Module):
             # stem -- K = 7 * 7 * 8 padded channels on the r04 kernel, merge, torch's pool, split again -- took ~15 ms and was less exact),
             # the (hi, lo) planes start behind the pool
             from .. import _lib
-            y = SplitAct.from_f32(_lib.maxpool2d_nhwc(self.conv1(x), 3, 2, 1))
+            y = SplitAct.from_f32(_lib.maxpool2d_nhwc(self.conv1(x), 3, 2, 1), state=getattr(self, "_entry_state", None), dynamic_batch=True)
             return self.layer4(self.layer3(self.layer2(self.layer1(y))))
         if split:
             x = SplitAct.from_f32(x, 8)
@@ -173,7 +175,23 @@ class PartBasedReID(nn.Module):
             # fp32 weights, fp32-class arithmetic on the 16-bit MFMA: every convolution of the backbone behind the stem in split mode
             # (csrc/tlk_conv16x.hip; the stem + pool in exact fp32), `reduce` hands fp32 back to the head below
             self.reduce.out_f32 = True
-            return self.reduce(self.backbone(x, split=True))
+            # r06: scaled planes -- every layer's largest |output| is recorded while it runs and the power-of-two scale of its planes follows it
+            # (common.SplitScales), so activations beyond float16's 65504 no longer saturate.  First forward outside a capture: calibration
+            # (run, update, repeat while a scale grew); afterwards one run + the update as the forward's last launch
+            sc = getattr(self, "_split_scales", None)
+            if sc is None and USE_SPLIT_SCALES:
+                sc = SplitScales(x.device)
+                layers = [m for m in self.backbone.modules() if isinstance(m, ConvBiasAct) and m is not self.backbone.conv1]
+                self.backbone._entry_state = sc.attach(layers, extra=1)[0]
+                self._split_scales = sc
+            run = lambda: self.reduce(self.backbone(x, split=True))      # noqa: E731
+            if sc is None:
+                return run()
+            if not sc.calibrated and not torch.cuda.is_current_stream_capturing():
+                return sc.calibrate(run)
+            f = run()
+            sc.update()
+            return f
         return self.reduce(self.backbone(x))                 # (N, D, h, w)
 
     def fused_head_ok(self, f):

@@ -228,6 +228,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
         }
     __syncthreads();
     constexpr int V_PER_ROW = BN / 8, NVEC = BM * V_PER_ROW, ITS = (NVEC + NT - 1) / NT;
+    const SplitScales sc = load_scales(p);
+    float amax = 0.f;
     for (int it = 0; it < ITS; ++it) {
         const int idx = it * NT + tid;
         const int row = idx / V_PER_ROW, ec = (idx - row * V_PER_ROW) * 8;
@@ -239,8 +241,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
             const float4 c0 = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec), c1 = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec + 4);
             float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
             if (p.bias) { b0 = *reinterpret_cast<const float4 *>(p.bias + co); b1 = *reinterpret_cast<const float4 *>(p.bias + co + 4); }
-            v[0] = c0.x + b0.x; v[1] = c0.y + b0.y; v[2] = c0.z + b0.z; v[3] = c0.w + b0.w;
-            v[4] = c1.x + b1.x; v[5] = c1.y + b1.y; v[6] = c1.z + b1.z; v[7] = c1.w + b1.w;
+            if (MODE == MODE_SPLIT) {      // scaled planes (r06): the accumulators hold the sum over x / s_in
+                v[0] = c0.x * sc.in + b0.x; v[1] = c0.y * sc.in + b0.y; v[2] = c0.z * sc.in + b0.z; v[3] = c0.w * sc.in + b0.w;
+                v[4] = c1.x * sc.in + b1.x; v[5] = c1.y * sc.in + b1.y; v[6] = c1.z * sc.in + b1.z; v[7] = c1.w * sc.in + b1.w;
+            } else {
+                v[0] = c0.x + b0.x; v[1] = c0.y + b0.y; v[2] = c0.z + b0.z; v[3] = c0.w + b0.w;
+                v[4] = c1.x + b1.x; v[5] = c1.y + b1.y; v[6] = c1.z + b1.z; v[7] = c1.w + b1.w;
+            }
         }
         float rv[8];
         if (RES) {
@@ -250,7 +257,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
             if (MODE == MODE_SPLIT) {
                 const h16x8 rl = *reinterpret_cast<const h16x8 *>(p.res_lo + m * p.r_pix + co);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) rv[e] += (float)rl[e] * LO_INV;
+                for (int e = 0; e < 8; ++e) rv[e] = (rv[e] + (float)rl[e] * LO_INV) * sc.res;
             }
             if (!p.res_post) {
 #pragma unroll
@@ -270,7 +277,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
         } else if (MODE == MODE_SPLIT) {
             h16x8 oh, ol;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f32(v[e], h, l); oh[e] = h; ol[e] = l; }
+            for (int e = 0; e < 8; ++e) { _Float16 h, l; amax = fmaxf(amax, fabsf(v[e])); split_f32(v[e] * sc.out_inv, h, l); oh[e] = h; ol[e] = l; }
             *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
             *reinterpret_cast<h16x8 *>(p.y_lo + m * p.y_pix + co) = ol;
         } else {
@@ -280,6 +287,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
             *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
         }
     }
+    if (MODE == MODE_SPLIT && !OUT_F32) note_amax(p, amax);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -423,6 +431,8 @@ __global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p,
         }
     __syncthreads();
     constexpr int V_PER_ROW = BN / 8, NVEC = BM * V_PER_ROW, ITS = NVEC / NT;
+    const SplitScales sc = load_scales(p);
+    float amax = 0.f;
 #pragma unroll 2
     for (int it = 0; it < ITS; ++it) {
         const int idx = it * NT + tid;
@@ -435,8 +445,13 @@ __global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p,
             const float4 c0 = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec), c1 = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec + 4);
             float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
             if (p.bias) { b0 = *reinterpret_cast<const float4 *>(p.bias + co); b1 = *reinterpret_cast<const float4 *>(p.bias + co + 4); }
-            v[0] = c0.x + b0.x; v[1] = c0.y + b0.y; v[2] = c0.z + b0.z; v[3] = c0.w + b0.w;
-            v[4] = c1.x + b1.x; v[5] = c1.y + b1.y; v[6] = c1.z + b1.z; v[7] = c1.w + b1.w;
+            if (MODE == MODE_SPLIT) {      // scaled planes (r06): the accumulators hold the sum over x / s_in
+                v[0] = c0.x * sc.in + b0.x; v[1] = c0.y * sc.in + b0.y; v[2] = c0.z * sc.in + b0.z; v[3] = c0.w * sc.in + b0.w;
+                v[4] = c1.x * sc.in + b1.x; v[5] = c1.y * sc.in + b1.y; v[6] = c1.z * sc.in + b1.z; v[7] = c1.w * sc.in + b1.w;
+            } else {
+                v[0] = c0.x + b0.x; v[1] = c0.y + b0.y; v[2] = c0.z + b0.z; v[3] = c0.w + b0.w;
+                v[4] = c1.x + b1.x; v[5] = c1.y + b1.y; v[6] = c1.z + b1.z; v[7] = c1.w + b1.w;
+            }
         }
         float rv[8];
         if (RES) {
@@ -446,7 +461,7 @@ __global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p,
             if (MODE == MODE_SPLIT) {
                 const h16x8 rl = *reinterpret_cast<const h16x8 *>(p.res_lo + m * p.r_pix + co);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) rv[e] += (float)rl[e] * LO_INV;
+                for (int e = 0; e < 8; ++e) rv[e] = (rv[e] + (float)rl[e] * LO_INV) * sc.res;
             }
             if (!p.res_post) {
 #pragma unroll
@@ -466,7 +481,7 @@ __global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p,
         } else if (MODE == MODE_SPLIT) {
             h16x8 oh, ol;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f32(v[e], h, l); oh[e] = h; ol[e] = l; }
+            for (int e = 0; e < 8; ++e) { _Float16 h, l; amax = fmaxf(amax, fabsf(v[e])); split_f32(v[e] * sc.out_inv, h, l); oh[e] = h; ol[e] = l; }
             *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
             *reinterpret_cast<h16x8 *>(p.y_lo + m * p.y_pix + co) = ol;
         } else {
@@ -476,6 +491,7 @@ __global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p,
             *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
         }
     }
+    if (MODE == MODE_SPLIT && !OUT_F32) note_amax(p, amax);
 }
 
 }  // namespace
@@ -566,29 +582,68 @@ template <int MODE, bool OUT_F32> int dispatch16(Conv16Args &a, int act, hipStre
 
 // fp32 NHWC (c_in channels) -> (hi, lo) f16 planes with c_out >= c_in channels (zero padded): the entry of a split-precision network
 __global__ void __launch_bounds__(BLOCK) split_planes_kernel(const float *__restrict__ x, long long pixels, int c_in, int x_pix, int c_out,
-                                                             _Float16 *__restrict__ hi, _Float16 *__restrict__ lo)
+                                                             _Float16 *__restrict__ hi, _Float16 *__restrict__ lo, float *__restrict__ state, const int *__restrict__ n_dyn,
+                                                             long long pix_per_image)
 {
-    const long long n = pixels * c_out;
+    long long n = pixels * c_out;
+    if (n_dyn) { const long long nd = (long long)n_dyn[0] * pix_per_image * c_out; n = nd < n ? (nd < 0 ? 0 : nd) : n; }      // dynamic batch: the live images only
+    const float inv = state ? 1.f / state[0] : 1.f;
+    float am = 0.f;
     for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) {
         const long long px = i / c_out;
         const int c = (int)(i - px * c_out);
         _Float16 h = (_Float16)0.f, l = (_Float16)0.f;
-        if (c < c_in) split_f32(x[px * x_pix + c], h, l);
+        if (c < c_in) { const float v = x[px * x_pix + c]; am = fmaxf(am, fabsf(v)); split_f32(v * inv, h, l); }
         hi[i] = h; lo[i] = l;
+    }
+    if (state) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+        if ((threadIdx.x & 63) == 0 && am > 0.f) atomicMax(reinterpret_cast<unsigned int *>(state + 1), __float_as_uint(am));
     }
 }
 
-__global__ void __launch_bounds__(BLOCK) merge_planes_kernel(const _Float16 *__restrict__ hi, const _Float16 *__restrict__ lo, long long n, float *__restrict__ y)
+__global__ void __launch_bounds__(BLOCK) merge_planes_kernel(const _Float16 *__restrict__ hi, const _Float16 *__restrict__ lo, long long n, float *__restrict__ y,
+                                                             const float *__restrict__ scale)
 {
-    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) y[i] = (float)hi[i] + (float)lo[i] * LO_INV;
+    const float s = scale ? scale[0] : 1.f;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) y[i] = ((float)hi[i] + (float)lo[i] * LO_INV) * s;
+}
+
+// One thread per plane state {scale, bits of the largest |value| recorded since the last update}: the scale for the NEXT forward.
+//   target: largest value / scale <= 2^14 (a factor 4 below float16's 65504); the scale only ever is a power of two >= 1 -- a tensor that fits float16
+//   keeps scale 1 and the planes of r05, bit for bit; it GROWS at once when the recorded maximum asks for it and SHRINKS (to twice the needed
+//   value) only when the maximum fell a factor 8 below what the current scale was chosen for.
+//   `changed` counts the states whose scale grew or whose maximum was not finite (an overflow upstream: the calibration loop runs again).
+__global__ void split_scale_update_kernel(float *__restrict__ states, int n, int *__restrict__ changed)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float scale = states[2 * i];
+    const float am = states[2 * i + 1];
+    if (!(scale >= 1.f)) scale = 1.f;
+    bool ch = false;
+    if (am != am || am > 3.0e38f) ch = true;
+    else if (am > 0.f) {
+        int e = 0;
+        (void)frexpf(am, &e);                              // am = f * 2^e, 0.5 <= f < 1: am < 2^e
+        const int need = e - 14 > 0 ? (e - 14 > 100 ? 100 : e - 14) : 0;
+        const float s_need = ldexpf(1.f, need);
+        if (s_need > scale) { scale = s_need; ch = true; }
+        else if (s_need * 8.f <= scale) scale = s_need * 2.f;
+    }
+    states[2 * i] = scale;
+    states[2 * i + 1] = 0.f;
+    if (ch && changed) atomicAdd(changed, 1);
 }
 
 }  // namespace
 
-extern "C" int tlk_conv2d_nhwc_16(const void *x_dev, const void *x_lo_dev, const void *w_dev, const void *w_lo_dev, const float *bias_dev,
-                                  const void *res_dev, const void *res_lo_dev, void *y_dev, void *y_lo_dev, float *y_f32_dev,
-                                  int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int act_kind,
-                                  int x_pix_stride, int y_pix_stride, int res_pix_stride, void *hip_stream)
+static int conv16_entry(const void *x_dev, const void *x_lo_dev, const void *w_dev, const void *w_lo_dev, const float *bias_dev,
+                        const void *res_dev, const void *res_lo_dev, void *y_dev, void *y_lo_dev, float *y_f32_dev,
+                        int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int act_kind,
+                        int x_pix_stride, int y_pix_stride, int res_pix_stride, const float *in_scale_dev, const float *res_scale_dev, float *out_state_dev,
+                        void *hip_stream)
 {
     if (n < 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || pad < 0)
         return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: bad shape");
@@ -615,6 +670,9 @@ extern "C" int tlk_conv2d_nhwc_16(const void *x_dev, const void *x_lo_dev, const
     a.r_pix = res_pix_stride > 0 ? res_pix_stride : cout;
     a.res_post = res_post;
     a.n_dyn = conv_dynamic_batch();
+    if ((in_scale_dev || res_scale_dev || out_state_dev) && !split) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16s: plane scales belong to the split mode");
+    if (out_state_dev && out32) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16s: an fp32 output carries no scale (out_state must be NULL)");
+    a.s_in = in_scale_dev; a.s_res = res_dev ? res_scale_dev : nullptr; a.s_out = out_state_dev;
     if (a.x_pix < cin || a.y_pix < cout || a.r_pix < cout || (a.x_pix | a.y_pix | a.r_pix) % 8 != 0)
         return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: pixel strides must cover the channels and be multiples of 8");
     if (((uintptr_t)x_dev | (uintptr_t)x_lo_dev | (uintptr_t)w_dev | (uintptr_t)w_lo_dev | (uintptr_t)res_dev | (uintptr_t)res_lo_dev | (uintptr_t)y_dev |
@@ -623,6 +681,25 @@ extern "C" int tlk_conv2d_nhwc_16(const void *x_dev, const void *x_lo_dev, const
     hipStream_t st = (hipStream_t)hip_stream;
     if (split) return out32 ? dispatch16<MODE_SPLIT, true>(a, act_kind, st) : dispatch16<MODE_SPLIT, false>(a, act_kind, st);
     return out32 ? dispatch16<MODE_F16, true>(a, act_kind, st) : dispatch16<MODE_F16, false>(a, act_kind, st);
+}
+
+extern "C" int tlk_conv2d_nhwc_16(const void *x_dev, const void *x_lo_dev, const void *w_dev, const void *w_lo_dev, const float *bias_dev,
+                                  const void *res_dev, const void *res_lo_dev, void *y_dev, void *y_lo_dev, float *y_f32_dev,
+                                  int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int act_kind,
+                                  int x_pix_stride, int y_pix_stride, int res_pix_stride, void *hip_stream)
+{
+    return conv16_entry(x_dev, x_lo_dev, w_dev, w_lo_dev, bias_dev, res_dev, res_lo_dev, y_dev, y_lo_dev, y_f32_dev, n, h, w, cin, cout, kh, kw, stride, pad, act_kind,
+                        x_pix_stride, y_pix_stride, res_pix_stride, nullptr, nullptr, nullptr, hip_stream);
+}
+
+extern "C" int tlk_conv2d_nhwc_16s(const void *x_dev, const void *x_lo_dev, const void *w_dev, const void *w_lo_dev, const float *bias_dev,
+                                   const void *res_dev, const void *res_lo_dev, void *y_dev, void *y_lo_dev, float *y_f32_dev,
+                                   int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int pad, int act_kind,
+                                   int x_pix_stride, int y_pix_stride, int res_pix_stride, const float *in_scale_dev, const float *res_scale_dev,
+                                   float *out_state_dev, void *hip_stream)
+{
+    return conv16_entry(x_dev, x_lo_dev, w_dev, w_lo_dev, bias_dev, res_dev, res_lo_dev, y_dev, y_lo_dev, y_f32_dev, n, h, w, cin, cout, kh, kw, stride, pad, act_kind,
+                        x_pix_stride, y_pix_stride, res_pix_stride, in_scale_dev, res_scale_dev, out_state_dev, hip_stream);
 }
 
 extern "C" int tlk_conv16_set_glds(int on) { g_glds = on ? 1 : 0; return TLK_OK; }
@@ -634,7 +711,8 @@ extern "C" int tlk_conv16_set_config(int cfg)
     return TLK_OK;
 }
 
-extern "C" int tlk_split_f32_planes(const float *x_dev, long long pixels, int c_in, int x_pix_stride, int c_out, void *hi_dev, void *lo_dev, void *hip_stream)
+static int split_planes_entry(const float *x_dev, long long pixels, int c_in, int x_pix_stride, int c_out, void *hi_dev, void *lo_dev, float *state_dev,
+                              long long pixels_per_image, void *hip_stream)
 {
     if (pixels < 0 || c_in <= 0 || c_out < c_in) return fail(TLK_EINVAL, "tlk_split_f32_planes: bad shape");
     if (pixels == 0) return TLK_OK;
@@ -643,19 +721,52 @@ extern "C" int tlk_split_f32_planes(const float *x_dev, long long pixels, int c_
     long long blocks = (n + BLOCK - 1) / BLOCK;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)hip_stream, x_dev, pixels, c_in,
-                       x_pix_stride > 0 ? x_pix_stride : c_in, c_out, (_Float16 *)hi_dev, (_Float16 *)lo_dev);
+                       x_pix_stride > 0 ? x_pix_stride : c_in, c_out, (_Float16 *)hi_dev, (_Float16 *)lo_dev, state_dev,
+                       pixels_per_image > 0 ? conv_dynamic_batch() : nullptr, pixels_per_image);
     TLK_HIP(hipGetLastError());
     return TLK_OK;
 }
 
-extern "C" int tlk_merge_planes_f32(const void *hi_dev, const void *lo_dev, long long n, float *y_dev, void *hip_stream)
+extern "C" int tlk_split_f32_planes(const float *x_dev, long long pixels, int c_in, int x_pix_stride, int c_out, void *hi_dev, void *lo_dev, void *hip_stream)
+{
+    return split_planes_entry(x_dev, pixels, c_in, x_pix_stride, c_out, hi_dev, lo_dev, nullptr, 0, hip_stream);
+}
+
+extern "C" int tlk_split_f32_planes_s(const float *x_dev, long long pixels, int c_in, int x_pix_stride, int c_out, void *hi_dev, void *lo_dev, float *state_dev,
+                                      long long pixels_per_image, void *hip_stream)
+{
+    return split_planes_entry(x_dev, pixels, c_in, x_pix_stride, c_out, hi_dev, lo_dev, state_dev, pixels_per_image, hip_stream);
+}
+
+static int merge_planes_entry(const void *hi_dev, const void *lo_dev, long long n, float *y_dev, const float *scale_dev, void *hip_stream)
 {
     if (n < 0) return fail(TLK_EINVAL, "tlk_merge_planes_f32: bad size");
     if (n == 0) return TLK_OK;
     if (!hi_dev || !lo_dev || !y_dev) return fail(TLK_EINVAL, "tlk_merge_planes_f32: null pointer");
     long long blocks = (n + BLOCK - 1) / BLOCK;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)hip_stream, (const _Float16 *)hi_dev, (const _Float16 *)lo_dev, n, y_dev);
+    hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)hip_stream, (const _Float16 *)hi_dev, (const _Float16 *)lo_dev, n, y_dev,
+                       scale_dev);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
+
+extern "C" int tlk_merge_planes_f32(const void *hi_dev, const void *lo_dev, long long n, float *y_dev, void *hip_stream)
+{
+    return merge_planes_entry(hi_dev, lo_dev, n, y_dev, nullptr, hip_stream);
+}
+
+extern "C" int tlk_merge_planes_f32_s(const void *hi_dev, const void *lo_dev, long long n, const float *scale_dev, float *y_dev, void *hip_stream)
+{
+    return merge_planes_entry(hi_dev, lo_dev, n, y_dev, scale_dev, hip_stream);
+}
+
+extern "C" int tlk_split_scale_update(float *states_dev, int n_states, int *changed_dev, void *hip_stream)
+{
+    if (n_states < 0) return fail(TLK_EINVAL, "tlk_split_scale_update: bad count");
+    if (n_states == 0) return TLK_OK;
+    if (!states_dev) return fail(TLK_EINVAL, "tlk_split_scale_update: null pointer");
+    hipLaunchKernelGGL(split_scale_update_kernel, dim3((unsigned)((n_states + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream, states_dev, n_states, changed_dev);
     TLK_HIP(hipGetLastError());
     return TLK_OK;
 }

@@ -29,6 +29,12 @@ struct Conv16Args {
     long long tiles;
     int res_post;                 // 1: the residual is added AFTER the activation (y = act(conv + bias) + r)
     const int *n_dyn;             // not NULL: live image count in device memory (tlk_conv_set_dynamic_batch); the call's n is the capacity
+    // r06, split mode only -- SCALED planes: a tensor's value is scale * (hi + lo * 2^-11) with scale a power of two kept in device memory beside
+    // the tensor, so that activations beyond float16's range (65504) no longer saturate.  s_in / s_res: the scale of the input / residual planes
+    // (NULL = 1); s_out: this layer's output state {scale in use, bits of the largest |output| seen since the last tlk_split_scale_update}
+    // (NULL = unscaled output, nothing recorded).  Powers of two: every multiplication by a scale is exact.
+    const float *s_in = nullptr, *s_res = nullptr;
+    float *s_out = nullptr;
 };
 
 #if defined(__HIPCC__)
@@ -43,6 +49,24 @@ __device__ __forceinline__ void split_f32(float v, _Float16 &hi, _Float16 &lo)
 {
     hi = (_Float16)v;
     lo = (_Float16)((v - (float)hi) * LO_SCALE);
+}
+
+struct SplitScales { float in, res, out_inv; };
+__device__ __forceinline__ SplitScales load_scales(const Conv16Args &p)
+{
+    SplitScales s;
+    s.in = p.s_in ? p.s_in[0] : 1.f;
+    s.res = p.s_res ? p.s_res[0] : 1.f;
+    s.out_inv = p.s_out ? 1.f / p.s_out[0] : 1.f;          // (a power of two: the reciprocal and the products with it are exact)
+    return s;
+}
+// largest |output| of this lane -> the layer's state word (one atomic per wavefront; non-negative floats order like their bit patterns)
+__device__ __forceinline__ void note_amax(const Conv16Args &p, float am)
+{
+    if (!p.s_out) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+    if ((threadIdx.x & 63) == 0 && am > 0.f) atomicMax(reinterpret_cast<unsigned int *>(p.s_out + 1), __float_as_uint(am));
 }
 
 // rows of this launch that exist: the static M, or n_dyn[0] images' worth when a dynamic batch is set

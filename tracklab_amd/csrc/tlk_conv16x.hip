@@ -408,6 +408,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
     // ---- epilogue: EPI MFMA tile rows of every wavefront at a time through LDS as fp32, then 8 output channels (16 bytes of f16) per lane.
     // C/D map of the 32x32 tile: column (= cout) = lane & 31, row (= pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     float *Cs = reinterpret_cast<float *>(lds);
+    SplitScales sc = {1.f, 1.f, 1.f};
+    if (MODE == MODE_SPLIT) sc = load_scales(p);
+    float amax = 0.f;
 #pragma unroll
     for (int i0 = 0; i0 < TM; i0 += EPI) {
 #pragma unroll
@@ -437,6 +440,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
                 const float4 c0 = *reinterpret_cast<const float4 *>(Cs + prow * LDC + ec + 4 * q4);
                 v[4 * q4] = c0.x; v[4 * q4 + 1] = c0.y; v[4 * q4 + 2] = c0.z; v[4 * q4 + 3] = c0.w;
             }
+            if (MODE == MODE_SPLIT) {      // scaled planes (r06): the accumulators hold the sum over x / s_in
+#pragma unroll
+                for (int e = 0; e < VW; ++e) v[e] *= sc.in;
+            }
             if (p.bias) {
 #pragma unroll
                 for (int q4 = 0; q4 < VW / 4; ++q4) {
@@ -460,7 +467,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
                     if (MODE == MODE_SPLIT) {
                         const h16x8 rl = *reinterpret_cast<const h16x8 *>(p.res_lo + m * p.r_pix + co);
 #pragma unroll
-                        for (int e = 0; e < VW; ++e) rv[e] += (float)rl[e & 7] * LO_INV;
+                        for (int e = 0; e < VW; ++e) rv[e] = (rv[e] + (float)rl[e & 7] * LO_INV) * sc.res;
                     }
                 }
                 if (!p.res_post) {
@@ -486,7 +493,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
             } else if (MODE == MODE_SPLIT) {
                 h16x8 oh, ol;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f32(v[e % VW], h, l); oh[e] = h; ol[e] = l; }
+                for (int e = 0; e < 8; ++e) { _Float16 h, l; amax = fmaxf(amax, fabsf(v[e % VW])); split_f32(v[e % VW] * sc.out_inv, h, l); oh[e] = h; ol[e] = l; }
                 *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
                 *reinterpret_cast<h16x8 *>(p.y_lo + m * p.y_pix + co) = ol;
             } else {
@@ -498,6 +505,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
         }
         if (i0 + EPI < TM) __syncthreads();
     }
+    if (MODE == MODE_SPLIT) note_amax(p, amax);
 }
 
 template <int WGM, int WGN, int TM, int TN, int MODE, int NST, bool RESPF> int launch_x(Conv16Args &a, int act, hipStream_t st)
@@ -655,6 +663,11 @@ int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream
         } else {
             if (a.Cout % 256 == 0 && a.K >= 256 && !a.res && ((a.M + 127) / 128) * (a.Cout / 256) >= 512) cfg = 1;
             else if (a.Cout % 128 == 0 && a.K >= 256 && !a.res && ((a.M + 255) / 256) * (a.Cout / 128) >= 512) cfg = 2;
+            // r06: the 1 x 1 expansions WITH residual (ResNet's c3: 44 of the split ReID forward's 120 ms sat on the r04 kernel).  128 x 128 tiles of
+            // EIGHT wavefronts of 32 x 64 -- 64 accumulator registers per lane, two workgroups' worth of wavefronts per SIMD, residual planes read in the
+            // epilogue: one stage for the short-K layers (K <= 128: 3.41 vs 3.69 ms on 64 -> 256, 2.12 vs 2.16 on 128 -> 512), two stages beyond
+            // (1.40 vs 1.45 on 256 -> 1024, 4.08 vs 4.37 on 512 -> 2048; profiles/r06_split_res_probe.txt)
+            else if (a.res && a.Cout % 128 == 0 && ((a.M + 127) / 128) * (a.Cout / 128) >= 512) cfg = a.K <= 128 ? 6 : 7;
             else return 1;
         }
     }

@@ -31,9 +31,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // upstream must stay visible to the pipeline's non-finite check, the reason the kernels' ReLU was rewritten in r05)
 template <typename V> __device__ __forceinline__ V vmax(V a, V b)
 {
-    V r;
-#pragma unroll
-    for (int e = 0; e < (int)(sizeof(V) / sizeof(a[0])); ++e) r[e] = (a[e] != a[e] || a[e] > b[e]) ? a[e] : b[e];
+    V r = __builtin_elementwise_max(a, b);               // the non-NaN operand where one is NaN ...
+    r = (a != a) ? a : r;                                 // ... put back (vector selects: packed v_cmp / v_cndmask)
+    r = (b != b) ? b : r;
     return r;
 }
 

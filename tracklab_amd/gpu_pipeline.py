@@ -26,6 +26,49 @@ from . import _lib
 from .backbones.yolox import yolox
 
 
+def streams_run_concurrently(sa, sb, cycles: int = 400_000) -> bool:
+    """Do two HIP streams execute side by side?  HIP deals the streams of a process to a small pool of hardware queues; two streams that landed
+    on ONE queue run their kernels strictly one after the other whatever the events between them say (measured r05 / r06: the stage-overlap
+    mode then LOSES to the serial pipeline; with an RCCL communicator alive in the process the assignment shifts and the priority trick of r05
+    no longer separates the two stage streams).  So it is MEASURED: a spin kernel of ~`cycles` shader cycles on each stream, timestamps from
+    events on a common clock -- concurrent iff each one started before the other ended."""
+    dev = sa.device
+    base = torch.cuda.Event(enable_timing=True)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(2)]
+    torch.cuda.synchronize(dev)
+    base.record(torch.cuda.current_stream(dev))
+    for s_ in (sa, sb):
+        s_.wait_event(base)
+    for _ in range(2):                        # first round: warm (module load of the spin kernel)
+        for i, s_ in enumerate((sa, sb)):
+            with torch.cuda.stream(s_):
+                ev[i][0].record(s_)
+                torch.cuda._sleep(cycles)
+                ev[i][1].record(s_)
+        sa.synchronize(); sb.synchronize()
+    a0, a1 = base.elapsed_time(ev[0][0]), base.elapsed_time(ev[0][1])
+    b0, b1 = base.elapsed_time(ev[1][0]), base.elapsed_time(ev[1][1])
+    # overlapping intervals, with at least a third of the shorter one shared (two back-to-back kernels touch at a point, never more)
+    shared = min(a1, b1) - max(a0, b0)
+    return shared > 0.33 * min(a1 - a0, b1 - b0)
+
+
+def pick_concurrent_streams(dev, tries: int = 6):
+    """(stage-A stream, stage-B stream, how) that were OBSERVED to run concurrently, or None.  Candidates: r05's pair first (detector stage at high
+    priority, ReID stage at normal), then further streams of either priority -- every creation moves on through the queue pool."""
+    prio = int(__import__("os").environ.get("TLK_DET_PRIO", "-1"))
+    cands = []
+    for k in range(tries):
+        if k == 0:
+            pair = (torch.cuda.Stream(device=dev, priority=prio), torch.cuda.Stream(device=dev))
+        else:
+            pair = (torch.cuda.Stream(device=dev, priority=prio if k % 2 == 0 else 0), torch.cuda.Stream(device=dev, priority=0 if k % 3 else prio))
+        cands.append(pair)                    # (kept alive: a destroyed stream hands its queue slot back and the next creation lands there again)
+        if streams_run_concurrently(*pair):
+            return pair[0], pair[1], f"pair {k} (priorities {pair[0].priority}, {pair[1].priority})"
+    return None
+
+
 def _record_null_pair(self):
     """Two timing events with nothing between them on the current stream: the cost of an event pair itself (a few us on this stack -- not negligible
     beside a 30 us kernel). bench.py subtracts its mean from the mean of the kernel's own event pairs and prints both."""
@@ -369,9 +412,26 @@ class DetReidTrackPipeline:
         # r05, overlap_stages: stage A (letterbox, detector, decode + NMS, crops) of step t + 1 runs on its own stream beside stage B (ReID
         # forward, hand-off) of step t; what A writes and B reads -- crops, slot bases, live count -- exists twice, B's results go to the
         # per-step ring `bufs` as before.  Only the plain BPBReID chain (no pose stage, no camera motion, dense batch) is wired for it.
+        # r06: `None` = AUTO -- on for the online shapes (at most two frames of every stream per step: a launch then has fewer tiles than the chip has
+        # CUs and the two stages fill each other's gaps: 344 vs 232 frames/s at one frame per step), off for the throughput shapes (24 frames per
+        # step fill the chip by themselves).  TLK_PIPE_OVERLAP=0 / 1 forces it.  Whatever asked for it, the mode is only ENTERED with a pair of
+        # streams that was observed to run concurrently (pick_concurrent_streams); without one the pipeline stays serial and says so
+        # (`overlap_note`): same rows either way (tests/test_gpu_zz_stage_overlap.py), so the fallback is a speed matter only.
+        env_ov = __import__("os").environ.get("TLK_PIPE_OVERLAP", "auto")
         if overlap_stages is None:
-            overlap_stages = __import__("os").environ.get("TLK_PIPE_OVERLAP", "0") == "1"
+            overlap_stages = (frames_per_step <= 2) if env_ov == "auto" else env_ov == "1"
         self.overlap = bool(overlap_stages) and self.dense_reid and self.pose is None and not camera_motion
+        self.overlap_note = "off"
+        picked = None
+        if self.overlap:
+            picked = pick_concurrent_streams(dev)
+            if picked is None:
+                self.overlap = False
+                self.overlap_note = "asked for, but no pair of streams ran concurrently on this device / in this process: serial pipeline"
+                import logging
+                logging.getLogger(__name__).warning("DetReidTrackPipeline: stage overlap %s", self.overlap_note)
+            else:
+                self.overlap_note = "on: " + picked[2]
         self.sets = [{"crops": self.crops, "slot_base": self.slot_base, "n_live": self.n_live, "slot_of": self.slot_of,
                       "a_done": torch.cuda.Event(), "b_done": torch.cuda.Event()}]
         if self.overlap:
@@ -380,8 +440,8 @@ class DetReidTrackPipeline:
             # the two stages only overlap when their streams sit on DIFFERENT hardware queues; HIP deals streams of one priority to a small
             # pool of queues round-robin, so two normal-priority streams may share one (measured: 219 frames/s then, 330 when they do not).
             # Streams of different priorities never share a queue: the detector stage gets the high-priority one (TLK_DET_PRIO overrides).
-            self.det_stream = torch.cuda.Stream(device=dev, priority=int(__import__("os").environ.get("TLK_DET_PRIO", "-1")))
-            self.reid_stream = torch.cuda.Stream(device=dev)
+            # (r06: the pair comes from pick_concurrent_streams, which MEASURED that the two run side by side)
+            self.det_stream, self.reid_stream = picked[0], picked[1]
         # f16 and split-precision backbones carry activations as float16 (pairs): |x| > 65504 saturates to infinity.  The envelope is stated in
         # DESIGN.md (tests/test_gpu_precision.py measures it); past it the run must fail LOUDLY, not track on infinities: every step ORs
         # "an embedding is not finite" into a device flag that travels to pinned memory with the results and is checked in synchronize()

@@ -352,8 +352,19 @@ def _signatures(g: OnnxGraph, intern: _Interner):
                 elif n.op == "Concat":
                     s = intern("cat", tuple(ins))
                 elif n.op == "Slice":                       # Focus: the four phase slices differ by their constant starts
-                    starts = tuple(int(t) for x in n.inputs[1:] if x in g.tensors for t in np.asarray(g.tensors[x]).reshape(-1)[:4])
-                    s = intern("slice", starts, tuple(ins[:1]))
+                    # canonical form (axes, starts, steps): the END of a slice is written differently by different exporters (INT64_MAX, the
+                    # concrete extent, a Shape-derived value) and does not say which phase it is; opset < 10 carries starts / axes as attributes
+                    def consts(k, attr):
+                        v_ = n.inputs[k] if k < len(n.inputs) else None
+                        for _ in range(6):                   # exporters without constant folding wrap the constants: Unsqueeze(Constant, axes)
+                            if v_ is None or v_ in g.tensors:
+                                break
+                            pi = producer.get(v_)
+                            v_ = g.nodes[pi].inputs[0] if pi is not None and g.nodes[pi].op in ("Unsqueeze", "Squeeze", "Identity", "Cast", "Reshape") else None
+                        if v_ is not None and v_ in g.tensors:
+                            return tuple(int(t) for t in np.asarray(g.tensors[v_]).reshape(-1)[:4])
+                        return tuple(int(t) for t in (n.attrs.get(attr) or []))[:4]
+                    s = intern("slice", consts(3, "axes"), consts(1, "starts"), consts(4, "steps"), tuple(ins[:1]))
                 else:
                     uniq = tuple(sorted(set(ins)))
                     if len(uniq) == 1:
@@ -391,13 +402,18 @@ def _signatures(g: OnnxGraph, intern: _Interner):
                     continue
                 if c.op in _SHAPE_ONLY:
                     continue
-                tok = ("cat", slot) if c.op == "Concat" else (c.op,)
+                # path tokens: Concat slots and the operators that change what flows (pooling, resizing, slicing).  The element-wise
+                # operators are NOT part of the path: how an exporter spells bias + activation differs between files of one architecture --
+                # Conv with the BatchNorm-folded bias inside, then Sigmoid + Mul (mmdeploy / rtmlib) against Conv, Add(bias), Sigmoid, Mul
+                # (this repo's modules keep the bias outside the convolution) -- r06, found by the hand-written rtmlib-style file of
+                # tests/test_weights.py
+                tok = (("cat", slot),) if c.op == "Concat" else () if c.op in _TRANSPARENT else ((c.op,),)
                 key = (ci, slot)
                 if key in seen or len(path) > 24:
                     continue
                 seen.add(key)
                 for o in c.outputs:
-                    stack.append((o, path + (tok,)))
+                    stack.append((o, path + tok))
         return out
 
     down = {i: first_weighted_consumers(i) for i in up}
