@@ -448,12 +448,10 @@ def main():
     if use_dist:
         dist = tdist.init("nccl")
         dist_note = f"nccl (RCCL), torchrun process group of {world}"
-    elif os.environ.get("TLK_NO_DIST") != "1":
-        try:
-            dist = tdist.init_single("nccl")
-            dist_note = "nccl (RCCL), one-rank process group initialised in-process: barrier / all-reduce(max, sum) / all-gather run on RCCL"
-        except Exception as ex:                                 # noqa: BLE001
-            dist, dist_note = None, f"none: one-rank nccl group failed to initialise ({type(ex).__name__}: {ex})"[:300]
+    # (the one-rank group of the no-torchrun N = 1 line is created BELOW, after the small-step legs: with an RCCL communicator alive in the process
+    #  the stage-overlap mode of the one-frame pipelines loses its gain -- 224 against 337-344 frames/s, profiles/r06_overlap_probe.txt -- although
+    #  its two streams still measure as concurrent; TrackLab's own process has no communicator, so the online legs are measured without one)
+    defer_group = not use_dist and os.environ.get("TLK_NO_DIST") != "1"
     if dist is None:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if use_dist else 0)
@@ -493,7 +491,7 @@ def main():
         if is3:
             kw = dict(dim=wl["dim"]) if "dim" in wl else {}
             if overlap is not None:
-                kw["overlap_stages"] = bool(overlap)
+                kw["overlap_stages"] = overlap if overlap == "auto" else bool(overlap)
             if "reid_arch" in wl:
                 kw["reid_arch"] = wl["reid_arch"]
             if wl.get("camera_motion"):
@@ -631,6 +629,97 @@ def main():
                       "tracks": int(max((g[:, 4].max() if len(g) else 0) for g in got))}
         pipe.reset()
 
+    # ---- small-step legs: the same chain at frames_per_step 1 / 2 / 4 and at 4 streams x 1 frame (what an online consumer sees; the
+    # reference's online engine is per-frame, engine/video.py:67-117). Each: pipelined frames/s, un-overlapped frame-in -> rows-out time,
+    # and for the BPBReID workloads the ids of up to 48 frames per checked stream against the oracle chain ----
+    def small_step_legs(dt, with_main, overlap=None):
+        """overlap None: the pipeline's default mode (auto); False: serial, forced; True: detector stage of step t + 1 beside the ReID stage of step t"""
+        shapes = [(1, 1), (1, 2), (1, 4), (4, 1)] if is3 else [(1, 1), (1, 4)]
+        if overlap:
+            shapes = [(1, 1), (1, 2), (4, 1)]
+        latency = []
+        for S_, F_ in shapes:
+            if S_ * F_ > B:
+                continue
+            p1 = make_pipe(F_, S_, dt, overlap=overlap)
+            T_ = 48 if S_ * F_ > 1 else 36
+            hs = [heads_np[0][:T_]] + [build_stream_inputs(5000 + s_, n_objects, T_, ratio)[0] for s_ in range(1, S_)]
+            hsteps = np.ascontiguousarray(np.stack(hs).reshape(S_, T_ // F_, F_, -1, heads_np.shape[-1]).transpose(1, 0, 2, 3, 4)).reshape(
+                T_ // F_, S_ * F_, -1, heads_np.shape[-1])
+            d_h1 = torch.from_numpy(hsteps).to(dev)
+            fr1 = d_pool[0][:S_ * F_]                            # one fixed frame buffer -> one hipGraph
+            n1 = T_ // F_
+            stp = lambda j: p1.step(fr1, d_h1[j % n1])                        # noqa: E731
+            leg_parity = None
+            if is3 and not ssort and wl.get("pose") is None:
+                import oracle
+                refs = {s_: oracle.StrongSORT(p1.K, p1.D, **p1.tracker_cfg) for s_ in sorted({0, S_ - 1})}
+                okl, nfr = True, 0
+                for j in range(n1):
+                    h_rows, h_cnt = stp(j)
+                    p1.synchronize()
+                    rws, _ = p1.rows_numpy(h_rows, h_cnt)
+                    emb = p1.last["emb"].cpu().numpy().reshape(S_, F_, p1.maxd, p1.K, p1.D)
+                    vis = p1.last["vis"].cpu().numpy().reshape(S_, F_, p1.maxd, p1.K)
+                    for s_, ref_ in refs.items():
+                        for f in range(F_):
+                            ltwh32 = detector_rows(oracle, hs[s_][j * F_ + f], ratio)
+                            n = len(ltwh32)
+                            ids = (j * S_ * F_ + s_ * F_ + f) * p1.maxd + np.arange(n)
+                            exp = ref_.update(ids, ltwh32.astype(np.float64), emb[s_, f, :n], vis[s_, f, :n], np.ones(n)) if n else []
+                            got = rws[s_][f]
+                            okl &= len(got) == len(exp) and (len(exp) == 0 or (np.array_equal(got["det_id"], exp["det_id"]) and
+                                                                               np.array_equal(got["track_id"], exp["track_id"])))
+                            nfr += 1
+                leg_parity = {"frames": nfr, "streams_checked": sorted(refs), "track_ids_equal_oracle": bool(okl)}
+                p1.reset()
+            for j in range(8):
+                stp(j)
+            p1.synchronize(); torch.cuda.synchronize()
+            nrun = max(n1, 40)
+            t0 = time.perf_counter()
+            for j in range(nrun):
+                stp(j)
+            p1.synchronize(); torch.cuda.synchronize()
+            el1 = time.perf_counter() - t0
+            lat = []
+            for j in range(15):                                  # true in-to-out latency: one step, wait for its rows
+                t1 = time.perf_counter(); stp(j); p1.synchronize(); lat.append(time.perf_counter() - t1)
+            latency.append({"n_streams": S_, "frames_per_step": F_, "fps": nrun * S_ * F_ / el1, "ms_per_step_pipelined": el1 / nrun * 1e3,
+                            "ms_frame_in_to_rows_out": float(np.median(lat) * 1e3), "parity": leg_parity, "overlap_stages": bool(getattr(p1, "overlap", False)), "overlap_note": getattr(p1, "overlap_note", None),
+                            "overlap_trial": getattr(p1, "overlap_trial", None)})
+            p1.close()
+            del p1, d_h1
+        if with_main:
+            lat_main = []
+            for j in range(4):
+                pipe.synchronize(); t1 = time.perf_counter(); run_step(j); pipe.synchronize(); lat_main.append(time.perf_counter() - t1)
+            latency.append({"n_streams": S, "frames_per_step": F, "fps": fps_res, "ms_per_step_pipelined": el_res / args.steps * 1e3,
+                            "ms_frame_in_to_rows_out": float(np.median(lat_main) * 1e3), "parity": "see `parity`"})
+            pipe.reset()
+        return latency
+
+    latency = latency_f16 = latency_f16_overlap = None
+    if rank == 0 and world == 1 and not args.no_latency_leg and F > 1:
+        pipe.reset()
+        latency = small_step_legs(tdtype, False)              # the pipeline's DEFAULT mode (r06: stage overlap is automatic for the one-frame f16 shapes)
+        if args.dtype == "f32":           # the online target (>= 240 frames/s at small steps) is out of any fp32 path's reach on this chip (one frame = 1.36 TFLOP of
+            latency_f16 = small_step_legs(torch.float16, False, overlap=False)      # convolutions = 8.6 ms at the fp32 MFMA peak): the f16 legs are reported beside (serial, forced)
+        if is3 and not ssort and wl.get("pose") is None and not wl.get("camera_motion"):
+            try:              # r06: the AUTO mode at every small shape -- the first step measures both modes on its own inputs and keeps the faster (`overlap_trial`);
+                              # reported beside the forced-serial legs: an exception here must not cost the run its line
+                latency_f16_overlap = small_step_legs(torch.float16, False, overlap="auto")
+            except Exception as ex:                             # noqa: BLE001
+                latency_f16_overlap = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+
+    if defer_group:
+        try:
+            dist = tdist.init_single("nccl")
+            dist_note = ("nccl (RCCL), one-rank process group initialised in-process (after the small-step legs, before the timed legs): barrier / "
+                         "all-reduce(max, sum) / all-gather of the timed legs and the HOTA statistics run on RCCL")
+        except Exception as ex:                                 # noqa: BLE001
+            dist, dist_note = None, f"none: one-rank nccl group failed to initialise ({type(ex).__name__}: {ex})"[:300]
+
     # ---- leg 1: frames resident in HBM. warmup, then the timed region ----
     def timed_resident(p, steps, warmup):
         for k in range(warmup):
@@ -652,6 +741,13 @@ def main():
     el_res_local = timed_resident(pipe, args.steps, args.warmup)
     el_res = tdist.allreduce_max(el_res_local, dist, dev)
     fps_res = args.steps * B * world / el_res
+    if latency is not None:
+        lat_main = []
+        for j in range(4):
+            pipe.synchronize(); t1 = time.perf_counter(); run_step(j); pipe.synchronize(); lat_main.append(time.perf_counter() - t1)
+        latency.append({"n_streams": S, "frames_per_step": F, "fps": fps_res, "ms_per_step_pipelined": el_res / args.steps * 1e3,
+                        "ms_frame_in_to_rows_out": float(np.median(lat_main) * 1e3), "parity": "see `parity`"})
+        pipe.reset()
 
     # ---- leg 2 (the headline): frames arrive from pinned host memory, one video through HipVideoEngine ----
     fps_h2d = el_h2d = None
@@ -861,93 +957,65 @@ def main():
                 pass
         return rf
 
+    def split_roofline(p_):
+        """MFMA roofline of the SPLIT-precision convolutions of pipeline `p_`'s ReID network: the 16-bit MFMA flops they really
+        execute -- three products per operand pair, i.e. 3 x the fp32 convolution's algorithmic flops -- / the sum of their launch durations (HIP
+        events around every launch of two eager passes over the step's own crops) / the dense f16 MFMA peak."""
+        from tracklab_amd.backbones import common as bc
+        from tracklab_amd import _lib as _tl
+        crops_v = p_.crops.permute(0, 3, 1, 2)
+        dense = bool(getattr(p_, "dense_reid", False))
+        live_crops = int(p_.n_live.item()) if dense else B * p_.maxd
+
+        def reid_eager():
+            if dense:
+                _tl.conv_set_dynamic_batch(p_.n_live)
+                bc.LIVE_BATCH = (B * p_.maxd, live_crops)
+            try:
+                p_.reid.features(crops_v)
+            finally:
+                if dense:
+                    _tl.conv_set_dynamic_batch(None)
+                    bc.LIVE_BATCH = None
+        with torch.no_grad():
+            reid_eager()
+            torch.cuda.synchronize()
+            bc.CONV_TIMER = []
+            for _ in range(2):
+                reid_eager()
+            torch.cuda.synchronize()
+            recs, bc.CONV_TIMER = bc.CONV_TIMER, None
+        sp = [r for r in recs if r[5][0] == "split"]
+        ms = sum(r[0].elapsed_time(r[1]) - r[2].elapsed_time(r[3]) for r in sp)
+        flop32 = sum(r[4] for r in sp)
+        nbytes = sum(r[6] for r in sp)
+        mfma_tf = 3.0 * flop32 / (ms * 1e-3) / 1e12
+        groups = {}
+        for r in sp:
+            g_ = groups.setdefault("1 x 1 expansions with residual" if r[5][2] else "no residual", [0, 0.0, 0.0])
+            g_[0] += 1; g_[1] += r[0].elapsed_time(r[1]) - r[2].elapsed_time(r[3]); g_[2] += r[4]
+        scales = getattr(p_.reid, "_split_scales", None)
+        return {"kernel": "conv16x_kernel / conv16_glds_kernel / conv16_mfma_kernel in split mode (tlk_conv2d_nhwc_16s: three v_mfma_f32_32x32x16_f16 per operand pair, "
+                          "two fp32 accumulators, scaled (hi, lo) planes)",
+                "bound": "mfma", "achieved": mfma_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": mfma_tf / 2500.0, "traffic": None,
+                "what_is_counted": "f16 MFMA flops executed = 3 x the algorithmic flops of the fp32 convolutions the launches stand for (live crops only); the "
+                                   "exact-fp32 stem + pool ahead of the planes and the detector are not in this block",
+                "fp32_equivalent_tflops": flop32 / (ms * 1e-3) / 1e12, "launches_per_step": len(sp) // 2, "conv_ms_per_step": ms / 2,
+                "algorithmic_tflop_per_step_fp32": flop32 / 2 / 1e12, "algorithmic_bytes_per_step": nbytes / 2,
+                "bytes_per_s_algorithmic_GB": nbytes / (ms * 1e-3) / 1e9,
+                "by_kind": [{"kind": k_, "launches_per_step": v_[0] // 2, "ms_per_step": v_[1] / 2, "fp32_equivalent_tflops": v_[2] / (v_[1] * 1e-3) / 1e12}
+                            for k_, v_ in sorted(groups.items(), key=lambda kv: -kv[1][1])],
+                "reid_crops_per_step": live_crops,
+                "plane_scales": (None if scales is None else {"layers": int(scales.n), "largest_scale_in_use": float(scales.buf[:, 0].max().item()),
+                                                                "note": "powers of two, 1 = the tensor fits float16 as it is (common.SplitScales)"}),
+                "peak_source": "MI355X_MICROARCH.md: f16 / bf16 MFMA ~2.5 PFLOP/s dense"}
+
     roofline_hbm = None
     if args.dtype == "f32" and is3:
         from tracklab_amd.backbones import common as bc
         if bc.USE_TLK_CONV_F32:
             roofline_hbm = roofline
             roofline = conv_roofline(pipe, args.workload)
-
-    # ---- small-step legs: the same chain at frames_per_step 1 / 2 / 4 and at 4 streams x 1 frame (what an online consumer sees; the
-    # reference's online engine is per-frame, engine/video.py:67-117). Each: pipelined frames/s, un-overlapped frame-in -> rows-out time,
-    # and for the BPBReID workloads the ids of up to 48 frames per checked stream against the oracle chain ----
-    def small_step_legs(dt, with_main, overlap=None):
-        """overlap None: the pipeline's default mode (auto); False: serial, forced; True: detector stage of step t + 1 beside the ReID stage of step t"""
-        shapes = [(1, 1), (1, 2), (1, 4), (4, 1)] if is3 else [(1, 1), (1, 4)]
-        if overlap:
-            shapes = [(1, 1), (4, 1)]
-        latency = []
-        for S_, F_ in shapes:
-            if S_ * F_ > B:
-                continue
-            p1 = make_pipe(F_, S_, dt, overlap=overlap)
-            T_ = 48 if S_ * F_ > 1 else 36
-            hs = [heads_np[0][:T_]] + [build_stream_inputs(5000 + s_, n_objects, T_, ratio)[0] for s_ in range(1, S_)]
-            hsteps = np.ascontiguousarray(np.stack(hs).reshape(S_, T_ // F_, F_, -1, heads_np.shape[-1]).transpose(1, 0, 2, 3, 4)).reshape(
-                T_ // F_, S_ * F_, -1, heads_np.shape[-1])
-            d_h1 = torch.from_numpy(hsteps).to(dev)
-            fr1 = d_pool[0][:S_ * F_]                            # one fixed frame buffer -> one hipGraph
-            n1 = T_ // F_
-            stp = lambda j: p1.step(fr1, d_h1[j % n1])                        # noqa: E731
-            leg_parity = None
-            if is3 and not ssort and wl.get("pose") is None:
-                import oracle
-                refs = {s_: oracle.StrongSORT(p1.K, p1.D, **p1.tracker_cfg) for s_ in sorted({0, S_ - 1})}
-                okl, nfr = True, 0
-                for j in range(n1):
-                    h_rows, h_cnt = stp(j)
-                    p1.synchronize()
-                    rws, _ = p1.rows_numpy(h_rows, h_cnt)
-                    emb = p1.last["emb"].cpu().numpy().reshape(S_, F_, p1.maxd, p1.K, p1.D)
-                    vis = p1.last["vis"].cpu().numpy().reshape(S_, F_, p1.maxd, p1.K)
-                    for s_, ref_ in refs.items():
-                        for f in range(F_):
-                            ltwh32 = detector_rows(oracle, hs[s_][j * F_ + f], ratio)
-                            n = len(ltwh32)
-                            ids = (j * S_ * F_ + s_ * F_ + f) * p1.maxd + np.arange(n)
-                            exp = ref_.update(ids, ltwh32.astype(np.float64), emb[s_, f, :n], vis[s_, f, :n], np.ones(n)) if n else []
-                            got = rws[s_][f]
-                            okl &= len(got) == len(exp) and (len(exp) == 0 or (np.array_equal(got["det_id"], exp["det_id"]) and
-                                                                               np.array_equal(got["track_id"], exp["track_id"])))
-                            nfr += 1
-                leg_parity = {"frames": nfr, "streams_checked": sorted(refs), "track_ids_equal_oracle": bool(okl)}
-                p1.reset()
-            for j in range(8):
-                stp(j)
-            p1.synchronize(); torch.cuda.synchronize()
-            nrun = max(n1, 40)
-            t0 = time.perf_counter()
-            for j in range(nrun):
-                stp(j)
-            p1.synchronize(); torch.cuda.synchronize()
-            el1 = time.perf_counter() - t0
-            lat = []
-            for j in range(15):                                  # true in-to-out latency: one step, wait for its rows
-                t1 = time.perf_counter(); stp(j); p1.synchronize(); lat.append(time.perf_counter() - t1)
-            latency.append({"n_streams": S_, "frames_per_step": F_, "fps": nrun * S_ * F_ / el1, "ms_per_step_pipelined": el1 / nrun * 1e3,
-                            "ms_frame_in_to_rows_out": float(np.median(lat) * 1e3), "parity": leg_parity, "overlap_stages": bool(getattr(p1, "overlap", False)), "overlap_note": getattr(p1, "overlap_note", None)})
-            p1.close()
-            del p1, d_h1
-        if with_main:
-            lat_main = []
-            for j in range(4):
-                pipe.synchronize(); t1 = time.perf_counter(); run_step(j); pipe.synchronize(); lat_main.append(time.perf_counter() - t1)
-            latency.append({"n_streams": S, "frames_per_step": F, "fps": fps_res, "ms_per_step_pipelined": el_res / args.steps * 1e3,
-                            "ms_frame_in_to_rows_out": float(np.median(lat_main) * 1e3), "parity": "see `parity`"})
-            pipe.reset()
-        return latency
-
-    latency = latency_f16 = latency_f16_overlap = None
-    if rank == 0 and world == 1 and not args.no_latency_leg and F > 1:
-        pipe.reset()
-        latency = small_step_legs(tdtype, True)               # the pipeline's DEFAULT mode (r06: stage overlap is automatic at <= 2 frames per step)
-        if args.dtype == "f32":           # the online target (>= 240 frames/s at small steps) is out of any fp32 path's reach on this chip (one frame = 1.36 TFLOP of
-            latency_f16 = small_step_legs(torch.float16, False, overlap=False)      # convolutions = 8.6 ms at the fp32 MFMA peak): the f16 legs are reported beside (serial, forced)
-        if is3 and not ssort and wl.get("pose") is None and not wl.get("camera_motion"):
-            try:              # opt-in pipeline mode, reported beside the serial legs (never as them): an exception here must not cost the run its line
-                latency_f16_overlap = small_step_legs(torch.float16, False, overlap=True)
-            except Exception as ex:                             # noqa: BLE001
-                latency_f16_overlap = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
     # ---- other-precision legs.  The default fp32 run (the reference's precision: ONNXRuntime / torchreid fp32, strong_sort.yaml:10 fp16: false)
     # also times (a) the f16 backbones (tolerance: tests/test_gpu_precision.py) and (b) the SPLIT-PRECISION ReID network: fp32 weights and
@@ -1004,7 +1072,8 @@ def main():
             "fp32 backbones = the reference's precision; the hand-written kernels are fp64 / fp32 / integer in both legs"
         if args.dtype == "f32" and wl.get("reid_arch", "resnet50") == "resnet50":
             split_leg, emb_split = precision_leg("f32 weights and activations as (hi, lo) f16 pairs, 3 f16 MFMAs per product pair, fp32 accumulation "
-                                                 "(ReID ResNet-50; detector exact fp32)", "f32", True)
+                                                 "(ReID ResNet-50 with scaled planes AND the detector, r06; the RGB stem + pool of the ReID network in exact fp32)",
+                                                 "f32", True, with_roofline=split_roofline, split_detector=True)
             # how far the legs' embeddings are from the EXACT fp32 run's, same crops (first step of stream 0)
             h_rows, h_cnt = run_step(0)
             pipe.synchronize()
@@ -1080,7 +1149,7 @@ def main():
             "f16_leg": alt_leg if alt_leg and alt_name == "f16" else None,
             "value_f32_split": split_leg["value"] if split_leg else None,
             "ms_per_step_f32_split": split_leg["ms_per_step"] if split_leg else None,
-            "f32_split_leg": split_leg,
+            "f32_split_leg": split_leg, "roofline_split": (split_leg or {}).get("roofline"),
             "value_hrnet32": hrnet_leg.get("value") if hrnet_leg else None,
             "ms_per_step_hrnet32": hrnet_leg.get("ms_per_step") if hrnet_leg else None,
             "hrnet32_leg": hrnet_leg,

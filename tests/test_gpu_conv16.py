@@ -149,6 +149,50 @@ def test_every_f16_tile_configuration_of_the_direct_to_lds_kernels(shape, cfg):
     assert bool((err <= ref.abs() * 2.0 ** -11 + 2e-6 * bound + 1e-7).all()), float((err / (ref.abs() + 1e-3)).max())
 
 
+# r06: HALF-STEP tiles (K step = 32 halfs) -- Cin a multiple of 32 but not of 64 (YOLOX-m's 96-channel layers, 160, 32, 288)
+HALF_SHAPES = [(4, 96, 20, 20, 96, 3, 1, True), (2, 96, 40, 40, 192, 1, 1, False), (3, 32, 17, 9, 72, 3, 2, False), (2, 160, 12, 8, 128, 1, 1, True),
+               (1, 288, 10, 10, 96, 3, 1, False)]
+
+
+@pytest.mark.parametrize("cfg", [0, 19, 20, 21, 22])
+@pytest.mark.parametrize("shape", HALF_SHAPES)
+def test_f16_half_step_tiles(shape, cfg):
+    """conv16x_kernel<..., ROWB = 64>: 64-byte LDS rows, 32 halfs per K step; cfg 0 = the heuristic, which routes these shapes to them (they used to
+    fall to the r04 register-staged kernel's general loader)"""
+    from tracklab_amd import _lib
+    x, wt, b, r, k, s = _inputs(shape, seed=60 + cfg)
+    xh, wh = x.half(), wt.half()
+    rh = r.half() if r is not None else None
+    try:
+        _force16(cfg)
+        y = _lib.conv2d_nhwc_16(xh, wh, b, "silu", rh, stride=s, residual_after_act=True) if r is not None else _lib.conv2d_nhwc_16(xh, wh, b, "relu", None, stride=s)
+    finally:
+        _force16(0)
+    pre = F.conv2d(xh.double(), wh.double(), b.double(), s, k // 2)
+    ref = F.silu(pre) + rh.double() if r is not None else F.relu(pre)
+    bound = F.conv2d(xh.double().abs(), wh.double().abs(), b.double().abs(), s, k // 2) + (rh.double().abs() if r is not None else 0)
+    err = (y.double() - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -11 + 4e-6 * bound + 1e-7).all()), float((err / (ref.abs() + 1e-3)).max())
+    # the r04 kernel on the same layer: same products, same fp32 accumulation order within a 16-wide slice -- at most the output rounding apart
+    try:
+        _force16(-1)
+        y0 = _lib.conv2d_nhwc_16(xh, wh, b, "silu", rh, stride=s, residual_after_act=True) if r is not None else _lib.conv2d_nhwc_16(xh, wh, b, "relu", None, stride=s)
+    finally:
+        _force16(0)
+    assert float((y.float() - y0.float()).abs().max()) <= 2.0 ** -9 * max(1.0, float(y0.float().abs().max()))
+
+
+def test_a_full_step_configuration_refuses_a_half_step_layer():
+    from tracklab_amd import _lib
+    x, wt, b, r, k, s = _inputs(HALF_SHAPES[0])
+    try:
+        _force16(3)
+        with pytest.raises(_lib.TlkError, match="half-step"):
+            _lib.conv2d_nhwc_16(x.half(), wt.half(), b, "relu", None, stride=s)
+    finally:
+        _force16(0)
+
+
 # (n, cin, h, w, cout, k, stride, residual): 3 x 3 / 1 on exactly 64 channels, whole image rows per 256- / 128-pixel tile
 PATCH16_SHAPES = [(3, 64, 16, 32, 64, 3, 1, True), (2, 64, 32, 16, 128, 3, 1, False), (2, 64, 8, 64, 72, 3, 1, True), (1, 64, 64, 8, 64, 3, 1, False)]
 

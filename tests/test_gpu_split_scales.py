@@ -97,3 +97,53 @@ def test_scale_update_rule():
     np.testing.assert_array_equal(got[:, 0], [1, 2, 32, 64, 64, 8, 4, 1])
     np.testing.assert_array_equal(got[:, 1], 0)
     assert int(ch.item()) == 3                                          # two grew, one was not finite
+
+
+def test_detector_in_split_mode_is_fp32_class():
+    """YOLOX with every convolution in split-precision mode ((hi, lo) planes through the CSP slice-concatenations, the
+    up-sampling, the SPP block and the decoupled head) against the same network on the exact-fp32 kernels"""
+    import importlib
+    import torch
+    ymod = importlib.import_module("tracklab_amd.backbones.yolox")
+    for size in ("s", "m"):
+        net = ymod.yolox(size, 1, device="cuda", dtype=torch.float32)
+        x = (torch.rand(3, 12, 160, 160, device="cuda") * 255).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            a = net(x, focused=True)
+            b = net(x, focused=True, split=True)
+        assert a.shape == b.shape and b.dtype == torch.float32 and bool(torch.isfinite(b).all())
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max())), (size, float((a - b).abs().max()), float(a.abs().max()))
+
+
+def test_pipeline_with_both_networks_in_split_mode_keeps_the_oracles_ids(orc):
+    import torch
+    from tracklab_amd import gpu_pipeline as gp
+    from tracklab_amd.synth import SyntheticStream, render_frame, synth_yolox_head
+    from test_gpu_pipeline_configs import _detector_rows
+    F, steps, nobj, maxd = 4, 4, 40, 48
+    pipe = gp.DetReidTrackPipeline("m", n_streams=1, frames_per_step=F, max_dets=maxd, use_graph=True, dtype=torch.float32,
+                                   reid_split_precision=True, detector_split_precision=True)
+    assert pipe.det_split and pipe.reid.split_precision and pipe.check_finite
+    rng = np.random.default_rng(12)
+    stream = list(SyntheticStream(5, nobj, F * steps))
+    heads = np.stack([synth_yolox_head(rng, fr["dets"][:, :4], ratio=pipe.ratio) for fr in stream])
+    d_frames = torch.from_numpy(np.stack([render_frame(rng, stream[i]["gt_boxes"]) for i in range(F)])).cuda()
+    d_heads = torch.from_numpy(heads).cuda().reshape(steps, F, -1, 6)
+    ref = orc.StrongSORT(pipe.K, pipe.D, **pipe.tracker_cfg)
+    for k in range(steps):
+        h_rows, h_cnt = pipe.step(d_frames, d_heads[k])
+        pipe.synchronize()
+        rows, _ = pipe.rows_numpy(h_rows, h_cnt)
+        emb = pipe.last["emb"].cpu().numpy().reshape(F, maxd, pipe.K, pipe.D)
+        vis = pipe.last["vis"].cpu().numpy().reshape(F, maxd, pipe.K)
+        for f in range(F):
+            ltwh = _detector_rows(orc, heads[k * F + f], pipe.ratio)
+            n = len(ltwh)
+            exp = ref.update((k * F + f) * maxd + np.arange(n), ltwh.astype(np.float64), emb[f, :n], vis[f, :n], np.ones(n))
+            got = rows[0][f]
+            assert len(got) == len(exp)
+            np.testing.assert_array_equal(got["det_id"], exp["det_id"])
+            np.testing.assert_array_equal(got["track_id"], exp["track_id"])
+    sc = pipe.reid._split_scales
+    assert sc is not None and sc.calibrated and bool((sc.buf[:, 0] == 1).all())      # a random-init network fits float16: every scale stays 1
+    pipe.close()

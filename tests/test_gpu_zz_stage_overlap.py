@@ -21,7 +21,7 @@ def test_overlapped_stages_give_the_serial_pipeline_rows(use_graph):
     rows = {}
     for overlap in (False, True):
         pipe = gp.DetReidTrackPipeline("s", n_streams=1, frames_per_step=F, max_dets=32, dim=64, use_graph=use_graph, overlap_stages=overlap)
-        assert pipe.overlap == overlap or (overlap and "no pair of streams" in pipe.overlap_note)      # (r06: only entered with streams observed to be concurrent)
+        assert pipe.overlap == overlap
         heads, frames = _inputs(31, 14, T, pipe.ratio)
         d_heads = torch.from_numpy(heads).cuda()
         d_frames = [torch.from_numpy(np.stack(frames[t:t + F])).cuda() for t in range(0, T, F)]      # a buffer per step: nothing serialises the steps but the pipeline's own events
@@ -42,48 +42,63 @@ def test_overlapped_stages_give_the_serial_pipeline_rows(use_graph):
         assert torch.equal(r0, r1)
 
 
-def test_overlap_mode_is_entered_only_with_streams_observed_to_run_concurrently():
-    """PROVE the concurrency the stage-overlap mode claims.  r06: the pipeline measures it itself before entering the mode
-    (gpu_pipeline.pick_concurrent_streams: spin kernels on the two candidate streams, event timestamps on one clock) and stays serial when no
-    pair of streams runs side by side -- the situation r05 could not tell apart from the real thing.  Here: (a) the measurement has a negative
-    control (a stream is never concurrent with itself); (b) a pipeline that reports the mode as entered holds two streams that are concurrent
-    when measured AGAIN; (c) at the real online shape (YOLOX-m + ReID R50, 100 objects, one frame per step, f16, hipGraphs) its steps are
-    faster than the serial pipeline's in the same process -- the two stages do overlap."""
+def test_auto_mode_measures_both_modes_and_is_never_slower_than_serial():
+    """VERDICT r05 next 4 ("earn the default").  r06 finding: whether the two stage streams really run side by side is decided by HIP's stream ->
+    hardware-queue -> command-processor-pipe assignment, which the pipeline cannot choose -- the same code ran 1.39x, 0.99x, 0.69x and 0.50x the
+    serial pipeline in one process as other streams came and went (profiles/r06_overlap_autotune.md), and a spin-kernel probe of the two
+    streams called all four "concurrent".  So the default is a MEASUREMENT: the first step of an eligible pipeline times both modes on its own
+    inputs and keeps the faster.  Here, at the real online shape (YOLOX-m + ReID R50, 100 objects, one frame per step, f16, hipGraphs), with
+    the stream assignment perturbed three ways: the trial ran, its decision follows its own numbers, the rows are those of a serial pipeline,
+    and the steady-state rate is never below the serial pipeline's in the same process."""
     import time
     import torch
     from tracklab_amd import gpu_pipeline as gp
-    s0 = torch.cuda.Stream()
-    assert not gp.streams_run_concurrently(s0, s0)
     heads, frames = _inputs(33, 100, 6, min(640 / 1080, 640 / 1920))
     d_heads = torch.from_numpy(heads).cuda()
     fr = torch.from_numpy(np.stack(frames[:1])).cuda()
-    rate = {}
-    for overlap in (False, True):
-        pipe = gp.DetReidTrackPipeline("m", n_streams=1, frames_per_step=1, max_dets=104, dtype=torch.float16, overlap_stages=overlap)
-        if overlap:
-            if not pipe.overlap:
-                assert "no pair of streams" in pipe.overlap_note
-                pipe.close()
-                pytest.skip("this device / process offers no two concurrent streams: the pipeline stayed serial (and said so) -- " + pipe.overlap_note)
-            assert gp.streams_run_concurrently(pipe.det_stream, pipe.reid_stream), pipe.overlap_note
+
+    def run(pipe, n=100):
+        rows = []
+        for j in range(6):
+            h_rows, h_cnt = pipe.step(fr, d_heads[j:j + 1])
+            pipe.synchronize()
+            rows.append((h_rows.clone(), h_cnt.clone()))
         for j in range(10):
             pipe.step(fr, d_heads[j % 6:j % 6 + 1], fetch=False)
         pipe.synchronize()
         t0 = time.perf_counter()
-        for j in range(120):
+        for j in range(n):
             pipe.step(fr, d_heads[j % 6:j % 6 + 1], fetch=False)
         pipe.synchronize()
-        rate[overlap] = 120 / (time.perf_counter() - t0)
-        pipe.close()
-    print(f"one frame per step, f16: serial {rate[False]:.1f} frames/s, stages overlapped {rate[True]:.1f} frames/s")
-    assert rate[True] > 1.1 * rate[False], rate
+        return n / (time.perf_counter() - t0), rows
+    keep, seen = [], []
+    for extra in (0, 1, 4):
+        keep += [torch.cuda.Stream(priority=(-1 if k % 2 else 0)) for k in range(extra)]          # shifts where the next streams land
+        ps = gp.DetReidTrackPipeline("m", n_streams=1, frames_per_step=1, max_dets=104, dtype=torch.float16, overlap_stages=False)
+        r_serial, rows_serial = run(ps)
+        ps.close()
+        pa = gp.DetReidTrackPipeline("m", n_streams=1, frames_per_step=1, max_dets=104, dtype=torch.float16)      # default = auto
+        assert pa._ov_mode == "trial" and not pa.overlap
+        r_auto, rows_auto = run(pa)
+        tr = pa.overlap_trial
+        assert tr is not None and pa._ov_mode in ("on", "off_tuned")
+        assert pa.overlap == (tr["overlapped_steps_per_s"] > 1.05 * tr["serial_steps_per_s"])
+        for (r0, c0), (r1, c1) in zip(rows_serial, rows_auto):                                   # the trial left no trace in the tracker
+            assert torch.equal(c0, c1) and torch.equal(r0, r1)
+        seen.append((extra, round(r_serial, 1), round(r_auto, 1), pa.overlap, pa.overlap_note))
+        pa.close()
+        assert r_auto > 0.93 * r_serial, seen
+    print("one frame per step, f16 (extra streams alive, serial frames/s, auto frames/s, overlapped?, note):")
+    for row in seen:
+        print("  ", row)
 
 
-def test_auto_mode_is_on_for_online_shapes_only():
+def test_auto_mode_is_for_the_online_16_bit_shapes_only():
     import torch
     from tracklab_amd import gpu_pipeline as gp
     p1 = gp.DetReidTrackPipeline("s", n_streams=1, frames_per_step=1, max_dets=16, dim=64, use_graph=False)
     p8 = gp.DetReidTrackPipeline("s", n_streams=1, frames_per_step=8, max_dets=16, dim=64, use_graph=False)
-    assert (p1.overlap and p1.overlap_note.startswith("on")) or "no pair of streams" in p1.overlap_note
+    p32 = gp.DetReidTrackPipeline("s", n_streams=1, frames_per_step=1, max_dets=16, dim=64, use_graph=False, dtype=torch.float32)
+    assert p1._ov_mode == "trial" and p8._ov_mode == "off" and p32._ov_mode == "off"          # fp32 one-frame launches fill the chip: measured slower overlapped
     assert not p8.overlap and p8.overlap_note == "off"
-    p1.close(); p8.close()
+    p1.close(); p8.close(); p32.close()

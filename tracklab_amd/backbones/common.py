@@ -187,6 +187,8 @@ class ConvBiasAct(nn.Module):
 
     def writes_slices(self, x):
         """True when forward(x, out=...) writes straight into `out` (a channel slice of a wider tensor): the libtlk convolution routes"""
+        if isinstance(x, SplitAct):
+            return True
         if not x.is_cuda or not x.is_contiguous(memory_format=torch.channels_last):
             return False
         if x.dtype == torch.float32:
@@ -207,11 +209,25 @@ class ConvBiasAct(nn.Module):
             wh, wl = self._split_weights(x.hi.shape[1])
             of32 = getattr(self, "out_f32", False)
             st = None if of32 else getattr(self, "_sstate", None)       # r06: this layer's plane state (SplitScales), None = unscaled planes
+            if CONV_TIMER is not None:
+                n0, n1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n0.record(); n1.record()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             res = _lib.conv2d_nhwc_16(x.hi, wh, self.bias.float() if self.bias.dtype != torch.float32 else self.bias, self.act,
                                       residual.hi if residual is not None else None, self.conv.stride[0], self.conv.padding[0],
                                       x_lo=x.lo, weight_lo=wl, residual_lo=residual.lo if residual is not None else None,
                                       out_f32=of32, residual_after_act=residual_after_act, out=(out.hi, out.lo) if out is not None else None,
                                       in_scale=x.state, res_scale=residual.state if residual is not None else None, out_state=st)
+            if CONV_TIMER is not None:
+                e1.record()
+                y_ = res if of32 else res[0]
+                cout, cin, kh, kw = self.conv.weight.shape
+                nb = LIVE_BATCH[1] if (LIVE_BATCH is not None and y_.shape[0] == LIVE_BATCH[0]) else y_.shape[0]
+                # algorithmic count = the fp32 convolution this stands for (the 16-bit MFMA does three products per operand pair: bench.py's
+                # roofline_split prices that); bytes: two f16 planes per tensor = 4 bytes per element, like fp32
+                nbytes = 4.0 * (nb * x.hi.shape[2] * x.hi.shape[3] * cin + nb * y_.shape[2] * y_.shape[3] * cout * (2 if residual is not None else 1) + cout * cin * kh * kw)
+                CONV_TIMER.append((e0, e1, n0, n1, 2.0 * nb * y_.shape[2] * y_.shape[3] * cout * cin * kh * kw, ("split", _lib.ACT[self.act], residual is not None), nbytes))
             return res if of32 else SplitAct(*res, state=st)
         if x.shape[1] == 3 and residual is None and x.dtype == torch.float16:
             y = self.stem16(x)

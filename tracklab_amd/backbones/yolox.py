@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from .common import ConvBiasAct as Conv
-from .common import finalize, random_init_, spp_concat
+from .common import SplitAct, finalize, random_init_, spp_concat
 
 import os as _os
 
@@ -27,6 +27,24 @@ USE_SLICE_CONCAT = _os.environ.get("TLK_SLICE_CONCAT", "1") != "0"
 USE_TLK_HEADS = _os.environ.get("TLK_HEADS", "1") != "0"
 
 SIZES = {"tiny": (0.33, 0.375), "s": (0.33, 0.50), "m": (0.67, 0.75), "l": (1.0, 1.0), "x": (1.33, 1.25)}
+
+
+# r06: split-precision route (fp32 values as (hi, lo) float16 plane pairs, common.SplitAct): the operators between the convolutions act on both
+# planes -- concatenation and nearest up-sampling move elements, so they commute with the split exactly; max pooling does not (it compares
+# VALUES), so the SPP block merges, pools in fp32 and splits again
+def _cat(ts):
+    if isinstance(ts[0], SplitAct):
+        return SplitAct(torch.cat([t.hi for t in ts], 1), torch.cat([t.lo for t in ts], 1))
+    return torch.cat(ts, 1)
+
+
+def _empty_like_wide(x, channels):
+    mk = lambda t: torch.empty((t.shape[0], channels, t.shape[2], t.shape[3]), dtype=t.dtype, device=t.device, memory_format=torch.channels_last)      # noqa: E731
+    return SplitAct(mk(x.hi), mk(x.lo)) if isinstance(x, SplitAct) else mk(x)
+
+
+def _chan(t, a, b):
+    return SplitAct(t.hi[:, a:b], t.lo[:, a:b]) if isinstance(t, SplitAct) else t[:, a:b]
 
 
 class Bottleneck(nn.Module):
@@ -52,18 +70,20 @@ class CSPLayer(nn.Module):
         self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0) for _ in range(n)])
 
     def forward(self, x):
-        if USE_SLICE_CONCAT and self.conv2.writes_slices(x) and len(self.m) > 0:
+        if USE_SLICE_CONCAT and (isinstance(x, SplitAct) or self.conv2.writes_slices(x)) and len(self.m) > 0:
             # the concatenation is never copied: the last bottleneck and the shortcut convolution write their halves of it directly
-            n, _, h, w = x.shape
             hid = self.conv2.conv.out_channels
-            y = torch.empty((n, 2 * hid, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            y = _empty_like_wide(x, 2 * hid)
             t = self.conv1(x)
             for blk in list(self.m)[:-1]:
                 t = blk(t)
-            self.m[-1](t, out=y[:, :hid])
-            self.conv2(x, out=y[:, hid:])
+            self.m[-1](t, out=_chan(y, 0, hid))
+            self.conv2(x, out=_chan(y, hid, 2 * hid))
             return self.conv3(y)
-        return self.conv3(torch.cat((self.m(self.conv1(x)), self.conv2(x)), dim=1))
+        t = self.conv1(x)
+        for blk in self.m:
+            t = blk(t)
+        return self.conv3(_cat((t, self.conv2(x))))
 
 
 class SPPBottleneck(nn.Module):
@@ -76,6 +96,8 @@ class SPPBottleneck(nn.Module):
 
     def forward(self, x):
         x = self.conv1(x)
+        if isinstance(x, SplitAct):           # max pooling compares values: pooled in fp32 (exact), split again
+            return self.conv2(SplitAct.from_f32(spp_concat(x.merge(), self.ks)))
         return self.conv2(spp_concat(x, self.ks))
 
 
@@ -84,11 +106,13 @@ class Focus(nn.Module):
         super().__init__()
         self.conv = Conv(cin * 4, cout, k)
 
-    def forward(self, x, focused=False):
+    def forward(self, x, focused=False, split=False):
         if not focused:
             tl, tr = x[..., ::2, ::2], x[..., ::2, 1::2]
             bl, br = x[..., 1::2, ::2], x[..., 1::2, 1::2]
             x = torch.cat((tl, bl, tr, br), dim=1)
+        if split:                             # the 12-channel space-to-depth image as planes of 16 channels (the 16-bit kernels take 16-byte channel groups)
+            x = SplitAct.from_f32(x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last), 16)
         return self.conv(x)
 
 
@@ -103,8 +127,8 @@ class CSPDarknet(nn.Module):
         self.dark5 = nn.Sequential(Conv(b * 8, b * 16, 3, 2), SPPBottleneck(b * 16, b * 16),
                                    CSPLayer(b * 16, b * 16, d, shortcut=False))
 
-    def forward(self, x, focused=False):
-        x = self.dark2(self.stem(x, focused))
+    def forward(self, x, focused=False, split=False):
+        x = self.dark2(self.stem(x, focused, split))
         c3 = self.dark3(x)
         c4 = self.dark4(c3)
         return c3, c4, self.dark5(c4)
@@ -127,12 +151,13 @@ class PAFPN(nn.Module):
 
     def forward(self, feats):
         x2, x1, x0 = feats
+        up = lambda t: SplitAct(self.up(t.hi), self.up(t.lo)) if isinstance(t, SplitAct) else self.up(t)      # noqa: E731
         fpn0 = self.lateral_conv0(x0)
-        f1 = self.C3_p4(torch.cat([self.up(fpn0), x1], 1))
+        f1 = self.C3_p4(_cat([up(fpn0), x1]))
         fpn1 = self.reduce_conv1(f1)
-        p3 = self.C3_p3(torch.cat([self.up(fpn1), x2], 1))
-        p4 = self.C3_n3(torch.cat([self.bu_conv2(p3), fpn1], 1))
-        p5 = self.C3_n4(torch.cat([self.bu_conv1(p4), fpn0], 1))
+        p3 = self.C3_p3(_cat([up(fpn1), x2]))
+        p4 = self.C3_n3(_cat([self.bu_conv2(p3), fpn1]))
+        p5 = self.C3_n4(_cat([self.bu_conv1(p4), fpn0]))
         return p3, p4, p5
 
 
@@ -168,6 +193,9 @@ class Head(nn.Module):
         cfs, rfs = [], []
         for k, x in enumerate(feats):
             x = self.stems[k](x)
+            if isinstance(x, SplitAct):       # split route: the branches' last convolutions hand fp32 to the prediction kernel
+                self.cls_convs[k][-1].out_f32 = True
+                self.reg_convs[k][-1].out_f32 = True
             cfs.append(self.cls_convs[k](x))
             rfs.append(self.reg_convs[k](x))
         x0 = cfs[0]
@@ -192,8 +220,10 @@ class YOLOX(nn.Module):
         self.head = Head(num_classes, wid)
         self.size, self.num_classes = size, num_classes
 
-    def forward(self, x, focused=False):
-        return self.head(self.neck(self.backbone(x, focused)))
+    def forward(self, x, focused=False, split=False):
+        """split (r06; fp32 weights and input on the GPU): every convolution in split-precision mode -- (hi, lo) float16 plane pairs, three f16 MFMAs
+        per product pair, fp32 accumulation (csrc/tlk_conv16*.hip) -- fp32-class results; the head's predictions come out in fp32 as always"""
+        return self.head(self.neck(self.backbone(x, focused, split and x.is_cuda and x.dtype == torch.float32)))
 
 
 def yolox(size="s", num_classes=1, device="cuda", dtype=torch.float16, channels_last=True, seed=0):

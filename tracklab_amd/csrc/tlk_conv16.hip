@@ -228,6 +228,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
         }
     __syncthreads();
     constexpr int V_PER_ROW = BN / 8, NVEC = BM * V_PER_ROW, ITS = (NVEC + NT - 1) / NT;
+    const bool scaled = MODE == MODE_SPLIT && (p.s_in || p.s_res || p.s_out);      // wave-uniform: the unscaled call runs the r05 epilogue, instruction for instruction
     const SplitScales sc = load_scales(p);
     float amax = 0.f;
     for (int it = 0; it < ITS; ++it) {
@@ -241,7 +242,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
             const float4 c0 = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec), c1 = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec + 4);
             float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
             if (p.bias) { b0 = *reinterpret_cast<const float4 *>(p.bias + co); b1 = *reinterpret_cast<const float4 *>(p.bias + co + 4); }
-            if (MODE == MODE_SPLIT) {      // scaled planes (r06): the accumulators hold the sum over x / s_in
+            if (MODE == MODE_SPLIT && scaled) {      // scaled planes (r06): the accumulators hold the sum over x / s_in
                 v[0] = c0.x * sc.in + b0.x; v[1] = c0.y * sc.in + b0.y; v[2] = c0.z * sc.in + b0.z; v[3] = c0.w * sc.in + b0.w;
                 v[4] = c1.x * sc.in + b1.x; v[5] = c1.y * sc.in + b1.y; v[6] = c1.z * sc.in + b1.z; v[7] = c1.w * sc.in + b1.w;
             } else {
@@ -257,7 +258,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
             if (MODE == MODE_SPLIT) {
                 const h16x8 rl = *reinterpret_cast<const h16x8 *>(p.res_lo + m * p.r_pix + co);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) rv[e] = (rv[e] + (float)rl[e] * LO_INV) * sc.res;
+                for (int e = 0; e < 8; ++e) rv[e] += (float)rl[e] * LO_INV;
+                if (scaled) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rv[e] *= sc.res;
+                }
             }
             if (!p.res_post) {
 #pragma unroll
@@ -276,8 +281,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
             *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else if (MODE == MODE_SPLIT) {
             h16x8 oh, ol;
+            if (scaled) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { _Float16 h, l; amax = fmaxf(amax, fabsf(v[e])); split_f32(v[e] * sc.out_inv, h, l); oh[e] = h; ol[e] = l; }
+                for (int e = 0; e < 8; ++e) { amax = fmaxf(amax, fabsf(v[e])); v[e] *= sc.out_inv; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f32(v[e], h, l); oh[e] = h; ol[e] = l; }
             *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
             *reinterpret_cast<h16x8 *>(p.y_lo + m * p.y_pix + co) = ol;
         } else {
@@ -287,7 +296,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16_mfma_kernel(const Conv1
             *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
         }
     }
-    if (MODE == MODE_SPLIT && !OUT_F32) note_amax(p, amax);
+    if (MODE == MODE_SPLIT && !OUT_F32 && scaled) note_amax(p, amax);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -431,6 +440,7 @@ __global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p,
         }
     __syncthreads();
     constexpr int V_PER_ROW = BN / 8, NVEC = BM * V_PER_ROW, ITS = NVEC / NT;
+    const bool scaled = MODE == MODE_SPLIT && (p.s_in || p.s_res || p.s_out);      // wave-uniform: the unscaled call runs the r05 epilogue, instruction for instruction
     const SplitScales sc = load_scales(p);
     float amax = 0.f;
 #pragma unroll 2
@@ -445,7 +455,7 @@ __global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p,
             const float4 c0 = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec), c1 = *reinterpret_cast<const float4 *>(Cs + row * LDC + ec + 4);
             float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
             if (p.bias) { b0 = *reinterpret_cast<const float4 *>(p.bias + co); b1 = *reinterpret_cast<const float4 *>(p.bias + co + 4); }
-            if (MODE == MODE_SPLIT) {      // scaled planes (r06): the accumulators hold the sum over x / s_in
+            if (MODE == MODE_SPLIT && scaled) {      // scaled planes (r06): the accumulators hold the sum over x / s_in
                 v[0] = c0.x * sc.in + b0.x; v[1] = c0.y * sc.in + b0.y; v[2] = c0.z * sc.in + b0.z; v[3] = c0.w * sc.in + b0.w;
                 v[4] = c1.x * sc.in + b1.x; v[5] = c1.y * sc.in + b1.y; v[6] = c1.z * sc.in + b1.z; v[7] = c1.w * sc.in + b1.w;
             } else {
@@ -461,7 +471,11 @@ __global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p,
             if (MODE == MODE_SPLIT) {
                 const h16x8 rl = *reinterpret_cast<const h16x8 *>(p.res_lo + m * p.r_pix + co);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) rv[e] = (rv[e] + (float)rl[e] * LO_INV) * sc.res;
+                for (int e = 0; e < 8; ++e) rv[e] += (float)rl[e] * LO_INV;
+                if (scaled) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rv[e] *= sc.res;
+                }
             }
             if (!p.res_post) {
 #pragma unroll
@@ -480,8 +494,12 @@ __global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p,
             *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else if (MODE == MODE_SPLIT) {
             h16x8 oh, ol;
+            if (scaled) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { _Float16 h, l; amax = fmaxf(amax, fabsf(v[e])); split_f32(v[e] * sc.out_inv, h, l); oh[e] = h; ol[e] = l; }
+                for (int e = 0; e < 8; ++e) { amax = fmaxf(amax, fabsf(v[e])); v[e] *= sc.out_inv; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f32(v[e], h, l); oh[e] = h; ol[e] = l; }
             *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
             *reinterpret_cast<h16x8 *>(p.y_lo + m * p.y_pix + co) = ol;
         } else {
@@ -491,7 +509,7 @@ __global__ void __launch_bounds__(256, 2) conv16_glds_kernel(const Conv16Args p,
             *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
         }
     }
-    if (MODE == MODE_SPLIT && !OUT_F32) note_amax(p, amax);
+    if (MODE == MODE_SPLIT && !OUT_F32 && scaled) note_amax(p, amax);
 }
 
 }  // namespace
@@ -596,11 +614,7 @@ __global__ void __launch_bounds__(BLOCK) split_planes_kernel(const float *__rest
         if (c < c_in) { const float v = x[px * x_pix + c]; am = fmaxf(am, fabsf(v)); split_f32(v * inv, h, l); }
         hi[i] = h; lo[i] = l;
     }
-    if (state) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
-        if ((threadIdx.x & 63) == 0 && am > 0.f) atomicMax(reinterpret_cast<unsigned int *>(state + 1), __float_as_uint(am));
-    }
+    if (state) record_amax(state + 1, am);
 }
 
 __global__ void __launch_bounds__(BLOCK) merge_planes_kernel(const _Float16 *__restrict__ hi, const _Float16 *__restrict__ lo, long long n, float *__restrict__ y,
@@ -706,7 +720,7 @@ extern "C" int tlk_conv16_set_glds(int on) { g_glds = on ? 1 : 0; return TLK_OK;
 
 extern "C" int tlk_conv16_set_config(int cfg)
 {
-    if (cfg < -1 || cfg > 18) return fail(TLK_EINVAL, "tlk_conv16_set_config: cfg is -1 (r04 kernels only), 0 (heuristic) or a tile configuration 1..18");
+    if (cfg < -1 || cfg > 22) return fail(TLK_EINVAL, "tlk_conv16_set_config: cfg is -1 (r04 kernels only), 0 (heuristic) or a tile configuration 1..22");
     g_cfg16x = cfg;
     return TLK_OK;
 }

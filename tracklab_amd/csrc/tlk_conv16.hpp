@@ -60,13 +60,23 @@ __device__ __forceinline__ SplitScales load_scales(const Conv16Args &p)
     s.out_inv = p.s_out ? 1.f / p.s_out[0] : 1.f;          // (a power of two: the reciprocal and the products with it are exact)
     return s;
 }
-// largest |output| of this lane -> the layer's state word (one atomic per wavefront; non-negative floats order like their bit patterns)
-__device__ __forceinline__ void note_amax(const Conv16Args &p, float am)
+// largest |value| of this wavefront -> a state word (non-negative floats order like their bit patterns).  The atomic is GUARDED by a relaxed
+// device-scope load of the word: a launch has ~10^5-10^6 wavefronts and same-address atomics retire one at a time in the L2 (~12 ns each: measured,
+// an unguarded atomic per wavefront took a 2.5 ms layer to 12 ms); once the first few wavefronts have raised the word almost nobody exceeds it, and a
+// stale read only costs a redundant atomic, never a missed maximum.
+__device__ __forceinline__ void record_amax(float *word, float am)
 {
-    if (!p.s_out) return;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
-    if ((threadIdx.x & 63) == 0 && am > 0.f) atomicMax(reinterpret_cast<unsigned int *>(p.s_out + 1), __float_as_uint(am));
+    if ((threadIdx.x & 63) == 0 && am > 0.f) {
+        unsigned int *w = reinterpret_cast<unsigned int *>(word);
+        const unsigned int mine = __float_as_uint(am);
+        if (mine > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(w, mine);
+    }
+}
+__device__ __forceinline__ void note_amax(const Conv16Args &p, float am)
+{
+    if (p.s_out) record_amax(p.s_out + 1, am);
 }
 
 // rows of this launch that exist: the static M, or n_dyn[0] images' worth when a dynamic batch is set

@@ -63,25 +63,29 @@ constexpr int pick_epi(int tm, int wgm, int rows_max)
     return e;
 }
 
-template <int WGM, int WGN, int TM, int TN, int MODE, int NST, bool RESPF, bool PATCH = false>
+// ROWB (r06): bytes of one K step per tile row in LDS -- 128 everywhere but the f16 HALF-STEP tiles (64: K step = 32 halfs, the geometry of one plane of
+// the split mode), for layers whose Cin is a multiple of 32 but not of 64 (YOLOX-m's 96-channel layers: they sat on the r04 register-staged kernel,
+// whose loader divides per load when a K step straddles taps: 7 % of the one-frame f16 step)
+template <int WGM, int WGN, int TM, int TN, int MODE, int NST, bool RESPF, bool PATCH = false, int ROWB = ROW_BYTES>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Args p, const int act)
 {
+    static_assert(ROWB == ROW_BYTES || (ROWB == 64 && MODE == MODE_F16 && !PATCH), "half-step rows: f16 mode only");
     constexpr bool USE_BUF = true;                        // (r05 A/B on the GPU: buffer loads with hardware zero fill >= 64-bit pointers + zero page on every layer)
     constexpr int NW = WGM * WGN, NT = 64 * NW;
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int PLANES = MODE == MODE_SPLIT ? 2 : 1;
     constexpr int ES = MODE == MODE_F32 ? 4 : 2;          // bytes per element
     constexpr int EPC = 16 / ES;                          // elements per 16-byte chunk: 8 / 4
-    constexpr int BKE = ROW_BYTES / PLANES / ES;          // K elements per step: 64 (f16), 32 (split: 32 hi + 32 lo), 32 (fp32)
-    constexpr int RB = ROW_BYTES / PLANES;                // bytes of one tile row in one plane's LDS region
+    constexpr int BKE = ROWB / PLANES / ES;               // K elements per step: 64 (f16), 32 (split: 32 hi + 32 lo), 32 (fp32), 32 (f16 half step)
+    constexpr int RB = ROWB / PLANES;                     // bytes of one tile row in one plane's LDS region
     constexpr int CPR = RB / 16;                          // 16-byte chunks per row: 8 / 4
     constexpr int RPI = 64 / CPR;                         // rows one wavefront-instruction fills: 8 / 16
-    constexpr int SWS = PLANES == 1 ? 1 : 2;              // chunk q of row i sits at position q ^ ((i >> SWS) & (CPR - 1))
+    constexpr int SWS = RB == 128 ? 1 : 2;                // chunk q of row i sits at position q ^ ((i >> SWS) & (CPR - 1))
     constexpr int QA = BM / (RPI * NW), QB = BN / (RPI * NW);      // load instructions per wavefront, plane and stage
     static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "tile rows must be a multiple of the loader pass");
     constexpr int A_REGION = BM * RB, B_REGION = BN * RB;
     constexpr int STAGE = PLANES * (A_REGION + B_REGION);          // (BM + BN) * 128 bytes
-    constexpr int NJ = ROW_BYTES / PLANES / 32;           // slices per step (two chunks = one fragment pair each): 4 / 2 / 4
+    constexpr int NJ = ROWB / PLANES / 32;                // slices per step (two chunks = one fragment pair each): 4 / 2 / 4 / 2
     constexpr int NACC = MODE == MODE_SPLIT ? 2 : 1;
     constexpr int NR = PLANES * (TM + TN);                // fragment reads per slice
     constexpr int NM = TM * TN * (MODE == MODE_SPLIT ? 3 : MODE == MODE_F32 ? 4 : 1);     // MFMAs per slice
@@ -408,8 +412,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
     // ---- epilogue: EPI MFMA tile rows of every wavefront at a time through LDS as fp32, then 8 output channels (16 bytes of f16) per lane.
     // C/D map of the 32x32 tile: column (= cout) = lane & 31, row (= pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     float *Cs = reinterpret_cast<float *>(lds);
+    const bool scaled = MODE == MODE_SPLIT && (p.s_in || p.s_res || p.s_out);      // wave-uniform: the unscaled call runs the r05 epilogue, instruction for instruction
     SplitScales sc = {1.f, 1.f, 1.f};
-    if (MODE == MODE_SPLIT) sc = load_scales(p);
+    if (scaled) sc = load_scales(p);
     float amax = 0.f;
 #pragma unroll
     for (int i0 = 0; i0 < TM; i0 += EPI) {
@@ -440,7 +445,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
                 const float4 c0 = *reinterpret_cast<const float4 *>(Cs + prow * LDC + ec + 4 * q4);
                 v[4 * q4] = c0.x; v[4 * q4 + 1] = c0.y; v[4 * q4 + 2] = c0.z; v[4 * q4 + 3] = c0.w;
             }
-            if (MODE == MODE_SPLIT) {      // scaled planes (r06): the accumulators hold the sum over x / s_in
+            if (MODE == MODE_SPLIT && scaled) {      // scaled planes (r06): the accumulators hold the sum over x / s_in
 #pragma unroll
                 for (int e = 0; e < VW; ++e) v[e] *= sc.in;
             }
@@ -467,7 +472,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
                     if (MODE == MODE_SPLIT) {
                         const h16x8 rl = *reinterpret_cast<const h16x8 *>(p.res_lo + m * p.r_pix + co);
 #pragma unroll
-                        for (int e = 0; e < VW; ++e) rv[e] = (rv[e] + (float)rl[e & 7] * LO_INV) * sc.res;
+                        for (int e = 0; e < VW; ++e) rv[e] += (float)rl[e & 7] * LO_INV;
+                        if (scaled) {
+#pragma unroll
+                            for (int e = 0; e < VW; ++e) rv[e] *= sc.res;
+                        }
                     }
                 }
                 if (!p.res_post) {
@@ -492,8 +501,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
                 for (int q4 = 0; q4 < VW / 4; ++q4) *reinterpret_cast<float4 *>(o + 4 * q4) = make_float4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
             } else if (MODE == MODE_SPLIT) {
                 h16x8 oh, ol;
+                if (scaled) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { _Float16 h, l; amax = fmaxf(amax, fabsf(v[e % VW])); split_f32(v[e % VW] * sc.out_inv, h, l); oh[e] = h; ol[e] = l; }
+                    for (int e = 0; e < VW; ++e) { amax = fmaxf(amax, fabsf(v[e])); v[e] *= sc.out_inv; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f32(v[e % VW], h, l); oh[e] = h; ol[e] = l; }
                 *reinterpret_cast<h16x8 *>(p.y + m * p.y_pix + co) = oh;
                 *reinterpret_cast<h16x8 *>(p.y_lo + m * p.y_pix + co) = ol;
             } else {
@@ -505,19 +518,19 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
         }
         if (i0 + EPI < TM) __syncthreads();
     }
-    if (MODE == MODE_SPLIT) note_amax(p, amax);
+    if (MODE == MODE_SPLIT && scaled) note_amax(p, amax);
 }
 
-template <int WGM, int WGN, int TM, int TN, int MODE, int NST, bool RESPF> int launch_x(Conv16Args &a, int act, hipStream_t st)
+template <int WGM, int WGN, int TM, int TN, int MODE, int NST, bool RESPF, int ROWB = ROW_BYTES> int launch_x(Conv16Args &a, int act, hipStream_t st)
 {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, NT = 64 * WGM * WGN;
-    constexpr size_t STAGES = (size_t)NST * (BM + BN) * ROW_BYTES, EPI_MIN = (size_t)WGM * 32 * (BN + 4) * 4;
+    constexpr size_t STAGES = (size_t)NST * (BM + BN) * ROWB, EPI_MIN = (size_t)WGM * 32 * (BN + 4) * 4;
     constexpr size_t LDS_BYTES = STAGES > EPI_MIN ? STAGES : EPI_MIN;
     static_assert(LDS_BYTES <= 160 * 1024, "the stages must fit the CU's LDS");
     a.tiles_n = (a.Cout + BN - 1) / BN;
     a.tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
     if (a.tiles > 0x7fffffffLL || a.M > 0x7fffffffLL) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: more than 2^31 - 1 output pixels in one launch");
-    auto kern = conv16x_kernel<WGM, WGN, TM, TN, MODE, NST, RESPF>;
+    auto kern = conv16x_kernel<WGM, WGN, TM, TN, MODE, NST, RESPF, false, ROWB>;
     static bool attr_set = false;
     if (!attr_set) { TLK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES)); attr_set = true; }
     hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles), dim3(NT), LDS_BYTES, st, a, act);
@@ -572,7 +585,12 @@ int launch_cfg_x(Conv16Args &a, bool split, int act, int cfg, hipStream_t st)
         case 16: return launch_x<2, 2, 1, 1, MODE_F16, 2, true>(a, act, st);     // 64 x 64, two stages
         case 17: return launch_patch<4, 1, 2, 2, MODE_F16, true>(a, act, st, "tlk_conv2d_nhwc_16");      // 256 x 64 PATCH: 3 x 3 / 1 on 64 channels, input rows resident (see the fp32 form)
         case 18: return launch_patch<4, 1, 1, 2, MODE_F16, true>(a, act, st, "tlk_conv2d_nhwc_16");      // 128 x 64 PATCH
-        default: return fail(TLK_EINVAL, "tlk_conv16_set_config: f16 configurations are 1..18");
+        // r06: HALF-STEP tiles (K step = 32 halfs): Cin a multiple of 32 but not of 64
+        case 19: return launch_x<2, 2, 1, 1, MODE_F16, 4, true, 64>(a, act, st);     // 64 x 64, four stages: the small launches
+        case 20: return launch_x<2, 2, 2, 2, MODE_F16, 1, true, 64>(a, act, st);     // 128 x 128, ONE stage, residual prefetched
+        case 21: return launch_x<2, 2, 1, 2, MODE_F16, 3, true, 64>(a, act, st);     // 64 x 128, three stages
+        case 22: return launch_x<2, 2, 2, 2, MODE_F16, 2, true, 64>(a, act, st);     // 128 x 128, two stages
+        default: return fail(TLK_EINVAL, "tlk_conv16_set_config: f16 configurations are 1..22");
         }
     }
     switch (cfg) {
@@ -628,8 +646,12 @@ int launch32x(Conv16Args &a, int act, int cfg, hipStream_t st)
 int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream_t st)
 {
     (void)out32;
-    const int bke = split ? 32 : 64;
+    const bool half_cfg = !split && cfg >= 19 && cfg <= 22;
+    // f16 layers whose Cin is a multiple of 32 but not of 64 take the half-step tiles (19..22); a forced full-step configuration on such a layer is refused
+    const bool half_step = !split && a.Cin % 32 == 0 && a.Cin % 64 != 0;
+    const int bke = (split || half_step || half_cfg) ? 32 : 64;
     if (a.Cin % bke != 0 || a.K % bke != 0) return cfg > 0 ? fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: the large-tile kernels need Cin to be a multiple of the K step") : 1;
+    if (cfg > 0 && !split && half_step && !half_cfg) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: Cin is a multiple of 32 but not of 64: half-step tile configurations 19..22 only");
     // every offset the loader forms stays below 2^31: the rows of one tile + their halo, and the weights
     {
         const long long span_rows = 512 / (a.Wo > 0 ? a.Wo : 1) + a.KH + 2;
@@ -644,7 +666,13 @@ int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream
         //     over the chip (1100 TFLOP/s on the 3 x 3 / 512 layers, r04: 830);
         //   * Cout <= 64: the 256 x 64 one-stage tile.
         const long long tiles256 = ((a.M + 255) / 256) * ((a.Cout + 255) / 256);
-        if (!split) {
+        if (!split && half_step) {
+            const long long t128h = ((a.M + 127) / 128) * ((a.Cout + 127) / 128);
+            if (t128h >= 384) cfg = 20;
+            else if (t128h >= 256) cfg = 22;
+            else if (((a.M + 63) / 64) * ((a.Cout + 127) / 128) >= 192) cfg = 21;
+            else cfg = 19;
+        } else if (!split) {
             const long long t128 = ((a.M + 127) / 128) * ((a.Cout + 127) / 128);
             //   * 3 x 3 / stride 1 on exactly 64 channels with whole image rows per tile (ResNet's layer 1): the PATCH kernel -- the tile's input
             //     rows land in LDS once instead of once per tap (716 vs 625 TFLOP/s at 2400 crops, 611 vs 510 at 100)
@@ -668,6 +696,8 @@ int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream
             // epilogue: one stage for the short-K layers (K <= 128: 3.41 vs 3.69 ms on 64 -> 256, 2.12 vs 2.16 on 128 -> 512), two stages beyond
             // (1.40 vs 1.45 on 256 -> 1024, 4.08 vs 4.37 on 512 -> 2048; profiles/r06_split_res_probe.txt)
             else if (a.res && a.Cout % 128 == 0 && ((a.M + 127) / 128) * (a.Cout / 128) >= 512) cfg = a.K <= 128 ? 6 : 7;
+            // ... and the 3 x 3 layers on 64 channels (ResNet's layer 1): 256 x 64 tiles of four 64 x 64 wavefronts, 2.57 vs 2.80 ms (profiles/r06_split_l1_probe.txt)
+            else if (!a.res && a.KH == 3 && a.Cout == 64 && (a.M + 255) / 256 >= 768) cfg = 4;
             else return 1;
         }
     }

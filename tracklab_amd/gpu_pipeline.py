@@ -26,49 +26,6 @@ from . import _lib
 from .backbones.yolox import yolox
 
 
-def streams_run_concurrently(sa, sb, cycles: int = 400_000) -> bool:
-    """Do two HIP streams execute side by side?  HIP deals the streams of a process to a small pool of hardware queues; two streams that landed
-    on ONE queue run their kernels strictly one after the other whatever the events between them say (measured r05 / r06: the stage-overlap
-    mode then LOSES to the serial pipeline; with an RCCL communicator alive in the process the assignment shifts and the priority trick of r05
-    no longer separates the two stage streams).  So it is MEASURED: a spin kernel of ~`cycles` shader cycles on each stream, timestamps from
-    events on a common clock -- concurrent iff each one started before the other ended."""
-    dev = sa.device
-    base = torch.cuda.Event(enable_timing=True)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(2)]
-    torch.cuda.synchronize(dev)
-    base.record(torch.cuda.current_stream(dev))
-    for s_ in (sa, sb):
-        s_.wait_event(base)
-    for _ in range(2):                        # first round: warm (module load of the spin kernel)
-        for i, s_ in enumerate((sa, sb)):
-            with torch.cuda.stream(s_):
-                ev[i][0].record(s_)
-                torch.cuda._sleep(cycles)
-                ev[i][1].record(s_)
-        sa.synchronize(); sb.synchronize()
-    a0, a1 = base.elapsed_time(ev[0][0]), base.elapsed_time(ev[0][1])
-    b0, b1 = base.elapsed_time(ev[1][0]), base.elapsed_time(ev[1][1])
-    # overlapping intervals, with at least a third of the shorter one shared (two back-to-back kernels touch at a point, never more)
-    shared = min(a1, b1) - max(a0, b0)
-    return shared > 0.33 * min(a1 - a0, b1 - b0)
-
-
-def pick_concurrent_streams(dev, tries: int = 6):
-    """(stage-A stream, stage-B stream, how) that were OBSERVED to run concurrently, or None.  Candidates: r05's pair first (detector stage at high
-    priority, ReID stage at normal), then further streams of either priority -- every creation moves on through the queue pool."""
-    prio = int(__import__("os").environ.get("TLK_DET_PRIO", "-1"))
-    cands = []
-    for k in range(tries):
-        if k == 0:
-            pair = (torch.cuda.Stream(device=dev, priority=prio), torch.cuda.Stream(device=dev))
-        else:
-            pair = (torch.cuda.Stream(device=dev, priority=prio if k % 2 == 0 else 0), torch.cuda.Stream(device=dev, priority=0 if k % 3 else prio))
-        cands.append(pair)                    # (kept alive: a destroyed stream hands its queue slot back and the next creation lands there again)
-        if streams_run_concurrently(*pair):
-            return pair[0], pair[1], f"pair {k} (priorities {pair[0].priority}, {pair[1].priority})"
-    return None
-
-
 def _record_null_pair(self):
     """Two timing events with nothing between them on the current stream: the cost of an event pair itself (a few us on this stack -- not negligible
     beside a 30 us kernel). bench.py subtracts its mean from the mean of the kernel's own event pairs and prints both."""
@@ -299,7 +256,7 @@ class DetReidTrackPipeline:
                  parts: int = 6, dim: int = 256, reid_hw=(384, 128), tracker_cfg: dict | None = None,
                  nms_thr: float = 0.45, score_thr: float = 0.7, max_tracks: int | None = None, use_graph: bool = True,
                  pose: str | None = None, tracker: str = "bpbreid", reid_arch: str = "resnet50", camera_motion: bool = False,
-                 reid_split_precision: bool = False, overlap_stages: bool | None = None):
+                 reid_split_precision: bool = False, overlap_stages: bool | str | None = None, detector_split_precision: bool = False):
         """overlap_stages (r05, default off; env TLK_PIPE_OVERLAP=1): detector stage of step t + 1 and ReID stage of step t on two streams
         (double-buffered crops): what the ONLINE configuration wants, where a one-frame step's kernels have fewer tiles than the chip has CUs.
         camera_motion (tracker "bot_sort"): the reference's default cmc_method sparseOptFlow (configs/modules/track/bot_sort.yaml) -- one
@@ -344,6 +301,9 @@ class DetReidTrackPipeline:
             self.tracker_cfg = dict(self.tracker_cfg, motion_criterium="oks")
             self.pose = rtmpose(pose, device=self.dev, dtype=dtype, channels_last=True)
         self.model = yolox(detector, 1, device=self.dev, dtype=dtype, channels_last=True)
+        # detector_split_precision (r06; dtype float32): the detector's convolutions in split mode too.  Its planes are unscaled:
+        # range = float16's, and a non-finite prediction is ORed into the same flag the embeddings use (fails loudly in synchronize())
+        self.det_split = bool(detector_split_precision) and dtype == torch.float32
         self.reid_arch = reid_arch
         # reid_split_precision (dtype float32, ResNet-50): the ReID backbone's convolutions in split mode -- fp32 values as (hi, lo) f16 pairs on the
         # 16-bit MFMA, fp32-class results (csrc/tlk_conv16.hip)
@@ -412,42 +372,43 @@ class DetReidTrackPipeline:
         # r05, overlap_stages: stage A (letterbox, detector, decode + NMS, crops) of step t + 1 runs on its own stream beside stage B (ReID
         # forward, hand-off) of step t; what A writes and B reads -- crops, slot bases, live count -- exists twice, B's results go to the
         # per-step ring `bufs` as before.  Only the plain BPBReID chain (no pose stage, no camera motion, dense batch) is wired for it.
-        # r06: `None` = AUTO -- on for the online shapes (at most two frames of every stream per step: a launch then has fewer tiles than the chip has
-        # CUs and the two stages fill each other's gaps: 344 vs 232 frames/s at one frame per step), off for the throughput shapes (24 frames per
-        # step fill the chip by themselves).  TLK_PIPE_OVERLAP=0 / 1 forces it.  Whatever asked for it, the mode is only ENTERED with a pair of
-        # streams that was observed to run concurrently (pick_concurrent_streams); without one the pipeline stays serial and says so
-        # (`overlap_note`): same rows either way (tests/test_gpu_zz_stage_overlap.py), so the fallback is a speed matter only.
+        # r06: `None` = AUTO for the online shape the mode was built for -- 16-bit backbones, at most two frames per step in all (a launch then has
+        # fewer tiles than the chip has CUs and the two stages can fill each other's gaps) -- and AUTO means MEASURED: whether two HIP streams of
+        # one process really run side by side is decided by how HIP dealt them to hardware queues and the queues to the command processor's
+        # pipes, which the pipeline cannot choose and which shifts with every stream created before (and with an RCCL communicator in the
+        # process): the same code measured 1.39x the serial pipeline, 0.99x, 0.69x and 0.50x in ONE process as other streams came and went
+        # (profiles/r06_overlap_autotune.md; a spin-kernel probe of the two streams says "concurrent" in all four cases).  So the first
+        # step() runs both modes on its own inputs (a few steps each, back to back, results discarded, tracker reset) and keeps the faster
+        # one: never slower than serial.  overlap_stages=True / False (or TLK_PIPE_OVERLAP=1 / 0) forces a mode without the trial.  Off for
+        # fp32 backbones (their one-frame launches fill the chip: overlapped 46 vs 61 frames/s) and for the throughput shapes.
         env_ov = __import__("os").environ.get("TLK_PIPE_OVERLAP", "auto")
+        eligible = self.dense_reid and self.pose is None and not camera_motion
         if overlap_stages is None:
-            overlap_stages = (frames_per_step <= 2) if env_ov == "auto" else env_ov == "1"
-        self.overlap = bool(overlap_stages) and self.dense_reid and self.pose is None and not camera_motion
-        self.overlap_note = "off"
-        picked = None
-        if self.overlap:
-            picked = pick_concurrent_streams(dev)
-            if picked is None:
-                self.overlap = False
-                self.overlap_note = "asked for, but no pair of streams ran concurrently on this device / in this process: serial pipeline"
-                import logging
-                logging.getLogger(__name__).warning("DetReidTrackPipeline: stage overlap %s", self.overlap_note)
-            else:
-                self.overlap_note = "on: " + picked[2]
+            mode = {"1": "on", "0": "off"}.get(env_ov, "trial" if (n_streams * frames_per_step <= 2 and dtype in (torch.float16, torch.bfloat16)) else "off")
+        elif overlap_stages == "auto":                    # the trial whatever the shape (bench legs)
+            mode = "trial"
+        else:
+            mode = "on" if overlap_stages else "off"
+        self._ov_mode = mode if eligible else "off"       # "on" / "off" / "trial" (decided by the first step)
+        self.overlap = self._ov_mode == "on"
+        self.overlap_note = {"on": "on (forced)", "off": "off", "trial": "auto: not decided yet (first step)"}[self._ov_mode]
+        self.overlap_trial = None
         self.sets = [{"crops": self.crops, "slot_base": self.slot_base, "n_live": self.n_live, "slot_of": self.slot_of,
                       "a_done": torch.cuda.Event(), "b_done": torch.cuda.Event()}]
-        if self.overlap:
+        if self._ov_mode != "off":
             self.sets.append({"crops": torch.zeros_like(self.crops), "slot_base": torch.zeros_like(self.slot_base), "n_live": self.n_live.clone(),
                               "slot_of": self.slot_of.clone(), "a_done": torch.cuda.Event(), "b_done": torch.cuda.Event()})
             # the two stages only overlap when their streams sit on DIFFERENT hardware queues; HIP deals streams of one priority to a small
             # pool of queues round-robin, so two normal-priority streams may share one (measured: 219 frames/s then, 330 when they do not).
             # Streams of different priorities never share a queue: the detector stage gets the high-priority one (TLK_DET_PRIO overrides).
-            # (r06: the pair comes from pick_concurrent_streams, which MEASURED that the two run side by side)
-            self.det_stream, self.reid_stream = picked[0], picked[1]
+            self.det_stream = torch.cuda.Stream(device=dev, priority=int(__import__("os").environ.get("TLK_DET_PRIO", "-1")))
+            self.reid_stream = torch.cuda.Stream(device=dev)
         # f16 and split-precision backbones carry activations as float16 (pairs): |x| > 65504 saturates to infinity.  The envelope is stated in
         # DESIGN.md (tests/test_gpu_precision.py measures it); past it the run must fail LOUDLY, not track on infinities: every step ORs
         # "an embedding is not finite" into a device flag that travels to pinned memory with the results and is checked in synchronize()
-        self.check_finite = dtype != torch.float32 or bool(reid_split_precision)
-        self.nf_flag = torch.zeros(1, dtype=torch.bool, device=dev)
-        self.h_nf_flag = torch.zeros(1, dtype=torch.bool).pin_memory()
+        self.check_finite = dtype != torch.float32 or bool(reid_split_precision) or bool(detector_split_precision)
+        self.nf_flag = torch.zeros(2, dtype=torch.bool, device=dev)          # [0] embeddings (ReID stage), [1] detector predictions (split-mode detector): one writer each
+        self.h_nf_flag = torch.zeros(2, dtype=torch.bool).pin_memory()
         self.nbuf = 2
         self.bufs = []
         row_bytes = self.row_dtype.itemsize
@@ -497,16 +458,18 @@ class DetReidTrackPipeline:
         self.h_nf_flag.zero_()
 
     def synchronize(self):
-        if self.overlap:
+        if self._ov_mode != "off":
             self.det_stream.synchronize()
             self.reid_stream.synchronize()
         self.trk_stream.synchronize()
         torch.cuda.current_stream(self.dev).synchronize()
-        if self.check_finite and bool(self.h_nf_flag[0]):
+        if self.check_finite and bool(self.h_nf_flag.any()):
+            which = "detector predictions" if bool(self.h_nf_flag[1]) and not bool(self.h_nf_flag[0]) else "ReID embeddings"
             self.nf_flag.zero_()
             self.h_nf_flag.zero_()
-            raise _lib.TlkError("ReID embeddings are not finite: the float16 / split-precision backbones saturated (an activation beyond +-65504, "
-                                "float16's range); this network needs dtype float32 (the reference's precision) -- DESIGN.md, precision envelope")
+            raise _lib.TlkError(f"{which} are not finite: the float16 / split-precision backbones saturated (an activation beyond +-65504, "
+                                "float16's range; the split-precision ReID network follows larger activations with its plane scales, r06); this network "
+                                "needs dtype float32 (the reference's precision) -- DESIGN.md, precision envelope")
 
     def _feat_probe(self):
         """a zero-size stand-in with the dtype / layout of the ReID feature map (what fused_head_ok looks at)"""
@@ -536,13 +499,42 @@ class DetReidTrackPipeline:
         ent[0].replay()
         return ent[1]
 
+    def _autotune_overlap(self, frames, synth_head, warm: int = 5, timed: int = 14):
+        """AUTO mode, first step: both modes on this step's inputs, back to back, results discarded; keep the faster one (see __init__)."""
+        import time
+        rates = {}
+        self._ov_mode = "tuning"
+        for ov in (False, True):
+            self.overlap = ov
+            for _ in range(warm):
+                self._step(frames, synth_head, False, None)
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            for _ in range(timed):
+                self._step(frames, synth_head, False, None)
+            torch.cuda.synchronize(self.dev)
+            rates[ov] = timed / (time.perf_counter() - t0)
+        self.overlap = rates[True] > 1.05 * rates[False]
+        self._ov_mode = "on" if self.overlap else "off_tuned"
+        self.overlap_trial = {"serial_steps_per_s": rates[False], "overlapped_steps_per_s": rates[True], "steps_timed": timed}
+        self.overlap_note = (f"auto: measured {rates[True] * self.B:.1f} frames/s overlapped vs {rates[False] * self.B:.1f} serial over {timed} back-to-back steps of the first "
+                             f"step's inputs -> {'overlapped' if self.overlap else 'serial'}")
+        self.reset()                              # the trial's tracks, ids and flags are gone: the real first step starts from a fresh tracker
+        self.step_idx = 0
+
     @torch.no_grad()
     def step(self, frames: torch.Tensor, synth_head: torch.Tensor | None = None, fetch: bool = True, sink=None):
         """frames (S*F, H, W, 3) uint8 RGB on device (channel contract: module docstring); sink / ``self.frames_free`` as in
         ``DetTrackPipeline.step``."""
+        if self._ov_mode == "trial":
+            self._autotune_overlap(frames, synth_head)
+        return self._step(frames, synth_head, fetch, sink)
+
+    @torch.no_grad()
+    def _step(self, frames, synth_head, fetch, sink):
         S, F, maxd = self.S, self.F, self.maxd
         buf = self.bufs[self.step_idx % self.nbuf]
-        st = self.sets[self.step_idx % len(self.sets)]
+        st = self.sets[self.step_idx % len(self.sets)] if self.overlap else self.sets[0]
         self.step_idx += 1
         main = torch.cuda.current_stream(self.dev)
         if self.overlap:
@@ -560,8 +552,10 @@ class DetReidTrackPipeline:
         with torch.cuda.stream(sa):
             def det_fwd():
                 x, _ = _lib.letterbox(frames, self.size, "focus_nhwc", self.dtype, out=self.lb, swap_rb=True)
-                return self.model(x, focused=True)
+                return self.model(x, focused=True, split=self.det_split)
             pred = self._graphed(self.det_graphs, frames.data_ptr(), det_fwd) if self.use_graph else det_fwd()
+            if self.det_split:
+                self.nf_flag[1:2].logical_or_(torch.logical_not(torch.isfinite(pred).all()))
             if synth_head is not None:
                 pred = torch.add(synth_head, torch.nan_to_num(pred), alpha=0.0)
             _lib.yolox_decode_nms(pred, self.size, float(np.float32(self.ratio)), self.W, self.H, maxd, self.nms_thr,
@@ -644,7 +638,7 @@ class DetReidTrackPipeline:
                     _lib.conv_set_dynamic_batch(None)
             if fused_head:
                 self.reid.head(res, counts=buf["counts"], slot_base=st["slot_base"] if self.dense_reid else None, max_dets=maxd,
-                               out_emb=buf["emb"], out_vis=buf["vis"], flag=self.nf_flag if self.check_finite else None)
+                               out_emb=buf["emb"], out_vis=buf["vis"], flag=self.nf_flag[0:1] if self.check_finite else None)
                 if self.check_finite:
                     self.h_nf_flag.copy_(self.nf_flag, non_blocking=True)
             else:
@@ -661,7 +655,7 @@ class DetReidTrackPipeline:
                     # detections, a row no convolution wrote)
                     livem = torch.arange(maxd, device=self.dev)[None, :] < buf["counts"][:, None]
                     bad = torch.logical_not(torch.isfinite(buf["emb"]).flatten(2).all(-1)) & livem
-                    self.nf_flag.logical_or_(bad.any())
+                    self.nf_flag[0:1].logical_or_(bad.any())
                     self.h_nf_flag.copy_(self.nf_flag, non_blocking=True)
             torch.add(self.id_off, self.frames_done * maxd, out=buf["ids"])
             buf["ready"].record(sb)
