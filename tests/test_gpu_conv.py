@@ -140,6 +140,23 @@ def test_patch_resident_3x3_kernel_is_bit_exact_with_the_oracle_chain(case, cfg)
     assert np.array_equal(got, exp), f"max |diff| {np.abs(got - exp).max()}"
 
 
+PATCH64_CASES = [
+    # r06: 3 x 3 / stride 1 / pad 1 on 64 channels (two K steps per pixel: two patch regions): ResNet's layer 1 (Wo = 32) and HRNet's 64-channel branch (Wo = 16)
+    (3, 16, 32, 64, 64, 3, 1, "relu", False),
+    (2, 48, 16, 64, 64, 3, 1, "relu", True),
+    (2, 8, 64, 64, 72, 3, 1, None, False),            # Cout ragged against the 64-wide tile
+    (1, 64, 8, 64, 128, 3, 1, "relu", True),
+]
+
+
+@pytest.mark.parametrize("cfg", [34, 35, 36, 37])
+@pytest.mark.parametrize("case", PATCH64_CASES)
+def test_patch_resident_3x3_kernel_on_64_channels_is_bit_exact_with_the_oracle_chain(case, cfg):
+    got, exp = _run(case, cfg)
+    assert got.shape == exp.shape
+    assert np.array_equal(got, exp), f"max |diff| {np.abs(got - exp).max()}"
+
+
 def test_patch_kernel_refuses_a_shape_outside_its_contract_and_the_heuristic_routes_the_32_channel_layers_to_it():
     from tracklab_amd import _lib
     L = _lib.lib()
@@ -157,6 +174,23 @@ def test_patch_kernel_refuses_a_shape_outside_its_contract_and_the_heuristic_rou
     L.tlk_conv2d_set_config(0)
     try:
         y0 = _lib.conv2d_nhwc_f32(x, w, None, "relu", None, stride=1)
+    finally:
+        L.tlk_conv2d_set_config(-1)
+    assert torch.equal(y, y0)
+
+
+def test_heuristic_routes_the_64_channel_3x3_layers_to_the_patch_kernel():
+    """r06: ResNet's layer 1 / HRNet's 64-channel branch (3 x 3, stride 1, 64 -> 64, whole image rows per 128-pixel tile, a launch of >= 64K pixels)"""
+    from tracklab_amd import _lib
+    L = _lib.lib()
+    x = torch.randn(32, 96, 32, 64, device="cuda").permute(0, 3, 1, 2)
+    w = (torch.randn(64, 3, 3, 64, device="cuda") * 0.05).permute(0, 3, 1, 2)
+    r = torch.randn(32, 96, 32, 64, device="cuda").permute(0, 3, 1, 2)
+    y = _lib.conv2d_nhwc_f32(x, w, None, "relu", r, stride=1)
+    assert L.tlk_conv2d_last_config() == 34
+    L.tlk_conv2d_set_config(0)
+    try:
+        y0 = _lib.conv2d_nhwc_f32(x, w, None, "relu", r, stride=1)
     finally:
         L.tlk_conv2d_set_config(-1)
     assert torch.equal(y, y0)

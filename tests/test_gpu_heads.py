@@ -180,3 +180,22 @@ def test_a_step_without_detections_is_not_a_precision_error(use_graph, dtype_nam
     with pytest.raises(Exception, match="not finite"):
         pipe.synchronize()
     pipe.close()
+
+
+def test_f16_focus_stem_on_libtlk_agrees_with_the_library_route():
+    """r06: the f16 Focus stem (12 channels = one and a half 16-byte groups) zero-padded to 16 channels on tlk_conv2d_nhwc_16 -- the detector's last
+    library convolution -- against the library route (TLK_FOCUS16=0: CK / MIOpen convolution + epilogue pass)"""
+    import importlib
+    import torch
+    ymod = importlib.import_module("tracklab_amd.backbones.yolox")
+    net = ymod.yolox("m", 1, device="cuda", dtype=torch.float16)
+    x = (torch.rand(2, 12, 160, 160, device="cuda") * 255).half().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        a = net.backbone.stem(x, True)
+        ymod.USE_TLK_FOCUS16 = False
+        try:
+            b = net.backbone.stem(x, True)
+        finally:
+            ymod.USE_TLK_FOCUS16 = True
+    assert a.shape == b.shape == (2, 48, 160, 160) and a.dtype == torch.float16
+    assert float((a.float() - b.float()).abs().max()) <= 2.0 ** -9 * max(1.0, float(b.float().abs().max()))

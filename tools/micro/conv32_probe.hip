@@ -121,7 +121,7 @@ int main(int argc, char **argv)
         struct Exp { const char *name; int H, W, Cin, Cout, res, k; };
         const Exp hr[] = {{"hr 3x3 32>32 @96x32", 96, 32, 32, 32, 0, 3}, {"hr 3x3 32>32 +res", 96, 32, 32, 32, 1, 3}, {"hr 3x3 64>64 @48x16", 48, 16, 64, 64, 0, 3},
                           {"hr 3x3 64>64 +res", 48, 16, 64, 64, 1, 3}, {"hr 3x3 128>128 @24x8", 24, 8, 128, 128, 1, 3}, {"hr 3x3 256>256 @12x4", 12, 4, 256, 256, 1, 3},
-                          {"hr 1x1 64>32 @48x16", 48, 16, 64, 32, 0, 1}, {"hr 3x3 s2 32>64", 96, 32, 32, 64, 0, 3}};
+                          {"hr 1x1 64>32 @48x16", 48, 16, 64, 32, 0, 1}, {"hr 3x3 s2 32>64", 96, 32, 32, 64, 0, 3}, {"l1 3x3 64>64 @96x32", 96, 32, 64, 64, 0, 3}};
         const Exp exps_[] = {
             {"l1 1x1 64>256 +res", 96, 32, 64, 256, 1}, {"l2 1x1 128>512 +res", 48, 16, 128, 512, 1}, {"l3 1x1 256>1024 +res", 24, 8, 256, 1024, 1},
             {"l4 1x1 512>2048 +res", 24, 8, 512, 2048, 1}, {"l1 1x1 256>64", 96, 32, 256, 64, 0}, {"l2 1x1 512>128", 48, 16, 512, 128, 0},
@@ -141,7 +141,7 @@ int main(int argc, char **argv)
             const long long Mo = (long long)crops * Ho * Wo;
             auto run = [&] { TK(tlk_conv2d_nhwc_f32(x, w, bias, E.res ? r : nullptr, y, crops, E.H, E.W, E.Cin, E.Cout, E.k, E.k, stride, pad, 1, 0, 0, 0, nullptr)); };
             const double flops = 2.0 * Mo * E.Cout * E.Cin * E.k * E.k, bytes = (double)(M * E.Cin + Mo * E.Cout * (E.res ? 2 : 1) + E.Cout * E.Cin * E.k * E.k) * 4;
-            const int cfgs[] = {-1, 0, 2, 4, 9, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33};      // heuristic; two-stage tiles; 64 x 128 one-stage; the direct-to-LDS kernels
+            const int cfgs[] = {-1, 0, 2, 4, 9, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37};      // heuristic; two-stage tiles; 64 x 128 one-stage; the direct-to-LDS kernels
             float *yref; CK(hipMalloc(&yref, M * E.Cout * 4));
             TK(tlk_conv2d_set_config(0)); run(); CK(hipMemcpy(yref, y, M * E.Cout * 4, hipMemcpyDeviceToDevice));
             for (int cfg : cfgs) {

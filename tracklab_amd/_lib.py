@@ -1048,7 +1048,8 @@ CONV_F32_X_TEMPLATES = {21: "2, 2, 2, 2, 2, 1, true, false", 22: "2, 2, 2, 2, 2,
                         24: "2, 2, 2, 2, 2, 2, true, false", 25: "2, 2, 1, 2, 2, 1, true, false", 26: "4, 1, 2, 2, 2, 1, true, false",
                         27: "4, 1, 2, 1, 2, 1, true, false", 28: "4, 1, 2, 1, 2, 2, true, false", 29: "4, 1, 4, 1, 2, 1, true, false",
                         30: "4, 1, 2, 1, 2, 1, true, true", 31: "4, 1, 2, 1, 2, 1, false, true", 32: "4, 1, 1, 1, 2, 1, true, true",
-                        33: "2, 1, 2, 1, 2, 1, true, true"}
+                        33: "2, 1, 2, 1, 2, 1, true, true", 34: "4, 1, 1, 2, 2, 1, true, true, 128, 2", 35: "4, 1, 2, 2, 2, 1, true, true, 128, 2",
+                        36: "2, 1, 2, 2, 2, 1, true, true, 128, 2", 37: "4, 1, 1, 2, 2, 1, false, true, 128, 2"}
 
 
 def conv_f32_config_template(cfg: int) -> str:

@@ -245,7 +245,15 @@ class ConvBiasAct(nn.Module):
             b32 = c[1]
             if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
                 residual = residual.contiguous(memory_format=torch.channels_last)
-            return _lib.conv2d_nhwc_16(x, self.conv.weight, b32, self.act, residual, self.conv.stride[0], self.conv.padding[0],
+            weight = self.conv.weight
+            if weight.shape[1] != x.shape[1]:         # input channels zero-padded by the caller (the Focus stem: 12 -> 16): the weight follows (cached)
+                c = getattr(self, "_w_cpad", None)
+                key = param_key(weight) + (x.shape[1],)
+                if c is None or c[0] != key:
+                    c = (key, F.pad(weight.detach(), (0, 0, 0, 0, 0, x.shape[1] - weight.shape[1])).contiguous(memory_format=torch.channels_last))
+                    self._w_cpad = c
+                weight = c[1]
+            return _lib.conv2d_nhwc_16(x, weight, b32, self.act, residual, self.conv.stride[0], self.conv.padding[0],
                                        residual_after_act=residual_after_act, out=out)
         if USE_TLK_CONV_F32 and x.is_cuda and x.dtype == torch.float32 and (x.shape[1] % 4 == 0 or x.shape[1] == 3) \
                 and x.is_contiguous(memory_format=torch.channels_last):

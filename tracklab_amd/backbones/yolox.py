@@ -25,6 +25,7 @@ USE_SLICE_CONCAT = _os.environ.get("TLK_SLICE_CONCAT", "1") != "0"
 # r06: the nine 1 / 4 / num_classes-channel prediction convolutions + sigmoid / cat / flatten / permute / cast of the head as ONE libtlk launch
 # (tlk_yolox_head_nhwc); TLK_HEADS=0 restores the library convolutions + torch glue for A/B runs
 USE_TLK_HEADS = _os.environ.get("TLK_HEADS", "1") != "0"
+USE_TLK_FOCUS16 = _os.environ.get("TLK_FOCUS16", "1") != "0"       # 0: the f16 Focus stem on the library route (A/B runs)
 
 SIZES = {"tiny": (0.33, 0.375), "s": (0.33, 0.50), "m": (0.67, 0.75), "l": (1.0, 1.0), "x": (1.33, 1.25)}
 
@@ -113,6 +114,10 @@ class Focus(nn.Module):
             x = torch.cat((tl, bl, tr, br), dim=1)
         if split:                             # the 12-channel space-to-depth image as planes of 16 channels (the 16-bit kernels take 16-byte channel groups)
             x = SplitAct.from_f32(x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last), 16)
+        elif USE_TLK_FOCUS16 and x.is_cuda and x.dtype == torch.float16 and x.shape[1] == 12 and self.conv.conv.weight.dtype == torch.float16:
+            # r06: f16 -- 12 channels are one and a half 16-byte groups; padded to 16 (one small pass over the letterboxed image) the stem runs on libtlk's
+            # 16-bit kernel with bias + SiLU inside, instead of a library convolution + epilogue pass: the last library convolution of the detector
+            x = nn.functional.pad(x, (0, 0, 0, 0, 0, 4)).contiguous(memory_format=torch.channels_last)
         return self.conv(x)
 
 

@@ -365,6 +365,11 @@ int pick_x32(const ConvArgs &a, int cout, bool has_res)
     if (a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin == 32 && a.H == a.Ho && a.W == a.Wo && a.Wo >= 8 && a.Wo <= 64 && 256 % a.Wo == 0 &&
         ((long long)a.Ho * a.Wo) % 256 == 0 && a.M >= 64 * 1024)
         return 11;
+    //  * r06: the same on 64 channels (two K steps per pixel: the patch is two regions) -- HRNet's 64-channel branch 1.01 vs 1.11 ms (124 vs 113 TFLOP/s),
+    //    1.04 vs 1.18 with a residual; ResNet's layer 1 4.04 vs 4.28 ms (profiles/r06_conv_f32_patch64.txt)
+    if (a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin == 64 && a.H == a.Ho && a.W == a.Wo && a.Wo >= 8 && a.Wo <= 64 && 128 % a.Wo == 0 &&
+        ((long long)a.Ho * a.Wo) % 128 == 0 && a.M >= 64 * 1024)
+        return 14;
     //  * other layers that are 32 wide: the one-stage 256 x 32 tile (1 x 1 64 > 32: 0.14 vs 0.21 ms)
     if (cout == 32 && a.M >= 64 * 1024) return 7;
     //  * 64 wide: the one-stage 256 x 64 tile on the 1 x 1 layers (0.92 vs 1.06 ms) and the 3 x 3 ones (1.08 vs 1.11 ms; stride 2: 0.63 vs 0.68)
@@ -386,7 +391,7 @@ int g_last_cfg = -1;      // configuration of the most recent launch (tlk_conv2d
 
 extern "C" int tlk_conv2d_set_config(int cfg)
 {
-    if (cfg < -1 || (cfg > 9 && (cfg < 21 || cfg > 33))) return fail(TLK_EINVAL, "tlk_conv2d_set_config: cfg must be -1 (heuristic), 0..9, or 21..33 (the direct-to-LDS kernels of tlk_conv16x.hip on fp32 tensors)");
+    if (cfg < -1 || (cfg > 9 && (cfg < 21 || cfg > 37))) return fail(TLK_EINVAL, "tlk_conv2d_set_config: cfg must be -1 (heuristic), 0..9, or 21..37 (the direct-to-LDS kernels of tlk_conv16x.hip on fp32 tensors)");
     g_force_cfg = cfg;
     return TLK_OK;
 }

@@ -66,10 +66,12 @@ constexpr int pick_epi(int tm, int wgm, int rows_max)
 // ROWB (r06): bytes of one K step per tile row in LDS -- 128 everywhere but the f16 HALF-STEP tiles (64: K step = 32 halfs, the geometry of one plane of
 // the split mode), for layers whose Cin is a multiple of 32 but not of 64 (YOLOX-m's 96-channel layers: they sat on the r04 register-staged kernel,
 // whose loader divides per load when a K step straddles taps: 7 % of the one-frame f16 step)
-template <int WGM, int WGN, int TM, int TN, int MODE, int NST, bool RESPF, bool PATCH = false, int ROWB = ROW_BYTES>
+// CPP (r06, PATCH only): K steps per input pixel -- Cin = CPP * (one K step): the patch is CPP regions of 128-byte rows, one region per channel part
+template <int WGM, int WGN, int TM, int TN, int MODE, int NST, bool RESPF, bool PATCH = false, int ROWB = ROW_BYTES, int CPP = 1>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Args p, const int act)
 {
     static_assert(ROWB == ROW_BYTES || (ROWB == 64 && MODE == MODE_F16 && !PATCH), "half-step rows: f16 mode only");
+    static_assert(CPP == 1 || PATCH, "channel parts: patch mode only");
     constexpr bool USE_BUF = true;                        // (r05 A/B on the GPU: buffer loads with hardware zero fill >= 64-bit pointers + zero page on every layer)
     constexpr int NW = WGM * WGN, NT = 64 * NW;
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
@@ -296,29 +298,31 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
         // swizzle is keyed on the PATCH row, so the reader recomputes its term per tap (three integer operations per 16 MFMAs).  The k order (kh, kw, ci) and the fmaf chain within it are the implicit GEMM's: same bits.
         const int Wp = p.Wo + 2;
         const int prows = (BM / p.Wo + 2) * Wp;
-        const int n_ai = (prows + 7) >> 3;                  // wavefront-instructions that fill the patch (8 rows of 128 bytes each)
-        unsigned char *bs = lds + n_ai * 1024;
+        const int n_ai = (prows + 7) >> 3;                  // wavefront-instructions that fill one region of the patch (8 rows of 128 bytes each)
+        const int preg = n_ai * 1024;                       // bytes of one region = one channel part (r06: CPP parts per pixel, Cin = CPP K steps)
+        unsigned char *bs = lds + CPP * preg;
         const int h0 = (int)(((unsigned)m0 % (unsigned)(p.Ho * p.Wo)) / (unsigned)p.Wo);
         const int hb = h0 > 0 ? h0 - 1 : 0;                 // base_pix's image row
-        for (int i = wave; i < n_ai; i += NW) {
-            const int row = i * 8 + lrow;
+        for (int i = wave; i < n_ai * CPP; i += NW) {
+            const int part = i / n_ai, ii = i - part * n_ai;
+            const int row = ii * 8 + lrow;
             const int pr = row / Wp, px = row - pr * Wp;
             const int hi = h0 - 1 + pr, wi = px - 1;
             const int lcq = pc ^ ((row >> 1) & 7);
-            int off = (((hi - hb) * p.W + wi) * p.x_pix + lcq * EPC) * ES;
+            int off = (((hi - hb) * p.W + wi) * p.x_pix + part * BKE + lcq * EPC) * ES;
             off = (row < prows && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) ? off : OOB;
-            load16(rs_a[0], abase[0], off, lds + i * 1024);
+            load16(rs_a[0], abase[0], off, lds + part * preg + ii * 1024);
         }
-        // the weights stream through a ring of two 128-byte-row tiles, one tap each: tap t + 1 is issued right behind the barrier that opens
-        // tap t (everybody is then done with tap t - 1, whose buffer it overwrites) and has the tap's MFMAs to land.  52 KB in all on the
-        // 32-wide layers: three workgroups per CU -- with all nine taps resident (81 KB, two per CU) the load and epilogue phases showed.
-        auto issue_b = [&](int t) {
+        // the weights stream through a ring of two 128-byte-row tiles, one K step (tap, channel part) each: step s + 1 is issued right behind the
+        // barrier that opens step s (everybody is then done with step s - 1, whose buffer it overwrites) and has the step's MFMAs to land.
+        // 52 KB in all on the 32-wide layers: three workgroups per CU -- with all nine taps resident (81 KB, two per CU) the load and epilogue phases showed.
+        auto issue_b = [&](int sidx) {
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
                 const int col = (q * NW + wave) * 8 + lrow;
                 const int lcq = pc ^ ((col >> 1) & 7);
                 const int co = n0 + col;
-                load16(rs_b[0], wbase[0], co < p.Cout ? (co * p.K + t * BKE + lcq * EPC) * ES : OOB, bs + (t & 1) * B_REGION + (q * NW + wave) * 1024);
+                load16(rs_b[0], wbase[0], co < p.Cout ? (co * p.K + sidx * BKE + lcq * EPC) * ES : OOB, bs + (sidx & 1) * B_REGION + (q * NW + wave) * 1024);
             }
         };
         issue_b(0);
@@ -329,26 +333,28 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv16x_kernel(const Conv16Arg
             prow0[i] = orow * Wp + (ml - orow * p.Wo);
         }
         const int bp_lane = (wn * TN * 32 + (lane & 31)) * RB;
-        auto read_patch = [&](int toff, int t, int j, int set) {
+        auto read_patch = [&](int toff, int aoff, int sidx, int j, int set) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int pr = prow0[i] + toff;
-                fa[set][0][i] = *reinterpret_cast<const i32x4 *>(lds + (pr << 7) + (((2 * j + hsel) ^ ((pr >> 1) & 7)) << 4));
+                fa[set][0][i] = *reinterpret_cast<const i32x4 *>(lds + aoff + (pr << 7) + (((2 * j + hsel) ^ ((pr >> 1) & 7)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fb[set][0][i] = *reinterpret_cast<const i32x4 *>(bs + (t & 1) * B_REGION + bp_lane + i * 32 * RB + coff[j]);
+            for (int i = 0; i < TN; ++i) fb[set][0][i] = *reinterpret_cast<const i32x4 *>(bs + (sidx & 1) * B_REGION + bp_lane + i * 32 * RB + coff[j]);
         };
+        constexpr int NSTEP = 9 * CPP;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int toff = (t / 3) * Wp + t % 3;
+        for (int sidx = 0; sidx < NSTEP; ++sidx) {
+            const int t = sidx / CPP, part = sidx - t * CPP;
+            const int toff = (t / 3) * Wp + t % 3, aoff = part * preg;
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < 9) issue_b(t + 1);
-            read_patch(toff, t, 0, 0);
+            if (sidx + 1 < NSTEP) issue_b(sidx + 1);
+            read_patch(toff, aoff, sidx, 0, 0);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                if (j + 1 < NJ) read_patch(toff, t, j + 1, (j + 1) & 1);
+                if (j + 1 < NJ) read_patch(toff, aoff, sidx, j + 1, (j + 1) & 1);
                 mfmas(j & 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -538,23 +544,25 @@ template <int WGM, int WGN, int TM, int TN, int MODE, int NST, bool RESPF, int R
     return TLK_OK;
 }
 
-// PATCH mode: 3 x 3 / stride 1 / pad 1 layers whose Cin is exactly one K step and whose tiles are whole image rows
-template <int WGM, int WGN, int TM, int TN, int MODE, bool RESPF> int launch_patch(Conv16Args &a, int act, hipStream_t st, const char *who)
+// PATCH mode: 3 x 3 / stride 1 / pad 1 layers whose Cin is exactly CPP K steps and whose tiles are whole image rows
+template <int WGM, int WGN, int TM, int TN, int MODE, bool RESPF, int CPP = 1> int launch_patch(Conv16Args &a, int act, hipStream_t st, const char *who)
 {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, NT = 64 * WGM * WGN;
     constexpr int BKE = MODE == MODE_F32 ? 32 : 64;
     static_assert(MODE != MODE_SPLIT, "patch mode: one plane");
-    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin != BKE || a.H != a.Ho || a.W != a.Wo || a.Wo < 8 || a.Wo > 64 || BM % a.Wo != 0 ||
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin != BKE * CPP || a.H != a.Ho || a.W != a.Wo || a.Wo < 8 || a.Wo > 64 || BM % a.Wo != 0 ||
         ((long long)a.Ho * a.Wo) % BM != 0)
-        return fail(TLK_EINVAL, std::string(who) + ": the patch kernel takes 3 x 3 / stride 1 / pad 1 layers with Cin == one K step and tiles of whole image rows");
+        return fail(TLK_EINVAL, std::string(who) + ": the patch kernel takes 3 x 3 / stride 1 / pad 1 layers with Cin == " + std::to_string(BKE * CPP) +
+                                    " (its K steps per pixel) and tiles of whole image rows");
     const int prows = (BM / a.Wo + 2) * (a.Wo + 2);
-    const size_t lds_bytes = (size_t)((prows + 7) / 8) * 1024 + (size_t)2 * BN * ROW_BYTES;
-    constexpr size_t LDS_MAX = (size_t)((BM / 8 + 2) * (8 + 2) > (BM / 64 + 2) * (64 + 2) ? (BM / 8 + 2) * (8 + 2) + 8 : (BM / 64 + 2) * (64 + 2) + 8) * ROW_BYTES + (size_t)2 * BN * ROW_BYTES;
+    const size_t lds_bytes = (size_t)CPP * ((prows + 7) / 8) * 1024 + (size_t)2 * BN * ROW_BYTES;
+    constexpr size_t LDS_MAX = (size_t)CPP * ((BM / 8 + 2) * (8 + 2) > (BM / 64 + 2) * (64 + 2) ? (BM / 8 + 2) * (8 + 2) + 8 : (BM / 64 + 2) * (64 + 2) + 8) * ROW_BYTES +
+                               (size_t)2 * BN * ROW_BYTES;
     static_assert(LDS_MAX <= 160 * 1024, "patch + weights must fit the CU's LDS");
     a.tiles_n = (a.Cout + BN - 1) / BN;
     a.tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
     if (a.tiles > 0x7fffffffLL || a.M > 0x7fffffffLL) return fail(TLK_EINVAL, std::string(who) + ": more than 2^31 - 1 output pixels in one launch");
-    auto kern = conv16x_kernel<WGM, WGN, TM, TN, MODE, 1, RESPF, true>;
+    auto kern = conv16x_kernel<WGM, WGN, TM, TN, MODE, 1, RESPF, true, ROW_BYTES, CPP>;
     static bool attr_set = false;
     if (!attr_set) { TLK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX)); attr_set = true; }
     hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles), dim3(NT), lds_bytes, st, a, act);
@@ -622,7 +630,12 @@ int launch_cfg_x32(Conv16Args &a, int act, int cfg, hipStream_t st)
     case 11: return launch_patch<4, 1, 2, 1, MODE_F32, false>(a, act, st, "tlk_conv2d_nhwc_f32");
     case 12: return launch_patch<4, 1, 1, 1, MODE_F32, true>(a, act, st, "tlk_conv2d_nhwc_f32");      // 128 x 32 PATCH (34 KB: four workgroups per CU)
     case 13: return launch_patch<2, 1, 2, 1, MODE_F32, true>(a, act, st, "tlk_conv2d_nhwc_f32");      // 128 x 32 PATCH, two wavefronts of 64 x 32
-    default: return fail(TLK_EINVAL, "tlk_conv2d_set_config: the direct-to-LDS fp32 configurations are 21..33");
+    // r06: PATCH on 64 channels (two K steps per pixel: the patch is two regions) -- ResNet's layer 1 and HRNet's 64-channel branch
+    case 14: return launch_patch<4, 1, 1, 2, MODE_F32, true, 2>(a, act, st, "tlk_conv2d_nhwc_f32");   // 128 x 64 PATCH, four wavefronts of 32 x 64
+    case 15: return launch_patch<4, 1, 2, 2, MODE_F32, true, 2>(a, act, st, "tlk_conv2d_nhwc_f32");   // 256 x 64 PATCH, four wavefronts of 64 x 64
+    case 16: return launch_patch<2, 1, 2, 2, MODE_F32, true, 2>(a, act, st, "tlk_conv2d_nhwc_f32");   // 128 x 64 PATCH, two wavefronts of 64 x 64
+    case 17: return launch_patch<4, 1, 1, 2, MODE_F32, false, 2>(a, act, st, "tlk_conv2d_nhwc_f32");  // 128 x 64 PATCH, residual read in the epilogue
+    default: return fail(TLK_EINVAL, "tlk_conv2d_set_config: the direct-to-LDS fp32 configurations are 21..37");
     }
 }
 

@@ -372,25 +372,27 @@ class DetReidTrackPipeline:
         # r05, overlap_stages: stage A (letterbox, detector, decode + NMS, crops) of step t + 1 runs on its own stream beside stage B (ReID
         # forward, hand-off) of step t; what A writes and B reads -- crops, slot bases, live count -- exists twice, B's results go to the
         # per-step ring `bufs` as before.  Only the plain BPBReID chain (no pose stage, no camera motion, dense batch) is wired for it.
-        # r06: `None` = AUTO for the online shape the mode was built for -- 16-bit backbones, at most two frames per step in all (a launch then has
-        # fewer tiles than the chip has CUs and the two stages can fill each other's gaps) -- and AUTO means MEASURED: whether two HIP streams of
+        # r06: `None` = AUTO for the online shapes -- at most two frames per step in all (with 16-bit backbones a launch then has fewer tiles than the
+        # chip has CUs and the two stages can fill each other's gaps) -- and AUTO means MEASURED: whether two HIP streams of
         # one process really run side by side is decided by how HIP dealt them to hardware queues and the queues to the command processor's
         # pipes, which the pipeline cannot choose and which shifts with every stream created before (and with an RCCL communicator in the
         # process): the same code measured 1.39x the serial pipeline, 0.99x, 0.69x and 0.50x in ONE process as other streams came and went
         # (profiles/r06_overlap_autotune.md; a spin-kernel probe of the two streams says "concurrent" in all four cases).  So the first
         # step() runs both modes on its own inputs (a few steps each, back to back, results discarded, tracker reset) and keeps the faster
-        # one: never slower than serial.  overlap_stages=True / False (or TLK_PIPE_OVERLAP=1 / 0) forces a mode without the trial.  Off for
-        # fp32 backbones (their one-frame launches fill the chip: overlapped 46 vs 61 frames/s) and for the throughput shapes.
+        # one: never slower than serial.  overlap_stages=True / False (or TLK_PIPE_OVERLAP=1 / 0) forces a mode without the trial.  No trial for the
+        # throughput shapes (24 frames per step fill the chip; their association hides on its side stream); with fp32 backbones the trial
+        # measures the overlap slower (one-frame fp32 launches fill the chip: 46 vs 61 frames/s) and drops it.
         env_ov = __import__("os").environ.get("TLK_PIPE_OVERLAP", "auto")
         eligible = self.dense_reid and self.pose is None and not camera_motion
         if overlap_stages is None:
-            mode = {"1": "on", "0": "off"}.get(env_ov, "trial" if (n_streams * frames_per_step <= 2 and dtype in (torch.float16, torch.bfloat16)) else "off")
+            mode = {"1": "on", "0": "off"}.get(env_ov, "trial" if n_streams * frames_per_step <= 2 else "off")
         elif overlap_stages == "auto":                    # the trial whatever the shape (bench legs)
             mode = "trial"
         else:
             mode = "on" if overlap_stages else "off"
         self._ov_mode = mode if eligible else "off"       # "on" / "off" / "trial" (decided by the first step)
         self.overlap = self._ov_mode == "on"
+        self.trk_inline = False
         self.overlap_note = {"on": "on (forced)", "off": "off", "trial": "auto: not decided yet (first step)"}[self._ov_mode]
         self.overlap_trial = None
         self.sets = [{"crops": self.crops, "slot_base": self.slot_base, "n_live": self.n_live, "slot_of": self.slot_of,
@@ -500,12 +502,19 @@ class DetReidTrackPipeline:
         return ent[1]
 
     def _autotune_overlap(self, frames, synth_head, warm: int = 5, timed: int = 14):
-        """AUTO mode, first step: both modes on this step's inputs, back to back, results discarded; keep the faster one (see __init__)."""
+        """AUTO mode, first step: the stream arrangements on this step's inputs, back to back, results discarded; keep the fastest (see __init__).
+        Three candidates -- (a) serial stages, association on its side stream (the r01-r05 arrangement); (b) stages overlapped on two streams;
+        (c) everything on ONE stream, association inline.  (c) is in the list because (a) is not immune either: its association stream is a
+        second hardware queue, and with an unlucky assignment the SERIAL pipeline itself was measured at 114 instead of 251 frames/s
+        (tests/test_gpu_zz_stage_overlap.py, one idle stream created before it); inline costs the association's ~0.2 ms per frame and
+        cannot be hit by queue placement."""
         import time
-        rates = {}
+        cands = [("serial stages, association on a side stream", False, False), ("stages overlapped, association on a side stream", True, False),
+                 ("one stream (association inline)", False, True)]
+        rates = []
         self._ov_mode = "tuning"
-        for ov in (False, True):
-            self.overlap = ov
+        for _, ov, inline in cands:
+            self.overlap, self.trk_inline = ov, inline
             for _ in range(warm):
                 self._step(frames, synth_head, False, None)
             torch.cuda.synchronize(self.dev)
@@ -513,12 +522,17 @@ class DetReidTrackPipeline:
             for _ in range(timed):
                 self._step(frames, synth_head, False, None)
             torch.cuda.synchronize(self.dev)
-            rates[ov] = timed / (time.perf_counter() - t0)
-        self.overlap = rates[True] > 1.05 * rates[False]
+            rates.append(timed / (time.perf_counter() - t0))
+        best = 0                                   # the r05 arrangement unless another one is clearly (5 %) faster
+        for i in (1, 2):
+            if rates[i] > 1.05 * rates[best]:
+                best = i
+        self.overlap, self.trk_inline = cands[best][1], cands[best][2]
         self._ov_mode = "on" if self.overlap else "off_tuned"
-        self.overlap_trial = {"serial_steps_per_s": rates[False], "overlapped_steps_per_s": rates[True], "steps_timed": timed}
-        self.overlap_note = (f"auto: measured {rates[True] * self.B:.1f} frames/s overlapped vs {rates[False] * self.B:.1f} serial over {timed} back-to-back steps of the first "
-                             f"step's inputs -> {'overlapped' if self.overlap else 'serial'}")
+        self.overlap_trial = {"serial_steps_per_s": rates[0], "overlapped_steps_per_s": rates[1], "one_stream_steps_per_s": rates[2], "steps_timed": timed,
+                              "chosen": cands[best][0]}
+        self.overlap_note = (f"auto: measured {rates[0] * self.B:.1f} / {rates[1] * self.B:.1f} / {rates[2] * self.B:.1f} frames/s (serial stages / stages overlapped / one "
+                             f"stream) over {timed} back-to-back steps of the first step's inputs -> {cands[best][0]}")
         self.reset()                              # the trial's tracks, ids and flags are gone: the real first step starts from a fresh tracker
         self.step_idx = 0
 
@@ -661,19 +675,20 @@ class DetReidTrackPipeline:
             buf["ready"].record(sb)
             st["b_done"].record(sb)
         self.frames_done += S * F
-        with torch.cuda.stream(self.trk_stream):
-            self.trk_stream.wait_event(buf["ready"])
+        ts = sb if self.trk_inline else self.trk_stream      # (trk_inline: the association behind stage B on ITS stream -- no third queue; see _autotune_overlap)
+        with torch.cuda.stream(ts):
+            ts.wait_event(buf["ready"])
             if self.cmc is not None:
-                self.trk_stream.wait_event(buf["cmc_done"])
+                ts.wait_event(buf["cmc_done"])
                 self.bank.update_dev(buf["trk_in"].data_ptr(), buf["emb"].data_ptr(), buf["counts"].data_ptr(), F, buf["rows"].data_ptr(),
-                                     maxd, buf["ocnt"].data_ptr(), C.c_void_p(self.trk_stream.cuda_stream), warps=buf["warps"].data_ptr())
+                                     maxd, buf["ocnt"].data_ptr(), C.c_void_p(ts.cuda_stream), warps=buf["warps"].data_ptr())
             elif self.global_feat:
                 self.bank.update_dev(buf["trk_in"].data_ptr(), buf["emb"].data_ptr(), buf["counts"].data_ptr(), F, buf["rows"].data_ptr(),
-                                     maxd, buf["ocnt"].data_ptr(), C.c_void_p(self.trk_stream.cuda_stream))
+                                     maxd, buf["ocnt"].data_ptr(), C.c_void_p(ts.cuda_stream))
             else:
                 self.bank.update_dev(buf["ids"].data_ptr(), buf["ltwh"].data_ptr(), buf["emb"].data_ptr(), buf["vis"].data_ptr(),
                                      self.conf.data_ptr(), buf["counts"].data_ptr(), F, buf["rows"].data_ptr(), maxd,
-                                     buf["ocnt"].data_ptr(), C.c_void_p(self.trk_stream.cuda_stream),
+                                     buf["ocnt"].data_ptr(), C.c_void_p(ts.cuda_stream),
                                      kps=buf["kps"].data_ptr() if self.pose is not None else None)
             if sink is not None:
                 sink(self.result_tensors(buf))
@@ -682,7 +697,7 @@ class DetReidTrackPipeline:
                 buf["h_ocnt"].copy_(buf["ocnt"], non_blocking=True)
                 buf["h_ltwh"].copy_(buf["ltwh"], non_blocking=True)
                 buf["h_dcnt"].copy_(buf["counts"], non_blocking=True)
-            buf["done"].record(self.trk_stream)
+            buf["done"].record(ts)
         self.last = buf
         return (buf["h_rows"], buf["h_ocnt"]) if fetch else (buf["rows"], buf["ocnt"])
 
