@@ -712,11 +712,20 @@ def main():
             except Exception as ex:                             # noqa: BLE001
                 latency_f16_overlap = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
-    if defer_group:
+    def init_deferred_group():
+        """the one-rank RCCL group of the no-torchrun N = 1 line: created BEHIND the timed regions (a one-rank barrier inside them is a no-op
+        anyway) and AHEAD of the line's reductions, which then run on RCCL.  Not earlier: a communicator alive in the process shifts HIP's
+        stream -> hardware-queue assignment, and a pipeline's association side stream (or its overlapped stage) can lose its concurrency --
+        config 2 measured 1857 frames/s with the group alive during the timed legs against 2460 without (profiles/r06_overlap_autotune.md)"""
+        nonlocal dist, dist_note, defer_group
+        if not defer_group:
+            return
+        defer_group = False
         try:
             dist = tdist.init_single("nccl")
-            dist_note = ("nccl (RCCL), one-rank process group initialised in-process (after the small-step legs, before the timed legs): barrier / "
-                         "all-reduce(max, sum) / all-gather of the timed legs and the HOTA statistics run on RCCL")
+            dist.barrier()
+            dist_note = ("nccl (RCCL), one-rank process group initialised in-process behind the timed regions: the line's all-reduces (max of the "
+                         "timed legs, SUM of the HOTA statistics), the all-gather of the per-rank rows and a barrier run on RCCL")
         except Exception as ex:                                 # noqa: BLE001
             dist, dist_note = None, f"none: one-rank nccl group failed to initialise ({type(ex).__name__}: {ex})"[:300]
 
@@ -772,6 +781,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         el_h2d_local = time.perf_counter() - t0
+        init_deferred_group()
+        el_res = tdist.allreduce_max(el_res_local, dist, dev)          # (again, now through the group: the same number at one rank)
         el_h2d = tdist.allreduce_max(el_h2d_local, dist, dev)
         fps_h2d = args.steps * B * world / el_h2d
         fps_local = args.steps * B / el_h2d_local
@@ -801,6 +812,7 @@ def main():
                                                  "hota_statistics_equal_host_fed": bool(np.allclose(dev_eval["hota"], vec, rtol=1e-9, atol=1e-9))}
             except Exception as ex:                             # noqa: BLE001  (an evaluator problem must not cost the run its line)
                 hota_all["from_device_table"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    init_deferred_group()                                           # (no H2D leg: the group is created here)
     per_rank, seen, placement = gather_ranks(dist, dev, fps_local)
     warm_serialized = None
     if world > 1 and dist is not None and len(warm_order) == 2:

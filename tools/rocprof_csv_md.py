@@ -13,7 +13,7 @@ rows = list(csv.DictReader(open(path)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 out = [f"# {dst.split('/')[-1]}", "", f"command: `{cmd}`", ""]
 if len(sys.argv) > 4:
-    d = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
+    d = json.loads([l for l in open(sys.argv[4]).read().strip().splitlines() if l.startswith("{")][-1])      # (RCCL prints its banner to stdout when the process ends)
     out += [f"bench line of this profiled run: value = {d['value']:.1f} frames/s ({d['dtype']}), ms_per_step = {d['ms_per_step']:.2f}; "
             f"roofline (HIP events): {d['roofline']['achieved']:.1f} {d['roofline']['unit']} = {d['roofline']['frac']:.3f} of peak, "
             f"avg launch {d['roofline']['avg_launch_ms']:.4f} ms", ""]

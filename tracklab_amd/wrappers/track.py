@@ -415,7 +415,9 @@ class HipBoTSORT(ImageLevelModule, _ReidTrackerBase):
             self._cmc_method = "none"
         if self._cmc_method not in ("none", None, "sparseOptFlow"):
             raise NotImplementedError(f"cmc_method {self._cmc_method!r} (gmc.py: cv2 ORB / SIFT / ECC estimators, GMC files) is not part of the HIP path; "
-                                      "use sparseOptFlow (the reference's default, on the device) or none")
+                                      "use sparseOptFlow (the reference's default, on the device) or none.  (In the reference itself 'file' / 'files' cannot "
+                                      "be constructed through BoTSORT -- bot_sort.py:273 passes verbose=[None, False] and gmc.py:38-45 then tests "
+                                      "'-FRCNN' in None -- and 'ecc' aligns every frame with the FIRST one: gmc.py:82-110 never refreshes prevFrame.)")
 
     def _update(self, inputs, feats, image):
         warp = None
