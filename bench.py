@@ -629,89 +629,6 @@ def main():
                       "tracks": int(max((g[:, 4].max() if len(g) else 0) for g in got))}
         pipe.reset()
 
-    # ---- small-step legs: the same chain at frames_per_step 1 / 2 / 4 and at 4 streams x 1 frame (what an online consumer sees; the
-    # reference's online engine is per-frame, engine/video.py:67-117). Each: pipelined frames/s, un-overlapped frame-in -> rows-out time,
-    # and for the BPBReID workloads the ids of up to 48 frames per checked stream against the oracle chain ----
-    def small_step_legs(dt, with_main, overlap=None):
-        """overlap None: the pipeline's default mode (auto); False: serial, forced; True: detector stage of step t + 1 beside the ReID stage of step t"""
-        shapes = [(1, 1), (1, 2), (1, 4), (4, 1)] if is3 else [(1, 1), (1, 4)]
-        if overlap:
-            shapes = [(1, 1), (1, 2), (4, 1)]
-        latency = []
-        for S_, F_ in shapes:
-            if S_ * F_ > B:
-                continue
-            p1 = make_pipe(F_, S_, dt, overlap=overlap)
-            T_ = 48 if S_ * F_ > 1 else 36
-            hs = [heads_np[0][:T_]] + [build_stream_inputs(5000 + s_, n_objects, T_, ratio)[0] for s_ in range(1, S_)]
-            hsteps = np.ascontiguousarray(np.stack(hs).reshape(S_, T_ // F_, F_, -1, heads_np.shape[-1]).transpose(1, 0, 2, 3, 4)).reshape(
-                T_ // F_, S_ * F_, -1, heads_np.shape[-1])
-            d_h1 = torch.from_numpy(hsteps).to(dev)
-            fr1 = d_pool[0][:S_ * F_]                            # one fixed frame buffer -> one hipGraph
-            n1 = T_ // F_
-            stp = lambda j: p1.step(fr1, d_h1[j % n1])                        # noqa: E731
-            leg_parity = None
-            if is3 and not ssort and wl.get("pose") is None:
-                import oracle
-                refs = {s_: oracle.StrongSORT(p1.K, p1.D, **p1.tracker_cfg) for s_ in sorted({0, S_ - 1})}
-                okl, nfr = True, 0
-                for j in range(n1):
-                    h_rows, h_cnt = stp(j)
-                    p1.synchronize()
-                    rws, _ = p1.rows_numpy(h_rows, h_cnt)
-                    emb = p1.last["emb"].cpu().numpy().reshape(S_, F_, p1.maxd, p1.K, p1.D)
-                    vis = p1.last["vis"].cpu().numpy().reshape(S_, F_, p1.maxd, p1.K)
-                    for s_, ref_ in refs.items():
-                        for f in range(F_):
-                            ltwh32 = detector_rows(oracle, hs[s_][j * F_ + f], ratio)
-                            n = len(ltwh32)
-                            ids = (j * S_ * F_ + s_ * F_ + f) * p1.maxd + np.arange(n)
-                            exp = ref_.update(ids, ltwh32.astype(np.float64), emb[s_, f, :n], vis[s_, f, :n], np.ones(n)) if n else []
-                            got = rws[s_][f]
-                            okl &= len(got) == len(exp) and (len(exp) == 0 or (np.array_equal(got["det_id"], exp["det_id"]) and
-                                                                               np.array_equal(got["track_id"], exp["track_id"])))
-                            nfr += 1
-                leg_parity = {"frames": nfr, "streams_checked": sorted(refs), "track_ids_equal_oracle": bool(okl)}
-                p1.reset()
-            for j in range(8):
-                stp(j)
-            p1.synchronize(); torch.cuda.synchronize()
-            nrun = max(n1, 40)
-            t0 = time.perf_counter()
-            for j in range(nrun):
-                stp(j)
-            p1.synchronize(); torch.cuda.synchronize()
-            el1 = time.perf_counter() - t0
-            lat = []
-            for j in range(15):                                  # true in-to-out latency: one step, wait for its rows
-                t1 = time.perf_counter(); stp(j); p1.synchronize(); lat.append(time.perf_counter() - t1)
-            latency.append({"n_streams": S_, "frames_per_step": F_, "fps": nrun * S_ * F_ / el1, "ms_per_step_pipelined": el1 / nrun * 1e3,
-                            "ms_frame_in_to_rows_out": float(np.median(lat) * 1e3), "parity": leg_parity, "overlap_stages": bool(getattr(p1, "overlap", False)), "overlap_note": getattr(p1, "overlap_note", None),
-                            "overlap_trial": getattr(p1, "overlap_trial", None)})
-            p1.close()
-            del p1, d_h1
-        if with_main:
-            lat_main = []
-            for j in range(4):
-                pipe.synchronize(); t1 = time.perf_counter(); run_step(j); pipe.synchronize(); lat_main.append(time.perf_counter() - t1)
-            latency.append({"n_streams": S, "frames_per_step": F, "fps": fps_res, "ms_per_step_pipelined": el_res / args.steps * 1e3,
-                            "ms_frame_in_to_rows_out": float(np.median(lat_main) * 1e3), "parity": "see `parity`"})
-            pipe.reset()
-        return latency
-
-    latency = latency_f16 = latency_f16_overlap = None
-    if rank == 0 and world == 1 and not args.no_latency_leg and F > 1:
-        pipe.reset()
-        latency = small_step_legs(tdtype, False)              # the pipeline's DEFAULT mode (r06: stage overlap is automatic for the one-frame f16 shapes)
-        if args.dtype == "f32":           # the online target (>= 240 frames/s at small steps) is out of any fp32 path's reach on this chip (one frame = 1.36 TFLOP of
-            latency_f16 = small_step_legs(torch.float16, False, overlap=False)      # convolutions = 8.6 ms at the fp32 MFMA peak): the f16 legs are reported beside (serial, forced)
-        if is3 and not ssort and wl.get("pose") is None and not wl.get("camera_motion"):
-            try:              # r06: the AUTO mode at every small shape -- the first step measures both modes on its own inputs and keeps the faster (`overlap_trial`);
-                              # reported beside the forced-serial legs: an exception here must not cost the run its line
-                latency_f16_overlap = small_step_legs(torch.float16, False, overlap="auto")
-            except Exception as ex:                             # noqa: BLE001
-                latency_f16_overlap = {"error": f"{type(ex).__name__}: {ex}"[:300]}
-
     def init_deferred_group():
         """the one-rank RCCL group of the no-torchrun N = 1 line: created BEHIND the timed regions (a one-rank barrier inside them is a no-op
         anyway) and AHEAD of the line's reductions, which then run on RCCL.  Not earlier: a communicator alive in the process shifts HIP's
@@ -724,8 +641,9 @@ def main():
         try:
             dist = tdist.init_single("nccl")
             dist.barrier()
-            dist_note = ("nccl (RCCL), one-rank process group initialised in-process behind the timed regions: the line's all-reduces (max of the "
-                         "timed legs, SUM of the HOTA statistics), the all-gather of the per-rank rows and a barrier run on RCCL")
+            dist_note = ("nccl (RCCL), one-rank process group initialised in-process after the line's legs (a communicator alive in the process perturbs the "
+                         "pipelines' side-stream overlap): the line's all-reduces (max of the timed legs, SUM of the HOTA statistics), the all-gather of the "
+                         "per-rank rows and a barrier are executed through it")
         except Exception as ex:                                 # noqa: BLE001
             dist, dist_note = None, f"none: one-rank nccl group failed to initialise ({type(ex).__name__}: {ex})"[:300]
 
@@ -750,17 +668,11 @@ def main():
     el_res_local = timed_resident(pipe, args.steps, args.warmup)
     el_res = tdist.allreduce_max(el_res_local, dist, dev)
     fps_res = args.steps * B * world / el_res
-    if latency is not None:
-        lat_main = []
-        for j in range(4):
-            pipe.synchronize(); t1 = time.perf_counter(); run_step(j); pipe.synchronize(); lat_main.append(time.perf_counter() - t1)
-        latency.append({"n_streams": S, "frames_per_step": F, "fps": fps_res, "ms_per_step_pipelined": el_res / args.steps * 1e3,
-                        "ms_frame_in_to_rows_out": float(np.median(lat_main) * 1e3), "parity": "see `parity`"})
-        pipe.reset()
 
     # ---- leg 2 (the headline): frames arrive from pinned host memory, one video through HipVideoEngine ----
     fps_h2d = el_h2d = None
     hota_all = None
+    hota_vec_local = el_h2d_local = None
     h2d_gbs = None
     fps_local = args.steps * B / el_res_local
     if S == 1 and not args.no_h2d_leg:
@@ -781,8 +693,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         el_h2d_local = time.perf_counter() - t0
-        init_deferred_group()
-        el_res = tdist.allreduce_max(el_res_local, dist, dev)          # (again, now through the group: the same number at one rank)
         el_h2d = tdist.allreduce_max(el_h2d_local, dist, dev)
         fps_h2d = args.steps * B * world / el_h2d
         fps_local = args.steps * B / el_h2d_local
@@ -790,6 +700,7 @@ def main():
         # per-epoch metric reduction across ranks (tiny, latency-bound): HOTA sufficient statistics of every rank's stream
         from tracklab_amd import hota
         vec = hota_pack_from_table(df, gts[0], args.steps * F)
+        hota_vec_local = vec
         fin = hota.finalize(tdist.allreduce_sum(vec, dist, dev))
         hota_all = {"HOTA": fin["summary"]["HOTA"], "DetA": fin["summary"]["DetA"], "AssA": fin["summary"]["AssA"], "frames": fin["frames"],
                     "rows": int(len(df)), "tracked_rows": int(df.track_id.notna().sum())}
@@ -812,7 +723,6 @@ def main():
                                                  "hota_statistics_equal_host_fed": bool(np.allclose(dev_eval["hota"], vec, rtol=1e-9, atol=1e-9))}
             except Exception as ex:                             # noqa: BLE001  (an evaluator problem must not cost the run its line)
                 hota_all["from_device_table"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
-    init_deferred_group()                                           # (no H2D leg: the group is created here)
     per_rank, seen, placement = gather_ranks(dist, dev, fps_local)
     warm_serialized = None
     if world > 1 and dist is not None and len(warm_order) == 2:
@@ -1029,6 +939,89 @@ def main():
             roofline_hbm = roofline
             roofline = conv_roofline(pipe, args.workload)
 
+    # ---- small-step legs: the same chain at frames_per_step 1 / 2 / 4 and at 4 streams x 1 frame (what an online consumer sees; the
+    # reference's online engine is per-frame, engine/video.py:67-117). Each: pipelined frames/s, un-overlapped frame-in -> rows-out time,
+    # and for the BPBReID workloads the ids of up to 48 frames per checked stream against the oracle chain ----
+    def small_step_legs(dt, with_main, overlap=None):
+        """overlap None: the pipeline's default mode (auto); False: serial, forced; True: detector stage of step t + 1 beside the ReID stage of step t"""
+        shapes = [(1, 1), (1, 2), (1, 4), (4, 1)] if is3 else [(1, 1), (1, 4)]
+        if overlap:
+            shapes = [(1, 1), (1, 2), (4, 1)]
+        latency = []
+        for S_, F_ in shapes:
+            if S_ * F_ > B:
+                continue
+            p1 = make_pipe(F_, S_, dt, overlap=overlap)
+            T_ = 48 if S_ * F_ > 1 else 36
+            hs = [heads_np[0][:T_]] + [build_stream_inputs(5000 + s_, n_objects, T_, ratio)[0] for s_ in range(1, S_)]
+            hsteps = np.ascontiguousarray(np.stack(hs).reshape(S_, T_ // F_, F_, -1, heads_np.shape[-1]).transpose(1, 0, 2, 3, 4)).reshape(
+                T_ // F_, S_ * F_, -1, heads_np.shape[-1])
+            d_h1 = torch.from_numpy(hsteps).to(dev)
+            fr1 = d_pool[0][:S_ * F_]                            # one fixed frame buffer -> one hipGraph
+            n1 = T_ // F_
+            stp = lambda j: p1.step(fr1, d_h1[j % n1])                        # noqa: E731
+            leg_parity = None
+            if is3 and not ssort and wl.get("pose") is None:
+                import oracle
+                refs = {s_: oracle.StrongSORT(p1.K, p1.D, **p1.tracker_cfg) for s_ in sorted({0, S_ - 1})}
+                okl, nfr = True, 0
+                for j in range(n1):
+                    h_rows, h_cnt = stp(j)
+                    p1.synchronize()
+                    rws, _ = p1.rows_numpy(h_rows, h_cnt)
+                    emb = p1.last["emb"].cpu().numpy().reshape(S_, F_, p1.maxd, p1.K, p1.D)
+                    vis = p1.last["vis"].cpu().numpy().reshape(S_, F_, p1.maxd, p1.K)
+                    for s_, ref_ in refs.items():
+                        for f in range(F_):
+                            ltwh32 = detector_rows(oracle, hs[s_][j * F_ + f], ratio)
+                            n = len(ltwh32)
+                            ids = (j * S_ * F_ + s_ * F_ + f) * p1.maxd + np.arange(n)
+                            exp = ref_.update(ids, ltwh32.astype(np.float64), emb[s_, f, :n], vis[s_, f, :n], np.ones(n)) if n else []
+                            got = rws[s_][f]
+                            okl &= len(got) == len(exp) and (len(exp) == 0 or (np.array_equal(got["det_id"], exp["det_id"]) and
+                                                                               np.array_equal(got["track_id"], exp["track_id"])))
+                            nfr += 1
+                leg_parity = {"frames": nfr, "streams_checked": sorted(refs), "track_ids_equal_oracle": bool(okl)}
+                p1.reset()
+            for j in range(8):
+                stp(j)
+            p1.synchronize(); torch.cuda.synchronize()
+            nrun = max(n1, 40)
+            t0 = time.perf_counter()
+            for j in range(nrun):
+                stp(j)
+            p1.synchronize(); torch.cuda.synchronize()
+            el1 = time.perf_counter() - t0
+            lat = []
+            for j in range(15):                                  # true in-to-out latency: one step, wait for its rows
+                t1 = time.perf_counter(); stp(j); p1.synchronize(); lat.append(time.perf_counter() - t1)
+            latency.append({"n_streams": S_, "frames_per_step": F_, "fps": nrun * S_ * F_ / el1, "ms_per_step_pipelined": el1 / nrun * 1e3,
+                            "ms_frame_in_to_rows_out": float(np.median(lat) * 1e3), "parity": leg_parity, "overlap_stages": bool(getattr(p1, "overlap", False)), "overlap_note": getattr(p1, "overlap_note", None),
+                            "overlap_trial": getattr(p1, "overlap_trial", None)})
+            p1.close()
+            del p1, d_h1
+        if with_main:
+            lat_main = []
+            for j in range(4):
+                pipe.synchronize(); t1 = time.perf_counter(); run_step(j); pipe.synchronize(); lat_main.append(time.perf_counter() - t1)
+            latency.append({"n_streams": S, "frames_per_step": F, "fps": fps_res, "ms_per_step_pipelined": el_res / args.steps * 1e3,
+                            "ms_frame_in_to_rows_out": float(np.median(lat_main) * 1e3), "parity": "see `parity`"})
+            pipe.reset()
+        return latency
+
+    latency = latency_f16 = latency_f16_overlap = None
+    if rank == 0 and world == 1 and not args.no_latency_leg and F > 1:
+        pipe.reset()
+        latency = small_step_legs(tdtype, True)               # the pipeline's DEFAULT mode (r06: the online shapes measure their stream arrangement on the first step)
+        if args.dtype == "f32":           # the online target (>= 240 frames/s at small steps) is out of any fp32 path's reach on this chip (one frame = 1.36 TFLOP of
+            latency_f16 = small_step_legs(torch.float16, False, overlap=False)      # convolutions = 8.6 ms at the fp32 MFMA peak): the f16 legs are reported beside (serial, forced)
+        if is3 and not ssort and wl.get("pose") is None and not wl.get("camera_motion"):
+            try:              # r06: the AUTO mode at every small shape -- the first step measures both modes on its own inputs and keeps the faster (`overlap_trial`);
+                              # reported beside the forced-serial legs: an exception here must not cost the run its line
+                latency_f16_overlap = small_step_legs(torch.float16, False, overlap="auto")
+            except Exception as ex:                             # noqa: BLE001
+                latency_f16_overlap = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+
     # ---- other-precision legs.  The default fp32 run (the reference's precision: ONNXRuntime / torchreid fp32, strong_sort.yaml:10 fp16: false)
     # also times (a) the f16 backbones (tolerance: tests/test_gpu_precision.py) and (b) the SPLIT-PRECISION ReID network: fp32 weights and
     # activations carried as (hi, lo) f16 pairs, three f16 MFMAs per product pair, fp32 accumulation -- fp32-class results (the same fp64
@@ -1127,6 +1120,25 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # rank 0 at N = 1 only (the other ranks would wait in the barrier for it)
         cpu = cpu_baseline(args, wl, pipe, detector, is3, ssort, byte, gfeat_oracle, gfeat_name, heads_np, gts, ratio, n_frames)
 
+    if defer_group:
+        # the no-torchrun N = 1 line: every leg above ran WITHOUT a communicator in the process (the legs' one-rank barriers are no-ops) -- an RCCL
+        # communicator shifts HIP's stream -> hardware-queue assignment and with it the overlap of the pipelines' side streams (association, H2D
+        # copies, overlapped stages): config 2 ran 1857 instead of 2599 frames/s with the group alive, the one-frame overlap 224 instead of 337.
+        # Here the group is created and the line's reductions are done AGAIN through it, so that barrier / all-reduce (max, sum) / all-gather have
+        # run on RCCL in a driver run: the same numbers at one rank, by construction.
+        init_deferred_group()
+        if dist is not None:
+            from tracklab_amd import hota as _h
+            el_res = tdist.allreduce_max(el_res_local, dist, dev)
+            fps_res = args.steps * B * world / el_res
+            if el_h2d_local is not None:
+                el_h2d = tdist.allreduce_max(el_h2d_local, dist, dev)
+                fps_h2d = args.steps * B * world / el_h2d
+            if hota_vec_local is not None and hota_all is not None:
+                fin_ = _h.finalize(tdist.allreduce_sum(hota_vec_local, dist, dev))
+                hota_all["HOTA_through_rccl"] = fin_["summary"]["HOTA"]
+                hota_all["equal_to_local"] = bool(abs(fin_["summary"]["HOTA"] - hota_all["HOTA"]) < 1e-12)
+            per_rank, seen, placement = gather_ranks(dist, dev, fps_local)
     if rank == 0:
         value = fps_h2d if fps_h2d is not None else fps_res
         el = el_h2d if fps_h2d is not None else el_res

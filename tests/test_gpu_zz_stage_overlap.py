@@ -104,3 +104,23 @@ def test_auto_mode_is_for_the_online_16_bit_shapes_only():
     assert p1._ov_mode == "trial" and p8._ov_mode == "off" and p32._ov_mode == "trial"        # (fp32 one-frame: the trial measures the overlap slower and drops it)
     assert not p8.overlap and p8.overlap_note == "off"
     p1.close(); p8.close(); p32.close()
+
+
+def test_side_streams_are_picked_by_measured_concurrency():
+    """r06: torch deals side streams from a pool and HIP deals each of them to one of a few hardware queues; a pipeline's association / copy / stage
+    stream that lands on the compute stream's queue serialises behind it.  gpu_pipeline.pick_stream draws until the chain probe says the new
+    stream runs beside the ones it must not collide with.  Negative control: a stream is never concurrent with itself."""
+    import torch
+    from tracklab_amd import gpu_pipeline as gp
+    dev = torch.device("cuda", 0)
+    cur = torch.cuda.current_stream(dev)
+    s0 = torch.cuda.Stream(device=dev)
+    assert not gp.streams_run_concurrently(s0, s0)
+    keep = [torch.cuda.Stream(device=dev) for _ in range(3)]            # shift the pool position
+    a = gp.pick_stream(dev, [cur])
+    b = gp.pick_stream(dev, [cur, a])
+    assert gp.streams_run_concurrently(a, cur) and gp.streams_run_concurrently(b, a) and gp.streams_run_concurrently(b, cur), gp._PICK_LOG[-4:]
+    pipe = gp.DetReidTrackPipeline("s", n_streams=1, frames_per_step=8, max_dets=16, dim=64, use_graph=False)
+    assert gp.streams_run_concurrently(pipe.trk_stream, cur)
+    pipe.close()
+    del keep

@@ -1,4 +1,4 @@
-"""GPU box: random shapes through the convolution entry points of r05, against the oracle (fp32: bit for bit) / fp32 arithmetic on the
+"""GPU box: random shapes through the convolution entry points of r05 / r06, against the oracle (fp32: bit for bit) / fp32 arithmetic on the
 f16-rounded operands (16-bit kernels: one f16 ulp of slack).  Covers what the parametrized tests fix by hand: every tile configuration that
 accepts the shape, channel slices (pixel strides), residual before / after the activation, the dynamic batch, ragged everything.
 usage: python tools/fuzz_gpu_conv.py [seconds] [seed]"""
@@ -18,7 +18,7 @@ rng = np.random.default_rng(seed)
 L = _lib.lib()
 _lib.conv2d_nhwc_f32(torch.zeros(0, 4, 2, 2, device="cuda").contiguous(memory_format=torch.channels_last),
                      torch.zeros(4, 4, 1, 1, device="cuda").contiguous(memory_format=torch.channels_last))
-stats = {"f32": 0, "f32_declined": 0, "f16": 0, "stem16": 0, "patch": 0}
+stats = {"f32": 0, "f32_declined": 0, "f16": 0, "stem16": 0, "patch": 0, "patch64": 0, "split": 0}
 t0 = time.time()
 
 
@@ -32,10 +32,14 @@ def fail(msg):
 
 
 while time.time() - t0 < budget:
-    kind = rng.choice(["f32", "f32", "patch", "f16", "stem16"])
+    kind = rng.choice(["f32", "f32", "patch", "patch64", "f16", "f16", "stem16", "split"])
     act = [None, "relu", "silu"][rng.integers(3)]
-    if kind in ("f32", "patch"):
-        if kind == "patch":                        # shapes the patch-resident kernel takes: 3 x 3 / 1 on 32 channels, whole rows per tile
+    if kind in ("f32", "patch", "patch64"):
+        if kind == "patch64":                      # r06: the patch-resident kernel on 64 channels (two K steps per pixel), whole rows per 128-pixel tile
+            wo = int(rng.choice([8, 16, 32, 64])); h = int(rng.choice([128 // wo, 256 // wo, 384 // wo])); n = int(rng.integers(1, 4))
+            cin, cout, k, s = 64, int(rng.choice([64, 72, 128])), 3, 1
+            w = wo
+        elif kind == "patch":                        # shapes the patch-resident kernel takes: 3 x 3 / 1 on 32 channels, whole rows per tile
             wo = int(rng.choice([8, 16, 32, 64])); h = int(rng.choice([256 // wo, 512 // wo, 768 // wo])); n = int(rng.integers(1, 4))
             cin, cout, k, s = 32, int(rng.choice([32, 36, 64, 96])), 3, 1
             w = wo
@@ -52,7 +56,9 @@ while time.time() - t0 < budget:
         if res:
             exp = oracle.conv2d_nhwc_f32(x, wt, b, r, stride=s, act=act, res_after_act=after)
         xt, wtt, rt = nhwc(x), nhwc(wt), (nhwc(r) if res else None)
-        cfgs = [-1] + list(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33], size=4, replace=False))
+        cfgs = [-1] + list(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37], size=4, replace=False))
+        if kind == "patch64":
+            cfgs = [-1, 0] + list(rng.choice([34, 35, 36, 37], size=3, replace=False))
         # a channel slice as the output (pixel stride > Cout) and a dynamic batch, sometimes
         slack = int(rng.choice([0, 0, 4, 16]))
         live = int(rng.integers(1, n + 1)) if rng.integers(3) == 0 else n
@@ -82,7 +88,7 @@ while time.time() - t0 < budget:
             stats[kind] += 1
     elif kind == "f16":
         n, h, w = int(rng.integers(1, 4)), int(rng.integers(3, 24)), int(rng.integers(3, 24))
-        cin = int(rng.choice([8, 48, 64, 96, 128, 192])); cout = int(rng.choice([8, 24, 64, 72, 128, 256, 264]))
+        cin = int(rng.choice([8, 32, 48, 64, 96, 128, 160, 192])); cout = int(rng.choice([8, 24, 64, 72, 128, 256, 264]))
         k = int(rng.choice([1, 3])); s = int(rng.choice([1, 2])); res = bool(rng.integers(2))
         x = torch.from_numpy(rng.standard_normal((n, h, w, cin)).astype(np.float32)).half().cuda().permute(0, 3, 1, 2)
         wt = torch.from_numpy((rng.standard_normal((cout, k, k, cin)) * 0.1).astype(np.float32)).half().cuda().permute(0, 3, 1, 2)
@@ -92,7 +98,7 @@ while time.time() - t0 < budget:
         if res:
             ref = ref + r.float()
         ref = torch.relu(ref) if act == "relu" else (F.silu(ref) if act == "silu" else ref)
-        for cfg in [-1] + list(rng.choice(np.arange(1, 17), size=3, replace=False)):
+        for cfg in [-1, 0] + list(rng.choice(np.arange(1, 23), size=4, replace=False)):      # (r06: 19..22 = the half-step tiles; a configuration that does not take the shape declines)
             if L.tlk_conv16_set_config(int(cfg)) != 0:
                 continue
             try:
@@ -106,6 +112,51 @@ while time.time() - t0 < budget:
             if not bool((err <= 3e-3 * ref.abs() + 3e-3 * (x.float().abs().max() * wt.float().abs().max() * (cin * k * k) ** 0.5)).all()):
                 fail(f"f16 cfg {cfg} case {(n, h, w, cin, cout, k, s, act, res)} max err {float(err.max())}")
             stats["f16"] += 1
+    elif kind == "split":
+        # r06: split mode with SCALED planes -- random magnitudes up to ~1e6 on the input, calibrated scales, against torch's fp64 convolution at the
+        # exact-fp32 kernel's bound; every split tile configuration that takes the shape
+        n, h, w = int(rng.integers(1, 4)), int(rng.integers(3, 20)), int(rng.integers(3, 20))
+        cin = int(rng.choice([32, 64, 96, 128])); cout = int(rng.choice([64, 72, 128, 256])); k = int(rng.choice([1, 3])); s = int(rng.choice([1, 2]))
+        res = bool(rng.integers(2)); mag = float(10.0 ** rng.uniform(0, 6))
+        x = (torch.from_numpy(rng.standard_normal((n, h, w, cin)).astype(np.float32)) * mag).cuda().permute(0, 3, 1, 2)
+        wt = torch.from_numpy((rng.standard_normal((cout, k, k, cin)) * 0.1).astype(np.float32)).cuda().permute(0, 3, 1, 2)
+        b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * mag).cuda()
+        ref = F.conv2d(x.double(), wt.double(), b.double(), stride=s, padding=k // 2)
+        bound = F.conv2d(x.double().abs(), wt.double().abs(), b.double().abs(), stride=s, padding=k // 2)
+        r = (torch.from_numpy(rng.standard_normal(tuple(ref.permute(0, 2, 3, 1).shape)).astype(np.float32)) * mag).cuda().permute(0, 3, 1, 2) if res else None
+        if res:
+            ref, bound = ref + r.double(), bound + r.double().abs()
+        ref = torch.relu(ref) if act == "relu" else ref
+        states = torch.zeros((3, 2), device="cuda"); states[:, 0] = 1.0
+        changed = torch.zeros(1, dtype=torch.int32, device="cuda")
+        wh, wl = _lib.split_planes(wt)
+        for cfg in [-1, 0] + list(rng.choice(np.arange(1, 8), size=3, replace=False)):
+            if L.tlk_conv16_set_config(int(cfg)) != 0:
+                continue
+            try:
+                y = None
+                for _ in range(4):                     # calibration: run, update, until no scale grew
+                    changed.zero_()
+                    xh, xl = _lib.split_planes(x, state=states[0])
+                    rh, rl = _lib.split_planes(r, state=states[1]) if res else (None, None)
+                    try:
+                        yy = _lib.conv2d_nhwc_16(xh, wh, b, "relu" if act == "relu" else None, rh, s, k // 2, x_lo=xl, weight_lo=wl, residual_lo=rl,
+                                                 in_scale=states[0], res_scale=states[1] if res else None, out_state=states[2])
+                    except _lib.TlkError:
+                        yy = None
+                        break
+                    y = _lib.merge_planes(yy[0], yy[1], scale=states[2])
+                    _lib.split_scale_update(states, changed)
+                    if int(changed.item()) == 0:
+                        break
+            finally:
+                L.tlk_conv16_set_config(-1)
+            if y is None:
+                continue
+            err = (y.double() - ref).abs()
+            if not bool(torch.isfinite(y).all()) or not bool((err <= 2e-6 * bound + 1e-30).all()):
+                fail(f"split cfg {cfg} case {(n, h, w, cin, cout, k, s, act, res, mag)} max err / bound {float((err / bound).max())} scales {states[:, 0].tolist()}")
+            stats["split"] += 1
     else:
         n, h, w = int(rng.integers(1, 4)), int(rng.integers(8, 90)), int(rng.integers(8, 150))
         k = int(rng.choice([7, 3])); cout = int(rng.choice([8, 32, 48, 64])); xp = int(rng.choice([3, 3, 4, 8]))

@@ -49,4 +49,4 @@ for extra in [int(a) for a in (args or ["0", "1", "2", "3", "5"])]:
             torch.zeros(1, device="cuda")
     rs, _ = rate(False)
     ro, note = rate(True)
-    print(f"extra streams +{extra} (alive {len(keep)}): serial {rs:.1f}  overlap-asked {ro:.1f}  ratio {ro / rs:.2f}  picker: {note}", flush=True)
+    print(f"extra streams +{extra} (alive {len(keep)}): serial {rs:.1f}  overlap-asked {ro:.1f}  ratio {ro / rs:.2f}  picker: {note}  stream picks (draws, ok): {gp._PICK_LOG[-8:]}", flush=True)

@@ -32,6 +32,8 @@ if len(sys.argv) > 4 and (d.get("roofline") or {}).get("per_instantiation"):
             "| instantiation | launches / step | bench: avg ms (events) | bench: TFLOP/s | rocprofv3: calls | rocprofv3: avg ms | events / rocprofv3 |", "|---|---|---|---|---|---|---|"]
     for e in d["roofline"]["per_instantiation"]:
         key = e["kernel"].split(" (")[0]                    # "conv_stem3_kernel (direct RGB stem, ...)" -> the kernel's name
+        if key.endswith(">"):
+            key = key[:-1]                                      # prefix match: rocprofv3 prints the defaulted trailing template arguments too (r06: ROWB, CPP)
         match = [r for r in rows if key in r["Name"]]
         if match:
             r = match[0]

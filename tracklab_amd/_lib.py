@@ -1044,11 +1044,11 @@ def conv2d_nhwc_f32(x, weight, bias=None, act=None, residual=None, stride=1, pad
 
 # tlk_conv2d_nhwc_f32 configurations 21..: the direct-to-LDS kernels of csrc/tlk_conv16x.hip on fp32 tensors, as rocprofv3 names them --
 # conv16x_kernel<WGM, WGN, TM, TN, MODE_F32 = 2, NST, RESPF, PATCH> (activation and residual are run-time switches there)
-CONV_F32_X_TEMPLATES = {21: "2, 2, 2, 2, 2, 1, true, false", 22: "2, 2, 2, 2, 2, 1, false, false", 23: "4, 1, 2, 2, 2, 1, false, false",
-                        24: "2, 2, 2, 2, 2, 2, true, false", 25: "2, 2, 1, 2, 2, 1, true, false", 26: "4, 1, 2, 2, 2, 1, true, false",
-                        27: "4, 1, 2, 1, 2, 1, true, false", 28: "4, 1, 2, 1, 2, 2, true, false", 29: "4, 1, 4, 1, 2, 1, true, false",
-                        30: "4, 1, 2, 1, 2, 1, true, true", 31: "4, 1, 2, 1, 2, 1, false, true", 32: "4, 1, 1, 1, 2, 1, true, true",
-                        33: "2, 1, 2, 1, 2, 1, true, true", 34: "4, 1, 1, 2, 2, 1, true, true, 128, 2", 35: "4, 1, 2, 2, 2, 1, true, true, 128, 2",
+CONV_F32_X_TEMPLATES = {21: "2, 2, 2, 2, 2, 1, true, false, 128, 1", 22: "2, 2, 2, 2, 2, 1, false, false, 128, 1", 23: "4, 1, 2, 2, 2, 1, false, false, 128, 1",
+                        24: "2, 2, 2, 2, 2, 2, true, false, 128, 1", 25: "2, 2, 1, 2, 2, 1, true, false, 128, 1", 26: "4, 1, 2, 2, 2, 1, true, false, 128, 1",
+                        27: "4, 1, 2, 1, 2, 1, true, false, 128, 1", 28: "4, 1, 2, 1, 2, 2, true, false, 128, 1", 29: "4, 1, 4, 1, 2, 1, true, false, 128, 1",
+                        30: "4, 1, 2, 1, 2, 1, true, true, 128, 1", 31: "4, 1, 2, 1, 2, 1, false, true, 128, 1", 32: "4, 1, 1, 1, 2, 1, true, true, 128, 1",
+                        33: "2, 1, 2, 1, 2, 1, true, true, 128, 1", 34: "4, 1, 1, 2, 2, 1, true, true, 128, 2", 35: "4, 1, 2, 2, 2, 1, true, true, 128, 2",
                         36: "2, 1, 2, 2, 2, 1, true, true, 128, 2", 37: "4, 1, 1, 2, 2, 1, false, true, 128, 2"}
 
 

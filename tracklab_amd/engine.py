@@ -141,7 +141,11 @@ class HipVideoEngine:
         self._dev = [torch.empty((self.F, H, W, 3), dtype=torch.uint8, device=pipeline.dev) for _ in range(2)]
         self._h2d_done = [torch.cuda.Event(), torch.cuda.Event()]
         self._frames_free = [None, None]
-        self._copy_stream = torch.cuda.Stream(device=pipeline.dev)
+        # r06: a copy stream MEASURED to run beside the compute stream and the pipeline's own side streams (gpu_pipeline.pick_stream: about one
+        # pool stream in four shares the compute stream's hardware queue, and an upload behind it does not overlap anything)
+        from .gpu_pipeline import pick_stream
+        others = [torch.cuda.current_stream(pipeline.dev)] + [getattr(pipeline, n_, None) for n_ in ("trk_stream", "det_stream", "reid_stream")]
+        self._copy_stream = pick_stream(pipeline.dev, others)
         self.h2d_bytes = 0
 
     # ---- frame batching -------------------------------------------------------------------------------------------------

@@ -26,6 +26,90 @@ from . import _lib
 from .backbones.yolox import yolox
 
 
+def streams_run_concurrently(sa, sb, cycles: int = 40_000, chain: int = 16) -> bool:
+    """Do two streams execute side by side?  torch hands out its side streams from a pool (32 per priority, round robin) and HIP deals each of
+    them -- at its creation -- to one of a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default); two streams on ONE queue run strictly one after
+    the other whatever the events between them say.  Which pool stream a `torch.cuda.Stream()` call returns depends on how many were drawn
+    before it in the process, so a pipeline's association / copy / stage stream lands on the compute stream's queue about one time in four:
+    measured r06 as a config-2 step of 17.2 instead of 12.3 ms, an f16 step of 54.7 instead of 50.3 ms, an H2D-inclusive leg 3 % behind the
+    resident one, the overlapped online pipeline at 0.5 x the serial one (profiles/r06_overlap_autotune.md).  Measured here with the launch
+    pattern of real work: a CHAIN of dependent spin kernels on each stream, submitted interleaved, timestamps on one clock."""
+    dev = sa.device
+    if sa is sb or sa.cuda_stream == sb.cuda_stream:
+        return False
+
+    def run(streams, n):
+        """`n` spin kernels per stream, submitted interleaved; wall time from the first start to the last end (events on one clock)"""
+        e0, e1 = torch.cuda.Event(enable_timing=True), [torch.cuda.Event(enable_timing=True) for _ in streams]
+        torch.cuda.synchronize(dev)
+        cur = torch.cuda.current_stream(dev)
+        e0.record(cur)
+        for s_ in streams:
+            s_.wait_event(e0)
+        for k in range(n):
+            for i, s_ in enumerate(streams):
+                with torch.cuda.stream(s_):
+                    torch.cuda._sleep(cycles)
+                    if k == n - 1:
+                        e1[i].record(s_)
+        for s_ in streams:
+            s_.synchronize()
+        return max(e0.elapsed_time(e) for e in e1)
+    run([sa, sb], 2)                          # warm (module load of the spin kernel)
+    t_one = min(run([sa], chain), run([sb], chain))
+    t_both = run([sa, sb], chain)
+    # side by side: both chains take about as long as one; one queue (or time-sliced queues): about twice as long
+    return t_both < 1.45 * t_one
+
+
+def streams_all_concurrent(streams, cycles: int = 40_000, chain: int = 16) -> bool:
+    """the same measurement for a SET of streams at once: every chain running beside all the others (pairwise concurrency does not imply it)"""
+    streams = [s_ for s_ in streams if s_ is not None]
+    if len(streams) < 2:
+        return True
+    if len({s_.cuda_stream for s_ in streams}) < len(streams):
+        return False
+    dev = streams[0].device
+
+    def run(ss, n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), [torch.cuda.Event(enable_timing=True) for _ in ss]
+        torch.cuda.synchronize(dev)
+        e0.record(torch.cuda.current_stream(dev))
+        for s_ in ss:
+            s_.wait_event(e0)
+        for k in range(n):
+            for i, s_ in enumerate(ss):
+                with torch.cuda.stream(s_):
+                    torch.cuda._sleep(cycles)
+                    if k == n - 1:
+                        e1[i].record(s_)
+        for s_ in ss:
+            s_.synchronize()
+        return max(e0.elapsed_time(e) for e in e1)
+    run(streams, 2)
+    t_one = min(run([s_], chain) for s_ in streams[:2])
+    return run(streams, chain) < 1.45 * t_one
+
+
+_PICK_LOG = []
+
+
+def pick_stream(dev, others, priority: int = 0, tries: int = 6):
+    """A side stream that was MEASURED to run concurrently with every stream in `others` (see streams_run_concurrently): draws from torch's pool
+    until one does (each draw is the next pool stream, i.e. usually the next hardware queue); after `tries` failures the first draw is returned
+    and the caller's work simply serialises.  TLK_PICK_STREAMS=0: the first draw, unmeasured (r01-r05)."""
+    first = None
+    measured = __import__("os").environ.get("TLK_PICK_STREAMS", "1") != "0"
+    for k in range(tries):
+        s_ = torch.cuda.Stream(device=dev, priority=priority)
+        first = first or s_
+        if not measured or streams_all_concurrent([s_] + [o for o in others if o is not None]):
+            _PICK_LOG.append((k, True))
+            return s_
+    _PICK_LOG.append((tries, False))
+    return first
+
+
 def _record_null_pair(self):
     """Two timing events with nothing between them on the current stream: the cost of an event pair itself (a few us on this stack -- not negligible
     beside a 30 us kernel). bench.py subtracts its mean from the mean of the kernel's own event pairs and prints both."""
@@ -94,7 +178,8 @@ class DetTrackPipeline:
                 "h_ltwh": torch.zeros((B, max_dets, 4), dtype=torch.float32).pin_memory(),
                 "h_dcnt": torch.zeros((B,), dtype=torch.int32).pin_memory(),
                 "det_ready": torch.cuda.Event(), "trk_done": torch.cuda.Event()})
-        self.trk_stream = torch.cuda.Stream(device=dev, priority=int(__import__("os").environ.get("TLK_TRK_PRIO", "0")))   # association overlaps the next step (high priority measured slower: 227 vs 262 frames/s)
+        # association overlaps the next step (high priority measured slower: 227 vs 262 frames/s); r06: a stream MEASURED to run beside the compute stream
+        self.trk_stream = pick_stream(dev, [torch.cuda.current_stream(dev)], priority=int(__import__("os").environ.get("TLK_TRK_PRIO", "0")))
         self.use_graph = use_graph
         self.graphs = {}        # frames.data_ptr() -> (hipGraph of letterbox + forward, static head output)
         self.step_idx = 0
@@ -403,8 +488,10 @@ class DetReidTrackPipeline:
             # the two stages only overlap when their streams sit on DIFFERENT hardware queues; HIP deals streams of one priority to a small
             # pool of queues round-robin, so two normal-priority streams may share one (measured: 219 frames/s then, 330 when they do not).
             # Streams of different priorities never share a queue: the detector stage gets the high-priority one (TLK_DET_PRIO overrides).
-            self.det_stream = torch.cuda.Stream(device=dev, priority=int(__import__("os").environ.get("TLK_DET_PRIO", "-1")))
-            self.reid_stream = torch.cuda.Stream(device=dev)
+            # r06: each measured to run beside the compute stream and beside each other (pick_stream); the association stream below beside all three
+            cur_ = torch.cuda.current_stream(dev)
+            self.det_stream = pick_stream(dev, [cur_], priority=int(__import__("os").environ.get("TLK_DET_PRIO", "-1")))
+            self.reid_stream = pick_stream(dev, [cur_, self.det_stream])
         # f16 and split-precision backbones carry activations as float16 (pairs): |x| > 65504 saturates to infinity.  The envelope is stated in
         # DESIGN.md (tests/test_gpu_precision.py measures it); past it the run must fail LOUDLY, not track on infinities: every step ORs
         # "an embedding is not finite" into a device flag that travels to pinned memory with the results and is checked in synchronize()
@@ -435,7 +522,8 @@ class DetReidTrackPipeline:
                 b_["warps"] = torch.zeros((n_streams, frames_per_step, 6), dtype=torch.float64, device=dev)
                 b_["cmc_done"] = torch.cuda.Event()
                 b_["gate"] = torch.zeros((B,), dtype=torch.int32, device=dev)
-        self.trk_stream = torch.cuda.Stream(device=dev, priority=int(__import__("os").environ.get("TLK_TRK_PRIO", "0")))
+        self.trk_stream = pick_stream(dev, [torch.cuda.current_stream(dev), getattr(self, "det_stream", None), getattr(self, "reid_stream", None)],
+                                      priority=int(__import__("os").environ.get("TLK_TRK_PRIO", "0")))
         self.use_graph = use_graph
         self.det_graphs, self.reid_graph = {}, None
         self.step_idx = 0
