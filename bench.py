@@ -1290,7 +1290,9 @@ def cpu_baseline(args, wl, pipe, detector, is3, ssort, byte, gfeat_oracle, gfeat
              " + oracle C crop-resize-normalize + part-based ReID R50 fp32 (torch CPU, 100 crops/batch) + oracle C BPBReID-StrongSORT"
              if is3 else (" + oracle C ByteTrack" if byte else " + oracle C OC-SORT"))
     out = {"value": done / cpu_t, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"{done} frames of the same stream in {cpu_t:.1f} s after one warm-up frame: {chain}"}
+           "sample": f"{done} frames of the same stream in {cpu_t:.1f} s after one warm-up frame: {chain}",
+           "c_abi": "the oracle C functions timed here are also exported under libtlk's names + `_cpu` with libtlk's signatures (include/tlk_cpu.h, "
+                    "oracle/src/cpu_twins.c in oracle/_build/liborc.so; SURVEY 8(b)'s `_cpu` twins) -- test infrastructure, not part of libtlk.so"}
 
     # (b) hand-written stages only, 1 thread and all cores (threads: ctypes releases the GIL inside the oracle's C functions)
     ecache = [cache[k] for k in sorted(cache)]

@@ -728,9 +728,14 @@ int tlk_merge_planes_f32(const void *hi_dev, const void *lo_dev, long long n, fl
  * NULL, c a multiple of 16 bytes of elements, x / w / y 16-byte aligned, pixel strides in elements (0 = dense; a call may read or write a
  * channel slice of a wider tensor).  fp32 accumulation for both types; each output element is ONE fmaf chain over ky then kx ascending
  * (rows outside the image skipped, columns outside as zero terms): bit-identical to oracle/src/conv.c orc_dwconv2d_nhwc_f32 in fp32.
- * HBM-bound: every input element read once from HBM, every output written once (tlk_dwconv.hip). */
+ * Every input element read once from HBM, every output written once (tlk_dwconv.hip).  r06: the arithmetic is packed fp32 FMAs (two channels
+ * per instruction, each half an ordinary fused multiply-add: same results), f16 inputs are widened once per loaded pixel, a lane owns two
+ * columns; SiLU is v * rcp(1 + exp(-v)) with the device reciprocal (~3e-7 relative; the pointwise kernels keep the IEEE division). */
 int tlk_dwconv2d_nhwc(const void *x_dev, const void *w_dev, const float *bias_dev, void *y_dev, int n, int h, int w, int c, int k,
                       int act_kind, int dtype, int x_pix_stride, int y_pix_stride, void *hip_stream);
+/* Probes: 0 = the default lane shape (two columns per lane, input rows loaded two ahead), 1..4 = (columns per lane, rows ahead) = (1, 1),
+ * (2, 1), (1, 2), (2, 2).  Same results in every configuration. */
+int tlk_dwconv_set_config(int cfg);
 
 /* The pooling half of an SPPBottleneck (YOLOX CSPDarknet / RTMPose CSPNeXt; kernel sizes 5, 9, 13, stride 1, -inf padding; the reference runs
  * both networks in ONNXRuntime behind tracklab/wrappers/bbox_detector/rtmlib_api.py:21 and wrappers/pose_estimator/rtmlib_api.py:21):

@@ -75,6 +75,44 @@ def test_dwconv_f16_is_the_fp32_chain_on_f16_operands(case):
     assert np.array_equal(got, exp32.astype(np.float16)), f"max |diff| {np.abs(got.astype(np.float32) - exp32).max()}"
 
 
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4])
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+def test_dwconv_every_lane_shape_gives_the_same_bits(cfg, dt):
+    """r06: columns per lane (1 / 2) x rows loaded ahead (1 / 2) -- odd widths (a lane's second column outside the image), images narrower than
+    the kernel, ragged strips; fp32 against the oracle chain, f16 against the chain on the f16 operands rounded once"""
+    import oracle
+    from tracklab_amd import _lib
+    _lib.dwconv_set_config(cfg)
+    try:
+        for case in CASES:
+            if dt == "f16" and case[3] % 8:
+                continue
+            x, wt, b = _inputs(case)
+            if dt == "f16":
+                x, wt = x.astype(np.float16), wt.astype(np.float16)
+            exp = oracle.dwconv2d_nhwc_f32(x.astype(np.float32), wt.astype(np.float32), b, case[5])
+            y = _lib.dwconv2d_nhwc(torch.from_numpy(x).cuda().permute(0, 3, 1, 2), torch.from_numpy(wt).cuda(), torch.from_numpy(b).cuda(), case[5])
+            got = y.permute(0, 2, 3, 1).cpu().numpy()
+            assert np.array_equal(got, exp.astype(got.dtype)), (case, cfg, dt)
+    finally:
+        _lib.dwconv_set_config(0)
+
+
+def test_dwconv_f16_silu_is_within_one_f16_step_of_the_oracle():
+    import oracle
+    from tracklab_amd import _lib
+    for case in ((3, 64, 48, 48, 5), (2, 17, 7, 8, 3), (2, 9, 5, 24, 5)):
+        x, wt, b = _inputs(case + (None,))
+        xh, wh = x.astype(np.float16), wt.astype(np.float16)
+        exp = oracle.dwconv2d_nhwc_f32(xh.astype(np.float32), wh.astype(np.float32), b, "silu")
+        y = _lib.dwconv2d_nhwc(torch.from_numpy(xh).cuda().permute(0, 3, 1, 2), torch.from_numpy(wh).cuda(), torch.from_numpy(b).cuda(), "silu")
+        got = y.permute(0, 2, 3, 1).cpu().numpy().astype(np.float32)
+        # fp32 SiLU within ~3e-7 (device exp + reciprocal), then ONE rounding to f16: equal, or the neighbouring f16 where the fp32 value sits on a tie
+        step = np.spacing(np.abs(exp).astype(np.float16)).astype(np.float32)
+        assert (np.abs(got - exp) <= 0.5 * step + 4e-7 * np.abs(exp) + 1e-12).all()
+        assert (got == exp.astype(np.float16).astype(np.float32)).mean() > 0.999
+
+
 def test_dwconv_reads_and_writes_channel_slices():
     import oracle
     from tracklab_amd import _lib
@@ -98,6 +136,8 @@ def test_dwconv_rejects_what_it_does_not_implement():
     x6 = torch.zeros(1, 6, 4, 4, device="cuda").contiguous(memory_format=torch.channels_last)
     with pytest.raises(_lib.TlkError):
         _lib.dwconv2d_nhwc(x6, torch.zeros(3, 3, 6, device="cuda"), None, None)         # 6 fp32 channels: not a multiple of 16 bytes
+    with pytest.raises(_lib.TlkError):
+        _lib.dwconv_set_config(5)
 
 
 def _pose_outputs(dtype, x):

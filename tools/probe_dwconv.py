@@ -2,6 +2,7 @@
 algorithmic bytes (every input element once + every output element once).  python tools/probe_dwconv.py [crops] [frames]"""
 import os
 import sys
+import time
 
 import torch
 
@@ -12,8 +13,13 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 2400
 FR = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 
 
-def timed(fn, n=10):
-    fn(); fn()
+def timed(fn, n=20):
+    # warm: the first milliseconds of a process run at idle clocks (r04's table was taken with two warm-up calls only and reads ~25 % slow on its
+    # first rows for that reason; its "variants" rows further down the same file were warm)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.05:
+        fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
@@ -32,6 +38,20 @@ for dt, es in ((torch.float16, 2), (torch.float32, 4)):
         t = timed(lambda: _lib.dwconv2d_nhwc(x, wk, b, "silu", out=out))
         by = 2.0 * x.numel() * es
         print(f"  {str(dt)[6:]:8s} {c:4d} ch @ {h:2d} x {w:2d}  x{cnt}: {t * 1e6:8.1f} us  {by / 1e6:8.1f} MB -> {by / t / 1e9:7.1f} GB/s = {by / t / 8e12:.2f} of 8 TB/s")
+if os.environ.get("PROBE_DW_SHAPES"):
+    print("lane shapes (tlk_dwconv_set_config: 1..4 = (columns per lane, rows ahead) = (1, 1), (2, 1), (1, 2), (2, 2)), 5 x 5 + SiLU / ReLU, us")
+    for dt in (torch.float16, torch.float32):
+        for c, h, w in ((48, 64, 48), (192, 16, 12), (384, 8, 6)):
+            x = torch.randn(B, c, h, w, device="cuda", dtype=dt).contiguous(memory_format=torch.channels_last)
+            wk = torch.randn(5, 5, c, device="cuda", dtype=dt) * 0.2
+            b = torch.randn(c, device="cuda")
+            out = torch.empty_like(x)
+            row = []
+            for cfg in (1, 2, 3, 4):
+                _lib.dwconv_set_config(cfg)
+                row.append("%7.1f / %7.1f" % (timed(lambda: _lib.dwconv2d_nhwc(x, wk, b, "silu", out=out)) * 1e6, timed(lambda: _lib.dwconv2d_nhwc(x, wk, b, "relu", out=out)) * 1e6))
+            _lib.dwconv_set_config(0)
+            print(f"  {str(dt)[6:]:8s} {c:4d} ch @ {h:2d} x {w:2d}: " + "   ".join(row))
 if os.environ.get("PROBE_DW_VARIANTS"):
     x = torch.randn(B, 48, 64, 48, device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last)
     out = torch.empty_like(x)

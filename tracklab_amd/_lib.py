@@ -1138,6 +1138,13 @@ def _bind_heads(L):
     L._heads_bound = True
 
 
+def dwconv_set_config(cfg):
+    """probes: lane shape of tlk_dwconv2d_nhwc (0 = by element type, 1..4 = (columns per lane, rows ahead) = (1, 1), (2, 1), (1, 2), (2, 2))"""
+    L = lib()
+    L.tlk_dwconv_set_config.argtypes = [C.c_int]
+    check(L.tlk_dwconv_set_config(int(cfg)))
+
+
 def dwconv2d_nhwc(x, weight_kkc, bias32=None, act=None, out=None):
     """Depthwise k x k convolution (stride 1, pad k // 2) + bias + activation in ONE hand-written kernel (tlk_dwconv2d_nhwc).
     x: (N, C, H, W) float32 / float16 cuda tensor in channels_last memory (or a channel slice of one); weight_kkc: (k, k, C) contiguous, the

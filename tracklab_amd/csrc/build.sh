@@ -12,6 +12,9 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I"$HERE/../
 # ResNet-50 forward ran on another stream and exact ones alone (profiles/r02_pk_f32_overlap.md); without packed code it is exact in both.
 # The pre/post-processing kernels below run in stream order with the networks and keep the default code generation they were measured with.
 PACKED_OK="tlk_image tlk_pil tlk_nms tlk_epilogue tlk_pose tlk_gemm"
+# tlk_dwconv spells its packed FMAs in assembly, in the plain form only (no op_sel: the form measured safe, profiles/r03_pk_f32_root_cause.md);
+# the assembler needs the feature for them, the compiler's own vectoriser stays off, and tools/audit_pk_f32.py checks the result
+PACKED_ASM="tlk_dwconv"
 NOPK=(-fno-slp-vectorize -Xclang -target-feature -Xclang -packed-fp32-ops)
 objs=()
 pids=()
@@ -24,6 +27,7 @@ for src in "$HERE"/*.hip; do
   if [[ $stale == 1 ]]; then
     extra=("${NOPK[@]}")
     for ok in $PACKED_OK; do [[ "$(basename "${src%.hip}")" == "$ok" ]] && extra=(); done
+    for ok in $PACKED_ASM; do [[ "$(basename "${src%.hip}")" == "$ok" ]] && extra=(-fno-slp-vectorize); done
     # (the host pass of the same command does not know the AMDGPU feature and says so: filtered, everything else is shown)
     "$HIPCC" "${FLAGS[@]}" "${extra[@]}" -c "$src" -o "$obj" 2> >(grep -v "is not a recognized feature for this target" >&2) &
     pids+=($!)
