@@ -22,8 +22,8 @@
 //     pixels they read: 24 conversions + 100 packed FMAs per 8 outputs, against 200 v_fma_mix_f32 before;
 //   * input rows are loaded two rows ahead with unconditional loads from clamped addresses (conditional loads made the compiler wait for
 //     ALL outstanding loads at every row).
-// Measured (2400 crops, 5 x 5 + SiLU; profiles/r06_dwconv_spp.txt): f16 48 ch @ 64 x 48 643 -> 402 us = 3.5 TB/s (0.44 of 8 TB/s; ReLU
-// 372 us = 0.48), fp32 990 -> 607 us = 4.7 TB/s (0.58).
+// Measured (2400 crops, 5 x 5 + SiLU, three boxes; profiles/r06_dwconv_spp.txt): f16 48 ch @ 64 x 48 643 -> 388-408 us = 3.5-3.65 TB/s
+// (0.43-0.46 of 8 TB/s; ReLU 371 us = 0.48), fp32 990 -> 528-553 us = 5.1-5.4 TB/s (0.64-0.67).
 // Each output element is ONE fmaf chain over (ky ascending, kx ascending), rows outside the image skipped, columns outside the image
 // entering as zero terms, then + bias, activation (oracle/src/conv.c: orc_dwconv2d_nhwc_f32 walks the same chain; fp32 results are
 // bit-identical, f16 results are that chain on the f16 operands rounded once, SiLU within the device exp's and reciprocal's error: ~3e-7
