@@ -17,9 +17,9 @@ def timed(fn, n=20):
     # warm: the first milliseconds of a process run at idle clocks (r04's table was taken with two warm-up calls only and reads ~25 % slow on its
     # first rows for that reason; its "variants" rows further down the same file were warm)
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < 0.05:
+    while time.perf_counter() - t0 < 0.05:              # (GPU time, not host time: synchronise inside the loop)
         fn()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):

@@ -370,14 +370,31 @@ int pick_x32(const ConvArgs &a, int cout, bool has_res)
     if (a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin == 64 && a.H == a.Ho && a.W == a.Wo && a.Wo >= 8 && a.Wo <= 64 && 128 % a.Wo == 0 &&
         ((long long)a.Ho * a.Wo) % 128 == 0 && a.M >= 64 * 1024)
         return 14;
-    //  * other layers that are 32 wide: the one-stage 256 x 32 tile (1 x 1 64 > 32: 0.14 vs 0.21 ms)
-    if (cout == 32 && a.M >= 64 * 1024) return 7;
-    //  * 64 wide: the one-stage 256 x 64 tile on the 1 x 1 layers (0.92 vs 1.06 ms) and the 3 x 3 ones (1.08 vs 1.11 ms; stride 2: 0.63 vs 0.68)
-    if (cout == 64 && big && ((a.KH == 1 && !has_res && a.K <= 256) || (a.KH == 3 && a.K <= 576))) return 3;
+    // r06: the rules below were re-derived from a sweep of EVERY distinct convolution of the six networks under every configuration
+    // (tools/sweep_conv_f32.py; profiles/r06_conv_f32_sweep.txt holds the tables before and after)
+    const long long tiles128 = ((a.M + 127) / 128) * ((cout + 127) / 128);
+    //  * 32 wide: the 256 x 32 tile, one LDS stage on a short K loop (1 x 1 64 > 32: 0.14 vs 0.21 ms), two stages from K = 256 (HRNet's fuse
+    //    layers 256 > 32: 3 x 3 9.31 vs 9.97 ms, 1 x 1 0.028 vs 0.031)
+    if (cout == 32 && a.M >= 64 * 1024) return a.K >= 256 ? 8 : 7;
+    //  * 96 wide = three of those tiles exactly -- YOLOX-m's / CSPNeXt-m's 96-channel stage on the 256 x 96 register-staged tile 0.065 / 0.315 /
+    //    0.219 ms, here 0.047 / 0.257 / 0.175 (1 x 1, 3 x 3 + residual, 1 x 1 at 160 x 160)
+    if (cout == 96 && a.M >= 64 * 1024) return 7;
+    //  * 64 wide: the one-stage 256 x 64 tile on the 1 x 1 layers of the largest maps (ResNet's layer 1, 6.8 M pixels: 0.92 vs 1.06 ms; at 0.4-0.6 M
+    //    pixels the register-staged 128 x 64 tile is 5-9 % ahead) and the 3 x 3 ones (1.08 vs 1.11 ms; stride 2: 0.63 vs 0.68)
+    if (cout == 64 && ((a.KH == 1 && !has_res && a.K <= 256 && a.M >= 1024 * 1024) || (a.KH == 3 && a.K <= 576 && big))) return 3;
     //  * the short-K 1 x 1 expansions (K <= 128): the one-stage 64 x 128 tile with the residual prefetched (4.05 vs 4.5 ms, 2.87 vs 3.13 ms)
     if (a.KH == 1 && a.KW == 1 && a.stride == 1 && has_res && a.K <= 128 && cout % 128 == 0 && big) return 5;
-    //  * 3 x 3 basic blocks on 128 / 256 channels with a residual: 128 x 128, two stages, residual prefetched (0.95 vs 0.98 ms, 0.99 vs 1.02 ms)
-    if (a.KH == 3 && a.stride == 1 && has_res && cout % 128 == 0 && a.K >= 1152 && ((a.M + 127) / 128) * (cout / 128) >= 1024) return 4;
+    //  * 3 x 3 on 128-multiple widths, K >= 1152 (with or without residual, any stride), enough tiles to fill the chip four times: the
+    //    two-stage 128 x 128 direct-to-LDS tile -- ResNet's layer-3 / layer-4 3 x 3 3.65 vs 3.77 ms and 14.35 vs 14.90 (139.7 TFLOP/s = 0.89 of
+    //    the peak), HRNet's 256-channel blocks 0.99 vs 1.03, CSPNeXt's 4.19 vs 4.35; basic blocks with residual as in r05 (0.95 vs 0.98 ms)
+    if (a.KH == 3 && cout % 128 == 0 && a.K >= 1152 && tiles128 >= 1024) return 4;
+    //  * the same layers on FEW tiles (the detectors' deep stages, the ReID net on one frame's crops): widths of 3 x 128 / 6 x 128 stay on that
+    //    tile (0.437 vs 0.488 ms, 0.427 vs 0.481); powers of two are 20-60 % faster on 64 x 128 tiles while the launch is small (256 > 256 on 19 K
+    //    pixels 0.235 vs 0.284, 128 > 128 on 13 K 0.051 vs 0.085)
+    if (a.KH == 3 && cout % 128 == 0 && a.K >= 1152 && a.M >= 8 * 1024) {
+        if ((cout / 128) % 3 == 0) return 4;
+        if (a.M <= 24 * 1024) return 5;
+    }
     // every other layer is as fast or faster on conv_f32_mfma_kernel
     return 0;
 }
@@ -476,6 +493,12 @@ extern "C" int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const
         else if (c % 96 == 0 && (c / 96) % 2 == 1 && a.M >= 64 * 1024) cfg = 3;
         else cfg = 2;
         if (cfg == 0 && ((a.M + 127) / 128) * (cout / 128) < 1024) cfg = 5;
+        // r06 (same sweep): the 128 x 64 tile with ONE LDS stage (28 KB: three workgroups per CU) wherever the K loop is short or the launch is
+        // large -- YOLOX-m's 48- / 192-wide layers 0.093 > 0.074 ms (1 x 1, K 48), 0.546 > 0.435 (the Focus stem), 0.136 > 0.121, 0.924 > 0.886
+        if (cfg == 2 && ((a.K <= 192 && a.M >= 16 * 1024) || (a.M >= 128 * 1024 && a.K <= 1728))) cfg = 8;
+        // r06: a 1 x 1 layer with K <= 64 that widens to a multiple of 128 (ResNet's / HRNet's 64 > 256 projection): 128 x 128 with ONE stage,
+        // 2.79 vs 3.13 ms
+        if (cfg == 0 && kh == 1 && kw == 1 && a.K <= 64 && residual_dev == nullptr && a.M >= 256 * 1024) cfg = 7;
     }
     g_last_cfg = cfg;
     switch (cfg) {
