@@ -711,6 +711,10 @@ int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream
             else if (a.res && a.Cout % 128 == 0 && ((a.M + 127) / 128) * (a.Cout / 128) >= 512) cfg = a.K <= 128 ? 6 : 7;
             // ... and the 3 x 3 layers on 64 channels (ResNet's layer 1): 256 x 64 tiles of four 64 x 64 wavefronts, 2.57 vs 2.80 ms (profiles/r06_split_l1_probe.txt)
             else if (!a.res && a.KH == 3 && a.Cout == 64 && (a.M + 255) / 256 >= 768) cfg = 4;
+            // r06 (tools/sweep_conv16.py, profiles/r06_conv16_sweep.txt): the detector's layers in split mode -- a few hundred tiles, widths of 96 ... 768 --
+            // all sat on the r04 kernel; the eight-wavefront 128 x 128 tile with two stages is 8-40 % faster on every one of them (YOLOX-m, 24 frames:
+            // 10.2 -> 9.0 ms per forward) and within 5-12 % of the best configuration of each
+            else if (a.Cout >= 96 && a.M <= 256 * 1024) cfg = 7;
             else return 1;
         }
     }
