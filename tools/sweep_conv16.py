@@ -40,16 +40,22 @@ with torch.no_grad():
         net = yolox(what.split("-")[1], device=dev, dtype=torch.float32 if split else torch.float16)
         x = torch.rand(batch, 3, 640, 640, device=dev).contiguous(memory_format=torch.channels_last)
         net(x, split=True) if split else net(x.half())
+    elif what.startswith("rtmpose"):
+        from tracklab_amd.backbones.rtmpose import rtmpose
+        net = rtmpose(what.split("-")[1], device=dev, dtype=torch.float16)
+        x = torch.rand(batch, 3, 256, 192, device=dev).contiguous(memory_format=torch.channels_last)
+        net(x.half())
     else:
         from tracklab_amd.backbones.reid import part_based_reid
-        net = part_based_reid(6, 512, device=dev, dtype=torch.float32 if split else torch.float16, split_precision=split)
+        net = part_based_reid(6, 512, device=dev, dtype=torch.float32 if split else torch.float16, split_precision=split,
+                              arch="hrnet32" if "hrnet" in what else "resnet50")
         x = torch.rand(batch, 3, 384, 128, device=dev).contiguous(memory_format=torch.channels_last)
         net(x if split else x.half())
         net(x if split else x.half())
 torch.cuda.synchronize()
 _lib.conv2d_nhwc_16 = real
 shapes = {}
-for c in calls[len(calls) // 2:] if not what.startswith("yolox") else calls:
+for c in calls[len(calls) // 2:] if what.startswith("reid") else calls:
     shapes.setdefault(c, [0])[0] += 1
 print(f"{mode} {what} x {batch}: {sum(v[0] for v in shapes.values())} convolutions per forward, {len(shapes)} distinct shapes", flush=True)
 

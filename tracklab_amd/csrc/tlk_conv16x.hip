@@ -681,7 +681,11 @@ int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream
         const long long tiles256 = ((a.M + 255) / 256) * ((a.Cout + 255) / 256);
         if (!split && half_step) {
             const long long t128h = ((a.M + 127) / 128) * ((a.Cout + 127) / 128);
-            if (t128h >= 384) cfg = 20;
+            // r06 (tools/sweep_conv16.py, profiles/r06_conv16_sweep.txt): narrow outputs on the 64 x 64 tile whatever the launch size -- a 128-wide tile
+            // multiplies 75 % padding on 32 channels (HRNet's high-resolution branch, 64 launches per forward: 0.83 -> 0.67 ms, with residual 0.91 -> 0.76;
+            // YOLOX-m's / CSPNeXt's 96 > 48 layers 0.84 -> 0.60)
+            if (a.Cout <= 64) cfg = 19;
+            else if (t128h >= 384) cfg = 20;
             else if (t128h >= 256) cfg = 22;
             else if (((a.M + 63) / 64) * ((a.Cout + 127) / 128) >= 192) cfg = 21;
             else cfg = 19;
@@ -692,9 +696,14 @@ int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream
             const bool patch_ok = a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin == 64 && a.H == a.Ho && a.W == a.Wo && a.Wo >= 8 && a.Wo <= 64 &&
                                   128 % a.Wo == 0 && ((long long)a.Ho * a.Wo) % 256 == 0 && a.Cout % 64 == 0;
             if (patch_ok) cfg = ((a.M + 255) / 256 >= 768) ? 17 : 18;
+            else if (a.Cout <= 32) cfg = 16;                // r06 sweep: 32 wide -> 64 x 64 tiles (HRNet's 256 > 32 fuse layers 4.06 -> 2.90 ms)
             else if (a.Cout <= 64) cfg = ((a.M + 255) / 256 >= 768) ? (a.res ? 7 : 10) : 12;
             else if (a.Cout % 256 == 0 && a.K >= 1024 && !a.res && tiles256 >= 512) cfg = 1;
-            else if (t128 >= 384) cfg = a.res ? 3 : 9;      // (without a residual to prefetch the tile needs fewer registers: four workgroups per CU)
+            // r06 sweep: odd multiples of 64 (192: CSPNeXt-m, YOLOX-m) are three 64-wide tiles exactly -- the 256 x 64 one-stage tile, 8-14 % ahead
+            else if (t128 >= 384 && a.Cout % 128 == 64) cfg = 10;
+            // (without a residual to prefetch the tile needs fewer registers: four workgroups per CU; r06 sweep: a long K loop -- basic blocks' 3 x 3
+            //  with residual, HRNet -- hides the residual read by itself: 0.149 -> 0.131 ms)
+            else if (t128 >= 384) cfg = (a.res && a.K < 1152) ? 3 : 9;
             //   * SMALL launches (the online step: one frame, ~100 crops): fewer than 1.5 128 x 128 tiles per CU -> no neighbours to hide a
             //     workgroup's memory round trips, so the pipeline goes back INSIDE the workgroup (two stages); fewer than one tile per CU ->
             //     smaller tiles, so that more CUs work, with three / four stages in flight (a 64 x 64 tile multiplies for ~130 cycles per step)
