@@ -653,8 +653,9 @@ int tlk_conv2d_nhwc_f32(const float *x_dev, const float *w_dev, const float *bia
  * pixels x output channels; r05: 7 / 8 / 9 = 128x128 / 128x64 / 64x128 with ONE LDS stage and the epilogue in passes; 21..33 = the direct-to-LDS
  * kernels of tlk_conv16x.hip on fp32 tensors (need cin % 32 == 0), of which 30..33 are the PATCH-resident 3 x 3 kernels: stride 1, pad 1,
  * cin == 32 exactly, tiles of whole image rows (8 <= wo <= 64, tile rows a multiple of wo, ho * wo a multiple of the tile) -- TLK_EINVAL
- * names the violated constraint; the heuristic routes 32-wide layers to 27 / 31 by itself); -1 = the heuristic.  Results do not depend
- * on it: one fmaf chain, as above. */
+ * names the violated constraint; the heuristic routes 32-wide layers to 27 / 31 by itself; r06: 34..37 the same on 64 channels, 38 / 39 = 128x128
+ * and 256x128 two-stage tiles with the residual read in the epilogue); -1 = the heuristic (r06: re-derived from a sweep of every layer of six
+ * networks under every configuration, tools/sweep_conv_f32.py).  Results do not depend on it: one fmaf chain, as above. */
 int tlk_conv2d_set_config(int cfg);
 /* Tile configuration the most recent tlk_conv2d_nhwc_f32 call of this process launched (as above; 15 = the direct RGB stem kernel), -1 before the first. */
 int tlk_conv2d_last_config(void);

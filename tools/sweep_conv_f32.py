@@ -1,5 +1,5 @@
 """Probe (not product): every distinct fp32 convolution of a network, timed under the tile configuration the heuristic picks and under every
-configuration tlk_conv2d_set_config can force (0-9: conv_f32_mfma_kernel tiles, 21-37: the direct-to-LDS kernels on fp32 tensors) -- where a
+configuration tlk_conv2d_set_config can force (0-9: conv_f32_mfma_kernel tiles, 21-39: the direct-to-LDS kernels on fp32 tensors) -- where a
 forced configuration beats the heuristic, the heuristic is wrong for that shape.
 
     python tools/sweep_conv_f32.py yolox-m 24          # detector, 24 frames of 640 x 640
@@ -67,7 +67,7 @@ def timed(fn, n):
 
 
 L = _lib.lib()
-CFGS = list(range(0, 10)) + list(range(21, 38))
+CFGS = list(range(0, 10)) + list(range(21, 40))
 tot_default = tot_best = 0.0
 print(f"{'n':>3s} {'x (N,C,H,W)':>22s} {'w':>16s} s act res | {'heuristic':>9s} {'ms':>8s} {'TF/s':>6s} | best forced")
 for key, (count, cfg_default) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):

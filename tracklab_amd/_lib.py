@@ -1049,7 +1049,8 @@ CONV_F32_X_TEMPLATES = {21: "2, 2, 2, 2, 2, 1, true, false, 128, 1", 22: "2, 2, 
                         27: "4, 1, 2, 1, 2, 1, true, false, 128, 1", 28: "4, 1, 2, 1, 2, 2, true, false, 128, 1", 29: "4, 1, 4, 1, 2, 1, true, false, 128, 1",
                         30: "4, 1, 2, 1, 2, 1, true, true, 128, 1", 31: "4, 1, 2, 1, 2, 1, false, true, 128, 1", 32: "4, 1, 1, 1, 2, 1, true, true, 128, 1",
                         33: "2, 1, 2, 1, 2, 1, true, true, 128, 1", 34: "4, 1, 1, 2, 2, 1, true, true, 128, 2", 35: "4, 1, 2, 2, 2, 1, true, true, 128, 2",
-                        36: "2, 1, 2, 2, 2, 1, true, true, 128, 2", 37: "4, 1, 1, 2, 2, 1, false, true, 128, 2"}
+                        36: "2, 1, 2, 2, 2, 1, true, true, 128, 2", 37: "4, 1, 1, 2, 2, 1, false, true, 128, 2",
+                        38: "2, 2, 2, 2, 2, 2, false, false, 128, 1", 39: "4, 2, 2, 2, 2, 2, false, false, 128, 1"}
 
 
 def conv_f32_config_template(cfg: int) -> str:

@@ -408,7 +408,7 @@ int g_last_cfg = -1;      // configuration of the most recent launch (tlk_conv2d
 
 extern "C" int tlk_conv2d_set_config(int cfg)
 {
-    if (cfg < -1 || (cfg > 9 && (cfg < 21 || cfg > 37))) return fail(TLK_EINVAL, "tlk_conv2d_set_config: cfg must be -1 (heuristic), 0..9, or 21..37 (the direct-to-LDS kernels of tlk_conv16x.hip on fp32 tensors)");
+    if (cfg < -1 || (cfg > 9 && (cfg < 21 || cfg > 39))) return fail(TLK_EINVAL, "tlk_conv2d_set_config: cfg must be -1 (heuristic), 0..9, or 21..39 (the direct-to-LDS kernels of tlk_conv16x.hip on fp32 tensors)");
     g_force_cfg = cfg;
     return TLK_OK;
 }

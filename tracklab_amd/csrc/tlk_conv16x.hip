@@ -635,7 +635,10 @@ int launch_cfg_x32(Conv16Args &a, int act, int cfg, hipStream_t st)
     case 15: return launch_patch<4, 1, 2, 2, MODE_F32, true, 2>(a, act, st, "tlk_conv2d_nhwc_f32");   // 256 x 64 PATCH, four wavefronts of 64 x 64
     case 16: return launch_patch<2, 1, 2, 2, MODE_F32, true, 2>(a, act, st, "tlk_conv2d_nhwc_f32");   // 128 x 64 PATCH, two wavefronts of 64 x 64
     case 17: return launch_patch<4, 1, 1, 2, MODE_F32, false, 2>(a, act, st, "tlk_conv2d_nhwc_f32");  // 128 x 64 PATCH, residual read in the epilogue
-    default: return fail(TLK_EINVAL, "tlk_conv2d_set_config: the direct-to-LDS fp32 configurations are 21..37");
+    // r06, from the with-residual 1 x 1 expansions of ResNet's layers 3 / 4 (K 256 / 512 > 1024 / 2048 channels): the residual read in the epilogue
+    case 18: return launch_x<2, 2, 2, 2, MODE_F32, 2, false>(a, act, st);    // 128 x 128, two stages, no residual prefetch (fewer registers)
+    case 19: return launch_x<4, 2, 2, 2, MODE_F32, 2, false>(a, act, st);    // 256 x 128, 8 wavefronts of 64 x 64, two stages
+    default: return fail(TLK_EINVAL, "tlk_conv2d_set_config: the direct-to-LDS fp32 configurations are 21..39");
     }
 }
 
