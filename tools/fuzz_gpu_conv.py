@@ -18,7 +18,7 @@ rng = np.random.default_rng(seed)
 L = _lib.lib()
 _lib.conv2d_nhwc_f32(torch.zeros(0, 4, 2, 2, device="cuda").contiguous(memory_format=torch.channels_last),
                      torch.zeros(4, 4, 1, 1, device="cuda").contiguous(memory_format=torch.channels_last))
-stats = {"f32": 0, "f32_declined": 0, "f16": 0, "stem16": 0, "patch": 0, "patch64": 0, "split": 0}
+stats = {"f32": 0, "f32_declined": 0, "f16": 0, "stem16": 0, "patch": 0, "patch64": 0, "split": 0, "dw": 0}
 t0 = time.time()
 
 
@@ -32,7 +32,7 @@ def fail(msg):
 
 
 while time.time() - t0 < budget:
-    kind = rng.choice(["f32", "f32", "patch", "patch64", "f16", "f16", "stem16", "split"])
+    kind = rng.choice(["f32", "f32", "patch", "patch64", "f16", "f16", "stem16", "split", "dw"])
     act = [None, "relu", "silu"][rng.integers(3)]
     if kind in ("f32", "patch", "patch64"):
         if kind == "patch64":                      # r06: the patch-resident kernel on 64 channels (two K steps per pixel), whole rows per 128-pixel tile
@@ -56,7 +56,7 @@ while time.time() - t0 < budget:
         if res:
             exp = oracle.conv2d_nhwc_f32(x, wt, b, r, stride=s, act=act, res_after_act=after)
         xt, wtt, rt = nhwc(x), nhwc(wt), (nhwc(r) if res else None)
-        cfgs = [-1] + list(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37], size=4, replace=False))
+        cfgs = [-1] + list(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39], size=4, replace=False))
         if kind == "patch64":
             cfgs = [-1, 0] + list(rng.choice([34, 35, 36, 37], size=3, replace=False))
         # a channel slice as the output (pixel stride > Cout) and a dynamic batch, sometimes
@@ -157,7 +157,7 @@ while time.time() - t0 < budget:
             if not bool(torch.isfinite(y).all()) or not bool((err <= 2e-6 * bound + 1e-30).all()):
                 fail(f"split cfg {cfg} case {(n, h, w, cin, cout, k, s, act, res, mag)} max err / bound {float((err / bound).max())} scales {states[:, 0].tolist()}")
             stats["split"] += 1
-    else:
+    elif kind == "stem16":
         n, h, w = int(rng.integers(1, 4)), int(rng.integers(8, 90)), int(rng.integers(8, 150))
         k = int(rng.choice([7, 3])); cout = int(rng.choice([8, 32, 48, 64])); xp = int(rng.choice([3, 3, 4, 8]))
         pool = bool(rng.integers(2)) and (w + 2 * (k // 2) - k) // 2 + 1 <= 64
@@ -175,4 +175,34 @@ while time.time() - t0 < budget:
         if not bool((err <= 2e-3 * ref.abs() + 2e-3).all()):
             fail(f"stem16 case {(n, h, w, k, cout, xp, act, pool)} max err {float(err.max())}")
         stats["stem16"] += 1
+    else:                                            # "dw", r06: depthwise k x k, every lane shape (columns per lane x rows ahead), channel slices, both element types
+        n, h, w = int(rng.integers(1, 4)), int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        half = bool(rng.integers(2))
+        c = int(rng.choice([8, 16, 24, 48, 96])) if half else int(rng.choice([4, 8, 12, 48, 100]))
+        k = int(rng.choice([3, 5]))
+        x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+        wt = (rng.standard_normal((k, k, c)) * 0.3).astype(np.float32)
+        b = rng.standard_normal(c).astype(np.float32) if rng.integers(4) else None
+        if half:
+            x, wt = x.astype(np.float16), wt.astype(np.float16)
+        exp = oracle.dwconv2d_nhwc_f32(x.astype(np.float32), wt.astype(np.float32), b, act)
+        slack = int(rng.choice([0, 0, 8, 16]))
+        for cfg in (0, 1, 2, 3, 4):
+            _lib.dwconv_set_config(cfg)
+            try:
+                wide = torch.full((n, h, w, c + slack), -7.0, device="cuda", dtype=torch.float16 if half else torch.float32).permute(0, 3, 1, 2)
+                _lib.dwconv2d_nhwc(nhwc(x), torch.from_numpy(wt).cuda(), torch.from_numpy(b).cuda() if b is not None else None, act, out=wide[:, :c])
+            finally:
+                _lib.dwconv_set_config(0)
+            got = wide.permute(0, 2, 3, 1).float().cpu().numpy()
+            if half:
+                e16 = exp.astype(np.float16).astype(np.float32)
+                ok = np.array_equal(got[..., :c], e16) if act != "silu" else bool((np.abs(got[..., :c] - exp) <= 0.5 * np.spacing(np.abs(e16).astype(np.float16)).astype(np.float32) + 4e-7 * np.abs(exp) + 1e-12).all())
+            else:
+                ok = np.array_equal(got[..., :c], exp) if act != "silu" else np.allclose(got[..., :c], exp, rtol=2e-6, atol=1e-6)
+            if not ok:
+                fail(f"dwconv cfg {cfg} case {(n, h, w, c, k, act, half, slack)} max diff {np.abs(got[..., :c] - exp).max()}")
+            if not (got[..., c:] == -7.0).all():
+                fail(f"dwconv cfg {cfg}: wrote outside its channels, case {(n, h, w, c, k, slack)}")
+            stats["dw"] += 1
 print(f"{sum(stats.values()) - stats['f32_declined']} launches compared in {time.time() - t0:.0f} s, 0 divergences: {stats}")
