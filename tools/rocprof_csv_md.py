@@ -8,7 +8,8 @@ import shutil
 import sys
 
 src, dst, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
-path = sorted(glob.glob(src + "/**/*kernel_stats.csv", recursive=True))[0]
+import os
+path = max(glob.glob(src + "/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)      # the newest run: gpurun merges every call's files into the same directory
 rows = list(csv.DictReader(open(path)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 out = [f"# {dst.split('/')[-1]}", "", f"command: `{cmd}`", ""]

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 d, win = sys.argv[1], float(sys.argv[2])
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
-path = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[0]
+path = max(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)      # the newest run
 rows = []
 with open(path) as f:
     for r in csv.DictReader(f):
