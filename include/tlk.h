@@ -716,6 +716,8 @@ int tlk_conv16_set_glds(int on);
  * tile configuration (probes / tests).  Same arithmetic contract as above in every configuration.  r06: in split mode the heuristic also
  * takes the 1 x 1 expansions WITH residual (128 x 128 tiles of eight 32 x 64 wavefronts, configurations 6 / 7). */
 int tlk_conv16_set_config(int cfg);
+/* Tile configuration the most recent tlk_conv2d_nhwc_16 / _16s call of this process launched (as above), -1 = the r04 kernels (tests of the heuristic). */
+int tlk_conv16_last_config(void);
 /* fp32 NHWC pixels (c_in channels, x_pix_stride floats apart, 0 = dense) -> (hi, lo) f16 planes with c_out >= c_in channels, zero padded. */
 int tlk_split_f32_planes(const float *x_dev, long long pixels, int c_in, int x_pix_stride, int c_out, void *hi_dev, void *lo_dev, void *hip_stream);
 /* y[i] = hi[i] + lo[i] * 2^-11 for n elements. */

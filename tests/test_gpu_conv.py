@@ -196,6 +196,45 @@ def test_heuristic_routes_the_64_channel_3x3_layers_to_the_patch_kernel():
     assert torch.equal(y, y0)
 
 
+# (n, h, w, cin, cout, k, stride, residual) at sizes where the r06 rules apply -> the configuration the heuristic must pick
+R06_ROUTES = [
+    ((24, 80, 80, 96, 96, 1, 1, False), 27),        # 96 wide: three 256 x 32 direct-to-LDS tiles (YOLOX-m / CSPNeXt-m)
+    ((24, 80, 80, 96, 96, 3, 1, True), 27),
+    ((100, 24, 8, 256, 256, 3, 1, False), 25),      # powers of two on few tiles, a small launch: 64 x 128 tiles (one frame's crops)
+    ((24, 40, 40, 192, 384, 3, 2, False), 24),      # 3 x 128 wide on few tiles: the two-stage 128 x 128 tile
+    ((700, 24, 8, 256, 256, 3, 1, False), 24),      # K >= 1152 on >= 1024 tiles, no residual (ResNet's layer 3 / 4 3 x 3)
+    ((90, 96, 32, 64, 256, 1, 1, False), 7),        # K <= 64 projection onto a 128-multiple width: 128 x 128, one stage
+    ((24, 160, 160, 48, 48, 1, 1, False), 8),       # short K on the 128 x 64 tile: one stage
+    ((40, 96, 32, 256, 32, 3, 1, False), 28),       # 32 wide with a long K loop: 256 x 32, two stages (HRNet's fuse layers)
+    ((700, 24, 8, 128, 64, 1, 1, False), 8),        # 64 wide 1 x 1 below a million pixels: back on the register-staged tile (one stage: K <= 192)
+]
+
+
+@pytest.mark.parametrize("case,want", R06_ROUTES)
+def test_r06_heuristic_routes_and_every_route_gives_the_generic_kernels_bits(case, want):
+    """the tile heuristic re-derived from tools/sweep_conv_f32.py (profiles/r06_conv_f32_sweep.txt): the configuration it picks for the shapes the
+    rules were written for, and -- the contract of every configuration -- the same bits as the 128 x 128 register-staged kernel"""
+    from tracklab_amd import _lib
+    L = _lib.lib()
+    n, h, w, cin, cout, k, s, res = case
+    g = torch.Generator(device="cuda").manual_seed(cin + cout + k)
+    x = torch.randn((n, h, w, cin), device="cuda", generator=g).permute(0, 3, 1, 2)
+    wt = (torch.randn((cout, k, k, cin), device="cuda", generator=g) * 0.05).permute(0, 3, 1, 2)
+    b = torch.randn(cout, device="cuda", generator=g)
+    y0 = None
+    L.tlk_conv2d_set_config(0 if cout % 128 == 0 else 2)
+    try:
+        y0 = _lib.conv2d_nhwc_f32(x, wt, b, "relu", None, stride=s)
+        r = torch.randn(y0.shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last) if res else None
+        if res:
+            y0 = _lib.conv2d_nhwc_f32(x, wt, b, "relu", r, stride=s)
+    finally:
+        L.tlk_conv2d_set_config(-1)
+    y = _lib.conv2d_nhwc_f32(x, wt, b, "relu", r, stride=s)
+    assert L.tlk_conv2d_last_config() == want, (case, L.tlk_conv2d_last_config())
+    assert torch.equal(y, y0)
+
+
 @pytest.mark.parametrize("case", [(2, 24, 16, 3, 64, 7, 2, "relu", False), (3, 17, 13, 3, 32, 3, 2, "relu", False), (1, 40, 130, 3, 48, 3, 2, None, False),
                                   (2, 9, 70, 3, 64, 7, 2, "relu", False)])
 def test_direct_rgb_stem_kernel_is_bit_exact_with_the_oracle_on_the_padded_problem(case):

@@ -4,6 +4,8 @@
   * f16 mode: equal to an fp32-accumulated convolution of the f16 operands rounded once to f16 (1 ulp of f16);
   * split / merge are exact inverses to 2^-22;
   * the ReID network in split precision agrees with the exact-fp32 network far below the f16 leg's distance."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -180,6 +182,53 @@ def test_f16_half_step_tiles(shape, cfg):
     finally:
         _force16(0)
     assert float((y.float() - y0.float()).abs().max()) <= 2.0 ** -9 * max(1.0, float(y0.float().abs().max()))
+
+
+# (n, cin, h, w, cout, k, stride, residual, split) at sizes where the r06 rules of the sweep apply -> the configuration the heuristic must pick
+R06_ROUTES16 = [
+    ((40, 32, 96, 32, 32, 3, 1, True, False), 19),      # half-step K, <= 64 outputs: 64 x 64 tiles whatever the launch size (HRNet's 32-channel branch)
+    ((24, 96, 80, 80, 48, 1, 1, False, False), 19),
+    ((40, 256, 96, 32, 32, 3, 1, False, False), 16),    # 32 wide on a full K step: 64 x 64 tiles
+    ((200, 192, 16, 12, 192, 3, 1, False, False), 10),  # 192 wide = three 64-wide tiles: 256 x 64, one stage
+    ((600, 256, 12, 4, 256, 3, 1, True, False), 9),     # a long K loop with residual: the tile that reads the residual in its epilogue
+    ((24, 192, 40, 40, 192, 3, 1, False, True), 7),     # split mode, the detector's few-tile layers: 128 x 128 of eight wavefronts
+    ((24, 384, 40, 40, 192, 1, 1, False, True), 7),
+]
+
+
+@pytest.mark.parametrize("case,want", R06_ROUTES16)
+def test_r06_heuristic_routes_of_the_16_bit_kernels(case, want):
+    """tools/sweep_conv16.py (profiles/r06_conv16_sweep.txt): the configuration the heuristic picks for the shapes the r06 rules were written for
+    (tlk_conv16_last_config), and the result against fp64 on the f16 operands to the bound of the tests above"""
+    from tracklab_amd import _lib
+    n, cin, h, w, cout, k, s, res, split = case
+    g = torch.Generator(device="cuda").manual_seed(cin + cout)
+    x = torch.randn((n, h, w, cin), device="cuda", generator=g).permute(0, 3, 1, 2)
+    wt = (torch.randn((cout, k, k, cin), device="cuda", generator=g) * 0.05).permute(0, 3, 1, 2)
+    b = torch.randn(cout, device="cuda", generator=g)
+    _force16(0)
+    L = _lib.lib()
+    L.tlk_conv16_last_config.restype = C.c_int
+    if split:
+        xh, xl = _lib.split_planes(x.contiguous(memory_format=torch.channels_last))
+        wh, wl = _lib.split_planes(wt.contiguous(memory_format=torch.channels_last))
+        y = _lib.conv2d_nhwc_16(xh, wh, b, "silu", None, stride=s, x_lo=xl, weight_lo=wl, out_f32=True)
+        assert L.tlk_conv16_last_config() == want, (case, L.tlk_conv16_last_config())
+        ref = F.silu(F.conv2d(x.double(), wt.double(), b.double(), s, k // 2))
+        bound = F.conv2d(x.double().abs(), wt.double().abs(), b.double().abs(), s, k // 2)
+        assert bool(((y.double() - ref).abs() <= 2e-6 * bound + 1e-7).all())
+        return
+    xh, wh = x.half(), wt.half()
+    rh = torch.randn((n, cout, (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1), device="cuda", generator=g).half().contiguous(memory_format=torch.channels_last) if res else None
+    y = _lib.conv2d_nhwc_16(xh, wh, b, "relu", rh, stride=s)
+    assert L.tlk_conv16_last_config() == want, (case, L.tlk_conv16_last_config())
+    ref = F.conv2d(xh.double(), wh.double(), b.double(), s, k // 2)
+    if res:
+        ref = ref + rh.double()
+    ref = F.relu(ref)
+    bound = F.conv2d(xh.double().abs(), wh.double().abs(), b.double().abs(), s, k // 2) + (rh.double().abs() if res else 0)
+    err = (y.double() - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -11 + 4e-6 * bound + 1e-7).all()), float((err / (ref.abs() + 1e-3)).max())
 
 
 def test_a_full_step_configuration_refuses_a_half_step_layer():

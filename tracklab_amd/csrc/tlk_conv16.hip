@@ -585,6 +585,7 @@ template <int TM, int TN, int WGM, int WGN, int MODE, bool OUT_F32> int launch16
 template <int MODE, bool OUT_F32> int dispatch16(Conv16Args &a, int act, hipStream_t st)
 {
     if (g_glds < 0) { const char *e = getenv("TLK_CONV16_GLDS"); g_glds = e ? atoi(e) : 1; }
+    g_last_cfg16x = -1;
     if (g_cfg16x >= 0) {
         const int r = launch16x(a, MODE == MODE_SPLIT, OUT_F32, act, g_cfg16x, st);
         if (r != 1) return r;                                                            // 1 = "not a shape for the large tiles"
@@ -724,6 +725,9 @@ extern "C" int tlk_conv16_set_config(int cfg)
     g_cfg16x = cfg;
     return TLK_OK;
 }
+
+// the tile configuration the most recent tlk_conv2d_nhwc_16 / _16s call launched (1..22 f16, 1..7 split), -1 = the r04 kernels
+extern "C" int tlk_conv16_last_config(void) { return c16::g_last_cfg16x; }
 
 static int split_planes_entry(const float *x_dev, long long pixels, int c_in, int x_pix_stride, int c_out, void *hi_dev, void *lo_dev, float *state_dev,
                               long long pixels_per_image, void *hip_stream)

@@ -102,6 +102,7 @@ const unsigned char *zero_page();      // 256 zero bytes on the current device (
 // tlk_conv16x.hip: the large-tile kernels.  cfg: 0 = choose by shape (may decline: returns 1 = "not mine", the caller keeps its own kernel),
 // > 0 = force that tile configuration (probes).  Returns TLK_OK when launched.
 int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream_t st);
+extern int g_last_cfg16x;     // what tlk_conv16_last_config reports
 // the same kernels on fp32 tensors (a.x / a.w / a.res / a.y32 hold float pointers): the memory-bound layers of the fp32 networks
 int launch32x(Conv16Args &a, int act, int cfg, hipStream_t st);
 

@@ -659,6 +659,8 @@ int launch32x(Conv16Args &a, int act, int cfg, hipStream_t st)
     return launch_cfg_x32(a, act, cfg, st);
 }
 
+int g_last_cfg16x = -1;      // tlk_conv16_last_config: the tile configuration of the most recent large-tile launch (-1: the call went to the r04 kernels)
+
 int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream_t st)
 {
     (void)out32;
@@ -730,6 +732,7 @@ int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream
             else return 1;
         }
     }
+    g_last_cfg16x = cfg;
     return launch_cfg_x(a, split, act, cfg, st);
 }
 
