@@ -201,4 +201,10 @@ def test_weight_derived_caches_follow_a_checkpoint_loaded_after_the_first_forwar
     a1 = net(xin)[0]
     fresh = rtmpose("t", device="cuda", dtype=torch.float16)
     fresh.load_state_dict(sd)
-    assert torch.equal(a1, fresh(xin)[0]) and not torch.equal(a0, a1)                                                     # _final_gemm + every cache above
+    # _final_gemm + every cache above.  libtlk's kernels are run-to-run deterministic (tools/probe_determinism.py: 0 of 400 repeated forwards
+    # differ), but the GAU / SimCC linears are library GEMMs whose algorithm choice can change between two module instances in a long-lived
+    # process (seen once in ~10 full-suite runs: single f16 steps on a handful of logits) -- a stale cache is off by the size of the weight
+    # perturbation, three orders of magnitude more
+    a2 = fresh(xin)[0]
+    assert float((a1.float() - a2.float()).abs().max()) <= 4e-3 * max(1.0, float(a2.float().abs().max()))
+    assert float((a0.float() - a1.float()).abs().max()) >= 0.05 * float(a1.float().abs().max())
