@@ -32,6 +32,7 @@ int tlk_lsa_f64_cpu(const double *cost, int batch, int nr, int nc, int32_t *rows
     if (!r64) return TLK_EINVAL;
     int64_t *c64 = r64 + (k > 0 ? k : 1);
     for (int b = 0; b < batch; ++b) {
+        if (k == 0) { n_pairs[b] = 0; continue; }                                  /* an empty problem has an empty assignment */
         const int n = orc_lsa(cost + (size_t)b * nr * nc, nr, nc, r64, c64);      /* pairs sorted by row; -1 infeasible, -2 NaN / -inf */
         n_pairs[b] = n;
         for (int i = 0; i < k; ++i) {
