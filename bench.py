@@ -1100,10 +1100,10 @@ def main():
     # ---- the ReID backbone the reference's yaml selects (tracklab/configs/modules/reid/bpbreid.yaml:53 backbone: "hrnet32"), driver-visible
     # (VERDICT r05 missing 3): the same step with HRNet-W32 behind the same part-based head, exact fp32, ids checked against the oracle chain,
     # its own convolution roofline.  The headline stays on ResNet-50 (an option the same yaml line lists; the r01-r05 numbers are quoted on it)
-    hrnet_leg = None
+    hrnet_leg = hrnet_split_leg = None
     if rank == 0 and world == 1 and args.workload == "config3" and args.dtype == "f32" and not args.no_hrnet_leg and not args.no_f32_leg:
         try:
-            hrnet_leg, _ = precision_leg("f32 (exact), ReID backbone HRNet-W32 (bpbreid.yaml:53)", "f32", False, reid_arch="hrnet32",
+            hrnet_leg, emb_hr = precision_leg("f32 (exact), ReID backbone HRNet-W32 (bpbreid.yaml:53)", "f32", False, reid_arch="hrnet32",
                                          with_roofline=lambda pf_: conv_roofline(pf_, "config3h"))
             hrnet_leg["workload"] = WORKLOADS["config3h"]["name"]
             r_ = hrnet_leg["roofline"]
@@ -1113,6 +1113,21 @@ def main():
             hrnet_leg["roofline"]["per_instantiation_top5"] = r_["per_instantiation"][:5]
         except Exception as ex:                                 # noqa: BLE001  (a side leg must not cost the run its line)
             hrnet_leg = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        # r06: the same HRNet-W32 step in split-precision mode (fp32-class arithmetic on the 16-bit MFMA, scaled planes; the exchange units' sums and
+        # the concatenation in tlk_split_fuse_sum), detector in split mode too -- value_hrnet32_split, ids checked against the oracle chain
+        if "error" not in hrnet_leg:
+            try:
+                hrnet_split_leg, emb_hs = precision_leg("f32 weights and activations as (hi, lo) f16 pairs (split precision, scaled planes), ReID backbone "
+                                                        "HRNet-W32 (bpbreid.yaml:53) AND the detector", "f32", True, reid_arch="hrnet32", split_detector=True)
+                import oracle
+                valid = np.zeros(emb_hr[0].shape[:2], dtype=bool)
+                for f in range(F):
+                    valid[f, :len(detector_rows(oracle, heads_np[0][f], ratio))] = True
+                e0 = emb_hr[0].astype(np.float64)
+                hrnet_split_leg["max_abs_embedding_difference_vs_exact_fp32"] = float(np.abs(emb_hs[0][valid] - e0[valid]).max() / (float(np.abs(e0[valid]).max()) or 1.0))
+                hrnet_split_leg["speedup_vs_exact_fp32"] = hrnet_split_leg["value"] / hrnet_leg["value"]
+            except Exception as ex:                             # noqa: BLE001
+                hrnet_split_leg = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
     # ---- CPU baseline: (a) the same chain on host cores (oracle C port + torch CPU fp32 forwards), warm, bounded sample;
     # (b) SURVEY 8d's form: the hand-written stages only (oracle C twins, backbones excluded), one thread and all cores ----
@@ -1177,6 +1192,9 @@ def main():
             "value_hrnet32": hrnet_leg.get("value") if hrnet_leg else None,
             "ms_per_step_hrnet32": hrnet_leg.get("ms_per_step") if hrnet_leg else None,
             "hrnet32_leg": hrnet_leg,
+            "value_hrnet32_split": hrnet_split_leg.get("value") if hrnet_split_leg else None,
+            "ms_per_step_hrnet32_split": hrnet_split_leg.get("ms_per_step") if hrnet_split_leg else None,
+            "hrnet32_split_leg": hrnet_split_leg,
             "precision_note": ("value is measured with fp32 backbones, the reference's precision (configs/modules/track/strong_sort.yaml:10 fp16: false; "
                                "ONNXRuntime / torchreid fp32): exact fp32 MFMA, no reduced-precision path exists on gfx950. One step is "
                                + (f"{roofline['algorithmic_tflop_per_step']:.1f} TFLOP of convolutions over the step's live crops, so 157.3 TFLOP/s (the chip's dense "

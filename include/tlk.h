@@ -705,6 +705,17 @@ int tlk_split_f32_planes_s(const float *x_dev, long long pixels, int c_in, int x
                            long long pixels_per_image, void *hip_stream);
 int tlk_merge_planes_f32_s(const void *hi_dev, const void *lo_dev, long long n, const float *scale_dev, float *y_dev, void *hip_stream);
 int tlk_split_scale_update(float *states_dev, int n_states, int *changed_dev, void *hip_stream);
+/* r06 -- the element-wise joints of a split-precision network in ONE pass (tlk_split_fuse.hip): y = [relu]( sum of 1..4 terms ), written as
+ * scaled (hi, lo) planes (out_state_dev as in tlk_conv2d_nhwc_16s: {scale in use, recorded maximum}; NULL = scale 1).  Term t is a plane pair
+ * (hi_dev[t], lo_dev[t], scale_dev[t] nullable = 1) or one fp32 tensor (f32_dev[t]; hi / lo NULL), NHWC with c channels at resolution
+ * (h >> shift[t], w >> shift[t]) -- nearest up-sampling by 2^shift -- and pixel stride pix_stride[t] elements (0 = c).  The tables are HOST arrays of
+ * n_terms entries holding device pointers.  y_pix_stride > c writes a channel slice of a wider tensor (one term, no ReLU: the concatenation of
+ * branches with different scales onto one).  dynamic_batch != 0 honours tlk_conv_set_dynamic_batch.  c % 8 == 0, 16-byte aligned pointers.
+ * The sum is taken in term order in fp32, as torch does for HRNet's exchange units (the ReID backbone the reference's yaml selects:
+ * tracklab/configs/modules/reid/bpbreid.yaml:53, run through tracklab/wrappers/reid/kpreid_api.py:147-182). */
+int tlk_split_fuse_sum(int n_terms, const void *const *hi_dev, const void *const *lo_dev, const float *const *f32_dev,
+                       const float *const *scale_dev, const int *shift, const int *pix_stride, int n, int h, int w, int c, int relu,
+                       void *y_hi_dev, void *y_lo_dev, int y_pix_stride, float *out_state_dev, int dynamic_batch, void *hip_stream);
 /* Probes / tests: 0 = the register-staged kernel for every shape, 1 (default; env TLK_CONV16_GLDS) = the direct-to-LDS kernel where it applies
  * (Cout > 64, Cin a multiple of the K step).  Results do not depend on it beyond fp32 summation order inside a 16-wide slice (none: same order). */
 int tlk_conv16_set_glds(int on);
@@ -712,7 +723,7 @@ int tlk_conv16_set_glds(int on);
  * one to four LDS stages with counted waits, residual prefetched into registers).  cfg 0 (default) = they take the shapes their launch-size
  * heuristic claims (cin a multiple of the K step: 64 in f16 mode, 32 in split mode) and the r04 kernels the rest; -1 = r04 kernels only;
  * 1..22 (f16; 17 / 18 = the patch-resident 3 x 3 kernel: stride 1, exactly 64 channels, whole image rows per tile; r06: 19..22 = the HALF-STEP
- * tiles, K step 32 halfs, for cin a multiple of 32 but not of 64 -- the only ones such a layer accepts) / 1..7 (split) = force one
+ * tiles, K step 32 halfs, for cin a multiple of 32 but not of 64 -- the only ones such a layer accepts) / 1..11 (split; 8..11: 32-column tiles) = force one
  * tile configuration (probes / tests).  Same arithmetic contract as above in every configuration.  r06: in split mode the heuristic also
  * takes the 1 x 1 expansions WITH residual (128 x 128 tiles of eight 32 x 64 wavefronts, configurations 6 / 7). */
 int tlk_conv16_set_config(int cfg);

@@ -269,8 +269,9 @@ def test_f16_patch_resident_3x3_kernel(shape, cfg):
     assert bool((err <= ref.abs() * 2.0 ** -11 + 2e-6 * bound + 1e-7).all()), float((err / (ref.abs() + 1e-3)).max())
 
 
-@pytest.mark.parametrize("cfg", list(range(1, 8)))
-@pytest.mark.parametrize("shape", [X_SHAPES[0], X_SHAPES[1], X_SHAPES[2], X_SHAPES[3]])
+# (8..11, r06: the 32-column tiles of HRNet-W32's high-resolution branch -- with a 32-channel layer, with and without residual, and a ragged Cout)
+@pytest.mark.parametrize("cfg", list(range(1, 12)))
+@pytest.mark.parametrize("shape", [X_SHAPES[0], X_SHAPES[1], X_SHAPES[2], X_SHAPES[3], (3, 32, 24, 8, 32, 3, 1, True), (2, 64, 13, 7, 40, 3, 2, False)])
 def test_every_split_tile_configuration_is_fp32_class(shape, cfg):
     from tracklab_amd import _lib
     x, wt, b, r, k, s = _inputs(shape, seed=10 + cfg)

@@ -1,0 +1,144 @@
+"""-m gpu: r06, the split-precision route of HRNet-W32 (the ReID backbone tracklab/configs/modules/reid/bpbreid.yaml:53 selects).
+(a) tlk_split_fuse_sum -- the element-wise joint of the exchange units: [relu](sum of plane / fp32 terms at mixed resolutions) as scaled planes --
+against the composition of torch passes it replaces (fp32 reference of the same op: the sum in term order, so the only difference is the
+2^-22 relative rounding of the planes); (b) the whole network in split mode against the same network on the exact-fp32 kernels."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(t):
+    import torch
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _state(scale=1.0):
+    import torch
+    return torch.tensor([scale, 0.0], dtype=torch.float32, device="cuda")
+
+
+def _up(t, s):
+    import torch.nn.functional as F
+    return t if s == 0 else F.interpolate(t, scale_factor=2 ** s, mode="nearest")
+
+
+@pytest.mark.parametrize("c,shifts,kinds,relu", [(32, (0, 1, 2), "pff", True), (64, (0, 0, 1, 2), "fpff", True), (256, (0, 0, 0, 0), "fffp", True),
+                                                  (128, (0,), "p", False), (32, (0, 3), "pp", False), (8, (1, 0), "fp", True)])
+def test_fuse_sum_is_the_torch_composition_to_plane_rounding(c, shifts, kinds, relu):
+    import torch
+    from tracklab_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(c + len(shifts))
+    n, h, w = 5, 48, 16
+    terms, ref = [], None
+    for s, kd in zip(shifts, kinds):
+        t = _cl(torch.randn(n, c, h >> s, w >> s, device="cuda", generator=g) * 7)
+        if kd == "p":
+            hi, lo = _lib.split_planes(t)
+            t = _lib.merge_planes(hi, lo)              # the value the planes hold
+            terms.append((hi, lo, None))
+        else:
+            terms.append(t)
+        u = _up(t, s)
+        ref = u if ref is None else ref + u
+    if relu:
+        ref = torch.relu(ref)
+    st = _state()
+    yh, yl = _lib.split_fuse_sum(terms, relu=relu, out_state=st)
+    y = _lib.merge_planes(yh, yl)
+    assert y.shape == ref.shape
+    err = (y - ref).abs()
+    assert float((err - ref.abs() * 2.0 ** -21).max()) <= 1e-9, float(err.max())      # (absolute term: the lo plane of a tiny value is a float16 subnormal)
+    assert float(st[0]) == 1.0 and float(st[1]) == float(ref.abs().max())
+
+
+def test_fuse_sum_scaled_terms_scaled_output_slices_and_dynamic_batch():
+    """terms far beyond float16's range (scaled planes), the output scaled too; written into a channel slice of a wider tensor (the concatenation in
+    front of the head); only the live images of a dynamic batch are touched and recorded"""
+    import torch
+    from tracklab_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n, c, h, w = 6, 64, 24, 8
+    a = _cl(torch.randn(n, c, h, w, device="cuda", generator=g) * 3e5)
+    b = _cl(torch.randn(n, c, h // 2, w // 2, device="cuda", generator=g) * 2e6)
+    sa, sb, so = _state(64.0), _state(512.0), _state(1024.0)
+    ah, al = _lib.split_planes(a, state=sa)
+    bh, bl = _lib.split_planes(b, state=sb)
+    av, bv = _lib.merge_planes(ah, al, scale=sa), _lib.merge_planes(bh, bl, scale=sb)
+    ref = av + _up(bv, 1)
+    wide_h = torch.full((n, 160, h, w), 7.0, dtype=torch.float16, device="cuda").contiguous(memory_format=torch.channels_last)
+    wide_l = wide_h.clone()
+    live = torch.tensor([4], dtype=torch.int32, device="cuda")
+    _lib.conv_set_dynamic_batch(live)
+    try:
+        _lib.split_fuse_sum([(ah, al, sa), (bh, bl, sb)], out=(wide_h[:, 32:96], wide_l[:, 32:96]), out_state=so, dynamic_batch=True)
+    finally:
+        _lib.conv_set_dynamic_batch(None)
+    torch.cuda.synchronize()
+    y = _lib.merge_planes(_cl(wide_h[:, 32:96]), _cl(wide_l[:, 32:96]), scale=so)
+    err = (y[:4] - ref[:4]).abs()
+    assert float((err - ref[:4].abs() * 2.0 ** -21).max()) <= 1e-9 * 1024, float(err.max())
+    assert float(so[1]) == float(ref[:4].abs().max())                     # the maximum of the LIVE images only
+    assert bool((wide_h[4:] == 7).all()) and bool((wide_l[4:] == 7).all())            # images beyond the live count: untouched
+    assert bool((wide_h[:, :32] == 7).all()) and bool((wide_h[:, 96:] == 7).all())    # channels beside the slice: untouched
+
+
+def test_fuse_sum_rejects_what_it_cannot_do():
+    import torch
+    from tracklab_amd import _lib
+    t = _cl(torch.zeros(1, 8, 6, 4, device="cuda"))
+    u = _cl(torch.zeros(1, 8, 3, 2, device="cuda"))
+    _lib.split_fuse_sum([t, u])
+    with pytest.raises(AssertionError):
+        _lib.split_fuse_sum([t, _cl(torch.zeros(1, 8, 2, 4, device="cuda"))])
+    with pytest.raises(_lib.TlkError):
+        _lib.split_fuse_sum([_cl(torch.zeros(1, 12, 6, 4, device="cuda"))])       # channels not a multiple of 8
+
+
+@pytest.mark.parametrize("scales", [True, False])
+def test_hrnet32_in_split_mode_is_fp32_class(scales, monkeypatch):
+    """the whole part-based ReID network on HRNet-W32: split mode against the exact-fp32 kernels, same weights, same crops"""
+    import importlib
+    import torch
+    rmod = importlib.import_module("tracklab_amd.backbones.reid")
+    monkeypatch.setattr(rmod, "USE_SPLIT_SCALES", scales)
+    exact = rmod.part_based_reid(6, 256, device="cuda", dtype=torch.float32, arch="hrnet32")
+    split = rmod.part_based_reid(6, 256, device="cuda", dtype=torch.float32, arch="hrnet32", split_precision=True)
+    # (random-init HRNet on 0..255 pixels leaves float16's range: the unscaled planes get 0..1 pixels)
+    x = _cl(torch.rand(6, 3, 384, 128, device="cuda") * (255 if scales else 1))
+    with torch.no_grad():
+        fa = exact.features(x)
+        fb = split.features(x)
+        fb2 = split.features(x)                     # steady state (calibrated scales)
+        ea, va = exact.head(fa)
+        eb, vb = split.head(fb)
+    assert fb.dtype == torch.float32 and fa.shape == fb.shape and bool(torch.isfinite(fb).all())
+    assert torch.equal(fb, fb2)
+    tol = 2e-5 * max(1.0, float(fa.abs().max()))
+    assert float((fa - fb).abs().max()) <= tol, (float((fa - fb).abs().max()), float(fa.abs().max()))
+    cos = torch.nn.functional.cosine_similarity(ea.double().flatten(1), eb.double().flatten(1), dim=1)
+    assert float((1 - cos).max()) <= 1e-6
+    assert torch.equal(va, vb)
+    assert (getattr(split, "_split_scales", None) is not None) == scales
+
+
+def test_hrnet32_split_mode_beyond_float16s_range():
+    """weights scaled so that the activations leave float16's range: the scaled planes follow (calibration on the first forward), the unscaled
+    route would saturate"""
+    import importlib
+    import torch
+    rmod = importlib.import_module("tracklab_amd.backbones.reid")
+    exact = rmod.part_based_reid(6, 256, device="cuda", dtype=torch.float32, arch="hrnet32")
+    split = rmod.part_based_reid(6, 256, device="cuda", dtype=torch.float32, arch="hrnet32", split_precision=True)
+    with torch.no_grad():
+        for m in (exact, split):
+            m.backbone.stem[0].conv.weight.mul_(4096.0)        # ReLU network, zero biases: every activation behind it scales by 4096
+    x = _cl(torch.rand(4, 3, 384, 128, device="cuda") * 255)
+    with torch.no_grad():
+        fa = exact.features(x)
+        fb = split.features(x)
+    assert float(fa.abs().max()) > 65504.0
+    assert bool(torch.isfinite(fb).all())
+    assert float((fa - fb).abs().max()) <= 2e-5 * float(fa.abs().max())
+    sc = split._split_scales.buf[:, 0].cpu().numpy()
+    assert sc.max() > 1 and np.all(np.log2(sc) == np.round(np.log2(sc)))

@@ -1,5 +1,5 @@
 """Probe (not product): every distinct 16-bit convolution (f16 or split precision) of a network, timed under the tile configuration the heuristic of
-tlk_conv2d_nhwc_16 picks and under every configuration tlk_conv16_set_config can force (-1: the r04 kernels, 1..22 f16 / 1..7 split).
+tlk_conv2d_nhwc_16 picks and under every configuration tlk_conv16_set_config can force (-1: the r04 kernels, 1..22 f16 / 1..11 split).
 
     python tools/sweep_conv16.py f16 reid 2211        # part-based ReID ResNet-50, f16
     python tools/sweep_conv16.py split reid 2211      # the same in split precision (scaled (hi, lo) planes)
@@ -50,12 +50,13 @@ with torch.no_grad():
         net = part_based_reid(6, 512, device=dev, dtype=torch.float32 if split else torch.float16, split_precision=split,
                               arch="hrnet32" if "hrnet" in what else "resnet50")
         x = torch.rand(batch, 3, 384, 128, device=dev).contiguous(memory_format=torch.channels_last)
-        net(x if split else x.half())
+        net(x if split else x.half())          # (split mode: the first forward calibrates the plane scales -- several passes)
+        calls.clear()
         net(x if split else x.half())
 torch.cuda.synchronize()
 _lib.conv2d_nhwc_16 = real
 shapes = {}
-for c in calls[len(calls) // 2:] if what.startswith("reid") else calls:
+for c in calls:
     shapes.setdefault(c, [0])[0] += 1
 print(f"{mode} {what} x {batch}: {sum(v[0] for v in shapes.values())} convolutions per forward, {len(shapes)} distinct shapes", flush=True)
 
@@ -75,7 +76,7 @@ def timed(fn, n):
 
 L = _lib.lib()
 _lib._bind_conv16(L)
-CFGS = [-1] + list(range(1, 8 if split else 23))
+CFGS = [-1] + list(range(1, 12 if split else 23))
 tot_default = tot_best = 0.0
 for key, (count,) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
     xs, ws, act, res, stride, pad, sp, of32, raa, s_in, s_res, s_out = key

@@ -1249,6 +1249,7 @@ def _bind_conv16(L):
         L.tlk_split_f32_planes_s.argtypes = [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
         L.tlk_merge_planes_f32_s.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]
         L.tlk_split_scale_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.tlk_split_fuse_sum.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L._conv16_bound = True
 
 
@@ -1339,6 +1340,54 @@ def merge_planes(hi, lo, scale=None):
         assert scale.dtype == torch.float32 and scale.is_cuda
         check(L.tlk_merge_planes_f32_s(hi.data_ptr(), lo.data_ptr(), hi.numel(), scale.data_ptr(), y.data_ptr(), current_stream_ptr()))
     return y
+
+
+def split_fuse_sum(terms, relu=False, out=None, out_state=None, dynamic_batch=False):
+    """``tlk_split_fuse_sum`` (r06): [relu]( sum of terms ) as scaled (hi, lo) planes in one pass.  terms: 1..4 of (hi, lo, scale-or-None) plane
+    triples or float32 tensors, channels_last (N, C, H >> s, W >> s) with s >= 0 relative to the output's resolution (H, W) = that of `out`, else the
+    largest among the terms; the others are up-sampled by 2**s (nearest).  out: a (hi, lo) pair of float16 channels_last tensors or channel
+    slices to write into (default: new tensors); out_state: {scale, recorded maximum} of the planes written.  Returns (hi, lo)."""
+    import torch
+    L = lib()
+    _bind_conv16(L)
+    assert 1 <= len(terms) <= 4
+    shapes = [(t[0] if isinstance(t, tuple) else t).shape for t in terms]
+    N, Cc = shapes[0][0], shapes[0][1]
+    H, W = (out[0].shape[2], out[0].shape[3]) if out is not None else (max(s[2] for s in shapes), max(s[3] for s in shapes))
+    n = len(terms)
+    P, I = C.c_void_p * n, C.c_int * n
+    hi_t, lo_t, f_t, sc_t, sh_t, px_t = P(), P(), P(), P(), I(), I()
+    keep = []
+    for i, t in enumerate(terms):
+        shp = shapes[i]
+        assert shp[0] == N and shp[1] == Cc, "terms must agree in batch and channels"
+        s = (H // shp[2]).bit_length() - 1
+        assert shp[2] << s == H and shp[3] << s == W, "a term's resolution must divide the output's by a power of two"
+        sh_t[i] = s
+        if isinstance(t, tuple):
+            h_, l_, sc = t
+            assert h_.dtype == torch.float16 and l_.dtype == torch.float16 and h_.shape == l_.shape
+            px_t[i] = _pix16(h_, Cc, shp[2], shp[3])
+            assert _pix16(l_, Cc, shp[2], shp[3]) == px_t[i]
+            hi_t[i], lo_t[i], f_t[i] = h_.data_ptr(), l_.data_ptr(), None
+            sc_t[i] = sc.data_ptr() if sc is not None else None
+        else:
+            assert t.dtype == torch.float32
+            px_t[i] = _pix16(t, Cc, shp[2], shp[3])
+            hi_t[i], lo_t[i], f_t[i], sc_t[i] = None, None, t.data_ptr(), None
+        keep.append(t)
+    if out is None:
+        yh = torch.empty((N, Cc, H, W), dtype=torch.float16, device=keep[0][0].device if isinstance(keep[0], tuple) else keep[0].device,
+                         memory_format=torch.channels_last)
+        yl = torch.empty_like(yh)
+    else:
+        yh, yl = out
+        assert yh.dtype == torch.float16 and yl.dtype == torch.float16 and tuple(yh.shape) == (N, Cc, H, W) and yl.shape == yh.shape
+        assert _pix16(yh, Cc, H, W) == _pix16(yl, Cc, H, W)
+    assert out_state is None or (out_state.dtype == torch.float32 and out_state.numel() == 2 and out_state.is_contiguous())
+    check(L.tlk_split_fuse_sum(n, hi_t, lo_t, f_t, sc_t, sh_t, px_t, N, H, W, Cc, 1 if relu else 0, yh.data_ptr(), yl.data_ptr(), _pix16(yh, Cc, H, W),
+                               out_state.data_ptr() if out_state is not None else None, 1 if dynamic_batch else 0, current_stream_ptr()))
+    return yh, yl
 
 
 def split_scale_update(states, changed=None):

@@ -129,9 +129,11 @@ class SplitScales:
         from .. import _lib
         _lib.split_scale_update(self.buf, self.changed if count_changes else None)
 
-    def calibrate(self, run, max_passes=12):
+    def calibrate(self, run, max_passes=None):
+        """max_passes: default = one per state + 2 (a chain in which EVERY layer saturates behind the previous one -- random-init HRNet-W32 on 0..255
+        pixels needs ~40; a network that fits float16 leaves after the first)"""
         out = None
-        for _ in range(max_passes):
+        for _ in range(max_passes if max_passes is not None else max(12, self.n + 2)):
             self.changed.zero_()
             out = run()
             self.update(count_changes=True)

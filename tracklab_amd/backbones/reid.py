@@ -21,6 +21,8 @@ USE_TLK_MAXPOOL = _os.environ.get("TLK_MAXPOOL", "1") != "0"       # 0: torch's 
 USE_TLK_HEADS = _os.environ.get("TLK_HEADS", "1") != "0"
 # r06: power-of-two plane scales in the split-precision route (activations beyond float16's range); TLK_SPLIT_SCALES=0: the unscaled planes of r05
 USE_SPLIT_SCALES = _os.environ.get("TLK_SPLIT_SCALES", "1") != "0"
+# r06: HRNet's split route reduces the branches one by one instead of concatenating them (PartBasedReID._reduce_branches); 0: concatenate (A/B runs)
+USE_BRANCH_REDUCE = _os.environ.get("TLK_BRANCH_REDUCE", "1") != "0"
 
 
 class _Bottleneck(nn.Module):
@@ -74,6 +76,8 @@ class _HRModule(nn.Module):
 
     def forward(self, xs):
         xs = [b(x) for b, x in zip(self.branches, xs)]
+        if isinstance(xs[0], SplitAct):
+            return self._exchange_split(xs)
         out = []
         for i, row in enumerate(self.fuse):
             y = None
@@ -84,6 +88,27 @@ class _HRModule(nn.Module):
                 y = t if y is None else y + t
             out.append(torch.relu_(y) if y is not xs[i] else torch.relu(y))
         return out
+
+
+    def _exchange_split(self, xs):
+        """split-precision route (r06): the exchange convolutions hand plain fp32 to ONE pass per receiving branch (tlk_split_fuse_sum: the branch's
+        own planes + the other branches' contributions, nearest up-sampling by index, ReLU, scaled planes out) -- the terms are summed in the
+        order of the fp32 route above"""
+        from .. import _lib
+        states = getattr(self, "_fuse_states", None)
+        out = []
+        for i, row in enumerate(self.fuse):
+            terms = [(xs[j].hi, xs[j].lo, xs[j].state) if j == i else f(xs[j]) for j, f in enumerate(row)]
+            st = states[i] if states is not None else None
+            out.append(SplitAct(*_lib.split_fuse_sum(terms, relu=True, out_state=st, dynamic_batch=True), state=st))
+        return out
+
+    def exchange_outputs_f32(self):
+        """mark the LAST convolution of every exchange path as writing plain fp32 in the split route (its output is a term of the fused sum)"""
+        for i, row in enumerate(self.fuse):
+            for j, f in enumerate(row):
+                if j != i:
+                    (f if isinstance(f, ConvBiasAct) else f[-1]).out_f32 = True
 
 
 class HRNetW32(nn.Module):
@@ -105,8 +130,17 @@ class HRNetW32(nn.Module):
         self.t3 = ConvBiasAct(c[2], c[3], 3, 2, "relu")
         self.stage4 = nn.ModuleList([_HRModule(c) for _ in range(3)])
 
-    def forward(self, x):
-        x = self.layer1(self.stem(x))
+    def hr_modules(self):
+        return list(self.stage2) + list(self.stage3) + list(self.stage4)
+
+    def forward(self, x, split=False, concat=True):
+        """concat=False (split route): the list of branches is returned as it is -- PartBasedReID reduces them branch by branch"""
+        if split:
+            # split-precision route (r06): the RGB convolution in EXACT fp32 (direct stem kernel), (hi, lo) planes from there on
+            x = SplitAct.from_f32(self.stem[0](x), state=getattr(self, "_entry_state", None), dynamic_batch=True)
+            x = self.layer1(self.stem[1](x))
+        else:
+            x = self.layer1(self.stem(x))
         xs = [t(x) for t in self.t1]
         for m in self.stage2:
             xs = m(xs)
@@ -116,6 +150,20 @@ class HRNetW32(nn.Module):
         xs = xs + [self.t3(xs[-1])]
         for m in self.stage4:
             xs = m(xs)
+        if not concat:
+            return xs
+        if isinstance(xs[0], SplitAct):
+            # the concatenation brings four tensors with four plane scales onto ONE: each branch is re-split into its channel slice (one pass each)
+            from .. import _lib
+            n, _, h, w = xs[0].shape
+            hi = torch.empty((n, self.out_channels, h, w), dtype=torch.float16, device=xs[0].hi.device, memory_format=torch.channels_last)
+            lo = torch.empty_like(hi)
+            st, off = getattr(self, "_cat_state", None), 0
+            for t in xs:
+                c = t.shape[1]
+                _lib.split_fuse_sum([(t.hi, t.lo, t.state)], out=(hi[:, off:off + c], lo[:, off:off + c]), out_state=st, dynamic_batch=True)
+                off += c
+            return SplitAct(hi, lo, st)
         size = xs[0].shape[-2:]
         return torch.cat([xs[0]] + [nn.functional.interpolate(t, size=size, mode="nearest") for t in xs[1:]], dim=1)
 
@@ -171,7 +219,8 @@ class PartBasedReID(nn.Module):
 
     def features(self, x):
         """backbone + dimension reduction: (N, D, h, w) feature map the head pools over"""
-        if getattr(self, "split_precision", False) and self.arch == "resnet50" and x.is_cuda and x.dtype == torch.float32:
+        if getattr(self, "split_precision", False) and x.is_cuda and x.dtype == torch.float32 \
+                and (self.arch == "resnet50" or x.is_contiguous(memory_format=torch.channels_last)):
             # fp32 weights, fp32-class arithmetic on the 16-bit MFMA: every convolution of the backbone behind the stem in split mode
             # (csrc/tlk_conv16x.hip; the stem + pool in exact fp32), `reduce` hands fp32 back to the head below
             self.reduce.out_f32 = True
@@ -181,10 +230,25 @@ class PartBasedReID(nn.Module):
             sc = getattr(self, "_split_scales", None)
             if sc is None and USE_SPLIT_SCALES:
                 sc = SplitScales(x.device)
-                layers = [m for m in self.backbone.modules() if isinstance(m, ConvBiasAct) and m is not self.backbone.conv1]
-                self.backbone._entry_state = sc.attach(layers, extra=1)[0]
+                first = self.backbone.conv1 if self.arch == "resnet50" else self.backbone.stem[0]
+                layers = [m for m in self.backbone.modules() if isinstance(m, ConvBiasAct) and m is not first]
+                hrm = self.backbone.hr_modules() if self.arch == "hrnet32" else []
+                extra = sc.attach(layers, extra=2 + sum(len(m.fuse) for m in hrm))
+                self.backbone._entry_state = extra[0]
+                self.backbone._cat_state = extra[1]
+                k = 2
+                for m in hrm:           # HRNet: one state per receiving branch of every exchange unit
+                    m._fuse_states = extra[k:k + len(m.fuse)]
+                    k += len(m.fuse)
                 self._split_scales = sc
-            run = lambda: self.reduce(self.backbone(x, split=True))      # noqa: E731
+            if self.arch == "hrnet32" and not getattr(self, "_hr_split_ready", False):
+                for m in self.backbone.hr_modules():
+                    m.exchange_outputs_f32()
+                self._hr_split_ready = True
+            if self.arch == "hrnet32" and USE_BRANCH_REDUCE:
+                run = lambda: self._reduce_branches(self.backbone(x, split=True, concat=False))      # noqa: E731
+            else:
+                run = lambda: self.reduce(self.backbone(x, split=True))      # noqa: E731
             if sc is None:
                 return run()
             if not sc.calibrated and not torch.cuda.is_current_stream_capturing():
@@ -193,6 +257,37 @@ class PartBasedReID(nn.Module):
             sc.update()
             return f
         return self.reduce(self.backbone(x))                 # (N, D, h, w)
+
+    def _reduce_branches(self, xs):
+        """HRNet, split route (r06): the 1 x 1 dimension reduction over the concatenated branches WITHOUT the concatenation.  A 1 x 1 convolution
+        commutes with nearest up-sampling and is linear in its input channels: reduce(cat(up(x_j))) = W_0 x_0 + sum_j up(W_j x_j) + b.  The
+        low-resolution branches are reduced at THEIR resolution (1/4, 1/16, 1/64 of the pixels), summed onto the high-resolution grid as one plane
+        pair (tlk_split_fuse_sum), and ride into the high-resolution branch's convolution as its residual: the 480-channel tensor (13 GB of planes
+        at 2400 crops, written once and read once) never exists.  The sum is taken in a different order than the concatenated convolution's --
+        fp32 round-off, inside the split route's tolerance (tests/test_gpu_split_hrnet.py)."""
+        from .. import _lib
+        from .common import param_key
+        conv, bias = self.reduce.conv, self.reduce.bias
+        c = getattr(self, "_reduce_parts", None)
+        key = param_key(conv.weight, bias) + tuple(t.shape[1] for t in xs)
+        if c is None or c[0] != key:
+            parts, off = [], 0
+            for t in xs:
+                w = conv.weight.detach().float()[:, off:off + t.shape[1]].contiguous(memory_format=torch.channels_last)
+                parts.append(_lib.split_planes(w))
+                off += t.shape[1]
+            c = (key, parts, bias.detach().float())
+            self._reduce_parts = c
+        parts, b32 = c[1], c[2]
+        low = [_lib.conv2d_nhwc_16(t.hi, parts[j][0], None, None, x_lo=t.lo, weight_lo=parts[j][1], out_f32=True, in_scale=t.state)
+               for j, t in enumerate(xs) if j > 0]
+        n, _, h, w = xs[0].shape
+        st = getattr(self.backbone, "_cat_state", None)
+        rh = torch.empty((n, conv.out_channels, h, w), dtype=torch.float16, device=low[0].device, memory_format=torch.channels_last)
+        rl = torch.empty_like(rh)
+        _lib.split_fuse_sum(low, out=(rh, rl), out_state=st, dynamic_batch=True)
+        return _lib.conv2d_nhwc_16(xs[0].hi, parts[0][0], b32, self.reduce.act, rh, x_lo=xs[0].lo, weight_lo=parts[0][1], residual_lo=rl, out_f32=True,
+                                   in_scale=xs[0].state, res_scale=st)
 
     def fused_head_ok(self, f):
         return USE_TLK_HEADS and f.is_cuda and f.dtype in (torch.float32, torch.float16) and f.shape[1] % 8 == 0 and f.shape[1] <= 512 \
@@ -226,7 +321,7 @@ class PartBasedReID(nn.Module):
 
 
 def part_based_reid(parts=6, dim=256, device="cuda", dtype=torch.float16, channels_last=True, seed=0, arch="resnet50", split_precision=False):
-    """split_precision (with dtype float32, ResNet-50): the backbone's convolutions run in split mode -- fp32 values as (hi, lo) float16 pairs,
+    """split_precision (with dtype float32; ResNet-50, and HRNet-W32 since r06): the backbone's convolutions run in split mode -- fp32 values as (hi, lo) float16 pairs,
     three f16 MFMAs per product pair, fp32 accumulation: fp32-class results at ~5x the fp32 MFMA rate (csrc/tlk_conv16.hip)."""
     m = finalize(random_init_(PartBasedReID(parts, dim, arch=arch), seed), device, dtype, channels_last)
     m.split_precision = bool(split_precision)

@@ -609,7 +609,13 @@ int launch_cfg_x(Conv16Args &a, bool split, int act, int cfg, hipStream_t st)
     case 5: return launch_x<2, 2, 2, 2, MODE_SPLIT, 1, false>(a, act, st);       // 128 x 128, ONE stage
     case 6: return launch_x<4, 2, 1, 2, MODE_SPLIT, 1, false>(a, act, st);       // 128 x 128, 8 wavefronts of 32 x 64, ONE stage
     case 7: return launch_x<4, 2, 1, 2, MODE_SPLIT, 2, false>(a, act, st);       // 128 x 128, 8 wavefronts of 32 x 64, two stages
-    default: return fail(TLK_EINVAL, "tlk_conv16_set_config: split configurations are 1..7");
+    // r06, 32-wide outputs (HRNet-W32's high-resolution branch: 64 of the split forward's 305 launches, 91 of its 245 ms on 64-wide tiles that
+    // multiply 50 % padding): tiles of 32 columns.  A split-mode loader instruction fills 16 rows, so a 32-row B tile allows two wavefronts
+    case 8: return launch_x<2, 1, 4, 1, MODE_SPLIT, 2, false>(a, act, st);       // 256 x 32, two wavefronts of 128 x 32, two stages
+    case 9: return launch_x<2, 1, 4, 1, MODE_SPLIT, 1, false>(a, act, st);       // 256 x 32, ONE stage
+    case 10: return launch_x<2, 1, 2, 1, MODE_SPLIT, 2, false>(a, act, st);      // 128 x 32, two wavefronts of 64 x 32, two stages
+    case 11: return launch_x<2, 1, 2, 1, MODE_SPLIT, 1, false>(a, act, st);      // 128 x 32, ONE stage
+    default: return fail(TLK_EINVAL, "tlk_conv16_set_config: split configurations are 1..11");
     }
 }
 
@@ -716,7 +722,10 @@ int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream
             else if (((a.M + 63) / 64) * ((a.Cout + 127) / 128) >= 192) cfg = 13;
             else cfg = 12;
         } else {
-            if (a.Cout % 256 == 0 && a.K >= 256 && !a.res && ((a.M + 127) / 128) * (a.Cout / 256) >= 512) cfg = 1;
+            // r06 (profiles/r06_conv16_sweep_hrnet_split.txt): outputs of <= 32 channels on 32-column tiles -- a 64-wide tile multiplies 50 % padding there
+            // (HRNet-W32's high-resolution branch, 3 x 3 on 32 channels at 96 x 32: 1.28 -> 0.74 ms, with residual 1.58 -> 0.88, 64 launches per forward)
+            if (a.Cout <= 32) cfg = a.K >= 1024 ? 10 : 11;
+            else if (a.Cout % 256 == 0 && a.K >= 256 && !a.res && ((a.M + 127) / 128) * (a.Cout / 256) >= 512) cfg = 1;
             else if (a.Cout % 128 == 0 && a.K >= 256 && !a.res && ((a.M + 255) / 256) * (a.Cout / 128) >= 512) cfg = 2;
             // r06: the 1 x 1 expansions WITH residual (ResNet's c3: 44 of the split ReID forward's 120 ms sat on the r04 kernel).  128 x 128 tiles of
             // EIGHT wavefronts of 32 x 64 -- 64 accumulator registers per lane, two workgroups' worth of wavefronts per SIMD, residual planes read in the

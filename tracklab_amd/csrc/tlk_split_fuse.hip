@@ -1,0 +1,133 @@
+// tlk_split_fuse.hip -- the element-wise joints of a split-precision network (r06): the sum of up to four tensors brought to one resolution,
+// an optional ReLU, and the result written as scaled (hi, lo) float16 planes -- one HBM pass where the composition of library passes
+// (merge every term to fp32, nearest up-sampling, n - 1 additions, ReLU, split) takes ten.  What HRNet's exchange units
+// (tracklab/configs/modules/reid/bpbreid.yaml:53 backbone "hrnet32") do between their branches, and -- with one term and a channel offset --
+// the concatenation of the branches in front of the part-based head, which has to bring four tensors with four scales onto one.
+//
+// HBM-bound: algorithmic bytes per output element = 4 (planes written) + per term 4 (planes) or 4 (fp32) / 4^shift.
+#include <hip/hip_runtime.h>
+
+#include "tlk.h"
+#include "tlk_conv16.hpp"
+
+using namespace tlk;
+using namespace tlk::c16;
+
+namespace {
+
+constexpr int FUSE_BLOCK = 256;
+constexpr int MAX_TERMS = 4;
+
+struct FuseTerm {
+    const _Float16 *hi, *lo;      // planes (both set), or
+    const float *f32;             // a plain fp32 tensor
+    const float *scale;           // the planes' scale (NULL = 1)
+    int shift;                    // the term lives at (h >> shift, w >> shift): nearest up-sampling by 2^shift
+    int pix;                      // elements between two of its pixels
+};
+
+struct FuseArgs {
+    FuseTerm t[MAX_TERMS];
+    int nt, h, w, c, relu, y_pix;
+    long long n;
+    _Float16 *yhi, *ylo;
+    float *state;                 // {scale of the planes written, recorded maximum} or NULL (scale 1, nothing recorded)
+    const int *n_dyn;             // live image count (tlk_conv_set_dynamic_batch) or NULL
+};
+
+// One item = 8 channels of one output pixel (16 bytes of each plane); consecutive lanes, consecutive 16 bytes.  (A two-items-per-lane form with all
+// loads issued ahead was measured SLOWER, 416 vs 348 us per launch over HRNet-W32's 30 joints: the kernel is not short of loads in flight.)
+__global__ void __launch_bounds__(FUSE_BLOCK) split_fuse_sum_kernel(const FuseArgs p)
+{
+    const int cg = p.c >> 3;
+    long long n = p.n;
+    if (p.n_dyn) { const long long nd = p.n_dyn[0]; n = nd < n ? (nd < 0 ? 0 : nd) : n; }
+    const long long hw = (long long)p.h * p.w;
+    const long long items = n * hw * cg;
+    const float inv = p.state ? 1.f / p.state[0] : 1.f;
+    float sc[MAX_TERMS];
+#pragma unroll
+    for (int t = 0; t < MAX_TERMS; ++t) sc[t] = (t < p.nt && p.t[t].hi && p.t[t].scale) ? p.t[t].scale[0] : 1.f;
+    float am = 0.f;
+    for (long long i = (long long)blockIdx.x * FUSE_BLOCK + threadIdx.x; i < items; i += (long long)gridDim.x * FUSE_BLOCK) {
+        const long long px = i / cg;
+        const int cv = (int)(i - px * cg) * 8;
+        const long long img = px / hw;
+        const int rem = (int)(px - img * hw);
+        const int y = rem / p.w, x = rem - y * p.w;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int t = 0; t < MAX_TERMS; ++t) {
+            if (t >= p.nt) break;
+            const FuseTerm &T = p.t[t];
+            const int s = T.shift, ws = p.w >> s;
+            const long long sp = (img * (p.h >> s) + (y >> s)) * ws + (x >> s);
+            const long long off = sp * T.pix + cv;
+            if (T.hi) {
+                const h16x8 hh = *reinterpret_cast<const h16x8 *>(T.hi + off), ll = *reinterpret_cast<const h16x8 *>(T.lo + off);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += ((float)hh[k] + (float)ll[k] * LO_INV) * sc[t];
+            } else {
+                const float4 a = *reinterpret_cast<const float4 *>(T.f32 + off), b = *reinterpret_cast<const float4 *>(T.f32 + off + 4);
+                acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+                acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+            }
+        }
+        h16x8 oh, ol;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = acc[k];
+            if (p.relu) v = v < 0.f ? 0.f : v;              // (lets NaN through, like torch.relu)
+            am = fmaxf(am, fabsf(v));
+            _Float16 a, b;
+            split_f32(v * inv, a, b);
+            oh[k] = a; ol[k] = b;
+        }
+        const long long yo = px * p.y_pix + cv;
+        *reinterpret_cast<h16x8 *>(p.yhi + yo) = oh;
+        *reinterpret_cast<h16x8 *>(p.ylo + yo) = ol;
+    }
+    if (p.state) record_amax(p.state + 1, am);
+}
+
+}  // namespace
+
+extern "C" int tlk_split_fuse_sum(int n_terms, const void *const *hi_dev, const void *const *lo_dev, const float *const *f32_dev,
+                                  const float *const *scale_dev, const int *shift, const int *pix_stride, int n, int h, int w, int c, int relu,
+                                  void *y_hi_dev, void *y_lo_dev, int y_pix_stride, float *out_state_dev, int dynamic_batch, void *hip_stream)
+{
+    if (n_terms < 1 || n_terms > MAX_TERMS) return fail(TLK_EINVAL, "tlk_split_fuse_sum: 1..4 terms");
+    if (n < 0 || h <= 0 || w <= 0 || c <= 0 || c % 8 != 0) return fail(TLK_EINVAL, "tlk_split_fuse_sum: bad shape (channels a multiple of 8)");
+    if (!hi_dev || !lo_dev || !f32_dev || !shift) return fail(TLK_EINVAL, "tlk_split_fuse_sum: null term table");
+    if (n == 0) return TLK_OK;
+    if (!y_hi_dev || !y_lo_dev) return fail(TLK_EINVAL, "tlk_split_fuse_sum: no output");
+    FuseArgs a{};
+    a.nt = n_terms; a.n = n; a.h = h; a.w = w; a.c = c; a.relu = relu ? 1 : 0;
+    a.y_pix = y_pix_stride > 0 ? y_pix_stride : c;
+    a.yhi = (_Float16 *)y_hi_dev; a.ylo = (_Float16 *)y_lo_dev; a.state = out_state_dev;
+    a.n_dyn = dynamic_batch ? conv_dynamic_batch() : nullptr;
+    uintptr_t align = (uintptr_t)y_hi_dev | (uintptr_t)y_lo_dev;
+    if (a.y_pix < c || a.y_pix % 8 != 0) return fail(TLK_EINVAL, "tlk_split_fuse_sum: the output's pixel stride must cover the channels and be a multiple of 8");
+    for (int t = 0; t < n_terms; ++t) {
+        FuseTerm &T = a.t[t];
+        T.hi = (const _Float16 *)hi_dev[t]; T.lo = (const _Float16 *)lo_dev[t]; T.f32 = f32_dev[t];
+        T.scale = scale_dev ? scale_dev[t] : nullptr;
+        T.shift = shift[t];
+        T.pix = pix_stride && pix_stride[t] > 0 ? pix_stride[t] : c;
+        if ((T.hi != nullptr) != (T.lo != nullptr) || (T.hi != nullptr) == (T.f32 != nullptr))
+            return fail(TLK_EINVAL, "tlk_split_fuse_sum: a term is a (hi, lo) plane pair or one fp32 tensor");
+        if (T.shift < 0 || T.shift > 8 || (h >> T.shift) << T.shift != h || (w >> T.shift) << T.shift != w)
+            return fail(TLK_EINVAL, "tlk_split_fuse_sum: a term's resolution must divide the output's by a power of two");
+        if (T.pix < c || T.pix % 8 != 0) return fail(TLK_EINVAL, "tlk_split_fuse_sum: a term's pixel stride must cover the channels and be a multiple of 8");
+        align |= (uintptr_t)T.hi | (uintptr_t)T.lo | (uintptr_t)T.f32;
+    }
+    if (align & 15) return fail(TLK_EINVAL, "tlk_split_fuse_sum: every pointer must be 16-byte aligned");
+    const long long items = (long long)n * h * w * (c / 8);
+    long long blocks = (items + FUSE_BLOCK - 1) / FUSE_BLOCK;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(split_fuse_sum_kernel, dim3((unsigned)blocks), dim3(FUSE_BLOCK), 0, (hipStream_t)hip_stream, a);
+    TLK_HIP(hipGetLastError());
+    return TLK_OK;
+}
