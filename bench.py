@@ -1126,6 +1126,11 @@ def main():
                 e0 = emb_hr[0].astype(np.float64)
                 hrnet_split_leg["max_abs_embedding_difference_vs_exact_fp32"] = float(np.abs(emb_hs[0][valid] - e0[valid]).max() / (float(np.abs(e0[valid]).max()) or 1.0))
                 hrnet_split_leg["speedup_vs_exact_fp32"] = hrnet_split_leg["value"] / hrnet_leg["value"]
+                hrnet_split_leg["note"] = ("same arithmetic as value_f32_split (tests/test_gpu_conv16.py: the exact kernel's fp64 bound on every split tile "
+                                           "configuration; tests/test_gpu_split_hrnet.py: features within 2e-5 of the exact network's, cos <= 1e-6).  The embedding "
+                                           "difference above is larger than ResNet-50's because random-init HRNet-W32 puts ~300 x larger features in front of the part "
+                                           "classifier's soft-max: the EXACT network moves by the same amount when its inputs are perturbed by a relative 2^-22 "
+                                           "(profiles/r06_split_conditioning.txt)")
             except Exception as ex:                             # noqa: BLE001
                 hrnet_split_leg = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 

@@ -142,3 +142,46 @@ def test_hrnet32_split_mode_beyond_float16s_range():
     assert float((fa - fb).abs().max()) <= 2e-5 * float(fa.abs().max())
     sc = split._split_scales.buf[:, 0].cpu().numpy()
     assert sc.max() > 1 and np.all(np.log2(sc) == np.round(np.log2(sc)))
+
+
+def test_pipeline_with_hrnet32_in_split_mode_keeps_the_oracles_ids(orc):
+    """the fused step (hipGraph, dense dynamic ReID batch) with the yaml's backbone in split mode and the detector in split mode: the tracker's rows
+    equal the oracle chain's on the embeddings the step produced, and those embeddings are the exact-fp32 pipeline's to cos 1e-6"""
+    import torch
+    from tracklab_amd import gpu_pipeline as gp
+    from tracklab_amd.synth import SyntheticStream, render_frame, synth_yolox_head
+    from test_gpu_pipeline_configs import _detector_rows
+    F, steps, nobj, maxd = 4, 3, 40, 48
+    kw = dict(n_streams=1, frames_per_step=F, max_dets=maxd, use_graph=True, dtype=torch.float32, reid_arch="hrnet32")
+    pipe = gp.DetReidTrackPipeline("m", reid_split_precision=True, detector_split_precision=True, **kw)
+    exact = gp.DetReidTrackPipeline("m", **kw)
+    assert pipe.reid.split_precision and pipe.reid.arch == "hrnet32" and pipe.check_finite
+    rng = np.random.default_rng(21)
+    stream = list(SyntheticStream(8, nobj, F * steps))
+    heads = np.stack([synth_yolox_head(rng, fr["dets"][:, :4], ratio=pipe.ratio) for fr in stream])
+    d_frames = torch.from_numpy(np.stack([render_frame(rng, stream[i]["gt_boxes"]) for i in range(F)])).cuda()
+    d_heads = torch.from_numpy(heads).cuda().reshape(steps, F, -1, 6)
+    ref = orc.StrongSORT(pipe.K, pipe.D, **pipe.tracker_cfg)
+    for k in range(steps):
+        h_rows, h_cnt = pipe.step(d_frames, d_heads[k])
+        pipe.synchronize()
+        exact.step(d_frames, d_heads[k])
+        exact.synchronize()
+        rows, _ = pipe.rows_numpy(h_rows, h_cnt)
+        emb = pipe.last["emb"].cpu().numpy().reshape(F, maxd, pipe.K, pipe.D)
+        vis = pipe.last["vis"].cpu().numpy().reshape(F, maxd, pipe.K)
+        emb_x = exact.last["emb"].cpu().numpy().reshape(F, maxd, pipe.K, pipe.D)
+        for f in range(F):
+            ltwh = _detector_rows(orc, heads[k * F + f], pipe.ratio)
+            n = len(ltwh)
+            exp = ref.update((k * F + f) * maxd + np.arange(n), ltwh.astype(np.float64), emb[f, :n], vis[f, :n], np.ones(n))
+            got = rows[0][f]
+            assert len(got) == len(exp)
+            np.testing.assert_array_equal(got["det_id"], exp["det_id"])
+            np.testing.assert_array_equal(got["track_id"], exp["track_id"])
+            a, b = emb[f, :n].reshape(n, -1).astype(np.float64), emb_x[f, :n].reshape(n, -1).astype(np.float64)
+            cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+            assert float((1 - cos).max()) <= 1e-6
+    sc = pipe.reid._split_scales
+    assert sc is not None and sc.calibrated
+    pipe.close(); exact.close()

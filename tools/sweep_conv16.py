@@ -78,7 +78,10 @@ L = _lib.lib()
 _lib._bind_conv16(L)
 CFGS = [-1] + list(range(1, 12 if split else 23))
 tot_default = tot_best = 0.0
+ONLY_COUT = int(os.environ.get("SWEEP_ONLY_COUT", "0"))      # e.g. 64: only the layers with that many output channels
 for key, (count,) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
+    if ONLY_COUT and key[1][0] != ONLY_COUT:
+        continue
     xs, ws, act, res, stride, pad, sp, of32, raa, s_in, s_res, s_out = key
     cl = lambda t: t.contiguous(memory_format=torch.channels_last)          # noqa: E731
     x = cl(torch.randn(xs, device=dev).half()); xl = cl(torch.randn(xs, device=dev).half() * 0.01) if sp else None

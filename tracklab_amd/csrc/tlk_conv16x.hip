@@ -615,6 +615,8 @@ int launch_cfg_x(Conv16Args &a, bool split, int act, int cfg, hipStream_t st)
     case 9: return launch_x<2, 1, 4, 1, MODE_SPLIT, 1, false>(a, act, st);       // 256 x 32, ONE stage
     case 10: return launch_x<2, 1, 2, 1, MODE_SPLIT, 2, false>(a, act, st);      // 128 x 32, two wavefronts of 64 x 32, two stages
     case 11: return launch_x<2, 1, 2, 1, MODE_SPLIT, 1, false>(a, act, st);      // 128 x 32, ONE stage
+    // (64-column tiles of two wavefronts -- 128 x 64 in one / two stages, 256 x 64 in one -- were measured on HRNet's 64-channel branch and gained
+    //  nothing over 4 / the r04 kernel: 68.2 vs 69.5 ms over its 64-wide layers; not kept)
     default: return fail(TLK_EINVAL, "tlk_conv16_set_config: split configurations are 1..11");
     }
 }
@@ -733,7 +735,8 @@ int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream
             // (1.40 vs 1.45 on 256 -> 1024, 4.08 vs 4.37 on 512 -> 2048; profiles/r06_split_res_probe.txt)
             else if (a.res && a.Cout % 128 == 0 && ((a.M + 127) / 128) * (a.Cout / 128) >= 512) cfg = a.K <= 128 ? 6 : 7;
             // ... and the 3 x 3 layers on 64 channels (ResNet's layer 1): 256 x 64 tiles of four 64 x 64 wavefronts, 2.57 vs 2.80 ms (profiles/r06_split_l1_probe.txt)
-            else if (!a.res && a.KH == 3 && a.Cout == 64 && (a.M + 255) / 256 >= 768) cfg = 4;
+            // (stride 2 with a short K loop -- HRNet's 32 > 64 and 64 > 64 down-sampling steps -- stays on the r04 kernel: 0.45 vs 0.53 ms)
+            else if (!a.res && a.KH == 3 && a.Cout == 64 && (a.M + 255) / 256 >= 768 && (a.stride == 1 || a.K >= 1024)) cfg = 4;
             // r06 (tools/sweep_conv16.py, profiles/r06_conv16_sweep.txt): the detector's layers in split mode -- a few hundred tiles, widths of 96 ... 768 --
             // all sat on the r04 kernel; the eight-wavefront 128 x 128 tile with two stages is 8-40 % faster on every one of them (YOLOX-m, 24 frames:
             // 10.2 -> 9.0 ms per forward) and within 5-12 % of the best configuration of each
