@@ -53,3 +53,17 @@ def test_integration_md_indexes_every_entry_point_with_its_header_section():
     assert not missing, f"not in the C ABI index: {missing}"
     assert subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_abi_index.py"), "--check"]).returncode == 0, \
         "INTEGRATION.md's C ABI index is stale: python tools/gen_abi_index.py"
+
+
+def test_split_fuse_sum_validates_its_arguments_before_touching_a_device():
+    """tlk_split_fuse_sum (r06): the shape / term-table checks are host code and come first -- callable without a GPU"""
+    from tracklab_amd import _lib
+    L = _lib.lib()
+    _lib._bind_conv16(L)
+    P, I = ctypes.c_void_p * 1, ctypes.c_int * 1
+    none, zero = P(None), I(0)
+    args = lambda n_terms, c, shift: (n_terms, none, none, none, none, I(shift), zero, 1, 8, 8, c, 0, None, None, 0, None, 0, None)      # noqa: E731
+    assert L.tlk_split_fuse_sum(*args(0, 8, 0)) == -1 and b"1..4 terms" in L.tlk_last_error()
+    assert L.tlk_split_fuse_sum(*args(5, 8, 0)) == -1
+    assert L.tlk_split_fuse_sum(*args(1, 12, 0)) == -1 and b"multiple of 8" in L.tlk_last_error()
+    assert L.tlk_split_fuse_sum(*args(1, 8, 0)) == -1 and b"no output" in L.tlk_last_error()
