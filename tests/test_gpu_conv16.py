@@ -128,8 +128,8 @@ def _force16(cfg):
     _lib.check(L.tlk_conv16_set_config(cfg))
 
 
-@pytest.mark.parametrize("cfg", list(range(1, 17)))
-@pytest.mark.parametrize("shape", X_SHAPES)
+@pytest.mark.parametrize("cfg", list(range(1, 17)) + [25, 26])          # (25 / 26, r06: the 32-column tiles)
+@pytest.mark.parametrize("shape", X_SHAPES + [(3, 64, 24, 8, 32, 1, 1, False)])
 def test_every_f16_tile_configuration_of_the_direct_to_lds_kernels(shape, cfg):
     """one / two / three / four LDS stages, 64 x 64 ... 256 x 256 tiles, residual prefetched or not: the same fp32-accumulated f16 convolution
     (ragged M and Cout, taps outside the image, strides), to the bound of the r04 kernels' test above"""
@@ -156,8 +156,8 @@ HALF_SHAPES = [(4, 96, 20, 20, 96, 3, 1, True), (2, 96, 40, 40, 192, 1, 1, False
                (1, 288, 10, 10, 96, 3, 1, False)]
 
 
-@pytest.mark.parametrize("cfg", [0, 19, 20, 21, 22])
-@pytest.mark.parametrize("shape", HALF_SHAPES)
+@pytest.mark.parametrize("cfg", [0, 19, 20, 21, 22, 23, 24])
+@pytest.mark.parametrize("shape", HALF_SHAPES + [(3, 32, 24, 8, 32, 3, 1, True)])
 def test_f16_half_step_tiles(shape, cfg):
     """conv16x_kernel<..., ROWB = 64>: 64-byte LDS rows, 32 halfs per K step; cfg 0 = the heuristic, which routes these shapes to them (they used to
     fall to the r04 register-staged kernel's general loader)"""
@@ -186,7 +186,11 @@ def test_f16_half_step_tiles(shape, cfg):
 
 # (n, cin, h, w, cout, k, stride, residual, split) at sizes where the r06 rules of the sweep apply -> the configuration the heuristic must pick
 R06_ROUTES16 = [
-    ((40, 32, 96, 32, 32, 3, 1, True, False), 19),      # half-step K, <= 64 outputs: 64 x 64 tiles whatever the launch size (HRNet's 32-channel branch)
+    ((40, 32, 96, 32, 32, 3, 1, True, False), 23),      # half-step K, <= 32 outputs, >= 2 tiles per CU: 128 x 32 tiles of two wavefronts (HRNet's 32-channel branch)
+    ((2, 32, 96, 32, 32, 3, 1, True, False), 19),       # ... a small launch of the same layer: 64 x 64 tiles, four stages
+    ((100, 64, 48, 16, 32, 1, 1, False, False), 25),    # full-step K < 1024 into 32 channels (the exchange paths): 128 x 32, one stage
+    ((40, 32, 96, 32, 32, 3, 1, True, True), 11),       # split mode, <= 32 outputs: 128 x 32, one stage
+    ((40, 256, 96, 32, 32, 3, 1, False, True), 10),     # ... on a long K loop: the two-stage form
     ((24, 96, 80, 80, 48, 1, 1, False, False), 19),
     ((40, 256, 96, 32, 32, 3, 1, False, False), 16),    # 32 wide on a full K step: 64 x 64 tiles
     ((200, 192, 16, 12, 192, 3, 1, False, False), 10),  # 192 wide = three 64-wide tiles: 256 x 64, one stage

@@ -98,7 +98,7 @@ while time.time() - t0 < budget:
         if res:
             ref = ref + r.float()
         ref = torch.relu(ref) if act == "relu" else (F.silu(ref) if act == "silu" else ref)
-        for cfg in [-1, 0] + list(rng.choice(np.arange(1, 23), size=4, replace=False)):      # (r06: 19..22 = the half-step tiles; a configuration that does not take the shape declines)
+        for cfg in [-1, 0] + list(rng.choice(np.arange(1, 27), size=4, replace=False)):      # (r06: 19..22 = the half-step tiles; a configuration that does not take the shape declines)
             if L.tlk_conv16_set_config(int(cfg)) != 0:
                 continue
             try:

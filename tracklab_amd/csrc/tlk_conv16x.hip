@@ -598,7 +598,12 @@ int launch_cfg_x(Conv16Args &a, bool split, int act, int cfg, hipStream_t st)
         case 20: return launch_x<2, 2, 2, 2, MODE_F16, 1, true, 64>(a, act, st);     // 128 x 128, ONE stage, residual prefetched
         case 21: return launch_x<2, 2, 1, 2, MODE_F16, 3, true, 64>(a, act, st);     // 64 x 128, three stages
         case 22: return launch_x<2, 2, 2, 2, MODE_F16, 2, true, 64>(a, act, st);     // 128 x 128, two stages
-        default: return fail(TLK_EINVAL, "tlk_conv16_set_config: f16 configurations are 1..22");
+        // r06: 32-COLUMN tiles (outputs of <= 32 channels: HRNet-W32's high-resolution branch and the exchange paths into it), as in split mode
+        case 23: return launch_x<2, 1, 2, 1, MODE_F16, 1, true, 64>(a, act, st);     // half step: 128 x 32, two wavefronts of 64 x 32, ONE stage
+        case 24: return launch_x<2, 1, 2, 1, MODE_F16, 2, true, 64>(a, act, st);     // half step: 128 x 32, two stages
+        case 25: return launch_x<2, 1, 2, 1, MODE_F16, 1, true>(a, act, st);         // full step: 128 x 32, two wavefronts, ONE stage
+        case 26: return launch_x<4, 1, 2, 1, MODE_F16, 1, true>(a, act, st);         // full step: 256 x 32, four wavefronts of 64 x 32, ONE stage
+        default: return fail(TLK_EINVAL, "tlk_conv16_set_config: f16 configurations are 1..26");
         }
     }
     switch (cfg) {
@@ -672,12 +677,12 @@ int g_last_cfg16x = -1;      // tlk_conv16_last_config: the tile configuration o
 int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream_t st)
 {
     (void)out32;
-    const bool half_cfg = !split && cfg >= 19 && cfg <= 22;
-    // f16 layers whose Cin is a multiple of 32 but not of 64 take the half-step tiles (19..22); a forced full-step configuration on such a layer is refused
+    const bool half_cfg = !split && cfg >= 19 && cfg <= 24;
+    // f16 layers whose Cin is a multiple of 32 but not of 64 take the half-step tiles (19..24); a forced full-step configuration on such a layer is refused
     const bool half_step = !split && a.Cin % 32 == 0 && a.Cin % 64 != 0;
     const int bke = (split || half_step || half_cfg) ? 32 : 64;
     if (a.Cin % bke != 0 || a.K % bke != 0) return cfg > 0 ? fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: the large-tile kernels need Cin to be a multiple of the K step") : 1;
-    if (cfg > 0 && !split && half_step && !half_cfg) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: Cin is a multiple of 32 but not of 64: half-step tile configurations 19..22 only");
+    if (cfg > 0 && !split && half_step && !half_cfg) return fail(TLK_EINVAL, "tlk_conv2d_nhwc_16: Cin is a multiple of 32 but not of 64: half-step tile configurations 19..24 only");
     // every offset the loader forms stays below 2^31: the rows of one tile + their halo, and the weights
     {
         const long long span_rows = 512 / (a.Wo > 0 ? a.Wo : 1) + a.KH + 2;
@@ -697,7 +702,10 @@ int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream
             // r06 (tools/sweep_conv16.py, profiles/r06_conv16_sweep.txt): narrow outputs on the 64 x 64 tile whatever the launch size -- a 128-wide tile
             // multiplies 75 % padding on 32 channels (HRNet's high-resolution branch, 64 launches per forward: 0.83 -> 0.67 ms, with residual 0.91 -> 0.76;
             // YOLOX-m's / CSPNeXt's 96 > 48 layers 0.84 -> 0.60)
-            if (a.Cout <= 64) cfg = 19;
+            // r06, second sweep (profiles/r06_conv16_sweep_hrnet_f16_32wide.txt): <= 32 outputs on 32-COLUMN tiles of two wavefronts where the launch has
+            // at least two of them per CU -- HRNet's 3 x 3 / 32 at 96 x 32: 0.67 -> 0.35 ms, with residual 0.75 -> 0.40 (64 launches per forward)
+            if (a.Cout <= 32 && (a.M + 127) / 128 >= 512) cfg = 23;
+            else if (a.Cout <= 64) cfg = 19;
             else if (t128h >= 384) cfg = 20;
             else if (t128h >= 256) cfg = 22;
             else if (((a.M + 63) / 64) * ((a.Cout + 127) / 128) >= 192) cfg = 21;
@@ -709,6 +717,7 @@ int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream
             const bool patch_ok = a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin == 64 && a.H == a.Ho && a.W == a.Wo && a.Wo >= 8 && a.Wo <= 64 &&
                                   128 % a.Wo == 0 && ((long long)a.Ho * a.Wo) % 256 == 0 && a.Cout % 64 == 0;
             if (patch_ok) cfg = ((a.M + 255) / 256 >= 768) ? 17 : 18;
+            else if (a.Cout <= 32 && a.K < 1024 && (a.M + 127) / 128 >= 512) cfg = 25;      // (the exchange paths' 1 x 1 into 32 channels: 0.121 -> 0.069 ms)
             else if (a.Cout <= 32) cfg = 16;                // r06 sweep: 32 wide -> 64 x 64 tiles (HRNet's 256 > 32 fuse layers 4.06 -> 2.90 ms)
             else if (a.Cout <= 64) cfg = ((a.M + 255) / 256 >= 768) ? (a.res ? 7 : 10) : 12;
             else if (a.Cout % 256 == 0 && a.K >= 1024 && !a.res && tiles256 >= 512) cfg = 1;
