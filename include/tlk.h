@@ -723,7 +723,7 @@ int tlk_conv16_set_glds(int on);
  * one to four LDS stages with counted waits, residual prefetched into registers).  cfg 0 (default) = they take the shapes their launch-size
  * heuristic claims (cin a multiple of the K step: 64 in f16 mode, 32 in split mode) and the r04 kernels the rest; -1 = r04 kernels only;
  * 1..26 (f16; 23..26 = 32-column tiles, 23 / 24 half-step; 17 / 18 = the patch-resident 3 x 3 kernel: stride 1, exactly 64 channels, whole image rows per tile; r06: 19..22 = the HALF-STEP
- * tiles, K step 32 halfs, for cin a multiple of 32 but not of 64 -- the only ones such a layer accepts) / 1..11 (split; 8..11: 32-column tiles) = force one
+ * tiles, K step 32 halfs, for cin a multiple of 32 but not of 64 -- the only ones such a layer accepts) / 1..12 (split; 8..12: 32-column tiles) = force one
  * tile configuration (probes / tests).  Same arithmetic contract as above in every configuration.  r06: in split mode the heuristic also
  * takes the 1 x 1 expansions WITH residual (128 x 128 tiles of eight 32 x 64 wavefronts, configurations 6 / 7). */
 int tlk_conv16_set_config(int cfg);

@@ -190,7 +190,7 @@ R06_ROUTES16 = [
     ((2, 32, 96, 32, 32, 3, 1, True, False), 19),       # ... a small launch of the same layer: 64 x 64 tiles, four stages
     ((100, 64, 48, 16, 32, 1, 1, False, False), 25),    # full-step K < 1024 into 32 channels (the exchange paths): 128 x 32, one stage
     ((40, 32, 96, 32, 32, 3, 1, True, True), 11),       # split mode, <= 32 outputs: 128 x 32, one stage
-    ((40, 256, 96, 32, 32, 3, 1, False, True), 10),     # ... on a long K loop: the two-stage form
+    ((40, 256, 96, 32, 32, 3, 1, False, True), 12),     # ... on a long K loop: three stages
     ((24, 96, 80, 80, 48, 1, 1, False, False), 19),
     ((40, 256, 96, 32, 32, 3, 1, False, False), 16),    # 32 wide on a full K step: 64 x 64 tiles
     ((200, 192, 16, 12, 192, 3, 1, False, False), 10),  # 192 wide = three 64-wide tiles: 256 x 64, one stage
@@ -273,8 +273,8 @@ def test_f16_patch_resident_3x3_kernel(shape, cfg):
     assert bool((err <= ref.abs() * 2.0 ** -11 + 2e-6 * bound + 1e-7).all()), float((err / (ref.abs() + 1e-3)).max())
 
 
-# (8..11, r06: the 32-column tiles of HRNet-W32's high-resolution branch -- with a 32-channel layer, with and without residual, and a ragged Cout)
-@pytest.mark.parametrize("cfg", list(range(1, 12)))
+# (8..12, r06: the 32-column tiles of HRNet-W32's high-resolution branch -- with a 32-channel layer, with and without residual, and a ragged Cout)
+@pytest.mark.parametrize("cfg", list(range(1, 13)))
 @pytest.mark.parametrize("shape", [X_SHAPES[0], X_SHAPES[1], X_SHAPES[2], X_SHAPES[3], (3, 32, 24, 8, 32, 3, 1, True), (2, 64, 13, 7, 40, 3, 2, False)])
 def test_every_split_tile_configuration_is_fp32_class(shape, cfg):
     from tracklab_amd import _lib

@@ -130,7 +130,7 @@ while time.time() - t0 < budget:
         states = torch.zeros((3, 2), device="cuda"); states[:, 0] = 1.0
         changed = torch.zeros(1, dtype=torch.int32, device="cuda")
         wh, wl = _lib.split_planes(wt)
-        for cfg in [-1, 0] + list(rng.choice(np.arange(1, 12), size=3, replace=False)):
+        for cfg in [-1, 0] + list(rng.choice(np.arange(1, 13), size=3, replace=False)):
             if L.tlk_conv16_set_config(int(cfg)) != 0:
                 continue
             try:

@@ -1,5 +1,5 @@
 """Probe (not product): every distinct 16-bit convolution (f16 or split precision) of a network, timed under the tile configuration the heuristic of
-tlk_conv2d_nhwc_16 picks and under every configuration tlk_conv16_set_config can force (-1: the r04 kernels, 1..26 f16 / 1..11 split).
+tlk_conv2d_nhwc_16 picks and under every configuration tlk_conv16_set_config can force (-1: the r04 kernels, 1..26 f16 / 1..12 split).
 
     python tools/sweep_conv16.py f16 reid 2211        # part-based ReID ResNet-50, f16
     python tools/sweep_conv16.py split reid 2211      # the same in split precision (scaled (hi, lo) planes)
@@ -76,7 +76,7 @@ def timed(fn, n):
 
 L = _lib.lib()
 _lib._bind_conv16(L)
-CFGS = [-1] + list(range(1, 12 if split else 27))
+CFGS = [-1] + list(range(1, 13 if split else 27))
 tot_default = tot_best = 0.0
 ONLY_COUT = int(os.environ.get("SWEEP_ONLY_COUT", "0"))      # e.g. 64: only the layers with that many output channels
 for key, (count,) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):

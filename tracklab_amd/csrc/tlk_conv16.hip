@@ -726,7 +726,7 @@ extern "C" int tlk_conv16_set_config(int cfg)
     return TLK_OK;
 }
 
-// the tile configuration the most recent tlk_conv2d_nhwc_16 / _16s call launched (1..26 f16, 1..11 split), -1 = the r04 kernels
+// the tile configuration the most recent tlk_conv2d_nhwc_16 / _16s call launched (1..26 f16, 1..12 split), -1 = the r04 kernels
 extern "C" int tlk_conv16_last_config(void) { return c16::g_last_cfg16x; }
 
 static int split_planes_entry(const float *x_dev, long long pixels, int c_in, int x_pix_stride, int c_out, void *hi_dev, void *lo_dev, float *state_dev,

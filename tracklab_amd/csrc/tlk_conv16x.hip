@@ -622,7 +622,9 @@ int launch_cfg_x(Conv16Args &a, bool split, int act, int cfg, hipStream_t st)
     case 11: return launch_x<2, 1, 2, 1, MODE_SPLIT, 1, false>(a, act, st);      // 128 x 32, ONE stage
     // (64-column tiles of two wavefronts -- 128 x 64 in one / two stages, 256 x 64 in one -- were measured on HRNet's 64-channel branch and gained
     //  nothing over 4 / the r04 kernel: 68.2 vs 69.5 ms over its 64-wide layers; not kept)
-    default: return fail(TLK_EINVAL, "tlk_conv16_set_config: split configurations are 1..11");
+    case 12: return launch_x<2, 1, 2, 1, MODE_SPLIT, 3, false>(a, act, st);      // 128 x 32, THREE stages: the long K loops (3 x 3 on 256 channels into 32: 8.24 -> 6.91 ms)
+    // (one-wavefront 64 x 32 / 128 x 32 tiles were measured too: 5-25 % behind 11 on the 3 x 3 / 32 layers; not kept)
+    default: return fail(TLK_EINVAL, "tlk_conv16_set_config: split configurations are 1..12");
     }
 }
 
@@ -735,7 +737,7 @@ int launch16x(Conv16Args &a, bool split, bool out32, int act, int cfg, hipStream
         } else {
             // r06 (profiles/r06_conv16_sweep_hrnet_split.txt): outputs of <= 32 channels on 32-column tiles -- a 64-wide tile multiplies 50 % padding there
             // (HRNet-W32's high-resolution branch, 3 x 3 on 32 channels at 96 x 32: 1.28 -> 0.74 ms, with residual 1.58 -> 0.88, 64 launches per forward)
-            if (a.Cout <= 32) cfg = a.K >= 1024 ? 10 : 11;
+            if (a.Cout <= 32) cfg = a.K >= 1024 ? 12 : 11;
             else if (a.Cout % 256 == 0 && a.K >= 256 && !a.res && ((a.M + 127) / 128) * (a.Cout / 256) >= 512) cfg = 1;
             else if (a.Cout % 128 == 0 && a.K >= 256 && !a.res && ((a.M + 255) / 256) * (a.Cout / 128) >= 512) cfg = 2;
             // r06: the 1 x 1 expansions WITH residual (ResNet's c3: 44 of the split ReID forward's 120 ms sat on the r04 kernel).  128 x 128 tiles of
