@@ -914,14 +914,15 @@ def main():
         mfma_tf = 3.0 * flop32 / (ms * 1e-3) / 1e12
         groups = {}
         for r in sp:
-            g_ = groups.setdefault("1 x 1 expansions with residual" if r[5][2] else "no residual", [0, 0.0, 0.0])
+            res_kind = "1 x 1 expansions with residual" if getattr(p_.reid, "arch", "resnet50") == "resnet50" else "with residual (the basic blocks' second 3 x 3, layer 1's expansions)"
+            g_ = groups.setdefault(res_kind if r[5][2] else "no residual", [0, 0.0, 0.0])
             g_[0] += 1; g_[1] += r[0].elapsed_time(r[1]) - r[2].elapsed_time(r[3]); g_[2] += r[4]
         scales = getattr(p_.reid, "_split_scales", None)
         return {"kernel": "conv16x_kernel / conv16_glds_kernel / conv16_mfma_kernel in split mode (tlk_conv2d_nhwc_16s: three v_mfma_f32_32x32x16_f16 per operand pair, "
                           "two fp32 accumulators, scaled (hi, lo) planes)",
                 "bound": "mfma", "achieved": mfma_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": mfma_tf / 2500.0, "traffic": None,
                 "what_is_counted": "f16 MFMA flops executed = 3 x the algorithmic flops of the fp32 convolutions the launches stand for (live crops only); the "
-                                   "exact-fp32 stem + pool ahead of the planes and the detector are not in this block",
+                                   "exact-fp32 RGB stem (ResNet-50: + its pool) ahead of the planes and the detector are not in this block",
                 "fp32_equivalent_tflops": flop32 / (ms * 1e-3) / 1e12, "launches_per_step": len(sp) // 2, "conv_ms_per_step": ms / 2,
                 "algorithmic_tflop_per_step_fp32": flop32 / 2 / 1e12, "algorithmic_bytes_per_step": nbytes / 2,
                 "bytes_per_s_algorithmic_GB": nbytes / (ms * 1e-3) / 1e9,
@@ -1118,7 +1119,8 @@ def main():
         if "error" not in hrnet_leg:
             try:
                 hrnet_split_leg, emb_hs = precision_leg("f32 weights and activations as (hi, lo) f16 pairs (split precision, scaled planes), ReID backbone "
-                                                        "HRNet-W32 (bpbreid.yaml:53) AND the detector", "f32", True, reid_arch="hrnet32", split_detector=True)
+                                                        "HRNet-W32 (bpbreid.yaml:53) AND the detector", "f32", True, reid_arch="hrnet32", split_detector=True,
+                                                        with_roofline=split_roofline)
                 import oracle
                 valid = np.zeros(emb_hr[0].shape[:2], dtype=bool)
                 for f in range(F):
@@ -1126,6 +1128,9 @@ def main():
                 e0 = emb_hr[0].astype(np.float64)
                 hrnet_split_leg["max_abs_embedding_difference_vs_exact_fp32"] = float(np.abs(emb_hs[0][valid] - e0[valid]).max() / (float(np.abs(e0[valid]).max()) or 1.0))
                 hrnet_split_leg["speedup_vs_exact_fp32"] = hrnet_split_leg["value"] / hrnet_leg["value"]
+                if isinstance(hrnet_split_leg.get("roofline"), dict):
+                    hrnet_split_leg["roofline"]["scope"] = ("the backbone's split convolutions (ConvBiasAct route); the four branch-wise reduce launches and the "
+                                                            "tlk_split_fuse_sum joints (HBM-bound, 0.64 of 8 TB/s: profiles/r06_split_fuse_traffic.txt) are not in it")
                 hrnet_split_leg["note"] = ("same arithmetic as value_f32_split (tests/test_gpu_conv16.py: the exact kernel's fp64 bound on every split tile "
                                            "configuration; tests/test_gpu_split_hrnet.py: features within 2e-5 of the exact network's, cos <= 1e-6).  The embedding "
                                            "difference above is larger than ResNet-50's because random-init HRNet-W32 puts ~300 x larger features in front of the part "
