@@ -716,6 +716,13 @@ int tlk_split_scale_update(float *states_dev, int n_states, int *changed_dev, vo
 int tlk_split_fuse_sum(int n_terms, const void *const *hi_dev, const void *const *lo_dev, const float *const *f32_dev,
                        const float *const *scale_dev, const int *shift, const int *pix_stride, int n, int h, int w, int c, int relu,
                        void *y_hi_dev, void *y_lo_dev, int y_pix_stride, float *out_state_dev, int dynamic_batch, void *hip_stream);
+/* The same joint for the EXACT fp32 route (same kernel, fp32 terms and fp32 output): y = [relu](((x_0 + x_1) + x_2) + x_3), term t an fp32 NHWC tensor at
+ * (h >> shift[t], w >> shift[t]) -- the association and rounding of torch's `y = y + t` chain over nearest-up-sampled tensors followed by relu, so the
+ * result equals that composition's bit for bit, in one pass instead of 2 n (HRNet's exchange units at the reference's precision,
+ * tracklab/configs/modules/reid/bpbreid.yaml:53 through tracklab/wrappers/reid/kpreid_api.py:147-182).  y_pix_stride > c: a channel slice of a wider
+ * tensor (one term: up-sampling + concatenation in one pass). */
+int tlk_fuse_sum_f32(int n_terms, const float *const *x_dev, const int *shift, const int *pix_stride, int n, int h, int w, int c, int relu,
+                     float *y_dev, int y_pix_stride, int dynamic_batch, void *hip_stream);
 /* Probes / tests: 0 = the register-staged kernel for every shape, 1 (default; env TLK_CONV16_GLDS) = the direct-to-LDS kernel where it applies
  * (Cout > 64, Cin a multiple of the K step).  Results do not depend on it beyond fp32 summation order inside a 16-wide slice (none: same order). */
 int tlk_conv16_set_glds(int on);

@@ -185,3 +185,42 @@ def test_pipeline_with_hrnet32_in_split_mode_keeps_the_oracles_ids(orc):
     sc = pipe.reid._split_scales
     assert sc is not None and sc.calibrated
     pipe.close(); exact.close()
+
+
+@pytest.mark.parametrize("c,shifts,relu", [(32, (0, 1, 2, 3), True), (64, (0, 0, 1, 2), True), (256, (0, 0, 0, 0), True), (128, (2,), False), (8, (1, 0), False)])
+def test_fuse_sum_f32_is_torchs_interpolate_add_relu_bit_for_bit(c, shifts, relu):
+    """tlk_fuse_sum_f32 (the joint of the EXACT fp32 route): ((t0 + t1) + t2) + t3 over nearest-up-sampled fp32 tensors, then ReLU == torch's passes"""
+    import torch
+    from tracklab_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(7 * c + len(shifts))
+    n, h, w = 5, 48, 16
+    terms = [_cl(torch.randn(n, c, h >> s, w >> s, device="cuda", generator=g) * 3) for s in shifts]
+    ref = None
+    for t, s in zip(terms, shifts):
+        u = _up(t, s)
+        ref = u if ref is None else ref + u
+    if relu:
+        ref = torch.relu(ref)
+    if len(shifts) == 1:                                  # one term: up-sampling into a channel slice of a wider tensor (the concatenation)
+        wide = torch.full((n, c + 64, h, w), 7.0, device="cuda").contiguous(memory_format=torch.channels_last)
+        _lib.fuse_sum_f32(terms, relu=relu, out=wide[:, 32:32 + c])
+        assert torch.equal(wide[:, 32:32 + c], ref) and bool((wide[:, :32] == 7).all()) and bool((wide[:, 32 + c:] == 7).all())
+        return
+    y = _lib.fuse_sum_f32(terms, relu=relu)
+    assert y.shape == ref.shape and torch.equal(y, ref)
+
+
+def test_hrnet32_exact_route_with_fused_joints_equals_the_torch_passes(monkeypatch):
+    """the exact-fp32 HRNet-W32 forward with tlk_fuse_sum_f32 for the exchange units and the concatenation == the same forward on torch's
+    interpolate / add / relu / cat passes, bit for bit (the exact route's arithmetic is untouched: only HBM passes are saved)"""
+    import importlib
+    import torch
+    rmod = importlib.import_module("tracklab_amd.backbones.reid")
+    net = rmod.part_based_reid(6, 256, device="cuda", dtype=torch.float32, arch="hrnet32")
+    x = _cl(torch.rand(5, 3, 384, 128, device="cuda"))
+    with torch.no_grad():
+        monkeypatch.setattr(rmod, "USE_TLK_FUSE32", True)
+        a = net.features(x)
+        monkeypatch.setattr(rmod, "USE_TLK_FUSE32", False)
+        b = net.features(x)
+    assert a.shape == b.shape and torch.equal(a, b)

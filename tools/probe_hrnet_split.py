@@ -1,5 +1,5 @@
 """Probe (not product): the part-based ReID forward on HRNet-W32 (bpbreid.yaml:53) at exact fp32 and in split-precision mode -- ms per forward,
-and the per-kernel share of the split forward's joints (tlk_split_fuse_sum).    python tools/probe_hrnet_split.py [crops]"""
+and the per-kernel share of the split forward's joints (tlk_split_fuse_sum).    python tools/probe_hrnet_split.py [crops] [exact fp32 | split]      TLK_FUSE32=0: the exact route on torch's interpolate / add / relu / cat passes"""
 import os
 import sys
 import time

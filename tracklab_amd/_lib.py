@@ -1250,6 +1250,7 @@ def _bind_conv16(L):
         L.tlk_merge_planes_f32_s.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]
         L.tlk_split_scale_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.tlk_split_fuse_sum.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.tlk_fuse_sum_f32.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L._conv16_bound = True
 
 
@@ -1388,6 +1389,32 @@ def split_fuse_sum(terms, relu=False, out=None, out_state=None, dynamic_batch=Fa
     check(L.tlk_split_fuse_sum(n, hi_t, lo_t, f_t, sc_t, sh_t, px_t, N, H, W, Cc, 1 if relu else 0, yh.data_ptr(), yl.data_ptr(), _pix16(yh, Cc, H, W),
                                out_state.data_ptr() if out_state is not None else None, 1 if dynamic_batch else 0, current_stream_ptr()))
     return yh, yl
+
+
+def fuse_sum_f32(terms, relu=False, out=None, dynamic_batch=False):
+    """``tlk_fuse_sum_f32`` (r06): [relu](((t0 + t1) + t2) + t3) over float32 channels_last tensors at mixed resolutions (nearest up-sampling by
+    2**s onto the output's grid = that of `out`, else the largest term's), bit-identical to torch's interpolate / add / relu composition, one pass.
+    out: a float32 channels_last tensor or channel slice to write into."""
+    import torch
+    L = lib()
+    _bind_conv16(L)
+    assert 1 <= len(terms) <= 4
+    N, Cc = terms[0].shape[0], terms[0].shape[1]
+    H, W = (out.shape[2], out.shape[3]) if out is not None else (max(t.shape[2] for t in terms), max(t.shape[3] for t in terms))
+    n = len(terms)
+    P, I = C.c_void_p * n, C.c_int * n
+    x_t, sh_t, px_t = P(), I(), I()
+    for i, t in enumerate(terms):
+        assert t.dtype == torch.float32 and t.shape[0] == N and t.shape[1] == Cc, "terms must be float32 and agree in batch and channels"
+        s = (H // t.shape[2]).bit_length() - 1
+        assert t.shape[2] << s == H and t.shape[3] << s == W, "a term's resolution must divide the output's by a power of two"
+        x_t[i], sh_t[i], px_t[i] = t.data_ptr(), s, _pix16(t, Cc, t.shape[2], t.shape[3])
+    if out is None:
+        out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=terms[0].device, memory_format=torch.channels_last)
+    assert out.dtype == torch.float32 and tuple(out.shape) == (N, Cc, H, W)
+    check(L.tlk_fuse_sum_f32(n, x_t, sh_t, px_t, N, H, W, Cc, 1 if relu else 0, out.data_ptr(), _pix16(out, Cc, H, W), 1 if dynamic_batch else 0,
+                             current_stream_ptr()))
+    return out
 
 
 def split_scale_update(states, changed=None):

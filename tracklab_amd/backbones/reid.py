@@ -23,6 +23,14 @@ USE_TLK_HEADS = _os.environ.get("TLK_HEADS", "1") != "0"
 USE_SPLIT_SCALES = _os.environ.get("TLK_SPLIT_SCALES", "1") != "0"
 # r06: HRNet's split route reduces the branches one by one instead of concatenating them (PartBasedReID._reduce_branches); 0: concatenate (A/B runs)
 USE_BRANCH_REDUCE = _os.environ.get("TLK_BRANCH_REDUCE", "1") != "0"
+# r06: HRNet's exact-fp32 route forms every exchange unit's receiving branch, and the concatenation in front of the head, with tlk_fuse_sum_f32 (one
+# pass, bit-identical to the interpolate / add / relu / cat composition it replaces); 0: the torch passes (A/B runs)
+USE_TLK_FUSE32 = _os.environ.get("TLK_FUSE32", "1") != "0"
+
+
+def _fuse32_ok(t):
+    return USE_TLK_FUSE32 and isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.shape[1] % 8 == 0 \
+        and t.is_contiguous(memory_format=torch.channels_last)
 
 
 class _Bottleneck(nn.Module):
@@ -78,6 +86,22 @@ class _HRModule(nn.Module):
         xs = [b(x) for b, x in zip(self.branches, xs)]
         if isinstance(xs[0], SplitAct):
             return self._exchange_split(xs)
+        if all(_fuse32_ok(t) for t in xs):
+            # exact-fp32 route, r06: ((t0 + t1) + t2) + t3 over the up-sampled terms, then ReLU -- the loop below in ONE pass per receiving branch, same bits
+            from .. import _lib
+            out = []
+            for i, row in enumerate(self.fuse):
+                terms = [xs[j] if j == i else f(xs[j]) for j, f in enumerate(row)]
+                if all(_fuse32_ok(t) for t in terms):
+                    out.append(_lib.fuse_sum_f32(terms, relu=True, dynamic_batch=True))
+                else:
+                    y = None
+                    for j, t in enumerate(terms):
+                        if j > i:
+                            t = nn.functional.interpolate(t, size=xs[i].shape[-2:], mode="nearest")
+                        y = t if y is None else y + t
+                    out.append(torch.relu(y))
+            return out
         out = []
         for i, row in enumerate(self.fuse):
             y = None
@@ -164,6 +188,16 @@ class HRNetW32(nn.Module):
                 _lib.split_fuse_sum([(t.hi, t.lo, t.state)], out=(hi[:, off:off + c], lo[:, off:off + c]), out_state=st, dynamic_batch=True)
                 off += c
             return SplitAct(hi, lo, st)
+        if all(_fuse32_ok(t) for t in xs):
+            # exact-fp32 route, r06: up-sampling + concatenation in one pass per branch (a copy: the bits of torch.cat over the interpolated tensors)
+            from .. import _lib
+            n, _, h, w = xs[0].shape
+            y = torch.empty((n, self.out_channels, h, w), dtype=torch.float32, device=xs[0].device, memory_format=torch.channels_last)
+            off = 0
+            for t in xs:
+                _lib.fuse_sum_f32([t], out=y[:, off:off + t.shape[1]], dynamic_batch=True)
+                off += t.shape[1]
+            return y
         size = xs[0].shape[-2:]
         return torch.cat([xs[0]] + [nn.functional.interpolate(t, size=size, mode="nearest") for t in xs[1:]], dim=1)
 

@@ -31,13 +31,14 @@ struct FuseArgs {
     int nt, h, w, c, relu, y_pix;
     long long n;
     _Float16 *yhi, *ylo;
+    float *y32;                   // OUT32 form (tlk_fuse_sum_f32): the result as plain fp32, no planes, no state
     float *state;                 // {scale of the planes written, recorded maximum} or NULL (scale 1, nothing recorded)
     const int *n_dyn;             // live image count (tlk_conv_set_dynamic_batch) or NULL
 };
 
 // One item = 8 channels of one output pixel (16 bytes of each plane); consecutive lanes, consecutive 16 bytes.  (A two-items-per-lane form with all
 // loads issued ahead was measured SLOWER, 416 vs 348 us per launch over HRNet-W32's 30 joints: the kernel is not short of loads in flight.)
-__global__ void __launch_bounds__(FUSE_BLOCK) split_fuse_sum_kernel(const FuseArgs p)
+template <bool OUT32> __global__ void __launch_bounds__(FUSE_BLOCK) split_fuse_sum_kernel(const FuseArgs p)
 {
     const int cg = p.c >> 3;
     long long n = p.n;
@@ -58,9 +59,9 @@ __global__ void __launch_bounds__(FUSE_BLOCK) split_fuse_sum_kernel(const FuseAr
         const long long img = px / hw;
         const int rem = (int)(px - img * hw);
         const int y = rem / p.w, x = rem - y * p.w;
+        // acc = term 0, then += term 1, 2, 3 in order: ((t0 + t1) + t2) + t3, the association of torch's `y = y + t` chain -- with fp32 terms and the
+        // fp32 output the result is that composition's, bit for bit
         float acc[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
 #pragma unroll
         for (int t = 0; t < MAX_TERMS; ++t) {
             if (t >= p.nt) break;
@@ -68,50 +69,64 @@ __global__ void __launch_bounds__(FUSE_BLOCK) split_fuse_sum_kernel(const FuseAr
             const int s = T.shift, ws = p.w >> s;
             const long long sp = (img * (p.h >> s) + (y >> s)) * ws + (x >> s);
             const long long off = sp * T.pix + cv;
+            float v[8];
             if (T.hi) {
                 const h16x8 hh = *reinterpret_cast<const h16x8 *>(T.hi + off), ll = *reinterpret_cast<const h16x8 *>(T.lo + off);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] += ((float)hh[k] + (float)ll[k] * LO_INV) * sc[t];
+                for (int k = 0; k < 8; ++k) v[k] = ((float)hh[k] + (float)ll[k] * LO_INV) * sc[t];
             } else {
                 const float4 a = *reinterpret_cast<const float4 *>(T.f32 + off), b = *reinterpret_cast<const float4 *>(T.f32 + off + 4);
-                acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-                acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
             }
-        }
-        h16x8 oh, ol;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float v = acc[k];
-            if (p.relu) v = v < 0.f ? 0.f : v;              // (lets NaN through, like torch.relu)
-            am = fmaxf(am, fabsf(v));
-            _Float16 a, b;
-            split_f32(v * inv, a, b);
-            oh[k] = a; ol[k] = b;
+            for (int k = 0; k < 8; ++k) acc[k] = t == 0 ? v[k] : acc[k] + v[k];
         }
         const long long yo = px * p.y_pix + cv;
-        *reinterpret_cast<h16x8 *>(p.yhi + yo) = oh;
-        *reinterpret_cast<h16x8 *>(p.ylo + yo) = ol;
+        if (OUT32) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (p.relu) acc[k] = acc[k] < 0.f ? 0.f : acc[k];      // (lets NaN through, like torch.relu)
+            *reinterpret_cast<float4 *>(p.y32 + yo) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4 *>(p.y32 + yo + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        } else {
+            h16x8 oh, ol;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float v = acc[k];
+                if (p.relu) v = v < 0.f ? 0.f : v;
+                am = fmaxf(am, fabsf(v));
+                _Float16 a, b;
+                split_f32(v * inv, a, b);
+                oh[k] = a; ol[k] = b;
+            }
+            *reinterpret_cast<h16x8 *>(p.yhi + yo) = oh;
+            *reinterpret_cast<h16x8 *>(p.ylo + yo) = ol;
+        }
     }
-    if (p.state) record_amax(p.state + 1, am);
+    if (!OUT32 && p.state) record_amax(p.state + 1, am);
 }
 
 }  // namespace
 
-extern "C" int tlk_split_fuse_sum(int n_terms, const void *const *hi_dev, const void *const *lo_dev, const float *const *f32_dev,
-                                  const float *const *scale_dev, const int *shift, const int *pix_stride, int n, int h, int w, int c, int relu,
-                                  void *y_hi_dev, void *y_lo_dev, int y_pix_stride, float *out_state_dev, int dynamic_batch, void *hip_stream)
+static int fuse_entry(int n_terms, const void *const *hi_dev, const void *const *lo_dev, const float *const *f32_dev,
+                      const float *const *scale_dev, const int *shift, const int *pix_stride, int n, int h, int w, int c, int relu,
+                      void *y_hi_dev, void *y_lo_dev, float *y_f32_dev, int y_pix_stride, float *out_state_dev, int dynamic_batch, void *hip_stream)
 {
+    static const void *const no_ptrs[MAX_TERMS] = {nullptr, nullptr, nullptr, nullptr};
+    if (y_f32_dev) {                                   // the fp32 form: fp32 terms only unless plane tables are given
+        if (!hi_dev) hi_dev = no_ptrs;
+        if (!lo_dev) lo_dev = no_ptrs;
+    }
     if (n_terms < 1 || n_terms > MAX_TERMS) return fail(TLK_EINVAL, "tlk_split_fuse_sum: 1..4 terms");
     if (n < 0 || h <= 0 || w <= 0 || c <= 0 || c % 8 != 0) return fail(TLK_EINVAL, "tlk_split_fuse_sum: bad shape (channels a multiple of 8)");
     if (!hi_dev || !lo_dev || !f32_dev || !shift) return fail(TLK_EINVAL, "tlk_split_fuse_sum: null term table");
     if (n == 0) return TLK_OK;
-    if (!y_hi_dev || !y_lo_dev) return fail(TLK_EINVAL, "tlk_split_fuse_sum: no output");
+    if (!y_f32_dev && (!y_hi_dev || !y_lo_dev)) return fail(TLK_EINVAL, "tlk_split_fuse_sum: no output");
     FuseArgs a{};
     a.nt = n_terms; a.n = n; a.h = h; a.w = w; a.c = c; a.relu = relu ? 1 : 0;
     a.y_pix = y_pix_stride > 0 ? y_pix_stride : c;
-    a.yhi = (_Float16 *)y_hi_dev; a.ylo = (_Float16 *)y_lo_dev; a.state = out_state_dev;
+    a.yhi = (_Float16 *)y_hi_dev; a.ylo = (_Float16 *)y_lo_dev; a.y32 = y_f32_dev; a.state = y_f32_dev ? nullptr : out_state_dev;
     a.n_dyn = dynamic_batch ? conv_dynamic_batch() : nullptr;
-    uintptr_t align = (uintptr_t)y_hi_dev | (uintptr_t)y_lo_dev;
+    uintptr_t align = (uintptr_t)y_hi_dev | (uintptr_t)y_lo_dev | (uintptr_t)y_f32_dev;
     if (a.y_pix < c || a.y_pix % 8 != 0) return fail(TLK_EINVAL, "tlk_split_fuse_sum: the output's pixel stride must cover the channels and be a multiple of 8");
     for (int t = 0; t < n_terms; ++t) {
         FuseTerm &T = a.t[t];
@@ -131,7 +146,24 @@ extern "C" int tlk_split_fuse_sum(int n_terms, const void *const *hi_dev, const 
     long long blocks = (items + FUSE_BLOCK - 1) / FUSE_BLOCK;
     if (blocks > 256 * 32) blocks = 256 * 32;
     blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL(split_fuse_sum_kernel, dim3((unsigned)blocks), dim3(FUSE_BLOCK), 0, (hipStream_t)hip_stream, a);
+    if (y_f32_dev) hipLaunchKernelGGL(split_fuse_sum_kernel<true>, dim3((unsigned)blocks), dim3(FUSE_BLOCK), 0, (hipStream_t)hip_stream, a);
+    else hipLaunchKernelGGL(split_fuse_sum_kernel<false>, dim3((unsigned)blocks), dim3(FUSE_BLOCK), 0, (hipStream_t)hip_stream, a);
     TLK_HIP(hipGetLastError());
     return TLK_OK;
+}
+
+extern "C" int tlk_split_fuse_sum(int n_terms, const void *const *hi_dev, const void *const *lo_dev, const float *const *f32_dev,
+                                  const float *const *scale_dev, const int *shift, const int *pix_stride, int n, int h, int w, int c, int relu,
+                                  void *y_hi_dev, void *y_lo_dev, int y_pix_stride, float *out_state_dev, int dynamic_batch, void *hip_stream)
+{
+    return fuse_entry(n_terms, hi_dev, lo_dev, f32_dev, scale_dev, shift, pix_stride, n, h, w, c, relu, y_hi_dev, y_lo_dev, nullptr, y_pix_stride,
+                      out_state_dev, dynamic_batch, hip_stream);
+}
+
+extern "C" int tlk_fuse_sum_f32(int n_terms, const float *const *x_dev, const int *shift, const int *pix_stride, int n, int h, int w, int c, int relu,
+                                float *y_dev, int y_pix_stride, int dynamic_batch, void *hip_stream)
+{
+    if (!y_dev) return fail(TLK_EINVAL, "tlk_fuse_sum_f32: no output");
+    return fuse_entry(n_terms, nullptr, nullptr, x_dev, nullptr, shift, pix_stride, n, h, w, c, relu, nullptr, nullptr, y_dev, y_pix_stride, nullptr,
+                      dynamic_batch, hip_stream);
 }
