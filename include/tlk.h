@@ -723,6 +723,10 @@ int tlk_split_fuse_sum(int n_terms, const void *const *hi_dev, const void *const
  * tensor (one term: up-sampling + concatenation in one pass). */
 int tlk_fuse_sum_f32(int n_terms, const float *const *x_dev, const int *shift, const int *pix_stride, int n, int h, int w, int c, int relu,
                      float *y_dev, int y_pix_stride, int dynamic_batch, void *hip_stream);
+/* ... and for the f16 route: f16 terms, f16 output, every partial sum rounded to f16 -- what torch's half-precision `y = y + t` chain computes (each
+ * add in fp32, rounded to half), bit for bit. */
+int tlk_fuse_sum_f16(int n_terms, const void *const *x_dev, const int *shift, const int *pix_stride, int n, int h, int w, int c, int relu,
+                     void *y_dev, int y_pix_stride, int dynamic_batch, void *hip_stream);
 /* Probes / tests: 0 = the register-staged kernel for every shape, 1 (default; env TLK_CONV16_GLDS) = the direct-to-LDS kernel where it applies
  * (Cout > 64, Cin a multiple of the K step).  Results do not depend on it beyond fp32 summation order inside a 16-wide slice (none: same order). */
 int tlk_conv16_set_glds(int on);

@@ -224,3 +224,40 @@ def test_hrnet32_exact_route_with_fused_joints_equals_the_torch_passes(monkeypat
         monkeypatch.setattr(rmod, "USE_TLK_FUSE32", False)
         b = net.features(x)
     assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("c,shifts,relu", [(32, (0, 1, 2, 3), True), (64, (0, 0, 1, 2), True), (128, (2,), False)])
+def test_fuse_sum_f16_is_torchs_half_precision_chain_bit_for_bit(c, shifts, relu):
+    """tlk_fuse_sum_f16: every partial sum rounded to float16, as torch's half `y = y + t` does"""
+    import torch
+    from tracklab_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(11 * c + len(shifts))
+    n, h, w = 5, 48, 16
+    terms = [_cl((torch.randn(n, c, h >> s, w >> s, device="cuda", generator=g) * 30).half()) for s in shifts]
+    ref = None
+    for t, s in zip(terms, shifts):
+        u = _up(t, s)
+        ref = u if ref is None else ref + u
+    if relu:
+        ref = torch.relu(ref)
+    if len(shifts) == 1:
+        wide = torch.full((n, c + 64, h, w), 7.0, device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+        _lib.fuse_sum_f16(terms, relu=relu, out=wide[:, 32:32 + c])
+        assert torch.equal(wide[:, 32:32 + c], ref) and bool((wide[:, :32] == 7).all()) and bool((wide[:, 32 + c:] == 7).all())
+        return
+    y = _lib.fuse_sum_f16(terms, relu=relu)
+    assert y.dtype == torch.float16 and torch.equal(y, ref)
+
+
+def test_hrnet32_f16_route_with_fused_joints_equals_the_torch_passes(monkeypatch):
+    import importlib
+    import torch
+    rmod = importlib.import_module("tracklab_amd.backbones.reid")
+    net = rmod.part_based_reid(6, 256, device="cuda", dtype=torch.float16, arch="hrnet32")
+    x = _cl(torch.rand(5, 3, 384, 128, device="cuda").half())
+    with torch.no_grad():
+        monkeypatch.setattr(rmod, "USE_TLK_FUSE16", True)
+        a = net.features(x)
+        monkeypatch.setattr(rmod, "USE_TLK_FUSE16", False)
+        b = net.features(x)
+    assert a.dtype == torch.float16 and a.shape == b.shape and torch.equal(a, b)

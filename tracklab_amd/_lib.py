@@ -1251,6 +1251,7 @@ def _bind_conv16(L):
         L.tlk_split_scale_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.tlk_split_fuse_sum.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.tlk_fuse_sum_f32.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.tlk_fuse_sum_f16.argtypes = L.tlk_fuse_sum_f32.argtypes
         L._conv16_bound = True
 
 
@@ -1396,6 +1397,17 @@ def fuse_sum_f32(terms, relu=False, out=None, dynamic_batch=False):
     2**s onto the output's grid = that of `out`, else the largest term's), bit-identical to torch's interpolate / add / relu composition, one pass.
     out: a float32 channels_last tensor or channel slice to write into."""
     import torch
+    return _fuse_sum_plain(terms, relu, out, dynamic_batch, torch.float32)
+
+
+def fuse_sum_f16(terms, relu=False, out=None, dynamic_batch=False):
+    """``tlk_fuse_sum_f16``: the same over float16 tensors, every partial sum rounded to float16 (torch's half-precision `y = y + t` chain, bit for bit)"""
+    import torch
+    return _fuse_sum_plain(terms, relu, out, dynamic_batch, torch.float16)
+
+
+def _fuse_sum_plain(terms, relu, out, dynamic_batch, dtype):
+    import torch
     L = lib()
     _bind_conv16(L)
     assert 1 <= len(terms) <= 4
@@ -1405,15 +1417,15 @@ def fuse_sum_f32(terms, relu=False, out=None, dynamic_batch=False):
     P, I = C.c_void_p * n, C.c_int * n
     x_t, sh_t, px_t = P(), I(), I()
     for i, t in enumerate(terms):
-        assert t.dtype == torch.float32 and t.shape[0] == N and t.shape[1] == Cc, "terms must be float32 and agree in batch and channels"
+        assert t.dtype == dtype and t.shape[0] == N and t.shape[1] == Cc, "terms must share the dtype and agree in batch and channels"
         s = (H // t.shape[2]).bit_length() - 1
         assert t.shape[2] << s == H and t.shape[3] << s == W, "a term's resolution must divide the output's by a power of two"
         x_t[i], sh_t[i], px_t[i] = t.data_ptr(), s, _pix16(t, Cc, t.shape[2], t.shape[3])
     if out is None:
-        out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=terms[0].device, memory_format=torch.channels_last)
-    assert out.dtype == torch.float32 and tuple(out.shape) == (N, Cc, H, W)
-    check(L.tlk_fuse_sum_f32(n, x_t, sh_t, px_t, N, H, W, Cc, 1 if relu else 0, out.data_ptr(), _pix16(out, Cc, H, W), 1 if dynamic_batch else 0,
-                             current_stream_ptr()))
+        out = torch.empty((N, Cc, H, W), dtype=dtype, device=terms[0].device, memory_format=torch.channels_last)
+    assert out.dtype == dtype and tuple(out.shape) == (N, Cc, H, W)
+    fn = L.tlk_fuse_sum_f32 if dtype == torch.float32 else L.tlk_fuse_sum_f16
+    check(fn(n, x_t, sh_t, px_t, N, H, W, Cc, 1 if relu else 0, out.data_ptr(), _pix16(out, Cc, H, W), 1 if dynamic_batch else 0, current_stream_ptr()))
     return out
 
 

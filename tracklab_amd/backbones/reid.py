@@ -28,9 +28,18 @@ USE_BRANCH_REDUCE = _os.environ.get("TLK_BRANCH_REDUCE", "1") != "0"
 USE_TLK_FUSE32 = _os.environ.get("TLK_FUSE32", "1") != "0"
 
 
+USE_TLK_FUSE16 = _os.environ.get("TLK_FUSE16", "1") != "0"       # the same for the f16 route (tlk_fuse_sum_f16: every partial sum rounded to f16, as torch's half adds)
+
+
 def _fuse32_ok(t):
-    return USE_TLK_FUSE32 and isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.shape[1] % 8 == 0 \
-        and t.is_contiguous(memory_format=torch.channels_last)
+    """a tensor the fused joints take: float32 (tlk_fuse_sum_f32) or float16 (tlk_fuse_sum_f16), channels_last, on the GPU"""
+    return isinstance(t, torch.Tensor) and t.is_cuda and ((USE_TLK_FUSE32 and t.dtype == torch.float32) or (USE_TLK_FUSE16 and t.dtype == torch.float16)) \
+        and t.shape[1] % 8 == 0 and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def _fuse_plain(terms, relu=False, out=None):
+    from .. import _lib
+    return (_lib.fuse_sum_f32 if terms[0].dtype == torch.float32 else _lib.fuse_sum_f16)(terms, relu=relu, out=out, dynamic_batch=True)
 
 
 class _Bottleneck(nn.Module):
@@ -87,13 +96,13 @@ class _HRModule(nn.Module):
         if isinstance(xs[0], SplitAct):
             return self._exchange_split(xs)
         if all(_fuse32_ok(t) for t in xs):
-            # exact-fp32 route, r06: ((t0 + t1) + t2) + t3 over the up-sampled terms, then ReLU -- the loop below in ONE pass per receiving branch, same bits
+            # exact-fp32 (and f16) route, r06: ((t0 + t1) + t2) + t3 over the up-sampled terms, then ReLU -- the loop below in ONE pass per receiving branch, same bits
             from .. import _lib
             out = []
             for i, row in enumerate(self.fuse):
                 terms = [xs[j] if j == i else f(xs[j]) for j, f in enumerate(row)]
-                if all(_fuse32_ok(t) for t in terms):
-                    out.append(_lib.fuse_sum_f32(terms, relu=True, dynamic_batch=True))
+                if all(_fuse32_ok(t) and t.dtype == terms[0].dtype for t in terms):
+                    out.append(_fuse_plain(terms, relu=True))
                 else:
                     y = None
                     for j, t in enumerate(terms):
@@ -192,10 +201,10 @@ class HRNetW32(nn.Module):
             # exact-fp32 route, r06: up-sampling + concatenation in one pass per branch (a copy: the bits of torch.cat over the interpolated tensors)
             from .. import _lib
             n, _, h, w = xs[0].shape
-            y = torch.empty((n, self.out_channels, h, w), dtype=torch.float32, device=xs[0].device, memory_format=torch.channels_last)
+            y = torch.empty((n, self.out_channels, h, w), dtype=xs[0].dtype, device=xs[0].device, memory_format=torch.channels_last)
             off = 0
             for t in xs:
-                _lib.fuse_sum_f32([t], out=y[:, off:off + t.shape[1]], dynamic_batch=True)
+                _fuse_plain([t], out=y[:, off:off + t.shape[1]])
                 off += t.shape[1]
             return y
         size = xs[0].shape[-2:]
