@@ -25,7 +25,7 @@ def test_reid_forward_is_bit_reproducible(mode):
     from tracklab_amd.backbones.reid import part_based_reid
     torch.manual_seed(1)
     dt = torch.float16 if mode == "f16" else torch.float32
-    for arch in (("resnet50", "hrnet32") if mode != "split" else ("resnet50",)):
+    for arch in ("resnet50", "hrnet32"):             # (hrnet32 in split mode: r06, second session)
         net = part_based_reid(6, 512, device="cuda", dtype=dt, arch=arch, split_precision=mode == "split")
         x = torch.randn(48, 3, 384, 128, device="cuda").to(dt).contiguous(memory_format=torch.channels_last)
         out = _same(net, x, 6)
