@@ -14,7 +14,11 @@ rows = []
 with open(path) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "?"))))
-end = max(r[1] for r in rows)
+# the window ends with the last CONVOLUTION launch of the trace, not with the trace: what follows the timed steps (the one-rank RCCL group's
+# set-up, the table fetch, teardown fills and copies) is not a step -- the r06 summaries taken at the end of the trace held only those
+conv_ends = [r[1] for r in rows if "conv_f32_mfma_kernel" in r[2] or "conv16x_kernel" in r[2] or "conv16_mfma_kernel" in r[2]]
+end = max(conv_ends) if conv_ends else max(r[1] for r in rows)
+rows = [r for r in rows if r[0] <= end]
 t0 = end - int(win * 1e6)
 sel = [r for r in rows if r[0] >= t0]
 agg = defaultdict(lambda: [0, 0])
